@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Chamfer point-pairs/sec (B x N x M) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one forward chamfer_distance over one batch of synthetic clouds already resident in
+HBM: BASELINE.json configs[1] (B=32, N=M=4096, Float32) per GPU.  With N GPUs the global batch is
+32*N (configs[4]: B=256 sharded 32/GPU on 8), each rank runs the kernel on its shard and the two
+Float64 partial sums are all-reduced over RCCL (weak scaling).  value = global pairs / max-rank time.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline      -- dominant kernel (nn1) vs the fp32 compute roofline that bounds it
+  roofline_hbm  -- the HBM fraction BASELINE.json's metric asks for (not the bound)
+  cpu_baseline  -- the oracle's KD-tree twin of the reference CPU path, timed on this host (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU, NPTS, MPTS, DIM = 32, 4096, 4096, 3
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector peak == fp32-input MFMA peak (dense)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+
+    import flux3d_jl_amd as fx
+    from flux3d_jl_amd import _lib
+    from flux3d_jl_amd.distributed import ShardedChamfer, chamfer_finalize, chamfer_sums
+    import ctypes as C
+
+    fx.set_device(local_rank)
+    Bg = B_PER_GPU * world
+    # this rank's contiguous slab of the global synthetic batch (documented SplitMix64 stream)
+    x = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_A, DIM, NPTS, B_PER_GPU, batch_offset=rank * B_PER_GPU))
+    y = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_B, DIM, MPTS, B_PER_GPU, batch_offset=rank * B_PER_GPU))
+
+    if world > 1:
+        sharded = ShardedChamfer()
+        bench_stream = fx.Stream(torch.cuda.current_stream().cuda_stream)
+
+        def step():
+            return sharded(x, y, Bg, sync=False)
+
+        def sync_all():
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+        def read_loss():
+            return float(sharded.loss.item())
+    else:
+        bench_stream = fx.Stream.create()
+        sums = fx.DeviceArray.empty((2,), np.float64)
+        loss_dev = fx.DeviceArray.empty((1,), np.float32)
+
+        def step():
+            with fx.stream(bench_stream):
+                chamfer_sums(x, y, out=sums, sync=False)
+                chamfer_finalize(sums, NPTS, MPTS, Bg, DIM, out=loss_dev, sync=False)
+
+        def sync_all():
+            bench_stream.synchronize()
+
+        def read_loss():
+            with fx.stream(bench_stream):
+                return float(loss_dev.item())
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+
+    _lib.call("fx3d_profile_enable", 1)  # HIP events around every nn1 launch, on its own stream
+    e0, e1 = fx.Event(), fx.Event()
+    sync_all()
+    t0 = time.perf_counter()
+    e0.record(bench_stream)
+    for _ in range(args.steps):
+        step()
+    e1.record(bench_stream)
+    sync_all()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = read_loss()
+
+    avg, mn, mx, cnt = C.c_double(0), C.c_double(0), C.c_double(0), C.c_int64(0)
+    _lib.call("fx3d_profile_kernel_stats", b"nn1", C.byref(avg), C.byref(mn), C.byref(mx), C.byref(cnt))
+    _lib.call("fx3d_profile_enable", 0)
+    ev_ms = e0.elapsed_ms(e1)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    pairs_per_step = Bg * NPTS * MPTS
+    value = pairs_per_step * args.steps / elapsed
+    ms_per_step = elapsed * 1e3 / args.steps
+    kern_s = avg.value * 1e-3
+    # algorithmic work of ONE nn1 launch on one GPU (DESIGN.md "Roofline"):
+    #   flops: 8 per ordered pair evaluation (3 sub, 3 mul, 2 add), both directions = 16*B*N*M
+    #   bytes: read both clouds once (4*D*B*(N+M)) + the per-block partial sums written
+    flops = 16.0 * B_PER_GPU * NPTS * MPTS
+    abytes = 4.0 * DIM * B_PER_GPU * (NPTS + MPTS) + 8.0 * 2 * B_PER_GPU * 8
+    traffic = None
+    try:  # PMC-derived HBM bytes per launch, collected by a separate rocprofv3 --pmc pass
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
+            traffic = json.load(fh).get("nn1_hbm_bytes_per_launch")
+    except Exception:
+        pass
+    out = {
+        "metric": "chamfer_point_pairs_per_sec", "value": value, "unit": "pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"chamfer_distance fwd B={Bg} ({B_PER_GPU}/GPU) N=M={NPTS} D=3 Float32 U[0,1)^3 (BASELINE configs[1]; configs[4] shape at 8 GPUs)",
+                   "global_batch": Bg, "points": NPTS, "parallelism": f"batch-sharded x{world}, 1 all-reduce of 2 f64"},
+        "loss": loss,
+        "roofline": {"bound": "mfma", "achieved": flops / kern_s / 1e12 if kern_s else None,
+                     "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": (flops / kern_s / 1e12 / FP32_PEAK_TFLOPS) if kern_s else None,
+                     "traffic": traffic,
+                     "kernel": "nn1_small_d_kernel<3,R,false>", "kernel_avg_ms": avg.value,
+                     "kernel_min_ms": mn.value, "launches_timed": cnt.value,
+                     "note": "all-pairs NN is fp32 issue bound (~1000 flop/byte); peak is the fp32 vector peak, "
+                             "which equals the dense fp32-input MFMA peak; the kernel uses VALU, not MFMA"},
+        "roofline_hbm": {"bound": "hbm", "achieved": abytes / kern_s / 1e9 if kern_s else None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (abytes / kern_s / 1e9 / HBM_PEAK_GBS) if kern_s else None,
+                         "note": "reported because BASELINE.json asks; brute-force NN cannot approach it"},
+        "stream_event_ms_per_step": ev_ms / args.steps,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(fx)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(fx):
+    """Reference CPU algorithm (per-batch-element KD-tree build + 1-NN queries, serial;
+    src/metrics/pcloud.jl:54-70) as restated in oracle/flux3d_oracle.c, 1 core, on the same
+    workload.  The oracle is the checker/baseline only -- never on the product path."""
+    from oracle import oracle
+    x = fx.synth.uniform_cloud(fx.synth.SEED_A, DIM, NPTS, B_PER_GPU)
+    y = fx.synth.uniform_cloud(fx.synth.SEED_B, DIM, MPTS, B_PER_GPU)
+    oracle.chamfer_distance(x[:, :, :1], y[:, :, :1], kdtree=True)  # page in
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        oracle.chamfer_distance(x, y, kdtree=True)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    xb, yb = x[:, :, :4], y[:, :, :4]
+    t0 = time.perf_counter()
+    oracle.chamfer_distance(xb, yb)
+    dt_bf = time.perf_counter() - t0
+    pairs = B_PER_GPU * NPTS * MPTS
+    return {"value": pairs / best, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": f"full workload B={B_PER_GPU} N=M={NPTS}, KD-tree 1-NN both directions, min of 3 ({best:.3f} s)",
+            "bruteforce_1core_pairs_per_s": 4 * NPTS * MPTS / dt_bf,
+            "bruteforce_sample": f"B=4 slice, exact fp32 all-pairs ({dt_bf:.3f} s)"}
+
+
+if __name__ == "__main__":
+    main()

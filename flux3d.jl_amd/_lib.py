@@ -1,0 +1,112 @@
+"""ctypes binding of libflux3d_hip.so (include/flux3d_hip.h).
+
+This is the Python twin of julia/Flux3DHip.jl's ``@ccall`` layer: one thin wrapper per C-ABI entry
+point, status codes turned into exceptions.  There is NO fallback: if the shared library is
+missing or a call fails (e.g. no GPU), an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libflux3d_hip.so")
+
+
+class Flux3DHipError(RuntimeError):
+    """Raised for any non-zero fx3d_status (mirrors the reference's `error(msg)`)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"[fx3d status {code}] {msg}")
+        self.code = code
+
+
+c_i32, c_i64, c_f32, c_f64, c_u64 = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint64
+vp, sz = C.c_void_p, C.c_size_t
+
+# name -> argtypes  (restype is int32 status unless listed in _RESTYPES)
+SIGNATURES = {
+    "fx3d_version": [],
+    "fx3d_last_error": [C.c_char_p, sz],
+    "fx3d_device_count": [C.POINTER(c_i32)],
+    "fx3d_set_device": [c_i32],
+    "fx3d_get_device": [C.POINTER(c_i32)],
+    "fx3d_device_name": [c_i32, C.c_char_p, sz],
+    "fx3d_device_sync": [],
+    "fx3d_malloc": [C.POINTER(vp), sz],
+    "fx3d_free": [vp],
+    "fx3d_memcpy_h2d": [vp, vp, sz, vp],
+    "fx3d_memcpy_d2h": [vp, vp, sz, vp],
+    "fx3d_memcpy_d2d": [vp, vp, sz, vp],
+    "fx3d_memset": [vp, c_i32, sz, vp],
+    "fx3d_stream_create": [C.POINTER(vp)],
+    "fx3d_stream_destroy": [vp],
+    "fx3d_stream_sync": [vp],
+    "fx3d_event_create": [C.POINTER(vp)],
+    "fx3d_event_destroy": [vp],
+    "fx3d_event_record": [vp, vp],
+    "fx3d_event_sync": [vp],
+    "fx3d_event_elapsed_ms": [vp, vp, C.POINTER(c_f32)],
+    "fx3d_profile_enable": [c_i32],
+    "fx3d_profile_kernel_stats": [C.c_char_p, C.POINTER(c_f64), C.POINTER(c_f64), C.POINTER(c_f64),
+                                  C.POINTER(c_i64)],
+    "fx3d_nn1": [vp, c_i32, vp, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp],
+    "fx3d_chamfer_workspace_bytes": [c_i32, c_i32, c_i32, c_i32, C.POINTER(sz)],
+    "fx3d_chamfer_sums": [vp, c_i32, vp, c_i32, c_i32, c_i32, vp, vp, vp, vp, sz, vp],
+    "fx3d_chamfer_finalize": [vp, c_i32, c_i32, c_i64, c_i32, c_f32, c_f32, vp, vp],
+    "fx3d_chamfer_fwd": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_f32, c_f32, vp, C.POINTER(c_f32),
+                         vp, vp, vp, sz, vp],
+    "fx3d_chamfer_bwd": [vp, c_i32, vp, c_i32, c_i32, c_i32, vp, vp, c_f32, c_f32, c_f32, c_i64,
+                         vp, vp, vp],
+    "fx3d_knn": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, vp, vp],
+    "fx3d_knn_gather": [vp, c_i32, c_i32, c_i32, c_i32, vp, vp, vp],
+    "fx3d_faces_areas_packed": [vp, c_i64, vp, c_i64, vp, vp],
+    "fx3d_faces_areas_padded": [vp, c_i32, vp, c_i32, vp, c_i32, vp, vp],
+    "fx3d_sample_points_explicit": [vp, c_i32, vp, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp],
+    "fx3d_sample_points_workspace_bytes": [c_i32, c_i32, C.POINTER(sz)],
+    "fx3d_sample_points": [vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_f64, c_u64, vp, vp, vp, vp,
+                           vp, sz, vp],
+    "fx3d_sample_points_bwd": [vp, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp, vp],
+    "fx3d_mesh_loss_workspace_bytes": [c_i64, C.POINTER(sz)],
+    "fx3d_edge_loss": [vp, c_i64, vp, c_i64, c_f32, vp, C.POINTER(c_f32), vp, sz, vp],
+    "fx3d_edge_loss_bwd": [vp, c_i64, vp, c_i64, c_f32, c_f32, vp, vp],
+    "fx3d_laplacian_loss": [vp, c_i64, vp, vp, vp, vp, C.POINTER(c_f32), vp, sz, vp],
+    "fx3d_laplacian_loss_bwd": [vp, c_i64, vp, vp, vp, c_f32, vp, vp],
+    "fx3d_build_edges_packed": [vp, c_i64, c_i64, c_i32, vp, vp, C.POINTER(c_i64)],
+    "fx3d_build_laplacian_csr": [vp, c_i64, c_i64, c_i32, vp, vp, vp, C.POINTER(c_i64)],
+}
+_RESTYPES = {"fx3d_version": C.c_char_p, "fx3d_last_error": sz}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built -- no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C flux3d.jl_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, c_i32)
+    _lib = lib
+    return lib
+
+
+def last_error():
+    lib = load()
+    buf = C.create_string_buffer(512)
+    lib.fx3d_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc):
+    if rc != 0:
+        raise Flux3DHipError(rc, last_error())
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))

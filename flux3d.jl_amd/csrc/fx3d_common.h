@@ -1,0 +1,92 @@
+// Internal helpers shared by the translation units of libflux3d_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "flux3d_hip.h"
+
+namespace fx3d {
+
+void set_error(const char *fmt, ...);
+
+inline fx3d_status hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    set_error("%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    if (e == hipErrorOutOfMemory) return FX3D_ERR_OOM;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return FX3D_ERR_NO_DEVICE;
+    return FX3D_ERR_HIP;
+}
+
+#define FX3D_HIP(call)                                                          \
+    do {                                                                        \
+        hipError_t e__ = (call);                                                \
+        if (e__ != hipSuccess) return fx3d::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define FX3D_REQUIRE(cond, ...)                  \
+    do {                                         \
+        if (!(cond)) {                           \
+            fx3d::set_error(__VA_ARGS__);        \
+            return FX3D_ERR_INVALID_ARG;         \
+        }                                        \
+    } while (0)
+
+// checks the launch itself (configuration errors); execution errors surface at the next sync
+#define FX3D_LAUNCH_CHECK() FX3D_HIP(hipGetLastError())
+
+inline hipStream_t as_stream(fx3d_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- optional per-kernel event timing (runtime.hip) -------------------------------------------
+bool profile_on();
+void profile_mark(const char *name, hipStream_t st, bool begin);
+struct ProfileScope {  // brackets one dominant-kernel launch when profiling is enabled
+    const char *name;
+    hipStream_t st;
+    bool on;
+    ProfileScope(const char *n, hipStream_t s) : name(n), st(s), on(profile_on()) {
+        if (on) profile_mark(name, st, true);
+    }
+    ~ProfileScope() {
+        if (on) profile_mark(name, st, false);
+    }
+};
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+// ---- device-side reductions (wave64) -------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Sum over a block of NT threads (NT multiple of 64, <= 1024); result valid in thread 0.
+// Fixed order: lanes by shuffle tree, then waves 0..n-1 sequentially => deterministic.
+template <int NT>
+__device__ inline double block_sum(double v, double *smem /* >= NT/64 doubles */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) r += smem[i];
+    }
+    return r;
+}
+
+// Sum `n` doubles written by a previous kernel, single block of 256, fixed order.
+// (file-local copy per translation unit: no relocatable device code needed)
+__global__ static void reduce_partials_kernel(const double *__restrict__ partials, int64_t n,
+                                              double *__restrict__ out) {
+    __shared__ double sm[4];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) acc += partials[i];
+    double r = block_sum<256>(acc, sm);
+    if (threadIdx.x == 0) out[0] = r;
+}
+
+}  // namespace fx3d

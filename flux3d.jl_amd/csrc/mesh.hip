@@ -1,0 +1,287 @@
+// TriMesh kernels (gfx950): face areas, edge_loss, laplacian_loss and their adjoints.
+//
+// All four are gather + reduce over packed arrays: HBM/L2-bandwidth bound.  The
+// reference does the gathers with `verts[:, faces]` temporaries (src/rep/mesh.jl:772,
+// src/metrics/mesh.jl:27-28) and runs laplacian_loss's SpMM on the host even for CuArray meshes
+// (`cpu(transpose(verts))`, src/metrics/mesh.jl:12); here each is a single fused pass with a
+// deterministic two-stage reduction (per-block double partials -> one fixed-order block).
+// Arithmetic order follows the reference expression by expression, unfused (-ffp-contract=off).
+#include <cmath>
+
+#include "fx3d_common.h"
+
+using namespace fx3d;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 1024;
+
+// ||(v2-v1) x (v3-v1)|| / 2 : _lg_cross (src/rep/utils.jl:4-21), _norm (:29),
+// compute_faces_areas_packed (src/rep/mesh.jl:772-779).
+__device__ __forceinline__ float tri_area(const float *__restrict__ v1, const float *__restrict__ v2,
+                                          const float *__restrict__ v3) {
+    const float p0 = v1[0], p1 = v1[1], p2 = v1[2];
+    const float a1 = v2[0] - p0, a2 = v2[1] - p1, a3 = v2[2] - p2;
+    const float b1 = v3[0] - p0, b2 = v3[1] - p1, b3 = v3[2] - p2;
+    const float c1 = (a2 * b3) - (a3 * b2);
+    const float c2 = (a3 * b1) - (a1 * b3);
+    const float c3 = (a1 * b2) - (a2 * b1);
+    const float s = ((c1 * c1) + (c2 * c2)) + (c3 * c3);
+    return sqrtf(s) / 2.0f;
+}
+
+__global__ __launch_bounds__(kThreads) void faces_areas_packed_kernel(
+    const float *__restrict__ verts, const int32_t *__restrict__ faces, long long F,
+    float *__restrict__ areas) {
+    for (long long f = (long long)blockIdx.x * kThreads + threadIdx.x; f < F;
+         f += (long long)gridDim.x * kThreads) {
+        const int i1 = faces[3 * f], i2 = faces[3 * f + 1], i3 = faces[3 * f + 2];
+        areas[f] = tri_area(verts + 3ll * i1, verts + 3ll * i2, verts + 3ll * i3);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void faces_areas_padded_kernel(
+    const float *__restrict__ verts_padded, int Vmax, const int32_t *__restrict__ faces_padded,
+    int Fmax, const int32_t *__restrict__ faces_len, int B, float *__restrict__ areas) {
+    const long long total = (long long)B * Fmax;
+    for (long long k = (long long)blockIdx.x * kThreads + threadIdx.x; k < total;
+         k += (long long)gridDim.x * kThreads) {
+        const int b = (int)(k / Fmax), f = (int)(k % Fmax);
+        float a = 0.0f;  // _packed_to_padded pad value 0 (src/rep/mesh.jl:806)
+        if (f < faces_len[b]) {
+            const int32_t *fc = faces_padded + 3 * k;
+            const float *vb = verts_padded + (size_t)b * Vmax * 3;
+            a = tri_area(vb + 3ll * fc[0], vb + 3ll * fc[1], vb + 3ll * fc[2]);
+        }
+        areas[k] = a;
+    }
+}
+
+// ---- edge_loss (src/metrics/mesh.jl:24-32) ---------------------------------------------------
+__global__ __launch_bounds__(kThreads) void edge_loss_kernel(
+    const float *__restrict__ verts, const int32_t *__restrict__ e1,
+    const int32_t *__restrict__ e2, long long E, float target, double *__restrict__ partials) {
+    __shared__ double sm[kThreads / 64];
+    double acc = 0.0;
+    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < E;
+         e += (long long)gridDim.x * kThreads) {
+        const float *a = verts + 3ll * e1[e], *b = verts + 3ll * e2[e];
+        const float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
+        const float nrm = sqrtf(((d0 * d0) + (d1 * d1)) + (d2 * d2));
+        const float t = nrm - target;
+        acc += (double)(t * t);
+    }
+    const double tot = block_sum<kThreads>(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kThreads) void edge_loss_bwd_kernel(
+    const float *__restrict__ verts, const int32_t *__restrict__ e1,
+    const int32_t *__restrict__ e2, long long E, float target, float c, float *gverts) {
+    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < E;
+         e += (long long)gridDim.x * kThreads) {
+        const int i = e1[e], j = e2[e];
+        const float d0 = verts[3ll * i] - verts[3ll * j];
+        const float d1 = verts[3ll * i + 1] - verts[3ll * j + 1];
+        const float d2 = verts[3ll * i + 2] - verts[3ll * j + 2];
+        const float nrm = sqrtf(((d0 * d0) + (d1 * d1)) + (d2 * d2));
+        if (!(nrm > 0.0f)) continue;
+        const float g = c * 2.0f * (nrm - target) / nrm;
+        atomicAdd(&gverts[3ll * i], g * d0);
+        atomicAdd(&gverts[3ll * i + 1], g * d1);
+        atomicAdd(&gverts[3ll * i + 2], g * d2);
+        atomicAdd(&gverts[3ll * j], -(g * d0));
+        atomicAdd(&gverts[3ll * j + 1], -(g * d1));
+        atomicAdd(&gverts[3ll * j + 2], -(g * d2));
+    }
+}
+
+// ---- laplacian_loss (src/metrics/mesh.jl:9-15): row i of L*verts' in ascending column order ----
+__device__ __forceinline__ void lap_row(const float *__restrict__ verts,
+                                        const int32_t *__restrict__ rowptr,
+                                        const int32_t *__restrict__ colind,
+                                        const float *__restrict__ vals, long long i, float &s0,
+                                        float &s1, float &s2) {
+    s0 = 0.0f; s1 = 0.0f; s2 = 0.0f;
+    const int k1 = rowptr[i + 1];
+    for (int k = rowptr[i]; k < k1; ++k) {
+        const float w = vals[k];
+        const float *v = verts + 3ll * colind[k];
+        s0 = s0 + w * v[0];
+        s1 = s1 + w * v[1];
+        s2 = s2 + w * v[2];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void laplacian_loss_kernel(
+    const float *__restrict__ verts, long long V, const int32_t *__restrict__ rowptr,
+    const int32_t *__restrict__ colind, const float *__restrict__ vals,
+    double *__restrict__ partials) {
+    __shared__ double sm[kThreads / 64];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < V;
+         i += (long long)gridDim.x * kThreads) {
+        float s0, s1, s2;
+        lap_row(verts, rowptr, colind, vals, i, s0, s1, s2);
+        acc += (double)sqrtf(((s0 * s0) + (s1 * s1)) + (s2 * s2));
+    }
+    const double tot = block_sum<kThreads>(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kThreads) void laplacian_loss_bwd_kernel(
+    const float *__restrict__ verts, long long V, const int32_t *__restrict__ rowptr,
+    const int32_t *__restrict__ colind, const float *__restrict__ vals, float c, float *gverts) {
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < V;
+         i += (long long)gridDim.x * kThreads) {
+        float s0, s1, s2;
+        lap_row(verts, rowptr, colind, vals, i, s0, s1, s2);
+        const float nrm = sqrtf(((s0 * s0) + (s1 * s1)) + (s2 * s2));
+        if (!(nrm > 0.0f)) continue;
+        const float u0 = s0 / nrm, u1 = s1 / nrm, u2 = s2 / nrm;
+        const int k1 = rowptr[i + 1];
+        for (int k = rowptr[i]; k < k1; ++k) {
+            const float w = c * vals[k];
+            float *g = gverts + 3ll * colind[k];
+            atomicAdd(&g[0], w * u0);
+            atomicAdd(&g[1], w * u1);
+            atomicAdd(&g[2], w * u2);
+        }
+    }
+}
+
+// loss = Float32(sum(partials)/count), fixed order
+__global__ __launch_bounds__(kThreads) void mean_finalize_kernel(const double *__restrict__ partials,
+                                                                 int n, double count,
+                                                                 float *__restrict__ loss) {
+    __shared__ double sm[kThreads / 64];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += kThreads) acc += partials[i];
+    const double tot = block_sum<kThreads>(acc, sm);
+    if (threadIdx.x == 0) *loss = (float)(tot / count);
+}
+
+int grid_for(long long n) {
+    long long g = (n + kThreads - 1) / kThreads;
+    if (g < 1) g = 1;
+    if (g > kMaxBlocks) g = kMaxBlocks;
+    return (int)g;
+}
+
+fx3d_status copy_back(float *host, const float *dev, hipStream_t st) {
+    if (host) {
+        FX3D_HIP(hipMemcpyAsync(host, dev, sizeof(float), hipMemcpyDeviceToHost, st));
+        FX3D_HIP(hipStreamSynchronize(st));
+    }
+    return FX3D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+fx3d_status fx3d_faces_areas_packed(const float *verts, int64_t V, const int32_t *faces, int64_t F,
+                                    float *areas, fx3d_stream_t s) {
+    FX3D_REQUIRE(verts && faces && areas, "fx3d_faces_areas_packed: null pointer");
+    FX3D_REQUIRE(V > 0 && F > 0 && V < (1ll << 31), "fx3d_faces_areas_packed: bad sizes V=%lld F=%lld",
+                 (long long)V, (long long)F);
+    ProfileScope prof("faces_areas", as_stream(s));
+    hipLaunchKernelGGL(faces_areas_packed_kernel, dim3(grid_for(F)), dim3(kThreads), 0, as_stream(s),
+                       verts, faces, (long long)F, areas);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_faces_areas_padded(const float *verts_padded, int32_t Vmax,
+                                    const int32_t *faces_padded, int32_t Fmax,
+                                    const int32_t *faces_len, int32_t B, float *areas,
+                                    fx3d_stream_t s) {
+    FX3D_REQUIRE(verts_padded && faces_padded && faces_len && areas, "fx3d_faces_areas_padded: null pointer");
+    FX3D_REQUIRE(Vmax > 0 && Fmax > 0 && B > 0, "fx3d_faces_areas_padded: bad sizes");
+    hipLaunchKernelGGL(faces_areas_padded_kernel, dim3(grid_for((long long)B * Fmax)), dim3(kThreads),
+                       0, as_stream(s), verts_padded, Vmax, faces_padded, Fmax, faces_len, B, areas);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_mesh_loss_workspace_bytes(int64_t count, size_t *bytes) {
+    FX3D_REQUIRE(bytes, "fx3d_mesh_loss_workspace_bytes: null output");
+    (void)count;
+    *bytes = sizeof(double) * kMaxBlocks;
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_edge_loss(const float *verts, int64_t V, const int32_t *edges, int64_t E,
+                           float target, float *loss_dev, float *loss_host, void *ws,
+                           size_t ws_bytes, fx3d_stream_t s) {
+    FX3D_REQUIRE(verts && edges && loss_dev, "fx3d_edge_loss: null pointer");
+    FX3D_REQUIRE(V > 0 && E > 0 && V < (1ll << 31), "fx3d_edge_loss: bad sizes V=%lld E=%lld",
+                 (long long)V, (long long)E);
+    if (!ws || ws_bytes < sizeof(double) * kMaxBlocks) {
+        set_error("fx3d_edge_loss: workspace too small");
+        return FX3D_ERR_WORKSPACE;
+    }
+    hipStream_t st = as_stream(s);
+    double *partials = reinterpret_cast<double *>(ws);
+    const int g = grid_for(E);
+    {
+        ProfileScope prof("edge_loss", st);
+        hipLaunchKernelGGL(edge_loss_kernel, dim3(g), dim3(kThreads), 0, st, verts, edges, edges + E,
+                           (long long)E, target, partials);
+    }
+    FX3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(kThreads), 0, st, partials, g, (double)E, loss_dev);
+    FX3D_LAUNCH_CHECK();
+    return copy_back(loss_host, loss_dev, st);
+}
+
+fx3d_status fx3d_edge_loss_bwd(const float *verts, int64_t V, const int32_t *edges, int64_t E,
+                               float target, float gout, float *gverts, fx3d_stream_t s) {
+    FX3D_REQUIRE(verts && edges && gverts, "fx3d_edge_loss_bwd: null pointer");
+    FX3D_REQUIRE(V > 0 && E > 0, "fx3d_edge_loss_bwd: bad sizes");
+    hipStream_t st = as_stream(s);
+    FX3D_HIP(hipMemsetAsync(gverts, 0, sizeof(float) * 3 * (size_t)V, st));
+    hipLaunchKernelGGL(edge_loss_bwd_kernel, dim3(grid_for(E)), dim3(kThreads), 0, st, verts, edges,
+                       edges + E, (long long)E, target, gout / (float)E, gverts);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_laplacian_loss(const float *verts, int64_t V, const int32_t *rowptr,
+                                const int32_t *colind, const float *vals, float *loss_dev,
+                                float *loss_host, void *ws, size_t ws_bytes, fx3d_stream_t s) {
+    FX3D_REQUIRE(verts && rowptr && colind && vals && loss_dev, "fx3d_laplacian_loss: null pointer");
+    FX3D_REQUIRE(V > 0 && V < (1ll << 31), "fx3d_laplacian_loss: bad V=%lld", (long long)V);
+    if (!ws || ws_bytes < sizeof(double) * kMaxBlocks) {
+        set_error("fx3d_laplacian_loss: workspace too small");
+        return FX3D_ERR_WORKSPACE;
+    }
+    hipStream_t st = as_stream(s);
+    double *partials = reinterpret_cast<double *>(ws);
+    const int g = grid_for(V);
+    {
+        ProfileScope prof("laplacian_loss", st);
+        hipLaunchKernelGGL(laplacian_loss_kernel, dim3(g), dim3(kThreads), 0, st, verts, (long long)V,
+                           rowptr, colind, vals, partials);
+    }
+    FX3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(kThreads), 0, st, partials, g, (double)V, loss_dev);
+    FX3D_LAUNCH_CHECK();
+    return copy_back(loss_host, loss_dev, st);
+}
+
+fx3d_status fx3d_laplacian_loss_bwd(const float *verts, int64_t V, const int32_t *rowptr,
+                                    const int32_t *colind, const float *vals, float gout,
+                                    float *gverts, fx3d_stream_t s) {
+    FX3D_REQUIRE(verts && rowptr && colind && vals && gverts, "fx3d_laplacian_loss_bwd: null pointer");
+    FX3D_REQUIRE(V > 0, "fx3d_laplacian_loss_bwd: bad V");
+    hipStream_t st = as_stream(s);
+    FX3D_HIP(hipMemsetAsync(gverts, 0, sizeof(float) * 3 * (size_t)V, st));
+    hipLaunchKernelGGL(laplacian_loss_bwd_kernel, dim3(grid_for(V)), dim3(kThreads), 0, st, verts,
+                       (long long)V, rowptr, colind, vals, gout / (float)V, gverts);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,231 @@
+// Device / stream / memory plumbing of the C ABI (include/flux3d_hip.h, first block).
+// Replaces what the reference gets from CUDA.jl + Flux's gpu/cpu functor walkers
+// (src/Flux3D.jl:52-61, src/rep/pcloud.jl:57, src/rep/mesh.jl:189-190).
+#include <atomic>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "fx3d_common.h"
+
+namespace fx3d {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- per-kernel event timing -------------------------------------------------------------------
+namespace {
+struct ProfRec { const char *name; hipEvent_t e0, e1; };
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+std::atomic<bool> g_prof_on{false};
+constexpr size_t kProfCap = 8192;
+}  // namespace
+
+bool profile_on() { return g_prof_on.load(std::memory_order_relaxed); }
+
+void profile_mark(const char *name, hipStream_t st, bool begin) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (begin) {
+        if (g_prof.size() >= kProfCap) return;
+        ProfRec r{name, nullptr, nullptr};
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+        (void)hipEventRecord(r.e0, st);
+        g_prof.push_back(r);
+    } else {
+        for (size_t i = g_prof.size(); i-- > 0;)
+            if (g_prof[i].name == name) { (void)hipEventRecord(g_prof[i].e1, st); break; }
+    }
+}
+
+static void profile_clear() {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &r : g_prof) {
+        if (r.e0) (void)hipEventDestroy(r.e0);
+        if (r.e1) (void)hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+}
+
+}  // namespace fx3d
+
+using namespace fx3d;
+
+extern "C" {
+
+const char *fx3d_version(void) { return "flux3d_hip 0.1.0 (gfx950)"; }
+
+size_t fx3d_last_error(char *buf, size_t n) {
+    size_t len = strlen(g_err);
+    if (buf && n) {
+        size_t c = len < n - 1 ? len : n - 1;
+        memcpy(buf, g_err, c);
+        buf[c] = 0;
+    }
+    return len;
+}
+
+fx3d_status fx3d_profile_enable(int32_t on) {
+    profile_clear();
+    g_prof_on.store(on != 0);
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_profile_kernel_stats(const char *name, double *avg_ms, double *min_ms,
+                                      double *max_ms, int64_t *count) {
+    FX3D_REQUIRE(name && count, "fx3d_profile_kernel_stats: null argument");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double sum = 0.0, mn = 1e30, mx = 0.0;
+    int64_t n = 0;
+    for (auto &r : g_prof) {
+        if (strcmp(r.name, name) != 0) continue;
+        if (hipEventSynchronize(r.e1) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        sum += ms; mn = ms < mn ? ms : mn; mx = ms > mx ? ms : mx; ++n;
+    }
+    *count = n;
+    if (avg_ms) *avg_ms = n ? sum / (double)n : 0.0;
+    if (min_ms) *min_ms = n ? mn : 0.0;
+    if (max_ms) *max_ms = n ? mx : 0.0;
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_device_count(int32_t *n) {
+    FX3D_REQUIRE(n, "fx3d_device_count: null output");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        return hip_fail(e, "hipGetDeviceCount", __FILE__, __LINE__);
+    }
+    *n = c;
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_set_device(int32_t dev) {
+    FX3D_HIP(hipSetDevice(dev));
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_get_device(int32_t *dev) {
+    FX3D_REQUIRE(dev, "fx3d_get_device: null output");
+    int d = 0;
+    FX3D_HIP(hipGetDevice(&d));
+    *dev = d;
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_device_name(int32_t dev, char *buf, size_t n) {
+    FX3D_REQUIRE(buf && n, "fx3d_device_name: null buffer");
+    hipDeviceProp_t p;
+    FX3D_HIP(hipGetDeviceProperties(&p, dev));
+    snprintf(buf, n, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_device_sync(void) {
+    FX3D_HIP(hipDeviceSynchronize());
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_malloc(void **p, size_t bytes) {
+    FX3D_REQUIRE(p, "fx3d_malloc: null output");
+    *p = nullptr;
+    if (bytes == 0) return FX3D_OK;
+    FX3D_HIP(hipMalloc(p, bytes));
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_free(void *p) {
+    if (p) FX3D_HIP(hipFree(p));
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_memcpy_h2d(void *dst, const void *src, size_t bytes, fx3d_stream_t s) {
+    if (bytes == 0) return FX3D_OK;
+    FX3D_REQUIRE(dst && src, "fx3d_memcpy_h2d: null pointer");
+    FX3D_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(s)));
+    FX3D_HIP(hipStreamSynchronize(as_stream(s)));  // pageable host memory: keep it blocking
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_memcpy_d2h(void *dst, const void *src, size_t bytes, fx3d_stream_t s) {
+    if (bytes == 0) return FX3D_OK;
+    FX3D_REQUIRE(dst && src, "fx3d_memcpy_d2h: null pointer");
+    FX3D_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(s)));
+    FX3D_HIP(hipStreamSynchronize(as_stream(s)));
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_memcpy_d2d(void *dst, const void *src, size_t bytes, fx3d_stream_t s) {
+    if (bytes == 0) return FX3D_OK;
+    FX3D_REQUIRE(dst && src, "fx3d_memcpy_d2d: null pointer");
+    FX3D_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(s)));
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_memset(void *dst, int32_t byte, size_t bytes, fx3d_stream_t s) {
+    if (bytes == 0) return FX3D_OK;
+    FX3D_REQUIRE(dst, "fx3d_memset: null pointer");
+    FX3D_HIP(hipMemsetAsync(dst, byte, bytes, as_stream(s)));
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_stream_create(fx3d_stream_t *s) {
+    FX3D_REQUIRE(s, "fx3d_stream_create: null output");
+    hipStream_t st;
+    FX3D_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *s = st;
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_stream_destroy(fx3d_stream_t s) {
+    if (s) FX3D_HIP(hipStreamDestroy(as_stream(s)));
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_stream_sync(fx3d_stream_t s) {
+    FX3D_HIP(hipStreamSynchronize(as_stream(s)));
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_event_create(fx3d_event_t *e) {
+    FX3D_REQUIRE(e, "fx3d_event_create: null output");
+    hipEvent_t ev;
+    FX3D_HIP(hipEventCreate(&ev));
+    *e = ev;
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_event_destroy(fx3d_event_t e) {
+    if (e) FX3D_HIP(hipEventDestroy(reinterpret_cast<hipEvent_t>(e)));
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_event_record(fx3d_event_t e, fx3d_stream_t s) {
+    FX3D_REQUIRE(e, "fx3d_event_record: null event");
+    FX3D_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(e), as_stream(s)));
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_event_sync(fx3d_event_t e) {
+    FX3D_REQUIRE(e, "fx3d_event_sync: null event");
+    FX3D_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(e)));
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_event_elapsed_ms(fx3d_event_t a, fx3d_event_t b, float *ms) {
+    FX3D_REQUIRE(a && b && ms, "fx3d_event_elapsed_ms: null argument");
+    FX3D_HIP(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(a), reinterpret_cast<hipEvent_t>(b)));
+    return FX3D_OK;
+}
+
+}  // extern "C"

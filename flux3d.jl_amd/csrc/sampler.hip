@@ -1,0 +1,259 @@
+// sample_points kernels (gfx950): face-area-weighted triangle sampler.
+//
+// Replaces sample_points / _sample_points / _rand_barycentric_coords
+// (src/transforms/mesh_func.jl:21-82).  The reference loops over meshes on the host, copies each
+// probability vector D2H, builds a Distributions.Categorical alias table and draws with the
+// host RNG (:43-55).  Here the whole batch is three launches, nothing leaves the device:
+//   1. faces_areas_padded (mesh.hip)                         -- gather, HBM/L2 bound
+//   2. face_cdf_kernel: Float64 probabilities (:32-39, incl. the last-padded-column fix-up) and
+//      their CDF, one block per mesh, summed in the order specified in oracle/flux3d_oracle.c
+//      ("blocked" order, chunks of 32) so oracle and device agree bit-for-bit
+//   3. sample_kernel: one thread per sample: Philox4x32-10 draw -> binary search in the CDF ->
+//      barycentric point  (w1*v1 + w2*v2) + w3*v3, unfused Float32 (:67-71,:75-82)
+#include <cmath>
+
+#include "fx3d_common.h"
+
+using namespace fx3d;
+
+// defined in mesh.hip
+extern "C" fx3d_status fx3d_faces_areas_padded(const float *, int32_t, const int32_t *, int32_t,
+                                               const int32_t *, int32_t, float *, fx3d_stream_t);
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kChunk = 32;  // FX_SCAN_CHUNK of the oracle
+
+// barycentric point, src/transforms/mesh_func.jl:67-71,:75-82
+__device__ __forceinline__ void bary_point(const float *__restrict__ vb, const int32_t *__restrict__ fc,
+                                           float r1, float r2, float *__restrict__ o) {
+    const float *v1 = vb + 3ll * fc[0], *v2 = vb + 3ll * fc[1], *v3 = vb + 3ll * fc[2];
+    const float u = sqrtf(r1);
+    const float w1 = 1.0f - u, w2 = u * (1.0f - r2), w3 = u * r2;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) o[d] = ((w1 * v1[d]) + (w2 * v2[d])) + (w3 * v3[d]);
+}
+
+__global__ __launch_bounds__(kThreads) void sample_explicit_kernel(
+    const float *__restrict__ verts_padded, int Vmax, const int32_t *__restrict__ faces_padded,
+    int Fmax, int B, int n, const int32_t *__restrict__ face_idx, const float *__restrict__ r1,
+    const float *__restrict__ r2, float *__restrict__ out) {
+    const long long total = (long long)B * n;
+    for (long long k = (long long)blockIdx.x * kThreads + threadIdx.x; k < total;
+         k += (long long)gridDim.x * kThreads) {
+        const int b = (int)(k / n);
+        const float *vb = verts_padded + (size_t)b * Vmax * 3;
+        const int32_t *fc = faces_padded + ((size_t)b * Fmax + face_idx[k]) * 3;
+        bary_point(vb, fc, r1[k], r2[k], out + 3 * k);
+    }
+}
+
+// One block per mesh.  ws layout per mesh: cdf[Fp] then tc[nchunks]  (doubles), Fp = roundup32.
+__global__ __launch_bounds__(kThreads) void face_cdf_kernel(const float *__restrict__ areas, int Fmax,
+                                                            int Fp, double eps,
+                                                            double *__restrict__ ws) {
+    const int b = blockIdx.x;
+    const int nch = Fp / kChunk;
+    const float *a = areas + (size_t)b * Fmax;
+    double *cdf = ws + (size_t)b * (Fp + nch);
+    double *tc = cdf + Fp;
+    __shared__ double sh[2];
+
+    // chunk totals of the areas
+    for (int c = threadIdx.x; c < nch; c += kThreads) {
+        double t = 0.0;
+        for (int k = c * kChunk; k < (c + 1) * kChunk; ++k) t += (k < Fmax) ? (double)a[k] : 0.0;
+        tc[c] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int c = 0; c < nch; ++c) s += tc[c];
+        sh[0] = s > eps ? s : eps;  // max(sum, eps), :35
+    }
+    __syncthreads();
+    const double den = sh[0];
+    // chunk totals of p = a/den
+    for (int c = threadIdx.x; c < nch; c += kThreads) {
+        double t = 0.0;
+        for (int k = c * kChunk; k < (c + 1) * kChunk; ++k) t += (k < Fmax) ? (double)a[k] / den : 0.0;
+        tc[c] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sp = 0.0;
+        for (int c = 0; c < nch; ++c) sp += tc[c];
+        const double fix = 1.0 - sp;
+        sh[1] = fix > 0.0 ? fix : 0.0;  // :36-37
+    }
+    __syncthreads();
+    const double fix = sh[1];
+    // local inclusive prefixes of p' (fix-up on the last padded column Fmax-1) + chunk totals
+    for (int c = threadIdx.x; c < nch; c += kThreads) {
+        double l = 0.0;
+        for (int k = c * kChunk; k < (c + 1) * kChunk; ++k) {
+            if (k < Fmax) {
+                double p = (double)a[k] / den;
+                if (k == Fmax - 1) p += fix;
+                l += p;
+                cdf[k] = l;
+            }
+        }
+        tc[c] = l;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // exclusive scan of the chunk totals, in place
+        double off = 0.0;
+        for (int c = 0; c < nch; ++c) { const double t = tc[c]; tc[c] = off; off += t; }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < Fmax; k += kThreads) cdf[k] = tc[k / kChunk] + cdf[k];
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void sample_seeded_kernel(
+    const float *__restrict__ verts_padded, int Vmax, const int32_t *__restrict__ faces_padded,
+    int Fmax, int Fp, const int32_t *__restrict__ faces_len, int B, int n, uint64_t seed,
+    const double *__restrict__ ws, float *__restrict__ out, int32_t *__restrict__ face_out,
+    float *__restrict__ r1_out, float *__restrict__ r2_out) {
+    const long long total = (long long)B * n;
+    const int nch = Fp / kChunk;
+    for (long long k = (long long)blockIdx.x * kThreads + threadIdx.x; k < total;
+         k += (long long)gridDim.x * kThreads) {
+        const int b = (int)(k / n), sidx = (int)(k % n);
+        const double *cdf = ws + (size_t)b * (Fp + nch);
+        const int L = faces_len[b];
+        uint32_t c[4] = {(uint32_t)sidx, (uint32_t)b, 0u, 0u};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const uint64_t bits = (((uint64_t)c[0] << 32) | c[1]) >> 11;
+        const double uf = (double)bits * (1.0 / 9007199254740992.0) * cdf[L - 1];
+        int lo = 0, hi = L - 1;  // first f with cdf[f] > uf
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] > uf) hi = mid; else lo = mid + 1;
+        }
+        const float r1 = (float)(c[2] >> 8) * (1.0f / 16777216.0f);
+        const float r2 = (float)(c[3] >> 8) * (1.0f / 16777216.0f);
+        const float *vb = verts_padded + (size_t)b * Vmax * 3;
+        const int32_t *fc = faces_padded + ((size_t)b * Fmax + lo) * 3;
+        bary_point(vb, fc, r1, r2, out + 3 * k);
+        if (face_out) face_out[k] = lo;
+        if (r1_out) r1_out[k] = r1;
+        if (r2_out) r2_out[k] = r2;
+    }
+}
+
+// adjoint of samples = w1*v1 + w2*v2 + w3*v3 w.r.t. the padded verts (gather -> scatter-add)
+__global__ __launch_bounds__(kThreads) void sample_bwd_kernel(
+    const int32_t *__restrict__ faces_padded, int Vmax, int Fmax, int B, int n,
+    const int32_t *__restrict__ face_idx, const float *__restrict__ r1,
+    const float *__restrict__ r2, const float *__restrict__ gout, float *gverts) {
+    const long long total = (long long)B * n;
+    for (long long k = (long long)blockIdx.x * kThreads + threadIdx.x; k < total;
+         k += (long long)gridDim.x * kThreads) {
+        const int b = (int)(k / n);
+        const int32_t *fc = faces_padded + ((size_t)b * Fmax + face_idx[k]) * 3;
+        const float u = sqrtf(r1[k]), v = r2[k];
+        const float w[3] = {1.0f - u, u * (1.0f - v), u * v};
+        float *gb = gverts + (size_t)b * Vmax * 3;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) atomicAdd(&gb[3ll * fc[t] + d], w[t] * gout[3 * k + d]);
+    }
+}
+
+int grid_for(long long n) {
+    long long g = (n + kThreads - 1) / kThreads;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return (int)g;
+}
+
+inline int roundup32(int v) { return (v + kChunk - 1) / kChunk * kChunk; }
+
+size_t ws_bytes_needed(int Fmax, int B) {
+    const int Fp = roundup32(Fmax);
+    const size_t cdf = sizeof(double) * (size_t)B * (Fp + Fp / kChunk);
+    const size_t areas = sizeof(float) * (size_t)B * Fmax;
+    return cdf + ((areas + 15) / 16) * 16;
+}
+
+}  // namespace
+
+extern "C" {
+
+fx3d_status fx3d_sample_points_explicit(const float *verts_padded, int32_t Vmax,
+                                        const int32_t *faces_padded, int32_t Fmax, int32_t B,
+                                        int32_t n, const int32_t *face_idx, const float *r1,
+                                        const float *r2, float *out, fx3d_stream_t s) {
+    FX3D_REQUIRE(verts_padded && faces_padded && face_idx && r1 && r2 && out,
+                 "fx3d_sample_points_explicit: null pointer");
+    FX3D_REQUIRE(Vmax > 0 && Fmax > 0 && B > 0 && n > 0, "fx3d_sample_points_explicit: bad sizes");
+    hipLaunchKernelGGL(sample_explicit_kernel, dim3(grid_for((long long)B * n)), dim3(kThreads), 0,
+                       as_stream(s), verts_padded, Vmax, faces_padded, Fmax, B, n, face_idx, r1, r2, out);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_sample_points_workspace_bytes(int32_t Fmax, int32_t B, size_t *bytes) {
+    FX3D_REQUIRE(bytes, "fx3d_sample_points_workspace_bytes: null output");
+    FX3D_REQUIRE(Fmax > 0 && B > 0, "fx3d_sample_points_workspace_bytes: bad sizes");
+    *bytes = ws_bytes_needed(Fmax, B);
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_sample_points(const float *verts_padded, int32_t Vmax, const int32_t *faces_padded,
+                               int32_t Fmax, const int32_t *faces_len, int32_t B, int32_t n,
+                               double eps, uint64_t seed, float *out, int32_t *face_out,
+                               float *r1_out, float *r2_out, void *ws, size_t ws_bytes,
+                               fx3d_stream_t s) {
+    FX3D_REQUIRE(verts_padded && faces_padded && faces_len && out, "fx3d_sample_points: null pointer");
+    FX3D_REQUIRE(Vmax > 0 && Fmax > 0 && B > 0 && n > 0, "fx3d_sample_points: bad sizes");
+    if (!ws || ws_bytes < ws_bytes_needed(Fmax, B)) {
+        set_error("fx3d_sample_points: workspace too small (%zu < %zu)", ws ? ws_bytes : (size_t)0,
+                  ws_bytes_needed(Fmax, B));
+        return FX3D_ERR_WORKSPACE;
+    }
+    hipStream_t st = as_stream(s);
+    const int Fp = roundup32(Fmax);
+    double *cdf = reinterpret_cast<double *>(ws);
+    float *areas = reinterpret_cast<float *>(cdf + (size_t)B * (Fp + Fp / kChunk));
+    fx3d_status rc = fx3d_faces_areas_padded(verts_padded, Vmax, faces_padded, Fmax, faces_len, B, areas, s);
+    if (rc) return rc;
+    ProfileScope prof("sample", st);  // cdf + draw kernels together
+    hipLaunchKernelGGL(face_cdf_kernel, dim3(B), dim3(kThreads), 0, st, areas, Fmax, Fp, eps, cdf);
+    FX3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sample_seeded_kernel, dim3(grid_for((long long)B * n)), dim3(kThreads), 0, st,
+                       verts_padded, Vmax, faces_padded, Fmax, Fp, faces_len, B, n, seed, cdf, out,
+                       face_out, r1_out, r2_out);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_sample_points_bwd(const int32_t *faces_padded, int32_t Vmax, int32_t Fmax, int32_t B,
+                                   int32_t n, const int32_t *face_idx, const float *r1,
+                                   const float *r2, const float *gout, float *gverts,
+                                   fx3d_stream_t s) {
+    FX3D_REQUIRE(faces_padded && face_idx && r1 && r2 && gout && gverts, "fx3d_sample_points_bwd: null pointer");
+    FX3D_REQUIRE(Vmax > 0 && Fmax > 0 && B > 0 && n > 0, "fx3d_sample_points_bwd: bad sizes");
+    hipStream_t st = as_stream(s);
+    FX3D_HIP(hipMemsetAsync(gverts, 0, sizeof(float) * 3 * (size_t)Vmax * B, st));
+    hipLaunchKernelGGL(sample_bwd_kernel, dim3(grid_for((long long)B * n)), dim3(kThreads), 0, st,
+                       faces_padded, Vmax, Fmax, B, n, face_idx, r1, r2, gout, gverts);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+}  // extern "C"

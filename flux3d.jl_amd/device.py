@@ -1,0 +1,262 @@
+"""Device memory / stream plumbing on top of the C ABI (no torch needed).
+
+Mirrors what the reference gets from CUDA.jl + Flux's functor walkers: ``gpu(x)`` / ``cpu(x)``
+(src/Flux3D.jl:16-18, src/rep/pcloud.jl:57, src/rep/mesh.jl:189-190) and ``CuArray``.  A
+:class:`DeviceArray` is the ``S`` storage type of ``TriMesh{T,R,S}`` / ``PointCloud``: a typed,
+Julia-shaped (column-major) view of a device allocation.  Interop: anything exposing
+``data_ptr()`` (a torch CUDA tensor) can be wrapped without a copy via :meth:`DeviceArray.wrap`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def device_count():
+    n = C.c_int32(0)
+    try:
+        _lib.call("fx3d_device_count", C.byref(n))
+    except _lib.Flux3DHipError:
+        return 0
+    return n.value
+
+
+def functional():
+    """`CUDA.functional()` analogue feeding the `use_cuda`-style flag (src/Flux3D.jl:52-61)."""
+    return device_count() > 0
+
+
+def set_device(dev):
+    _lib.call("fx3d_set_device", int(dev))
+
+
+def device_name(dev=0):
+    buf = C.create_string_buffer(256)
+    _lib.call("fx3d_device_name", int(dev), buf, 256)
+    return buf.value.decode()
+
+
+def synchronize():
+    _lib.call("fx3d_device_sync")
+
+
+class Stream:
+    """A HIP stream owned by the library (``None``/0 handle = the default stream)."""
+
+    def __init__(self, handle=None, owned=False):
+        self.handle = handle
+        self._owned = owned
+
+    @classmethod
+    def create(cls):
+        h = C.c_void_p()
+        _lib.call("fx3d_stream_create", C.byref(h))
+        return cls(h.value, owned=True)
+
+    def synchronize(self):
+        _lib.call("fx3d_stream_sync", self.handle)
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and self.handle:
+            try:
+                _lib.load().fx3d_stream_destroy(self.handle)
+            except Exception:
+                pass
+            self.handle = None
+
+
+DEFAULT_STREAM = Stream(None)
+_current = [DEFAULT_STREAM]
+
+
+def current_stream():
+    return _current[-1]
+
+
+class stream:
+    """``with stream(s):`` routes every op of this package to ``s``."""
+
+    def __init__(self, s):
+        self.s = s
+
+    def __enter__(self):
+        _current.append(self.s)
+        return self.s
+
+    def __exit__(self, *a):
+        _current.pop()
+
+
+class Event:
+    def __init__(self):
+        h = C.c_void_p()
+        _lib.call("fx3d_event_create", C.byref(h))
+        self.handle = h.value
+
+    def record(self, s=None):
+        _lib.call("fx3d_event_record", self.handle, (s or current_stream()).handle)
+
+    def synchronize(self):
+        _lib.call("fx3d_event_sync", self.handle)
+
+    def elapsed_ms(self, later):
+        ms = C.c_float(0)
+        _lib.call("fx3d_event_elapsed_ms", self.handle, later.handle, C.byref(ms))
+        return ms.value
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            try:
+                _lib.load().fx3d_event_destroy(self.handle)
+            except Exception:
+                pass
+            self.handle = None
+
+
+class DeviceArray:
+    """Device buffer with a Julia-style (column-major) shape.  ``to_host()`` returns an
+    F-contiguous numpy array of the same shape: byte-identical to the Julia ``Array``."""
+
+    __slots__ = ("ptr", "shape", "dtype", "_owned", "_keep")
+
+    def __init__(self, ptr, shape, dtype, owned=False, keep=None):
+        self.ptr = ptr
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self._owned = owned
+        self._keep = keep
+
+    # -- construction ---------------------------------------------------------------------
+    @classmethod
+    def empty(cls, shape, dtype=np.float32):
+        shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        _lib.call("fx3d_malloc", C.byref(p), max(nbytes, 1))
+        return cls(p.value, shape, dtype, owned=True)
+
+    @classmethod
+    def zeros(cls, shape, dtype=np.float32):
+        a = cls.empty(shape, dtype)
+        _lib.call("fx3d_memset", a.ptr, 0, max(a.nbytes, 1), current_stream().handle)
+        return a
+
+    @classmethod
+    def from_host(cls, arr, dtype=None):
+        arr = np.asfortranarray(arr, dtype=dtype)
+        a = cls.empty(arr.shape, arr.dtype)
+        if arr.nbytes:
+            _lib.call("fx3d_memcpy_h2d", a.ptr, arr.ctypes.data, arr.nbytes, current_stream().handle)
+        return a
+
+    @classmethod
+    def wrap(cls, obj, shape=None, dtype=np.float32):
+        """Zero-copy view of foreign device memory (e.g. a torch CUDA tensor).  The tensor's
+        memory is interpreted as the column-major array ``shape`` (default: reversed dims)."""
+        ptr = obj.data_ptr()
+        if shape is None:
+            shape = tuple(reversed(tuple(obj.shape)))
+        return cls(ptr, shape, dtype, owned=False, keep=obj)
+
+    # -- properties -----------------------------------------------------------------------
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def reshape(self, *shape):
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        assert int(np.prod(shape, dtype=np.int64)) == self.size
+        return DeviceArray(self.ptr, shape, self.dtype, owned=False, keep=self)
+
+    def slab(self, start, count):
+        """Contiguous sub-range along the LAST (slowest) dimension -- e.g. a batch shard."""
+        inner = int(np.prod(self.shape[:-1], dtype=np.int64))
+        off = start * inner * self.dtype.itemsize
+        return DeviceArray(self.ptr + off, self.shape[:-1] + (count,), self.dtype, owned=False, keep=self)
+
+    # -- transfers ------------------------------------------------------------------------
+    def to_host(self):
+        out = np.empty(self.shape, dtype=self.dtype, order="F")
+        if self.nbytes:
+            _lib.call("fx3d_memcpy_d2h", out.ctypes.data, self.ptr, self.nbytes, current_stream().handle)
+        return out
+
+    def copy_(self, host):
+        host = np.asfortranarray(host, dtype=self.dtype)
+        assert host.size == self.size
+        _lib.call("fx3d_memcpy_h2d", self.ptr, host.ctypes.data, self.nbytes, current_stream().handle)
+        return self
+
+    def clone(self):
+        out = DeviceArray.empty(self.shape, self.dtype)
+        _lib.call("fx3d_memcpy_d2d", out.ptr, self.ptr, self.nbytes, current_stream().handle)
+        return out
+
+    def item(self):
+        return self.to_host().reshape(-1)[0]
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and self.ptr:
+            try:
+                _lib.load().fx3d_free(self.ptr)
+            except Exception:
+                pass
+            self.ptr = None
+
+    def __repr__(self):
+        return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, ptr=0x{(self.ptr or 0):x})"
+
+
+def is_device(x):
+    return isinstance(x, DeviceArray)
+
+
+def gpu(x):
+    """`gpu(x)` (src/Flux3D.jl:16-18): move an array / PointCloud / TriMesh to the device."""
+    if hasattr(x, "_to_device"):
+        return x._to_device()
+    if is_device(x):
+        return x
+    return DeviceArray.from_host(np.asarray(x))
+
+
+def cpu(x):
+    """`cpu(x)`: bring an array / PointCloud / TriMesh back to host numpy arrays."""
+    if hasattr(x, "_to_host"):
+        return x._to_host()
+    if is_device(x):
+        return x.to_host()
+    return x
+
+
+class Workspace:
+    """Grow-only scratch buffer handed to the ops that need one (caller-provided scratch is part
+    of the C ABI contract).  One per stream in use; the default one serves the default stream."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes):
+        if self.buf is None or self.buf.nbytes < nbytes:
+            self.buf = DeviceArray.empty((max(int(nbytes), 4096),), np.uint8)
+        return self.buf
+
+
+_workspaces = {}
+
+
+def workspace(nbytes, tag="default"):
+    key = (current_stream().handle, tag)
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = _workspaces[key] = Workspace()
+    return ws.get(nbytes)

@@ -1,0 +1,84 @@
+"""Data-parallel sharding of the batch dimension: one process per GPU, contiguous
+split of B, no data-path collective for kNN / sampling / per-mesh work, and exactly one
+all-reduce(sum) of two Float64 partial sums for chamfer_distance -- RCCL over xGMI when
+``torch.distributed`` runs the ``nccl`` backend (which is RCCL on ROCm), gloo in the CPU tests.
+
+The reference has no multi-device code at all; the batch loop it serialises
+(`for i = 1:size(x,3)`, src/metrics/pcloud.jl:57-58) is what is being split here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray, Stream, current_stream, stream
+from .metrics import _as_dev_points, _check_pair, chamfer_workspace
+
+
+def shard_bounds(B, world_size, rank):
+    """Contiguous split of B items over `world_size` ranks; the first B % world ranks get one
+    extra.  The (3,N,B) layout makes every shard one contiguous slab (``DeviceArray.slab``)."""
+    base, rem = divmod(int(B), int(world_size))
+    count = base + (1 if rank < rem else 0)
+    start = rank * base + min(rank, rem)
+    return start, count
+
+
+def chamfer_sums(x, y, out=None, idx_x=None, idx_y=None, sync=True):
+    """Partial sums [sum_i min_j ||x_i-y_j||^2, sum_j min_i ||.||^2] of this shard
+    (fx3d_chamfer_sums).  Host float64[2] when ``sync`` else the device array."""
+    x, y = _as_dev_points(x), _as_dev_points(y)
+    D, N, M, B = _check_pair(x, y)
+    ws = chamfer_workspace(N, M, B, D)
+    sums = out if out is not None else DeviceArray.empty((2,), np.float64)
+    _lib.call("fx3d_chamfer_sums", x.ptr, N, y.ptr, M, B, D, sums.ptr,
+              idx_x.ptr if idx_x else None, idx_y.ptr if idx_y else None, ws.ptr, ws.nbytes,
+              current_stream().handle)
+    return sums.to_host() if sync else sums
+
+
+def chamfer_finalize(sums, N, M, B_global, D, w1=1.0, w2=1.0, out=None, sync=True):
+    """loss from (all-reduced) sums with the GLOBAL batch size (fx3d_chamfer_finalize)."""
+    loss = out if out is not None else DeviceArray.empty((1,), np.float32)
+    _lib.call("fx3d_chamfer_finalize", sums.ptr, N, M, int(B_global), D, float(w1), float(w2),
+              loss.ptr, current_stream().handle)
+    return np.float32(loss.item()) if sync else loss
+
+
+def loss_from_sums(sums, N, M, B_global, D, w1=1.0, w2=1.0):
+    """The same scalar formula on the host (used by callers that reduced on the host, and by the
+    gloo tests): src/metrics/pcloud.jl:47-50."""
+    dA = np.float32(np.float32(sums[0] / (float(D) * N * B_global)) * np.float32(3.0))
+    dB = np.float32(np.float32(sums[1] / (float(D) * M * B_global)) * np.float32(3.0))
+    return np.float32(np.float32(w1) * dA + np.float32(w2) * dB)
+
+
+class ShardedChamfer:
+    """chamfer_distance over a batch sharded across the ranks of a torch.distributed group.
+
+    Every rank passes ITS shard (device arrays (3,N,Bs), (3,M,Bs)) and the global batch size;
+    every rank gets the global loss.  One all-reduce of 16 bytes per call (latency bound)."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+        self.loss = torch.zeros(1, dtype=torch.float32, device="cuda")
+        self._sums = DeviceArray.wrap(self.sums, shape=(2,), dtype=np.float64)
+        self._loss = DeviceArray.wrap(self.loss, shape=(1,), dtype=np.float32)
+
+    def __call__(self, x_shard, y_shard, B_global, w1=1.0, w2=1.0, sync=True):
+        torch, dist = self.torch, self.dist
+        # run on torch's current stream so the collective is ordered after the kernel
+        with stream(Stream(torch.cuda.current_stream().cuda_stream)):
+            D, N, Bs = x_shard.shape
+            M = y_shard.shape[1]
+            if Bs > 0:
+                chamfer_sums(x_shard, y_shard, out=self._sums, sync=False)
+            else:
+                self.sums.zero_()  # B < world: idle ranks contribute zeros
+            if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+                dist.all_reduce(self.sums, op=dist.ReduceOp.SUM, group=self.group)
+            chamfer_finalize(self._sums, N, M, B_global, D, w1, w2, out=self._loss, sync=False)
+        return float(self.loss.item()) if sync else self.loss

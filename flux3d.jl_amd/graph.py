@@ -1,0 +1,41 @@
+"""k-NN graph construction for DGCNN's EdgeConv (src/models/dgcnn.jl:3-9,36)."""
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray, current_stream
+from .metrics import _as_dev_points
+
+
+def knn(x, k, y=None, drop_first=False, return_dist=True):
+    """`knn(KDTree(y), x, k, true)` for every batch element (NearestNeighbors.jl call at
+    src/models/dgcnn.jl:5-6).  x:(D,N,B), y:(D,M,B) (default: x itself).  Returns device
+    ``idx (k,N,B)`` int32 0-based sorted by (distance, index) and ``dist (k,N,B)`` squared
+    distances.  ``drop_first`` drops the rank-0 hit (the reference's `[2:K+1]`)."""
+    x = _as_dev_points(x)
+    y = x if y is None else _as_dev_points(y)
+    D, N, B = x.shape
+    M = y.shape[1]
+    if y.shape[0] != D or y.shape[2] != B:
+        raise ValueError("DimensionMismatch between x and y")
+    idx = DeviceArray.empty((k, N, B), np.int32)
+    dist = DeviceArray.empty((k, N, B), np.float32) if return_dist else None
+    _lib.call("fx3d_knn", x.ptr, N, y.ptr, M, B, D, int(k), int(bool(drop_first)), idx.ptr,
+              dist.ptr if dist else None, current_stream().handle)
+    return (idx, dist) if return_dist else idx
+
+
+def knn_gather(x, idx):
+    """X[:, idxs] for every point: (F,k,N,B) (src/models/dgcnn.jl:6, cat at :36)."""
+    x = _as_dev_points(x)
+    F, N, B = x.shape
+    k = idx.shape[0]
+    out = DeviceArray.empty((F, k, N, B), np.float32)
+    _lib.call("fx3d_knn_gather", x.ptr, N, B, F, k, idx.ptr, out.ptr, current_stream().handle)
+    return out
+
+
+def create_knn_graph(X, K):
+    """EdgeConv's graph build (src/models/dgcnn.jl:36): for X (F,N,B) the K nearest neighbours of
+    every point in feature space, self excluded -> neighbour features (F,K,N,B) on the device."""
+    idx = knn(X, K, drop_first=True, return_dist=False)
+    return knn_gather(X, idx)

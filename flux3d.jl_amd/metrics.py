@@ -1,0 +1,161 @@
+"""Geometric metrics: chamfer_distance, laplacian_loss, edge_loss (+ their adjoints).
+
+Mirror of src/metrics/pcloud.jl and src/metrics/mesh.jl over the HIP C ABI.  Every function
+accepts host data (numpy / host PointCloud / host TriMesh: uploaded, computed on the GPU, scalar
+returned) or device data (:class:`DeviceArray`-backed): there is no CPU code path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray, current_stream, is_device, workspace
+from .rep import PointCloud, TriMesh
+
+
+def _as_dev_points(a):
+    """Float32 (D,N,B) device array from PointCloud / ndarray / DeviceArray (rank-2 lifted to
+    (D,N,1), src/metrics/pcloud.jl:28-37; non-Float32 cast, :14-19)."""
+    if isinstance(a, PointCloud):
+        a = a.points
+    if is_device(a):
+        if a.dtype != np.float32:
+            raise TypeError("device point arrays must be Float32")
+        return a.reshape(a.shape + (1,)) if a.ndim == 2 else a
+    a = np.asfortranarray(np.asarray(a, dtype=np.float32))
+    if a.ndim == 2:
+        a = a.reshape(a.shape[0], a.shape[1], 1, order="F")
+    if a.ndim != 3:
+        raise ValueError("points must be (D,N) or (D,N,B)")
+    return DeviceArray.from_host(a)
+
+
+def _check_pair(x, y):
+    D, N, B = x.shape
+    D2, M, B2 = y.shape
+    if D != D2:
+        raise ValueError(f"DimensionMismatch: point dimensionality differs ({D} vs {D2})")
+    if B != B2:
+        raise ValueError(f"DimensionMismatch: batch sizes differ ({B} vs {B2})")
+    return D, N, M, B
+
+
+def nearest_neighbors(x, y, return_dist=False):
+    """_nearest_neighbors(x, y) (src/metrics/pcloud.jl:54-86): for every point of x the index of
+    its nearest point in y (same batch element) and vice versa.  Returns device int32 arrays
+    (N,B) and (M,B), 0-based (the reference returns CartesianIndex(j, b), 1-based)."""
+    x, y = _as_dev_points(x), _as_dev_points(y)
+    D, N, M, B = _check_pair(x, y)
+    ix = DeviceArray.empty((N, B), np.int32)
+    iy = DeviceArray.empty((M, B), np.int32)
+    dx = DeviceArray.empty((N, B), np.float32) if return_dist else None
+    dy = DeviceArray.empty((M, B), np.float32) if return_dist else None
+    _lib.call("fx3d_nn1", x.ptr, N, y.ptr, M, B, D, ix.ptr, iy.ptr, dx.ptr if dx else None,
+              dy.ptr if dy else None, current_stream().handle)
+    return (ix, iy, dx, dy) if return_dist else (ix, iy)
+
+
+def chamfer_workspace(N, M, B, D):
+    n = C.c_size_t(0)
+    _lib.call("fx3d_chamfer_workspace_bytes", N, M, B, D, C.byref(n))
+    return workspace(n.value, "chamfer")
+
+
+def _chamfer_points(x, y, w1, w2, return_indices=False, loss_out=None, sync=True):
+    x, y = _as_dev_points(x), _as_dev_points(y)
+    D, N, M, B = _check_pair(x, y)
+    ws = chamfer_workspace(N, M, B, D)
+    loss_dev = loss_out if loss_out is not None else DeviceArray.empty((1,), np.float32)
+    ix = DeviceArray.empty((N, B), np.int32) if return_indices else None
+    iy = DeviceArray.empty((M, B), np.int32) if return_indices else None
+    host = C.c_float(0)
+    _lib.call("fx3d_chamfer_fwd", x.ptr, N, y.ptr, M, B, D, float(w1), float(w2), loss_dev.ptr,
+              C.byref(host) if sync else None, ix.ptr if ix else None, iy.ptr if iy else None,
+              ws.ptr, ws.nbytes, current_stream().handle)
+    loss = np.float32(host.value) if sync else loss_dev
+    return (loss, ix, iy) if return_indices else loss
+
+
+def chamfer_distance(A, B, num_samples=5000, w1=1.0, w2=1.0, return_indices=False, seed=None,
+                     loss_out=None, sync=True):
+    """chamfer_distance(A, B; w1, w2) for PointCloud / arrays (src/metrics/pcloud.jl:11-26) and
+    chamfer_distance(m1::TriMesh, m2::TriMesh, num_samples=5000; w1, w2) (src/metrics/mesh.jl:34-44).
+
+    Returns the Float32 loss (host scalar; with ``sync=False`` the 1-element device array).
+    ``return_indices=True`` also returns the nearest-neighbour index arrays (device)."""
+    if isinstance(A, TriMesh) or isinstance(B, TriMesh):
+        if not (isinstance(A, TriMesh) and isinstance(B, TriMesh)):
+            raise TypeError("chamfer_distance: both arguments must be TriMesh")
+        from .transforms import sample_points
+        s1 = None if seed is None else seed
+        s2 = None if seed is None else seed + 1
+        PA = sample_points(A, num_samples, seed=s1)
+        PB = sample_points(B, num_samples, seed=s2)
+        return _chamfer_points(PA, PB, w1, w2, return_indices, loss_out, sync)
+    return _chamfer_points(A, B, w1, w2, return_indices, loss_out, sync)
+
+
+def chamfer_distance_grad(A, B, idx_a, idx_b, w1=1.0, w2=1.0, gout=1.0, B_global=None):
+    """Adjoint of _chamfer_distance w.r.t. both clouds with the indices held constant
+    (Zygote through src/metrics/pcloud.jl:47-48; `@ignore` at :45).  Returns device (D,N,B), (D,M,B)."""
+    x, y = _as_dev_points(A), _as_dev_points(B)
+    D, N, M, Bn = _check_pair(x, y)
+    gx = DeviceArray.empty(x.shape, np.float32)
+    gy = DeviceArray.empty(y.shape, np.float32)
+    _lib.call("fx3d_chamfer_bwd", x.ptr, N, y.ptr, M, Bn, D, idx_a.ptr, idx_b.ptr, float(w1),
+              float(w2), float(gout), int(B_global or Bn), gx.ptr, gy.ptr, current_stream().handle)
+    return gx, gy
+
+
+def _mesh_ws(count):
+    n = C.c_size_t(0)
+    _lib.call("fx3d_mesh_loss_workspace_bytes", int(count), C.byref(n))
+    return workspace(n.value, "mesh")
+
+
+def laplacian_loss(m, sync=True):
+    """laplacian_loss(m::TriMesh) (src/metrics/mesh.jl:9-15)."""
+    verts = m.dev("verts_packed")
+    V = verts.shape[1]
+    ws = _mesh_ws(V)
+    loss_dev = DeviceArray.empty((1,), np.float32)
+    host = C.c_float(0)
+    _lib.call("fx3d_laplacian_loss", verts.ptr, V, m.dev("lap_rowptr").ptr, m.dev("lap_colind").ptr,
+              m.dev("lap_vals").ptr, loss_dev.ptr, C.byref(host) if sync else None, ws.ptr,
+              ws.nbytes, current_stream().handle)
+    return np.float32(host.value) if sync else loss_dev
+
+
+def laplacian_loss_grad(m, gout=1.0):
+    """Adjoint of laplacian_loss w.r.t. the packed verts: device (3, sumV)."""
+    verts = m.dev("verts_packed")
+    V = verts.shape[1]
+    g = DeviceArray.empty((3, V), np.float32)
+    _lib.call("fx3d_laplacian_loss_bwd", verts.ptr, V, m.dev("lap_rowptr").ptr,
+              m.dev("lap_colind").ptr, m.dev("lap_vals").ptr, float(gout), g.ptr,
+              current_stream().handle)
+    return g
+
+
+def edge_loss(m, target_length=0.0, sync=True):
+    """edge_loss(m::TriMesh, target_length=0.0) (src/metrics/mesh.jl:24-32)."""
+    verts = m.dev("verts_packed")
+    V = verts.shape[1]
+    edges = m.dev("edges")
+    E = edges.shape[0]
+    ws = _mesh_ws(E)
+    loss_dev = DeviceArray.empty((1,), np.float32)
+    host = C.c_float(0)
+    _lib.call("fx3d_edge_loss", verts.ptr, V, edges.ptr, E, float(target_length), loss_dev.ptr,
+              C.byref(host) if sync else None, ws.ptr, ws.nbytes, current_stream().handle)
+    return np.float32(host.value) if sync else loss_dev
+
+
+def edge_loss_grad(m, target_length=0.0, gout=1.0):
+    verts = m.dev("verts_packed")
+    V = verts.shape[1]
+    edges = m.dev("edges")
+    g = DeviceArray.empty((3, V), np.float32)
+    _lib.call("fx3d_edge_loss_bwd", verts.ptr, V, edges.ptr, edges.shape[0], float(target_length),
+              float(gout), g.ptr, current_stream().handle)
+    return g

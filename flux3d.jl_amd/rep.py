@@ -1,0 +1,438 @@
+"""PointCloud / TriMesh: host-side mirror of the reference's types for the hot path.
+
+* ``PointCloud``  -- src/rep/pcloud.jl:25-84: ``points`` is ``(D, N, B)`` Float32 (column-major,
+  i.e. an F-ordered numpy array or a :class:`DeviceArray`), optional ``normals``.
+* ``TriMesh``     -- src/rep/mesh.jl:70-231, 344-567, 838-1002: batched heterogeneous triangle
+  meshes in list / packed ``(3, sumV)`` / padded ``(3, Vmax, B)`` form with the same lazy validity
+  flags; faces are integer and stay on the host in the reference (:87-97) -- here they also get a
+  cached int32 0-based device mirror because the kernels gather through them.
+
+Faces keep the reference's 1-based numbering at this level (``index_base=1``), so fixtures copied
+from the reference's tests read the same; the C ABI takes 0-based int32.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray, current_stream, is_device
+
+
+def _f32(a):
+    return np.asfortranarray(np.asarray(a, dtype=np.float32))
+
+
+class PointCloud:
+    """PointCloud(points, normals=None) -- src/rep/pcloud.jl:25-55."""
+
+    def __init__(self, points, normals=None):
+        if isinstance(points, PointCloud):
+            points, normals = points.points, points.normals
+        self.points = self._lift(points)
+        self.normals = None if normals is None else self._lift(normals)
+        if self.normals is not None and self.normals.shape[1] != self.points.shape[1]:
+            raise ValueError("number of points and normals must match in PointCloud.")
+
+    @staticmethod
+    def _lift(a):
+        if is_device(a):
+            if a.dtype != np.float32:
+                raise TypeError("PointCloud device storage must be Float32")
+            return a.reshape(a.shape + (1,)) if a.ndim == 2 else a
+        a = _f32(a)
+        if a.ndim == 2:  # (D,N) -> (D,N,1), src/rep/pcloud.jl:30-44
+            a = a.reshape(a.shape[0], a.shape[1], 1, order="F")
+        if a.ndim != 3:
+            raise ValueError("points must be (D,N) or (D,N,B)")
+        return a
+
+    def __getitem__(self, index):  # p[i] -> points[:, :, i]  (:66), 0-based here
+        pts = self.points.to_host() if is_device(self.points) else self.points
+        return pts[:, :, index]
+
+    @property
+    def on_device(self):
+        return is_device(self.points)
+
+    def _to_device(self):
+        if self.on_device:
+            return self
+        return PointCloud(DeviceArray.from_host(self.points),
+                          None if self.normals is None else DeviceArray.from_host(self.normals))
+
+    def _to_host(self):
+        if not self.on_device:
+            return self
+        return PointCloud(self.points.to_host(),
+                          None if self.normals is None else self.normals.to_host())
+
+    def __repr__(self):
+        D, N, B = self.points.shape
+        return (f"PointCloud{{Float32}} Structure:\n    Batch size: {B}\n    Points: {N}\n"
+                f"    Normals {0 if self.normals is None else self.normals.shape[1]}\n"
+                f"    Storage type: {type(self.points).__name__}")
+
+
+def npoints(p):
+    """npoints(p::PointCloud), src/rep/pcloud.jl:84."""
+    return p.points.shape[1]
+
+
+# ------------------------------------------------------------------------------------ converters
+def _list_to_packed(lst):
+    """src/rep/utils.jl:95-101."""
+    return np.asfortranarray(np.concatenate(lst, axis=1))
+
+
+def _list_to_padded(lst, pad_value=0, pad_size=None):
+    """src/rep/utils.jl:51-93."""
+    if pad_size is None:
+        pad_size = (max(x.shape[0] for x in lst), max(x.shape[1] for x in lst))
+    out = np.full((pad_size[0], pad_size[1], len(lst)), pad_value, dtype=lst[0].dtype, order="F")
+    for i, x in enumerate(lst):
+        out[: x.shape[0], : x.shape[1], i] = x
+    return out
+
+
+def _packed_to_padded(packed, items_len, pad_value=0):
+    """src/rep/utils.jl:119-139."""
+    M = int(max(items_len))
+    out = np.full((packed.shape[0], M, len(items_len)), pad_value, dtype=packed.dtype, order="F")
+    cur = 0
+    for i, n in enumerate(items_len):
+        out[:, :n, i] = packed[:, cur:cur + n]
+        cur += n
+    return out
+
+
+def _packed_to_list(packed, items_len):
+    """src/rep/utils.jl:141-157."""
+    out, cur = [], 0
+    for n in items_len:
+        out.append(np.asfortranarray(packed[:, cur:cur + n]))
+        cur += n
+    return out
+
+
+def _padded_to_packed(padded, items_len):
+    """src/rep/utils.jl:159-181."""
+    return np.asfortranarray(np.concatenate([padded[:, :n, i] for i, n in enumerate(items_len)], axis=1))
+
+
+def _padded_to_list(padded, items_len):
+    """src/rep/utils.jl:183-206."""
+    return [np.asfortranarray(padded[:, :n, i]) for i, n in enumerate(items_len)]
+
+
+def _auxiliary_mesh(lst):
+    """src/rep/utils.jl:31-49 (1-based first indices, like the reference)."""
+    items_len = np.array([x.shape[1] for x in lst], dtype=np.int64)
+    first = np.concatenate([[1], 1 + np.cumsum(items_len)[:-1]]).astype(np.int64)
+    to_list = np.repeat(np.arange(1, len(lst) + 1), items_len).astype(np.int64)
+    return items_len, first, to_list
+
+
+# ---------------------------------------------------------------------------------------- TriMesh
+class TriMesh:
+    """TriMesh(verts_list, faces_list; offset=-1) -- src/rep/mesh.jl:70-187.
+
+    ``verts_list[i]`` is ``(3, V_i)`` float (numpy or DeviceArray), ``faces_list[i]`` is
+    ``(3, F_i)`` integer, 1-based mesh-local vertex ids (``index_base=1``) like the reference.
+    """
+
+    def __init__(self, verts_list, faces_list, offset=-1, index_base=1, faces_dtype=None):
+        if len(verts_list) != len(faces_list):
+            raise ValueError(
+                f"batch size of verts and faces should match, {len(verts_list)} != {len(faces_list)}")
+        self._device = any(is_device(v) for v in verts_list)
+        host_verts = [_f32(v.to_host() if is_device(v) else v) for v in verts_list]
+        for v in host_verts:
+            if v.ndim != 2 or v.shape[0] != 3:
+                raise ValueError("each verts array must be (3, V)")
+        R = faces_dtype or np.asarray(faces_list[0]).dtype
+        if not np.issubdtype(R, np.integer):
+            R = np.int64
+        self.R = np.dtype(R)
+        self.index_base = int(index_base)
+        self._faces_list = [np.asfortranarray(np.asarray(f, dtype=self.R)) for f in faces_list]
+        self._verts_len = np.array([v.shape[1] for v in host_verts], dtype=np.int64)
+        self._faces_len = np.array([f.shape[1] for f in self._faces_list], dtype=np.int64)
+        for f, nv in zip(self._faces_list, self._verts_len):
+            if f.ndim != 2 or f.shape[0] != 3:
+                raise ValueError("each faces array must be (3, F)")
+            if f.size and (f.min() < self.index_base or f.max() >= nv + self.index_base):
+                raise ValueError("face index outside the mesh's vertex range")
+        self.N = len(host_verts)
+        self.V = int(self._verts_len.max())
+        self.F = int(self._faces_len.max())
+        self.equalised = bool(np.all(self._verts_len == self.V) and np.all(self._faces_len == self.F))
+        self.valid = self._faces_len > 0
+        self.offset = int(offset)
+
+        # verts: list is the primary host form (always valid, src/rep/mesh.jl:208-231)
+        self._verts_list = host_verts
+        self._verts_packed = None
+        self._verts_padded = None
+        self._verts_packed_valid = False
+        self._verts_padded_valid = False
+        self._verts_list_valid = True
+        self._faces_packed = None
+        self._faces_padded = None
+        # topology caches (never invalidated: faces are immutable, :87-97)
+        self._edges_packed = None
+        self._faces_to_edges_packed = None
+        self._laplacian_packed = None  # (rowptr, colind, vals) host CSR, 0-based
+        # device mirrors
+        self._dev = {}
+        if self._device:
+            self._dev["verts_packed"] = DeviceArray.from_host(self.get_verts_packed_host())
+
+    # ---- verts -----------------------------------------------------------------------------
+    def get_verts_list(self):
+        if self._device and not self._verts_list_valid:
+            self._verts_list = _packed_to_list(self._dev["verts_packed"].to_host(), self._verts_len)
+            self._verts_list_valid = True
+        return self._verts_list
+
+    def get_verts_packed_host(self):
+        if self._device and "verts_packed" in self._dev and not self._verts_list_valid:
+            return self._dev["verts_packed"].to_host()
+        if not self._verts_packed_valid:
+            self._verts_packed = _list_to_packed(self.get_verts_list())
+            self._verts_packed_valid = True
+        return self._verts_packed
+
+    def get_verts_padded_host(self):
+        if not self._verts_padded_valid or self._device:
+            self._verts_padded = _packed_to_padded(self.get_verts_packed_host(), self._verts_len, 0)
+            self._verts_padded_valid = True
+        return self._verts_padded
+
+    def get_verts_packed(self):
+        """get_verts_packed (src/rep/mesh.jl:344-347): (3, sumV), storage type of the mesh."""
+        return self._dev["verts_packed"] if self._device else self.get_verts_packed_host()
+
+    def get_verts_padded(self):
+        """get_verts_padded (src/rep/mesh.jl:366-369): (3, Vmax, B) zero padded."""
+        if not self._device:
+            return self.get_verts_padded_host()
+        if "verts_padded" not in self._dev:
+            self._dev["verts_padded"] = self._packed_to_padded_dev(self._dev["verts_packed"])
+        return self._dev["verts_padded"]
+
+    def _packed_to_padded_dev(self, packed):
+        """_packed_to_padded (src/rep/utils.jl:119-139) without leaving the device."""
+        out = DeviceArray.zeros((3, self.V, self.N), np.float32)
+        cur, st = 0, current_stream().handle
+        for i, n in enumerate(self._verts_len):
+            n = int(n)
+            _lib.call("fx3d_memcpy_d2d", out.ptr + i * self.V * 12, packed.ptr + cur * 12, n * 12, st)
+            cur += n
+        return out
+
+    def set_verts_packed(self, new):
+        """`m._verts_packed = v` (setproperty!, src/rep/mesh.jl:208-231): replaces the vertex
+        positions and invalidates the other forms.  Topology caches are kept."""
+        if is_device(new):
+            assert new.shape == (3, int(self._verts_len.sum())) and new.dtype == np.float32
+            self._device = True
+            self._dev["verts_packed"] = new
+            self._dev.pop("verts_padded", None)
+            self._verts_list_valid = False
+            self._verts_packed_valid = False
+            self._verts_padded_valid = False
+        else:
+            new = _f32(new)
+            assert new.shape == (3, int(self._verts_len.sum()))
+            self._verts_list = _packed_to_list(new, self._verts_len)
+            self._verts_list_valid = True
+            self._verts_packed, self._verts_packed_valid = new, True
+            self._verts_padded_valid = False
+            if self._device:
+                self._dev["verts_packed"] = DeviceArray.from_host(new)
+                self._dev.pop("verts_padded", None)
+
+    # ---- faces (host, reference numbering) ------------------------------------------------------
+    def get_faces_list(self):
+        return self._faces_list
+
+    def get_faces_packed(self):
+        """get_faces_packed (src/rep/mesh.jl:413-416, _compute_faces_packed :884-896): (3, sumF),
+        ids offset by the cumulative vertex count of the preceding meshes."""
+        if self._faces_packed is None:
+            offs = np.concatenate([[0], np.cumsum(self._verts_len)[:-1]])
+            self._faces_packed = np.asfortranarray(np.concatenate(
+                [f.astype(np.int64) + o for f, o in zip(self._faces_list, offs)], axis=1).astype(self.R))
+        return self._faces_packed
+
+    def get_faces_padded(self):
+        """get_faces_padded (src/rep/mesh.jl:435-438): (3, Fmax, B), pad value 0."""
+        if self._faces_padded is None:
+            self._faces_padded = _list_to_padded(self._faces_list, 0, (3, self.F))
+        return self._faces_padded
+
+    # ---- topology (host builders of the C ABI; cached forever like the reference) ---------------
+    def _build_edges(self):
+        faces = np.asfortranarray(self.get_faces_packed(), dtype=np.int64)
+        F = faces.shape[1]
+        V = int(self._verts_len.sum())
+        f2e = np.zeros((F, 3), np.int64, order="F")
+        E = C.c_int64(0)
+        buf = np.zeros(6 * F, np.int64)  # capacity 3F rows; written densely as (E,2) column-major
+        _lib.call("fx3d_build_edges_packed", faces.ctypes.data, F, V, self.index_base,
+                  buf.ctypes.data, f2e.ctypes.data, C.byref(E))
+        E = E.value
+        edges = np.asfortranarray(buf[: 2 * E].reshape((E, 2), order="F")).astype(self.R)
+        self._edges_packed = edges
+        self._faces_to_edges_packed = f2e.astype(self.R)
+
+    def get_edges_packed(self):
+        """get_edges_packed (src/rep/mesh.jl:482-485): (E,2) sorted unique, reference numbering."""
+        if self._edges_packed is None:
+            self._build_edges()
+        return self._edges_packed
+
+    def get_faces_to_edges_packed(self):
+        if self._faces_to_edges_packed is None:
+            self._build_edges()
+        return self._faces_to_edges_packed
+
+    def get_edges_to_key(self):
+        """get_edges_to_key: Dict edge tuple -> key (src/rep/mesh.jl:939-940), key in reference numbering."""
+        e = self.get_edges_packed()
+        return {(int(a), int(b)): i + self.index_base for i, (a, b) in enumerate(e)}
+
+    def get_laplacian_packed(self):
+        """get_laplacian_packed (src/rep/mesh.jl:559-565) as 0-based CSR (rowptr, colind, vals)."""
+        if self._laplacian_packed is None:
+            e = np.asfortranarray(self.get_edges_packed(), dtype=np.int64)
+            E, V = e.shape[0], int(self._verts_len.sum())
+            rowptr = np.zeros(V + 1, np.int32)
+            colind = np.zeros(2 * E + V, np.int32)
+            vals = np.zeros(2 * E + V, np.float32)
+            nnz = C.c_int64(0)
+            _lib.call("fx3d_build_laplacian_csr", e.ctypes.data, E, V, self.index_base,
+                      rowptr.ctypes.data, colind.ctypes.data, vals.ctypes.data, C.byref(nnz))
+            self._laplacian_packed = (rowptr, colind[: nnz.value].copy(), vals[: nnz.value].copy())
+        return self._laplacian_packed
+
+    def laplacian_dense(self):
+        rowptr, colind, vals = self.get_laplacian_packed()
+        V = len(rowptr) - 1
+        L = np.zeros((V, V), np.float32)
+        for i in range(V):
+            L[i, colind[rowptr[i]:rowptr[i + 1]]] = vals[rowptr[i]:rowptr[i + 1]]
+        return L
+
+    # ---- device mirrors of the integer data ---------------------------------------------------------
+    def dev(self, name):
+        """Cached device copies: faces_packed / faces_padded / faces_len (int32 0-based), edges
+        (E,2) int32 0-based, lap_rowptr / lap_colind / lap_vals, and verts_* float32."""
+        if name in self._dev:
+            return self._dev[name]
+        b = self.index_base
+        if name == "verts_packed":
+            arr = DeviceArray.from_host(self.get_verts_packed_host())
+        elif name == "verts_padded":
+            arr = DeviceArray.from_host(self.get_verts_padded_host())
+        elif name == "faces_packed":
+            arr = DeviceArray.from_host((self.get_faces_packed().astype(np.int64) - b).astype(np.int32))
+        elif name == "faces_padded":
+            fp = self.get_faces_padded().astype(np.int64) - b
+            fp[fp < 0] = 0  # pad entries (value 0 in the reference) are never dereferenced
+            arr = DeviceArray.from_host(fp.astype(np.int32))
+        elif name == "faces_len":
+            arr = DeviceArray.from_host(self._faces_len.astype(np.int32))
+        elif name == "edges":
+            arr = DeviceArray.from_host((self.get_edges_packed().astype(np.int64) - b).astype(np.int32))
+        elif name in ("lap_rowptr", "lap_colind", "lap_vals"):
+            rowptr, colind, vals = self.get_laplacian_packed()
+            self._dev["lap_rowptr"] = DeviceArray.from_host(rowptr)
+            self._dev["lap_colind"] = DeviceArray.from_host(colind)
+            self._dev["lap_vals"] = DeviceArray.from_host(vals)
+            return self._dev[name]
+        else:
+            raise KeyError(name)
+        if name.startswith("verts") and not self._device:
+            return arr  # host mesh: do not cache vertex uploads (verts may change)
+        self._dev[name] = arr
+        return arr
+
+    # ---- gpu / cpu (functor(::TriMesh) moves only the verts, src/rep/mesh.jl:189-190) ---------------
+    @property
+    def on_device(self):
+        return self._device
+
+    def _to_device(self):
+        if self._device:
+            return self
+        m = TriMesh(self.get_verts_list(), self._faces_list, offset=self.offset,
+                    index_base=self.index_base, faces_dtype=self.R)
+        m._share_topology(self)
+        m._device = True
+        m._dev["verts_packed"] = DeviceArray.from_host(m.get_verts_packed_host())
+        return m
+
+    def _to_host(self):
+        if not self._device:
+            return self
+        m = TriMesh(self.get_verts_list(), self._faces_list, offset=self.offset,
+                    index_base=self.index_base, faces_dtype=self.R)
+        m._share_topology(self)
+        return m
+
+    def _share_topology(self, other):
+        self._faces_packed, self._faces_padded = other._faces_packed, other._faces_padded
+        self._edges_packed = other._edges_packed
+        self._faces_to_edges_packed = other._faces_to_edges_packed
+        self._laplacian_packed = other._laplacian_packed
+        for k, v in other._dev.items():
+            if not k.startswith("verts"):
+                self._dev[k] = v
+
+    def __getitem__(self, i):
+        return self.get_verts_list()[i], self._faces_list[i]
+
+    def __repr__(self):
+        return (f"TriMesh{{Float32, {self.R}, {'DeviceArray' if self._device else 'Array'}}} Structure:\n"
+                f"    Batch size: {self.N}\n    Max verts: {self.V}\n    Max faces: {self.F}\n"
+                f"    offset: {self.offset}\n    Storage type: {'DeviceArray' if self._device else 'Array'}")
+
+
+# accessor functions with the reference's names
+def get_verts_packed(m): return m.get_verts_packed()
+def get_verts_padded(m): return m.get_verts_padded()
+def get_verts_list(m): return m.get_verts_list()
+def get_faces_packed(m): return m.get_faces_packed()
+def get_faces_padded(m): return m.get_faces_padded()
+def get_faces_list(m): return m.get_faces_list()
+def get_edges_packed(m): return m.get_edges_packed()
+def get_faces_to_edges_packed(m): return m.get_faces_to_edges_packed()
+def get_edges_to_key(m): return m.get_edges_to_key()
+def get_laplacian_packed(m): return m.get_laplacian_packed()
+
+
+def load_obj(path):
+    """Minimal Wavefront OBJ reader (``v`` and triangular ``f`` records, ``a/b/c`` index forms).
+    Stands in for MeshIO behind load_trimesh (src/rep/mesh.jl:244-262) for the test assets."""
+    verts, faces = [], []
+    with open(path) as fh:
+        for line in fh:
+            if line.startswith("v "):
+                verts.append([float(t) for t in line.split()[1:4]])
+            elif line.startswith("f "):
+                ids = [int(t.split("/")[0]) for t in line.split()[1:]]
+                for k in range(1, len(ids) - 1):  # fan-triangulate polygons
+                    faces.append([ids[0], ids[k], ids[k + 1]])
+    v = np.asfortranarray(np.array(verts, dtype=np.float32).T)
+    f = np.asfortranarray(np.array(faces, dtype=np.uint32).T)
+    return v, f
+
+
+def load_trimesh(*paths):
+    """load_trimesh(fn...) (src/rep/mesh.jl:244-262) for .obj files: one batched TriMesh."""
+    flat = []
+    for p in paths:
+        flat.extend(p if isinstance(p, (list, tuple)) else [p])
+    vs, fs = zip(*[load_obj(p) for p in flat])
+    return TriMesh(list(vs), list(fs))

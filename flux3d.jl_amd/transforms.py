@@ -1,0 +1,90 @@
+"""sample_points and face areas (src/transforms/mesh_func.jl:21-82, src/rep/mesh.jl:765-836)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray, current_stream, workspace
+
+EPS = 1e-6  # src/transforms/utils.jl:4
+
+_seed_counter = [0x5EED5A4D]
+
+
+def compute_faces_areas_packed(m):
+    """compute_faces_areas_packed (src/rep/mesh.jl:765-780): device (sumF,) Float32."""
+    verts, faces = m.dev("verts_packed"), m.dev("faces_packed")
+    F = faces.shape[1]
+    out = DeviceArray.empty((F,), np.float32)
+    _lib.call("fx3d_faces_areas_packed", verts.ptr, verts.shape[1], faces.ptr, F, out.ptr,
+              current_stream().handle)
+    return out
+
+
+def compute_faces_areas_padded(m):
+    """compute_faces_areas_padded (src/rep/mesh.jl:799-808): device (1,Fmax,B), zero padded."""
+    verts, faces = m.dev("verts_padded") if not m.on_device else m.get_verts_padded(), m.dev("faces_padded")
+    out = DeviceArray.empty((1, m.F, m.N), np.float32)
+    _lib.call("fx3d_faces_areas_padded", verts.ptr, m.V, faces.ptr, m.F, m.dev("faces_len").ptr, m.N,
+              out.ptr, current_stream().handle)
+    return out
+
+
+def compute_faces_areas_list(m):
+    """compute_faces_areas_list (src/rep/mesh.jl:826-836): list of host (1,F_i) arrays."""
+    a = compute_faces_areas_packed(m).to_host()
+    out, cur = [], 0
+    for n in m._faces_len:
+        out.append(np.asfortranarray(a[cur:cur + n].reshape(1, -1)))
+        cur += int(n)
+    return out
+
+
+def _verts_padded_dev(m):
+    return m.get_verts_padded() if m.on_device else m.dev("verts_padded")
+
+
+def sample_points(m, num_samples=5000, eps=EPS, seed=None, return_draws=False,
+                  face_idx=None, r1=None, r2=None):
+    """sample_points(m::TriMesh, num_samples=5000; eps) (src/transforms/mesh_func.jl:21-58).
+
+    Returns a device ``(3, num_samples, B)`` Float32 array (the mesh's storage type in the
+    reference, ``::S{T,3}``).  Draws come from the device Philox stream keyed by ``seed`` (a fresh
+    seed per call when None, like the reference's global RNG); or pass explicit ``face_idx`` (n,B)
+    0-based mesh-local, ``r1``, ``r2`` (n,B) to reproduce `_sample_points` for given draws.
+    ``return_draws=True`` also returns (face_idx, r1, r2) device arrays for the adjoint."""
+    verts = _verts_padded_dev(m)
+    faces = m.dev("faces_padded")
+    n, B = int(num_samples), m.N
+    out = DeviceArray.empty((3, n, B), np.float32)
+    st = current_stream().handle
+    if face_idx is not None:
+        fi = face_idx if isinstance(face_idx, DeviceArray) else DeviceArray.from_host(np.asarray(face_idx, np.int32))
+        a = r1 if isinstance(r1, DeviceArray) else DeviceArray.from_host(np.asarray(r1, np.float32))
+        b = r2 if isinstance(r2, DeviceArray) else DeviceArray.from_host(np.asarray(r2, np.float32))
+        _lib.call("fx3d_sample_points_explicit", verts.ptr, m.V, faces.ptr, m.F, B, n, fi.ptr, a.ptr,
+                  b.ptr, out.ptr, st)
+        return (out, fi, a, b) if return_draws else out
+    if seed is None:
+        _seed_counter[0] = (_seed_counter[0] * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        seed = _seed_counter[0]
+    nb = C.c_size_t(0)
+    _lib.call("fx3d_sample_points_workspace_bytes", m.F, B, C.byref(nb))
+    ws = workspace(nb.value, "sampler")
+    fo = DeviceArray.empty((n, B), np.int32) if return_draws else None
+    a = DeviceArray.empty((n, B), np.float32) if return_draws else None
+    b = DeviceArray.empty((n, B), np.float32) if return_draws else None
+    _lib.call("fx3d_sample_points", verts.ptr, m.V, faces.ptr, m.F, m.dev("faces_len").ptr, B, n,
+              float(eps), int(seed) & ((1 << 64) - 1), out.ptr, fo.ptr if fo else None,
+              a.ptr if a else None, b.ptr if b else None, ws.ptr, ws.nbytes, st)
+    return (out, fo, a, b) if return_draws else out
+
+
+def sample_points_grad(m, face_idx, r1, r2, gout):
+    """Adjoint of sample_points w.r.t. the padded verts for fixed draws: device (3,Vmax,B)."""
+    n, B = face_idx.shape
+    g = DeviceArray.empty((3, m.V, m.N), np.float32)
+    gout = gout if isinstance(gout, DeviceArray) else DeviceArray.from_host(np.asarray(gout, np.float32))
+    _lib.call("fx3d_sample_points_bwd", m.dev("faces_padded").ptr, m.V, m.F, B, n, face_idx.ptr,
+              r1.ptr, r2.ptr, gout.ptr, g.ptr, current_stream().handle)
+    return g

@@ -1,0 +1,226 @@
+/*
+ * flux3d_hip.h -- C ABI of libflux3d_hip.so: the MI355X (gfx950) implementation of Flux3D.jl's
+ * batched geometric-metric hot path.
+ *
+ * The reference (FluxML/Flux3D.jl, pure Julia) has no FFI; its only device seam is Julia
+ * dispatch on array storage type (src/metrics/pcloud.jl:54 vs :72, TriMesh{T,R,S}
+ * src/rep/mesh.jl:70).  This header is what a `@ccall` shim binds to replace the CuArray methods
+ * (julia/Flux3DHip.jl; INTEGRATION.md shows the binding).  Each entry point cites the
+ * reference function it replaces.
+ *
+ * Conventions
+ *   - every function returns fx3d_status (0 = ok, <0 = error); text via fx3d_last_error().
+ *     No exceptions cross the boundary.  The shim turns non-zero into `error(msg)`, matching the
+ *     reference's error()/DimensionMismatch style (src/rep/pcloud.jl:37-38).
+ *   - layouts are exactly Julia's column-major arrays: a point batch (D,N,B) Float32 is the
+ *     contiguous stream x[(b*N+i)*D+d]; index outputs are int32, 0-based (the shim adds 1 and
+ *     builds CartesianIndex), shaped (N,B).
+ *   - pointers named *_dev / documented "device" are device pointers (from fx3d_malloc or any
+ *     HIP allocation of the same process, e.g. a torch tensor's data_ptr); "host" are host.
+ *   - the caller owns every buffer; the library keeps no pointer past return.
+ *   - ops are asynchronous on `stream` (NULL = the device's default stream) unless they have a
+ *     host output, which makes them synchronise that stream before returning.
+ *   - scratch is caller-provided: query the size with the matching *_workspace_bytes().
+ *   - floating point is Float32 without fused multiply-add on the result-defining path
+ *     (distance, area, sampling), so results are bit-identical to the CPU restatement.
+ */
+#ifndef FLUX3D_HIP_H
+#define FLUX3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FX3D_API __attribute__((visibility("default")))
+
+typedef int32_t fx3d_status;
+#define FX3D_OK 0
+#define FX3D_ERR_INVALID_ARG (-1) /* bad shape / null pointer / unsupported size */
+#define FX3D_ERR_HIP (-2)         /* a HIP runtime call failed (text in fx3d_last_error) */
+#define FX3D_ERR_OOM (-3)
+#define FX3D_ERR_NO_DEVICE (-4)   /* no gfx950 device visible */
+#define FX3D_ERR_UNSUPPORTED (-5)
+#define FX3D_ERR_WORKSPACE (-6)   /* workspace pointer null or too small */
+
+typedef void *fx3d_stream_t; /* hipStream_t */
+typedef void *fx3d_event_t;  /* hipEvent_t  */
+
+/* ---- library / device management (replaces Flux3D.use_cuda + CUDA.jl plumbing,
+ *      src/Flux3D.jl:52-61; `gpu`/`cpu` functor walkers src/rep/pcloud.jl:57) -------------- */
+FX3D_API const char *fx3d_version(void);
+FX3D_API size_t fx3d_last_error(char *buf, size_t n); /* thread-local message; returns strlen */
+FX3D_API fx3d_status fx3d_device_count(int32_t *n);
+FX3D_API fx3d_status fx3d_set_device(int32_t dev);
+FX3D_API fx3d_status fx3d_get_device(int32_t *dev);
+FX3D_API fx3d_status fx3d_device_name(int32_t dev, char *buf, size_t n);
+FX3D_API fx3d_status fx3d_device_sync(void);
+FX3D_API fx3d_status fx3d_malloc(void **dev_ptr, size_t bytes);
+FX3D_API fx3d_status fx3d_free(void *dev_ptr);
+FX3D_API fx3d_status fx3d_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_memset(void *dst_dev, int32_t byte, size_t bytes, fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_stream_create(fx3d_stream_t *s);
+FX3D_API fx3d_status fx3d_stream_destroy(fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_stream_sync(fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_event_create(fx3d_event_t *e);
+FX3D_API fx3d_status fx3d_event_destroy(fx3d_event_t e);
+FX3D_API fx3d_status fx3d_event_record(fx3d_event_t e, fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_event_sync(fx3d_event_t e);
+FX3D_API fx3d_status fx3d_event_elapsed_ms(fx3d_event_t start, fx3d_event_t stop, float *ms);
+
+/* ---- kernel timing hooks (the reference has no tracing; BenchmarkTools/CUDA.@sync
+ *      in benchmarks/metrics.jl:27-31,82 is what this replaces).  When enabled, every op brackets
+ *      its DOMINANT kernel launch with HIP events on the op's own stream; stats are per kernel name
+ *      ("nn1", "knn", "sample", "edge_loss", "laplacian_loss", "faces_areas", ...).  Reading the
+ *      stats synchronises the recorded events.  Up to 8192 launches are kept per enable. ---- */
+FX3D_API fx3d_status fx3d_profile_enable(int32_t on); /* also resets */
+FX3D_API fx3d_status fx3d_profile_kernel_stats(const char *name, double *avg_ms, double *min_ms,
+                                               double *max_ms, int64_t *count);
+
+/* ---- nearest neighbours + chamfer (src/metrics/pcloud.jl) ----------------------------------
+ * fx3d_nn1 replaces _nearest_neighbors(::CuArray{Float32,3}, ::CuArray{Float32,3})
+ * (src/metrics/pcloud.jl:72-86) with the *CPU method's* semantics (:54-70): exact Float32
+ * direct-difference distance, lowest index on ties.  x:(D,N,B) y:(D,M,B) device.
+ * idx_x:(N,B) int32 0-based index into y ; idx_y:(M,B) into x ; dmin_* squared distances.
+ * Any of the four outputs may be NULL. */
+FX3D_API fx3d_status fx3d_nn1(const float *x, int32_t N, const float *y, int32_t M, int32_t B,
+                              int32_t D, int32_t *idx_x, int32_t *idx_y, float *dmin_x,
+                              float *dmin_y, fx3d_stream_t s);
+
+/* Scratch needed by the chamfer entry points below (bytes). */
+FX3D_API fx3d_status fx3d_chamfer_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_t D,
+                                                  size_t *bytes);
+
+/* Partial sums of _chamfer_distance (src/metrics/pcloud.jl:47-48) for this batch (shard):
+ *   sums_dev[0] = sum_b sum_i ||x_i - y_nn(i)||^2 ,  sums_dev[1] = sum_b sum_j ||y_j - x_nn(j)||^2
+ * (double, device, deterministic reduction order).  idx_x/idx_y optional (NULL to skip). */
+FX3D_API fx3d_status fx3d_chamfer_sums(const float *x, int32_t N, const float *y, int32_t M,
+                                       int32_t B, int32_t D, double *sums_dev, int32_t *idx_x,
+                                       int32_t *idx_y, void *ws, size_t ws_bytes,
+                                       fx3d_stream_t s);
+
+/* loss = w1 * (Float32(sums[0]/(D*N*Bg)) * 3f0) + w2 * (Float32(sums[1]/(D*M*Bg)) * 3f0)
+ * (src/metrics/pcloud.jl:47-50; the hard-coded 3.0f0 is kept for D != 3).  Bg is the GLOBAL batch
+ * size: after an all-reduce(sum) of sums_dev over the ranks that sharded the batch, every rank
+ * calls this with the same Bg.  loss_dev: device float. */
+FX3D_API fx3d_status fx3d_chamfer_finalize(const double *sums_dev, int32_t N, int32_t M,
+                                           int64_t B_global, int32_t D, float w1, float w2,
+                                           float *loss_dev, fx3d_stream_t s);
+
+/* _chamfer_distance(A,B,w1,w2) forward in one call (src/metrics/pcloud.jl:39-52). loss_dev
+ * device float; loss_host optional host float (non-NULL => stream is synchronised). */
+FX3D_API fx3d_status fx3d_chamfer_fwd(const float *x, int32_t N, const float *y, int32_t M,
+                                      int32_t B, int32_t D, float w1, float w2, float *loss_dev,
+                                      float *loss_host, int32_t *idx_x, int32_t *idx_y,
+                                      void *ws, size_t ws_bytes, fx3d_stream_t s);
+
+/* Zygote adjoint of src/metrics/pcloud.jl:47-48 with indices constant (@ignore, :45):
+ *   gx = gout*w1*6/(D*N*Bg) * (x - y[idx_x])  - scatter_add_{idx_y}(gout*w2*6/(D*M*Bg)*(y - x[idx_y]))
+ *   gy symmetric.   gx:(D,N,B) gy:(D,M,B) device, overwritten. */
+FX3D_API fx3d_status fx3d_chamfer_bwd(const float *x, int32_t N, const float *y, int32_t M,
+                                      int32_t B, int32_t D, const int32_t *idx_x,
+                                      const int32_t *idx_y, float w1, float w2, float gout,
+                                      int64_t B_global, float *gx, float *gy, fx3d_stream_t s);
+
+/* ---- k-NN graph (src/models/dgcnn.jl:3-7,36) ---------------------------------------------------
+ * knn(KDTree(y), x, k+drop_first, true)[1][1+drop_first:end] for every point of every batch
+ * element: idx:(k,N,B) int32 0-based sorted by (distance, index); dist:(k,N,B) squared distances
+ * (optional).  y may equal x (self graph; drop_first=1 drops the rank-0 hit as the reference
+ * does).  Supported: k+drop_first <= 64, any D >= 1. */
+FX3D_API fx3d_status fx3d_knn(const float *x, int32_t N, const float *y, int32_t M, int32_t B,
+                              int32_t D, int32_t k, int32_t drop_first, int32_t *idx,
+                              float *dist, fx3d_stream_t s);
+
+/* X[:, idxs] gather -> (F,k,N,B)  (src/models/dgcnn.jl:6 `X[:, knn(...)]`, cat at :36). */
+FX3D_API fx3d_status fx3d_knn_gather(const float *x, int32_t N, int32_t B, int32_t F, int32_t k,
+                                     const int32_t *idx, float *out, fx3d_stream_t s);
+
+/* ---- TriMesh kernels --------------------------------------------------------------------------
+ * Faces/edges cross the ABI as int32, 0-based (the shim converts the reference's 1-based
+ * UInt32/Int64, src/rep/mesh.jl:87-89).  verts_packed (3,sumV); faces_packed (3,sumF) global
+ * ids; verts_padded (3,Vmax,B) zero padded; faces_padded (3,Fmax,B) mesh-local ids (pad entries
+ * ignored); faces_len (B) int32 -- all device. */
+
+/* compute_faces_areas_packed (src/rep/mesh.jl:765-780): areas (sumF). */
+FX3D_API fx3d_status fx3d_faces_areas_packed(const float *verts, int64_t V, const int32_t *faces,
+                                             int64_t F, float *areas, fx3d_stream_t s);
+/* compute_faces_areas_padded (src/rep/mesh.jl:799-808): areas (1,Fmax,B), zero padded. */
+FX3D_API fx3d_status fx3d_faces_areas_padded(const float *verts_padded, int32_t Vmax,
+                                             const int32_t *faces_padded, int32_t Fmax,
+                                             const int32_t *faces_len, int32_t B, float *areas,
+                                             fx3d_stream_t s);
+
+/* _sample_points + _rand_barycentric_coords (src/transforms/mesh_func.jl:60-82) with the random
+ * draws supplied: face_idx (n,B) int32 mesh-local 0-based, r1,r2 (n,B) in [0,1).  out (3,n,B). */
+FX3D_API fx3d_status fx3d_sample_points_explicit(const float *verts_padded, int32_t Vmax,
+                                                 const int32_t *faces_padded, int32_t Fmax,
+                                                 int32_t B, int32_t n, const int32_t *face_idx,
+                                                 const float *r1, const float *r2, float *out,
+                                                 fx3d_stream_t s);
+
+FX3D_API fx3d_status fx3d_sample_points_workspace_bytes(int32_t Fmax, int32_t B, size_t *bytes);
+
+/* sample_points(m, n; eps) (src/transforms/mesh_func.jl:21-58), drawing on device:
+ * face ~ Categorical(area/ max(sum area, eps)) through a Float64 CDF (the reference computes the
+ * probabilities in Float64 too, :32-39, including the last-padded-column fix-up), Philox4x32-10
+ * counter RNG keyed by `seed`.  out (3,n,B); face_out, r1_out, r2_out (n,B) optional: the draws,
+ * so that the adjoint (fx3d_sample_points_bwd) can be taken for the same sample. */
+FX3D_API fx3d_status fx3d_sample_points(const float *verts_padded, int32_t Vmax,
+                                        const int32_t *faces_padded, int32_t Fmax,
+                                        const int32_t *faces_len, int32_t B, int32_t n,
+                                        double eps, uint64_t seed, float *out, int32_t *face_out,
+                                        float *r1_out, float *r2_out, void *ws, size_t ws_bytes,
+                                        fx3d_stream_t s);
+
+/* Adjoint of sample_points w.r.t. verts_padded for the same draws (Zygote through :67-71):
+ * gverts_padded (3,Vmax,B) += scatter of w_k * gout over the sampled faces. Overwrites gverts. */
+FX3D_API fx3d_status fx3d_sample_points_bwd(const int32_t *faces_padded, int32_t Vmax,
+                                            int32_t Fmax, int32_t B, int32_t n,
+                                            const int32_t *face_idx, const float *r1,
+                                            const float *r2, const float *gout, float *gverts,
+                                            fx3d_stream_t s);
+
+/* Scratch for the two mesh losses (bytes), count = E or V. */
+FX3D_API fx3d_status fx3d_mesh_loss_workspace_bytes(int64_t count, size_t *bytes);
+
+/* edge_loss(m, target) (src/metrics/mesh.jl:24-32).  edges (E,2) int32 0-based packed vertex
+ * ids, column-major (first E entries = column 1).  loss_dev device float; loss_host optional. */
+FX3D_API fx3d_status fx3d_edge_loss(const float *verts, int64_t V, const int32_t *edges,
+                                    int64_t E, float target, float *loss_dev, float *loss_host,
+                                    void *ws, size_t ws_bytes, fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_edge_loss_bwd(const float *verts, int64_t V, const int32_t *edges,
+                                        int64_t E, float target, float gout, float *gverts,
+                                        fx3d_stream_t s);
+
+/* laplacian_loss(m) (src/metrics/mesh.jl:9-15) with L in CSR (rows = vertices, columns
+ * ascending, values Float32 as built by _compute_laplacian_packed, src/rep/mesh.jl:957-1002). */
+FX3D_API fx3d_status fx3d_laplacian_loss(const float *verts, int64_t V, const int32_t *rowptr,
+                                         const int32_t *colind, const float *vals,
+                                         float *loss_dev, float *loss_host, void *ws,
+                                         size_t ws_bytes, fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_laplacian_loss_bwd(const float *verts, int64_t V, const int32_t *rowptr,
+                                             const int32_t *colind, const float *vals, float gout,
+                                             float *gverts, fx3d_stream_t s);
+
+/* ---- host-side topology (integer work; the reference keeps faces/edges/Laplacian on the host,
+ *      src/rep/mesh.jl:87-97, and caches them forever) ------------------------------------------
+ * _compute_edges_packed (src/rep/mesh.jl:907-955).  faces (3,F) host int64, `index_base` 0 or 1.
+ * edges_out capacity 3F rows, column-major with leading dimension 3F?  No: written densely as
+ * (E,2) column-major once E is known.  faces_to_edges (F,3) column-major, optional.
+ * Outputs keep the caller's index_base. */
+FX3D_API fx3d_status fx3d_build_edges_packed(const int64_t *faces, int64_t F, int64_t V,
+                                             int32_t index_base, int64_t *edges_out,
+                                             int64_t *faces_to_edges, int64_t *E_out);
+/* _compute_laplacian_packed (src/rep/mesh.jl:957-1002) as 0-based CSR; capacity 2E+V. */
+FX3D_API fx3d_status fx3d_build_laplacian_csr(const int64_t *edges, int64_t E, int64_t V,
+                                              int32_t index_base, int32_t *rowptr,
+                                              int32_t *colind, float *vals, int64_t *nnz_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUX3D_HIP_H */

@@ -1,0 +1,441 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Bar (BASELINE.json north_star): bit-exact indices (and distances, areas, samples -- anything the
+oracle defines in unfused Float32); losses within 1e-5 relative.  Edge cases follow the
+reference's tests (N != M, B = 2, ragged meshes) plus ragged tile/chunk boundaries, ties, D != 3.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-5  # north_star: "Chamfer/Laplacian within 1e-5 relative fp32"
+
+
+def _rand(shape, seed):
+    return np.asfortranarray(np.random.default_rng(seed).random(shape, dtype=np.float32))
+
+
+def _check_nn(fx, oracle, x, y):
+    ix, iy, dx, dy = fx.nearest_neighbors(x, y, return_dist=True)
+    ox, oy, odx, ody = oracle.nn1(x, y, want_dist=True)
+    assert np.array_equal(ix.to_host(), ox), "idx_x differs from the oracle"
+    assert np.array_equal(iy.to_host(), oy), "idx_y differs from the oracle"
+    assert np.array_equal(dx.to_host(), odx) and np.array_equal(dy.to_host(), ody)
+
+
+def _check_chamfer(fx, oracle, x, y, w1=1.0, w2=1.0):
+    loss, ix, iy = fx.chamfer_distance(x, y, w1=w1, w2=w2, return_indices=True)
+    oloss, ox, oy, _ = oracle.chamfer_distance(x, y, w1, w2, return_all=True)
+    assert np.array_equal(ix.to_host(), ox) and np.array_equal(iy.to_host(), oy)
+    assert np.isclose(loss, oloss, rtol=LOSS_RTOL, atol=0), (loss, oloss)
+    loss2 = fx.chamfer_distance(x, y, w1=w1, w2=w2)  # loss-only kernel variant (no rescan)
+    assert loss2 == loss
+    return loss
+
+
+# ------------------------------------------------------------------------------ chamfer / nn1
+def test_c1_chamfer_b2_n1024(gpu_fx, oracle):
+    """BASELINE config 1: B=2, N=M=1024, the documented synthetic stream."""
+    fx = gpu_fx
+    x = fx.synth.uniform_cloud(fx.synth.SEED_A, 3, 1024, 2)
+    y = fx.synth.uniform_cloud(fx.synth.SEED_B, 3, 1024, 2)
+    _check_nn(fx, oracle, x, y)
+    _check_chamfer(fx, oracle, x, y)
+
+
+def test_reference_test_shapes(gpu_fx, oracle):
+    """test/metrics.jl:109-114: x (3,1000,2), y (3,500,2) -- N != M -- vs the dense naive formula."""
+    fx = gpu_fx
+    x, y = _rand((3, 1000, 2), 1), _rand((3, 500, 2), 2)
+    loss = _check_chamfer(fx, oracle, x, y)
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    naive = 0.0
+    for b in range(2):
+        P = ((x64[:, :, b] ** 2).sum(0)[:, None] + (y64[:, :, b] ** 2).sum(0)[None, :]
+             - 2 * x64[:, :, b].T @ y64[:, :, b])
+        naive += P.min(1).mean() / 2 + P.min(0).mean() / 2
+    assert np.isclose(loss, naive, rtol=3.45e-4)
+    # PointCloud front door, device resident, weights (src/metrics/pcloud.jl:11-12)
+    pa, pb = fx.gpu(fx.PointCloud(x)), fx.gpu(fx.PointCloud(y))
+    assert pa.on_device
+    l2 = fx.chamfer_distance(pa, pb, w1=0.25, w2=2.0)
+    assert np.isclose(l2, oracle.chamfer_distance(x, y, 0.25, 2.0), rtol=LOSS_RTOL)
+    # rank-2 inputs are lifted to B=1 (src/metrics/pcloud.jl:28-37); Float64 input is cast (:14-19)
+    l3 = fx.chamfer_distance(x[:, :, 0].astype(np.float64), y[:, :, 0].astype(np.float64))
+    assert np.isclose(l3, oracle.chamfer_distance(x[:, :, :1], y[:, :, :1]), rtol=LOSS_RTOL)
+
+
+def test_committed_golden_fixture(gpu_fx):
+    """HIP vs the committed vectors (no oracle in the loop)."""
+    fx = gpu_fx
+    g = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    loss, ix, iy = fx.chamfer_distance(g["cx"], g["cy"], return_indices=True)
+    assert np.array_equal(ix.to_host(), g["c_ix"]) and np.array_equal(iy.to_host(), g["c_iy"])
+    assert np.isclose(loss, g["c_loss"], rtol=LOSS_RTOL)
+    idx, dist = fx.knn(g["kx"], 20, drop_first=True)
+    assert np.array_equal(idx.to_host(), g["k_idx"]) and np.array_equal(dist.to_host(), g["k_dist"])
+
+
+@pytest.mark.parametrize("N,M,B", [(1, 1, 1), (1, 77, 3), (33, 4097, 1), (257, 31, 9), (513, 1025, 8),
+                                   (2048, 300, 2), (5000, 5000, 2), (4096, 8200, 1), (100, 12289, 2)])
+def test_ragged_sizes(gpu_fx, oracle, N, M, B):
+    """Tile (32), block (256*R), LDS-chunk (4096) and cloud-count (8 per XCD group) boundaries."""
+    x, y = _rand((3, N, B), N + B), _rand((3, M, B), M + 7 * B)
+    _check_nn(gpu_fx, oracle, x, y)
+    _check_chamfer(gpu_fx, oracle, x, y, 0.5, 1.5)
+
+
+def test_ties_lowest_index_wins(gpu_fx, oracle):
+    """Lattice clouds: many exactly equal distances; the first (lowest) index must win, in every
+    tile/chunk position."""
+    rng = np.random.default_rng(9)
+    x = np.asfortranarray(rng.integers(0, 5, (3, 700, 2)).astype(np.float32))
+    y = np.asfortranarray(rng.integers(0, 5, (3, 9000, 2)).astype(np.float32))
+    _check_nn(gpu_fx, oracle, x, y)
+    # all candidates identical: index 0 everywhere
+    y1 = np.asfortranarray(np.ones((3, 4500, 1), np.float32))
+    ix, _ = gpu_fx.nearest_neighbors(x[:, :, :1], y1)
+    assert np.all(ix.to_host() == 0)
+
+
+@pytest.mark.parametrize("D", [1, 2, 5, 64])
+def test_other_dimensions(gpu_fx, oracle, D):
+    """D=2 clouds are allowed (src/rep/pcloud.jl:8-9; the *3 factor is kept);
+    D=1 / D>3 take the generic kernel."""
+    x, y = _rand((D, 300, 3), D), _rand((D, 411, 3), D + 100)
+    _check_nn(gpu_fx, oracle, x, y)
+    _check_chamfer(gpu_fx, oracle, x, y)
+
+
+def test_identical_and_degenerate_clouds(gpu_fx, oracle):
+    fx = gpu_fx
+    x = _rand((3, 2000, 2), 5)
+    assert fx.chamfer_distance(x, x) == 0.0
+    ix, iy = fx.nearest_neighbors(x, x)
+    assert np.array_equal(ix.to_host(), np.tile(np.arange(2000, dtype=np.int32)[:, None], (1, 2)))
+    # the reference harness's input p_i = (i,i,i)/n, A == B (benchmarks/metrics.jl:11-15)
+    for n in (64, 1024, 16384):
+        p = fx.synth.reference_bench_cloud(n)
+        assert fx.chamfer_distance(p, p) == 0.0
+        _check_nn(fx, oracle, p[:, : min(n, 2048)], p[:, : min(n, 2048)])
+
+
+def test_c2_full_size_parity_and_properties(gpu_fx, oracle):
+    """BASELINE config 2 at full size (B=32, N=M=4096): indices bit-exact vs the oracle, loss within
+    1e-5, plus size-independent properties."""
+    fx = gpu_fx
+    x = fx.synth.uniform_cloud(fx.synth.SEED_A, 3, 4096, 32)
+    y = fx.synth.uniform_cloud(fx.synth.SEED_B, 3, 4096, 32)
+    dx_, dy_ = fx.gpu(x), fx.gpu(y)
+    loss, ix, iy = fx.chamfer_distance(dx_, dy_, return_indices=True)
+    oloss, ox, oy, osums = oracle.chamfer_distance(x, y, return_all=True)
+    ixh, iyh = ix.to_host(), iy.to_host()
+    assert np.array_equal(ixh, ox) and np.array_equal(iyh, oy)
+    assert np.isclose(loss, oloss, rtol=LOSS_RTOL, atol=0)
+    # distances returned == distance to the returned index, recomputed in unfused float32
+    _, _, dmx, _ = fx.nearest_neighbors(dx_, dy_, return_dist=True)
+    b = 17
+    d = x[:, :, b] - y[:, ixh[:, b], b]
+    ref = ((d[0] * d[0]) + (d[1] * d[1])) + (d[2] * d[2])
+    assert np.array_equal(dmx.to_host()[:, b], ref.astype(np.float32))
+    # linearity in (w1, w2)
+    la = fx.chamfer_distance(dx_, dy_, w1=1.0, w2=0.0)
+    lb = fx.chamfer_distance(dx_, dy_, w1=0.0, w2=1.0)
+    assert np.isclose(la + lb, loss, rtol=1e-6)
+    assert np.isclose(fx.chamfer_distance(dx_, dy_, w1=0.3, w2=1.7), 0.3 * la + 1.7 * lb, rtol=1e-6)
+    # symmetry: swapping the clouds swaps the two directional terms
+    assert np.isclose(fx.chamfer_distance(dy_, dx_, w1=1.0, w2=0.0), lb, rtol=1e-6)
+    # permuting the points of y permutes the indices and leaves the loss unchanged
+    perm = np.random.default_rng(0).permutation(4096)
+    yp = np.asfortranarray(y[:, perm, :])
+    lp, ixp, _ = fx.chamfer_distance(dx_, yp, return_indices=True)
+    assert np.isclose(lp, loss, rtol=1e-6)
+    assert np.array_equal(perm[ixp.to_host()[:, 3]], ixh[:, 3])  # unique minima on random data
+    # batch shards reproduce the full result (what the multi-GPU split relies on)
+    from flux3d_jl_amd.distributed import chamfer_sums
+    s_full = chamfer_sums(dx_, dy_)
+    s_parts = sum(chamfer_sums(dx_.slab(s, 8), dy_.slab(s, 8)) for s in range(0, 32, 8))
+    assert np.allclose(s_full, s_parts, rtol=1e-12) and np.allclose(s_full, osums, rtol=1e-6)
+
+
+def test_chamfer_backward(gpu_fx, oracle):
+    """Adjoint (test/metrics.jl:112-114 tolerance: atol 1e-2, rtol 1e-3 -- we hold 1e-5)."""
+    fx = gpu_fx
+    x, y = _rand((3, 1000, 2), 21), _rand((3, 500, 2), 22)
+    loss, ix, iy = fx.chamfer_distance(x, y, w1=0.7, w2=1.3, return_indices=True)
+    gx, gy = fx.chamfer_distance_grad(x, y, ix, iy, w1=0.7, w2=1.3, gout=2.0)
+    ogx, ogy = oracle.chamfer_bwd(x, y, ix.to_host(), iy.to_host(), 0.7, 1.3, 2.0)
+    assert np.allclose(gx.to_host(), ogx, rtol=1e-5, atol=1e-9)
+    assert np.allclose(gy.to_host(), ogy, rtol=1e-5, atol=1e-9)
+
+
+def test_invalid_arguments_raise(gpu_fx):
+    fx = gpu_fx
+    x = _rand((3, 10, 2), 0)
+    with pytest.raises(ValueError):
+        fx.chamfer_distance(x, _rand((3, 10, 3), 0))  # batch mismatch (src/metrics/pcloud.jl:57-58)
+    with pytest.raises(ValueError):
+        fx.chamfer_distance(x, _rand((2, 10, 2), 0))
+    fx.knn(x, 10)  # k == M is fine without drop_first
+    with pytest.raises(fx.Flux3DHipError):
+        fx.knn(x, 10, drop_first=True)  # k+1 > M
+    with pytest.raises(fx.Flux3DHipError):
+        fx.knn(_rand((3, 100, 1), 0), 64, drop_first=True)  # k+1 > 64 unsupported
+    from flux3d_jl_amd import _lib
+    import ctypes
+    d = fx.gpu(x)
+    rc = _lib.load().fx3d_chamfer_fwd(d.ptr, 10, d.ptr, 10, 2, 3, 1.0, 1.0, d.ptr, None, None, None, None, 0, None)
+    assert rc == -6 and "workspace" in _lib.last_error()
+
+
+def test_non_default_stream_and_async(gpu_fx, oracle):
+    fx = gpu_fx
+    x, y = _rand((3, 3000, 4), 31), _rand((3, 2500, 4), 32)
+    s = fx.Stream.create()
+    with fx.stream(s):
+        dx_, dy_ = fx.gpu(x), fx.gpu(y)
+        out = fx.chamfer_distance(dx_, dy_, sync=False)  # device scalar, no host sync
+        e0, e1 = fx.Event(), fx.Event()
+        e0.record()
+        for _ in range(3):
+            fx.chamfer_distance(dx_, dy_, loss_out=out, sync=False)
+        e1.record()
+        s.synchronize()
+        assert e0.elapsed_ms(e1) > 0
+        assert np.isclose(out.item(), oracle.chamfer_distance(x, y), rtol=LOSS_RTOL)
+
+
+def test_torch_interop_zero_copy(gpu_fx):
+    """A torch CUDA tensor's memory is consumed in place (DeviceArray.wrap).  Runs in a fresh
+    process that imports torch FIRST, so that one HIP runtime (torch's) serves both -- the same
+    order bench.py uses for its multi-GPU path."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+assert torch.cuda.is_available()
+import flux3d_jl_amd as fx
+from oracle import oracle
+rng = np.random.default_rng(41)
+x = np.asfortranarray(rng.random((3, 600, 2), dtype=np.float32))
+y = np.asfortranarray(rng.random((3, 700, 2), dtype=np.float32))
+# torch row-major (B,N,3) has the same bytes as Julia's column-major (3,N,B)
+tx = torch.from_numpy(np.ascontiguousarray(x.transpose(2, 1, 0))).cuda()
+ty = torch.from_numpy(np.ascontiguousarray(y.transpose(2, 1, 0))).cuda()
+torch.cuda.synchronize()
+loss = fx.chamfer_distance(fx.DeviceArray.wrap(tx), fx.DeviceArray.wrap(ty))
+assert np.isclose(loss, oracle.chamfer_distance(x, y), rtol=1e-5), loss
+from flux3d_jl_amd.distributed import ShardedChamfer
+sc = ShardedChamfer()
+l2 = sc(fx.DeviceArray.wrap(tx), fx.DeviceArray.wrap(ty), 2)
+assert np.isclose(l2, loss, rtol=1e-6), (l2, loss)
+print("TORCH_INTEROP_OK")
+""" % (os.path.dirname(GOLDEN).rsplit(os.sep, 1)[0],)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "TORCH_INTEROP_OK" in r.stdout, r.stdout + r.stderr
+
+
+# ------------------------------------------------------------------------------------------ kNN
+@pytest.mark.parametrize("N,B,k,drop", [(1024, 4, 20, True), (200, 2, 1, False), (64, 2, 10, True),
+                                        (300, 1, 63, True), (2500, 2, 5, False), (70, 3, 7, False)])
+def test_knn_d3(gpu_fx, oracle, N, B, k, drop):
+    """BASELINE config 4 shape (k=20 self-graph, drop first) and the K=10 of the example
+    (examples/dgcnn_classification.jl:28); chunk boundary (N > 2048); kk = 64."""
+    x = _rand((3, N, B), N + k)
+    idx, dist = gpu_fx.knn(x, k, drop_first=drop)
+    oi, od = oracle.knn(x, k, drop_first=drop)
+    assert np.array_equal(idx.to_host(), oi)
+    assert np.array_equal(dist.to_host(), od)
+
+
+def test_knn_ties_and_cross_set(gpu_fx, oracle):
+    rng = np.random.default_rng(2)
+    x = np.asfortranarray(rng.integers(0, 4, (3, 500, 2)).astype(np.float32))
+    y = np.asfortranarray(rng.integers(0, 4, (3, 333, 2)).astype(np.float32))
+    idx, dist = gpu_fx.knn(x, 16, y=y)
+    oi, od = oracle.knn(x, 16, y=y)
+    assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+
+
+@pytest.mark.parametrize("D", [2, 16, 64])
+def test_knn_feature_space(gpu_fx, oracle, D):
+    """Second EdgeConv: kNN in 64-D feature space (src/models/dgcnn.jl:121)."""
+    x = np.asfortranarray(np.random.default_rng(D).standard_normal((D, 512, 2)).astype(np.float32))
+    idx, dist = gpu_fx.knn(x, 20, drop_first=True)
+    oi, od = oracle.knn(x, 20, drop_first=True)
+    assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+
+
+def test_knn_graph_gather(gpu_fx, oracle):
+    """create_knn_graph == cat([X[:, knn idx]]...) (src/models/dgcnn.jl:3-7,36): (F,K,N,B)."""
+    for F in (3, 64):
+        x = np.asfortranarray(np.random.default_rng(F).standard_normal((F, 256, 3)).astype(np.float32))
+        g = gpu_fx.create_knn_graph(x, 10)
+        assert g.shape == (F, 10, 256, 3)
+        oi = oracle.knn(x, 10, drop_first=True, want_dist=False)
+        assert np.array_equal(g.to_host(), oracle.knn_gather(x, oi))
+
+
+# --------------------------------------------------------------------------------------- meshes
+def _teapot_sphere(fx):
+    return fx.load_trimesh(os.path.join(GOLDEN, "teapot.obj"), os.path.join(GOLDEN, "sphere.obj"))
+
+
+def test_face_areas(gpu_fx, oracle, known):
+    """Known answers (test/rep.jl:259-260) and bit parity with the oracle on teapot+sphere."""
+    fx = gpu_fx
+    k = known["areas_batch"]
+    vl = [np.asfortranarray(np.array(v, np.float32).T) for v in k["verts"]]
+    fl = [np.asfortranarray(np.array(f, np.int64).T) for f in k["faces"]]
+    m = fx.TriMesh(vl, fl)
+    a = fx.compute_faces_areas_packed(m).to_host()
+    assert np.allclose(a, np.concatenate(k["areas"]), rtol=1e-4, atol=1e-4)
+    ap = fx.compute_faces_areas_padded(m).to_host()
+    assert ap.shape == (1, 4, 2) and np.all(ap[0, 2:, 1] == 0)
+    al = fx.compute_faces_areas_list(m)
+    assert [x.shape for x in al] == [(1, 4), (1, 2)]
+    for mm in (_teapot_sphere(fx), fx.gpu(_teapot_sphere(fx))):
+        got = fx.compute_faces_areas_packed(mm).to_host()
+        exp = oracle.faces_areas_packed(mm.get_verts_packed_host(), mm.get_faces_packed().astype(np.int64) - 1)
+        assert np.array_equal(got, exp)
+        gp = fx.compute_faces_areas_padded(mm).to_host()
+        ep = oracle.faces_areas_padded(mm.get_verts_padded_host(), mm.get_faces_padded().astype(np.int64) - 1,
+                                       mm._faces_len)
+        assert np.array_equal(gp, ep)
+
+
+def test_mesh_losses(gpu_fx, oracle, known):
+    fx = gpu_fx
+    t = fx.load_trimesh(os.path.join(GOLDEN, "teapot.obj"))
+    # README.md:111-112 known answer, on a device-resident mesh like the README example
+    assert abs(float(fx.laplacian_loss(fx.gpu(t))) - known["teapot_laplacian_loss"]["value"]) < 1e-7
+    for m in (t, _teapot_sphere(fx), fx.gpu(_teapot_sphere(fx))):
+        v = m.get_verts_packed_host()
+        e0 = m.get_edges_packed().astype(np.int64) - 1
+        rowptr, colind, vals = m.get_laplacian_packed()
+        ol = oracle.laplacian_loss(v, rowptr.astype(np.int64), colind.astype(np.int64), vals)
+        assert np.isclose(fx.laplacian_loss(m), ol, rtol=LOSS_RTOL, atol=0)
+        for target in (0.0, 0.05):
+            assert np.isclose(fx.edge_loss(m, target), oracle.edge_loss(v, e0, target), rtol=LOSS_RTOL, atol=0)
+        gl = fx.laplacian_loss_grad(m, 1.5).to_host()
+        assert np.allclose(gl, oracle.laplacian_loss_bwd(v, rowptr.astype(np.int64), colind.astype(np.int64), vals, 1.5),
+                           rtol=1e-4, atol=1e-9)
+        ge = fx.edge_loss_grad(m, 0.05, 0.5).to_host()
+        assert np.allclose(ge, oracle.edge_loss_bwd(v, e0, 0.05, 0.5), rtol=1e-4, atol=1e-9)
+
+
+def test_three_mesh_batch_losses(gpu_fx, oracle, known):
+    """test/metrics.jl:8-73: laplacian_loss on the hand-written ragged batch == dense construction."""
+    fx = gpu_fx
+    k = known["three_mesh_batch"]
+    vl = [np.asfortranarray(np.array(v, np.float32).T) for v in k["verts"]]
+    fl = [np.asfortranarray(np.array(f, np.uint32).T) for f in k["faces"]]
+    m = fx.TriMesh(vl, fl)
+    Ld = m.laplacian_dense().astype(np.float64)
+    vp = m.get_verts_packed_host().astype(np.float64)
+    ref = np.sqrt(((Ld @ vp.T) ** 2).sum(1)).mean()
+    assert np.isclose(fx.laplacian_loss(m), ref, rtol=3.45e-4)
+    e0 = m.get_edges_packed().astype(np.int64) - 1
+    d = vp[:, e0[:, 0]] - vp[:, e0[:, 1]]
+    assert np.isclose(fx.edge_loss(m), (d ** 2).sum(0).mean(), rtol=1e-6)
+
+
+def test_degenerate_benchmark_mesh(gpu_fx):
+    """generate_trimesh (benchmarks/metrics.jl:17-22): faces (i,i,i) -> both losses are 0."""
+    n = 1024
+    v = np.asfortranarray((np.cumsum(np.ones((3, n)), axis=1) / n).astype(np.float32))
+    f = np.asfortranarray(np.tile(np.arange(1, n + 1), (3, 1)).astype(np.int32))
+    m = gpu_fx.TriMesh([v], [f])
+    assert gpu_fx.laplacian_loss(m) == 0.0 and gpu_fx.edge_loss(m) == 0.0
+
+
+# -------------------------------------------------------------------------------------- sampler
+def test_sample_points_explicit_draws(gpu_fx, oracle):
+    """_sample_points for given (face, r1, r2): bit-exact (src/transforms/mesh_func.jl:60-82)."""
+    fx = gpu_fx
+    m = _teapot_sphere(fx)
+    rng = np.random.default_rng(8)
+    n = 3000
+    fi = np.asfortranarray(np.stack([rng.integers(0, 2256, n), rng.integers(0, 5120, n)], axis=1).astype(np.int32))
+    r1 = np.asfortranarray(rng.random((n, 2), dtype=np.float32))
+    r2 = np.asfortranarray(rng.random((n, 2), dtype=np.float32))
+    r1[0, 0], r2[0, 0], r1[1, 0] = 0.0, 0.0, np.float32(1.0 - 2 ** -24)
+    got = fx.sample_points(m, n, face_idx=fi, r1=r1, r2=r2).to_host()
+    exp = oracle.sample_points_explicit(m.get_verts_padded_host(), m.get_faces_padded().astype(np.int64) - 1, fi, r1, r2)
+    assert got.shape == (3, n, 2) and np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("on_device", [False, True])
+def test_sample_points_seeded_parity(gpu_fx, oracle, on_device):
+    """Device Philox/CDF draw == oracle restatement, bit for bit, on a ragged batch; the sphere
+    samples satisfy the reference's radius test (test/transforms/mesh_func.jl:10-12)."""
+    fx = gpu_fx
+    m = _teapot_sphere(fx)
+    if on_device:
+        m = fx.gpu(m)
+    out, fi, r1, r2 = fx.sample_points(m, 5000, seed=4242, return_draws=True)
+    eo, efi, er1, er2 = oracle.sample_points_seeded(
+        m.get_verts_padded_host(), m.get_faces_padded().astype(np.int64) - 1, m._faces_len, 5000, 4242,
+        return_draws=True)
+    assert np.array_equal(fi.to_host(), efi)
+    assert np.array_equal(r1.to_host(), er1) and np.array_equal(r2.to_host(), er2)
+    s = out.to_host()
+    assert np.array_equal(s, eo)
+    r = np.sqrt((s[:, :, 1].astype(np.float64) ** 2).sum(0))
+    assert np.allclose(r, 1.0, rtol=1e-2, atol=1e-5)
+    assert fi.to_host()[:, 0].max() < 2256  # shorter mesh never samples its padding
+    # fresh seed per call, like the reference's global RNG
+    a, b = fx.sample_points(m, 100).to_host(), fx.sample_points(m, 100).to_host()
+    assert not np.array_equal(a, b)
+
+
+def test_sample_points_statistics(gpu_fx, oracle):
+    fx = gpu_fx
+    t = fx.load_trimesh(os.path.join(GOLDEN, "teapot.obj"))
+    n = 200000
+    _, fi, _, _ = fx.sample_points(t, n, seed=7, return_draws=True)
+    area = fx.compute_faces_areas_packed(t).to_host().astype(np.float64)
+    p = area / area.sum()
+    cnt = np.bincount(fi.to_host()[:, 0], minlength=2256)
+    keep = p * n >= 5
+    chi2 = (((cnt - p * n) ** 2)[keep] / (p * n)[keep]).sum()
+    dof = keep.sum() - 1
+    assert abs(chi2 - dof) < 6 * np.sqrt(2 * dof)
+
+
+def test_sample_points_backward(gpu_fx):
+    fx = gpu_fx
+    m = _teapot_sphere(fx)
+    out, fi, r1, r2 = fx.sample_points(m, 2000, seed=5, return_draws=True)
+    gout = _rand((3, 2000, 2), 77)
+    g = fx.sample_points_grad(m, fi, r1, r2, gout).to_host()
+    # reference: scatter in float64 on the host from the same draws
+    fih, r1h, r2h = fi.to_host(), r1.to_host(), r2.to_host()
+    fp = m.get_faces_padded().astype(np.int64) - 1
+    exp = np.zeros((3, m.V, 2))
+    for b in range(2):
+        u = np.sqrt(r1h[:, b].astype(np.float32)).astype(np.float64)
+        v = r2h[:, b].astype(np.float64)
+        w = [1 - u, u * (1 - v), u * v]
+        for t in range(3):
+            np.add.at(exp[:, :, b].T, fp[t, fih[:, b], b], (w[t][None, :] * gout[:, :, b]).T)
+    assert np.allclose(g, exp, rtol=1e-4, atol=1e-6)
+
+
+def test_trimesh_chamfer(gpu_fx):
+    """test/metrics.jl:86-90: chamfer_distance(m, m) ~ 0 (two independent samplings), atol 1e-2;
+    config 3 shape: B=8 teapot-class meshes, 5000 samples."""
+    fx = gpu_fx
+    m = _teapot_sphere(fx)
+    assert abs(float(fx.chamfer_distance(m, m))) < 1e-2
+    t = os.path.join(GOLDEN, "teapot.obj")
+    m8 = fx.gpu(fx.load_trimesh(*[t] * 8))
+    l8 = float(fx.chamfer_distance(m8, m8, 5000, seed=11))
+    assert 0 < l8 < 1e-2
+    assert l8 == float(fx.chamfer_distance(m8, m8, 5000, seed=11))  # deterministic given the seed

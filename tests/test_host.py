@@ -1,0 +1,179 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every declared symbol,
+the TriMesh/PointCloud mirror reproduces the reference's layout tables, the host topology builders
+agree with the oracle, and compute calls fail loudly without a GPU (no fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def _mesh_lists(k, R=np.int64):
+    vl = [np.asfortranarray(np.array(v, np.float32).T) for v in k["verts"]]
+    fl = [np.asfortranarray(np.array(f, R).T) for f in k["faces"]]
+    return vl, fl
+
+
+def test_abi_exports_every_declared_symbol(fx):
+    hdr = open(os.path.join(ROOT, "include", "flux3d_hip.h")).read()
+    declared = set(re.findall(r"FX3D_API\s+[\w\s\*]+?\b(fx3d_\w+)\s*\(", hdr))
+    assert len(declared) >= 40
+    lib = ctypes.CDLL(fx.LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    from flux3d_jl_amd import _lib
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+
+
+def test_version_and_last_error(fx):
+    assert "gfx950" in fx.__version__
+    from flux3d_jl_amd import _lib
+    rc = _lib.load().fx3d_chamfer_workspace_bytes(0, 1, 1, 3, ctypes.byref(ctypes.c_size_t()))
+    assert rc == -1 and "empty" in _lib.last_error()
+
+
+def test_no_cpu_fallback(fx):
+    """Without a device every compute entry point raises (status != 0); nothing is computed on
+    the host.  (On the GPU box this test is skipped: a device is present.)"""
+    if fx.functional():
+        pytest.skip("GPU present")
+    x = np.zeros((3, 8, 1), np.float32, order="F")
+    with pytest.raises(fx.Flux3DHipError):
+        fx.chamfer_distance(x, x)
+    with pytest.raises(fx.Flux3DHipError):
+        fx.knn(x, 2)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "flux3d.jl_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".cpp", ".h", ".jl")):
+                txt = open(os.path.join(dp, fn)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, fn
+                assert "flux3d_oracle" not in txt or "oracle/flux3d_oracle.c" in txt, fn
+
+
+def test_pointcloud_shapes(fx):
+    """src/rep/pcloud.jl:30-55: rank-2 input is lifted to (D,N,1); Float64 is cast."""
+    p = fx.PointCloud(np.random.rand(3, 16))
+    assert p.points.shape == (3, 16, 1) and p.points.dtype == np.float32 and p.points.flags.f_contiguous
+    assert fx.npoints(p) == 16
+    p2 = fx.PointCloud(np.random.rand(3, 16, 4), np.random.rand(3, 16, 4))
+    assert p2.normals.shape == (3, 16, 4)
+    with pytest.raises(ValueError):
+        fx.PointCloud(np.random.rand(3, 16, 1), np.random.rand(3, 15, 1))
+    assert p2[1].shape == (3, 16)
+
+
+@pytest.mark.parametrize("R", [np.int64, np.uint32])
+def test_trimesh_layouts(fx, known, R):
+    """test/rep.jl:112-133: list/packed/padded verts, packed face offsets, pad value 0."""
+    vl, fl = _mesh_lists(known["three_mesh_batch"], R)
+    m = fx.TriMesh(vl, fl)
+    assert (m.N, m.V, m.F, m.equalised) == (3, 5, 7, False)
+    assert all(np.array_equal(a, b) for a, b in zip(vl, fx.get_verts_list(m)))
+    assert np.array_equal(np.concatenate(vl, axis=1), fx.get_verts_packed(m))
+    pad = fx.get_verts_padded(m)
+    for i, v in enumerate(vl):
+        assert np.array_equal(pad[:, : v.shape[1], i], v) and np.all(pad[:, v.shape[1]:, i] == 0)
+    packed = fx.get_faces_packed(m)
+    assert packed.dtype == R
+    cur = off = 0
+    for i, f in enumerate(fl):
+        assert np.array_equal(packed[:, cur:cur + f.shape[1]], f + off)
+        cur += f.shape[1]
+        off += vl[i].shape[1]
+    fp = fx.get_faces_padded(m)
+    for i, f in enumerate(fl):
+        assert np.array_equal(fp[:, : f.shape[1], i], f) and np.all(fp[:, f.shape[1]:, i] == 0)
+    with pytest.raises(ValueError):
+        fx.TriMesh(vl, fl[:2])
+    with pytest.raises(ValueError):
+        fx.TriMesh([vl[0]], [np.array([[1], [2], [9]], R)])
+
+
+def test_converter_tables(fx, known):
+    """test/rep.jl:392-489."""
+    from flux3d_jl_amd import rep
+    k = known["converters"]
+    for T in (np.float64, np.float32, np.int64, np.uint32):
+        lst = [np.asfortranarray(np.array(a, T).T) for a in k["list"]]
+        packed = np.concatenate(lst, axis=1)
+        padded = np.zeros((3, 4, 3), T)
+        for i, a in enumerate(lst):
+            padded[:, : a.shape[1], i] = a
+        items_len, first, to_list = rep._auxiliary_mesh(lst)
+        assert list(items_len) == k["items_len"] and list(first) == k["packed_first_idx"]
+        assert np.all(to_list[:4] == 1) and np.all(to_list[4:6] == 2) and np.all(to_list[6:] == 3)
+        assert np.array_equal(rep._list_to_padded(lst, 0), padded)
+        assert np.array_equal(rep._list_to_packed(lst), packed)
+        assert np.array_equal(rep._packed_to_padded(packed, items_len, 0), padded)
+        assert all(np.array_equal(a, b) for a, b in zip(rep._packed_to_list(packed, items_len), lst))
+        assert all(np.array_equal(a, b) for a, b in zip(rep._padded_to_list(padded, items_len), lst))
+        assert np.array_equal(rep._padded_to_packed(padded, items_len), packed)
+        assert rep._list_to_padded(lst, 0).dtype == T
+
+
+def test_topology_builders_match_oracle(fx, oracle, known):
+    """fx3d_build_edges_packed / fx3d_build_laplacian_csr (host C++) vs the oracle and the
+    reference's identities (test/rep.jl:135-175)."""
+    vl, fl = _mesh_lists(known["three_mesh_batch"])
+    m = fx.TriMesh(vl, fl)
+    edges = fx.get_edges_packed(m)  # 1-based (E,2)
+    fp0 = fx.get_faces_packed(m).astype(np.int64) - 1
+    oe, of2e = oracle.edges_packed(fp0, 12, want_f2e=True)
+    assert np.array_equal(edges.astype(np.int64) - 1, oe)
+    assert np.array_equal(fx.get_faces_to_edges_packed(m).astype(np.int64) - 1, of2e)
+    d = fx.get_edges_to_key(m)
+    for i, (a, b) in enumerate(edges):
+        assert d[(int(a), int(b))] == i + 1
+    rowptr, colind, vals = fx.get_laplacian_packed(m)
+    orp, oci, ov = oracle.laplacian_csr(oe, 12)
+    assert np.array_equal(rowptr, orp) and np.array_equal(colind, oci) and np.array_equal(vals, ov)
+    # teapot + sphere batch
+    mm = fx.load_trimesh(os.path.join(GOLDEN, "teapot.obj"), os.path.join(GOLDEN, "sphere.obj"))
+    e2 = fx.get_edges_packed(mm).astype(np.int64) - 1
+    oe2 = oracle.edges_packed(fx.get_faces_packed(mm).astype(np.int64) - 1, 1202 + 2562)
+    assert np.array_equal(e2, oe2)
+    r2 = fx.get_laplacian_packed(mm)
+    o2 = oracle.laplacian_csr(oe2, 1202 + 2562)
+    assert all(np.array_equal(a, b) for a, b in zip(r2, o2))
+
+
+def test_degenerate_faces_laplacian(fx, oracle):
+    """benchmarks/metrics.jl:17-22 generate_trimesh: faces (i,i,i) -> self edges; sparse() sums the
+    duplicate entries so L == 0 and laplacian_loss == 0."""
+    n = 16
+    v = np.asfortranarray((np.cumsum(np.ones((3, n)), axis=1) / n).astype(np.float32))
+    f = np.asfortranarray(np.tile(np.arange(1, n + 1), (3, 1)).astype(np.int64))
+    m = fx.TriMesh([v], [f])
+    rowptr, colind, vals = fx.get_laplacian_packed(m)
+    assert len(colind) == n and np.all(vals == 0.0)
+    oe = oracle.edges_packed(f - 1, n)
+    orp, oci, ov = oracle.laplacian_csr(oe, n)
+    assert np.array_equal(rowptr, orp) and np.array_equal(vals, ov)
+    assert float(oracle.laplacian_loss(v, orp, oci, ov)) == 0.0
+
+
+def test_synth_generator_is_stable(fx):
+    """The documented SplitMix64 stream: fixed first values, shard == slice of the global batch."""
+    u = fx.synth.splitmix_uniform(fx.synth.SEED_A, 4)
+    assert u.dtype == np.float32 and np.all((u >= 0) & (u < 1))
+    # independent scalar restatement of the recurrence
+    def sm(seed, k):
+        M = (1 << 64) - 1
+        z = (seed + (k + 1) * 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z ^= z >> 31
+        return np.float32((z >> 40) * 2.0 ** -24)
+    assert [sm(fx.synth.SEED_A, k) for k in range(4)] == list(u)
+    full = fx.synth.uniform_cloud(fx.synth.SEED_A, 3, 8, 4)
+    part = fx.synth.uniform_cloud(fx.synth.SEED_A, 3, 8, 2, batch_offset=2)
+    assert np.array_equal(full[:, :, 2:], part)
+    p = fx.synth.reference_bench_cloud(8)
+    assert np.allclose(p[:, 3], 0.5)
