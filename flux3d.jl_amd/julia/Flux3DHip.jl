@@ -1,0 +1,205 @@
+# Flux3DHip.jl -- thin @ccall shim that puts libflux3d_hip.so behind Flux3D.jl's own API.
+#
+# NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no `julia`.  It is kept declarative --
+# one @ccall per C-ABI entry point (include/flux3d_hip.h), no logic beyond shape bookkeeping -- so
+# that it can be checked by inspection against the header; the same call sequence is exercised by
+# the Python twin of this layer (flux3d.jl_amd/*.py), which the test-suite runs on the GPU.
+#
+# Usage inside Flux3D (INTEGRATION.md):
+#     include("Flux3DHip.jl"); using .Flux3DHip
+#     A = hip(PointCloud(rand(Float32, 3, 4096, 32)));  B = hip(...)
+#     chamfer_distance(A, B)                 # dispatches to the HipArray methods below
+#
+# No CUDA.jl, no AMDGPU.jl, no Triton: device memory is owned by the library (fx3d_malloc) and
+# wrapped in a HipArray with a finalizer.
+module Flux3DHip
+
+using Flux3D
+import Flux3D: chamfer_distance, _chamfer_distance, _nearest_neighbors, sample_points,
+               laplacian_loss, edge_loss, TriMesh, PointCloud,
+               get_verts_packed, get_verts_padded, get_faces_packed, get_faces_padded,
+               get_edges_packed, get_laplacian_packed
+using SparseArrays: SparseMatrixCSC, findnz
+import Zygote
+
+export HipArray, hip, unhip, use_hip, knn_graph
+
+const LIB = get(ENV, "FLUX3D_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libflux3d_hip.so"))
+const Stream = Ptr{Cvoid}
+const DEFAULT_STREAM = Stream(C_NULL)
+
+# ---- status handling (include/flux3d_hip.h: every call returns fx3d_status) -------------------
+function last_error()
+    buf = Vector{UInt8}(undef, 512)
+    @ccall LIB.fx3d_last_error(buf::Ptr{UInt8}, 512::Csize_t)::Csize_t
+    return unsafe_string(pointer(buf))
+end
+@inline check(rc::Int32) = rc == 0 ? nothing : error("flux3d_hip [$rc]: " * last_error())
+
+function device_count()
+    n = Ref{Int32}(0)
+    rc = @ccall LIB.fx3d_device_count(n::Ref{Int32})::Int32
+    return rc == 0 ? Int(n[]) : 0
+end
+# analogue of Flux3D.use_cuda (src/Flux3D.jl:52-61)
+const use_hip = Ref(false)
+__init__() = (use_hip[] = isfile(LIB) && device_count() > 0)
+
+# ---- device array: the `S` storage type of TriMesh{T,R,S} / PointCloud.points -----------------
+mutable struct HipArray{T,N} <: AbstractArray{T,N}
+    ptr::Ptr{Cvoid}
+    dims::NTuple{N,Int}
+    owner::Any            # parent HipArray for views (keeps the allocation alive)
+end
+Base.size(a::HipArray) = a.dims
+Base.sizeof(a::HipArray{T}) where {T} = prod(a.dims) * sizeof(T)
+Base.getindex(a::HipArray, i...) = error("scalar indexing of a HipArray is not supported; use unhip(a)")
+
+function HipArray{T}(::UndefInitializer, dims::Int...) where {T}
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(@ccall LIB.fx3d_malloc(p::Ref{Ptr{Cvoid}}, max(prod(dims) * sizeof(T), 1)::Csize_t)::Int32)
+    a = HipArray{T,length(dims)}(p[], dims, nothing)
+    finalizer(x -> (@ccall LIB.fx3d_free(x.ptr::Ptr{Cvoid})::Int32), a)
+    return a
+end
+function hip(x::Array{T,N}) where {T,N}
+    a = HipArray{T}(undef, size(x)...)
+    check(@ccall LIB.fx3d_memcpy_h2d(a.ptr::Ptr{Cvoid}, x::Ptr{T}, sizeof(x)::Csize_t, DEFAULT_STREAM::Stream)::Int32)
+    return a
+end
+function unhip(a::HipArray{T,N}) where {T,N}
+    x = Array{T,N}(undef, a.dims)
+    check(@ccall LIB.fx3d_memcpy_d2h(x::Ptr{T}, a.ptr::Ptr{Cvoid}, sizeof(x)::Csize_t, DEFAULT_STREAM::Stream)::Int32)
+    return x
+end
+Base.Array(a::HipArray) = unhip(a)
+Base.reshape(a::HipArray{T}, dims::Int...) where {T} = HipArray{T,length(dims)}(a.ptr, dims, a)
+hip(p::PointCloud) = PointCloud(hip(p.points), p.normals === nothing ? nothing : hip(p.normals))
+# functor(::TriMesh) moves only the verts (src/rep/mesh.jl:189-190)
+hip(m::TriMesh) = TriMesh([hip(v) for v in Flux3D.get_verts_list(m)], Flux3D.get_faces_list(m); offset = m.offset)
+
+# scratch: caller-provided by ABI contract; one grow-only buffer per task is enough here
+const _ws = Ref{Union{Nothing,HipArray{UInt8,1}}}(nothing)
+function workspace(nbytes::Integer)
+    if _ws[] === nothing || length(_ws[]) < nbytes
+        _ws[] = HipArray{UInt8}(undef, max(Int(nbytes), 4096))
+    end
+    return _ws[]
+end
+
+# ---- nearest neighbours / chamfer: replaces src/metrics/pcloud.jl:72-86 (CuArray method) -------
+function _nearest_neighbors(x::HipArray{Float32,3}, y::HipArray{Float32,3})
+    D, N, B = size(x); _, M, _ = size(y)
+    ix = HipArray{Int32}(undef, N, B); iy = HipArray{Int32}(undef, M, B)
+    check(@ccall LIB.fx3d_nn1(x.ptr::Ptr{Cvoid}, N::Int32, y.ptr::Ptr{Cvoid}, M::Int32, B::Int32, D::Int32,
+                              ix.ptr::Ptr{Cvoid}, iy.ptr::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
+                              DEFAULT_STREAM::Stream)::Int32)
+    # the reference returns Matrix{CartesianIndex{2}} (point, batch), 1-based (:83-84)
+    hx, hy = unhip(ix), unhip(iy)
+    nn_for_x = [CartesianIndex(Int(hx[i, b]) + 1, b) for i in 1:N, b in 1:B]
+    nn_for_y = [CartesianIndex(Int(hy[j, b]) + 1, b) for j in 1:M, b in 1:B]
+    return nn_for_x, nn_for_y
+end
+
+# fused forward (never materialises indices on the host): replaces :39-52 for HipArray storage
+function _chamfer_fwd(A::HipArray{Float32,3}, B::HipArray{Float32,3}, w1::Float32, w2::Float32; indices::Bool = false)
+    D, N, Bn = size(A); _, M, _ = size(B)
+    nb = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_chamfer_workspace_bytes(N::Int32, M::Int32, Bn::Int32, D::Int32, nb::Ref{Csize_t})::Int32)
+    ws = workspace(nb[])
+    loss_dev = HipArray{Float32}(undef, 1); loss = Ref{Float32}(0)
+    ix = indices ? HipArray{Int32}(undef, N, Bn) : nothing
+    iy = indices ? HipArray{Int32}(undef, M, Bn) : nothing
+    check(@ccall LIB.fx3d_chamfer_fwd(A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32, Bn::Int32, D::Int32,
+                                      w1::Float32, w2::Float32, loss_dev.ptr::Ptr{Cvoid}, loss::Ref{Float32},
+                                      (indices ? ix.ptr : C_NULL)::Ptr{Cvoid}, (indices ? iy.ptr : C_NULL)::Ptr{Cvoid},
+                                      ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t, DEFAULT_STREAM::Stream)::Int32)
+    return loss[], ix, iy
+end
+_chamfer_distance(A::HipArray{Float32,3}, B::HipArray{Float32,3}, w1::Float32 = 1.0f0, w2::Float32 = 1.0f0) =
+    _chamfer_fwd(A, B, w1, w2)[1]
+
+# adjoint: indices are constants (`@ignore`, :45); the scatter-add runs on the device
+Zygote.@adjoint function _chamfer_distance(A::HipArray{Float32,3}, B::HipArray{Float32,3}, w1::Float32, w2::Float32)
+    loss, ix, iy = _chamfer_fwd(A, B, w1, w2; indices = true)
+    function back(g)
+        D, N, Bn = size(A); _, M, _ = size(B)
+        gA = HipArray{Float32}(undef, D, N, Bn); gB = HipArray{Float32}(undef, D, M, Bn)
+        check(@ccall LIB.fx3d_chamfer_bwd(A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32, Bn::Int32, D::Int32,
+                                          ix.ptr::Ptr{Cvoid}, iy.ptr::Ptr{Cvoid}, w1::Float32, w2::Float32,
+                                          Float32(g)::Float32, Bn::Int64, gA.ptr::Ptr{Cvoid}, gB.ptr::Ptr{Cvoid},
+                                          DEFAULT_STREAM::Stream)::Int32)
+        return (gA, gB, nothing, nothing)
+    end
+    return loss, back
+end
+
+# ---- k-NN graph: replaces CreateSingleKNNGraph + the per-batch loop (src/models/dgcnn.jl:3-7,36) --
+function knn_graph(X::HipArray{Float32,3}, K::Int)
+    F, N, B = size(X)
+    idx = HipArray{Int32}(undef, K, N, B)
+    check(@ccall LIB.fx3d_knn(X.ptr::Ptr{Cvoid}, N::Int32, X.ptr::Ptr{Cvoid}, N::Int32, B::Int32, F::Int32,
+                              K::Int32, 1::Int32, idx.ptr::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    out = HipArray{Float32}(undef, F, K, N, B)
+    check(@ccall LIB.fx3d_knn_gather(X.ptr::Ptr{Cvoid}, N::Int32, B::Int32, F::Int32, K::Int32, idx.ptr::Ptr{Cvoid},
+                                     out.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    return out      # (F,K,N,B), what `cat([CreateSingleKNNGraph(X[:,:,i],K) ...]..., dims=4)` builds at :36
+end
+
+# ---- TriMesh device mirrors: int32 0-based copies of the host integer data (cached per mesh) ---
+const _mirror = WeakKeyDict{Any,Dict{Symbol,Any}}()
+mirror(m::TriMesh) = get!(() -> Dict{Symbol,Any}(), _mirror, m)
+dev_i32(a) = hip(Int32.(a .- 1))
+faces_padded_dev(m) = get!(() -> hip(Int32.(max.(Int64.(get_faces_padded(m)) .- 1, 0))), mirror(m), :faces_padded)
+faces_len_dev(m) = get!(() -> hip(Int32.(m._faces_len)), mirror(m), :faces_len)
+edges_dev(m) = get!(() -> dev_i32(get_edges_packed(m)), mirror(m), :edges)          # (E,2) column-major
+function laplacian_csr_dev(m)
+    get!(mirror(m), :lap) do
+        # CSR of L == CSC of L' ; build from the reference's own cached SparseMatrixCSC (src/rep/mesh.jl:559-565)
+        Lt = SparseMatrixCSC(transpose(get_laplacian_packed(m)))
+        (hip(Int32.(Lt.colptr .- 1)), hip(Int32.(Lt.rowval .- 1)), hip(Float32.(Lt.nzval)))
+    end
+end
+
+# ---- sample_points: replaces src/transforms/mesh_func.jl:21-58 for HipArray-backed meshes -------
+function sample_points(m::TriMesh{Float32,R,HipArray}, num_samples::Int = 5000; eps::Number = Flux3D.EPS,
+                       seed::UInt64 = rand(UInt64)) where {R}
+    verts = get_verts_padded(m)::HipArray{Float32,3}
+    nb = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_sample_points_workspace_bytes(m.F::Int32, m.N::Int32, nb::Ref{Csize_t})::Int32)
+    ws = workspace(nb[])
+    out = HipArray{Float32}(undef, 3, num_samples, m.N)
+    check(@ccall LIB.fx3d_sample_points(verts.ptr::Ptr{Cvoid}, m.V::Int32, faces_padded_dev(m).ptr::Ptr{Cvoid}, m.F::Int32,
+                                        faces_len_dev(m).ptr::Ptr{Cvoid}, m.N::Int32, num_samples::Int32,
+                                        Float64(eps)::Float64, seed::UInt64, out.ptr::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
+                                        C_NULL::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t,
+                                        DEFAULT_STREAM::Stream)::Int32)
+    return out
+end
+
+# ---- mesh losses: replace src/metrics/mesh.jl:9-32 (no `cpu(transpose(verts))` round trip) -------
+function laplacian_loss(m::TriMesh{Float32,R,HipArray}) where {R}
+    verts = get_verts_packed(m)::HipArray{Float32,2}
+    rowptr, colind, vals = laplacian_csr_dev(m)
+    nb = Ref{Csize_t}(0); check(@ccall LIB.fx3d_mesh_loss_workspace_bytes(size(verts, 2)::Int64, nb::Ref{Csize_t})::Int32)
+    ws = workspace(nb[]); loss_dev = HipArray{Float32}(undef, 1); loss = Ref{Float32}(0)
+    check(@ccall LIB.fx3d_laplacian_loss(verts.ptr::Ptr{Cvoid}, size(verts, 2)::Int64, rowptr.ptr::Ptr{Cvoid},
+                                         colind.ptr::Ptr{Cvoid}, vals.ptr::Ptr{Cvoid}, loss_dev.ptr::Ptr{Cvoid},
+                                         loss::Ref{Float32}, ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t,
+                                         DEFAULT_STREAM::Stream)::Int32)
+    return loss[]
+end
+
+function edge_loss(m::TriMesh{Float32,R,HipArray}, target_length::Number = 0.0) where {R}
+    verts = get_verts_packed(m)::HipArray{Float32,2}
+    edges = edges_dev(m)
+    nb = Ref{Csize_t}(0); check(@ccall LIB.fx3d_mesh_loss_workspace_bytes(size(edges, 1)::Int64, nb::Ref{Csize_t})::Int32)
+    ws = workspace(nb[]); loss_dev = HipArray{Float32}(undef, 1); loss = Ref{Float32}(0)
+    check(@ccall LIB.fx3d_edge_loss(verts.ptr::Ptr{Cvoid}, size(verts, 2)::Int64, edges.ptr::Ptr{Cvoid},
+                                    size(edges, 1)::Int64, Float32(target_length)::Float32, loss_dev.ptr::Ptr{Cvoid},
+                                    loss::Ref{Float32}, ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t,
+                                    DEFAULT_STREAM::Stream)::Int32)
+    return loss[]
+end
+
+end # module
