@@ -1,0 +1,57 @@
+// Phase-level timing of the nn1 kernels at BASELINE config 2 (B=32, N=M=4096): includes chamfer.hip
+// with FX3D_PROBE so the kernel stores s_memtime stamps per block.  Build:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DFX3D_PROBE -I include -I flux3d.jl_amd/csrc \
+//         tools/nn1_probe.hip flux3d.jl_amd/csrc/runtime.hip -o tools/nn1_probe
+#include "../flux3d.jl_amd/csrc/chamfer.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+int main(int argc, char **argv) {
+    const int B = 32, N = 4096, M = 4096;
+    std::vector<float> hx((size_t)3 * N * B), hy((size_t)3 * M * B);
+    unsigned s = 12345;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
+    for (auto &v : hx) v = rnd();
+    for (auto &v : hy) v = rnd();
+    float *x, *y; double *part; float *loss;
+    hipMalloc(&x, hx.size() * 4); hipMalloc(&y, hy.size() * 4);
+    hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(y, hy.data(), hy.size() * 4, hipMemcpyHostToDevice);
+    size_t wsb; fx3d_chamfer_workspace_bytes(N, M, B, 3, &wsb);
+    void *ws; hipMalloc(&ws, wsb); hipMalloc(&loss, 4);
+    float hl = 0;
+    for (int it = 0; it < 5; ++it) fx3d_chamfer_fwd(x, N, y, M, B, 3, 1.f, 1.f, loss, &hl, nullptr, nullptr, ws, wsb, nullptr);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    for (int it = 0; it < 20; ++it) fx3d_chamfer_fwd(x, N, y, M, B, 3, 1.f, 1.f, loss, nullptr, nullptr, nullptr, ws, wsb, nullptr);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("loss %.8f  avg per call %.3f us\n", hl, ms * 1000 / 20);
+    std::vector<unsigned long long> pr(4096 * 16);
+    hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_probe), pr.size() * 8);
+    // s_memtime runs at 100 MHz on gfx9 (constant), report in ns*10 -> convert: ticks * 10 ns
+    const char *names[] = {"start", "bbox done", "c0 image staged", "c0 main loop done", "c0 exact done", "-",
+                           "c1 image staged", "c1 main loop done", "c1 exact done", "-", "-", "merge", "end"};
+    int nb = 512;
+    std::vector<double> d(13, 0.0);
+    unsigned long long t0min = ~0ull, tmax = 0;
+    for (int b = 0; b < nb; ++b) {
+        const unsigned long long *q = &pr[b * 16];
+        if (!q[12]) continue;
+        t0min = std::min(t0min, q[0]); tmax = std::max(tmax, q[12]);
+        unsigned long long prev = q[0];
+        for (int k = 1; k <= 12; ++k) { if (!q[k]) continue; d[k] += (double)(q[k] - prev); prev = q[k]; }
+    }
+    printf("kernel span (first block start -> last block end): %llu ticks\n", tmax - t0min);
+    for (int k = 1; k <= 12; ++k) printf("  %-20s avg %10.1f ticks\n", names[k], d[k] / nb);
+    // block start/end distribution
+    std::vector<unsigned long long> st, en;
+    for (int b = 0; b < nb; ++b) { st.push_back(pr[b * 16] - t0min); en.push_back(pr[b * 16 + 12] - t0min); }
+    std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
+    printf("block start ticks: p0 %llu p25 %llu p50 %llu p75 %llu p100 %llu\n", st[0], st[nb / 4], st[nb / 2], st[3 * nb / 4], st[nb - 1]);
+    printf("block end   ticks: p0 %llu p25 %llu p50 %llu p75 %llu p100 %llu\n", en[0], en[nb / 4], en[nb / 2], en[3 * nb / 4], en[nb - 1]);
+    return 0;
+}
