@@ -456,6 +456,8 @@ constexpr int kMThreads = 512;     // 8 waves share one LDS chunk
 constexpr int kLT = 4;             // 16-candidate blocks per lane tile
 constexpr int kMFifo = 4;
 constexpr int kMChunkMax = 4096;   // 16 B per candidate in LDS => 64 KiB => 2 blocks (16 waves) per CU
+constexpr int kItemCap = 128;      // exact-phase items per wave (typ. ~ QG*16 = 32)
+constexpr size_t kMScratchBytes = (kMThreads / 64) * (2 * 16 * 8 + kItemCap * 4 + 2 * 16 * 3 * 4);  // QG <= 2
 
 // wave64 min / max by DPP (VALU speed; __shfl_xor would go through the LDS crossbar)
 template <int CTRL>
@@ -511,6 +513,10 @@ __global__ __launch_bounds__(kMThreads, 4) void nn1_mfma_kernel(Nn1Params p) {
     const int jq = lane & 15, kg = lane >> 4;
     const int CH = p.chunk;
     float *img = lds;
+    // per-wave scratch of the exact phase, carved behind the image (16-B aligned offsets)
+    unsigned long long *wres = reinterpret_cast<unsigned long long *>(lds + 4 * CH);
+    unsigned int *witems = reinterpret_cast<unsigned int *>(wres + (kMThreads / 64) * QG * 16);
+    float *wq = reinterpret_cast<float *>(witems + (kMThreads / 64) * kItemCap);
     const bool vec = (reinterpret_cast<uintptr_t>(cb) & 15) == 0;  // 16-B aligned cloud: float4 loads
     // fast path: the whole cloud is one chunk: the raw coordinates are parked in the LDS image slots
     // while the bounding box is reduced, then centred in place (each thread re-reads only what it wrote)
@@ -708,8 +714,26 @@ __global__ __launch_bounds__(kMThreads, 4) void nn1_mfma_kernel(Nn1Params p) {
 #endif
             FX3D_PROBE_MARK(tp == 0 ? 3 : 7);
 
-            // ---- exact phase: lane tiles within the band of the QUERY's filter minimum (4 lanes per
-            //      query); raw coordinates come from global memory (L2 resident) -----------------------------
+            // ---- exact phase, wave-cooperative ---------------------------------------------------------------
+            // Lane tiles within the band of the QUERY's filter minimum (4 lanes share a query) become ITEMS
+            // in a per-wave LDS list; every item is kLT runs of 4 consecutive candidates (48 contiguous
+            // bytes of the raw cloud, L2 resident).  All 64 lanes then take (item, run) tasks, evaluate
+            // the oracle's distance and reduce (d, index) per query with a 64-bit LDS atomic min
+            // (d >= 0, so the IEEE bit pattern orders like the value; ties resolve to the lower index).
+            unsigned long long *qres = wres + wv * (QG * 16);        // per-wave: one slot per query
+            unsigned int *items = witems + wv * kItemCap;            // per-wave item list
+            float *qtab = wq + wv * (QG * 16 * 3);                   // per-wave raw query coordinates
+            if (j0 == 0 && kg == 0) {
+#pragma unroll
+                for (int g = 0; g < QG; ++g) {
+                    qres[g * 16 + jq] = ~0ull;
+                    qtab[(g * 16 + jq) * 3 + 0] = qr[g][0];
+                    qtab[(g * 16 + jq) * 3 + 1] = qr[g][1];
+                    qtab[(g * 16 + jq) * 3 + 2] = qr[g][2];
+                }
+            }
+            int nitems = 0;
+            bool any_slow = false;
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
                 float m = best[g];
@@ -718,73 +742,127 @@ __global__ __launch_bounds__(kMThreads, 4) void nn1_mfma_kernel(Nn1Params p) {
                 const float thr1 = m + delta[g], thr2 = thr1 + delta[g];
                 const bool slow = !sane || !(ft[g][kMFifo - 1] > thr2) || !(m < INFINITY);
 #ifdef FX3D_ABLATE_EXACT
-                if (m == 123.456f) { dbest[g] = thr1; ibest[g] = fi[g][0]; }
+                if (m == 123.456f) qres[g * 16 + jq] = fi[g][0];
                 continue;
 #endif
-                if (slow) {  // rare: this lane scans all of its rows of the chunk exactly
+                if (__ballot(slow)) {
+                    any_slow = true;
+                    if (slow) {  // rare: this lane scans all of its rows of the chunk exactly
+                        float db = INFINITY;
+                        int ib = 0x7fffffff;
 #pragma unroll 1
-                    for (int blk = 0; blk < cnt_pad / 16; ++blk) {
+                        for (int blk = 0; blk < cnt_pad / 16; ++blk) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int jl = blk * 16 + kg * 4 + r;
-                            if (jl < cnt) {
-                                const float *src = cb + (size_t)(j0 + jl) * 3;
-                                const float cc[3] = {src[0], src[1], src[2]};
-                                const float dd = sqd<3>(qr[g], cc);
-                                const int jg = j0 + jl;
-                                if (dd < dbest[g] || (dd == dbest[g] && jg < ibest[g])) { dbest[g] = dd; ibest[g] = jg; }
+                            for (int r = 0; r < 4; ++r) {
+                                const int jl = blk * 16 + kg * 4 + r;
+                                if (jl < cnt) {
+                                    const float *src = cb + (size_t)(j0 + jl) * 3;
+                                    const float cc[3] = {src[0], src[1], src[2]};
+                                    const float dd = sqd<3>(qr[g], cc);
+                                    if (dd < db) { db = dd; ib = j0 + jl; }
+                                }
                             }
                         }
+                        atomicMin(&qres[g * 16 + jq],
+                                  ((unsigned long long)__builtin_bit_cast(unsigned int, db) << 32) | (unsigned int)ib);
                     }
-                } else {
+                }
 #pragma unroll
+                for (int s = 0; s < kMFifo; ++s) {
+                    const bool qual = !slow && fi[g][s] >= 0 && ft[g][s] <= thr1;
+                    const unsigned long long bal = __ballot(qual);
+                    if (bal) {
+                        const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
+                                                __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
+                        if (qual && pos < kItemCap)
+                            items[pos] = ((unsigned int)(g * 16 + jq) << 16) | ((unsigned int)kg << 12) | (unsigned int)fi[g][s];
+                        nitems += __builtin_popcountll(bal);
+                    }
+                }
+            }
+            // all lanes of the wave see the list (same wave: LDS ops are in order, wait for the writes)
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+            const int ntask = (nitems < kItemCap ? nitems : kItemCap) * kLT;
+            for (int t0 = 0; t0 < ntask; t0 += 64) {
+                const int t = t0 + lane;
+                if (t < ntask) {
+                    const unsigned int it = items[t / kLT];
+                    const int run = t % kLT;
+                    const int qs = it >> 16, ikg = (it >> 12) & 3, tl = it & 0xfff;
+                    const int jl0 = (tl * kLT + run) * 16 + ikg * 4;
+                    float cx[4], cy[4], cz[4];
+                    if (vec && jl0 + 4 <= cnt) {
+                        load4pts(cb, j0 + jl0, cx, cy, cz);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int jc = jl0 + r < cnt ? jl0 + r : cnt - 1;
+                            const float *src = cb + (size_t)(j0 + jc) * 3;
+                            cx[r] = src[0]; cy[r] = src[1]; cz[r] = src[2];
+                        }
+                    }
+                    const float qq[3] = {qtab[qs * 3], qtab[qs * 3 + 1], qtab[qs * 3 + 2]};
+                    float db = INFINITY;
+                    int ib = 0x7fffffff;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float cc3[3] = {cx[r], cy[r], cz[r]};
+                        const float dd = sqd<3>(qq, cc3);
+                        if (jl0 + r < cnt && dd < db) { db = dd; ib = j0 + jl0 + r; }  // ascending index: first min
+                    }
+                    atomicMin(&qres[qs], ((unsigned long long)__builtin_bit_cast(unsigned int, db) << 32) | (unsigned int)ib);
+                }
+            }
+            if (nitems > kItemCap) {  // list overflow (pathological ties): every lane re-scans its FIFO tiles
+#pragma unroll
+                for (int g = 0; g < QG; ++g) {
+                    float m = best[g];
+                    m = fminf(m, __shfl_xor(m, 16, 64));
+                    m = fminf(m, __shfl_xor(m, 32, 64));
+                    const float thr1 = m + delta[g];
+#pragma unroll 1
                     for (int s = 0; s < kMFifo; ++s) {
                         if (fi[g][s] >= 0 && ft[g][s] <= thr1) {
-#pragma unroll 2
-                            for (int bb = 0; bb < kLT; ++bb) {
-                                const int jl0 = (fi[g][s] * kLT + bb) * 16 + kg * 4;
-                                float cx[4], cy[4], cz[4];
-                                if (vec && jl0 + 4 <= cnt) {  // 4 consecutive rows = 48 contiguous bytes
-                                    load4pts(cb, j0 + jl0, cx, cy, cz);
-                                } else {
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) {
-                                        const int jc = jl0 + r < cnt ? jl0 + r : cnt - 1;
-                                        const float *src = cb + (size_t)(j0 + jc) * 3;
-                                        cx[r] = src[0]; cy[r] = src[1]; cz[r] = src[2];
-                                    }
-                                }
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const float cc3[3] = {cx[r], cy[r], cz[r]};
-                                    const float dd = sqd<3>(qr[g], cc3);
-                                    const int jg = j0 + jl0 + r;
-                                    const bool ok = jl0 + r < cnt;
-                                    if (ok && (dd < dbest[g] || (dd == dbest[g] && jg < ibest[g]))) { dbest[g] = dd; ibest[g] = jg; }
+                            float db = INFINITY;
+                            int ib = 0x7fffffff;
+                            for (int e = 0; e < kLT * 4; ++e) {
+                                const int jl = (fi[g][s] * kLT + (e >> 2)) * 16 + kg * 4 + (e & 3);
+                                if (jl < cnt) {
+                                    const float *src = cb + (size_t)(j0 + jl) * 3;
+                                    const float cc[3] = {src[0], src[1], src[2]};
+                                    const float dd = sqd<3>(qr[g], cc);
+                                    if (dd < db) { db = dd; ib = j0 + jl; }
                                 }
                             }
+                            atomicMin(&qres[g * 16 + jq],
+                                      ((unsigned long long)__builtin_bit_cast(unsigned int, db) << 32) | (unsigned int)ib);
                         }
                     }
                 }
             }
+            (void)any_slow;
             FX3D_PROBE_MARK(tp == 0 ? 4 : 8);
 
             if (j0 + CH >= NC) {
-                // ---- last chunk: merge the four lanes of every query, lexicographic (d, index) minimum ----
+                // ---- last chunk: results of this tile pass ---------------------------------------------------
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                if (kg == 0) {
 #pragma unroll
-                for (int g = 0; g < QG; ++g) {
-#pragma unroll
-                    for (int off = 16; off <= 32; off <<= 1) {
-                        const float od = __shfl_xor(dbest[g], off, 64);
-                        const int oi = __shfl_xor(ibest[g], off, 64);
-                        if (od < dbest[g] || (od == dbest[g] && oi < ibest[g])) { dbest[g] = od; ibest[g] = oi; }
-                    }
-                    if (kg == 0 && qi[g] < NQ) {
-                        if (WANT_IDX && idx_out) idx_out[(size_t)b * NQ + qi[g]] = ibest[g];
-                        if (dmin_out) dmin_out[(size_t)b * NQ + qi[g]] = dbest[g];
-                        acc += (double)dbest[g];
+                    for (int g = 0; g < QG; ++g) {
+                        const unsigned long long r = qres[g * 16 + jq];
+                        const float dd = __builtin_bit_cast(float, (unsigned int)(r >> 32));
+                        const int ii = (int)(unsigned int)r;
+                        if (qi[g] < NQ) {
+                            if (WANT_IDX && idx_out) idx_out[(size_t)b * NQ + qi[g]] = ii;
+                            if (dmin_out) dmin_out[(size_t)b * NQ + qi[g]] = dd;
+                            acc += (double)dd;
+                        }
+                        qres[g * 16 + jq] = ~0ull;  // ready for the next tile pass
                     }
                 }
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
@@ -792,6 +870,370 @@ __global__ __launch_bounds__(kMThreads, 4) void nn1_mfma_kernel(Nn1Params p) {
     if (p.partials) {
         __shared__ double sm[kMThreads / 64];
         const double tot = block_sum<kMThreads>(acc, sm);
+        if (tid == 0) p.partials[(size_t)c * p.tiles + tile] = tot;
+    }
+    FX3D_PROBE_MARK(12);
+}
+
+// ------------------------------------------------------------------------------------------------
+// nn1_f16_kernel (D = 3): the filter recast as a dense 16-bit GEMM tile (north_star: "MFMA only if the
+// pairwise-distance inner product is recast as a dense 16-bit GEMM and rocprof shows it beating the
+// LDS-tiled path" -- it does: profiles/).
+//
+//   One v_mfma_f32_32x32x16_f16 produces 1024 filter values (32 candidates x 32 queries) in the time
+//   the f32 form needs for 256.  Precision is recovered by 2-way fp16 splits (hi + lo ~ 22 bits) of
+//   coordinates pre-scaled by a power of two s so that |c~| = |s (c - mu)| <= 1:
+//     K slot : 0      1      2      3      4      5      6      7    | 8      9  10 11  12     13     14    15
+//     A (c~) : chx    chx    clx    chy    chy    cly    chz    chz  | clz    n1 n2 n3  clx    cly    clz   0
+//     B (qm~): qhx    qlx    qhx    qhy    qly    qhy    qhz    qlz  | qhz    1  1  1   qlx    qly    qlz   0
+//   with qm~ = -2 s (q - mu) and n1+n2+n3 the 3-way split of the Float32 |c~|^2, so
+//     D[i][j] = |c~_i|^2 + qm~_j . c~_i  =  s^2 (|c'_i|^2 - 2 q'_j . c'_i)     up to
+//     |err| <= 2^-20 (4 + 2 S),  S = sum_d |qm~_d|   (measured max: 2^-23.2 (3 + S), tools/test_f16_filter.hip).
+//   Band (scaled units), including the oracle's own Float32 rounding 6u D~, D~ <= S^2/2 + 6:
+//     delta~ = 2^-19 (6 + 2 S + S^2/8).
+//   Queries with |qm~| beyond the fp16 range take the exact path.
+//   Lane l of a wave holds query l&31 and the 16 candidate rows (r&3)+8(r>>2)+4(l>>5) of every
+//   32-candidate block; the two half-waves are merged through the per-query LDS slot.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kHThreads = 1024;   // 16 waves share one LDS image: 1 block per CU, 4 waves per SIMD
+constexpr int kHLT = 2;           // 32-candidate blocks per lane tile (lane sees 16 rows of each)
+constexpr int kHFifo = 4;
+constexpr int kHChunkMax = 4096;  // 32 B per candidate => 128 KiB
+constexpr int kHItemCap = 128;
+constexpr size_t kHScratchBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 4 + 32 * 3 * 4);
+
+__device__ __forceinline__ void split2h(float v, _Float16 &h, _Float16 &l) {
+    h = (_Float16)v;
+    l = (_Float16)(v - (float)h);
+}
+
+// fp16 image pieces of one candidate: c~ = s (c - mu)
+__device__ __forceinline__ void make_pieces(float cx, float cy, float cz, h8 &p0, h8 &p1) {
+    _Float16 hx, lx, hy, ly, hz, lz, n1, n2, n3;
+    split2h(cx, hx, lx); split2h(cy, hy, ly); split2h(cz, hz, lz);
+    const float n = ((cx * cx) + (cy * cy)) + (cz * cz);
+    n1 = (_Float16)n;
+    const float r1 = n - (float)n1;
+    n2 = (_Float16)r1;
+    n3 = (_Float16)(r1 - (float)n2);
+    const _Float16 z = (_Float16)0.0f;
+    p0 = h8{hx, hx, lx, hy, hy, ly, hz, hz};
+    p1 = h8{lz, n1, n2, n3, lx, ly, lz, z};
+}
+
+template <bool WANT_IDX>
+__global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float red[2 * 4 * (kHThreads / 64)];
+    constexpr int QB = (kHThreads / 64) * 32;  // queries per tile pass
+
+    const int L = blockIdx.x;
+    const int xcd = L & 7, slot = L >> 3;
+    const int c = (slot / p.tiles) * 8 + xcd;
+    const int tile = slot % p.tiles;
+    if (c >= 2 * p.B) return;
+    const int dir = c >= p.B ? 1 : 0;
+    const int b = dir ? c - p.B : c;
+    const int NQ = dir ? p.M : p.N;
+    const int NC = dir ? p.N : p.M;
+    if (tile >= (dir ? p.tiles_y : p.tiles_x)) return;
+    const float *__restrict__ qb = (dir ? p.y : p.x) + (size_t)b * NQ * 3;
+    const float *__restrict__ cb = (dir ? p.x : p.y) + (size_t)b * NC * 3;
+    int32_t *idx_out = dir ? p.idx_y : p.idx_x;
+    float *dmin_out = dir ? p.dmin_y : p.dmin_x;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int jq = lane & 31, hh = lane >> 5;
+    const int CH = p.chunk;
+    h8 *imgp = reinterpret_cast<h8 *>(lds);  // piece (blk, half, row) at (blk*2 + half)*32 + row, 16 B each
+    float4 *imgf = reinterpret_cast<float4 *>(lds);
+    unsigned long long *wres = reinterpret_cast<unsigned long long *>(lds + 8 * CH);
+    unsigned int *witems = reinterpret_cast<unsigned int *>(wres + (kHThreads / 64) * 32);
+    float *wq = reinterpret_cast<float *>(witems + (kHThreads / 64) * kHItemCap);
+    unsigned long long *qres = wres + wv * 32;
+    unsigned int *items = witems + wv * kHItemCap;
+    float *qtab = wq + wv * 96;
+    const bool vec = (reinterpret_cast<uintptr_t>(cb) & 15) == 0;
+    const bool one_shot = vec && NC <= CH;
+    FX3D_PROBE_MARK(0);
+
+    // ---- bounding box -> centre mu, half extent cinf, power-of-two scale sc with cinf*sc in [0.5,1) ----
+    float mu[3], cinf = 0.0f;
+    const int nv = vec ? NC / 4 : 0;
+    {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int q4 = tid; q4 < nv; q4 += kHThreads) {
+            float ax[4], ay[4], az[4];
+            load4pts(cb, q4 * 4, ax, ay, az);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mn[0] = fminf(mn[0], ax[e]); mx[0] = fmaxf(mx[0], ax[e]);
+                mn[1] = fminf(mn[1], ay[e]); mx[1] = fmaxf(mx[1], ay[e]);
+                mn[2] = fminf(mn[2], az[e]); mx[2] = fmaxf(mx[2], az[e]);
+                if (one_shot) {  // park the raw point in its own first piece
+                    const int pt = q4 * 4 + e;
+                    imgf[((pt >> 5) * 2) * 32 + (pt & 31)] = float4{ax[e], ay[e], az[e], 0.0f};
+                }
+            }
+        }
+        for (int pt = nv * 4 + tid; pt < NC; pt += kHThreads) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float v = cb[(size_t)pt * 3 + d];
+                mn[d] = fminf(mn[d], v);
+                mx[d] = fmaxf(mx[d], v);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float lo = wave_min_f(mn[d]), hi = wave_max_f(mx[d]);
+            if (lane == 0) { red[(wv * 2) * 4 + d] = lo; red[(wv * 2 + 1) * 4 + d] = hi; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float lo = red[d], hi = red[4 + d];
+#pragma unroll
+            for (int w = 1; w < kHThreads / 64; ++w) {
+                lo = fminf(lo, red[(w * 2) * 4 + d]);
+                hi = fmaxf(hi, red[(w * 2 + 1) * 4 + d]);
+            }
+            mu[d] = 0.5f * lo + 0.5f * hi;
+            cinf = fmaxf(cinf, fmaxf(hi - mu[d], mu[d] - lo));
+        }
+        cinf = cinf * 1.000001f;
+    }
+    const bool sane = cinf < 1.0e18f;
+    float sc = 1.0f;
+    if (sane && cinf > 1.0e-30f) {
+        int e;
+        (void)frexpf(cinf, &e);  // cinf = m 2^e, m in [0.5,1)
+        sc = ldexpf(1.0f, -e);
+    }
+    FX3D_PROBE_MARK(1);
+
+    float qr[3], delta = 0.0f;
+    int qi = 0;
+    bool qok = true;
+    h8 bq;
+    double acc = 0.0;
+
+    for (int j0 = 0; j0 < NC; j0 += CH) {
+        const int cnt = (NC - j0) < CH ? (NC - j0) : CH;
+        const int cnt_pad = (cnt + 32 * kHLT - 1) / (32 * kHLT) * (32 * kHLT);
+        if (j0 > 0) __syncthreads();
+        // ---- stage the fp16 split image ------------------------------------------------------------------
+        if (one_shot) {
+            for (int q4 = tid; q4 < nv; q4 += kHThreads) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int pt = q4 * 4 + e;
+                    const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
+                    const float4 r = imgf[i0];
+                    h8 p0, p1;
+                    make_pieces((r.x - mu[0]) * sc, (r.y - mu[1]) * sc, (r.z - mu[2]) * sc, p0, p1);
+                    imgp[i0] = p0;
+                    imgp[i0 + 32] = p1;
+                }
+            }
+            for (int pt = nv * 4 + tid; pt < cnt_pad; pt += kHThreads) {
+                const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
+                h8 p0, p1;
+                if (pt < cnt) {
+                    const float *src = cb + (size_t)pt * 3;
+                    make_pieces((src[0] - mu[0]) * sc, (src[1] - mu[1]) * sc, (src[2] - mu[2]) * sc, p0, p1);
+                } else {  // padding: n1 = +inf => t = +inf, never within any band
+                    make_pieces(0.f, 0.f, 0.f, p0, p1);
+                    p1[1] = (_Float16)INFINITY;
+                }
+                imgp[i0] = p0;
+                imgp[i0 + 32] = p1;
+            }
+        } else {
+            for (int pt = tid; pt < cnt_pad; pt += kHThreads) {
+                const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
+                h8 p0, p1;
+                if (pt < cnt) {
+                    const float *src = cb + (size_t)(j0 + pt) * 3;
+                    make_pieces((src[0] - mu[0]) * sc, (src[1] - mu[1]) * sc, (src[2] - mu[2]) * sc, p0, p1);
+                } else {
+                    make_pieces(0.f, 0.f, 0.f, p0, p1);
+                    p1[1] = (_Float16)INFINITY;
+                }
+                imgp[i0] = p0;
+                imgp[i0 + 32] = p1;
+            }
+        }
+        __syncthreads();
+        FX3D_PROBE_MARK(j0 == 0 ? 2 : 6);
+
+        for (int tp = 0; tp < p.tpb; ++tp) {
+            if ((tile * p.tpb + tp) * QB >= NQ) break;  // uniform
+            if (j0 == 0) {
+                qi = (tile * p.tpb + tp) * QB + wv * 32 + jq;
+                const int qc = qi < NQ ? qi : NQ - 1;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) qr[d] = qb[(size_t)qc * 3 + d];
+                const float m0 = -2.0f * ((qr[0] - mu[0]) * sc), m1 = -2.0f * ((qr[1] - mu[1]) * sc),
+                            m2 = -2.0f * ((qr[2] - mu[2]) * sc);
+                const float S = (fabsf(m0) + fabsf(m1)) + fabsf(m2);
+                qok = S < 3.0e4f;  // inside the fp16 range (also false for NaN)
+                delta = (6.0f + 2.0f * S + 0.125f * S * S) * 0x1p-19f;
+                _Float16 hx, lx, hy, ly, hz, lz;
+                split2h(qok ? m0 : 0.f, hx, lx); split2h(qok ? m1 : 0.f, hy, ly); split2h(qok ? m2 : 0.f, hz, lz);
+                const _Float16 one = (_Float16)1.0f, z = (_Float16)0.0f;
+                bq = hh == 0 ? h8{hx, lx, hx, hy, ly, hy, hz, lz} : h8{hz, one, one, one, lx, ly, lz, z};
+                if (hh == 0) {
+                    qres[jq] = ~0ull;
+                    qtab[jq * 3 + 0] = qr[0]; qtab[jq * 3 + 1] = qr[1]; qtab[jq * 3 + 2] = qr[2];
+                }
+            }
+
+            float best = INFINITY, tm = INFINITY, ft[kHFifo];
+            int fi[kHFifo];
+#pragma unroll
+            for (int s = 0; s < kHFifo; ++s) { ft[s] = INFINITY; fi[s] = -1; }
+
+            // ---- main loop, software-pipelined by one 32-candidate block -----------------------------------
+            const int nblk = cnt_pad / 32;  // multiple of kHLT
+            f32x16 zero;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
+            f32x16 accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(imgp[hh * 32 + jq], bq, zero, 0, 0, 0);
+            h8 a_nxt = imgp[((nblk > 1 ? 1 : 0) * 2 + hh) * 32 + jq];
+            for (int lt = 0; lt < nblk / kHLT; ++lt) {
+#pragma unroll
+                for (int bb = 0; bb < kHLT; ++bb) {
+                    const int blk = lt * kHLT + bb;
+                    const int b2 = blk + 2 < nblk ? blk + 2 : nblk - 1;
+                    const h8 a_n2 = imgp[(b2 * 2 + hh) * 32 + jq];
+                    const f32x16 accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_nxt, bq, zero, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) tm = min3f(tm, accC[r], accC[r + 1]);
+                    accC = accN;
+                    a_nxt = a_n2;
+                }
+                const bool qual = tm <= best + delta;
+#pragma unroll
+                for (int s = kHFifo - 1; s > 0; --s) {
+                    ft[s] = qual ? ft[s - 1] : ft[s];
+                    fi[s] = qual ? fi[s - 1] : fi[s];
+                }
+                ft[0] = qual ? tm : ft[0];
+                fi[0] = qual ? lt : fi[0];
+                best = fminf(best, tm);
+                tm = INFINITY;
+            }
+            FX3D_PROBE_MARK(tp == 0 ? 3 : 7);
+
+            // ---- exact phase, wave-cooperative (see nn1_mfma_kernel) ----------------------------------------
+            int nitems = 0;
+            {
+                float m = fminf(best, __shfl_xor(best, 32, 64));
+                const float thr1 = m + delta, thr2 = thr1 + delta;
+                const bool slow = !sane || !qok || !(ft[kHFifo - 1] > thr2) || !(m < INFINITY);
+                if (__ballot(slow)) {  // rare: a slow lane enqueues every lane tile of the chunk
+                    for (int lt = 0; lt < nblk / kHLT; ++lt) {
+                        const unsigned long long bal = __ballot(slow);
+                        const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
+                        if (slow && pos < kHItemCap) items[pos] = ((unsigned int)jq << 16) | ((unsigned int)hh << 12) | (unsigned int)lt;
+                        nitems += __builtin_popcountll(bal);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < kHFifo; ++s) {
+                    const bool qual = !slow && fi[s] >= 0 && ft[s] <= thr1;
+                    const unsigned long long bal = __ballot(qual);
+                    if (bal) {
+                        const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
+                        if (qual && pos < kHItemCap) items[pos] = ((unsigned int)jq << 16) | ((unsigned int)hh << 12) | (unsigned int)fi[s];
+                        nitems += __builtin_popcountll(bal);
+                    }
+                }
+                if (nitems > kHItemCap) {  // list overflow: lanes scan their own tiles (pathological ties)
+                    const int lt_lo = slow ? 0 : -1;
+                    for (int lt = 0; lt < nblk / kHLT; ++lt) {
+                        bool take = lt_lo == 0;
+#pragma unroll
+                        for (int s = 0; s < kHFifo; ++s) take = take || (!slow && fi[s] == lt && ft[s] <= thr1);
+                        if (take) {
+                            float db = INFINITY;
+                            int ib = 0x7fffffff;
+                            for (int e = 0; e < kHLT * 16; ++e) {
+                                const int rr = e & 15;
+                                const int jl = (lt * kHLT + (e >> 4)) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hh;
+                                if (jl < cnt) {
+                                    const float *src = cb + (size_t)(j0 + jl) * 3;
+                                    const float cc[3] = {src[0], src[1], src[2]};
+                                    const float dd = sqd<3>(qr, cc);
+                                    if (dd < db) { db = dd; ib = j0 + jl; }
+                                }
+                            }
+                            atomicMin(&qres[jq], ((unsigned long long)__builtin_bit_cast(unsigned int, db) << 32) | (unsigned int)ib);
+                        }
+                    }
+                    nitems = 0;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const int ntask = nitems * (kHLT * 4);
+            for (int t0 = 0; t0 < ntask; t0 += 64) {
+                const int t = t0 + lane;
+                if (t < ntask) {
+                    const unsigned int it = items[t / (kHLT * 4)];
+                    const int run = t % (kHLT * 4);
+                    const int qs = it >> 16, ih = (it >> 12) & 1, tl = it & 0xfff;
+                    const int jl0 = (tl * kHLT + (run >> 2)) * 32 + 8 * (run & 3) + 4 * ih;
+                    float cx[4], cy[4], cz[4];
+                    if (vec && jl0 + 4 <= cnt) {
+                        load4pts(cb, j0 + jl0, cx, cy, cz);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int jc = jl0 + r < cnt ? jl0 + r : cnt - 1;
+                            const float *src = cb + (size_t)(j0 + jc) * 3;
+                            cx[r] = src[0]; cy[r] = src[1]; cz[r] = src[2];
+                        }
+                    }
+                    const float qq[3] = {qtab[qs * 3], qtab[qs * 3 + 1], qtab[qs * 3 + 2]};
+                    float db = INFINITY;
+                    int ib = 0x7fffffff;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float cc3[3] = {cx[r], cy[r], cz[r]};
+                        const float dd = sqd<3>(qq, cc3);
+                        if (jl0 + r < cnt && dd < db) { db = dd; ib = j0 + jl0 + r; }
+                    }
+                    atomicMin(&qres[qs], ((unsigned long long)__builtin_bit_cast(unsigned int, db) << 32) | (unsigned int)ib);
+                }
+            }
+            FX3D_PROBE_MARK(tp == 0 ? 4 : 8);
+
+            if (j0 + CH >= NC) {  // last chunk: results of this tile pass
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                if (hh == 0) {
+                    const unsigned long long r = qres[jq];
+                    const float dd = __builtin_bit_cast(float, (unsigned int)(r >> 32));
+                    const int ii = (int)(unsigned int)r;
+                    if (qi < NQ) {
+                        if (WANT_IDX && idx_out) idx_out[(size_t)b * NQ + qi] = ii;
+                        if (dmin_out) dmin_out[(size_t)b * NQ + qi] = dd;
+                        acc += (double)dd;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    FX3D_PROBE_MARK(11);
+    if (p.partials) {
+        __shared__ double sm[kHThreads / 64];
+        const double tot = block_sum<kHThreads>(acc, sm);
         if (tid == 0) p.partials[(size_t)c * p.tiles + tile] = tot;
     }
     FX3D_PROBE_MARK(12);
@@ -912,7 +1354,7 @@ __global__ __launch_bounds__(kThreads) void chamfer_bwd_kernel(
 struct Plan {
     int R, tiles_x, tiles_y, tiles, chunk, grid;
     size_t lds_bytes;
-    int variant;  // 0 = exact hot loop, 1 = VALU filter + exact re-scan, 2 = MFMA filter + exact re-scan
+    int variant;  // 0 = exact hot loop, 1 = VALU filter, 2 = f32 MFMA filter, 3 = fp16-split MFMA filter (+ exact re-scan)
     int threads, tpb;
 };
 
@@ -920,7 +1362,7 @@ struct Plan {
 int nn1_variant() {
     static const int v = [] {
         const char *e = getenv("FX3D_NN1_VARIANT");
-        return e ? atoi(e) : 2;
+        return e ? atoi(e) : 3;
     }();
     return v;
 }
@@ -931,8 +1373,8 @@ Plan make_plan(int N, int M, int B, int D) {
     // blocking (LDS-read amortisation, ILP) as the problem size allows.
     const long long work = (long long)B * ((long long)N + M);  // total queries, both directions
     pl.variant = nn1_variant();
-    if (D != 3 && pl.variant == 2) pl.variant = 1;  // the MFMA image is K=4: D=3 only
-    pl.threads = pl.variant == 2 ? kMThreads : kThreads;
+    if (D != 3 && pl.variant >= 2) pl.variant = 1;  // the MFMA images are built for D = 3
+    pl.threads = pl.variant == 3 ? kHThreads : (pl.variant == 2 ? kMThreads : kThreads);
     int R = 4;
     if (pl.variant == 2) {
         // R = query groups of 16 per wave: 8 waves x R x 16 queries per block
@@ -943,6 +1385,12 @@ Plan make_plan(int N, int M, int B, int D) {
     }
     pl.R = R;
     pl.tpb = 1;
+    if (pl.variant == 3 && N <= kHChunkMax && M <= kHChunkMax) {
+        // one-chunk clouds: several 512-query tile passes per block; keep >= 256 blocks (1 per CU)
+        while (pl.tpb < 8 && work / (512 * pl.tpb * 2) >= 256) pl.tpb *= 2;
+        static const int tpb_env3 = [] { const char *e = getenv("FX3D_NN1_TPB"); return e ? atoi(e) : 0; }();
+        if (tpb_env3 > 0) pl.tpb = tpb_env3;
+    }
     if (pl.variant == 2 && N <= kMChunkMax && M <= kMChunkMax) {
         // one-chunk clouds: a block may run several query tiles against the staged image; keep >= 512
         // blocks (2 per CU) in flight
@@ -950,18 +1398,20 @@ Plan make_plan(int N, int M, int B, int D) {
         static const int tpb_env = [] { const char *e = getenv("FX3D_NN1_TPB"); return e ? atoi(e) : 0; }();
         if (tpb_env > 0) pl.tpb = tpb_env;
     }
-    const int per_block = pl.variant == 2 ? 128 * R * pl.tpb : kThreads * R;
+    const int per_block = pl.variant == 3 ? 512 * pl.tpb : (pl.variant == 2 ? 128 * R * pl.tpb : kThreads * R);
     pl.tiles_x = (N + per_block - 1) / per_block;
     pl.tiles_y = (M + per_block - 1) / per_block;
     pl.tiles = pl.tiles_x > pl.tiles_y ? pl.tiles_x : pl.tiles_y;
     const int maxc = N > M ? N : M;
-    const int cmax = pl.variant == 2 ? kMChunkMax : (pl.variant == 1 ? kFChunkMax : kChunkMax);
-    const int gran = pl.variant == 2 ? 16 * kLT : kTile;
+    const int cmax = pl.variant == 3 ? kHChunkMax : (pl.variant == 2 ? kMChunkMax : (pl.variant == 1 ? kFChunkMax : kChunkMax));
+    const int gran = pl.variant == 3 ? 32 * kHLT : (pl.variant == 2 ? 16 * kLT : kTile);
     int chunk = (maxc + gran - 1) / gran * gran;
     if (chunk > cmax) chunk = cmax;
     pl.chunk = chunk;
-    const int floats_per_cand = pl.variant == 2 ? 4 : (pl.variant == 1 ? 2 * D + 1 : D);
+    const int floats_per_cand = pl.variant == 3 ? 8 : (pl.variant == 2 ? 4 : (pl.variant == 1 ? 2 * D + 1 : D));
     pl.lds_bytes = (size_t)chunk * (D <= 3 ? floats_per_cand : 0) * sizeof(float);
+    if (pl.variant == 2) pl.lds_bytes += kMScratchBytes;
+    if (pl.variant == 3) pl.lds_bytes += kHScratchBytes;
     const int clouds8 = (2 * B + 7) / 8;
     pl.grid = clouds8 * 8 * pl.tiles;
     return pl;
@@ -971,6 +1421,18 @@ size_t partials_count(const Plan &pl, int B) { return (size_t)2 * B * pl.tiles; 
 
 template <int DIM, bool WANT_IDX>
 fx3d_status launch_small(const Nn1Params &p, const Plan &pl, hipStream_t st) {
+    if (pl.variant == 3) {
+        if (DIM == 3) {
+            // > 64 KiB of dynamic LDS needs an explicit opt-in (static LDS of the kernel: < 1 KiB)
+            static const hipError_t attr_rc = hipFuncSetAttribute(
+                reinterpret_cast<const void *>(&nn1_f16_kernel<WANT_IDX>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHChunkMax * 32 + kHScratchBytes));
+            if (attr_rc != hipSuccess) return hip_fail(attr_rc, "hipFuncSetAttribute(nn1_f16_kernel)", __FILE__, __LINE__);
+            hipLaunchKernelGGL((nn1_f16_kernel<WANT_IDX>), dim3(pl.grid), dim3(kHThreads), pl.lds_bytes, st, p);
+        }
+        FX3D_LAUNCH_CHECK();
+        return FX3D_OK;
+    }
     if (pl.variant == 2) {
         if (DIM == 3) {
             if (pl.R == 2)

@@ -35,7 +35,7 @@ int main(int argc, char **argv) {
     // s_memtime runs at 100 MHz on gfx9 (constant), report in ns*10 -> convert: ticks * 10 ns
     const char *names[] = {"start", "bbox done", "c0 image staged", "c0 main loop done", "c0 exact done", "-",
                            "c1 image staged", "c1 main loop done", "c1 exact done", "-", "-", "merge", "end"};
-    int nb = 512;
+    int nb = 256;
     std::vector<double> d(13, 0.0);
     unsigned long long t0min = ~0ull, tmax = 0;
     for (int b = 0; b < nb; ++b) {
