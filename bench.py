@@ -81,10 +81,9 @@ def main():
         sums = fx.DeviceArray.empty((2,), np.float64)
         loss_dev = fx.DeviceArray.empty((1,), np.float32)
 
-        def step():
+        def step():  # chamfer_distance(A, B) forward: ONE launch (the last block finalises the loss)
             with fx.stream(bench_stream):
-                chamfer_sums(x, y, out=sums, sync=False)
-                chamfer_finalize(sums, NPTS, MPTS, Bg, DIM, out=loss_dev, sync=False)
+                fx.chamfer_distance(x, y, loss_out=loss_dev, sync=False)
 
         def sync_all():
             bench_stream.synchronize()
@@ -151,10 +150,17 @@ def main():
                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": (flops / kern_s / 1e12 / FP32_PEAK_TFLOPS) if kern_s else None,
                      "traffic": traffic,
-                     "kernel": "nn1_small_d_kernel<3,R,false>", "kernel_avg_ms": avg.value,
+                     "kernel": "nn1_f16_kernel<false>", "kernel_avg_ms": avg.value,
                      "kernel_min_ms": mn.value, "launches_timed": cnt.value,
-                     "note": "all-pairs NN is fp32 issue bound (~1000 flop/byte); peak is the fp32 vector peak, "
-                             "which equals the dense fp32-input MFMA peak; the kernel uses VALU, not MFMA"},
+                     "note": "ALGORITHMIC flops (16 per unordered pair: the exact Float32 form, both directions) vs the "
+                             "fp32 peak (vector == fp32-input MFMA, 157.3 TF). The kernel does not execute those flops: "
+                             "it evaluates a 2-way fp16-split filter on v_mfma_f32_32x32x16_f16 and re-scans the "
+                             "surviving 32-candidate tiles exactly in Float32; see roofline_mfma_f16 for the hardware "
+                             "matrix flops and DESIGN.md 3.1 (the VALU min-fold of the MFMA outputs is the limiter)"},
+        "roofline_mfma_f16": {"bound": "mfma", "achieved": (2.0 * 16 * 2 * B_PER_GPU * NPTS * MPTS) / kern_s / 1e12 if kern_s else None,
+                              "peak": 2500.0, "unit": "TFLOP/s",
+                              "frac": ((2.0 * 16 * 2 * B_PER_GPU * NPTS * MPTS) / kern_s / 1e12 / 2500.0) if kern_s else None,
+                              "note": "hardware MFMA flops actually issued (K=16 per pair, both directions) vs the dense f16 peak"},
         "roofline_hbm": {"bound": "hbm", "achieved": abytes / kern_s / 1e9 if kern_s else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (abytes / kern_s / 1e9 / HBM_PEAK_GBS) if kern_s else None,

@@ -21,8 +21,10 @@
 //     winning tile from LDS (1/128 of the work at M=4096) with the reference's strict `<`.
 //   * grid is 1-D and XCD-aware: block L runs on XCD L%8 (MI355X_MICROARCH.md), so all query
 //     tiles of one (direction,batch) cloud are given ids with equal L%8 and share that XCD's L2.
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 
 #include "fx3d_common.h"
 
@@ -56,6 +58,13 @@ struct Nn1Params {
     int tiles_x, tiles_y;
     int chunk;               // LDS chunk capacity (multiple of kTile)
     int tpb;                 // MFMA variant: query-tile passes per block (>1 only for one-chunk clouds)
+    // fused finalisation (fp16 variant): the last block to arrive reduces the partials in fixed order
+    unsigned int *ticket;    // library-owned arrival counter, zero between launches; nullptr = no fusion
+    unsigned int nvalid;     // number of blocks that deliver a partial
+    double *sums_out;        // [2] optional
+    float *loss_out;         // optional
+    float w1, w2;
+    long long Bg;
 };
 
 __device__ __forceinline__ float min3f(float a, float b, float c) {
@@ -896,12 +905,14 @@ __global__ __launch_bounds__(kMThreads, 4) void nn1_mfma_kernel(Nn1Params p) {
 //   32-candidate block; the two half-waves are merged through the per-query LDS slot.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ float chamfer_loss_from_sums(double sa, double sb, int N, int M, int D,
+                                                        long long Bg, float w1, float w2);
 constexpr int kHThreads = 1024;   // 16 waves share one LDS image: 1 block per CU, 4 waves per SIMD
 constexpr int kHLT = 2;           // 32-candidate blocks per lane tile (lane sees 16 rows of each)
 constexpr int kHFifo = 4;
 constexpr int kHChunkMax = 4096;  // 32 B per candidate => 128 KiB
 constexpr int kHItemCap = 128;
-constexpr size_t kHScratchBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 4 + 32 * 3 * 4);
+constexpr size_t kHScratchBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 4 + 32 * 3 * 4) + 64 * 32;  // + 2 pad blocks
 
 __device__ __forceinline__ void split2h(float v, _Float16 &h, _Float16 &l) {
     h = (_Float16)v;
@@ -948,7 +959,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     const int CH = p.chunk;
     h8 *imgp = reinterpret_cast<h8 *>(lds);  // piece (blk, half, row) at (blk*2 + half)*32 + row, 16 B each
     float4 *imgf = reinterpret_cast<float4 *>(lds);
-    unsigned long long *wres = reinterpret_cast<unsigned long long *>(lds + 8 * CH);
+    unsigned long long *wres = reinterpret_cast<unsigned long long *>(lds + 8 * (CH + 64));  // image + 2 pad blocks
     unsigned int *witems = reinterpret_cast<unsigned int *>(wres + (kHThreads / 64) * 32);
     float *wq = reinterpret_cast<float *>(witems + (kHThreads / 64) * kHItemCap);
     unsigned long long *qres = wres + wv * 32;
@@ -1037,7 +1048,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     imgp[i0 + 32] = p1;
                 }
             }
-            for (int pt = nv * 4 + tid; pt < cnt_pad; pt += kHThreads) {
+            for (int pt = nv * 4 + tid; pt < cnt_pad + 64; pt += kHThreads) {
                 const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
                 h8 p0, p1;
                 if (pt < cnt) {
@@ -1051,7 +1062,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 imgp[i0 + 32] = p1;
             }
         } else {
-            for (int pt = tid; pt < cnt_pad; pt += kHThreads) {
+            for (int pt = tid; pt < cnt_pad + 64; pt += kHThreads) {
                 const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
                 h8 p0, p1;
                 if (pt < cnt) {
@@ -1096,24 +1107,31 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             for (int s = 0; s < kHFifo; ++s) { ft[s] = INFINITY; fi[s] = -1; }
 
             // ---- main loop, software-pipelined by one 32-candidate block -----------------------------------
+            // (the image carries two padding blocks behind cnt_pad, so the prefetch never needs a clamp
+            //  and every ds_read_b128 is base + immediate offset: no address VALU in the loop)
             const int nblk = cnt_pad / 32;  // multiple of kHLT
             f32x16 zero;
 #pragma unroll
             for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
-            f32x16 accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(imgp[hh * 32 + jq], bq, zero, 0, 0, 0);
-            h8 a_nxt = imgp[((nblk > 1 ? 1 : 0) * 2 + hh) * 32 + jq];
+            const h8 *pa = imgp + hh * 32 + jq;
+            f32x16 accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[0], bq, zero, 0, 0, 0);
+            h8 a_nxt = pa[64];
+            pa += 128;  // -> block 2
             for (int lt = 0; lt < nblk / kHLT; ++lt) {
 #pragma unroll
                 for (int bb = 0; bb < kHLT; ++bb) {
-                    const int blk = lt * kHLT + bb;
-                    const int b2 = blk + 2 < nblk ? blk + 2 : nblk - 1;
-                    const h8 a_n2 = imgp[(b2 * 2 + hh) * 32 + jq];
+                    const h8 a_n2 = pa[bb * 64];
                     const f32x16 accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_nxt, bq, zero, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) tm = min3f(tm, accC[r], accC[r + 1]);
+                    // fold 16 values: 8 x v_min3, depth 3
+                    const float t0 = min3f(accC[0], accC[1], accC[2]), t1 = min3f(accC[3], accC[4], accC[5]);
+                    const float t2 = min3f(accC[6], accC[7], accC[8]), t3 = min3f(accC[9], accC[10], accC[11]);
+                    const float t4 = min3f(accC[12], accC[13], accC[14]);
+                    const float t5 = min3f(t0, t1, t2), t6 = min3f(t3, t4, accC[15]);
+                    tm = min3f(tm, t5, t6);
                     accC = accN;
                     a_nxt = a_n2;
                 }
+                pa += kHLT * 64;
                 const bool qual = tm <= best + delta;
 #pragma unroll
                 for (int s = kHFifo - 1; s > 0; --s) {
@@ -1234,7 +1252,44 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     if (p.partials) {
         __shared__ double sm[kHThreads / 64];
         const double tot = block_sum<kHThreads>(acc, sm);
-        if (tid == 0) p.partials[(size_t)c * p.tiles + tile] = tot;
+        if (!p.ticket) {
+            if (tid == 0) p.partials[(size_t)c * p.tiles + tile] = tot;
+        } else {
+            // ---- fused finalisation: placement-independent hand-off through 8-byte agent-scope atomics
+            //      (write-through store -> drain -> relaxed ticket; the last arriver reads with agent-scope
+            //      loads), MI355X_MICROARCH.md "valid forms".  Fixed summation order => deterministic.
+            __shared__ int is_last;
+            unsigned long long *pp = reinterpret_cast<unsigned long long *>(p.partials);
+            if (tid == 0) {
+                __hip_atomic_store(&pp[(size_t)c * p.tiles + tile], __builtin_bit_cast(unsigned long long, tot),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned int old = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                is_last = old == p.nvalid - 1;
+            }
+            __syncthreads();
+            if (is_last) {
+                double tsum[2];
+                for (int dd = 0; dd < 2; ++dd) {
+                    const int nt = dd ? p.tiles_y : p.tiles_x;
+                    const long long n = (long long)p.B * nt;
+                    double a = 0.0;
+                    for (long long k = tid; k < n; k += kHThreads) {
+                        const int bb = (int)(k / nt), tt = (int)(k % nt);
+                        const unsigned long long v = __hip_atomic_load(&pp[((size_t)(dd * p.B + bb)) * p.tiles + tt],
+                                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a += __builtin_bit_cast(double, v);
+                    }
+                    __syncthreads();
+                    tsum[dd] = block_sum<kHThreads>(a, sm);
+                }
+                if (tid == 0) {
+                    if (p.sums_out) { p.sums_out[0] = tsum[0]; p.sums_out[1] = tsum[1]; }
+                    if (p.loss_out) *p.loss_out = chamfer_loss_from_sums(tsum[0], tsum[1], p.N, p.M, 3, p.Bg, p.w1, p.w2);
+                    __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for reuse
+                }
+            }
+        }
     }
     FX3D_PROBE_MARK(12);
 }
@@ -1481,10 +1536,23 @@ fx3d_status check_shapes(const char *fn, const void *x, int N, const void *y, in
     return FX3D_OK;
 }
 
+struct Fused {
+    unsigned int *ticket;
+    unsigned int nvalid;
+    double *sums_out;
+    float *loss_out;
+    float w1, w2;
+    long long Bg;
+};
+
 fx3d_status run_nn1(const float *x, int N, const float *y, int M, int B, int D, int32_t *idx_x,
                     int32_t *idx_y, float *dmin_x, float *dmin_y, double *partials,
-                    const Plan &pl, hipStream_t st) {
+                    const Plan &pl, hipStream_t st, const Fused *fu = nullptr) {
     Nn1Params p{};
+    if (fu) {
+        p.ticket = fu->ticket; p.nvalid = fu->nvalid; p.sums_out = fu->sums_out; p.loss_out = fu->loss_out;
+        p.w1 = fu->w1; p.w2 = fu->w2; p.Bg = fu->Bg;
+    }
     p.x = x; p.y = y; p.N = N; p.M = M; p.B = B;
     p.idx_x = idx_x; p.idx_y = idx_y; p.dmin_x = dmin_x; p.dmin_y = dmin_y;
     p.partials = partials;
@@ -1535,6 +1603,34 @@ fx3d_status fx3d_chamfer_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_
     return FX3D_OK;
 }
 
+// Library-owned arrival counters for the fused finalisation: zeroed once at allocation, every
+// launch returns its counter to zero.  One slot per launch, round robin over kTickets slots (two
+// launches share a slot only if more than kTickets launches are simultaneously in flight).
+static constexpr int kTickets = 1024;
+static unsigned int *ticket_slot(fx3d_status *rc) {
+    static thread_local int cached_dev = -1;
+    static std::mutex mu;
+    static unsigned int *pools[64] = {nullptr};
+    static std::atomic<unsigned int> next{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { *rc = FX3D_ERR_HIP; return nullptr; }
+    (void)cached_dev;
+    if (!pools[dev]) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!pools[dev]) {
+            unsigned int *pnew = nullptr;
+            if (hipMalloc(&pnew, kTickets * sizeof(unsigned int)) != hipSuccess ||
+                hipMemset(pnew, 0, kTickets * sizeof(unsigned int)) != hipSuccess) {
+                set_error("ticket pool allocation failed");
+                *rc = FX3D_ERR_OOM;
+                return nullptr;
+            }
+            pools[dev] = pnew;
+        }
+    }
+    return pools[dev] + (next.fetch_add(1) % kTickets);
+}
+
 static fx3d_status chamfer_common(const float *x, int N, const float *y, int M, int B, int D,
                                   double *sums_dev, float *loss_dev, long long Bg, float w1,
                                   float w2, int32_t *idx_x, int32_t *idx_y, void *ws,
@@ -1550,6 +1646,14 @@ static fx3d_status chamfer_common(const float *x, int N, const float *y, int M, 
         return FX3D_ERR_WORKSPACE;
     }
     double *partials = reinterpret_cast<double *>(ws);
+    if (pl.variant == 3 && D == 3) {  // one launch: the last block reduces the partials
+        fx3d_status trc = FX3D_OK;
+        unsigned int *ticket = ticket_slot(&trc);
+        if (!ticket) return trc;
+        Fused fu{ticket, (unsigned int)((long long)B * tx + (long long)B * ty),
+                 sums_dev ? sums_dev : partials + (size_t)2 * B * tiles, loss_dev, w1, w2, Bg};
+        return run_nn1(x, N, y, M, B, D, idx_x, idx_y, nullptr, nullptr, partials, pl, st, &fu);
+    }
     rc = run_nn1(x, N, y, M, B, D, idx_x, idx_y, nullptr, nullptr, partials, pl, st);
     if (rc) return rc;
     FinalizeParams f{};

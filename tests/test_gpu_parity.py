@@ -103,6 +103,52 @@ def test_ties_lowest_index_wins(gpu_fx, oracle):
     assert np.all(ix.to_host() == 0)
 
 
+def _shell(rng, n, centre, radius):
+    v = rng.standard_normal((3, n)).astype(np.float64)
+    v /= np.linalg.norm(v, axis=0)
+    return (centre[:, None] + radius * v).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", ["offset1000", "tiny_extent", "far_apart", "far_apart_swapped", "duplicates",
+                                  "shell", "anisotropic", "huge_values", "multi_chunk_offset"])
+def test_filter_robustness(gpu_fx, oracle, case):
+    """Inputs chosen to stress the 16-bit-split filter + error band + exact re-scan: data far from the
+    origin (Float32 spacing comparable to the NN gaps -> many near ties), tiny extents, clouds far from
+    each other (fp16 range guard -> exact path), duplicate points, equidistant shells, extreme aspect
+    ratios, very large magnitudes.  Indices must stay bit-identical to the oracle."""
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    N, M, B = 1500, 4200, 2
+    x, y = rng.random((3, N, B), dtype=np.float32), rng.random((3, M, B), dtype=np.float32)
+    if case == "offset1000":
+        x, y = x + np.float32(1000.0), y + np.float32(1000.0)
+    elif case == "tiny_extent":
+        x, y = x * np.float32(1e-6) + np.float32(5.0), y * np.float32(1e-6) + np.float32(5.0)
+    elif case == "far_apart":
+        y = y * np.float32(1e-3) + np.float32(1e4)
+    elif case == "far_apart_swapped":
+        x = x * np.float32(1e-3) - np.float32(3e3)
+    elif case == "duplicates":
+        y[:, ::2, :] = y[:, 1::2, :]
+        x[:, :700, :] = y[:, :700, :]
+    elif case == "shell":
+        for b in range(B):
+            c = rng.random(3) + 2.0
+            y[:, :, b] = _shell(rng, M, c, 0.75)
+            x[:, :, b] = (c[:, None] + 1e-3 * rng.standard_normal((3, N))).astype(np.float32)
+    elif case == "anisotropic":
+        sc = np.array([1e3, 1.0, 1e-3], np.float32)[:, None, None]
+        x, y = x * sc, y * sc
+    elif case == "huge_values":
+        x, y = x * np.float32(1e15) + np.float32(3e15), y * np.float32(1e15) + np.float32(3e15)
+    elif case == "multi_chunk_offset":
+        M2 = 9000
+        y = rng.random((3, M2, B), dtype=np.float32) - np.float32(250.0)
+        x = x - np.float32(250.0)
+    x, y = np.asfortranarray(x), np.asfortranarray(y)
+    _check_nn(gpu_fx, oracle, x, y)
+    _check_chamfer(gpu_fx, oracle, x, y)
+
+
 @pytest.mark.parametrize("D", [1, 2, 5, 64])
 def test_other_dimensions(gpu_fx, oracle, D):
     """D=2 clouds are allowed (src/rep/pcloud.jl:8-9; the *3 factor is kept, SURVEY 3.1);
