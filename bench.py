@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the multi-GPU code path (torch.distributed/RCCL all-reduce) even at world size 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -45,10 +47,15 @@ def main():
     import numpy as np
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
 
     import flux3d_jl_amd as fx
@@ -62,7 +69,7 @@ def main():
     x = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_A, DIM, NPTS, B_PER_GPU, batch_offset=rank * B_PER_GPU))
     y = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_B, DIM, MPTS, B_PER_GPU, batch_offset=rank * B_PER_GPU))
 
-    if world > 1:
+    if use_dist:
         sharded = ShardedChamfer()
         bench_stream = fx.Stream(torch.cuda.current_stream().cuda_stream)
 
@@ -75,6 +82,7 @@ def main():
             torch.cuda.synchronize()
 
         def read_loss():
+            sharded.synchronize()
             return float(sharded.loss.item())
     else:
         bench_stream = fx.Stream.create()
@@ -107,7 +115,7 @@ def main():
     sync_all()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())

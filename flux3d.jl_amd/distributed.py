@@ -57,28 +57,56 @@ class ShardedChamfer:
     """chamfer_distance over a batch sharded across the ranks of a torch.distributed group.
 
     Every rank passes ITS shard (device arrays (3,N,Bs), (3,M,Bs)) and the global batch size;
-    every rank gets the global loss.  One all-reduce of 16 bytes per call (latency bound)."""
+    every rank gets the global loss.  One all-reduce of 16 bytes per call (latency bound, ~10 us over
+    xGMI).  ``overlap=True`` issues it on a side stream so that it overlaps the NEXT call's kernel
+    (2 result slots, event-ordered); measured on MI355X the extra host work (events, stream switches)
+    makes a 66 us step host-bound from Python, so the default keeps everything on one stream."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, overlap=False):
         import torch
         import torch.distributed as dist
-        self.torch, self.dist, self.group = torch, dist, group
-        self.sums = torch.zeros(2, dtype=torch.float64, device="cuda")
-        self.loss = torch.zeros(1, dtype=torch.float32, device="cuda")
-        self._sums = DeviceArray.wrap(self.sums, shape=(2,), dtype=np.float64)
-        self._loss = DeviceArray.wrap(self.loss, shape=(1,), dtype=np.float32)
+        self.torch, self.dist, self.group, self.overlap = torch, dist, group, overlap
+        self.nslot = 2 if overlap else 1
+        self.sums = [torch.zeros(2, dtype=torch.float64, device="cuda") for _ in range(self.nslot)]
+        self.losses = [torch.zeros(1, dtype=torch.float32, device="cuda") for _ in range(self.nslot)]
+        self._sums = [DeviceArray.wrap(t, shape=(2,), dtype=np.float64) for t in self.sums]
+        self._loss = [DeviceArray.wrap(t, shape=(1,), dtype=np.float32) for t in self.losses]
+        self.comm = torch.cuda.Stream() if overlap else None
+        self.done = [torch.cuda.Event() for _ in range(self.nslot)]
+        self.k = 0
+        self.loss = self.losses[0]  # most recent result
 
     def __call__(self, x_shard, y_shard, B_global, w1=1.0, w2=1.0, sync=True):
         torch, dist = self.torch, self.dist
-        # run on torch's current stream so the collective is ordered after the kernel
-        with stream(Stream(torch.cuda.current_stream().cuda_stream)):
-            D, N, Bs = x_shard.shape
-            M = y_shard.shape[1]
+        i = self.k % self.nslot
+        self.k += 1
+        main = torch.cuda.current_stream()
+        D, N, Bs = x_shard.shape
+        M = y_shard.shape[1]
+        if self.overlap and self.k > self.nslot:
+            main.wait_event(self.done[i])  # slot i was last used two calls ago
+        with stream(Stream(main.cuda_stream)):
             if Bs > 0:
-                chamfer_sums(x_shard, y_shard, out=self._sums, sync=False)
+                chamfer_sums(x_shard, y_shard, out=self._sums[i], sync=False)
             else:
-                self.sums.zero_()  # B < world: idle ranks contribute zeros
-            if dist.is_initialized() and dist.get_world_size(self.group) > 1:
-                dist.all_reduce(self.sums, op=dist.ReduceOp.SUM, group=self.group)
-            chamfer_finalize(self._sums, N, M, B_global, D, w1, w2, out=self._loss, sync=False)
-        return float(self.loss.item()) if sync else self.loss
+                self.sums[i].zero_()  # B < world: idle ranks contribute zeros
+        side = self.comm if self.overlap else main
+        if self.overlap:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+        with torch.cuda.stream(side):
+            if dist.is_initialized():
+                dist.all_reduce(self.sums[i], op=dist.ReduceOp.SUM, group=self.group)
+            with stream(Stream(side.cuda_stream)):
+                chamfer_finalize(self._sums[i], N, M, B_global, D, w1, w2, out=self._loss[i], sync=False)
+            self.done[i].record(side)
+        self.loss = self.losses[i]
+        if sync:
+            self.done[i].synchronize()
+            return float(self.loss.item())
+        return self.loss
+
+    def synchronize(self):
+        for e in self.done:
+            e.synchronize()
