@@ -14,7 +14,7 @@ _lib.load()  # fail loudly (ImportError) if the HIP library has not been built
 
 from ._lib import Flux3DHipError, LIB_PATH  # noqa: E402
 from .device import (DeviceArray, Event, Stream, cpu, current_stream, device_count,  # noqa: E402
-                     device_name, functional, gpu, set_device, stream, synchronize)
+                     device_name, empty_cache, functional, gpu, set_device, stream, synchronize)
 from .rep import (PointCloud, TriMesh, get_edges_packed, get_edges_to_key, get_faces_list,  # noqa: E402
                   get_faces_packed, get_faces_padded, get_faces_to_edges_packed,
                   get_laplacian_packed, get_verts_list, get_verts_packed, get_verts_padded,

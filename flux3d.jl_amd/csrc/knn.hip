@@ -13,6 +13,7 @@
 // src/models/dgcnn.jl:121): the query lives in LDS transposed ([d][thread], conflict-free), the
 // candidate row is read through the scalar/L1 path (same address for every lane).
 #include <cmath>
+#include <cstdlib>
 
 #include "fx3d_common.h"
 
@@ -129,6 +130,172 @@ __global__ __launch_bounds__(kThreads) void knn_generic_kernel(const float *__re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// knn_wave_d3_kernel: one WAVE per query (D = 3).  The 64 lanes split the candidates (16 per lane and
+// 1024-candidate chunk, held in registers and reused for every query of the wave), so a cloud of
+// 1024 points keeps 4 waves per SIMD busy where the thread-per-query kernel had half a wave.
+//   per query and chunk:
+//     1. 16 exact distances per lane (the oracle's unfused Float32 form)
+//     2. threshold tau: the current kk-th best; for the first chunk the kk-th smallest of the 64
+//        lane minima (an upper bound of the kk-th smallest overall, typically admitting ~1.2 kk points)
+//     3. candidates with d <= tau are compacted (ballot + mbcnt) into a per-wave LDS list
+//     4. list + current best list (<= 64 keys, one per lane) are sorted by a 64-lane bitonic network
+//        on the key (distance, index) -- exactly the reference ordering -- and the first kk survive.
+// Output is bit-identical to fx3d_oracle_knn (same arithmetic, same (distance, index) order).
+constexpr int kWQ = 8;           // queries per wave
+constexpr int kWThreads = 256;   // 4 waves
+
+struct Key { float d; int j; };
+__device__ __forceinline__ bool key_less(float d, int j, float od, int oj) { return d < od || (d == od && j < oj); }
+
+// ascending bitonic sort of one (d, j) key per lane
+__device__ __forceinline__ void bitonic64(float &d, int &j, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int s = k >> 1; s > 0; s >>= 1) {
+            const float od = __shfl_xor(d, s, 64);
+            const int oj = __shfl_xor(j, s, 64);
+            const bool up = (lane & k) == 0 || k == 64;   // final merge: ascending everywhere
+            const bool lower = (lane & s) == 0;
+            const bool take_min = lower == up;
+            const bool o_less = key_less(od, oj, d, j);
+            const bool swap = take_min ? o_less : !o_less && !(od == d && oj == j);
+            d = swap ? od : d;
+            j = swap ? oj : j;
+        }
+    }
+}
+__device__ __forceinline__ void bitonic64f(float &v, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int s = k >> 1; s > 0; s >>= 1) {
+            const float o = __shfl_xor(v, s, 64);
+            const bool up = (lane & k) == 0 || k == 64;
+            const bool lower = (lane & s) == 0;
+            v = (lower == up) ? fminf(v, o) : fmaxf(v, o);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kWThreads) void knn_wave_d3_kernel(const float *__restrict__ x, int N,
+                                                                const float *__restrict__ y, int M, int B,
+                                                                int k, int drop, int32_t *__restrict__ idx,
+                                                                float *__restrict__ dist) {
+    __shared__ float lst_d[kWThreads / 64][64];
+    __shared__ int lst_j[kWThreads / 64][64];
+    __shared__ float best_d[kWThreads / 64][kWQ][64];   // per-query best lists across chunks
+    __shared__ int best_j[kWThreads / 64][kWQ][64];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int kk = k + drop;
+    const float *xb = x + (size_t)b * N * 3, *yb = y + (size_t)b * M * 3;
+    const int q0 = (blockIdx.x * (kWThreads / 64) + wv) * kWQ;
+    if (q0 >= N) return;  // wave-uniform; no block-level sync below
+#pragma unroll
+    for (int qq = 0; qq < kWQ; ++qq) { best_d[wv][qq][lane] = INFINITY; best_j[wv][qq][lane] = 0x7fffffff; }
+
+    for (int j0 = 0; j0 < M; j0 += 1024) {
+        float cx[16], cy[16], cz[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int j = j0 + lane + 64 * i;
+            if (j < M) {
+                cx[i] = yb[(size_t)j * 3]; cy[i] = yb[(size_t)j * 3 + 1]; cz[i] = yb[(size_t)j * 3 + 2];
+            } else {
+                cx[i] = INFINITY; cy[i] = INFINITY; cz[i] = INFINITY;  // d = +inf: never selected
+            }
+        }
+#pragma unroll 1
+        for (int qq = 0; qq < kWQ; ++qq) {
+            const int qi = q0 + qq;
+            if (qi >= N) break;
+            const float qx = xb[(size_t)qi * 3], qy = xb[(size_t)qi * 3 + 1], qz = xb[(size_t)qi * 3 + 2];  // uniform
+            float d[16];
+            float lmin = INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float t0 = qx - cx[i], t1 = qy - cy[i], t2 = qz - cz[i];
+                d[i] = ((t0 * t0) + (t1 * t1)) + (t2 * t2);
+                lmin = fminf(lmin, d[i]);
+            }
+            float bd = best_d[wv][qq][lane];
+            int bj = best_j[wv][qq][lane];
+            float tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bd), kk - 1));
+            if (j0 == 0) {  // kk-th smallest lane minimum bounds the kk-th smallest distance
+                float v = lmin;
+                bitonic64f(v, lane);
+                tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), kk - 1));
+            }
+            int cnt = 0;
+            const int cap = 64 - kk;  // list + best list must fit one key per lane
+            if (cap > 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    bool pred = d[i] <= tau && d[i] < INFINITY;
+                    unsigned long long bal = __ballot(pred);
+                    while (bal) {  // usually one pass; more only when > cap candidates qualify
+                        const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
+                                              __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
+                        const bool put = pred && pos < cap;
+                        if (put) { lst_d[wv][pos] = d[i]; lst_j[wv][pos] = j0 + lane + 64 * i; }
+                        const int np = __builtin_popcountll(bal);
+                        const bool overflow = cnt + np > cap;
+                        cnt = overflow ? cap : cnt + np;
+                        pred = pred && !put;
+                        if (overflow) {  // flush: merge the full list into the best list, tighten tau
+                            float sd = lane < kk ? bd : (lane - kk < cnt ? lst_d[wv][lane - kk] : INFINITY);
+                            int sj = lane < kk ? bj : (lane - kk < cnt ? lst_j[wv][lane - kk] : 0x7fffffff);
+                            bitonic64(sd, sj, lane);
+                            bd = lane < kk ? sd : INFINITY;
+                            bj = lane < kk ? sj : 0x7fffffff;
+                            tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sd), kk - 1));
+                            cnt = 0;
+                            pred = pred && d[i] <= tau;
+                        }
+                        bal = __ballot(pred);
+                    }
+                }
+            }
+            if (cnt > 0 || cap == 0) {
+                float sd, sj_f;
+                int sj;
+                if (cap > 0) {
+                    sd = lane < kk ? bd : (lane - kk < cnt ? lst_d[wv][lane - kk] : INFINITY);
+                    sj = lane < kk ? bj : (lane - kk < cnt ? lst_j[wv][lane - kk] : 0x7fffffff);
+                    bitonic64(sd, sj, lane);
+                    bd = sd; bj = sj;
+                } else {
+                    // kk == 64: no room for a list; merge the chunk 64 candidates at a time
+#pragma unroll 1
+                    for (int i = 0; i < 16; ++i) {
+                        float nd = d[i];
+                        int nj = nd < INFINITY ? j0 + lane + 64 * i : 0x7fffffff;
+                        bitonic64(nd, nj, lane);                      // ascending new batch
+                        const float rd = __shfl(nd, 63 - lane, 64);   // reversed
+                        const int rj = __shfl(nj, 63 - lane, 64);
+                        const bool o_less = key_less(rd, rj, bd, bj);
+                        bd = o_less ? rd : bd;                         // lower half of the union (bitonic)
+                        bj = o_less ? rj : bj;
+                        bitonic64(bd, bj, lane);
+                    }
+                }
+                (void)sj_f;
+            }
+            best_d[wv][qq][lane] = bd;
+            best_j[wv][qq][lane] = bj;
+            if (j0 + 1024 >= M) {  // last chunk: lanes drop..drop+k-1 hold the answer
+                const int r = lane - drop;
+                if (r >= 0 && r < k) {
+                    idx[((size_t)b * N + qi) * k + r] = bj;
+                    if (dist) dist[((size_t)b * N + qi) * k + r] = bd;
+                }
+            }
+        }
+    }
+}
+
 // out[(((b*N+i)*k + r)*F + f] = x[(b*N + idx[(b*N+i)*k + r])*F + f]
 __global__ __launch_bounds__(kThreads) void knn_gather_kernel(const float *__restrict__ x, int N, int B,
                                                               int F, int k,
@@ -151,7 +318,12 @@ fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int 
                        int32_t *idx, float *dist, hipStream_t st) {
     dim3 grid((N + kThreads - 1) / kThreads, B);
     ProfileScope prof("knn", st);
-    if (D == 3) {
+    static const bool legacy = [] { const char *e = getenv("FX3D_KNN_LEGACY"); return e && atoi(e); }();
+    if (D == 3 && !legacy) {
+        const int qpb = (kWThreads / 64) * kWQ;
+        hipLaunchKernelGGL(knn_wave_d3_kernel, dim3((N + qpb - 1) / qpb, B), dim3(kWThreads), 0, st, x, N, y, M, B, k,
+                           drop, idx, dist);
+    } else if (D == 3) {
         hipLaunchKernelGGL(knn_d3_kernel<KMAX>, grid, dim3(kThreads), 0, st, x, N, y, M, B, k, drop, idx, dist);
     } else {
         const size_t lds = sizeof(float) * (size_t)D * kThreads;

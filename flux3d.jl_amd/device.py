@@ -114,27 +114,94 @@ class Event:
             self.handle = None
 
 
+class _Pool:
+    """Caching device allocator (what CUDA.jl's pool / torch's caching allocator give the reference's
+    GPU path): hipMalloc/hipFree synchronise the device and cost tens of microseconds, so freed
+    blocks are kept in power-of-two size classes and reused.  ``empty_cache()`` returns them."""
+
+    def __init__(self, limit_bytes=4 << 30):
+        self.free = {}
+        self.cached = 0
+        self.limit = limit_bytes
+
+    @staticmethod
+    def _cls(nbytes):
+        n = 256
+        while n < nbytes:
+            n <<= 1
+        return n
+
+    def alloc(self, nbytes):
+        c = self._cls(max(int(nbytes), 1))
+        lst = self.free.get(c)
+        if lst:
+            self.cached -= c
+            return lst.pop(), c
+        p = C.c_void_p()
+        try:
+            _lib.call("fx3d_malloc", C.byref(p), c)
+        except _lib.Flux3DHipError:
+            self.empty()
+            _lib.call("fx3d_malloc", C.byref(p), c)
+        return p.value, c
+
+    def release(self, ptr, c):
+        if self.cached + c > self.limit:
+            _lib.load().fx3d_free(ptr)
+            return
+        self.free.setdefault(c, []).append(ptr)
+        self.cached += c
+
+    def empty(self):
+        lib = _lib.load()
+        for lst in self.free.values():
+            for ptr in lst:
+                lib.fx3d_free(ptr)
+        self.free.clear()
+        self.cached = 0
+
+
+_pools = {}
+
+
+def _pool():
+    d = C.c_int32(0)
+    _lib.load().fx3d_get_device(C.byref(d))
+    pl = _pools.get(d.value)
+    if pl is None:
+        pl = _pools[d.value] = _Pool()
+    return pl
+
+
+def empty_cache():
+    """Return every cached block to the driver (cf. CUDA.reclaim / torch.cuda.empty_cache)."""
+    for pl in _pools.values():
+        pl.empty()
+
+
 class DeviceArray:
     """Device buffer with a Julia-style (column-major) shape.  ``to_host()`` returns an
     F-contiguous numpy array of the same shape: byte-identical to the Julia ``Array``."""
 
-    __slots__ = ("ptr", "shape", "dtype", "_owned", "_keep")
+    __slots__ = ("ptr", "shape", "dtype", "_owned", "_keep", "_pool", "_cls")
 
-    def __init__(self, ptr, shape, dtype, owned=False, keep=None):
+    def __init__(self, ptr, shape, dtype, owned=False, keep=None, pool=None, cls=0):
         self.ptr = ptr
         self.shape = tuple(int(s) for s in shape)
         self.dtype = np.dtype(dtype)
         self._owned = owned
         self._keep = keep
+        self._pool = pool
+        self._cls = cls
 
     # -- construction ---------------------------------------------------------------------
     @classmethod
     def empty(cls, shape, dtype=np.float32):
         shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
-        p = C.c_void_p()
-        _lib.call("fx3d_malloc", C.byref(p), max(nbytes, 1))
-        return cls(p.value, shape, dtype, owned=True)
+        pl = _pool()
+        ptr, c = pl.alloc(nbytes)
+        return cls(ptr, shape, dtype, owned=True, pool=pl, cls=c)
 
     @classmethod
     def zeros(cls, shape, dtype=np.float32):
@@ -207,7 +274,12 @@ class DeviceArray:
     def __del__(self):
         if getattr(self, "_owned", False) and self.ptr:
             try:
-                _lib.load().fx3d_free(self.ptr)
+                # stream-ordered reuse is safe here: every op of this package is enqueued in program
+                # order, and a recycled block is only touched by later-enqueued work
+                if self._pool is not None:
+                    self._pool.release(self.ptr, self._cls)
+                else:
+                    _lib.load().fx3d_free(self.ptr)
             except Exception:
                 pass
             self.ptr = None

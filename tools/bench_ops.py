@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Timing of every op on the hot path at the BASELINE.json configs (beyond the headline bench.py):
+C1, C2 (+indices, +backward), C3 (sample_points -> chamfer on B=8 teapot-class meshes, 5000 samples),
+C4 (kNN k=20, B=32x1024, D=3 and D=64, + graph gather), mesh losses, and the reference harness's own
+degenerate input p_i=(i,i,i)/n (benchmarks/metrics.jl:11-15) for comparison with BASELINE.md.
+HIP events on the op's stream, min/median over repeats; CPU = oracle on one core (bounded samples).
+
+  python tools/bench_ops.py [--cpu]      -> one JSON object per line
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import flux3d_jl_amd as fx  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def gpu_time(fn, reps=30, warm=3):
+    s = fx.Stream.create()
+    with fx.stream(s):
+        for _ in range(warm):
+            fn()
+        s.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = fx.Event(), fx.Event()
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_ms(e1) * 1e3)
+    return float(np.min(ts)), float(np.median(ts))
+
+
+def cpu_time(fn, reps=1):
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best * 1e6
+
+
+def emit(name, us_min, us_med, **kw):
+    d = {"op": name, "gpu_us_min": round(us_min, 2), "gpu_us_median": round(us_med, 2)}
+    d.update(kw)
+    print(json.dumps(d), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle (1 core)")
+    args = ap.parse_args()
+    orc = None
+    if args.cpu:
+        from oracle import oracle as orc
+
+    # ---- chamfer -------------------------------------------------------------------------------------
+    for tag, B, N in (("C1 chamfer fwd B=2 N=M=1024", 2, 1024), ("C2 chamfer fwd B=32 N=M=4096", 32, 4096)):
+        x = fx.synth.uniform_cloud(fx.synth.SEED_A, 3, N, B)
+        y = fx.synth.uniform_cloud(fx.synth.SEED_B, 3, N, B)
+        dx, dy = fx.gpu(x), fx.gpu(y)
+        out = fx.DeviceArray.empty((1,), np.float32)
+        mn, md = gpu_time(lambda: fx.chamfer_distance(dx, dy, loss_out=out, sync=False))
+        kw = {"pairs_per_s": B * N * N / (mn * 1e-6)}
+        if orc:
+            kw["cpu_kdtree_us"] = cpu_time(lambda: orc.chamfer_distance(x, y, kdtree=True))
+        emit(tag, mn, md, **kw)
+        mn, md = gpu_time(lambda: fx.chamfer_distance(dx, dy, return_indices=True, loss_out=out, sync=False))
+        emit(tag + " +indices", mn, md)
+        _, ix, iy = fx.chamfer_distance(dx, dy, return_indices=True)
+        mn, md = gpu_time(lambda: fx.chamfer_distance_grad(dx, dy, ix, iy))
+        emit(tag.replace("fwd", "bwd"), mn, md, bytes=4 * 3 * B * 2 * N * 4)
+    # reference harness input: B=1, A == B, p_i = (i,i,i)/n
+    for n in (64, 256, 1024, 4096, 16384):
+        p = fx.gpu(fx.synth.reference_bench_cloud(n))
+        out = fx.DeviceArray.empty((1,), np.float32)
+        mn, md = gpu_time(lambda: fx.chamfer_distance(p, p, loss_out=out, sync=False))
+        emit(f"reference-harness chamfer fwd n={n}", mn, md, ref_cpu_ms_plot={64: .065, 256: .19, 1024: .8, 4096: 3.2, 16384: 13}[n],
+             ref_gpu_ms_plot={64: .33, 256: .38, 1024: .75, 4096: 6, 16384: 85}[n])
+
+    # ---- C4 kNN ---------------------------------------------------------------------------------------
+    x = fx.synth.uniform_cloud(0x5EED0004, 3, 1024, 32)
+    dx = fx.gpu(x)
+    mn, md = gpu_time(lambda: fx.knn(dx, 20, drop_first=True))
+    kw = {"pairs_per_s": 32 * 1024 * 1024 / (mn * 1e-6)}
+    if orc:
+        kw["cpu_bruteforce_us"] = cpu_time(lambda: orc.knn(x[:, :, :4], 20, drop_first=True)) * 8
+    emit("C4 kNN k=20 drop-first B=32 N=1024 D=3", mn, md, **kw)
+    idx = fx.knn(dx, 20, drop_first=True, return_dist=False)
+    mn, md = gpu_time(lambda: fx.knn_gather(dx, idx))
+    emit("C4 knn_gather F=3", mn, md, GBps=(4 * 3 * 20 * 1024 * 32 + 4 * 20 * 1024 * 32) / (mn * 1e-6) / 1e9)
+    f = np.asfortranarray(np.random.default_rng(1).standard_normal((64, 1024, 32)).astype(np.float32))
+    df = fx.gpu(f)
+    mn, md = gpu_time(lambda: fx.knn(df, 20, drop_first=True), reps=10)
+    emit("C4' kNN k=20 D=64 (second EdgeConv)", mn, md, pairs_per_s=32 * 1024 * 1024 / (mn * 1e-6))
+    idx = fx.knn(df, 20, drop_first=True, return_dist=False)
+    mn, md = gpu_time(lambda: fx.knn_gather(df, idx))
+    emit("C4' knn_gather F=64", mn, md, GBps=(4 * 64 * 20 * 1024 * 32 * 2) / (mn * 1e-6) / 1e9)
+
+    # ---- C3 meshes -------------------------------------------------------------------------------------
+    t = os.path.join(GOLD, "teapot.obj")
+    m8 = fx.gpu(fx.load_trimesh(*[t] * 8))
+    mn, md = gpu_time(lambda: fx.sample_points(m8, 5000, seed=3))
+    kw = {}
+    if orc:
+        vp, fp = m8.get_verts_padded_host(), m8.get_faces_padded().astype(np.int64) - 1
+        kw["cpu_us"] = cpu_time(lambda: orc.sample_points_seeded(vp, fp, m8._faces_len, 5000, 3))
+    emit("C3 sample_points B=8 teapot n=5000", mn, md, **kw)
+    out = fx.DeviceArray.empty((1,), np.float32)
+    mn, md = gpu_time(lambda: fx.chamfer_distance(m8, m8, 5000, seed=5, loss_out=out, sync=False))
+    emit("C3 chamfer_distance(mesh, mesh, 5000) B=8 (2 samplings + chamfer)", mn, md, pairs_per_s=8 * 5000 * 5000 / (mn * 1e-6))
+    mn, md = gpu_time(lambda: fx.laplacian_loss(m8, sync=False))
+    emit("laplacian_loss B=8 teapot", mn, md)
+    mn, md = gpu_time(lambda: fx.edge_loss(m8, sync=False))
+    emit("edge_loss B=8 teapot", mn, md)
+    mn, md = gpu_time(lambda: fx.laplacian_loss_grad(m8))
+    emit("laplacian_loss bwd B=8 teapot", mn, md)
+    mn, md = gpu_time(lambda: fx.edge_loss_grad(m8))
+    emit("edge_loss bwd B=8 teapot", mn, md)
+    mn, md = gpu_time(lambda: fx.compute_faces_areas_packed(m8))
+    emit("faces_areas_packed B=8 teapot", mn, md)
+
+
+if __name__ == "__main__":
+    main()
