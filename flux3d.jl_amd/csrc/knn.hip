@@ -296,6 +296,169 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_d3_kernel(const float *__r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// knn_wave_generic_kernel: any D (the second EdgeConv runs kNN in 64-D feature space,
+// src/models/dgcnn.jl:121).  Same wave-per-query selection as knn_wave_d3_kernel; the distance stage
+// works on candidate tiles of kGT rows staged in LDS with a padded row stride (D+1 floats: lane j reads
+// row j, bank (j+d)%32 -- conflict-free), each wave evaluating its kGQ queries against the tile (query
+// values are wave-uniform: scalar loads).  Distances are the oracle's: s = s + t*t in dimension order.
+// Per-query state (best list, pending list, count, threshold) lives in LDS across tiles; pending
+// candidates are merged lazily (when the list is full, and once at the end).
+constexpr int kGT = 128;   // candidates per tile (2 per lane)
+constexpr int kGQ = 4;     // queries per wave
+
+__global__ __launch_bounds__(kWThreads) void knn_wave_generic_kernel(const float *__restrict__ x, int N,
+                                                                     const float *__restrict__ y, int M, int B,
+                                                                     int D, int k, int drop,
+                                                                     int32_t *__restrict__ idx,
+                                                                     float *__restrict__ dist) {
+    extern __shared__ __attribute__((aligned(16))) float gl[];
+    constexpr int NW = kWThreads / 64;
+    const int RS = D + 1;                       // padded row stride
+    float *tile = gl;                           // [kGT][RS]
+    float *bestd = tile + kGT * RS;             // [NW][kGQ][64]
+    int *bestj = reinterpret_cast<int *>(bestd + NW * kGQ * 64);
+    float *lstd = reinterpret_cast<float *>(bestj + NW * kGQ * 64);
+    int *lstj = reinterpret_cast<int *>(lstd + NW * kGQ * 64);
+    float *taus = reinterpret_cast<float *>(lstj + NW * kGQ * 64);   // [NW][kGQ]
+    int *cnts = reinterpret_cast<int *>(taus + NW * kGQ);            // [NW][kGQ]
+    float4 *qs4 = reinterpret_cast<float4 *>(cnts + NW * kGQ);       // [NW][D] : the wave's kGQ=4 queries, interleaved
+
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int kk = k + drop, cap = 64 - kk;
+    const float *xb = x + (size_t)b * N * D, *yb = y + (size_t)b * M * D;
+    const int q0 = (blockIdx.x * NW + wv) * kGQ;
+#pragma unroll
+    for (int qq = 0; qq < kGQ; ++qq) {
+        bestd[(wv * kGQ + qq) * 64 + lane] = INFINITY;
+        bestj[(wv * kGQ + qq) * 64 + lane] = 0x7fffffff;
+        if (lane == 0) { taus[wv * kGQ + qq] = INFINITY; cnts[wv * kGQ + qq] = 0; }
+    }
+    for (int d = lane; d < D; d += 64) {  // the wave's queries, component-interleaved: one b128 broadcast per d
+        float4 v;
+        float *pv = &v.x;
+#pragma unroll
+        for (int qq = 0; qq < kGQ; ++qq) {
+            const int qi = q0 + qq < N ? q0 + qq : N - 1;
+            pv[qq] = xb[(size_t)qi * D + d];
+        }
+        qs4[wv * D + d] = v;
+    }
+
+    for (int j0 = 0; j0 < M; j0 += kGT) {
+        const int cntc = (M - j0) < kGT ? (M - j0) : kGT;
+        __syncthreads();
+        for (int e = tid; e < cntc * D; e += kWThreads) {  // coalesced: the tile is contiguous in memory
+            const int r = e / D, d = e - r * D;
+            tile[r * RS + d] = yb[(size_t)j0 * D + e];
+        }
+        __syncthreads();
+        if (q0 < N) {
+            // distances of the wave's 4 queries to its 2 tile rows per lane, all dims
+            float acc0[kGQ], acc1[kGQ];
+#pragma unroll
+            for (int qq = 0; qq < kGQ; ++qq) { acc0[qq] = 0.0f; acc1[qq] = 0.0f; }
+            {
+                const float *r0 = tile + lane * RS, *r1 = tile + (lane + 64) * RS;
+                const float4 *qw = qs4 + wv * D;
+#pragma unroll 4
+                for (int d = 0; d < D; ++d) {
+                    const float4 qd = qw[d];
+                    const float c0 = r0[d], c1 = r1[d];
+                    const float qv4[4] = {qd.x, qd.y, qd.z, qd.w};
+#pragma unroll
+                    for (int qq = 0; qq < kGQ; ++qq) {
+                        const float t0 = qv4[qq] - c0, t1 = qv4[qq] - c1;
+                        acc0[qq] = acc0[qq] + t0 * t0;
+                        acc1[qq] = acc1[qq] + t1 * t1;
+                    }
+                }
+            }
+#pragma unroll
+            for (int qq = 0; qq < kGQ; ++qq) {
+                const int qi = q0 + qq;
+                if (qi >= N) break;
+                float d0 = acc0[qq], d1 = acc1[qq];
+                if (lane >= cntc) d0 = INFINITY;
+                if (lane + 64 >= cntc) d1 = INFINITY;
+                const int sidx = (wv * kGQ + qq) * 64;
+                float tau = taus[wv * kGQ + qq];
+                int cnt = cnts[wv * kGQ + qq];
+                float bd = bestd[sidx + lane];
+                int bj = bestj[sidx + lane];
+                if (j0 == 0) {
+                    float v = fminf(d0, d1);
+                    bitonic64f(v, lane);
+                    tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), kk - 1));
+                }
+                bool dirty = false;
+                if (cap > 0) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float di = i ? d1 : d0;
+                        bool pred = di <= tau && di < INFINITY;
+                        unsigned long long bal = __ballot(pred);
+                        while (bal) {
+                            const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
+                                                  __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
+                            const bool put = pred && pos < cap;
+                            if (put) { lstd[sidx + pos] = di; lstj[sidx + pos] = j0 + lane + 64 * i; }
+                            const int np = __builtin_popcountll(bal);
+                            const bool overflow = cnt + np > cap;
+                            cnt = overflow ? cap : cnt + np;
+                            pred = pred && !put;
+                            if (overflow) {
+                                float sd = lane < kk ? bd : (lane - kk < cnt ? lstd[sidx + lane - kk] : INFINITY);
+                                int sj = lane < kk ? bj : (lane - kk < cnt ? lstj[sidx + lane - kk] : 0x7fffffff);
+                                bitonic64(sd, sj, lane);
+                                bd = sd; bj = sj;
+                                tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sd), kk - 1));
+                                cnt = 0;
+                                dirty = true;
+                                pred = pred && di <= tau;
+                            }
+                            bal = __ballot(pred);
+                        }
+                    }
+                } else {  // kk == 64: merge 64 candidates at a time
+#pragma unroll 1
+                    for (int i = 0; i < 2; ++i) {
+                        float nd = i ? d1 : d0;
+                        int nj = nd < INFINITY ? j0 + lane + 64 * i : 0x7fffffff;
+                        bitonic64(nd, nj, lane);
+                        const float rd = __shfl(nd, 63 - lane, 64);
+                        const int rj = __shfl(nj, 63 - lane, 64);
+                        const bool o_less = key_less(rd, rj, bd, bj);
+                        bd = o_less ? rd : bd;
+                        bj = o_less ? rj : bj;
+                        bitonic64(bd, bj, lane);
+                    }
+                    dirty = true;
+                }
+                const bool last = j0 + kGT >= M;
+                if (last && cnt > 0) {
+                    float sd = lane < kk ? bd : (lane - kk < cnt ? lstd[sidx + lane - kk] : INFINITY);
+                    int sj = lane < kk ? bj : (lane - kk < cnt ? lstj[sidx + lane - kk] : 0x7fffffff);
+                    bitonic64(sd, sj, lane);
+                    bd = sd; bj = sj;
+                    cnt = 0;
+                    dirty = true;
+                }
+                if (dirty) { bestd[sidx + lane] = bd; bestj[sidx + lane] = bj; }
+                if (lane == 0) { taus[wv * kGQ + qq] = tau; cnts[wv * kGQ + qq] = cnt; }
+                if (last) {
+                    const int r = lane - drop;
+                    if (r >= 0 && r < k) {
+                        idx[((size_t)b * N + qi) * k + r] = bj;
+                        if (dist) dist[((size_t)b * N + qi) * k + r] = bd;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // out[(((b*N+i)*k + r)*F + f] = x[(b*N + idx[(b*N+i)*k + r])*F + f]
 __global__ __launch_bounds__(kThreads) void knn_gather_kernel(const float *__restrict__ x, int N, int B,
                                                               int F, int k,
@@ -325,6 +488,11 @@ fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int 
                            drop, idx, dist);
     } else if (D == 3) {
         hipLaunchKernelGGL(knn_d3_kernel<KMAX>, grid, dim3(kThreads), 0, st, x, N, y, M, B, k, drop, idx, dist);
+    } else if (!legacy && (size_t)kGT * (D + 1) * 4 + (kWThreads / 64) * (kGQ * (64 * 16 + 8) + D * 16) + 16 <= 64 * 1024) {
+        const size_t lds = (size_t)kGT * (D + 1) * 4 + (kWThreads / 64) * (kGQ * (64 * 16 + 8) + D * 16) + 16;
+        const int qpb = (kWThreads / 64) * kGQ;
+        hipLaunchKernelGGL(knn_wave_generic_kernel, dim3((N + qpb - 1) / qpb, B), dim3(kWThreads), lds, st, x, N, y, M,
+                           B, D, k, drop, idx, dist);
     } else {
         const size_t lds = sizeof(float) * (size_t)D * kThreads;
         hipLaunchKernelGGL(knn_generic_kernel<KMAX>, grid, dim3(kThreads), lds, st, x, N, y, M, B, D, k,

@@ -50,65 +50,73 @@ __global__ __launch_bounds__(kThreads) void sample_explicit_kernel(
 }
 
 // One block per mesh.  ws layout per mesh: cdf[Fp] then tc[nchunks]  (doubles), Fp = roundup32.
+// The SUMMATION ORDER is fixed by the specification shared with the oracle (chunks of 32 summed
+// left to right, chunk totals summed left to right); everything order-free (the Float64 divisions, the
+// final offset add) runs on all 256 threads, the order-bound parts are 32- or nch-long add chains.
+template <bool IN_LDS>
 __global__ __launch_bounds__(kThreads) void face_cdf_kernel(const float *__restrict__ areas, int Fmax,
                                                             int Fp, double eps,
                                                             double *__restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) double dsm[];  // IN_LDS: work[Fp] + tc[nch]
     const int b = blockIdx.x;
     const int nch = Fp / kChunk;
     const float *a = areas + (size_t)b * Fmax;
-    double *cdf = ws + (size_t)b * (Fp + nch);
-    double *tc = cdf + Fp;
+    double *out = ws + (size_t)b * (Fp + nch);
+    double *cdf = IN_LDS ? dsm : out;          // working copy: LDS when the mesh fits (latency-bound chains)
+    double *tc = IN_LDS ? dsm + Fp : out + Fp;
     __shared__ double sh[2];
 
-    // chunk totals of the areas
-    for (int c = threadIdx.x; c < nch; c += kThreads) {
+    for (int k = threadIdx.x; k < Fp; k += kThreads) cdf[k] = (k < Fmax) ? (double)a[k] : 0.0;
+    __syncthreads();
+    for (int c = threadIdx.x; c < nch; c += kThreads) {  // chunk totals of the areas
         double t = 0.0;
-        for (int k = c * kChunk; k < (c + 1) * kChunk; ++k) t += (k < Fmax) ? (double)a[k] : 0.0;
+#pragma unroll 8
+        for (int k = c * kChunk; k < (c + 1) * kChunk; ++k) t += cdf[k];
         tc[c] = t;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         double s = 0.0;
+#pragma unroll 8
         for (int c = 0; c < nch; ++c) s += tc[c];
         sh[0] = s > eps ? s : eps;  // max(sum, eps), :35
     }
     __syncthreads();
     const double den = sh[0];
-    // chunk totals of p = a/den
-    for (int c = threadIdx.x; c < nch; c += kThreads) {
+    for (int k = threadIdx.x; k < Fmax; k += kThreads) cdf[k] = cdf[k] / den;  // p, parallel
+    __syncthreads();
+    for (int c = threadIdx.x; c < nch; c += kThreads) {  // chunk totals of p
         double t = 0.0;
-        for (int k = c * kChunk; k < (c + 1) * kChunk; ++k) t += (k < Fmax) ? (double)a[k] / den : 0.0;
+#pragma unroll 8
+        for (int k = c * kChunk; k < (c + 1) * kChunk; ++k) t += cdf[k];
         tc[c] = t;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         double sp = 0.0;
+#pragma unroll 8
         for (int c = 0; c < nch; ++c) sp += tc[c];
         const double fix = 1.0 - sp;
-        sh[1] = fix > 0.0 ? fix : 0.0;  // :36-37
+        cdf[Fmax - 1] += fix > 0.0 ? fix : 0.0;  // :36-37, lands on the last PADDED column
     }
     __syncthreads();
-    const double fix = sh[1];
-    // local inclusive prefixes of p' (fix-up on the last padded column Fmax-1) + chunk totals
-    for (int c = threadIdx.x; c < nch; c += kThreads) {
+    for (int c = threadIdx.x; c < nch; c += kThreads) {  // local inclusive prefixes + chunk totals of p'
         double l = 0.0;
+#pragma unroll 8
         for (int k = c * kChunk; k < (c + 1) * kChunk; ++k) {
-            if (k < Fmax) {
-                double p = (double)a[k] / den;
-                if (k == Fmax - 1) p += fix;
-                l += p;
-                cdf[k] = l;
-            }
+            l += cdf[k];
+            cdf[k] = l;
         }
         tc[c] = l;
     }
     __syncthreads();
     if (threadIdx.x == 0) {  // exclusive scan of the chunk totals, in place
         double off = 0.0;
+#pragma unroll 8
         for (int c = 0; c < nch; ++c) { const double t = tc[c]; tc[c] = off; off += t; }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < Fmax; k += kThreads) cdf[k] = tc[k / kChunk] + cdf[k];
+    for (int k = threadIdx.x; k < Fmax; k += kThreads) out[k] = tc[k / kChunk] + cdf[k];
 }
 
 __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
@@ -233,7 +241,11 @@ fx3d_status fx3d_sample_points(const float *verts_padded, int32_t Vmax, const in
     fx3d_status rc = fx3d_faces_areas_padded(verts_padded, Vmax, faces_padded, Fmax, faces_len, B, areas, s);
     if (rc) return rc;
     ProfileScope prof("sample", st);  // cdf + draw kernels together
-    hipLaunchKernelGGL(face_cdf_kernel, dim3(B), dim3(kThreads), 0, st, areas, Fmax, Fp, eps, cdf);
+    const size_t cdf_lds = sizeof(double) * (size_t)(Fp + Fp / kChunk);
+    if (cdf_lds <= 60 * 1024)
+        hipLaunchKernelGGL(face_cdf_kernel<true>, dim3(B), dim3(kThreads), cdf_lds, st, areas, Fmax, Fp, eps, cdf);
+    else
+        hipLaunchKernelGGL(face_cdf_kernel<false>, dim3(B), dim3(kThreads), 0, st, areas, Fmax, Fp, eps, cdf);
     FX3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(sample_seeded_kernel, dim3(grid_for((long long)B * n)), dim3(kThreads), 0, st,
                        verts_padded, Vmax, faces_padded, Fmax, Fp, faces_len, B, n, seed, cdf, out,
