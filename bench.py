@@ -104,7 +104,9 @@ def main():
         step()
     sync_all()
 
-    _lib.call("fx3d_profile_enable", 1)  # HIP events around every nn1 launch, on its own stream
+    # HIP events around every 5th nn1 launch, on the launch's own stream (bracketing every launch
+    # costs ~5 us per step in event records; measured)
+    _lib.call("fx3d_profile_enable", 0 if os.environ.get("FX3D_BENCH_NOPROFILE") else 5)
     e0, e1 = fx.Event(), fx.Event()
     sync_all()
     t0 = time.perf_counter()

@@ -25,11 +25,16 @@ namespace {
 struct ProfRec { const char *name; hipEvent_t e0, e1; };
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
-std::atomic<bool> g_prof_on{false};
+std::atomic<int> g_prof_on{0};     // 0 = off, n = bracket every n-th launch of a kernel
+std::atomic<unsigned> g_prof_seq{0};
 constexpr size_t kProfCap = 8192;
 }  // namespace
 
-bool profile_on() { return g_prof_on.load(std::memory_order_relaxed); }
+bool profile_on() {
+    const int n = g_prof_on.load(std::memory_order_relaxed);
+    if (n <= 0) return false;
+    return n == 1 || (g_prof_seq.fetch_add(1, std::memory_order_relaxed) % (unsigned)n) == 0;
+}
 
 void profile_mark(const char *name, hipStream_t st, bool begin) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -74,7 +79,8 @@ size_t fx3d_last_error(char *buf, size_t n) {
 
 fx3d_status fx3d_profile_enable(int32_t on) {
     profile_clear();
-    g_prof_on.store(on != 0);
+    g_prof_seq.store(0);
+    g_prof_on.store(on > 0 ? on : 0);
     return FX3D_OK;
 }
 

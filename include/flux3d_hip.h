@@ -77,7 +77,7 @@ FX3D_API fx3d_status fx3d_event_elapsed_ms(fx3d_event_t start, fx3d_event_t stop
  *      its DOMINANT kernel launch with HIP events on the op's own stream; stats are per kernel name
  *      ("nn1", "knn", "sample", "edge_loss", "laplacian_loss", "faces_areas", ...).  Reading the
  *      stats synchronises the recorded events.  Up to 8192 launches are kept per enable. ---- */
-FX3D_API fx3d_status fx3d_profile_enable(int32_t on); /* also resets */
+FX3D_API fx3d_status fx3d_profile_enable(int32_t every_nth); /* 0 = off, 1 = every launch, n = every n-th; resets */
 FX3D_API fx3d_status fx3d_profile_kernel_stats(const char *name, double *avg_ms, double *min_ms,
                                                double *max_ms, int64_t *count);
 
