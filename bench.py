@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm", choices=["torch", "native"], default="native",
+                    help="multi-GPU all-reduce through torch.distributed (RCCL) or the library's own RCCL communicator")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the multi-GPU code path (torch.distributed/RCCL all-reduce) even at world size 1")
     args = ap.parse_args()
@@ -69,7 +71,38 @@ def main():
     x = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_A, DIM, NPTS, B_PER_GPU, batch_offset=rank * B_PER_GPU))
     y = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_B, DIM, MPTS, B_PER_GPU, batch_offset=rank * B_PER_GPU))
 
-    if use_dist:
+    native = None
+    if use_dist and args.comm == "native":
+        # the library's own RCCL communicator: one C call per step.  Any failure to set it up (all
+        # ranks agree through an all-reduce) falls back to torch.distributed's all_reduce.
+        from flux3d_jl_amd.distributed import NativeComm, NativeShardedChamfer
+        try:
+            native = NativeShardedChamfer(NativeComm(rank, world))
+            ok = 1
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] native RCCL communicator unavailable on rank {rank}: {e}", file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            native = None
+    if native is not None:
+        sharded = native
+        bench_stream = fx.Stream.create()
+
+        def step():
+            with fx.stream(bench_stream):
+                sharded(x, y, Bg, sync=False)
+
+        def sync_all():
+            bench_stream.synchronize()
+            dist.barrier()
+            bench_stream.synchronize()
+
+        def read_loss():
+            with fx.stream(bench_stream):
+                return float(sharded.loss.item())
+    elif use_dist:
         sharded = ShardedChamfer()
         bench_stream = fx.Stream(torch.cuda.current_stream().cuda_stream)
 
@@ -154,7 +187,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"chamfer_distance fwd B={Bg} ({B_PER_GPU}/GPU) N=M={NPTS} D=3 Float32 U[0,1)^3 (BASELINE configs[1]; configs[4] shape at 8 GPUs)",
-                   "global_batch": Bg, "points": NPTS, "parallelism": f"batch-sharded x{world}, 1 all-reduce of 2 f64"},
+                   "global_batch": Bg, "points": NPTS, "parallelism": f"batch-sharded x{world}, 1 all-reduce of 2 f64"
+                                  + ((" (fx3d_comm RCCL)" if native is not None else " (torch.distributed RCCL)") if use_dist else "")},
         "loss": loss,
         "roofline": {"bound": "mfma", "achieved": flops / kern_s / 1e12 if kern_s else None,
                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -70,6 +70,12 @@ SIGNATURES = {
     "fx3d_edge_loss_bwd": [vp, c_i64, vp, c_i64, c_f32, c_f32, vp, vp],
     "fx3d_laplacian_loss": [vp, c_i64, vp, vp, vp, vp, C.POINTER(c_f32), vp, sz, vp],
     "fx3d_laplacian_loss_bwd": [vp, c_i64, vp, vp, vp, c_f32, vp, vp],
+    "fx3d_comm_unique_id": [vp],
+    "fx3d_comm_init_rank": [C.POINTER(vp), c_i32, vp, c_i32],
+    "fx3d_comm_destroy": [vp],
+    "fx3d_comm_allreduce_sum_f64": [vp, vp, c_i64, vp],
+    "fx3d_chamfer_fwd_sharded": [vp, vp, c_i32, vp, c_i32, c_i32, c_i32, c_i64, c_f32, c_f32, vp, vp,
+                                 C.POINTER(c_f32), vp, sz, vp],
     "fx3d_build_edges_packed": [vp, c_i64, c_i64, c_i32, vp, vp, C.POINTER(c_i64)],
     "fx3d_build_laplacian_csr": [vp, c_i64, c_i64, c_i32, vp, vp, vp, C.POINTER(c_i64)],
 }

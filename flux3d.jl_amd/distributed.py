@@ -110,3 +110,57 @@ class ShardedChamfer:
     def synchronize(self):
         for e in self.done:
             e.synchronize()
+
+
+class NativeComm:
+    """RCCL communicator owned by the C library (fx3d_comm_*): the torch-free path a Julia host uses.
+    The 128-byte unique id is created on rank 0 and handed over by ``exchange`` (default: a
+    torch.distributed broadcast when a process group exists; world size 1 needs no exchange)."""
+
+    def __init__(self, rank=0, world_size=1, exchange=None):
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            _lib.call("fx3d_comm_unique_id", ident)
+        if world_size > 1:
+            if exchange is None:
+                import torch
+                import torch.distributed as dist
+                t = torch.tensor(list(bytes(ident)), dtype=torch.uint8, device="cuda")
+                dist.broadcast(t, src=0)
+                ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+            else:
+                ident = (C.c_uint8 * 128)(*exchange(bytes(ident)))
+        h = C.c_void_p()
+        _lib.call("fx3d_comm_init_rank", C.byref(h), int(world_size), ident, int(rank))
+        self.handle, self.rank, self.world_size = h.value, rank, world_size
+
+    def allreduce_sum(self, buf):
+        _lib.call("fx3d_comm_allreduce_sum_f64", self.handle, buf.ptr, buf.size, current_stream().handle)
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            try:
+                _lib.load().fx3d_comm_destroy(self.handle)
+            except Exception:
+                pass
+            self.handle = None
+
+
+class NativeShardedChamfer:
+    """fx3d_chamfer_fwd_sharded: one C call per evaluation (kernel -> RCCL all-reduce of 2 Float64 ->
+    finalise with the global batch size), no Python between the three."""
+
+    def __init__(self, comm):
+        self.comm = comm
+        self.sums = DeviceArray.empty((2,), np.float64)
+        self.loss = DeviceArray.empty((1,), np.float32)
+
+    def __call__(self, x_shard, y_shard, B_global, w1=1.0, w2=1.0, sync=True):
+        x, y = _as_dev_points(x_shard), _as_dev_points(y_shard)
+        D, N, M, Bs = _check_pair(x, y)
+        ws = chamfer_workspace(N, M, max(Bs, 1), D)
+        host = C.c_float(0)
+        _lib.call("fx3d_chamfer_fwd_sharded", self.comm.handle, x.ptr, N, y.ptr, M, Bs, D, int(B_global),
+                  float(w1), float(w2), self.sums.ptr, self.loss.ptr, C.byref(host) if sync else None,
+                  ws.ptr, ws.nbytes, current_stream().handle)
+        return np.float32(host.value) if sync else self.loss

@@ -202,4 +202,36 @@ function edge_loss(m::TriMesh{Float32,R,HipArray}, target_length::Number = 0.0) 
     return loss[]
 end
 
+# ---- multi-GPU (one Julia process per GPU): RCCL through the C ABI, SURVEY.md 8e ----------------------
+# rank 0: id = comm_unique_id(); ship the 128 bytes to the other ranks (Distributed.jl, MPI.jl, a file);
+# every rank: comm = comm_init(nranks, id, rank) after fx3d_set_device(local_rank).
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    check(@ccall LIB.fx3d_comm_unique_id(id::Ptr{UInt8})::Int32)
+    return id
+end
+function comm_init(nranks::Integer, id::Vector{UInt8}, rank::Integer)
+    c = Ref{Ptr{Cvoid}}(C_NULL)
+    check(@ccall LIB.fx3d_comm_init_rank(c::Ref{Ptr{Cvoid}}, nranks::Int32, id::Ptr{UInt8}, rank::Int32)::Int32)
+    return c[]
+end
+comm_destroy(c) = check(@ccall LIB.fx3d_comm_destroy(c::Ptr{Cvoid})::Int32)
+
+# chamfer_distance of a batch whose slab [start, start+B_local) lives on this rank; every rank gets the
+# global loss (kernel -> all-reduce of 2 Float64 -> finalise with B_global), cf. src/metrics/pcloud.jl:39-52
+function chamfer_distance_sharded(comm, A::HipArray{Float32,3}, B::HipArray{Float32,3}, B_global::Integer;
+                                  w1::Number = 1.0, w2::Number = 1.0)
+    D, N, Bl = size(A); _, M, _ = size(B)
+    nb = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_chamfer_workspace_bytes(N::Int32, M::Int32, max(Bl, 1)::Int32, D::Int32, nb::Ref{Csize_t})::Int32)
+    ws = workspace(nb[])
+    sums = HipArray{Float64}(undef, 2); loss_dev = HipArray{Float32}(undef, 1); loss = Ref{Float32}(0)
+    check(@ccall LIB.fx3d_chamfer_fwd_sharded(comm::Ptr{Cvoid}, A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32,
+                                              Bl::Int32, D::Int32, B_global::Int64, Float32(w1)::Float32,
+                                              Float32(w2)::Float32, sums.ptr::Ptr{Cvoid}, loss_dev.ptr::Ptr{Cvoid},
+                                              loss::Ref{Float32}, ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t,
+                                              DEFAULT_STREAM::Stream)::Int32)
+    return loss[]
+end
+
 end # module

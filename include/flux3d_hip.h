@@ -44,9 +44,11 @@ typedef int32_t fx3d_status;
 #define FX3D_ERR_NO_DEVICE (-4)   /* no gfx950 device visible */
 #define FX3D_ERR_UNSUPPORTED (-5)
 #define FX3D_ERR_WORKSPACE (-6)   /* workspace pointer null or too small */
+#define FX3D_ERR_RCCL (-7)        /* librccl missing or an RCCL call failed */
 
 typedef void *fx3d_stream_t; /* hipStream_t */
 typedef void *fx3d_event_t;  /* hipEvent_t  */
+typedef void *fx3d_comm_t;   /* ncclComm_t (RCCL) */
 
 /* ---- library / device management (replaces Flux3D.use_cuda + CUDA.jl plumbing,
  *      src/Flux3D.jl:52-61; `gpu`/`cpu` functor walkers src/rep/pcloud.jl:57) -------------- */
@@ -205,6 +207,26 @@ FX3D_API fx3d_status fx3d_laplacian_loss(const float *verts, int64_t V, const in
 FX3D_API fx3d_status fx3d_laplacian_loss_bwd(const float *verts, int64_t V, const int32_t *rowptr,
                                              const int32_t *colind, const float *vals, float gout,
                                              float *gverts, fx3d_stream_t s);
+
+/* ---- multi-GPU: one process per GPU, batch sharded contiguously -------------------
+ * The reference is single-device; the only collective the sharded path needs is all-reduce(sum) of
+ * the two Float64 chamfer partial sums (RCCL over xGMI).  librccl is loaded at run time.
+ * rank 0 calls fx3d_comm_unique_id and hands the 128 bytes to the other ranks by any host channel;
+ * every rank then calls fx3d_comm_init_rank with its own device current. */
+FX3D_API fx3d_status fx3d_comm_unique_id(uint8_t *id128);
+FX3D_API fx3d_status fx3d_comm_init_rank(fx3d_comm_t *comm, int32_t nranks, const uint8_t *id128,
+                                         int32_t rank);
+FX3D_API fx3d_status fx3d_comm_destroy(fx3d_comm_t comm);
+FX3D_API fx3d_status fx3d_comm_allreduce_sum_f64(fx3d_comm_t comm, double *buf_dev, int64_t count,
+                                                 fx3d_stream_t s);
+/* chamfer_distance of a batch sharded over the ranks of comm: kernel -> all-reduce(2 x f64) ->
+ * finalise with B_global.  x:(D,N,B_local) y:(D,M,B_local) are THIS rank's slab (B_local may be 0);
+ * sums_dev (2 doubles) and loss_dev device scratch/outputs; every rank receives the global loss. */
+FX3D_API fx3d_status fx3d_chamfer_fwd_sharded(fx3d_comm_t comm, const float *x, int32_t N,
+                                              const float *y, int32_t M, int32_t B_local, int32_t D,
+                                              int64_t B_global, float w1, float w2, double *sums_dev,
+                                              float *loss_dev, float *loss_host, void *ws,
+                                              size_t ws_bytes, fx3d_stream_t s);
 
 /* ---- host-side topology (integer work; the reference keeps faces/edges/Laplacian on the host,
  *      src/rep/mesh.jl:87-97, and caches them forever) ------------------------------------------

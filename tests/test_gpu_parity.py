@@ -287,6 +287,35 @@ print("TORCH_INTEROP_OK")
     assert "TORCH_INTEROP_OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_native_rccl_comm_single_rank(gpu_fx, oracle):
+    """fx3d_comm_* / fx3d_chamfer_fwd_sharded with a 1-rank RCCL communicator (fresh process: RCCL is
+    dlopen'ed by the library, no torch involved)."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import flux3d_jl_amd as fx
+from flux3d_jl_amd.distributed import NativeComm, NativeShardedChamfer
+from oracle import oracle
+x = fx.synth.uniform_cloud(1, 3, 700, 4); y = fx.synth.uniform_cloud(2, 3, 900, 4)
+comm = NativeComm(0, 1)
+sc = NativeShardedChamfer(comm)
+loss = sc(fx.gpu(x), fx.gpu(y), 4, 0.5, 1.5)
+assert np.isclose(loss, oracle.chamfer_distance(x, y, 0.5, 1.5), rtol=1e-5), loss
+buf = fx.DeviceArray.from_host(np.array([1.5, 2.5], np.float64)); comm.allreduce_sum(buf)
+assert list(buf.to_host()) == [1.5, 2.5]
+# a shard of the batch with the GLOBAL batch size divides by B_global
+l2 = sc(fx.gpu(x[:, :, :2]), fx.gpu(y[:, :, :2]), 4)
+s = oracle.chamfer_distance(x[:, :, :2], y[:, :, :2], return_all=True)[3]
+from flux3d_jl_amd.distributed import loss_from_sums
+assert np.isclose(l2, loss_from_sums(s, 700, 900, 4, 3), rtol=1e-6)
+print("NATIVE_COMM_OK")
+""" % (os.path.dirname(GOLDEN).rsplit(os.sep, 1)[0],)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "NATIVE_COMM_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 # ------------------------------------------------------------------------------------------ kNN
 @pytest.mark.parametrize("N,B,k,drop", [(1024, 4, 20, True), (200, 2, 1, False), (64, 2, 10, True),
                                         (300, 1, 63, True), (2500, 2, 5, False), (70, 3, 7, False)])
