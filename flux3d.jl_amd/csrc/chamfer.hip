@@ -909,10 +909,18 @@ __device__ __forceinline__ float chamfer_loss_from_sums(double sa, double sb, in
                                                         long long Bg, float w1, float w2);
 constexpr int kHThreads = 1024;   // 16 waves share one LDS image: 1 block per CU, 4 waves per SIMD
 constexpr int kHLT = 2;           // 32-candidate blocks per lane tile (lane sees 16 rows of each)
-constexpr int kHFifo = 4;
+constexpr int kHFifo = 3;
 constexpr int kHChunkMax = 4096;  // 32 B per candidate => 128 KiB
 constexpr int kHItemCap = 128;
 constexpr size_t kHScratchBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 4 + 32 * 3 * 4) + 64 * 32;  // + 2 pad blocks
+
+// plain v_min_f32 (fminf() also emits a canonicalising v_max in IEEE mode; the filter values are never
+// signalling NaNs, and a NaN filter value only sends the query down the exact path)
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 __device__ __forceinline__ void split2h(float v, _Float16 &h, _Float16 &l) {
     h = (_Float16)v;
@@ -1127,7 +1135,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     const float t2 = min3f(accC[6], accC[7], accC[8]), t3 = min3f(accC[9], accC[10], accC[11]);
                     const float t4 = min3f(accC[12], accC[13], accC[14]);
                     const float t5 = min3f(t0, t1, t2), t6 = min3f(t3, t4, accC[15]);
-                    tm = min3f(tm, t5, t6);
+                    tm = bb == 0 ? vmin(t5, t6) : min3f(tm, t5, t6);  // first block of the lane tile restarts tm
                     accC = accN;
                     a_nxt = a_n2;
                 }
@@ -1140,8 +1148,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 }
                 ft[0] = qual ? tm : ft[0];
                 fi[0] = qual ? lt : fi[0];
-                best = fminf(best, tm);
-                tm = INFINITY;
+                best = vmin(best, tm);
             }
             FX3D_PROBE_MARK(tp == 0 ? 3 : 7);
 
