@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libflux3d_hip.so")
+# FX3D_HIP_LIB overrides the in-tree library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("FX3D_HIP_LIB") or os.path.join(_HERE, "lib", "libflux3d_hip.so")
 
 
 class Flux3DHipError(RuntimeError):

@@ -65,6 +65,11 @@ struct Nn1Params {
     float *loss_out;         // optional
     float w1, w2;
     long long Bg;
+    // candidate split (few, large clouds): blocks of one query tile take different chunk subsets and
+    // merge per query through 64-bit atomics in global scratch; nn1_split_finalize_kernel unpacks
+    int nsplit;                  // 1 = off
+    unsigned long long *gres;    // [2B][qstride] packed (d_bits << 32 | index), pre-filled with ~0
+    int qstride;
 };
 
 __device__ __forceinline__ float min3f(float a, float b, float c) {
@@ -911,7 +916,7 @@ constexpr int kHThreads = 1024;   // 16 waves share one LDS image: 1 block per C
 constexpr int kHLT = 2;           // 32-candidate blocks per lane tile (lane sees 16 rows of each)
 constexpr int kHFifo = 3;
 constexpr int kHChunkMax = 4096;  // 32 B per candidate => 128 KiB
-constexpr int kHItemCap = 128;
+constexpr int kHItemCap = 64 * kHFifo;  // the FIFO path never overflows the list
 constexpr size_t kHScratchBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 4 + 32 * 3 * 4) + 64 * 32;  // + 2 pad blocks
 
 // plain v_min_f32 (fminf() also emits a canonicalising v_max in IEEE mode; the filter values are never
@@ -948,15 +953,21 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     constexpr int QB = (kHThreads / 64) * 32;  // queries per tile pass
 
     const int L = blockIdx.x;
-    const int xcd = L & 7, slot = L >> 3;
-    const int c = (slot / p.tiles) * 8 + xcd;
-    const int tile = slot % p.tiles;
+    const int per_cloud = p.tiles * p.nsplit;
+    // >= 8 clouds: all blocks of a cloud get ids with equal L%8, i.e. one XCD and one L2 (block L runs on
+    // XCD L%8).  Fewer clouds than XCDs: plain order, so that a cloud's blocks spread over every XCD.
+    const bool by_xcd = 2 * p.B >= 8;
+    const int slot = by_xcd ? L >> 3 : L;
+    const int c = by_xcd ? (slot / per_cloud) * 8 + (L & 7) : slot / per_cloud;
+    const int tile = (slot % per_cloud) / p.nsplit;
+    const int split = (slot % per_cloud) % p.nsplit;
     if (c >= 2 * p.B) return;
     const int dir = c >= p.B ? 1 : 0;
     const int b = dir ? c - p.B : c;
     const int NQ = dir ? p.M : p.N;
     const int NC = dir ? p.N : p.M;
     if (tile >= (dir ? p.tiles_y : p.tiles_x)) return;
+    if ((long long)split * p.chunk >= NC) return;  // this direction has fewer chunks than splits
     const float *__restrict__ qb = (dir ? p.y : p.x) + (size_t)b * NQ * 3;
     const float *__restrict__ cb = (dir ? p.x : p.y) + (size_t)b * NC * 3;
     int32_t *idx_out = dir ? p.idx_y : p.idx_x;
@@ -1038,10 +1049,11 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     h8 bq;
     double acc = 0.0;
 
-    for (int j0 = 0; j0 < NC; j0 += CH) {
+    const int jfirst = split * CH, jstep = p.nsplit * CH;
+    for (int j0 = jfirst; j0 < NC; j0 += jstep) {
         const int cnt = (NC - j0) < CH ? (NC - j0) : CH;
         const int cnt_pad = (cnt + 32 * kHLT - 1) / (32 * kHLT) * (32 * kHLT);
-        if (j0 > 0) __syncthreads();
+        if (j0 > jfirst) __syncthreads();
         // ---- stage the fp16 split image ------------------------------------------------------------------
         if (one_shot) {
             for (int q4 = tid; q4 < nv; q4 += kHThreads) {
@@ -1085,11 +1097,11 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             }
         }
         __syncthreads();
-        FX3D_PROBE_MARK(j0 == 0 ? 2 : 6);
+        FX3D_PROBE_MARK(j0 == jfirst ? 2 : 6);
 
         for (int tp = 0; tp < p.tpb; ++tp) {
             if ((tile * p.tpb + tp) * QB >= NQ) break;  // uniform
-            if (j0 == 0) {
+            if (j0 == jfirst) {
                 qi = (tile * p.tpb + tp) * QB + wv * 32 + jq;
                 const int qc = qi < NQ ? qi : NQ - 1;
 #pragma unroll
@@ -1153,99 +1165,102 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             FX3D_PROBE_MARK(tp == 0 ? 3 : 7);
 
             // ---- exact phase, wave-cooperative (see nn1_mfma_kernel) ----------------------------------------
-            int nitems = 0;
             {
-                float m = fminf(best, __shfl_xor(best, 32, 64));
+                const float m = fminf(best, __shfl_xor(best, 32, 64));
                 const float thr1 = m + delta, thr2 = thr1 + delta;
-                const bool slow = !sane || !qok || !(ft[kHFifo - 1] > thr2) || !(m < INFINITY);
-                if (__ballot(slow)) {  // rare: a slow lane enqueues every lane tile of the chunk
-                    for (int lt = 0; lt < nblk / kHLT; ++lt) {
-                        const unsigned long long bal = __ballot(slow);
-                        const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
-                                                 __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
-                        if (slow && pos < kHItemCap) items[pos] = ((unsigned int)jq << 16) | ((unsigned int)hh << 12) | (unsigned int)lt;
-                        nitems += __builtin_popcountll(bal);
-                    }
-                }
+                const bool usable = sane && qok && m < INFINITY;        // filter meaningful for this query
+                const bool slow = !usable || !(ft[kHFifo - 1] > thr2);  // FIFO may have dropped a tile in band
+                // Common case (no slow lane in the wave): the items are the FIFO entries within the band.
+                // Rare case (degenerate / near-tied data, unusable filter): the wave re-runs its filter pass
+                // with the now known threshold and enqueues exactly the lane tiles within the band (every
+                // tile for lanes whose filter is unusable), draining the list whenever it is full.
+                const bool retry = __ballot(slow) != 0;
+                const int nlt = nblk / kHLT;
+                int lt2 = 0;
+                do {
+                    int nitems = 0;
+                    if (!retry) {
 #pragma unroll
-                for (int s = 0; s < kHFifo; ++s) {
-                    const bool qual = !slow && fi[s] >= 0 && ft[s] <= thr1;
-                    const unsigned long long bal = __ballot(qual);
-                    if (bal) {
-                        const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
-                                                 __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
-                        if (qual && pos < kHItemCap) items[pos] = ((unsigned int)jq << 16) | ((unsigned int)hh << 12) | (unsigned int)fi[s];
-                        nitems += __builtin_popcountll(bal);
-                    }
-                }
-                if (nitems > kHItemCap) {  // list overflow: lanes scan their own tiles (pathological ties)
-                    const int lt_lo = slow ? 0 : -1;
-                    for (int lt = 0; lt < nblk / kHLT; ++lt) {
-                        bool take = lt_lo == 0;
+                        for (int s = 0; s < kHFifo; ++s) {
+                            const bool qual = fi[s] >= 0 && ft[s] <= thr1;
+                            const unsigned long long bal = __ballot(qual);
+                            if (bal) {
+                                const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
+                                if (qual) items[pos] = ((unsigned int)jq << 16) | ((unsigned int)hh << 12) | (unsigned int)fi[s];
+                                nitems += __builtin_popcountll(bal);  // <= 64 * kHFifo == kHItemCap
+                            }
+                        }
+                        lt2 = nlt;
+                    } else {
+                        const h8 *pb = imgp + hh * 32 + jq;
+#pragma unroll 1
+                        for (; lt2 < nlt && nitems <= kHItemCap - 64; ++lt2) {
+                            float t2 = INFINITY;
 #pragma unroll
-                        for (int s = 0; s < kHFifo; ++s) take = take || (!slow && fi[s] == lt && ft[s] <= thr1);
-                        if (take) {
-                            float db = INFINITY;
-                            int ib = 0x7fffffff;
-                            for (int e = 0; e < kHLT * 16; ++e) {
-                                const int rr = e & 15;
-                                const int jl = (lt * kHLT + (e >> 4)) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hh;
-                                if (jl < cnt) {
-                                    const float *src = cb + (size_t)(j0 + jl) * 3;
-                                    const float cc[3] = {src[0], src[1], src[2]};
-                                    const float dd = sqd<3>(qr, cc);
-                                    if (dd < db) { db = dd; ib = j0 + jl; }
+                            for (int bb = 0; bb < kHLT; ++bb) {
+                                const f32x16 av = __builtin_amdgcn_mfma_f32_32x32x16_f16(pb[(lt2 * kHLT + bb) * 64], bq, zero, 0, 0, 0);
+#pragma unroll
+                                for (int r = 0; r < 16; r += 2) t2 = min3f(t2, av[r], av[r + 1]);
+                            }
+                            const bool qual = !usable || t2 <= thr1;
+                            const unsigned long long bal = __ballot(qual);
+                            if (bal) {
+                                const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
+                                if (qual) items[pos] = ((unsigned int)jq << 16) | ((unsigned int)hh << 12) | (unsigned int)lt2;
+                                nitems += __builtin_popcountll(bal);
+                            }
+                        }
+                    }
+                    // all 64 lanes share the (item, run-of-4-candidates) tasks
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                    const int ntask = nitems * (kHLT * 4);
+                    for (int t0 = 0; t0 < ntask; t0 += 64) {
+                        const int t = t0 + lane;
+                        if (t < ntask) {
+                            const unsigned int it = items[t / (kHLT * 4)];
+                            const int run = t % (kHLT * 4);
+                            const int qs = it >> 16, ih = (it >> 12) & 1, tl = it & 0xfff;
+                            const int jl0 = (tl * kHLT + (run >> 2)) * 32 + 8 * (run & 3) + 4 * ih;
+                            float cx[4], cy[4], cz[4];
+                            if (vec && jl0 + 4 <= cnt) {
+                                load4pts(cb, j0 + jl0, cx, cy, cz);
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int jc = jl0 + r < cnt ? jl0 + r : cnt - 1;
+                                    const float *src = cb + (size_t)(j0 + jc) * 3;
+                                    cx[r] = src[0]; cy[r] = src[1]; cz[r] = src[2];
                                 }
                             }
-                            atomicMin(&qres[jq], ((unsigned long long)__builtin_bit_cast(unsigned int, db) << 32) | (unsigned int)ib);
+                            const float qq[3] = {qtab[qs * 3], qtab[qs * 3 + 1], qtab[qs * 3 + 2]};
+                            float db = INFINITY;
+                            int ib = 0x7fffffff;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float cc3[3] = {cx[r], cy[r], cz[r]};
+                                const float dd = sqd<3>(qq, cc3);
+                                if (jl0 + r < cnt && dd < db) { db = dd; ib = j0 + jl0 + r; }
+                            }
+                            atomicMin(&qres[qs], ((unsigned long long)__builtin_bit_cast(unsigned int, db) << 32) | (unsigned int)ib);
                         }
                     }
-                    nitems = 0;
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            const int ntask = nitems * (kHLT * 4);
-            for (int t0 = 0; t0 < ntask; t0 += 64) {
-                const int t = t0 + lane;
-                if (t < ntask) {
-                    const unsigned int it = items[t / (kHLT * 4)];
-                    const int run = t % (kHLT * 4);
-                    const int qs = it >> 16, ih = (it >> 12) & 1, tl = it & 0xfff;
-                    const int jl0 = (tl * kHLT + (run >> 2)) * 32 + 8 * (run & 3) + 4 * ih;
-                    float cx[4], cy[4], cz[4];
-                    if (vec && jl0 + 4 <= cnt) {
-                        load4pts(cb, j0 + jl0, cx, cy, cz);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int jc = jl0 + r < cnt ? jl0 + r : cnt - 1;
-                            const float *src = cb + (size_t)(j0 + jc) * 3;
-                            cx[r] = src[0]; cy[r] = src[1]; cz[r] = src[2];
-                        }
-                    }
-                    const float qq[3] = {qtab[qs * 3], qtab[qs * 3 + 1], qtab[qs * 3 + 2]};
-                    float db = INFINITY;
-                    int ib = 0x7fffffff;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float cc3[3] = {cx[r], cy[r], cz[r]};
-                        const float dd = sqd<3>(qq, cc3);
-                        if (jl0 + r < cnt && dd < db) { db = dd; ib = j0 + jl0 + r; }
-                    }
-                    atomicMin(&qres[qs], ((unsigned long long)__builtin_bit_cast(unsigned int, db) << 32) | (unsigned int)ib);
-                }
+                } while (lt2 < nlt);
             }
             FX3D_PROBE_MARK(tp == 0 ? 4 : 8);
 
-            if (j0 + CH >= NC) {  // last chunk: results of this tile pass
+            if (j0 + jstep >= NC) {  // last chunk of this block: results of this tile pass
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();
                 if (hh == 0) {
                     const unsigned long long r = qres[jq];
                     const float dd = __builtin_bit_cast(float, (unsigned int)(r >> 32));
                     const int ii = (int)(unsigned int)r;
-                    if (qi < NQ) {
+                    if (p.nsplit > 1) {  // merge with the other chunk subsets; unpacked by the finalize kernel
+                        if (qi < NQ) atomicMin(&p.gres[(size_t)c * p.qstride + qi], r);
+                    } else if (qi < NQ) {
                         if (WANT_IDX && idx_out) idx_out[(size_t)b * NQ + qi] = ii;
                         if (dmin_out) dmin_out[(size_t)b * NQ + qi] = dd;
                         acc += (double)dd;
@@ -1299,6 +1314,31 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         }
     }
     FX3D_PROBE_MARK(12);
+}
+
+// Unpack the per-query (d, index) slots of a candidate-split run, write the outputs and the per-block
+// partial sums (layout: tiles = ceil(max(N,M)/256) blocks per cloud).
+__global__ __launch_bounds__(kThreads) void nn1_split_finalize_kernel(Nn1Params p, int tiles_f) {
+    const int c = blockIdx.y;
+    const int dir = c >= p.B ? 1 : 0;
+    const int b = dir ? c - p.B : c;
+    const int NQ = dir ? p.M : p.N;
+    const int qi = blockIdx.x * kThreads + threadIdx.x;
+    double acc = 0.0;
+    if (qi < NQ) {
+        const unsigned long long r = p.gres[(size_t)c * p.qstride + qi];
+        const float dd = __builtin_bit_cast(float, (unsigned int)(r >> 32));
+        int32_t *idx_out = dir ? p.idx_y : p.idx_x;
+        float *dmin_out = dir ? p.dmin_y : p.dmin_x;
+        if (idx_out) idx_out[(size_t)b * NQ + qi] = (int)(unsigned int)r;
+        if (dmin_out) dmin_out[(size_t)b * NQ + qi] = dd;
+        acc = (double)dd;
+    }
+    if (p.partials) {
+        __shared__ double sm[kThreads / 64];
+        const double tot = block_sum<kThreads>(acc, sm);
+        if (threadIdx.x == 0) p.partials[(size_t)c * tiles_f + blockIdx.x] = tot;
+    }
 }
 
 // Generic dimension (D == 1 or D > 3): one thread per query, candidates read through L1/L2.
@@ -1422,6 +1462,7 @@ struct Plan {
     size_t lds_bytes;
     int variant;  // 0 = exact hot loop, 1 = VALU filter, 2 = f32 MFMA filter, 3 = fp16-split MFMA filter (+ exact re-scan)
     int threads, tpb;
+    int nsplit;  // fp16 variant: chunk subsets per query tile (multi-chunk clouds with too few blocks)
 };
 
 // FX3D_NN1_VARIANT=0/1 overrides the default (for A/B measurements).
@@ -1479,7 +1520,17 @@ Plan make_plan(int N, int M, int B, int D) {
     if (pl.variant == 2) pl.lds_bytes += kMScratchBytes;
     if (pl.variant == 3) pl.lds_bytes += kHScratchBytes;
     const int clouds8 = (2 * B + 7) / 8;
-    pl.grid = clouds8 * 8 * pl.tiles;
+    pl.nsplit = 1;
+    if (pl.variant == 3 && maxc > pl.chunk) {
+        const int chunks = (maxc + pl.chunk - 1) / pl.chunk;
+        const long long blocks = (long long)2 * B * pl.tiles;
+        if (blocks < 256) {
+            long long want = (512 + blocks - 1) / blocks;
+            pl.nsplit = (int)(want < chunks ? want : chunks);
+        }
+    }
+    pl.grid = clouds8 * 8 * pl.tiles * pl.nsplit;
+    if (pl.variant == 3 && 2 * B < 8) pl.grid = 2 * B * pl.tiles * pl.nsplit;  // plain block order (see kernel)
     return pl;
 }
 
@@ -1558,8 +1609,12 @@ struct Fused {
 
 fx3d_status run_nn1(const float *x, int N, const float *y, int M, int B, int D, int32_t *idx_x,
                     int32_t *idx_y, float *dmin_x, float *dmin_y, double *partials,
-                    const Plan &pl, hipStream_t st, const Fused *fu = nullptr) {
+                    const Plan &pl, hipStream_t st, const Fused *fu = nullptr,
+                    unsigned long long *gres = nullptr, int qstride = 0) {
     Nn1Params p{};
+    p.nsplit = gres ? pl.nsplit : 1;
+    p.gres = gres;
+    p.qstride = qstride;
     if (fu) {
         p.ticket = fu->ticket; p.nvalid = fu->nvalid; p.sums_out = fu->sums_out; p.loss_out = fu->loss_out;
         p.w1 = fu->w1; p.w2 = fu->w2; p.Bg = fu->Bg;
@@ -1600,7 +1655,11 @@ fx3d_status fx3d_nn1(const float *x, int32_t N, const float *y, int32_t M, int32
                      fx3d_stream_t s) {
     fx3d_status rc = check_shapes("fx3d_nn1", x, N, y, M, B, D);
     if (rc) return rc;
-    const Plan pl = make_plan(N, M, B, D);
+    Plan pl = make_plan(N, M, B, D);
+    if (pl.nsplit > 1) {  // no scratch at this entry point: run unsplit
+        pl.grid /= pl.nsplit;
+        pl.nsplit = 1;
+    }
     return run_nn1(x, N, y, M, B, D, idx_x, idx_y, dmin_x, dmin_y, nullptr, pl, as_stream(s));
 }
 
@@ -1611,6 +1670,11 @@ fx3d_status fx3d_chamfer_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_
     int tiles, tx, ty;
     partial_layout(pl, N, M, D, &tiles, &tx, &ty);
     *bytes = ((size_t)2 * B * tiles + 2) * sizeof(double);
+    if (pl.nsplit > 1) {  // split run: 256-query finalize tiles + the per-query merge slots
+        const int maxq = N > M ? N : M;
+        const int tiles_f = (maxq + kThreads - 1) / kThreads;
+        *bytes = ((size_t)2 * B * tiles_f + 2) * sizeof(double) + (size_t)2 * B * maxq * sizeof(unsigned long long);
+    }
     return FX3D_OK;
 }
 
@@ -1651,12 +1715,36 @@ static fx3d_status chamfer_common(const float *x, int N, const float *y, int M, 
     const Plan pl = make_plan(N, M, B, D);
     int tiles, tx, ty;
     partial_layout(pl, N, M, D, &tiles, &tx, &ty);
-    const size_t need = ((size_t)2 * B * tiles + 2) * sizeof(double);
+    size_t need = ((size_t)2 * B * tiles + 2) * sizeof(double);
+    const int maxq = N > M ? N : M;
+    const int tiles_f = (maxq + kThreads - 1) / kThreads;
+    if (pl.nsplit > 1)
+        need = ((size_t)2 * B * tiles_f + 2) * sizeof(double) + (size_t)2 * B * maxq * sizeof(unsigned long long);
     if (!ws || ws_bytes < need) {
         set_error("%s: workspace too small (%zu < %zu bytes)", fn, ws ? ws_bytes : (size_t)0, need);
         return FX3D_ERR_WORKSPACE;
     }
     double *partials = reinterpret_cast<double *>(ws);
+    if (pl.nsplit > 1) {
+        // few large clouds: chunk subsets run in parallel blocks and merge through gres
+        unsigned long long *gres = reinterpret_cast<unsigned long long *>(partials + (size_t)2 * B * tiles_f + 2);
+        FX3D_HIP(hipMemsetAsync(gres, 0xFF, (size_t)2 * B * maxq * sizeof(unsigned long long), st));
+        rc = run_nn1(x, N, y, M, B, D, nullptr, nullptr, nullptr, nullptr, nullptr, pl, st, nullptr, gres, maxq);
+        if (rc) return rc;
+        Nn1Params fp{};
+        fp.N = N; fp.M = M; fp.B = B; fp.idx_x = idx_x; fp.idx_y = idx_y; fp.partials = partials;
+        fp.gres = gres; fp.qstride = maxq; fp.nsplit = pl.nsplit;
+        hipLaunchKernelGGL(nn1_split_finalize_kernel, dim3(tiles_f, 2 * B), dim3(kThreads), 0, st, fp, tiles_f);
+        FX3D_LAUNCH_CHECK();
+        FinalizeParams f{};
+        f.partials = partials; f.B = B; f.tiles = tiles_f;
+        f.tiles_x = (N + kThreads - 1) / kThreads; f.tiles_y = (M + kThreads - 1) / kThreads;
+        f.sums = sums_dev ? sums_dev : partials + (size_t)2 * B * tiles_f;
+        f.loss = loss_dev; f.N = N; f.M = M; f.D = D; f.Bg = Bg; f.w1 = w1; f.w2 = w2;
+        hipLaunchKernelGGL(chamfer_finalize_partials_kernel, dim3(1), dim3(kThreads), 0, st, f);
+        FX3D_LAUNCH_CHECK();
+        return FX3D_OK;
+    }
     if (pl.variant == 3 && D == 3) {  // one launch: the last block reduces the partials
         fx3d_status trc = FX3D_OK;
         unsigned int *ticket = ticket_slot(&trc);

@@ -87,6 +87,14 @@ def main():
         emit(f"reference-harness chamfer fwd n={n}", mn, md, ref_cpu_ms_plot={64: .065, 256: .19, 1024: .8, 4096: 3.2, 16384: 13}[n],
              ref_gpu_ms_plot={64: .33, 256: .38, 1024: .75, 4096: 6, 16384: 85}[n])
 
+    # large single clouds (candidate split across blocks keeps the chip busy when B is small)
+    for (B, N) in ((1, 16384), (4, 8192), (1, 65536)):
+        x = fx.gpu(fx.synth.uniform_cloud(11, 3, N, B))
+        y = fx.gpu(fx.synth.uniform_cloud(12, 3, N, B))
+        out = fx.DeviceArray.empty((1,), np.float32)
+        mn, md = gpu_time(lambda: fx.chamfer_distance(x, y, loss_out=out, sync=False), reps=10)
+        emit(f"chamfer fwd uniform B={B} N=M={N}", mn, md, pairs_per_s=B * N * N / (mn * 1e-6))
+
     # ---- C4 kNN ---------------------------------------------------------------------------------------
     x = fx.synth.uniform_cloud(0x5EED0004, 3, 1024, 32)
     dx = fx.gpu(x)

@@ -47,6 +47,7 @@ int main(int argc, char **argv) {
     }
     printf("kernel span (first block start -> last block end): %llu ticks\n", tmax - t0min);
     for (int k = 1; k <= 12; ++k) printf("  %-20s avg %10.1f ticks\n", names[k], d[k] / nb);
+    printf("wave-passes %llu, with a slow lane %llu, slow lanes %llu (last launch x25 accumulated)\n", pr[4095 * 16], pr[4095 * 16 + 1], pr[4095 * 16 + 2]);
     // block start/end distribution
     std::vector<unsigned long long> st, en;
     for (int b = 0; b < nb; ++b) { st.push_back(pr[b * 16] - t0min); en.push_back(pr[b * 16 + 12] - t0min); }
