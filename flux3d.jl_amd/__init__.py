@@ -22,7 +22,8 @@ from .rep import (PointCloud, TriMesh, get_edges_packed, get_edges_to_key, get_f
 from .metrics import (chamfer_distance, chamfer_distance_grad, edge_loss, edge_loss_grad,  # noqa: E402
                       laplacian_loss, laplacian_loss_grad, nearest_neighbors)
 from .transforms import (EPS, compute_faces_areas_list, compute_faces_areas_packed,  # noqa: E402
-                         compute_faces_areas_padded, sample_points, sample_points_grad)
+                         compute_faces_areas_padded, lincomb, offset, sample_points, sample_points_grad)
+from .fit import Momentum, loss_dolphin  # noqa: E402
 from .graph import create_knn_graph, knn, knn_gather  # noqa: E402
 from . import synth  # noqa: E402
 

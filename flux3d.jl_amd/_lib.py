@@ -66,6 +66,9 @@ SIGNATURES = {
     "fx3d_sample_points": [vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_f64, c_u64, vp, vp, vp, vp,
                            vp, sz, vp],
     "fx3d_sample_points_bwd": [vp, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp, vp],
+    "fx3d_lincomb": [c_i64, c_f32, vp, c_f32, vp, c_f32, vp, vp, vp],
+    "fx3d_packed_to_padded": [vp, vp, c_i32, c_i32, vp, vp],
+    "fx3d_padded_to_packed": [vp, vp, c_i32, c_i32, vp, vp],
     "fx3d_mesh_loss_workspace_bytes": [c_i64, C.POINTER(sz)],
     "fx3d_edge_loss": [vp, c_i64, vp, c_i64, c_f32, vp, C.POINTER(c_f32), vp, sz, vp],
     "fx3d_edge_loss_bwd": [vp, c_i64, vp, c_i64, c_f32, c_f32, vp, vp],

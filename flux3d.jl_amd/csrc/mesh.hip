@@ -162,6 +162,16 @@ __global__ __launch_bounds__(kThreads) void mean_finalize_kernel(const double *_
     if (threadIdx.x == 0) *loss = (float)(tot / count);
 }
 
+__global__ __launch_bounds__(kThreads) void lincomb_kernel(long long n, float a, const float *__restrict__ x, float b,
+                                                          const float *__restrict__ y, float c,
+                                                          const float *__restrict__ z, float *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        float v = (a * x[i]) + (b * y[i]);
+        if (z) v = v + (c * z[i]);
+        out[i] = v;
+    }
+}
+
 int grid_for(long long n) {
     long long g = (n + kThreads - 1) / kThreads;
     if (g < 1) g = 1;
@@ -202,6 +212,43 @@ fx3d_status fx3d_faces_areas_padded(const float *verts_padded, int32_t Vmax,
     hipLaunchKernelGGL(faces_areas_padded_kernel, dim3(grid_for((long long)B * Fmax)), dim3(kThreads),
                        0, as_stream(s), verts_padded, Vmax, faces_padded, Fmax, faces_len, B, areas);
     FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_lincomb(int64_t n, float a, const float *x, float b, const float *y, float c,
+                         const float *z, float *out, fx3d_stream_t s) {
+    FX3D_REQUIRE(x && y && out && n > 0, "fx3d_lincomb: bad argument");
+    hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(n)), dim3(kThreads), 0, as_stream(s), (long long)n, a, x, b, y, c, z, out);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_packed_to_padded(const float *packed, const int64_t *verts_len_host, int32_t B, int32_t Vmax,
+                                  float *padded, fx3d_stream_t s) {
+    FX3D_REQUIRE(packed && verts_len_host && padded && B > 0 && Vmax > 0, "fx3d_packed_to_padded: bad argument");
+    hipStream_t st = as_stream(s);
+    FX3D_HIP(hipMemsetAsync(padded, 0, sizeof(float) * 3 * (size_t)Vmax * B, st));  // pad value 0
+    size_t cur = 0;
+    for (int b = 0; b < B; ++b) {
+        const size_t n = (size_t)verts_len_host[b];
+        FX3D_REQUIRE(n <= (size_t)Vmax, "fx3d_packed_to_padded: mesh %d longer than Vmax", b);
+        if (n) FX3D_HIP(hipMemcpyAsync(padded + (size_t)b * Vmax * 3, packed + cur * 3, n * 12, hipMemcpyDeviceToDevice, st));
+        cur += n;
+    }
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_padded_to_packed(const float *padded, const int64_t *verts_len_host, int32_t B, int32_t Vmax,
+                                  float *packed, fx3d_stream_t s) {
+    FX3D_REQUIRE(packed && verts_len_host && padded && B > 0 && Vmax > 0, "fx3d_padded_to_packed: bad argument");
+    hipStream_t st = as_stream(s);
+    size_t cur = 0;
+    for (int b = 0; b < B; ++b) {
+        const size_t n = (size_t)verts_len_host[b];
+        FX3D_REQUIRE(n <= (size_t)Vmax, "fx3d_padded_to_packed: mesh %d longer than Vmax", b);
+        if (n) FX3D_HIP(hipMemcpyAsync(packed + cur * 3, padded + (size_t)b * Vmax * 3, n * 12, hipMemcpyDeviceToDevice, st));
+        cur += n;
+    }
     return FX3D_OK;
 }
 

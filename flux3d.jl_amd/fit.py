@@ -1,0 +1,48 @@
+"""The fit_mesh objective of the reference's tutorial (examples/fit_mesh.jl:78-110), loss AND gradient
+w.r.t. the vertex offsets, entirely on the device:
+
+    loss_dolphin(x, src, tgt) = chamfer_distance(offset(src, x), tgt, 5000)
+                                + 0.1 * laplacian_loss(offset(src, x)) + edge_loss(offset(src, x))
+
+The reference differentiates it with Zygote; here the same chain is spelled out with the adjoint
+kernels of the C ABI (chamfer_bwd -> sample_points_bwd -> padded->packed, laplacian/edge bwd)."""
+import numpy as np
+
+from .device import DeviceArray
+from .metrics import (_chamfer_points, chamfer_distance_grad, edge_loss, edge_loss_grad, laplacian_loss,
+                      laplacian_loss_grad)
+from .transforms import lincomb, offset, sample_points, sample_points_grad
+
+
+def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_lap=0.1, w_edge=1.0):
+    """Returns the Float32 loss (and the gradient w.r.t. x, device (3,sumV), when with_grad)."""
+    m = offset(src, x)
+    s1 = None if seed is None else seed
+    s2 = None if seed is None else seed + 1
+    A, fa, r1, r2 = sample_points(m, num_samples, seed=s1, return_draws=True)
+    Bp = sample_points(tgt, num_samples, seed=s2)
+    loss1, ix, iy = _chamfer_points(A, Bp, 1.0, 1.0, return_indices=True)
+    loss2, loss3 = laplacian_loss(m), edge_loss(m)
+    loss = np.float32(np.float32(loss1 + np.float32(w_lap) * loss2) + np.float32(w_edge) * loss3)
+    if not with_grad:
+        return loss
+    gA, _ = chamfer_distance_grad(A, Bp, ix, iy)
+    gpad = sample_points_grad(m, fa, r1, r2, gA)           # (3,Vmax,B)
+    g1 = m.padded_to_packed_dev(gpad)                       # adjoint of _packed_to_padded
+    g2 = laplacian_loss_grad(m, w_lap)
+    g3 = edge_loss_grad(m, 0.0, w_edge)
+    return loss, lincomb(1.0, g1, 1.0, g2, 1.0, g3)
+
+
+class Momentum:
+    """Flux.Optimise.Momentum(eta, rho): v = rho*v - eta*g ; x += v  (examples/fit_mesh.jl:87-88,110)."""
+
+    def __init__(self, eta=1.0, rho=0.9):
+        self.eta, self.rho, self.v = eta, rho, None
+
+    def update(self, x, g):
+        if self.v is None:
+            self.v = DeviceArray.zeros(x.shape, np.float32)
+        lincomb(self.rho, self.v, -self.eta, g, out=self.v)
+        lincomb(1.0, x, 1.0, self.v, out=x)
+        return x

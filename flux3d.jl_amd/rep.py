@@ -222,13 +222,30 @@ class TriMesh:
 
     def _packed_to_padded_dev(self, packed):
         """_packed_to_padded (src/rep/utils.jl:119-139) without leaving the device."""
-        out = DeviceArray.zeros((3, self.V, self.N), np.float32)
-        cur, st = 0, current_stream().handle
-        for i, n in enumerate(self._verts_len):
-            n = int(n)
-            _lib.call("fx3d_memcpy_d2d", out.ptr + i * self.V * 12, packed.ptr + cur * 12, n * 12, st)
-            cur += n
+        out = DeviceArray.empty((3, self.V, self.N), np.float32)
+        _lib.call("fx3d_packed_to_padded", packed.ptr, self._verts_len.ctypes.data, self.N, self.V, out.ptr,
+                  current_stream().handle)
         return out
+
+    def padded_to_packed_dev(self, padded):
+        """_padded_to_packed (src/rep/utils.jl:159-181) on the device: (3,Vmax,B) -> (3,sumV)."""
+        out = DeviceArray.empty((3, int(self._verts_len.sum())), np.float32)
+        _lib.call("fx3d_padded_to_packed", padded.ptr, self._verts_len.ctypes.data, self.N, self.V, out.ptr,
+                  current_stream().handle)
+        return out
+
+    def with_verts_packed(self, new_packed):
+        """A TriMesh with the same topology (shared caches and device mirrors) and new device vertex
+        positions -- what `offset(m, x)` (deepcopy + offset!, src/transforms/mesh_func.jl:409-438) needs."""
+        m = TriMesh.__new__(TriMesh)
+        m.__dict__.update(self.__dict__)
+        m._dev = {k: v for k, v in self._dev.items() if not k.startswith("verts")}
+        m._device = True
+        m._dev["verts_packed"] = new_packed
+        m._verts_list_valid = False
+        m._verts_packed_valid = False
+        m._verts_padded_valid = False
+        return m
 
     def set_verts_packed(self, new):
         """`m._verts_packed = v` (setproperty!, src/rep/mesh.jl:208-231): replaces the vertex

@@ -88,3 +88,22 @@ def sample_points_grad(m, face_idx, r1, r2, gout):
     _lib.call("fx3d_sample_points_bwd", m.dev("faces_padded").ptr, m.V, m.F, B, n, face_idx.ptr,
               r1.ptr, r2.ptr, gout.ptr, g.ptr, current_stream().handle)
     return g
+
+
+def lincomb(a, x, b, y, c=0.0, z=None, out=None):
+    """out = a*x + b*y (+ c*z): Float32 device arrays of equal size (fx3d_lincomb)."""
+    out = out if out is not None else DeviceArray.empty(x.shape, np.float32)
+    _lib.call("fx3d_lincomb", x.size, float(a), x.ptr, float(b), y.ptr, float(c), z.ptr if z is not None else None,
+              out.ptr, current_stream().handle)
+    return out
+
+
+def offset(m, offset_verts_packed):
+    """offset(m::TriMesh, offset_verts_packed) (src/transforms/mesh_func.jl:435-438): a new mesh whose
+    packed vertices are `verts + offset`; stays on the device, topology caches are shared."""
+    verts = m.dev("verts_packed")
+    off = offset_verts_packed if isinstance(offset_verts_packed, DeviceArray) else \
+        DeviceArray.from_host(np.asarray(offset_verts_packed, np.float32))
+    if off.shape != verts.shape:
+        raise ValueError("mesh and offset_verts size mismatch")
+    return m.with_verts_packed(lincomb(1.0, verts, 1.0, off))

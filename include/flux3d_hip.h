@@ -186,6 +186,18 @@ FX3D_API fx3d_status fx3d_sample_points_bwd(const int32_t *faces_padded, int32_t
                                             const float *r2, const float *gout, float *gverts,
                                             fx3d_stream_t s);
 
+/* out[i] = a*x[i] + b*y[i] (+ c*z[i] when z != NULL), Float32, unfused.  The device-side arithmetic of
+ * the fit_mesh loop: offset!(m, delta) is verts + delta (src/transforms/mesh_func.jl:409-416, a = b = 1),
+ * the sum of the three loss gradients, and the Momentum update (examples/fit_mesh.jl:87-110). */
+FX3D_API fx3d_status fx3d_lincomb(int64_t n, float a, const float *x, float b, const float *y, float c,
+                                  const float *z, float *out, fx3d_stream_t s);
+/* _packed_to_padded / _padded_to_packed for (3,*) Float32 vertex arrays without leaving the device
+ * (src/rep/utils.jl:119-181).  verts_len is a HOST array of B lengths. */
+FX3D_API fx3d_status fx3d_packed_to_padded(const float *packed, const int64_t *verts_len_host, int32_t B,
+                                           int32_t Vmax, float *padded, fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_padded_to_packed(const float *padded, const int64_t *verts_len_host, int32_t B,
+                                           int32_t Vmax, float *packed, fx3d_stream_t s);
+
 /* Scratch for the two mesh losses (bytes), count = E or V. */
 FX3D_API fx3d_status fx3d_mesh_loss_workspace_bytes(int64_t count, size_t *bytes);
 

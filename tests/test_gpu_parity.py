@@ -514,3 +514,77 @@ def test_trimesh_chamfer(gpu_fx):
     l8 = float(fx.chamfer_distance(m8, m8, 5000, seed=11))
     assert 0 < l8 < 1e-2
     assert l8 == float(fx.chamfer_distance(m8, m8, 5000, seed=11))  # deterministic given the seed
+
+
+# ------------------------------------------------------------------------------- fit_mesh objective
+def test_offset_and_converters(gpu_fx):
+    """offset(m, x) (src/transforms/mesh_func.jl:409-438) and the device packed<->padded converters
+    (src/rep/utils.jl:119-181) against their host definitions."""
+    fx = gpu_fx
+    m = fx.gpu(_teapot_sphere(fx))
+    v = m.get_verts_packed_host()
+    off = _rand(v.shape, 3) * np.float32(0.01)
+    m2 = fx.offset(m, off)
+    assert np.array_equal(m2.get_verts_packed().to_host(), v + off)      # exact Float32 add
+    assert np.array_equal(m.get_verts_packed().to_host(), v)              # original untouched (deepcopy semantics)
+    pad = m2.get_verts_padded().to_host()
+    from flux3d_jl_amd import rep
+    assert np.array_equal(pad, rep._packed_to_padded(v + off, m._verts_len, 0))
+    back = m2.padded_to_packed_dev(m2.get_verts_padded()).to_host()
+    assert np.array_equal(back, v + off)
+    assert np.isclose(fx.edge_loss(m2), fx.edge_loss(fx.TriMesh(rep._packed_to_list(v + off, m._verts_len), m.get_faces_list())), rtol=1e-6)
+    with pytest.raises(ValueError):
+        fx.offset(m, off[:, :-1])
+
+
+def test_loss_dolphin_gradient(gpu_fx, oracle):
+    """examples/fit_mesh.jl:78-84 objective: device gradient == the same chain composed from the oracle's
+    adjoints (chamfer_bwd -> barycentric scatter -> padded->packed, laplacian/edge bwd)."""
+    fx = gpu_fx
+    src = fx.gpu(fx.load_trimesh(os.path.join(GOLDEN, "sphere.obj")))
+    tgt = fx.gpu(fx.load_trimesh(os.path.join(GOLDEN, "teapot.obj")))
+    x = fx.gpu(_rand((3, 2562), 5) * np.float32(0.02))
+    n, seed = 3000, 77
+    loss, g = fx.loss_dolphin(x, src, tgt, n, seed=seed, with_grad=True)
+    assert loss == fx.loss_dolphin(x, src, tgt, n, seed=seed)  # deterministic given the seed
+    # oracle chain
+    m = fx.offset(src, x)
+    vp = m.get_verts_padded_host()
+    fp = m.get_faces_padded().astype(np.int64) - 1
+    A, fa, r1, r2 = oracle.sample_points_seeded(vp, fp, m._faces_len, n, seed, return_draws=True)
+    tp = tgt.get_verts_padded_host()
+    Bp = oracle.sample_points_seeded(tp, tgt.get_faces_padded().astype(np.int64) - 1, tgt._faces_len, n, seed + 1)
+    l1, ix, iy, _ = oracle.chamfer_distance(A, Bp, return_all=True)
+    gA, _ = oracle.chamfer_bwd(A, Bp, ix, iy)
+    u = np.sqrt(r1[:, 0]); w = [1 - u, u * (1 - r2[:, 0]), u * r2[:, 0]]
+    g1 = np.zeros((2562, 3))
+    for t in range(3):
+        np.add.at(g1, fp[t, fa[:, 0], 0], (w[t][None, :] * gA[:, :, 0]).T)
+    v = m.get_verts_packed_host()
+    e0 = m.get_edges_packed().astype(np.int64) - 1
+    rp, ci, va = m.get_laplacian_packed()
+    g2 = oracle.laplacian_loss_bwd(v, rp.astype(np.int64), ci.astype(np.int64), va, 0.1)
+    g3 = oracle.edge_loss_bwd(v, e0, 0.0, 1.0)
+    ref = g1.T + g2 + g3
+    l_ref = np.float32(np.float32(l1 + np.float32(0.1) * oracle.laplacian_loss(v, rp.astype(np.int64), ci.astype(np.int64), va))
+                       + oracle.edge_loss(v, e0))
+    assert np.isclose(loss, l_ref, rtol=1e-5)
+    assert np.allclose(g.to_host(), ref, rtol=1e-3, atol=1e-7)
+
+
+def test_fit_mesh_loop_decreases_loss(gpu_fx):
+    """A short run of the tutorial's optimisation (examples/fit_mesh.jl:99-110) entirely on the device."""
+    fx = gpu_fx
+    src = fx.gpu(fx.load_trimesh(os.path.join(GOLDEN, "sphere.obj")))
+    tv, tf = fx.load_obj(os.path.join(GOLDEN, "teapot.obj"))
+    tv = (tv - tv.mean(1, keepdims=True)) / tv.std()        # the tutorial normalises both meshes
+    tgt = fx.gpu(fx.TriMesh([np.asfortranarray(tv.astype(np.float32))], [tf]))
+    x = fx.DeviceArray.zeros((3, 2562), np.float32)
+    opt = fx.Momentum(1.0, 0.9)
+    first = last = None
+    for it in range(60):
+        loss, g = fx.loss_dolphin(x, src, tgt, 5000, seed=1000 + 2 * it, with_grad=True)
+        opt.update(x, g)
+        first = loss if first is None else first
+        last = loss
+    assert np.isfinite(last) and last < 0.5 * first, (first, last)
