@@ -202,6 +202,80 @@ function edge_loss(m::TriMesh{Float32,R,HipArray}, target_length::Number = 0.0) 
     return loss[]
 end
 
+# ---- fit_mesh chain (examples/fit_mesh.jl:78-110): offset, packed<->padded and the three adjoints ----------
+# verts + delta on device; `Flux3D.offset(m, delta)` (src/transforms/mesh_func.jl:409-438) for HipArray meshes
+function lincomb(a::Number, x::HipArray{Float32}, b::Number, y::HipArray{Float32}, c::Number = 0,
+                 z::Union{Nothing,HipArray{Float32}} = nothing)
+    out = HipArray{Float32}(undef, size(x)...)
+    check(@ccall LIB.fx3d_lincomb(length(x)::Int64, Float32(a)::Float32, x.ptr::Ptr{Cvoid}, Float32(b)::Float32,
+                                  y.ptr::Ptr{Cvoid}, Float32(c)::Float32,
+                                  (z === nothing ? C_NULL : z.ptr)::Ptr{Cvoid}, out.ptr::Ptr{Cvoid},
+                                  DEFAULT_STREAM::Stream)::Int32)
+    return out
+end
+offset_verts(m::TriMesh{Float32,R,HipArray}, delta::HipArray{Float32,2}) where {R} =
+    lincomb(1, get_verts_packed(m)::HipArray{Float32,2}, 1, delta)
+Zygote.@adjoint offset_verts(m, delta) = offset_verts(m, delta), g -> (nothing, g)
+
+# src/rep/utils.jl:119-181 for (3,*) vertex arrays, device to device
+function packed_to_padded(packed::HipArray{Float32,2}, verts_len::Vector{Int64}, Vmax::Int)
+    out = HipArray{Float32}(undef, 3, Vmax, length(verts_len))
+    check(@ccall LIB.fx3d_packed_to_padded(packed.ptr::Ptr{Cvoid}, verts_len::Ptr{Int64}, length(verts_len)::Int32,
+                                           Vmax::Int32, out.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    return out
+end
+function padded_to_packed(padded::HipArray{Float32,3}, verts_len::Vector{Int64})
+    out = HipArray{Float32}(undef, 3, sum(verts_len))
+    check(@ccall LIB.fx3d_padded_to_packed(padded.ptr::Ptr{Cvoid}, verts_len::Ptr{Int64}, length(verts_len)::Int32,
+                                           size(padded, 2)::Int32, out.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    return out
+end
+Zygote.@adjoint packed_to_padded(p, len, Vmax) = packed_to_padded(p, len, Vmax), g -> (padded_to_packed(g, len), nothing, nothing)
+
+# sample_points keeping its draws, and the adjoint w.r.t. the padded vertices for the same draws
+function sample_points_with_draws(m::TriMesh{Float32,R,HipArray}, verts::HipArray{Float32,3}, n::Int, eps, seed::UInt64) where {R}
+    nb = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_sample_points_workspace_bytes(m.F::Int32, m.N::Int32, nb::Ref{Csize_t})::Int32)
+    ws = workspace(nb[])
+    out = HipArray{Float32}(undef, 3, n, m.N); face = HipArray{Int32}(undef, n, m.N)
+    r1 = HipArray{Float32}(undef, n, m.N); r2 = HipArray{Float32}(undef, n, m.N)
+    check(@ccall LIB.fx3d_sample_points(verts.ptr::Ptr{Cvoid}, m.V::Int32, faces_padded_dev(m).ptr::Ptr{Cvoid}, m.F::Int32,
+                                        faces_len_dev(m).ptr::Ptr{Cvoid}, m.N::Int32, n::Int32, Float64(eps)::Float64,
+                                        seed::UInt64, out.ptr::Ptr{Cvoid}, face.ptr::Ptr{Cvoid}, r1.ptr::Ptr{Cvoid},
+                                        r2.ptr::Ptr{Cvoid}, ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t,
+                                        DEFAULT_STREAM::Stream)::Int32)
+    return out, (face, r1, r2)
+end
+Zygote.@adjoint function sample_points_with_draws(m, verts, n, eps, seed)
+    out, (face, r1, r2) = sample_points_with_draws(m, verts, n, eps, seed)
+    function back(g)
+        gv = HipArray{Float32}(undef, 3, m.V, m.N)
+        check(@ccall LIB.fx3d_sample_points_bwd(faces_padded_dev(m).ptr::Ptr{Cvoid}, m.V::Int32, m.F::Int32, m.N::Int32,
+                                                n::Int32, face.ptr::Ptr{Cvoid}, r1.ptr::Ptr{Cvoid}, r2.ptr::Ptr{Cvoid},
+                                                g[1].ptr::Ptr{Cvoid}, gv.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+        return (nothing, gv, nothing, nothing, nothing)
+    end
+    return (out, (face, r1, r2)), back
+end
+
+# d laplacian_loss / d verts_packed and d edge_loss / d verts_packed (Zygote through src/metrics/mesh.jl:9-32)
+function laplacian_loss_grad(m::TriMesh{Float32,R,HipArray}, verts::HipArray{Float32,2}, gout::Number = 1) where {R}
+    rowptr, colind, vals = laplacian_csr_dev(m)
+    g = HipArray{Float32}(undef, size(verts)...)
+    check(@ccall LIB.fx3d_laplacian_loss_bwd(verts.ptr::Ptr{Cvoid}, size(verts, 2)::Int64, rowptr.ptr::Ptr{Cvoid},
+                                             colind.ptr::Ptr{Cvoid}, vals.ptr::Ptr{Cvoid}, Float32(gout)::Float32,
+                                             g.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    return g
+end
+function edge_loss_grad(m::TriMesh{Float32,R,HipArray}, verts::HipArray{Float32,2}, target::Number = 0, gout::Number = 1) where {R}
+    edges = edges_dev(m)
+    g = HipArray{Float32}(undef, size(verts)...)
+    check(@ccall LIB.fx3d_edge_loss_bwd(verts.ptr::Ptr{Cvoid}, size(verts, 2)::Int64, edges.ptr::Ptr{Cvoid},
+                                        size(edges, 1)::Int64, Float32(target)::Float32, Float32(gout)::Float32,
+                                        g.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    return g
+end
+
 # ---- multi-GPU (one Julia process per GPU): RCCL through the C ABI, SURVEY.md 8e ----------------------
 # rank 0: id = comm_unique_id(); ship the 128 bytes to the other ranks (Distributed.jl, MPI.jl, a file);
 # every rank: comm = comm_init(nranks, id, rank) after fx3d_set_device(local_rank).
