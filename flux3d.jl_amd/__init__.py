@@ -24,7 +24,9 @@ from .metrics import (chamfer_distance, chamfer_distance_grad, edge_loss, edge_l
 from .transforms import (EPS, compute_faces_areas_list, compute_faces_areas_packed,  # noqa: E402
                          compute_faces_areas_padded, lincomb, offset, sample_points, sample_points_grad)
 from .fit import Momentum, loss_dolphin  # noqa: E402
-from .graph import create_knn_graph, knn, knn_gather  # noqa: E402
+from .graph import (create_knn_graph, edge_features, edge_features_grad, edgeconv_graph, knn,  # noqa: E402
+                    knn_gather)
+from .conversions import pointcloud_to_voxel  # noqa: E402
 from . import synth  # noqa: E402
 
 use_hip = [functional()]  # the `Flux3D.use_cuda[]` analogue (src/Flux3D.jl:52-61)

@@ -59,6 +59,9 @@ SIGNATURES = {
                          vp, vp, vp],
     "fx3d_knn": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, vp, vp],
     "fx3d_knn_gather": [vp, c_i32, c_i32, c_i32, c_i32, vp, vp, vp],
+    "fx3d_edge_features": [vp, c_i32, c_i32, c_i32, c_i32, vp, c_i32, vp, vp],
+    "fx3d_edge_features_bwd": [vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, vp],
+    "fx3d_edgeconv_graph": [vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, vp, vp],
     "fx3d_faces_areas_packed": [vp, c_i64, vp, c_i64, vp, vp],
     "fx3d_faces_areas_padded": [vp, c_i32, vp, c_i32, vp, c_i32, vp, vp],
     "fx3d_sample_points_explicit": [vp, c_i32, vp, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp],
@@ -66,6 +69,8 @@ SIGNATURES = {
     "fx3d_sample_points": [vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_f64, c_u64, vp, vp, vp, vp,
                            vp, sz, vp],
     "fx3d_sample_points_bwd": [vp, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp, vp],
+    "fx3d_voxel_workspace_bytes": [c_i32, C.POINTER(sz)],
+    "fx3d_pointcloud_to_voxel": [vp, c_i32, c_i32, c_i32, vp, vp, sz, vp],
     "fx3d_lincomb": [c_i64, c_f32, vp, c_f32, vp, c_f32, vp, vp, vp],
     "fx3d_packed_to_padded": [vp, vp, c_i32, c_i32, vp, vp],
     "fx3d_padded_to_packed": [vp, vp, c_i32, c_i32, vp, vp],

@@ -476,6 +476,109 @@ __global__ __launch_bounds__(kThreads) void knn_gather_kernel(const float *__res
     }
 }
 
+
+// ---- EdgeConv graph features (src/models/dgcnn.jl:36-51): cat(X, KNNGraph - X, dims=1) in one pass --------
+// layout 0: out (2F,K,N,B) as the reference holds it after `cat(..., dims = 1)` (:45)
+__global__ __launch_bounds__(kThreads) void edge_features_cat_kernel(const float *__restrict__ x, int N, int B,
+                                                                     int F, int k,
+                                                                     const int32_t *__restrict__ idx,
+                                                                     float *__restrict__ out) {
+    const long long total = (long long)B * N * k * 2 * F;
+    const int F2 = 2 * F;
+    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total;
+         e += (long long)gridDim.x * kThreads) {
+        const long long row = e / F2;  // (b*N+i)*k + r
+        const int f = (int)(e - row * F2);
+        const long long bn = row / k;  // b*N + i
+        if (f < F) {
+            out[e] = x[(size_t)bn * F + f];
+        } else {
+            const int b = (int)(bn / N);
+            const int j = idx[row];
+            out[e] = x[((size_t)b * N + j) * F + (f - F)] - x[(size_t)bn * F + (f - F)];
+        }
+    }
+}
+
+// layout 1: out (K*N, 2F, B), what reaches the 1x1 conv after PermutedDimsArray + reshape (:48-51).
+// One thread per (r,i) position (the contiguous dimension of the output), looping over features, so every
+// feature row is written with unit stride; the two source rows are read as float4 when F % 4 == 0.
+template <bool VEC4>
+__global__ __launch_bounds__(kThreads) void edge_features_mlp_kernel(const float *__restrict__ x, int N, int B,
+                                                                     int F, int k,
+                                                                     const int32_t *__restrict__ idx,
+                                                                     float *__restrict__ out) {
+    const int b = blockIdx.y;
+    const long long KN = (long long)k * N;
+    const long long e = (long long)blockIdx.x * kThreads + threadIdx.x;  // i*k + r
+    if (e >= KN) return;
+    const int i = (int)(e / k);
+    const int j = idx[(size_t)b * KN + e];
+    const float *xi = x + ((size_t)b * N + i) * F;
+    const float *xj = x + ((size_t)b * N + j) * F;
+    float *o = out + (size_t)b * 2 * F * KN + e;
+    if (VEC4) {
+        for (int f = 0; f < F; f += 4) {
+            const float4 a = *reinterpret_cast<const float4 *>(xi + f);
+            const float4 c = *reinterpret_cast<const float4 *>(xj + f);
+            o[(size_t)(f + 0) * KN] = a.x;
+            o[(size_t)(f + 1) * KN] = a.y;
+            o[(size_t)(f + 2) * KN] = a.z;
+            o[(size_t)(f + 3) * KN] = a.w;
+            o[(size_t)(F + f + 0) * KN] = c.x - a.x;
+            o[(size_t)(F + f + 1) * KN] = c.y - a.y;
+            o[(size_t)(F + f + 2) * KN] = c.z - a.z;
+            o[(size_t)(F + f + 3) * KN] = c.w - a.w;
+        }
+    } else {
+        for (int f = 0; f < F; ++f) {
+            const float a = xi[f];
+            o[(size_t)f * KN] = a;
+            o[(size_t)(F + f) * KN] = xj[f] - a;
+        }
+    }
+}
+
+// Adjoint w.r.t. X.  CreateSingleKNNGraph is @nograd (src/models/dgcnn.jl:9), so the gathered neighbours are
+// constants and dX[f,i,b] = sum_r (g[f,r,i,b] - g[F+f,r,i,b]), accumulated in rank order.
+__global__ __launch_bounds__(kThreads) void edge_features_bwd_kernel(const float *__restrict__ g, int N, int B, int F,
+                                                                     int k, int layout, float *__restrict__ gx) {
+    const long long total = (long long)B * N * F;
+    const long long KN = (long long)k * N;
+    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total;
+         e += (long long)gridDim.x * kThreads) {
+        long long bn;
+        int f;
+        if (layout == 0) {  // consecutive threads -> consecutive f (reads stride 1 in f)
+            bn = e / F;
+            f = (int)(e - bn * F);
+        } else {            // consecutive threads -> consecutive i (reads k-float runs)
+            const long long bf = e / N;
+            const int i = (int)(e - bf * N);
+            const int b = (int)(bf / F);
+            f = (int)(bf - (long long)b * F);
+            bn = (long long)b * N + i;
+        }
+        const int b = (int)(bn / N);
+        const int i = (int)(bn - (long long)b * N);
+        float acc = 0.0f;
+        for (int r = 0; r < k; ++r) {
+            float a, c;
+            if (layout == 0) {
+                const size_t base = ((size_t)bn * k + r) * 2 * F;
+                a = g[base + f];
+                c = g[base + F + f];
+            } else {
+                const size_t base = (size_t)b * 2 * F * KN + (size_t)i * k + r;
+                a = g[base + (size_t)f * KN];
+                c = g[base + (size_t)(F + f) * KN];
+            }
+            acc = acc + (a - c);
+        }
+        gx[(size_t)bn * F + f] = acc;
+    }
+}
+
 template <int KMAX>
 fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int D, int k, int drop,
                        int32_t *idx, float *dist, hipStream_t st) {
@@ -540,6 +643,53 @@ fx3d_status fx3d_knn_gather(const float *x, int32_t N, int32_t B, int32_t F, int
     hipLaunchKernelGGL(knn_gather_kernel, dim3((unsigned)g), dim3(kThreads), 0, as_stream(s), x, N, B, F, k, idx, out);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
+}
+
+
+fx3d_status fx3d_edge_features(const float *x, int32_t N, int32_t B, int32_t F, int32_t k, const int32_t *idx,
+                               int32_t layout, float *out, fx3d_stream_t s) {
+    FX3D_REQUIRE(x && idx && out, "fx3d_edge_features: null pointer");
+    FX3D_REQUIRE(N > 0 && B > 0 && F > 0 && k > 0, "fx3d_edge_features: bad sizes");
+    FX3D_REQUIRE(layout == 0 || layout == 1, "fx3d_edge_features: layout must be 0 (2F,K,N,B) or 1 (K*N,2F,B)");
+    ProfileScope prof("edge_features", as_stream(s));
+    if (layout == 0) {
+        const long long total = (long long)B * N * k * 2 * F;
+        long long g = (total + kThreads - 1) / kThreads;
+        if (g > 16384) g = 16384;
+        hipLaunchKernelGGL(edge_features_cat_kernel, dim3((unsigned)g), dim3(kThreads), 0, as_stream(s), x, N, B, F, k,
+                           idx, out);
+    } else {
+        const long long KN = (long long)k * N;
+        dim3 grid((unsigned)((KN + kThreads - 1) / kThreads), B);
+        if (F % 4 == 0 && ((uintptr_t)x & 15) == 0)
+            hipLaunchKernelGGL(edge_features_mlp_kernel<true>, grid, dim3(kThreads), 0, as_stream(s), x, N, B, F, k, idx, out);
+        else
+            hipLaunchKernelGGL(edge_features_mlp_kernel<false>, grid, dim3(kThreads), 0, as_stream(s), x, N, B, F, k, idx, out);
+    }
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_edge_features_bwd(const float *gout, int32_t N, int32_t B, int32_t F, int32_t k, int32_t layout,
+                                   float *gx, fx3d_stream_t s) {
+    FX3D_REQUIRE(gout && gx, "fx3d_edge_features_bwd: null pointer");
+    FX3D_REQUIRE(N > 0 && B > 0 && F > 0 && k > 0, "fx3d_edge_features_bwd: bad sizes");
+    FX3D_REQUIRE(layout == 0 || layout == 1, "fx3d_edge_features_bwd: bad layout");
+    const long long total = (long long)B * N * F;
+    long long g = (total + kThreads - 1) / kThreads;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(edge_features_bwd_kernel, dim3((unsigned)g), dim3(kThreads), 0, as_stream(s), gout, N, B, F, k,
+                       layout, gx);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_edgeconv_graph(const float *x, int32_t N, int32_t B, int32_t F, int32_t k, int32_t layout,
+                                int32_t *idx, float *out, fx3d_stream_t s) {
+    FX3D_REQUIRE(idx, "fx3d_edgeconv_graph: idx (k,N,B) is required (it is also the adjoint's side input)");
+    fx3d_status rc = fx3d_knn(x, N, x, N, B, F, k, 1, idx, nullptr, s);
+    if (rc != FX3D_OK) return rc;
+    return fx3d_edge_features(x, N, B, F, k, idx, layout, out, s);
 }
 
 }  // extern "C"

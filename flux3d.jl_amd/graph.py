@@ -39,3 +39,40 @@ def create_knn_graph(X, K):
     every point in feature space, self excluded -> neighbour features (F,K,N,B) on the device."""
     idx = knn(X, K, drop_first=True, return_dist=False)
     return knn_gather(X, idx)
+
+
+_LAYOUTS = {"cat": 0, "mlp": 1, 0: 0, 1: 1}
+
+
+def edge_features(X, idx, layout="mlp"):
+    """EdgeConv's input features (src/models/dgcnn.jl:36-51) from X (F,N,B) and idx (K,N,B):
+    ``cat(X, KNNGraph - X, dims=1)``.  layout "cat": (2F,K,N,B), the array at :45; layout "mlp":
+    (K*N, 2F, B), the array handed to the 1x1 convolution after the permute + reshape (:48-51).
+    The gathered graph and the K copies of X are never materialised."""
+    X = _as_dev_points(X)
+    F, N, B = X.shape
+    k = idx.shape[0]
+    lay = _LAYOUTS[layout]
+    out = DeviceArray.empty((2 * F, k, N, B) if lay == 0 else (k * N, 2 * F, B), np.float32)
+    _lib.call("fx3d_edge_features", X.ptr, N, B, F, k, idx.ptr, lay, out.ptr, current_stream().handle)
+    return out
+
+
+def edge_features_grad(gout, F, N, B, K, layout="mlp"):
+    """Adjoint of :func:`edge_features` w.r.t. X; the graph is ``@nograd`` upstream
+    (src/models/dgcnn.jl:9) so only the repeated-X terms carry gradient."""
+    gx = DeviceArray.empty((F, N, B), np.float32)
+    _lib.call("fx3d_edge_features_bwd", gout.ptr, N, B, F, K, _LAYOUTS[layout], gx.ptr, current_stream().handle)
+    return gx
+
+
+def edgeconv_graph(X, K, layout="mlp", return_idx=False):
+    """The whole graph build of ``(m::EdgeConv)(X)`` up to the MLP input (src/models/dgcnn.jl:32-51) in
+    one library call: self-kNN in feature space (self dropped) + features."""
+    X = _as_dev_points(X)
+    F, N, B = X.shape
+    lay = _LAYOUTS[layout]
+    idx = DeviceArray.empty((K, N, B), np.int32)
+    out = DeviceArray.empty((2 * F, K, N, B) if lay == 0 else (K * N, 2 * F, B), np.float32)
+    _lib.call("fx3d_edgeconv_graph", X.ptr, N, B, F, int(K), lay, idx.ptr, out.ptr, current_stream().handle)
+    return (out, idx) if return_idx else out

@@ -141,6 +141,20 @@ FX3D_API fx3d_status fx3d_knn(const float *x, int32_t N, const float *y, int32_t
 FX3D_API fx3d_status fx3d_knn_gather(const float *x, int32_t N, int32_t B, int32_t F, int32_t k,
                                      const int32_t *idx, float *out, fx3d_stream_t s);
 
+/* EdgeConv graph features (src/models/dgcnn.jl:36-51): cat(X, KNNGraph - X, dims=1) for x (F,N,B) and
+ * idx (k,N,B) from fx3d_knn, without materialising the gathered (F,k,N,B) array or the k copies of X.
+ * layout 0: out (2F,k,N,B), the array at :45;  layout 1: out (k*N, 2F, B), the array handed to the 1x1
+ * convolution after PermutedDimsArray + reshape at :48-51. */
+FX3D_API fx3d_status fx3d_edge_features(const float *x, int32_t N, int32_t B, int32_t F, int32_t k,
+                                        const int32_t *idx, int32_t layout, float *out, fx3d_stream_t s);
+/* Adjoint w.r.t. x.  The graph is @nograd in the reference (src/models/dgcnn.jl:9): neighbours are
+ * constants, gx[f,i,b] = sum_r gout[f,r,i,b] - gout[F+f,r,i,b] (rank order).  Overwrites gx (F,N,B). */
+FX3D_API fx3d_status fx3d_edge_features_bwd(const float *gout, int32_t N, int32_t B, int32_t F, int32_t k,
+                                            int32_t layout, float *gx, fx3d_stream_t s);
+/* Self-kNN (drop_first) + fx3d_edge_features in one call: EdgeConv's whole graph build.  idx (k,N,B) out. */
+FX3D_API fx3d_status fx3d_edgeconv_graph(const float *x, int32_t N, int32_t B, int32_t F, int32_t k,
+                                         int32_t layout, int32_t *idx, float *out, fx3d_stream_t s);
+
 /* ---- TriMesh kernels --------------------------------------------------------------------------
  * Faces/edges cross the ABI as int32, 0-based (the shim converts the reference's 1-based
  * UInt32/Int64, src/rep/mesh.jl:87-89).  verts_packed (3,sumV); faces_packed (3,sumF) global
@@ -219,6 +233,15 @@ FX3D_API fx3d_status fx3d_laplacian_loss(const float *verts, int64_t V, const in
 FX3D_API fx3d_status fx3d_laplacian_loss_bwd(const float *verts, int64_t V, const int32_t *rowptr,
                                              const int32_t *colind, const float *vals, float gout,
                                              float *gverts, fx3d_stream_t s);
+
+/* ---- pointcloud_to_voxel (src/conversions.jl:91-131) ------------------------------------------------
+ * points (3,N,B) -> voxels (res,res,res,B) Float32 0/1: voxel set iff the nearest cloud point of its
+ * lattice centre lies within sqrt(0.6)/res after normalising the cloud by its scalar min/max; Float64
+ * distance test exactly as at :125-129 (lattice (i+0.5)/res for i = 1..res, first array dimension = the
+ * reference's innermost loop variable z).  ws: fx3d_voxel_workspace_bytes(B). */
+FX3D_API fx3d_status fx3d_voxel_workspace_bytes(int32_t B, size_t *bytes);
+FX3D_API fx3d_status fx3d_pointcloud_to_voxel(const float *points, int32_t N, int32_t B, int32_t res,
+                                              float *voxels, void *ws, size_t ws_bytes, fx3d_stream_t s);
 
 /* ---- multi-GPU: one process per GPU, batch sharded contiguously -------------------
  * The reference is single-device; the only collective the sharded path needs is all-reduce(sum) of

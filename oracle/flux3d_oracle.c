@@ -666,3 +666,55 @@ FX_API int fx3d_oracle_edge_loss_bwd(const float *verts, int64_t V, const int64_
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * pointcloud_to_voxel, src/conversions.jl:91-131, restated literally:
+ *   verts_max/min: one scalar per cloud (maximum over coordinates and over points, :94-95);
+ *   cloud = (p .- min) ./ (max - min) in Float32 (:96);
+ *   grid_points = (ind .+ 0.5) ./ res with ind = 1..res, loop order x outer, z inner (:102-113), Float64;
+ *   nearest cloud point of every grid point (knn(KDTree(cloud), grid, 1), :115-123; Euclidean in the
+ *   promoted type = Float64, dimension order; first minimum here, tie order is unspecified upstream and
+ *   cannot change the distance);
+ *   dists = sum((grid - cloud[nn]).^2, dims=1) (Float64), voxel = dists <= 0.6/(res*res) (:125-129);
+ *   reshape(dists, res,res,res,B): column-major, so the first dimension is z.
+ * vox: (res,res,res,B) Float32 0/1.
+ * ---------------------------------------------------------------------------------------- */
+FX_API int fx3d_oracle_pointcloud_to_voxel(const float *points, int N, int B, int res, float *vox) {
+    const size_t R3 = (size_t)res * res * res;
+    float *cloud = (float *)malloc(sizeof(float) * 3 * (size_t)N);
+    const double thr = 0.6 / (double)((long long)res * res);
+    for (int b = 0; b < B; ++b) {
+        const float *p = points + (size_t)b * N * 3;
+        float lo = p[0], hi = p[0];
+        int has_nan = 0;
+        for (int e = 0; e < 3 * N; ++e) {
+            if (p[e] != p[e]) has_nan = 1;
+            if (p[e] < lo) lo = p[e];
+            if (p[e] > hi) hi = p[e];
+        }
+        if (has_nan) lo = hi = NAN;
+        for (int e = 0; e < 3 * N; ++e) cloud[e] = (p[e] - lo) / (hi - lo);
+        size_t g = 0;
+        for (int x = 1; x <= res; ++x)
+            for (int y = 1; y <= res; ++y)
+                for (int z = 1; z <= res; ++z, ++g) {
+                    const double gx = ((double)x + 0.5) / (double)res;
+                    const double gy = ((double)y + 0.5) / (double)res;
+                    const double gz = ((double)z + 0.5) / (double)res;
+                    double best = INFINITY;
+                    int bj = 0;
+                    for (int j = 0; j < N; ++j) {
+                        const double dx = gx - (double)cloud[3 * j], dy = gy - (double)cloud[3 * j + 1],
+                                     dz = gz - (double)cloud[3 * j + 2];
+                        const double d = ((dx * dx) + (dy * dy)) + (dz * dz);
+                        if (d < best) { best = d; bj = j; }
+                    }
+                    const double dx = gx - (double)cloud[3 * bj], dy = gy - (double)cloud[3 * bj + 1],
+                                 dz = gz - (double)cloud[3 * bj + 2];
+                    const double d = ((dx * dx) + (dy * dy)) + (dz * dz);
+                    vox[(size_t)b * R3 + g] = (d <= thr) ? 1.0f : 0.0f;
+                }
+    }
+    free(cloud);
+    return 0;
+}

@@ -254,3 +254,47 @@ def edge_loss_bwd(verts_packed, edges0, target=0.0, gout=1.0):
     lib().fx3d_oracle_edge_loss_bwd(_p(v), C.c_int64(v.shape[1]), _p(e), C.c_int64(e.shape[0]),
                                     C.c_float(target), C.c_float(gout), _p(g))
     return g
+
+
+# ------------------------------------------------------------------------- EdgeConv graph features
+def edge_features(x, idx, layout=1):
+    """EdgeConv's input features (src/models/dgcnn.jl:36-51), array op by array op:
+    KNNGraph (F,K,N,B) gathered with idx (k,N,B, 0-based); X repeated K times along a new dim 2 (:39-43);
+    cat(X, KNNGraph - X, dims=1) (:45) -> layout 0;  PermutedDimsArray (2,3,1,4) + reshape (N*K, 2F, B)
+    (:48-51) -> layout 1."""
+    x, F, N, B = _dims(x)
+    idx = np.asarray(idx)
+    k = idx.shape[0]
+    graph = knn_gather(x, idx)                                  # (F,K,N,B)
+    xr = np.broadcast_to(x.reshape(F, 1, N, B, order="F"), (F, k, N, B))
+    out = np.concatenate([xr, graph - xr], axis=0)              # (2F,K,N,B)
+    if layout == 0:
+        return np.asfortranarray(out)
+    out = np.transpose(out, (1, 2, 0, 3))                       # (K,N,2F,B)
+    return np.asfortranarray(out).reshape(N * k, 2 * F, B, order="F")
+
+
+def edge_features_bwd(g, F, N, B, k, layout=1):
+    """Adjoint of edge_features w.r.t. X with the graph held constant (@nograd, src/models/dgcnn.jl:9):
+    reverse of the reshape/permute/cat/repeat chain; the K copies' gradients are added in rank order."""
+    g = np.asarray(g, dtype=np.float32)
+    if layout == 1:
+        g = g.reshape(k, N, 2 * F, B, order="F").transpose(2, 0, 1, 3)   # (2F,K,N,B)
+    else:
+        g = g.reshape(2 * F, k, N, B, order="F")
+    d = g[:F] - g[F:]
+    acc = np.zeros((F, N, B), np.float32)
+    for r in range(k):
+        acc = acc + d[:, r]
+    return np.asfortranarray(acc)
+
+
+# ------------------------------------------------------------------------------- pointcloud_to_voxel
+def pointcloud_to_voxel(points, res=32):
+    """pointcloud_to_voxel (src/conversions.jl:91-131) -> (res,res,res,B) Float32 0/1."""
+    x, D, N, B = _dims(points)
+    assert D == 3
+    out = np.zeros((res, res, res, B), np.float32, order="F")
+    rc = lib().fx3d_oracle_pointcloud_to_voxel(_p(x), N, B, int(res), _p(out))
+    assert rc == 0
+    return out

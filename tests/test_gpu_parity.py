@@ -588,3 +588,49 @@ def test_fit_mesh_loop_decreases_loss(gpu_fx):
         first = loss if first is None else first
         last = loss
     assert np.isfinite(last) and last < 0.5 * first, (first, last)
+
+
+# ------------------------------------------------------------------- widened rows: EdgeConv features, voxels
+@pytest.mark.parametrize("F,N,B,K", [(3, 256, 3, 10), (64, 128, 2, 20), (6, 70, 2, 5)])
+def test_edge_features_parity(gpu_fx, oracle, F, N, B, K):
+    """cat(X, KNNGraph - X) in both layouts (src/models/dgcnn.jl:36-51), bit-exact, + the @nograd adjoint."""
+    rng = np.random.default_rng(F * 7 + N)
+    x = np.asfortranarray(rng.standard_normal((F, N, B)).astype(np.float32))
+    dx = gpu_fx.gpu(x)
+    idx = gpu_fx.knn(dx, K, drop_first=True, return_dist=False)
+    oi = oracle.knn(x, K, drop_first=True, want_dist=False)
+    assert np.array_equal(idx.to_host(), oi)
+    for layout, lay in (("cat", 0), ("mlp", 1)):
+        got = gpu_fx.edge_features(dx, idx, layout=layout).to_host()
+        exp = oracle.edge_features(x, oi, layout=lay)
+        assert got.shape == exp.shape and np.array_equal(got, exp)
+        out, idx2 = gpu_fx.edgeconv_graph(dx, K, layout=layout, return_idx=True)
+        assert np.array_equal(idx2.to_host(), oi) and np.array_equal(out.to_host(), exp)
+        g = np.asfortranarray(rng.standard_normal(exp.shape).astype(np.float32))
+        gx = gpu_fx.edge_features_grad(gpu_fx.gpu(g), F, N, B, K, layout=layout).to_host()
+        assert np.array_equal(gx, oracle.edge_features_bwd(g, F, N, B, K, layout=lay))
+
+
+@pytest.mark.parametrize("res,N,B", [(16, 300, 2), (32, 1024, 2), (8, 5, 1)])
+def test_pointcloud_to_voxel_parity(gpu_fx, oracle, res, N, B):
+    """Occupancy grid of pointcloud_to_voxel (src/conversions.jl:91-131): identical to the oracle's
+    brute-force Float64 restatement although the kernel scatters from the points."""
+    rng = np.random.default_rng(res + N)
+    p = np.asfortranarray((rng.random((3, N, B), dtype=np.float32) * 5 - 2).astype(np.float32))
+    vox = gpu_fx.pointcloud_to_voxel(gpu_fx.PointCloud(p), res).to_host()
+    exp = oracle.pointcloud_to_voxel(p, res)
+    assert vox.shape == (res, res, res, B)
+    assert np.array_equal(vox, exp)
+    assert 0 < exp.sum() < exp.size
+
+
+def test_pointcloud_to_voxel_sphere_and_degenerate(gpu_fx, oracle):
+    """The reference's own conversion input (test/conversions.jl:8-38: a sphere mesh's vertices) and a
+    cloud with zero extent (division by zero -> no voxel set, like the reference's NaN distances)."""
+    m = gpu_fx.load_trimesh(os.path.join(GOLDEN, "sphere.obj"))
+    p = np.asfortranarray(m.get_verts_packed_host().reshape(3, -1, 1, order="F"))
+    vox = gpu_fx.pointcloud_to_voxel(p, 32).to_host()
+    assert np.array_equal(vox, oracle.pointcloud_to_voxel(p, 32)) and vox.sum() > 0
+    flat = np.ones((3, 16, 1), np.float32, order="F")
+    assert gpu_fx.pointcloud_to_voxel(flat, 8).to_host().sum() == 0
+    assert oracle.pointcloud_to_voxel(flat, 8).sum() == 0

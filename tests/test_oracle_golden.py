@@ -304,3 +304,52 @@ def test_committed_golden_vectors(oracle):
     assert np.array_equal(idx, g["k_idx"]) and np.array_equal(dist, g["k_dist"])
     s = oracle.sample_points_seeded(g["s_verts"], g["s_faces0"], g["s_faces_len"], 64, seed=int(g["s_seed"]))
     assert np.array_equal(s, g["s_out"])
+
+
+def test_edge_features_structure(oracle):
+    """EdgeConv input features (src/models/dgcnn.jl:36-51): shape contract of test/models.jl:29-35 and the
+    two layouts hold the same numbers; entry [f, k, n, b] = X[f,n,b] and [F+f, ...] = X[f,idx] - X[f,n]."""
+    rng = np.random.default_rng(5)
+    F, N, B, K = 5, 40, 2, 6
+    x = np.asfortranarray(rng.standard_normal((F, N, B)).astype(np.float32))
+    idx = oracle.knn(x, K, drop_first=True, want_dist=False)
+    cat = oracle.edge_features(x, idx, layout=0)
+    mlp = oracle.edge_features(x, idx, layout=1)
+    assert cat.shape == (2 * F, K, N, B) and mlp.shape == (K * N, 2 * F, B)
+    for (f, k, n, b) in ((0, 0, 0, 0), (4, 5, 39, 1), (2, 3, 17, 0)):
+        assert cat[f, k, n, b] == x[f, n, b]
+        assert cat[F + f, k, n, b] == x[f, idx[k, n, b], b] - x[f, n, b]
+        assert mlp[k + K * n, f, b] == cat[f, k, n, b] and mlp[k + K * n, F + f, b] == cat[F + f, k, n, b]
+    # adjoint: <edge_features'(x) dx, g> with the graph frozen == <dx, bwd(g)>
+    g = rng.standard_normal(mlp.shape).astype(np.float32)
+    gx = oracle.edge_features_bwd(g, F, N, B, K, layout=1)
+    dx = np.asfortranarray(rng.standard_normal(x.shape).astype(np.float32))
+    # only the repeated-X terms move: d out = cat(dX, -dX)
+    dcat = np.concatenate([np.broadcast_to(dx.reshape(F, 1, N, B, order="F"), (F, K, N, B))] * 2, axis=0).copy()
+    dcat[F:] *= -1
+    dmlp = np.asfortranarray(np.transpose(dcat, (1, 2, 0, 3))).reshape(N * K, 2 * F, B, order="F")
+    assert np.isclose(float((dmlp.astype(np.float64) * g).sum()), float((dx.astype(np.float64) * gx).sum()), rtol=1e-4)
+
+
+def test_pointcloud_to_voxel_vs_kdtree(oracle):
+    """pointcloud_to_voxel (src/conversions.jl:91-131): the reference's tests pin only type and shape
+    (test/conversions.jl:36-38), so the restatement is cross-checked against an independent Float64
+    KD-tree (scipy) evaluation of the same formula, including the lattice order and the 1-based shift."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(11)
+    res, N, B = 16, 300, 2
+    p = np.asfortranarray((rng.random((3, N, B), dtype=np.float32) * 3 - 1).astype(np.float32))
+    vox = oracle.pointcloud_to_voxel(p, res)
+    assert vox.shape == (res, res, res, B) and vox.dtype == np.float32
+    assert set(np.unique(vox)) <= {0.0, 1.0} and 0 < vox.sum() < vox.size
+    ax = (np.arange(1, res + 1) + 0.5) / res
+    gx, gy, gz = np.meshgrid(ax, ax, ax, indexing="ij")            # x outer ... z inner
+    grid = np.stack([gx.ravel(), gy.ravel(), gz.ravel()], axis=1)  # C-order ravel: z fastest
+    for b in range(B):
+        pb = p[:, :, b]
+        cloud = ((pb - pb.min()) / (pb.max() - pb.min())).astype(np.float32).T.astype(np.float64)
+        d, _ = cKDTree(cloud).query(grid, k=1)
+        near_thr = np.abs(d * d - 0.6 / res ** 2) < 1e-12
+        ref = (d * d <= 0.6 / res ** 2).astype(np.float32)
+        got = vox[:, :, :, b].ravel(order="F")                     # first dim (fastest) = z
+        assert np.array_equal(got[~near_thr], ref[~near_thr])

@@ -114,6 +114,27 @@ def main():
     mn, md = gpu_time(lambda: fx.knn_gather(df, idx))
     emit("C4' knn_gather F=64", mn, md, GBps=(4 * 64 * 20 * 1024 * 32 * 2) / (mn * 1e-6) / 1e9)
 
+    # EdgeConv graph build up to the MLP input (kNN + cat(X, KNN - X) + permute), src/models/dgcnn.jl:32-51
+    for tag, d in (("F=3", dx), ("F=64", df)):
+        F = d.shape[0]
+        ii = fx.knn(d, 20, drop_first=True, return_dist=False)
+        mn, md = gpu_time(lambda: fx.edge_features(d, ii, layout="mlp"), reps=10)
+        nbytes = 4 * (2 * F * 20 * 1024 * 32 + 20 * 1024 * 32 + F * 1024 * 32)
+        emit(f"EdgeConv edge_features (K*N,2F,B) {tag}", mn, md, GBps=nbytes / (mn * 1e-6) / 1e9)
+        mn, md = gpu_time(lambda: fx.edgeconv_graph(d, 20, layout="mlp"), reps=10)
+        emit(f"EdgeConv graph build kNN+features {tag}", mn, md)
+
+    # pointcloud_to_voxel (src/conversions.jl:91-131), res 32, B=32 clouds of 1024 / 4096 points
+    for N in (1024, 4096):
+        pc = fx.gpu(fx.synth.uniform_cloud(21, 3, N, 32))
+        mn, md = gpu_time(lambda: fx.pointcloud_to_voxel(pc, 32))
+        kw = {"GBps": (4 * 32 ** 3 * 32 + 12 * N * 32) / (mn * 1e-6) / 1e9,
+              "equiv_nn_pairs_per_s": 32 ** 3 * N * 32 / (mn * 1e-6)}
+        if orc and N == 1024:
+            ph = fx.synth.uniform_cloud(21, 3, N, 32)
+            kw["cpu_bruteforce_us"] = cpu_time(lambda: orc.pointcloud_to_voxel(ph[:, :, :1], 32)) * 32
+        emit(f"pointcloud_to_voxel res=32 B=32 N={N}", mn, md, **kw)
+
     # ---- C3 meshes -------------------------------------------------------------------------------------
     t = os.path.join(GOLD, "teapot.obj")
     m8 = fx.gpu(fx.load_trimesh(*[t] * 8))
