@@ -18,7 +18,7 @@ from .device import (DeviceArray, Event, Stream, cpu, current_stream, device_cou
 from .rep import (PointCloud, TriMesh, get_edges_packed, get_edges_to_key, get_faces_list,  # noqa: E402
                   get_faces_packed, get_faces_padded, get_faces_to_edges_packed,
                   get_laplacian_packed, get_verts_list, get_verts_packed, get_verts_padded,
-                  load_obj, load_trimesh, npoints)
+                  load_obj, load_off, load_trimesh, npoints)
 from .metrics import (chamfer_distance, chamfer_distance_grad, edge_loss, edge_loss_grad,  # noqa: E402
                       laplacian_loss, laplacian_loss_grad, nearest_neighbors)
 from .transforms import (EPS, compute_faces_areas_list, compute_faces_areas_packed,  # noqa: E402

@@ -164,3 +164,62 @@ class NativeShardedChamfer:
                   float(w1), float(w2), self.sums.ptr, self.loss.ptr, C.byref(host) if sync else None,
                   ws.ptr, ws.nbytes, current_stream().handle)
         return np.float32(host.value) if sync else self.loss
+
+
+# ---- per-mesh losses over a batch sharded BY MESH ------------------------------------------
+# laplacian_loss / edge_loss are means over the packed vertices / edges of the WHOLE batch
+# (src/metrics/mesh.jl:9-32), so a rank holding some of the meshes contributes (sum, count) and the global
+# value is sum(sums) / sum(counts): one all-reduce of 2 Float64, like the chamfer path.
+def mean_parts(local_mean, local_count):
+    """(sum, count) of a rank's local mean over ``local_count`` items (0 items -> zeros)."""
+    if local_count <= 0:
+        return np.zeros(2, np.float64)
+    return np.array([float(local_mean) * float(local_count), float(local_count)], np.float64)
+
+
+def mean_from_parts(parts):
+    return np.float32(parts[0] / parts[1]) if parts[1] > 0 else np.float32(0.0)
+
+
+class ShardedMeshLoss:
+    """``laplacian_loss`` / ``edge_loss`` of a TriMesh batch whose meshes are split over the ranks.
+    ``reduce`` sums a (2,) Float64 host array over the ranks: by default torch.distributed all_reduce
+    (backend nccl == RCCL on the GPU box, gloo in the CPU tests); pass ``comm`` (a :class:`NativeComm`) to
+    use the library's own RCCL communicator instead."""
+
+    def __init__(self, group=None, comm=None):
+        self.group, self.comm = group, comm
+        self._buf = None
+
+    def _reduce(self, parts):
+        if self.comm is not None:
+            if self._buf is None:
+                self._buf = DeviceArray.empty((2,), np.float64)
+            self._buf.copy_(parts)
+            self.comm.allreduce_sum(self._buf)
+            return self._buf.to_host()
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            return parts
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.from_numpy(parts.copy()).to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def combine(self, local_mean, local_count):
+        return mean_from_parts(self._reduce(mean_parts(local_mean, local_count)))
+
+    def laplacian_loss(self, mesh_shard):
+        """mesh_shard: this rank's TriMesh (or None when it holds no mesh)."""
+        from .metrics import laplacian_loss
+        if mesh_shard is None:
+            return self.combine(0.0, 0)
+        return self.combine(laplacian_loss(mesh_shard), int(sum(mesh_shard._verts_len)))
+
+    def edge_loss(self, mesh_shard, target_length=0.0):
+        from .metrics import edge_loss
+        from .rep import get_edges_packed
+        if mesh_shard is None:
+            return self.combine(0.0, 0)
+        return self.combine(edge_loss(mesh_shard, target_length), int(get_edges_packed(mesh_shard).shape[0]))

@@ -446,10 +446,35 @@ def load_obj(path):
     return v, f
 
 
+def load_off(path):
+    """Minimal OFF reader (the ModelNet on-disk format read by load_trimesh at
+    src/datasets/modelnet/base.jl:100-101): header ``OFF`` (ModelNet also ships files with the counts glued
+    to it, ``OFF490 518 0``), ``nv nf ne``, nv vertex lines, nf face lines ``k i0 .. ik-1`` (0-based;
+    polygons are fan-triangulated).  Returns the same (verts (3,V) Float32, faces (3,F) UInt32 1-based)."""
+    with open(path) as fh:
+        toks = fh.read().split()
+    if not toks or not toks[0].upper().startswith("OFF"):
+        raise ValueError(f"{path}: not an OFF file")
+    head = toks[0][3:]
+    toks = ([head] if head else []) + toks[1:]
+    nv, nf = int(toks[0]), int(toks[1])
+    pos = 3
+    v = np.array(toks[pos:pos + 3 * nv], dtype=np.float32).reshape(nv, 3)
+    pos += 3 * nv
+    faces = []
+    for _ in range(nf):
+        k = int(toks[pos])
+        ids = [int(t) + 1 for t in toks[pos + 1:pos + 1 + k]]
+        pos += 1 + k
+        for j in range(1, k - 1):
+            faces.append([ids[0], ids[j], ids[j + 1]])
+    return (np.asfortranarray(v.T), np.asfortranarray(np.array(faces, dtype=np.uint32).reshape(-1, 3).T))
+
+
 def load_trimesh(*paths):
-    """load_trimesh(fn...) (src/rep/mesh.jl:244-262) for .obj files: one batched TriMesh."""
+    """load_trimesh(fn...) (src/rep/mesh.jl:244-262) for .obj / .off files: one batched TriMesh."""
     flat = []
     for p in paths:
         flat.extend(p if isinstance(p, (list, tuple)) else [p])
-    vs, fs = zip(*[load_obj(p) for p in flat])
+    vs, fs = zip(*[(load_off(p) if str(p).lower().endswith(".off") else load_obj(p)) for p in flat])
     return TriMesh(list(vs), list(fs))

@@ -177,3 +177,22 @@ def test_synth_generator_is_stable(fx):
     assert np.array_equal(full[:, :, 2:], part)
     p = fx.synth.reference_bench_cloud(8)
     assert np.allclose(p[:, 3], 0.5)
+
+
+def test_off_loader_roundtrip(fx, tmp_path):
+    """OFF (ModelNet's format, src/datasets/modelnet/base.jl:100-101) parses to the same arrays as the OBJ
+    twin of the same mesh, including the glued-header variant and polygon faces."""
+    v, f = fx.load_obj(os.path.join(GOLDEN, "sphere.obj"))
+    lines = ["OFF", f"{v.shape[1]} {f.shape[1]} 0"]
+    lines += [" ".join(repr(float(c)) for c in v[:, i]) for i in range(v.shape[1])]
+    lines += ["3 " + " ".join(str(int(c) - 1) for c in f[:, j]) for j in range(f.shape[1])]
+    p = tmp_path / "sphere.off"
+    p.write_text("\n".join(lines) + "\n")
+    v2, f2 = fx.load_off(str(p))
+    assert np.array_equal(v, v2) and np.array_equal(f, f2)
+    q = tmp_path / "quad.off"
+    q.write_text("OFF4 1 0\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n")
+    v3, f3 = fx.load_off(str(q))
+    assert v3.shape == (3, 4) and np.array_equal(f3, np.array([[1, 1], [2, 3], [3, 4]], np.uint32))
+    m = fx.load_trimesh(str(p), str(q))
+    assert m.N == 2 and m.V == v.shape[1]
