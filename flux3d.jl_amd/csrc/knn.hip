@@ -19,6 +19,18 @@
 
 using namespace fx3d;
 
+// Phase timestamps for tools/knn_probe.hip (compiled out of the product build).
+#ifdef FX3D_PROBE
+__device__ unsigned long long g_kprobe[4096 * 32];
+#define KNN_PROBE_MARK(k)                                                                              \
+    do {                                                                                               \
+        const int pb__ = blockIdx.x + gridDim.x * blockIdx.y;                                          \
+        if (threadIdx.x == 0 && pb__ < 4096) g_kprobe[pb__ * 32 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define KNN_PROBE_MARK(k) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -477,6 +489,498 @@ __global__ __launch_bounds__(kThreads) void knn_gather_kernel(const float *__res
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// knn_mfma_kernel<DK>: feature-space kNN (4 <= D <= 128, k+drop <= 32) with the distance matrix recast as
+// a dense Float32 GEMM on the matrix cores and an exact re-scan of the few survivors.
+//
+//   Filter  F[q][c] = fl(|c|^2) + sum_d (-2 q_d) c_d   on v_mfma_f32_32x32x2_f32 (rows = a wave's 32
+//   queries, columns = 32 candidates; the accumulator starts at |c|^2).  With u = 2^-24 and the usual
+//   gamma_n bounds, |F + |q|^2 - d_oracle| <= eps_q = 8 (D+4) u (|q|^2 + Cmax^2) for every candidate
+//   (Cmax = largest candidate norm of the cloud; the factor leaves 2x head-room for the matrix core's
+//   internal rounding), d_oracle being the CPU path's unfused dimension-order Float32 sum.
+//   Phase A: per query the minimum of F over each lane's columns; the kk-th smallest of the 32 lane minima
+//            (bitonic sort inside each half-wave, 16 queries at a time) bounds the kk-th smallest F: tau.
+//   Phase B: the GEMM again; columns with F <= tau + 2 eps_q are compacted (ballot + mbcnt) into the
+//            query's LDS list -- a superset of the true k nearest, ~1.6 kk entries.
+//   Exact:   one lane per survivor evaluates the oracle's distance; its rank under (distance, index) among
+//            the query's survivors is its output position: bit-identical output.
+//   Queries whose list overflows (heavy ties, degenerate clouds) or whose band is not finite take an exact
+//   brute-force merge over all candidates instead.
+// Block = 4 consumer waves (32 queries each: MFMA + selection) + 4 producer waves that stage the next
+// candidate chunk into the other LDS buffer while the consumers work (the shape has one consumer wave per
+// SIMD, so nothing else would hide the global-memory latency).  Lane l = (h, jl) = (l>>5, l&31).  The
+// reduction dimension is permuted so that half h owns d in [h*DP/2, (h+1)*DP/2): every operand fetch is
+// one b128 (4 k-steps).  A (the -2q rows) lives in registers; chunks have row stride DP+4 (conflict-free).
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+constexpr int kMWaves = 4;                       // consumer waves
+constexpr int kMThreads = 2 * kMWaves * 64;      // + as many producer waves
+constexpr int kMProd = kMWaves * 64;             // producer threads
+constexpr int kMListCap = 64;
+
+// plain v_min_f32 (fminf() adds canonicalising v_max ops; a NaN filter value only sends the query down
+// the exact path through its non-finite threshold)
+__device__ __forceinline__ float vmin_f32(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// branch-free (distance, index) comparison, 0 / 1
+__device__ __forceinline__ int key_less_bf(float d, int j, float od, int oj) {
+    return (int)(d < od) | ((int)(d == od) & (int)(j < oj));
+}
+
+// exact top-kk of ONE query over all candidates: 64 at a time, bitonic merge (always correct; slow path)
+__device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q, const float *__restrict__ yb, int M,
+                                                      int D, int lane, float &bd, int &bj) {
+    bd = INFINITY;
+    bj = 0x7fffffff;
+    for (int j0 = 0; j0 < M; j0 += 64) {
+        const int j = j0 + lane;
+        float nd = INFINITY;
+        int nj = 0x7fffffff;
+        if (j < M) {
+            const float *c = yb + (size_t)j * D;
+            float s = 0.0f;
+            for (int d = 0; d < D; ++d) {
+                const float t = q[d] - c[d];
+                s = s + t * t;
+            }
+            nd = s;
+            nj = j;
+        }
+        bitonic64(nd, nj, lane);
+        const float rd = __shfl(nd, 63 - lane, 64);
+        const int rj = __shfl(nj, 63 - lane, 64);
+        const bool o_less = key_less(rd, rj, bd, bj);
+        bd = o_less ? rd : bd;
+        bj = o_less ? rj : bj;
+        bitonic64(bd, bj, lane);
+    }
+}
+
+// LDS image of a chunk: rows of PPR = DP/4 16-byte pieces, no padding; piece c of row r sits at position
+// (c + r) mod PPR of its row.  The rotation makes the consumers' b128 operand fetches (32 consecutive rows, one
+// column) conflict-free, and it is applied on the SOURCE side of the direct-to-LDS loads
+// (global_load_lds_dwordx4 writes lane-linear: wave-uniform base + lane*16), so staging costs one
+// instruction per KiB and no VGPR round trip -- the producers share their SIMD's issue slots with the
+// consumers' MFMAs, every VALU instruction they do not execute is matrix-core time.
+template <int DK>
+__device__ __forceinline__ int knn_piece_off(int row, int c) {  // float offset of piece c of row `row`
+    constexpr int PPR = DK * 8;
+    return (row * PPR + ((c + row) & (PPR - 1))) * 4;
+}
+
+// producer wave pw stages rows [pw*RW, (pw+1)*RW) of the chunk [j0, j0+cn) and their norms
+template <int DK>
+__device__ __forceinline__ void knn_stage_chunk(const float *__restrict__ yb, int D, int j0, int cn, int CH, float *img,
+                                                float *cnorm, unsigned int *cmax, bool want_cmax, bool do_norms,
+                                                bool vec4, int pw, int lane) {
+    constexpr int DP = DK * 32, PPR = DK * 8;
+    const int RW = CH / kMWaves;          // rows per producer wave (CH is a multiple of 64)
+    const int row_lo = pw * RW;
+    const int rq = D / 4;
+    if (vec4) {
+        const int ninstr = RW * PPR / 64;
+        for (int i = 0; i < ninstr; ++i) {
+            const int S0 = row_lo * PPR + i * 64;  // first 16-byte slot of this wave-instruction
+            const int S = S0 + lane;
+            const int row = S / PPR, pos = S & (PPR - 1);
+            const int c = (pos - row) & (PPR - 1);
+            if (row < cn && c < rq)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(yb + (size_t)(j0 + row) * D + 4 * c),
+                    (__attribute__((address_space(3))) void *)(img + (size_t)S0 * 4), 16, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces have landed
+    } else {
+        for (int e = lane; e < RW * D; e += 64) {
+            const int row = row_lo + e / D, d = e % D;
+            if (row < cn) img[knn_piece_off<DK>(row, d >> 2) + (d & 3)] = yb[(size_t)(j0 + row) * D + d];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (!do_norms) return;  // phase B with the norms of phase A kept in LDS
+    // norms of this wave's rows (padding columns hold zeros); rows beyond the chunk get +inf: F = +inf
+    float wmax = 0.0f;
+    bool wnan = false;
+    for (int r0 = 0; r0 < RW; r0 += 64) {
+        const int row = row_lo + r0 + lane;
+        if (r0 + lane < RW) {
+            float t = INFINITY;
+            if (row < cn) {
+                t = 0.0f;
+#pragma unroll
+                for (int c = 0; c < PPR; ++c) {
+                    const float4 v = *reinterpret_cast<const float4 *>(img + knn_piece_off<DK>(row, c));
+                    t = __builtin_fmaf(v.x, v.x, t);
+                    t = __builtin_fmaf(v.y, v.y, t);
+                    t = __builtin_fmaf(v.z, v.z, t);
+                    t = __builtin_fmaf(v.w, v.w, t);
+                }
+                wnan |= (t != t);
+                wmax = fmaxf(wmax, t);
+            }
+            cnorm[row] = t;
+        }
+    }
+    if (want_cmax) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, m, 64));
+        const bool anynan = __ballot(wnan) != 0;
+        if (lane == 0) atomicMax(cmax, anynan ? 0x7fc00000u : __builtin_bit_cast(unsigned int, wmax));  // NaN > +inf
+    }
+}
+
+template <int DK>
+__global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__restrict__ x, int N,
+                                                             const float *__restrict__ y, int M, int B, int D,
+                                                             int k, int drop, int32_t *__restrict__ idx,
+                                                             float *__restrict__ dist, int CH, int img_floats, int keep_norms) {
+    constexpr int DP = DK * 32;      // padded feature dimension
+    constexpr int RS = DP + 4;       // row stride of the query rows staged in the prologue (floats)
+    constexpr int PPR = DK * 8;      // 16-byte pieces per candidate row
+    constexpr int NT = DP / 8;       // b128 operand fetches per tile and half
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int buf_floats = CH * DP + CH;                                   // image [CH][DP] + norms [CH]
+    int *lists = reinterpret_cast<int *>(sm + img_floats);                 // [kMWaves][32][kMListCap]
+    int *cntl = lists + kMWaves * 32 * kMListCap;                          // [kMWaves][32]
+    unsigned int *cmax = reinterpret_cast<unsigned int *>(cntl + kMWaves * 32);  // bits of max |c|^2 (>= 0)
+    float *nall = reinterpret_cast<float *>(cmax + 4);  // [nchunk*CH] all candidate norms (when keep_norms)
+
+    // block L runs on XCD L % 8: give every cloud's blocks ids with equal L % 8 so that its candidates stay in
+    // one L2 (8 or more clouds; fewer: plain order, a cloud's blocks spread over all XCDs)
+    const int nbx = (N + kMWaves * 32 - 1) / (kMWaves * 32);
+    const int L = blockIdx.x;
+    const bool by_xcd = B >= 8;
+    const int b = by_xcd ? ((L >> 3) / nbx) * 8 + (L & 7) : L / nbx;
+    const int bxq = by_xcd ? (L >> 3) % nbx : L % nbx;
+    if (b >= B) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool consumer = wv < kMWaves;
+    const int cw = consumer ? wv : wv - kMWaves;   // the consumer wave this wave is paired with
+    const int ptid = tid - kMProd;                 // producer thread id (negative for consumers)
+    const int h = lane >> 5, jl = lane & 31;
+    const int kk = k + drop;
+    const float *xb = x + (size_t)b * N * D, *yb = y + (size_t)b * M * D;
+    const int q0 = (bxq * kMWaves + cw) * 32;
+    const bool wave_active = q0 < N;
+    const bool vec4y = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(yb) & 15) == 0);
+    const bool vec4x = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(xb) & 15) == 0);
+    KNN_PROBE_MARK(0);
+
+    // ---- A operand: the wave's 32 query rows, staged through LDS (coalesced), then -2 q in registers --------
+    float4 a[NT];
+    float qn = 0.0f;
+    if (tid == 0) *cmax = 0u;
+    if (consumer) {
+        float *qs = sm + (size_t)cw * 32 * RS;
+        const int nrow = wave_active ? ((N - q0) < 32 ? (N - q0) : 32) : 0;
+        const float *src = xb + (size_t)q0 * D;
+        if (vec4x) {
+            const int rq = D / 4;
+            for (int e = lane; e < nrow * rq; e += 64) {
+                const int row = e / rq, c4 = e - row * rq;
+                *reinterpret_cast<float4 *>(qs + (size_t)row * RS + 4 * c4) = reinterpret_cast<const float4 *>(src)[e];
+            }
+        } else {
+            for (int e = lane; e < nrow * D; e += 64) {
+                const int row = e / D, d = e - row * D;
+                qs[(size_t)row * RS + d] = src[e];
+            }
+        }
+        for (int e = lane; e < 32 * DP; e += 64) {  // zero padding: columns >= D, rows >= nrow
+            const int row = e / DP, d = e - row * DP;
+            if (row >= nrow || d >= D) qs[(size_t)row * RS + d] = 0.0f;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const float *qr = qs + (size_t)jl * RS + h * (DP / 2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 v = *reinterpret_cast<const float4 *>(qr + 4 * t);
+            qn = qn + v.x * v.x;
+            qn = qn + v.y * v.y;
+            qn = qn + v.z * v.z;
+            qn = qn + v.w * v.w;
+            a[t] = float4{-2.0f * v.x, -2.0f * v.y, -2.0f * v.z, -2.0f * v.w};
+        }
+        qn = qn + __shfl_xor(qn, 32, 64);
+    }
+    __syncthreads();
+    KNN_PROBE_MARK(1);
+
+    // ---- chunk schedule: phase A walks the chunks forwards, phase B backwards (its first chunk is resident) ----
+    const int nchunk = (M + CH - 1) / CH;
+    const int nstep = 2 * nchunk;
+    if (D < DP || !vec4y) {  // padding columns must read as zeros; the direct loads never touch them
+        for (int e = tid; e < 2 * buf_floats / 4; e += kMThreads)
+            reinterpret_cast<float4 *>(sm)[e] = float4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+    }
+    if (!consumer) {
+        const int cn = M < CH ? M : CH;
+        knn_stage_chunk<DK>(yb, D, 0, cn, CH, sm, keep_norms ? nall : sm + (size_t)CH * DP, cmax, true, true, vec4y,
+                            wv - kMWaves, lane);
+    }
+    __syncthreads();
+    KNN_PROBE_MARK(2);
+
+    float mn[16], thr[16];
+    int cnt[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { mn[r] = INFINITY; thr[r] = 0.0f; cnt[r] = 0; }
+    int *mylists = lists + cw * 32 * kMListCap;
+
+    int cur = 0;  // buffer holding the chunk of this step
+    for (int step = 0; step < nstep; ++step) {
+        const int phase = step >= nchunk ? 1 : 0;
+        const int ci = phase ? nstep - 1 - step : step;
+        const int j0 = ci * CH;
+        const int cn = (M - j0) < CH ? (M - j0) : CH;
+        const int cn_pad = (cn + 63) & ~63;
+        const int nstep1 = step + 1;
+        const int ci_next = nstep1 >= nchunk ? nstep - 1 - nstep1 : nstep1;
+        const bool stage_next = nstep1 < nstep && ci_next != ci;
+        if (consumer) {
+            if (wave_active) {
+                const float *cand = sm + (size_t)cur * buf_floats;
+                const float *cnorm = keep_norms ? nall + (size_t)ci * CH : cand + (size_t)CH * DP;
+                // two 32-candidate tiles at a time on two accumulators: consecutive MFMAs are independent, so the
+                // matrix core issues back to back instead of waiting out each dependent accumulate
+                const int npair = cn_pad / 64;
+                for (int pr = 0; pr < npair; ++pr) {
+                    // rows pr*64 + jl and + 32 share (row mod PPR) = jl mod PPR: one rotated offset per fetch
+                    const float *c0 = cand + (size_t)(pr * 64 + jl) * DP, *c1 = c0 + (size_t)32 * DP;
+                    float4 b0[NT], b1[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int po = ((h * NT + t + jl) & (PPR - 1)) * 4;
+                        b0[t] = *reinterpret_cast<const float4 *>(c0 + po);
+                        b1[t] = *reinterpret_cast<const float4 *>(c1 + po);
+                    }
+                    const float nc0 = cnorm[pr * 64 + jl], nc1 = cnorm[pr * 64 + 32 + jl];
+                    f32x16v acc0, acc1;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { acc0[r] = nc0; acc1[r] = nc1; }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b0[t].x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b1[t].x, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b0[t].y, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b1[t].y, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b0[t].z, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b1[t].z, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b0[t].w, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b1[t].w, acc1, 0, 0, 0);
+                    }
+                    if (phase == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mn[r] = vmin_f32(mn[r], vmin_f32(acc0[r], acc1[r]));
+                    } else {
+                        // branch-free compaction: the query pairs of a tile are independent instruction streams
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) {
+                            const int jg = j0 + pr * 64 + tt * 32 + jl;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const bool pred = (tt ? acc1[r] : acc0[r]) <= thr[r];
+                                const unsigned long long bal = __ballot(pred);
+                                const unsigned int lo = (unsigned int)bal, hi = (unsigned int)(bal >> 32);
+                                const int below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0)) -
+                                                  (h ? __builtin_popcount(lo) : 0);
+                                const int pos = cnt[r] + below;
+                                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                                if (pred && pos < kMListCap) mylists[row * kMListCap + pos] = jg;
+                                cnt[r] += h ? __builtin_popcount(hi) : __builtin_popcount(lo);
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (stage_next) {
+            const int j0n = ci_next * CH;
+            const int cnn = (M - j0n) < CH ? (M - j0n) : CH;
+            float *img = sm + (size_t)(1 - cur) * buf_floats;
+            const bool phase_a = nstep1 < nchunk;
+            knn_stage_chunk<DK>(yb, D, j0n, cnn, CH, img, keep_norms ? nall + (size_t)ci_next * CH : img + (size_t)CH * DP,
+                                cmax, phase_a, phase_a || !keep_norms, vec4y, wv - kMWaves, lane);
+        }
+        __syncthreads();
+        KNN_PROBE_MARK(3 + step);
+        if (stage_next) cur = 1 - cur;
+        if (step == nchunk - 1 && consumer) {
+            // ---- thresholds: kk-th smallest lane minimum per query, 16 queries per half-wave side by side ----
+            const float c2 = __builtin_bit_cast(float, *cmax);
+#pragma unroll
+            for (int kb = 2; kb <= 32; kb <<= 1) {
+#pragma unroll
+                for (int s = kb >> 1; s > 0; s >>= 1) {
+                    float o[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] = __shfl_xor(mn[r], s, 64);
+                    const bool up = (jl & kb) == 0 || kb == 32;
+                    const bool lower = (jl & s) == 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mn[r] = (lower == up) ? fminf(mn[r], o[r]) : fmaxf(mn[r], o[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float tau = __shfl(mn[r], (lane & 32) | (kk - 1), 64);
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float q2 = __shfl(qn, row, 64);
+                const float eps = (8.0f * (float)(D + 4) * 0x1p-24f) * (q2 + c2);
+                thr[r] = tau + 2.0f * eps;  // NaN / inf => slow path below
+            }
+        }
+    }
+    KNN_PROBE_MARK(20);
+
+    // ---- exact phase: consumer wave cw takes rows 0-15 of its queries, its producer partner rows 16-31 ----
+    if (consumer && jl == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const bool ok = thr[r] < INFINITY;  // false for NaN and +inf bands
+            cntl[cw * 32 + row] = ok ? cnt[r] : kMListCap + 1;
+        }
+    }
+    __syncthreads();  // lists + counts visible to the partner waves; the chunk buffers are free from here on
+    if (!wave_active) return;
+    // survivors' keys (distance bits << 32 | index): squared distances are >= +0, so the unsigned 64-bit order
+    // of the keys IS the reference's (distance, index) order and one v_cmp_lt_u64 compares a pair
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(sm) + (size_t)cw * 32 * kMListCap;
+    constexpr int QR = DK <= 2 ? 16 : 8;  // query rows staged per round (LDS budget)
+    float *qbuf = sm + (size_t)2 * kMWaves * 32 * kMListCap + (size_t)wv * QR * DP;
+    const int rbase = consumer ? 0 : 16;
+    const int need = kk < M ? kk : M;
+    if (q0 + rbase >= N) return;
+    for (int rs0 = 0; rs0 < 16; rs0 += QR) {
+        if (q0 + rbase + rs0 >= N) break;
+        {
+            const int left = N - (q0 + rbase + rs0);
+            const int nrow = left < QR ? left : QR;
+            const float *src = xb + (size_t)(q0 + rbase + rs0) * D;  // nrow contiguous rows
+            __builtin_amdgcn_wave_barrier();
+            for (int e = lane; e < nrow * D; e += 64) qbuf[e] = src[e];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+        // the oracle's distance for every survivor: eight queries in flight per lane, 16 dimensions at a time
+        for (int g0 = rs0; g0 < rs0 + QR; g0 += 8) {
+            if (q0 + rbase + g0 >= N) break;
+            bool on[8];
+            int jj[8];
+            const float *cp[8];
+            float s[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = rbase + g0 + u;
+                const int n = cntl[cw * 32 + row];
+                on[u] = q0 + row < N && n <= kMListCap && n >= need && lane < n;
+                jj[u] = on[u] ? mylists[row * kMListCap + lane] : 0;
+                cp[u] = yb + (size_t)jj[u] * D;
+                s[u] = 0.0f;
+            }
+            if (vec4y) {
+                for (int d0 = 0; d0 < D; d0 += 16) {
+                    float4 cv[8][4];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (d0 + 4 * t < D) cv[u][t] = *reinterpret_cast<const float4 *>(cp[u] + d0 + 4 * t);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float *qp = qbuf + (size_t)(g0 - rs0 + u) * D + d0;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (d0 + 4 * t < D) {
+                                const float4 qv = *reinterpret_cast<const float4 *>(qp + 4 * t);
+                                const float t0 = qv.x - cv[u][t].x, t1 = qv.y - cv[u][t].y, t2 = qv.z - cv[u][t].z,
+                                            t3 = qv.w - cv[u][t].w;
+                                s[u] = s[u] + t0 * t0;
+                                s[u] = s[u] + t1 * t1;
+                                s[u] = s[u] + t2 * t2;
+                                s[u] = s[u] + t3 * t3;
+                            }
+                    }
+                }
+            } else {
+                for (int d = 0; d < D; ++d) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float t = qbuf[(size_t)(g0 - rs0 + u) * D + d] - cp[u][d];
+                        s[u] = s[u] + t * t;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = rbase + g0 + u;
+                const unsigned long long key =
+                    ((unsigned long long)__builtin_bit_cast(unsigned int, s[u]) << 32) | (unsigned int)jj[u];
+                keys[row * kMListCap + lane] = on[u] ? key : ~0ull;  // sentinels behind the list
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    KNN_PROBE_MARK(21);
+    // rank of every survivor among its query's survivors: distinct keys => the ranks are a permutation.
+    // Four queries side by side, two keys per LDS read.
+    for (int g0 = 0; g0 < 16; g0 += 4) {
+        if (q0 + rbase + g0 >= N) break;
+        int n[4], rank[4], nmax = 0;
+        unsigned long long mine[4];
+        bool fast[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = rbase + g0 + u;
+            n[u] = cntl[cw * 32 + row];
+            fast[u] = q0 + row < N && n[u] <= kMListCap && n[u] >= need;
+            mine[u] = keys[row * kMListCap + lane];
+            rank[u] = 0;
+            nmax = fast[u] && n[u] > nmax ? n[u] : nmax;
+        }
+        for (int i = 0; i < nmax; i += 2) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = rbase + g0 + u;
+                const ulonglong2 o = *reinterpret_cast<const ulonglong2 *>(keys + row * kMListCap + i);
+                rank[u] += (o.x < mine[u] ? 1 : 0) + (o.y < mine[u] ? 1 : 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int qi = q0 + rbase + g0 + u;
+            const int r = rank[u] - drop;
+            if (fast[u] && lane < n[u] && r >= 0 && r < k) {
+                idx[((size_t)b * N + qi) * k + r] = (int)(unsigned int)mine[u];
+                if (dist) dist[((size_t)b * N + qi) * k + r] = __builtin_bit_cast(float, (unsigned int)(mine[u] >> 32));
+            }
+        }
+    }
+    // leftovers: overflowed lists, unusable bands
+    for (int row = rbase; row < rbase + 16; ++row) {
+        const int qi = q0 + row;
+        if (qi >= N) break;
+        const int n = cntl[cw * 32 + row];
+        if (n <= kMListCap && n >= need) continue;
+        float bd;
+        int bj;
+        knn_exact_bruteforce(xb + (size_t)qi * D, yb, M, D, lane, bd, bj);
+        const int r = lane - drop;
+        if (r >= 0 && r < k) {
+            idx[((size_t)b * N + qi) * k + r] = bj;
+            if (dist) dist[((size_t)b * N + qi) * k + r] = bd;
+        }
+    }
+    KNN_PROBE_MARK(22);
+}
+
 // ---- EdgeConv graph features (src/models/dgcnn.jl:36-51): cat(X, KNNGraph - X, dims=1) in one pass --------
 // layout 0: out (2F,K,N,B) as the reference holds it after `cat(..., dims = 1)` (:45)
 __global__ __launch_bounds__(kThreads) void edge_features_cat_kernel(const float *__restrict__ x, int N, int B,
@@ -579,6 +1083,53 @@ __global__ __launch_bounds__(kThreads) void edge_features_bwd_kernel(const float
     }
 }
 
+
+template <int DK>
+fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int B, int D, int k, int drop,
+                               int32_t *idx, float *dist, hipStream_t st) {
+    constexpr int DP = DK * 32, RS = DP + 4;
+    size_t fixed = (size_t)kMWaves * 32 * kMListCap * 4 + kMWaves * 32 * 4 + 64;
+    const int keep_norms = M <= 4096;  // all candidate norms stay in LDS: phase B does not recompute them
+    if (keep_norms) fixed += (size_t)((M + 255) / 256 * 256 + 256) * 4;
+    const size_t budget = 150 * 1024 - fixed;                                  // floats*4 for the two chunk buffers
+    int CH = (int)(budget / 2 / ((size_t)DP * 4 + 4)) / 64 * 64;
+    if (CH > 256) CH = 256;
+    const int mpad = (M + 63) / 64 * 64;
+    if (CH > mpad) CH = mpad;
+    size_t img = 2 * ((size_t)CH * DP + CH);                                   // floats
+    const size_t qstage = (size_t)kMWaves * 32 * RS;                           // prologue: query rows
+    const size_t exact = (size_t)2 * kMWaves * 32 * kMListCap + (size_t)2 * kMWaves * (DK <= 2 ? 16 : 8) * DP;  // keys + query rows
+    if (img < qstage) img = qstage;
+    if (img < exact) img = exact;
+    img = (img + 3) & ~(size_t)3;
+    const size_t lds = img * 4 + fixed;
+    static bool attr_done = false;
+    if (!attr_done) {
+        FX3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<DK>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        attr_done = true;
+    }
+    FX3D_REQUIRE(lds <= 152 * 1024, "fx3d_knn: internal LDS plan exceeds the CU (D=%d)", D);
+    const int qpb = kMWaves * 32;
+    const int nbx = (N + qpb - 1) / qpb;
+    const int bpad = B >= 8 ? (B + 7) / 8 * 8 : B;
+    hipLaunchKernelGGL((knn_mfma_kernel<DK>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
+                       k, drop, idx, dist, CH, (int)img, keep_norms);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status launch_knn_mfma(const float *x, int N, const float *y, int M, int B, int D, int k, int drop, int32_t *idx,
+                            float *dist, hipStream_t st) {
+    const int dk = (D + 31) / 32;
+    switch (dk) {
+        case 1: return launch_knn_mfma_dk<1>(x, N, y, M, B, D, k, drop, idx, dist, st);
+        case 2: return launch_knn_mfma_dk<2>(x, N, y, M, B, D, k, drop, idx, dist, st);
+        case 4: return launch_knn_mfma_dk<4>(x, N, y, M, B, D, k, drop, idx, dist, st);
+        default: return launch_knn_mfma_dk<4>(x, N, y, M, B, D, k, drop, idx, dist, st);
+    }
+}
+
 template <int KMAX>
 fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int D, int k, int drop,
                        int32_t *idx, float *dist, hipStream_t st) {
@@ -591,6 +1142,8 @@ fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int 
                            drop, idx, dist);
     } else if (D == 3) {
         hipLaunchKernelGGL(knn_d3_kernel<KMAX>, grid, dim3(kThreads), 0, st, x, N, y, M, B, k, drop, idx, dist);
+    } else if (!legacy && !getenv("FX3D_KNN_NO_MFMA") && D >= 4 && D <= 128 && k + drop <= 32 && M >= 64) {
+        return launch_knn_mfma(x, N, y, M, B, D, k, drop, idx, dist, st);
     } else if (!legacy && (size_t)kGT * (D + 1) * 4 + (kWThreads / 64) * (kGQ * (64 * 16 + 8) + D * 16) + 16 <= 64 * 1024) {
         const size_t lds = (size_t)kGT * (D + 1) * 4 + (kWThreads / 64) * (kGQ * (64 * 16 + 8) + D * 16) + 16;
         const int qpb = (kWThreads / 64) * kGQ;
@@ -621,8 +1174,9 @@ fx3d_status fx3d_knn(const float *x, int32_t N, const float *y, int32_t M, int32
         set_error("fx3d_knn: k+drop_first=%d > 64 is not supported", kk);
         return FX3D_ERR_UNSUPPORTED;
     }
-    if (D != 3 && (size_t)D * kThreads * sizeof(float) > 64 * 1024) {
-        set_error("fx3d_knn: D=%d > 64 is not supported", D);
+    const bool mfma_ok = D >= 4 && D <= 128 && kk <= 32 && M >= 64;
+    if (D != 3 && !mfma_ok && (size_t)D * kThreads * sizeof(float) > 64 * 1024) {
+        set_error("fx3d_knn: D=%d is supported for D <= 64, or D <= 128 with k+drop_first <= 32 and M >= 64", D);
         return FX3D_ERR_UNSUPPORTED;
     }
     hipStream_t st = as_stream(s);

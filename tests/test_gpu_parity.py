@@ -347,6 +347,40 @@ def test_knn_feature_space(gpu_fx, oracle, D):
     assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
 
 
+@pytest.mark.parametrize("D,N,M,B,k,drop,kind", [
+    (64, 1024, 1024, 2, 20, True, "normal"),     # second EdgeConv (src/models/dgcnn.jl:121), 3 LDS chunks
+    (4, 100, 77, 2, 5, False, "normal"),         # smallest D of the matrix-core path, ragged M
+    (5, 130, 200, 1, 31, True, "normal"),        # D % 4 != 0 (scalar staging), kk = 32
+    (33, 97, 333, 2, 10, True, "normal"),        # D just above a 32 multiple (zero-padded k-steps)
+    (100, 64, 640, 1, 8, False, "normal"),
+    (128, 300, 300, 1, 20, True, "scaled"),      # large norms: wide band, still exact
+    (120, 50, 90, 1, 3, False, "normal"),        # DK = 4, ragged d padding
+    (16, 256, 256, 1, 12, True, "lattice"),      # integer features: masses of exact ties
+    (8, 128, 160, 1, 20, False, "same"),         # all candidates identical: list overflow -> brute-force merge
+    (64, 96, 1500, 1, 20, False, "offset"),      # far-from-origin cloud (cancellation in the expanded form)
+])
+def test_knn_matrix_core_path(gpu_fx, oracle, D, N, M, B, k, drop, kind):
+    """knn_mfma_kernel: Float32 GEMM filter + exact re-scan must reproduce the oracle's (distance, index)
+    order bit for bit on ragged shapes, ties, degenerate and badly scaled inputs."""
+    rng = np.random.default_rng(D * 1000 + M)
+    if kind == "lattice":
+        gen = lambda n: rng.integers(0, 3, (D, n, B)).astype(np.float32)
+    elif kind == "same":
+        gen = lambda n: np.ones((D, n, B), np.float32) * np.float32(0.37)
+    else:
+        gen = lambda n: rng.standard_normal((D, n, B)).astype(np.float32)
+    x = np.asfortranarray(gen(N))
+    y = x if (N == M and kind != "scaled") else np.asfortranarray(gen(M))
+    if kind == "scaled":
+        x, y = x * np.float32(1.0e4), y * np.float32(1.0e4)
+    if kind == "offset":
+        x, y = x + np.float32(300.0), y + np.float32(300.0)
+    idx, dist = gpu_fx.knn(x, k, y=None if y is x else y, drop_first=drop)
+    oi, od = oracle.knn(x, k, y=None if y is x else y, drop_first=drop)
+    assert np.array_equal(idx.to_host(), oi)
+    assert np.array_equal(dist.to_host(), od)
+
+
 def test_knn_graph_gather(gpu_fx, oracle):
     """create_knn_graph == cat([X[:, knn idx]]...) (src/models/dgcnn.jl:3-7,36): (F,K,N,B)."""
     for F in (3, 64):
