@@ -22,7 +22,7 @@ import Flux3D: chamfer_distance, _chamfer_distance, _nearest_neighbors, sample_p
 using SparseArrays: SparseMatrixCSC, findnz
 import Zygote
 
-export HipArray, hip, unhip, use_hip, knn_graph
+export HipArray, hip, unhip, use_hip, knn_graph, edgeconv_graph, pointcloud_to_voxel
 
 const LIB = get(ENV, "FLUX3D_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libflux3d_hip.so"))
 const Stream = Ptr{Cvoid}
@@ -144,6 +144,40 @@ function knn_graph(X::HipArray{Float32,3}, K::Int)
     check(@ccall LIB.fx3d_knn_gather(X.ptr::Ptr{Cvoid}, N::Int32, B::Int32, F::Int32, K::Int32, idx.ptr::Ptr{Cvoid},
                                      out.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
     return out      # (F,K,N,B), what `cat([CreateSingleKNNGraph(X[:,:,i],K) ...]..., dims=4)` builds at :36
+end
+
+# EdgeConv's graph build up to the MLP input (src/models/dgcnn.jl:32-51): self-kNN + cat(X, KNNGraph - X) +
+# PermutedDimsArray + reshape in one library call; layout 1 = (K*N, 2F, B), layout 0 = (2F, K, N, B)
+function edgeconv_graph(X::HipArray{Float32,3}, K::Int; layout::Int = 1)
+    F, N, B = size(X)
+    idx = HipArray{Int32}(undef, K, N, B)
+    out = layout == 1 ? HipArray{Float32}(undef, K * N, 2F, B) : HipArray{Float32}(undef, 2F, K, N, B)
+    check(@ccall LIB.fx3d_edgeconv_graph(X.ptr::Ptr{Cvoid}, N::Int32, B::Int32, F::Int32, K::Int32, layout::Int32,
+                                         idx.ptr::Ptr{Cvoid}, out.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    return out
+end
+# the graph is @nograd upstream (src/models/dgcnn.jl:9): only the repeated-X terms carry gradient
+Zygote.@adjoint function edgeconv_graph(X::HipArray{Float32,3}, K::Int; layout::Int = 1)
+    F, N, B = size(X)
+    out = edgeconv_graph(X, K; layout = layout)
+    function back(g)
+        gx = HipArray{Float32}(undef, F, N, B)
+        check(@ccall LIB.fx3d_edge_features_bwd(g.ptr::Ptr{Cvoid}, N::Int32, B::Int32, F::Int32, K::Int32,
+                                                layout::Int32, gx.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+        return (gx, nothing)
+    end
+    return out, back
+end
+
+# pointcloud_to_voxel (src/conversions.jl:91-131) for device clouds -> (res,res,res,B) Float32 0/1
+function pointcloud_to_voxel(p::PointCloud, res::Int = 32)
+    pts = p.points::HipArray{Float32,3}
+    _, N, B = size(pts)
+    nb = Ref{Csize_t}(0); check(@ccall LIB.fx3d_voxel_workspace_bytes(B::Int32, nb::Ref{Csize_t})::Int32)
+    ws = workspace(nb[]); vox = HipArray{Float32}(undef, res, res, res, B)
+    check(@ccall LIB.fx3d_pointcloud_to_voxel(pts.ptr::Ptr{Cvoid}, N::Int32, B::Int32, res::Int32, vox.ptr::Ptr{Cvoid},
+                                              ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t, DEFAULT_STREAM::Stream)::Int32)
+    return vox
 end
 
 # ---- TriMesh device mirrors: int32 0-based copies of the host integer data (cached per mesh) ---
