@@ -31,8 +31,8 @@ FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector peak == fp32-input
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm", choices=["torch", "native"], default="native",
                     help="multi-GPU all-reduce through torch.distributed (RCCL) or the library's own RCCL communicator")

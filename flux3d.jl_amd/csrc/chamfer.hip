@@ -917,6 +917,7 @@ constexpr int kHLT = 2;           // 32-candidate blocks per lane tile (lane see
 constexpr int kHFifo = 3;
 constexpr int kHChunkMax = 4096;  // 32 B per candidate => 128 KiB
 constexpr int kHItemCap = 64 * kHFifo;  // the FIFO path never overflows the list
+static_assert(kHFifo <= 4 && kHChunkMax / (32 * kHLT) < 255, "FIFO lane-tile ids are packed one byte each");
 constexpr size_t kHScratchBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 4 + 32 * 3 * 4) + 64 * 32;  // + 2 pad blocks
 
 // plain v_min_f32 (fminf() also emits a canonicalising v_max in IEEE mode; the filter values are never
@@ -1122,9 +1123,9 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             }
 
             float best = INFINITY, tm = INFINITY, ft[kHFifo];
-            int fi[kHFifo];
+            unsigned int fis = 0xffffffffu;  // the FIFO's lane-tile ids, one byte each (0xff = empty): a shift register
 #pragma unroll
-            for (int s = 0; s < kHFifo; ++s) { ft[s] = INFINITY; fi[s] = -1; }
+            for (int s = 0; s < kHFifo; ++s) ft[s] = INFINITY;
 
             // ---- main loop, software-pipelined by one 32-candidate block -----------------------------------
             // (the image carries two padding blocks behind cnt_pad, so the prefetch never needs a clamp
@@ -1154,13 +1155,16 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 pa += kHLT * 64;
                 const bool qual = tm <= best + delta;
 #pragma unroll
-                for (int s = kHFifo - 1; s > 0; --s) {
-                    ft[s] = qual ? ft[s - 1] : ft[s];
-                    fi[s] = qual ? fi[s - 1] : fi[s];
-                }
+                for (int s = kHFifo - 1; s > 0; --s) ft[s] = qual ? ft[s - 1] : ft[s];
                 ft[0] = qual ? tm : ft[0];
-                fi[0] = qual ? lt : fi[0];
+                fis = qual ? ((fis << 8) | (unsigned int)lt) : fis;  // one v_lshl_or + one v_cndmask
                 best = vmin(best, tm);
+            }
+            int fi[kHFifo];
+#pragma unroll
+            for (int s = 0; s < kHFifo; ++s) {
+                const unsigned int id = (fis >> (8 * s)) & 0xffu;
+                fi[s] = id == 0xffu ? -1 : (int)id;
             }
             FX3D_PROBE_MARK(tp == 0 ? 3 : 7);
 
