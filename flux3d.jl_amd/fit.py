@@ -14,16 +14,22 @@ from .metrics import (_chamfer_points, chamfer_distance_grad, edge_loss, edge_lo
 from .transforms import lincomb, offset, sample_points, sample_points_grad
 
 
-def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_lap=0.1, w_edge=1.0):
-    """Returns the Float32 loss (and the gradient w.r.t. x, device (3,sumV), when with_grad)."""
+def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_lap=0.1, w_edge=1.0, sync=True):
+    """Returns the Float32 loss (and the gradient w.r.t. x, device (3,sumV), when with_grad).
+    ``sync=False``: the loss stays a 1-element device array (the three terms are combined by fx3d_lincomb in
+    the reference's order) and the call enqueues without a single host round trip."""
     m = offset(src, x)
     s1 = None if seed is None else seed
     s2 = None if seed is None else seed + 1
     A, fa, r1, r2 = sample_points(m, num_samples, seed=s1, return_draws=True)
     Bp = sample_points(tgt, num_samples, seed=s2)
-    loss1, ix, iy = _chamfer_points(A, Bp, 1.0, 1.0, return_indices=True)
-    loss2, loss3 = laplacian_loss(m), edge_loss(m)
-    loss = np.float32(np.float32(loss1 + np.float32(w_lap) * loss2) + np.float32(w_edge) * loss3)
+    loss1, ix, iy = _chamfer_points(A, Bp, 1.0, 1.0, return_indices=True, sync=sync)
+    loss2, loss3 = laplacian_loss(m, sync=sync), edge_loss(m, sync=sync)
+    if sync:
+        loss = np.float32(np.float32(loss1 + np.float32(w_lap) * loss2) + np.float32(w_edge) * loss3)
+    else:  # fl(fl(l1 + fl(w_lap*l2)) + fl(w_edge*l3)) on the device as well (unfused)
+        loss = lincomb(1.0, loss1, w_lap, loss2)
+        loss = lincomb(1.0, loss, w_edge, loss3)
     if not with_grad:
         return loss
     gA, _ = chamfer_distance_grad(A, Bp, ix, iy)

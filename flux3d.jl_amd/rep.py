@@ -176,16 +176,25 @@ class TriMesh:
         self._verts_packed_valid = False
         self._verts_padded_valid = False
         self._verts_list_valid = True
-        self._faces_packed = None
-        self._faces_padded = None
-        # topology caches (never invalidated: faces are immutable, :87-97)
-        self._edges_packed = None
-        self._faces_to_edges_packed = None
-        self._laplacian_packed = None  # (rowptr, colind, vals) host CSR, 0-based
-        # device mirrors
+        # topology caches (never invalidated: faces are immutable, :87-97).  They live in dicts SHARED by every
+        # TriMesh derived from this one (gpu/cpu, offset): `offset(m, x)` is deepcopy + offset! upstream
+        # (src/transforms/mesh_func.jl:435-438) and must not rebuild edges / Laplacian per optimiser step
+        self._topo = {}       # faces_packed, faces_padded, edges_packed, faces_to_edges_packed, laplacian_packed
+        self._topo_dev = {}   # int32 0-based device mirrors of the integer data
+        # device mirrors of the vertex positions (per mesh)
         self._dev = {}
         if self._device:
             self._dev["verts_packed"] = DeviceArray.from_host(self.get_verts_packed_host())
+
+    def _topo_prop(name):  # noqa: N805  (attribute backed by the shared topology dict)
+        return property(lambda self: self._topo.get(name), lambda self, v: self._topo.__setitem__(name, v))
+
+    _faces_packed = _topo_prop("faces_packed")
+    _faces_padded = _topo_prop("faces_padded")
+    _edges_packed = _topo_prop("edges_packed")
+    _faces_to_edges_packed = _topo_prop("faces_to_edges_packed")
+    _laplacian_packed = _topo_prop("laplacian_packed")  # (rowptr, colind, vals) host CSR, 0-based
+    del _topo_prop
 
     # ---- verts -----------------------------------------------------------------------------
     def get_verts_list(self):
@@ -239,7 +248,7 @@ class TriMesh:
         positions -- what `offset(m, x)` (deepcopy + offset!, src/transforms/mesh_func.jl:409-438) needs."""
         m = TriMesh.__new__(TriMesh)
         m.__dict__.update(self.__dict__)
-        m._dev = {k: v for k, v in self._dev.items() if not k.startswith("verts")}
+        m._dev = {}  # vertex mirrors are per mesh; _topo / _topo_dev stay shared
         m._device = True
         m._dev["verts_packed"] = new_packed
         m._verts_list_valid = False
@@ -345,8 +354,9 @@ class TriMesh:
     def dev(self, name):
         """Cached device copies: faces_packed / faces_padded / faces_len (int32 0-based), edges
         (E,2) int32 0-based, lap_rowptr / lap_colind / lap_vals, and verts_* float32."""
-        if name in self._dev:
-            return self._dev[name]
+        store = self._dev if name.startswith("verts") else self._topo_dev
+        if name in store:
+            return store[name]
         b = self.index_base
         if name == "verts_packed":
             arr = DeviceArray.from_host(self.get_verts_packed_host())
@@ -364,15 +374,15 @@ class TriMesh:
             arr = DeviceArray.from_host((self.get_edges_packed().astype(np.int64) - b).astype(np.int32))
         elif name in ("lap_rowptr", "lap_colind", "lap_vals"):
             rowptr, colind, vals = self.get_laplacian_packed()
-            self._dev["lap_rowptr"] = DeviceArray.from_host(rowptr)
-            self._dev["lap_colind"] = DeviceArray.from_host(colind)
-            self._dev["lap_vals"] = DeviceArray.from_host(vals)
-            return self._dev[name]
+            store["lap_rowptr"] = DeviceArray.from_host(rowptr)
+            store["lap_colind"] = DeviceArray.from_host(colind)
+            store["lap_vals"] = DeviceArray.from_host(vals)
+            return store[name]
         else:
             raise KeyError(name)
         if name.startswith("verts") and not self._device:
             return arr  # host mesh: do not cache vertex uploads (verts may change)
-        self._dev[name] = arr
+        store[name] = arr
         return arr
 
     # ---- gpu / cpu (functor(::TriMesh) moves only the verts, src/rep/mesh.jl:189-190) ---------------
@@ -399,13 +409,7 @@ class TriMesh:
         return m
 
     def _share_topology(self, other):
-        self._faces_packed, self._faces_padded = other._faces_packed, other._faces_padded
-        self._edges_packed = other._edges_packed
-        self._faces_to_edges_packed = other._faces_to_edges_packed
-        self._laplacian_packed = other._laplacian_packed
-        for k, v in other._dev.items():
-            if not k.startswith("verts"):
-                self._dev[k] = v
+        self._topo, self._topo_dev = other._topo, other._topo_dev
 
     def __getitem__(self, i):
         return self.get_verts_list()[i], self._faces_list[i]

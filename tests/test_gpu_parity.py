@@ -606,6 +606,21 @@ def test_loss_dolphin_gradient(gpu_fx, oracle):
     assert np.allclose(g.to_host(), ref, rtol=1e-3, atol=1e-7)
 
 
+def test_loss_dolphin_async_matches_sync(gpu_fx):
+    """sync=False keeps the three loss terms and their sum on the device: same Float32 value, same gradient."""
+    fx = gpu_fx
+    src = fx.gpu(fx.load_trimesh(os.path.join(GOLDEN, "sphere.obj")))
+    tgt = fx.gpu(fx.load_trimesh(os.path.join(GOLDEN, "teapot.obj")))
+    x = fx.DeviceArray.zeros((3, src.get_verts_packed().shape[1]), np.float32)
+    l0, g0 = fx.loss_dolphin(x, src, tgt, 2000, seed=11, with_grad=True)
+    l1, g1 = fx.loss_dolphin(x, src, tgt, 2000, seed=11, with_grad=True, sync=False)
+    assert np.float32(l1.item()) == l0
+    # the scatter-adds of the two adjoints use float atomics: order-dependent in the last bit
+    assert np.allclose(g0.to_host(), g1.to_host(), rtol=1e-4, atol=1e-8)
+    # offset() shares the topology caches: the Laplacian is built once for all derived meshes
+    assert fx.offset(src, x)._topo is src._topo and src._topo.get("laplacian_packed") is not None
+
+
 def test_fit_mesh_loop_decreases_loss(gpu_fx):
     """A short run of the tutorial's optimisation (examples/fit_mesh.jl:99-110) entirely on the device."""
     fx = gpu_fx
