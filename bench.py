@@ -237,6 +237,27 @@ def cpu_baseline(fx):
     oracle.chamfer_distance(xb, yb)
     dt_bf = time.perf_counter() - t0
     pairs = B_PER_GPU * NPTS * MPTS
+    oracle.nn1_allcores(x[:, :64, :1], y[:, :64, :1])  # spawn the OpenMP team outside the timed region
+    dt_kd_mt = dt_bf_mt = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        _, _, nthr = oracle.nn1_allcores(x, y, kdtree=True)
+        dt = time.perf_counter() - t0
+        dt_kd_mt = dt if dt_kd_mt is None else min(dt_kd_mt, dt)
+        t0 = time.perf_counter()
+        oracle.nn1_allcores(x, y, kdtree=False)
+        dt = time.perf_counter() - t0
+        dt_bf_mt = dt if dt_bf_mt is None else min(dt_bf_mt, dt)
+    extra = {"allcores_threads": nthr,
+             "kdtree_allcores_pairs_per_s": pairs / dt_kd_mt,
+             "bruteforce_allcores_pairs_per_s": pairs / dt_bf_mt,
+             "allcores_sample": f"full workload, min of 3: KD-tree {dt_kd_mt:.4f} s (64 tasks), brute force {dt_bf_mt:.4f} s",
+             "allcores_note": "NN searches only, OpenMP threads = usable cores (affinity capped by the cgroup quota); the reference itself is "
+                              "single-threaded (src/metrics/pcloud.jl:57-58), so `value` stays the 1-core figure"}
+    return {**_cpu_main(pairs, best, dt_bf), **extra}
+
+
+def _cpu_main(pairs, best, dt_bf):
     return {"value": pairs / best, "unit": "pairs/s", "cores": 1, "kind": "port",
             "sample": f"full workload B={B_PER_GPU} N=M={NPTS}, KD-tree 1-NN both directions, min of 3 ({best:.3f} s)",
             "bruteforce_1core_pairs_per_s": 4 * NPTS * MPTS / dt_bf,

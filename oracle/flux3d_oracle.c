@@ -247,6 +247,55 @@ FX_API int fx3d_oracle_nn1_kdtree(const float *x, int N, const float *y, int M, 
     return 0;
 }
 
+/* All-core variants for the cpu_baseline leg only ("brute-force fp32 on 1 core and on all
+ * cores"): the 2*B independent (batch element, direction) searches are spread over OpenMP threads; every
+ * search is the serial code above, so the results are identical.  Returns the number of threads used. */
+#include <omp.h>
+FX_API int fx3d_oracle_nn1_allcores(const float *x, int N, const float *y, int M, int B, int D,
+                                    int32_t *idx_x, int32_t *idx_y, int use_kdtree, int want_threads) {
+    if (N <= 0 || M <= 0 || B <= 0 || D <= 0) return -1;
+    int nthreads = 1;
+    if (want_threads > 0) omp_set_num_threads(want_threads);
+    if (use_kdtree) {  /* one task per (batch element, direction): tree build + its queries */
+#pragma omp parallel
+        {
+#pragma omp single
+            nthreads = omp_get_num_threads();
+#pragma omp for schedule(dynamic, 1)
+            for (int t = 0; t < 2 * B; ++t) {
+                const int b = t >> 1;
+                const float *xb = x + (size_t)b * N * D, *yb = y + (size_t)b * M * D;
+                if ((t & 1) == 0) kdt_nn1_dir(xb, N, yb, M, D, idx_x + (size_t)b * N);
+                else kdt_nn1_dir(yb, M, xb, N, D, idx_y + (size_t)b * M);
+            }
+        }
+        return nthreads;
+    }
+    /* brute force: tasks of 128 queries */
+    const int QB = 128;
+    const int nbx = (N + QB - 1) / QB, nby = (M + QB - 1) / QB;
+    const long long ntask = (long long)B * (nbx + nby);
+#pragma omp parallel
+    {
+#pragma omp single
+        nthreads = omp_get_num_threads();
+#pragma omp for schedule(dynamic, 4)
+        for (long long t = 0; t < ntask; ++t) {
+            const int b = (int)(t / (nbx + nby));
+            const int r = (int)(t % (nbx + nby));
+            const float *xb = x + (size_t)b * N * D, *yb = y + (size_t)b * M * D;
+            if (r < nbx) {
+                const int lo = r * QB, n = (N - lo) < QB ? (N - lo) : QB;
+                nn1_dir(xb + (size_t)lo * D, n, yb, M, D, idx_x + (size_t)b * N + lo, NULL);
+            } else {
+                const int lo = (r - nbx) * QB, n = (M - lo) < QB ? (M - lo) : QB;
+                nn1_dir(yb + (size_t)lo * D, n, xb, N, D, idx_y + (size_t)b * M + lo, NULL);
+            }
+        }
+    }
+    return nthreads;
+}
+
 /* Whole reference CPU forward (KD-tree NN + gather + mean), for the cpu_baseline timing leg. */
 FX_API int fx3d_oracle_chamfer_fwd_kdtree(const float *x, int N, const float *y, int M, int B,
                                           int D, float w1, float w2, float *loss) {

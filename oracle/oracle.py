@@ -72,6 +72,33 @@ def nn1(x, y, want_dist=False, kdtree=False):
     return (ix, iy, dx, dy) if want_dist else (ix, iy)
 
 
+def usable_cores():
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota."""
+    import os
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def nn1_allcores(x, y, kdtree=False, threads=None):
+    """cpu_baseline leg only: the same searches spread over the usable host cores (OpenMP).
+    Returns (idx_x, idx_y, threads_used)."""
+    x, D, N, B = _dims(x)
+    y, D2, M, B2 = _dims(y)
+    assert D == D2 and B == B2
+    ix = np.zeros((N, B), np.int32, order="F")
+    iy = np.zeros((M, B), np.int32, order="F")
+    nt = lib().fx3d_oracle_nn1_allcores(_p(x), N, _p(y), M, B, D, _p(ix), _p(iy), int(bool(kdtree)),
+                                        int(threads or usable_cores()))
+    assert nt >= 1
+    return ix, iy, nt
+
+
 def chamfer_distance(x, y, w1=1.0, w2=1.0, return_all=False, kdtree=False):
     """_chamfer_distance (src/metrics/pcloud.jl:39-52)."""
     x, D, N, B = _dims(x)
