@@ -981,6 +981,469 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     KNN_PROBE_MARK(22);
 }
 
+// ------------------------------------------------------------------------------------------------
+// knn_f16_d3_kernel: kNN for D = 3 (DGCNN's first EdgeConv, BASELINE config 4) with the chamfer kernel's
+// fp16-split filter (chamfer.hip, nn1_f16_kernel: t = |c~|^2 + qm~ . c~ on ONE v_mfma_f32_32x32x16_f16 per
+// 32 x 32 tile, |t - s^2 (d_oracle - |q'|^2)| <= delta~/2 with delta~ = 2^-19 (6 + 2S + S^2/8)).
+//   Lane l = (hh, jq) holds query jq of its wave and the 16 candidate rows (r&3)+8(r>>2)+4hh of every tile.
+//   Phase A: per lane and register the minimum over all tiles: 32 group minima per query (16 registers x
+//            2 half-waves), each over M/32 candidates.  The kk-th smallest of them bounds the kk-th smallest
+//            filter value: tau.  Selection = 16-element sorting network in registers + one exchange with the
+//            partner lane + bitonic merge: no LDS, all 32 queries of the wave at once.
+//   Phase B: the filter again; rows with t <= tau + delta~ are appended to the LANE's private LDS list
+//            (unconditional store at the list head, the head advances by the compare's carry bit: 5 VALU per
+//            row, no ballots, no atomics).  A superset of the k nearest, ~1.6 kk entries per query.
+//   Exact:   every lane evaluates the oracle's distance of its own entries (the query is in its registers)
+//            and writes keys (distance bits << 32 | index) into the query's list; a key's rank among the
+//            query's keys is its output slot.  Bit-identical to fx3d_oracle_knn.
+//   Queries outside the fp16 range, with overflowing lists or non-finite thresholds take the brute-force merge.
+typedef _Float16 kh8 __attribute__((ext_vector_type(8)));
+constexpr int kTWaves = 2;            // 64 queries per block: C4 gets 512 blocks, two per CU
+constexpr int kTThreads = kTWaves * 64;
+constexpr int kTCap = 48;             // rows of a lane's list (47 usable + the scratch head)
+constexpr int kTKeyCap = 64;          // keys per query (the two lanes' survivors + sentinels)
+constexpr int kTKeyStride = kTKeyCap + 4;  // row stride in words: 32 queries x b128 reads without bank conflicts
+constexpr int kTChunk = 4096;         // candidates per LDS image (32 B each)
+constexpr int kTRawMax = 2048;        // clouds up to this size also keep their raw coordinates in LDS
+
+__device__ __forceinline__ float vmax_f32(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void k3_split2h(float v, _Float16 &h, _Float16 &l) {
+    h = (_Float16)v;
+    l = (_Float16)(v - (float)h);
+}
+// fp16 image pieces of one candidate c~ = s (c - mu): same K-slot table as nn1_f16_kernel
+__device__ __forceinline__ void k3_make_pieces(float cx, float cy, float cz, kh8 &p0, kh8 &p1) {
+    _Float16 hx, lx, hy, ly, hz, lz, n1, n2, n3;
+    k3_split2h(cx, hx, lx); k3_split2h(cy, hy, ly); k3_split2h(cz, hz, lz);
+    const float n = ((cx * cx) + (cy * cy)) + (cz * cz);
+    n1 = (_Float16)n;
+    const float r1 = n - (float)n1;
+    n2 = (_Float16)r1;
+    n3 = (_Float16)(r1 - (float)n2);
+    const _Float16 z = (_Float16)0.0f;
+    p0 = kh8{hx, hx, lx, hy, hy, ly, hz, hz};
+    p1 = kh8{lz, n1, n2, n3, lx, ly, lz, z};
+}
+// ascending bitonic sorting network on NV registers (compile-time indices only)
+template <int NV>
+__device__ __forceinline__ void k3_sort_regs(float (&v)[NV]) {
+#pragma unroll
+    for (int kb = 2; kb <= NV; kb <<= 1) {
+#pragma unroll
+        for (int j = kb >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool asc = (i & kb) == 0;
+                    const float lo = vmin_f32(v[i], v[l]), hi = vmax_f32(v[i], v[l]);
+                    v[i] = asc ? lo : hi;
+                    v[l] = asc ? hi : lo;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__restrict__ x, int N,
+                                                               const float *__restrict__ y, int M, int B, int k,
+                                                               int drop, int32_t *__restrict__ idx,
+                                                               float *__restrict__ dist, int CH, int img_bytes,
+                                                               int raw_ok) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char k3sm[];
+    __shared__ float red[2 * 4 * kTWaves];
+    kh8 *imgp = reinterpret_cast<kh8 *>(k3sm);  // piece (blk, half, row) at (blk*2 + half)*32 + row
+    constexpr int kListBytes = kTWaves * kTCap * 64 * 4;
+    int *lists_all = reinterpret_cast<int *>(k3sm + img_bytes);                                  // [kTWaves][kTCap][64]
+    const float4 *rawc = reinterpret_cast<const float4 *>(k3sm + img_bytes + kListBytes);      // [M] when raw_ok
+
+    const int nbx = (N + kTWaves * 32 - 1) / (kTWaves * 32);
+    const int L = blockIdx.x;
+    const bool by_xcd = B >= 8;
+    const int b = by_xcd ? ((L >> 3) / nbx) * 8 + (L & 7) : L / nbx;
+    const int bxq = by_xcd ? (L >> 3) % nbx : L % nbx;
+    if (b >= B) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int jq = lane & 31, hh = lane >> 5;
+    const int kk = k + drop;
+    const float *xb = x + (size_t)b * N * 3, *yb = y + (size_t)b * M * 3;
+    const int q0 = (bxq * kTWaves + wv) * 32;
+    const bool wave_active = q0 < N;
+    KNN_PROBE_MARK(0);
+
+    // ---- one pass over the cloud: bounding box (-> centre mu, power-of-two scale sc with |c~| <= 1) and, for
+    //      clouds up to kTRawMax points, the raw coordinates parked in LDS for the staging and the exact phase ----
+    float mu[3], cinf = 0.0f;
+    {
+        float4 *raww = reinterpret_cast<float4 *>(k3sm + img_bytes + kListBytes);
+        float mn3[3] = {INFINITY, INFINITY, INFINITY}, mx3[3] = {-INFINITY, -INFINITY, -INFINITY};
+        const bool vec = (reinterpret_cast<uintptr_t>(yb) & 15) == 0;
+        const int nv4 = vec ? M / 4 : 0;
+        for (int g = tid; g < nv4; g += kTThreads) {  // four points = three 16-byte loads
+            const float4 *s4 = reinterpret_cast<const float4 *>(yb + (size_t)g * 12);
+            const float4 f0 = s4[0], f1 = s4[1], f2 = s4[2];
+            const float px[4] = {f0.x, f0.w, f1.z, f2.y}, py[4] = {f0.y, f1.x, f1.w, f2.z}, pz[4] = {f0.z, f1.y, f2.x, f2.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mn3[0] = fminf(mn3[0], px[e]); mx3[0] = fmaxf(mx3[0], px[e]);
+                mn3[1] = fminf(mn3[1], py[e]); mx3[1] = fmaxf(mx3[1], py[e]);
+                mn3[2] = fminf(mn3[2], pz[e]); mx3[2] = fmaxf(mx3[2], pz[e]);
+                if (raw_ok) raww[g * 4 + e] = float4{px[e], py[e], pz[e], 0.0f};
+            }
+        }
+        for (int pt = nv4 * 4 + tid; pt < M; pt += kTThreads) {
+            float v[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                v[d] = yb[(size_t)pt * 3 + d];
+                mn3[d] = fminf(mn3[d], v[d]);
+                mx3[d] = fmaxf(mx3[d], v[d]);
+            }
+            if (raw_ok) raww[pt] = float4{v[0], v[1], v[2], 0.0f};
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float lo = mn3[d], hi = mx3[d];
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                lo = fminf(lo, __shfl_xor(lo, m, 64));
+                hi = fmaxf(hi, __shfl_xor(hi, m, 64));
+            }
+            if (lane == 0) { red[(wv * 2) * 4 + d] = lo; red[(wv * 2 + 1) * 4 + d] = hi; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float lo = red[d], hi = red[4 + d];
+#pragma unroll
+            for (int w = 1; w < kTWaves; ++w) {
+                lo = fminf(lo, red[(w * 2) * 4 + d]);
+                hi = fmaxf(hi, red[(w * 2 + 1) * 4 + d]);
+            }
+            mu[d] = 0.5f * lo + 0.5f * hi;
+            cinf = fmaxf(cinf, fmaxf(hi - mu[d], mu[d] - lo));
+        }
+        cinf = cinf * 1.000001f;
+    }
+    const bool sane = cinf < 1.0e18f;  // false for NaN / inf coordinates
+    float sc = 1.0f;
+    if (sane && cinf > 1.0e-30f) {
+        int e;
+        (void)frexpf(cinf, &e);
+        sc = ldexpf(1.0f, -e);
+    }
+    KNN_PROBE_MARK(1);
+
+    // ---- this lane's query: B operand, band --------------------------------------------------------------------
+    const int qi = q0 + jq;
+    const int qc = qi < N ? qi : N - 1;
+    const float qr[3] = {xb[(size_t)qc * 3], xb[(size_t)qc * 3 + 1], xb[(size_t)qc * 3 + 2]};
+    const float m0 = -2.0f * ((qr[0] - mu[0]) * sc), m1 = -2.0f * ((qr[1] - mu[1]) * sc), m2 = -2.0f * ((qr[2] - mu[2]) * sc);
+    const float S = (fabsf(m0) + fabsf(m1)) + fabsf(m2);
+    const bool qok = S < 3.0e4f;  // inside the fp16 range (also false for NaN)
+    const float delta = (6.0f + 2.0f * S + 0.125f * S * S) * 0x1p-19f;
+    kh8 bq;
+    {
+        _Float16 hx, lx, hy, ly, hz, lz;
+        k3_split2h(qok ? m0 : 0.f, hx, lx); k3_split2h(qok ? m1 : 0.f, hy, ly); k3_split2h(qok ? m2 : 0.f, hz, lz);
+        const _Float16 one = (_Float16)1.0f, z = (_Float16)0.0f;
+        bq = hh == 0 ? kh8{hx, lx, hx, hy, ly, hy, hz, lz} : kh8{hz, one, one, one, lx, ly, lz, z};
+    }
+
+    float mn[32];  // group minima: [r] even tiles, [16 + r] odd tiles -> 64 groups of M/64 candidates per query
+#pragma unroll
+    for (int r = 0; r < 32; ++r) mn[r] = INFINITY;
+    float thr = 0.0f;
+    int cnt = 0;
+    int *mylist = lists_all + wv * kTCap * 64 + lane;  // entry e at mylist[e * 64]
+    f32x16v zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
+    const int nchunk = (M + CH - 1) / CH;
+
+    for (int phase = 0; phase < 2; ++phase) {
+        for (int ci = 0; ci < nchunk; ++ci) {
+            const int j0 = (phase == 0 ? ci : nchunk - 1 - ci) * CH;  // phase B backwards: its first chunk is staged
+            const int cn = (M - j0) < CH ? (M - j0) : CH;
+            const int cn_pad = (cn + 63) & ~63;
+            if (!(phase == 1 && ci == 0)) {
+                __syncthreads();
+                // (two separate loops: a select between an LDS and a global pointer trips the compiler)
+                if (raw_ok) {
+                    for (int pt = tid; pt < cn_pad; pt += kTThreads) {
+                        const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
+                        kh8 p0, p1;
+                        if (pt < cn) {
+                            const float4 rc = rawc[j0 + pt];
+                            k3_make_pieces((rc.x - mu[0]) * sc, (rc.y - mu[1]) * sc, (rc.z - mu[2]) * sc, p0, p1);
+                        } else {  // padding: n1 = +inf => t = +inf, never below a finite threshold
+                            k3_make_pieces(0.f, 0.f, 0.f, p0, p1);
+                            p1[1] = (_Float16)INFINITY;
+                        }
+                        imgp[i0] = p0;
+                        imgp[i0 + 32] = p1;
+                    }
+                } else {
+                    for (int pt = tid; pt < cn_pad; pt += kTThreads) {
+                        const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
+                        kh8 p0, p1;
+                        if (pt < cn) {
+                            const float *src = yb + (size_t)(j0 + pt) * 3;
+                            k3_make_pieces((src[0] - mu[0]) * sc, (src[1] - mu[1]) * sc, (src[2] - mu[2]) * sc, p0, p1);
+                        } else {
+                            k3_make_pieces(0.f, 0.f, 0.f, p0, p1);
+                            p1[1] = (_Float16)INFINITY;
+                        }
+                        imgp[i0] = p0;
+                        imgp[i0 + 32] = p1;
+                    }
+                }
+                __syncthreads();
+                KNN_PROBE_MARK(2);
+            }
+            if (wave_active) {
+                const kh8 *pa = imgp + hh * 32 + jq;
+                const int npair = cn_pad / 64;
+                const int tile0 = j0 / 32;
+                for (int pr = 0; pr < npair; ++pr) {
+                    const f32x16v acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[(pr * 2) * 64], bq, zero, 0, 0, 0);
+                    const f32x16v acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[(pr * 2 + 1) * 64], bq, zero, 0, 0, 0);
+                    if (phase == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            mn[r] = vmin_f32(mn[r], acc0[r]);
+                            mn[16 + r] = vmin_f32(mn[16 + r], acc1[r]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) {
+                            // one word per tile: (tile index << 16) | mask of the rows with t <= thr; stored at the
+                            // list head unconditionally, the head advances when the mask is not empty
+                            unsigned int m = 0;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) m |= ((tt ? acc1[r] : acc0[r]) <= thr) ? (1u << r) : 0u;
+                            const int pp = cnt < kTCap - 1 ? cnt : kTCap - 1;
+                            mylist[pp * 64] = (int)((unsigned int)(tile0 + pr * 2 + tt) << 16 | m);
+                            cnt += m != 0 ? 1 : 0;
+                        }
+                    }
+                }
+            }
+        }
+        KNN_PROBE_MARK(phase ? 5 : 3);
+        if (phase == 0) {
+            // ---- tau: kk-th smallest of the 64 group minima of every query (32 in this lane, 32 in its partner) ----
+            k3_sort_regs<32>(mn);
+            float oth[32];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) oth[r] = __shfl_xor(mn[31 - r], 32, 64);
+#pragma unroll
+            for (int r = 0; r < 32; ++r)  // half 0 keeps the 32 smallest of the 64 (a bitonic sequence)
+                mn[r] = hh ? vmax_f32(mn[r], oth[r]) : vmin_f32(mn[r], oth[r]);
+#pragma unroll
+            for (int j = 16; j > 0; j >>= 1) {  // one bitonic merge sorts it ascending
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const float lo = vmin_f32(mn[i], mn[l]), hi = vmax_f32(mn[i], mn[l]);
+                        mn[i] = lo;
+                        mn[l] = hi;
+                    }
+                }
+            }
+            float val = mn[0];
+#pragma unroll
+            for (int r = 1; r < 32; ++r) val = (kk - 1) == r ? mn[r] : val;
+            const float tau = __shfl(val, jq, 64);  // kk <= 32: always among the 32 smallest (half 0)
+            thr = tau + delta;
+            KNN_PROBE_MARK(4);
+        }
+    }
+
+    // ---- exact phase ----------------------------------------------------------------------------------------------
+    __syncthreads();  // every wave is done with the image: its space now holds the keys
+    KNN_PROBE_MARK(6);
+    if (!wave_active) return;
+    unsigned int *qd = reinterpret_cast<unsigned int *>(k3sm) + (size_t)(wv * 32 + jq) * kTKeyStride;                    // distance bits
+    int *qj = reinterpret_cast<int *>(k3sm) + (size_t)kTWaves * 32 * kTKeyStride + (size_t)(wv * 32 + jq) * kTKeyStride;  // indices
+    const int nv = cnt < kTCap - 1 ? cnt : kTCap - 1;
+    int tot = 0;
+    for (int e = 0; e < nv; ++e) tot += __builtin_popcount((unsigned int)mylist[e * 64] & 0xffffu);
+    const int totp = __shfl_xor(tot, 32, 64);
+    const int cntp = __shfl_xor(cnt, 32, 64);
+    const int n = tot + totp, off = hh ? totp : 0;
+    const bool usable = sane && qok && thr < INFINITY;
+    bool slowq = qi < N && (!usable || cnt > kTCap - 1 || cntp > kTCap - 1 || n > kTKeyCap - 4 || n < (kk < M ? kk : M));
+    if (qi < N && !slowq) {
+        // (1) decode the (tile, mask) words into candidate ids: integer work only, no memory latency in the chain
+        int pos = off;
+        for (int e = 0; e < nv; ++e) {
+            const unsigned int w = (unsigned int)mylist[e * 64];
+            unsigned int m = w & 0xffffu;
+            const int rowbase = (int)(w >> 16) * 32 + 4 * hh;
+            while (m) {
+                const int r = __builtin_ctz(m);
+                m &= m - 1;
+                qj[pos++] = rowbase + (r & 3) + 8 * (r >> 2);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // from here on the query's n survivors are split evenly between its two lanes (the lists are not)
+    const int h0 = (n + 1) >> 1;
+    const int mystart = hh ? h0 : 0, mycount = hh ? n - h0 : h0;
+    if (qi < N && !slowq) {
+        // (2) the oracle's distance of every id, four in flight
+        for (int p0 = mystart; p0 < mystart + mycount; p0 += 4) {
+            int id[4];
+            float c0[4], c1[4], c2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) id[u] = qj[p0 + u < mystart + mycount ? p0 + u : mystart];
+            if (raw_ok) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 rc = rawc[id[u]];
+                    c0[u] = rc.x; c1[u] = rc.y; c2[u] = rc.z;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float *c = yb + (size_t)id[u] * 3;
+                    c0[u] = c[0]; c1[u] = c[1]; c2[u] = c[2];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float t0 = qr[0] - c0[u], t1 = qr[1] - c1[u], t2 = qr[2] - c2[u];
+                float sd = t0 * t0;
+                sd = sd + t1 * t1;
+                sd = sd + t2 * t2;
+                if (p0 + u < mystart + mycount) qd[p0 + u] = __builtin_bit_cast(unsigned int, sd);
+            }
+        }
+        if (hh) {  // sentinels: the rank loop reads four distances at a time
+            qd[n] = 0xffffffffu; qd[n + 1] = 0xffffffffu; qd[n + 2] = 0xffffffffu;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    KNN_PROBE_MARK(7);
+    // ---- order: rank of a survivor = number of survivors of its query with a smaller distance (squared distances
+    //      are >= +0: unsigned order of the bits).  Ties in the distance are resolved by the index; they are rare,
+    //      so the ranks are computed on the distances alone and verified: every entry with rank < kk writes its
+    //      key into slot[rank] and reads it back -- a lost write means a tie and sends the query down the exact
+    //      brute-force path.  The lane lists are dead by now: their space holds the slots.
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(lists_all + wv * kTCap * 64) + jq * 33;  // [32][32 + 1 pad]
+    int *badq = lists_all + wv * kTCap * 64 + 32 * 33 * 2;                                                       // [32]
+    if (hh == 0) badq[jq] = 0;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (qi < N && !slowq) {
+        for (int e0 = 0; e0 < mycount; e0 += 8) {
+            unsigned int md[8];
+            int rank[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                md[u] = e0 + u < mycount ? qd[mystart + e0 + u] : 0xffffffffu;
+                rank[u] = 0;
+            }
+            for (int i = 0; i < n; i += 4) {
+                const uint4 o = *reinterpret_cast<const uint4 *>(qd + i);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {  // compare + add-with-carry: two VALU ops per pair
+                    unsigned long long cc;
+                    asm("v_cmp_lt_u32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, 0, %0, %1" : "+v"(rank[u]), "=&s"(cc) : "v"(o.x), "v"(md[u]));
+                    asm("v_cmp_lt_u32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, 0, %0, %1" : "+v"(rank[u]), "=&s"(cc) : "v"(o.y), "v"(md[u]));
+                    asm("v_cmp_lt_u32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, 0, %0, %1" : "+v"(rank[u]), "=&s"(cc) : "v"(o.z), "v"(md[u]));
+                    asm("v_cmp_lt_u32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, 0, %0, %1" : "+v"(rank[u]), "=&s"(cc) : "v"(o.w), "v"(md[u]));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u < mycount && rank[u] < kk)
+                    slots[rank[u]] = ((unsigned long long)md[u] << 32) | (unsigned int)qj[mystart + e0 + u];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)  // NB: checked after every sweep; a later overwrite is caught by its writer
+                if (e0 + u < mycount && rank[u] < kk &&
+                    slots[rank[u]] != (((unsigned long long)md[u] << 32) | (unsigned int)qj[mystart + e0 + u]))
+                    badq[jq] = 1;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (qi < N && !slowq) {
+        // re-check every slot against all entries is unnecessary: two entries with the same rank both wrote the
+        // slot, at most one reads its own key back, so at least one of them raised the flag
+        if (badq[jq]) {
+            slowq = true;
+        } else {
+            // slots [drop, kk) are the answer, in order; the two half-lanes share the writes
+            for (int r = drop + hh; r < kk; r += 2) {
+                const unsigned long long key = slots[r];
+                idx[((size_t)b * N + qi) * k + r - drop] = (int)(unsigned int)key;
+                if (dist) dist[((size_t)b * N + qi) * k + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
+            }
+        }
+    }
+    KNN_PROBE_MARK(8);
+#ifdef FX3D_PROBE
+    if (qi < N && hh == 0) {
+        atomicAdd(&g_kprobe[4095 * 32 + 0], 1ull);
+        if (slowq) atomicAdd(&g_kprobe[4095 * 32 + 1], 1ull);
+        if (!usable) atomicAdd(&g_kprobe[4095 * 32 + 2], 1ull);
+        if (cnt > kTCap - 1 || cntp > kTCap - 1) atomicAdd(&g_kprobe[4095 * 32 + 3], 1ull);
+        if (n > kTKeyCap - 4) atomicAdd(&g_kprobe[4095 * 32 + 4], 1ull);
+        if (n < kk) atomicAdd(&g_kprobe[4095 * 32 + 5], 1ull);
+        atomicAdd(&g_kprobe[4095 * 32 + 6], (unsigned long long)n);
+    }
+#endif
+    // leftovers, wave-cooperative
+    const unsigned long long slowmask = __ballot(slowq);
+    const unsigned int slow32 = (unsigned int)slowmask | (unsigned int)(slowmask >> 32);
+    for (int j = 0; j < 32; ++j) {
+        if (!((slow32 >> j) & 1u) || q0 + j >= N) continue;
+        float bd;
+        int bj;
+        knn_exact_bruteforce(xb + (size_t)(q0 + j) * 3, yb, M, 3, lane, bd, bj);
+        const int r = lane - drop;
+        if (r >= 0 && r < k) {
+            idx[((size_t)b * N + q0 + j) * k + r] = bj;
+            if (dist) dist[((size_t)b * N + q0 + j) * k + r] = bd;
+        }
+    }
+    KNN_PROBE_MARK(9);
+}
+
+fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int B, int k, int drop, int32_t *idx,
+                              float *dist, hipStream_t st) {
+    int CH = (M + 63) / 64 * 64;
+    if (CH > kTChunk) CH = kTChunk;
+    size_t img = (size_t)CH * 32;
+    const size_t keys = (size_t)kTWaves * 32 * kTKeyStride * 8;  // distance bits + indices
+    if (img < keys) img = keys;
+    const int raw_ok = M <= kTRawMax;
+    const size_t lds = img + (size_t)kTWaves * kTCap * 64 * 4 + (raw_ok ? (size_t)M * 16 : 0);
+    static bool attr_done = false;
+    if (!attr_done) {
+        FX3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_f16_d3_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        attr_done = true;
+    }
+    const int nbx = (N + kTWaves * 32 - 1) / (kTWaves * 32);
+    const int bpad = B >= 8 ? (B + 7) / 8 * 8 : B;
+    hipLaunchKernelGGL(knn_f16_d3_kernel, dim3(nbx * bpad), dim3(kTThreads), lds, st, x, N, y, M, B, k, drop, idx, dist,
+                       CH, (int)img, raw_ok);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
 // ---- EdgeConv graph features (src/models/dgcnn.jl:36-51): cat(X, KNNGraph - X, dims=1) in one pass --------
 // layout 0: out (2F,K,N,B) as the reference holds it after `cat(..., dims = 1)` (:45)
 __global__ __launch_bounds__(kThreads) void edge_features_cat_kernel(const float *__restrict__ x, int N, int B,
@@ -1136,7 +1599,9 @@ fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int 
     dim3 grid((N + kThreads - 1) / kThreads, B);
     ProfileScope prof("knn", st);
     static const bool legacy = [] { const char *e = getenv("FX3D_KNN_LEGACY"); return e && atoi(e); }();
-    if (D == 3 && !legacy) {
+    if (D == 3 && !legacy && !getenv("FX3D_KNN_D3_WAVE") && k + drop <= 32 && M >= 64 && M < (1 << 21)) {
+        return launch_knn_f16_d3(x, N, y, M, B, k, drop, idx, dist, st);
+    } else if (D == 3 && !legacy) {
         const int qpb = (kWThreads / 64) * kWQ;
         hipLaunchKernelGGL(knn_wave_d3_kernel, dim3((N + qpb - 1) / qpb, B), dim3(kWThreads), 0, st, x, N, y, M, B, k,
                            drop, idx, dist);

@@ -8,8 +8,8 @@
 #include <cstdio>
 #include <vector>
 
-int main() {
-    const int B = 32, N = 1024, D = 64, K = 20;
+int main(int argc, char **argv) {
+    const int B = 32, N = 1024, D = argc > 1 ? atoi(argv[1]) : 64, K = 20;
     std::vector<float> hx((size_t)D * N * B);
     unsigned s = 12345;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) * (1.0f / 16777216.0f)) * 4.0f - 2.0f; };
@@ -26,7 +26,7 @@ int main() {
     printf("avg per call %.2f us\n", ms * 100);
     std::vector<unsigned long long> pr(4096 * 32);
     hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_kprobe), pr.size() * 8);
-    const int nb = 256;
+    const int nb = D == 3 ? 512 : 256;
     std::vector<double> d(32, 0.0);
     std::vector<int> c(32, 0);
     for (int b = 0; b < nb; ++b) {
@@ -36,7 +36,9 @@ int main() {
     }
     for (int k = 1; k < 32; ++k) if (c[k]) printf("  mark %2d: avg +%9.1f ticks (n=%d)\n", k, d[k] / c[k], c[k]);
     unsigned long long tmin = ~0ull, tmax = 0;
-    for (int b = 0; b < nb; ++b) { tmin = std::min(tmin, pr[b * 32]); tmax = std::max(tmax, pr[b * 32 + 22]); }
+    for (int b = 0; b < nb; ++b) { tmin = std::min(tmin, pr[b * 32]); tmax = std::max(tmax, std::max(pr[b * 32 + 22], pr[b * 32 + 9])); }
+    printf("queries %llu slow %llu unusable %llu list-overflow %llu n>cap %llu n<kk %llu sum(n) %llu (x13 launches)\n", pr[4095 * 32], pr[4095 * 32 + 1],
+           pr[4095 * 32 + 2], pr[4095 * 32 + 3], pr[4095 * 32 + 4], pr[4095 * 32 + 5], pr[4095 * 32 + 6]);
     printf("first start -> last end: %llu ticks\n", tmax - tmin);
     return 0;
 }
