@@ -1335,15 +1335,17 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     __builtin_amdgcn_wave_barrier();
     KNN_PROBE_MARK(7);
     // ---- order: rank of a survivor = number of survivors of its query with a smaller distance (squared distances
-    //      are >= +0: unsigned order of the bits).  Ties in the distance are resolved by the index; they are rare,
-    //      so the ranks are computed on the distances alone and verified: every entry with rank < kk writes its
-    //      key into slot[rank] and reads it back -- a lost write means a tie and sends the query down the exact
-    //      brute-force path.  The lane lists are dead by now: their space holds the slots.
+    //      are >= +0: unsigned order of the bits).  Ties in the distance are resolved by the index in the
+    //      reference; they are rare, so the ranks are computed on the distances alone and VERIFIED: the ranks below
+    //      kk are a permutation of 0..kk-1 iff every slot is written and exactly min(kk, n) entries have rank < kk
+    //      (two tied entries share a rank: either a slot stays empty or, for a tie straddling the kk boundary,
+    //      the count is off).  A query that fails is ranked again on the full keys.  The lane lists are dead by
+    //      now: their space holds the slots.
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(lists_all + wv * kTCap * 64) + jq * 33;  // [32][32 + 1 pad]
-    int *badq = lists_all + wv * kTCap * 64 + 32 * 33 * 2;                                                       // [32]
-    if (hh == 0) badq[jq] = 0;
+    for (int r = hh; r < kk; r += 2) slots[r] = ~0ull;
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+    int below = 0;  // own entries with rank < kk
     if (qi < N && !slowq) {
         for (int e0 = 0; e0 < mycount; e0 += 8) {
             unsigned int md[8];
@@ -1366,24 +1368,57 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (e0 + u < mycount && rank[u] < kk)
+                if (e0 + u < mycount && rank[u] < kk) {
                     slots[rank[u]] = ((unsigned long long)md[u] << 32) | (unsigned int)qj[mystart + e0 + u];
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-#pragma unroll
-            for (int u = 0; u < 8; ++u)  // NB: checked after every sweep; a later overwrite is caught by its writer
-                if (e0 + u < mycount && rank[u] < kk &&
-                    slots[rank[u]] != (((unsigned long long)md[u] << 32) | (unsigned int)qj[mystart + e0 + u]))
-                    badq[jq] = 1;
+                    ++below;
+                }
         }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    if (qi < N && !slowq) {
-        // re-check every slot against all entries is unnecessary: two entries with the same rank both wrote the
-        // slot, at most one reads its own key back, so at least one of them raised the flag
-        if (badq[jq]) {
-            slowq = true;
-        } else {
+    {
+        bool bad = below + __shfl_xor(below, 32, 64) != (kk < n ? kk : n);
+        for (int r = hh; r < kk; r += 2) bad |= slots[r] == ~0ull;
+        bad |= __shfl_xor((int)bad, 32, 64) != 0;
+#ifdef FX3D_PROBE
+        if (qi < N && !slowq && hh == 0) {
+            const int tb = below + __shfl_xor(below, 32, 64);
+            if (tb != (kk < n ? kk : n)) atomicAdd(&g_kprobe[4095 * 32 + 7], 1ull);
+            if (bad) atomicAdd(&g_kprobe[4095 * 32 + 8], 1ull);
+        }
+#endif
+        if (qi < N && !slowq && bad) {
+            // a tie in the distance among the first kk: rank this query again on the full (distance, index) keys
+            // (keys are unique, so the ranks are a permutation; no verification needed)
+            if (hh) { qj[n] = 0x7fffffff; qj[n + 1] = 0x7fffffff; qj[n + 2] = 0x7fffffff; }  // index sentinels (partner lane writes)
+            for (int e0 = 0; e0 < mycount; e0 += 8) {
+                unsigned int md[8];
+                int mj[8], rank[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    md[u] = e0 + u < mycount ? qd[mystart + e0 + u] : 0xffffffffu;
+                    mj[u] = e0 + u < mycount ? qj[mystart + e0 + u] : 0x7fffffff;
+                    rank[u] = 0;
+                }
+                for (int i = 0; i < n; i += 4) {
+                    const uint4 od = *reinterpret_cast<const uint4 *>(qd + i);
+                    const int4 oj = *reinterpret_cast<const int4 *>(qj + i);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        rank[u] += (int)(od.x < md[u]) | ((int)(od.x == md[u]) & (int)(oj.x < mj[u]));
+                        rank[u] += (int)(od.y < md[u]) | ((int)(od.y == md[u]) & (int)(oj.y < mj[u]));
+                        rank[u] += (int)(od.z < md[u]) | ((int)(od.z == md[u]) & (int)(oj.z < mj[u]));
+                        rank[u] += (int)(od.w < md[u]) | ((int)(od.w == md[u]) & (int)(oj.w < mj[u]));
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u < mycount && rank[u] < kk) slots[rank[u]] = ((unsigned long long)md[u] << 32) | (unsigned int)mj[u];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (qi < N && !slowq) {
             // slots [drop, kk) are the answer, in order; the two half-lanes share the writes
             for (int r = drop + hh; r < kk; r += 2) {
                 const unsigned long long key = slots[r];

@@ -683,3 +683,61 @@ def test_pointcloud_to_voxel_sphere_and_degenerate(gpu_fx, oracle):
     flat = np.ones((3, 16, 1), np.float32, order="F")
     assert gpu_fx.pointcloud_to_voxel(flat, 8).to_host().sum() == 0
     assert oracle.pointcloud_to_voxel(flat, 8).sum() == 0
+
+
+# ------------------------------------------------------------------------------ randomised shape sweeps
+def _sweep_cases(seed, count, lo, hi):
+    rng = np.random.default_rng(seed)
+    return [(int(rng.integers(lo, hi)), int(rng.integers(lo, hi)), int(rng.integers(1, 4)), int(rng.integers(0, 1 << 30)))
+            for _ in range(count)]
+
+
+@pytest.mark.parametrize("N,M,B,seed", _sweep_cases(101, 12, 1, 3000))
+def test_chamfer_random_shapes(gpu_fx, oracle, N, M, B, seed):
+    """Ragged N != M (1 .. 3000: below one tile, across the 512-query pass and 4096-candidate chunk logic),
+    clustered + uniform points: indices bit-exact, loss within 1e-5 relative."""
+    rng = np.random.default_rng(seed)
+    x = rng.random((3, N, B), dtype=np.float32)
+    y = rng.random((3, M, B), dtype=np.float32)
+    if seed & 1:  # half of the cases: a tight cluster far from the rest (stresses the centring / scaling)
+        y[:, : M // 2, :] = y[:, : M // 2, :] * np.float32(1e-3) + np.float32(7.0)
+    x, y = np.asfortranarray(x), np.asfortranarray(y)
+    _check_nn(gpu_fx, oracle, x, y)
+    _check_chamfer(gpu_fx, oracle, x, y, w1=0.5, w2=2.0)
+
+
+@pytest.mark.parametrize("N,M,B,seed", _sweep_cases(202, 10, 33, 2600))
+def test_knn_random_shapes(gpu_fx, oracle, N, M, B, seed):
+    """kNN with y != x over ragged shapes, D = 3 (matrix-core filter for M >= 64, wave kernel below) and a
+    random feature dimension: (index, distance) lists bit-exact."""
+    rng = np.random.default_rng(seed)
+    k = int(rng.integers(1, min(31, M - 1)))
+    drop = bool(seed & 2)
+    x = np.asfortranarray(rng.random((3, N, B), dtype=np.float32))
+    y = np.asfortranarray(rng.random((3, M, B), dtype=np.float32))
+    idx, dist = gpu_fx.knn(x, k, y=y, drop_first=drop)
+    oi, od = oracle.knn(x, k, y=y, drop_first=drop)
+    assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+    D = int(rng.integers(4, 100))
+    n2, m2 = min(N, 300), min(M, 700)
+    xf = np.asfortranarray(rng.standard_normal((D, n2, B)).astype(np.float32))
+    yf = np.asfortranarray(rng.standard_normal((D, m2, B)).astype(np.float32))
+    k2 = min(k, m2 - 1)
+    idx, dist = gpu_fx.knn(xf, k2, y=yf, drop_first=drop)
+    oi, od = oracle.knn(xf, k2, y=yf, drop_first=drop)
+    assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+
+
+def test_knn_d3_degenerate_inputs(gpu_fx, oracle):
+    """D = 3 matrix-core path on inputs that defeat the filter: exact ties everywhere (lattice), all points equal,
+    a query far outside the candidates' fp16 range, and NaN-free huge coordinates."""
+    rng = np.random.default_rng(9)
+    lat = np.asfortranarray(rng.integers(0, 5, (3, 400, 2)).astype(np.float32))
+    for x, y, k, drop in ((lat, None, 12, True),
+                          (np.full((3, 96, 1), 0.25, np.float32, order="F"), None, 20, False),
+                          (np.asfortranarray(rng.random((3, 64, 1), dtype=np.float32) * np.float32(1e9)),
+                           np.asfortranarray(rng.random((3, 128, 1), dtype=np.float32)), 7, False),
+                          (np.asfortranarray(rng.random((3, 200, 1), dtype=np.float32) * np.float32(3e18)), None, 9, True)):
+        idx, dist = gpu_fx.knn(x, k, y=y, drop_first=drop)
+        oi, od = oracle.knn(x, k, y=y, drop_first=drop)
+        assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)

@@ -12,15 +12,17 @@ int main(int argc, char **argv) {
     const int B = 32, N = 1024, D = argc > 1 ? atoi(argv[1]) : 64, K = 20;
     std::vector<float> hx((size_t)D * N * B);
     unsigned s = 12345;
-    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) * (1.0f / 16777216.0f)) * 4.0f - 2.0f; };
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return getenv("UNIT") ? ((s >> 8) * (1.0f / 16777216.0f)) : ((s >> 8) * (1.0f / 16777216.0f)) * 4.0f - 2.0f; };
     for (auto &v : hx) v = rnd();
-    float *x; int32_t *idx;
+    if (getenv("CLOUD")) { FILE *f = fopen(getenv("CLOUD"), "rb"); size_t got = fread(hx.data(), 4, hx.size(), f); fclose(f); printf("loaded %zu floats\n", got); }
+    float *x, *dst = nullptr; int32_t *idx;
     hipMalloc(&x, hx.size() * 4); hipMalloc(&idx, (size_t)K * N * B * 4);
+    if (getenv("DIST")) hipMalloc(&dst, (size_t)K * N * B * 4);
     hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
-    for (int it = 0; it < 3; ++it) fx3d_knn(x, N, x, N, B, D, K, 1, idx, nullptr, nullptr);
+    for (int it = 0; it < 3; ++it) fx3d_knn(x, N, x, N, B, D, K, 1, idx, dst, nullptr);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    for (int it = 0; it < 10; ++it) fx3d_knn(x, N, x, N, B, D, K, 1, idx, nullptr, nullptr);
+    for (int it = 0; it < 10; ++it) fx3d_knn(x, N, x, N, B, D, K, 1, idx, dst, nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("avg per call %.2f us\n", ms * 100);
@@ -39,6 +41,7 @@ int main(int argc, char **argv) {
     for (int b = 0; b < nb; ++b) { tmin = std::min(tmin, pr[b * 32]); tmax = std::max(tmax, std::max(pr[b * 32 + 22], pr[b * 32 + 9])); }
     printf("queries %llu slow %llu unusable %llu list-overflow %llu n>cap %llu n<kk %llu sum(n) %llu (x13 launches)\n", pr[4095 * 32], pr[4095 * 32 + 1],
            pr[4095 * 32 + 2], pr[4095 * 32 + 3], pr[4095 * 32 + 4], pr[4095 * 32 + 5], pr[4095 * 32 + 6]);
+    printf("count-mismatch %llu bad %llu\n", pr[4095 * 32 + 7], pr[4095 * 32 + 8]);
     printf("first start -> last end: %llu ticks\n", tmax - tmin);
     return 0;
 }
