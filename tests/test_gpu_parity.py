@@ -741,3 +741,63 @@ def test_knn_d3_degenerate_inputs(gpu_fx, oracle):
         idx, dist = gpu_fx.knn(x, k, y=y, drop_first=drop)
         oi, od = oracle.knn(x, k, y=y, drop_first=drop)
         assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+
+
+def _random_mesh_batch(rng, nmesh):
+    """Ragged batch of random triangle soups with shared vertices (1-based UInt32 faces like the reference),
+    including thin and zero-area triangles."""
+    vl, fl = [], []
+    for _ in range(nmesh):
+        V = int(rng.integers(4, 400))
+        F = int(rng.integers(2, 900))
+        v = rng.standard_normal((3, V)).astype(np.float32) * np.float32(rng.choice([1e-3, 1.0, 50.0]))
+        f = np.stack([rng.choice(V, 3, replace=False) for _ in range(F)], axis=1).astype(np.uint32) + 1
+        if F > 4:
+            v[:, f[1, 0] - 1] = v[:, f[0, 0] - 1]  # one degenerate (zero-area) face
+        vl.append(np.asfortranarray(v))
+        fl.append(np.asfortranarray(f))
+    return vl, fl
+
+
+@pytest.mark.parametrize("seed", [3, 14, 159, 2653])
+def test_mesh_ops_random_batches(gpu_fx, oracle, seed):
+    """Areas, both mesh losses with gradients, explicit and seeded sampling on random ragged batches."""
+    fx = gpu_fx
+    rng = np.random.default_rng(seed)
+    vl, fl = _random_mesh_batch(rng, int(rng.integers(1, 5)))
+    m = fx.gpu(fx.TriMesh(vl, fl))
+    v = m.get_verts_packed_host()
+    f0 = m.get_faces_packed().astype(np.int64) - 1
+    assert np.array_equal(fx.compute_faces_areas_packed(m).to_host().ravel(), oracle.faces_areas_packed(v, f0))
+    e0 = m.get_edges_packed().astype(np.int64) - 1
+    assert np.array_equal(e0, oracle.edges_packed(f0, v.shape[1]))
+    rowptr, colind, vals = m.get_laplacian_packed()
+    r64, c64 = rowptr.astype(np.int64), colind.astype(np.int64)
+    assert np.isclose(fx.laplacian_loss(m), oracle.laplacian_loss(v, r64, c64, vals), rtol=LOSS_RTOL, atol=1e-30)
+    assert np.isclose(fx.edge_loss(m, 0.1), oracle.edge_loss(v, e0, 0.1), rtol=LOSS_RTOL, atol=1e-30)
+    gl, ol = fx.laplacian_loss_grad(m, 0.7).to_host(), oracle.laplacian_loss_bwd(v, r64, c64, vals, 0.7)
+    assert np.allclose(gl, ol, rtol=2e-4, atol=1e-7 * max(1.0, float(np.abs(ol).max())))
+    ge, oe = fx.edge_loss_grad(m, 0.1, 1.3).to_host(), oracle.edge_loss_bwd(v, e0, 0.1, 1.3)
+    assert np.allclose(ge, oe, rtol=2e-4, atol=1e-7 * max(1.0, float(np.abs(oe).max())))
+    n = int(rng.integers(1, 700))
+    out, fi, r1, r2 = fx.sample_points(m, n, seed=seed, return_draws=True)
+    eo, efi, er1, er2 = oracle.sample_points_seeded(m.get_verts_padded_host(), m.get_faces_padded().astype(np.int64) - 1,
+                                                    m._faces_len, n, seed, return_draws=True)
+    assert np.array_equal(fi.to_host(), efi) and np.array_equal(r1.to_host(), er1) and np.array_equal(r2.to_host(), er2)
+    assert np.array_equal(out.to_host(), eo)
+    assert (fi.to_host() < np.asarray(m._faces_len)[None, :]).all()  # never a padding face
+
+
+@pytest.mark.parametrize("seed", [5, 50])
+def test_voxel_and_edge_features_random(gpu_fx, oracle, seed):
+    rng = np.random.default_rng(seed)
+    N, B, res = int(rng.integers(2, 900)), int(rng.integers(1, 4)), int(rng.choice([4, 9, 20]))
+    p = np.asfortranarray((rng.standard_normal((3, N, B)) * rng.choice([1e-2, 1.0, 1e3])).astype(np.float32))
+    assert np.array_equal(gpu_fx.pointcloud_to_voxel(p, res).to_host(), oracle.pointcloud_to_voxel(p, res))
+    F, n2, K = int(rng.integers(1, 40)), int(rng.integers(40, 300)), int(rng.integers(1, 20))
+    x = np.asfortranarray(rng.standard_normal((F, n2, B)).astype(np.float32))
+    oi = oracle.knn(x, K, drop_first=True, want_dist=False)
+    for layout, lay in (("cat", 0), ("mlp", 1)):
+        out, idx = gpu_fx.edgeconv_graph(x, K, layout=layout, return_idx=True)
+        assert np.array_equal(idx.to_host(), oi)
+        assert np.array_equal(out.to_host(), oracle.edge_features(x, oi, layout=lay))
