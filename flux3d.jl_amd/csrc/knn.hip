@@ -489,33 +489,11 @@ __global__ __launch_bounds__(kThreads) void knn_gather_kernel(const float *__res
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// knn_mfma_kernel<DK>: feature-space kNN (4 <= D <= 128, k+drop <= 32) with the distance matrix recast as
-// a dense Float32 GEMM on the matrix cores and an exact re-scan of the few survivors.
-//
-//   Filter  F[q][c] = fl(|c|^2) + sum_d (-2 q_d) c_d   on v_mfma_f32_32x32x2_f32 (rows = a wave's 32
-//   queries, columns = 32 candidates; the accumulator starts at |c|^2).  With u = 2^-24 and the usual
-//   gamma_n bounds, |F + |q|^2 - d_oracle| <= eps_q = 8 (D+4) u (|q|^2 + Cmax^2) for every candidate
-//   (Cmax = largest candidate norm of the cloud; the factor leaves 2x head-room for the matrix core's
-//   internal rounding), d_oracle being the CPU path's unfused dimension-order Float32 sum.
-//   Phase A: per query the minimum of F over each lane's columns; the kk-th smallest of the 32 lane minima
-//            (bitonic sort inside each half-wave, 16 queries at a time) bounds the kk-th smallest F: tau.
-//   Phase B: the GEMM again; columns with F <= tau + 2 eps_q are compacted (ballot + mbcnt) into the
-//            query's LDS list -- a superset of the true k nearest, ~1.6 kk entries.
-//   Exact:   one lane per survivor evaluates the oracle's distance; its rank under (distance, index) among
-//            the query's survivors is its output position: bit-identical output.
-//   Queries whose list overflows (heavy ties, degenerate clouds) or whose band is not finite take an exact
-//   brute-force merge over all candidates instead.
-// Block = 4 consumer waves (32 queries each: MFMA + selection) + 4 producer waves that stage the next
-// candidate chunk into the other LDS buffer while the consumers work (the shape has one consumer wave per
-// SIMD, so nothing else would hide the global-memory latency).  Lane l = (h, jl) = (l>>5, l&31).  The
-// reduction dimension is permuted so that half h owns d in [h*DP/2, (h+1)*DP/2): every operand fetch is
-// one b128 (4 k-steps).  A (the -2q rows) lives in registers; chunks have row stride DP+4 (conflict-free).
+// ---- shared by the matrix-core kNN kernels ------------------------------------------------------------
 typedef float f32x16v __attribute__((ext_vector_type(16)));
 constexpr int kMWaves = 4;                       // consumer waves
 constexpr int kMThreads = 2 * kMWaves * 64;      // + as many producer waves
 constexpr int kMProd = kMWaves * 64;             // producer threads
-constexpr int kMListCap = 64;
 
 // plain v_min_f32 (fminf() adds canonicalising v_max ops; a NaN filter value only sends the query down
 // the exact path through its non-finite threshold)
@@ -631,354 +609,6 @@ __device__ __forceinline__ void knn_stage_chunk(const float *__restrict__ yb, in
         const bool anynan = __ballot(wnan) != 0;
         if (lane == 0) atomicMax(cmax, anynan ? 0x7fc00000u : __builtin_bit_cast(unsigned int, wmax));  // NaN > +inf
     }
-}
-
-template <int DK>
-__global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__restrict__ x, int N,
-                                                             const float *__restrict__ y, int M, int B, int D,
-                                                             int k, int drop, int32_t *__restrict__ idx,
-                                                             float *__restrict__ dist, int CH, int img_floats, int keep_norms) {
-    constexpr int DP = DK * 32;      // padded feature dimension
-    constexpr int RS = DP + 4;       // row stride of the query rows staged in the prologue (floats)
-    constexpr int PPR = DK * 8;      // 16-byte pieces per candidate row
-    constexpr int NT = DP / 8;       // b128 operand fetches per tile and half
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int buf_floats = CH * DP + CH;                                   // image [CH][DP] + norms [CH]
-    int *lists = reinterpret_cast<int *>(sm + img_floats);                 // [kMWaves][32][kMListCap]
-    int *cntl = lists + kMWaves * 32 * kMListCap;                          // [kMWaves][32]
-    unsigned int *cmax = reinterpret_cast<unsigned int *>(cntl + kMWaves * 32);  // bits of max |c|^2 (>= 0)
-    float *nall = reinterpret_cast<float *>(cmax + 4);  // [nchunk*CH] all candidate norms (when keep_norms)
-
-    // block L runs on XCD L % 8: give every cloud's blocks ids with equal L % 8 so that its candidates stay in
-    // one L2 (8 or more clouds; fewer: plain order, a cloud's blocks spread over all XCDs)
-    const int nbx = (N + kMWaves * 32 - 1) / (kMWaves * 32);
-    const int L = blockIdx.x;
-    const bool by_xcd = B >= 8;
-    const int b = by_xcd ? ((L >> 3) / nbx) * 8 + (L & 7) : L / nbx;
-    const int bxq = by_xcd ? (L >> 3) % nbx : L % nbx;
-    if (b >= B) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const bool consumer = wv < kMWaves;
-    const int cw = consumer ? wv : wv - kMWaves;   // the consumer wave this wave is paired with
-    const int ptid = tid - kMProd;                 // producer thread id (negative for consumers)
-    const int h = lane >> 5, jl = lane & 31;
-    const int kk = k + drop;
-    const float *xb = x + (size_t)b * N * D, *yb = y + (size_t)b * M * D;
-    const int q0 = (bxq * kMWaves + cw) * 32;
-    const bool wave_active = q0 < N;
-    const bool vec4y = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(yb) & 15) == 0);
-    const bool vec4x = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(xb) & 15) == 0);
-    KNN_PROBE_MARK(0);
-
-    // ---- A operand: the wave's 32 query rows, staged through LDS (coalesced), then -2 q in registers --------
-    float4 a[NT];
-    float qn = 0.0f;
-    if (tid == 0) *cmax = 0u;
-    if (consumer) {
-        float *qs = sm + (size_t)cw * 32 * RS;
-        const int nrow = wave_active ? ((N - q0) < 32 ? (N - q0) : 32) : 0;
-        const float *src = xb + (size_t)q0 * D;
-        if (vec4x) {
-            const int rq = D / 4;
-            for (int e = lane; e < nrow * rq; e += 64) {
-                const int row = e / rq, c4 = e - row * rq;
-                *reinterpret_cast<float4 *>(qs + (size_t)row * RS + 4 * c4) = reinterpret_cast<const float4 *>(src)[e];
-            }
-        } else {
-            for (int e = lane; e < nrow * D; e += 64) {
-                const int row = e / D, d = e - row * D;
-                qs[(size_t)row * RS + d] = src[e];
-            }
-        }
-        for (int e = lane; e < 32 * DP; e += 64) {  // zero padding: columns >= D, rows >= nrow
-            const int row = e / DP, d = e - row * DP;
-            if (row >= nrow || d >= D) qs[(size_t)row * RS + d] = 0.0f;
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        const float *qr = qs + (size_t)jl * RS + h * (DP / 2);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float4 v = *reinterpret_cast<const float4 *>(qr + 4 * t);
-            qn = qn + v.x * v.x;
-            qn = qn + v.y * v.y;
-            qn = qn + v.z * v.z;
-            qn = qn + v.w * v.w;
-            a[t] = float4{-2.0f * v.x, -2.0f * v.y, -2.0f * v.z, -2.0f * v.w};
-        }
-        qn = qn + __shfl_xor(qn, 32, 64);
-    }
-    __syncthreads();
-    KNN_PROBE_MARK(1);
-
-    // ---- chunk schedule: phase A walks the chunks forwards, phase B backwards (its first chunk is resident) ----
-    const int nchunk = (M + CH - 1) / CH;
-    const int nstep = 2 * nchunk;
-    if (D < DP || !vec4y) {  // padding columns must read as zeros; the direct loads never touch them
-        for (int e = tid; e < 2 * buf_floats / 4; e += kMThreads)
-            reinterpret_cast<float4 *>(sm)[e] = float4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();
-    }
-    if (!consumer) {
-        const int cn = M < CH ? M : CH;
-        knn_stage_chunk<DK>(yb, D, 0, cn, CH, sm, keep_norms ? nall : sm + (size_t)CH * DP, cmax, true, true, vec4y,
-                            wv - kMWaves, lane);
-    }
-    __syncthreads();
-    KNN_PROBE_MARK(2);
-
-    float mn[16], thr[16];
-    int cnt[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { mn[r] = INFINITY; thr[r] = 0.0f; cnt[r] = 0; }
-    int *mylists = lists + cw * 32 * kMListCap;
-
-    int cur = 0;  // buffer holding the chunk of this step
-    for (int step = 0; step < nstep; ++step) {
-        const int phase = step >= nchunk ? 1 : 0;
-        const int ci = phase ? nstep - 1 - step : step;
-        const int j0 = ci * CH;
-        const int cn = (M - j0) < CH ? (M - j0) : CH;
-        const int cn_pad = (cn + 63) & ~63;
-        const int nstep1 = step + 1;
-        const int ci_next = nstep1 >= nchunk ? nstep - 1 - nstep1 : nstep1;
-        const bool stage_next = nstep1 < nstep && ci_next != ci;
-        if (consumer) {
-            if (wave_active) {
-                const float *cand = sm + (size_t)cur * buf_floats;
-                const float *cnorm = keep_norms ? nall + (size_t)ci * CH : cand + (size_t)CH * DP;
-                // two 32-candidate tiles at a time on two accumulators: consecutive MFMAs are independent, so the
-                // matrix core issues back to back instead of waiting out each dependent accumulate
-                const int npair = cn_pad / 64;
-                for (int pr = 0; pr < npair; ++pr) {
-                    // rows pr*64 + jl and + 32 share (row mod PPR) = jl mod PPR: one rotated offset per fetch
-                    const float *c0 = cand + (size_t)(pr * 64 + jl) * DP, *c1 = c0 + (size_t)32 * DP;
-                    float4 b0[NT], b1[NT];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const int po = ((h * NT + t + jl) & (PPR - 1)) * 4;
-                        b0[t] = *reinterpret_cast<const float4 *>(c0 + po);
-                        b1[t] = *reinterpret_cast<const float4 *>(c1 + po);
-                    }
-                    const float nc0 = cnorm[pr * 64 + jl], nc1 = cnorm[pr * 64 + 32 + jl];
-                    f32x16v acc0, acc1;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { acc0[r] = nc0; acc1[r] = nc1; }
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b0[t].x, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b1[t].x, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b0[t].y, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b1[t].y, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b0[t].z, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b1[t].z, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b0[t].w, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b1[t].w, acc1, 0, 0, 0);
-                    }
-                    if (phase == 0) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) mn[r] = vmin_f32(mn[r], vmin_f32(acc0[r], acc1[r]));
-                    } else {
-                        // branch-free compaction: the query pairs of a tile are independent instruction streams
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt) {
-                            const int jg = j0 + pr * 64 + tt * 32 + jl;
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const bool pred = (tt ? acc1[r] : acc0[r]) <= thr[r];
-                                const unsigned long long bal = __ballot(pred);
-                                const unsigned int lo = (unsigned int)bal, hi = (unsigned int)(bal >> 32);
-                                const int below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0)) -
-                                                  (h ? __builtin_popcount(lo) : 0);
-                                const int pos = cnt[r] + below;
-                                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                                if (pred && pos < kMListCap) mylists[row * kMListCap + pos] = jg;
-                                cnt[r] += h ? __builtin_popcount(hi) : __builtin_popcount(lo);
-                            }
-                        }
-                    }
-                }
-            }
-        } else if (stage_next) {
-            const int j0n = ci_next * CH;
-            const int cnn = (M - j0n) < CH ? (M - j0n) : CH;
-            float *img = sm + (size_t)(1 - cur) * buf_floats;
-            const bool phase_a = nstep1 < nchunk;
-            knn_stage_chunk<DK>(yb, D, j0n, cnn, CH, img, keep_norms ? nall + (size_t)ci_next * CH : img + (size_t)CH * DP,
-                                cmax, phase_a, phase_a || !keep_norms, vec4y, wv - kMWaves, lane);
-        }
-        __syncthreads();
-        KNN_PROBE_MARK(3 + step);
-        if (stage_next) cur = 1 - cur;
-        if (step == nchunk - 1 && consumer) {
-            // ---- thresholds: kk-th smallest lane minimum per query, 16 queries per half-wave side by side ----
-            const float c2 = __builtin_bit_cast(float, *cmax);
-#pragma unroll
-            for (int kb = 2; kb <= 32; kb <<= 1) {
-#pragma unroll
-                for (int s = kb >> 1; s > 0; s >>= 1) {
-                    float o[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[r] = __shfl_xor(mn[r], s, 64);
-                    const bool up = (jl & kb) == 0 || kb == 32;
-                    const bool lower = (jl & s) == 0;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mn[r] = (lower == up) ? fminf(mn[r], o[r]) : fmaxf(mn[r], o[r]);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float tau = __shfl(mn[r], (lane & 32) | (kk - 1), 64);
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float q2 = __shfl(qn, row, 64);
-                const float eps = (8.0f * (float)(D + 4) * 0x1p-24f) * (q2 + c2);
-                thr[r] = tau + 2.0f * eps;  // NaN / inf => slow path below
-            }
-        }
-    }
-    KNN_PROBE_MARK(20);
-
-    // ---- exact phase: consumer wave cw takes rows 0-15 of its queries, its producer partner rows 16-31 ----
-    if (consumer && jl == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const bool ok = thr[r] < INFINITY;  // false for NaN and +inf bands
-            cntl[cw * 32 + row] = ok ? cnt[r] : kMListCap + 1;
-        }
-    }
-    __syncthreads();  // lists + counts visible to the partner waves; the chunk buffers are free from here on
-    if (!wave_active) return;
-    // survivors' keys (distance bits << 32 | index): squared distances are >= +0, so the unsigned 64-bit order
-    // of the keys IS the reference's (distance, index) order and one v_cmp_lt_u64 compares a pair
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(sm) + (size_t)cw * 32 * kMListCap;
-    constexpr int QR = DK <= 2 ? 16 : 8;  // query rows staged per round (LDS budget)
-    float *qbuf = sm + (size_t)2 * kMWaves * 32 * kMListCap + (size_t)wv * QR * DP;
-    const int rbase = consumer ? 0 : 16;
-    const int need = kk < M ? kk : M;
-    if (q0 + rbase >= N) return;
-    for (int rs0 = 0; rs0 < 16; rs0 += QR) {
-        if (q0 + rbase + rs0 >= N) break;
-        {
-            const int left = N - (q0 + rbase + rs0);
-            const int nrow = left < QR ? left : QR;
-            const float *src = xb + (size_t)(q0 + rbase + rs0) * D;  // nrow contiguous rows
-            __builtin_amdgcn_wave_barrier();
-            for (int e = lane; e < nrow * D; e += 64) qbuf[e] = src[e];
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-        }
-        // the oracle's distance for every survivor: eight queries in flight per lane, 16 dimensions at a time
-        for (int g0 = rs0; g0 < rs0 + QR; g0 += 8) {
-            if (q0 + rbase + g0 >= N) break;
-            bool on[8];
-            int jj[8];
-            const float *cp[8];
-            float s[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int row = rbase + g0 + u;
-                const int n = cntl[cw * 32 + row];
-                on[u] = q0 + row < N && n <= kMListCap && n >= need && lane < n;
-                jj[u] = on[u] ? mylists[row * kMListCap + lane] : 0;
-                cp[u] = yb + (size_t)jj[u] * D;
-                s[u] = 0.0f;
-            }
-            if (vec4y) {
-                for (int d0 = 0; d0 < D; d0 += 16) {
-                    float4 cv[8][4];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            if (d0 + 4 * t < D) cv[u][t] = *reinterpret_cast<const float4 *>(cp[u] + d0 + 4 * t);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const float *qp = qbuf + (size_t)(g0 - rs0 + u) * D + d0;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            if (d0 + 4 * t < D) {
-                                const float4 qv = *reinterpret_cast<const float4 *>(qp + 4 * t);
-                                const float t0 = qv.x - cv[u][t].x, t1 = qv.y - cv[u][t].y, t2 = qv.z - cv[u][t].z,
-                                            t3 = qv.w - cv[u][t].w;
-                                s[u] = s[u] + t0 * t0;
-                                s[u] = s[u] + t1 * t1;
-                                s[u] = s[u] + t2 * t2;
-                                s[u] = s[u] + t3 * t3;
-                            }
-                    }
-                }
-            } else {
-                for (int d = 0; d < D; ++d) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const float t = qbuf[(size_t)(g0 - rs0 + u) * D + d] - cp[u][d];
-                        s[u] = s[u] + t * t;
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int row = rbase + g0 + u;
-                const unsigned long long key =
-                    ((unsigned long long)__builtin_bit_cast(unsigned int, s[u]) << 32) | (unsigned int)jj[u];
-                keys[row * kMListCap + lane] = on[u] ? key : ~0ull;  // sentinels behind the list
-            }
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    KNN_PROBE_MARK(21);
-    // rank of every survivor among its query's survivors: distinct keys => the ranks are a permutation.
-    // Four queries side by side, two keys per LDS read.
-    for (int g0 = 0; g0 < 16; g0 += 4) {
-        if (q0 + rbase + g0 >= N) break;
-        int n[4], rank[4], nmax = 0;
-        unsigned long long mine[4];
-        bool fast[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = rbase + g0 + u;
-            n[u] = cntl[cw * 32 + row];
-            fast[u] = q0 + row < N && n[u] <= kMListCap && n[u] >= need;
-            mine[u] = keys[row * kMListCap + lane];
-            rank[u] = 0;
-            nmax = fast[u] && n[u] > nmax ? n[u] : nmax;
-        }
-        for (int i = 0; i < nmax; i += 2) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int row = rbase + g0 + u;
-                const ulonglong2 o = *reinterpret_cast<const ulonglong2 *>(keys + row * kMListCap + i);
-                rank[u] += (o.x < mine[u] ? 1 : 0) + (o.y < mine[u] ? 1 : 0);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int qi = q0 + rbase + g0 + u;
-            const int r = rank[u] - drop;
-            if (fast[u] && lane < n[u] && r >= 0 && r < k) {
-                idx[((size_t)b * N + qi) * k + r] = (int)(unsigned int)mine[u];
-                if (dist) dist[((size_t)b * N + qi) * k + r] = __builtin_bit_cast(float, (unsigned int)(mine[u] >> 32));
-            }
-        }
-    }
-    // leftovers: overflowed lists, unusable bands
-    for (int row = rbase; row < rbase + 16; ++row) {
-        const int qi = q0 + row;
-        if (qi >= N) break;
-        const int n = cntl[cw * 32 + row];
-        if (n <= kMListCap && n >= need) continue;
-        float bd;
-        int bj;
-        knn_exact_bruteforce(xb + (size_t)qi * D, yb, M, D, lane, bd, bj);
-        const int r = lane - drop;
-        if (r >= 0 && r < k) {
-            idx[((size_t)b * N + qi) * k + r] = bj;
-            if (dist) dist[((size_t)b * N + qi) * k + r] = bd;
-        }
-    }
-    KNN_PROBE_MARK(22);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1479,6 +1109,443 @@ fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int 
     return FX3D_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// knn_mfma_kernel<DK>: feature-space kNN (4 <= D <= 128, k+drop <= 32; the second EdgeConv runs at D = 64).
+// Same selection scheme as knn_f16_d3_kernel (lane = query; 64 group minima -> tau in registers; per-lane mask
+// lists; verified distance-only ranking), with the filter as a dense Float32 GEMM:
+//   F[c][q] = fl(|c|^2) + sum_d c_d (-2 q_d)   on v_mfma_f32_32x32x2_f32 (rows = 32 candidates of a tile, columns
+//   = the wave's 32 queries, the accumulator starts at |c|^2; two tiles on two accumulators).  With u = 2^-24 and
+//   the usual gamma_n bounds, |F + |q|^2 - d_oracle| <= eps_q = 8 (D+4) u (|q|^2 + Cmax^2) for every candidate
+//   (Cmax = largest candidate norm of the cloud; 2x head-room for the matrix core's internal rounding), so the
+//   candidates with F <= tau + 2 eps_q are a superset of the k nearest.
+// Block = 4 consumer waves (32 queries each) + 4 producer waves that stage the next candidate chunk into the other
+// LDS buffer with global_load_lds_dwordx4 while the consumers work (one consumer wave per SIMD: nothing else
+// would hide global latency; VALU work of any wave delays that SIMD's MFMAs, hence the direct loads).  The
+// reduction dimension is permuted so that half-wave h owns d in [h*DP/2, (h+1)*DP/2): every operand fetch is a
+// b128 (4 k-steps); the LDS image is lane-linear, the conflict-free rotation sits on the source addresses.
+// In the exact phase all eight waves work: the four lanes of a query (two halves x consumer/producer) split its
+// survivors; candidate and query rows are gathered from L2.
+constexpr int kMLCap = 40;        // rows of a lane's mask list (39 usable + the scratch head)
+constexpr int kMKeyCap = 60;      // survivors per query handled by the fast path
+constexpr int kMKeyStride = 64;   // row stride of the key arrays in words
+
+template <int DK>
+__global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__restrict__ x, int N,
+                                                             const float *__restrict__ y, int M, int B, int D,
+                                                             int k, int drop, int32_t *__restrict__ idx,
+                                                             float *__restrict__ dist, int CH, int img_floats,
+                                                             int keep_norms) {
+    constexpr int DP = DK * 32;      // padded feature dimension
+    constexpr int RS = DP + 4;       // row stride of the query rows staged in the prologue (floats)
+    constexpr int PPR = DK * 8;      // 16-byte pieces per candidate row
+    constexpr int NT = DP / 8;       // b128 operand fetches per tile and half
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int buf_floats = CH * DP + CH;                                   // image [CH][DP] + norms [CH]
+    int *lists = reinterpret_cast<int *>(sm + img_floats);                 // [kMWaves][kMLCap][64] mask words
+    int *lcnt = lists + kMWaves * kMLCap * 64;                             // [kMWaves][64]  list lengths
+    int *qn_n = lcnt + kMWaves * 64;                                       // [kMWaves][32]  survivors per query
+    int *qflag = qn_n + kMWaves * 32;                                      // [kMWaves][32]  1 = fast path
+    int *qbelow = qflag + kMWaves * 32;                                    // [kMWaves][32]  entries with rank < kk
+    unsigned int *cmax = reinterpret_cast<unsigned int *>(qbelow + kMWaves * 32);  // bits of max |c|^2 (>= 0)
+    float *nall = reinterpret_cast<float *>(cmax + 4);                     // [nchunk*CH] all candidate norms (keep_norms)
+
+    // block L runs on XCD L % 8: give every cloud's blocks ids with equal L % 8 so that its candidates stay in
+    // one L2 (8 or more clouds; fewer: plain order, a cloud's blocks spread over all XCDs)
+    const int nbx = (N + kMWaves * 32 - 1) / (kMWaves * 32);
+    const int L = blockIdx.x;
+    const bool by_xcd = B >= 8;
+    const int b = by_xcd ? ((L >> 3) / nbx) * 8 + (L & 7) : L / nbx;
+    const int bxq = by_xcd ? (L >> 3) % nbx : L % nbx;
+    if (b >= B) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool consumer = wv < kMWaves;
+    const int cw = consumer ? wv : wv - kMWaves;   // the consumer wave this wave is paired with
+    const int h = lane >> 5, jl = lane & 31;
+    const int kk = k + drop;
+    const float *xb = x + (size_t)b * N * D, *yb = y + (size_t)b * M * D;
+    const int q0 = (bxq * kMWaves + cw) * 32;
+    const bool wave_active = q0 < N;
+    const int qi = q0 + jl;
+    const bool vec4y = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(yb) & 15) == 0);
+    const bool vec4x = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(xb) & 15) == 0);
+    KNN_PROBE_MARK(0);
+
+    // ---- B operand: the wave's 32 query rows, staged through LDS (coalesced), then -2 q in registers ------------
+    float4 a[NT];
+    float qn = 0.0f;
+    if (tid == 0) *cmax = 0u;
+    if (consumer) {
+        float *qs = sm + (size_t)cw * 32 * RS;
+        const int nrow = wave_active ? ((N - q0) < 32 ? (N - q0) : 32) : 0;
+        const float *src = xb + (size_t)q0 * D;
+        if (vec4x) {
+            const int rq = D / 4;
+            for (int e = lane; e < nrow * rq; e += 64) {
+                const int row = e / rq, c4 = e - row * rq;
+                *reinterpret_cast<float4 *>(qs + (size_t)row * RS + 4 * c4) = reinterpret_cast<const float4 *>(src)[e];
+            }
+        } else {
+            for (int e = lane; e < nrow * D; e += 64) {
+                const int row = e / D, d = e - row * D;
+                qs[(size_t)row * RS + d] = src[e];
+            }
+        }
+        for (int e = lane; e < 32 * DP; e += 64) {  // zero padding: columns >= D, rows >= nrow
+            const int row = e / DP, d = e - row * DP;
+            if (row >= nrow || d >= D) qs[(size_t)row * RS + d] = 0.0f;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const float *qr = qs + (size_t)jl * RS + h * (DP / 2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 v = *reinterpret_cast<const float4 *>(qr + 4 * t);
+            qn = qn + v.x * v.x;
+            qn = qn + v.y * v.y;
+            qn = qn + v.z * v.z;
+            qn = qn + v.w * v.w;
+            a[t] = float4{-2.0f * v.x, -2.0f * v.y, -2.0f * v.z, -2.0f * v.w};
+        }
+        qn = qn + __shfl_xor(qn, 32, 64);
+    }
+    __syncthreads();
+    KNN_PROBE_MARK(1);
+
+    // ---- chunk schedule: phase A walks the chunks forwards, phase B backwards (its first chunk is resident) ----
+    const int nchunk = (M + CH - 1) / CH;
+    const int nstep = 2 * nchunk;
+    if (D < DP || !vec4y) {  // padding columns must read as zeros; the direct loads never touch them
+        for (int e = tid; e < 2 * buf_floats / 4; e += kMThreads)
+            reinterpret_cast<float4 *>(sm)[e] = float4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+    }
+    if (!consumer) {
+        const int cn = M < CH ? M : CH;
+        knn_stage_chunk<DK>(yb, D, 0, cn, CH, sm, keep_norms ? nall : sm + (size_t)CH * DP, cmax, true, true, vec4y,
+                            wv - kMWaves, lane);
+    }
+    __syncthreads();
+    KNN_PROBE_MARK(2);
+
+    float mn[32];  // group minima: [r] even tiles, [16 + r] odd tiles -> 64 groups per query
+#pragma unroll
+    for (int r = 0; r < 32; ++r) mn[r] = INFINITY;
+    float thr = 0.0f;
+    int cnt = 0;
+    int *mylist = lists + cw * kMLCap * 64 + lane;  // entry e at mylist[e * 64]
+
+    int cur = 0;  // buffer holding the chunk of this step
+    for (int step = 0; step < nstep; ++step) {
+        const int phase = step >= nchunk ? 1 : 0;
+        const int ci = phase ? nstep - 1 - step : step;
+        const int j0 = ci * CH;
+        const int cn = (M - j0) < CH ? (M - j0) : CH;
+        const int cn_pad = (cn + 63) & ~63;
+        const int nstep1 = step + 1;
+        const int ci_next = nstep1 >= nchunk ? nstep - 1 - nstep1 : nstep1;
+        const bool stage_next = nstep1 < nstep && ci_next != ci;
+        if (consumer) {
+            if (wave_active) {
+                const float *cand = sm + (size_t)cur * buf_floats;
+                const float *cnorm = keep_norms ? nall + (size_t)ci * CH : cand + (size_t)CH * DP;
+                const int npair = cn_pad / 64;
+                const int tile0 = j0 / 32;
+                for (int pr = 0; pr < npair; ++pr) {
+                    // rows pr*64 + jl and + 32 share (row mod PPR) = jl mod PPR: one rotated offset per fetch
+                    const float *c0 = cand + (size_t)(pr * 64 + jl) * DP, *c1 = c0 + (size_t)32 * DP;
+                    float4 b0[NT], b1[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int po = ((h * NT + t + jl) & (PPR - 1)) * 4;
+                        b0[t] = *reinterpret_cast<const float4 *>(c0 + po);
+                        b1[t] = *reinterpret_cast<const float4 *>(c1 + po);
+                    }
+                    // accumulators start at the candidate norms: register r of half h is row (r&3) + 8(r>>2) + 4h
+                    f32x16v acc0, acc1;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 n0 = *reinterpret_cast<const float4 *>(cnorm + pr * 64 + 8 * g + 4 * h);
+                        const float4 n1 = *reinterpret_cast<const float4 *>(cnorm + pr * 64 + 32 + 8 * g + 4 * h);
+                        acc0[4 * g] = n0.x; acc0[4 * g + 1] = n0.y; acc0[4 * g + 2] = n0.z; acc0[4 * g + 3] = n0.w;
+                        acc1[4 * g] = n1.x; acc1[4 * g + 1] = n1.y; acc1[4 * g + 2] = n1.z; acc1[4 * g + 3] = n1.w;
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {  // A = candidates (rows), B = queries (columns)
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[t].x, a[t].x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[t].x, a[t].x, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[t].y, a[t].y, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[t].y, a[t].y, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[t].z, a[t].z, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[t].z, a[t].z, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[t].w, a[t].w, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[t].w, a[t].w, acc1, 0, 0, 0);
+                    }
+                    if (phase == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            mn[r] = vmin_f32(mn[r], acc0[r]);
+                            mn[16 + r] = vmin_f32(mn[16 + r], acc1[r]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) {
+                            // one word per tile: (tile index << 16) | mask of the rows with F <= thr; stored at the
+                            // list head unconditionally, the head advances when the mask is not empty
+                            unsigned int m = 0;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) m |= ((tt ? acc1[r] : acc0[r]) <= thr) ? (1u << r) : 0u;
+                            const int pp = cnt < kMLCap - 1 ? cnt : kMLCap - 1;
+                            mylist[pp * 64] = (int)((unsigned int)(tile0 + pr * 2 + tt) << 16 | m);
+                            cnt += m != 0 ? 1 : 0;
+                        }
+                    }
+                }
+            }
+        } else if (stage_next) {
+            const int j0n = ci_next * CH;
+            const int cnn = (M - j0n) < CH ? (M - j0n) : CH;
+            float *img = sm + (size_t)(1 - cur) * buf_floats;
+            const bool phase_a = nstep1 < nchunk;
+            knn_stage_chunk<DK>(yb, D, j0n, cnn, CH, img, keep_norms ? nall + (size_t)ci_next * CH : img + (size_t)CH * DP,
+                                cmax, phase_a, phase_a || !keep_norms, vec4y, wv - kMWaves, lane);
+        }
+        __syncthreads();
+        KNN_PROBE_MARK(3 + step);
+        if (stage_next) cur = 1 - cur;
+        if (step == nchunk - 1 && consumer) {
+            // ---- tau: kk-th smallest of the 64 group minima of every query (32 in this lane, 32 in its partner) ----
+            const float c2 = __builtin_bit_cast(float, *cmax);
+            k3_sort_regs<32>(mn);
+            float oth[32];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) oth[r] = __shfl_xor(mn[31 - r], 32, 64);
+#pragma unroll
+            for (int r = 0; r < 32; ++r)  // half 0 keeps the 32 smallest of the 64 (a bitonic sequence)
+                mn[r] = h ? vmax_f32(mn[r], oth[r]) : vmin_f32(mn[r], oth[r]);
+#pragma unroll
+            for (int j = 16; j > 0; j >>= 1) {  // one bitonic merge sorts it ascending
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const float lo = vmin_f32(mn[i], mn[l]), hi = vmax_f32(mn[i], mn[l]);
+                        mn[i] = lo;
+                        mn[l] = hi;
+                    }
+                }
+            }
+            float val = mn[0];
+#pragma unroll
+            for (int r = 1; r < 32; ++r) val = (kk - 1) == r ? mn[r] : val;
+            const float tau = __shfl(val, jl, 64);  // kk <= 32: always among the 32 smallest (half 0)
+            const float eps = (8.0f * (float)(D + 4) * 0x1p-24f) * (qn + c2);
+            thr = tau + 2.0f * eps;  // NaN / inf => slow path below
+        }
+    }
+    KNN_PROBE_MARK(20);
+
+    // ---- exact phase -----------------------------------------------------------------------------------------------
+    // (1) consumers: list lengths, survivors per query, fast-path flag
+    const int need = kk < M ? kk : M;
+    if (consumer) {
+        const int nv = cnt < kMLCap - 1 ? cnt : kMLCap - 1;
+        int tot = 0;
+        for (int e = 0; e < nv; ++e) tot += __builtin_popcount((unsigned int)mylist[e * 64] & 0xffffu);
+        const int totp = __shfl_xor(tot, 32, 64);
+        const int cntp = __shfl_xor(cnt, 32, 64);
+        const int n = tot + totp;
+        const bool fast = wave_active && qi < N && thr < INFINITY && cnt <= kMLCap - 1 && cntp <= kMLCap - 1 &&
+                          n <= kMKeyCap && n >= need;
+        lcnt[cw * 64 + lane] = (h ? totp : 0) | (nv << 16);  // start offset of this lane's ids | entries
+        if (h == 0) { qn_n[cw * 32 + jl] = n; qflag[cw * 32 + jl] = fast ? 1 : 0; qbelow[cw * 32 + jl] = 0; }
+    }
+    __syncthreads();  // the chunk buffers are free from here on: they hold the keys
+    KNN_PROBE_MARK(21);
+    unsigned int *qd = reinterpret_cast<unsigned int *>(sm) + (size_t)(cw * 32 + jl) * kMKeyStride;                       // distance bits
+    int *qj = reinterpret_cast<int *>(sm) + (size_t)kMWaves * 32 * kMKeyStride + (size_t)(cw * 32 + jl) * kMKeyStride;     // indices
+    const int n = qn_n[cw * 32 + jl];
+    const bool fast = qflag[cw * 32 + jl] != 0;
+    // (2) consumers decode their mask words into candidate ids (integer work only)
+    if (consumer && fast) {
+        const int meta = lcnt[cw * 64 + lane];
+        int pos = meta & 0xffff;
+        const int nv = meta >> 16;
+        for (int e = 0; e < nv; ++e) {
+            const unsigned int w = (unsigned int)mylist[e * 64];
+            unsigned int m = w & 0xffffu;
+            const int rowbase = (int)(w >> 16) * 32 + 4 * h;
+            while (m) {
+                const int r = __builtin_ctz(m);
+                m &= m - 1;
+                qj[pos++] = rowbase + (r & 3) + 8 * (r >> 2);
+            }
+        }
+        if (h) { qd[n] = 0xffffffffu; qd[n + 1] = 0xffffffffu; qd[n + 2] = 0xffffffffu;
+                 qj[n] = 0x7fffffff; qj[n + 1] = 0x7fffffff; qj[n + 2] = 0x7fffffff; }  // sentinels for the b128 sweeps
+    }
+    __syncthreads();  // ids visible to the producer partners; the lane lists are dead: their space holds the slots
+    KNN_PROBE_MARK(22);
+    // (3) the query's survivors are split over its four lanes (two halves x consumer / producer wave)
+    const int part = (consumer ? 0 : 2) + h;
+    const int per = (n + 3) >> 2;
+    const int mystart = part * per < n ? part * per : n;
+    const int mycount = (mystart + per <= n ? per : n - mystart);
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(lists) + (size_t)(cw * 32 + jl) * 33;  // [..][32 + 1 pad]
+    if (wave_active && fast) {
+        if (part == 0)
+            for (int r = 0; r < kk; ++r) slots[r] = ~0ull;
+        // the oracle's distance of every id.  The query row sits in registers; candidate rows are gathered from L2
+        // one full 128-byte line per request (32 dimensions), two candidates in flight
+        const float *qrow = xb + (size_t)qi * D;
+        if (vec4y && vec4x) {
+            float4 qreg[DP / 4];
+#pragma unroll
+            for (int t = 0; t < DP / 4; ++t)
+                qreg[t] = 4 * t < D ? *reinterpret_cast<const float4 *>(qrow + 4 * t) : float4{0.f, 0.f, 0.f, 0.f};
+            for (int p0 = mystart; p0 < mystart + mycount; p0 += 2) {
+                const bool two = p0 + 1 < mystart + mycount;
+                const float *cp0 = yb + (size_t)qj[p0] * D;
+                const float *cp1 = yb + (size_t)qj[two ? p0 + 1 : p0] * D;
+                float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+                for (int d0 = 0; d0 < DP; d0 += 32) {
+                    if (d0 < D) {
+                        float4 c0[8], c1[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            if (d0 + 4 * t < D) {
+                                c0[t] = *reinterpret_cast<const float4 *>(cp0 + d0 + 4 * t);
+                                c1[t] = *reinterpret_cast<const float4 *>(cp1 + d0 + 4 * t);
+                            }
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            if (d0 + 4 * t < D) {
+                                const float4 qv = qreg[d0 / 4 + t];
+                                float t0 = qv.x - c0[t].x, t1 = qv.y - c0[t].y, t2 = qv.z - c0[t].z, t3 = qv.w - c0[t].w;
+                                s0 = s0 + t0 * t0;
+                                s0 = s0 + t1 * t1;
+                                s0 = s0 + t2 * t2;
+                                s0 = s0 + t3 * t3;
+                                t0 = qv.x - c1[t].x; t1 = qv.y - c1[t].y; t2 = qv.z - c1[t].z; t3 = qv.w - c1[t].w;
+                                s1 = s1 + t0 * t0;
+                                s1 = s1 + t1 * t1;
+                                s1 = s1 + t2 * t2;
+                                s1 = s1 + t3 * t3;
+                            }
+                    }
+                }
+                qd[p0] = __builtin_bit_cast(unsigned int, s0);
+                if (two) qd[p0 + 1] = __builtin_bit_cast(unsigned int, s1);
+            }
+        } else {
+            for (int p0 = mystart; p0 < mystart + mycount; ++p0) {
+                const float *cp = yb + (size_t)qj[p0] * D;
+                float sd = 0.0f;
+                for (int d = 0; d < D; ++d) {
+                    const float t = qrow[d] - cp[d];
+                    sd = sd + t * t;
+                }
+                qd[p0] = __builtin_bit_cast(unsigned int, sd);
+            }
+        }
+    }
+    __syncthreads();
+    KNN_PROBE_MARK(23);
+    // (4) rank on the distance bits (squared distances are >= +0: unsigned order), verified as in knn_f16_d3_kernel
+    if (wave_active && fast) {
+        int below = 0;
+        for (int e0 = 0; e0 < mycount; e0 += 8) {
+            unsigned int md[8];
+            int rank[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                md[u] = e0 + u < mycount ? qd[mystart + e0 + u] : 0xffffffffu;
+                rank[u] = 0;
+            }
+            for (int i = 0; i < n; i += 4) {
+                const uint4 o = *reinterpret_cast<const uint4 *>(qd + i);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {  // compare + add-with-carry: two VALU ops per pair
+                    unsigned long long cc;
+                    asm("v_cmp_lt_u32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, 0, %0, %1" : "+v"(rank[u]), "=&s"(cc) : "v"(o.x), "v"(md[u]));
+                    asm("v_cmp_lt_u32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, 0, %0, %1" : "+v"(rank[u]), "=&s"(cc) : "v"(o.y), "v"(md[u]));
+                    asm("v_cmp_lt_u32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, 0, %0, %1" : "+v"(rank[u]), "=&s"(cc) : "v"(o.z), "v"(md[u]));
+                    asm("v_cmp_lt_u32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, 0, %0, %1" : "+v"(rank[u]), "=&s"(cc) : "v"(o.w), "v"(md[u]));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u < mycount && rank[u] < kk) {
+                    slots[rank[u]] = ((unsigned long long)md[u] << 32) | (unsigned int)qj[mystart + e0 + u];
+                    ++below;
+                }
+        }
+        if (below) atomicAdd(&qbelow[cw * 32 + jl], below);
+    }
+    __syncthreads();
+    KNN_PROBE_MARK(24);
+    if (!consumer || !wave_active) return;
+    // (5) consumers: verify, re-rank tied queries on the full keys, write the answer
+    bool slowq = qi < N && !fast;
+    if (qi < N && fast) {
+        bool bad = qbelow[cw * 32 + jl] != (kk < n ? kk : n);
+        for (int r = h; r < kk; r += 2) bad |= slots[r] == ~0ull;
+        bad |= __shfl_xor((int)bad, 32, 64) != 0;
+        if (bad) {  // a tie in the distance among the first kk: the keys (distance, index) are unique
+            const int h0 = (n + 1) >> 1;
+            const int st = h ? h0 : 0, ct = h ? n - h0 : h0;
+            for (int e0 = 0; e0 < ct; e0 += 8) {
+                unsigned int md[8];
+                int mj[8], rank[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    md[u] = e0 + u < ct ? qd[st + e0 + u] : 0xffffffffu;
+                    mj[u] = e0 + u < ct ? qj[st + e0 + u] : 0x7fffffff;
+                    rank[u] = 0;
+                }
+                for (int i = 0; i < n; i += 4) {
+                    const uint4 od = *reinterpret_cast<const uint4 *>(qd + i);
+                    const int4 oj = *reinterpret_cast<const int4 *>(qj + i);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        rank[u] += (int)(od.x < md[u]) | ((int)(od.x == md[u]) & (int)(oj.x < mj[u]));
+                        rank[u] += (int)(od.y < md[u]) | ((int)(od.y == md[u]) & (int)(oj.y < mj[u]));
+                        rank[u] += (int)(od.z < md[u]) | ((int)(od.z == md[u]) & (int)(oj.z < mj[u]));
+                        rank[u] += (int)(od.w < md[u]) | ((int)(od.w == md[u]) & (int)(oj.w < mj[u]));
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u < ct && rank[u] < kk) slots[rank[u]] = ((unsigned long long)md[u] << 32) | (unsigned int)mj[u];
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (qi < N && fast) {
+        for (int r = drop + h; r < kk; r += 2) {  // slots [drop, kk) are the answer, in order
+            const unsigned long long key = slots[r];
+            idx[((size_t)b * N + qi) * k + r - drop] = (int)(unsigned int)key;
+            if (dist) dist[((size_t)b * N + qi) * k + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
+        }
+    }
+    // leftovers (overflowing lists, non-finite bands), wave-cooperative
+    const unsigned long long slowmask = __ballot(slowq);
+    const unsigned int slow32 = (unsigned int)slowmask | (unsigned int)(slowmask >> 32);
+    for (int j = 0; j < 32; ++j) {
+        if (!((slow32 >> j) & 1u) || q0 + j >= N) continue;
+        float bd;
+        int bj;
+        knn_exact_bruteforce(xb + (size_t)(q0 + j) * D, yb, M, D, lane, bd, bj);
+        const int r = lane - drop;
+        if (r >= 0 && r < k) {
+            idx[((size_t)b * N + q0 + j) * k + r] = bj;
+            if (dist) dist[((size_t)b * N + q0 + j) * k + r] = bd;
+        }
+    }
+    KNN_PROBE_MARK(25);
+}
+
 // ---- EdgeConv graph features (src/models/dgcnn.jl:36-51): cat(X, KNNGraph - X, dims=1) in one pass --------
 // layout 0: out (2F,K,N,B) as the reference holds it after `cat(..., dims = 1)` (:45)
 __global__ __launch_bounds__(kThreads) void edge_features_cat_kernel(const float *__restrict__ x, int N, int B,
@@ -1586,7 +1653,9 @@ template <int DK>
 fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int B, int D, int k, int drop,
                                int32_t *idx, float *dist, hipStream_t st) {
     constexpr int DP = DK * 32, RS = DP + 4;
-    size_t fixed = (size_t)kMWaves * 32 * kMListCap * 4 + kMWaves * 32 * 4 + 64;
+    // lists (later the slots) + list lengths + per-query counters + cmax
+    size_t fixed = (size_t)kMWaves * kMLCap * 64 * 4 + (size_t)kMWaves * 64 * 4 + (size_t)3 * kMWaves * 32 * 4 + 64;
+    static_assert(kMWaves * 32 * 33 * 8 <= kMWaves * kMLCap * 64 * 4, "the rank slots alias the mask lists");
     const int keep_norms = M <= 4096;  // all candidate norms stay in LDS: phase B does not recompute them
     if (keep_norms) fixed += (size_t)((M + 255) / 256 * 256 + 256) * 4;
     const size_t budget = 150 * 1024 - fixed;                                  // floats*4 for the two chunk buffers
@@ -1596,7 +1665,7 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     if (CH > mpad) CH = mpad;
     size_t img = 2 * ((size_t)CH * DP + CH);                                   // floats
     const size_t qstage = (size_t)kMWaves * 32 * RS;                           // prologue: query rows
-    const size_t exact = (size_t)2 * kMWaves * 32 * kMListCap + (size_t)2 * kMWaves * (DK <= 2 ? 16 : 8) * DP;  // keys + query rows
+    const size_t exact = (size_t)2 * kMWaves * 32 * kMKeyStride;               // exact phase: distance bits + indices
     if (img < qstage) img = qstage;
     if (img < exact) img = exact;
     img = (img + 3) & ~(size_t)3;

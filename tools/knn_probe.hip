@@ -38,7 +38,7 @@ int main(int argc, char **argv) {
     }
     for (int k = 1; k < 32; ++k) if (c[k]) printf("  mark %2d: avg +%9.1f ticks (n=%d)\n", k, d[k] / c[k], c[k]);
     unsigned long long tmin = ~0ull, tmax = 0;
-    for (int b = 0; b < nb; ++b) { tmin = std::min(tmin, pr[b * 32]); tmax = std::max(tmax, std::max(pr[b * 32 + 22], pr[b * 32 + 9])); }
+    for (int b = 0; b < nb; ++b) { tmin = std::min(tmin, pr[b * 32]); tmax = std::max(tmax, std::max(pr[b * 32 + 25], pr[b * 32 + 9])); }
     printf("queries %llu slow %llu unusable %llu list-overflow %llu n>cap %llu n<kk %llu sum(n) %llu (x13 launches)\n", pr[4095 * 32], pr[4095 * 32 + 1],
            pr[4095 * 32 + 2], pr[4095 * 32 + 3], pr[4095 * 32 + 4], pr[4095 * 32 + 5], pr[4095 * 32 + 6]);
     printf("count-mismatch %llu bad %llu\n", pr[4095 * 32 + 7], pr[4095 * 32 + 8]);
