@@ -508,32 +508,78 @@ __device__ __forceinline__ int key_less_bf(float d, int j, float od, int oj) {
     return (int)(d < od) | ((int)(d == od) & (int)(j < oj));
 }
 
-// exact top-kk of ONE query over all candidates: 64 at a time, bitonic merge (always correct; slow path)
+// Exact top-kk of ONE query by the whole wave -- the fallback of the matrix-core kernels (queries whose filter is
+// unusable or whose survivor lists overflow: heavy ties, degenerate clouds).  Same scheme as knn_wave_d3_kernel:
+// per 1024-candidate chunk 16 exact distances per lane, threshold = kk-th smallest lane minimum (first chunk) or the
+// current kk-th best, candidates <= threshold compacted into a 64-entry LDS list (flushed into the best list
+// whenever it is full), one 64-lane bitonic sort on (distance, index) per merge.  kk <= 32.
+// lst_d / lst_j: 64 floats / ints of wave-private LDS.  Result: lanes 0..kk-1 hold the answer in order.
 __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q, const float *__restrict__ yb, int M,
-                                                      int D, int lane, float &bd, int &bj) {
+                                                      int D, int kk, int lane, float *lst_d, int *lst_j, float &bd,
+                                                      int &bj) {
     bd = INFINITY;
     bj = 0x7fffffff;
-    for (int j0 = 0; j0 < M; j0 += 64) {
-        const int j = j0 + lane;
-        float nd = INFINITY;
-        int nj = 0x7fffffff;
-        if (j < M) {
-            const float *c = yb + (size_t)j * D;
-            float s = 0.0f;
-            for (int d = 0; d < D; ++d) {
-                const float t = q[d] - c[d];
-                s = s + t * t;
+    const int cap = 64 - kk;
+    for (int j0 = 0; j0 < M; j0 += 1024) {
+        float d[16];
+        float lmin = INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int j = j0 + lane + 64 * i;
+            d[i] = INFINITY;
+            if (j < M) {
+                const float *c = yb + (size_t)j * D;
+                float s = 0.0f;
+                for (int dd = 0; dd < D; ++dd) {
+                    const float t = q[dd] - c[dd];
+                    s = s + t * t;
+                }
+                d[i] = s;
             }
-            nd = s;
-            nj = j;
+            lmin = fminf(lmin, d[i]);
         }
-        bitonic64(nd, nj, lane);
-        const float rd = __shfl(nd, 63 - lane, 64);
-        const int rj = __shfl(nj, 63 - lane, 64);
-        const bool o_less = key_less(rd, rj, bd, bj);
-        bd = o_less ? rd : bd;
-        bj = o_less ? rj : bj;
-        bitonic64(bd, bj, lane);
+        float tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bd), kk - 1));
+        if (j0 == 0) {  // kk-th smallest lane minimum bounds the kk-th smallest distance
+            float v = lmin;
+            bitonic64f(v, lane);
+            tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), kk - 1));
+        }
+        int cnt = 0;
+#pragma unroll 1
+        for (int i = 0; i < 16; ++i) {
+            bool pred = d[i] <= tau && d[i] < INFINITY;
+            unsigned long long bal = __ballot(pred);
+            while (bal) {  // usually one pass; more only when > cap candidates qualify
+                const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
+                                      __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
+                const bool put = pred && pos < cap;
+                if (put) { lst_d[pos] = d[i]; lst_j[pos] = j0 + lane + 64 * i; }
+                const int np = __builtin_popcountll(bal);
+                const bool overflow = cnt + np > cap;
+                cnt = overflow ? cap : cnt + np;
+                pred = pred && !put;
+                if (overflow) {  // flush: merge the full list into the best list, tighten tau
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    float sd = lane < kk ? bd : (lane - kk < cnt ? lst_d[lane - kk] : INFINITY);
+                    int sj = lane < kk ? bj : (lane - kk < cnt ? lst_j[lane - kk] : 0x7fffffff);
+                    bitonic64(sd, sj, lane);
+                    bd = lane < kk ? sd : INFINITY;
+                    bj = lane < kk ? sj : 0x7fffffff;
+                    tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sd), kk - 1));
+                    cnt = 0;
+                    pred = pred && d[i] <= tau;
+                }
+                bal = __ballot(pred);
+            }
+        }
+        if (cnt > 0) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            float sd = lane < kk ? bd : (lane - kk < cnt ? lst_d[lane - kk] : INFINITY);
+            int sj = lane < kk ? bj : (lane - kk < cnt ? lst_j[lane - kk] : 0x7fffffff);
+            bitonic64(sd, sj, lane);
+            bd = lane < kk ? sd : INFINITY;
+            bj = lane < kk ? sj : 0x7fffffff;
+        }
     }
 }
 
@@ -1069,14 +1115,16 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
         atomicAdd(&g_kprobe[4095 * 32 + 6], (unsigned long long)n);
     }
 #endif
-    // leftovers, wave-cooperative
+    // leftovers, wave-cooperative (scratch: behind this wave's slots)
+    int *wscratch = lists_all + wv * kTCap * 64 + 32 * 33 * 2;
     const unsigned long long slowmask = __ballot(slowq);
     const unsigned int slow32 = (unsigned int)slowmask | (unsigned int)(slowmask >> 32);
     for (int j = 0; j < 32; ++j) {
         if (!((slow32 >> j) & 1u) || q0 + j >= N) continue;
         float bd;
         int bj;
-        knn_exact_bruteforce(xb + (size_t)(q0 + j) * 3, yb, M, 3, lane, bd, bj);
+        __builtin_amdgcn_wave_barrier();
+        knn_exact_bruteforce(xb + (size_t)(q0 + j) * 3, yb, M, 3, kk, lane, reinterpret_cast<float *>(wscratch), wscratch + 64, bd, bj);
         const int r = lane - drop;
         if (r >= 0 && r < k) {
             idx[((size_t)b * N + q0 + j) * k + r] = bj;
@@ -1529,14 +1577,16 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             if (dist) dist[((size_t)b * N + qi) * k + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
         }
     }
-    // leftovers (overflowing lists, non-finite bands), wave-cooperative
+    // leftovers (overflowing lists, non-finite bands), wave-cooperative (scratch: behind all the slots)
+    int *wscratch = lists + kMWaves * 32 * 33 * 2 + cw * 128;
     const unsigned long long slowmask = __ballot(slowq);
     const unsigned int slow32 = (unsigned int)slowmask | (unsigned int)(slowmask >> 32);
     for (int j = 0; j < 32; ++j) {
         if (!((slow32 >> j) & 1u) || q0 + j >= N) continue;
         float bd;
         int bj;
-        knn_exact_bruteforce(xb + (size_t)(q0 + j) * D, yb, M, D, lane, bd, bj);
+        __builtin_amdgcn_wave_barrier();
+        knn_exact_bruteforce(xb + (size_t)(q0 + j) * D, yb, M, D, kk, lane, reinterpret_cast<float *>(wscratch), wscratch + 64, bd, bj);
         const int r = lane - drop;
         if (r >= 0 && r < k) {
             idx[((size_t)b * N + q0 + j) * k + r] = bj;
@@ -1655,7 +1705,7 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     constexpr int DP = DK * 32, RS = DP + 4;
     // lists (later the slots) + list lengths + per-query counters + cmax
     size_t fixed = (size_t)kMWaves * kMLCap * 64 * 4 + (size_t)kMWaves * 64 * 4 + (size_t)3 * kMWaves * 32 * 4 + 64;
-    static_assert(kMWaves * 32 * 33 * 8 <= kMWaves * kMLCap * 64 * 4, "the rank slots alias the mask lists");
+    static_assert(kMWaves * 32 * 33 * 8 + kMWaves * 128 * 4 <= kMWaves * kMLCap * 64 * 4, "rank slots + fallback scratch alias the mask lists");
     const int keep_norms = M <= 4096;  // all candidate norms stay in LDS: phase B does not recompute them
     if (keep_norms) fixed += (size_t)((M + 255) / 256 * 256 + 256) * 4;
     const size_t budget = 150 * 1024 - fixed;                                  // floats*4 for the two chunk buffers
