@@ -1478,7 +1478,7 @@ int nn1_variant() {
     return v;
 }
 
-Plan make_plan(int N, int M, int B, int D) {
+Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
     Plan pl{};
     // R queries per thread: enough blocks to fill 256 CUs x ~2 blocks, but as much register
     // blocking (LDS-read amortisation, ILP) as the problem size allows.
@@ -1525,13 +1525,44 @@ Plan make_plan(int N, int M, int B, int D) {
     if (pl.variant == 3) pl.lds_bytes += kHScratchBytes;
     const int clouds8 = (2 * B + 7) / 8;
     pl.nsplit = 1;
-    if (pl.variant == 3 && maxc > pl.chunk) {
-        const int chunks = (maxc + pl.chunk - 1) / pl.chunk;
-        const long long blocks = (long long)2 * B * pl.tiles;
-        if (blocks < 256) {
-            long long want = (512 + blocks - 1) / blocks;
-            pl.nsplit = (int)(want < chunks ? want : chunks);
+    if (pl.variant == 3) {
+        // nn1_f16_kernel: choose (candidate chunk size, chunks per block, 512-query passes per block) by a small
+        // cost model in microseconds, measured at C2 (tools/nn1_probe.hip): bounding box 2.8 per 4096 candidates of
+        // the cloud, image 5.0 per 4096 of the chunk, one pass (filter + exact) 9.7 per 4096, 256 resident blocks.
+        // A block either walks all chunks serially (one pass per block: the per-query slot lives in LDS) or takes
+        // ONE chunk of a split run (any number of passes; subsets merge through 64-bit atomicMin slots, +8 us of
+        // extra launches).  Few large clouds want many small chunks, many small clouds want passes.
+        const int cminc = (maxc + cmax - 1) / cmax;
+        double best = 1e30;
+        int b_chunk = chunk, b_tpb = pl.tpb, b_split = 1;
+        static const int tpb_env = [] { const char *e = getenv("FX3D_NN1_TPB"); return e ? atoi(e) : 0; }();
+        for (int nch = cminc; nch <= cminc * 8 && nch <= 64; ++nch) {
+            int ch = ((maxc + nch - 1) / nch + gran - 1) / gran * gran;
+            if (ch > cmax) continue;
+            const int anch = (maxc + ch - 1) / ch;
+            for (int split = 0; split < 2; ++split) {
+                if (split && (!allow_split || anch == 1)) continue;
+                for (int tpb = 1; tpb <= 8; tpb *= 2) {
+                    if (!split && anch > 1 && tpb > 1) continue;
+                    if (tpb_env > 0 && tpb != tpb_env && (split || anch == 1)) continue;
+                    const long long tiles = ((long long)maxc + 512 * tpb - 1) / (512 * tpb);
+                    const long long blocks = 2ll * B * tiles * (split ? anch : 1);
+                    const double per_chunk = 5.0 * ch / 4096.0 + 0.5 + tpb * (9.7 * ch / 4096.0 + 0.8);
+                    const double t_block = 2.8 * maxc / 4096.0 + (split ? 1 : anch) * per_chunk;
+                    const double rounds = (double)((blocks + 255) / 256);
+                    const double t = rounds * t_block + (split ? 8.0 : 0.0);
+                    if (t < best - 1e-9) { best = t; b_chunk = ch; b_tpb = tpb; b_split = split ? anch : 1; }
+                }
+            }
         }
+        pl.chunk = b_chunk;
+        pl.tpb = b_tpb;
+        pl.nsplit = b_split;
+        pl.lds_bytes = (size_t)pl.chunk * 8 * sizeof(float) + kHScratchBytes;
+        const int per_block3 = 512 * pl.tpb;
+        pl.tiles_x = (N + per_block3 - 1) / per_block3;
+        pl.tiles_y = (M + per_block3 - 1) / per_block3;
+        pl.tiles = pl.tiles_x > pl.tiles_y ? pl.tiles_x : pl.tiles_y;
     }
     pl.grid = clouds8 * 8 * pl.tiles * pl.nsplit;
     if (pl.variant == 3 && 2 * B < 8) pl.grid = 2 * B * pl.tiles * pl.nsplit;  // plain block order (see kernel)
@@ -1660,9 +1691,8 @@ fx3d_status fx3d_nn1(const float *x, int32_t N, const float *y, int32_t M, int32
     fx3d_status rc = check_shapes("fx3d_nn1", x, N, y, M, B, D);
     if (rc) return rc;
     Plan pl = make_plan(N, M, B, D);
-    if (pl.nsplit > 1) {  // no scratch at this entry point: run unsplit
-        pl.grid /= pl.nsplit;
-        pl.nsplit = 1;
+    if (pl.nsplit > 1) {  // no scratch at this entry point: plan without the split option
+        pl = make_plan(N, M, B, D, false);
     }
     return run_nn1(x, N, y, M, B, D, idx_x, idx_y, dmin_x, dmin_y, nullptr, pl, as_stream(s));
 }

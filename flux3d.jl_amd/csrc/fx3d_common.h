@@ -55,6 +55,21 @@ struct ProfileScope {  // brackets one dominant-kernel launch when profiling is 
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// ||(v2-v1) x (v3-v1)|| / 2 : _lg_cross (src/rep/utils.jl:4-21), _norm (:29),
+// compute_faces_areas_packed (src/rep/mesh.jl:772-779).
+__device__ __forceinline__ float tri_area(const float *__restrict__ v1, const float *__restrict__ v2,
+                                          const float *__restrict__ v3) {
+    const float p0 = v1[0], p1 = v1[1], p2 = v1[2];
+    const float a1 = v2[0] - p0, a2 = v2[1] - p1, a3 = v2[2] - p2;
+    const float b1 = v3[0] - p0, b2 = v3[1] - p1, b3 = v3[2] - p2;
+    const float c1 = (a2 * b3) - (a3 * b2);
+    const float c2 = (a3 * b1) - (a1 * b3);
+    const float c3 = (a1 * b2) - (a2 * b1);
+    const float s = ((c1 * c1) + (c2 * c2)) + (c3 * c3);
+    return sqrtf(s) / 2.0f;
+}
+
+
 // ---- device-side reductions (wave64) -------------------------------------------------------
 __device__ inline double wave_sum(double v) {
 #pragma unroll

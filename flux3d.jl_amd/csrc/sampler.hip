@@ -53,20 +53,29 @@ __global__ __launch_bounds__(kThreads) void sample_explicit_kernel(
 // The SUMMATION ORDER is fixed by the specification shared with the oracle (chunks of 32 summed
 // left to right, chunk totals summed left to right); everything order-free (the Float64 divisions, the
 // final offset add) runs on all 256 threads, the order-bound parts are 32- or nch-long add chains.
+// The face areas are computed in place (compute_faces_areas_padded, src/rep/mesh.jl:799-808: pad faces -> 0).
 template <bool IN_LDS>
-__global__ __launch_bounds__(kThreads) void face_cdf_kernel(const float *__restrict__ areas, int Fmax,
+__global__ __launch_bounds__(kThreads) void face_cdf_kernel(const float *__restrict__ verts_padded, int Vmax,
+                                                            const int32_t *__restrict__ faces_padded,
+                                                            const int32_t *__restrict__ faces_len, int Fmax,
                                                             int Fp, double eps,
                                                             double *__restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) double dsm[];  // IN_LDS: work[Fp] + tc[nch]
     const int b = blockIdx.x;
     const int nch = Fp / kChunk;
-    const float *a = areas + (size_t)b * Fmax;
+    const float *vb = verts_padded + (size_t)b * Vmax * 3;
+    const int32_t *fb = faces_padded + (size_t)b * Fmax * 3;
+    const int flen = faces_len[b];
     double *out = ws + (size_t)b * (Fp + nch);
     double *cdf = IN_LDS ? dsm : out;          // working copy: LDS when the mesh fits (latency-bound chains)
     double *tc = IN_LDS ? dsm + Fp : out + Fp;
     __shared__ double sh[2];
 
-    for (int k = threadIdx.x; k < Fp; k += kThreads) cdf[k] = (k < Fmax) ? (double)a[k] : 0.0;
+    for (int k = threadIdx.x; k < Fp; k += kThreads) {
+        float a = 0.0f;
+        if (k < flen) a = tri_area(vb + 3ll * fb[3 * k], vb + 3ll * fb[3 * k + 1], vb + 3ll * fb[3 * k + 2]);
+        cdf[k] = (double)a;
+    }
     __syncthreads();
     for (int c = threadIdx.x; c < nch; c += kThreads) {  // chunk totals of the areas
         double t = 0.0;
@@ -237,15 +246,14 @@ fx3d_status fx3d_sample_points(const float *verts_padded, int32_t Vmax, const in
     hipStream_t st = as_stream(s);
     const int Fp = roundup32(Fmax);
     double *cdf = reinterpret_cast<double *>(ws);
-    float *areas = reinterpret_cast<float *>(cdf + (size_t)B * (Fp + Fp / kChunk));
-    fx3d_status rc = fx3d_faces_areas_padded(verts_padded, Vmax, faces_padded, Fmax, faces_len, B, areas, s);
-    if (rc) return rc;
-    ProfileScope prof("sample", st);  // cdf + draw kernels together
+    ProfileScope prof("sample", st);  // areas + cdf, draw: two kernels
     const size_t cdf_lds = sizeof(double) * (size_t)(Fp + Fp / kChunk);
     if (cdf_lds <= 60 * 1024)
-        hipLaunchKernelGGL(face_cdf_kernel<true>, dim3(B), dim3(kThreads), cdf_lds, st, areas, Fmax, Fp, eps, cdf);
+        hipLaunchKernelGGL(face_cdf_kernel<true>, dim3(B), dim3(kThreads), cdf_lds, st, verts_padded, Vmax, faces_padded,
+                           faces_len, Fmax, Fp, eps, cdf);
     else
-        hipLaunchKernelGGL(face_cdf_kernel<false>, dim3(B), dim3(kThreads), 0, st, areas, Fmax, Fp, eps, cdf);
+        hipLaunchKernelGGL(face_cdf_kernel<false>, dim3(B), dim3(kThreads), 0, st, verts_padded, Vmax, faces_padded,
+                           faces_len, Fmax, Fp, eps, cdf);
     FX3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(sample_seeded_kernel, dim3(grid_for((long long)B * n)), dim3(kThreads), 0, st,
                        verts_padded, Vmax, faces_padded, Fmax, Fp, faces_len, B, n, seed, cdf, out,
