@@ -1177,7 +1177,75 @@ constexpr int kMLCap = 40;        // rows of a lane's mask list (39 usable + the
 constexpr int kMKeyCap = 60;      // survivors per query handled by the fast path
 constexpr int kMKeyStride = 64;   // row stride of the key arrays in words
 
+// fp16-split staging of a candidate chunk (producer side, F16 filter): unit = (row, group of 8 dimensions).
+// A thread converts two float4 of a row (scaled by sc) into one hi piece and one lo piece of 8 halves each.
+// LDS row: pieces [0, PPR/2) = hi of dimension groups, [PPR/2, PPR) = lo; piece c of row r sits at (c + r) mod PPR.
+constexpr int kMUnits = 6;  // (row, group) units per producer thread and chunk: CH * (DP/8) <= 6 * 256
 template <int DK>
+__device__ __forceinline__ void knn_f16_load_chunk(const float *__restrict__ yb, int D, int j0, int cn, int CH, int ptid,
+                                                   float4 (&reg)[kMUnits][2]) {
+    constexpr int DP = DK * 32, G = DP / 8;
+    // unconditional loads from clamped (always valid) addresses, zeroed afterwards: predicated loads would be
+    // issued one branch at a time, each waiting for its data
+    const float4 zero4 = float4{0.f, 0.f, 0.f, 0.f};
+    const int cnm1 = cn - 1;
+#pragma unroll
+    for (int u = 0; u < kMUnits; ++u) {
+        const int un = ptid + u * kMProd;
+        const int row = un / G, g = un - row * G;
+        const int rowc = row < cnm1 ? row : cnm1;
+        const int d0 = 8 * g < D ? 8 * g : 0, d1 = 8 * g + 4 < D ? 8 * g + 4 : 0;
+        const float *src = yb + (size_t)(j0 + rowc) * D;
+        reg[u][0] = *reinterpret_cast<const float4 *>(src + d0);
+        reg[u][1] = *reinterpret_cast<const float4 *>(src + d1);
+    }
+#pragma unroll
+    for (int u = 0; u < kMUnits; ++u) {
+        const int un = ptid + u * kMProd;
+        const int row = un / G, g = un - row * G;
+        const bool ok = un < CH * G && row < cn;
+        if (!(ok && 8 * g < D)) reg[u][0] = zero4;
+        if (!(ok && 8 * g + 4 < D)) reg[u][1] = zero4;
+    }
+}
+// Converts and stores the units; the G = DP/8 consecutive lanes that hold one row also sum its scaled norm
+// (3..4 butterfly steps).  norms != nullptr: phase A, norms[row] and the running maximum are recorded.
+template <int DK>
+__device__ __forceinline__ void knn_f16_store_chunk(float *img, int CH, int cn, float sc, int ptid,
+                                                    const float4 (&reg)[kMUnits][2], float *norms, float &tmax, bool &tnan) {
+    constexpr int DP = DK * 32, G = DP / 8, PPR = DK * 8;
+#pragma unroll
+    for (int u = 0; u < kMUnits; ++u) {
+        const int un = ptid + u * kMProd;
+        const int row = un / G, g = un - row * G;
+        const float v[8] = {reg[u][0].x * sc, reg[u][0].y * sc, reg[u][0].z * sc, reg[u][0].w * sc,
+                            reg[u][1].x * sc, reg[u][1].y * sc, reg[u][1].z * sc, reg[u][1].w * sc};
+        kh8 hi, lo;
+        float part = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const _Float16 hh_ = (_Float16)v[e];
+            hi[e] = hh_;
+            lo[e] = (_Float16)(v[e] - (float)hh_);
+            part = __builtin_fmaf(v[e], v[e], part);
+        }
+        if (un < CH * G) {
+            *reinterpret_cast<kh8 *>(img + knn_piece_off<DK>(row, g)) = hi;
+            *reinterpret_cast<kh8 *>(img + knn_piece_off<DK>(row, PPR / 2 + g)) = lo;
+        }
+        if (norms) {  // wave-uniform
+#pragma unroll
+            for (int m = 1; m < G; m <<= 1) part = part + __shfl_xor(part, m, 64);
+            if (un < CH * G && g == 0) {
+                const float t = row < cn ? part : INFINITY;  // rows beyond the cloud: F = +inf
+                norms[row] = t;
+                if (row < cn) { tnan |= (t != t); tmax = fmaxf(tmax, t); }
+            }
+        }
+    }
+}
+
+template <int DK, bool F16>
 __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__restrict__ x, int N,
                                                              const float *__restrict__ y, int M, int B, int D,
                                                              int k, int drop, int32_t *__restrict__ idx,
@@ -1187,6 +1255,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     constexpr int RS = DP + 4;       // row stride of the query rows staged in the prologue (floats)
     constexpr int PPR = DK * 8;      // 16-byte pieces per candidate row
     constexpr int NT = DP / 8;       // b128 operand fetches per tile and half
+    constexpr int NB16 = DP / 16;    // K blocks of the fp16 filter
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int buf_floats = CH * DP + CH;                                   // image [CH][DP] + norms [CH]
     int *lists = reinterpret_cast<int *>(sm + img_floats);                 // [kMWaves][kMLCap][64] mask words
@@ -1208,6 +1277,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool consumer = wv < kMWaves;
     const int cw = consumer ? wv : wv - kMWaves;   // the consumer wave this wave is paired with
+    const int ptid = tid - kMProd;                 // producer thread id (negative for consumers)
     const int h = lane >> 5, jl = lane & 31;
     const int kk = k + drop;
     const float *xb = x + (size_t)b * N * D, *yb = y + (size_t)b * M * D;
@@ -1216,12 +1286,49 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     const int qi = q0 + jl;
     const bool vec4y = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(yb) & 15) == 0);
     const bool vec4x = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(xb) & 15) == 0);
+    const int nchunk = (M + CH - 1) / CH;
     KNN_PROBE_MARK(0);
 
-    // ---- B operand: the wave's 32 query rows, staged through LDS (coalesced), then -2 q in registers ------------
-    float4 a[NT];
-    float qn = 0.0f;
     if (tid == 0) *cmax = 0u;
+    float sc = 1.0f;  // F16: power-of-two scale with |sc * c| < 1 for every candidate
+    if (F16) {
+        // ---- scale: largest |coordinate| of the cloud, one coalesced pass (F16 => 16-byte loads are legal) ----
+        __syncthreads();
+        float amax = 0.0f;
+        bool tnan = false;
+        const float4 *c4 = reinterpret_cast<const float4 *>(yb);
+        const int total4 = M * (D / 4);
+        for (int e0 = tid; e0 < total4; e0 += 8 * kMThreads) {
+            float4 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = c4[e0 + e * kMThreads < total4 ? e0 + e * kMThreads : 0];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float m4 = fmaxf(fmaxf(fabsf(v[e].x), fabsf(v[e].y)), fmaxf(fabsf(v[e].z), fabsf(v[e].w)));
+                tnan |= (m4 != m4);
+                amax = fmaxf(amax, m4);
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m, 64));
+        const bool anynan = __ballot(tnan) != 0;
+        if (lane == 0) atomicMax(cmax, anynan ? 0x7fc00000u : __builtin_bit_cast(unsigned int, amax));
+        __syncthreads();
+        const float cinf = __builtin_bit_cast(float, *cmax);
+        if (cinf > 1.0e-30f && cinf < 1.0e30f) {
+            int e;
+            (void)frexpf(cinf * 1.000001f, &e);  // = m 2^e, m in [0.5, 1)
+            sc = ldexpf(1.0f, -e);
+        }
+        __syncthreads();
+        if (tid == 0) *cmax = anynan ? 0x7fc00000u : 0u;  // from here on: bits of the largest SCALED squared norm
+    }
+
+    // ---- B operand: the wave's 32 query rows, staged through LDS (coalesced), then -2 q in registers ------------
+    float4 a[NT];            // f32 filter: -2 q, this lane's half of the permuted reduction dimension
+    kh8 ah[NB16], al[NB16];  // fp16 filter: hi / lo halves of -2 sc q, 8 dimensions per K block and half-wave
+    float qn = 0.0f;
+    bool qok = true;
     if (consumer) {
         float *qs = sm + (size_t)cw * 32 * RS;
         const int nrow = wave_active ? ((N - q0) < 32 ? (N - q0) : 32) : 0;
@@ -1244,15 +1351,38 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        const float *qr = qs + (size_t)jl * RS + h * (DP / 2);
+        if (F16) {
+            // K block bb covers dimensions 16 bb + 8 h + [0, 8) in half-wave h: hi and lo halves of -2 sc q
+            float amax = 0.0f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float4 v = *reinterpret_cast<const float4 *>(qr + 4 * t);
-            qn = qn + v.x * v.x;
-            qn = qn + v.y * v.y;
-            qn = qn + v.z * v.z;
-            qn = qn + v.w * v.w;
-            a[t] = float4{-2.0f * v.x, -2.0f * v.y, -2.0f * v.z, -2.0f * v.w};
+            for (int bb = 0; bb < NB16; ++bb) {
+                const float *qr = qs + (size_t)jl * RS + 16 * bb + 8 * h;
+                const float4 v0 = *reinterpret_cast<const float4 *>(qr), v1 = *reinterpret_cast<const float4 *>(qr + 4);
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float qs_ = v[e] * sc;
+                    qn = qn + qs_ * qs_;
+                    const float av = -2.0f * qs_;
+                    amax = fmaxf(amax, fabsf(av));
+                    const _Float16 hh_ = (_Float16)av;
+                    ah[bb][e] = hh_;
+                    al[bb][e] = (_Float16)(av - (float)hh_);
+                }
+            }
+            amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+            qok = amax < 6.0e4f;  // inside the fp16 range (false for NaN too)
+        } else {
+            const float *qr = qs + (size_t)jl * RS + h * (DP / 2);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float4 v = *reinterpret_cast<const float4 *>(qr + 4 * t);
+                qn = qn + v.x * v.x;
+                qn = qn + v.y * v.y;
+                qn = qn + v.z * v.z;
+                qn = qn + v.w * v.w;
+                a[t] = float4{-2.0f * v.x, -2.0f * v.y, -2.0f * v.z, -2.0f * v.w};
+            }
         }
         qn = qn + __shfl_xor(qn, 32, 64);
     }
@@ -1260,17 +1390,39 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     KNN_PROBE_MARK(1);
 
     // ---- chunk schedule: phase A walks the chunks forwards, phase B backwards (its first chunk is resident) ----
-    const int nchunk = (M + CH - 1) / CH;
     const int nstep = 2 * nchunk;
-    if (D < DP || !vec4y) {  // padding columns must read as zeros; the direct loads never touch them
-        for (int e = tid; e < 2 * buf_floats / 4; e += kMThreads)
-            reinterpret_cast<float4 *>(sm)[e] = float4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();
-    }
-    if (!consumer) {
-        const int cn = M < CH ? M : CH;
-        knn_stage_chunk<DK>(yb, D, 0, cn, CH, sm, keep_norms ? nall : sm + (size_t)CH * DP, cmax, true, true, vec4y,
-                            wv - kMWaves, lane);
+    float4 preg[kMUnits][2];  // F16 producers: the chunk after next, loaded one step ahead
+    float pmax = 0.0f;        // F16 producers: largest scaled norm seen
+    bool pnan = false;
+    int stage_ev = 0;                    // F16 producers: staging events done (chunks 0..n-1, n-2..0)
+    const int nevents = 2 * nchunk - 1;
+    if (F16) {
+        if (!consumer) {
+            knn_f16_load_chunk<DK>(yb, D, 0, M < CH ? M : CH, CH, ptid, preg);
+            knn_f16_store_chunk<DK>(sm, CH, M < CH ? M : CH, sc, ptid, preg, nall, pmax, pnan);
+            if (nchunk == 1) {
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, m, 64));
+                const bool anyn = __ballot(pnan) != 0;
+                if (lane == 0) atomicMax(cmax, anyn ? 0x7fc00000u : __builtin_bit_cast(unsigned int, pmax));
+            }
+            if (nevents > 1) {
+                const int c1 = 1 < nchunk ? 1 : 2 * nchunk - 3;
+                knn_f16_load_chunk<DK>(yb, D, c1 * CH, (M - c1 * CH) < CH ? (M - c1 * CH) : CH, CH, ptid, preg);
+            }
+            stage_ev = 1;
+        }
+    } else {
+        if (D < DP || !vec4y) {  // padding columns must read as zeros; the direct loads never touch them
+            for (int e = tid; e < 2 * buf_floats / 4; e += kMThreads)
+                reinterpret_cast<float4 *>(sm)[e] = float4{0.f, 0.f, 0.f, 0.f};
+            __syncthreads();
+        }
+        if (!consumer) {
+            const int cn = M < CH ? M : CH;
+            knn_stage_chunk<DK>(yb, D, 0, cn, CH, sm, keep_norms ? nall : sm + (size_t)CH * DP, cmax, true, true, vec4y,
+                                wv - kMWaves, lane);
+        }
     }
     __syncthreads();
     KNN_PROBE_MARK(2);
@@ -1301,13 +1453,6 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                 for (int pr = 0; pr < npair; ++pr) {
                     // rows pr*64 + jl and + 32 share (row mod PPR) = jl mod PPR: one rotated offset per fetch
                     const float *c0 = cand + (size_t)(pr * 64 + jl) * DP, *c1 = c0 + (size_t)32 * DP;
-                    float4 b0[NT], b1[NT];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const int po = ((h * NT + t + jl) & (PPR - 1)) * 4;
-                        b0[t] = *reinterpret_cast<const float4 *>(c0 + po);
-                        b1[t] = *reinterpret_cast<const float4 *>(c1 + po);
-                    }
                     // accumulators start at the candidate norms: register r of half h is row (r&3) + 8(r>>2) + 4h
                     f32x16v acc0, acc1;
 #pragma unroll
@@ -1317,16 +1462,45 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                         acc0[4 * g] = n0.x; acc0[4 * g + 1] = n0.y; acc0[4 * g + 2] = n0.z; acc0[4 * g + 3] = n0.w;
                         acc1[4 * g] = n1.x; acc1[4 * g + 1] = n1.y; acc1[4 * g + 2] = n1.z; acc1[4 * g + 3] = n1.w;
                     }
+                    if (F16) {
+                        // A = candidate pieces (rows), B = query pieces (columns); hi*hi + lo*hi + hi*lo
+                        kh8 h0[NB16], l0[NB16], h1[NB16], l1[NB16];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {  // A = candidates (rows), B = queries (columns)
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[t].x, a[t].x, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[t].x, a[t].x, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[t].y, a[t].y, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[t].y, a[t].y, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[t].z, a[t].z, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[t].z, a[t].z, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[t].w, a[t].w, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[t].w, a[t].w, acc1, 0, 0, 0);
+                        for (int bb = 0; bb < NB16; ++bb) {
+                            const int ph = ((2 * bb + h + jl) & (PPR - 1)) * 4, pl = ((PPR / 2 + 2 * bb + h + jl) & (PPR - 1)) * 4;
+                            h0[bb] = *reinterpret_cast<const kh8 *>(c0 + ph);
+                            l0[bb] = *reinterpret_cast<const kh8 *>(c0 + pl);
+                            h1[bb] = *reinterpret_cast<const kh8 *>(c1 + ph);
+                            l1[bb] = *reinterpret_cast<const kh8 *>(c1 + pl);
+                        }
+#pragma unroll
+                        for (int bb = 0; bb < NB16; ++bb) {
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0[bb], ah[bb], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1[bb], ah[bb], acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(l0[bb], ah[bb], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(l1[bb], ah[bb], acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0[bb], al[bb], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1[bb], al[bb], acc1, 0, 0, 0);
+                        }
+                    } else {
+                        float4 b0[NT], b1[NT];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const int po = ((h * NT + t + jl) & (PPR - 1)) * 4;
+                            b0[t] = *reinterpret_cast<const float4 *>(c0 + po);
+                            b1[t] = *reinterpret_cast<const float4 *>(c1 + po);
+                        }
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {  // A = candidates (rows), B = queries (columns)
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[t].x, a[t].x, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[t].x, a[t].x, acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[t].y, a[t].y, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[t].y, a[t].y, acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[t].z, a[t].z, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[t].z, a[t].z, acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[t].w, a[t].w, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[t].w, a[t].w, acc1, 0, 0, 0);
+                        }
                     }
                     if (phase == 0) {
 #pragma unroll
@@ -1353,9 +1527,26 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             const int j0n = ci_next * CH;
             const int cnn = (M - j0n) < CH ? (M - j0n) : CH;
             float *img = sm + (size_t)(1 - cur) * buf_floats;
-            const bool phase_a = nstep1 < nchunk;
-            knn_stage_chunk<DK>(yb, D, j0n, cnn, CH, img, keep_norms ? nall + (size_t)ci_next * CH : img + (size_t)CH * DP,
-                                cmax, phase_a, phase_a || !keep_norms, vec4y, wv - kMWaves, lane);
+            if (F16) {
+                // the registers hold chunk ci_next (loaded one step ago); then fetch the chunk after it
+                knn_f16_store_chunk<DK>(img, CH, cnn, sc, ptid, preg, stage_ev < nchunk ? nall + (size_t)stage_ev * CH : nullptr,
+                                        pmax, pnan);
+                if (stage_ev == nchunk - 1) {  // last phase-A chunk: publish this wave's maximum norm
+#pragma unroll
+                    for (int m = 1; m < 64; m <<= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, m, 64));
+                    const bool anyn = __ballot(pnan) != 0;
+                    if (lane == 0) atomicMax(cmax, anyn ? 0x7fc00000u : __builtin_bit_cast(unsigned int, pmax));
+                }
+                ++stage_ev;
+                if (stage_ev < nevents) {
+                    const int cnx = stage_ev < nchunk ? stage_ev : 2 * nchunk - 2 - stage_ev;
+                    knn_f16_load_chunk<DK>(yb, D, cnx * CH, (M - cnx * CH) < CH ? (M - cnx * CH) : CH, CH, ptid, preg);
+                }
+            } else {
+                const bool phase_a = nstep1 < nchunk;
+                knn_stage_chunk<DK>(yb, D, j0n, cnn, CH, img, keep_norms ? nall + (size_t)ci_next * CH : img + (size_t)CH * DP,
+                                    cmax, phase_a, phase_a || !keep_norms, vec4y, wv - kMWaves, lane);
+            }
         }
         __syncthreads();
         KNN_PROBE_MARK(3 + step);
@@ -1386,7 +1577,16 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
 #pragma unroll
             for (int r = 1; r < 32; ++r) val = (kk - 1) == r ? mn[r] : val;
             const float tau = __shfl(val, jl, 64);  // kk <= 32: always among the 32 smallest (half 0)
-            const float eps = (8.0f * (float)(D + 4) * 0x1p-24f) * (qn + c2);
+            float eps;
+            if (F16) {
+                // scaled units (c~ = sc c, |c~| < 1; qn = |sc q|^2): split representation 3 2^-22 |a~||c~|, fp32
+                // accumulation of the 3D exact products (3D+1) u, the oracle's own (D+2) u, fp16 underflow floor
+                eps = (8.0f * (float)(4 * D + 8) * 0x1p-24f + 0x1p-18f) * (qn + c2) +
+                      0x1p-24f * sqrtf((float)D) * (qn + 2.0f);
+                eps = qok ? eps : INFINITY;
+            } else {
+                eps = (8.0f * (float)(D + 4) * 0x1p-24f) * (qn + c2);
+            }
             thr = tau + 2.0f * eps;  // NaN / inf => slow path below
         }
     }
@@ -1699,7 +1899,7 @@ __global__ __launch_bounds__(kThreads) void edge_features_bwd_kernel(const float
 }
 
 
-template <int DK>
+template <int DK, bool F16>
 fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int B, int D, int k, int drop,
                                int32_t *idx, float *dist, hipStream_t st) {
     constexpr int DP = DK * 32, RS = DP + 4;
@@ -1711,6 +1911,7 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     const size_t budget = 150 * 1024 - fixed;                                  // floats*4 for the two chunk buffers
     int CH = (int)(budget / 2 / ((size_t)DP * 4 + 4)) / 64 * 64;
     if (CH > 256) CH = 256;
+    if (F16 && CH > kMUnits * kMProd * 8 / DP / 64 * 64) CH = kMUnits * kMProd * 8 / DP / 64 * 64;  // producer register budget
     const int mpad = (M + 63) / 64 * 64;
     if (CH > mpad) CH = mpad;
     size_t img = 2 * ((size_t)CH * DP + CH);                                   // floats
@@ -1722,7 +1923,7 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     const size_t lds = img * 4 + fixed;
     static bool attr_done = false;
     if (!attr_done) {
-        FX3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<DK>),
+        FX3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<DK, F16>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         attr_done = true;
     }
@@ -1730,7 +1931,7 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     const int qpb = kMWaves * 32;
     const int nbx = (N + qpb - 1) / qpb;
     const int bpad = B >= 8 ? (B + 7) / 8 * 8 : B;
-    hipLaunchKernelGGL((knn_mfma_kernel<DK>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
+    hipLaunchKernelGGL((knn_mfma_kernel<DK, F16>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
                        k, drop, idx, dist, CH, (int)img, keep_norms);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
@@ -1739,11 +1940,21 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
 fx3d_status launch_knn_mfma(const float *x, int N, const float *y, int M, int B, int D, int k, int drop, int32_t *idx,
                             float *dist, hipStream_t st) {
     const int dk = (D + 31) / 32;
+    // fp16-split filter: needs 16-byte loads (D % 4 == 0, aligned clouds) and all norms in LDS up front
+    static const bool f32_only = [] { const char *e = getenv("FX3D_KNN_F32"); return e && atoi(e); }();
+    const bool f16 = !f32_only && D % 4 == 0 && M <= 4096 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
+                     ((size_t)M * D * 4) % 16 == 0;
+    if (f16) {
+        switch (dk) {
+            case 1: return launch_knn_mfma_dk<1, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
+            case 2: return launch_knn_mfma_dk<2, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
+            default: return launch_knn_mfma_dk<4, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
+        }
+    }
     switch (dk) {
-        case 1: return launch_knn_mfma_dk<1>(x, N, y, M, B, D, k, drop, idx, dist, st);
-        case 2: return launch_knn_mfma_dk<2>(x, N, y, M, B, D, k, drop, idx, dist, st);
-        case 4: return launch_knn_mfma_dk<4>(x, N, y, M, B, D, k, drop, idx, dist, st);
-        default: return launch_knn_mfma_dk<4>(x, N, y, M, B, D, k, drop, idx, dist, st);
+        case 1: return launch_knn_mfma_dk<1, false>(x, N, y, M, B, D, k, drop, idx, dist, st);
+        case 2: return launch_knn_mfma_dk<2, false>(x, N, y, M, B, D, k, drop, idx, dist, st);
+        default: return launch_knn_mfma_dk<4, false>(x, N, y, M, B, D, k, drop, idx, dist, st);
     }
 }
 
