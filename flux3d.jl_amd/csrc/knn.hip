@@ -1941,7 +1941,8 @@ fx3d_status launch_knn_mfma(const float *x, int N, const float *y, int M, int B,
                             float *dist, hipStream_t st) {
     const int dk = (D + 31) / 32;
     // fp16-split filter: needs 16-byte loads (D % 4 == 0, aligned clouds) and all norms in LDS up front
-    static const bool f32_only = [] { const char *e = getenv("FX3D_KNN_F32"); return e && atoi(e); }();
+    const char *f32_env = getenv("FX3D_KNN_F32");  // read per call: the tests flip it
+    const bool f32_only = f32_env && atoi(f32_env);
     const bool f16 = !f32_only && D % 4 == 0 && M <= 4096 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
                      ((size_t)M * D * 4) % 16 == 0;
     if (f16) {

@@ -381,6 +381,19 @@ def test_knn_matrix_core_path(gpu_fx, oracle, D, N, M, B, k, drop, kind):
     assert np.array_equal(dist.to_host(), od)
 
 
+def test_knn_float32_filter_variant(gpu_fx, oracle, monkeypatch):
+    """FX3D_KNN_F32=1 keeps the Float32 GEMM filter (the default for D % 4 == 0, M <= 4096 is the fp16 split):
+    both must give the oracle's lists."""
+    monkeypatch.setenv("FX3D_KNN_F32", "1")
+    rng = np.random.default_rng(77)
+    for (D, N, M, k) in ((64, 300, 1024, 20), (32, 100, 200, 9), (128, 64, 96, 5)):
+        x = np.asfortranarray(rng.standard_normal((D, N, 2)).astype(np.float32))
+        y = np.asfortranarray(rng.standard_normal((D, M, 2)).astype(np.float32))
+        idx, dist = gpu_fx.knn(x, k, y=y)
+        oi, od = oracle.knn(x, k, y=y)
+        assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+
+
 def test_knn_graph_gather(gpu_fx, oracle):
     """create_knn_graph == cat([X[:, knn idx]]...) (src/models/dgcnn.jl:3-7,36): (F,K,N,B)."""
     for F in (3, 64):
