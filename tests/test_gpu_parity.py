@@ -220,6 +220,21 @@ def test_chamfer_backward(gpu_fx, oracle):
     assert np.allclose(gy.to_host(), ogy, rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("N,M,B", [(4096, 4096, 3), (700, 5000, 1), (14000, 300, 1), (1, 9, 2), (257, 256, 40)])
+def test_chamfer_backward_shapes(gpu_fx, oracle, monkeypatch, N, M, B):
+    """LDS-accumulating adjoint (row ranges split over blocks, clouds beyond one LDS image) and the global-atomics
+    variant against the oracle's adjoint."""
+    fx = gpu_fx
+    x, y = _rand((3, N, B), N + 1), _rand((3, M, B), M + 2)
+    _, ix, iy = fx.chamfer_distance(x, y, return_indices=True)
+    ogx, ogy = oracle.chamfer_bwd(x, y, ix.to_host(), iy.to_host(), 1.0, 0.5, 1.5)
+    for glob in ("0", "1"):
+        monkeypatch.setenv("FX3D_BWD_GLOBAL_ATOMICS", glob)
+        gx, gy = fx.chamfer_distance_grad(x, y, ix, iy, w1=1.0, w2=0.5, gout=1.5)
+        assert np.allclose(gx.to_host(), ogx, rtol=1e-5, atol=1e-9)
+        assert np.allclose(gy.to_host(), ogy, rtol=1e-5, atol=1e-9)
+
+
 def test_invalid_arguments_raise(gpu_fx):
     fx = gpu_fx
     x = _rand((3, 10, 2), 0)
