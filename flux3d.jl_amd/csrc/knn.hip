@@ -6,12 +6,10 @@
 // CPU path's arithmetic (Float32 sum of squared differences in dimension order, unfused), so the
 // index lists are bit-identical to oracle/flux3d_oracle.c:fx3d_oracle_knn.
 //
-// knn_d3_kernel<KMAX>: one thread per query, candidates broadcast from LDS (SoA, like chamfer.hip),
-// the running top-KMAX list lives in registers (fully unrolled insertion network, guarded by one
-// compare against the current worst).  KMAX in {8,16,32,64} >= k+drop_first.
-// knn_generic_kernel<KMAX>: any D (the second EdgeConv runs in 64-D feature space,
-// src/models/dgcnn.jl:121): the query lives in LDS transposed ([d][thread], conflict-free), the
-// candidate row is read through the scalar/L1 path (same address for every lane).
+// Kernels (dispatch in launch_knn at the end of the file):
+//   knn_f16_d3_kernel        D = 3, k+drop <= 32, M >= 64: fp16-split matrix-core filter + exact re-scan
+//   knn_mfma_kernel<DK,F16>  4 <= D <= 128, k+drop <= 32, M >= 64: GEMM filter (fp16 split or Float32) + exact re-scan
+//   knn_wave_d3_kernel / knn_wave_generic_kernel: one wave per query, exact distances, every other supported shape
 #include <cmath>
 #include <cstdlib>
 
@@ -34,113 +32,6 @@ __device__ unsigned long long g_kprobe[4096 * 32];
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kChunk = 2048;  // candidates staged per LDS pass (D=3: 24 KiB)
-
-template <int KMAX>
-struct TopK {
-    float d[KMAX];
-    int j[KMAX];
-    __device__ __forceinline__ void init() {
-#pragma unroll
-        for (int p = 0; p < KMAX; ++p) { d[p] = INFINITY; j[p] = 0x7fffffff; }
-    }
-    // insert (dist, idx) keeping (d, j) sorted ascending; equal distances keep arrival order
-    // (candidates arrive in ascending index => ties resolve to the lower index first).
-    __device__ __forceinline__ void insert(float dist, int idx) {
-        if (dist < d[KMAX - 1]) {
-            bool lt[KMAX];
-#pragma unroll
-            for (int p = 0; p < KMAX; ++p) lt[p] = dist < d[p];
-#pragma unroll
-            for (int p = KMAX - 1; p > 0; --p) {
-                // lt[p-1] => shift slot p-1 up; else if lt[p] => land here
-                d[p] = lt[p - 1] ? d[p - 1] : (lt[p] ? dist : d[p]);
-                j[p] = lt[p - 1] ? j[p - 1] : (lt[p] ? idx : j[p]);
-            }
-            d[0] = lt[0] ? dist : d[0];
-            j[0] = lt[0] ? idx : j[0];
-        }
-    }
-};
-
-template <int KMAX>
-__global__ __launch_bounds__(kThreads) void knn_d3_kernel(const float *__restrict__ x, int N,
-                                                          const float *__restrict__ y, int M, int B,
-                                                          int k, int drop, int32_t *__restrict__ idx,
-                                                          float *__restrict__ dist) {
-    __shared__ __attribute__((aligned(16))) float lds[3 * kChunk];
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * kThreads + threadIdx.x;
-    const float *xb = x + (size_t)b * N * 3, *yb = y + (size_t)b * M * 3;
-    const int ic = i < N ? i : N - 1;
-    const float q0 = xb[3ll * ic], q1 = xb[3ll * ic + 1], q2 = xb[3ll * ic + 2];
-    TopK<KMAX> top;
-    top.init();
-    for (int j0 = 0; j0 < M; j0 += kChunk) {
-        const int cnt = (M - j0) < kChunk ? (M - j0) : kChunk;
-        if (j0 > 0) __syncthreads();
-        for (int e = threadIdx.x; e < cnt * 3; e += kThreads) {
-            const float v = yb[(size_t)j0 * 3 + e];
-            const int pt = e / 3, cc = e - pt * 3;
-            lds[cc * kChunk + pt] = v;
-        }
-        __syncthreads();
-        for (int jj = 0; jj < cnt; ++jj) {
-            const float t0 = q0 - lds[jj], t1 = q1 - lds[kChunk + jj], t2 = q2 - lds[2 * kChunk + jj];
-            const float dd = ((t0 * t0) + (t1 * t1)) + (t2 * t2);
-            top.insert(dd, j0 + jj);
-        }
-    }
-    if (i < N) {
-        int32_t *o = idx + ((size_t)b * N + i) * k;
-        float *od = dist ? dist + ((size_t)b * N + i) * k : nullptr;
-#pragma unroll
-        for (int p = 0; p < KMAX; ++p) {
-            const int r = p - drop;
-            if (r >= 0 && r < k) {
-                o[r] = top.j[p];
-                if (od) od[r] = top.d[p];
-            }
-        }
-    }
-}
-
-template <int KMAX>
-__global__ __launch_bounds__(kThreads) void knn_generic_kernel(const float *__restrict__ x, int N,
-                                                               const float *__restrict__ y, int M,
-                                                               int B, int D, int k, int drop,
-                                                               int32_t *__restrict__ idx,
-                                                               float *__restrict__ dist) {
-    extern __shared__ __attribute__((aligned(16))) float qs[];  // [D][kThreads]
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * kThreads + threadIdx.x;
-    const float *xb = x + (size_t)b * N * D, *yb = y + (size_t)b * M * D;
-    const int ic = i < N ? i : N - 1;
-    for (int d = 0; d < D; ++d) qs[d * kThreads + threadIdx.x] = xb[(size_t)ic * D + d];
-    TopK<KMAX> top;
-    top.init();
-    for (int j = 0; j < M; ++j) {
-        const float *c = yb + (size_t)j * D;  // wave-uniform address
-        float s = 0.0f;
-        for (int d = 0; d < D; ++d) {
-            const float t = qs[d * kThreads + threadIdx.x] - c[d];
-            s = s + t * t;
-        }
-        top.insert(s, j);
-    }
-    if (i < N) {
-        int32_t *o = idx + ((size_t)b * N + i) * k;
-        float *od = dist ? dist + ((size_t)b * N + i) * k : nullptr;
-#pragma unroll
-        for (int p = 0; p < KMAX; ++p) {
-            const int r = p - drop;
-            if (r >= 0 && r < k) {
-                o[r] = top.j[p];
-                if (od) od[r] = top.d[p];
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // knn_wave_d3_kernel: one WAVE per query (D = 3).  The 64 lanes split the candidates (16 per lane and
@@ -600,7 +491,7 @@ template <int DK>
 __device__ __forceinline__ void knn_stage_chunk(const float *__restrict__ yb, int D, int j0, int cn, int CH, float *img,
                                                 float *cnorm, unsigned int *cmax, bool want_cmax, bool do_norms,
                                                 bool vec4, int pw, int lane) {
-    constexpr int DP = DK * 32, PPR = DK * 8;
+    constexpr int PPR = DK * 8;
     const int RW = CH / kMWaves;          // rows per producer wave (CH is a multiple of 64)
     const int row_lo = pw * RW;
     const int rq = D / 4;
@@ -1959,31 +1850,27 @@ fx3d_status launch_knn_mfma(const float *x, int N, const float *y, int M, int B,
     }
 }
 
-template <int KMAX>
+size_t knn_wave_generic_lds(int D) {
+    return (size_t)kGT * (D + 1) * 4 + (kWThreads / 64) * (kGQ * (64 * 16 + 8) + D * 16) + 16;
+}
+bool knn_mfma_eligible(int M, int D, int kk) { return D >= 4 && D <= 128 && kk <= 32 && M >= 64; }
+
 fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int D, int k, int drop,
                        int32_t *idx, float *dist, hipStream_t st) {
-    dim3 grid((N + kThreads - 1) / kThreads, B);
     ProfileScope prof("knn", st);
-    static const bool legacy = [] { const char *e = getenv("FX3D_KNN_LEGACY"); return e && atoi(e); }();
-    if (D == 3 && !legacy && !getenv("FX3D_KNN_D3_WAVE") && k + drop <= 32 && M >= 64 && M < (1 << 21)) {
+    const int kk = k + drop;
+    if (D == 3 && !getenv("FX3D_KNN_D3_WAVE") && kk <= 32 && M >= 64 && M < (1 << 21))
         return launch_knn_f16_d3(x, N, y, M, B, k, drop, idx, dist, st);
-    } else if (D == 3 && !legacy) {
+    if (D == 3) {
         const int qpb = (kWThreads / 64) * kWQ;
         hipLaunchKernelGGL(knn_wave_d3_kernel, dim3((N + qpb - 1) / qpb, B), dim3(kWThreads), 0, st, x, N, y, M, B, k,
                            drop, idx, dist);
-    } else if (D == 3) {
-        hipLaunchKernelGGL(knn_d3_kernel<KMAX>, grid, dim3(kThreads), 0, st, x, N, y, M, B, k, drop, idx, dist);
-    } else if (!legacy && !getenv("FX3D_KNN_NO_MFMA") && D >= 4 && D <= 128 && k + drop <= 32 && M >= 64) {
+    } else if (!getenv("FX3D_KNN_NO_MFMA") && knn_mfma_eligible(M, D, kk)) {
         return launch_knn_mfma(x, N, y, M, B, D, k, drop, idx, dist, st);
-    } else if (!legacy && (size_t)kGT * (D + 1) * 4 + (kWThreads / 64) * (kGQ * (64 * 16 + 8) + D * 16) + 16 <= 64 * 1024) {
-        const size_t lds = (size_t)kGT * (D + 1) * 4 + (kWThreads / 64) * (kGQ * (64 * 16 + 8) + D * 16) + 16;
-        const int qpb = (kWThreads / 64) * kGQ;
-        hipLaunchKernelGGL(knn_wave_generic_kernel, dim3((N + qpb - 1) / qpb, B), dim3(kWThreads), lds, st, x, N, y, M,
-                           B, D, k, drop, idx, dist);
     } else {
-        const size_t lds = sizeof(float) * (size_t)D * kThreads;
-        hipLaunchKernelGGL(knn_generic_kernel<KMAX>, grid, dim3(kThreads), lds, st, x, N, y, M, B, D, k,
-                           drop, idx, dist);
+        const int qpb = (kWThreads / 64) * kGQ;
+        hipLaunchKernelGGL(knn_wave_generic_kernel, dim3((N + qpb - 1) / qpb, B), dim3(kWThreads), knn_wave_generic_lds(D),
+                           st, x, N, y, M, B, D, k, drop, idx, dist);
     }
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
@@ -2005,16 +1892,12 @@ fx3d_status fx3d_knn(const float *x, int32_t N, const float *y, int32_t M, int32
         set_error("fx3d_knn: k+drop_first=%d > 64 is not supported", kk);
         return FX3D_ERR_UNSUPPORTED;
     }
-    const bool mfma_ok = D >= 4 && D <= 128 && kk <= 32 && M >= 64;
-    if (D != 3 && !mfma_ok && (size_t)D * kThreads * sizeof(float) > 64 * 1024) {
-        set_error("fx3d_knn: D=%d is supported for D <= 64, or D <= 128 with k+drop_first <= 32 and M >= 64", D);
+    if (D != 3 && !knn_mfma_eligible(M, D, kk) && knn_wave_generic_lds(D) > 64 * 1024) {
+        set_error("fx3d_knn: D=%d is supported up to D = %d, or up to 128 with k+drop_first <= 32 and M >= 64", D,
+                  (int)((64 * 1024 - 16 - (kWThreads / 64) * kGQ * (64 * 16 + 8)) / (kGT * 4 + (kWThreads / 64) * 16)) - 1);
         return FX3D_ERR_UNSUPPORTED;
     }
-    hipStream_t st = as_stream(s);
-    if (kk <= 8) return launch_knn<8>(x, N, y, M, B, D, k, drop, idx, dist, st);
-    if (kk <= 16) return launch_knn<16>(x, N, y, M, B, D, k, drop, idx, dist, st);
-    if (kk <= 32) return launch_knn<32>(x, N, y, M, B, D, k, drop, idx, dist, st);
-    return launch_knn<64>(x, N, y, M, B, D, k, drop, idx, dist, st);
+    return launch_knn(x, N, y, M, B, D, k, drop, idx, dist, as_stream(s));
 }
 
 fx3d_status fx3d_knn_gather(const float *x, int32_t N, int32_t B, int32_t F, int32_t k,
