@@ -829,3 +829,36 @@ def test_voxel_and_edge_features_random(gpu_fx, oracle, seed):
         out, idx = gpu_fx.edgeconv_graph(x, K, layout=layout, return_idx=True)
         assert np.array_equal(idx.to_host(), oi)
         assert np.array_equal(out.to_host(), oracle.edge_features(x, oi, layout=lay))
+
+
+@pytest.mark.parametrize("D", [3, 64])
+def test_c4_full_size_knn_properties(gpu_fx, oracle, D):
+    """BASELINE config 4 at full size (k = 20 self-graph on B = 32 clouds of 1024 points; D = 3 and the second
+    EdgeConv's D = 64): oracle parity on a few batch elements, size-independent properties on all of them."""
+    fx = gpu_fx
+    if D == 3:
+        x = fx.synth.uniform_cloud(0x5EED0004, 3, 1024, 32)
+    else:
+        x = np.asfortranarray(np.random.default_rng(1).standard_normal((D, 1024, 32)).astype(np.float32))
+    idx, dist = fx.knn(x, 20, drop_first=True)
+    gi, gd = idx.to_host(), dist.to_host()
+    for b in (0, 17, 31):
+        oi, od = oracle.knn(x[:, :, b:b + 1], 20, drop_first=True)
+        assert np.array_equal(gi[:, :, b], oi[:, :, 0]) and np.array_equal(gd[:, :, b], od[:, :, 0])
+    assert (np.diff(gd, axis=0) >= 0).all()                       # ascending distances
+    assert (gi != np.arange(1024)[None, :, None]).all()           # self dropped
+    assert gi.min() >= 0 and gi.max() < 1024
+    srt = np.sort(gi, axis=0)
+    assert (np.diff(srt, axis=0) > 0).all()                       # no neighbour twice
+    # the recorded distance is the oracle-arithmetic distance of the recorded neighbour
+    b, n = 5, np.arange(0, 1024, 97)
+    for q in n:
+        c = x[:, gi[:, q, b], b]
+        d = np.zeros(20, np.float32)
+        for dd in range(D):
+            t = (x[dd, q, b] - c[dd]).astype(np.float32)
+            d = (d + t * t).astype(np.float32)
+        assert np.array_equal(d, gd[:, q, b])
+    # idempotence
+    idx2, dist2 = fx.knn(x, 20, drop_first=True)
+    assert np.array_equal(idx2.to_host(), gi) and np.array_equal(dist2.to_host(), gd)
