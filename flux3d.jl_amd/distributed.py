@@ -119,17 +119,28 @@ class NativeComm:
 
     def __init__(self, rank=0, world_size=1, exchange=None):
         ident = (C.c_uint8 * 128)()
+        err = None
         if rank == 0:
-            _lib.call("fx3d_comm_unique_id", ident)
+            try:
+                _lib.call("fx3d_comm_unique_id", ident)
+            except _lib.Flux3DHipError as e:  # keep going: the other ranks are waiting for the broadcast
+                err = e
         if world_size > 1:
             if exchange is None:
                 import torch
                 import torch.distributed as dist
-                t = torch.tensor(list(bytes(ident)), dtype=torch.uint8, device="cuda")
+                t = torch.tensor(list(bytes(ident)) + [0 if err is None else 1], dtype=torch.uint8, device="cuda")
                 dist.broadcast(t, src=0)
-                ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+                vals = t.cpu().tolist()
+                if vals[128]:
+                    raise err if err is not None else _lib.Flux3DHipError(-7, "rank 0 could not create the RCCL unique id")
+                ident = (C.c_uint8 * 128)(*vals[:128])
             else:
+                if err is not None:
+                    raise err
                 ident = (C.c_uint8 * 128)(*exchange(bytes(ident)))
+        elif err is not None:
+            raise err
         h = C.c_void_p()
         _lib.call("fx3d_comm_init_rank", C.byref(h), int(world_size), ident, int(rank))
         self.handle, self.rank, self.world_size = h.value, rank, world_size
