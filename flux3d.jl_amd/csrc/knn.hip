@@ -480,6 +480,21 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
 // (global_load_lds_dwordx4 writes lane-linear: wave-uniform base + lane*16), so staging costs one
 // instruction per KiB and no VGPR round trip -- the producers share their SIMD's issue slots with the
 // consumers' MFMAs, every VALU instruction they do not execute is matrix-core time.
+// knn_gather_kernel with 16-byte elements (F4 = F/4 float4 per row)
+__global__ __launch_bounds__(kThreads) void knn_gather4_kernel(const float *__restrict__ x, int N, int B, int F4, int k,
+                                                               const int32_t *__restrict__ idx, float *__restrict__ out) {
+    const long long total = (long long)B * N * k * F4;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    float4 *o4 = reinterpret_cast<float4 *>(out);
+    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total;
+         e += (long long)gridDim.x * kThreads) {
+        const long long row = e / F4;  // (b*N+i)*k + r
+        const int f = (int)(e - row * F4);
+        const int b = (int)(row / k / N);
+        o4[e] = x4[((size_t)b * N + idx[row]) * F4 + f];
+    }
+}
+
 template <int DK>
 __device__ __forceinline__ int knn_piece_off(int row, int c) {  // float offset of piece c of row `row`
     constexpr int PPR = DK * 8;
@@ -1749,6 +1764,40 @@ __global__ __launch_bounds__(kThreads) void edge_features_mlp_kernel(const float
     }
 }
 
+// Same, four consecutive (r,i) positions per thread: the 4 x 4 block (4 positions x 4 features) is read as
+// float4 along the features and written as float4 along the positions -- every store is 16 bytes, a wave writes
+// 1 KiB runs.  Needs F % 4 == 0, (k*N) % 4 == 0 and 16-byte aligned x / out.
+__global__ __launch_bounds__(kThreads) void edge_features_mlp4_kernel(const float *__restrict__ x, int N, int B,
+                                                                      int F, int k,
+                                                                      const int32_t *__restrict__ idx,
+                                                                      float *__restrict__ out) {
+    const int b = blockIdx.y;
+    const long long KN = (long long)k * N;
+    const long long e0 = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4;  // i*k + r of the first position
+    if (e0 >= KN) return;
+    const int4 jj = *reinterpret_cast<const int4 *>(idx + (size_t)b * KN + e0);
+    const float *xb = x + (size_t)b * N * F;
+    const float *xi0 = xb + (size_t)(e0 / k) * F, *xi1 = xb + (size_t)((e0 + 1) / k) * F;
+    const float *xi2 = xb + (size_t)((e0 + 2) / k) * F, *xi3 = xb + (size_t)((e0 + 3) / k) * F;
+    const float *xj0 = xb + (size_t)jj.x * F, *xj1 = xb + (size_t)jj.y * F, *xj2 = xb + (size_t)jj.z * F,
+                *xj3 = xb + (size_t)jj.w * F;
+    float *o = out + (size_t)b * 2 * F * KN + e0;
+    for (int f = 0; f < F; f += 4) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(xi0 + f), a1 = *reinterpret_cast<const float4 *>(xi1 + f);
+        const float4 a2 = *reinterpret_cast<const float4 *>(xi2 + f), a3 = *reinterpret_cast<const float4 *>(xi3 + f);
+        const float4 c0 = *reinterpret_cast<const float4 *>(xj0 + f), c1 = *reinterpret_cast<const float4 *>(xj1 + f);
+        const float4 c2 = *reinterpret_cast<const float4 *>(xj2 + f), c3 = *reinterpret_cast<const float4 *>(xj3 + f);
+        *reinterpret_cast<float4 *>(o + (size_t)(f + 0) * KN) = float4{a0.x, a1.x, a2.x, a3.x};
+        *reinterpret_cast<float4 *>(o + (size_t)(f + 1) * KN) = float4{a0.y, a1.y, a2.y, a3.y};
+        *reinterpret_cast<float4 *>(o + (size_t)(f + 2) * KN) = float4{a0.z, a1.z, a2.z, a3.z};
+        *reinterpret_cast<float4 *>(o + (size_t)(f + 3) * KN) = float4{a0.w, a1.w, a2.w, a3.w};
+        *reinterpret_cast<float4 *>(o + (size_t)(F + f + 0) * KN) = float4{c0.x - a0.x, c1.x - a1.x, c2.x - a2.x, c3.x - a3.x};
+        *reinterpret_cast<float4 *>(o + (size_t)(F + f + 1) * KN) = float4{c0.y - a0.y, c1.y - a1.y, c2.y - a2.y, c3.y - a3.y};
+        *reinterpret_cast<float4 *>(o + (size_t)(F + f + 2) * KN) = float4{c0.z - a0.z, c1.z - a1.z, c2.z - a2.z, c3.z - a3.z};
+        *reinterpret_cast<float4 *>(o + (size_t)(F + f + 3) * KN) = float4{c0.w - a0.w, c1.w - a1.w, c2.w - a2.w, c3.w - a3.w};
+    }
+}
+
 // Adjoint w.r.t. X.  CreateSingleKNNGraph is @nograd (src/models/dgcnn.jl:9), so the gathered neighbours are
 // constants and dX[f,i,b] = sum_r (g[f,r,i,b] - g[F+f,r,i,b]), accumulated in rank order.
 __global__ __launch_bounds__(kThreads) void edge_features_bwd_kernel(const float *__restrict__ g, int N, int B, int F,
@@ -1904,6 +1953,15 @@ fx3d_status fx3d_knn_gather(const float *x, int32_t N, int32_t B, int32_t F, int
                             const int32_t *idx, float *out, fx3d_stream_t s) {
     FX3D_REQUIRE(x && idx && out, "fx3d_knn_gather: null pointer");
     FX3D_REQUIRE(N > 0 && B > 0 && F > 0 && k > 0, "fx3d_knn_gather: bad sizes");
+    if (F % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {  // 16-byte copies
+        const long long total4 = (long long)B * N * k * (F / 4);
+        long long g4 = (total4 + kThreads - 1) / kThreads;
+        if (g4 > 16384) g4 = 16384;
+        ProfileScope prof4("knn_gather", as_stream(s));
+        hipLaunchKernelGGL(knn_gather4_kernel, dim3((unsigned)g4), dim3(kThreads), 0, as_stream(s), x, N, B, F / 4, k, idx, out);
+        FX3D_LAUNCH_CHECK();
+        return FX3D_OK;
+    }
     const long long total = (long long)B * N * k * F;
     long long g = (total + kThreads - 1) / kThreads;
     if (g > 8192) g = 8192;
@@ -1929,7 +1987,11 @@ fx3d_status fx3d_edge_features(const float *x, int32_t N, int32_t B, int32_t F, 
     } else {
         const long long KN = (long long)k * N;
         dim3 grid((unsigned)((KN + kThreads - 1) / kThreads), B);
-        if (F % 4 == 0 && ((uintptr_t)x & 15) == 0)
+        const bool al16 = (((uintptr_t)x | (uintptr_t)out | (uintptr_t)idx) & 15) == 0;
+        if (F % 4 == 0 && KN % 4 == 0 && al16 && !getenv("FX3D_EDGE_SCALAR_STORES"))
+            hipLaunchKernelGGL(edge_features_mlp4_kernel, dim3((unsigned)((KN / 4 + kThreads - 1) / kThreads), B), dim3(kThreads),
+                               0, as_stream(s), x, N, B, F, k, idx, out);
+        else if (F % 4 == 0 && ((uintptr_t)x & 15) == 0)
             hipLaunchKernelGGL(edge_features_mlp_kernel<true>, grid, dim3(kThreads), 0, as_stream(s), x, N, B, F, k, idx, out);
         else
             hipLaunchKernelGGL(edge_features_mlp_kernel<false>, grid, dim3(kThreads), 0, as_stream(s), x, N, B, F, k, idx, out);
