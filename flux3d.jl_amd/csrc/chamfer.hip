@@ -1576,10 +1576,9 @@ fx3d_status launch_small(const Nn1Params &p, const Plan &pl, hipStream_t st) {
     if (pl.variant == 3) {
         if (DIM == 3) {
             // > 64 KiB of dynamic LDS needs an explicit opt-in (static LDS of the kernel: < 1 KiB)
-            static const hipError_t attr_rc = hipFuncSetAttribute(
-                reinterpret_cast<const void *>(&nn1_f16_kernel<WANT_IDX>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHChunkMax * 32 + kHScratchBytes));
-            if (attr_rc != hipSuccess) return hip_fail(attr_rc, "hipFuncSetAttribute(nn1_f16_kernel)", __FILE__, __LINE__);
+            const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&nn1_f16_kernel<WANT_IDX>),
+                                                       (int)(kHChunkMax * 32 + kHScratchBytes), "nn1_f16_kernel");
+            if (arc != FX3D_OK) return arc;
             hipLaunchKernelGGL((nn1_f16_kernel<WANT_IDX>), dim3(pl.grid), dim3(kHThreads), pl.lds_bytes, st, p);
         }
         FX3D_LAUNCH_CHECK();
@@ -1899,9 +1898,9 @@ fx3d_status fx3d_chamfer_bwd(const float *x, int32_t N, const float *y, int32_t 
     while ((size_t)((maxr + nsplit - 1) / nsplit) * D * sizeof(float) > 144 * 1024) ++nsplit;  // ... nor more than fit in LDS
     const size_t lds = sizeof(float) * (size_t)((maxr + nsplit - 1) / nsplit) * D;
     if ((long long)2 * B * nsplit < (1ll << 30) && !no_lds) {
-        static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&chamfer_bwd_lds_kernel),
-                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-        if (attr_rc != hipSuccess) return hip_fail(attr_rc, "hipFuncSetAttribute(chamfer_bwd_lds_kernel)", __FILE__, __LINE__);
+        const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&chamfer_bwd_lds_kernel), 144 * 1024,
+                                                   "chamfer_bwd_lds_kernel");
+        if (arc != FX3D_OK) return arc;
         ProfileScope prof("chamfer_bwd", st);
         hipLaunchKernelGGL(chamfer_bwd_lds_kernel, dim3(2 * B * nsplit), dim3(kBwdThreads), lds, st, x, N, y, M, D, idx_x,
                            idx_y, ca, cb, gx, gy, nsplit);

@@ -38,6 +38,10 @@ inline fx3d_status hip_fail(hipError_t e, const char *what, const char *file, in
 
 inline hipStream_t as_stream(fx3d_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Opt a kernel in to more than 64 KiB of dynamic LDS, once per (kernel, device): the attribute is per device, and
+// a process may drive several (runtime.hip).
+fx3d_status ensure_dynamic_lds(const void *kernel, int bytes, const char *name);
+
 // ---- optional per-kernel event timing (runtime.hip) -------------------------------------------
 bool profile_on();
 void profile_mark(const char *name, hipStream_t st, bool begin);

@@ -1049,12 +1049,8 @@ fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int 
     if (img < keys) img = keys;
     const int raw_ok = M <= kTRawMax;
     const size_t lds = img + (size_t)kTWaves * kTCap * 64 * 4 + (raw_ok ? (size_t)M * 16 : 0);
-    static bool attr_done = false;
-    if (!attr_done) {
-        FX3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_f16_d3_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        attr_done = true;
-    }
+    const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_f16_d3_kernel), 156 * 1024, "knn_f16_d3_kernel");
+    if (arc != FX3D_OK) return arc;
     const int nbx = (N + kTWaves * 32 - 1) / (kTWaves * 32);
     const int bpad = B >= 8 ? (B + 7) / 8 * 8 : B;
     hipLaunchKernelGGL(knn_f16_d3_kernel, dim3(nbx * bpad), dim3(kTThreads), lds, st, x, N, y, M, B, k, drop, idx, dist,
@@ -1861,12 +1857,8 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     if (img < exact) img = exact;
     img = (img + 3) & ~(size_t)3;
     const size_t lds = img * 4 + fixed;
-    static bool attr_done = false;
-    if (!attr_done) {
-        FX3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<DK, F16>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        attr_done = true;
-    }
+    const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_mfma_kernel<DK, F16>), 152 * 1024, "knn_mfma_kernel");
+    if (arc != FX3D_OK) return arc;
     FX3D_REQUIRE(lds <= 152 * 1024, "fx3d_knn: internal LDS plan exceeds the CU (D=%d)", D);
     const int qpb = kMWaves * 32;
     const int nbx = (N + qpb - 1) / qpb;

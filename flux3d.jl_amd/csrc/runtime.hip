@@ -4,7 +4,9 @@
 #include <atomic>
 #include <cstring>
 #include <mutex>
+#include <set>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "fx3d_common.h"
@@ -235,3 +237,21 @@ fx3d_status fx3d_event_elapsed_ms(fx3d_event_t a, fx3d_event_t b, float *ms) {
 }
 
 }  // extern "C"
+
+namespace fx3d {
+fx3d_status ensure_dynamic_lds(const void *kernel, int bytes, const char *name) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    FX3D_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, dev})) return FX3D_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(%s, %d bytes of dynamic LDS) failed: %s", name, bytes, hipGetErrorString(e));
+        return FX3D_ERR_HIP;
+    }
+    done.insert({kernel, dev});
+    return FX3D_OK;
+}
+}  // namespace fx3d
