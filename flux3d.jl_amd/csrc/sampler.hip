@@ -23,6 +23,7 @@ extern "C" fx3d_status fx3d_faces_areas_padded(const float *, int32_t, const int
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kCdfThreads = 1024;  // one block per mesh: the area / division passes are the parallel part
 constexpr int kChunk = 32;  // FX_SCAN_CHUNK of the oracle
 
 // barycentric point, src/transforms/mesh_func.jl:67-71,:75-82
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(kThreads) void sample_explicit_kernel(
 // final offset add) runs on all 256 threads, the order-bound parts are 32- or nch-long add chains.
 // The face areas are computed in place (compute_faces_areas_padded, src/rep/mesh.jl:799-808: pad faces -> 0).
 template <bool IN_LDS>
-__global__ __launch_bounds__(kThreads) void face_cdf_kernel(const float *__restrict__ verts_padded, int Vmax,
+__global__ __launch_bounds__(kCdfThreads) void face_cdf_kernel(const float *__restrict__ verts_padded, int Vmax,
                                                             const int32_t *__restrict__ faces_padded,
                                                             const int32_t *__restrict__ faces_len, int Fmax,
                                                             int Fp, double eps,
@@ -71,13 +72,13 @@ __global__ __launch_bounds__(kThreads) void face_cdf_kernel(const float *__restr
     double *tc = IN_LDS ? dsm + Fp : out + Fp;
     __shared__ double sh[2];
 
-    for (int k = threadIdx.x; k < Fp; k += kThreads) {
+    for (int k = threadIdx.x; k < Fp; k += kCdfThreads) {
         float a = 0.0f;
         if (k < flen) a = tri_area(vb + 3ll * fb[3 * k], vb + 3ll * fb[3 * k + 1], vb + 3ll * fb[3 * k + 2]);
         cdf[k] = (double)a;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < nch; c += kThreads) {  // chunk totals of the areas
+    for (int c = threadIdx.x; c < nch; c += kCdfThreads) {  // chunk totals of the areas
         double t = 0.0;
 #pragma unroll 8
         for (int k = c * kChunk; k < (c + 1) * kChunk; ++k) t += cdf[k];
@@ -92,9 +93,9 @@ __global__ __launch_bounds__(kThreads) void face_cdf_kernel(const float *__restr
     }
     __syncthreads();
     const double den = sh[0];
-    for (int k = threadIdx.x; k < Fmax; k += kThreads) cdf[k] = cdf[k] / den;  // p, parallel
+    for (int k = threadIdx.x; k < Fmax; k += kCdfThreads) cdf[k] = cdf[k] / den;  // p, parallel
     __syncthreads();
-    for (int c = threadIdx.x; c < nch; c += kThreads) {  // chunk totals of p
+    for (int c = threadIdx.x; c < nch; c += kCdfThreads) {  // chunk totals of p
         double t = 0.0;
 #pragma unroll 8
         for (int k = c * kChunk; k < (c + 1) * kChunk; ++k) t += cdf[k];
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(kThreads) void face_cdf_kernel(const float *__restr
         cdf[Fmax - 1] += fix > 0.0 ? fix : 0.0;  // :36-37, lands on the last PADDED column
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < nch; c += kThreads) {  // local inclusive prefixes + chunk totals of p'
+    for (int c = threadIdx.x; c < nch; c += kCdfThreads) {  // local inclusive prefixes + chunk totals of p'
         double l = 0.0;
 #pragma unroll 8
         for (int k = c * kChunk; k < (c + 1) * kChunk; ++k) {
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(kThreads) void face_cdf_kernel(const float *__restr
         for (int c = 0; c < nch; ++c) { const double t = tc[c]; tc[c] = off; off += t; }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < Fmax; k += kThreads) out[k] = tc[k / kChunk] + cdf[k];
+    for (int k = threadIdx.x; k < Fmax; k += kCdfThreads) out[k] = tc[k / kChunk] + cdf[k];
 }
 
 __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
@@ -249,10 +250,10 @@ fx3d_status fx3d_sample_points(const float *verts_padded, int32_t Vmax, const in
     ProfileScope prof("sample", st);  // areas + cdf, draw: two kernels
     const size_t cdf_lds = sizeof(double) * (size_t)(Fp + Fp / kChunk);
     if (cdf_lds <= 60 * 1024)
-        hipLaunchKernelGGL(face_cdf_kernel<true>, dim3(B), dim3(kThreads), cdf_lds, st, verts_padded, Vmax, faces_padded,
+        hipLaunchKernelGGL(face_cdf_kernel<true>, dim3(B), dim3(kCdfThreads), cdf_lds, st, verts_padded, Vmax, faces_padded,
                            faces_len, Fmax, Fp, eps, cdf);
     else
-        hipLaunchKernelGGL(face_cdf_kernel<false>, dim3(B), dim3(kThreads), 0, st, verts_padded, Vmax, faces_padded,
+        hipLaunchKernelGGL(face_cdf_kernel<false>, dim3(B), dim3(kCdfThreads), 0, st, verts_padded, Vmax, faces_padded,
                            faces_len, Fmax, Fp, eps, cdf);
     FX3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(sample_seeded_kernel, dim3(grid_for((long long)B * n)), dim3(kThreads), 0, st,
