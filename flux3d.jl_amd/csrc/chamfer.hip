@@ -1541,7 +1541,7 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
             if (ch > cmax) continue;
             const int anch = (maxc + ch - 1) / ch;
             for (int split = 0; split < 2; ++split) {
-                if (split && (!allow_split || anch == 1)) continue;
+                if (split && (!allow_split || anch == 1 || getenv("FX3D_NN1_NOSPLIT"))) continue;
                 for (int tpb = 1; tpb <= 8; tpb *= 2) {
                     if (!split && anch > 1 && tpb > 1) continue;
                     if (tpb_env > 0 && tpb != tpb_env && (split || anch == 1)) continue;
