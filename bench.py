@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm", choices=["torch", "native"], default="native",
                     help="multi-GPU all-reduce through torch.distributed (RCCL) or the library's own RCCL communicator")
+    ap.add_argument("--allreduce-every", type=int, default=32,
+                    help="multi-GPU: evaluations per all-reduce (each step parks its 2 Float64 partial sums in a slot; "
+                         "one collective carries G slots and one kernel finalises G losses). 1 = a collective per step")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the multi-GPU code path (torch.distributed/RCCL all-reduce) even at world size 1")
     args = ap.parse_args()
@@ -77,7 +80,8 @@ def main():
         # ranks agree through an all-reduce) falls back to torch.distributed's all_reduce.
         from flux3d_jl_amd.distributed import NativeComm, NativeShardedChamfer
         try:
-            native = NativeShardedChamfer(NativeComm(rank, world))
+            native_comm = NativeComm(rank, world)
+            native = NativeShardedChamfer(native_comm)
             ok = 1
         except Exception as e:  # noqa: BLE001
             print(f"[bench] native RCCL communicator unavailable on rank {rank}: {e}", file=sys.stderr)
@@ -86,7 +90,32 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             native = None
-    if native is not None:
+    G = max(1, args.allreduce_every)
+    if use_dist and G > 1:
+        # deferred reduction: G evaluations per collective (every evaluation still gets its global loss)
+        from flux3d_jl_amd.distributed import DeferredShardedChamfer
+        if native is not None:
+            bench_stream = fx.Stream.create()
+            sharded = DeferredShardedChamfer(comm=native_comm, group=G)
+        else:
+            bench_stream = fx.Stream(torch.cuda.current_stream().cuda_stream)
+            sharded = DeferredShardedChamfer(comm=None, group=G)
+
+        def step():
+            with fx.stream(bench_stream):
+                sharded(x, y, Bg)
+
+        def sync_all():
+            with fx.stream(bench_stream):
+                sharded.flush()
+            bench_stream.synchronize()
+            dist.barrier()
+            bench_stream.synchronize()
+
+        def read_loss():
+            with fx.stream(bench_stream):
+                return float(sharded.losses.to_host()[max(sharded.last_count - 1, 0)])
+    elif native is not None:
         sharded = native
         bench_stream = fx.Stream.create()
 
@@ -187,7 +216,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"chamfer_distance fwd B={Bg} ({B_PER_GPU}/GPU) N=M={NPTS} D=3 Float32 U[0,1)^3 (BASELINE configs[1]; configs[4] shape at 8 GPUs)",
-                   "global_batch": Bg, "points": NPTS, "parallelism": f"batch-sharded x{world}, 1 all-reduce of 2 f64"
+                   "global_batch": Bg, "points": NPTS, "parallelism": f"batch-sharded x{world}, " + (f"1 all-reduce of {2 * G} f64 per {G} steps" if (use_dist and G > 1) else "1 all-reduce of 2 f64 per step")
                                   + ((" (fx3d_comm RCCL)" if native is not None else " (torch.distributed RCCL)") if use_dist else "")},
         "loss": loss,
         "roofline": {"bound": "mfma", "achieved": flops / kern_s / 1e12 if kern_s else None,

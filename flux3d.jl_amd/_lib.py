@@ -53,6 +53,7 @@ SIGNATURES = {
     "fx3d_chamfer_workspace_bytes": [c_i32, c_i32, c_i32, c_i32, C.POINTER(sz)],
     "fx3d_chamfer_sums": [vp, c_i32, vp, c_i32, c_i32, c_i32, vp, vp, vp, vp, sz, vp],
     "fx3d_chamfer_finalize": [vp, c_i32, c_i32, c_i64, c_i32, c_f32, c_f32, vp, vp],
+    "fx3d_chamfer_finalize_many": [vp, c_i32, c_i32, c_i32, c_i64, c_i32, c_f32, c_f32, vp, vp],
     "fx3d_chamfer_fwd": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_f32, c_f32, vp, C.POINTER(c_f32),
                          vp, vp, vp, sz, vp],
     "fx3d_chamfer_bwd": [vp, c_i32, vp, c_i32, c_i32, c_i32, vp, vp, c_f32, c_f32, c_f32, c_i64,

@@ -1427,6 +1427,12 @@ __global__ void chamfer_loss_kernel(const double *sums, int N, int M, int D, lon
         *loss = chamfer_loss_from_sums(sums[0], sums[1], N, M, D, Bg, w1, w2);
 }
 
+__global__ void chamfer_loss_many_kernel(const double *sums, int count, int N, int M, int D, long long Bg,
+                                         float w1, float w2, float *loss) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) loss[i] = chamfer_loss_from_sums(sums[2 * i], sums[2 * i + 1], N, M, D, Bg, w1, w2);
+}
+
 // Backward (adjoint of the two gathers at :47-48), two ordered passes:
 //   own pass     : gx[i] = ca (x_i - y[ix[i]]),  gy[j] = cb (y_j - x[iy[j]])        plain coalesced stores
 //   scatter pass : gy[ix[i]] -= ca (x_i - y[ix[i]]),  gx[iy[j]] -= cb (y_j - x[iy[j]])   float atomics
@@ -1812,6 +1818,16 @@ fx3d_status fx3d_chamfer_finalize(const double *sums_dev, int32_t N, int32_t M, 
     FX3D_REQUIRE(N > 0 && M > 0 && B_global > 0 && D > 0, "fx3d_chamfer_finalize: bad sizes");
     hipLaunchKernelGGL(chamfer_loss_kernel, dim3(1), dim3(64), 0, as_stream(s), sums_dev, N, M, D,
                        (long long)B_global, w1, w2, loss_dev);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_chamfer_finalize_many(const double *sums_dev, int32_t count, int32_t N, int32_t M, int64_t B_global,
+                                       int32_t D, float w1, float w2, float *losses_dev, fx3d_stream_t s) {
+    FX3D_REQUIRE(sums_dev && losses_dev, "fx3d_chamfer_finalize_many: null pointer");
+    FX3D_REQUIRE(count > 0 && N > 0 && M > 0 && B_global > 0 && D > 0, "fx3d_chamfer_finalize_many: bad sizes");
+    hipLaunchKernelGGL(chamfer_loss_many_kernel, dim3((count + 63) / 64), dim3(64), 0, as_stream(s), sums_dev, count, N, M,
+                       D, (long long)B_global, w1, w2, losses_dev);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }

@@ -342,4 +342,18 @@ function chamfer_distance_sharded(comm, A::HipArray{Float32,3}, B::HipArray{Floa
     return loss[]
 end
 
+# Deferred form for evaluation loops: `sums` (2,count) Float64 holds one slot per sharded batch
+# (fx3d_chamfer_sums writes a slot), one all-reduce carries them all, one kernel finalises `count` losses.
+function chamfer_finalize_many(comm, sums::HipArray{Float64,2}, N::Integer, M::Integer, B_global::Integer, D::Integer;
+                               w1::Number = 1.0, w2::Number = 1.0)
+    count = size(sums, 2)
+    check(@ccall LIB.fx3d_comm_allreduce_sum_f64(comm::Ptr{Cvoid}, sums.ptr::Ptr{Cvoid}, (2 * count)::Int64,
+                                                 DEFAULT_STREAM::Stream)::Int32)
+    losses = HipArray{Float32}(undef, count)
+    check(@ccall LIB.fx3d_chamfer_finalize_many(sums.ptr::Ptr{Cvoid}, count::Int32, N::Int32, M::Int32, B_global::Int64,
+                                                D::Int32, Float32(w1)::Float32, Float32(w2)::Float32,
+                                                losses.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    return losses
+end
+
 end # module

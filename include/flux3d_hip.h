@@ -112,6 +112,12 @@ FX3D_API fx3d_status fx3d_chamfer_sums(const float *x, int32_t N, const float *y
 FX3D_API fx3d_status fx3d_chamfer_finalize(const double *sums_dev, int32_t N, int32_t M,
                                            int64_t B_global, int32_t D, float w1, float w2,
                                            float *loss_dev, fx3d_stream_t s);
+/* The same for `count` evaluations at once: sums_dev (2,count), losses_dev (count).  An evaluation loop over
+ * many sharded batches (ModelNet-style eval, BASELINE config 5) keeps one sums slot per batch, all-reduces them
+ * with ONE collective per `count` batches and finalises them here. */
+FX3D_API fx3d_status fx3d_chamfer_finalize_many(const double *sums_dev, int32_t count, int32_t N, int32_t M,
+                                                int64_t B_global, int32_t D, float w1, float w2,
+                                                float *losses_dev, fx3d_stream_t s);
 
 /* _chamfer_distance(A,B,w1,w2) forward in one call (src/metrics/pcloud.jl:39-52). loss_dev
  * device float; loss_host optional host float (non-NULL => stream is synchronised). */

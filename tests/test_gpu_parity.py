@@ -872,3 +872,24 @@ def test_chamfer_split_plans(gpu_fx, oracle, N, M, B):
     x, y = _rand((3, N, B), N), _rand((3, M, B), M + 1)
     _check_nn(gpu_fx, oracle, x, y)           # fx3d_nn1: serial chunks
     _check_chamfer(gpu_fx, oracle, x, y)      # fx3d_chamfer_fwd: split run
+
+
+def test_deferred_sharded_chamfer_single_rank(gpu_fx, oracle):
+    """DeferredShardedChamfer (one collective per group of evaluations, RCCL behind the C ABI) at world size 1:
+    every evaluation's loss equals the direct call, across group boundaries and a shape change."""
+    fx = gpu_fx
+    from flux3d_jl_amd.distributed import DeferredShardedChamfer, NativeComm
+    comm = NativeComm(0, 1)
+    d = DeferredShardedChamfer(comm=comm, group=3)
+    clouds = [(_rand((3, 300 + 10 * i, 2), i), _rand((3, 200, 2), 50 + i)) for i in range(5)]
+    got = []
+    for i, (x, y) in enumerate(clouds):
+        d(fx.gpu(x), fx.gpu(y), 2, 0.5, 2.0)
+        if d.k == 0:  # a flush just happened (group full, or shape change flushed the previous ones first)
+            got.extend(d.losses.to_host()[: d.last_count].tolist())
+        elif i > 0 and clouds[i][0].shape != clouds[i - 1][0].shape and d.last_count and len(got) < i:
+            got.extend(d.losses.to_host()[: d.last_count].tolist())
+    if d.flush():
+        got.extend(d.losses.to_host()[: d.last_count].tolist())
+    exp = [float(fx.chamfer_distance(x, y, w1=0.5, w2=2.0)) for x, y in clouds]
+    assert len(got) == len(exp) and np.allclose(got, exp, rtol=1e-6, atol=0)
