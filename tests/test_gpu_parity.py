@@ -893,3 +893,21 @@ def test_deferred_sharded_chamfer_single_rank(gpu_fx, oracle):
         got.extend(d.losses.to_host()[: d.last_count].tolist())
     exp = [float(fx.chamfer_distance(x, y, w1=0.5, w2=2.0)) for x, y in clouds]
     assert len(got) == len(exp) and np.allclose(got, exp, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("D", [3, 64])
+def test_knn_outlier_dynamic_range(gpu_fx, oracle, D):
+    """One far outlier sets the fp16 filter's scale, so a tight cluster collapses below its resolution: the band
+    admits the whole cluster, the lists overflow and the exact fallback has to deliver the oracle's lists."""
+    rng = np.random.default_rng(D)
+    x = (rng.standard_normal((D, 300, 1)) * 1e-3).astype(np.float32)
+    x[:, 7, 0] = 1.0e6
+    x[:, 123, 0] = -3.0e5
+    x = np.asfortranarray(x)
+    idx, dist = gpu_fx.knn(x, 12, drop_first=True)
+    oi, od = oracle.knn(x, 12, drop_first=True)
+    assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+    # and the 1-NN / chamfer path on the same cloud against a shifted copy
+    if D == 3:
+        y = np.asfortranarray(x + np.float32(1e-4))
+        _check_nn(gpu_fx, oracle, x, y)
