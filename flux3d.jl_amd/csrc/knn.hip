@@ -580,12 +580,12 @@ __device__ __forceinline__ void knn_stage_chunk(const float *__restrict__ yb, in
 //            query's keys is its output slot.  Bit-identical to fx3d_oracle_knn.
 //   Queries outside the fp16 range, with overflowing lists or non-finite thresholds take the brute-force merge.
 typedef _Float16 kh8 __attribute__((ext_vector_type(8)));
-constexpr int kTWaves = 2;            // 64 queries per block: C4 gets 512 blocks, two per CU
+constexpr int kTWaves = 4;            // 128 queries per block: C4 gets 256 blocks, one per CU (2 waves: 56 -> 50 us)
 constexpr int kTThreads = kTWaves * 64;
 constexpr int kTCap = 48;             // rows of a lane's list (47 usable + the scratch head)
 constexpr int kTKeyCap = 64;          // keys per query (the two lanes' survivors + sentinels)
 constexpr int kTKeyStride = kTKeyCap + 4;  // row stride in words: 32 queries x b128 reads without bank conflicts
-constexpr int kTChunk = 4096;         // candidates per LDS image (32 B each)
+constexpr int kTChunk = 3328;         // candidates per LDS image (32 B each): image + lists <= 152 KiB
 constexpr int kTRawMax = 2048;        // clouds up to this size also keep their raw coordinates in LDS
 
 __device__ __forceinline__ float vmax_f32(float a, float b) {

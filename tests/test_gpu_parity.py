@@ -911,3 +911,14 @@ def test_knn_outlier_dynamic_range(gpu_fx, oracle, D):
     if D == 3:
         y = np.asfortranarray(x + np.float32(1e-4))
         _check_nn(gpu_fx, oracle, x, y)
+
+
+def test_knn_d3_multi_chunk(gpu_fx, oracle):
+    """More candidates than one LDS image (3328): phase A and phase B restage the chunks, the group minima and the
+    lane lists run across them."""
+    rng = np.random.default_rng(31)
+    x = np.asfortranarray(rng.random((3, 333, 2), dtype=np.float32))
+    y = np.asfortranarray(rng.random((3, 7777, 2), dtype=np.float32))
+    idx, dist = gpu_fx.knn(x, 20, y=y)
+    oi, od = oracle.knn(x, 20, y=y)
+    assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
