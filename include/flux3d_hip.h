@@ -138,7 +138,8 @@ FX3D_API fx3d_status fx3d_chamfer_bwd(const float *x, int32_t N, const float *y,
  * knn(KDTree(y), x, k+drop_first, true)[1][1+drop_first:end] for every point of every batch
  * element: idx:(k,N,B) int32 0-based sorted by (distance, index); dist:(k,N,B) squared distances
  * (optional).  y may equal x (self graph; drop_first=1 drops the rank-0 hit as the reference
- * does).  Supported: k+drop_first <= 64, any D >= 1. */
+ * does).  Supported: k+drop_first <= 64; D <= ~110 for any k, D <= 128 when k+drop_first <= 32 and M >= 64
+ * (the matrix-core kernels: D = 3 and 4 <= D <= 128); otherwise FX3D_ERR_UNSUPPORTED. */
 FX3D_API fx3d_status fx3d_knn(const float *x, int32_t N, const float *y, int32_t M, int32_t B,
                               int32_t D, int32_t k, int32_t drop_first, int32_t *idx,
                               float *dist, fx3d_stream_t s);
