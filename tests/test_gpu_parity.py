@@ -922,3 +922,37 @@ def test_knn_d3_multi_chunk(gpu_fx, oracle):
     idx, dist = gpu_fx.knn(x, 20, y=y)
     oi, od = oracle.knn(x, 20, y=y)
     assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+
+
+def test_interleaved_calls_share_state_correctly(gpu_fx, oracle):
+    """Many back-to-back calls of different ops and shapes on one stream: the caching allocator, the grow-only
+    workspaces, the library's ticket pool (fused finalisation) and the per-device attribute cache must never leak
+    state from one call into the next."""
+    fx = gpu_fx
+    rng = np.random.default_rng(2024)
+    pending = []
+    for it in range(60):
+        N, M, B = int(rng.integers(1, 1500)), int(rng.integers(1, 1500)), int(rng.integers(1, 4))
+        x = np.asfortranarray(rng.random((3, N, B), dtype=np.float32))
+        y = np.asfortranarray(rng.random((3, M, B), dtype=np.float32))
+        kind = it % 3
+        if kind == 0:
+            out = fx.DeviceArray.empty((1,), np.float32)
+            fx.chamfer_distance(fx.gpu(x), fx.gpu(y), loss_out=out, sync=False)   # not synchronised: stays in flight
+            pending.append(("ch", out, x, y, None))
+        elif kind == 1 and M >= 3:
+            k = int(rng.integers(1, min(20, M)))
+            idx = fx.knn(fx.gpu(x), k, y=fx.gpu(y), return_dist=False)
+            pending.append(("knn", idx, x, y, k))
+        else:
+            _, ix, iy = fx.chamfer_distance(x, y, return_indices=True)
+            pending.append(("nn", (ix, iy), x, y, None))
+    fx.synchronize()
+    for kind, res, x, y, k in pending:
+        if kind == "ch":
+            assert np.isclose(res.item(), oracle.chamfer_distance(x, y), rtol=LOSS_RTOL, atol=0)
+        elif kind == "knn":
+            assert np.array_equal(res.to_host(), oracle.knn(x, k, y=y, want_dist=False))
+        else:
+            ox, oy = oracle.nn1(x, y)
+            assert np.array_equal(res[0].to_host(), ox) and np.array_equal(res[1].to_host(), oy)
