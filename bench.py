@@ -242,6 +242,10 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(fx)
+    try:  # C stdio of the loaded libraries first (RCCL prints its NCCL_DEBUG=VERSION banner there): the JSON goes last
+        C.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
