@@ -25,8 +25,14 @@ __device__ unsigned long long g_kprobe[4096 * 32];
         const int pb__ = blockIdx.x + gridDim.x * blockIdx.y;                                          \
         if (threadIdx.x == 0 && pb__ < 4096) g_kprobe[pb__ * 32 + (k)] = __builtin_readcyclecounter(); \
     } while (0)
+#ifdef FX3D_PROBE_STATS  // (same-address atomics: distorts the timings)
+#define KNN_PROBE_STAT(i, v) atomicAdd(&g_kprobe[4095 * 32 + (i)], (unsigned long long)(v))
+#else
+#define KNN_PROBE_STAT(i, v) do { } while (0)
+#endif
 #else
 #define KNN_PROBE_MARK(k) do { } while (0)
+#define KNN_PROBE_STAT(i, v) do { } while (0)
 #endif
 
 namespace {
@@ -394,6 +400,19 @@ __device__ __forceinline__ float vmin_f32(float a, float b) {
     return r;
 }
 
+// The filter loops consume MFMA results with inline asm, which the compiler's hazard recogniser does not look
+// into (an 8-pass MFMA's result may be read 11 issue slots after its issue at the earliest).  mfma_settle()
+// marks the point where the listed accumulators have been issued and spends four slots; the consumers are
+// `asm volatile`, so they stay behind it and in program order, and each loop reads the accumulator issued last
+// only after sixteen other consumers.
+#define KNN_MFMA_SETTLE2(a, b) asm volatile("s_nop 3" : "+v"(a), "+v"(b))
+#define KNN_MFMA_SETTLE4(a, b, c, d) asm volatile("s_nop 3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+__device__ __forceinline__ float vmin_acc(float a, float b) {  // v_min_f32 on an MFMA result (ordered)
+    float r;
+    asm volatile("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // branch-free (distance, index) comparison, 0 / 1
 __device__ __forceinline__ int key_less_bf(float d, int j, float od, int oj) {
     return (int)(d < od) | ((int)(d == od) & (int)(j < oj));
@@ -566,26 +585,34 @@ __device__ __forceinline__ void knn_stage_chunk(const float *__restrict__ yb, in
 // ------------------------------------------------------------------------------------------------
 // knn_f16_d3_kernel: kNN for D = 3 (DGCNN's first EdgeConv, BASELINE config 4) with the chamfer kernel's
 // fp16-split filter (chamfer.hip, nn1_f16_kernel: t = |c~|^2 + qm~ . c~ on ONE v_mfma_f32_32x32x16_f16 per
-// 32 x 32 tile, |t - s^2 (d_oracle - |q'|^2)| <= delta~/2 with delta~ = 2^-19 (6 + 2S + S^2/8)).
-//   Lane l = (hh, jq) holds query jq of its wave and the 16 candidate rows (r&3)+8(r>>2)+4hh of every tile.
-//   Phase A: per lane and register the minimum over all tiles: 32 group minima per query (16 registers x
-//            2 half-waves), each over M/32 candidates.  The kk-th smallest of them bounds the kk-th smallest
-//            filter value: tau.  Selection = 16-element sorting network in registers + one exchange with the
-//            partner lane + bitonic merge: no LDS, all 32 queries of the wave at once.
-//   Phase B: the filter again; rows with t <= tau + delta~ are appended to the LANE's private LDS list
-//            (unconditional store at the list head, the head advances by the compare's carry bit: 5 VALU per
-//            row, no ballots, no atomics).  A superset of the k nearest, ~1.6 kk entries per query.
-//   Exact:   every lane evaluates the oracle's distance of its own entries (the query is in its registers)
-//            and writes keys (distance bits << 32 | index) into the query's list; a key's rank among the
-//            query's keys is its output slot.  Bit-identical to fx3d_oracle_knn.
+// 32 x 32 tile, |t - s^2 (d_oracle - |q'|^2)| <= 2^-20 (4 + 2S)).
+//   A block = 4 groups of 32 queries x 2 waves per group; the two waves of a group take alternate pairs of
+//   32-candidate tiles (two waves per SIMD hide each other's LDS latencies).  Lane l = (hh, jq) of a wave holds
+//   query jq of its group and the 16 candidate rows (r&3)+8(r>>2)+4hh of its tiles: four lanes per query.
+//   Phase A: per lane and register the minimum over its tiles (one v_min3 folds two tiles): 32 group minima per
+//            lane, 128 per query, each over M/128 candidates.  The kk-th smallest of them bounds the kk-th
+//            smallest filter value: tau.  Selection = 32-element sorting network in registers, the partner
+//            lane's values by v_permlane32_swap, the other wave's 32 smallest through LDS, two bitonic merges.
+//   Phase B: the filter again with the threshold folded into the MFMA (K slot 15: 1 x -thr16, thr16 the
+//            smallest fp16 above tau + delta~): the sign of the result is the test, one v_alignbit per row
+//            shifts it into the tile's 16-bit row mask; (tile, mask) words go to the LANE's private LDS list
+//            (unconditional store at the list head, the head advances when the mask is not empty).
+//            delta~ = 2^-19 (6 + 2.25 S + S^2/8): the filter's error in phase A + in phase B (17 terms) + the
+//            oracle's own rounding.  A superset of the k nearest, ~1.1 kk entries per query at config 4.
+//   Exact:   every lane decodes its list and evaluates the oracle's distance of its entries (the query is in its
+//            registers); the ranking of a query's keys is shared by its four lanes: rank = number of keys with
+//            a smaller distance = output slot, verified by count and rank sum, ties re-ranked on (distance,
+//            index).  Bit-identical to fx3d_oracle_knn.
 //   Queries outside the fp16 range, with overflowing lists or non-finite thresholds take the brute-force merge.
 typedef _Float16 kh8 __attribute__((ext_vector_type(8)));
-constexpr int kTWaves = 4;            // 128 queries per block: C4 gets 256 blocks, one per CU (2 waves: 56 -> 50 us)
+constexpr int kTGroups = 4;           // query groups (32 queries each) per block: C4 gets 256 blocks, one per CU
+constexpr int kTWaves = 2 * kTGroups; // two waves per group, each taking every other pair of candidate tiles:
+                                      // two waves per SIMD overlap each other's LDS / shuffle latencies
 constexpr int kTThreads = kTWaves * 64;
-constexpr int kTCap = 48;             // rows of a lane's list (47 usable + the scratch head)
+constexpr int kTCap = 24;             // rows of a lane's list (23 usable + the scratch head); a lane sees half the tiles
 constexpr int kTKeyCap = 64;          // keys per query (the two lanes' survivors + sentinels)
 constexpr int kTKeyStride = kTKeyCap + 4;  // row stride in words: 32 queries x b128 reads without bank conflicts
-constexpr int kTChunk = 3328;         // candidates per LDS image (32 B each): image + lists <= 152 KiB
+constexpr int kTChunk = 3072;         // candidates per LDS image (32 B each): image + lists + counters <= 152 KiB
 constexpr int kTRawMax = 2048;        // clouds up to this size also keep their raw coordinates in LDS
 
 __device__ __forceinline__ float vmax_f32(float a, float b) {
@@ -606,25 +633,27 @@ __device__ __forceinline__ void k3_make_pieces(float cx, float cy, float cz, kh8
     const float r1 = n - (float)n1;
     n2 = (_Float16)r1;
     n3 = (_Float16)(r1 - (float)n2);
-    const _Float16 z = (_Float16)0.0f;
     p0 = kh8{hx, hx, lx, hy, hy, ly, hz, hz};
-    p1 = kh8{lz, n1, n2, n3, lx, ly, lz, z};
+    p1 = kh8{lz, n1, n2, n3, lx, ly, lz, (_Float16)1.0f};  // slot 15: times the query's -threshold in phase B
 }
-// ascending bitonic sorting network on NV registers (compile-time indices only)
+// ascending sort of NV registers (compile-time indices only): Batcher's odd-even merge sort, 191 compare-exchanges
+// for 32 values (the bitonic network needs 240)
 template <int NV>
 __device__ __forceinline__ void k3_sort_regs(float (&v)[NV]) {
+    static_assert((NV & (NV - 1)) == 0, "power of two");
 #pragma unroll
-    for (int kb = 2; kb <= NV; kb <<= 1) {
+    for (int p = 1; p < NV; p <<= 1) {
 #pragma unroll
-        for (int j = kb >> 1; j > 0; j >>= 1) {
+        for (int k = p; k >= 1; k >>= 1) {
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const bool asc = (i & kb) == 0;
-                    const float lo = vmin_f32(v[i], v[l]), hi = vmax_f32(v[i], v[l]);
-                    v[i] = asc ? lo : hi;
-                    v[l] = asc ? hi : lo;
+            for (int j = k % p; j <= NV - 1 - k; j += 2 * k) {
+#pragma unroll
+                for (int i = 0; i < k; ++i) {
+                    if (i <= NV - j - k - 1 && (i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+                        const float lo = vmin_f32(v[i + j], v[i + j + k]), hi = vmax_f32(v[i + j], v[i + j + k]);
+                        v[i + j] = lo;
+                        v[i + j + k] = hi;
+                    }
                 }
             }
         }
@@ -639,11 +668,13 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     extern __shared__ __attribute__((aligned(16))) unsigned char k3sm[];
     __shared__ float red[2 * 4 * kTWaves];
     kh8 *imgp = reinterpret_cast<kh8 *>(k3sm);  // piece (blk, half, row) at (blk*2 + half)*32 + row
-    constexpr int kListBytes = kTWaves * kTCap * 64 * 4;
+    constexpr int kListBytes = kTWaves * kTCap * 64 * 4;      // lane lists; also the tau exchange and, later, the slots
+    constexpr int kCtrInts = kTGroups * 32 * 8;               // per query: 4 part counts, overflow, n, fast, below
     int *lists_all = reinterpret_cast<int *>(k3sm + img_bytes);                                  // [kTWaves][kTCap][64]
-    const float4 *rawc = reinterpret_cast<const float4 *>(k3sm + img_bytes + kListBytes);      // [M] when raw_ok
+    int *ctr = reinterpret_cast<int *>(k3sm + img_bytes + kListBytes);                           // [kTGroups*32][8]
+    const float4 *rawc = reinterpret_cast<const float4 *>(k3sm + img_bytes + kListBytes + kCtrInts * 4);  // [M] when raw_ok
 
-    const int nbx = (N + kTWaves * 32 - 1) / (kTWaves * 32);
+    const int nbx = (N + kTGroups * 32 - 1) / (kTGroups * 32);
     const int L = blockIdx.x;
     const bool by_xcd = B >= 8;
     const int b = by_xcd ? ((L >> 3) / nbx) * 8 + (L & 7) : L / nbx;
@@ -653,15 +684,20 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     const int jq = lane & 31, hh = lane >> 5;
     const int kk = k + drop;
     const float *xb = x + (size_t)b * N * 3, *yb = y + (size_t)b * M * 3;
-    const int q0 = (bxq * kTWaves + wv) * 32;
+    const int grp = wv % kTGroups, half = wv / kTGroups;  // query group; which pairs of tiles this wave takes
+    const int q0 = (bxq * kTGroups + grp) * 32;
     const bool wave_active = q0 < N;
+    for (int e = tid; e < kCtrInts; e += kTThreads) ctr[e] = 0;
+    const int qi = q0 + jq;  // this lane's query (loaded here: the latency hides behind the pass over the cloud)
+    const int qc = qi < N ? qi : N - 1;
+    const float qr[3] = {xb[(size_t)qc * 3], xb[(size_t)qc * 3 + 1], xb[(size_t)qc * 3 + 2]};
     KNN_PROBE_MARK(0);
 
     // ---- one pass over the cloud: bounding box (-> centre mu, power-of-two scale sc with |c~| <= 1) and, for
     //      clouds up to kTRawMax points, the raw coordinates parked in LDS for the staging and the exact phase ----
     float mu[3], cinf = 0.0f;
     {
-        float4 *raww = reinterpret_cast<float4 *>(k3sm + img_bytes + kListBytes);
+        float4 *raww = reinterpret_cast<float4 *>(k3sm + img_bytes + kListBytes + kCtrInts * 4);
         float mn3[3] = {INFINITY, INFINITY, INFINITY}, mx3[3] = {-INFINITY, -INFINITY, -INFINITY};
         const bool vec = (reinterpret_cast<uintptr_t>(yb) & 15) == 0;
         const int nv4 = vec ? M / 4 : 0;
@@ -721,13 +757,11 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     KNN_PROBE_MARK(1);
 
     // ---- this lane's query: B operand, band --------------------------------------------------------------------
-    const int qi = q0 + jq;
-    const int qc = qi < N ? qi : N - 1;
-    const float qr[3] = {xb[(size_t)qc * 3], xb[(size_t)qc * 3 + 1], xb[(size_t)qc * 3 + 2]};
     const float m0 = -2.0f * ((qr[0] - mu[0]) * sc), m1 = -2.0f * ((qr[1] - mu[1]) * sc), m2 = -2.0f * ((qr[2] - mu[2]) * sc);
     const float S = (fabsf(m0) + fabsf(m1)) + fabsf(m2);
     const bool qok = S < 3.0e4f;  // inside the fp16 range (also false for NaN)
-    const float delta = (6.0f + 2.0f * S + 0.125f * S * S) * 0x1p-19f;
+    // band: the filter's error twice (once with the threshold as a 17th term: + 2^-22 (3 + S)) + the oracle's rounding
+    const float delta = (6.0f + 2.25f * S + 0.125f * S * S) * 0x1p-19f;
     kh8 bq;
     {
         _Float16 hx, lx, hy, ly, hz, lz;
@@ -736,11 +770,11 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
         bq = hh == 0 ? kh8{hx, lx, hx, hy, ly, hy, hz, lz} : kh8{hz, one, one, one, lx, ly, lz, z};
     }
 
-    float mn[32];  // group minima: [r] even tiles, [16 + r] odd tiles -> 64 groups of M/64 candidates per query
+    float mn[32];  // group minima: [r] first / [16 + r] second tile of this wave's pairs -> 128 groups per query
 #pragma unroll
     for (int r = 0; r < 32; ++r) mn[r] = INFINITY;
     float thr = 0.0f;
-    int cnt = 0;
+    int cnt = 0, tot = 0;
     int *mylist = lists_all + wv * kTCap * 64 + lane;  // entry e at mylist[e * 64]
     f32x16v zero;
 #pragma unroll
@@ -791,26 +825,43 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                 const kh8 *pa = imgp + hh * 32 + jq;
                 const int npair = cn_pad / 64;
                 const int tile0 = j0 / 32;
-                for (int pr = 0; pr < npair; ++pr) {
-                    const f32x16v acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[(pr * 2) * 64], bq, zero, 0, 0, 0);
-                    const f32x16v acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[(pr * 2 + 1) * 64], bq, zero, 0, 0, 0);
-                    if (phase == 0) {
+                int pr = half;  // this wave's pairs of 32-candidate tiles: half, half + 2, ...
+                if (phase == 0) {
+                    for (; pr + 2 < npair; pr += 4) {  // two pairs per step: one v_min3 folds two tiles' rows
+                        f32x16v a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[(pr * 2) * 64], bq, zero, 0, 0, 0);
+                        f32x16v b0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[(pr * 2 + 4) * 64], bq, zero, 0, 0, 0);
+                        f32x16v a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[(pr * 2 + 1) * 64], bq, zero, 0, 0, 0);
+                        f32x16v b1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[(pr * 2 + 5) * 64], bq, zero, 0, 0, 0);
+                        KNN_MFMA_SETTLE4(a0, b0, a1, b1);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            mn[r] = vmin_f32(mn[r], acc0[r]);
-                            mn[16 + r] = vmin_f32(mn[16 + r], acc1[r]);
-                        }
+                        for (int r = 0; r < 16; ++r) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(mn[r]) : "v"(a0[r]), "v"(b0[r]));
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(mn[16 + r]) : "v"(a1[r]), "v"(b1[r]));
+                    }
+                }
+                for (; pr < npair; pr += 2) {
+                    f32x16v acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[(pr * 2) * 64], bq, zero, 0, 0, 0);
+                    f32x16v acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[(pr * 2 + 1) * 64], bq, zero, 0, 0, 0);
+                    if (phase == 0) {
+                        KNN_MFMA_SETTLE2(acc0, acc1);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mn[r] = vmin_acc(mn[r], acc0[r]);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mn[16 + r] = vmin_acc(mn[16 + r], acc1[r]);
                     } else {
 #pragma unroll
                         for (int tt = 0; tt < 2; ++tt) {
-                            // one word per tile: (tile index << 16) | mask of the rows with t <= thr; stored at the
-                            // list head unconditionally, the head advances when the mask is not empty
+                            // one word per tile: (tile index << 16) | mask of the rows with t - thr16 < 0 (row r at
+                            // bit 15 - r: one v_alignbit shifts the sign in); stored at the list head
+                            // unconditionally, the head advances when the mask is not empty
                             unsigned int m = 0;
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) m |= ((tt ? acc1[r] : acc0[r]) <= thr) ? (1u << r) : 0u;
+                            for (int r = 0; r < 16; ++r)
+                                m = __builtin_amdgcn_alignbit(m, __builtin_bit_cast(unsigned int, tt ? acc1[r] : acc0[r]), 31);
                             const int pp = cnt < kTCap - 1 ? cnt : kTCap - 1;
                             mylist[pp * 64] = (int)((unsigned int)(tile0 + pr * 2 + tt) << 16 | m);
                             cnt += m != 0 ? 1 : 0;
+                            tot += __builtin_popcount(m);
                         }
                     }
                 }
@@ -818,14 +869,20 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
         }
         KNN_PROBE_MARK(phase ? 5 : 3);
         if (phase == 0) {
-            // ---- tau: kk-th smallest of the 64 group minima of every query (32 in this lane, 32 in its partner) ----
+            // ---- tau: kk-th smallest of the 128 group minima of every query: 32 in this lane, 32 in its partner
+            //      lane, 64 in the other wave of the group.  Sorting network in registers, one exchange with the
+            //      partner lane, one exchange with the other wave through LDS, bitonic merges in between.
             k3_sort_regs<32>(mn);
-            float oth[32];
+            {
+                float oth[32];  // the partner lane's values (v_permlane32_swap: no LDS round trip)
 #pragma unroll
-            for (int r = 0; r < 32; ++r) oth[r] = __shfl_xor(mn[31 - r], 32, 64);
+                for (int r = 0; r < 32; ++r)  // mn[r] <- lanes 0-31's value, oth[r] <- lanes 32-63's, in every lane
+                    // (inline asm: this compiler's __builtin_amdgcn_permlane32_swap returns its first result twice)
+                    asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(mn[r]), "=&v"(oth[r]));
 #pragma unroll
-            for (int r = 0; r < 32; ++r)  // half 0 keeps the 32 smallest of the 64 (a bitonic sequence)
-                mn[r] = hh ? vmax_f32(mn[r], oth[r]) : vmin_f32(mn[r], oth[r]);
+                for (int r = 0; r < 32; ++r)  // the 32 smallest of the wave's 64 (a bitonic sequence), in both half-lanes
+                    mn[r] = vmin_f32(mn[r], oth[31 - r]);
+            }
 #pragma unroll
             for (int j = 16; j > 0; j >>= 1) {  // one bitonic merge sorts it ascending
 #pragma unroll
@@ -838,97 +895,132 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                     }
                 }
             }
-            float val = mn[0];
+            float *xch = reinterpret_cast<float *>(lists_all);  // [kTWaves][32][33]: the lists are not in use yet
+            if (hh == 0) {
 #pragma unroll
-            for (int r = 1; r < 32; ++r) val = (kk - 1) == r ? mn[r] : val;
-            const float tau = __shfl(val, jq, 64);  // kk <= 32: always among the 32 smallest (half 0)
+                for (int r = 0; r < 32; ++r) xch[(wv * 32 + jq) * 33 + r] = mn[r];
+            }
+            __syncthreads();
+            {
+                const float *po = xch + (((wv + kTGroups) % kTWaves) * 32 + jq) * 33;  // the group's other wave
+#pragma unroll
+                for (int r = 0; r < 32; ++r) mn[r] = vmin_f32(mn[r], po[31 - r]);     // the 32 smallest of the 128
+#pragma unroll
+                for (int j = 16; j > 0; j >>= 1) {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) {
+                        const int l = i ^ j;
+                        if (l > i) {
+                            const float lo = vmin_f32(mn[i], mn[l]), hi = vmax_f32(mn[i], mn[l]);
+                            mn[i] = lo;
+                            mn[l] = hi;
+                        }
+                    }
+                }
+            }
+            float tau = mn[0];  // kk <= 32: among the 32 smallest
+#pragma unroll
+            for (int r = 1; r < 32; ++r) tau = (kk - 1) == r ? mn[r] : tau;
             thr = tau + delta;
+            {
+                // phase B subtracts the threshold inside the MFMA (K slot 15: candidate side 1, query side -thr16)
+                // and keeps the sign: thr16 = the smallest fp16 value strictly above thr, so that t <= thr gives a
+                // negative difference (no -0) -- at most a few more survivors than the Float32 threshold
+                _Float16 h = (_Float16)thr;
+                unsigned short hb = __builtin_bit_cast(unsigned short, h);
+                if ((float)h <= thr) hb = (hb & 0x7fffu) == 0 ? 0x0001u : ((hb & 0x8000u) ? hb - 1 : hb + 1);
+                h = __builtin_bit_cast(_Float16, hb);
+                if (!((float)h < INFINITY)) thr = INFINITY;  // (also NaN) -> the query is not usable
+                if (hh == 1) bq[7] = -h;
+            }
+            __syncthreads();  // the exchange space becomes the lane lists
             KNN_PROBE_MARK(4);
         }
     }
 
-    // ---- exact phase ----------------------------------------------------------------------------------------------
+    // ---- exact phase: the four lanes of a query (two half-lanes x two waves) share its survivors ------------------
+    const int part = half * 2 + hh;
+    const int qslot = grp * 32 + jq;
+    int *qctr = ctr + qslot * 8;  // [0..3] entries decoded by part, [4] overflow, [5] below
+    const int need = kk < M ? kk : M;
+    const int nv = cnt < kTCap - 1 ? cnt : kTCap - 1;
+    qctr[part] = tot;
+    if (cnt > kTCap - 1) qctr[4] = 1;
     __syncthreads();  // every wave is done with the image: its space now holds the keys
     KNN_PROBE_MARK(6);
-    if (!wave_active) return;
-    unsigned int *qd = reinterpret_cast<unsigned int *>(k3sm) + (size_t)(wv * 32 + jq) * kTKeyStride;                    // distance bits
-    int *qj = reinterpret_cast<int *>(k3sm) + (size_t)kTWaves * 32 * kTKeyStride + (size_t)(wv * 32 + jq) * kTKeyStride;  // indices
-    const int nv = cnt < kTCap - 1 ? cnt : kTCap - 1;
-    int tot = 0;
-    for (int e = 0; e < nv; ++e) tot += __builtin_popcount((unsigned int)mylist[e * 64] & 0xffffu);
-    const int totp = __shfl_xor(tot, 32, 64);
-    const int cntp = __shfl_xor(cnt, 32, 64);
-    const int n = tot + totp, off = hh ? totp : 0;
+    unsigned int *qd = reinterpret_cast<unsigned int *>(k3sm) + (size_t)qslot * kTKeyStride;                          // distance bits
+    int *qj = reinterpret_cast<int *>(k3sm) + (size_t)kTGroups * 32 * kTKeyStride + (size_t)qslot * kTKeyStride;     // indices
+    const int c0 = qctr[0], c1 = qctr[1], c2 = qctr[2], c3 = qctr[3];
+    const int n = c0 + c1 + c2 + c3;
+    const int off = part == 0 ? 0 : (part == 1 ? c0 : (part == 2 ? c0 + c1 : c0 + c1 + c2));
     const bool usable = sane && qok && thr < INFINITY;
-    bool slowq = qi < N && (!usable || cnt > kTCap - 1 || cntp > kTCap - 1 || n > kTKeyCap - 4 || n < (kk < M ? kk : M));
-    if (qi < N && !slowq) {
+    const bool fast = wave_active && qi < N && usable && qctr[4] == 0 && n <= kTKeyCap - 4 && n >= need;
+    if (fast) {
         // (1) decode the (tile, mask) words into candidate ids: integer work only, no memory latency in the chain
         int pos = off;
-        for (int e = 0; e < nv; ++e) {
-            const unsigned int w = (unsigned int)mylist[e * 64];
-            unsigned int m = w & 0xffffu;
-            const int rowbase = (int)(w >> 16) * 32 + 4 * hh;
-            while (m) {
-                const int r = __builtin_ctz(m);
-                m &= m - 1;
-                qj[pos++] = rowbase + (r & 3) + 8 * (r >> 2);
+        for (int e0 = 0; e0 < nv; e0 += 4) {  // four list words in flight
+            unsigned int w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = (unsigned int)mylist[(e0 + u < kTCap ? e0 + u : kTCap - 1) * 64];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                unsigned int m = e0 + u < nv ? (w[u] & 0xffffu) : 0u;
+                const int rowbase = (int)(w[u] >> 16) * 32 + 4 * hh;
+                while (m) {
+                    const int r = 15 - __builtin_ctz(m);
+                    m &= m - 1;
+                    qj[pos++] = rowbase + (r & 3) + 8 * (r >> 2);
+                }
             }
         }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    // from here on the query's n survivors are split evenly between its two lanes (the lists are not)
-    const int h0 = (n + 1) >> 1;
-    const int mystart = hh ? h0 : 0, mycount = hh ? n - h0 : h0;
-    if (qi < N && !slowq) {
-        // (2) the oracle's distance of every id, four in flight
-        for (int p0 = mystart; p0 < mystart + mycount; p0 += 4) {
-            int id[4];
-            float c0[4], c1[4], c2[4];
+        // (2) the oracle's distance of the ids this lane just wrote (its own LDS writes: no barrier), eight in flight
+        for (int p0 = off; p0 < pos; p0 += 8) {
+            int id[8];
+            float c0f[8], c1f[8], c2f[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) id[u] = qj[p0 + u < mystart + mycount ? p0 + u : mystart];
+            for (int u = 0; u < 8; ++u) id[u] = qj[p0 + u < pos ? p0 + u : off];
             if (raw_ok) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const float4 rc = rawc[id[u]];
-                    c0[u] = rc.x; c1[u] = rc.y; c2[u] = rc.z;
+                    c0f[u] = rc.x; c1f[u] = rc.y; c2f[u] = rc.z;
                 }
             } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const float *c = yb + (size_t)id[u] * 3;
-                    c0[u] = c[0]; c1[u] = c[1]; c2[u] = c[2];
+                    c0f[u] = c[0]; c1f[u] = c[1]; c2f[u] = c[2];
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float t0 = qr[0] - c0[u], t1 = qr[1] - c1[u], t2 = qr[2] - c2[u];
+            for (int u = 0; u < 8; ++u) {
+                const float t0 = qr[0] - c0f[u], t1 = qr[1] - c1f[u], t2 = qr[2] - c2f[u];
                 float sd = t0 * t0;
                 sd = sd + t1 * t1;
                 sd = sd + t2 * t2;
-                if (p0 + u < mystart + mycount) qd[p0 + u] = __builtin_bit_cast(unsigned int, sd);
+                if (p0 + u < pos) qd[p0 + u] = __builtin_bit_cast(unsigned int, sd);
             }
         }
-        if (hh) {  // sentinels: the rank loop reads four distances at a time
+        if (part == 3) {  // sentinels: the rank loops read four keys at a time
             qd[n] = 0xffffffffu; qd[n + 1] = 0xffffffffu; qd[n + 2] = 0xffffffffu;
+            qj[n] = 0x7fffffff; qj[n + 1] = 0x7fffffff; qj[n + 2] = 0x7fffffff;
         }
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    KNN_PROBE_MARK(7);
+    __syncthreads();  // keys visible to the query's four lanes; the lane lists are dead: their space holds the slots
+    KNN_PROBE_MARK(8);
+    const int per = (n + 3) >> 2;  // the ranking is shared evenly
+    const int mystart = part * per < n ? part * per : n;
+    const int mycount = mystart + per <= n ? per : n - mystart;
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(lists_all) + (size_t)qslot * 33;  // [..][32 + 1 pad]
     // ---- order: rank of a survivor = number of survivors of its query with a smaller distance (squared distances
     //      are >= +0: unsigned order of the bits).  Ties in the distance are resolved by the index in the
     //      reference; they are rare, so the ranks are computed on the distances alone and VERIFIED: the ranks below
-    //      kk are a permutation of 0..kk-1 iff every slot is written and exactly min(kk, n) entries have rank < kk
-    //      (two tied entries share a rank: either a slot stays empty or, for a tie straddling the kk boundary,
-    //      the count is off).  A query that fails is ranked again on the full keys.  The lane lists are dead by
-    //      now: their space holds the slots.
-    unsigned long long *slots = reinterpret_cast<unsigned long long *>(lists_all + wv * kTCap * 64) + jq * 33;  // [32][32 + 1 pad]
-    for (int r = hh; r < kk; r += 2) slots[r] = ~0ull;
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    int below = 0;  // own entries with rank < kk
-    if (qi < N && !slowq) {
+    //      kk are a permutation of 0..kk-1 iff exactly kk entries have rank < kk and their ranks sum to
+    //      kk (kk - 1) / 2: an entry's rank is at most its position in the sorted order, strictly less for every
+    //      entry tied with an earlier one; a tie straddling the kk boundary makes the count kk + 1.  A query that
+    //      fails is ranked again on the full keys.
+    if (fast) {
+        int below = 0;  // own entries with rank < kk: count | sum of ranks << 8
         for (int e0 = 0; e0 < mycount; e0 += 8) {
             unsigned int md[8];
             int rank[8];
@@ -952,77 +1044,96 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
             for (int u = 0; u < 8; ++u)
                 if (e0 + u < mycount && rank[u] < kk) {
                     slots[rank[u]] = ((unsigned long long)md[u] << 32) | (unsigned int)qj[mystart + e0 + u];
-                    ++below;
+                    below += 1 + (rank[u] << 8);
                 }
+        }
+        if (below) atomicAdd(&qctr[5], below);
+    }
+    __syncthreads();
+    KNN_PROBE_MARK(9);
+    const bool bad = fast && qctr[5] != kk + ((kk * (kk - 1) / 2) << 8);  // (n >= kk here)
+    if (part == 0 && wave_active && qi < N) {
+        KNN_PROBE_STAT(0, 1);
+        KNN_PROBE_STAT(1, !fast);
+        KNN_PROBE_STAT(6, n);
+        KNN_PROBE_STAT(8, bad);
+    }
+    if (fast && !bad) {
+        // slots [drop, kk) are the answer, in order; the query's four lanes share the writes, 16 bytes at a time
+        const size_t obase = ((size_t)b * N + qi) * k;
+        if ((k & 3) == 0 && ((reinterpret_cast<uintptr_t>(idx) | (dist ? reinterpret_cast<uintptr_t>(dist) : 0)) & 15) == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int v = part + 4 * u;
+                if (4 * v < k) {
+                    unsigned long long key[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) key[e] = slots[drop + 4 * v + e];
+                    *reinterpret_cast<int4 *>(idx + obase + 4 * v) =
+                        int4{(int)(unsigned int)key[0], (int)(unsigned int)key[1], (int)(unsigned int)key[2], (int)(unsigned int)key[3]};
+                    if (dist)
+                        *reinterpret_cast<float4 *>(dist + obase + 4 * v) =
+                            float4{__builtin_bit_cast(float, (unsigned int)(key[0] >> 32)), __builtin_bit_cast(float, (unsigned int)(key[1] >> 32)),
+                                   __builtin_bit_cast(float, (unsigned int)(key[2] >> 32)), __builtin_bit_cast(float, (unsigned int)(key[3] >> 32))};
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = drop + part + 4 * u;
+                if (r < kk) {
+                    const unsigned long long key = slots[r];
+                    idx[obase + r - drop] = (int)(unsigned int)key;
+                    if (dist) dist[obase + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
+                }
+            }
+        }
+    }
+    KNN_PROBE_MARK(10);
+    if (half != 0 || !wave_active) return;  // the first wave of every group finishes its 32 queries: ties, leftovers
+    const bool slowq = qi < N && !fast;
+    if (__ballot(bad || slowq) == 0) return;
+    if (bad) {
+        // a tie in the distance among the first kk: rank this query again on the full (distance, index) keys
+        // (keys are unique, so the ranks are a permutation; no verification needed)
+        const int h0 = (n + 1) >> 1;
+        const int st = hh ? h0 : 0, ct = hh ? n - h0 : h0;
+        for (int e0 = 0; e0 < ct; e0 += 8) {
+            unsigned int md[8];
+            int mj[8], rank[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                md[u] = e0 + u < ct ? qd[st + e0 + u] : 0xffffffffu;
+                mj[u] = e0 + u < ct ? qj[st + e0 + u] : 0x7fffffff;
+                rank[u] = 0;
+            }
+            for (int i = 0; i < n; i += 4) {
+                const uint4 od = *reinterpret_cast<const uint4 *>(qd + i);
+                const int4 oj = *reinterpret_cast<const int4 *>(qj + i);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    rank[u] += (int)(od.x < md[u]) | ((int)(od.x == md[u]) & (int)(oj.x < mj[u]));
+                    rank[u] += (int)(od.y < md[u]) | ((int)(od.y == md[u]) & (int)(oj.y < mj[u]));
+                    rank[u] += (int)(od.z < md[u]) | ((int)(od.z == md[u]) & (int)(oj.z < mj[u]));
+                    rank[u] += (int)(od.w < md[u]) | ((int)(od.w == md[u]) & (int)(oj.w < mj[u]));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u < ct && rank[u] < kk) slots[rank[u]] = ((unsigned long long)md[u] << 32) | (unsigned int)mj[u];
         }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    {
-        bool bad = below + __shfl_xor(below, 32, 64) != (kk < n ? kk : n);
-        for (int r = hh; r < kk; r += 2) bad |= slots[r] == ~0ull;
-        bad |= __shfl_xor((int)bad, 32, 64) != 0;
-#ifdef FX3D_PROBE
-        if (qi < N && !slowq && hh == 0) {
-            const int tb = below + __shfl_xor(below, 32, 64);
-            if (tb != (kk < n ? kk : n)) atomicAdd(&g_kprobe[4095 * 32 + 7], 1ull);
-            if (bad) atomicAdd(&g_kprobe[4095 * 32 + 8], 1ull);
-        }
-#endif
-        if (qi < N && !slowq && bad) {
-            // a tie in the distance among the first kk: rank this query again on the full (distance, index) keys
-            // (keys are unique, so the ranks are a permutation; no verification needed)
-            if (hh) { qj[n] = 0x7fffffff; qj[n + 1] = 0x7fffffff; qj[n + 2] = 0x7fffffff; }  // index sentinels (partner lane writes)
-            for (int e0 = 0; e0 < mycount; e0 += 8) {
-                unsigned int md[8];
-                int mj[8], rank[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    md[u] = e0 + u < mycount ? qd[mystart + e0 + u] : 0xffffffffu;
-                    mj[u] = e0 + u < mycount ? qj[mystart + e0 + u] : 0x7fffffff;
-                    rank[u] = 0;
-                }
-                for (int i = 0; i < n; i += 4) {
-                    const uint4 od = *reinterpret_cast<const uint4 *>(qd + i);
-                    const int4 oj = *reinterpret_cast<const int4 *>(qj + i);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        rank[u] += (int)(od.x < md[u]) | ((int)(od.x == md[u]) & (int)(oj.x < mj[u]));
-                        rank[u] += (int)(od.y < md[u]) | ((int)(od.y == md[u]) & (int)(oj.y < mj[u]));
-                        rank[u] += (int)(od.z < md[u]) | ((int)(od.z == md[u]) & (int)(oj.z < mj[u]));
-                        rank[u] += (int)(od.w < md[u]) | ((int)(od.w == md[u]) & (int)(oj.w < mj[u]));
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (e0 + u < mycount && rank[u] < kk) slots[rank[u]] = ((unsigned long long)md[u] << 32) | (unsigned int)mj[u];
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        if (qi < N && !slowq) {
-            // slots [drop, kk) are the answer, in order; the two half-lanes share the writes
-            for (int r = drop + hh; r < kk; r += 2) {
-                const unsigned long long key = slots[r];
-                idx[((size_t)b * N + qi) * k + r - drop] = (int)(unsigned int)key;
-                if (dist) dist[((size_t)b * N + qi) * k + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
-            }
+    if (bad) {
+        for (int r = drop + hh; r < kk; r += 2) {
+            const unsigned long long key = slots[r];
+            idx[((size_t)b * N + qi) * k + r - drop] = (int)(unsigned int)key;
+            if (dist) dist[((size_t)b * N + qi) * k + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
         }
     }
-    KNN_PROBE_MARK(8);
-#ifdef FX3D_PROBE
-    if (qi < N && hh == 0) {
-        atomicAdd(&g_kprobe[4095 * 32 + 0], 1ull);
-        if (slowq) atomicAdd(&g_kprobe[4095 * 32 + 1], 1ull);
-        if (!usable) atomicAdd(&g_kprobe[4095 * 32 + 2], 1ull);
-        if (cnt > kTCap - 1 || cntp > kTCap - 1) atomicAdd(&g_kprobe[4095 * 32 + 3], 1ull);
-        if (n > kTKeyCap - 4) atomicAdd(&g_kprobe[4095 * 32 + 4], 1ull);
-        if (n < kk) atomicAdd(&g_kprobe[4095 * 32 + 5], 1ull);
-        atomicAdd(&g_kprobe[4095 * 32 + 6], (unsigned long long)n);
-    }
-#endif
-    // leftovers, wave-cooperative (scratch: behind this wave's slots)
-    int *wscratch = lists_all + wv * kTCap * 64 + 32 * 33 * 2;
+    // leftovers, wave-cooperative (scratch: behind the slots)
+    int *wscratch = lists_all + kTGroups * 32 * 33 * 2 + grp * 128;
     const unsigned long long slowmask = __ballot(slowq);
     const unsigned int slow32 = (unsigned int)slowmask | (unsigned int)(slowmask >> 32);
     for (int j = 0; j < 32; ++j) {
@@ -1037,7 +1148,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
             if (dist) dist[((size_t)b * N + q0 + j) * k + r] = bd;
         }
     }
-    KNN_PROBE_MARK(9);
+    KNN_PROBE_MARK(11);
 }
 
 fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int B, int k, int drop, int32_t *idx,
@@ -1045,13 +1156,16 @@ fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int 
     int CH = (M + 63) / 64 * 64;
     if (CH > kTChunk) CH = kTChunk;
     size_t img = (size_t)CH * 32;
-    const size_t keys = (size_t)kTWaves * 32 * kTKeyStride * 8;  // distance bits + indices
+    const size_t keys = (size_t)kTGroups * 32 * kTKeyStride * 8;  // distance bits + indices
     if (img < keys) img = keys;
-    const int raw_ok = M <= kTRawMax;
-    const size_t lds = img + (size_t)kTWaves * kTCap * 64 * 4 + (raw_ok ? (size_t)M * 16 : 0);
+    const size_t fixed = (size_t)kTWaves * kTCap * 64 * 4 + (size_t)kTGroups * 32 * 8 * 4;  // lists (exchange, slots) + counters
+    static_assert((size_t)kTWaves * 32 * 33 * 4 <= (size_t)kTWaves * kTCap * 64 * 4, "the tau exchange aliases the lists");
+    static_assert((size_t)kTGroups * 32 * 33 * 8 + kTGroups * 128 * 4 <= (size_t)kTWaves * kTCap * 64 * 4, "slots + scratch alias the lists");
+    const int raw_ok = M <= kTRawMax && img + fixed + (size_t)M * 16 <= 152 * 1024;
+    const size_t lds = img + fixed + (raw_ok ? (size_t)M * 16 : 0);
     const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_f16_d3_kernel), 156 * 1024, "knn_f16_d3_kernel");
     if (arc != FX3D_OK) return arc;
-    const int nbx = (N + kTWaves * 32 - 1) / (kTWaves * 32);
+    const int nbx = (N + kTGroups * 32 - 1) / (kTGroups * 32);
     const int bpad = B >= 8 ? (B + 7) / 8 * 8 : B;
     hipLaunchKernelGGL(knn_f16_d3_kernel, dim3(nbx * bpad), dim3(kTThreads), lds, st, x, N, y, M, B, k, drop, idx, dist,
                        CH, (int)img, raw_ok);
@@ -1405,11 +1519,11 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                         }
                     }
                     if (phase == 0) {
+                        KNN_MFMA_SETTLE2(acc0, acc1);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            mn[r] = vmin_f32(mn[r], acc0[r]);
-                            mn[16 + r] = vmin_f32(mn[16 + r], acc1[r]);
-                        }
+                        for (int r = 0; r < 16; ++r) mn[r] = vmin_acc(mn[r], acc0[r]);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mn[16 + r] = vmin_acc(mn[16 + r], acc1[r]);
                     } else {
 #pragma unroll
                         for (int tt = 0; tt < 2; ++tt) {

@@ -22,7 +22,9 @@ import flux3d_jl_amd as fx  # noqa: E402
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def gpu_time(fn, reps=30, warm=3):
+def gpu_time(fn, reps=30, warm=3, inner=8):
+    """Per-call device time: `inner` calls are enqueued between two events so that the host's launch path
+    (ctypes, allocation) overlaps the previous call's kernels instead of being timed as an idle device."""
     s = fx.Stream.create()
     with fx.stream(s):
         for _ in range(warm):
@@ -32,10 +34,11 @@ def gpu_time(fn, reps=30, warm=3):
         for _ in range(reps):
             e0, e1 = fx.Event(), fx.Event()
             e0.record()
-            fn()
+            for _ in range(inner):
+                fn()
             e1.record()
             e1.synchronize()
-            ts.append(e0.elapsed_ms(e1) * 1e3)
+            ts.append(e0.elapsed_ms(e1) * 1e3 / inner)
     return float(np.min(ts)), float(np.median(ts))
 
 
