@@ -924,6 +924,22 @@ def test_knn_d3_multi_chunk(gpu_fx, oracle):
     assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
 
 
+@pytest.mark.parametrize("M,k,drop", [(64, 32, False), (64, 31, True), (96, 5, False), (192, 17, True), (200, 32, False),
+                                      (1000, 1, False), (3072 + 64 * 3 + 5, 30, True), (6500, 8, False)])
+def test_knn_d3_wave_split_cases(gpu_fx, oracle, M, k, drop):
+    """The D = 3 kernel splits a query group's tiles over two waves and ranks with four lanes per query: odd and
+    single tile pairs (one wave has nothing to do), k + drop at the 32-value limit of the threshold selection,
+    k not a multiple of four (scalar output path), exact ties across the four lanes' shares."""
+    rng = np.random.default_rng(M * 37 + k)
+    x = np.asfortranarray(rng.random((3, 150, 3), dtype=np.float32))
+    y = np.asfortranarray(rng.random((3, M, 3), dtype=np.float32))
+    x[:, :40, :] = np.round(x[:, :40, :] * 4) / 4  # lattice queries against ...
+    y[:, : M // 2, :] = np.round(y[:, : M // 2, :] * 4) / 4  # ... lattice candidates: duplicates and exact distance ties
+    idx, dist = gpu_fx.knn(x, k, y=y, drop_first=drop)
+    oi, od = oracle.knn(x, k, y=y, drop_first=drop)
+    assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+
+
 def test_interleaved_calls_share_state_correctly(gpu_fx, oracle):
     """Many back-to-back calls of different ops and shapes on one stream: the caching allocator, the grow-only
     workspaces, the library's ticket pool (fused finalisation) and the per-device attribute cache must never leak
