@@ -582,6 +582,31 @@ __device__ __forceinline__ void knn_stage_chunk(const float *__restrict__ yb, in
     }
 }
 
+// Wave-cooperative ranking of ONE query's n survivors on the full (distance bits, index) keys -- the path of the
+// rare query whose distance-only ranks collide (an exact tie among its first kk).  Lane e ranks key e against all
+// n (LDS broadcast reads; qd / qj are padded with sentinels up to a multiple of four); keys are unique, so the
+// ranks below kk are a permutation and slots[0, kk) is the sorted answer.  One tied query costs its wave well
+// under a microsecond (a per-lane loop over the query's keys made the whole grid wait ~10 us for one wave).
+__device__ __forceinline__ void knn_rank_ties(const unsigned int *qd, const int *qj, int n, int kk,
+                                              unsigned long long *slots, int lane) {
+    for (int e = lane; e < n; e += 64) {
+        const unsigned int md = qd[e];
+        const int mj = qj[e];
+        int rank = 0;
+        for (int i = 0; i < n; i += 4) {
+            const uint4 od = *reinterpret_cast<const uint4 *>(qd + i);
+            const int4 oj = *reinterpret_cast<const int4 *>(qj + i);
+            rank += (int)(od.x < md) | ((int)(od.x == md) & (int)(oj.x < mj));
+            rank += (int)(od.y < md) | ((int)(od.y == md) & (int)(oj.y < mj));
+            rank += (int)(od.z < md) | ((int)(od.z == md) & (int)(oj.z < mj));
+            rank += (int)(od.w < md) | ((int)(od.w == md) & (int)(oj.w < mj));
+        }
+        if (rank < kk) slots[rank] = ((unsigned long long)md << 32) | (unsigned int)mj;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ------------------------------------------------------------------------------------------------
 // knn_f16_d3_kernel: kNN for D = 3 (DGCNN's first EdgeConv, BASELINE config 4) with the chamfer kernel's
 // fp16-split filter (chamfer.hip, nn1_f16_kernel: t = |c~|^2 + qm~ . c~ on ONE v_mfma_f32_32x32x16_f16 per
@@ -1092,49 +1117,25 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     KNN_PROBE_MARK(10);
     if (half != 0 || !wave_active) return;  // the first wave of every group finishes its 32 queries: ties, leftovers
     const bool slowq = qi < N && !fast;
-    if (__ballot(bad || slowq) == 0) return;
-    if (bad) {
-        // a tie in the distance among the first kk: rank this query again on the full (distance, index) keys
-        // (keys are unique, so the ranks are a permutation; no verification needed)
-        const int h0 = (n + 1) >> 1;
-        const int st = hh ? h0 : 0, ct = hh ? n - h0 : h0;
-        for (int e0 = 0; e0 < ct; e0 += 8) {
-            unsigned int md[8];
-            int mj[8], rank[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                md[u] = e0 + u < ct ? qd[st + e0 + u] : 0xffffffffu;
-                mj[u] = e0 + u < ct ? qj[st + e0 + u] : 0x7fffffff;
-                rank[u] = 0;
-            }
-            for (int i = 0; i < n; i += 4) {
-                const uint4 od = *reinterpret_cast<const uint4 *>(qd + i);
-                const int4 oj = *reinterpret_cast<const int4 *>(qj + i);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    rank[u] += (int)(od.x < md[u]) | ((int)(od.x == md[u]) & (int)(oj.x < mj[u]));
-                    rank[u] += (int)(od.y < md[u]) | ((int)(od.y == md[u]) & (int)(oj.y < mj[u]));
-                    rank[u] += (int)(od.z < md[u]) | ((int)(od.z == md[u]) & (int)(oj.z < mj[u]));
-                    rank[u] += (int)(od.w < md[u]) | ((int)(od.w == md[u]) & (int)(oj.w < mj[u]));
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (e0 + u < ct && rank[u] < kk) slots[rank[u]] = ((unsigned long long)md[u] << 32) | (unsigned int)mj[u];
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    if (bad) {
-        for (int r = drop + hh; r < kk; r += 2) {
-            const unsigned long long key = slots[r];
-            idx[((size_t)b * N + qi) * k + r - drop] = (int)(unsigned int)key;
-            if (dist) dist[((size_t)b * N + qi) * k + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
+    const unsigned long long badmask = __ballot(bad), slowmask = __ballot(slowq);
+    if ((badmask | slowmask) == 0) return;
+    for (unsigned int bm = (unsigned int)badmask | (unsigned int)(badmask >> 32); bm; bm &= bm - 1) {
+        // a tie in the distance among the first kk of query j: the whole wave ranks its keys again, on (distance, index)
+        const int j = __builtin_ctz(bm);
+        const int qs = grp * 32 + j;
+        const int *cj = ctr + qs * 8;
+        unsigned long long *sj = reinterpret_cast<unsigned long long *>(lists_all) + (size_t)qs * 33;
+        knn_rank_ties(reinterpret_cast<const unsigned int *>(k3sm) + (size_t)qs * kTKeyStride,
+                      reinterpret_cast<const int *>(k3sm) + (size_t)kTGroups * 32 * kTKeyStride + (size_t)qs * kTKeyStride,
+                      cj[0] + cj[1] + cj[2] + cj[3], kk, sj, lane);
+        for (int r = drop + lane; r < kk; r += 64) {
+            const unsigned long long key = sj[r];
+            idx[((size_t)b * N + q0 + j) * k + r - drop] = (int)(unsigned int)key;
+            if (dist) dist[((size_t)b * N + q0 + j) * k + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
         }
     }
     // leftovers, wave-cooperative (scratch: behind the slots)
     int *wscratch = lists_all + kTGroups * 32 * 33 * 2 + grp * 128;
-    const unsigned long long slowmask = __ballot(slowq);
     const unsigned int slow32 = (unsigned int)slowmask | (unsigned int)(slowmask >> 32);
     for (int j = 0; j < 32; ++j) {
         if (!((slow32 >> j) & 1u) || q0 + j >= N) continue;
@@ -1656,8 +1657,6 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     const int mycount = (mystart + per <= n ? per : n - mystart);
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(lists) + (size_t)(cw * 32 + jl) * 33;  // [..][32 + 1 pad]
     if (wave_active && fast) {
-        if (part == 0)
-            for (int r = 0; r < kk; ++r) slots[r] = ~0ull;
         // the oracle's distance of every id.  The query row sits in registers; candidate rows are gathered from L2
         // one full 128-byte line per request (32 dimensions), two candidates in flight
         const float *qrow = xb + (size_t)qi * D;
@@ -1741,7 +1740,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             for (int u = 0; u < 8; ++u)
                 if (e0 + u < mycount && rank[u] < kk) {
                     slots[rank[u]] = ((unsigned long long)md[u] << 32) | (unsigned int)qj[mystart + e0 + u];
-                    ++below;
+                    below += 1 + (rank[u] << 8);
                 }
         }
         if (below) atomicAdd(&qbelow[cw * 32 + jl], below);
@@ -1749,48 +1748,28 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     __syncthreads();
     KNN_PROBE_MARK(24);
     if (!consumer || !wave_active) return;
-    // (5) consumers: verify, re-rank tied queries on the full keys, write the answer
-    bool slowq = qi < N && !fast;
-    if (qi < N && fast) {
-        bool bad = qbelow[cw * 32 + jl] != (kk < n ? kk : n);
-        for (int r = h; r < kk; r += 2) bad |= slots[r] == ~0ull;
-        bad |= __shfl_xor((int)bad, 32, 64) != 0;
-        if (bad) {  // a tie in the distance among the first kk: the keys (distance, index) are unique
-            const int h0 = (n + 1) >> 1;
-            const int st = h ? h0 : 0, ct = h ? n - h0 : h0;
-            for (int e0 = 0; e0 < ct; e0 += 8) {
-                unsigned int md[8];
-                int mj[8], rank[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    md[u] = e0 + u < ct ? qd[st + e0 + u] : 0xffffffffu;
-                    mj[u] = e0 + u < ct ? qj[st + e0 + u] : 0x7fffffff;
-                    rank[u] = 0;
-                }
-                for (int i = 0; i < n; i += 4) {
-                    const uint4 od = *reinterpret_cast<const uint4 *>(qd + i);
-                    const int4 oj = *reinterpret_cast<const int4 *>(qj + i);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        rank[u] += (int)(od.x < md[u]) | ((int)(od.x == md[u]) & (int)(oj.x < mj[u]));
-                        rank[u] += (int)(od.y < md[u]) | ((int)(od.y == md[u]) & (int)(oj.y < mj[u]));
-                        rank[u] += (int)(od.z < md[u]) | ((int)(od.z == md[u]) & (int)(oj.z < mj[u]));
-                        rank[u] += (int)(od.w < md[u]) | ((int)(od.w == md[u]) & (int)(oj.w < mj[u]));
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (e0 + u < ct && rank[u] < kk) slots[rank[u]] = ((unsigned long long)md[u] << 32) | (unsigned int)mj[u];
-            }
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    if (qi < N && fast) {
+    // (5) consumers: verify (count and rank sum, see knn_f16_d3_kernel), write the answer, re-rank tied queries
+    const bool slowq = qi < N && !fast;
+    const bool bad = qi < N && fast && qbelow[cw * 32 + jl] != kk + ((kk * (kk - 1) / 2) << 8);  // (n >= kk here)
+    if (qi < N && fast && !bad) {
         for (int r = drop + h; r < kk; r += 2) {  // slots [drop, kk) are the answer, in order
             const unsigned long long key = slots[r];
             idx[((size_t)b * N + qi) * k + r - drop] = (int)(unsigned int)key;
             if (dist) dist[((size_t)b * N + qi) * k + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
+        }
+    }
+    const unsigned long long badmask = __ballot(bad);
+    for (unsigned int bm = (unsigned int)badmask | (unsigned int)(badmask >> 32); bm; bm &= bm - 1) {
+        const int j = __builtin_ctz(bm);  // a tie in the distance among the first kk of query j
+        const int qs = cw * 32 + j;
+        unsigned long long *sj = reinterpret_cast<unsigned long long *>(lists) + (size_t)qs * 33;
+        knn_rank_ties(reinterpret_cast<const unsigned int *>(sm) + (size_t)qs * kMKeyStride,
+                      reinterpret_cast<const int *>(sm) + (size_t)kMWaves * 32 * kMKeyStride + (size_t)qs * kMKeyStride, qn_n[qs], kk,
+                      sj, lane);
+        for (int r = drop + lane; r < kk; r += 64) {
+            const unsigned long long key = sj[r];
+            idx[((size_t)b * N + q0 + j) * k + r - drop] = (int)(unsigned int)key;
+            if (dist) dist[((size_t)b * N + q0 + j) * k + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
         }
     }
     // leftovers (overflowing lists, non-finite bands), wave-cooperative (scratch: behind all the slots)

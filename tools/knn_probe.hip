@@ -8,6 +8,11 @@
 #include <cstdio>
 #include <vector>
 
+__global__ __launch_bounds__(512) void probe_empty_kernel(int *p) {
+    extern __shared__ int sm[];
+    if (p && threadIdx.x == 9999) p[0] = sm[0];
+}
+
 int main(int argc, char **argv) {
     const int B = 32, N = 1024, D = argc > 1 ? atoi(argv[1]) : 64, K = 20;
     std::vector<float> hx((size_t)D * N * B);
@@ -26,6 +31,21 @@ int main(int argc, char **argv) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("avg per call %.2f us\n", ms * 100);
+    {
+        // isolated launches (a dependent pipeline sees these, not the back-to-back rate) + an empty kernel of the
+        // D = 3 kernel's geometry (256 x 512 threads, 136 KiB LDS) as the launch floor
+        float iso = 0, emp = 0, t;
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&probe_empty_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        for (int it = 0; it < 10; ++it) {
+            hipDeviceSynchronize();
+            hipEventRecord(e0); fx3d_knn(x, N, x, N, B, D, K, 1, idx, dst, nullptr); hipEventRecord(e1); hipEventSynchronize(e1);
+            hipEventElapsedTime(&t, e0, e1); iso += t;
+            hipDeviceSynchronize();
+            hipEventRecord(e0); hipLaunchKernelGGL(probe_empty_kernel, dim3(256), dim3(512), 136 * 1024, 0, nullptr); hipEventRecord(e1); hipEventSynchronize(e1);
+            hipEventElapsedTime(&t, e0, e1); emp += t;
+        }
+        printf("isolated launch: %.2f us; empty kernel of the same geometry: %.2f us\n", iso * 100, emp * 100);
+    }
     std::vector<unsigned long long> pr(4096 * 32);
     hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_kprobe), pr.size() * 8);
     const int nb = D == 3 ? 512 : 256;
@@ -38,10 +58,29 @@ int main(int argc, char **argv) {
     }
     for (int k = 1; k < 32; ++k) if (c[k]) printf("  mark %2d: avg +%9.1f ticks (n=%d)\n", k, d[k] / c[k], c[k]);
     unsigned long long tmin = ~0ull, tmax = 0;
-    for (int b = 0; b < nb; ++b) { tmin = std::min(tmin, pr[b * 32]); tmax = std::max(tmax, std::max(pr[b * 32 + 25], pr[b * 32 + 9])); }
+    double bsum = 0, bmax = 0, smax = 0;
+    int nbk = 0;
+    for (int b = 0; b < nb; ++b) {
+        const unsigned long long *q = &pr[b * 32];
+        if (!q[0]) continue;
+        unsigned long long last = 0;
+        for (int k = 1; k < 32; ++k) last = std::max(last, q[k]);
+        tmin = std::min(tmin, q[0]);
+        tmax = std::max(tmax, last);
+        bsum += (double)(last - q[0]);
+        bmax = std::max(bmax, (double)(last - q[0]));
+        ++nbk;
+    }
+    for (int b = 0; b < nb; ++b) if (pr[b * 32]) smax = std::max(smax, (double)(pr[b * 32] - tmin));
+    if (D == 3)
+        for (int b = 0; b < nb; ++b) {
+            const unsigned long long *q = &pr[b * 32];
+            if (q[11] > q[10]) printf("block %d: tail after the output stage (tie re-rank / leftovers) %llu ticks\n", b, q[11] - q[10]);
+        }
+    printf("blocks %d: thread-0 time avg %.0f max %.0f ticks; latest block start +%.0f; first start -> last end %.0f ticks\n", nbk,
+           bsum / std::max(nbk, 1), bmax, smax, (double)(tmax - tmin));
     printf("queries %llu slow %llu unusable %llu list-overflow %llu n>cap %llu n<kk %llu sum(n) %llu (x13 launches)\n", pr[4095 * 32], pr[4095 * 32 + 1],
            pr[4095 * 32 + 2], pr[4095 * 32 + 3], pr[4095 * 32 + 4], pr[4095 * 32 + 5], pr[4095 * 32 + 6]);
     printf("count-mismatch %llu bad %llu\n", pr[4095 * 32 + 7], pr[4095 * 32 + 8]);
-    printf("first start -> last end: %llu ticks\n", tmax - tmin);
     return 0;
 }
