@@ -28,17 +28,27 @@ def main():
     ap.add_argument("--iters", type=int, default=500)
     ap.add_argument("--target", default=os.path.join(ROOT, "tests", "golden", "teapot.obj"))
     ap.add_argument("--samples", type=int, default=5000)
+    ap.add_argument("--graph", action="store_true", help="capture one iteration as a hipGraph and replay it")
     args = ap.parse_args()
     src = fx.gpu(normalized(os.path.join(ROOT, "tests", "golden", "sphere.obj")))
     tgt = fx.gpu(normalized(args.target))
     x = fx.DeviceArray.zeros((3, src.get_verts_packed().shape[1]), np.float32)
     opt = fx.Momentum(1.0, 0.9)        # examples/fit_mesh.jl:87-88
     t0 = time.perf_counter()
-    for it in range(1, args.iters + 1):
-        loss, g = fx.loss_dolphin(x, src, tgt, args.samples, with_grad=True, sync=False)
-        opt.update(x, g)
-        if it % 50 == 1 or it == args.iters:  # the only host round trip of the loop
-            print(f"itr {it:5d}  loss {float(loss.item()):.6f}", flush=True)
+    if args.graph:
+        step = fx.FitStepGraph(x, src, tgt, opt, args.samples)  # runs iteration 1 eagerly, records iteration 2
+        for it in range(2, args.iters + 1):
+            loss = step.step()
+            if it % 50 == 1 or it == args.iters:
+                step.synchronize()
+                print(f"itr {it:5d}  loss {float(loss.item()):.6f}", flush=True)
+        step.synchronize()
+    else:
+        for it in range(1, args.iters + 1):
+            loss, g = fx.loss_dolphin(x, src, tgt, args.samples, with_grad=True, sync=False)
+            opt.update(x, g)
+            if it % 50 == 1 or it == args.iters:  # the only host round trip of the loop
+                print(f"itr {it:5d}  loss {float(loss.item()):.6f}", flush=True)
     fx.synchronize()
     dt = time.perf_counter() - t0
     print(f"{args.iters} iterations in {dt:.3f} s  ({dt / args.iters * 1e3:.3f} ms / iteration)")

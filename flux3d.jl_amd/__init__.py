@@ -13,7 +13,7 @@ from . import _lib
 _lib.load()  # fail loudly (ImportError) if the HIP library has not been built
 
 from ._lib import Flux3DHipError, LIB_PATH  # noqa: E402
-from .device import (DeviceArray, Event, Stream, cpu, current_stream, device_count,  # noqa: E402
+from .device import (DeviceArray, Event, Graph, Stream, cpu, current_stream, device_count,  # noqa: E402
                      device_name, empty_cache, functional, gpu, set_device, stream, synchronize)
 from .rep import (PointCloud, TriMesh, get_edges_packed, get_edges_to_key, get_faces_list,  # noqa: E402
                   get_faces_packed, get_faces_padded, get_faces_to_edges_packed,
@@ -23,7 +23,7 @@ from .metrics import (chamfer_distance, chamfer_distance_grad, edge_loss, edge_l
                       laplacian_loss, laplacian_loss_grad, nearest_neighbors)
 from .transforms import (EPS, compute_faces_areas_list, compute_faces_areas_packed,  # noqa: E402
                          compute_faces_areas_padded, lincomb, offset, sample_points, sample_points_grad)
-from .fit import Momentum, loss_dolphin  # noqa: E402
+from .fit import FitStepGraph, Momentum, loss_dolphin  # noqa: E402
 from .graph import (create_knn_graph, edge_features, edge_features_grad, edgeconv_graph, knn,  # noqa: E402
                     knn_gather)
 from .conversions import pointcloud_to_voxel  # noqa: E402

@@ -41,6 +41,11 @@ SIGNATURES = {
     "fx3d_stream_create": [C.POINTER(vp)],
     "fx3d_stream_destroy": [vp],
     "fx3d_stream_sync": [vp],
+    "fx3d_graph_begin_capture": [vp],
+    "fx3d_graph_end_capture": [vp, C.POINTER(vp)],
+    "fx3d_graph_launch": [vp, vp],
+    "fx3d_graph_destroy": [vp],
+    "fx3d_counter_add": [vp, c_u64, vp],
     "fx3d_event_create": [C.POINTER(vp)],
     "fx3d_event_destroy": [vp],
     "fx3d_event_record": [vp, vp],
@@ -69,17 +74,20 @@ SIGNATURES = {
     "fx3d_sample_points_workspace_bytes": [c_i32, c_i32, C.POINTER(sz)],
     "fx3d_sample_points": [vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_f64, c_u64, vp, vp, vp, vp,
                            vp, sz, vp],
-    "fx3d_sample_points_bwd": [vp, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp, vp],
+    "fx3d_sample_points_cdf": [vp, c_i32, vp, c_i32, vp, c_i32, c_f64, vp, sz, vp],
+    "fx3d_sample_points_draw": [vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_u64, vp, vp, sz, vp, vp, vp, vp, vp],
+    "fx3d_sample_points_bwd": [vp, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp, c_i32, vp],
     "fx3d_voxel_workspace_bytes": [c_i32, C.POINTER(sz)],
     "fx3d_pointcloud_to_voxel": [vp, c_i32, c_i32, c_i32, vp, vp, sz, vp],
     "fx3d_lincomb": [c_i64, c_f32, vp, c_f32, vp, c_f32, vp, vp, vp],
+    "fx3d_momentum_step": [c_i64, c_f32, c_f32, vp, vp, vp, vp],
     "fx3d_packed_to_padded": [vp, vp, c_i32, c_i32, vp, vp],
     "fx3d_padded_to_packed": [vp, vp, c_i32, c_i32, vp, vp],
     "fx3d_mesh_loss_workspace_bytes": [c_i64, C.POINTER(sz)],
     "fx3d_edge_loss": [vp, c_i64, vp, c_i64, c_f32, vp, C.POINTER(c_f32), vp, sz, vp],
-    "fx3d_edge_loss_bwd": [vp, c_i64, vp, c_i64, c_f32, c_f32, vp, vp],
+    "fx3d_edge_loss_bwd": [vp, c_i64, vp, c_i64, c_f32, c_f32, vp, c_i32, vp],
     "fx3d_laplacian_loss": [vp, c_i64, vp, vp, vp, vp, C.POINTER(c_f32), vp, sz, vp],
-    "fx3d_laplacian_loss_bwd": [vp, c_i64, vp, vp, vp, c_f32, vp, vp],
+    "fx3d_laplacian_loss_bwd": [vp, c_i64, vp, vp, vp, c_f32, vp, c_i32, vp],
     "fx3d_comm_unique_id": [vp],
     "fx3d_comm_init_rank": [C.POINTER(vp), c_i32, vp, c_i32],
     "fx3d_comm_destroy": [vp],

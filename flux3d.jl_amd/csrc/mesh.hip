@@ -158,6 +158,16 @@ __global__ __launch_bounds__(kThreads) void lincomb_kernel(long long n, float a,
     }
 }
 
+// Flux.Optimise.Momentum in one pass: v <- rho v - eta g ; x <- x + v  (the arithmetic of two fx3d_lincomb calls)
+__global__ __launch_bounds__(kThreads) void momentum_kernel(long long n, float rho, float eta, const float *__restrict__ g,
+                                                           float *__restrict__ v, float *__restrict__ x) {
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const float vn = (rho * v[i]) + (-eta * g[i]);
+        v[i] = vn;
+        x[i] = (1.0f * x[i]) + (1.0f * vn);
+    }
+}
+
 int grid_for(long long n) {
     long long g = (n + kThreads - 1) / kThreads;
     if (g < 1) g = 1;
@@ -205,6 +215,13 @@ fx3d_status fx3d_lincomb(int64_t n, float a, const float *x, float b, const floa
                          const float *z, float *out, fx3d_stream_t s) {
     FX3D_REQUIRE(x && y && out && n > 0, "fx3d_lincomb: bad argument");
     hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(n)), dim3(kThreads), 0, as_stream(s), (long long)n, a, x, b, y, c, z, out);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_momentum_step(int64_t n, float rho, float eta, const float *g, float *v, float *x, fx3d_stream_t s) {
+    FX3D_REQUIRE(g && v && x && n > 0, "fx3d_momentum_step: bad argument");
+    hipLaunchKernelGGL(momentum_kernel, dim3(grid_for(n)), dim3(kThreads), 0, as_stream(s), (long long)n, rho, eta, g, v, x);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }
@@ -270,11 +287,11 @@ fx3d_status fx3d_edge_loss(const float *verts, int64_t V, const int32_t *edges, 
 }
 
 fx3d_status fx3d_edge_loss_bwd(const float *verts, int64_t V, const int32_t *edges, int64_t E,
-                               float target, float gout, float *gverts, fx3d_stream_t s) {
+                               float target, float gout, float *gverts, int32_t accumulate, fx3d_stream_t s) {
     FX3D_REQUIRE(verts && edges && gverts, "fx3d_edge_loss_bwd: null pointer");
     FX3D_REQUIRE(V > 0 && E > 0, "fx3d_edge_loss_bwd: bad sizes");
     hipStream_t st = as_stream(s);
-    FX3D_HIP(hipMemsetAsync(gverts, 0, sizeof(float) * 3 * (size_t)V, st));
+    if (!accumulate) FX3D_HIP(hipMemsetAsync(gverts, 0, sizeof(float) * 3 * (size_t)V, st));
     hipLaunchKernelGGL(edge_loss_bwd_kernel, dim3(grid_for(E)), dim3(kThreads), 0, st, verts, edges,
                        edges + E, (long long)E, target, gout / (float)E, gverts);
     FX3D_LAUNCH_CHECK();
@@ -306,11 +323,11 @@ fx3d_status fx3d_laplacian_loss(const float *verts, int64_t V, const int32_t *ro
 
 fx3d_status fx3d_laplacian_loss_bwd(const float *verts, int64_t V, const int32_t *rowptr,
                                     const int32_t *colind, const float *vals, float gout,
-                                    float *gverts, fx3d_stream_t s) {
+                                    float *gverts, int32_t accumulate, fx3d_stream_t s) {
     FX3D_REQUIRE(verts && rowptr && colind && vals && gverts, "fx3d_laplacian_loss_bwd: null pointer");
     FX3D_REQUIRE(V > 0, "fx3d_laplacian_loss_bwd: bad V");
     hipStream_t st = as_stream(s);
-    FX3D_HIP(hipMemsetAsync(gverts, 0, sizeof(float) * 3 * (size_t)V, st));
+    if (!accumulate) FX3D_HIP(hipMemsetAsync(gverts, 0, sizeof(float) * 3 * (size_t)V, st));
     hipLaunchKernelGGL(laplacian_loss_bwd_kernel, dim3(grid_for(V)), dim3(kThreads), 0, st, verts,
                        (long long)V, rowptr, colind, vals, gout / (float)V, gverts);
     FX3D_LAUNCH_CHECK();

@@ -205,6 +205,52 @@ fx3d_status fx3d_stream_sync(fx3d_stream_t s) {
     return FX3D_OK;
 }
 
+// ---- stream capture: a launch-bound loop body (the fit_mesh iteration: ~30 small kernels, memsets and copies)
+//      is recorded once and replayed as one hipGraph launch ---------------------------------------------------------
+fx3d_status fx3d_graph_begin_capture(fx3d_stream_t s) {
+    FX3D_REQUIRE(s, "fx3d_graph_begin_capture: capture needs a created stream (not the default stream)");
+    FX3D_HIP(hipStreamBeginCapture(as_stream(s), hipStreamCaptureModeRelaxed));
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_graph_end_capture(fx3d_stream_t s, fx3d_graph_t *g) {
+    FX3D_REQUIRE(s && g, "fx3d_graph_end_capture: bad argument");
+    hipGraph_t graph = nullptr;
+    FX3D_HIP(hipStreamEndCapture(as_stream(s), &graph));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        set_error("fx3d_graph_end_capture: hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        return FX3D_ERR_HIP;
+    }
+    *g = exec;
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_graph_launch(fx3d_graph_t g, fx3d_stream_t s) {
+    FX3D_REQUIRE(g, "fx3d_graph_launch: null graph");
+    FX3D_HIP(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(g), as_stream(s)));
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_graph_destroy(fx3d_graph_t g) {
+    if (g) FX3D_HIP(hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(g)));
+    return FX3D_OK;
+}
+
+namespace {
+__global__ void counter_add_kernel(unsigned long long *ctr, unsigned long long inc) { *ctr += inc; }
+}  // namespace
+
+fx3d_status fx3d_counter_add(uint64_t *ctr, uint64_t inc, fx3d_stream_t s) {
+    FX3D_REQUIRE(ctr, "fx3d_counter_add: null pointer");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, as_stream(s), reinterpret_cast<unsigned long long *>(ctr),
+                       (unsigned long long)inc);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
 fx3d_status fx3d_event_create(fx3d_event_t *e) {
     FX3D_REQUIRE(e, "fx3d_event_create: null output");
     hipEvent_t ev;

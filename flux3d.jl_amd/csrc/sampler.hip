@@ -142,11 +142,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
 
 __global__ __launch_bounds__(kThreads) void sample_seeded_kernel(
     const float *__restrict__ verts_padded, int Vmax, const int32_t *__restrict__ faces_padded,
-    int Fmax, int Fp, const int32_t *__restrict__ faces_len, int B, int n, uint64_t seed,
-    const double *__restrict__ ws, float *__restrict__ out, int32_t *__restrict__ face_out,
-    float *__restrict__ r1_out, float *__restrict__ r2_out) {
+    int Fmax, int Fp, const int32_t *__restrict__ faces_len, int B, int n, uint64_t seed_host,
+    const uint64_t *__restrict__ seed_dev, const double *__restrict__ ws, float *__restrict__ out,
+    int32_t *__restrict__ face_out, float *__restrict__ r1_out, float *__restrict__ r2_out) {
     const long long total = (long long)B * n;
     const int nch = Fp / kChunk;
+    const uint64_t seed = seed_host + (seed_dev ? *seed_dev : 0);  // device part: advanced between replays of a graph
     for (long long k = (long long)blockIdx.x * kThreads + threadIdx.x; k < total;
          k += (long long)gridDim.x * kThreads) {
         const int b = (int)(k / n), sidx = (int)(k % n);
@@ -232,22 +233,20 @@ fx3d_status fx3d_sample_points_workspace_bytes(int32_t Fmax, int32_t B, size_t *
     return FX3D_OK;
 }
 
-fx3d_status fx3d_sample_points(const float *verts_padded, int32_t Vmax, const int32_t *faces_padded,
-                               int32_t Fmax, const int32_t *faces_len, int32_t B, int32_t n,
-                               double eps, uint64_t seed, float *out, int32_t *face_out,
-                               float *r1_out, float *r2_out, void *ws, size_t ws_bytes,
-                               fx3d_stream_t s) {
-    FX3D_REQUIRE(verts_padded && faces_padded && faces_len && out, "fx3d_sample_points: null pointer");
-    FX3D_REQUIRE(Vmax > 0 && Fmax > 0 && B > 0 && n > 0, "fx3d_sample_points: bad sizes");
+fx3d_status fx3d_sample_points_cdf(const float *verts_padded, int32_t Vmax, const int32_t *faces_padded,
+                                   int32_t Fmax, const int32_t *faces_len, int32_t B, double eps, void *ws,
+                                   size_t ws_bytes, fx3d_stream_t s) {
+    FX3D_REQUIRE(verts_padded && faces_padded && faces_len, "fx3d_sample_points_cdf: null pointer");
+    FX3D_REQUIRE(Vmax > 0 && Fmax > 0 && B > 0, "fx3d_sample_points_cdf: bad sizes");
     if (!ws || ws_bytes < ws_bytes_needed(Fmax, B)) {
-        set_error("fx3d_sample_points: workspace too small (%zu < %zu)", ws ? ws_bytes : (size_t)0,
+        set_error("fx3d_sample_points_cdf: workspace too small (%zu < %zu)", ws ? ws_bytes : (size_t)0,
                   ws_bytes_needed(Fmax, B));
         return FX3D_ERR_WORKSPACE;
     }
     hipStream_t st = as_stream(s);
     const int Fp = roundup32(Fmax);
     double *cdf = reinterpret_cast<double *>(ws);
-    ProfileScope prof("sample", st);  // areas + cdf, draw: two kernels
+    ProfileScope prof("sample_cdf", st);
     const size_t cdf_lds = sizeof(double) * (size_t)(Fp + Fp / kChunk);
     if (cdf_lds <= 60 * 1024)
         hipLaunchKernelGGL(face_cdf_kernel<true>, dim3(B), dim3(kCdfThreads), cdf_lds, st, verts_padded, Vmax, faces_padded,
@@ -256,21 +255,49 @@ fx3d_status fx3d_sample_points(const float *verts_padded, int32_t Vmax, const in
         hipLaunchKernelGGL(face_cdf_kernel<false>, dim3(B), dim3(kCdfThreads), 0, st, verts_padded, Vmax, faces_padded,
                            faces_len, Fmax, Fp, eps, cdf);
     FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_sample_points_draw(const float *verts_padded, int32_t Vmax, const int32_t *faces_padded,
+                                    int32_t Fmax, const int32_t *faces_len, int32_t B, int32_t n, uint64_t seed,
+                                    const uint64_t *seed_dev, const void *cdf_ws, size_t ws_bytes, float *out,
+                                    int32_t *face_out, float *r1_out, float *r2_out, fx3d_stream_t s) {
+    FX3D_REQUIRE(verts_padded && faces_padded && faces_len && out, "fx3d_sample_points_draw: null pointer");
+    FX3D_REQUIRE(Vmax > 0 && Fmax > 0 && B > 0 && n > 0, "fx3d_sample_points_draw: bad sizes");
+    if (!cdf_ws || ws_bytes < ws_bytes_needed(Fmax, B)) {
+        set_error("fx3d_sample_points_draw: CDF workspace too small (%zu < %zu)", cdf_ws ? ws_bytes : (size_t)0,
+                  ws_bytes_needed(Fmax, B));
+        return FX3D_ERR_WORKSPACE;
+    }
+    hipStream_t st = as_stream(s);
+    ProfileScope prof("sample_draw", st);
     hipLaunchKernelGGL(sample_seeded_kernel, dim3(grid_for((long long)B * n)), dim3(kThreads), 0, st,
-                       verts_padded, Vmax, faces_padded, Fmax, Fp, faces_len, B, n, seed, cdf, out,
-                       face_out, r1_out, r2_out);
+                       verts_padded, Vmax, faces_padded, Fmax, roundup32(Fmax), faces_len, B, n, seed, seed_dev,
+                       reinterpret_cast<const double *>(cdf_ws), out, face_out, r1_out, r2_out);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }
 
+fx3d_status fx3d_sample_points(const float *verts_padded, int32_t Vmax, const int32_t *faces_padded,
+                               int32_t Fmax, const int32_t *faces_len, int32_t B, int32_t n,
+                               double eps, uint64_t seed, float *out, int32_t *face_out,
+                               float *r1_out, float *r2_out, void *ws, size_t ws_bytes,
+                               fx3d_stream_t s) {
+    FX3D_REQUIRE(out && n > 0, "fx3d_sample_points: bad argument");
+    const fx3d_status rc = fx3d_sample_points_cdf(verts_padded, Vmax, faces_padded, Fmax, faces_len, B, eps, ws, ws_bytes, s);
+    if (rc != FX3D_OK) return rc;
+    return fx3d_sample_points_draw(verts_padded, Vmax, faces_padded, Fmax, faces_len, B, n, seed, nullptr, ws, ws_bytes, out,
+                                   face_out, r1_out, r2_out, s);
+}
+
 fx3d_status fx3d_sample_points_bwd(const int32_t *faces_padded, int32_t Vmax, int32_t Fmax, int32_t B,
                                    int32_t n, const int32_t *face_idx, const float *r1,
-                                   const float *r2, const float *gout, float *gverts,
+                                   const float *r2, const float *gout, float *gverts, int32_t accumulate,
                                    fx3d_stream_t s) {
     FX3D_REQUIRE(faces_padded && face_idx && r1 && r2 && gout && gverts, "fx3d_sample_points_bwd: null pointer");
     FX3D_REQUIRE(Vmax > 0 && Fmax > 0 && B > 0 && n > 0, "fx3d_sample_points_bwd: bad sizes");
     hipStream_t st = as_stream(s);
-    FX3D_HIP(hipMemsetAsync(gverts, 0, sizeof(float) * 3 * (size_t)Vmax * B, st));
+    if (!accumulate) FX3D_HIP(hipMemsetAsync(gverts, 0, sizeof(float) * 3 * (size_t)Vmax * B, st));
     hipLaunchKernelGGL(sample_bwd_kernel, dim3(grid_for((long long)B * n)), dim3(kThreads), 0, st,
                        faces_padded, Vmax, Fmax, B, n, face_idx, r1, r2, gout, gverts);
     FX3D_LAUNCH_CHECK();

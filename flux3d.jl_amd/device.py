@@ -162,15 +162,78 @@ class _Pool:
 
 
 _pools = {}
+_pool_override = []  # innermost private pool of an active Graph capture
 
 
 def _pool():
+    if _pool_override:
+        return _pool_override[-1]
     d = C.c_int32(0)
     _lib.load().fx3d_get_device(C.byref(d))
     pl = _pools.get(d.value)
     if pl is None:
         pl = _pools[d.value] = _Pool()
     return pl
+
+
+class Graph:
+    """A captured sequence of this package's device ops (hipGraph), replayed with one launch.
+
+        g = Graph()
+        with g.capture(stream):          # everything enqueued on `stream` inside the block is recorded, not run
+            step()
+        g.launch()                       # runs the recorded sequence on `stream`
+
+    Arrays allocated inside the block come from a pool private to the graph, so the addresses baked into the
+    recording are never handed to anybody else while the graph is alive.  Run the block once eagerly on the same
+    stream before capturing (grow-only workspaces, per-kernel attribute caches, optimiser state), and keep host
+    round trips (``sync=True`` paths, ``to_host``) out of it."""
+
+    def __init__(self):
+        self.handle = None
+        self.stream = None
+        self._pool = _Pool(limit_bytes=1 << 62)
+
+    def capture(self, s):
+        return _GraphCapture(self, s)
+
+    def launch(self, s=None):
+        _lib.call("fx3d_graph_launch", self.handle, (s or self.stream).handle)
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            try:
+                _lib.load().fx3d_graph_destroy(self.handle)
+                self._pool.empty()
+            except Exception:
+                pass
+            self.handle = None
+
+
+class _GraphCapture:
+    def __init__(self, g, s):
+        if s is None or not s.handle:
+            raise ValueError("Graph.capture needs a created stream (Stream.create()), not the default stream")
+        self.g, self.s = g, s
+
+    def __enter__(self):
+        _current.append(self.s)
+        _pool_override.append(self.g._pool)
+        _lib.call("fx3d_graph_begin_capture", self.s.handle)
+        return self.g
+
+    def __exit__(self, exc_type, exc, tb):
+        h = C.c_void_p()
+        try:
+            _lib.call("fx3d_graph_end_capture", self.s.handle, C.byref(h))
+            self.g.handle, self.g.stream = h.value, self.s
+        except Exception:
+            if exc_type is None:
+                raise
+        finally:
+            _pool_override.pop()
+            _current.pop()
+        return False
 
 
 def empty_cache():

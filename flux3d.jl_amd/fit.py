@@ -8,32 +8,39 @@ The reference differentiates it with Zygote; here the same chain is spelled out 
 kernels of the C ABI (chamfer_bwd -> sample_points_bwd -> padded->packed, laplacian/edge bwd)."""
 import numpy as np
 
-from .device import DeviceArray
+from . import _lib
+from .device import DeviceArray, Graph, Stream, current_stream, stream
 from .metrics import (_chamfer_points, chamfer_distance_grad, edge_loss, edge_loss_grad, laplacian_loss,
                       laplacian_loss_grad)
 from .transforms import lincomb, offset, sample_points, sample_points_grad
 
 
-def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_lap=0.1, w_edge=1.0, sync=True):
+def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_lap=0.1, w_edge=1.0, sync=True,
+                 seed_dev=None):
     """Returns the Float32 loss (and the gradient w.r.t. x, device (3,sumV), when with_grad).
     ``sync=False``: the loss stays a 1-element device array (the three terms are combined by fx3d_lincomb in
-    the reference's order) and the call enqueues without a single host round trip."""
+    the reference's order) and the call enqueues without a single host round trip.  ``seed_dev``: device uint64
+    added to both sampling seeds by the kernels (FitStepGraph advances it between replays)."""
     m = offset(src, x)
     s1 = None if seed is None else seed
     s2 = None if seed is None else seed + 1
-    A, fa, r1, r2 = sample_points(m, num_samples, seed=s1, return_draws=True)
-    Bp = sample_points(tgt, num_samples, seed=s2)
+    A, fa, r1, r2 = sample_points(m, num_samples, seed=s1, return_draws=True, seed_dev=seed_dev)
+    Bp = sample_points(tgt, num_samples, seed=s2, seed_dev=seed_dev)
     loss1, ix, iy = _chamfer_points(A, Bp, 1.0, 1.0, return_indices=True, sync=sync)
     loss2, loss3 = laplacian_loss(m, sync=sync), edge_loss(m, sync=sync)
     if sync:
         loss = np.float32(np.float32(loss1 + np.float32(w_lap) * loss2) + np.float32(w_edge) * loss3)
-    else:  # fl(fl(l1 + fl(w_lap*l2)) + fl(w_edge*l3)) on the device as well (unfused)
-        loss = lincomb(1.0, loss1, w_lap, loss2)
-        loss = lincomb(1.0, loss, w_edge, loss3)
+    else:  # fl(fl(l1 + fl(w_lap*l2)) + fl(w_edge*l3)) on the device as well (unfused), one launch
+        loss = lincomb(1.0, loss1, w_lap, loss2, w_edge, loss3)
     if not with_grad:
         return loss
     gA, _ = chamfer_distance_grad(A, Bp, ix, iy)
-    gpad = sample_points_grad(m, fa, r1, r2, gA)           # (3,Vmax,B)
+    gpad = sample_points_grad(m, fa, r1, r2, gA)           # (3,Vmax,B), zeroed + scatter-added
+    if m.N == 1:  # one mesh: padded == packed, the two mesh-loss adjoints add into the same buffer
+        g = gpad.reshape(3, m.V)
+        laplacian_loss_grad(m, w_lap, out=g)
+        edge_loss_grad(m, 0.0, w_edge, out=g)
+        return loss, g
     g1 = m.padded_to_packed_dev(gpad)                       # adjoint of _packed_to_padded
     g2 = laplacian_loss_grad(m, w_lap)
     g3 = edge_loss_grad(m, 0.0, w_edge)
@@ -49,6 +56,47 @@ class Momentum:
     def update(self, x, g):
         if self.v is None:
             self.v = DeviceArray.zeros(x.shape, np.float32)
-        lincomb(self.rho, self.v, -self.eta, g, out=self.v)
-        lincomb(1.0, x, 1.0, self.v, out=x)
+        _lib.call("fx3d_momentum_step", x.size, float(self.rho), float(self.eta), g.ptr, self.v.ptr, x.ptr,
+                  current_stream().handle)
         return x
+
+
+class FitStepGraph:
+    """One iteration of the fit_mesh loop (examples/fit_mesh.jl:98-110: loss, gradient, Momentum update) captured
+    as a hipGraph: ~30 launch-bound kernels, memsets and copies replayed with one launch per iteration.
+
+    The sampling seeds recorded in the graph are ``seed`` and ``seed + 1`` plus a device counter that the graph
+    itself advances by two per replay, so every iteration draws fresh samples (the reference draws from the global
+    RNG).  The constructor runs iteration 1 eagerly (``first_loss``) and records iteration 2; ``loss`` is the
+    1-element device array every replay writes -- read it whenever a host value is wanted
+    (``float(step.loss.item())`` after ``synchronize()``): the only host round trip."""
+
+    def __init__(self, x, src, tgt, opt, num_samples=5000, seed=0x5EED0C3, w_lap=0.1, w_edge=1.0):
+        self.x, self.opt = x, opt
+        self.stream = Stream.create()
+        self.counter = DeviceArray.zeros((1,), np.uint64)
+        self.iterations = 0
+
+        def body():
+            loss, g = loss_dolphin(x, src, tgt, num_samples, seed=seed, with_grad=True, w_lap=w_lap, w_edge=w_edge,
+                                   sync=False, seed_dev=self.counter)
+            opt.update(x, g)
+            _lib.call("fx3d_counter_add", self.counter.ptr, 2, current_stream().handle)
+            return loss
+
+        current_stream().synchronize()  # x / optimiser state may still be in flight on the caller's stream
+        with stream(self.stream):
+            self.first_loss = body()  # eager once on the capture stream: workspaces, caches, optimiser state
+            self.stream.synchronize()    # (a real step: iteration 1)
+        self.iterations = 1
+        self.graph = Graph()
+        with self.graph.capture(self.stream):
+            self.loss = body()
+
+    def step(self):
+        self.graph.launch(self.stream)
+        self.iterations += 1
+        return self.loss
+
+    def synchronize(self):
+        self.stream.synchronize()

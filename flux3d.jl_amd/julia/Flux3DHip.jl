@@ -286,7 +286,7 @@ Zygote.@adjoint function sample_points_with_draws(m, verts, n, eps, seed)
         gv = HipArray{Float32}(undef, 3, m.V, m.N)
         check(@ccall LIB.fx3d_sample_points_bwd(faces_padded_dev(m).ptr::Ptr{Cvoid}, m.V::Int32, m.F::Int32, m.N::Int32,
                                                 n::Int32, face.ptr::Ptr{Cvoid}, r1.ptr::Ptr{Cvoid}, r2.ptr::Ptr{Cvoid},
-                                                g[1].ptr::Ptr{Cvoid}, gv.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+                                                g[1].ptr::Ptr{Cvoid}, gv.ptr::Ptr{Cvoid}, 0::Int32, DEFAULT_STREAM::Stream)::Int32)
         return (nothing, gv, nothing, nothing, nothing)
     end
     return (out, (face, r1, r2)), back
@@ -298,7 +298,7 @@ function laplacian_loss_grad(m::TriMesh{Float32,R,HipArray}, verts::HipArray{Flo
     g = HipArray{Float32}(undef, size(verts)...)
     check(@ccall LIB.fx3d_laplacian_loss_bwd(verts.ptr::Ptr{Cvoid}, size(verts, 2)::Int64, rowptr.ptr::Ptr{Cvoid},
                                              colind.ptr::Ptr{Cvoid}, vals.ptr::Ptr{Cvoid}, Float32(gout)::Float32,
-                                             g.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+                                             g.ptr::Ptr{Cvoid}, 0::Int32, DEFAULT_STREAM::Stream)::Int32)
     return g
 end
 function edge_loss_grad(m::TriMesh{Float32,R,HipArray}, verts::HipArray{Float32,2}, target::Number = 0, gout::Number = 1) where {R}
@@ -306,7 +306,7 @@ function edge_loss_grad(m::TriMesh{Float32,R,HipArray}, verts::HipArray{Float32,
     g = HipArray{Float32}(undef, size(verts)...)
     check(@ccall LIB.fx3d_edge_loss_bwd(verts.ptr::Ptr{Cvoid}, size(verts, 2)::Int64, edges.ptr::Ptr{Cvoid},
                                         size(edges, 1)::Int64, Float32(target)::Float32, Float32(gout)::Float32,
-                                        g.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+                                        g.ptr::Ptr{Cvoid}, 0::Int32, DEFAULT_STREAM::Stream)::Int32)
     return g
 end
 

@@ -126,13 +126,13 @@ def laplacian_loss(m, sync=True):
     return np.float32(host.value) if sync else loss_dev
 
 
-def laplacian_loss_grad(m, gout=1.0):
-    """Adjoint of laplacian_loss w.r.t. the packed verts: device (3, sumV)."""
+def laplacian_loss_grad(m, gout=1.0, out=None):
+    """Adjoint of laplacian_loss w.r.t. the packed verts: device (3, sumV).  ``out``: add to this array instead."""
     verts = m.dev("verts_packed")
     V = verts.shape[1]
-    g = DeviceArray.empty((3, V), np.float32)
+    g = DeviceArray.empty((3, V), np.float32) if out is None else out
     _lib.call("fx3d_laplacian_loss_bwd", verts.ptr, V, m.dev("lap_rowptr").ptr,
-              m.dev("lap_colind").ptr, m.dev("lap_vals").ptr, float(gout), g.ptr,
+              m.dev("lap_colind").ptr, m.dev("lap_vals").ptr, float(gout), g.ptr, int(out is not None),
               current_stream().handle)
     return g
 
@@ -151,11 +151,12 @@ def edge_loss(m, target_length=0.0, sync=True):
     return np.float32(host.value) if sync else loss_dev
 
 
-def edge_loss_grad(m, target_length=0.0, gout=1.0):
+def edge_loss_grad(m, target_length=0.0, gout=1.0, out=None):
+    """Adjoint of edge_loss w.r.t. the packed verts: device (3, sumV).  ``out``: add to this array instead."""
     verts = m.dev("verts_packed")
     V = verts.shape[1]
     edges = m.dev("edges")
-    g = DeviceArray.empty((3, V), np.float32)
+    g = DeviceArray.empty((3, V), np.float32) if out is None else out
     _lib.call("fx3d_edge_loss_bwd", verts.ptr, V, edges.ptr, edges.shape[0], float(target_length),
-              float(gout), g.ptr, current_stream().handle)
+              float(gout), g.ptr, int(out is not None), current_stream().handle)
     return g

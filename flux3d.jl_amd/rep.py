@@ -226,7 +226,10 @@ class TriMesh:
         if not self._device:
             return self.get_verts_padded_host()
         if "verts_padded" not in self._dev:
-            self._dev["verts_padded"] = self._packed_to_padded_dev(self._dev["verts_packed"])
+            if self.N == 1:  # one mesh: (3,V) and (3,V,1) are the same bytes
+                self._dev["verts_padded"] = self._dev["verts_packed"].reshape(3, self.V, 1)
+            else:
+                self._dev["verts_padded"] = self._packed_to_padded_dev(self._dev["verts_packed"])
         return self._dev["verts_padded"]
 
     def _packed_to_padded_dev(self, packed):
@@ -238,6 +241,8 @@ class TriMesh:
 
     def padded_to_packed_dev(self, padded):
         """_padded_to_packed (src/rep/utils.jl:159-181) on the device: (3,Vmax,B) -> (3,sumV)."""
+        if self.N == 1:
+            return padded.reshape(3, self.V)
         out = DeviceArray.empty((3, int(self._verts_len.sum())), np.float32)
         _lib.call("fx3d_padded_to_packed", padded.ptr, self._verts_len.ctypes.data, self.N, self.V, out.ptr,
                   current_stream().handle)
@@ -262,8 +267,7 @@ class TriMesh:
         if is_device(new):
             assert new.shape == (3, int(self._verts_len.sum())) and new.dtype == np.float32
             self._device = True
-            self._dev["verts_packed"] = new
-            self._dev.pop("verts_padded", None)
+            self._dev = {"verts_packed": new}  # every vertex-derived mirror (padded form, sampling CDF) is stale
             self._verts_list_valid = False
             self._verts_packed_valid = False
             self._verts_padded_valid = False
@@ -275,8 +279,7 @@ class TriMesh:
             self._verts_packed, self._verts_packed_valid = new, True
             self._verts_padded_valid = False
             if self._device:
-                self._dev["verts_packed"] = DeviceArray.from_host(new)
-                self._dev.pop("verts_padded", None)
+                self._dev = {"verts_packed": DeviceArray.from_host(new)}
 
     # ---- faces (host, reference numbering) ------------------------------------------------------
     def get_faces_list(self):

@@ -44,15 +44,35 @@ def _verts_padded_dev(m):
     return m.get_verts_padded() if m.on_device else m.dev("verts_padded")
 
 
+def _face_cdf(m, verts, faces, eps):
+    """The mesh's sampling CDF (areas -> Float64 probabilities -> prefix sums, src/transforms/mesh_func.jl:27-39)
+    on the device.  It depends only on the vertices, so it is kept with the mesh's device vertex mirrors:
+    computed once for a mesh that is sampled again and again (the target of a fitting loop), dropped with them
+    when the vertices are replaced (set_verts_packed; offset / with_verts_packed start from empty mirrors)."""
+    key = ("face_cdf", float(eps))
+    ws = m._dev.get(key) if m.on_device else None
+    if ws is None:
+        nb = C.c_size_t(0)
+        _lib.call("fx3d_sample_points_workspace_bytes", m.F, m.N, C.byref(nb))
+        ws = DeviceArray.empty((nb.value,), np.uint8)
+        _lib.call("fx3d_sample_points_cdf", verts.ptr, m.V, faces.ptr, m.F, m.dev("faces_len").ptr, m.N, float(eps),
+                  ws.ptr, ws.nbytes, current_stream().handle)
+        if m.on_device:
+            m._dev[key] = ws
+    return ws
+
+
 def sample_points(m, num_samples=5000, eps=EPS, seed=None, return_draws=False,
-                  face_idx=None, r1=None, r2=None):
+                  face_idx=None, r1=None, r2=None, seed_dev=None):
     """sample_points(m::TriMesh, num_samples=5000; eps) (src/transforms/mesh_func.jl:21-58).
 
     Returns a device ``(3, num_samples, B)`` Float32 array (the mesh's storage type in the
     reference, ``::S{T,3}``).  Draws come from the device Philox stream keyed by ``seed`` (a fresh
     seed per call when None, like the reference's global RNG); or pass explicit ``face_idx`` (n,B)
     0-based mesh-local, ``r1``, ``r2`` (n,B) to reproduce `_sample_points` for given draws.
-    ``return_draws=True`` also returns (face_idx, r1, r2) device arrays for the adjoint."""
+    ``return_draws=True`` also returns (face_idx, r1, r2) device arrays for the adjoint.
+    ``seed_dev``: optional device uint64 added to ``seed`` by the kernel (a captured graph advances it between
+    replays, see fit.FitStepGraph)."""
     verts = _verts_padded_dev(m)
     faces = m.dev("faces_padded")
     n, B = int(num_samples), m.N
@@ -68,15 +88,13 @@ def sample_points(m, num_samples=5000, eps=EPS, seed=None, return_draws=False,
     if seed is None:
         _seed_counter[0] = (_seed_counter[0] * 6364136223846793005 + 1442695040888963407) % (1 << 64)
         seed = _seed_counter[0]
-    nb = C.c_size_t(0)
-    _lib.call("fx3d_sample_points_workspace_bytes", m.F, B, C.byref(nb))
-    ws = workspace(nb.value, "sampler")
+    ws = _face_cdf(m, verts, faces, eps)
     fo = DeviceArray.empty((n, B), np.int32) if return_draws else None
     a = DeviceArray.empty((n, B), np.float32) if return_draws else None
     b = DeviceArray.empty((n, B), np.float32) if return_draws else None
-    _lib.call("fx3d_sample_points", verts.ptr, m.V, faces.ptr, m.F, m.dev("faces_len").ptr, B, n,
-              float(eps), int(seed) & ((1 << 64) - 1), out.ptr, fo.ptr if fo else None,
-              a.ptr if a else None, b.ptr if b else None, ws.ptr, ws.nbytes, st)
+    _lib.call("fx3d_sample_points_draw", verts.ptr, m.V, faces.ptr, m.F, m.dev("faces_len").ptr, B, n,
+              int(seed) & ((1 << 64) - 1), seed_dev.ptr if seed_dev is not None else None, ws.ptr, ws.nbytes, out.ptr,
+              fo.ptr if fo else None, a.ptr if a else None, b.ptr if b else None, st)
     return (out, fo, a, b) if return_draws else out
 
 
@@ -86,7 +104,7 @@ def sample_points_grad(m, face_idx, r1, r2, gout):
     g = DeviceArray.empty((3, m.V, m.N), np.float32)
     gout = gout if isinstance(gout, DeviceArray) else DeviceArray.from_host(np.asarray(gout, np.float32))
     _lib.call("fx3d_sample_points_bwd", m.dev("faces_padded").ptr, m.V, m.F, B, n, face_idx.ptr,
-              r1.ptr, r2.ptr, gout.ptr, g.ptr, current_stream().handle)
+              r1.ptr, r2.ptr, gout.ptr, g.ptr, 0, current_stream().handle)
     return g
 
 

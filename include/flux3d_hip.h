@@ -68,6 +68,17 @@ FX3D_API fx3d_status fx3d_memset(void *dst_dev, int32_t byte, size_t bytes, fx3d
 FX3D_API fx3d_status fx3d_stream_create(fx3d_stream_t *s);
 FX3D_API fx3d_status fx3d_stream_destroy(fx3d_stream_t s);
 FX3D_API fx3d_status fx3d_stream_sync(fx3d_stream_t s);
+/* Stream capture (hipGraph): record everything enqueued on `s` between begin and end, replay it with one launch.
+ * No reference counterpart (the reference runs op by op through CUDA.jl); it serves the launch-bound fit_mesh
+ * iteration (examples/fit_mesh.jl:98-110).  Capture needs a created stream; the captured calls must not allocate
+ * through hipMalloc-synchronising paths or copy to the host (warm the loop up once before capturing). */
+typedef void *fx3d_graph_t; /* hipGraphExec_t */
+FX3D_API fx3d_status fx3d_graph_begin_capture(fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_graph_end_capture(fx3d_stream_t s, fx3d_graph_t *g);
+FX3D_API fx3d_status fx3d_graph_launch(fx3d_graph_t g, fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_graph_destroy(fx3d_graph_t g);
+/* *ctr += inc on the device, stream ordered: the per-replay part of a sampling seed (fx3d_sample_points_draw). */
+FX3D_API fx3d_status fx3d_counter_add(uint64_t *ctr, uint64_t inc, fx3d_stream_t s);
 FX3D_API fx3d_status fx3d_event_create(fx3d_event_t *e);
 FX3D_API fx3d_status fx3d_event_destroy(fx3d_event_t e);
 FX3D_API fx3d_status fx3d_event_record(fx3d_event_t e, fx3d_stream_t s);
@@ -199,19 +210,40 @@ FX3D_API fx3d_status fx3d_sample_points(const float *verts_padded, int32_t Vmax,
                                         float *r1_out, float *r2_out, void *ws, size_t ws_bytes,
                                         fx3d_stream_t s);
 
+/* The two halves of fx3d_sample_points.  The CDF (areas -> Float64 probabilities -> prefix sums, :27-39) depends
+ * only on the mesh: a caller keeps it while the vertices do not change (the target mesh of a fitting loop).  The
+ * draw (:41-58) uses seed + *seed_dev (seed_dev optional, device memory): a captured graph replays with fresh
+ * samples when fx3d_counter_add advances the device part. */
+FX3D_API fx3d_status fx3d_sample_points_cdf(const float *verts_padded, int32_t Vmax,
+                                            const int32_t *faces_padded, int32_t Fmax,
+                                            const int32_t *faces_len, int32_t B, double eps, void *ws,
+                                            size_t ws_bytes, fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_sample_points_draw(const float *verts_padded, int32_t Vmax,
+                                             const int32_t *faces_padded, int32_t Fmax,
+                                             const int32_t *faces_len, int32_t B, int32_t n, uint64_t seed,
+                                             const uint64_t *seed_dev, const void *cdf_ws, size_t ws_bytes,
+                                             float *out, int32_t *face_out, float *r1_out, float *r2_out,
+                                             fx3d_stream_t s);
+
 /* Adjoint of sample_points w.r.t. verts_padded for the same draws (Zygote through :67-71):
- * gverts_padded (3,Vmax,B) += scatter of w_k * gout over the sampled faces. Overwrites gverts. */
+ * gverts_padded (3,Vmax,B) = scatter of w_k * gout over the sampled faces.  accumulate = 0 overwrites gverts;
+ * accumulate != 0 adds to it (this and the two mesh-loss adjoints then sum into one gradient buffer: the fit_mesh
+ * objective's three terms without separate buffers, memsets and a final sum). */
 FX3D_API fx3d_status fx3d_sample_points_bwd(const int32_t *faces_padded, int32_t Vmax,
                                             int32_t Fmax, int32_t B, int32_t n,
                                             const int32_t *face_idx, const float *r1,
                                             const float *r2, const float *gout, float *gverts,
-                                            fx3d_stream_t s);
+                                            int32_t accumulate, fx3d_stream_t s);
 
 /* out[i] = a*x[i] + b*y[i] (+ c*z[i] when z != NULL), Float32, unfused.  The device-side arithmetic of
  * the fit_mesh loop: offset!(m, delta) is verts + delta (src/transforms/mesh_func.jl:409-416, a = b = 1),
  * the sum of the three loss gradients, and the Momentum update (examples/fit_mesh.jl:87-110). */
 FX3D_API fx3d_status fx3d_lincomb(int64_t n, float a, const float *x, float b, const float *y, float c,
                                   const float *z, float *out, fx3d_stream_t s);
+/* Flux.Optimise.Momentum(eta, rho) on device arrays (examples/fit_mesh.jl:87-88,110): v <- rho*v - eta*g, then
+ * x <- x + v, in one pass with the arithmetic of the two fx3d_lincomb calls it replaces. */
+FX3D_API fx3d_status fx3d_momentum_step(int64_t n, float rho, float eta, const float *g, float *v, float *x,
+                                        fx3d_stream_t s);
 /* _packed_to_padded / _padded_to_packed for (3,*) Float32 vertex arrays without leaving the device
  * (src/rep/utils.jl:119-181).  verts_len is a HOST array of B lengths. */
 FX3D_API fx3d_status fx3d_packed_to_padded(const float *packed, const int64_t *verts_len_host, int32_t B,
@@ -229,7 +261,7 @@ FX3D_API fx3d_status fx3d_edge_loss(const float *verts, int64_t V, const int32_t
                                     void *ws, size_t ws_bytes, fx3d_stream_t s);
 FX3D_API fx3d_status fx3d_edge_loss_bwd(const float *verts, int64_t V, const int32_t *edges,
                                         int64_t E, float target, float gout, float *gverts,
-                                        fx3d_stream_t s);
+                                        int32_t accumulate, fx3d_stream_t s);
 
 /* laplacian_loss(m) (src/metrics/mesh.jl:9-15) with L in CSR (rows = vertices, columns
  * ascending, values Float32 as built by _compute_laplacian_packed, src/rep/mesh.jl:957-1002). */
@@ -239,7 +271,7 @@ FX3D_API fx3d_status fx3d_laplacian_loss(const float *verts, int64_t V, const in
                                          size_t ws_bytes, fx3d_stream_t s);
 FX3D_API fx3d_status fx3d_laplacian_loss_bwd(const float *verts, int64_t V, const int32_t *rowptr,
                                              const int32_t *colind, const float *vals, float gout,
-                                             float *gverts, fx3d_stream_t s);
+                                             float *gverts, int32_t accumulate, fx3d_stream_t s);
 
 /* ---- pointcloud_to_voxel (src/conversions.jl:91-131) ------------------------------------------------
  * points (3,N,B) -> voxels (res,res,res,B) Float32 0/1: voxel set iff the nearest cloud point of its

@@ -667,6 +667,43 @@ def test_fit_mesh_loop_decreases_loss(gpu_fx):
     assert np.isfinite(last) and last < 0.5 * first, (first, last)
 
 
+def test_fit_step_graph_matches_eager_loop(gpu_fx):
+    """The hipGraph recording of one fit_mesh iteration replays to the same trajectory as the eager loop: same
+    samples (seed + 2 per iteration through the device counter), same losses, same offsets up to the float
+    atomics of the adjoints; the cached target CDF and the single-mesh packed/padded alias are on this path."""
+    fx = gpu_fx
+    tv, tf = fx.load_obj(os.path.join(GOLDEN, "teapot.obj"))
+    tv = (tv - tv.mean(1, keepdims=True)) / tv.std()
+    iters, seed = 8, 4242
+
+    def fresh():
+        src = fx.gpu(fx.load_trimesh(os.path.join(GOLDEN, "sphere.obj")))
+        tgt = fx.gpu(fx.TriMesh([np.asfortranarray(tv.astype(np.float32))], [tf]))
+        return src, tgt, fx.DeviceArray.zeros((3, 2562), np.float32), fx.Momentum(1.0, 0.9)
+
+    src, tgt, x0, opt0 = fresh()
+    eager = []
+    for it in range(iters):
+        loss, g = fx.loss_dolphin(x0, src, tgt, 5000, seed=seed + 2 * it, with_grad=True, sync=False)
+        opt0.update(x0, g)
+        eager.append(float(loss.item()))
+    src, tgt, x1, opt1 = fresh()
+    step = fx.FitStepGraph(x1, src, tgt, opt1, 5000, seed=seed)
+    step.synchronize()
+    graph = [float(step.first_loss.item())]
+    for it in range(1, iters):
+        loss = step.step()
+        step.synchronize()
+        graph.append(float(loss.item()))
+    assert np.allclose(graph, eager, rtol=2e-4), (graph, eager)
+    assert graph[-1] < graph[0]
+    assert np.allclose(x1.to_host(), x0.to_host(), rtol=1e-3, atol=1e-5)
+    # the target's CDF was computed once and kept with its vertex mirrors; replacing the vertices drops it
+    assert any(isinstance(k, tuple) and k[0] == "face_cdf" for k in tgt._dev)
+    tgt.set_verts_packed(tgt.get_verts_packed().clone())
+    assert not any(isinstance(k, tuple) and k[0] == "face_cdf" for k in tgt._dev)
+
+
 # ------------------------------------------------------------------- widened rows: EdgeConv features, voxels
 @pytest.mark.parametrize("F,N,B,K", [(3, 256, 3, 10), (64, 128, 2, 20), (6, 70, 2, 5)])
 def test_edge_features_parity(gpu_fx, oracle, F, N, B, K):
