@@ -251,6 +251,55 @@ offset_verts(m::TriMesh{Float32,R,HipArray}, delta::HipArray{Float32,2}) where {
     lincomb(1, get_verts_packed(m)::HipArray{Float32,2}, 1, delta)
 Zygote.@adjoint offset_verts(m, delta) = offset_verts(m, delta), g -> (nothing, g)
 
+# Flux.Optimise.Momentum(eta, rho) on device arrays in one launch (examples/fit_mesh.jl:87-88,110)
+function momentum_step!(x::HipArray{Float32}, v::HipArray{Float32}, g::HipArray{Float32}; eta = 1.0, rho = 0.9)
+    check(@ccall LIB.fx3d_momentum_step(length(x)::Int64, Float32(rho)::Float32, Float32(eta)::Float32, g.ptr::Ptr{Cvoid},
+                                        v.ptr::Ptr{Cvoid}, x.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    return x
+end
+
+# Stream capture: record the loop body once, replay it with one launch (hipGraph).  `f()` must only enqueue on
+# `stream` (no host copies); run it once eagerly before capturing.
+struct HipGraph; handle::Ptr{Cvoid}; end
+function capture(f, stream::Stream)
+    check(@ccall LIB.fx3d_graph_begin_capture(stream::Stream)::Int32)
+    local h = Ref{Ptr{Cvoid}}(C_NULL)
+    try
+        f()
+    finally
+        check(@ccall LIB.fx3d_graph_end_capture(stream::Stream, h::Ref{Ptr{Cvoid}})::Int32)
+    end
+    return HipGraph(h[])
+end
+launch(g::HipGraph, stream::Stream) = check(@ccall LIB.fx3d_graph_launch(g.handle::Ptr{Cvoid}, stream::Stream)::Int32)
+destroy(g::HipGraph) = check(@ccall LIB.fx3d_graph_destroy(g.handle::Ptr{Cvoid})::Int32)
+# the per-replay part of a sampling seed: a device UInt64 the recorded graph advances itself
+counter_add!(ctr::HipArray{UInt64}, inc::Integer, stream::Stream = DEFAULT_STREAM) =
+    check(@ccall LIB.fx3d_counter_add(ctr.ptr::Ptr{Cvoid}, UInt64(inc)::UInt64, stream::Stream)::Int32)
+
+# The two halves of sample_points: the CDF depends only on the mesh (keep it while the vertices do not change),
+# the draw on (cdf, seed + seed_dev[]).
+function sample_cdf(m::TriMesh{Float32,R,HipArray}, verts::HipArray{Float32,3}, eps = EPS) where {R}
+    nb = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_sample_points_workspace_bytes(m.F::Int32, m.N::Int32, nb::Ref{Csize_t})::Int32)
+    ws = HipArray{UInt8}(undef, nb[])
+    check(@ccall LIB.fx3d_sample_points_cdf(verts.ptr::Ptr{Cvoid}, m.V::Int32, faces_padded_dev(m).ptr::Ptr{Cvoid}, m.F::Int32,
+                                            faces_len_dev(m).ptr::Ptr{Cvoid}, m.N::Int32, Float64(eps)::Float64,
+                                            ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t, DEFAULT_STREAM::Stream)::Int32)
+    return ws
+end
+function sample_draw(m::TriMesh{Float32,R,HipArray}, verts::HipArray{Float32,3}, cdf::HipArray{UInt8}, n::Int, seed::UInt64;
+                     seed_dev::Union{Nothing,HipArray{UInt64}} = nothing) where {R}
+    out = HipArray{Float32}(undef, 3, n, m.N); face = HipArray{Int32}(undef, n, m.N)
+    r1 = HipArray{Float32}(undef, n, m.N); r2 = HipArray{Float32}(undef, n, m.N)
+    check(@ccall LIB.fx3d_sample_points_draw(verts.ptr::Ptr{Cvoid}, m.V::Int32, faces_padded_dev(m).ptr::Ptr{Cvoid}, m.F::Int32,
+                                             faces_len_dev(m).ptr::Ptr{Cvoid}, m.N::Int32, n::Int32, seed::UInt64,
+                                             (seed_dev === nothing ? C_NULL : seed_dev.ptr)::Ptr{Cvoid}, cdf.ptr::Ptr{Cvoid},
+                                             length(cdf)::Csize_t, out.ptr::Ptr{Cvoid}, face.ptr::Ptr{Cvoid},
+                                             r1.ptr::Ptr{Cvoid}, r2.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    return out, (face, r1, r2)
+end
+
 # src/rep/utils.jl:119-181 for (3,*) vertex arrays, device to device
 function packed_to_padded(packed::HipArray{Float32,2}, verts_len::Vector{Int64}, Vmax::Int)
     out = HipArray{Float32}(undef, 3, Vmax, length(verts_len))
