@@ -1197,8 +1197,11 @@ constexpr int kMKeyStride = 64;   // row stride of the key arrays in words
 // fp16-split staging of a candidate chunk (producer side, F16 filter): unit = (row, group of 8 dimensions).
 // A thread converts two float4 of a row (scaled by sc) into one hi piece and one lo piece of 8 halves each.
 // LDS row: pieces [0, PPR/2) = hi of dimension groups, [PPR/2, PPR) = lo; piece c of row r sits at (c + r) mod PPR.
-constexpr int kMUnits = 6;  // (row, group) units per producer thread and chunk: CH * (DP/8) <= 6 * 256
-template <int DK>
+// (row, group) units per producer thread and chunk: CH * (DP/8) <= units * 256.  The single-piece image is half
+// the size, so its chunks can be twice as long (fewer steps: a step cannot be shorter than the latency of the
+// global loads issued one step ahead)
+constexpr int kMUnitsSplit = 6, kMUnitsSingle = 8;
+template <int DK, int kMUnits>
 __device__ __forceinline__ void knn_f16_load_chunk(const float *__restrict__ yb, int D, int j0, int cn, int CH, int ptid,
                                                    float4 (&reg)[kMUnits][2]) {
     constexpr int DP = DK * 32, G = DP / 8;
@@ -1225,9 +1228,16 @@ __device__ __forceinline__ void knn_f16_load_chunk(const float *__restrict__ yb,
         if (!(ok && 8 * g + 4 < D)) reg[u][1] = zero4;
     }
 }
+// fp16 single-piece image (SPLIT = false): rows of PPI = DP/8 pieces (16 bytes = 8 halves); piece c of row r sits
+// at (c + r / RPB) mod PPI, RPB = rows per 256 bytes, so that 16 consecutive rows cover all LDS banks.
+template <int PPI>
+__device__ __forceinline__ int knn_hpiece_off(int row, int c) {
+    constexpr int RPB = PPI >= 16 ? 1 : 16 / PPI;
+    return (row * PPI + ((c + row / RPB) & (PPI - 1))) * 4;
+}
 // Converts and stores the units; the G = DP/8 consecutive lanes that hold one row also sum its scaled norm
 // (3..4 butterfly steps).  norms != nullptr: phase A, norms[row] and the running maximum are recorded.
-template <int DK>
+template <int DK, bool SPLIT, int kMUnits>
 __device__ __forceinline__ void knn_f16_store_chunk(float *img, int CH, int cn, float sc, int ptid,
                                                     const float4 (&reg)[kMUnits][2], float *norms, float &tmax, bool &tnan) {
     constexpr int DP = DK * 32, G = DP / 8, PPR = DK * 8;
@@ -1243,12 +1253,16 @@ __device__ __forceinline__ void knn_f16_store_chunk(float *img, int CH, int cn, 
         for (int e = 0; e < 8; ++e) {
             const _Float16 hh_ = (_Float16)v[e];
             hi[e] = hh_;
-            lo[e] = (_Float16)(v[e] - (float)hh_);
+            if (SPLIT) lo[e] = (_Float16)(v[e] - (float)hh_);
             part = __builtin_fmaf(v[e], v[e], part);
         }
         if (un < CH * G) {
-            *reinterpret_cast<kh8 *>(img + knn_piece_off<DK>(row, g)) = hi;
-            *reinterpret_cast<kh8 *>(img + knn_piece_off<DK>(row, PPR / 2 + g)) = lo;
+            if (SPLIT) {
+                *reinterpret_cast<kh8 *>(img + knn_piece_off<DK>(row, g)) = hi;
+                *reinterpret_cast<kh8 *>(img + knn_piece_off<DK>(row, PPR / 2 + g)) = lo;
+            } else {
+                *reinterpret_cast<kh8 *>(img + knn_hpiece_off<G>(row, g)) = hi;
+            }
         }
         if (norms) {  // wave-uniform
 #pragma unroll
@@ -1262,7 +1276,7 @@ __device__ __forceinline__ void knn_f16_store_chunk(float *img, int CH, int cn, 
     }
 }
 
-template <int DK, bool F16>
+template <int DK, bool F16, bool SPLIT>
 __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__restrict__ x, int N,
                                                              const float *__restrict__ y, int M, int B, int D,
                                                              int k, int drop, int32_t *__restrict__ idx,
@@ -1273,8 +1287,10 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     constexpr int PPR = DK * 8;      // 16-byte pieces per candidate row
     constexpr int NT = DP / 8;       // b128 operand fetches per tile and half
     constexpr int NB16 = DP / 16;    // K blocks of the fp16 filter
+    constexpr int RSI = (F16 && !SPLIT) ? DP / 2 : DP;  // image row stride in floats (single-piece fp16: hi halves only)
+    constexpr int PPI = RSI / 4;     // 16-byte pieces per image row
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int buf_floats = CH * DP + CH;                                   // image [CH][DP] + norms [CH]
+    const int buf_floats = CH * RSI + CH;                                  // image [CH][RSI] + norms [CH]
     int *lists = reinterpret_cast<int *>(sm + img_floats);                 // [kMWaves][kMLCap][64] mask words
     int *lcnt = lists + kMWaves * kMLCap * 64;                             // [kMWaves][64]  list lengths
     int *qn_n = lcnt + kMWaves * 64;                                       // [kMWaves][32]  survivors per query
@@ -1384,7 +1400,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                     amax = fmaxf(amax, fabsf(av));
                     const _Float16 hh_ = (_Float16)av;
                     ah[bb][e] = hh_;
-                    al[bb][e] = (_Float16)(av - (float)hh_);
+                    if (SPLIT) al[bb][e] = (_Float16)(av - (float)hh_);
                 }
             }
             amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
@@ -1408,6 +1424,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
 
     // ---- chunk schedule: phase A walks the chunks forwards, phase B backwards (its first chunk is resident) ----
     const int nstep = 2 * nchunk;
+    constexpr int kMUnits = SPLIT ? kMUnitsSplit : kMUnitsSingle;
     float4 preg[kMUnits][2];  // F16 producers: the chunk after next, loaded one step ahead
     float pmax = 0.0f;        // F16 producers: largest scaled norm seen
     bool pnan = false;
@@ -1415,8 +1432,8 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     const int nevents = 2 * nchunk - 1;
     if (F16) {
         if (!consumer) {
-            knn_f16_load_chunk<DK>(yb, D, 0, M < CH ? M : CH, CH, ptid, preg);
-            knn_f16_store_chunk<DK>(sm, CH, M < CH ? M : CH, sc, ptid, preg, nall, pmax, pnan);
+            knn_f16_load_chunk<DK, kMUnits>(yb, D, 0, M < CH ? M : CH, CH, ptid, preg);
+            knn_f16_store_chunk<DK, SPLIT, kMUnits>(sm, CH, M < CH ? M : CH, sc, ptid, preg, nall, pmax, pnan);
             if (nchunk == 1) {
 #pragma unroll
                 for (int m = 1; m < 64; m <<= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, m, 64));
@@ -1425,7 +1442,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             }
             if (nevents > 1) {
                 const int c1 = 1 < nchunk ? 1 : 2 * nchunk - 3;
-                knn_f16_load_chunk<DK>(yb, D, c1 * CH, (M - c1 * CH) < CH ? (M - c1 * CH) : CH, CH, ptid, preg);
+                knn_f16_load_chunk<DK, kMUnits>(yb, D, c1 * CH, (M - c1 * CH) < CH ? (M - c1 * CH) : CH, CH, ptid, preg);
             }
             stage_ev = 1;
         }
@@ -1469,7 +1486,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                 const int tile0 = j0 / 32;
                 for (int pr = 0; pr < npair; ++pr) {
                     // rows pr*64 + jl and + 32 share (row mod PPR) = jl mod PPR: one rotated offset per fetch
-                    const float *c0 = cand + (size_t)(pr * 64 + jl) * DP, *c1 = c0 + (size_t)32 * DP;
+                    const float *c0 = cand + (size_t)(pr * 64 + jl) * RSI, *c1 = c0 + (size_t)32 * RSI;
                     // accumulators start at the candidate norms: register r of half h is row (r&3) + 8(r>>2) + 4h
                     f32x16v acc0, acc1;
 #pragma unroll
@@ -1479,7 +1496,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                         acc0[4 * g] = n0.x; acc0[4 * g + 1] = n0.y; acc0[4 * g + 2] = n0.z; acc0[4 * g + 3] = n0.w;
                         acc1[4 * g] = n1.x; acc1[4 * g + 1] = n1.y; acc1[4 * g + 2] = n1.z; acc1[4 * g + 3] = n1.w;
                     }
-                    if (F16) {
+                    if (F16 && SPLIT) {
                         // A = candidate pieces (rows), B = query pieces (columns); hi*hi + lo*hi + hi*lo
                         kh8 h0[NB16], l0[NB16], h1[NB16], l1[NB16];
 #pragma unroll
@@ -1498,6 +1515,21 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(l1[bb], ah[bb], acc1, 0, 0, 0);
                             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0[bb], al[bb], acc0, 0, 0, 0);
                             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1[bb], al[bb], acc1, 0, 0, 0);
+                        }
+                    } else if (F16) {
+                        // single-piece filter: one MFMA per K block and tile on the rounded (hi) halves
+                        constexpr int RPB = PPI >= 16 ? 1 : 16 / PPI;
+                        kh8 h0[NB16], h1[NB16];
+#pragma unroll
+                        for (int bb = 0; bb < NB16; ++bb) {
+                            const int ph = ((2 * bb + h + jl / RPB) & (PPI - 1)) * 4;
+                            h0[bb] = *reinterpret_cast<const kh8 *>(c0 + ph);
+                            h1[bb] = *reinterpret_cast<const kh8 *>(c1 + ph);
+                        }
+#pragma unroll
+                        for (int bb = 0; bb < NB16; ++bb) {
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0[bb], ah[bb], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1[bb], ah[bb], acc1, 0, 0, 0);
                         }
                     } else {
                         float4 b0[NT], b1[NT];
@@ -1546,7 +1578,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             float *img = sm + (size_t)(1 - cur) * buf_floats;
             if (F16) {
                 // the registers hold chunk ci_next (loaded one step ago); then fetch the chunk after it
-                knn_f16_store_chunk<DK>(img, CH, cnn, sc, ptid, preg, stage_ev < nchunk ? nall + (size_t)stage_ev * CH : nullptr,
+                knn_f16_store_chunk<DK, SPLIT, kMUnits>(img, CH, cnn, sc, ptid, preg, stage_ev < nchunk ? nall + (size_t)stage_ev * CH : nullptr,
                                         pmax, pnan);
                 if (stage_ev == nchunk - 1) {  // last phase-A chunk: publish this wave's maximum norm
 #pragma unroll
@@ -1557,7 +1589,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                 ++stage_ev;
                 if (stage_ev < nevents) {
                     const int cnx = stage_ev < nchunk ? stage_ev : 2 * nchunk - 2 - stage_ev;
-                    knn_f16_load_chunk<DK>(yb, D, cnx * CH, (M - cnx * CH) < CH ? (M - cnx * CH) : CH, CH, ptid, preg);
+                    knn_f16_load_chunk<DK, kMUnits>(yb, D, cnx * CH, (M - cnx * CH) < CH ? (M - cnx * CH) : CH, CH, ptid, preg);
                 }
             } else {
                 const bool phase_a = nstep1 < nchunk;
@@ -1598,7 +1630,8 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             if (F16) {
                 // scaled units (c~ = sc c, |c~| < 1; qn = |sc q|^2): split representation 3 2^-22 |a~||c~|, fp32
                 // accumulation of the 3D exact products (3D+1) u, the oracle's own (D+2) u, fp16 underflow floor
-                eps = (8.0f * (float)(4 * D + 8) * 0x1p-24f + 0x1p-18f) * (qn + c2) +
+                // single piece: the rounded operands differ by 2^-11 relative each, sum |c~_d a_d| <= 2 |c~||q~| <= qn + c2
+                eps = (8.0f * (float)(4 * D + 8) * 0x1p-24f + (SPLIT ? 0x1p-18f : 0x1.01p-10f)) * (qn + c2) +
                       0x1p-24f * sqrtf((float)D) * (qn + 2.0f);
                 eps = qok ? eps : INFINITY;
             } else {
@@ -1928,35 +1961,36 @@ __global__ __launch_bounds__(kThreads) void edge_features_bwd_kernel(const float
 }
 
 
-template <int DK, bool F16>
+template <int DK, bool F16, bool SPLIT>
 fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int B, int D, int k, int drop,
                                int32_t *idx, float *dist, hipStream_t st) {
-    constexpr int DP = DK * 32, RS = DP + 4;
+    constexpr int DP = DK * 32, RS = DP + 4, RSI = (F16 && !SPLIT) ? DP / 2 : DP;
     // lists (later the slots) + list lengths + per-query counters + cmax
     size_t fixed = (size_t)kMWaves * kMLCap * 64 * 4 + (size_t)kMWaves * 64 * 4 + (size_t)3 * kMWaves * 32 * 4 + 64;
     static_assert(kMWaves * 32 * 33 * 8 + kMWaves * 128 * 4 <= kMWaves * kMLCap * 64 * 4, "rank slots + fallback scratch alias the mask lists");
     const int keep_norms = M <= 4096;  // all candidate norms stay in LDS: phase B does not recompute them
     if (keep_norms) fixed += (size_t)((M + 255) / 256 * 256 + 256) * 4;
     const size_t budget = 150 * 1024 - fixed;                                  // floats*4 for the two chunk buffers
-    int CH = (int)(budget / 2 / ((size_t)DP * 4 + 4)) / 64 * 64;
+    int CH = (int)(budget / 2 / ((size_t)RSI * 4 + 4)) / 64 * 64;
     if (CH > 256) CH = 256;
+    constexpr int kMUnits = SPLIT ? kMUnitsSplit : kMUnitsSingle;
     if (F16 && CH > kMUnits * kMProd * 8 / DP / 64 * 64) CH = kMUnits * kMProd * 8 / DP / 64 * 64;  // producer register budget
     const int mpad = (M + 63) / 64 * 64;
     if (CH > mpad) CH = mpad;
-    size_t img = 2 * ((size_t)CH * DP + CH);                                   // floats
+    size_t img = 2 * ((size_t)CH * RSI + CH);                                  // floats
     const size_t qstage = (size_t)kMWaves * 32 * RS;                           // prologue: query rows
     const size_t exact = (size_t)2 * kMWaves * 32 * kMKeyStride;               // exact phase: distance bits + indices
     if (img < qstage) img = qstage;
     if (img < exact) img = exact;
     img = (img + 3) & ~(size_t)3;
     const size_t lds = img * 4 + fixed;
-    const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_mfma_kernel<DK, F16>), 152 * 1024, "knn_mfma_kernel");
+    const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_mfma_kernel<DK, F16, SPLIT>), 152 * 1024, "knn_mfma_kernel");
     if (arc != FX3D_OK) return arc;
     FX3D_REQUIRE(lds <= 152 * 1024, "fx3d_knn: internal LDS plan exceeds the CU (D=%d)", D);
     const int qpb = kMWaves * 32;
     const int nbx = (N + qpb - 1) / qpb;
     const int bpad = B >= 8 ? (B + 7) / 8 * 8 : B;
-    hipLaunchKernelGGL((knn_mfma_kernel<DK, F16>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
+    hipLaunchKernelGGL((knn_mfma_kernel<DK, F16, SPLIT>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
                        k, drop, idx, dist, CH, (int)img, keep_norms);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
@@ -1970,17 +2004,25 @@ fx3d_status launch_knn_mfma(const float *x, int N, const float *y, int M, int B,
     const bool f32_only = f32_env && atoi(f32_env);
     const bool f16 = !f32_only && D % 4 == 0 && M <= 4096 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
                      ((size_t)M * D * 4) % 16 == 0;
+    const char *split_env = getenv("FX3D_KNN_F16_SPLIT");
+    if (f16 && split_env && atoi(split_env)) {  // 2-way split operands: 3 MFMAs per K block, band 2^-18 instead of 2^-10
+        switch (dk) {
+            case 1: return launch_knn_mfma_dk<1, true, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
+            case 2: return launch_knn_mfma_dk<2, true, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
+            default: return launch_knn_mfma_dk<4, true, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
+        }
+    }
     if (f16) {
         switch (dk) {
-            case 1: return launch_knn_mfma_dk<1, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
-            case 2: return launch_knn_mfma_dk<2, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
-            default: return launch_knn_mfma_dk<4, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
+            case 1: return launch_knn_mfma_dk<1, true, false>(x, N, y, M, B, D, k, drop, idx, dist, st);
+            case 2: return launch_knn_mfma_dk<2, true, false>(x, N, y, M, B, D, k, drop, idx, dist, st);
+            default: return launch_knn_mfma_dk<4, true, false>(x, N, y, M, B, D, k, drop, idx, dist, st);
         }
     }
     switch (dk) {
-        case 1: return launch_knn_mfma_dk<1, false>(x, N, y, M, B, D, k, drop, idx, dist, st);
-        case 2: return launch_knn_mfma_dk<2, false>(x, N, y, M, B, D, k, drop, idx, dist, st);
-        default: return launch_knn_mfma_dk<4, false>(x, N, y, M, B, D, k, drop, idx, dist, st);
+        case 1: return launch_knn_mfma_dk<1, false, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
+        case 2: return launch_knn_mfma_dk<2, false, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
+        default: return launch_knn_mfma_dk<4, false, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
     }
 }
 

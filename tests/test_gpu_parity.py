@@ -409,6 +409,24 @@ def test_knn_float32_filter_variant(gpu_fx, oracle, monkeypatch):
         assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
 
 
+@pytest.mark.parametrize("env", [None, "FX3D_KNN_F16_SPLIT"])
+def test_knn_fp16_filter_variants(gpu_fx, oracle, monkeypatch, env):
+    """The default feature-space filter uses the fp16-rounded operands alone (one MFMA per K block, band 2^-10);
+    FX3D_KNN_F16_SPLIT=1 selects the 2-way split (three MFMAs, band 2^-18).  Both must give the oracle's lists, on
+    centred data and on data with a large common offset (the band grows with |q|^2 + |c|^2: more survivors, and
+    past the list capacity the exact fallback)."""
+    if env:
+        monkeypatch.setenv(env, "1")
+    rng = np.random.default_rng(78)
+    for (D, N, M, k, shift) in ((64, 300, 1024, 20, 0.0), (64, 200, 512, 20, 3.0), (32, 100, 200, 9, 0.0),
+                                (128, 64, 96, 5, 0.5), (16, 130, 700, 31, 10.0), (64, 96, 1024, 12, 40.0)):
+        x = np.asfortranarray((rng.standard_normal((D, N, 2)) + shift).astype(np.float32))
+        y = np.asfortranarray((rng.standard_normal((D, M, 2)) + shift).astype(np.float32))
+        idx, dist = gpu_fx.knn(x, k, y=y)
+        oi, od = oracle.knn(x, k, y=y)
+        assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+
+
 def test_knn_graph_gather(gpu_fx, oracle):
     """create_knn_graph == cat([X[:, knn idx]]...) (src/models/dgcnn.jl:3-7,36): (F,K,N,B)."""
     for F in (3, 64):
