@@ -1688,6 +1688,36 @@ void partial_layout(const Plan &pl, int N, int M, int D, int *tiles, int *tx, in
 
 }  // namespace
 
+// Library-owned arrival counters for the fused finalisation: zeroed once at allocation, every
+// launch returns its counter to zero.  One slot per launch, round robin over kTickets slots (two
+// launches share a slot only if more than kTickets launches are simultaneously in flight).
+namespace fx3d {
+static constexpr int kTickets = 1024;
+unsigned int *ticket_slot(fx3d_status *rc) {
+    static thread_local int cached_dev = -1;
+    static std::mutex mu;
+    static unsigned int *pools[64] = {nullptr};
+    static std::atomic<unsigned int> next{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { *rc = FX3D_ERR_HIP; return nullptr; }
+    (void)cached_dev;
+    if (!pools[dev]) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!pools[dev]) {
+            unsigned int *pnew = nullptr;
+            if (hipMalloc(&pnew, kTickets * sizeof(unsigned int)) != hipSuccess ||
+                hipMemset(pnew, 0, kTickets * sizeof(unsigned int)) != hipSuccess) {
+                set_error("ticket pool allocation failed");
+                *rc = FX3D_ERR_OOM;
+                return nullptr;
+            }
+            pools[dev] = pnew;
+        }
+    }
+    return pools[dev] + (next.fetch_add(1) % kTickets);
+}
+}  // namespace fx3d
+
 extern "C" {
 
 fx3d_status fx3d_nn1(const float *x, int32_t N, const float *y, int32_t M, int32_t B, int32_t D,
@@ -1717,33 +1747,6 @@ fx3d_status fx3d_chamfer_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_
     return FX3D_OK;
 }
 
-// Library-owned arrival counters for the fused finalisation: zeroed once at allocation, every
-// launch returns its counter to zero.  One slot per launch, round robin over kTickets slots (two
-// launches share a slot only if more than kTickets launches are simultaneously in flight).
-static constexpr int kTickets = 1024;
-static unsigned int *ticket_slot(fx3d_status *rc) {
-    static thread_local int cached_dev = -1;
-    static std::mutex mu;
-    static unsigned int *pools[64] = {nullptr};
-    static std::atomic<unsigned int> next{0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { *rc = FX3D_ERR_HIP; return nullptr; }
-    (void)cached_dev;
-    if (!pools[dev]) {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!pools[dev]) {
-            unsigned int *pnew = nullptr;
-            if (hipMalloc(&pnew, kTickets * sizeof(unsigned int)) != hipSuccess ||
-                hipMemset(pnew, 0, kTickets * sizeof(unsigned int)) != hipSuccess) {
-                set_error("ticket pool allocation failed");
-                *rc = FX3D_ERR_OOM;
-                return nullptr;
-            }
-            pools[dev] = pnew;
-        }
-    }
-    return pools[dev] + (next.fetch_add(1) % kTickets);
-}
 
 static fx3d_status chamfer_common(const float *x, int N, const float *y, int M, int B, int D,
                                   double *sums_dev, float *loss_dev, long long Bg, float w1,

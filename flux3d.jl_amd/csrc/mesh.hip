@@ -44,10 +44,37 @@ __global__ __launch_bounds__(kThreads) void faces_areas_padded_kernel(
     }
 }
 
+// Fused finalisation of a mean over per-block partial sums: every block publishes its sum and takes a ticket; the
+// last arriver adds the partials in index order (deterministic) and writes loss = Float32(sum / count), then
+// returns the ticket to zero.  Hand-off through 8-byte agent-scope atomics as in nn1_f16_kernel (chamfer.hip).
+__device__ __forceinline__ void mean_finalize_last_block(double tot, double *partials, unsigned int *ticket, double count,
+                                                         float *loss, double *sm) {
+    __shared__ int is_last;
+    unsigned long long *pp = reinterpret_cast<unsigned long long *>(partials);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&pp[blockIdx.x], __builtin_bit_cast(unsigned long long, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = old == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += kThreads)
+        acc += __builtin_bit_cast(double, __hip_atomic_load(&pp[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
+    const double all = block_sum<kThreads>(acc, sm);
+    if (threadIdx.x == 0) {
+        *loss = (float)(all / count);
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---- edge_loss (src/metrics/mesh.jl:24-32) ---------------------------------------------------
 __global__ __launch_bounds__(kThreads) void edge_loss_kernel(
     const float *__restrict__ verts, const int32_t *__restrict__ e1,
-    const int32_t *__restrict__ e2, long long E, float target, double *__restrict__ partials) {
+    const int32_t *__restrict__ e2, long long E, float target, double *__restrict__ partials,
+    unsigned int *ticket, float *__restrict__ loss) {
     __shared__ double sm[kThreads / 64];
     double acc = 0.0;
     for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < E;
@@ -59,7 +86,7 @@ __global__ __launch_bounds__(kThreads) void edge_loss_kernel(
         acc += (double)(t * t);
     }
     const double tot = block_sum<kThreads>(acc, sm);
-    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+    mean_finalize_last_block(tot, partials, ticket, (double)E, loss, sm);
 }
 
 __global__ __launch_bounds__(kThreads) void edge_loss_bwd_kernel(
@@ -103,7 +130,7 @@ __device__ __forceinline__ void lap_row(const float *__restrict__ verts,
 __global__ __launch_bounds__(kThreads) void laplacian_loss_kernel(
     const float *__restrict__ verts, long long V, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ colind, const float *__restrict__ vals,
-    double *__restrict__ partials) {
+    double *__restrict__ partials, unsigned int *ticket, float *__restrict__ loss) {
     __shared__ double sm[kThreads / 64];
     double acc = 0.0;
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < V;
@@ -113,7 +140,7 @@ __global__ __launch_bounds__(kThreads) void laplacian_loss_kernel(
         acc += (double)sqrtf(((s0 * s0) + (s1 * s1)) + (s2 * s2));
     }
     const double tot = block_sum<kThreads>(acc, sm);
-    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+    mean_finalize_last_block(tot, partials, ticket, (double)V, loss, sm);
 }
 
 __global__ __launch_bounds__(kThreads) void laplacian_loss_bwd_kernel(
@@ -135,17 +162,6 @@ __global__ __launch_bounds__(kThreads) void laplacian_loss_bwd_kernel(
             atomicAdd(&g[2], w * u2);
         }
     }
-}
-
-// loss = Float32(sum(partials)/count), fixed order
-__global__ __launch_bounds__(kThreads) void mean_finalize_kernel(const double *__restrict__ partials,
-                                                                 int n, double count,
-                                                                 float *__restrict__ loss) {
-    __shared__ double sm[kThreads / 64];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += kThreads) acc += partials[i];
-    const double tot = block_sum<kThreads>(acc, sm);
-    if (threadIdx.x == 0) *loss = (float)(tot / count);
 }
 
 __global__ __launch_bounds__(kThreads) void lincomb_kernel(long long n, float a, const float *__restrict__ x, float b,
@@ -274,14 +290,15 @@ fx3d_status fx3d_edge_loss(const float *verts, int64_t V, const int32_t *edges, 
     }
     hipStream_t st = as_stream(s);
     double *partials = reinterpret_cast<double *>(ws);
+    fx3d_status trc = FX3D_OK;
+    unsigned int *ticket = ticket_slot(&trc);
+    if (!ticket) return trc;
     const int g = grid_for(E);
     {
         ProfileScope prof("edge_loss", st);
         hipLaunchKernelGGL(edge_loss_kernel, dim3(g), dim3(kThreads), 0, st, verts, edges, edges + E,
-                           (long long)E, target, partials);
+                           (long long)E, target, partials, ticket, loss_dev);  // the last block writes the mean
     }
-    FX3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(kThreads), 0, st, partials, g, (double)E, loss_dev);
     FX3D_LAUNCH_CHECK();
     return copy_back(loss_host, loss_dev, st);
 }
@@ -309,14 +326,15 @@ fx3d_status fx3d_laplacian_loss(const float *verts, int64_t V, const int32_t *ro
     }
     hipStream_t st = as_stream(s);
     double *partials = reinterpret_cast<double *>(ws);
+    fx3d_status trc = FX3D_OK;
+    unsigned int *ticket = ticket_slot(&trc);
+    if (!ticket) return trc;
     const int g = grid_for(V);
     {
         ProfileScope prof("laplacian_loss", st);
         hipLaunchKernelGGL(laplacian_loss_kernel, dim3(g), dim3(kThreads), 0, st, verts, (long long)V,
-                           rowptr, colind, vals, partials);
+                           rowptr, colind, vals, partials, ticket, loss_dev);  // the last block writes the mean
     }
-    FX3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(kThreads), 0, st, partials, g, (double)V, loss_dev);
     FX3D_LAUNCH_CHECK();
     return copy_back(loss_host, loss_dev, st);
 }
