@@ -54,6 +54,7 @@ def main():
     torch = None
     use_dist = world > 1 or args.force_dist
     if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
