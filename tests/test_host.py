@@ -196,3 +196,15 @@ def test_off_loader_roundtrip(fx, tmp_path):
     assert v3.shape == (3, 4) and np.array_equal(f3, np.array([[1, 1], [2, 3], [3, 4]], np.uint32))
     m = fx.load_trimesh(str(p), str(q))
     assert m.N == 2 and m.V == v.shape[1]
+
+
+def test_graph_capture_needs_a_created_stream(fx):
+    """Graph.capture refuses the default stream before touching the device (hipGraph capture is per stream), and the
+    Julia shim binds every entry point the fit_mesh graph path uses."""
+    g = fx.Graph()
+    with pytest.raises(ValueError):
+        g.capture(fx.current_stream())
+    shim = open(os.path.join(ROOT, "flux3d.jl_amd", "julia", "Flux3DHip.jl")).read()
+    for name in ("fx3d_graph_begin_capture", "fx3d_graph_end_capture", "fx3d_graph_launch", "fx3d_graph_destroy",
+                 "fx3d_counter_add", "fx3d_sample_points_cdf", "fx3d_sample_points_draw", "fx3d_momentum_step"):
+        assert name in shim, name
