@@ -186,6 +186,7 @@ mirror(m::TriMesh) = get!(() -> Dict{Symbol,Any}(), _mirror, m)
 dev_i32(a) = hip(Int32.(a .- 1))
 faces_padded_dev(m) = get!(() -> hip(Int32.(max.(Int64.(get_faces_padded(m)) .- 1, 0))), mirror(m), :faces_padded)
 faces_len_dev(m) = get!(() -> hip(Int32.(m._faces_len)), mirror(m), :faces_len)
+faces_packed_dev(m) = get!(() -> hip(Int32.(Int64.(get_faces_packed(m)) .- 1)), mirror(m), :faces_packed)
 edges_dev(m) = get!(() -> dev_i32(get_edges_packed(m)), mirror(m), :edges)          # (E,2) column-major
 function laplacian_csr_dev(m)
     get!(mirror(m), :lap) do
@@ -403,6 +404,87 @@ function chamfer_finalize_many(comm, sums::HipArray{Float64,2}, N::Integer, M::I
                                                 D::Int32, Float32(w1)::Float32, Float32(w2)::Float32,
                                                 losses.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
     return losses
+end
+
+# ---- the rest of the ABI: device / stream / event utilities, explicit-draw sampling, face areas, host topology ----
+version() = unsafe_string(@ccall LIB.fx3d_version()::Cstring)
+function current_device()
+    d = Ref{Int32}(0); check(@ccall LIB.fx3d_get_device(d::Ref{Int32})::Int32); return Int(d[])
+end
+function device_name(dev::Integer = current_device())
+    buf = Vector{UInt8}(undef, 256)
+    check(@ccall LIB.fx3d_device_name(dev::Int32, buf::Ptr{UInt8}, length(buf)::Csize_t)::Int32)
+    return unsafe_string(pointer(buf))
+end
+device_synchronize() = check(@ccall LIB.fx3d_device_sync()::Int32)
+function stream_create()
+    s = Ref{Stream}(C_NULL); check(@ccall LIB.fx3d_stream_create(s::Ref{Stream})::Int32); return s[]
+end
+stream_destroy(s::Stream) = check(@ccall LIB.fx3d_stream_destroy(s::Stream)::Int32)
+stream_synchronize(s::Stream = DEFAULT_STREAM) = check(@ccall LIB.fx3d_stream_sync(s::Stream)::Int32)
+const Event = Ptr{Cvoid}
+function event_create()
+    e = Ref{Event}(C_NULL); check(@ccall LIB.fx3d_event_create(e::Ref{Event})::Int32); return e[]
+end
+event_destroy(e::Event) = check(@ccall LIB.fx3d_event_destroy(e::Event)::Int32)
+event_record(e::Event, s::Stream = DEFAULT_STREAM) = check(@ccall LIB.fx3d_event_record(e::Event, s::Stream)::Int32)
+event_synchronize(e::Event) = check(@ccall LIB.fx3d_event_sync(e::Event)::Int32)
+function event_elapsed_ms(a::Event, b::Event)
+    ms = Ref{Float32}(0); check(@ccall LIB.fx3d_event_elapsed_ms(a::Event, b::Event, ms::Ref{Float32})::Int32); return ms[]
+end
+Base.copy(a::HipArray{T,N}) where {T,N} = (out = HipArray{T}(undef, size(a)...);
+    check(@ccall LIB.fx3d_memcpy_d2d(out.ptr::Ptr{Cvoid}, a.ptr::Ptr{Cvoid}, sizeof(T) * length(a)::Csize_t, DEFAULT_STREAM::Stream)::Int32); out)
+Base.fill!(a::HipArray{T}, z::Integer) where {T} = (z == 0 || error("HipArray fill!: only zero");
+    check(@ccall LIB.fx3d_memset(a.ptr::Ptr{Cvoid}, 0::Int32, sizeof(T) * length(a)::Csize_t, DEFAULT_STREAM::Stream)::Int32); a)
+# per-kernel HIP-event timing inside the library (bench.py's `roofline` object)
+profile_enable(every_nth::Integer) = check(@ccall LIB.fx3d_profile_enable(every_nth::Int32)::Int32)
+function profile_kernel_stats(name::AbstractString)
+    avg = Ref{Float64}(0); mn = Ref{Float64}(0); mx = Ref{Float64}(0); cnt = Ref{Int64}(0)
+    check(@ccall LIB.fx3d_profile_kernel_stats(name::Cstring, avg::Ref{Float64}, mn::Ref{Float64}, mx::Ref{Float64}, cnt::Ref{Int64})::Int32)
+    return (avg_ms = avg[], min_ms = mn[], max_ms = mx[], count = cnt[])
+end
+
+# compute_faces_areas_packed / _padded (src/rep/mesh.jl:765-808) on HipArray meshes
+function compute_faces_areas_packed(m::TriMesh{Float32,R,HipArray}) where {R}
+    verts = get_verts_packed(m)::HipArray{Float32,2}; faces = faces_packed_dev(m)
+    out = HipArray{Float32}(undef, size(faces, 2))
+    check(@ccall LIB.fx3d_faces_areas_packed(verts.ptr::Ptr{Cvoid}, size(verts, 2)::Int64, faces.ptr::Ptr{Cvoid},
+                                             size(faces, 2)::Int64, out.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    return out
+end
+function compute_faces_areas_padded(m::TriMesh{Float32,R,HipArray}) where {R}
+    verts = get_verts_padded(m)::HipArray{Float32,3}
+    out = HipArray{Float32}(undef, 1, m.F, m.N)
+    check(@ccall LIB.fx3d_faces_areas_padded(verts.ptr::Ptr{Cvoid}, m.V::Int32, faces_padded_dev(m).ptr::Ptr{Cvoid}, m.F::Int32,
+                                             faces_len_dev(m).ptr::Ptr{Cvoid}, m.N::Int32, out.ptr::Ptr{Cvoid},
+                                             DEFAULT_STREAM::Stream)::Int32)
+    return out
+end
+# _sample_points for given draws (src/transforms/mesh_func.jl:60-82): face_idx (n,B) Int32 0-based, r1, r2 (n,B)
+function sample_points_explicit(m::TriMesh{Float32,R,HipArray}, verts::HipArray{Float32,3}, face_idx::HipArray{Int32,2},
+                                r1::HipArray{Float32,2}, r2::HipArray{Float32,2}) where {R}
+    n = size(face_idx, 1)
+    out = HipArray{Float32}(undef, 3, n, m.N)
+    check(@ccall LIB.fx3d_sample_points_explicit(verts.ptr::Ptr{Cvoid}, m.V::Int32, faces_padded_dev(m).ptr::Ptr{Cvoid}, m.F::Int32,
+                                                 m.N::Int32, n::Int32, face_idx.ptr::Ptr{Cvoid}, r1.ptr::Ptr{Cvoid},
+                                                 r2.ptr::Ptr{Cvoid}, out.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    return out
+end
+# host topology builders (integer work of src/rep/mesh.jl:907-1002 in C++; the reference's own Julia versions stay valid)
+function build_edges_packed(faces::Matrix{Int64}, V::Integer; index_base::Integer = 1)
+    F = size(faces, 2)
+    buf = Vector{Int64}(undef, 6F); f2e = Matrix{Int64}(undef, F, 3); E = Ref{Int64}(0)
+    check(@ccall LIB.fx3d_build_edges_packed(faces::Ptr{Int64}, F::Int64, V::Int64, index_base::Int32, buf::Ptr{Int64},
+                                             f2e::Ptr{Int64}, E::Ref{Int64})::Int32)
+    return reshape(buf[1:2E[]], Int(E[]), 2), f2e
+end
+function build_laplacian_csr(edges::Matrix{Int64}, V::Integer; index_base::Integer = 1)
+    E = size(edges, 1)
+    rowptr = Vector{Int32}(undef, V + 1); colind = Vector{Int32}(undef, 2E + V); vals = Vector{Float32}(undef, 2E + V)
+    nnz = Ref{Int64}(0)
+    check(@ccall LIB.fx3d_build_laplacian_csr(edges::Ptr{Int64}, E::Int64, V::Int64, index_base::Int32, rowptr::Ptr{Int32},
+                                              colind::Ptr{Int32}, vals::Ptr{Float32}, nnz::Ref{Int64})::Int32)
+    return rowptr, colind[1:nnz[]], vals[1:nnz[]]
 end
 
 end # module
