@@ -685,11 +685,29 @@ __device__ __forceinline__ void k3_sort_regs(float (&v)[NV]) {
     }
 }
 
+// EdgeConv's features of ONE (point i, neighbour rank r) pair for F = 3 (src/models/dgcnn.jl:36-51): cat(x_i, x_j - x_i),
+// layout 0 = (2F,K,N,B), 1 = (K*N,2F,B).  Used by the rare paths of the fused kernel (ties, exact fallback).
+__device__ __forceinline__ void knn_d3_feature_entry(float *__restrict__ feat, int layout, int b, int N, int k, int i, int r,
+                                                     const float *a, const float *c) {
+    if (layout == 0) {
+        float *o = feat + (((size_t)b * N + i) * k + r) * 6;
+        o[0] = a[0]; o[1] = a[1]; o[2] = a[2];
+        o[3] = c[0] - a[0]; o[4] = c[1] - a[1]; o[5] = c[2] - a[2];
+    } else {
+        const size_t KN = (size_t)k * N;
+        float *o = feat + (size_t)b * 6 * KN + (size_t)i * k + r;
+        o[0] = a[0]; o[KN] = a[1]; o[2 * KN] = a[2];
+        o[3 * KN] = c[0] - a[0]; o[4 * KN] = c[1] - a[1]; o[5 * KN] = c[2] - a[2];
+    }
+}
+
+// FEAT: EdgeConv's graph build in one kernel (self-kNN, x == y): the epilogue also writes cat(x_i, x_j - x_i).
+template <bool FEAT>
 __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__restrict__ x, int N,
                                                                const float *__restrict__ y, int M, int B, int k,
                                                                int drop, int32_t *__restrict__ idx,
                                                                float *__restrict__ dist, int CH, int img_bytes,
-                                                               int raw_ok) {
+                                                               int raw_ok, float *__restrict__ feat, int layout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k3sm[];
     __shared__ float red[2 * 4 * kTWaves];
     kh8 *imgp = reinterpret_cast<kh8 *>(k3sm);  // piece (blk, half, row) at (blk*2 + half)*32 + row
@@ -1100,6 +1118,49 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                         *reinterpret_cast<float4 *>(dist + obase + 4 * v) =
                             float4{__builtin_bit_cast(float, (unsigned int)(key[0] >> 32)), __builtin_bit_cast(float, (unsigned int)(key[1] >> 32)),
                                    __builtin_bit_cast(float, (unsigned int)(key[2] >> 32)), __builtin_bit_cast(float, (unsigned int)(key[3] >> 32))};
+                    if (FEAT) {
+                        // four neighbours of point qi: 16-byte stores along the rank dimension (mlp layout: one per
+                        // channel row; cat layout: 24 contiguous floats)
+                        float cx[4], cy[4], cz[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int j = (int)(unsigned int)key[e];
+                            if (raw_ok) {
+                                const float4 rc = rawc[j];
+                                cx[e] = rc.x - qr[0]; cy[e] = rc.y - qr[1]; cz[e] = rc.z - qr[2];
+                            } else {
+                                const float *c = yb + (size_t)j * 3;
+                                cx[e] = c[0] - qr[0]; cy[e] = c[1] - qr[1]; cz[e] = c[2] - qr[2];
+                            }
+                        }
+                        if (layout == 1 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0) {
+                            const size_t KN = (size_t)k * N;
+                            float *o = feat + (size_t)b * 6 * KN + (size_t)qi * k + 4 * v;
+                            *reinterpret_cast<float4 *>(o) = float4{qr[0], qr[0], qr[0], qr[0]};
+                            *reinterpret_cast<float4 *>(o + KN) = float4{qr[1], qr[1], qr[1], qr[1]};
+                            *reinterpret_cast<float4 *>(o + 2 * KN) = float4{qr[2], qr[2], qr[2], qr[2]};
+                            *reinterpret_cast<float4 *>(o + 3 * KN) = float4{cx[0], cx[1], cx[2], cx[3]};
+                            *reinterpret_cast<float4 *>(o + 4 * KN) = float4{cy[0], cy[1], cy[2], cy[3]};
+                            *reinterpret_cast<float4 *>(o + 5 * KN) = float4{cz[0], cz[1], cz[2], cz[3]};
+                        } else if (layout == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0) {
+                            float4 *o = reinterpret_cast<float4 *>(feat + (obase + 4 * v) * 6);
+                            o[0] = float4{qr[0], qr[1], qr[2], cx[0]};
+                            o[1] = float4{cy[0], cz[0], qr[0], qr[1]};
+                            o[2] = float4{qr[2], cx[1], cy[1], cz[1]};
+                            o[3] = float4{qr[0], qr[1], qr[2], cx[2]};
+                            o[4] = float4{cy[2], cz[2], qr[0], qr[1]};
+                            o[5] = float4{qr[2], cx[3], cy[3], cz[3]};
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float cc[3] = {cx[e], cy[e], cz[e]};
+                                float *o0 = layout == 0 ? feat + (obase + 4 * v + e) * 6 : feat + (size_t)b * 6 * k * N + (size_t)qi * k + 4 * v + e;
+                                const size_t st = layout == 0 ? 1 : (size_t)k * N;
+                                o0[0] = qr[0]; o0[st] = qr[1]; o0[2 * st] = qr[2];
+                                o0[3 * st] = cc[0]; o0[4 * st] = cc[1]; o0[5 * st] = cc[2];
+                            }
+                        }
+                    }
                 }
             }
         } else {
@@ -1110,6 +1171,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                     const unsigned long long key = slots[r];
                     idx[obase + r - drop] = (int)(unsigned int)key;
                     if (dist) dist[obase + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
+                    if (FEAT) knn_d3_feature_entry(feat, layout, b, N, k, qi, r - drop, qr, yb + (size_t)(unsigned int)key * 3);
                 }
             }
         }
@@ -1132,6 +1194,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
             const unsigned long long key = sj[r];
             idx[((size_t)b * N + q0 + j) * k + r - drop] = (int)(unsigned int)key;
             if (dist) dist[((size_t)b * N + q0 + j) * k + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
+            if (FEAT) knn_d3_feature_entry(feat, layout, b, N, k, q0 + j, r - drop, xb + (size_t)(q0 + j) * 3, yb + (size_t)(unsigned int)key * 3);
         }
     }
     // leftovers, wave-cooperative (scratch: behind the slots)
@@ -1147,13 +1210,14 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
         if (r >= 0 && r < k) {
             idx[((size_t)b * N + q0 + j) * k + r] = bj;
             if (dist) dist[((size_t)b * N + q0 + j) * k + r] = bd;
+            if (FEAT) knn_d3_feature_entry(feat, layout, b, N, k, q0 + j, r, xb + (size_t)(q0 + j) * 3, yb + (size_t)bj * 3);
         }
     }
     KNN_PROBE_MARK(11);
 }
 
 fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int B, int k, int drop, int32_t *idx,
-                              float *dist, hipStream_t st) {
+                              float *dist, hipStream_t st, float *feat = nullptr, int layout = 0) {
     int CH = (M + 63) / 64 * 64;
     if (CH > kTChunk) CH = kTChunk;
     size_t img = (size_t)CH * 32;
@@ -1164,12 +1228,17 @@ fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int 
     static_assert((size_t)kTGroups * 32 * 33 * 8 + kTGroups * 128 * 4 <= (size_t)kTWaves * kTCap * 64 * 4, "slots + scratch alias the lists");
     const int raw_ok = M <= kTRawMax && img + fixed + (size_t)M * 16 <= 152 * 1024;
     const size_t lds = img + fixed + (raw_ok ? (size_t)M * 16 : 0);
-    const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_f16_d3_kernel), 156 * 1024, "knn_f16_d3_kernel");
+    const fx3d_status arc = feat ? ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_f16_d3_kernel<true>), 156 * 1024, "knn_f16_d3_kernel<feat>")
+                                 : ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_f16_d3_kernel<false>), 156 * 1024, "knn_f16_d3_kernel");
     if (arc != FX3D_OK) return arc;
     const int nbx = (N + kTGroups * 32 - 1) / (kTGroups * 32);
     const int bpad = B >= 8 ? (B + 7) / 8 * 8 : B;
-    hipLaunchKernelGGL(knn_f16_d3_kernel, dim3(nbx * bpad), dim3(kTThreads), lds, st, x, N, y, M, B, k, drop, idx, dist,
-                       CH, (int)img, raw_ok);
+    if (feat)
+        hipLaunchKernelGGL(knn_f16_d3_kernel<true>, dim3(nbx * bpad), dim3(kTThreads), lds, st, x, N, y, M, B, k, drop, idx, dist,
+                           CH, (int)img, raw_ok, feat, layout);
+    else
+        hipLaunchKernelGGL(knn_f16_d3_kernel<false>, dim3(nbx * bpad), dim3(kTThreads), lds, st, x, N, y, M, B, k, drop, idx, dist,
+                           CH, (int)img, raw_ok, feat, layout);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }
@@ -2144,6 +2213,14 @@ fx3d_status fx3d_edge_features_bwd(const float *gout, int32_t N, int32_t B, int3
 fx3d_status fx3d_edgeconv_graph(const float *x, int32_t N, int32_t B, int32_t F, int32_t k, int32_t layout,
                                 int32_t *idx, float *out, fx3d_stream_t s) {
     FX3D_REQUIRE(idx, "fx3d_edgeconv_graph: idx (k,N,B) is required (it is also the adjoint's side input)");
+    FX3D_REQUIRE(x && out && N > 0 && B > 0 && F > 0 && k > 0, "fx3d_edgeconv_graph: bad argument");
+    FX3D_REQUIRE(layout == 0 || layout == 1, "fx3d_edgeconv_graph: layout must be 0 (2F,K,N,B) or 1 (K*N,2F,B)");
+    if (F == 3 && k + 1 <= 32 && k + 1 <= N && N >= 64 && N < (1 << 21) && !getenv("FX3D_KNN_D3_WAVE") &&
+        !getenv("FX3D_EDGECONV_UNFUSED")) {
+        // first EdgeConv (coordinates): neighbour search and features in ONE kernel
+        ProfileScope prof("edgeconv_graph", as_stream(s));
+        return launch_knn_f16_d3(x, N, x, N, B, k, 1, idx, nullptr, as_stream(s), out, layout);
+    }
     fx3d_status rc = fx3d_knn(x, N, x, N, B, F, k, 1, idx, nullptr, s);
     if (rc != FX3D_OK) return rc;
     return fx3d_edge_features(x, N, B, F, k, idx, layout, out, s);

@@ -169,7 +169,8 @@ FX3D_API fx3d_status fx3d_edge_features(const float *x, int32_t N, int32_t B, in
  * constants, gx[f,i,b] = sum_r gout[f,r,i,b] - gout[F+f,r,i,b] (rank order).  Overwrites gx (F,N,B). */
 FX3D_API fx3d_status fx3d_edge_features_bwd(const float *gout, int32_t N, int32_t B, int32_t F, int32_t k,
                                             int32_t layout, float *gx, fx3d_stream_t s);
-/* Self-kNN (drop_first) + fx3d_edge_features in one call: EdgeConv's whole graph build.  idx (k,N,B) out. */
+/* Self-kNN (drop_first) + fx3d_edge_features in one call: EdgeConv's whole graph build.  idx (k,N,B) out.
+ * F = 3 (the first EdgeConv, coordinates) runs as ONE kernel: the neighbour search's epilogue writes the features. */
 FX3D_API fx3d_status fx3d_edgeconv_graph(const float *x, int32_t N, int32_t B, int32_t F, int32_t k,
                                          int32_t layout, int32_t *idx, float *out, fx3d_stream_t s);
 

@@ -743,6 +743,33 @@ def test_edge_features_parity(gpu_fx, oracle, F, N, B, K):
         assert np.array_equal(gx, oracle.edge_features_bwd(g, F, N, B, K, layout=lay))
 
 
+@pytest.mark.parametrize("N,B,K,kind", [(1024, 3, 20, "uniform"), (200, 2, 10, "uniform"), (333, 2, 7, "lattice"),
+                                         (96, 1, 31, "uniform"), (300, 2, 12, "outlier"), (70, 2, 4, "same")])
+def test_edgeconv_graph_fused_first_layer(gpu_fx, oracle, N, B, K, kind, monkeypatch):
+    """F = 3: fx3d_edgeconv_graph runs the neighbour search and cat(X, KNN - X) in ONE kernel.  Vector and scalar
+    rank stores (K % 4), distance ties re-ranked by the wave (lattice), lists overflowing into the exact fallback
+    (outlier / identical points): indices and features bit-identical to the oracle and to the two-kernel path."""
+    rng = np.random.default_rng(N * 3 + K)
+    x = rng.random((3, N, B), dtype=np.float32)
+    if kind == "lattice":
+        x = np.round(x * 4) / 4
+    elif kind == "outlier":
+        x = (x * 1e-3).astype(np.float32)
+        x[:, 5, :] = 1.0e6
+    elif kind == "same":
+        x[:] = 0.25
+    x = np.asfortranarray(x.astype(np.float32))
+    dx = gpu_fx.gpu(x)
+    oi = oracle.knn(x, K, drop_first=True, want_dist=False)
+    for layout, lay in (("cat", 0), ("mlp", 1)):
+        exp = oracle.edge_features(x, oi, layout=lay)
+        out, idx = gpu_fx.edgeconv_graph(dx, K, layout=layout, return_idx=True)
+        assert np.array_equal(idx.to_host(), oi) and np.array_equal(out.to_host(), exp)
+    monkeypatch.setenv("FX3D_EDGECONV_UNFUSED", "1")
+    out2, idx2 = gpu_fx.edgeconv_graph(dx, K, layout="mlp", return_idx=True)
+    assert np.array_equal(idx2.to_host(), oi) and np.array_equal(out2.to_host(), exp)
+
+
 @pytest.mark.parametrize("res,N,B", [(16, 300, 2), (32, 1024, 2), (8, 5, 1)])
 def test_pointcloud_to_voxel_parity(gpu_fx, oracle, res, N, B):
     """Occupancy grid of pointcloud_to_voxel (src/conversions.jl:91-131): identical to the oracle's
