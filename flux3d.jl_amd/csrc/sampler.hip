@@ -72,6 +72,9 @@ __global__ __launch_bounds__(kCdfThreads) void face_cdf_kernel(const float *__re
     double *tc = IN_LDS ? dsm + Fp : out + Fp;
     __shared__ double sh[2];
 
+    // The summation order is the oracle's "blocked" order (chunks of 32 summed sequentially, chunk totals summed
+    // sequentially); the passes are arranged so that every chain of that order is walked once:
+    __shared__ double pF[kChunk];  // probabilities of the chunk that holds the fix-up column, before the fix-up
     for (int k = threadIdx.x; k < Fp; k += kCdfThreads) {
         float a = 0.0f;
         if (k < flen) a = tri_area(vb + 3ll * fb[3 * k], vb + 3ll * fb[3 * k + 1], vb + 3ll * fb[3 * k + 2]);
@@ -93,13 +96,20 @@ __global__ __launch_bounds__(kCdfThreads) void face_cdf_kernel(const float *__re
     }
     __syncthreads();
     const double den = sh[0];
-    for (int k = threadIdx.x; k < Fmax; k += kCdfThreads) cdf[k] = cdf[k] / den;  // p, parallel
+    const int cF = (Fmax - 1) / kChunk;  // chunk of the last PADDED column, where the fix-up lands (:36-37)
+    for (int k = threadIdx.x; k < Fmax; k += kCdfThreads) cdf[k] = cdf[k] / den;  // p, parallel (Float64 divisions)
     __syncthreads();
-    for (int c = threadIdx.x; c < nch; c += kCdfThreads) {  // chunk totals of p
-        double t = 0.0;
+    for (int c = threadIdx.x; c < nch; c += kCdfThreads) {
+        // local inclusive prefixes of p in place; the last prefix of a chunk is its total of p
+        double l = 0.0;
 #pragma unroll 8
-        for (int k = c * kChunk; k < (c + 1) * kChunk; ++k) t += cdf[k];
-        tc[c] = t;
+        for (int k = c * kChunk; k < (c + 1) * kChunk; ++k) {
+            const double pk = cdf[k];
+            if (c == cF) pF[k - c * kChunk] = pk;
+            l += pk;
+            cdf[k] = l;
+        }
+        tc[c] = l;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -107,21 +117,15 @@ __global__ __launch_bounds__(kCdfThreads) void face_cdf_kernel(const float *__re
 #pragma unroll 8
         for (int c = 0; c < nch; ++c) sp += tc[c];
         const double fix = 1.0 - sp;
-        cdf[Fmax - 1] += fix > 0.0 ? fix : 0.0;  // :36-37, lands on the last PADDED column
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < nch; c += kCdfThreads) {  // local inclusive prefixes + chunk totals of p'
-        double l = 0.0;
-#pragma unroll 8
-        for (int k = c * kChunk; k < (c + 1) * kChunk; ++k) {
-            l += cdf[k];
-            cdf[k] = l;
+        if (fix > 0.0) {  // p[Fmax-1] += fix: only this chunk's prefixes and total change
+            double l = 0.0;
+            for (int k = cF * kChunk; k < (cF + 1) * kChunk; ++k) {
+                l += pF[k - cF * kChunk] + (k == Fmax - 1 ? fix : 0.0);
+                cdf[k] = l;
+            }
+            tc[cF] = l;
         }
-        tc[c] = l;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {  // exclusive scan of the chunk totals, in place
-        double off = 0.0;
+        double off = 0.0;  // exclusive scan of the chunk totals, in place
 #pragma unroll 8
         for (int c = 0; c < nch; ++c) { const double t = tc[c]; tc[c] = off; off += t; }
     }
