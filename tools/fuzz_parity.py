@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep beyond the test-suite: nearest neighbours, chamfer sums, kNN (D = 3 and feature space) and
+EdgeConv features on random shapes and data distributions (uniform, clustered, lattice with exact ties, duplicated
+points, large offsets, wide dynamic range), every index / distance / feature compared bit for bit with the CPU oracle (the chamfer loss to 1e-5 relative).
+
+  python tools/fuzz_parity.py [--seconds 300] [--seed 1]        exit code 1 on the first mismatch (case is printed)
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import flux3d_jl_amd as fx  # noqa: E402
+import oracle as orc  # noqa: E402
+
+
+def cloud(rng, D, N, B, kind):
+    if kind == "uniform":
+        x = rng.random((D, N, B))
+    elif kind == "normal":
+        x = rng.standard_normal((D, N, B))
+    elif kind == "clustered":
+        c = rng.standard_normal((D, 1 + N // 50, B)) * 3
+        x = c[:, rng.integers(0, c.shape[1], N), :] + rng.standard_normal((D, N, B)) * 0.05
+    elif kind == "lattice":
+        x = rng.integers(0, 6, (D, N, B)).astype(np.float64) * 0.25
+    elif kind == "dupes":
+        x = rng.random((D, N, B))
+        x[:, N // 2:, :] = x[:, : N - N // 2, :]
+    elif kind == "offset":
+        x = rng.standard_normal((D, N, B)) + rng.choice([5.0, 50.0, 1000.0])
+    else:  # "range": a few far outliers
+        x = rng.standard_normal((D, N, B)) * 1e-2
+        x[:, rng.integers(0, N, 3), :] *= 1e5
+    return np.asfortranarray(x.astype(np.float32))
+
+
+KINDS = ["uniform", "normal", "clustered", "lattice", "dupes", "offset", "range"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t0, ncase = time.time(), 0
+    while time.time() - t0 < args.seconds:
+        kind = KINDS[int(rng.integers(0, len(KINDS)))]
+        what = int(rng.integers(0, 4))
+        B = int(rng.integers(1, 4))
+        if what == 0:  # 1-NN both directions + chamfer
+            N, M = int(rng.integers(1, 3000)), int(rng.integers(1, 3000))
+            x, y = cloud(rng, 3, N, B, kind), cloud(rng, 3, M, B, kind)
+            desc = f"nn1 {kind} N={N} M={M} B={B}"
+            ix, iy = fx.nearest_neighbors(fx.gpu(x), fx.gpu(y))
+            ox, oy = orc.nn1(x, y)
+            ok = np.array_equal(ix.to_host(), ox) and np.array_equal(iy.to_host(), oy)
+            if ok:
+                got = fx.chamfer_distance(fx.gpu(x), fx.gpu(y), w1=0.7, w2=1.3)
+                exp = orc.chamfer_distance(x, y, 0.7, 1.3)
+                ok = bool(np.isclose(got, exp, rtol=1e-5, atol=0))  # the loss: 1e-5 relative (Float64 partial-sum order)
+                if not ok:
+                    desc += f" [indices equal; loss {got!r} vs oracle {exp!r}]"
+            else:
+                desc += " [indices differ]"
+        elif what == 1:  # kNN D = 3
+            N, M = int(rng.integers(1, 1500)), int(rng.integers(2, 6000))
+            k = int(rng.integers(1, min(33, M)))
+            drop = bool(rng.integers(0, 2)) and k + 1 <= min(32, M)
+            x, y = cloud(rng, 3, N, B, kind), cloud(rng, 3, M, B, kind)
+            desc = f"knn3 {kind} N={N} M={M} B={B} k={k} drop={drop}"
+            gi, gd = fx.knn(fx.gpu(x), k, y=fx.gpu(y), drop_first=drop)
+            oi, od = orc.knn(x, k, y=y, drop_first=drop)
+            ok = np.array_equal(gi.to_host(), oi) and np.array_equal(gd.to_host(), od)
+        elif what == 2:  # kNN feature space
+            D = int(rng.choice([4, 8, 16, 32, 64, 64, 96, 128, 20, 7]))
+            N, M = int(rng.integers(1, 400)), int(rng.integers(64, 1500))
+            k = int(rng.integers(1, 32))
+            x, y = cloud(rng, D, N, B, kind), cloud(rng, D, M, B, kind)
+            desc = f"knnF {kind} D={D} N={N} M={M} B={B} k={k}"
+            gi, gd = fx.knn(fx.gpu(x), k, y=fx.gpu(y))
+            oi, od = orc.knn(x, k, y=y)
+            ok = np.array_equal(gi.to_host(), oi) and np.array_equal(gd.to_host(), od)
+        else:  # EdgeConv graph build, first layer (fused kernel) and a feature layer
+            F = int(rng.choice([3, 3, 16, 64]))
+            N = int(rng.integers(70, 700))
+            K = int(rng.integers(1, 31))
+            x = cloud(rng, F, N, B, kind)
+            desc = f"edgeconv {kind} F={F} N={N} B={B} K={K}"
+            lay = int(rng.integers(0, 2))
+            out, idx = fx.edgeconv_graph(fx.gpu(x), K, layout=("cat", "mlp")[lay], return_idx=True)
+            oi = orc.knn(x, K, drop_first=True, want_dist=False)
+            ok = np.array_equal(idx.to_host(), oi) and np.array_equal(out.to_host(), orc.edge_features(x, oi, layout=lay))
+        ncase += 1
+        if not ok:
+            print("MISMATCH:", desc, "seed", args.seed, "case", ncase, flush=True)
+            return 1
+    print(f"{ncase} random cases in {time.time() - t0:.0f} s: all bit-identical to the oracle", flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
