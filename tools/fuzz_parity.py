@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep beyond the test-suite: nearest neighbours, chamfer sums, kNN (D = 3 and feature space) and
-EdgeConv features on random shapes and data distributions (uniform, clustered, lattice with exact ties, duplicated
+EdgeConv features and the mesh ops (areas, sampler, losses) on random shapes and data distributions (uniform, clustered, lattice with exact ties, duplicated
 points, large offsets, wide dynamic range), every index / distance / feature compared bit for bit with the CPU oracle (the chamfer loss to 1e-5 relative).
 
   python tools/fuzz_parity.py [--seconds 300] [--seed 1]        exit code 1 on the first mismatch (case is printed)
@@ -43,6 +43,43 @@ def cloud(rng, D, N, B, kind):
 KINDS = ["uniform", "normal", "clustered", "lattice", "dupes", "offset", "range"]
 
 
+def mesh_batch(rng):
+    """Ragged batch of random triangle soups over shared vertices (1-based faces like the reference), with thin,
+    zero-area and repeated faces."""
+    vl, fl = [], []
+    for _ in range(int(rng.integers(1, 5))):
+        V, F = int(rng.integers(4, 500)), int(rng.integers(2, 1200))
+        v = rng.standard_normal((3, V)).astype(np.float32) * np.float32(rng.choice([1e-3, 1.0, 50.0]))
+        f = np.stack([rng.choice(V, 3, replace=False) for _ in range(F)], axis=1).astype(np.uint32) + 1
+        if F > 4:
+            v[:, f[1, 0] - 1] = v[:, f[0, 0] - 1]
+            f[:, 3] = f[:, 2]
+        vl.append(np.asfortranarray(v))
+        fl.append(np.asfortranarray(f))
+    return vl, fl
+
+
+def mesh_case(rng):
+    """Areas, sampler (CDF + draws + points, bit exact), both mesh losses (1e-5 relative)."""
+    vl, fl = mesh_batch(rng)
+    m = fx.gpu(fx.TriMesh(vl, fl))
+    v = m.get_verts_packed_host()
+    f0 = m.get_faces_packed().astype(np.int64) - 1
+    ok = np.array_equal(fx.compute_faces_areas_packed(m).to_host().ravel(), orc.faces_areas_packed(v, f0))
+    e0 = m.get_edges_packed().astype(np.int64) - 1
+    rowptr, colind, vals = m.get_laplacian_packed()
+    ok = ok and bool(np.isclose(fx.laplacian_loss(m), orc.laplacian_loss(v, rowptr.astype(np.int64), colind.astype(np.int64), vals),
+                                rtol=1e-5, atol=1e-30))
+    ok = ok and bool(np.isclose(fx.edge_loss(m, 0.1), orc.edge_loss(v, e0, 0.1), rtol=1e-5, atol=1e-30))
+    n, seed = int(rng.integers(1, 900)), int(rng.integers(0, 1 << 62))
+    out, fi, r1, r2 = fx.sample_points(m, n, seed=seed, return_draws=True)
+    eo, efi, er1, er2 = orc.sample_points_seeded(m.get_verts_padded_host(), m.get_faces_padded().astype(np.int64) - 1,
+                                                 m._faces_len, n, seed, return_draws=True)
+    ok = ok and np.array_equal(fi.to_host(), efi) and np.array_equal(r1.to_host(), er1) and np.array_equal(r2.to_host(), er2)
+    ok = ok and np.array_equal(out.to_host(), eo)
+    return ok, f"mesh batch of {m.N} (V={m.V} F={m.F}) n={n} seed={seed}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300.0)
@@ -52,9 +89,11 @@ def main():
     t0, ncase = time.time(), 0
     while time.time() - t0 < args.seconds:
         kind = KINDS[int(rng.integers(0, len(KINDS)))]
-        what = int(rng.integers(0, 4))
+        what = int(rng.integers(0, 5))
         B = int(rng.integers(1, 4))
-        if what == 0:  # 1-NN both directions + chamfer
+        if what == 4:
+            ok, desc = mesh_case(rng)
+        elif what == 0:  # 1-NN both directions + chamfer
             N, M = int(rng.integers(1, 3000)), int(rng.integers(1, 3000))
             x, y = cloud(rng, 3, N, B, kind), cloud(rng, 3, M, B, kind)
             desc = f"nn1 {kind} N={N} M={M} B={B}"
