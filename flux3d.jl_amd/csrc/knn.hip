@@ -1261,7 +1261,7 @@ fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int 
 // survivors; candidate and query rows are gathered from L2.
 constexpr int kMLCap = 40;        // rows of a lane's mask list (39 usable + the scratch head)
 constexpr int kMKeyCap = 60;      // survivors per query handled by the fast path
-constexpr int kMKeyStride = 64;   // row stride of the key arrays in words
+constexpr int kMKeyStride = 68;   // row stride of the key arrays in words: 32 queries x b128 reads without bank conflicts
 
 // fp16-split staging of a candidate chunk (producer side, F16 filter): unit = (row, group of 8 dimensions).
 // A thread converts two float4 of a row (scaled by sc) into one hi piece and one lo piece of 8 halves each.
@@ -1849,17 +1849,42 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     }
     __syncthreads();
     KNN_PROBE_MARK(24);
-    if (!consumer || !wave_active) return;
-    // (5) consumers: verify (count and rank sum, see knn_f16_d3_kernel), write the answer, re-rank tied queries
-    const bool slowq = qi < N && !fast;
-    const bool bad = qi < N && fast && qbelow[cw * 32 + jl] != kk + ((kk * (kk - 1) / 2) << 8);  // (n >= kk here)
-    if (qi < N && fast && !bad) {
-        for (int r = drop + h; r < kk; r += 2) {  // slots [drop, kk) are the answer, in order
-            const unsigned long long key = slots[r];
-            idx[((size_t)b * N + qi) * k + r - drop] = (int)(unsigned int)key;
-            if (dist) dist[((size_t)b * N + qi) * k + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
+    // (5) verify (count and rank sum, see knn_f16_d3_kernel); slots [drop, kk) are the answer, in order: the query's
+    //     four lanes share the writes, 16 bytes at a time
+    const bool bad = wave_active && qi < N && fast && qbelow[cw * 32 + jl] != kk + ((kk * (kk - 1) / 2) << 8);  // (n >= kk here)
+    if (wave_active && qi < N && fast && !bad) {
+        const size_t obase = ((size_t)b * N + qi) * k;
+        if ((k & 3) == 0 && ((reinterpret_cast<uintptr_t>(idx) | (dist ? reinterpret_cast<uintptr_t>(dist) : 0)) & 15) == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int v = part + 4 * u;
+                if (4 * v < k) {
+                    unsigned long long key[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) key[e] = slots[drop + 4 * v + e];
+                    *reinterpret_cast<int4 *>(idx + obase + 4 * v) =
+                        int4{(int)(unsigned int)key[0], (int)(unsigned int)key[1], (int)(unsigned int)key[2], (int)(unsigned int)key[3]};
+                    if (dist)
+                        *reinterpret_cast<float4 *>(dist + obase + 4 * v) =
+                            float4{__builtin_bit_cast(float, (unsigned int)(key[0] >> 32)), __builtin_bit_cast(float, (unsigned int)(key[1] >> 32)),
+                                   __builtin_bit_cast(float, (unsigned int)(key[2] >> 32)), __builtin_bit_cast(float, (unsigned int)(key[3] >> 32))};
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = drop + part + 4 * u;
+                if (r < kk) {
+                    const unsigned long long key = slots[r];
+                    idx[obase + r - drop] = (int)(unsigned int)key;
+                    if (dist) dist[obase + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
+                }
+            }
         }
     }
+    if (!consumer || !wave_active) return;
+    // consumers: tied queries are ranked again on the full keys, leftovers take the exact merge
+    const bool slowq = qi < N && !fast;
     const unsigned long long badmask = __ballot(bad);
     for (unsigned int bm = (unsigned int)badmask | (unsigned int)(badmask >> 32); bm; bm &= bm - 1) {
         const int j = __builtin_ctz(bm);  // a tie in the distance among the first kk of query j
