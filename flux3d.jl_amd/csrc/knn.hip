@@ -1737,14 +1737,19 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         const int meta = lcnt[cw * 64 + lane];
         int pos = meta & 0xffff;
         const int nv = meta >> 16;
-        for (int e = 0; e < nv; ++e) {
-            const unsigned int w = (unsigned int)mylist[e * 64];
-            unsigned int m = w & 0xffffu;
-            const int rowbase = (int)(w >> 16) * 32 + 4 * h;
-            while (m) {
-                const int r = __builtin_ctz(m);
-                m &= m - 1;
-                qj[pos++] = rowbase + (r & 3) + 8 * (r >> 2);
+        for (int e0 = 0; e0 < nv; e0 += 4) {  // four list words in flight
+            unsigned int w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = (unsigned int)mylist[(e0 + u < kMLCap ? e0 + u : kMLCap - 1) * 64];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                unsigned int m = e0 + u < nv ? (w[u] & 0xffffu) : 0u;
+                const int rowbase = (int)(w[u] >> 16) * 32 + 4 * h;
+                while (m) {
+                    const int r = __builtin_ctz(m);
+                    m &= m - 1;
+                    qj[pos++] = rowbase + (r & 3) + 8 * (r >> 2);
+                }
             }
         }
         if (h) { qd[n] = 0xffffffffu; qd[n + 1] = 0xffffffffu; qd[n + 2] = 0xffffffffu;
