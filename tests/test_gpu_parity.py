@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -1020,6 +1020,32 @@ def test_knn_d3_wave_split_cases(gpu_fx, oracle, M, k, drop):
     idx, dist = gpu_fx.knn(x, k, y=y, drop_first=drop)
     oi, od = oracle.knn(x, k, y=y, drop_first=drop)
     assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+
+
+def test_c_abi_example_runs_on_the_device(gpu_fx, oracle, tmp_path):
+    """examples/c_abi_example.c (plain C against the shared library, no Python in the call path) prints the oracle's
+    loss for its LCG clouds."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "c_abi_example")
+    libdir = os.path.dirname(gpu_fx.LIB_PATH)
+    subprocess.run([gcc, "-std=c99", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_example.c"),
+                    "-o", exe, "-L", libdir, "-lflux3d_hip", "-Wl,-rpath," + libdir], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = float(r.stdout.split("chamfer_distance(A, B) = ")[1].split()[0])
+    s = np.uint32(12345)
+    vals = np.empty(2 * 3 * 1024 * 2, np.float32)
+    with np.errstate(over="ignore"):
+        for i in range(vals.size):
+            s = np.uint32(s * np.uint32(1664525) + np.uint32(1013904223))
+            vals[i] = np.float32(s >> np.uint32(8)) * np.float32(1.0 / 16777216.0)
+    x = np.asfortranarray(vals[: 3 * 1024 * 2].reshape((3, 1024, 2), order="F"))
+    y = np.asfortranarray(vals[3 * 1024 * 2:].reshape((3, 1024, 2), order="F"))
+    assert np.isclose(got, oracle.chamfer_distance(x, y, 1.0, 1.0), rtol=1e-5)
 
 
 def test_interleaved_calls_share_state_correctly(gpu_fx, oracle):
