@@ -1307,15 +1307,17 @@ __device__ __forceinline__ int knn_hpiece_off(int row, int c) {
 // Converts and stores the units; the G = DP/8 consecutive lanes that hold one row also sum its scaled norm
 // (3..4 butterfly steps).  norms != nullptr: phase A, norms[row] and the running maximum are recorded.
 template <int DK, bool SPLIT, int kMUnits>
-__device__ __forceinline__ void knn_f16_store_chunk(float *img, int CH, int cn, float sc, int ptid,
+__device__ __forceinline__ void knn_f16_store_chunk(float *img, int CH, int cn, float sc, const float (&mu8)[8], int ptid,
                                                     const float4 (&reg)[kMUnits][2], float *norms, float &tmax, bool &tnan) {
     constexpr int DP = DK * 32, G = DP / 8, PPR = DK * 8;
+    static_assert(kMProd % G == 0, "a producer thread always converts the same group of eight dimensions (mu8)");
 #pragma unroll
     for (int u = 0; u < kMUnits; ++u) {
         const int un = ptid + u * kMProd;
         const int row = un / G, g = un - row * G;
-        const float v[8] = {reg[u][0].x * sc, reg[u][0].y * sc, reg[u][0].z * sc, reg[u][0].w * sc,
-                            reg[u][1].x * sc, reg[u][1].y * sc, reg[u][1].z * sc, reg[u][1].w * sc};
+        const float v[8] = {(reg[u][0].x - mu8[0]) * sc, (reg[u][0].y - mu8[1]) * sc, (reg[u][0].z - mu8[2]) * sc,
+                            (reg[u][0].w - mu8[3]) * sc, (reg[u][1].x - mu8[4]) * sc, (reg[u][1].y - mu8[5]) * sc,
+                            (reg[u][1].z - mu8[6]) * sc, (reg[u][1].w - mu8[7]) * sc};
         kh8 hi, lo;
         float part = 0.0f;
 #pragma unroll
@@ -1366,7 +1368,8 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     int *qflag = qn_n + kMWaves * 32;                                      // [kMWaves][32]  1 = fast path
     int *qbelow = qflag + kMWaves * 32;                                    // [kMWaves][32]  entries with rank < kk
     unsigned int *cmax = reinterpret_cast<unsigned int *>(qbelow + kMWaves * 32);  // bits of max |c|^2 (>= 0)
-    float *nall = reinterpret_cast<float *>(cmax + 4);                     // [nchunk*CH] all candidate norms (keep_norms)
+    float *mu = reinterpret_cast<float *>(cmax + 4);                       // [DP] F16: per-dimension centre of the cloud
+    float *nall = mu + DP;                                                 // [nchunk*CH] all candidate norms (keep_norms)
 
     // block L runs on XCD L % 8: give every cloud's blocks ids with equal L % 8 so that its candidates stay in
     // one L2 (8 or more clouds; fewer: plain order, a cloud's blocks spread over all XCDs)
@@ -1394,26 +1397,72 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     if (tid == 0) *cmax = 0u;
     float sc = 1.0f;  // F16: power-of-two scale with |sc * c| < 1 for every candidate
     if (F16) {
-        // ---- scale: largest |coordinate| of the cloud, one coalesced pass (F16 => 16-byte loads are legal) ----
+        // ---- centre and scale: per-dimension mid-range mu and the largest |c - mu| of the cloud, one coalesced pass
+        //      (F16 => 16-byte loads are legal).  Distances do not depend on the origin, the fp16 band does: it grows
+        //      with |q~|^2 + |c~|^2, so a common offset of a few standard deviations would flood the lists.
+        //      Thread t always sees the same four dimensions when the block size is a multiple of D/4.
         __syncthreads();
-        float amax = 0.0f;
+        const int rq = D / 4;
+        const bool centre = (kMThreads % rq) == 0 && rq <= 32;
+        float4 lo4 = float4{INFINITY, INFINITY, INFINITY, INFINITY}, hi4 = float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         bool tnan = false;
         const float4 *c4 = reinterpret_cast<const float4 *>(yb);
         const int total4 = M * (D / 4);
         for (int e0 = tid; e0 < total4; e0 += 8 * kMThreads) {
             float4 v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = c4[e0 + e * kMThreads < total4 ? e0 + e * kMThreads : 0];
+            for (int e = 0; e < 8; ++e) v[e] = c4[e0 + e * kMThreads < total4 ? e0 + e * kMThreads : e0];  // (clamped: same dimensions)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float m4 = fmaxf(fmaxf(fabsf(v[e].x), fabsf(v[e].y)), fmaxf(fabsf(v[e].z), fabsf(v[e].w)));
-                tnan |= (m4 != m4);
-                amax = fmaxf(amax, m4);
+                // NaN or +-inf coordinates: no scale exists, every query of the block takes the exact path
+                tnan |= !(fmaxf(fmaxf(fabsf(v[e].x), fabsf(v[e].y)), fmaxf(fabsf(v[e].z), fabsf(v[e].w))) < INFINITY) || v[e].x != v[e].x ||
+                        v[e].y != v[e].y || v[e].z != v[e].z || v[e].w != v[e].w;
+                lo4.x = fminf(lo4.x, v[e].x); lo4.y = fminf(lo4.y, v[e].y); lo4.z = fminf(lo4.z, v[e].z); lo4.w = fminf(lo4.w, v[e].w);
+                hi4.x = fmaxf(hi4.x, v[e].x); hi4.y = fmaxf(hi4.y, v[e].y); hi4.z = fmaxf(hi4.z, v[e].z); hi4.w = fmaxf(hi4.w, v[e].w);
             }
+        }
+        const bool anynan = __syncthreads_or(tnan) != 0;
+        float *red = sm;  // [kMThreads / 64][32][8] scratch in the (still unused) chunk buffers
+        if (centre) {
+            for (int m = rq; m < 64; m <<= 1) {  // lanes with equal lane % rq hold the same dimensions
+                lo4.x = fminf(lo4.x, __shfl_xor(lo4.x, m, 64)); lo4.y = fminf(lo4.y, __shfl_xor(lo4.y, m, 64));
+                lo4.z = fminf(lo4.z, __shfl_xor(lo4.z, m, 64)); lo4.w = fminf(lo4.w, __shfl_xor(lo4.w, m, 64));
+                hi4.x = fmaxf(hi4.x, __shfl_xor(hi4.x, m, 64)); hi4.y = fmaxf(hi4.y, __shfl_xor(hi4.y, m, 64));
+                hi4.z = fmaxf(hi4.z, __shfl_xor(hi4.z, m, 64)); hi4.w = fmaxf(hi4.w, __shfl_xor(hi4.w, m, 64));
+            }
+            if (lane < rq) {
+                float *r8 = red + (size_t)(wv * 32 + lane) * 8;
+                r8[0] = lo4.x; r8[1] = lo4.y; r8[2] = lo4.z; r8[3] = lo4.w;
+                r8[4] = hi4.x; r8[5] = hi4.y; r8[6] = hi4.z; r8[7] = hi4.w;
+            }
+        }
+        __syncthreads();
+        float amax = 0.0f;
+        if (centre) {
+            if (tid < rq) {
+                float lo[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, hi[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                for (int w = 0; w < kMThreads / 64; ++w) {
+                    const float *r8 = red + (size_t)(w * 32 + tid) * 8;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { lo[c] = fminf(lo[c], r8[c]); hi[c] = fmaxf(hi[c], r8[4 + c]); }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float m0 = 0.5f * lo[c] + 0.5f * hi[c];
+                    mu[4 * tid + c] = m0;
+                    amax = fmaxf(amax, fmaxf(hi[c] - m0, m0 - lo[c]));
+                }
+            } else if (tid < DP / 4) {
+                mu[4 * tid] = 0.0f; mu[4 * tid + 1] = 0.0f; mu[4 * tid + 2] = 0.0f; mu[4 * tid + 3] = 0.0f;
+            }
+        } else {
+            if (tid < DP / 4) { mu[4 * tid] = 0.0f; mu[4 * tid + 1] = 0.0f; mu[4 * tid + 2] = 0.0f; mu[4 * tid + 3] = 0.0f; }
+            if (tid < total4)  // (threads without an element hold +-inf)
+                amax = fmaxf(fmaxf(fmaxf(fabsf(lo4.x), fabsf(hi4.x)), fmaxf(fabsf(lo4.y), fabsf(hi4.y))),
+                             fmaxf(fmaxf(fabsf(lo4.z), fabsf(hi4.z)), fmaxf(fabsf(lo4.w), fabsf(hi4.w))));
         }
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m, 64));
-        const bool anynan = __ballot(tnan) != 0;
         if (lane == 0) atomicMax(cmax, anynan ? 0x7fc00000u : __builtin_bit_cast(unsigned int, amax));
         __syncthreads();
         const float cinf = __builtin_bit_cast(float, *cmax);
@@ -1463,7 +1512,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                 const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float qs_ = v[e] * sc;
+                    const float qs_ = (v[e] - mu[16 * bb + 8 * h + e]) * sc;  // centred like the candidates
                     qn = qn + qs_ * qs_;
                     const float av = -2.0f * qs_;
                     amax = fmaxf(amax, fabsf(av));
@@ -1495,6 +1544,12 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     const int nstep = 2 * nchunk;
     constexpr int kMUnits = SPLIT ? kMUnitsSplit : kMUnitsSingle;
     float4 preg[kMUnits][2];  // F16 producers: the chunk after next, loaded one step ahead
+    float mu8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // F16 producers: centre of this thread's eight dimensions
+    if (F16 && !consumer) {
+        const int g = ptid % (DP / 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mu8[e] = mu[8 * g + e];
+    }
     float pmax = 0.0f;        // F16 producers: largest scaled norm seen
     bool pnan = false;
     int stage_ev = 0;                    // F16 producers: staging events done (chunks 0..n-1, n-2..0)
@@ -1502,7 +1557,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     if (F16) {
         if (!consumer) {
             knn_f16_load_chunk<DK, kMUnits>(yb, D, 0, M < CH ? M : CH, CH, ptid, preg);
-            knn_f16_store_chunk<DK, SPLIT, kMUnits>(sm, CH, M < CH ? M : CH, sc, ptid, preg, nall, pmax, pnan);
+            knn_f16_store_chunk<DK, SPLIT, kMUnits>(sm, CH, M < CH ? M : CH, sc, mu8, ptid, preg, nall, pmax, pnan);
             if (nchunk == 1) {
 #pragma unroll
                 for (int m = 1; m < 64; m <<= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, m, 64));
@@ -1647,7 +1702,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             float *img = sm + (size_t)(1 - cur) * buf_floats;
             if (F16) {
                 // the registers hold chunk ci_next (loaded one step ago); then fetch the chunk after it
-                knn_f16_store_chunk<DK, SPLIT, kMUnits>(img, CH, cnn, sc, ptid, preg, stage_ev < nchunk ? nall + (size_t)stage_ev * CH : nullptr,
+                knn_f16_store_chunk<DK, SPLIT, kMUnits>(img, CH, cnn, sc, mu8, ptid, preg, stage_ev < nchunk ? nall + (size_t)stage_ev * CH : nullptr,
                                         pmax, pnan);
                 if (stage_ev == nchunk - 1) {  // last phase-A chunk: publish this wave's maximum norm
 #pragma unroll
@@ -2068,6 +2123,7 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     size_t fixed = (size_t)kMWaves * kMLCap * 64 * 4 + (size_t)kMWaves * 64 * 4 + (size_t)3 * kMWaves * 32 * 4 + 64;
     static_assert(kMWaves * 32 * 33 * 8 + kMWaves * 128 * 4 <= kMWaves * kMLCap * 64 * 4, "rank slots + fallback scratch alias the mask lists");
     const int keep_norms = M <= 4096;  // all candidate norms stay in LDS: phase B does not recompute them
+    fixed += (size_t)DP * 4;  // per-dimension centre
     if (keep_norms) fixed += (size_t)((M + 255) / 256 * 256 + 256) * 4;
     const size_t budget = 150 * 1024 - fixed;                                  // floats*4 for the two chunk buffers
     int CH = (int)(budget / 2 / ((size_t)RSI * 4 + 4)) / 64 * 64;
