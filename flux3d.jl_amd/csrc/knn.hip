@@ -1406,6 +1406,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         const bool centre = (kMThreads % rq) == 0 && rq <= 32;
         float4 lo4 = float4{INFINITY, INFINITY, INFINITY, INFINITY}, hi4 = float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         bool tnan = false;
+        float poison = 0.0f;
         const float4 *c4 = reinterpret_cast<const float4 *>(yb);
         const int total4 = M * (D / 4);
         for (int e0 = tid; e0 < total4; e0 += 8 * kMThreads) {
@@ -1414,13 +1415,14 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             for (int e = 0; e < 8; ++e) v[e] = c4[e0 + e * kMThreads < total4 ? e0 + e * kMThreads : e0];  // (clamped: same dimensions)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                // NaN or +-inf coordinates: no scale exists, every query of the block takes the exact path
-                tnan |= !(fmaxf(fmaxf(fabsf(v[e].x), fabsf(v[e].y)), fmaxf(fabsf(v[e].z), fabsf(v[e].w))) < INFINITY) || v[e].x != v[e].x ||
-                        v[e].y != v[e].y || v[e].z != v[e].z || v[e].w != v[e].w;
-                lo4.x = fminf(lo4.x, v[e].x); lo4.y = fminf(lo4.y, v[e].y); lo4.z = fminf(lo4.z, v[e].z); lo4.w = fminf(lo4.w, v[e].w);
-                hi4.x = fmaxf(hi4.x, v[e].x); hi4.y = fmaxf(hi4.y, v[e].y); hi4.z = fmaxf(hi4.z, v[e].z); hi4.w = fmaxf(hi4.w, v[e].w);
+                // NaN or +-inf coordinates (x * 0 is NaN for them): no scale exists, every query takes the exact path
+                poison = __builtin_fmaf(v[e].x, 0.0f, poison); poison = __builtin_fmaf(v[e].y, 0.0f, poison);
+                poison = __builtin_fmaf(v[e].z, 0.0f, poison); poison = __builtin_fmaf(v[e].w, 0.0f, poison);
+                lo4.x = vmin_f32(lo4.x, v[e].x); lo4.y = vmin_f32(lo4.y, v[e].y); lo4.z = vmin_f32(lo4.z, v[e].z); lo4.w = vmin_f32(lo4.w, v[e].w);
+                hi4.x = vmax_f32(hi4.x, v[e].x); hi4.y = vmax_f32(hi4.y, v[e].y); hi4.z = vmax_f32(hi4.z, v[e].z); hi4.w = vmax_f32(hi4.w, v[e].w);
             }
         }
+        tnan = poison != poison;
         const bool anynan = __syncthreads_or(tnan) != 0;
         float *red = sm;  // [kMThreads / 64][32][8] scratch in the (still unused) chunk buffers
         if (centre) {
