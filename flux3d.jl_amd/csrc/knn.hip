@@ -430,23 +430,57 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
     bd = INFINITY;
     bj = 0x7fffffff;
     const int cap = 64 - kk;
+    const bool vec4 = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(yb)) & 15) == 0;
     for (int j0 = 0; j0 < M; j0 += 1024) {
         float d[16];
         float lmin = INFINITY;
+        if (vec4) {
+            // rows as 16-byte pieces, four candidates in flight (dimension order kept: x, y, z, w of every piece)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int j = j0 + lane + 64 * i;
-            d[i] = INFINITY;
-            if (j < M) {
-                const float *c = yb + (size_t)j * D;
-                float s = 0.0f;
-                for (int dd = 0; dd < D; ++dd) {
-                    const float t = q[dd] - c[dd];
-                    s = s + t * t;
+            for (int i0 = 0; i0 < 16; i0 += 4) {
+                const float *c[4];
+                float sacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + lane + 64 * (i0 + u);
+                    c[u] = yb + (size_t)(j < M ? j : M - 1) * D;
                 }
-                d[i] = s;
+                for (int dd = 0; dd < D; dd += 4) {
+                    const float4 qv = *reinterpret_cast<const float4 *>(q + dd);
+                    float4 cv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) cv[u] = *reinterpret_cast<const float4 *>(c[u] + dd);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float t0 = qv.x - cv[u].x, t1 = qv.y - cv[u].y, t2 = qv.z - cv[u].z, t3 = qv.w - cv[u].w;
+                        sacc[u] = sacc[u] + t0 * t0;
+                        sacc[u] = sacc[u] + t1 * t1;
+                        sacc[u] = sacc[u] + t2 * t2;
+                        sacc[u] = sacc[u] + t3 * t3;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    d[i0 + u] = j0 + lane + 64 * (i0 + u) < M ? sacc[u] : INFINITY;
+                    lmin = fminf(lmin, d[i0 + u]);
+                }
             }
-            lmin = fminf(lmin, d[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int j = j0 + lane + 64 * i;
+                d[i] = INFINITY;
+                if (j < M) {
+                    const float *c = yb + (size_t)j * D;
+                    float s = 0.0f;
+                    for (int dd = 0; dd < D; ++dd) {
+                        const float t = q[dd] - c[dd];
+                        s = s + t * t;
+                    }
+                    d[i] = s;
+                }
+                lmin = fminf(lmin, d[i]);
+            }
         }
         float tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bd), kk - 1));
         if (j0 == 0) {  // kk-th smallest lane minimum bounds the kk-th smallest distance
@@ -1177,9 +1211,10 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
         }
     }
     KNN_PROBE_MARK(10);
-    if (half != 0 || !wave_active) return;  // the first wave of every group finishes its 32 queries: ties, leftovers
+    if (!wave_active) return;
+    // ties are ranked again by the group's first wave; the leftovers (exact merge) are shared by its two waves
     const bool slowq = qi < N && !fast;
-    const unsigned long long badmask = __ballot(bad), slowmask = __ballot(slowq);
+    const unsigned long long badmask = half == 0 ? __ballot(bad) : 0ull, slowmask = __ballot(slowq);
     if ((badmask | slowmask) == 0) return;
     for (unsigned int bm = (unsigned int)badmask | (unsigned int)(badmask >> 32); bm; bm &= bm - 1) {
         // a tie in the distance among the first kk of query j: the whole wave ranks its keys again, on (distance, index)
@@ -1198,9 +1233,9 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
         }
     }
     // leftovers, wave-cooperative (scratch: behind the slots)
-    int *wscratch = lists_all + kTGroups * 32 * 33 * 2 + grp * 128;
+    int *wscratch = lists_all + kTGroups * 32 * 33 * 2 + wv * 128;
     const unsigned int slow32 = (unsigned int)slowmask | (unsigned int)(slowmask >> 32);
-    for (int j = 0; j < 32; ++j) {
+    for (int j = half; j < 32; j += 2) {
         if (!((slow32 >> j) & 1u) || q0 + j >= N) continue;
         float bd;
         int bj;
@@ -1225,7 +1260,7 @@ fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int 
     if (img < keys) img = keys;
     const size_t fixed = (size_t)kTWaves * kTCap * 64 * 4 + (size_t)kTGroups * 32 * 8 * 4;  // lists (exchange, slots) + counters
     static_assert((size_t)kTWaves * 32 * 33 * 4 <= (size_t)kTWaves * kTCap * 64 * 4, "the tau exchange aliases the lists");
-    static_assert((size_t)kTGroups * 32 * 33 * 8 + kTGroups * 128 * 4 <= (size_t)kTWaves * kTCap * 64 * 4, "slots + scratch alias the lists");
+    static_assert((size_t)kTGroups * 32 * 33 * 8 + kTWaves * 128 * 4 <= (size_t)kTWaves * kTCap * 64 * 4, "slots + scratch alias the lists");
     const int raw_ok = M <= kTRawMax && img + fixed + (size_t)M * 16 <= 152 * 1024;
     const size_t lds = img + fixed + (raw_ok ? (size_t)M * 16 : 0);
     const fx3d_status arc = feat ? ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_f16_d3_kernel<true>), 156 * 1024, "knn_f16_d3_kernel<feat>")
@@ -1944,10 +1979,11 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             }
         }
     }
-    if (!consumer || !wave_active) return;
-    // consumers: tied queries are ranked again on the full keys, leftovers take the exact merge
+    if (!wave_active) return;
+    // tied queries are ranked again on the full keys by the consumer wave; the leftovers (exact merge) are shared by
+    // the consumer wave and its producer partner
     const bool slowq = qi < N && !fast;
-    const unsigned long long badmask = __ballot(bad);
+    const unsigned long long badmask = consumer ? __ballot(bad) : 0ull;
     for (unsigned int bm = (unsigned int)badmask | (unsigned int)(badmask >> 32); bm; bm &= bm - 1) {
         const int j = __builtin_ctz(bm);  // a tie in the distance among the first kk of query j
         const int qs = cw * 32 + j;
@@ -1962,10 +1998,10 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         }
     }
     // leftovers (overflowing lists, non-finite bands), wave-cooperative (scratch: behind all the slots)
-    int *wscratch = lists + kMWaves * 32 * 33 * 2 + cw * 128;
+    int *wscratch = lists + kMWaves * 32 * 33 * 2 + wv * 128;
     const unsigned long long slowmask = __ballot(slowq);
     const unsigned int slow32 = (unsigned int)slowmask | (unsigned int)(slowmask >> 32);
-    for (int j = 0; j < 32; ++j) {
+    for (int j = consumer ? 0 : 1; j < 32; j += 2) {
         if (!((slow32 >> j) & 1u) || q0 + j >= N) continue;
         float bd;
         int bj;
@@ -2123,7 +2159,7 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     constexpr int DP = DK * 32, RS = DP + 4, RSI = (F16 && !SPLIT) ? DP / 2 : DP;
     // lists (later the slots) + list lengths + per-query counters + cmax
     size_t fixed = (size_t)kMWaves * kMLCap * 64 * 4 + (size_t)kMWaves * 64 * 4 + (size_t)3 * kMWaves * 32 * 4 + 64;
-    static_assert(kMWaves * 32 * 33 * 8 + kMWaves * 128 * 4 <= kMWaves * kMLCap * 64 * 4, "rank slots + fallback scratch alias the mask lists");
+    static_assert(kMWaves * 32 * 33 * 8 + 2 * kMWaves * 128 * 4 <= kMWaves * kMLCap * 64 * 4, "rank slots + fallback scratch alias the mask lists");
     const int keep_norms = M <= 4096;  // all candidate norms stay in LDS: phase B does not recompute them
     fixed += (size_t)DP * 4;  // per-dimension centre
     if (keep_norms) fixed += (size_t)((M + 255) / 256 * 256 + 256) * 4;

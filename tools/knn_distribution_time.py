@@ -1,0 +1,52 @@
+"""kNN (k = 20, self, drop first) at the C4 shapes (B = 32 x 1024; D = 3 and D = 64) on data distributions that stress
+the filter's band and the survivor lists: uniform / Gaussian, offset, tight clusters, lattice (exact ties), duplicated
+points, a far outlier.  Prints microseconds per call.   python tools/knn_distribution_time.py"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import flux3d_jl_amd as fx  # noqa: E402
+
+rng = np.random.default_rng(9)
+B, N = 32, 1024
+
+
+def make(kind, D):
+    if kind == "uniform":
+        return rng.random((D, N, B))
+    if kind == "normal":
+        return rng.standard_normal((D, N, B))
+    if kind == "normal+100":
+        return rng.standard_normal((D, N, B)) + 100.0
+    if kind == "clusters":
+        c = rng.standard_normal((D, 16, B)) * 3
+        return c[:, rng.integers(0, 16, N), :] + rng.standard_normal((D, N, B)) * 1e-3
+    if kind == "lattice":
+        return rng.integers(0, 8, (D, N, B)) * 0.125
+    if kind == "dupes":
+        x = rng.random((D, N, B))
+        x[:, N // 2:, :] = x[:, : N // 2, :]
+        return x
+    if kind == "outlier":
+        x = rng.random((D, N, B)) * 1e-2
+        x[:, 0, :] = 1e4
+        return x
+    raise KeyError(kind)
+
+
+for D in (3, 64):
+    for kind in ("uniform", "normal", "normal+100", "clusters", "lattice", "dupes", "outlier"):
+        dx = fx.gpu(np.asfortranarray(make(kind, D).astype(np.float32)))
+        for _ in range(2):
+            fx.knn(dx, 20, drop_first=True, return_dist=False)
+        fx.synchronize()
+        e0, e1 = fx.Event(), fx.Event()
+        e0.record()
+        for _ in range(5):
+            fx.knn(dx, 20, drop_first=True, return_dist=False)
+        e1.record()
+        e1.synchronize()
+        print(f"D={D:3d} {kind:12s}: {e0.elapsed_ms(e1) * 200:10.1f} us", flush=True)
