@@ -424,9 +424,11 @@ __device__ __forceinline__ int key_less_bf(float d, int j, float od, int oj) {
 // current kk-th best, candidates <= threshold compacted into a 64-entry LDS list (flushed into the best list
 // whenever it is full), one 64-lane bitonic sort on (distance, index) per merge.  kk <= 32.
 // lst_d / lst_j: 64 floats / ints of wave-private LDS.  Result: lanes 0..kk-1 hold the answer in order.
+// ids == nullptr: all M candidates; else the M candidates ids[0..M) (LDS): a query's own survivors when they exceed the
+// fast path's key capacity.
 __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q, const float *__restrict__ yb, int M,
                                                       int D, int kk, int lane, float *lst_d, int *lst_j, float &bd,
-                                                      int &bj) {
+                                                      int &bj, const int *ids = nullptr) {
     bd = INFINITY;
     bj = 0x7fffffff;
     const int cap = 64 - kk;
@@ -443,7 +445,8 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = j0 + lane + 64 * (i0 + u);
-                    c[u] = yb + (size_t)(j < M ? j : M - 1) * D;
+                    const int jc = j < M ? j : M - 1;
+                    c[u] = yb + (size_t)(ids ? ids[jc] : jc) * D;
                 }
                 for (int dd = 0; dd < D; dd += 4) {
                     const float4 qv = *reinterpret_cast<const float4 *>(q + dd);
@@ -471,7 +474,7 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
                 const int j = j0 + lane + 64 * i;
                 d[i] = INFINITY;
                 if (j < M) {
-                    const float *c = yb + (size_t)j * D;
+                    const float *c = yb + (size_t)(ids ? ids[j] : j) * D;
                     float s = 0.0f;
                     for (int dd = 0; dd < D; ++dd) {
                         const float t = q[dd] - c[dd];
@@ -497,7 +500,7 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
                 const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
                                       __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
                 const bool put = pred && pos < cap;
-                if (put) { lst_d[pos] = d[i]; lst_j[pos] = j0 + lane + 64 * i; }
+                if (put) { lst_d[pos] = d[i]; lst_j[pos] = ids ? ids[j0 + lane + 64 * i] : j0 + lane + 64 * i; }
                 const int np = __builtin_popcountll(bal);
                 const bool overflow = cnt + np > cap;
                 cnt = overflow ? cap : cnt + np;
@@ -1296,6 +1299,7 @@ fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int 
 // survivors; candidate and query rows are gathered from L2.
 constexpr int kMLCap = 40;        // rows of a lane's mask list (39 usable + the scratch head)
 constexpr int kMKeyCap = 60;      // survivors per query handled by the fast path
+constexpr int kMMedCap = 512;     // ... by the medium path: exact selection among the query's own survivors
 constexpr int kMKeyStride = 68;   // row stride of the key arrays in words: 32 queries x b128 reads without bank conflicts
 
 // fp16-split staging of a candidate chunk (producer side, F16 filter): unit = (row, group of 8 dimensions).
@@ -1404,7 +1408,8 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     int *qbelow = qflag + kMWaves * 32;                                    // [kMWaves][32]  entries with rank < kk
     unsigned int *cmax = reinterpret_cast<unsigned int *>(qbelow + kMWaves * 32);  // bits of max |c|^2 (>= 0)
     float *mu = reinterpret_cast<float *>(cmax + 4);                       // [DP] F16: per-dimension centre of the cloud
-    float *nall = mu + DP;                                                 // [nchunk*CH] all candidate norms (keep_norms)
+    int *med = reinterpret_cast<int *>(mu + DP);                           // [2 kMWaves][kMMedCap + 128] medium path: ids + merge lists
+    float *nall = reinterpret_cast<float *>(med + 2 * kMWaves * (kMMedCap + 128));  // [nchunk*CH] all candidate norms (keep_norms)
 
     // block L runs on XCD L % 8: give every cloud's blocks ids with equal L % 8 so that its candidates stay in
     // one L2 (8 or more clouds; fewer: plain order, a cloud's blocks spread over all XCDs)
@@ -1813,17 +1818,64 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         const int totp = __shfl_xor(tot, 32, 64);
         const int cntp = __shfl_xor(cnt, 32, 64);
         const int n = tot + totp;
-        const bool fast = wave_active && qi < N && thr < INFINITY && cnt <= kMLCap - 1 && cntp <= kMLCap - 1 &&
-                          n <= kMKeyCap && n >= need;
+        const bool lists_ok = wave_active && qi < N && thr < INFINITY && cnt <= kMLCap - 1 && cntp <= kMLCap - 1 && n >= need;
+        const bool fast = lists_ok && n <= kMKeyCap;
+        const bool medium = lists_ok && n > kMKeyCap && n <= kMMedCap;  // too many for the key arrays, lists intact
         lcnt[cw * 64 + lane] = (h ? totp : 0) | (nv << 16);  // start offset of this lane's ids | entries
-        if (h == 0) { qn_n[cw * 32 + jl] = n; qflag[cw * 32 + jl] = fast ? 1 : 0; qbelow[cw * 32 + jl] = 0; }
+        if (h == 0) { qn_n[cw * 32 + jl] = n; qflag[cw * 32 + jl] = fast ? 1 : (medium ? 2 : 0); qbelow[cw * 32 + jl] = 0; }
     }
     __syncthreads();  // the chunk buffers are free from here on: they hold the keys
     KNN_PROBE_MARK(21);
     unsigned int *qd = reinterpret_cast<unsigned int *>(sm) + (size_t)(cw * 32 + jl) * kMKeyStride;                       // distance bits
     int *qj = reinterpret_cast<int *>(sm) + (size_t)kMWaves * 32 * kMKeyStride + (size_t)(cw * 32 + jl) * kMKeyStride;     // indices
     const int n = qn_n[cw * 32 + jl];
-    const bool fast = qflag[cw * 32 + jl] != 0;
+    const bool fast = qflag[cw * 32 + jl] == 1;
+    const bool handled = qflag[cw * 32 + jl] == 2;  // answered by the medium path
+    if (wave_active) {
+        // ---- medium path (tight clusters, many duplicates: more candidates inside the band than the key arrays hold):
+        //      the wave decodes the query's two lane lists into an id list and selects exactly among those ids,
+        //      instead of scanning all M candidates in the fallback.  The lists are intact until the barrier after (2).
+        const unsigned long long mmask = __ballot(handled);
+        int *ids = med + wv * (kMMedCap + 128);
+        for (unsigned int bm = (unsigned int)mmask | (unsigned int)(mmask >> 32); bm; bm &= bm - 1) {
+            const int j = __builtin_ctz(bm);
+            if ((j & 1) != (consumer ? 0 : 1)) continue;  // the pair's two waves share the queries
+            int total = 0;
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int src = h2 * 32 + j;
+                const int nv2 = lcnt[cw * 64 + src] >> 16;
+                const unsigned int w = lane < nv2 ? (unsigned int)lists[(cw * kMLCap + lane) * 64 + src] : 0u;  // nv2 < 64
+                const int pc = __builtin_popcount(w & 0xffffu);
+                int incl = pc;
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) {
+                    const int t = __shfl_up(incl, m, 64);
+                    if (lane >= m) incl += t;
+                }
+                int pos = total + incl - pc;
+                unsigned int m16 = w & 0xffffu;
+                const int rowbase = (int)(w >> 16) * 32 + 4 * h2;
+                while (m16) {
+                    const int r = __builtin_ctz(m16);
+                    m16 &= m16 - 1;
+                    ids[pos++] = rowbase + (r & 3) + 8 * (r >> 2);
+                }
+                total += __shfl(incl, 63, 64);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            float bd;
+            int bj;
+            knn_exact_bruteforce(xb + (size_t)(q0 + j) * D, yb, total, D, kk, lane, reinterpret_cast<float *>(ids + kMMedCap),
+                                 ids + kMMedCap + 64, bd, bj, ids);
+            const int r = lane - drop;
+            if (r >= 0 && r < k) {
+                idx[((size_t)b * N + q0 + j) * k + r] = bj;
+                if (dist) dist[((size_t)b * N + q0 + j) * k + r] = bd;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
     // (2) consumers decode their mask words into candidate ids (integer work only)
     if (consumer && fast) {
         const int meta = lcnt[cw * 64 + lane];
@@ -1982,7 +2034,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     if (!wave_active) return;
     // tied queries are ranked again on the full keys by the consumer wave; the leftovers (exact merge) are shared by
     // the consumer wave and its producer partner
-    const bool slowq = qi < N && !fast;
+    const bool slowq = qi < N && !fast && !handled;
     const unsigned long long badmask = consumer ? __ballot(bad) : 0ull;
     for (unsigned int bm = (unsigned int)badmask | (unsigned int)(badmask >> 32); bm; bm &= bm - 1) {
         const int j = __builtin_ctz(bm);  // a tie in the distance among the first kk of query j
@@ -2162,6 +2214,7 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     static_assert(kMWaves * 32 * 33 * 8 + 2 * kMWaves * 128 * 4 <= kMWaves * kMLCap * 64 * 4, "rank slots + fallback scratch alias the mask lists");
     const int keep_norms = M <= 4096;  // all candidate norms stay in LDS: phase B does not recompute them
     fixed += (size_t)DP * 4;  // per-dimension centre
+    fixed += (size_t)2 * kMWaves * (kMMedCap + 128) * 4;  // medium path: id lists + merge scratch, one per wave
     if (keep_norms) fixed += (size_t)((M + 255) / 256 * 256 + 256) * 4;
     const size_t budget = 150 * 1024 - fixed;                                  // floats*4 for the two chunk buffers
     int CH = (int)(budget / 2 / ((size_t)RSI * 4 + 4)) / 64 * 64;

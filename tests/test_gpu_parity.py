@@ -427,6 +427,20 @@ def test_knn_fp16_filter_variants(gpu_fx, oracle, monkeypatch, env):
         assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
 
 
+@pytest.mark.parametrize("D,csize,spread", [(64, 80, 1e-3), (32, 200, 1e-4), (64, 700, 1e-3)])
+def test_knn_feature_space_clustered_data(gpu_fx, oracle, D, csize, spread):
+    """Tight clusters put more candidates inside a query's band than the fast path's key arrays hold (60): the medium
+    path selects exactly among the query's own survivors (up to 512), larger clusters take the full exact merge."""
+    rng = np.random.default_rng(D + csize)
+    N = 1024
+    centres = rng.standard_normal((D, N // csize + 1, 2)) * 3
+    x = centres[:, rng.integers(0, centres.shape[1], N), :] + rng.standard_normal((D, N, 2)) * spread
+    x = np.asfortranarray(x.astype(np.float32))
+    idx, dist = gpu_fx.knn(x, 20, drop_first=True)
+    oi, od = oracle.knn(x, 20, drop_first=True)
+    assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+
+
 def test_knn_graph_gather(gpu_fx, oracle):
     """create_knn_graph == cat([X[:, knn idx]]...) (src/models/dgcnn.jl:3-7,36): (F,K,N,B)."""
     for F in (3, 64):
