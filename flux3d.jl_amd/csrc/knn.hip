@@ -1297,6 +1297,12 @@ fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int 
 // b128 (4 k-steps); the LDS image is lane-linear, the conflict-free rotation sits on the source addresses.
 // In the exact phase all eight waves work: the four lanes of a query (two halves x consumer/producer) split its
 // survivors; candidate and query rows are gathered from L2.
+// Template modes: F16 = false: the Float32 GEMM above.  F16 = true (default for D % 4 == 0, M <= 4096): the cloud is
+// centred per dimension and scaled by a power of two, operands are fp16; SPLIT = false (default) uses the rounded halves
+// alone (one v_mfma_f32_32x32x16_f16 per K block, band 2^-10 (|q~|^2 + C~max^2)), SPLIT = true the 2-way split
+// hi*hi + lo*hi + hi*lo (band 2^-18).  Producers convert while staging.
+// Queries whose band holds more candidates than the key arrays (60) but whose lane lists are intact take the medium
+// path (exact selection among their own survivors, up to kMMedCap); the rest of the leftovers the full exact merge.
 constexpr int kMLCap = 40;        // rows of a lane's mask list (39 usable + the scratch head)
 constexpr int kMKeyCap = 60;      // survivors per query handled by the fast path
 constexpr int kMMedCap = 512;     // ... by the medium path: exact selection among the query's own survivors
