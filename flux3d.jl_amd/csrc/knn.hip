@@ -1314,7 +1314,7 @@ constexpr int kMKeyStride = 68;   // row stride of the key arrays in words: 32 q
 // (row, group) units per producer thread and chunk: CH * (DP/8) <= units * 256.  The single-piece image is half
 // the size, so its chunks can be twice as long (fewer steps: a step cannot be shorter than the latency of the
 // global loads issued one step ahead)
-constexpr int kMUnitsSplit = 6, kMUnitsSingle = 8;
+constexpr int kMUnitsSplit = 5, kMUnitsSingle = 6;
 template <int DK, int kMUnits>
 __device__ __forceinline__ void knn_f16_load_chunk(const float *__restrict__ yb, int D, int j0, int cn, int CH, int ptid,
                                                    float4 (&reg)[kMUnits][2]) {
@@ -1352,10 +1352,18 @@ __device__ __forceinline__ int knn_hpiece_off(int row, int c) {
 // Converts and stores the units; the G = DP/8 consecutive lanes that hold one row also sum its scaled norm
 // (3..4 butterfly steps).  norms != nullptr: phase A, norms[row] and the running maximum are recorded.
 template <int DK, bool SPLIT, int kMUnits>
-__device__ __forceinline__ void knn_f16_store_chunk(float *img, int CH, int cn, float sc, const float (&mu8)[8], int ptid,
-                                                    const float4 (&reg)[kMUnits][2], float *norms, float &tmax, bool &tnan) {
+__device__ __forceinline__ void knn_f16_store_chunk(float *img, int CH, int cn, float sc, const float *mu_lds, int ptid,
+                                                    const float4 (&reg)[kMUnits][2], float *norms, float *norms_m,
+                                                    const float *acoef_lds, float &tmax, bool &tnan) {
     constexpr int DP = DK * 32, G = DP / 8, PPR = DK * 8;
-    static_assert(kMProd % G == 0, "a producer thread always converts the same group of eight dimensions (mu8)");
+    static_assert(kMProd % G == 0, "a producer thread always converts the same group of eight dimensions");
+    // (centre and error coefficient are re-read from LDS per call: holding them in registers across the chunk loop spills)
+    float mu8[8];
+    {
+        const float4 m0 = *reinterpret_cast<const float4 *>(mu_lds + 8 * (ptid % G)), m1 = *reinterpret_cast<const float4 *>(mu_lds + 8 * (ptid % G) + 4);
+        mu8[0] = m0.x; mu8[1] = m0.y; mu8[2] = m0.z; mu8[3] = m0.w; mu8[4] = m1.x; mu8[5] = m1.y; mu8[6] = m1.z; mu8[7] = m1.w;
+    }
+    const float acoef = norms_m ? *acoef_lds : 0.0f;
 #pragma unroll
     for (int u = 0; u < kMUnits; ++u) {
         const int un = ptid + u * kMProd;
@@ -1385,7 +1393,10 @@ __device__ __forceinline__ void knn_f16_store_chunk(float *img, int CH, int cn, 
             for (int m = 1; m < G; m <<= 1) part = part + __shfl_xor(part, m, 64);
             if (un < CH * G && g == 0) {
                 const float t = row < cn ? part : INFINITY;  // rows beyond the cloud: F = +inf
-                norms[row] = t;
+                // norms_m: the candidate's own share of the filter error is folded into its norm, upwards for the
+                // threshold search (phase A), downwards for the test (phase B)
+                norms[row] = norms_m ? t + acoef * t : t;
+                if (norms_m) norms_m[row] = row < cn ? t - acoef * t : INFINITY;
                 if (row < cn) { tnan |= (t != t); tmax = fmaxf(tmax, t); }
             }
         }
@@ -1397,7 +1408,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                                                              const float *__restrict__ y, int M, int B, int D,
                                                              int k, int drop, int32_t *__restrict__ idx,
                                                              float *__restrict__ dist, int CH, int img_floats,
-                                                             int keep_norms) {
+                                                             int keep_norms, int two_norms) {
     constexpr int DP = DK * 32;      // padded feature dimension
     constexpr int RS = DP + 4;       // row stride of the query rows staged in the prologue (floats)
     constexpr int PPR = DK * 8;      // 16-byte pieces per candidate row
@@ -1438,19 +1449,29 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     const bool vec4y = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(yb) & 15) == 0);
     const bool vec4x = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(xb) & 15) == 0);
     const int nchunk = (M + CH - 1) / CH;
+    // filter error per unit of (candidate norm + query norm), scaled units: fp32 accumulation + centring + the oracle's own
+    // rounding 8 (4D + 8) u (4x head-room), operand representation 2^-10 (rounded halves) or 2^-18 (2-way split)
+    float *nallm = two_norms ? nall + (size_t)nchunk * CH : nullptr;  // [nchunk*CH] norms for the phase-B test
     KNN_PROBE_MARK(0);
 
-    if (tid == 0) *cmax = 0u;
+    if (tid == 0) {
+        *cmax = 0u;
+        const float aq = 8.0f * (float)(4 * D + 8) * 0x1p-24f + (SPLIT ? 0x1p-18f : 0x1.01p-10f);
+        // candidate side: + its share of the subnormal floor, + the rounding of n (1 +- A); parked in LDS (cmax[1])
+        reinterpret_cast<float *>(cmax)[1] = aq * 1.01f + 0x1p-26f * sqrtf((float)D) + 0x1p-23f;
+    }
     float sc = 1.0f;  // F16: power-of-two scale with |sc * c| < 1 for every candidate
     if (F16) {
-        // ---- centre and scale: per-dimension mid-range mu and the largest |c - mu| of the cloud, one coalesced pass
-        //      (F16 => 16-byte loads are legal).  Distances do not depend on the origin, the fp16 band does: it grows
-        //      with |q~|^2 + |c~|^2, so a common offset of a few standard deviations would flood the lists.
-        //      Thread t always sees the same four dimensions when the block size is a multiple of D/4.
+        // ---- centre and scale: per-dimension MEAN mu (robust against a few far points, unlike the mid-range) and the
+        //      largest |c - mu| of the cloud, one coalesced pass (F16 => 16-byte loads are legal).  Distances do not
+        //      depend on the origin, the fp16 band does: it grows with |q~|^2 + |c~|^2, so a common offset of a few
+        //      standard deviations would flood the lists.  Thread t always sees the same four dimensions when the
+        //      block size is a multiple of D/4.  (Any mu is correct; it only has to be the same for all points.)
         __syncthreads();
         const int rq = D / 4;
         const bool centre = (kMThreads % rq) == 0 && rq <= 32;
         float4 lo4 = float4{INFINITY, INFINITY, INFINITY, INFINITY}, hi4 = float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        float4 sum4 = float4{0.f, 0.f, 0.f, 0.f};
         bool tnan = false;
         float poison = 0.0f;
         const float4 *c4 = reinterpret_cast<const float4 *>(yb);
@@ -1466,22 +1487,28 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                 poison = __builtin_fmaf(v[e].z, 0.0f, poison); poison = __builtin_fmaf(v[e].w, 0.0f, poison);
                 lo4.x = vmin_f32(lo4.x, v[e].x); lo4.y = vmin_f32(lo4.y, v[e].y); lo4.z = vmin_f32(lo4.z, v[e].z); lo4.w = vmin_f32(lo4.w, v[e].w);
                 hi4.x = vmax_f32(hi4.x, v[e].x); hi4.y = vmax_f32(hi4.y, v[e].y); hi4.z = vmax_f32(hi4.z, v[e].z); hi4.w = vmax_f32(hi4.w, v[e].w);
+                if (e0 + e * kMThreads < total4) {  // (the clamped duplicates must not enter the mean)
+                    sum4.x = sum4.x + v[e].x; sum4.y = sum4.y + v[e].y; sum4.z = sum4.z + v[e].z; sum4.w = sum4.w + v[e].w;
+                }
             }
         }
         tnan = poison != poison;
         const bool anynan = __syncthreads_or(tnan) != 0;
-        float *red = sm;  // [kMThreads / 64][32][8] scratch in the (still unused) chunk buffers
+        float *red = sm;  // [kMThreads / 64][32][12] scratch in the (still unused) chunk buffers
         if (centre) {
             for (int m = rq; m < 64; m <<= 1) {  // lanes with equal lane % rq hold the same dimensions
                 lo4.x = fminf(lo4.x, __shfl_xor(lo4.x, m, 64)); lo4.y = fminf(lo4.y, __shfl_xor(lo4.y, m, 64));
                 lo4.z = fminf(lo4.z, __shfl_xor(lo4.z, m, 64)); lo4.w = fminf(lo4.w, __shfl_xor(lo4.w, m, 64));
                 hi4.x = fmaxf(hi4.x, __shfl_xor(hi4.x, m, 64)); hi4.y = fmaxf(hi4.y, __shfl_xor(hi4.y, m, 64));
                 hi4.z = fmaxf(hi4.z, __shfl_xor(hi4.z, m, 64)); hi4.w = fmaxf(hi4.w, __shfl_xor(hi4.w, m, 64));
+                sum4.x = sum4.x + __shfl_xor(sum4.x, m, 64); sum4.y = sum4.y + __shfl_xor(sum4.y, m, 64);
+                sum4.z = sum4.z + __shfl_xor(sum4.z, m, 64); sum4.w = sum4.w + __shfl_xor(sum4.w, m, 64);
             }
             if (lane < rq) {
-                float *r8 = red + (size_t)(wv * 32 + lane) * 8;
+                float *r8 = red + (size_t)(wv * 32 + lane) * 12;
                 r8[0] = lo4.x; r8[1] = lo4.y; r8[2] = lo4.z; r8[3] = lo4.w;
                 r8[4] = hi4.x; r8[5] = hi4.y; r8[6] = hi4.z; r8[7] = hi4.w;
+                r8[8] = sum4.x; r8[9] = sum4.y; r8[10] = sum4.z; r8[11] = sum4.w;
             }
         }
         __syncthreads();
@@ -1489,14 +1516,16 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         if (centre) {
             if (tid < rq) {
                 float lo[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, hi[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                float sm4[4] = {0.f, 0.f, 0.f, 0.f};
                 for (int w = 0; w < kMThreads / 64; ++w) {
-                    const float *r8 = red + (size_t)(w * 32 + tid) * 8;
+                    const float *r8 = red + (size_t)(w * 32 + tid) * 12;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { lo[c] = fminf(lo[c], r8[c]); hi[c] = fmaxf(hi[c], r8[4 + c]); }
+                    for (int c = 0; c < 4; ++c) { lo[c] = fminf(lo[c], r8[c]); hi[c] = fmaxf(hi[c], r8[4 + c]); sm4[c] = sm4[c] + r8[8 + c]; }
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float m0 = 0.5f * lo[c] + 0.5f * hi[c];
+                    float m0 = sm4[c] / (float)M;
+                    m0 = fminf(fmaxf(m0, lo[c]), hi[c]);  // (rounding of the sum cannot leave the range)
                     mu[4 * tid + c] = m0;
                     amax = fmaxf(amax, fmaxf(hi[c] - m0, m0 - lo[c]));
                 }
@@ -1517,7 +1546,9 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         if (cinf > 1.0e-30f && cinf < 1.0e30f) {
             int e;
             (void)frexpf(cinf * 1.000001f, &e);  // = m 2^e, m in [0.5, 1)
-            sc = ldexpf(1.0f, -e);
+            // |sc (c - mu)| < 2^10: ten binades above 1 so that a bulk far smaller than the largest |c - mu| (a few far
+            // points) still sits in fp16's normal range; queries up to 30 x the cloud's extent stay below 6e4
+            sc = ldexpf(1.0f, 10 - e);
         }
         __syncthreads();
         if (tid == 0) *cmax = anynan ? 0x7fc00000u : 0u;  // from here on: bits of the largest SCALED squared norm
@@ -1592,12 +1623,6 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     const int nstep = 2 * nchunk;
     constexpr int kMUnits = SPLIT ? kMUnitsSplit : kMUnitsSingle;
     float4 preg[kMUnits][2];  // F16 producers: the chunk after next, loaded one step ahead
-    float mu8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // F16 producers: centre of this thread's eight dimensions
-    if (F16 && !consumer) {
-        const int g = ptid % (DP / 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) mu8[e] = mu[8 * g + e];
-    }
     float pmax = 0.0f;        // F16 producers: largest scaled norm seen
     bool pnan = false;
     int stage_ev = 0;                    // F16 producers: staging events done (chunks 0..n-1, n-2..0)
@@ -1605,7 +1630,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     if (F16) {
         if (!consumer) {
             knn_f16_load_chunk<DK, kMUnits>(yb, D, 0, M < CH ? M : CH, CH, ptid, preg);
-            knn_f16_store_chunk<DK, SPLIT, kMUnits>(sm, CH, M < CH ? M : CH, sc, mu8, ptid, preg, nall, pmax, pnan);
+            knn_f16_store_chunk<DK, SPLIT, kMUnits>(sm, CH, M < CH ? M : CH, sc, mu, ptid, preg, nall, nallm, reinterpret_cast<const float *>(cmax + 1), pmax, pnan);
             if (nchunk == 1) {
 #pragma unroll
                 for (int m = 1; m < 64; m <<= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, m, 64));
@@ -1653,7 +1678,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         if (consumer) {
             if (wave_active) {
                 const float *cand = sm + (size_t)cur * buf_floats;
-                const float *cnorm = keep_norms ? nall + (size_t)ci * CH : cand + (size_t)CH * DP;
+                const float *cnorm = keep_norms ? (phase && nallm ? nallm : nall) + (size_t)ci * CH : cand + (size_t)CH * DP;
                 const int npair = cn_pad / 64;
                 const int tile0 = j0 / 32;
                 for (int pr = 0; pr < npair; ++pr) {
@@ -1750,8 +1775,9 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             float *img = sm + (size_t)(1 - cur) * buf_floats;
             if (F16) {
                 // the registers hold chunk ci_next (loaded one step ago); then fetch the chunk after it
-                knn_f16_store_chunk<DK, SPLIT, kMUnits>(img, CH, cnn, sc, mu8, ptid, preg, stage_ev < nchunk ? nall + (size_t)stage_ev * CH : nullptr,
-                                        pmax, pnan);
+                knn_f16_store_chunk<DK, SPLIT, kMUnits>(img, CH, cnn, sc, mu, ptid, preg, stage_ev < nchunk ? nall + (size_t)stage_ev * CH : nullptr,
+                                        stage_ev < nchunk && nallm ? nallm + (size_t)stage_ev * CH : nullptr,
+                                        reinterpret_cast<const float *>(cmax + 1), pmax, pnan);
                 if (stage_ev == nchunk - 1) {  // last phase-A chunk: publish this wave's maximum norm
 #pragma unroll
                     for (int m = 1; m < 64; m <<= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, m, 64));
@@ -1803,8 +1829,13 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                 // scaled units (c~ = sc c, |c~| < 1; qn = |sc q|^2): split representation 3 2^-22 |a~||c~|, fp32
                 // accumulation of the 3D exact products (3D+1) u, the oracle's own (D+2) u, fp16 underflow floor
                 // single piece: the rounded operands differ by 2^-11 relative each, sum |c~_d a_d| <= 2 |c~||q~| <= qn + c2
-                eps = (8.0f * (float)(4 * D + 8) * 0x1p-24f + (SPLIT ? 0x1p-18f : 0x1.01p-10f)) * (qn + c2) +
-                      0x1p-24f * sqrtf((float)D) * (qn + 2.0f);
+                // |F^ - (sc^2 d_oracle - qn)| <= A (n_c + qn) + floor for candidate c with scaled norm n_c (A = acoef_q).
+                // two_norms: the candidate's share A n_c is already inside the norms (upwards in phase A, downwards
+                // in phase B), the query keeps B_q = A qn + floor_q: a far candidate no longer widens everybody's
+                // band.  Otherwise n_c <= c2 for all of them.
+                const float acoef_q = 8.0f * (float)(4 * D + 8) * 0x1p-24f + (SPLIT ? 0x1p-18f : 0x1.01p-10f);
+                const float floor_q = 0x1p-24f * sqrtf((float)D) * (qn + 2.0f);
+                eps = two_norms ? acoef_q * qn + floor_q : acoef_q * (qn + c2) + floor_q + 0x1p-26f * sqrtf((float)D) * c2;
                 eps = qok ? eps : INFINITY;
             } else {
                 eps = (8.0f * (float)(D + 4) * 0x1p-24f) * (qn + c2);
@@ -2222,6 +2253,9 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     fixed += (size_t)DP * 4;  // per-dimension centre
     fixed += (size_t)2 * kMWaves * (kMMedCap + 128) * 4;  // medium path: id lists + merge scratch, one per wave
     if (keep_norms) fixed += (size_t)((M + 255) / 256 * 256 + 256) * 4;
+    // fp16 filter, room permitting: a second norms array (the candidate's error share folded in, upwards / downwards)
+    const int two_norms = F16 && keep_norms && M <= 2048;
+    if (two_norms) fixed += (size_t)((M + 255) / 256 * 256 + 256) * 4;
     const size_t budget = 150 * 1024 - fixed;                                  // floats*4 for the two chunk buffers
     int CH = (int)(budget / 2 / ((size_t)RSI * 4 + 4)) / 64 * 64;
     if (CH > 256) CH = 256;
@@ -2243,7 +2277,7 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     const int nbx = (N + qpb - 1) / qpb;
     const int bpad = B >= 8 ? (B + 7) / 8 * 8 : B;
     hipLaunchKernelGGL((knn_mfma_kernel<DK, F16, SPLIT>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
-                       k, drop, idx, dist, CH, (int)img, keep_norms);
+                       k, drop, idx, dist, CH, (int)img, keep_norms, two_norms);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }
