@@ -934,10 +934,22 @@ __device__ __forceinline__ void split2h(float v, _Float16 &h, _Float16 &l) {
 }
 
 // fp16 image pieces of one candidate: c~ = s (c - mu)
+// Error model of the fp16-split filter value t^ of candidate c for query q (scaled units, any magnitudes):
+//   |t^ - (|c~|^2 - 2 q~.c~)| <= beta (|c~|^2 + |q~|^2) + floor,   beta = 2^-18
+// (2-way splits 3 2^-22 |c~_d||m_d|, fp32 accumulation of 16 exact products 2^-20 (2|c~|^2 + |q~|^2), norm split;
+// >= the absolute bound 2^-20 (4 + 2S) used while |c~| <= 1, which tools/test_f16_filter.hip showed 9x pessimistic).
+// The candidate's share is folded into its norm (x (1 + kBetaC): the image holds UPPER bounds U_c), so that a far
+// point's large norm inflates only its own value.  The nearest candidate c* then satisfies
+//   U_c* <= Umin (1 + 4 beta) + 10.1 beta |q~|^2 + floor        (|c~*| <= |q~| + d*, d*^2 <= Umin + (1 + beta)|q~|^2)
+// and the oracle's own rounding (6u of the distances) adds 2^-20 (Umin + 2|q~|^2): kBandB1, kBandA below.
+constexpr float kBetaC = 0x1.1p-18f;                       // beta (+6 %: rounding of n (1 + beta), subnormal share 2^-26 sqrt(3))
+constexpr float kBandB1 = 1.0f + 4.0f * kBetaC + 0x1p-20f;
+constexpr float kBandA = 10.1f * kBetaC + 0x1p-19f;
 __device__ __forceinline__ void make_pieces(float cx, float cy, float cz, h8 &p0, h8 &p1) {
     _Float16 hx, lx, hy, ly, hz, lz, n1, n2, n3;
     split2h(cx, hx, lx); split2h(cy, hy, ly); split2h(cz, hz, lz);
-    const float n = ((cx * cx) + (cy * cy)) + (cz * cz);
+    const float n0 = ((cx * cx) + (cy * cy)) + (cz * cz);
+    const float n = n0 + kBetaC * n0;
     n1 = (_Float16)n;
     const float r1 = n - (float)n1;
     n2 = (_Float16)r1;
@@ -950,7 +962,7 @@ __device__ __forceinline__ void make_pieces(float cx, float cy, float cz, h8 &p0
 template <bool WANT_IDX>
 __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ float red[2 * 4 * (kHThreads / 64)];
+    __shared__ float red[3 * 4 * (kHThreads / 64)];  // per wave: min, max, sum (padded to 4 dims)
     constexpr int QB = (kHThreads / 64) * 32;  // queries per tile pass
 
     const int L = blockIdx.x;
@@ -989,11 +1001,13 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     const bool one_shot = vec && NC <= CH;
     FX3D_PROBE_MARK(0);
 
-    // ---- bounding box -> centre mu, half extent cinf, power-of-two scale sc with cinf*sc in [0.5,1) ----
+    // ---- bounding box and mean -> centre mu = the MEAN (a stray far point moves the box centre, hardly the mean), largest
+    //      |c - mu| cinf, power-of-two scale sc with cinf*sc in [64,128): seven binades of fp16 range above 1, so that a bulk
+    //      much smaller than the farthest point keeps its fp16 pieces out of the subnormals; |c~|^2 < 3 * 2^14 fits fp16 ----
     float mu[3], cinf = 0.0f;
     const int nv = vec ? NC / 4 : 0;
     {
-        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sm3[3] = {0.f, 0.f, 0.f};
         for (int q4 = tid; q4 < nv; q4 += kHThreads) {
             float ax[4], ay[4], az[4];
             load4pts(cb, q4 * 4, ax, ay, az);
@@ -1002,6 +1016,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 mn[0] = fminf(mn[0], ax[e]); mx[0] = fmaxf(mx[0], ax[e]);
                 mn[1] = fminf(mn[1], ay[e]); mx[1] = fmaxf(mx[1], ay[e]);
                 mn[2] = fminf(mn[2], az[e]); mx[2] = fmaxf(mx[2], az[e]);
+                sm3[0] = sm3[0] + ax[e]; sm3[1] = sm3[1] + ay[e]; sm3[2] = sm3[2] + az[e];
                 if (one_shot) {  // park the raw point in its own first piece
                     const int pt = q4 * 4 + e;
                     imgf[((pt >> 5) * 2) * 32 + (pt & 31)] = float4{ax[e], ay[e], az[e], 0.0f};
@@ -1014,23 +1029,28 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 const float v = cb[(size_t)pt * 3 + d];
                 mn[d] = fminf(mn[d], v);
                 mx[d] = fmaxf(mx[d], v);
+                sm3[d] = sm3[d] + v;
             }
         }
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const float lo = wave_min_f(mn[d]), hi = wave_max_f(mx[d]);
-            if (lane == 0) { red[(wv * 2) * 4 + d] = lo; red[(wv * 2 + 1) * 4 + d] = hi; }
+            float sw = sm3[d];
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) sw = sw + __shfl_xor(sw, m, 64);
+            if (lane == 0) { red[(wv * 3) * 4 + d] = lo; red[(wv * 3 + 1) * 4 + d] = hi; red[(wv * 3 + 2) * 4 + d] = sw; }
         }
         __syncthreads();
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            float lo = red[d], hi = red[4 + d];
+            float lo = red[d], hi = red[4 + d], st = red[8 + d];
 #pragma unroll
             for (int w = 1; w < kHThreads / 64; ++w) {
-                lo = fminf(lo, red[(w * 2) * 4 + d]);
-                hi = fmaxf(hi, red[(w * 2 + 1) * 4 + d]);
+                lo = fminf(lo, red[(w * 3) * 4 + d]);
+                hi = fmaxf(hi, red[(w * 3 + 1) * 4 + d]);
+                st = st + red[(w * 3 + 2) * 4 + d];
             }
-            mu[d] = 0.5f * lo + 0.5f * hi;
+            mu[d] = fminf(fmaxf(st / (float)NC, lo), hi);  // (any centre is correct; NaN data -> not sane below)
             cinf = fmaxf(cinf, fmaxf(hi - mu[d], mu[d] - lo));
         }
         cinf = cinf * 1.000001f;
@@ -1040,11 +1060,11 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     if (sane && cinf > 1.0e-30f) {
         int e;
         (void)frexpf(cinf, &e);  // cinf = m 2^e, m in [0.5,1)
-        sc = ldexpf(1.0f, -e);
+        sc = ldexpf(1.0f, 7 - e);
     }
     FX3D_PROBE_MARK(1);
 
-    float qr[3], delta = 0.0f;
+    float qr[3], da = 0.0f;  // band: a tile qualifies while its minimum <= best * kBandB1 + da
     int qi = 0;
     bool qok = true;
     h8 bq;
@@ -1111,7 +1131,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                             m2 = -2.0f * ((qr[2] - mu[2]) * sc);
                 const float S = (fabsf(m0) + fabsf(m1)) + fabsf(m2);
                 qok = S < 3.0e4f;  // inside the fp16 range (also false for NaN)
-                delta = (6.0f + 2.0f * S + 0.125f * S * S) * 0x1p-19f;
+                const float qn = 0.25f * ((m0 * m0 + m1 * m1) + m2 * m2);  // |q~|^2
+                da = kBandA * qn + 0x1p-24f * (S + 4.0f);
                 _Float16 hx, lx, hy, ly, hz, lz;
                 split2h(qok ? m0 : 0.f, hx, lx); split2h(qok ? m1 : 0.f, hy, ly); split2h(qok ? m2 : 0.f, hz, lz);
                 const _Float16 one = (_Float16)1.0f, z = (_Float16)0.0f;
@@ -1153,7 +1174,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     a_nxt = a_n2;
                 }
                 pa += kHLT * 64;
-                const bool qual = tm <= best + delta;
+                const bool qual = tm <= __builtin_fmaf(best, kBandB1, da);
 #pragma unroll
                 for (int s = kHFifo - 1; s > 0; --s) ft[s] = qual ? ft[s - 1] : ft[s];
                 ft[0] = qual ? tm : ft[0];
@@ -1171,7 +1192,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             // ---- exact phase, wave-cooperative (see nn1_mfma_kernel) ----------------------------------------
             {
                 const float m = fminf(best, __shfl_xor(best, 32, 64));
-                const float thr1 = m + delta, thr2 = thr1 + delta;
+                const float thr1 = __builtin_fmaf(m, kBandB1, da), thr2 = __builtin_fmaf(thr1, kBandB1, da);
                 const bool usable = sane && qok && m < INFINITY;        // filter meaningful for this query
                 const bool slow = !usable || !(ft[kHFifo - 1] > thr2);  // FIFO may have dropped a tile in band
                 // Common case (no slow lane in the wave): the items are the FIFO entries within the band.
