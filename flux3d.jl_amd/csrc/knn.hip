@@ -687,10 +687,12 @@ __device__ __forceinline__ void k3_split2h(float v, _Float16 &h, _Float16 &l) {
     l = (_Float16)(v - (float)h);
 }
 // fp16 image pieces of one candidate c~ = s (c - mu): same K-slot table as nn1_f16_kernel
+constexpr float kK3BetaC = 0x1.2p-18f;  // candidate's share of the filter error, folded into its norm (chamfer.hip kBetaC, + the 17th term)
 __device__ __forceinline__ void k3_make_pieces(float cx, float cy, float cz, kh8 &p0, kh8 &p1) {
     _Float16 hx, lx, hy, ly, hz, lz, n1, n2, n3;
     k3_split2h(cx, hx, lx); k3_split2h(cy, hy, ly); k3_split2h(cz, hz, lz);
-    const float n = ((cx * cx) + (cy * cy)) + (cz * cz);
+    const float n0 = ((cx * cx) + (cy * cy)) + (cz * cz);
+    const float n = n0 + kK3BetaC * n0;
     n1 = (_Float16)n;
     const float r1 = n - (float)n1;
     n2 = (_Float16)r1;
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                                                                float *__restrict__ dist, int CH, int img_bytes,
                                                                int raw_ok, float *__restrict__ feat, int layout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k3sm[];
-    __shared__ float red[2 * 4 * kTWaves];
+    __shared__ float red[3 * 4 * kTWaves];  // per wave: min, max, sum (padded to 4 dims)
     kh8 *imgp = reinterpret_cast<kh8 *>(k3sm);  // piece (blk, half, row) at (blk*2 + half)*32 + row
     constexpr int kListBytes = kTWaves * kTCap * 64 * 4;      // lane lists; also the tau exchange and, later, the slots
     constexpr int kCtrInts = kTGroups * 32 * 8;               // per query: 4 part counts, overflow, n, fast, below
@@ -778,7 +780,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     float mu[3], cinf = 0.0f;
     {
         float4 *raww = reinterpret_cast<float4 *>(k3sm + img_bytes + kListBytes + kCtrInts * 4);
-        float mn3[3] = {INFINITY, INFINITY, INFINITY}, mx3[3] = {-INFINITY, -INFINITY, -INFINITY};
+        float mn3[3] = {INFINITY, INFINITY, INFINITY}, mx3[3] = {-INFINITY, -INFINITY, -INFINITY}, sm3[3] = {0.f, 0.f, 0.f};
         const bool vec = (reinterpret_cast<uintptr_t>(yb) & 15) == 0;
         const int nv4 = vec ? M / 4 : 0;
         for (int g = tid; g < nv4; g += kTThreads) {  // four points = three 16-byte loads
@@ -790,6 +792,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                 mn3[0] = fminf(mn3[0], px[e]); mx3[0] = fmaxf(mx3[0], px[e]);
                 mn3[1] = fminf(mn3[1], py[e]); mx3[1] = fmaxf(mx3[1], py[e]);
                 mn3[2] = fminf(mn3[2], pz[e]); mx3[2] = fmaxf(mx3[2], pz[e]);
+                sm3[0] = sm3[0] + px[e]; sm3[1] = sm3[1] + py[e]; sm3[2] = sm3[2] + pz[e];
                 if (raw_ok) raww[g * 4 + e] = float4{px[e], py[e], pz[e], 0.0f};
             }
         }
@@ -800,29 +803,33 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                 v[d] = yb[(size_t)pt * 3 + d];
                 mn3[d] = fminf(mn3[d], v[d]);
                 mx3[d] = fmaxf(mx3[d], v[d]);
+                sm3[d] = sm3[d] + v[d];
             }
             if (raw_ok) raww[pt] = float4{v[0], v[1], v[2], 0.0f};
         }
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            float lo = mn3[d], hi = mx3[d];
+            float lo = mn3[d], hi = mx3[d], sw = sm3[d];
 #pragma unroll
             for (int m = 1; m < 64; m <<= 1) {
                 lo = fminf(lo, __shfl_xor(lo, m, 64));
                 hi = fmaxf(hi, __shfl_xor(hi, m, 64));
+                sw = sw + __shfl_xor(sw, m, 64);
             }
-            if (lane == 0) { red[(wv * 2) * 4 + d] = lo; red[(wv * 2 + 1) * 4 + d] = hi; }
+            if (lane == 0) { red[(wv * 3) * 4 + d] = lo; red[(wv * 3 + 1) * 4 + d] = hi; red[(wv * 3 + 2) * 4 + d] = sw; }
         }
         __syncthreads();
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            float lo = red[d], hi = red[4 + d];
+            float lo = red[d], hi = red[4 + d], st = red[8 + d];
 #pragma unroll
             for (int w = 1; w < kTWaves; ++w) {
-                lo = fminf(lo, red[(w * 2) * 4 + d]);
-                hi = fmaxf(hi, red[(w * 2 + 1) * 4 + d]);
+                lo = fminf(lo, red[(w * 3) * 4 + d]);
+                hi = fmaxf(hi, red[(w * 3 + 1) * 4 + d]);
+                st = st + red[(w * 3 + 2) * 4 + d];
             }
-            mu[d] = 0.5f * lo + 0.5f * hi;
+            // centre = the MEAN (a stray far point moves the box centre, hardly the mean); any centre is correct
+            mu[d] = fminf(fmaxf(st / (float)M, lo), hi);
             cinf = fmaxf(cinf, fmaxf(hi - mu[d], mu[d] - lo));
         }
         cinf = cinf * 1.000001f;
@@ -832,7 +839,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     if (sane && cinf > 1.0e-30f) {
         int e;
         (void)frexpf(cinf, &e);
-        sc = ldexpf(1.0f, -e);
+        sc = ldexpf(1.0f, 7 - e);  // |c~| < 2^7: a bulk far smaller than the farthest point stays out of fp16's subnormals
     }
     KNN_PROBE_MARK(1);
 
@@ -840,8 +847,12 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     const float m0 = -2.0f * ((qr[0] - mu[0]) * sc), m1 = -2.0f * ((qr[1] - mu[1]) * sc), m2 = -2.0f * ((qr[2] - mu[2]) * sc);
     const float S = (fabsf(m0) + fabsf(m1)) + fabsf(m2);
     const bool qok = S < 3.0e4f;  // inside the fp16 range (also false for NaN)
-    // band: the filter's error twice (once with the threshold as a 17th term: + 2^-22 (3 + S)) + the oracle's rounding
-    const float delta = (6.0f + 2.25f * S + 0.125f * S * S) * 0x1p-19f;
+    // band (chamfer.hip, make_pieces: the image holds upper bounds U_c = t^ + beta n_c): a candidate among the kk nearest
+    // has U_c <= tau_U (1 + 4 beta) + 10.1 beta |q~|^2 + floor, + the oracle's rounding, + the threshold as a 17th
+    // MFMA term in phase B (2^-21 of its magnitude)
+    const float qn = 0.25f * ((m0 * m0 + m1 * m1) + m2 * m2);
+    const float band_b1 = 1.0f + 4.0f * kK3BetaC + 0x1p-20f + 0x1p-21f;
+    const float band_a = (10.1f * kK3BetaC + 0x1p-19f + 0x1p-21f) * qn + 0x1p-24f * (S + 4.0f);
     kh8 bq;
     {
         _Float16 hx, lx, hy, ly, hz, lz;
@@ -1001,7 +1012,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
             float tau = mn[0];  // kk <= 32: among the 32 smallest
 #pragma unroll
             for (int r = 1; r < 32; ++r) tau = (kk - 1) == r ? mn[r] : tau;
-            thr = tau + delta;
+            thr = __builtin_fmaf(tau, band_b1, band_a);
             {
                 // phase B subtracts the threshold inside the MFMA (K slot 15: candidate side 1, query side -thr16)
                 // and keeps the sign: thr16 = the smallest fp16 value strictly above thr, so that t <= thr gives a
