@@ -896,15 +896,15 @@ __global__ __launch_bounds__(kMThreads, 4) void nn1_mfma_kernel(Nn1Params p) {
 //
 //   One v_mfma_f32_32x32x16_f16 produces 1024 filter values (32 candidates x 32 queries) in the time
 //   the f32 form needs for 256.  Precision is recovered by 2-way fp16 splits (hi + lo ~ 22 bits) of
-//   coordinates pre-scaled by a power of two s so that |c~| = |s (c - mu)| <= 1:
+//   coordinates centred on the cloud's mean mu and pre-scaled by a power of two s so that |c~| = |s (c - mu)| < 2^7:
 //     K slot : 0      1      2      3      4      5      6      7    | 8      9  10 11  12     13     14    15
 //     A (c~) : chx    chx    clx    chy    chy    cly    chz    chz  | clz    n1 n2 n3  clx    cly    clz   0
 //     B (qm~): qhx    qlx    qhx    qhy    qly    qhy    qhz    qlz  | qhz    1  1  1   qlx    qly    qlz   0
 //   with qm~ = -2 s (q - mu) and n1+n2+n3 the 3-way split of the Float32 |c~|^2, so
 //     D[i][j] = |c~_i|^2 + qm~_j . c~_i  =  s^2 (|c'_i|^2 - 2 q'_j . c'_i)     up to
-//     |err| <= 2^-20 (4 + 2 S),  S = sum_d |qm~_d|   (measured max: 2^-23.2 (3 + S), tools/test_f16_filter.hip).
-//   Band (scaled units), including the oracle's own Float32 rounding 6u D~, D~ <= S^2/2 + 6:
-//     delta~ = 2^-19 (6 + 2 S + S^2/8).
+//     |err| <= beta (|c~|^2 + |q~|^2) + floor, beta = 2^-18  (with |c~| <= 1: 2^-20 (4 + 2 S), S = sum_d |qm~_d|; measured
+//     max 2^-23.2 (3 + S), tools/test_f16_filter.hip).  The candidate's share is folded into its norm and the band is
+//     relative to the running minimum: see make_pieces / kBandB1 / kBandA below.
 //   Queries with |qm~| beyond the fp16 range take the exact path.
 //   Lane l of a wave holds query l&31 and the 16 candidate rows (r&3)+8(r>>2)+4(l>>5) of every
 //   32-candidate block; the two half-waves are merged through the per-query LDS slot.

@@ -656,11 +656,12 @@ __device__ __forceinline__ void knn_rank_ties(const unsigned int *qd, const int 
 //            smallest filter value: tau.  Selection = 32-element sorting network in registers, the partner
 //            lane's values by v_permlane32_swap, the other wave's 32 smallest through LDS, two bitonic merges.
 //   Phase B: the filter again with the threshold folded into the MFMA (K slot 15: 1 x -thr16, thr16 the
-//            smallest fp16 above tau + delta~): the sign of the result is the test, one v_alignbit per row
+//            smallest fp16 above the threshold): the sign of the result is the test, one v_alignbit per row
 //            shifts it into the tile's 16-bit row mask; (tile, mask) words go to the LANE's private LDS list
 //            (unconditional store at the list head, the head advances when the mask is not empty).
-//            delta~ = 2^-19 (6 + 2.25 S + S^2/8): the filter's error in phase A + in phase B (17 terms) + the
-//            oracle's own rounding.  A superset of the k nearest, ~1.1 kk entries per query at config 4.
+//            threshold = tau (1 + 4 beta + ...) + (10.1 beta + ...) |q~|^2 + floor on the upper-bound values of the image
+//            (mean centring, 2^7 scale, folded norms: chamfer.hip make_pieces; band_b1 / band_a below).  A superset
+//            of the k nearest, ~1.1 kk entries per query at config 4.
 //   Exact:   every lane decodes its list and evaluates the oracle's distance of its entries (the query is in its
 //            registers); the ranking of a query's keys is shared by its four lanes: rank = number of keys with
 //            a smaller distance = output slot, verified by count and rank sum, ties re-ranked on (distance,
