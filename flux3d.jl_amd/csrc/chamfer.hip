@@ -940,11 +940,13 @@ __device__ __forceinline__ void split2h(float v, _Float16 &h, _Float16 &l) {
 // >= the absolute bound 2^-20 (4 + 2S) used while |c~| <= 1, which tools/test_f16_filter.hip showed 9x pessimistic).
 // The candidate's share is folded into its norm (x (1 + kBetaC): the image holds UPPER bounds U_c), so that a far
 // point's large norm inflates only its own value.  The nearest candidate c* then satisfies
-//   U_c* <= Umin (1 + 4 beta) + 10.1 beta |q~|^2 + floor        (|c~*| <= |q~| + d*, d*^2 <= Umin + (1 + beta)|q~|^2)
-// and the oracle's own rounding (6u of the distances) adds 2^-20 (Umin + 2|q~|^2): kBandB1, kBandA below.
+//   U_c* <= Umin + 2 beta |c~*|^2 + 2 beta |q~|^2,   |c~*|^2 <= (|q~| + d*)^2 <= (1 + e)|q~|^2 + (1 + 1/e) d*^2  (any e > 0),
+//   d*^2 <= Umin + (1 + beta)|q~|^2;   with e = 1/8:   U_c* <= Umin (1 + 18 beta) + 22.3 beta |q~|^2 + floor.
+// (Umin ~ -|q~|^2 + d*^2 and d* << |q~| for most queries: the band is ~4.3 beta |q~|^2 there, e = 1 would give 6.)
+// The oracle's own rounding (6u of the distances) adds 2^-20 (Umin + 2|q~|^2): kBandB1, kBandA below.
 constexpr float kBetaC = 0x1.1p-18f;                       // beta (+6 %: rounding of n (1 + beta), subnormal share 2^-26 sqrt(3))
-constexpr float kBandB1 = 1.0f + 4.0f * kBetaC + 0x1p-20f;
-constexpr float kBandA = 10.1f * kBetaC + 0x1p-19f;
+constexpr float kBandB1 = 1.0f + 18.0f * kBetaC + 0x1p-20f;
+constexpr float kBandA = 22.3f * kBetaC + 0x1p-19f;
 __device__ __forceinline__ void make_pieces(float cx, float cy, float cz, h8 &p0, h8 &p1) {
     _Float16 hx, lx, hy, ly, hz, lz, n1, n2, n3;
     split2h(cx, hx, lx); split2h(cy, hy, ly); split2h(cz, hz, lz);

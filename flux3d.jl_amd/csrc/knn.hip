@@ -849,11 +849,11 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     const float S = (fabsf(m0) + fabsf(m1)) + fabsf(m2);
     const bool qok = S < 3.0e4f;  // inside the fp16 range (also false for NaN)
     // band (chamfer.hip, make_pieces: the image holds upper bounds U_c = t^ + beta n_c): a candidate among the kk nearest
-    // has U_c <= tau_U (1 + 4 beta) + 10.1 beta |q~|^2 + floor, + the oracle's rounding, + the threshold as a 17th
+    // has U_c <= tau_U (1 + 18 beta) + 22.3 beta |q~|^2 + floor, + the oracle's rounding, + the threshold as a 17th
     // MFMA term in phase B (2^-21 of its magnitude)
     const float qn = 0.25f * ((m0 * m0 + m1 * m1) + m2 * m2);
-    const float band_b1 = 1.0f + 4.0f * kK3BetaC + 0x1p-20f + 0x1p-21f;
-    const float band_a = (10.1f * kK3BetaC + 0x1p-19f + 0x1p-21f) * qn + 0x1p-24f * (S + 4.0f);
+    const float band_b1 = 1.0f + 18.0f * kK3BetaC + 0x1p-20f + 0x1p-21f;
+    const float band_a = (22.3f * kK3BetaC + 0x1p-19f + 0x1p-21f) * qn + 0x1p-24f * (S + 4.0f);
     kh8 bq;
     {
         _Float16 hx, lx, hy, ly, hz, lz;
