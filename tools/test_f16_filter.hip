@@ -46,10 +46,12 @@ int main() {
     hipMalloc(&dc, 384); hipMalloc(&dq, 384); hipMalloc(&dout, 4096);
     unsigned s = 7;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
-    double worst = 0, worst_rel = 0;
-    for (int trial = 0; trial < 2000; ++trial) {
-        const float cs = trial % 4 == 0 ? 1.0f : (trial % 4 == 1 ? 1e-2f : (trial % 4 == 2 ? 0.3f : 1e-4f));
-        const float qs = trial % 3 == 0 ? 2.0f : (trial % 3 == 1 ? 8.0f : 0.5f);
+    double worst = 0, worst_rel = 0, worst_model = 0;
+    for (int trial = 0; trial < 5600; ++trial) {
+        // magnitudes of the robust scaling (|c~| < 2^7, |qm~| < 2^8 for queries inside the cloud) down to a bulk 10^-5 of it
+        const float csv[8] = {1.0f, 1e-2f, 0.3f, 1e-4f, 127.0f, 30.0f, 3.0f, 1e-3f};
+        const float qsv[7] = {2.0f, 8.0f, 0.5f, 250.0f, 60.0f, 1e-2f, 2e-3f};
+        const float cs = csv[trial % 8], qs = qsv[trial % 7];
         for (auto &v : c) v = (2 * rnd() - 1) * cs;
         for (auto &v : q) v = (2 * rnd() - 1) * qs;
         hipMemcpy(dc, c.data(), 384, hipMemcpyHostToDevice); hipMemcpy(dq, q.data(), 384, hipMemcpyHostToDevice);
@@ -65,8 +67,13 @@ int main() {
             const double bound = 3.0 + qsum;  // scaled-units denominator: (3 + sum|qm~|)
             if (err / bound > worst) worst = err / bound;
             if (mag > 0 && err / mag > worst_rel) worst_rel = err / mag;
+            const double qn = 0.25 * ((double)q[j * 3] * q[j * 3] + (double)q[j * 3 + 1] * q[j * 3 + 1] + (double)q[j * 3 + 2] * q[j * 3 + 2]);
+            // the kernels' model: err <= beta (n_c + |q~|^2) + floor, floor = 2^-25 (S + 2) (subnormal fp16 pieces)
+            const double excess = err - 0x1p-25 * (qsum + 2.0);
+            if (excess > 0 && excess / (n + qn) > worst_model) worst_model = excess / (n + qn);
         }
     }
     printf("max |err| / (3 + sum|qm~|) = %.3e  (2^%.2f)   max err/sum|terms| = %.3e\n", worst, log2(worst), worst_rel);
+    printf("max (|err| - 2^-25 (S + 2)) / (n_c + |q~|^2) = %.3e  (2^%.2f);  the kernels use beta = 2^-18\n", worst_model, log2(worst_model));
     return 0;
 }
