@@ -6,10 +6,15 @@
 // CPU path's arithmetic (Float32 sum of squared differences in dimension order, unfused), so the
 // index lists are bit-identical to oracle/flux3d_oracle.c:fx3d_oracle_knn.
 //
-// Kernels (dispatch in launch_knn at the end of the file):
-//   knn_f16_d3_kernel        D = 3, k+drop <= 32, M >= 64: fp16-split matrix-core filter + exact re-scan
-//   knn_mfma_kernel<DK,F16>  4 <= D <= 128, k+drop <= 32, M >= 64: GEMM filter (fp16 split or Float32) + exact re-scan
-//   knn_wave_d3_kernel / knn_wave_generic_kernel: one wave per query, exact distances, every other supported shape
+// Kernels, in file order (dispatch in launch_knn / fx3d_edgeconv_graph at the end of the file):
+//   knn_wave_d3_kernel / knn_wave_generic_kernel   one wave per query, exact distances: every shape the two below do not take
+//   knn_exact_bruteforce / knn_rank_ties           wave-cooperative exact selection / tie re-rank shared by all kernels
+//   knn_gather[4]_kernel                           X[:, idx] (src/models/dgcnn.jl:6)
+//   knn_f16_d3_kernel<FEAT>                        D = 3, k+drop <= 32, M >= 64: fp16-split matrix-core filter + exact re-scan;
+//                                                  FEAT: EdgeConv's cat(X, KNN - X) written by the same kernel
+//   knn_mfma_kernel<DK, F16, SPLIT>                4 <= D <= 128, k+drop <= 32, M >= 64: GEMM filter (fp16 rounded halves, 2-way
+//                                                  fp16 split, or Float32) + exact re-scan, medium path for crowded bands
+//   edge_features_*_kernel                         cat(X, KNN - X) + permute for any F, and the @nograd adjoint
 #include <cmath>
 #include <cstdlib>
 
