@@ -1,24 +1,33 @@
 # Flux3DHip.jl -- thin @ccall shim that puts libflux3d_hip.so behind Flux3D.jl's own API.
 #
 # NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no `julia`.  It is kept declarative --
-# one @ccall per C-ABI entry point (include/flux3d_hip.h), no logic beyond shape bookkeeping -- so
-# that it can be checked by inspection against the header; the same call sequence is exercised by
-# the Python twin of this layer (flux3d.jl_amd/*.py), which the test-suite runs on the GPU.
+# one @ccall per C-ABI entry point (include/flux3d_hip.h), no logic beyond shape bookkeeping.  What IS
+# checked mechanically (tests/test_julia_shim.py, CPU suite): every `@ccall LIB.fx3d_*` in this file
+# against the header prototype (arity, every argument's C type, the return type), every FX3D_API symbol
+# bound here, block structure (`function`/`end` balance), and the checklist of reference generic functions
+# a HipArray-backed TriMesh touches (INTEGRATION.md section 2a) against the methods defined below.  The same
+# call sequence is exercised by the Python twin of this layer (flux3d.jl_amd/*.py) on the GPU.
 #
-# Usage inside Flux3D (INTEGRATION.md):
+# Usage: this file is `include`d INSIDE `module Flux3D` (INTEGRATION.md section 2), after the rep / metrics /
+# transforms includes, hence the relative `using ..Flux3D`.  (As a stand-alone package that depends on
+# Flux3D, replace the two `..Flux3D` below by `Flux3D`; nothing else changes.)
 #     include("Flux3DHip.jl"); using .Flux3DHip
 #     A = hip(PointCloud(rand(Float32, 3, 4096, 32)));  B = hip(...)
 #     chamfer_distance(A, B)                 # dispatches to the HipArray methods below
+#     m = hip(load_trimesh("teapot.obj"));   laplacian_loss(m); sample_points(m, 5000)
 #
 # No CUDA.jl, no AMDGPU.jl, no Triton: device memory is owned by the library (fx3d_malloc) and
 # wrapped in a HipArray with a finalizer.
 module Flux3DHip
 
-using Flux3D
-import Flux3D: chamfer_distance, _chamfer_distance, _nearest_neighbors, sample_points,
-               laplacian_loss, edge_loss, TriMesh, PointCloud,
-               get_verts_packed, get_verts_padded, get_faces_packed, get_faces_padded,
-               get_edges_packed, get_laplacian_packed
+using ..Flux3D
+import ..Flux3D: chamfer_distance, _chamfer_distance, _nearest_neighbors, sample_points,
+                 laplacian_loss, edge_loss, TriMesh, PointCloud,
+                 get_verts_packed, get_verts_padded, get_verts_list, get_faces_packed, get_faces_padded,
+                 get_faces_list, get_edges_packed, get_laplacian_packed,
+                 compute_faces_areas_packed, compute_faces_areas_padded,
+                 _list_to_packed, _list_to_padded, _packed_to_padded, _packed_to_list,
+                 _padded_to_list, _padded_to_packed, offset!
 using SparseArrays: SparseMatrixCSC, findnz
 import Zygote
 
@@ -46,6 +55,9 @@ const use_hip = Ref(false)
 __init__() = (use_hip[] = isfile(LIB) && device_count() > 0)
 
 # ---- device array: the `S` storage type of TriMesh{T,R,S} / PointCloud.points -----------------
+# An AbstractArray without scalar indexing: everything the reference's generic rep code does to the storage type
+# (constructors S{T,N}(undef, ...), similar, reshape, hcat, range getindex, T.(x), +, copy, deepcopy, fill!) has a
+# method here that stays on the device; the checklist is INTEGRATION.md section 2a.
 mutable struct HipArray{T,N} <: AbstractArray{T,N}
     ptr::Ptr{Cvoid}
     dims::NTuple{N,Int}
@@ -53,30 +65,210 @@ mutable struct HipArray{T,N} <: AbstractArray{T,N}
 end
 Base.size(a::HipArray) = a.dims
 Base.sizeof(a::HipArray{T}) where {T} = prod(a.dims) * sizeof(T)
-Base.getindex(a::HipArray, i...) = error("scalar indexing of a HipArray is not supported; use unhip(a)")
+Base.IndexStyle(::Type{<:HipArray}) = IndexLinear()
+Base.getindex(a::HipArray, i::Int) = error("scalar indexing of a HipArray is not supported; use unhip(a)")
+Base.setindex!(a::HipArray, v, i::Int) = error("scalar indexing of a HipArray is not supported; use hip(x)")
+Base.show(io::IO, a::HipArray{T,N}) where {T,N} = print(io, "HipArray{$T,$N}", size(a))
+Base.show(io::IO, ::MIME"text/plain", a::HipArray) = show(io, a)
 
-function HipArray{T}(::UndefInitializer, dims::Int...) where {T}
+_free(a::HipArray) = (@ccall LIB.fx3d_free(a.ptr::Ptr{Cvoid})::Int32; nothing)
+# `S{T,2}(undef, 3, n)` / `S{T,3}(undef, 3, V, N)` in the reference's TriMesh constructor (src/rep/mesh.jl:151-152)
+function HipArray{T,N}(::UndefInitializer, dims::NTuple{N,Int}) where {T,N}
     p = Ref{Ptr{Cvoid}}(C_NULL)
     check(@ccall LIB.fx3d_malloc(p::Ref{Ptr{Cvoid}}, max(prod(dims) * sizeof(T), 1)::Csize_t)::Int32)
-    a = HipArray{T,length(dims)}(p[], dims, nothing)
-    finalizer(x -> (@ccall LIB.fx3d_free(x.ptr::Ptr{Cvoid})::Int32), a)
+    a = HipArray{T,N}(p[], dims, nothing)
+    finalizer(_free, a)
     return a
 end
+HipArray{T,N}(::UndefInitializer, dims::Vararg{Integer,N}) where {T,N} = HipArray{T,N}(undef, map(Int, dims))
+HipArray{T}(::UndefInitializer, dims::NTuple{N,Integer}) where {T,N} = HipArray{T,N}(undef, map(Int, dims))
+HipArray{T}(::UndefInitializer, dims::Vararg{Integer,N}) where {T,N} = HipArray{T,N}(undef, map(Int, dims))
+# `similar(packed, D, M, N)` / `similar(verts_padded, 3, n, B)` (src/rep/utils.jl:129, src/transforms/mesh_func.jl:40)
+Base.similar(a::HipArray, ::Type{T}, dims::Dims{N}) where {T,N} = HipArray{T,N}(undef, dims)
+
 function hip(x::Array{T,N}) where {T,N}
-    a = HipArray{T}(undef, size(x)...)
+    a = HipArray{T,N}(undef, size(x))
     check(@ccall LIB.fx3d_memcpy_h2d(a.ptr::Ptr{Cvoid}, x::Ptr{T}, sizeof(x)::Csize_t, DEFAULT_STREAM::Stream)::Int32)
     return a
 end
+hip(a::HipArray) = a
 function unhip(a::HipArray{T,N}) where {T,N}
     x = Array{T,N}(undef, a.dims)
     check(@ccall LIB.fx3d_memcpy_d2h(x::Ptr{T}, a.ptr::Ptr{Cvoid}, sizeof(x)::Csize_t, DEFAULT_STREAM::Stream)::Int32)
     return x
 end
+unhip(x::Array) = x
 Base.Array(a::HipArray) = unhip(a)
-Base.reshape(a::HipArray{T}, dims::Int...) where {T} = HipArray{T,length(dims)}(a.ptr, dims, a)
+Base.collect(a::HipArray) = unhip(a)
+
+# reshape shares the allocation (a view with an owner); one Colon is resolved as Base does
+function _reshape(a::HipArray{T}, full::Dims{N}) where {T,N}
+    prod(full) == length(a) ||
+        throw(DimensionMismatch("new dimensions $(full) must be consistent with array size $(length(a))"))
+    return HipArray{T,N}(a.ptr, full, a)
+end
+function _uncolon(a::HipArray, dims::Tuple{Vararg{Union{Int,Colon}}})
+    count(d -> d isa Colon, dims) == 1 || throw(DimensionMismatch("new dimensions $(dims) may have at most one omitted dimension"))
+    known = 1
+    for d in dims
+        d isa Int && (known *= d)
+    end
+    rest = known == 0 ? 0 : div(length(a), known)
+    return map(d -> d isa Colon ? rest : d, dims)
+end
+Base.reshape(a::HipArray, dims::Dims) = _reshape(a, dims)
+Base.reshape(a::HipArray, dims::Tuple{Vararg{Union{Int,Colon}}}) = _reshape(a, _uncolon(a, dims))
+Base.dropdims(a::HipArray; dims) = _reshape(a, Tuple(s for (i, s) in enumerate(size(a)) if !(i in dims)))
+
+# device-to-device copy of `n` elements, offsets in elements (0-based)
+function copyto_d2d!(dst::HipArray{T}, doff::Int, src::HipArray{T}, soff::Int, n::Int) where {T}
+    n == 0 && return dst
+    (0 <= doff && doff + n <= length(dst) && 0 <= soff && soff + n <= length(src)) || throw(BoundsError())
+    check(@ccall LIB.fx3d_memcpy_d2d((dst.ptr + doff * sizeof(T))::Ptr{Cvoid}, (src.ptr + soff * sizeof(T))::Ptr{Cvoid},
+                                     (n * sizeof(T))::Csize_t, DEFAULT_STREAM::Stream)::Int32)
+    return dst
+end
+function Base.copy(a::HipArray{T,N}) where {T,N}
+    out = HipArray{T,N}(undef, size(a))
+    return copyto_d2d!(out, 0, a, 0, length(a))
+end
+# deepcopy(m::TriMesh) in `offset` (src/transforms/mesh_func.jl:436): a bitwise copy would alias the allocation
+Base.deepcopy_internal(a::HipArray, dict::IdDict) = get!(() -> copy(a), dict, a)
+function Base.fill!(a::HipArray{T}, z::Number) where {T}
+    iszero(z) || error("HipArray fill!: only zero is supported (the reference pads vertices with 0, src/rep/mesh.jl:855)")
+    check(@ccall LIB.fx3d_memset(a.ptr::Ptr{Cvoid}, 0::Int32, sizeof(a)::Csize_t, DEFAULT_STREAM::Stream)::Int32)
+    return a
+end
+# `T.(v)` ("To remove lazy wrappers", src/rep/mesh.jl:129; PointCloud(points) src/rep/pcloud.jl:45-51): identity
+Base.Broadcast.broadcasted(::Type{T}, a::HipArray{T}) where {T} = a
+# contiguous column ranges: `packed[:, i:j]`, `padded[:, 1:len, b]`, `points[:, :, b]` are device copies
+function Base.getindex(a::HipArray{T,2}, ::Colon, r::UnitRange{Int}) where {T}
+    D = size(a, 1)
+    out = HipArray{T,2}(undef, D, length(r))
+    return copyto_d2d!(out, 0, a, (first(r) - 1) * D, D * length(r))
+end
+function Base.getindex(a::HipArray{T,3}, ::Colon, r::UnitRange{Int}, b::Int) where {T}
+    D, M, _ = size(a)
+    out = HipArray{T,2}(undef, D, length(r))
+    return copyto_d2d!(out, 0, a, ((b - 1) * M + first(r) - 1) * D, D * length(r))
+end
+Base.getindex(a::HipArray{T,3}, ::Colon, ::Colon, b::Int) where {T} = a[:, 1:size(a, 2), b]
+# `hcat(list...)` in _list_to_packed (src/rep/utils.jl:98)
+function Base.hcat(list::HipArray{T,2}...) where {T}
+    D = size(list[1], 1)
+    all(size(x, 1) == D for x in list) || throw(DimensionMismatch("hcat: mismatched leading dimension"))
+    packed = HipArray{T,2}(undef, D, sum(size(x, 2) for x in list))
+    off = 0
+    for x in list
+        copyto_d2d!(packed, off, x, 0, length(x)); off += length(x)
+    end
+    return packed
+end
+
 hip(p::PointCloud) = PointCloud(hip(p.points), p.normals === nothing ? nothing : hip(p.normals))
+unhip(p::PointCloud) = PointCloud(unhip(p.points), p.normals === nothing ? nothing : unhip(p.normals))
+
+# ---- TriMesh on HipArray storage ---------------------------------------------------------------------------------
+# The reference only has constructor methods for Vector{<:CuArray} and Vector{<:Array} (src/rep/mesh.jl:107-117; the
+# generic one is commented out, :100-105).  This is the third: same body as the S-typed constructor (:119-177) with
+# S = HipArray; the functor (src/rep/mesh.jl:189-190) rebuilds through it, so `hip(m)` / `unhip(m)` / fmap work.
+function TriMesh(verts::Vector{<:HipArray{T,2}}, faces::Vector{<:AbstractArray{R,2}};
+                 offset::Number = -1) where {T<:AbstractFloat,R<:Integer}
+    length(verts) == length(faces) ||
+        error("batch size of verts and faces should match, $(length(verts)) != $(length(faces))")
+    all(size(v, 1) == 3 for v in verts) || error("verts must be (3, V) arrays")
+    verts_list = HipArray{T,2}[v for v in verts]
+    faces_list = Array{R,2}[Array{R,2}(f) for f in faces]
+    _verts_len = Int64[size(v, 2) for v in verts_list]
+    _faces_len = Int64[size(f, 2) for f in faces_list]
+    N = length(verts_list); V = maximum(_verts_len); F = maximum(_faces_len)
+    equalised = all(_verts_len .== V) && all(_faces_len .== F)
+    valid = _faces_len .> 0
+    return TriMesh{T,R,HipArray}(
+        N, V, F, equalised, valid, Int8(offset), _verts_len, _faces_len,
+        HipArray{T,2}(undef, 3, sum(_verts_len)), HipArray{T,3}(undef, 3, V, N), verts_list, false, false, true,
+        Array{R,2}(undef, 3, sum(_faces_len)), Array{R,3}(undef, 3, F, N), faces_list, false, false,
+        nothing, nothing, nothing, nothing)
+end
 # functor(::TriMesh) moves only the verts (src/rep/mesh.jl:189-190)
-hip(m::TriMesh) = TriMesh([hip(v) for v in Flux3D.get_verts_list(m)], Flux3D.get_faces_list(m); offset = m.offset)
+hip(m::TriMesh) = TriMesh([hip(v) for v in get_verts_list(m)], get_faces_list(m); offset = m.offset)
+unhip(m::TriMesh) = TriMesh([unhip(v) for v in get_verts_list(m)], get_faces_list(m); offset = m.offset)
+
+# Converters between the list / packed / padded forms (src/rep/utils.jl:58-206) for device storage.  The accessors
+# get_verts_packed / get_verts_padded / get_verts_list (src/rep/mesh.jl:344-394) and the lazy cache logic
+# (_compute_verts_*, :838-882; setproperty!, :208-231) are the reference's own code: they only reach the storage
+# through these six functions, `size`, and `convert(S, x)`.
+_list_to_packed(list::Vector{<:HipArray{T,2}}) where {T<:Number} = hcat(list...)
+
+function _packed_to_padded(packed::HipArray{T,2}, items_len::AbstractArray{<:Number,1}, pad_value::Number) where {T<:Number}
+    iszero(pad_value) || error("HipArray _packed_to_padded: only pad_value = 0 is supported")
+    lens = Int64[l for l in items_len]
+    D = size(packed, 1); M = maximum(lens); B = length(lens)
+    sum(lens) == size(packed, 2) || error("items_len does not add up to the packed size")
+    padded = HipArray{T,3}(undef, D, M, B)
+    if T === Float32 && D == 3
+        check(@ccall LIB.fx3d_packed_to_padded(packed.ptr::Ptr{Cvoid}, lens::Ptr{Int64}, B::Int32, M::Int32,
+                                               padded.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    else
+        fill!(padded, 0)
+        cur = 0
+        for (i, len) in enumerate(lens)
+            copyto_d2d!(padded, (i - 1) * M * D, packed, cur * D, len * D); cur += len
+        end
+    end
+    return padded
+end
+Zygote.@adjoint function _packed_to_padded(packed::HipArray{T,2}, items_len::AbstractArray{<:Number,1}, pad_value::Number) where {T<:Number}
+    return _packed_to_padded(packed, items_len, pad_value), g -> (_padded_to_packed(g, items_len), nothing, nothing)
+end
+
+function _packed_to_list(packed::HipArray{T,2}, items_len::AbstractArray{<:Number,1}) where {T<:Number}
+    list = HipArray{T,2}[]
+    cur = 1
+    for len in items_len
+        push!(list, packed[:, cur:cur+Int(len)-1]); cur += Int(len)
+    end
+    return list
+end
+
+function _padded_to_list(padded::HipArray{T,3}, items_len::Union{Nothing,AbstractArray{<:Number,1}}) where {T<:Number}
+    lens = items_len === nothing ? fill(size(padded, 2), size(padded, 3)) : items_len
+    length(lens) == size(padded, 3) || error("items_len length should match the last dimension of padded array")
+    return HipArray{T,2}[padded[:, 1:Int(len), i] for (i, len) in enumerate(lens)]
+end
+
+function _padded_to_packed(padded::HipArray{T,3}, items_len::Union{Nothing,AbstractArray{<:Number,1}} = nothing,
+                           pad_value::Union{Nothing,Number} = nothing) where {T<:Number}
+    (pad_value === nothing || items_len === nothing) || error("pad_value and items_len both should not be given")
+    items_len === nothing && error("HipArray _padded_to_packed needs items_len")
+    lens = Int64[l for l in items_len]
+    D, M, B = size(padded)
+    length(lens) == B || error("items_len length should match the last dimension of padded array")
+    packed = HipArray{T,2}(undef, D, sum(lens))
+    if T === Float32 && D == 3
+        check(@ccall LIB.fx3d_padded_to_packed(padded.ptr::Ptr{Cvoid}, lens::Ptr{Int64}, B::Int32, M::Int32,
+                                               packed.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    else
+        cur = 0
+        for (i, len) in enumerate(lens)
+            copyto_d2d!(packed, cur * D, padded, (i - 1) * M * D, len * D); cur += len
+        end
+    end
+    return packed
+end
+
+function _list_to_padded(list::Vector{<:HipArray{T,2}}, pad_value::Number, pad_size::Union{Nothing,Tuple} = nothing) where {T<:Number}
+    pad_size === nothing || length(pad_size) == 2 || error("pad_size should be a tuple of length 2")
+    padded = _packed_to_padded(_list_to_packed(list), Int64[size(x, 2) for x in list], pad_value)
+    pad_size === nothing || (size(padded, 1), size(padded, 2)) == pad_size ||
+        error("HipArray _list_to_padded: pad_size must equal the largest item")
+    return padded
+end
+
+# `verts_packed += offset_verts_packed` in offset! (src/transforms/mesh_func.jl:409-416)
+Base.:+(a::HipArray{Float32,N}, b::HipArray{Float32,N}) where {N} = lincomb(1, a, 1, b)
+Base.:-(a::HipArray{Float32,N}, b::HipArray{Float32,N}) where {N} = lincomb(1, a, -1, b)
+offset!(m::TriMesh{Float32,R,HipArray}, offset_verts_packed::Array{Float32,2}) where {R} = offset!(m, hip(offset_verts_packed))
 
 # scratch: caller-provided by ABI contract; one grow-only buffer per task is enough here
 const _ws = Ref{Union{Nothing,HipArray{UInt8,1}}}(nothing)
@@ -406,6 +598,41 @@ function chamfer_finalize_many(comm, sums::HipArray{Float64,2}, N::Integer, M::I
     return losses
 end
 
+# The two halves of _chamfer_distance (src/metrics/pcloud.jl:47-50) for a caller that runs its own collective between
+# them (MPI.jl, Distributed.jl): this rank's partial sums into `sums` (2 Float64: a slot of a (2,count) array), then the
+# loss from globally reduced sums with the GLOBAL batch size.
+function chamfer_sums!(sums::HipArray{Float64}, A::HipArray{Float32,3}, B::HipArray{Float32,3}; indices::Bool = false,
+                       stream::Stream = DEFAULT_STREAM)
+    D, N, Bn = size(A); _, M, _ = size(B)
+    nb = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_chamfer_workspace_bytes(N::Int32, M::Int32, max(Bn, 1)::Int32, D::Int32, nb::Ref{Csize_t})::Int32)
+    ws = workspace(nb[])
+    ix = indices ? HipArray{Int32}(undef, N, Bn) : nothing
+    iy = indices ? HipArray{Int32}(undef, M, Bn) : nothing
+    check(@ccall LIB.fx3d_chamfer_sums(A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32, Bn::Int32, D::Int32,
+                                       sums.ptr::Ptr{Cvoid}, (indices ? ix.ptr : C_NULL)::Ptr{Cvoid},
+                                       (indices ? iy.ptr : C_NULL)::Ptr{Cvoid}, ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t,
+                                       stream::Stream)::Int32)
+    return sums, ix, iy
+end
+function chamfer_finalize(sums::HipArray{Float64}, N::Integer, M::Integer, B_global::Integer, D::Integer;
+                          w1::Number = 1.0, w2::Number = 1.0, stream::Stream = DEFAULT_STREAM)
+    loss_dev = HipArray{Float32}(undef, 1)
+    check(@ccall LIB.fx3d_chamfer_finalize(sums.ptr::Ptr{Cvoid}, N::Int32, M::Int32, B_global::Int64, D::Int32,
+                                           Float32(w1)::Float32, Float32(w2)::Float32, loss_dev.ptr::Ptr{Cvoid},
+                                           stream::Stream)::Int32)
+    return unhip(loss_dev)[1]
+end
+# cat(X, KNNGraph - X; dims = 1) for given neighbour indices (src/models/dgcnn.jl:36-51); idx (K,N,B) Int32 0-based
+function edge_features(X::HipArray{Float32,3}, idx::HipArray{Int32,3}; layout::Int = 1)
+    F, N, B = size(X); K = size(idx, 1)
+    out = layout == 1 ? HipArray{Float32}(undef, K * N, 2F, B) : HipArray{Float32}(undef, 2F, K, N, B)
+    check(@ccall LIB.fx3d_edge_features(X.ptr::Ptr{Cvoid}, N::Int32, B::Int32, F::Int32, K::Int32, idx.ptr::Ptr{Cvoid},
+                                        layout::Int32, out.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    return out
+end
+set_device(dev::Integer) = check(@ccall LIB.fx3d_set_device(dev::Int32)::Int32)
+
 # ---- the rest of the ABI: device / stream / event utilities, explicit-draw sampling, face areas, host topology ----
 version() = unsafe_string(@ccall LIB.fx3d_version()::Cstring)
 function current_device()
@@ -432,10 +659,6 @@ event_synchronize(e::Event) = check(@ccall LIB.fx3d_event_sync(e::Event)::Int32)
 function event_elapsed_ms(a::Event, b::Event)
     ms = Ref{Float32}(0); check(@ccall LIB.fx3d_event_elapsed_ms(a::Event, b::Event, ms::Ref{Float32})::Int32); return ms[]
 end
-Base.copy(a::HipArray{T,N}) where {T,N} = (out = HipArray{T}(undef, size(a)...);
-    check(@ccall LIB.fx3d_memcpy_d2d(out.ptr::Ptr{Cvoid}, a.ptr::Ptr{Cvoid}, sizeof(T) * length(a)::Csize_t, DEFAULT_STREAM::Stream)::Int32); out)
-Base.fill!(a::HipArray{T}, z::Integer) where {T} = (z == 0 || error("HipArray fill!: only zero");
-    check(@ccall LIB.fx3d_memset(a.ptr::Ptr{Cvoid}, 0::Int32, sizeof(T) * length(a)::Csize_t, DEFAULT_STREAM::Stream)::Int32); a)
 # per-kernel HIP-event timing inside the library (bench.py's `roofline` object)
 profile_enable(every_nth::Integer) = check(@ccall LIB.fx3d_profile_enable(every_nth::Int32)::Int32)
 function profile_kernel_stats(name::AbstractString)
@@ -445,14 +668,14 @@ function profile_kernel_stats(name::AbstractString)
 end
 
 # compute_faces_areas_packed / _padded (src/rep/mesh.jl:765-808) on HipArray meshes
-function compute_faces_areas_packed(m::TriMesh{Float32,R,HipArray}) where {R}
+function compute_faces_areas_packed(m::TriMesh{Float32,R,HipArray}; eps::Number = 1e-6) where {R}
     verts = get_verts_packed(m)::HipArray{Float32,2}; faces = faces_packed_dev(m)
     out = HipArray{Float32}(undef, size(faces, 2))
     check(@ccall LIB.fx3d_faces_areas_packed(verts.ptr::Ptr{Cvoid}, size(verts, 2)::Int64, faces.ptr::Ptr{Cvoid},
                                              size(faces, 2)::Int64, out.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
     return out
 end
-function compute_faces_areas_padded(m::TriMesh{Float32,R,HipArray}) where {R}
+function compute_faces_areas_padded(m::TriMesh{Float32,R,HipArray}; eps::Number = 1e-6) where {R}
     verts = get_verts_padded(m)::HipArray{Float32,3}
     out = HipArray{Float32}(undef, 1, m.F, m.N)
     check(@ccall LIB.fx3d_faces_areas_padded(verts.ptr::Ptr{Cvoid}, m.V::Int32, faces_padded_dev(m).ptr::Ptr{Cvoid}, m.F::Int32,
