@@ -10,11 +10,24 @@ HBM: BASELINE.json configs[1] (B=32, N=M=4096, Float32) per GPU.  With N GPUs th
 Float64 partial sums are all-reduced over RCCL (weak scaling).  value = global pairs / max-rank time.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline      -- dominant kernel (nn1) vs the fp32 compute roofline that bounds it
-  roofline_hbm  -- the HBM fraction BASELINE.json's metric asks for (not the bound)
-  cpu_baseline  -- the oracle's KD-tree twin of the reference CPU path, timed on this host (N=1 only)
+  roofline             -- dominant kernel (nn1) against what limits it: SIMD issue slots (VALU + MFMA issue), from the
+                          SQ counters of a rocprofv3 pass of THIS kernel source (profiles/pmc_latest.json, hash-checked)
+  roofline_mfma_pipe   -- matrix-pipe busy fraction, analytic (2*B*N*M/1024 MFMAs of 32 cycles on 1024 SIMDs)
+  roofline_algorithmic_fp32 / roofline_hbm -- the exact-Float32 algorithm's flops vs the fp32 peak, and the HBM fraction
+                          BASELINE.json's metric asks for (neither is the bound)
+  protocol             -- benchmarks/metrics.jl:24-38 style numbers: min / median per step, forward and forward+backward
+  configs              -- one-liners for BASELINE configs C1 / C3 / C4 and the reference harness's own input
+  cpu_baseline         -- the oracle's KD-tree twin of the reference CPU path, timed on this host (N=1 only)
+Everything beyond the timed K steps runs after them (N=1, rank 0) and does not enter `value`.
+
+N > 1 (one process per GPU): the data-plane collective is the library's own RCCL communicator (fx3d_comm_bootstrap:
+unique id over a file rendezvous, no torch); torch.distributed is the control plane only (barrier, max over ranks).
+Default mode `overlap`: one all-reduce of 2 Float64 PER EVALUATION, issued on a second stream so that it overlaps the
+next evaluation's kernel (north_star: "RCCL all-reduce of the scalar loss").  `serial` (same, on the compute stream) and
+`deferred` (one collective per 32 evaluations) are timed right after and printed as `modes`.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,6 +39,17 @@ sys.path.insert(0, ROOT)
 B_PER_GPU, NPTS, MPTS, DIM = 32, 4096, 4096, 3
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector peak == fp32-input MFMA peak (dense)
+PEAK_CLOCK_GHZ = 2.4
+N_SIMD = 1024              # 256 CUs x 4
+
+
+def kernel_source_hash():
+    """sha256 over the sources the nn1 kernel is built from: ties profiles/pmc_latest.json to a binary."""
+    h = hashlib.sha256()
+    for f in ("chamfer.hip", "fx3d_common.h", "Makefile"):
+        with open(os.path.join(ROOT, "flux3d.jl_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -34,13 +58,15 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the protocol / configs measurements after the timed steps")
     ap.add_argument("--comm", choices=["torch", "native"], default="native",
                     help="multi-GPU all-reduce through torch.distributed (RCCL) or the library's own RCCL communicator")
-    ap.add_argument("--allreduce-every", type=int, default=32,
-                    help="multi-GPU: evaluations per all-reduce (each step parks its 2 Float64 partial sums in a slot; "
-                         "one collective carries G slots and one kernel finalises G losses). 1 = a collective per step")
+    ap.add_argument("--mode", choices=["overlap", "serial", "deferred"], default="overlap",
+                    help="multi-GPU: per-evaluation all-reduce overlapped on a second stream (default), on the compute "
+                         "stream, or one collective per --allreduce-every evaluations")
+    ap.add_argument("--allreduce-every", type=int, default=32, help="evaluations per collective in mode `deferred`")
     ap.add_argument("--force-dist", action="store_true",
-                    help="run the multi-GPU code path (torch.distributed/RCCL all-reduce) even at world size 1")
+                    help="run the multi-GPU code path (RCCL communicator, collectives) even at world size 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -66,7 +92,8 @@ def main():
 
     import flux3d_jl_amd as fx
     from flux3d_jl_amd import _lib
-    from flux3d_jl_amd.distributed import ShardedChamfer, chamfer_finalize, chamfer_sums
+    from flux3d_jl_amd.distributed import (DeferredShardedChamfer, NativeComm, NativeShardedChamfer, ShardedChamfer,
+                                           default_rendezvous)
     import ctypes as C
 
     fx.set_device(local_rank)
@@ -75,14 +102,15 @@ def main():
     x = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_A, DIM, NPTS, B_PER_GPU, batch_offset=rank * B_PER_GPU))
     y = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_B, DIM, MPTS, B_PER_GPU, batch_offset=rank * B_PER_GPU))
 
-    native = None
+    native_comm = None
+    comm_info = None
     if use_dist and args.comm == "native":
-        # the library's own RCCL communicator: one C call per step.  Any failure to set it up (all
-        # ranks agree through an all-reduce) falls back to torch.distributed's all_reduce.
-        from flux3d_jl_amd.distributed import NativeComm, NativeShardedChamfer
+        # the library's own RCCL communicator, bootstrapped without torch (file rendezvous keyed by the launcher's pid).
+        # Any failure to set it up (all ranks agree through a control-plane all-reduce) falls back to torch's all_reduce.
+        rdv = default_rendezvous()
         try:
-            native_comm = NativeComm(rank, world)
-            native = NativeShardedChamfer(native_comm)
+            native_comm = NativeComm(rank, world, rendezvous=rdv)
+            comm_info = dict(native_comm.info(), backend="fx3d_comm (RCCL behind the C ABI)", bootstrap=rdv.split(":", 1)[0])
             ok = 1
         except Exception as e:  # noqa: BLE001
             print(f"[bench] native RCCL communicator unavailable on rank {rank}: {e}", file=sys.stderr)
@@ -90,112 +118,150 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            native = None
-    G = max(1, args.allreduce_every)
-    if use_dist and G > 1:
-        # deferred reduction: G evaluations per collective (every evaluation still gets its global loss)
-        from flux3d_jl_amd.distributed import DeferredShardedChamfer
-        if native is not None:
-            bench_stream = fx.Stream.create()
-            sharded = DeferredShardedChamfer(comm=native_comm, group=G)
-        else:
-            bench_stream = fx.Stream(torch.cuda.current_stream().cuda_stream)
-            sharded = DeferredShardedChamfer(comm=None, group=G)
+            native_comm = None
+    if use_dist and native_comm is None:
+        v = C.c_int32(0)
+        _lib.load().fx3d_comm_info(None, None, None, C.byref(v))
+        comm_info = {"nranks": dist.get_world_size(), "rank": dist.get_rank(), "rccl_version": v.value,
+                     "backend": "torch.distributed nccl (RCCL)", "bootstrap": "torch"}
+
+    def make_runner(mode):
+        """(step, sync_all, read_loss, stream, description) for one way of running a step."""
+        if not use_dist:
+            s = fx.Stream.create()
+            loss_dev = fx.DeviceArray.empty((1,), np.float32)
+
+            def step():  # chamfer_distance(A, B) forward: ONE launch (the last block finalises the loss)
+                with fx.stream(s):
+                    fx.chamfer_distance(x, y, loss_out=loss_dev, sync=False)
+
+            def read_loss():
+                with fx.stream(s):
+                    return float(loss_dev.item())
+            return step, s.synchronize, read_loss, s, "single GPU, no collective"
+        if native_comm is None:  # torch data plane
+            if mode == "deferred":
+                s = fx.Stream(torch.cuda.current_stream().cuda_stream)
+                sh = DeferredShardedChamfer(comm=None, group=max(1, args.allreduce_every))
+
+                def step():
+                    with fx.stream(s):
+                        sh(x, y, Bg)
+
+                def sync_all():
+                    with fx.stream(s):
+                        sh.flush()
+                    torch.cuda.synchronize()
+
+                def read_loss():
+                    with fx.stream(s):
+                        return float(sh.losses.to_host()[max(sh.last_count - 1, 0)])
+                return step, sync_all, read_loss, s, f"torch all_reduce of {2 * sh.group} f64 per {sh.group} steps"
+            sh = ShardedChamfer(overlap=(mode == "overlap"))
+            s = fx.Stream(torch.cuda.current_stream().cuda_stream)
+
+            def sync_all():
+                sh.synchronize()
+                torch.cuda.synchronize()
+            return (lambda: sh(x, y, Bg, sync=False)), sync_all, (lambda: (sh.synchronize(), float(sh.loss.item()))[1]), s, \
+                "torch all_reduce of 2 f64 per step" + (" on a side stream" if mode == "overlap" else "")
+        s = fx.Stream.create()
+        if mode == "deferred":
+            sh = DeferredShardedChamfer(comm=native_comm, group=max(1, args.allreduce_every))
+
+            def step():
+                with fx.stream(s):
+                    sh(x, y, Bg)
+
+            def sync_all():
+                with fx.stream(s):
+                    sh.flush()
+                s.synchronize()
+
+            def read_loss():
+                with fx.stream(s):
+                    return float(sh.losses.to_host()[max(sh.last_count - 1, 0)])
+            return step, sync_all, read_loss, s, f"fx3d_comm all-reduce of {2 * sh.group} f64 per {sh.group} steps"
+        sh = NativeShardedChamfer(native_comm, overlap=(mode == "overlap"))
 
         def step():
-            with fx.stream(bench_stream):
-                sharded(x, y, Bg)
+            with fx.stream(s):
+                sh(x, y, Bg, sync=False)
 
         def sync_all():
-            with fx.stream(bench_stream):
-                sharded.flush()
-            bench_stream.synchronize()
-            dist.barrier()
-            bench_stream.synchronize()
+            sh.synchronize()
+            s.synchronize()
 
         def read_loss():
-            with fx.stream(bench_stream):
-                return float(sharded.losses.to_host()[max(sharded.last_count - 1, 0)])
-    elif native is not None:
-        sharded = native
-        bench_stream = fx.Stream.create()
+            with fx.stream(s):
+                return sh.result()
+        return step, sync_all, read_loss, s, "fx3d_comm all-reduce of 2 f64 per step" + \
+            (" on a second stream, overlapping the next step's kernel" if mode == "overlap" else " on the compute stream")
 
-        def step():
-            with fx.stream(bench_stream):
-                sharded(x, y, Bg, sync=False)
-
-        def sync_all():
-            bench_stream.synchronize()
-            dist.barrier()
-            bench_stream.synchronize()
-
-        def read_loss():
-            with fx.stream(bench_stream):
-                return float(sharded.loss.item())
-    elif use_dist:
-        sharded = ShardedChamfer()
-        bench_stream = fx.Stream(torch.cuda.current_stream().cuda_stream)
-
-        def step():
-            return sharded(x, y, Bg, sync=False)
-
-        def sync_all():
+    def barrier():
+        if dist is not None:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
-        def read_loss():
-            sharded.synchronize()
-            return float(sharded.loss.item())
-    else:
-        bench_stream = fx.Stream.create()
-        sums = fx.DeviceArray.empty((2,), np.float64)
-        loss_dev = fx.DeviceArray.empty((1,), np.float32)
-
-        def step():  # chamfer_distance(A, B) forward: ONE launch (the last block finalises the loss)
-            with fx.stream(bench_stream):
-                fx.chamfer_distance(x, y, loss_out=loss_dev, sync=False)
-
-        def sync_all():
-            bench_stream.synchronize()
-
-        def read_loss():
-            with fx.stream(bench_stream):
-                return float(loss_dev.item())
-
-    for _ in range(args.warmup):
-        step()
-    sync_all()
+    def timed(mode, steps, warmup, profile_every=0):
+        step, sync_all, read_loss, s, desc = make_runner(mode)
+        for _ in range(warmup):
+            step()
+        sync_all()
+        barrier()
+        _lib.call("fx3d_profile_enable", profile_every)
+        e0, e1 = fx.Event(), fx.Event()
+        sync_all()
+        barrier()
+        t0 = time.perf_counter()
+        e0.record(s)
+        for _ in range(steps):
+            step()
+        e1.record(s)
+        sync_all()
+        barrier()
+        t1 = time.perf_counter()
+        elapsed = t1 - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return {"elapsed": elapsed, "loss": read_loss(), "event_ms": e0.elapsed_ms(e1), "desc": desc,
+                "runner": (step, sync_all, s)}
 
     # HIP events around every 5th nn1 launch, on the launch's own stream (bracketing every launch
     # costs ~5 us per step in event records; measured, see DESIGN.md 5)
-    _lib.call("fx3d_profile_enable", 0 if os.environ.get("FX3D_BENCH_NOPROFILE") else 5)
-    e0, e1 = fx.Event(), fx.Event()
-    sync_all()
-    t0 = time.perf_counter()
-    e0.record(bench_stream)
-    for _ in range(args.steps):
-        step()
-    e1.record(bench_stream)
-    sync_all()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    loss = read_loss()
-
+    main_mode = args.mode if use_dist else "single"
+    res = timed(main_mode, args.steps, args.warmup, 0 if os.environ.get("FX3D_BENCH_NOPROFILE") else 5)
     avg, mn, mx, cnt = C.c_double(0), C.c_double(0), C.c_double(0), C.c_int64(0)
     _lib.call("fx3d_profile_kernel_stats", b"nn1", C.byref(avg), C.byref(mn), C.byref(mx), C.byref(cnt))
     _lib.call("fx3d_profile_enable", 0)
-    ev_ms = e0.elapsed_ms(e1)
+    step, sync_all, bench_stream = res["runner"]
+    if cnt.value < 50 and not os.environ.get("FX3D_BENCH_NOPROFILE"):
+        # short runs (--steps 20): the kernel average still comes from >= 50 launches, timed outside the K steps
+        _lib.call("fx3d_profile_enable", 1)
+        for _ in range(60):
+            step()
+        sync_all()
+        _lib.call("fx3d_profile_kernel_stats", b"nn1", C.byref(avg), C.byref(mn), C.byref(mx), C.byref(cnt))
+        _lib.call("fx3d_profile_enable", 0)
+
+    modes = None
+    if use_dist:  # the other ways of placing the collective, same steps, right after (every rank takes part)
+        modes = {main_mode: {"ms_per_step": res["elapsed"] * 1e3 / args.steps, "collective": res["desc"]}}
+        for m in ("overlap", "serial", "deferred"):
+            if m != main_mode:
+                r2 = timed(m, args.steps, min(args.warmup, 20))
+                modes[m] = {"ms_per_step": r2["elapsed"] * 1e3 / args.steps, "collective": r2["desc"],
+                            "loss_equal": bool(np.float32(r2["loss"]) == np.float32(res["loss"]))}
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
+    elapsed, loss = res["elapsed"], res["loss"]
     pairs_per_step = Bg * NPTS * MPTS
     value = pairs_per_step * args.steps / elapsed
     ms_per_step = elapsed * 1e3 / args.steps
@@ -205,57 +271,71 @@ def main():
     #   bytes: read both clouds once (4*D*B*(N+M)) + the per-block partial sums written
     flops = 16.0 * B_PER_GPU * NPTS * MPTS
     abytes = 4.0 * DIM * B_PER_GPU * (NPTS + MPTS) + 8.0 * 2 * B_PER_GPU * 8
+    n_mfma = 2.0 * B_PER_GPU * NPTS * MPTS / 1024.0            # one v_mfma_f32_32x32x16_f16 per 32 x 32 pairs and direction
+    mfma_busy = n_mfma * 32.0 / N_SIMD                           # cycles per SIMD
+    pipe = {"bound": "mfma", "achieved": mfma_busy / kern_s / 1e9 if kern_s else None, "peak": PEAK_CLOCK_GHZ, "unit": "GHz",
+            "frac": (mfma_busy / kern_s / 1e9 / PEAK_CLOCK_GHZ) if kern_s else None,
+            "note": "matrix-pipe busy cycles per SIMD and launch (2*B*N*M/1024 MFMAs x 32 cycles / 1024 SIMDs, analytic: every "
+                    "pair is evaluated) / kernel time, against the 2.4 GHz peak clock; hardware MFMA flops = "
+                    f"{2.0 * 16 * 2 * B_PER_GPU * NPTS * MPTS / kern_s / 1e12 if kern_s else 0:.0f} TF of the 2500 TF dense f16 peak"}
     traffic = None
-    issue = None
-    try:  # PMC-derived HBM bytes per launch, collected by a separate rocprofv3 --pmc pass
+    roof = None
+    pmc_note = "no profiles/pmc_latest.json"
+    try:  # PMC-derived numbers per launch, collected by separate rocprofv3 --pmc passes (tools/profile_round.sh)
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
             pmc = json.load(fh)
+        stale = pmc.get("kernel_source_sha16") != kernel_source_hash()
         traffic = pmc.get("nn1_hbm_bytes_per_launch")
-        # SIMD issue time of one launch from the SQ counters of the same pass: a wave64 VALU instruction holds its
-        # SIMD's issue port for 4 cycles, v_mfma_f32_32x32x16_f16 for 32 (SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA),
-        # and the two do not overlap on one SIMD (measured).  1024 SIMDs.
+        # SIMD issue time of one launch from the SQ counters: a wave64 VALU instruction holds its SIMD's issue port for
+        # 4 cycles, v_mfma_f32_32x32x16_f16 for 32 (SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA), and the two do not overlap
+        # on one SIMD (measured).
         valu, mfma = float(pmc["SQ_INSTS_VALU"]), float(pmc["SQ_INSTS_MFMA"])
-        cyc = ((valu - mfma) * 4.0 + float(pmc["SQ_VALU_MFMA_BUSY_CYCLES"])) / 1024.0
-        issue = {"bound": "simd-issue", "achieved": cyc / kern_s / 1e9 if kern_s else None, "peak": 2.4, "unit": "GHz",
-                 "frac": (cyc / kern_s / 1e9 / 2.4) if kern_s else None,
-                 "note": "issue cycles per SIMD and launch ((SQ_INSTS_VALU - SQ_INSTS_MFMA) x 4 + MFMA busy cycles, "
-                         "profiles/pmc_latest.json) / kernel time, against the 2.4 GHz peak engine clock: the kernel's "
-                         "actual limiter; the sustained clock under this load is ~2.0 GHz, i.e. the SIMDs issue ~90 % of "
-                         "the time (SQ_INSTS_VALU is taken to include the MFMA instructions)"}
-    except Exception:
-        pass
+        cyc = ((valu - mfma) * 4.0 + float(pmc["SQ_VALU_MFMA_BUSY_CYCLES"])) / N_SIMD
+        roof = {"bound": "simd-issue", "achieved": cyc / kern_s / 1e9 if kern_s else None, "peak": PEAK_CLOCK_GHZ, "unit": "GHz",
+                "frac": (cyc / kern_s / 1e9 / PEAK_CLOCK_GHZ) if kern_s else None, "traffic": traffic,
+                "valu_per_mfma": (valu - mfma) / mfma,
+                "counters_from": pmc.get("source"), "counters_stale": stale,
+                "note": "what limits nn1: issue cycles per SIMD and launch ((SQ_INSTS_VALU - SQ_INSTS_MFMA) x 4 + MFMA busy cycles) / "
+                        "kernel time of THIS run, against the 2.4 GHz peak clock (the part sustains ~2.0 GHz under this load). The "
+                        "instruction counts come from a separate rocprofv3 --pmc pass of the same kernel source (sha16 checked: "
+                        "counters_stale), not from this run; they do not depend on timing"}
+        pmc_note = None
+    except Exception as e:  # noqa: BLE001
+        pmc_note = f"profiles/pmc_latest.json unusable: {e}"
+    if roof is None:  # no counters for this source: the analytic matrix-pipe figure is the hardware-side fraction
+        roof = dict(pipe, traffic=None, note=pipe["note"] + f" ({pmc_note}: SIMD-issue fraction not available)")
+    roof.update({"kernel": "nn1_f16_kernel<false>", "kernel_avg_ms": avg.value, "kernel_min_ms": mn.value,
+                 "launches_timed": cnt.value})
     out = {
         "metric": "chamfer_point_pairs_per_sec", "value": value, "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"chamfer_distance fwd B={Bg} ({B_PER_GPU}/GPU) N=M={NPTS} D=3 Float32 U[0,1)^3 (BASELINE configs[1]; configs[4] shape at 8 GPUs)",
-                   "global_batch": Bg, "points": NPTS, "parallelism": f"batch-sharded x{world}, " + (f"1 all-reduce of {2 * G} f64 per {G} steps" if (use_dist and G > 1) else "1 all-reduce of 2 f64 per step")
-                                  + ((" (fx3d_comm RCCL)" if native is not None else " (torch.distributed RCCL)") if use_dist else "")},
+                   "global_batch": Bg, "points": NPTS,
+                   "parallelism": f"batch-sharded x{world}, " + (res["desc"] if use_dist else "no collective")},
         "loss": loss,
-        "roofline": {"bound": "mfma", "achieved": flops / kern_s / 1e12 if kern_s else None,
-                     "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": (flops / kern_s / 1e12 / FP32_PEAK_TFLOPS) if kern_s else None,
-                     "traffic": traffic,
-                     "kernel": "nn1_f16_kernel<false>", "kernel_avg_ms": avg.value,
-                     "kernel_min_ms": mn.value, "launches_timed": cnt.value,
-                     "note": "ALGORITHMIC flops (16 per unordered pair: the exact Float32 form, both directions) vs the "
-                             "fp32 peak (vector == fp32-input MFMA, 157.3 TF). The kernel does not execute those flops: "
-                             "it evaluates a 2-way fp16-split filter on v_mfma_f32_32x32x16_f16 and re-scans the "
-                             "surviving 32-candidate tiles exactly in Float32; see roofline_mfma_f16 for the hardware "
-                             "matrix flops and DESIGN.md 3.1 (the VALU min-fold of the MFMA outputs is the limiter)"},
-        "roofline_mfma_f16": {"bound": "mfma", "achieved": (2.0 * 16 * 2 * B_PER_GPU * NPTS * MPTS) / kern_s / 1e12 if kern_s else None,
-                              "peak": 2500.0, "unit": "TFLOP/s",
-                              "frac": ((2.0 * 16 * 2 * B_PER_GPU * NPTS * MPTS) / kern_s / 1e12 / 2500.0) if kern_s else None,
-                              "note": "hardware MFMA flops actually issued (K=16 per pair, both directions) vs the dense f16 peak"},
+        "roofline": roof,
+        "roofline_mfma_pipe": pipe,
+        "roofline_algorithmic_fp32": {
+            "bound": "mfma", "achieved": flops / kern_s / 1e12 if kern_s else None, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": (flops / kern_s / 1e12 / FP32_PEAK_TFLOPS) if kern_s else None,
+            "note": "ALGORITHMIC flops (16 per unordered pair: the exact Float32 form, both directions) vs the fp32 peak "
+                    "(vector == fp32-input MFMA). The kernel does NOT execute these flops (fp16-split filter on the matrix cores + "
+                    "exact Float32 re-scan of the surviving tiles): a throughput equivalence, not a hardware fraction"},
         "roofline_hbm": {"bound": "hbm", "achieved": abytes / kern_s / 1e9 if kern_s else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (abytes / kern_s / 1e9 / HBM_PEAK_GBS) if kern_s else None,
                          "note": "reported because BASELINE.json asks; brute-force NN cannot approach it"},
-        "stream_event_ms_per_step": ev_ms / args.steps,
+        "stream_event_ms_per_step": res["event_ms"] / args.steps,
     }
-    if issue is not None:
-        out["roofline_issue"] = issue
+    if comm_info is not None:
+        out["comm"] = comm_info
+    if modes is not None:
+        out["modes"] = modes
+    if world == 1 and not use_dist and not args.no_extras:
+        out["protocol"] = protocol_numbers(fx, x, y)
+        out["configs"] = config_one_liners(fx)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(fx)
     try:  # C stdio of the loaded libraries first (RCCL prints its NCCL_DEBUG=VERSION banner there): the JSON goes last
@@ -267,20 +347,87 @@ def main():
         dist.destroy_process_group()
 
 
+def _per_call_ms(fx, fn, n=100, warm=5):
+    """min / median of n single calls, each between two HIP events on one stream (benchmarks/metrics.jl:24-31: warm-up,
+    many samples, minimum -- plus the median SURVEY 8d asks for).  Calls are enqueued back to back."""
+    import numpy as np
+    s = fx.Stream.create()
+    with fx.stream(s):
+        for _ in range(warm):
+            fn()
+        s.synchronize()
+        ev = [fx.Event() for _ in range(n + 1)]
+        ev[0].record(s)
+        for i in range(n):
+            fn()
+            ev[i + 1].record(s)
+        s.synchronize()
+        ts = np.array([ev[i].elapsed_ms(ev[i + 1]) for i in range(n)])
+    return {"min_ms": float(ts.min()), "median_ms": float(np.median(ts)), "samples": n}
+
+
+def protocol_numbers(fx, x, y):
+    """SURVEY 8(d) / benchmarks/metrics.jl:24-38: forward, and forward + backward (loss with indices, then the adjoint
+    w.r.t. both clouds), min and median over 100 event-bracketed calls at the headline config."""
+    import numpy as np
+    loss_dev = fx.DeviceArray.empty((1,), np.float32)
+    fwd = _per_call_ms(fx, lambda: fx.chamfer_distance(x, y, loss_out=loss_dev, sync=False))
+
+    def fb():
+        _, ix, iy = fx.chamfer_distance(x, y, return_indices=True, loss_out=loss_dev, sync=False)
+        fx.chamfer_distance_grad(x, y, ix, iy)
+    fwdbwd = _per_call_ms(fx, fb)
+    pairs = B_PER_GPU * NPTS * MPTS
+    return {"forward": dict(fwd, pairs_per_s_at_min=pairs / (fwd["min_ms"] * 1e-3)),
+            "forward_backward": dict(fwdbwd, pairs_per_s_at_min=pairs / (fwdbwd["min_ms"] * 1e-3)),
+            "note": "single calls between HIP events on one stream (event records included); `value` above is K back-to-back steps"}
+
+
+def config_one_liners(fx):
+    """The other BASELINE configs and the reference harness's own input, one number each (min over 100 calls, ms)."""
+    import numpy as np
+    out = {}
+    loss_dev = fx.DeviceArray.empty((1,), np.float32)
+    a = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_A, 3, 1024, 2))
+    b = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_B, 3, 1024, 2))
+    out["C1 chamfer fwd B=2 N=M=1024"] = _per_call_ms(fx, lambda: fx.chamfer_distance(a, b, loss_out=loss_dev, sync=False))
+    for n in (4096, 16384):  # benchmarks/metrics.jl:11-15,40: p_i = (i,i,i)/n, A == B, B = 1
+        p = fx.gpu(fx.synth.reference_bench_cloud(n))
+        out[f"reference harness chamfer fwd n={n} (A == B, collinear)"] = _per_call_ms(
+            fx, lambda: fx.chamfer_distance(p, p, loss_out=loss_dev, sync=False))
+    t = os.path.join(ROOT, "tests", "golden", "teapot.obj")
+    m8, m8b = fx.gpu(fx.load_trimesh(*[t] * 8)), fx.gpu(fx.load_trimesh(*[t] * 8))
+    out["C3 chamfer_distance(mesh, mesh, 5000) B=8 teapots (2 samplings + chamfer)"] = _per_call_ms(
+        fx, lambda: fx.chamfer_distance(m8, m8b, 5000, seed=5, loss_out=loss_dev, sync=False))
+    c4 = fx.gpu(fx.synth.uniform_cloud(0x5EED0004, 3, 1024, 32))
+    out["C4 kNN k=20 self graph B=32 N=1024 D=3"] = _per_call_ms(fx, lambda: fx.knn(c4, 20, drop_first=True))
+    f64 = fx.gpu(np.asfortranarray(np.random.default_rng(1).standard_normal((64, 1024, 32)).astype(np.float32)))
+    out["C4' kNN k=20 self graph B=32 N=1024 D=64 (second EdgeConv)"] = _per_call_ms(fx, lambda: fx.knn(f64, 20, drop_first=True))
+    return out
+
+
 def cpu_baseline(fx):
     """Reference CPU algorithm (per-batch-element KD-tree build + 1-NN queries, serial;
     src/metrics/pcloud.jl:54-70) as restated in oracle/flux3d_oracle.c, 1 core, on the same
     workload.  The oracle is the checker/baseline only -- never on the product path."""
+    import numpy as np
     from oracle import oracle
     x = fx.synth.uniform_cloud(fx.synth.SEED_A, DIM, NPTS, B_PER_GPU)
     y = fx.synth.uniform_cloud(fx.synth.SEED_B, DIM, MPTS, B_PER_GPU)
     oracle.chamfer_distance(x[:, :, :1], y[:, :, :1], kdtree=True)  # page in
-    best = None
-    for _ in range(3):
+    ts = []
+    for _ in range(5):
         t0 = time.perf_counter()
         oracle.chamfer_distance(x, y, kdtree=True)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
+        ts.append(time.perf_counter() - t0)
+    best, med = min(ts), float(np.median(ts))
+    # forward + backward (benchmarks/metrics.jl:28-32): KD-tree forward with indices, then the adjoint
+    tfb = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ix, iy = oracle.nn1(x, y, kdtree=True)[:2]   # the forward's KD-tree searches (its gather + mean add < 1 %)
+        oracle.chamfer_bwd(x, y, ix, iy)
+        tfb.append(time.perf_counter() - t0)
     xb, yb = x[:, :, :4], y[:, :, :4]
     t0 = time.perf_counter()
     oracle.chamfer_distance(xb, yb)
@@ -297,20 +444,18 @@ def cpu_baseline(fx):
         oracle.nn1_allcores(x, y, kdtree=False)
         dt = time.perf_counter() - t0
         dt_bf_mt = dt if dt_bf_mt is None else min(dt_bf_mt, dt)
-    extra = {"allcores_threads": nthr,
-             "kdtree_allcores_pairs_per_s": pairs / dt_kd_mt,
-             "bruteforce_allcores_pairs_per_s": pairs / dt_bf_mt,
-             "allcores_sample": f"full workload, min of 3: KD-tree {dt_kd_mt:.4f} s (64 tasks), brute force {dt_bf_mt:.4f} s",
-             "allcores_note": "NN searches only, OpenMP threads = usable cores (affinity capped by the cgroup quota); the reference itself is "
-                              "single-threaded (src/metrics/pcloud.jl:57-58), so `value` stays the 1-core figure"}
-    return {**_cpu_main(pairs, best, dt_bf), **extra}
-
-
-def _cpu_main(pairs, best, dt_bf):
     return {"value": pairs / best, "unit": "pairs/s", "cores": 1, "kind": "port",
-            "sample": f"full workload B={B_PER_GPU} N=M={NPTS}, KD-tree 1-NN both directions, min of 3 ({best:.3f} s)",
+            "sample": f"full workload B={B_PER_GPU} N=M={NPTS}, KD-tree 1-NN both directions + gather + mean, min of 5 ({best:.3f} s)",
+            "min_ms": best * 1e3, "median_ms": med * 1e3,
+            "forward_backward_min_ms": min(tfb) * 1e3, "forward_backward_median_ms": float(np.median(tfb)) * 1e3,
             "bruteforce_1core_pairs_per_s": 4 * NPTS * MPTS / dt_bf,
-            "bruteforce_sample": f"B=4 slice, exact fp32 all-pairs ({dt_bf:.3f} s)"}
+            "bruteforce_sample": f"B=4 slice, exact fp32 all-pairs ({dt_bf:.3f} s)",
+            "allcores_threads": nthr,
+            "kdtree_allcores_pairs_per_s": pairs / dt_kd_mt,
+            "bruteforce_allcores_pairs_per_s": pairs / dt_bf_mt,
+            "allcores_sample": f"full workload, min of 3: KD-tree {dt_kd_mt:.4f} s (64 tasks), brute force {dt_bf_mt:.4f} s",
+            "allcores_note": "NN searches only, OpenMP threads = usable cores (affinity capped by the cgroup quota); the reference itself is "
+                             "single-threaded (src/metrics/pcloud.jl:57-58), so `value` stays the 1-core figure"}
 
 
 if __name__ == "__main__":

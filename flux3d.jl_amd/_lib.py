@@ -50,6 +50,7 @@ SIGNATURES = {
     "fx3d_event_destroy": [vp],
     "fx3d_event_record": [vp, vp],
     "fx3d_event_sync": [vp],
+    "fx3d_stream_wait_event": [vp, vp],
     "fx3d_event_elapsed_ms": [vp, vp, C.POINTER(c_f32)],
     "fx3d_profile_enable": [c_i32],
     "fx3d_profile_kernel_stats": [C.c_char_p, C.POINTER(c_f64), C.POINTER(c_f64), C.POINTER(c_f64),
@@ -90,10 +91,15 @@ SIGNATURES = {
     "fx3d_laplacian_loss_bwd": [vp, c_i64, vp, vp, vp, c_f32, vp, c_i32, vp],
     "fx3d_comm_unique_id": [vp],
     "fx3d_comm_init_rank": [C.POINTER(vp), c_i32, vp, c_i32],
+    "fx3d_comm_bootstrap": [C.POINTER(vp), c_i32, c_i32, C.c_char_p],
+    "fx3d_comm_exchange_id": [vp, c_i32, c_i32, C.c_char_p],
+    "fx3d_comm_info": [vp, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32)],
     "fx3d_comm_destroy": [vp],
     "fx3d_comm_allreduce_sum_f64": [vp, vp, c_i64, vp],
     "fx3d_chamfer_fwd_sharded": [vp, vp, c_i32, vp, c_i32, c_i32, c_i32, c_i64, c_f32, c_f32, vp, vp,
                                  C.POINTER(c_f32), vp, sz, vp],
+    "fx3d_chamfer_fwd_sharded_async": [vp, vp, c_i32, vp, c_i32, c_i32, c_i32, c_i64, c_f32, c_f32, vp, vp, vp, sz,
+                                       vp, vp, vp, vp],
     "fx3d_build_edges_packed": [vp, c_i64, c_i64, c_i32, vp, vp, C.POINTER(c_i64)],
     "fx3d_build_laplacian_csr": [vp, c_i64, c_i64, c_i32, vp, vp, vp, C.POINTER(c_i64)],
 }

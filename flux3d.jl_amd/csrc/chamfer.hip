@@ -57,7 +57,7 @@ struct Nn1Params {
     int tiles;               // max(tiles_x, tiles_y)
     int tiles_x, tiles_y;
     int chunk;               // LDS chunk capacity (multiple of kTile)
-    int tpb;                 // MFMA variant: query-tile passes per block (>1 only for one-chunk clouds)
+    int tpb;                 // fp16 variant: query-tile passes per block (>1 only for one-chunk clouds)
     // fused finalisation (fp16 variant): the last block to arrive reduces the partials in fixed order
     unsigned int *ticket;    // library-owned arrival counter, zero between launches; nullptr = no fusion
     unsigned int nvalid;     // number of blocks that deliver a partial
@@ -86,6 +86,30 @@ __device__ __forceinline__ float sqd(const float (&q)[DIM], const float (&c)[DIM
         s = s + t * t;
     }
     return s;
+}
+
+// Order of distances = the oracle's (oracle/flux3d_oracle.c: fless): Julia's isless on Float32 -- ascending, every NaN
+// after +Inf, all NaNs equal -- then the lower index.  Squared distances are >= +0 or NaN, so the order is the unsigned
+// order of the bit patterns once NaNs are canonical; finite data never produces a NaN distance (at worst +Inf), and
+// the hot paths below only pay for this on data that is not finite.
+__device__ __forceinline__ bool fless(float a, float b) { return (a < b) || (b != b && a == a); }
+__device__ __forceinline__ unsigned int dist_key(float d) { return d != d ? 0x7fc00000u : __builtin_bit_cast(unsigned int, d); }
+
+// exact scan of a whole cloud in that order (the rare exit of the exact-loop kernels: no distance below +Inf)
+template <int DIM>
+__device__ __forceinline__ void nn1_scan_isless(const float (&q)[DIM], const float *__restrict__ cb, int NC, float &best, int &bi) {
+    float c0[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) c0[d] = cb[d];
+    best = sqd<DIM>(q, c0);
+    bi = 0;
+    for (int j = 1; j < NC; ++j) {
+        float cc[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) cc[d] = cb[(size_t)j * DIM + d];
+        const float dd = sqd<DIM>(q, cc);
+        if (fless(dd, best)) { best = dd; bi = j; }
+    }
 }
 
 template <int DIM, int R, bool WANT_IDX>
@@ -202,6 +226,8 @@ __global__ __launch_bounds__(kThreads) void nn1_small_d_kernel(Nn1Params p) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (qi[r] < NQ) {
+            // nothing below +Inf (overflowing or non-finite coordinates): min3 / `<` skipped every candidate
+            if (!(best[r] < INFINITY)) nn1_scan_isless<DIM>(q[r], cb, NC, best[r], bidx[r]);
             if (WANT_IDX && idx_out) idx_out[(size_t)b * NQ + qi[r]] = bidx[r];
             if (dmin_out) dmin_out[(size_t)b * NQ + qi[r]] = best[r];
             acc += (double)best[r];
@@ -213,265 +239,6 @@ __global__ __launch_bounds__(kThreads) void nn1_small_d_kernel(Nn1Params p) {
         if (tid == 0) p.partials[(size_t)c * p.tiles + tile] = tot;
     }
 }
-
-// ------------------------------------------------------------------------------------------------
-// nn1_filter_kernel: same decomposition as nn1_small_d_kernel, but the hot loop evaluates a cheap
-// FILTER instead of the exact distance, and the exact distance is only evaluated for the few
-// 32-candidate tiles the filter cannot rule out.  Results stay bit-identical to the oracle.
-//
-//   filter  t(i,j) = |c'_j|^2 - 2 q'_i.c'_j  =  fma(qm_x,c'_x, fma(qm_y,c'_y, fma(qm_z,c'_z, cn_j)))
-//           with c' = c - mu, q' = q - mu (mu = centre of the chunk's bounding box), qm = -2 q':
-//           3 FMA + 1/2 v_min3 per pair instead of 8 + 1/2.   argmin_j t(i,j) == argmin_j |q_i-c_j|^2
-//           in exact arithmetic (the |q'|^2 term is constant per query).
-//   band    every rounding in the filter chain is bounded by u*|partial| (u = 2^-24); with
-//           Cinf >= max|c'| per coordinate and Qs = sum_d |q'_d|:
-//             |t - T| <= E = 6u(3 Cinf^2 + 2 Cinf Qs),  and the oracle's own Float32 distance differs
-//           from the real one by <= 3u D, D <= 2 Qs^2 + 6 Cinf^2.  If j* is the oracle's argmin
-//           (lowest index among exact ties) then  t(j*) <= min_j t(j) + delta  with
-//             delta = 32u (6 Cinf^2 + 2 Cinf Qs + Qs^2)   (>= 2E + 6uD, factor >2.6 slack).
-//   track   per query a FIFO of the last kFifo tiles whose tile-minimum was within delta of the
-//           running minimum when they were processed (a superset of the tiles within delta of the
-//           FINAL minimum; if the oldest entry is within 2*delta of the final minimum an older
-//           qualifying tile may have been dropped => that query re-scans the whole chunk exactly).
-//   exact   tiles of the FIFO within delta of the chunk's filter minimum are re-scanned from the RAW
-//           coordinates kept in LDS with the oracle's arithmetic; (d, index) is reduced
-//           lexicographically, so the lowest index wins exact ties, also across chunks.
-constexpr int kFifo = 5;
-constexpr int kFChunkMax = 2048;  // (2*DIM+1)*4 B per candidate in LDS: 56 KiB at DIM=3 => 2 blocks/CU
-
-template <int DIM, int R, bool WANT_IDX>
-__global__ __launch_bounds__(kThreads) void nn1_filter_kernel(Nn1Params p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ float red[2 * 4 * (kThreads / 64)];  // bbox partials per wave (padded to 4 dims)
-
-    const int L = blockIdx.x;
-    const int xcd = L & 7, slot = L >> 3;
-    const int c = (slot / p.tiles) * 8 + xcd;
-    const int tile = slot % p.tiles;
-    if (c >= 2 * p.B) return;
-    const int dir = c >= p.B ? 1 : 0;
-    const int b = dir ? c - p.B : c;
-    const int NQ = dir ? p.M : p.N;
-    const int NC = dir ? p.N : p.M;
-    if (tile >= (dir ? p.tiles_y : p.tiles_x)) return;
-    const float *__restrict__ qb = (dir ? p.y : p.x) + (size_t)b * NQ * DIM;
-    const float *__restrict__ cb = (dir ? p.x : p.y) + (size_t)b * NC * DIM;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int CH = p.chunk, CH4 = CH >> 2;
-    float *img = lds;                   // [DIM+1][CH]: c'_x.., cn
-    float *raw = lds + (DIM + 1) * CH;  // [DIM][CH]  : untouched coordinates for the exact re-scan
-    const float4 *img4 = reinterpret_cast<const float4 *>(img);
-
-    float q[R][DIM];
-    int qi[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        qi[r] = tile * (kThreads * R) + r * kThreads + tid;
-        const int qc = qi[r] < NQ ? qi[r] : NQ - 1;
-#pragma unroll
-        for (int d = 0; d < DIM; ++d) q[r][d] = qb[(size_t)qc * DIM + d];
-    }
-    float dbest[R];
-    int ibest[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) { dbest[r] = INFINITY; ibest[r] = 0x7fffffff; }
-
-    for (int j0 = 0; j0 < NC; j0 += CH) {
-        const int cnt = (NC - j0) < CH ? (NC - j0) : CH;
-        const int cnt_pad = (cnt + kTile - 1) / kTile * kTile;
-        if (j0 > 0) __syncthreads();
-        for (int e = tid; e < cnt * DIM; e += kThreads) {  // coalesced AoS stream -> SoA
-            const float v = cb[(size_t)j0 * DIM + e];
-            const int pt = e / DIM, cc = e - pt * DIM;
-            raw[cc * CH + pt] = v;
-        }
-        __syncthreads();
-        // ---- bounding box of the chunk -> centre mu, half extent Cinf ------------------------------
-        float mn[DIM], mx[DIM];
-#pragma unroll
-        for (int d = 0; d < DIM; ++d) { mn[d] = INFINITY; mx[d] = -INFINITY; }
-        for (int pt = tid; pt < cnt; pt += kThreads) {
-#pragma unroll
-            for (int d = 0; d < DIM; ++d) {
-                const float v = raw[d * CH + pt];
-                mn[d] = fminf(mn[d], v);
-                mx[d] = fmaxf(mx[d], v);
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < DIM; ++d) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                mn[d] = fminf(mn[d], __shfl_xor(mn[d], off, 64));
-                mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off, 64));
-            }
-            if (lane == 0) { red[(wv * 2) * 4 + d] = mn[d]; red[(wv * 2 + 1) * 4 + d] = mx[d]; }
-        }
-        __syncthreads();
-        float mu[DIM], cinf = 0.0f;
-#pragma unroll
-        for (int d = 0; d < DIM; ++d) {
-            float lo = red[d], hi = red[4 + d];
-#pragma unroll
-            for (int w = 1; w < kThreads / 64; ++w) {
-                lo = fminf(lo, red[(w * 2) * 4 + d]);
-                hi = fmaxf(hi, red[(w * 2 + 1) * 4 + d]);
-            }
-            mu[d] = 0.5f * lo + 0.5f * hi;
-            cinf = fmaxf(cinf, fmaxf(hi - mu[d], mu[d] - lo));
-        }
-        cinf = cinf * 1.000001f;                      // covers the rounding of c - mu
-        const bool sane = cinf < 1.0e18f;             // false for inf/NaN/huge data: filter unusable
-        // ---- filter image --------------------------------------------------------------------------
-        for (int pt = tid; pt < cnt_pad; pt += kThreads) {
-            if (pt < cnt) {
-                float cn = 0.0f;
-#pragma unroll
-                for (int d = 0; d < DIM; ++d) {
-                    const float cc = raw[d * CH + pt] - mu[d];
-                    img[d * CH + pt] = cc;
-                    cn = cn + cc * cc;
-                }
-                img[DIM * CH + pt] = cn;
-            } else {  // padding: never wins the filter (t = +inf) nor the exact scan (d = +inf)
-#pragma unroll
-                for (int d = 0; d < DIM; ++d) { img[d * CH + pt] = 0.0f; raw[d * CH + pt] = INFINITY; }
-                img[DIM * CH + pt] = INFINITY;
-            }
-        }
-        __syncthreads();
-
-        float qm[R][DIM], delta[R], best[R], ft[R][kFifo];
-        int fi[R][kFifo];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float qs = 0.0f;
-#pragma unroll
-            for (int d = 0; d < DIM; ++d) {
-                const float qq = q[r][d] - mu[d];
-                qs += fabsf(qq);
-                qm[r][d] = -2.0f * qq;
-            }
-            delta[r] = (6.0f * cinf * cinf + 2.0f * cinf * qs + qs * qs) * 0x1p-19f;
-            best[r] = INFINITY;
-#pragma unroll
-            for (int s = 0; s < kFifo; ++s) { ft[r][s] = INFINITY; fi[r][s] = -1; }
-        }
-
-        const int ntile = cnt_pad / kTile;
-        for (int t = 0; t < ntile; ++t) {
-            float tm[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) tm[r] = INFINITY;
-#pragma unroll
-            for (int jj = 0; jj < kTile; jj += 4) {
-                float4 cv[DIM + 1];
-#pragma unroll
-                for (int d = 0; d <= DIM; ++d) cv[d] = img4[d * CH4 + t * (kTile / 4) + jj / 4];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float t0 = cv[DIM].x, t1 = cv[DIM].y, t2 = cv[DIM].z, t3 = cv[DIM].w;
-#pragma unroll
-                    for (int d = DIM - 1; d >= 0; --d) {
-                        t0 = __builtin_fmaf(qm[r][d], cv[d].x, t0);
-                        t1 = __builtin_fmaf(qm[r][d], cv[d].y, t1);
-                        t2 = __builtin_fmaf(qm[r][d], cv[d].z, t2);
-                        t3 = __builtin_fmaf(qm[r][d], cv[d].w, t3);
-                    }
-                    tm[r] = min3f(tm[r], t0, t1);
-                    tm[r] = min3f(tm[r], t2, t3);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const bool qual = tm[r] <= best[r] + delta[r];  // +inf start: first tile qualifies
-#pragma unroll
-                for (int s = kFifo - 1; s > 0; --s) {
-                    ft[r][s] = qual ? ft[r][s - 1] : ft[r][s];
-                    fi[r][s] = qual ? fi[r][s - 1] : fi[r][s];
-                }
-                ft[r][0] = qual ? tm[r] : ft[r][0];
-                fi[r][0] = qual ? t : fi[r][0];
-                best[r] = fminf(best[r], tm[r]);
-            }
-        }
-
-        // ---- exact phase --------------------------------------------------------------------------
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float thr1 = best[r] + delta[r], thr2 = thr1 + delta[r];
-            const bool slow = !sane || !(ft[r][kFifo - 1] > thr2) || !(best[r] < INFINITY);
-            if (slow) {  // rare: exact scan of the whole chunk for this query
-#pragma unroll 1
-                for (int jj = 0; jj < cnt_pad; ++jj) {
-                    float cc[DIM];
-#pragma unroll
-                    for (int d = 0; d < DIM; ++d) cc[d] = raw[d * CH + jj];
-                    const float dd = sqd<DIM>(q[r], cc);
-                    const int jg = j0 + jj;
-                    if (dd < dbest[r] || (dd == dbest[r] && jg < ibest[r])) { dbest[r] = dd; ibest[r] = jg; }
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < kFifo; ++s) {
-                    if (fi[r][s] >= 0 && ft[r][s] <= thr1) {
-                        const int off = fi[r][s] * kTile;
-#pragma unroll 2
-                        for (int jj = 0; jj < kTile; ++jj) {
-                            float cc[DIM];
-#pragma unroll
-                            for (int d = 0; d < DIM; ++d) cc[d] = raw[d * CH + off + jj];
-                            const float dd = sqd<DIM>(q[r], cc);
-                            const int jg = j0 + off + jj;
-                            if (dd < dbest[r] || (dd == dbest[r] && jg < ibest[r])) { dbest[r] = dd; ibest[r] = jg; }
-                        }
-                    }
-                }
-            }
-        }
-    }
-
-    int32_t *idx_out = dir ? p.idx_y : p.idx_x;
-    float *dmin_out = dir ? p.dmin_y : p.dmin_x;
-    double acc = 0.0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (qi[r] < NQ) {
-            if (WANT_IDX && idx_out) idx_out[(size_t)b * NQ + qi[r]] = ibest[r];
-            if (dmin_out) dmin_out[(size_t)b * NQ + qi[r]] = dbest[r];
-            acc += (double)dbest[r];
-        }
-    }
-    if (p.partials) {
-        __shared__ double sm[kThreads / 64];
-        const double tot = block_sum<kThreads>(acc, sm);
-        if (tid == 0) p.partials[(size_t)c * p.tiles + tile] = tot;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// nn1_mfma_kernel (D = 3): the same filter as nn1_filter_kernel, evaluated on the matrix pipe.
-//
-//   t(i,j) = [c'_x c'_y c'_z cn]_i . [-2q'_x -2q'_y -2q'_z 1]_j  is a K=4 inner product, exactly the shape
-//   of v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate, an fmaf chain, at the full fp32 rate and on a
-//   pipe separate from the VALU): A = 16 candidates x 4, B = 4 x 16 queries, one instruction = 256
-//   filter values; the VALU only folds them (v_min3) and tracks tiles.  A wave owns QG groups of 16
-//   queries (B operands stay in registers: 1 VGPR per group) and streams the candidate image from LDS
-//   with ONE conflict-free ds_read_b32 per 16 candidates (the image is stored in A-fragment order:
-//   [block][k][16]).  D[row][col]: lane l holds rows (l>>4)*4+r, r=0..3, of column l&15, i.e. 4
-//   candidates of ONE query, so folding needs no cross-lane traffic; the four lanes that share a
-//   query (l, l^16, l^32, l^48) are merged once per chunk (filter minimum) and once at the end
-//   (exact (d, index), lexicographic).
-//   Tile tracking / error band / exact re-scan are those of nn1_filter_kernel, per lane: a "lane
-//   tile" is kLT blocks = 64 consecutive candidates of which the lane sees 16.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kMThreads = 512;     // 8 waves share one LDS chunk
-constexpr int kLT = 4;             // 16-candidate blocks per lane tile
-constexpr int kMFifo = 4;
-constexpr int kMChunkMax = 4096;   // 16 B per candidate in LDS => 64 KiB => 2 blocks (16 waves) per CU
-constexpr int kItemCap = 128;      // exact-phase items per wave (typ. ~ QG*16 = 32)
-constexpr size_t kMScratchBytes = (kMThreads / 64) * (2 * 16 * 8 + kItemCap * 4 + 2 * 16 * 3 * 4);  // QG <= 2
 
 // wave64 min / max by DPP (VALU speed; __shfl_xor would go through the LDS crossbar)
 template <int CTRL>
@@ -500,393 +267,6 @@ __device__ __forceinline__ void load4pts(const float *__restrict__ base, int p0,
     px[1] = f0.w; py[1] = f1.x; pz[1] = f1.y;
     px[2] = f1.z; py[2] = f1.w; pz[2] = f2.x;
     px[3] = f2.y; py[3] = f2.z; pz[3] = f2.w;
-}
-
-template <int QG, bool WANT_IDX>
-__global__ __launch_bounds__(kMThreads, 4) void nn1_mfma_kernel(Nn1Params p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // image [CH/16][4][16], A-fragment order
-    __shared__ float red[2 * 4 * (kMThreads / 64)];
-    constexpr int QB = (kMThreads / 64) * QG * 16;  // queries per tile pass
-
-    const int L = blockIdx.x;
-    const int xcd = L & 7, slot = L >> 3;
-    const int c = (slot / p.tiles) * 8 + xcd;
-    const int tile = slot % p.tiles;
-    if (c >= 2 * p.B) return;
-    const int dir = c >= p.B ? 1 : 0;
-    const int b = dir ? c - p.B : c;
-    const int NQ = dir ? p.M : p.N;
-    const int NC = dir ? p.N : p.M;
-    if (tile >= (dir ? p.tiles_y : p.tiles_x)) return;
-    const float *__restrict__ qb = (dir ? p.y : p.x) + (size_t)b * NQ * 3;
-    const float *__restrict__ cb = (dir ? p.x : p.y) + (size_t)b * NC * 3;
-    int32_t *idx_out = dir ? p.idx_y : p.idx_x;
-    float *dmin_out = dir ? p.dmin_y : p.dmin_x;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int jq = lane & 15, kg = lane >> 4;
-    const int CH = p.chunk;
-    float *img = lds;
-    // per-wave scratch of the exact phase, carved behind the image (16-B aligned offsets)
-    unsigned long long *wres = reinterpret_cast<unsigned long long *>(lds + 4 * CH);
-    unsigned int *witems = reinterpret_cast<unsigned int *>(wres + (kMThreads / 64) * QG * 16);
-    float *wq = reinterpret_cast<float *>(witems + (kMThreads / 64) * kItemCap);
-    const bool vec = (reinterpret_cast<uintptr_t>(cb) & 15) == 0;  // 16-B aligned cloud: float4 loads
-    // fast path: the whole cloud is one chunk: the raw coordinates are parked in the LDS image slots
-    // while the bounding box is reduced, then centred in place (each thread re-reads only what it wrote)
-    // => ONE global round trip for bbox + image, no registers held across the barrier.
-    const bool one_shot = vec && NC <= CH;
-    FX3D_PROBE_MARK(0);
-
-    // ---- bounding box of the whole candidate cloud -> centre mu, half extent cinf ---------------------
-    float mu[3], cinf = 0.0f;
-    const int nv = vec ? NC / 4 : 0;
-    {
-        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int q4 = tid; q4 < nv; q4 += kMThreads) {
-            float ax[4], ay[4], az[4];
-            load4pts(cb, q4 * 4, ax, ay, az);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                mn[0] = fminf(mn[0], ax[e]); mx[0] = fmaxf(mx[0], ax[e]);
-                mn[1] = fminf(mn[1], ay[e]); mx[1] = fmaxf(mx[1], ay[e]);
-                mn[2] = fminf(mn[2], az[e]); mx[2] = fmaxf(mx[2], az[e]);
-            }
-            if (one_shot) {
-                const int pt = q4 * 4;
-                float4 *dst4 = reinterpret_cast<float4 *>(img + (pt >> 4) * 64 + (pt & 15));
-                dst4[0] = float4{ax[0], ax[1], ax[2], ax[3]};
-                dst4[4] = float4{ay[0], ay[1], ay[2], ay[3]};
-                dst4[8] = float4{az[0], az[1], az[2], az[3]};
-            }
-        }
-        for (int pt = nv * 4 + tid; pt < NC; pt += kMThreads) {  // tail / unaligned clouds
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const float v = cb[(size_t)pt * 3 + d];
-                mn[d] = fminf(mn[d], v);
-                mx[d] = fmaxf(mx[d], v);
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float lo = wave_min_f(mn[d]), hi = wave_max_f(mx[d]);
-            if (lane == 0) { red[(wv * 2) * 4 + d] = lo; red[(wv * 2 + 1) * 4 + d] = hi; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            float lo = red[d], hi = red[4 + d];
-#pragma unroll
-            for (int w = 1; w < kMThreads / 64; ++w) {
-                lo = fminf(lo, red[(w * 2) * 4 + d]);
-                hi = fmaxf(hi, red[(w * 2 + 1) * 4 + d]);
-            }
-            mu[d] = 0.5f * lo + 0.5f * hi;
-            cinf = fmaxf(cinf, fmaxf(hi - mu[d], mu[d] - lo));
-        }
-        cinf = cinf * 1.000001f;  // covers the rounding of c - mu
-    }
-    const bool sane = cinf < 1.0e18f;  // false for inf/NaN/huge data: filter unusable, exact scan instead
-    FX3D_PROBE_MARK(1);
-
-    // per-tile-pass query state (persists across chunks when the cloud needs several; then tpb == 1)
-    float qr[QG][3], bq[QG], delta[QG], dbest[QG];
-    int qi[QG], ibest[QG];
-    double acc = 0.0;
-
-    for (int j0 = 0; j0 < NC; j0 += CH) {
-        const int cnt = (NC - j0) < CH ? (NC - j0) : CH;
-        const int cnt_pad = (cnt + 16 * kLT - 1) / (16 * kLT) * (16 * kLT);
-        if (j0 > 0) __syncthreads();
-        // ---- stage the filter image (c' and |c'|^2 in A-fragment order) ----------------------------------
-        const int cnt4 = vec ? cnt / 4 : 0;
-        if (one_shot) {
-            for (int q4 = tid; q4 < cnt4; q4 += kMThreads) {  // centre in place what this thread parked
-                const int pt = q4 * 4;
-                float4 *dst4 = reinterpret_cast<float4 *>(img + (pt >> 4) * 64 + (pt & 15));
-                float4 vx = dst4[0], vy = dst4[4], vz = dst4[8], vn;
-                float *ox = &vx.x, *oy = &vy.x, *oz = &vz.x, *on = &vn.x;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float c0 = ox[e] - mu[0], c1 = oy[e] - mu[1], c2 = oz[e] - mu[2];
-                    ox[e] = c0; oy[e] = c1; oz[e] = c2;
-                    on[e] = ((c0 * c0) + (c1 * c1)) + (c2 * c2);
-                }
-                dst4[0] = vx; dst4[4] = vy; dst4[8] = vz; dst4[12] = vn;
-            }
-        } else {
-            for (int q4 = tid; q4 < cnt4; q4 += kMThreads) {
-                float ax[4], ay[4], az[4];
-                load4pts(cb, j0 + q4 * 4, ax, ay, az);
-                float4 vx, vy, vz, vn;
-                float *ox = &vx.x, *oy = &vy.x, *oz = &vz.x, *on = &vn.x;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float c0 = ax[e] - mu[0], c1 = ay[e] - mu[1], c2 = az[e] - mu[2];
-                    ox[e] = c0; oy[e] = c1; oz[e] = c2;
-                    on[e] = ((c0 * c0) + (c1 * c1)) + (c2 * c2);
-                }
-                const int pt = q4 * 4;
-                float4 *dst4 = reinterpret_cast<float4 *>(img + (pt >> 4) * 64 + (pt & 15));
-                dst4[0] = vx; dst4[4] = vy; dst4[8] = vz; dst4[12] = vn;
-            }
-        }
-        for (int pt = cnt4 * 4 + tid; pt < cnt_pad; pt += kMThreads) {
-            float *dst = img + (pt >> 4) * 64 + (pt & 15);
-            if (pt < cnt) {
-                const float *src = cb + (size_t)(j0 + pt) * 3;
-                const float c0 = src[0] - mu[0], c1 = src[1] - mu[1], c2 = src[2] - mu[2];
-                dst[0] = c0; dst[16] = c1; dst[32] = c2;
-                dst[48] = ((c0 * c0) + (c1 * c1)) + (c2 * c2);
-            } else {  // padding: t = +inf, never within any band
-                dst[0] = 0.0f; dst[16] = 0.0f; dst[32] = 0.0f; dst[48] = INFINITY;
-            }
-        }
-        __syncthreads();
-        FX3D_PROBE_MARK(j0 == 0 ? 2 : 6);
-
-        // ---- tile passes: several query tiles reuse the staged image (single-chunk clouds) ---------------
-        for (int tp = 0; tp < p.tpb; ++tp) {
-            if (j0 == 0) {
-#pragma unroll
-                for (int g = 0; g < QG; ++g) {
-                    qi[g] = (tile * p.tpb + tp) * QB + (wv * QG + g) * 16 + jq;
-                    const int qc = qi[g] < NQ ? qi[g] : NQ - 1;
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) qr[g][d] = qb[(size_t)qc * 3 + d];
-                    // B operand rows k = 0..2: -2 q'_k ; row k = 3: 1.0
-                    const float q0 = qr[g][0] - mu[0], q1 = qr[g][1] - mu[1], q2 = qr[g][2] - mu[2];
-                    const float qs = (fabsf(q0) + fabsf(q1)) + fabsf(q2);
-                    const float sel = kg == 0 ? q0 : (kg == 1 ? q1 : (kg == 2 ? q2 : -0.5f));
-                    bq[g] = -2.0f * sel;
-                    delta[g] = (6.0f * cinf * cinf + 2.0f * cinf * qs + qs * qs) * 0x1p-19f;
-                    dbest[g] = INFINITY;
-                    ibest[g] = 0x7fffffff;
-                }
-            }
-            if ((tile * p.tpb + tp) * QB >= NQ) break;  // uniform: no queries left for this block
-
-            float best[QG], ft[QG][kMFifo], tm[QG];
-            int fi[QG][kMFifo];
-#pragma unroll
-            for (int g = 0; g < QG; ++g) {
-                best[g] = INFINITY;
-                tm[g] = INFINITY;
-#pragma unroll
-                for (int s = 0; s < kMFifo; ++s) { ft[g][s] = INFINITY; fi[g][s] = -1; }
-            }
-
-            // ---- main loop: software-pipelined by one 16-candidate block ----------------------------------
-            // MFMAs of block blk+1 are issued before the results of block blk are folded, so no VALU
-            // instruction ever waits on the matrix pipe and the pipe always has work queued.
-            const int nblk = cnt_pad / 16;  // multiple of kLT
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            f32x4 accC[QG], accN[QG];
-            float a_nxt;
-            {
-                const float a0 = img[lane];
-#pragma unroll
-                for (int g = 0; g < QG; ++g) accC[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bq[g], zero, 0, 0, 0);
-                a_nxt = img[(nblk > 1 ? 64 : 0) + lane];
-            }
-            for (int lt = 0; lt < nblk / kLT; ++lt) {
-#pragma unroll
-                for (int bb = 0; bb < kLT; ++bb) {
-                    const int blk = lt * kLT + bb;
-                    const int b2 = blk + 2 < nblk ? blk + 2 : nblk - 1;
-                    const float a_n2 = img[b2 * 64 + lane];
-#pragma unroll
-                    for (int g = 0; g < QG; ++g) accN[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_nxt, bq[g], zero, 0, 0, 0);
-#pragma unroll
-                    for (int g = 0; g < QG; ++g) {
-                        tm[g] = min3f(tm[g], accC[g][0], accC[g][1]);
-                        tm[g] = min3f(tm[g], accC[g][2], accC[g][3]);
-                        accC[g] = accN[g];
-                    }
-                    a_nxt = a_n2;
-                }
-#ifndef FX3D_ABLATE_TRACK
-#pragma unroll
-                for (int g = 0; g < QG; ++g) {
-                    const bool qual = tm[g] <= best[g] + delta[g];
-#pragma unroll
-                    for (int s = kMFifo - 1; s > 0; --s) {
-                        ft[g][s] = qual ? ft[g][s - 1] : ft[g][s];
-                        fi[g][s] = qual ? fi[g][s - 1] : fi[g][s];
-                    }
-                    ft[g][0] = qual ? tm[g] : ft[g][0];
-                    fi[g][0] = qual ? lt : fi[g][0];
-                    best[g] = fminf(best[g], tm[g]);
-                    tm[g] = INFINITY;
-                }
-#endif
-            }
-#ifdef FX3D_ABLATE_TRACK
-#pragma unroll
-            for (int g = 0; g < QG; ++g) { best[g] = tm[g]; ft[g][0] = tm[g]; fi[g][0] = 0; }
-#endif
-            FX3D_PROBE_MARK(tp == 0 ? 3 : 7);
-
-            // ---- exact phase, wave-cooperative ---------------------------------------------------------------
-            // Lane tiles within the band of the QUERY's filter minimum (4 lanes share a query) become ITEMS
-            // in a per-wave LDS list; every item is kLT runs of 4 consecutive candidates (48 contiguous
-            // bytes of the raw cloud, L2 resident).  All 64 lanes then take (item, run) tasks, evaluate
-            // the oracle's distance and reduce (d, index) per query with a 64-bit LDS atomic min
-            // (d >= 0, so the IEEE bit pattern orders like the value; ties resolve to the lower index).
-            unsigned long long *qres = wres + wv * (QG * 16);        // per-wave: one slot per query
-            unsigned int *items = witems + wv * kItemCap;            // per-wave item list
-            float *qtab = wq + wv * (QG * 16 * 3);                   // per-wave raw query coordinates
-            if (j0 == 0 && kg == 0) {
-#pragma unroll
-                for (int g = 0; g < QG; ++g) {
-                    qres[g * 16 + jq] = ~0ull;
-                    qtab[(g * 16 + jq) * 3 + 0] = qr[g][0];
-                    qtab[(g * 16 + jq) * 3 + 1] = qr[g][1];
-                    qtab[(g * 16 + jq) * 3 + 2] = qr[g][2];
-                }
-            }
-            int nitems = 0;
-            bool any_slow = false;
-#pragma unroll
-            for (int g = 0; g < QG; ++g) {
-                float m = best[g];
-                m = fminf(m, __shfl_xor(m, 16, 64));
-                m = fminf(m, __shfl_xor(m, 32, 64));
-                const float thr1 = m + delta[g], thr2 = thr1 + delta[g];
-                const bool slow = !sane || !(ft[g][kMFifo - 1] > thr2) || !(m < INFINITY);
-#ifdef FX3D_ABLATE_EXACT
-                if (m == 123.456f) qres[g * 16 + jq] = fi[g][0];
-                continue;
-#endif
-                if (__ballot(slow)) {
-                    any_slow = true;
-                    if (slow) {  // rare: this lane scans all of its rows of the chunk exactly
-                        float db = INFINITY;
-                        int ib = 0x7fffffff;
-#pragma unroll 1
-                        for (int blk = 0; blk < cnt_pad / 16; ++blk) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int jl = blk * 16 + kg * 4 + r;
-                                if (jl < cnt) {
-                                    const float *src = cb + (size_t)(j0 + jl) * 3;
-                                    const float cc[3] = {src[0], src[1], src[2]};
-                                    const float dd = sqd<3>(qr[g], cc);
-                                    if (dd < db) { db = dd; ib = j0 + jl; }
-                                }
-                            }
-                        }
-                        atomicMin(&qres[g * 16 + jq],
-                                  ((unsigned long long)__builtin_bit_cast(unsigned int, db) << 32) | (unsigned int)ib);
-                    }
-                }
-#pragma unroll
-                for (int s = 0; s < kMFifo; ++s) {
-                    const bool qual = !slow && fi[g][s] >= 0 && ft[g][s] <= thr1;
-                    const unsigned long long bal = __ballot(qual);
-                    if (bal) {
-                        const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
-                                                __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
-                        if (qual && pos < kItemCap)
-                            items[pos] = ((unsigned int)(g * 16 + jq) << 16) | ((unsigned int)kg << 12) | (unsigned int)fi[g][s];
-                        nitems += __builtin_popcountll(bal);
-                    }
-                }
-            }
-            // all lanes of the wave see the list (same wave: LDS ops are in order, wait for the writes)
-            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-            __builtin_amdgcn_wave_barrier();
-            const int ntask = (nitems < kItemCap ? nitems : kItemCap) * kLT;
-            for (int t0 = 0; t0 < ntask; t0 += 64) {
-                const int t = t0 + lane;
-                if (t < ntask) {
-                    const unsigned int it = items[t / kLT];
-                    const int run = t % kLT;
-                    const int qs = it >> 16, ikg = (it >> 12) & 3, tl = it & 0xfff;
-                    const int jl0 = (tl * kLT + run) * 16 + ikg * 4;
-                    float cx[4], cy[4], cz[4];
-                    if (vec && jl0 + 4 <= cnt) {
-                        load4pts(cb, j0 + jl0, cx, cy, cz);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int jc = jl0 + r < cnt ? jl0 + r : cnt - 1;
-                            const float *src = cb + (size_t)(j0 + jc) * 3;
-                            cx[r] = src[0]; cy[r] = src[1]; cz[r] = src[2];
-                        }
-                    }
-                    const float qq[3] = {qtab[qs * 3], qtab[qs * 3 + 1], qtab[qs * 3 + 2]};
-                    float db = INFINITY;
-                    int ib = 0x7fffffff;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float cc3[3] = {cx[r], cy[r], cz[r]};
-                        const float dd = sqd<3>(qq, cc3);
-                        if (jl0 + r < cnt && dd < db) { db = dd; ib = j0 + jl0 + r; }  // ascending index: first min
-                    }
-                    atomicMin(&qres[qs], ((unsigned long long)__builtin_bit_cast(unsigned int, db) << 32) | (unsigned int)ib);
-                }
-            }
-            if (nitems > kItemCap) {  // list overflow (pathological ties): every lane re-scans its FIFO tiles
-#pragma unroll
-                for (int g = 0; g < QG; ++g) {
-                    float m = best[g];
-                    m = fminf(m, __shfl_xor(m, 16, 64));
-                    m = fminf(m, __shfl_xor(m, 32, 64));
-                    const float thr1 = m + delta[g];
-#pragma unroll 1
-                    for (int s = 0; s < kMFifo; ++s) {
-                        if (fi[g][s] >= 0 && ft[g][s] <= thr1) {
-                            float db = INFINITY;
-                            int ib = 0x7fffffff;
-                            for (int e = 0; e < kLT * 4; ++e) {
-                                const int jl = (fi[g][s] * kLT + (e >> 2)) * 16 + kg * 4 + (e & 3);
-                                if (jl < cnt) {
-                                    const float *src = cb + (size_t)(j0 + jl) * 3;
-                                    const float cc[3] = {src[0], src[1], src[2]};
-                                    const float dd = sqd<3>(qr[g], cc);
-                                    if (dd < db) { db = dd; ib = j0 + jl; }
-                                }
-                            }
-                            atomicMin(&qres[g * 16 + jq],
-                                      ((unsigned long long)__builtin_bit_cast(unsigned int, db) << 32) | (unsigned int)ib);
-                        }
-                    }
-                }
-            }
-            (void)any_slow;
-            FX3D_PROBE_MARK(tp == 0 ? 4 : 8);
-
-            if (j0 + CH >= NC) {
-                // ---- last chunk: results of this tile pass ---------------------------------------------------
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                if (kg == 0) {
-#pragma unroll
-                    for (int g = 0; g < QG; ++g) {
-                        const unsigned long long r = qres[g * 16 + jq];
-                        const float dd = __builtin_bit_cast(float, (unsigned int)(r >> 32));
-                        const int ii = (int)(unsigned int)r;
-                        if (qi[g] < NQ) {
-                            if (WANT_IDX && idx_out) idx_out[(size_t)b * NQ + qi[g]] = ii;
-                            if (dmin_out) dmin_out[(size_t)b * NQ + qi[g]] = dd;
-                            acc += (double)dd;
-                        }
-                        qres[g * 16 + jq] = ~0ull;  // ready for the next tile pass
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
-    FX3D_PROBE_MARK(11);
-    if (p.partials) {
-        __shared__ double sm[kMThreads / 64];
-        const double tot = block_sum<kMThreads>(acc, sm);
-        if (tid == 0) p.partials[(size_t)c * p.tiles + tile] = tot;
-    }
-    FX3D_PROBE_MARK(12);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1007,6 +387,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     //      |c - mu| cinf, power-of-two scale sc with cinf*sc in [64,128): seven binades of fp16 range above 1, so that a bulk
     //      much smaller than the farthest point keeps its fp16 pieces out of the subnormals; |c~|^2 < 3 * 2^14 fits fp16 ----
     float mu[3], cinf = 0.0f;
+    bool allfin = true;
     const int nv = vec ? NC / 4 : 0;
     {
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sm3[3] = {0.f, 0.f, 0.f};
@@ -1052,12 +433,17 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 hi = fmaxf(hi, red[(w * 3 + 1) * 4 + d]);
                 st = st + red[(w * 3 + 2) * 4 + d];
             }
-            mu[d] = fminf(fmaxf(st / (float)NC, lo), hi);  // (any centre is correct; NaN data -> not sane below)
+            mu[d] = fminf(fmaxf(st / (float)NC, lo), hi);  // (any centre is correct)
             cinf = fmaxf(cinf, fmaxf(hi - mu[d], mu[d] - lo));
+            // a NaN or +-Inf coordinate makes the coordinate sum non-finite (fminf / fmaxf above skip NaNs)
+            allfin = allfin && fabsf(st) < INFINITY;
         }
         cinf = cinf * 1.000001f;
     }
-    const bool sane = cinf < 1.0e18f;
+    // not sane (non-finite or huge coordinates): the filter is unusable, every query of the block scans every lane
+    // tile exactly, in the isless order (a finite cloud with cinf < 1e16 never produces an infinite or NaN distance
+    // to a query inside the fp16 range)
+    const bool sane = allfin && cinf < 1.0e16f;  // usable queries lie within 234 cinf of the centre: 3 (235 cinf)^2 stays finite
     float sc = 1.0f;
     if (sane && cinf > 1.0e-30f) {
         int e;
@@ -1191,7 +577,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             }
             FX3D_PROBE_MARK(tp == 0 ? 3 : 7);
 
-            // ---- exact phase, wave-cooperative (see nn1_mfma_kernel) ----------------------------------------
+            // ---- exact phase, wave-cooperative ----------------------------------------------------------------
             {
                 const float m = fminf(best, __shfl_xor(best, 32, 64));
                 const float thr1 = __builtin_fmaf(m, kBandB1, da), thr2 = __builtin_fmaf(thr1, kBandB1, da);
@@ -1202,6 +588,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 // with the now known threshold and enqueues exactly the lane tiles within the band (every
                 // tile for lanes whose filter is unusable), draining the list whenever it is full.
                 const bool retry = __ballot(slow) != 0;
+                // a NaN distance needs a non-finite cloud or a non-finite query (wave-uniform switch of the task code)
+                const bool nonfinite = !sane || __ballot(!(fabsf(qr[0]) + fabsf(qr[1]) + fabsf(qr[2]) < INFINITY)) != 0;
                 const int nlt = nblk / kHLT;
                 int lt2 = 0;
                 do {
@@ -1263,15 +651,27 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                                 }
                             }
                             const float qq[3] = {qtab[qs * 3], qtab[qs * 3 + 1], qtab[qs * 3 + 2]};
-                            float db = INFINITY;
-                            int ib = 0x7fffffff;
+                            unsigned int kb;
+                            int ib = j0 + jl0;  // an all-+Inf run still names a real candidate (its first)
+                            if (!nonfinite) {   // distances are >= 0 or +Inf: float order == key order
+                                float db = INFINITY;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float cc3[3] = {cx[r], cy[r], cz[r]};
-                                const float dd = sqd<3>(qq, cc3);
-                                if (jl0 + r < cnt && dd < db) { db = dd; ib = j0 + jl0 + r; }
+                                for (int r = 0; r < 4; ++r) {
+                                    const float cc3[3] = {cx[r], cy[r], cz[r]};
+                                    const float dd = sqd<3>(qq, cc3);
+                                    if (jl0 + r < cnt && dd < db) { db = dd; ib = j0 + jl0 + r; }
+                                }
+                                kb = __builtin_bit_cast(unsigned int, db);
+                            } else {            // NaN distances possible: canonical keys, NaN after +Inf
+                                kb = 0xffffffffu;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float cc3[3] = {cx[r], cy[r], cz[r]};
+                                    const unsigned int kd = dist_key(sqd<3>(qq, cc3));
+                                    if (jl0 + r < cnt && kd < kb) { kb = kd; ib = j0 + jl0 + r; }
+                                }
                             }
-                            atomicMin(&qres[qs], ((unsigned long long)__builtin_bit_cast(unsigned int, db) << 32) | (unsigned int)ib);
+                            if (jl0 < cnt) atomicMin(&qres[qs], ((unsigned long long)kb << 32) | (unsigned int)ib);
                         }
                     }
                 } while (lt2 < nlt);
@@ -1381,14 +781,14 @@ __global__ __launch_bounds__(kThreads) void nn1_generic_kernel(Nn1Params p, int 
     const int i = tile * kThreads + threadIdx.x;
     double acc = 0.0;
     if (i < NQ) {
-        float best = INFINITY;
+        float best = 0.0f;
         int bi = 0;
         const float *a = qb + (size_t)i * D;
         for (int j = 0; j < NC; ++j) {
             const float *cc = cb + (size_t)j * D;
             float s = 0.0f;
             for (int d = 0; d < D; ++d) { float t = a[d] - cc[d]; s = s + t * t; }
-            if (s < best) { best = s; bi = j; }
+            if (j == 0 || fless(s, best)) { best = s; bi = j; }
         }
         int32_t *idx_out = dir ? p.idx_y : p.idx_x;
         float *dmin_out = dir ? p.dmin_y : p.dmin_x;
@@ -1493,108 +893,87 @@ __global__ __launch_bounds__(kThreads) void chamfer_bwd_kernel(
 struct Plan {
     int R, tiles_x, tiles_y, tiles, chunk, grid;
     size_t lds_bytes;
-    int variant;  // 0 = exact hot loop, 1 = VALU filter, 2 = f32 MFMA filter, 3 = fp16-split MFMA filter (+ exact re-scan)
+    int variant;  // 0 = exact hot loop (D = 2, and D = 3 under FX3D_NN1_VARIANT=0), 3 = fp16-split MFMA filter + exact re-scan
     int threads, tpb;
     int nsplit;  // fp16 variant: chunk subsets per query tile (multi-chunk clouds with too few blocks)
 };
 
-// FX3D_NN1_VARIANT=0/1 overrides the default (for A/B measurements).
+// FX3D_NN1_VARIANT=0 selects the exact VALU loop for D = 3 (A/B measurements; the f32 VALU / MFMA filter variants
+// of round 1 are in the history: DESIGN.md 3.1 "ladder").
 int nn1_variant() {
     static const int v = [] {
         const char *e = getenv("FX3D_NN1_VARIANT");
-        return e ? atoi(e) : 3;
+        return e && atoi(e) == 0 ? 0 : 3;
     }();
     return v;
 }
 
 Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
     Plan pl{};
-    // R queries per thread: enough blocks to fill 256 CUs x ~2 blocks, but as much register
-    // blocking (LDS-read amortisation, ILP) as the problem size allows.
     const long long work = (long long)B * ((long long)N + M);  // total queries, both directions
-    pl.variant = nn1_variant();
-    if (D != 3 && pl.variant >= 2) pl.variant = 1;  // the MFMA images are built for D = 3
-    pl.threads = pl.variant == 3 ? kHThreads : (pl.variant == 2 ? kMThreads : kThreads);
+    pl.variant = D == 3 ? nn1_variant() : 0;
+    pl.threads = pl.variant == 3 ? kHThreads : kThreads;
+    // exact loop: R queries per thread -- enough blocks to fill 256 CUs x ~2 blocks, but as much register
+    // blocking (LDS-read amortisation, ILP) as the problem size allows.
     int R = 4;
-    if (pl.variant == 2) {
-        // R = query groups of 16 per wave: 8 waves x R x 16 queries per block
-        R = 2;
-        while (R > 1 && work / (128 * R) < 1024) R >>= 1;
-    } else {
-        while (R > 1 && work / (kThreads * R) < 512) R >>= 1;
-    }
+    while (R > 1 && work / (kThreads * R) < 512) R >>= 1;
     pl.R = R;
     pl.tpb = 1;
-    if (pl.variant == 3 && N <= kHChunkMax && M <= kHChunkMax) {
-        // one-chunk clouds: several 512-query tile passes per block; keep >= 256 blocks (1 per CU)
-        while (pl.tpb < 8 && work / (512 * pl.tpb * 2) >= 256) pl.tpb *= 2;
-        static const int tpb_env3 = [] { const char *e = getenv("FX3D_NN1_TPB"); return e ? atoi(e) : 0; }();
-        if (tpb_env3 > 0) pl.tpb = tpb_env3;
-    }
-    if (pl.variant == 2 && N <= kMChunkMax && M <= kMChunkMax) {
-        // one-chunk clouds: a block may run several query tiles against the staged image; keep >= 512
-        // blocks (2 per CU) in flight
-        while (pl.tpb < 8 && work / (128 * R * pl.tpb * 2) >= 512) pl.tpb *= 2;
-        static const int tpb_env = [] { const char *e = getenv("FX3D_NN1_TPB"); return e ? atoi(e) : 0; }();
-        if (tpb_env > 0) pl.tpb = tpb_env;
-    }
-    const int per_block = pl.variant == 3 ? 512 * pl.tpb : (pl.variant == 2 ? 128 * R * pl.tpb : kThreads * R);
-    pl.tiles_x = (N + per_block - 1) / per_block;
-    pl.tiles_y = (M + per_block - 1) / per_block;
-    pl.tiles = pl.tiles_x > pl.tiles_y ? pl.tiles_x : pl.tiles_y;
     const int maxc = N > M ? N : M;
-    const int cmax = pl.variant == 3 ? kHChunkMax : (pl.variant == 2 ? kMChunkMax : (pl.variant == 1 ? kFChunkMax : kChunkMax));
-    const int gran = pl.variant == 3 ? 32 * kHLT : (pl.variant == 2 ? 16 * kLT : kTile);
-    int chunk = (maxc + gran - 1) / gran * gran;
-    if (chunk > cmax) chunk = cmax;
-    pl.chunk = chunk;
-    const int floats_per_cand = pl.variant == 3 ? 8 : (pl.variant == 2 ? 4 : (pl.variant == 1 ? 2 * D + 1 : D));
-    pl.lds_bytes = (size_t)chunk * (D <= 3 ? floats_per_cand : 0) * sizeof(float);
-    if (pl.variant == 2) pl.lds_bytes += kMScratchBytes;
-    if (pl.variant == 3) pl.lds_bytes += kHScratchBytes;
     const int clouds8 = (2 * B + 7) / 8;
     pl.nsplit = 1;
-    if (pl.variant == 3) {
-        // nn1_f16_kernel: choose (candidate chunk size, chunks per block, 512-query passes per block) by a small
-        // cost model in microseconds, measured at C2 (tools/nn1_probe.hip): bounding box 2.8 per 4096 candidates of
-        // the cloud, image 5.0 per 4096 of the chunk, one pass (filter + exact) 9.7 per 4096, 256 resident blocks.
-        // A block either walks all chunks serially (one pass per block: the per-query slot lives in LDS) or takes
-        // ONE chunk of a split run (any number of passes; subsets merge through 64-bit atomicMin slots, +8 us of
-        // extra launches).  Few large clouds want many small chunks, many small clouds want passes.
-        const int cminc = (maxc + cmax - 1) / cmax;
-        double best = 1e30;
-        int b_chunk = chunk, b_tpb = pl.tpb, b_split = 1;
-        static const int tpb_env = [] { const char *e = getenv("FX3D_NN1_TPB"); return e ? atoi(e) : 0; }();
-        for (int nch = cminc; nch <= cminc * 8 && nch <= 64; ++nch) {
-            int ch = ((maxc + nch - 1) / nch + gran - 1) / gran * gran;
-            if (ch > cmax) continue;
-            const int anch = (maxc + ch - 1) / ch;
-            for (int split = 0; split < 2; ++split) {
-                if (split && (!allow_split || anch == 1 || getenv("FX3D_NN1_NOSPLIT"))) continue;
-                for (int tpb = 1; tpb <= 8; tpb *= 2) {
-                    if (!split && anch > 1 && tpb > 1) continue;
-                    if (tpb_env > 0 && tpb != tpb_env && (split || anch == 1)) continue;
-                    const long long tiles = ((long long)maxc + 512 * tpb - 1) / (512 * tpb);
-                    const long long blocks = 2ll * B * tiles * (split ? anch : 1);
-                    const double per_chunk = 5.0 * ch / 4096.0 + 0.5 + tpb * (9.7 * ch / 4096.0 + 0.8);
-                    const double t_block = 2.8 * maxc / 4096.0 + (split ? 1 : anch) * per_chunk;
-                    const double rounds = (double)((blocks + 255) / 256);
-                    const double t = rounds * t_block + (split ? 8.0 : 0.0);
-                    if (t < best - 1e-9) { best = t; b_chunk = ch; b_tpb = tpb; b_split = split ? anch : 1; }
-                }
+    if (pl.variant == 0) {
+        const int per_block = kThreads * R;
+        pl.tiles_x = (N + per_block - 1) / per_block;
+        pl.tiles_y = (M + per_block - 1) / per_block;
+        pl.tiles = pl.tiles_x > pl.tiles_y ? pl.tiles_x : pl.tiles_y;
+        int chunk = (maxc + kTile - 1) / kTile * kTile;
+        if (chunk > kChunkMax) chunk = kChunkMax;
+        pl.chunk = chunk;
+        pl.lds_bytes = (size_t)chunk * (D <= 3 ? D : 0) * sizeof(float);
+        pl.grid = clouds8 * 8 * pl.tiles;
+        return pl;
+    }
+    // nn1_f16_kernel: choose (candidate chunk size, chunks per block, 512-query passes per block) by a small
+    // cost model in microseconds, measured at C2 (tools/nn1_probe.hip): bounding box 2.8 per 4096 candidates of
+    // the cloud, image 5.0 per 4096 of the chunk, one pass (filter + exact) 9.7 per 4096, 256 resident blocks.
+    // A block either walks all chunks serially (one pass per block: the per-query slot lives in LDS) or takes
+    // ONE chunk of a split run (any number of passes; subsets merge through 64-bit atomicMin slots, +8 us of
+    // extra launches).  Few large clouds want many small chunks, many small clouds want passes.
+    const int cmax = kHChunkMax, gran = 32 * kHLT;
+    const int cminc = (maxc + cmax - 1) / cmax;
+    double best = 1e30;
+    int b_chunk = (maxc + gran - 1) / gran * gran < cmax ? (maxc + gran - 1) / gran * gran : cmax, b_tpb = 1, b_split = 1;
+    static const int tpb_env = [] { const char *e = getenv("FX3D_NN1_TPB"); return e ? atoi(e) : 0; }();
+    for (int nch = cminc; nch <= cminc * 8 && nch <= 64; ++nch) {
+        int ch = ((maxc + nch - 1) / nch + gran - 1) / gran * gran;
+        if (ch > cmax) continue;
+        const int anch = (maxc + ch - 1) / ch;
+        for (int split = 0; split < 2; ++split) {
+            if (split && (!allow_split || anch == 1 || getenv("FX3D_NN1_NOSPLIT"))) continue;
+            for (int tpb = 1; tpb <= 8; tpb *= 2) {
+                if (!split && anch > 1 && tpb > 1) continue;
+                if (tpb_env > 0 && tpb != tpb_env && (split || anch == 1)) continue;
+                const long long tiles = ((long long)maxc + 512 * tpb - 1) / (512 * tpb);
+                const long long blocks = 2ll * B * tiles * (split ? anch : 1);
+                const double per_chunk = 5.0 * ch / 4096.0 + 0.5 + tpb * (9.7 * ch / 4096.0 + 0.8);
+                const double t_block = 2.8 * maxc / 4096.0 + (split ? 1 : anch) * per_chunk;
+                const double rounds = (double)((blocks + 255) / 256);
+                const double t = rounds * t_block + (split ? 8.0 : 0.0);
+                if (t < best - 1e-9) { best = t; b_chunk = ch; b_tpb = tpb; b_split = split ? anch : 1; }
             }
         }
-        pl.chunk = b_chunk;
-        pl.tpb = b_tpb;
-        pl.nsplit = b_split;
-        pl.lds_bytes = (size_t)pl.chunk * 8 * sizeof(float) + kHScratchBytes;
-        const int per_block3 = 512 * pl.tpb;
-        pl.tiles_x = (N + per_block3 - 1) / per_block3;
-        pl.tiles_y = (M + per_block3 - 1) / per_block3;
-        pl.tiles = pl.tiles_x > pl.tiles_y ? pl.tiles_x : pl.tiles_y;
     }
+    pl.chunk = b_chunk;
+    pl.tpb = b_tpb;
+    pl.nsplit = b_split;
+    pl.lds_bytes = (size_t)pl.chunk * 8 * sizeof(float) + kHScratchBytes;
+    const int per_block3 = 512 * pl.tpb;
+    pl.tiles_x = (N + per_block3 - 1) / per_block3;
+    pl.tiles_y = (M + per_block3 - 1) / per_block3;
+    pl.tiles = pl.tiles_x > pl.tiles_y ? pl.tiles_x : pl.tiles_y;
     pl.grid = clouds8 * 8 * pl.tiles * pl.nsplit;
-    if (pl.variant == 3 && 2 * B < 8) pl.grid = 2 * B * pl.tiles * pl.nsplit;  // plain block order (see kernel)
+    if (2 * B < 8) pl.grid = 2 * B * pl.tiles * pl.nsplit;  // plain block order (see kernel)
     return pl;
 }
 
@@ -1609,31 +988,6 @@ fx3d_status launch_small(const Nn1Params &p, const Plan &pl, hipStream_t st) {
                                                        (int)(kHChunkMax * 32 + kHScratchBytes), "nn1_f16_kernel");
             if (arc != FX3D_OK) return arc;
             hipLaunchKernelGGL((nn1_f16_kernel<WANT_IDX>), dim3(pl.grid), dim3(kHThreads), pl.lds_bytes, st, p);
-        }
-        FX3D_LAUNCH_CHECK();
-        return FX3D_OK;
-    }
-    if (pl.variant == 2) {
-        if (DIM == 3) {
-            if (pl.R == 2)
-                hipLaunchKernelGGL((nn1_mfma_kernel<2, WANT_IDX>), dim3(pl.grid), dim3(kMThreads), pl.lds_bytes, st, p);
-            else
-                hipLaunchKernelGGL((nn1_mfma_kernel<1, WANT_IDX>), dim3(pl.grid), dim3(kMThreads), pl.lds_bytes, st, p);
-        }
-        FX3D_LAUNCH_CHECK();
-        return FX3D_OK;
-    }
-    if (pl.variant == 1) {
-        switch (pl.R) {
-            case 4:
-                hipLaunchKernelGGL((nn1_filter_kernel<DIM, 4, WANT_IDX>), dim3(pl.grid), dim3(kThreads), pl.lds_bytes, st, p);
-                break;
-            case 2:
-                hipLaunchKernelGGL((nn1_filter_kernel<DIM, 2, WANT_IDX>), dim3(pl.grid), dim3(kThreads), pl.lds_bytes, st, p);
-                break;
-            default:
-                hipLaunchKernelGGL((nn1_filter_kernel<DIM, 1, WANT_IDX>), dim3(pl.grid), dim3(kThreads), pl.lds_bytes, st, p);
-                break;
         }
         FX3D_LAUNCH_CHECK();
         return FX3D_OK;
@@ -1711,33 +1065,54 @@ void partial_layout(const Plan &pl, int N, int M, int D, int *tiles, int *tx, in
 
 }  // namespace
 
-// Library-owned arrival counters for the fused finalisation: zeroed once at allocation, every
-// launch returns its counter to zero.  One slot per launch, round robin over kTickets slots (two
-// launches share a slot only if more than kTickets launches are simultaneously in flight).
+// Library-owned arrival counters for the fused finalisation: zeroed once at allocation, every launch returns its
+// counter to zero.  EAGER launches take one of kTickets slots round robin (two launches share a slot only if more than
+// kTickets launches are simultaneously in flight).  A launch recorded by a STREAM CAPTURE bakes its slot's address into
+// the graph for good, so it gets a slot of its own that is never handed out again: replays of the graph (ordered on
+// their stream) are its only users, and no eager launch 1024 k launches later can share the counter.
 namespace fx3d {
-static constexpr int kTickets = 1024;
-unsigned int *ticket_slot(fx3d_status *rc) {
-    static thread_local int cached_dev = -1;
+static constexpr int kTickets = 1024;      // eager, round robin
+static constexpr int kCapChunk = 4096;     // capture-owned slots per allocation (grows chunk by chunk)
+unsigned int *ticket_slot(fx3d_status *rc, hipStream_t st) {
     static std::mutex mu;
-    static unsigned int *pools[64] = {nullptr};
+    static std::atomic<unsigned int *> pools[64];
+    static unsigned int *cap_chunk[64] = {nullptr};
+    static int cap_used[64] = {0};
     static std::atomic<unsigned int> next{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { *rc = FX3D_ERR_HIP; return nullptr; }
-    (void)cached_dev;
-    if (!pools[dev]) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (st && hipStreamIsCapturing(st, &cs) != hipSuccess) cs = hipStreamCaptureStatusNone;
+    auto fresh = [&](size_t n) -> unsigned int * {
+        unsigned int *pnew = nullptr;
+        if (hipMalloc(&pnew, n * sizeof(unsigned int)) != hipSuccess || hipMemset(pnew, 0, n * sizeof(unsigned int)) != hipSuccess) {
+            set_error("ticket pool allocation failed");
+            *rc = FX3D_ERR_OOM;
+            return nullptr;
+        }
+        return pnew;
+    };
+    if (cs == hipStreamCaptureStatusActive) {
         std::lock_guard<std::mutex> lk(mu);
-        if (!pools[dev]) {
-            unsigned int *pnew = nullptr;
-            if (hipMalloc(&pnew, kTickets * sizeof(unsigned int)) != hipSuccess ||
-                hipMemset(pnew, 0, kTickets * sizeof(unsigned int)) != hipSuccess) {
-                set_error("ticket pool allocation failed");
-                *rc = FX3D_ERR_OOM;
-                return nullptr;
-            }
-            pools[dev] = pnew;
+        if (!cap_chunk[dev] || cap_used[dev] == kCapChunk) {  // (earlier chunks stay alive: graphs hold their addresses)
+            unsigned int *c = fresh(kCapChunk);
+            if (!c) return nullptr;
+            cap_chunk[dev] = c;
+            cap_used[dev] = 0;
+        }
+        return cap_chunk[dev] + cap_used[dev]++;
+    }
+    unsigned int *pool = pools[dev].load(std::memory_order_acquire);
+    if (!pool) {
+        std::lock_guard<std::mutex> lk(mu);
+        pool = pools[dev].load(std::memory_order_relaxed);
+        if (!pool) {
+            pool = fresh(kTickets);
+            if (!pool) return nullptr;
+            pools[dev].store(pool, std::memory_order_release);
         }
     }
-    return pools[dev] + (next.fetch_add(1) % kTickets);
+    return pool + (next.fetch_add(1) % kTickets);
 }
 }  // namespace fx3d
 
@@ -1812,7 +1187,7 @@ static fx3d_status chamfer_common(const float *x, int N, const float *y, int M, 
     }
     if (pl.variant == 3 && D == 3) {  // one launch: the last block reduces the partials
         fx3d_status trc = FX3D_OK;
-        unsigned int *ticket = ticket_slot(&trc);
+        unsigned int *ticket = ticket_slot(&trc, st);
         if (!ticket) return trc;
         Fused fu{ticket, (unsigned int)((long long)B * tx + (long long)B * ty),
                  sums_dev ? sums_dev : partials + (size_t)2 * B * tiles, loss_dev, w1, w2, Bg};

@@ -41,8 +41,9 @@ inline hipStream_t as_stream(fx3d_stream_t s) { return reinterpret_cast<hipStrea
 // Opt a kernel in to more than 64 KiB of dynamic LDS, once per (kernel, device): the attribute is per device, and
 // a process may drive several (runtime.hip).
 // Library-owned arrival counter for a fused "last block finalises" reduction: zero at hand-out, the kernel returns
-// it to zero (chamfer.hip).  nullptr + *rc on allocation failure.
-unsigned int *ticket_slot(fx3d_status *rc);
+// it to zero (chamfer.hip).  A launch that `st` is capturing into a graph gets a slot of its own, never reused.
+// nullptr + *rc on allocation failure.
+unsigned int *ticket_slot(fx3d_status *rc, hipStream_t st);
 fx3d_status ensure_dynamic_lds(const void *kernel, int bytes, const char *name);
 
 // ---- optional per-kernel event timing (runtime.hip) -------------------------------------------

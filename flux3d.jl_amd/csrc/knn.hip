@@ -59,16 +59,23 @@ constexpr int kThreads = 256;
 constexpr int kWQ = 8;           // queries per wave
 constexpr int kWThreads = 256;   // 4 waves
 
-struct Key { float d; int j; };
-__device__ __forceinline__ bool key_less(float d, int j, float od, int oj) { return d < od || (d == od && j < oj); }
+// Order of the exact selection paths = the oracle's (oracle/flux3d_oracle.c: fless): Julia's isless on the Float32
+// squared distance -- ascending, every NaN after +Inf, all NaNs equal -- then the lower index.  A squared distance is
+// >= +0 or NaN, so with NaNs made canonical this is the UNSIGNED order of the bit patterns: the wave-per-query kernels
+// and the brute-force fallback below keep distances as such keys (kNoKey = "no candidate", above every real key) and
+// compare them as integers -- the same instructions as the float compares, and non-finite data needs no special case.
+constexpr unsigned int kNoKey = 0xffffffffu;
+__device__ __forceinline__ unsigned int dist_key(float d) { return d != d ? 0x7fc00000u : __builtin_bit_cast(unsigned int, d); }
+__device__ __forceinline__ float key_dist(unsigned int k) { return __builtin_bit_cast(float, k); }
+__device__ __forceinline__ bool key_less(unsigned int d, int j, unsigned int od, int oj) { return d < od || (d == od && j < oj); }
 
-// ascending bitonic sort of one (d, j) key per lane
-__device__ __forceinline__ void bitonic64(float &d, int &j, int lane) {
+// ascending bitonic sort of one (key, j) pair per lane
+__device__ __forceinline__ void bitonic64(unsigned int &d, int &j, int lane) {
 #pragma unroll
     for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
         for (int s = k >> 1; s > 0; s >>= 1) {
-            const float od = __shfl_xor(d, s, 64);
+            const unsigned int od = (unsigned int)__shfl_xor((int)d, s, 64);
             const int oj = __shfl_xor(j, s, 64);
             const bool up = (lane & k) == 0 || k == 64;   // final merge: ascending everywhere
             const bool lower = (lane & s) == 0;
@@ -80,26 +87,27 @@ __device__ __forceinline__ void bitonic64(float &d, int &j, int lane) {
         }
     }
 }
-__device__ __forceinline__ void bitonic64f(float &v, int lane) {
+__device__ __forceinline__ void bitonic64u(unsigned int &v, int lane) {
 #pragma unroll
     for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
         for (int s = k >> 1; s > 0; s >>= 1) {
-            const float o = __shfl_xor(v, s, 64);
+            const unsigned int o = (unsigned int)__shfl_xor((int)v, s, 64);
             const bool up = (lane & k) == 0 || k == 64;
             const bool lower = (lane & s) == 0;
-            v = (lower == up) ? fminf(v, o) : fmaxf(v, o);
+            v = (lower == up) ? (v < o ? v : o) : (v > o ? v : o);
         }
     }
 }
+__device__ __forceinline__ unsigned int readlane_u(unsigned int v, int l) { return (unsigned int)__builtin_amdgcn_readlane((int)v, l); }
 
 __global__ __launch_bounds__(kWThreads) void knn_wave_d3_kernel(const float *__restrict__ x, int N,
                                                                 const float *__restrict__ y, int M, int B,
                                                                 int k, int drop, int32_t *__restrict__ idx,
                                                                 float *__restrict__ dist) {
-    __shared__ float lst_d[kWThreads / 64][64];
+    __shared__ unsigned int lst_d[kWThreads / 64][64];
     __shared__ int lst_j[kWThreads / 64][64];
-    __shared__ float best_d[kWThreads / 64][kWQ][64];   // per-query best lists across chunks
+    __shared__ unsigned int best_d[kWThreads / 64][kWQ][64];   // per-query best lists across chunks (distance keys)
     __shared__ int best_j[kWThreads / 64][kWQ][64];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_d3_kernel(const float *__r
     const int q0 = (blockIdx.x * (kWThreads / 64) + wv) * kWQ;
     if (q0 >= N) return;  // wave-uniform; no block-level sync below
 #pragma unroll
-    for (int qq = 0; qq < kWQ; ++qq) { best_d[wv][qq][lane] = INFINITY; best_j[wv][qq][lane] = 0x7fffffff; }
+    for (int qq = 0; qq < kWQ; ++qq) { best_d[wv][qq][lane] = kNoKey; best_j[wv][qq][lane] = 0x7fffffff; }
 
     for (int j0 = 0; j0 < M; j0 += 1024) {
         float cx[16], cy[16], cz[16];
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_d3_kernel(const float *__r
             if (j < M) {
                 cx[i] = yb[(size_t)j * 3]; cy[i] = yb[(size_t)j * 3 + 1]; cz[i] = yb[(size_t)j * 3 + 2];
             } else {
-                cx[i] = INFINITY; cy[i] = INFINITY; cz[i] = INFINITY;  // d = +inf: never selected
+                cx[i] = 0.0f; cy[i] = 0.0f; cz[i] = 0.0f;  // beyond the cloud: key = kNoKey below, never selected
             }
         }
 #pragma unroll 1
@@ -126,28 +134,28 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_d3_kernel(const float *__r
             const int qi = q0 + qq;
             if (qi >= N) break;
             const float qx = xb[(size_t)qi * 3], qy = xb[(size_t)qi * 3 + 1], qz = xb[(size_t)qi * 3 + 2];  // uniform
-            float d[16];
-            float lmin = INFINITY;
+            unsigned int d[16];
+            unsigned int lmin = kNoKey;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float t0 = qx - cx[i], t1 = qy - cy[i], t2 = qz - cz[i];
-                d[i] = ((t0 * t0) + (t1 * t1)) + (t2 * t2);
-                lmin = fminf(lmin, d[i]);
+                d[i] = j0 + lane + 64 * i < M ? dist_key(((t0 * t0) + (t1 * t1)) + (t2 * t2)) : kNoKey;
+                lmin = lmin < d[i] ? lmin : d[i];
             }
-            float bd = best_d[wv][qq][lane];
+            unsigned int bd = best_d[wv][qq][lane];
             int bj = best_j[wv][qq][lane];
-            float tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bd), kk - 1));
+            unsigned int tau = readlane_u(bd, kk - 1);
             if (j0 == 0) {  // kk-th smallest lane minimum bounds the kk-th smallest distance
-                float v = lmin;
-                bitonic64f(v, lane);
-                tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), kk - 1));
+                unsigned int v = lmin;
+                bitonic64u(v, lane);
+                tau = readlane_u(v, kk - 1);
             }
             int cnt = 0;
             const int cap = 64 - kk;  // list + best list must fit one key per lane
             if (cap > 0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    bool pred = d[i] <= tau && d[i] < INFINITY;
+                    bool pred = d[i] <= tau && d[i] != kNoKey;
                     unsigned long long bal = __ballot(pred);
                     while (bal) {  // usually one pass; more only when > cap candidates qualify
                         const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
@@ -159,12 +167,12 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_d3_kernel(const float *__r
                         cnt = overflow ? cap : cnt + np;
                         pred = pred && !put;
                         if (overflow) {  // flush: merge the full list into the best list, tighten tau
-                            float sd = lane < kk ? bd : (lane - kk < cnt ? lst_d[wv][lane - kk] : INFINITY);
+                            unsigned int sd = lane < kk ? bd : (lane - kk < cnt ? lst_d[wv][lane - kk] : kNoKey);
                             int sj = lane < kk ? bj : (lane - kk < cnt ? lst_j[wv][lane - kk] : 0x7fffffff);
                             bitonic64(sd, sj, lane);
-                            bd = lane < kk ? sd : INFINITY;
+                            bd = lane < kk ? sd : kNoKey;
                             bj = lane < kk ? sj : 0x7fffffff;
-                            tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sd), kk - 1));
+                            tau = readlane_u(sd, kk - 1);
                             cnt = 0;
                             pred = pred && d[i] <= tau;
                         }
@@ -173,10 +181,10 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_d3_kernel(const float *__r
                 }
             }
             if (cnt > 0 || cap == 0) {
-                float sd, sj_f;
+                unsigned int sd;
                 int sj;
                 if (cap > 0) {
-                    sd = lane < kk ? bd : (lane - kk < cnt ? lst_d[wv][lane - kk] : INFINITY);
+                    sd = lane < kk ? bd : (lane - kk < cnt ? lst_d[wv][lane - kk] : kNoKey);
                     sj = lane < kk ? bj : (lane - kk < cnt ? lst_j[wv][lane - kk] : 0x7fffffff);
                     bitonic64(sd, sj, lane);
                     bd = sd; bj = sj;
@@ -184,10 +192,10 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_d3_kernel(const float *__r
                     // kk == 64: no room for a list; merge the chunk 64 candidates at a time
 #pragma unroll 1
                     for (int i = 0; i < 16; ++i) {
-                        float nd = d[i];
-                        int nj = nd < INFINITY ? j0 + lane + 64 * i : 0x7fffffff;
+                        unsigned int nd = d[i];
+                        int nj = nd != kNoKey ? j0 + lane + 64 * i : 0x7fffffff;
                         bitonic64(nd, nj, lane);                      // ascending new batch
-                        const float rd = __shfl(nd, 63 - lane, 64);   // reversed
+                        const unsigned int rd = (unsigned int)__shfl((int)nd, 63 - lane, 64);   // reversed
                         const int rj = __shfl(nj, 63 - lane, 64);
                         const bool o_less = key_less(rd, rj, bd, bj);
                         bd = o_less ? rd : bd;                         // lower half of the union (bitonic)
@@ -195,7 +203,6 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_d3_kernel(const float *__r
                         bitonic64(bd, bj, lane);
                     }
                 }
-                (void)sj_f;
             }
             best_d[wv][qq][lane] = bd;
             best_j[wv][qq][lane] = bj;
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_d3_kernel(const float *__r
                 const int r = lane - drop;
                 if (r >= 0 && r < k) {
                     idx[((size_t)b * N + qi) * k + r] = bj;
-                    if (dist) dist[((size_t)b * N + qi) * k + r] = bd;
+                    if (dist) dist[((size_t)b * N + qi) * k + r] = key_dist(bd);
                 }
             }
         }
@@ -230,11 +237,11 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_generic_kernel(const float
     constexpr int NW = kWThreads / 64;
     const int RS = D + 1;                       // padded row stride
     float *tile = gl;                           // [kGT][RS]
-    float *bestd = tile + kGT * RS;             // [NW][kGQ][64]
+    unsigned int *bestd = reinterpret_cast<unsigned int *>(tile + kGT * RS);   // [NW][kGQ][64] distance keys
     int *bestj = reinterpret_cast<int *>(bestd + NW * kGQ * 64);
-    float *lstd = reinterpret_cast<float *>(bestj + NW * kGQ * 64);
+    unsigned int *lstd = reinterpret_cast<unsigned int *>(bestj + NW * kGQ * 64);
     int *lstj = reinterpret_cast<int *>(lstd + NW * kGQ * 64);
-    float *taus = reinterpret_cast<float *>(lstj + NW * kGQ * 64);   // [NW][kGQ]
+    unsigned int *taus = reinterpret_cast<unsigned int *>(lstj + NW * kGQ * 64);   // [NW][kGQ]
     int *cnts = reinterpret_cast<int *>(taus + NW * kGQ);            // [NW][kGQ]
     float4 *qs4 = reinterpret_cast<float4 *>(cnts + NW * kGQ);       // [NW][D] : the wave's kGQ=4 queries, interleaved
 
@@ -245,9 +252,9 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_generic_kernel(const float
     const int q0 = (blockIdx.x * NW + wv) * kGQ;
 #pragma unroll
     for (int qq = 0; qq < kGQ; ++qq) {
-        bestd[(wv * kGQ + qq) * 64 + lane] = INFINITY;
+        bestd[(wv * kGQ + qq) * 64 + lane] = kNoKey;
         bestj[(wv * kGQ + qq) * 64 + lane] = 0x7fffffff;
-        if (lane == 0) { taus[wv * kGQ + qq] = INFINITY; cnts[wv * kGQ + qq] = 0; }
+        if (lane == 0) { taus[wv * kGQ + qq] = kNoKey; cnts[wv * kGQ + qq] = 0; }
     }
     for (int d = lane; d < D; d += 64) {  // the wave's queries, component-interleaved: one b128 broadcast per d
         float4 v;
@@ -293,25 +300,24 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_generic_kernel(const float
             for (int qq = 0; qq < kGQ; ++qq) {
                 const int qi = q0 + qq;
                 if (qi >= N) break;
-                float d0 = acc0[qq], d1 = acc1[qq];
-                if (lane >= cntc) d0 = INFINITY;
-                if (lane + 64 >= cntc) d1 = INFINITY;
+                const unsigned int d0 = lane < cntc ? dist_key(acc0[qq]) : kNoKey;
+                const unsigned int d1 = lane + 64 < cntc ? dist_key(acc1[qq]) : kNoKey;
                 const int sidx = (wv * kGQ + qq) * 64;
-                float tau = taus[wv * kGQ + qq];
+                unsigned int tau = taus[wv * kGQ + qq];
                 int cnt = cnts[wv * kGQ + qq];
-                float bd = bestd[sidx + lane];
+                unsigned int bd = bestd[sidx + lane];
                 int bj = bestj[sidx + lane];
                 if (j0 == 0) {
-                    float v = fminf(d0, d1);
-                    bitonic64f(v, lane);
-                    tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), kk - 1));
+                    unsigned int v = d0 < d1 ? d0 : d1;
+                    bitonic64u(v, lane);
+                    tau = readlane_u(v, kk - 1);
                 }
                 bool dirty = false;
                 if (cap > 0) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        const float di = i ? d1 : d0;
-                        bool pred = di <= tau && di < INFINITY;
+                        const unsigned int di = i ? d1 : d0;
+                        bool pred = di <= tau && di != kNoKey;
                         unsigned long long bal = __ballot(pred);
                         while (bal) {
                             const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
@@ -323,11 +329,11 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_generic_kernel(const float
                             cnt = overflow ? cap : cnt + np;
                             pred = pred && !put;
                             if (overflow) {
-                                float sd = lane < kk ? bd : (lane - kk < cnt ? lstd[sidx + lane - kk] : INFINITY);
+                                unsigned int sd = lane < kk ? bd : (lane - kk < cnt ? lstd[sidx + lane - kk] : kNoKey);
                                 int sj = lane < kk ? bj : (lane - kk < cnt ? lstj[sidx + lane - kk] : 0x7fffffff);
                                 bitonic64(sd, sj, lane);
                                 bd = sd; bj = sj;
-                                tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sd), kk - 1));
+                                tau = readlane_u(sd, kk - 1);
                                 cnt = 0;
                                 dirty = true;
                                 pred = pred && di <= tau;
@@ -338,10 +344,10 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_generic_kernel(const float
                 } else {  // kk == 64: merge 64 candidates at a time
 #pragma unroll 1
                     for (int i = 0; i < 2; ++i) {
-                        float nd = i ? d1 : d0;
-                        int nj = nd < INFINITY ? j0 + lane + 64 * i : 0x7fffffff;
+                        unsigned int nd = i ? d1 : d0;
+                        int nj = nd != kNoKey ? j0 + lane + 64 * i : 0x7fffffff;
                         bitonic64(nd, nj, lane);
-                        const float rd = __shfl(nd, 63 - lane, 64);
+                        const unsigned int rd = (unsigned int)__shfl((int)nd, 63 - lane, 64);
                         const int rj = __shfl(nj, 63 - lane, 64);
                         const bool o_less = key_less(rd, rj, bd, bj);
                         bd = o_less ? rd : bd;
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_generic_kernel(const float
                 }
                 const bool last = j0 + kGT >= M;
                 if (last && cnt > 0) {
-                    float sd = lane < kk ? bd : (lane - kk < cnt ? lstd[sidx + lane - kk] : INFINITY);
+                    unsigned int sd = lane < kk ? bd : (lane - kk < cnt ? lstd[sidx + lane - kk] : kNoKey);
                     int sj = lane < kk ? bj : (lane - kk < cnt ? lstj[sidx + lane - kk] : 0x7fffffff);
                     bitonic64(sd, sj, lane);
                     bd = sd; bj = sj;
@@ -365,9 +371,90 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_generic_kernel(const float
                     const int r = lane - drop;
                     if (r >= 0 && r < k) {
                         idx[((size_t)b * N + qi) * k + r] = bj;
-                        if (dist) dist[((size_t)b * N + qi) * k + r] = bd;
+                        if (dist) dist[((size_t)b * N + qi) * k + r] = key_dist(bd);
                     }
                 }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// knn_select_kernel: the general path -- ANY k + drop <= M and ANY D (the reference's `knn(kdtree, x, K+1, true)`,
+// src/models/dgcnn.jl:3-7, takes any K <= N) -- for the shapes none of the other kernels takes: k + drop > 64, or a D the
+// wave kernel's tile does not fit.  One wave per query, all M distance keys of the query in LDS (dist_key: the
+// oracle's isless order as unsigned integers):
+//   1. keys: lane l evaluates candidates l, l+64, ... with the oracle's unfused dimension-order sum;
+//   2. T = the kk-th smallest key VALUE by a most-significant-bit-first search (32 counting sweeps over the LDS keys);
+//   3. every candidate with key <= T ranks itself: #(keys below it) + #(equal keys with a lower index) -- the oracle's
+//      (distance, index) order without a sort -- and writes slot rank - drop if drop <= rank < kk.
+// Cost O(M (32 + kk) / 64) LDS reads per lane and query: a correct general path, not a tuned one (C4 shapes with
+// kk = 100: ~0.3 ms); the tuned kernels keep k + drop <= 32 (matrix cores) and <= 64 (wave kernels).
+constexpr int kSelMaxLds = 144 * 1024;
+__global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict__ x, int N, const float *__restrict__ y,
+                                                         int M, int B, int D, int k, int drop,
+                                                         int32_t *__restrict__ idx, float *__restrict__ dist, int Mpad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int selkeys[];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int qi = blockIdx.x * nw + wv;
+    if (qi >= N) return;  // wave-uniform; no block-level sync below
+    unsigned int *keys = selkeys + (size_t)wv * Mpad;
+    const uint4 *keys4 = reinterpret_cast<const uint4 *>(keys);
+    const int kk = k + drop;
+    const float *q = x + ((size_t)b * N + qi) * D, *yb = y + (size_t)b * M * D;
+    const bool vec4 = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(yb)) & 15) == 0;
+    for (int j = lane; j < Mpad; j += 64) {
+        unsigned int key = kNoKey;
+        if (j < M) {
+            const float *c = yb + (size_t)j * D;
+            float sacc = 0.0f;
+            if (vec4) {
+                for (int dd = 0; dd < D; dd += 4) {
+                    const float4 qv = *reinterpret_cast<const float4 *>(q + dd), cv = *reinterpret_cast<const float4 *>(c + dd);
+                    const float t0 = qv.x - cv.x, t1 = qv.y - cv.y, t2 = qv.z - cv.z, t3 = qv.w - cv.w;
+                    sacc = sacc + t0 * t0; sacc = sacc + t1 * t1; sacc = sacc + t2 * t2; sacc = sacc + t3 * t3;
+                }
+            } else {
+                for (int dd = 0; dd < D; ++dd) { const float t = q[dd] - c[dd]; sacc = sacc + t * t; }
+            }
+            key = dist_key(sacc);
+        }
+        keys[j] = key;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const int n4 = Mpad / 4;
+    // ---- T: largest value with #(keys < T) < kk, i.e. the kk-th smallest key (bit by bit, most significant first) ----
+    unsigned int T = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned int trial = T | (1u << bit);
+        int c = 0;
+        for (int i = lane; i < n4; i += 64) {
+            const uint4 v = keys4[i];
+            c += (int)(v.x < trial) + (int)(v.y < trial) + (int)(v.z < trial) + (int)(v.w < trial);
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m, 64);
+        if (c < kk) T = trial;
+    }
+    // ---- ranks of the candidates at or below T ---------------------------------------------------------------------
+    for (int j0 = 0; j0 < M; j0 += 64) {
+        const int e = j0 + lane;
+        const unsigned int me = e < M ? keys[e] : kNoKey;
+        if (me <= T && e < M) {
+            int rank = 0;
+            for (int i = 0; i < n4; ++i) {  // every lane reads the same address: LDS broadcast
+                const uint4 v = keys4[i];
+                const int p = 4 * i;
+                rank += (int)(v.x < me) | ((int)(v.x == me) & (int)(p < e));
+                rank += (int)(v.y < me) | ((int)(v.y == me) & (int)(p + 1 < e));
+                rank += (int)(v.z < me) | ((int)(v.z == me) & (int)(p + 2 < e));
+                rank += (int)(v.w < me) | ((int)(v.w == me) & (int)(p + 3 < e));
+            }
+            if (rank >= drop && rank < kk) {
+                idx[((size_t)b * N + qi) * k + rank - drop] = e;
+                if (dist) dist[((size_t)b * N + qi) * k + rank - drop] = key_dist(me);
             }
         }
     }
@@ -432,15 +519,17 @@ __device__ __forceinline__ int key_less_bf(float d, int j, float od, int oj) {
 // ids == nullptr: all M candidates; else the M candidates ids[0..M) (LDS): a query's own survivors when they exceed the
 // fast path's key capacity.
 __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q, const float *__restrict__ yb, int M,
-                                                      int D, int kk, int lane, float *lst_d, int *lst_j, float &bd,
+                                                      int D, int kk, int lane, float *lst_f, int *lst_j, float &bd_out,
                                                       int &bj, const int *ids = nullptr) {
-    bd = INFINITY;
+    // distances as canonical unsigned keys: the isless order of the oracle, non-finite data included (see dist_key)
+    unsigned int *lst_d = reinterpret_cast<unsigned int *>(lst_f);
+    unsigned int bd = kNoKey;
     bj = 0x7fffffff;
     const int cap = 64 - kk;
     const bool vec4 = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(yb)) & 15) == 0;
     for (int j0 = 0; j0 < M; j0 += 1024) {
-        float d[16];
-        float lmin = INFINITY;
+        unsigned int d[16];
+        unsigned int lmin = kNoKey;
         if (vec4) {
             // rows as 16-byte pieces, four candidates in flight (dimension order kept: x, y, z, w of every piece)
 #pragma unroll
@@ -469,15 +558,15 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    d[i0 + u] = j0 + lane + 64 * (i0 + u) < M ? sacc[u] : INFINITY;
-                    lmin = fminf(lmin, d[i0 + u]);
+                    d[i0 + u] = j0 + lane + 64 * (i0 + u) < M ? dist_key(sacc[u]) : kNoKey;
+                    lmin = lmin < d[i0 + u] ? lmin : d[i0 + u];
                 }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int j = j0 + lane + 64 * i;
-                d[i] = INFINITY;
+                d[i] = kNoKey;
                 if (j < M) {
                     const float *c = yb + (size_t)(ids ? ids[j] : j) * D;
                     float s = 0.0f;
@@ -485,21 +574,21 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
                         const float t = q[dd] - c[dd];
                         s = s + t * t;
                     }
-                    d[i] = s;
+                    d[i] = dist_key(s);
                 }
-                lmin = fminf(lmin, d[i]);
+                lmin = lmin < d[i] ? lmin : d[i];
             }
         }
-        float tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bd), kk - 1));
+        unsigned int tau = readlane_u(bd, kk - 1);
         if (j0 == 0) {  // kk-th smallest lane minimum bounds the kk-th smallest distance
-            float v = lmin;
-            bitonic64f(v, lane);
-            tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), kk - 1));
+            unsigned int v = lmin;
+            bitonic64u(v, lane);
+            tau = readlane_u(v, kk - 1);
         }
         int cnt = 0;
 #pragma unroll 1
         for (int i = 0; i < 16; ++i) {
-            bool pred = d[i] <= tau && d[i] < INFINITY;
+            bool pred = d[i] <= tau && d[i] != kNoKey;
             unsigned long long bal = __ballot(pred);
             while (bal) {  // usually one pass; more only when > cap candidates qualify
                 const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
@@ -512,12 +601,12 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
                 pred = pred && !put;
                 if (overflow) {  // flush: merge the full list into the best list, tighten tau
                     __builtin_amdgcn_s_waitcnt(0xc07f);
-                    float sd = lane < kk ? bd : (lane - kk < cnt ? lst_d[lane - kk] : INFINITY);
+                    unsigned int sd = lane < kk ? bd : (lane - kk < cnt ? lst_d[lane - kk] : kNoKey);
                     int sj = lane < kk ? bj : (lane - kk < cnt ? lst_j[lane - kk] : 0x7fffffff);
                     bitonic64(sd, sj, lane);
-                    bd = lane < kk ? sd : INFINITY;
+                    bd = lane < kk ? sd : kNoKey;
                     bj = lane < kk ? sj : 0x7fffffff;
-                    tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sd), kk - 1));
+                    tau = readlane_u(sd, kk - 1);
                     cnt = 0;
                     pred = pred && d[i] <= tau;
                 }
@@ -526,13 +615,14 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
         }
         if (cnt > 0) {
             __builtin_amdgcn_s_waitcnt(0xc07f);
-            float sd = lane < kk ? bd : (lane - kk < cnt ? lst_d[lane - kk] : INFINITY);
+            unsigned int sd = lane < kk ? bd : (lane - kk < cnt ? lst_d[lane - kk] : kNoKey);
             int sj = lane < kk ? bj : (lane - kk < cnt ? lst_j[lane - kk] : 0x7fffffff);
             bitonic64(sd, sj, lane);
-            bd = lane < kk ? sd : INFINITY;
+            bd = lane < kk ? sd : kNoKey;
             bj = lane < kk ? sj : 0x7fffffff;
         }
     }
+    bd_out = key_dist(bd);
 }
 
 // LDS image of a chunk: rows of PPR = DP/4 16-byte pieces, no padding; piece c of row r sits at position
@@ -784,6 +874,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     // ---- one pass over the cloud: bounding box (-> centre mu, power-of-two scale sc with |c~| <= 1) and, for
     //      clouds up to kTRawMax points, the raw coordinates parked in LDS for the staging and the exact phase ----
     float mu[3], cinf = 0.0f;
+    bool allfin = true;
     {
         float4 *raww = reinterpret_cast<float4 *>(k3sm + img_bytes + kListBytes + kCtrInts * 4);
         float mn3[3] = {INFINITY, INFINITY, INFINITY}, mx3[3] = {-INFINITY, -INFINITY, -INFINITY}, sm3[3] = {0.f, 0.f, 0.f};
@@ -837,10 +928,13 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
             // centre = the MEAN (a stray far point moves the box centre, hardly the mean); any centre is correct
             mu[d] = fminf(fmaxf(st / (float)M, lo), hi);
             cinf = fmaxf(cinf, fmaxf(hi - mu[d], mu[d] - lo));
+            allfin = allfin && fabsf(st) < INFINITY;  // a NaN / +-Inf coordinate makes the sum non-finite (fminf / fmaxf skip NaNs)
         }
         cinf = cinf * 1.000001f;
     }
-    const bool sane = cinf < 1.0e18f;  // false for NaN / inf coordinates
+    // not sane (non-finite or huge coordinates): every query takes the brute-force merge, which orders distances as the
+    // oracle does (dist_key); a finite cloud with cinf < 1e16 has no infinite or NaN distance to a usable query
+    const bool sane = allfin && cinf < 1.0e16f;  // usable queries lie within 234 cinf of the centre: 3 (235 cinf)^2 stays finite
     float sc = 1.0f;
     if (sane && cinf > 1.0e-30f) {
         int e;
@@ -1568,7 +1662,10 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             sc = ldexpf(1.0f, 10 - e);
         }
         __syncthreads();
-        if (tid == 0) *cmax = anynan ? 0x7fc00000u : 0u;  // from here on: bits of the largest SCALED squared norm
+        // from here on: bits of the largest SCALED squared norm.  A cloud whose extent lets exact Float32 distances overflow
+        // (D (61 cinf)^2 >= 3.4e38 for usable queries) is handled like a non-finite one: its +Inf ties are ordered by index in
+        // the oracle, which only the brute-force merge reproduces.
+        if (tid == 0) *cmax = (anynan || !(cinf < 1.0e15f)) ? 0x7fc00000u : 0u;
     }
 
     // ---- B operand: the wave's 32 query rows, staged through LDS (coalesced), then -2 q in registers ------------
@@ -1856,6 +1953,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                 eps = qok ? eps : INFINITY;
             } else {
                 eps = (8.0f * (float)(D + 4) * 0x1p-24f) * (qn + c2);
+                eps = qn + c2 < 1.0e38f ? eps : INFINITY;  // (|q| + |c|)^2 <= 2 (qn + c2): no exact distance overflows
             }
             thr = tau + 2.0f * eps;  // NaN / inf => slow path below
         }
@@ -2334,10 +2432,32 @@ size_t knn_wave_generic_lds(int D) {
 }
 bool knn_mfma_eligible(int M, int D, int kk) { return D >= 4 && D <= 128 && kk <= 32 && M >= 64; }
 
+// the general path's geometry: as many waves per block as their key arrays fit in LDS (0 = M too large)
+int knn_select_waves(int M) {
+    const size_t per_wave = (size_t)((M + 255) / 256 * 256) * 4;
+    int w = (int)(kSelMaxLds / per_wave);
+    return w > 4 ? 4 : w;
+}
+bool knn_needs_select(int M, int D, int kk) {
+    return kk > 64 || (D != 3 && !knn_mfma_eligible(M, D, kk) && knn_wave_generic_lds(D) > 64 * 1024);
+}
+
 fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int D, int k, int drop,
                        int32_t *idx, float *dist, hipStream_t st) {
     ProfileScope prof("knn", st);
     const int kk = k + drop;
+    const bool grid_y = knn_needs_select(M, D, kk) || (D == 3 ? !(kk <= 32 && M >= 64) : !knn_mfma_eligible(M, D, kk));
+    FX3D_REQUIRE(!grid_y || B <= 65535, "fx3d_knn: B=%d exceeds the grid's y range for this shape", B);
+    if (knn_needs_select(M, D, kk)) {
+        const int nw = knn_select_waves(M);
+        const int Mpad = (M + 255) / 256 * 256;
+        const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_select_kernel), kSelMaxLds, "knn_select_kernel");
+        if (arc != FX3D_OK) return arc;
+        hipLaunchKernelGGL(knn_select_kernel, dim3((N + nw - 1) / nw, B), dim3(64 * nw), (size_t)nw * Mpad * 4, st, x, N, y, M,
+                           B, D, k, drop, idx, dist, Mpad);
+        FX3D_LAUNCH_CHECK();
+        return FX3D_OK;
+    }
     if (D == 3 && !getenv("FX3D_KNN_D3_WAVE") && kk <= 32 && M >= 64 && M < (1 << 21))
         return launch_knn_f16_d3(x, N, y, M, B, k, drop, idx, dist, st);
     if (D == 3) {
@@ -2367,13 +2487,9 @@ fx3d_status fx3d_knn(const float *x, int32_t N, const float *y, int32_t M, int32
     const int drop = drop_first ? 1 : 0;
     const int kk = k + drop;
     FX3D_REQUIRE(kk <= M, "fx3d_knn: k+drop_first=%d exceeds the number of candidates M=%d", kk, M);
-    if (kk > 64) {
-        set_error("fx3d_knn: k+drop_first=%d > 64 is not supported", kk);
-        return FX3D_ERR_UNSUPPORTED;
-    }
-    if (D != 3 && !knn_mfma_eligible(M, D, kk) && knn_wave_generic_lds(D) > 64 * 1024) {
-        set_error("fx3d_knn: D=%d is supported up to D = %d, or up to 128 with k+drop_first <= 32 and M >= 64", D,
-                  (int)((64 * 1024 - 16 - (kWThreads / 64) * kGQ * (64 * 16 + 8)) / (kGT * 4 + (kWThreads / 64) * 16)) - 1);
+    if (knn_needs_select(M, D, kk) && knn_select_waves(M) < 1) {
+        set_error("fx3d_knn: k+drop_first=%d > 64 (or D=%d beyond the wave kernel) is supported for M <= %d candidates, got M=%d", kk, D,
+                  kSelMaxLds / 4, M);
         return FX3D_ERR_UNSUPPORTED;
     }
     return launch_knn(x, N, y, M, B, D, k, drop, idx, dist, as_stream(s));

@@ -291,7 +291,7 @@ fx3d_status fx3d_edge_loss(const float *verts, int64_t V, const int32_t *edges, 
     hipStream_t st = as_stream(s);
     double *partials = reinterpret_cast<double *>(ws);
     fx3d_status trc = FX3D_OK;
-    unsigned int *ticket = ticket_slot(&trc);
+    unsigned int *ticket = ticket_slot(&trc, st);
     if (!ticket) return trc;
     const int g = grid_for(E);
     {
@@ -327,7 +327,7 @@ fx3d_status fx3d_laplacian_loss(const float *verts, int64_t V, const int32_t *ro
     hipStream_t st = as_stream(s);
     double *partials = reinterpret_cast<double *>(ws);
     fx3d_status trc = FX3D_OK;
-    unsigned int *ticket = ticket_slot(&trc);
+    unsigned int *ticket = ticket_slot(&trc, st);
     if (!ticket) return trc;
     const int g = grid_for(V);
     {

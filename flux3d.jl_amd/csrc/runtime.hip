@@ -276,6 +276,12 @@ fx3d_status fx3d_event_sync(fx3d_event_t e) {
     return FX3D_OK;
 }
 
+fx3d_status fx3d_stream_wait_event(fx3d_stream_t s, fx3d_event_t e) {
+    FX3D_REQUIRE(e, "fx3d_stream_wait_event: null event");
+    FX3D_HIP(hipStreamWaitEvent(as_stream(s), reinterpret_cast<hipEvent_t>(e), 0));
+    return FX3D_OK;
+}
+
 fx3d_status fx3d_event_elapsed_ms(fx3d_event_t a, fx3d_event_t b, float *ms) {
     FX3D_REQUIRE(a && b && ms, "fx3d_event_elapsed_ms: null argument");
     FX3D_HIP(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(a), reinterpret_cast<hipEvent_t>(b)));

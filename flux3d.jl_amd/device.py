@@ -52,6 +52,7 @@ class Stream:
     def create(cls):
         h = C.c_void_p()
         _lib.call("fx3d_stream_create", C.byref(h))
+        _live_streams.add(h.value)
         return cls(h.value, owned=True)
 
     def synchronize(self):
@@ -60,10 +61,24 @@ class Stream:
     def __del__(self):
         if getattr(self, "_owned", False) and self.handle:
             try:
-                _lib.load().fx3d_stream_destroy(self.handle)
+                _live_streams.discard(self.handle)
+                _lib.load().fx3d_stream_destroy(self.handle)  # (hipStreamDestroy lets queued work finish)
             except Exception:
                 pass
             self.handle = None
+
+
+_live_streams = set()  # handles created here and not yet destroyed (the pool only synchronises these)
+
+
+def _sync_handle(h):
+    """Synchronise stream handle h (0 / None = the default stream) if it still exists."""
+    if not h:
+        _lib.load().fx3d_stream_sync(None)
+    elif h in _live_streams:
+        _lib.load().fx3d_stream_sync(h)
+    else:  # destroyed, or a foreign handle: fall back to the whole device
+        _lib.load().fx3d_device_sync()
 
 
 DEFAULT_STREAM = Stream(None)
@@ -117,12 +132,20 @@ class Event:
 class _Pool:
     """Caching device allocator (what CUDA.jl's pool / torch's caching allocator give the reference's
     GPU path): hipMalloc/hipFree synchronise the device and cost tens of microseconds, so freed
-    blocks are kept in power-of-two size classes and reused.  ``empty_cache()`` returns them."""
+    blocks are kept in power-of-two size classes and reused.  ``empty_cache()`` returns them.
+
+    Reuse is STREAM-ORDERED: a block is cached under the stream that was current when it was allocated, and handed
+    out again only to an allocation made under that same stream -- work enqueued there later runs after whatever
+    still reads or writes the block.  A block released while a different stream is current (it may have been used on
+    either) goes back only after both streams have drained; an allocation that finds nothing under its own stream may
+    take a block cached under another one after synchronising that stream.  (the pool used to ignore
+    streams, so a temporary released after an async launch on stream A could be handed at once to work on stream B.)"""
 
     def __init__(self, limit_bytes=4 << 30):
-        self.free = {}
+        self.free = {}  # (stream handle or 0, size class) -> [ptr]
         self.cached = 0
         self.limit = limit_bytes
+        self.steals = 0  # allocations served from another stream's cache (after synchronising it)
 
     @staticmethod
     def _cls(nbytes):
@@ -133,27 +156,41 @@ class _Pool:
 
     def alloc(self, nbytes):
         c = self._cls(max(int(nbytes), 1))
-        lst = self.free.get(c)
+        sh = current_stream().handle or 0
+        lst = self.free.get((sh, c))
         if lst:
             self.cached -= c
-            return lst.pop(), c
+            return lst.pop(), c, sh
+        for (osh, oc), olst in self.free.items():
+            if oc == c and olst and osh != sh:
+                _sync_handle(osh)  # its pending work may still touch the block
+                self.cached -= c
+                self.steals += 1
+                return olst.pop(), c, sh
         p = C.c_void_p()
         try:
             _lib.call("fx3d_malloc", C.byref(p), c)
         except _lib.Flux3DHipError:
             self.empty()
             _lib.call("fx3d_malloc", C.byref(p), c)
-        return p.value, c
+        return p.value, c, sh
 
-    def release(self, ptr, c):
+    def release(self, ptr, c, sh=0):
+        cur = current_stream().handle or 0
+        if cur != sh:  # possibly used on both: neither may still be running on it when it is handed out again
+            _sync_handle(cur)
+            _sync_handle(sh)
         if self.cached + c > self.limit:
+            if cur == sh:
+                _sync_handle(sh)  # hipFree of a block with work in flight
             _lib.load().fx3d_free(ptr)
             return
-        self.free.setdefault(c, []).append(ptr)
+        self.free.setdefault((sh, c), []).append(ptr)
         self.cached += c
 
     def empty(self):
         lib = _lib.load()
+        lib.fx3d_device_sync()
         for lst in self.free.values():
             for ptr in lst:
                 lib.fx3d_free(ptr)
@@ -163,6 +200,7 @@ class _Pool:
 
 _pools = {}
 _pool_override = []  # innermost private pool of an active Graph capture
+_capturing = []      # the Graph objects being captured (innermost last)
 
 
 def _pool():
@@ -193,6 +231,7 @@ class Graph:
         self.handle = None
         self.stream = None
         self._pool = _Pool(limit_bytes=1 << 62)
+        self._ws = {}  # (stream, tag) -> Workspace used by the recorded ops
 
     def capture(self, s):
         return _GraphCapture(self, s)
@@ -204,6 +243,7 @@ class Graph:
         if getattr(self, "handle", None):
             try:
                 _lib.load().fx3d_graph_destroy(self.handle)
+                self._ws.clear()
                 self._pool.empty()
             except Exception:
                 pass
@@ -219,6 +259,7 @@ class _GraphCapture:
     def __enter__(self):
         _current.append(self.s)
         _pool_override.append(self.g._pool)
+        _capturing.append(self.g)
         _lib.call("fx3d_graph_begin_capture", self.s.handle)
         return self.g
 
@@ -231,6 +272,7 @@ class _GraphCapture:
             if exc_type is None:
                 raise
         finally:
+            _capturing.pop()
             _pool_override.pop()
             _current.pop()
         return False
@@ -246,9 +288,9 @@ class DeviceArray:
     """Device buffer with a Julia-style (column-major) shape.  ``to_host()`` returns an
     F-contiguous numpy array of the same shape: byte-identical to the Julia ``Array``."""
 
-    __slots__ = ("ptr", "shape", "dtype", "_owned", "_keep", "_pool", "_cls")
+    __slots__ = ("ptr", "shape", "dtype", "_owned", "_keep", "_pool", "_cls", "_stream")
 
-    def __init__(self, ptr, shape, dtype, owned=False, keep=None, pool=None, cls=0):
+    def __init__(self, ptr, shape, dtype, owned=False, keep=None, pool=None, cls=0, stream=0):
         self.ptr = ptr
         self.shape = tuple(int(s) for s in shape)
         self.dtype = np.dtype(dtype)
@@ -256,6 +298,7 @@ class DeviceArray:
         self._keep = keep
         self._pool = pool
         self._cls = cls
+        self._stream = stream  # handle of the stream current at allocation (the pool's reuse key)
 
     # -- construction ---------------------------------------------------------------------
     @classmethod
@@ -263,8 +306,8 @@ class DeviceArray:
         shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
         pl = _pool()
-        ptr, c = pl.alloc(nbytes)
-        return cls(ptr, shape, dtype, owned=True, pool=pl, cls=c)
+        ptr, c, sh = pl.alloc(nbytes)
+        return cls(ptr, shape, dtype, owned=True, pool=pl, cls=c, stream=sh)
 
     @classmethod
     def zeros(cls, shape, dtype=np.float32):
@@ -337,10 +380,10 @@ class DeviceArray:
     def __del__(self):
         if getattr(self, "_owned", False) and self.ptr:
             try:
-                # stream-ordered reuse is safe here: every op of this package is enqueued in program
-                # order, and a recycled block is only touched by later-enqueued work
+                # stream-ordered reuse: the block goes back to the cache of the stream it was allocated under
+                # (see _Pool); a recycled block is only touched by work enqueued later on that stream
                 if self._pool is not None:
-                    self._pool.release(self.ptr, self._cls)
+                    self._pool.release(self.ptr, self._cls, self._stream)
                 else:
                     _lib.load().fx3d_free(self.ptr)
             except Exception:
@@ -390,8 +433,12 @@ _workspaces = {}
 
 
 def workspace(nbytes, tag="default"):
+    """The grow-only scratch of (current stream, tag).  Inside a Graph capture the scratch is private to the graph
+    (allocated from its pool, kept alive by it): the recording bakes the address in, and a later, larger eager call
+    on the same stream must not regrow -- and thereby release -- a buffer that graph replays still write."""
     key = (current_stream().handle, tag)
-    ws = _workspaces.get(key)
+    table = _capturing[-1]._ws if _capturing else _workspaces
+    ws = table.get(key)
     if ws is None:
-        ws = _workspaces[key] = Workspace()
+        ws = table[key] = Workspace()
     return ws.get(nbytes)

@@ -112,38 +112,46 @@ class ShardedChamfer:
             e.synchronize()
 
 
+def default_rendezvous():
+    """Where the ranks of one node meet to pass the RCCL unique id (fx3d_comm_bootstrap).  ``FX3D_COMM_RENDEZVOUS``
+    if set (``tcp://host:port`` or ``file://path``); otherwise a file in the temp directory keyed by the launcher's
+    pid and MASTER_PORT -- every rank of one torchrun shares both, a later job shares neither, and rank 0 removes
+    the file once all ranks have read it."""
+    import os
+    import tempfile
+    r = os.environ.get("FX3D_COMM_RENDEZVOUS")
+    if r:
+        return r
+    return "file://" + os.path.join(tempfile.gettempdir(), f"fx3d_uid_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}")
+
+
 class NativeComm:
     """RCCL communicator owned by the C library (fx3d_comm_*): the torch-free path a Julia host uses.
-    The 128-byte unique id is created on rank 0 and handed over by ``exchange`` (default: a
-    torch.distributed broadcast when a process group exists; world size 1 needs no exchange)."""
 
-    def __init__(self, rank=0, world_size=1, exchange=None):
-        ident = (C.c_uint8 * 128)()
-        err = None
-        if rank == 0:
-            try:
-                _lib.call("fx3d_comm_unique_id", ident)
-            except _lib.Flux3DHipError as e:  # keep going: the other ranks are waiting for the broadcast
-                err = e
-        if world_size > 1:
-            if exchange is None:
-                import torch
-                import torch.distributed as dist
-                t = torch.tensor(list(bytes(ident)) + [0 if err is None else 1], dtype=torch.uint8, device="cuda")
-                dist.broadcast(t, src=0)
-                vals = t.cpu().tolist()
-                if vals[128]:
-                    raise err if err is not None else _lib.Flux3DHipError(-7, "rank 0 could not create the RCCL unique id")
-                ident = (C.c_uint8 * 128)(*vals[:128])
-            else:
-                if err is not None:
-                    raise err
-                ident = (C.c_uint8 * 128)(*exchange(bytes(ident)))
-        elif err is not None:
-            raise err
+    ``rendezvous`` ("tcp://host:port" / "file://path", see :func:`default_rendezvous`): the library does the whole
+    bootstrap itself -- rank 0 creates the 128-byte unique id and hands it to the other ranks (fx3d_comm_bootstrap).
+    ``exchange``: a callable ``bytes -> bytes`` that moves rank 0's id to this rank by a channel of the host's own
+    (MPI, a torch broadcast, ...) for callers that prefer theirs.  World size 1 needs neither."""
+
+    def __init__(self, rank=0, world_size=1, exchange=None, rendezvous=None):
         h = C.c_void_p()
-        _lib.call("fx3d_comm_init_rank", C.byref(h), int(world_size), ident, int(rank))
+        if exchange is None:
+            rdv = rendezvous or default_rendezvous()
+            _lib.call("fx3d_comm_bootstrap", C.byref(h), int(world_size), int(rank), rdv.encode())
+        else:
+            ident = (C.c_uint8 * 128)()
+            if rank == 0:
+                _lib.call("fx3d_comm_unique_id", ident)
+            if world_size > 1:
+                ident = (C.c_uint8 * 128)(*exchange(bytes(ident)))
+            _lib.call("fx3d_comm_init_rank", C.byref(h), int(world_size), ident, int(rank))
         self.handle, self.rank, self.world_size = h.value, rank, world_size
+
+    def info(self):
+        """What the communicator says about itself: {"nranks", "rank", "rccl_version"} (ncclCommCount / UserRank / GetVersion)."""
+        n, r, v = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        _lib.call("fx3d_comm_info", self.handle, C.byref(n), C.byref(r), C.byref(v))
+        return {"nranks": n.value, "rank": r.value, "rccl_version": v.value}
 
     def allreduce_sum(self, buf):
         _lib.call("fx3d_comm_allreduce_sum_f64", self.handle, buf.ptr, buf.size, current_stream().handle)
@@ -158,23 +166,62 @@ class NativeComm:
 
 
 class NativeShardedChamfer:
-    """fx3d_chamfer_fwd_sharded: one C call per evaluation (kernel -> RCCL all-reduce of 2 Float64 ->
-    finalise with the global batch size), no Python between the three."""
+    """One C call per evaluation: kernel -> RCCL all-reduce of 2 Float64 -> finalise with the global batch size, no
+    Python between the three (north_star: "RCCL all-reduce of the scalar loss", once per evaluation).
 
-    def __init__(self, comm):
-        self.comm = comm
-        self.sums = DeviceArray.empty((2,), np.float64)
-        self.loss = DeviceArray.empty((1,), np.float32)
+    ``overlap=False``: fx3d_chamfer_fwd_sharded, everything on the current stream.
+    ``overlap=True``: fx3d_chamfer_fwd_sharded_async -- the collective and the finalisation run on a second stream
+    behind an event, so the NEXT evaluation's kernel overlaps this evaluation's 16-byte all-reduce (latency bound,
+    ~10-20 us over xGMI against a ~60 us kernel).  Results rotate through ``slots`` (sums, loss, events); a slot is
+    reused only after the compute stream has waited for its previous collective."""
+
+    def __init__(self, comm, overlap=False, slots=4):
+        self.comm, self.overlap = comm, overlap
+        self.nslot = slots if overlap else 1
+        self.sums = [DeviceArray.empty((2,), np.float64) for _ in range(self.nslot)]
+        self.losses = [DeviceArray.empty((1,), np.float32) for _ in range(self.nslot)]
+        self.k = 0
+        self.loss = self.losses[0]
+        self._last = 0
+        if overlap:
+            from .device import Event
+            self.side = Stream.create()
+            self.ready = [Event() for _ in range(self.nslot)]
+            self.done = [Event() for _ in range(self.nslot)]
 
     def __call__(self, x_shard, y_shard, B_global, w1=1.0, w2=1.0, sync=True):
         x, y = _as_dev_points(x_shard), _as_dev_points(y_shard)
         D, N, M, Bs = _check_pair(x, y)
         ws = chamfer_workspace(N, M, max(Bs, 1), D)
-        host = C.c_float(0)
-        _lib.call("fx3d_chamfer_fwd_sharded", self.comm.handle, x.ptr, N, y.ptr, M, Bs, D, int(B_global),
-                  float(w1), float(w2), self.sums.ptr, self.loss.ptr, C.byref(host) if sync else None,
-                  ws.ptr, ws.nbytes, current_stream().handle)
-        return np.float32(host.value) if sync else self.loss
+        i = self.k % self.nslot
+        self.k += 1
+        self._last = i
+        self.loss = self.losses[i]
+        st = current_stream().handle
+        if not self.overlap:
+            host = C.c_float(0)
+            _lib.call("fx3d_chamfer_fwd_sharded", self.comm.handle, x.ptr, N, y.ptr, M, Bs, D, int(B_global),
+                      float(w1), float(w2), self.sums[i].ptr, self.loss.ptr, C.byref(host) if sync else None,
+                      ws.ptr, ws.nbytes, st)
+            return np.float32(host.value) if sync else self.loss
+        if self.k > self.nslot:  # the slot's previous collective must have read its sums before the kernel overwrites them
+            _lib.call("fx3d_stream_wait_event", st, self.done[i].handle)
+        _lib.call("fx3d_chamfer_fwd_sharded_async", self.comm.handle, x.ptr, N, y.ptr, M, Bs, D, int(B_global),
+                  float(w1), float(w2), self.sums[i].ptr, self.loss.ptr, ws.ptr, ws.nbytes, st, self.side.handle,
+                  self.ready[i].handle, self.done[i].handle)
+        return self.result() if sync else self.loss
+
+    def synchronize(self):
+        if self.overlap and self.k:
+            self.side.synchronize()
+
+    def result(self):
+        """Host value of the most recent evaluation's loss."""
+        if self.overlap and self.k:
+            self.done[self._last].synchronize()
+            with stream(self.side):
+                return np.float32(self.loss.item())
+        return np.float32(self.loss.item())
 
 
 # ---- per-mesh losses over a batch sharded BY MESH (SURVEY.md 8e) ------------------------------------------

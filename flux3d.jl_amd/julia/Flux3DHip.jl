@@ -36,6 +36,7 @@ export HipArray, hip, unhip, use_hip, knn_graph, edgeconv_graph, pointcloud_to_v
 const LIB = get(ENV, "FLUX3D_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libflux3d_hip.so"))
 const Stream = Ptr{Cvoid}
 const DEFAULT_STREAM = Stream(C_NULL)
+const Event = Ptr{Cvoid}
 
 # ---- status handling (include/flux3d_hip.h: every call returns fx3d_status) -------------------
 function last_error()
@@ -565,6 +566,23 @@ function comm_init(nranks::Integer, id::Vector{UInt8}, rank::Integer)
     check(@ccall LIB.fx3d_comm_init_rank(c::Ref{Ptr{Cvoid}}, nranks::Int32, id::Ptr{UInt8}, rank::Int32)::Int32)
     return c[]
 end
+# the whole rendezvous inside the library (no MPI.jl / Distributed.jl): "tcp://host:port" or "file://path"
+function comm_bootstrap(nranks::Integer, rank::Integer, rendezvous::AbstractString)
+    c = Ref{Ptr{Cvoid}}(C_NULL)
+    check(@ccall LIB.fx3d_comm_bootstrap(c::Ref{Ptr{Cvoid}}, nranks::Int32, rank::Int32, rendezvous::Cstring)::Int32)
+    return c[]
+end
+# the rendezvous alone: rank 0's id arrives in every rank's buffer
+function comm_exchange_id!(id::Vector{UInt8}, nranks::Integer, rank::Integer, rendezvous::AbstractString)
+    length(id) == 128 || error("the RCCL unique id has 128 bytes")
+    check(@ccall LIB.fx3d_comm_exchange_id(id::Ptr{UInt8}, nranks::Int32, rank::Int32, rendezvous::Cstring)::Int32)
+    return id
+end
+function comm_info(c)
+    n = Ref{Int32}(0); r = Ref{Int32}(0); v = Ref{Int32}(0)
+    check(@ccall LIB.fx3d_comm_info(c::Ptr{Cvoid}, n::Ref{Int32}, r::Ref{Int32}, v::Ref{Int32})::Int32)
+    return (nranks = Int(n[]), rank = Int(r[]), rccl_version = Int(v[]))
+end
 comm_destroy(c) = check(@ccall LIB.fx3d_comm_destroy(c::Ptr{Cvoid})::Int32)
 
 # chamfer_distance of a batch whose slab [start, start+B_local) lives on this rank; every rank gets the
@@ -582,6 +600,23 @@ function chamfer_distance_sharded(comm, A::HipArray{Float32,3}, B::HipArray{Floa
                                               loss::Ref{Float32}, ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t,
                                               DEFAULT_STREAM::Stream)::Int32)
     return loss[]
+end
+
+# Overlapped form: kernel on `stream`, all-reduce + finalise on `comm_stream`; `slot` = (sums, loss_dev, ready, done) of a
+# small ring owned by the caller.  Returns at once; event_synchronize(slot.done) before reading slot.loss_dev.
+function chamfer_distance_sharded_async(comm, A::HipArray{Float32,3}, B::HipArray{Float32,3}, B_global::Integer, slot,
+                                        stream::Stream, comm_stream::Stream; w1::Number = 1.0, w2::Number = 1.0)
+    D, N, Bl = size(A); _, M, _ = size(B)
+    nb = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_chamfer_workspace_bytes(N::Int32, M::Int32, max(Bl, 1)::Int32, D::Int32, nb::Ref{Csize_t})::Int32)
+    ws = workspace(nb[])
+    check(@ccall LIB.fx3d_stream_wait_event(stream::Stream, slot.done::Event)::Int32)   # the slot's previous use
+    check(@ccall LIB.fx3d_chamfer_fwd_sharded_async(comm::Ptr{Cvoid}, A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32,
+                                                    Bl::Int32, D::Int32, B_global::Int64, Float32(w1)::Float32,
+                                                    Float32(w2)::Float32, slot.sums.ptr::Ptr{Cvoid}, slot.loss_dev.ptr::Ptr{Cvoid},
+                                                    ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t, stream::Stream, comm_stream::Stream,
+                                                    slot.ready::Event, slot.done::Event)::Int32)
+    return slot
 end
 
 # Deferred form for evaluation loops: `sums` (2,count) Float64 holds one slot per sharded batch
@@ -649,7 +684,6 @@ function stream_create()
 end
 stream_destroy(s::Stream) = check(@ccall LIB.fx3d_stream_destroy(s::Stream)::Int32)
 stream_synchronize(s::Stream = DEFAULT_STREAM) = check(@ccall LIB.fx3d_stream_sync(s::Stream)::Int32)
-const Event = Ptr{Cvoid}
 function event_create()
     e = Ref{Event}(C_NULL); check(@ccall LIB.fx3d_event_create(e::Ref{Event})::Int32); return e[]
 end

@@ -83,6 +83,8 @@ FX3D_API fx3d_status fx3d_event_create(fx3d_event_t *e);
 FX3D_API fx3d_status fx3d_event_destroy(fx3d_event_t e);
 FX3D_API fx3d_status fx3d_event_record(fx3d_event_t e, fx3d_stream_t s);
 FX3D_API fx3d_status fx3d_event_sync(fx3d_event_t e);
+/* Work enqueued on `s` after this call starts only once `e` has completed (device-side ordering, no host wait). */
+FX3D_API fx3d_status fx3d_stream_wait_event(fx3d_stream_t s, fx3d_event_t e);
 FX3D_API fx3d_status fx3d_event_elapsed_ms(fx3d_event_t start, fx3d_event_t stop, float *ms);
 
 /* ---- kernel timing hooks (the reference has no tracing; BenchmarkTools/CUDA.@sync
@@ -117,7 +119,9 @@ FX3D_API fx3d_status fx3d_chamfer_sums(const float *x, int32_t N, const float *y
                                        fx3d_stream_t s);
 
 /* loss = w1 * (Float32(sums[0]/(D*N*Bg)) * 3f0) + w2 * (Float32(sums[1]/(D*M*Bg)) * 3f0)
- * (src/metrics/pcloud.jl:47-50; the hard-coded 3.0f0 is kept for D != 3).  Bg is the GLOBAL batch
+ * (src/metrics/pcloud.jl:47-50; the hard-coded 3.0f0 is kept for D != 3).  The sums are Float64 accumulations of the
+ * Float32 squared distances, rounded to Float32 once; the reference's `mean` is a Float32 pairwise sum: the two differ
+ * by O(log2(n) 2^-24) relative, inside north_star's 1e-5 (the oracle defines the loss the same way).  Bg is the GLOBAL batch
  * size: after an all-reduce(sum) of sums_dev over the ranks that sharded the batch, every rank
  * calls this with the same Bg.  loss_dev: device float. */
 FX3D_API fx3d_status fx3d_chamfer_finalize(const double *sums_dev, int32_t N, int32_t M,
@@ -149,8 +153,11 @@ FX3D_API fx3d_status fx3d_chamfer_bwd(const float *x, int32_t N, const float *y,
  * knn(KDTree(y), x, k+drop_first, true)[1][1+drop_first:end] for every point of every batch
  * element: idx:(k,N,B) int32 0-based sorted by (distance, index); dist:(k,N,B) squared distances
  * (optional).  y may equal x (self graph; drop_first=1 drops the rank-0 hit as the reference
- * does).  Supported: k+drop_first <= 64; D <= ~110 for any k, D <= 128 when k+drop_first <= 32 and M >= 64
- * (the matrix-core kernels: D = 3 and 4 <= D <= 128); otherwise FX3D_ERR_UNSUPPORTED. */
+ * does).  Any k+drop_first <= M and any D: the matrix-core kernels take k+drop_first <= 32 with M >= 64 (D = 3 and
+ * 4 <= D <= 128), wave-per-query kernels k+drop_first <= 64 (D up to ~110), a general selection kernel everything else
+ * (k+drop_first up to M, any D) for M <= 36864 candidates; beyond that FX3D_ERR_UNSUPPORTED.
+ * Order = Julia's isless on the Float32 squared distance, then the lower index: NaN distances (non-finite coordinates)
+ * sort after +Inf, so every returned index is valid; fx3d_nn1 / the chamfer entry points use the same order. */
 FX3D_API fx3d_status fx3d_knn(const float *x, int32_t N, const float *y, int32_t M, int32_t B,
                               int32_t D, int32_t k, int32_t drop_first, int32_t *idx,
                               float *dist, fx3d_stream_t s);
@@ -286,11 +293,23 @@ FX3D_API fx3d_status fx3d_pointcloud_to_voxel(const float *points, int32_t N, in
 /* ---- multi-GPU: one process per GPU, batch sharded contiguously -------------------
  * The reference is single-device; the only collective the sharded path needs is all-reduce(sum) of
  * the two Float64 chamfer partial sums (RCCL over xGMI).  librccl is loaded at run time.
- * rank 0 calls fx3d_comm_unique_id and hands the 128 bytes to the other ranks by any host channel;
- * every rank then calls fx3d_comm_init_rank with its own device current. */
+ * Two ways to a communicator: fx3d_comm_bootstrap does the whole rendezvous itself (rank 0 creates the unique id and
+ * hands it to the other ranks over TCP or a file: no torch, no MPI); or rank 0 calls fx3d_comm_unique_id, the host
+ * moves the 128 bytes by any channel it has, and every rank calls fx3d_comm_init_rank.  Either way each rank makes its
+ * own device current first (fx3d_set_device(local_rank)). */
 FX3D_API fx3d_status fx3d_comm_unique_id(uint8_t *id128);
 FX3D_API fx3d_status fx3d_comm_init_rank(fx3d_comm_t *comm, int32_t nranks, const uint8_t *id128,
                                          int32_t rank);
+/* rendezvous: "tcp://host:port" (rank 0 listens on `port`, the others connect to host:port and retry until it is up;
+ * nothing persists) or "file://path" (rank 0 publishes path by rename, removes it once every rank has read it).
+ * Under torchrun: tcp://$MASTER_ADDR:<a free port, e.g. $MASTER_PORT + 1>.  Blocks until all ranks have joined (120 s). */
+FX3D_API fx3d_status fx3d_comm_bootstrap(fx3d_comm_t *comm, int32_t nranks, int32_t rank, const char *rendezvous);
+/* The rendezvous alone: rank 0's 128 bytes arrive in every other rank's id128 (what fx3d_comm_bootstrap does between
+ * fx3d_comm_unique_id and fx3d_comm_init_rank).  Host memory; needs neither a GPU nor RCCL. */
+FX3D_API fx3d_status fx3d_comm_exchange_id(uint8_t *id128, int32_t nranks, int32_t rank, const char *rendezvous);
+/* What the communicator says about itself (ncclCommCount / ncclCommUserRank) and the RCCL version code
+ * (ncclGetVersion); any output may be NULL, comm may be NULL when only the version is asked for. */
+FX3D_API fx3d_status fx3d_comm_info(fx3d_comm_t comm, int32_t *nranks, int32_t *rank, int32_t *rccl_version);
 FX3D_API fx3d_status fx3d_comm_destroy(fx3d_comm_t comm);
 FX3D_API fx3d_status fx3d_comm_allreduce_sum_f64(fx3d_comm_t comm, double *buf_dev, int64_t count,
                                                  fx3d_stream_t s);
@@ -302,6 +321,16 @@ FX3D_API fx3d_status fx3d_chamfer_fwd_sharded(fx3d_comm_t comm, const float *x, 
                                               int64_t B_global, float w1, float w2, double *sums_dev,
                                               float *loss_dev, float *loss_host, void *ws,
                                               size_t ws_bytes, fx3d_stream_t s);
+
+/* The same with the collective off the compute stream: kernel on `s`, all-reduce + finalise on `comm_stream` behind
+ * the event `ready` (recorded on s), `done` (recorded on comm_stream) marks the loss.  No host wait: the next
+ * evaluation's kernel on `s` overlaps this one's collective.  The caller rotates (sums_dev, loss_dev, ready, done) over
+ * a few slots and calls fx3d_stream_wait_event(s, done) before a slot is reused. */
+FX3D_API fx3d_status fx3d_chamfer_fwd_sharded_async(fx3d_comm_t comm, const float *x, int32_t N, const float *y,
+                                                    int32_t M, int32_t B_local, int32_t D, int64_t B_global,
+                                                    float w1, float w2, double *sums_dev, float *loss_dev,
+                                                    void *ws, size_t ws_bytes, fx3d_stream_t s,
+                                                    fx3d_stream_t comm_stream, fx3d_event_t ready, fx3d_event_t done);
 
 /* ---- host-side topology (integer work; the reference keeps faces/edges/Laplacian on the host,
  *      src/rep/mesh.jl:87-97, and caches them forever) ------------------------------------------

@@ -43,17 +43,25 @@ static inline float sqdist(const float *a, const float *b, int D) {
     return s;
 }
 
+/* Order of distances: Julia's `isless` total order on Float32 -- ascending, every NaN after +Inf, all NaNs
+ * equal -- then the lower index.  For finite data this is the plain `<` scan with the first minimum winning.
+ * Non-finite data is outside anything the reference pins (NearestNeighbors' `dist <= best` skips NaN candidates and
+ * leaves its -1 sentinel when none qualifies; the CuArray method's argmin, src/metrics/pcloud.jl:80-81, puts NaN first):
+ * this order keeps every index valid, skips NaN candidates while a comparable one exists and lets a NaN query
+ * propagate NaN into the loss, as the reference's mean would. */
+static inline int fless(float a, float b) { return (a < b) || (b != b && a == a); }
+
 /* 1-NN of every x point in y (same batch element), brute force, first minimum wins.
  * Semantics of `knn(KDTree(y[:,:,b]), x[:,:,b], 1)[1]`, src/metrics/pcloud.jl:54-61. */
 static void nn1_dir(const float *x, int N, const float *y, int M, int D, int32_t *idx,
                     float *dmin) {
     for (int i = 0; i < N; ++i) {
-        float best = INFINITY;
-        int32_t bi = 0;
         const float *a = x + (size_t)i * D;
-        for (int j = 0; j < M; ++j) {
+        float best = sqdist(a, y, D);
+        int32_t bi = 0;
+        for (int j = 1; j < M; ++j) {
             float d = sqdist(a, y + (size_t)j * D, D);
-            if (d < best) { best = d; bi = j; }
+            if (fless(d, best)) { best = d; bi = j; }
         }
         idx[i] = bi;
         if (dmin) dmin[i] = best;
@@ -77,8 +85,9 @@ FX_API int fx3d_oracle_nn1(const float *x, int N, const float *y, int M, int B, 
  *   dist_A_to_B = mean((A .- B[:, nn_for_A]).^2) * 3.0f0   (mean over D*N*B elements)
  *   dist_B_to_A = mean((B .- A[:, nn_for_B]).^2) * 3.0f0
  *   w1*dist_A_to_B + w2*dist_B_to_A
- * Element squares are Float32; the mean is accumulated here in double (the reference uses
- * Float32 pairwise summation; both are within 1e-6 relative of the exact sum). */
+ * Element squares are Float32; the mean is accumulated here in double, where the reference's `mean` is a
+ * Float32 pairwise sum (Base.mean -> sum / n): the two differ by O(log2(n) * 2^-24) relative, inside the 1e-5 of
+ * north_star; fx3d_chamfer_finalize (csrc/chamfer.hip) follows THIS definition (double sums, one rounding). */
 FX_API int fx3d_oracle_chamfer_fwd(const float *x, int N, const float *y, int M, int B, int D,
                                    float w1, float w2, float *loss, int32_t *idx_x,
                                    int32_t *idx_y, double *sums /* [2] optional */) {
@@ -145,7 +154,8 @@ FX_API int fx3d_oracle_chamfer_bwd(const float *x, int N, const float *y, int M,
  * N queries, serial), src/metrics/pcloud.jl:54-70.  NearestNeighbors.jl defaults: leafsize 10,
  * split on the widest dimension at the median.  Used (a) as the like-for-like cpu_baseline in
  * bench.py, (b) as an independent check that the brute-force result is what a tree returns.
- * Ties resolve to the lowest index so the answer is identical to nn1_dir.
+ * Ties resolve to the lowest index so the answer is identical to nn1_dir (finite data only: the tree's
+ * pruning test assumes comparable distances; non-finite inputs are defined by nn1_dir's order alone).
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
     const float *pts;
@@ -320,7 +330,7 @@ FX_API int fx3d_oracle_chamfer_fwd_kdtree(const float *x, int N, const float *y,
 /* ------------------------------------------------------------------------------------------
  * k-NN graph: CreateSingleKNNGraph(X,K), src/models/dgcnn.jl:3-7:
  *   knn(kdtree, X[:,i], K+1, true)[1][2:K+1]   -- K+1 nearest sorted ascending, first dropped.
- * Here: sorted by (distance, index); drop_first removes rank 0 (the reference assumes it is
+ * Here: sorted by (distance in the isless order above, index); drop_first removes rank 0 (the reference assumes it is
  * the query itself).  idx[(b*N+i)*k + r], dist likewise (squared distance, Float32).
  * ---------------------------------------------------------------------------------------- */
 FX_API int fx3d_oracle_knn(const float *x, int N, const float *y, int M, int B, int D, int k,
@@ -335,9 +345,9 @@ FX_API int fx3d_oracle_knn(const float *x, int N, const float *y, int M, int B, 
             int cnt = 0;
             for (int j = 0; j < M; ++j) {
                 float d = sqdist(xb + (size_t)i * D, yb + (size_t)j * D, D);
-                if (cnt == kk && !(d < bd[kk - 1])) continue; /* ties keep the earlier index */
+                if (cnt == kk && !fless(d, bd[kk - 1])) continue; /* ties keep the earlier index */
                 int p = cnt < kk ? cnt : kk - 1;
-                while (p > 0 && d < bd[p - 1]) { bd[p] = bd[p - 1]; bj[p] = bj[p - 1]; --p; }
+                while (p > 0 && fless(d, bd[p - 1])) { bd[p] = bd[p - 1]; bj[p] = bj[p - 1]; --p; }
                 bd[p] = d; bj[p] = j;
                 if (cnt < kk) ++cnt;
             }
