@@ -194,7 +194,7 @@ def main():
 
         def read_loss():
             with fx.stream(s):
-                return sh.result()
+                return float(sh.result())
         return step, sync_all, read_loss, s, "fx3d_comm all-reduce of 2 f64 per step" + \
             (" on a second stream, overlapping the next step's kernel" if mode == "overlap" else " on the compute stream")
 

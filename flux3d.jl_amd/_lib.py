@@ -89,6 +89,9 @@ SIGNATURES = {
     "fx3d_edge_loss_bwd": [vp, c_i64, vp, c_i64, c_f32, c_f32, vp, c_i32, vp],
     "fx3d_laplacian_loss": [vp, c_i64, vp, vp, vp, vp, C.POINTER(c_f32), vp, sz, vp],
     "fx3d_laplacian_loss_bwd": [vp, c_i64, vp, vp, vp, c_f32, vp, c_i32, vp],
+    "fx3d_mesh_losses_workspace_bytes": [c_i64, c_i64, C.POINTER(sz)],
+    "fx3d_mesh_losses": [vp, c_i64, vp, vp, vp, vp, c_i64, c_f32, c_f32, c_f32, vp, vp, vp, vp, vp, sz, vp],
+    "fx3d_mesh_losses_bwd": [vp, c_i64, vp, vp, vp, c_i64, c_f32, c_f32, c_f32, c_i32, vp, c_i32, vp, sz, vp],
     "fx3d_comm_unique_id": [vp],
     "fx3d_comm_init_rank": [C.POINTER(vp), c_i32, vp, c_i32],
     "fx3d_comm_bootstrap": [C.POINTER(vp), c_i32, c_i32, C.c_char_p],

@@ -1950,7 +1950,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                 const float acoef_q = 8.0f * (float)(4 * D + 8) * 0x1p-24f + (SPLIT ? 0x1p-18f : 0x1.01p-10f);
                 const float floor_q = 0x1p-24f * sqrtf((float)D) * (qn + 2.0f);
                 eps = two_norms ? acoef_q * qn + floor_q : acoef_q * (qn + c2) + floor_q + 0x1p-26f * sqrtf((float)D) * c2;
-                eps = qok ? eps : INFINITY;
+                eps = (qok && c2 == c2) ? eps : INFINITY;  // c2 is NaN for a non-finite / overflow-prone cloud (scale pass)
             } else {
                 eps = (8.0f * (float)(D + 4) * 0x1p-24f) * (qn + c2);
                 eps = qn + c2 < 1.0e38f ? eps : INFINITY;  // (|q| + |c|)^2 <= 2 (qn + c2): no exact distance overflows

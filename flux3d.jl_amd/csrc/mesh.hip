@@ -164,6 +164,140 @@ __global__ __launch_bounds__(kThreads) void laplacian_loss_bwd_kernel(
     }
 }
 
+// ---- both mesh losses in ONE launch, both adjoints in ONE gather launch (the fit_mesh regularisers,
+//      examples/fit_mesh.jl:80-83: 0.1 laplacian_loss + edge_loss, launch bound at teapot scale) -----------------------
+// Forward: blocks [0, gV) take Laplacian rows, blocks [gV, gV + gE) take edges; every block publishes one Float64
+// partial, the last arriver adds each range in index order and writes both means (+ the weighted total).  As a
+// by-product the row kernel stores u_r = (L v)_r / ||(L v)_r|| and 1/deg(r) per vertex (float4): all the adjoint needs.
+// Adjoint, gather form, one thread per vertex i walking row i of the Laplacian's CSR (columns ascending):
+//   Laplacian term  sum_{r in row i}  (c_l L[r,i]) u_r,  L[r,i] = -1 (r == i) or 1/deg(r);
+//   edge term       sum_{j ~ i}  -+ g_ij d_ij           (j < i: edge (j,i), i is its second vertex; j > i: edge (i,j)).
+// Both sums run in exactly the order in which the oracle's row-by-row / edge-by-edge scatter reaches vertex i (rows and
+// sorted edges ascending), with its expressions, so the gradients are BIT-IDENTICAL to the oracle -- and run to run:
+// no float atomics (the scatter versions above depend on the atomics' arrival order in the last bit).
+// Requires the CSR to be the Laplacian of the SAME edge list (it is: both are cached per mesh, src/rep/mesh.jl:957-1002).
+__global__ __launch_bounds__(kThreads) void mesh_losses_kernel(
+    const float *__restrict__ verts, long long V, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+    const float *__restrict__ vals, const int32_t *__restrict__ e1, const int32_t *__restrict__ e2, long long E, float target,
+    int gV, int gE, double *__restrict__ partials, unsigned int *ticket, float w_lap, float w_edge,
+    const float *__restrict__ base, float *__restrict__ loss_lap, float *__restrict__ loss_edge, float *__restrict__ total,
+    float4 *__restrict__ u_out) {
+    __shared__ double sm[kThreads / 64];
+    __shared__ int is_last;
+    double acc = 0.0;
+    const int blk = blockIdx.x;
+    if (blk < gV) {
+        for (long long i = (long long)blk * kThreads + threadIdx.x; i < V; i += (long long)gV * kThreads) {
+            float s0, s1, s2;
+            lap_row(verts, rowptr, colind, vals, i, s0, s1, s2);
+            const float nrm = sqrtf(((s0 * s0) + (s1 * s1)) + (s2 * s2));
+            acc += (double)nrm;
+            if (u_out) {
+                const int k0 = rowptr[i], k1 = rowptr[i + 1];
+                float invdeg = 0.0f;  // any off-diagonal value of the row (all equal 1/deg(i)); 0 for an isolated vertex
+                if (k1 - k0 >= 2) invdeg = colind[k0] == (int)i ? vals[k0 + 1] : vals[k0];
+                const bool ok = nrm > 0.0f;
+                u_out[i] = float4{ok ? s0 / nrm : 0.0f, ok ? s1 / nrm : 0.0f, ok ? s2 / nrm : 0.0f, invdeg};
+            }
+        }
+    } else {
+        for (long long e = (long long)(blk - gV) * kThreads + threadIdx.x; e < E; e += (long long)gE * kThreads) {
+            const float *a = verts + 3ll * e1[e], *b = verts + 3ll * e2[e];
+            const float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
+            const float nrm = sqrtf(((d0 * d0) + (d1 * d1)) + (d2 * d2));
+            const float t = nrm - target;
+            acc += (double)(t * t);
+        }
+    }
+    const double tot = block_sum<kThreads>(acc, sm);
+    unsigned long long *pp = reinterpret_cast<unsigned long long *>(partials);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&pp[blk], __builtin_bit_cast(unsigned long long, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = old == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = threadIdx.x; i < gV; i += kThreads)
+        a0 += __builtin_bit_cast(double, __hip_atomic_load(&pp[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (int i = threadIdx.x; i < gE; i += kThreads)
+        a1 += __builtin_bit_cast(double, __hip_atomic_load(&pp[gV + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
+    const double t0 = block_sum<kThreads>(a0, sm);
+    __syncthreads();
+    const double t1 = block_sum<kThreads>(a1, sm);
+    if (threadIdx.x == 0) {
+        const float ll = (float)(t0 / (double)V), le = (float)(t1 / (double)E);
+        if (loss_lap) *loss_lap = ll;
+        if (loss_edge) *loss_edge = le;
+        if (total) *total = ((base ? *base : 0.0f) + (w_lap * ll)) + (w_edge * le);  // the tutorial's sum, its order, unfused
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// u_r and 1/deg(r) alone (the adjoint without a preceding fused forward)
+__global__ __launch_bounds__(kThreads) void lap_unit_rows_kernel(const float *__restrict__ verts, long long V,
+                                                                const int32_t *__restrict__ rowptr,
+                                                                const int32_t *__restrict__ colind,
+                                                                const float *__restrict__ vals, float4 *__restrict__ u_out) {
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < V; i += (long long)gridDim.x * kThreads) {
+        float s0, s1, s2;
+        lap_row(verts, rowptr, colind, vals, i, s0, s1, s2);
+        const float nrm = sqrtf(((s0 * s0) + (s1 * s1)) + (s2 * s2));
+        const int k0 = rowptr[i], k1 = rowptr[i + 1];
+        float invdeg = 0.0f;
+        if (k1 - k0 >= 2) invdeg = colind[k0] == (int)i ? vals[k0 + 1] : vals[k0];
+        const bool ok = nrm > 0.0f;
+        u_out[i] = float4{ok ? s0 / nrm : 0.0f, ok ? s1 / nrm : 0.0f, ok ? s2 / nrm : 0.0f, invdeg};
+    }
+}
+
+template <bool LAP, bool EDGE>
+__global__ __launch_bounds__(kThreads) void mesh_losses_bwd_gather_kernel(
+    const float *__restrict__ verts, long long V, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+    const float4 *__restrict__ u, float c_lap, float c_edge, float target, float *__restrict__ gverts, int accumulate) {
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < V; i += (long long)gridDim.x * kThreads) {
+        const float v0 = verts[3 * i], v1 = verts[3 * i + 1], v2 = verts[3 * i + 2];
+        float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
+        const int k1 = rowptr[i + 1];
+        for (int k = rowptr[i]; k < k1; ++k) {
+            const int r = colind[k];
+            if (LAP) {  // row r of the oracle's scatter: gverts[i] += (c * L[r,i]) * u_r
+                const float4 ur = u[r];
+                const float w = c_lap * (r == (int)i ? -1.0f : ur.w);
+                l0 = l0 + w * ur.x;
+                l1 = l1 + w * ur.y;
+                l2 = l2 + w * ur.z;
+            }
+            if (EDGE && r != (int)i) {
+                const float *vr = verts + 3ll * r;
+                if (r < (int)i) {  // edge (r, i): d = v_r - v_i, vertex i receives -= g d
+                    const float d0 = vr[0] - v0, d1 = vr[1] - v1, d2 = vr[2] - v2;
+                    const float nrm = sqrtf(((d0 * d0) + (d1 * d1)) + (d2 * d2));
+                    if (nrm > 0.0f) {
+                        const float g = c_edge * 2.0f * (nrm - target) / nrm;
+                        e0 = e0 - g * d0; e1 = e1 - g * d1; e2 = e2 - g * d2;
+                    }
+                } else {           // edge (i, r): d = v_i - v_r, vertex i receives += g d
+                    const float d0 = v0 - vr[0], d1 = v1 - vr[1], d2 = v2 - vr[2];
+                    const float nrm = sqrtf(((d0 * d0) + (d1 * d1)) + (d2 * d2));
+                    if (nrm > 0.0f) {
+                        const float g = c_edge * 2.0f * (nrm - target) / nrm;
+                        e0 = e0 + g * d0; e1 = e1 + g * d1; e2 = e2 + g * d2;
+                    }
+                }
+            }
+        }
+        // (prev + laplacian term) + edge term: the order of the tutorial's chain (g_chamfer + g_lap) + g_edge
+        float o0 = accumulate ? gverts[3 * i] : 0.0f, o1 = accumulate ? gverts[3 * i + 1] : 0.0f, o2 = accumulate ? gverts[3 * i + 2] : 0.0f;
+        if (LAP) { o0 = accumulate ? o0 + l0 : l0; o1 = accumulate ? o1 + l1 : l1; o2 = accumulate ? o2 + l2 : l2; }
+        if (EDGE) { o0 = (LAP || accumulate) ? o0 + e0 : e0; o1 = (LAP || accumulate) ? o1 + e1 : e1; o2 = (LAP || accumulate) ? o2 + e2 : e2; }
+        gverts[3 * i] = o0; gverts[3 * i + 1] = o1; gverts[3 * i + 2] = o2;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void lincomb_kernel(long long n, float a, const float *__restrict__ x, float b,
                                                           const float *__restrict__ y, float c,
                                                           const float *__restrict__ z, float *__restrict__ out) {
@@ -339,12 +473,69 @@ fx3d_status fx3d_laplacian_loss(const float *verts, int64_t V, const int32_t *ro
     return copy_back(loss_host, loss_dev, st);
 }
 
+fx3d_status fx3d_mesh_losses_workspace_bytes(int64_t V, int64_t E, size_t *bytes) {
+    FX3D_REQUIRE(bytes && V > 0 && E >= 0, "fx3d_mesh_losses_workspace_bytes: bad argument");
+    // per-block partials of both ranges + the (4,V) unit rows of the Laplacian (16-byte aligned behind them)
+    *bytes = sizeof(double) * 2 * kMaxBlocks + sizeof(float) * 4 * (size_t)V;
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_mesh_losses(const float *verts, int64_t V, const int32_t *rowptr, const int32_t *colind,
+                             const float *vals, const int32_t *edges, int64_t E, float target, float w_lap, float w_edge,
+                             const float *base_dev, float *loss_lap_dev, float *loss_edge_dev, float *total_dev,
+                             void *ws, size_t ws_bytes, fx3d_stream_t s) {
+    FX3D_REQUIRE(verts && rowptr && colind && vals && edges, "fx3d_mesh_losses: null pointer");
+    FX3D_REQUIRE(loss_lap_dev || loss_edge_dev || total_dev, "fx3d_mesh_losses: no output requested");
+    FX3D_REQUIRE(V > 0 && E > 0 && V < (1ll << 31), "fx3d_mesh_losses: bad sizes V=%lld E=%lld", (long long)V, (long long)E);
+    size_t need = 0;
+    fx3d_mesh_losses_workspace_bytes(V, E, &need);
+    if (!ws || ws_bytes < need) { set_error("fx3d_mesh_losses: workspace too small (%zu < %zu bytes)", ws ? ws_bytes : (size_t)0, need); return FX3D_ERR_WORKSPACE; }
+    hipStream_t st = as_stream(s);
+    double *partials = reinterpret_cast<double *>(ws);
+    float4 *u = reinterpret_cast<float4 *>(partials + 2 * kMaxBlocks);
+    fx3d_status trc = FX3D_OK;
+    unsigned int *ticket = ticket_slot(&trc, st);
+    if (!ticket) return trc;
+    const int gV = grid_for(V), gE = grid_for(E);
+    {
+        ProfileScope prof("mesh_losses", st);
+        hipLaunchKernelGGL(mesh_losses_kernel, dim3(gV + gE), dim3(kThreads), 0, st, verts, (long long)V, rowptr, colind, vals,
+                           edges, edges + E, (long long)E, target, gV, gE, partials, ticket, w_lap, w_edge, base_dev,
+                           loss_lap_dev, loss_edge_dev, total_dev, u);
+    }
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_mesh_losses_bwd(const float *verts, int64_t V, const int32_t *rowptr, const int32_t *colind,
+                                 const float *vals, int64_t E, float target, float g_lap, float g_edge, int32_t reuse_forward,
+                                 float *gverts, int32_t accumulate, void *ws, size_t ws_bytes, fx3d_stream_t s) {
+    FX3D_REQUIRE(verts && rowptr && colind && vals && gverts, "fx3d_mesh_losses_bwd: null pointer");
+    FX3D_REQUIRE(V > 0 && E > 0 && V < (1ll << 31), "fx3d_mesh_losses_bwd: bad sizes");
+    size_t need = 0;
+    fx3d_mesh_losses_workspace_bytes(V, E, &need);
+    if (!ws || ws_bytes < need) { set_error("fx3d_mesh_losses_bwd: workspace too small (%zu < %zu bytes)", ws ? ws_bytes : (size_t)0, need); return FX3D_ERR_WORKSPACE; }
+    hipStream_t st = as_stream(s);
+    float4 *u = reinterpret_cast<float4 *>(reinterpret_cast<double *>(ws) + 2 * kMaxBlocks);
+    if (!reuse_forward) {  // no fx3d_mesh_losses on the same vertices and workspace before this call: build the unit rows
+        hipLaunchKernelGGL(lap_unit_rows_kernel, dim3(grid_for(V)), dim3(kThreads), 0, st, verts, (long long)V, rowptr, colind, vals, u);
+        FX3D_LAUNCH_CHECK();
+    }
+    ProfileScope prof("mesh_losses_bwd", st);
+    hipLaunchKernelGGL((mesh_losses_bwd_gather_kernel<true, true>), dim3(grid_for(V)), dim3(kThreads), 0, st, verts, (long long)V,
+                       rowptr, colind, u, g_lap / (float)V, g_edge / (float)E, target, gverts, accumulate);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
 fx3d_status fx3d_laplacian_loss_bwd(const float *verts, int64_t V, const int32_t *rowptr,
                                     const int32_t *colind, const float *vals, float gout,
                                     float *gverts, int32_t accumulate, fx3d_stream_t s) {
     FX3D_REQUIRE(verts && rowptr && colind && vals && gverts, "fx3d_laplacian_loss_bwd: null pointer");
     FX3D_REQUIRE(V > 0, "fx3d_laplacian_loss_bwd: bad V");
     hipStream_t st = as_stream(s);
+    // scatter form (float atomics): this entry point has no scratch for the unit rows the gather form needs;
+    // fx3d_mesh_losses_bwd is the atomic-free, bit-reproducible route
     if (!accumulate) FX3D_HIP(hipMemsetAsync(gverts, 0, sizeof(float) * 3 * (size_t)V, st));
     hipLaunchKernelGGL(laplacian_loss_bwd_kernel, dim3(grid_for(V)), dim3(kThreads), 0, st, verts,
                        (long long)V, rowptr, colind, vals, gout / (float)V, gverts);

@@ -10,8 +10,7 @@ import numpy as np
 
 from . import _lib
 from .device import DeviceArray, Graph, Stream, current_stream, stream
-from .metrics import (_chamfer_points, chamfer_distance_grad, edge_loss, edge_loss_grad, laplacian_loss,
-                      laplacian_loss_grad)
+from .metrics import _chamfer_points, chamfer_distance_grad, mesh_losses, mesh_losses_grad
 from .transforms import lincomb, offset, sample_points, sample_points_grad
 
 
@@ -27,24 +26,23 @@ def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_la
     A, fa, r1, r2 = sample_points(m, num_samples, seed=s1, return_draws=True, seed_dev=seed_dev)
     Bp = sample_points(tgt, num_samples, seed=s2, seed_dev=seed_dev)
     loss1, ix, iy = _chamfer_points(A, Bp, 1.0, 1.0, return_indices=True, sync=sync)
-    loss2, loss3 = laplacian_loss(m, sync=sync), edge_loss(m, sync=sync)
+    # both regularisers and the tutorial's sum fl(fl(l1 + fl(w_lap*l2)) + fl(w_edge*l3)) in ONE launch (unfused Float32)
     if sync:
+        loss2, loss3, _ = mesh_losses(m, 0.0, w_lap, w_edge, sync=True)
         loss = np.float32(np.float32(loss1 + np.float32(w_lap) * loss2) + np.float32(w_edge) * loss3)
-    else:  # fl(fl(l1 + fl(w_lap*l2)) + fl(w_edge*l3)) on the device as well (unfused), one launch
-        loss = lincomb(1.0, loss1, w_lap, loss2, w_edge, loss3)
+    else:
+        _, _, loss = mesh_losses(m, 0.0, w_lap, w_edge, base=loss1, sync=False)
     if not with_grad:
         return loss
     gA, _ = chamfer_distance_grad(A, Bp, ix, iy)
     gpad = sample_points_grad(m, fa, r1, r2, gA)           # (3,Vmax,B), zeroed + scatter-added
-    if m.N == 1:  # one mesh: padded == packed, the two mesh-loss adjoints add into the same buffer
+    if m.N == 1:  # one mesh: padded == packed, the mesh-loss adjoints add into the same buffer
         g = gpad.reshape(3, m.V)
-        laplacian_loss_grad(m, w_lap, out=g)
-        edge_loss_grad(m, 0.0, w_edge, out=g)
-        return loss, g
-    g1 = m.padded_to_packed_dev(gpad)                       # adjoint of _packed_to_padded
-    g2 = laplacian_loss_grad(m, w_lap)
-    g3 = edge_loss_grad(m, 0.0, w_edge)
-    return loss, lincomb(1.0, g1, 1.0, g2, 1.0, g3)
+    else:
+        g = m.padded_to_packed_dev(gpad)                    # adjoint of _packed_to_padded
+    # both mesh-loss adjoints in ONE gather launch (no float atomics), reusing the forward's unit rows
+    mesh_losses_grad(m, 0.0, w_lap, w_edge, out=g, reuse_forward=True)
+    return loss, g
 
 
 class Momentum:

@@ -553,6 +553,41 @@ function edge_loss_grad(m::TriMesh{Float32,R,HipArray}, verts::HipArray{Float32,
     return g
 end
 
+# Both regularisers of the fit_mesh objective in ONE launch and both adjoints in ONE gather launch (no float atomics:
+# gradients are bit-reproducible).  `ws` keeps the Laplacian's unit rows between the two calls (same mesh, same vertices).
+function mesh_losses_workspace(m::TriMesh{Float32,R,HipArray}) where {R}
+    nb = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_mesh_losses_workspace_bytes(size(get_verts_packed(m), 2)::Int64, size(get_edges_packed(m), 1)::Int64,
+                                                      nb::Ref{Csize_t})::Int32)
+    return HipArray{UInt8}(undef, Int(nb[]))
+end
+function mesh_losses(m::TriMesh{Float32,R,HipArray}, ws::HipArray{UInt8}; target::Number = 0, w_lap::Number = 0.1,
+                     w_edge::Number = 1.0, base::Union{Nothing,HipArray{Float32}} = nothing) where {R}
+    verts = get_verts_packed(m)::HipArray{Float32,2}
+    rowptr, colind, vals = laplacian_csr_dev(m); edges = edges_dev(m)
+    out = HipArray{Float32}(undef, 3)
+    check(@ccall LIB.fx3d_mesh_losses(verts.ptr::Ptr{Cvoid}, size(verts, 2)::Int64, rowptr.ptr::Ptr{Cvoid}, colind.ptr::Ptr{Cvoid},
+                                      vals.ptr::Ptr{Cvoid}, edges.ptr::Ptr{Cvoid}, size(edges, 1)::Int64, Float32(target)::Float32,
+                                      Float32(w_lap)::Float32, Float32(w_edge)::Float32,
+                                      (base === nothing ? C_NULL : base.ptr)::Ptr{Cvoid}, out.ptr::Ptr{Cvoid},
+                                      (out.ptr + 4)::Ptr{Cvoid}, (out.ptr + 8)::Ptr{Cvoid}, ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t,
+                                      DEFAULT_STREAM::Stream)::Int32)
+    return out      # (laplacian_loss, edge_loss, (base + w_lap*lap) + w_edge*edge) on the device
+end
+function mesh_losses_grad(m::TriMesh{Float32,R,HipArray}, ws::HipArray{UInt8}; target::Number = 0, g_lap::Number = 0.1,
+                          g_edge::Number = 1.0, reuse_forward::Bool = false,
+                          out::Union{Nothing,HipArray{Float32,2}} = nothing) where {R}
+    verts = get_verts_packed(m)::HipArray{Float32,2}
+    rowptr, colind, vals = laplacian_csr_dev(m)
+    g = out === nothing ? HipArray{Float32}(undef, size(verts)...) : out
+    check(@ccall LIB.fx3d_mesh_losses_bwd(verts.ptr::Ptr{Cvoid}, size(verts, 2)::Int64, rowptr.ptr::Ptr{Cvoid}, colind.ptr::Ptr{Cvoid},
+                                          vals.ptr::Ptr{Cvoid}, size(get_edges_packed(m), 1)::Int64, Float32(target)::Float32,
+                                          Float32(g_lap)::Float32, Float32(g_edge)::Float32, (reuse_forward ? 1 : 0)::Int32,
+                                          g.ptr::Ptr{Cvoid}, (out === nothing ? 0 : 1)::Int32, ws.ptr::Ptr{Cvoid},
+                                          length(ws)::Csize_t, DEFAULT_STREAM::Stream)::Int32)
+    return g
+end
+
 # ---- multi-GPU (one Julia process per GPU): RCCL through the C ABI, SURVEY.md 8e ----------------------
 # rank 0: id = comm_unique_id(); ship the 128 bytes to the other ranks (Distributed.jl, MPI.jl, a file);
 # every rank: comm = comm_init(nranks, id, rank) after fx3d_set_device(local_rank).

@@ -160,3 +160,52 @@ def edge_loss_grad(m, target_length=0.0, gout=1.0, out=None):
     _lib.call("fx3d_edge_loss_bwd", verts.ptr, V, edges.ptr, edges.shape[0], float(target_length),
               float(gout), g.ptr, int(out is not None), current_stream().handle)
     return g
+
+
+def _mesh_fused_ws(m, V, E):
+    """Scratch of the fused mesh-loss pair, owned by the mesh object: the forward leaves the Laplacian's unit rows
+    in it and the adjoint of the SAME mesh (same vertices) reads them back."""
+    ws = m._dev.get("mesh_fused_ws") if m.on_device else None
+    if ws is None:
+        n = C.c_size_t(0)
+        _lib.call("fx3d_mesh_losses_workspace_bytes", int(V), int(E), C.byref(n))
+        ws = DeviceArray.empty((n.value,), np.uint8)
+        if m.on_device:
+            m._dev["mesh_fused_ws"] = ws
+    return ws
+
+
+def mesh_losses(m, target_length=0.0, w_lap=0.1, w_edge=1.0, base=None, sync=True):
+    """laplacian_loss(m) and edge_loss(m, target_length) (src/metrics/mesh.jl:9-32) in ONE launch, plus the fit_mesh
+    objective's weighted sum ``(base + w_lap*lap) + w_edge*edge`` (examples/fit_mesh.jl:80-83; ``base``: a 1-element
+    device array, e.g. the chamfer term, or None).  Returns (lap, edge, total): host Float32 when ``sync`` else
+    1-element device arrays."""
+    verts = m.dev("verts_packed")
+    V = verts.shape[1]
+    edges = m.dev("edges")
+    E = edges.shape[0]
+    ws = _mesh_fused_ws(m, V, E)
+    out = DeviceArray.empty((3,), np.float32)
+    f4 = out.dtype.itemsize
+    _lib.call("fx3d_mesh_losses", verts.ptr, V, m.dev("lap_rowptr").ptr, m.dev("lap_colind").ptr, m.dev("lap_vals").ptr,
+              edges.ptr, E, float(target_length), float(w_lap), float(w_edge), base.ptr if base is not None else None,
+              out.ptr, out.ptr + f4, out.ptr + 2 * f4, ws.ptr, ws.nbytes, current_stream().handle)
+    if sync:
+        h = out.to_host()
+        return np.float32(h[0]), np.float32(h[1]), np.float32(h[2])
+    return out.slab(0, 1), out.slab(1, 1), out.slab(2, 1)
+
+
+def mesh_losses_grad(m, target_length=0.0, g_lap=0.1, g_edge=1.0, out=None, reuse_forward=False):
+    """``g_lap * d laplacian_loss/dv + g_edge * d edge_loss/dv`` w.r.t. the packed verts, device (3, sumV), in ONE gather
+    launch without float atomics (bit-reproducible; bit-identical to the oracle's adjoints).  ``out``: add to this array.
+    ``reuse_forward``: :func:`mesh_losses` ran on this very mesh object since its vertices were set."""
+    verts = m.dev("verts_packed")
+    V = verts.shape[1]
+    E = m.dev("edges").shape[0]
+    ws = _mesh_fused_ws(m, V, E)
+    g = DeviceArray.empty((3, V), np.float32) if out is None else out
+    _lib.call("fx3d_mesh_losses_bwd", verts.ptr, V, m.dev("lap_rowptr").ptr, m.dev("lap_colind").ptr, m.dev("lap_vals").ptr,
+              E, float(target_length), float(g_lap), float(g_edge), int(bool(reuse_forward)), g.ptr, int(out is not None),
+              ws.ptr, ws.nbytes, current_stream().handle)
+    return g

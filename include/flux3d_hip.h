@@ -281,6 +281,26 @@ FX3D_API fx3d_status fx3d_laplacian_loss_bwd(const float *verts, int64_t V, cons
                                              const int32_t *colind, const float *vals, float gout,
                                              float *gverts, int32_t accumulate, fx3d_stream_t s);
 
+/* Both mesh losses in ONE launch and both adjoints in ONE gather launch -- the regularisers of the fit_mesh objective
+ * (examples/fit_mesh.jl:80-83), launch bound at teapot scale.  rowptr/colind/vals: the Laplacian CSR of the SAME edge
+ * list `edges` (E,2) (both are per-mesh caches of the reference, src/rep/mesh.jl:907-1002).
+ * Forward: loss_lap_dev / loss_edge_dev (optional) receive laplacian_loss(m) / edge_loss(m, target); total_dev (optional)
+ * receives ((*base_dev or 0) + w_lap*lap) + w_edge*edge in Float32, unfused -- the tutorial's sum in its order.  The
+ * workspace keeps the Laplacian's unit rows for the adjoint.
+ * Adjoint: gverts (3,V) = g_lap * d laplacian_loss/dv + g_edge * d edge_loss/dv (added to gverts when accumulate != 0),
+ * gathered per vertex in the order of the reference's row-by-row / edge-by-edge accumulation: no float atomics, results
+ * bit-identical run to run and to the CPU restatement.  reuse_forward != 0: fx3d_mesh_losses ran on the same vertices
+ * with the same workspace since they last changed (its unit rows are reused); 0: they are rebuilt first. */
+FX3D_API fx3d_status fx3d_mesh_losses_workspace_bytes(int64_t V, int64_t E, size_t *bytes);
+FX3D_API fx3d_status fx3d_mesh_losses(const float *verts, int64_t V, const int32_t *rowptr, const int32_t *colind,
+                                      const float *vals, const int32_t *edges, int64_t E, float target, float w_lap,
+                                      float w_edge, const float *base_dev, float *loss_lap_dev, float *loss_edge_dev,
+                                      float *total_dev, void *ws, size_t ws_bytes, fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_mesh_losses_bwd(const float *verts, int64_t V, const int32_t *rowptr, const int32_t *colind,
+                                          const float *vals, int64_t E, float target, float g_lap, float g_edge,
+                                          int32_t reuse_forward, float *gverts, int32_t accumulate, void *ws,
+                                          size_t ws_bytes, fx3d_stream_t s);
+
 /* ---- pointcloud_to_voxel (src/conversions.jl:91-131) ------------------------------------------------
  * points (3,N,B) -> voxels (res,res,res,B) Float32 0/1: voxel set iff the nearest cloud point of its
  * lattice centre lies within sqrt(0.6)/res after normalising the cloud by its scalar min/max; Float64

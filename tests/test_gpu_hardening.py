@@ -360,3 +360,65 @@ def test_pool_is_stream_ordered(gpu_fx):
         c = fx.DeviceArray.empty((1 << 20,), np.float32)   # same stream: immediate, stream-ordered reuse is fine
         assert c.ptr == ptr_a or b.ptr == ptr_a
     sa.synchronize(); sb.synchronize()
+
+
+# ------------------------------------------------------------------------------ fused mesh losses (one launch each way)
+def _mesh_batch(fx, seed):
+    t, s = os.path.join(GOLDEN, "teapot.obj"), os.path.join(GOLDEN, "sphere.obj")
+    tv, tf = fx.load_obj(t)
+    sv, sf = fx.load_obj(s)
+    rng = np.random.default_rng(seed)
+    vs = [np.asfortranarray(tv + rng.standard_normal(tv.shape).astype(np.float32) * np.float32(0.02)),
+          np.asfortranarray(sv * np.float32(1.3)), np.asfortranarray(tv * np.float32(0.5))]
+    return fx.gpu(fx.TriMesh(vs, [tf, sf, tf]))
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fused_mesh_losses_and_gather_adjoint_are_bit_identical_to_the_oracle(gpu_fx, oracle, seed):
+    """laplacian_loss + edge_loss in ONE launch; both adjoints in ONE gather launch without float atomics.
+    The losses equal the single-loss kernels bit for bit; the gradient equals the oracle's two scatter adjoints (rows / sorted
+    edges in order) added in Float32 -- bit for bit, and run to run."""
+    fx = gpu_fx
+    m = _mesh_batch(fx, seed)
+    v = m.get_verts_packed_host()
+    e0 = m.get_edges_packed().astype(np.int64) - 1
+    rp, ci, va = m.get_laplacian_packed()
+    rp64, ci64 = rp.astype(np.int64), ci.astype(np.int64)
+    tgt = 0.03
+    lap, edge, total = fx.mesh_losses(m, tgt, w_lap=0.1, w_edge=1.0)
+    assert lap == fx.laplacian_loss(m) and edge == fx.edge_loss(m, tgt)
+    assert np.isclose(lap, oracle.laplacian_loss(v, rp64, ci64, va), rtol=1e-6)
+    assert np.isclose(edge, oracle.edge_loss(v, e0, tgt), rtol=1e-6)
+    assert total == np.float32(np.float32(np.float32(0.1) * lap) + edge)
+    base = fx.DeviceArray.from_host(np.array([0.25], np.float32))
+    _, _, tot_dev = fx.mesh_losses(m, tgt, w_lap=0.1, w_edge=1.0, base=base, sync=False)
+    assert np.float32(tot_dev.item()) == np.float32(np.float32(np.float32(0.25) + np.float32(0.1) * lap) + edge)
+    # adjoint: with and without the forward's unit rows, overwrite and accumulate
+    g_lap, g_edge = 0.1, 1.0
+    ol = oracle.laplacian_loss_bwd(v, rp64, ci64, va, g_lap)
+    oe = oracle.edge_loss_bwd(v, e0, tgt, g_edge)
+    ref = (ol + oe).astype(np.float32)
+    g1 = fx.mesh_losses_grad(m, tgt, g_lap, g_edge, reuse_forward=True).to_host()
+    g2 = fx.mesh_losses_grad(m, tgt, g_lap, g_edge, reuse_forward=False).to_host()
+    assert np.array_equal(g1, ref) and np.array_equal(g2, ref)
+    prev = np.asfortranarray(np.random.default_rng(5).standard_normal(v.shape).astype(np.float32))
+    acc = fx.DeviceArray.from_host(prev)
+    fx.mesh_losses_grad(m, tgt, g_lap, g_edge, out=acc)
+    assert np.array_equal(acc.to_host(), ((prev + ol).astype(np.float32) + oe).astype(np.float32))
+    # the scatter kernels agree to rounding (their atomics' order is not fixed)
+    gs = fx.laplacian_loss_grad(m, g_lap).to_host() + fx.edge_loss_grad(m, tgt, g_edge).to_host()
+    assert np.allclose(gs, ref, rtol=1e-4, atol=1e-7)
+
+
+def test_fused_mesh_losses_degenerate_mesh(gpu_fx, oracle):
+    """Coincident vertices (zero-length edges, zero Laplacian rows): the `nrm > 0` guards of both adjoints."""
+    fx = gpu_fx
+    v = np.asfortranarray(np.array([[0, 0, 0], [1, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 0]], np.float32).T)
+    f = np.asfortranarray(np.array([[1, 2, 4], [2, 3, 4], [1, 4, 5]], np.int64).T)
+    m = fx.gpu(fx.TriMesh([v], [f]))
+    e0 = m.get_edges_packed().astype(np.int64) - 1
+    rp, ci, va = m.get_laplacian_packed()
+    ref = (oracle.laplacian_loss_bwd(v, rp.astype(np.int64), ci.astype(np.int64), va, 1.0) + oracle.edge_loss_bwd(v, e0, 0.0, 1.0)).astype(np.float32)
+    assert np.array_equal(fx.mesh_losses_grad(m, 0.0, 1.0, 1.0).to_host(), ref)
+    lap, edge, _ = fx.mesh_losses(m)
+    assert lap == fx.laplacian_loss(m) and edge == fx.edge_loss(m)
