@@ -1072,12 +1072,15 @@ void partial_layout(const Plan &pl, int N, int M, int D, int *tiles, int *tx, in
 // their stream) are its only users, and no eager launch 1024 k launches later can share the counter.
 namespace fx3d {
 static constexpr int kTickets = 1024;      // eager, round robin
-static constexpr int kCapChunk = 4096;     // capture-owned slots per allocation (grows chunk by chunk)
+static constexpr int kCapChunk = 4096;     // capture-owned slots per allocation
 unsigned int *ticket_slot(fx3d_status *rc, hipStream_t st) {
     static std::mutex mu;
     static std::atomic<unsigned int *> pools[64];
-    static unsigned int *cap_chunk[64] = {nullptr};
-    static int cap_used[64] = {0};
+    // capture-owned slots: the chunk in use and a spare.  Allocation + zeroing are not legal while a stream captures
+    // (hipMemset synchronises), so both happen on EAGER calls: the first call of the process sets up the chunk, an
+    // eager call that sees it more than half used sets up the spare.  Chunks are never freed: graphs hold their addresses.
+    static unsigned int *cap_chunk[64] = {nullptr}, *cap_spare[64] = {nullptr};
+    static std::atomic<int> cap_used[64];
     static std::atomic<unsigned int> next{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { *rc = FX3D_ERR_HIP; return nullptr; }
@@ -1094,22 +1097,35 @@ unsigned int *ticket_slot(fx3d_status *rc, hipStream_t st) {
     };
     if (cs == hipStreamCaptureStatusActive) {
         std::lock_guard<std::mutex> lk(mu);
-        if (!cap_chunk[dev] || cap_used[dev] == kCapChunk) {  // (earlier chunks stay alive: graphs hold their addresses)
-            unsigned int *c = fresh(kCapChunk);
-            if (!c) return nullptr;
-            cap_chunk[dev] = c;
-            cap_used[dev] = 0;
+        if (cap_chunk[dev] && cap_used[dev].load() == kCapChunk && cap_spare[dev]) {
+            cap_chunk[dev] = cap_spare[dev];
+            cap_spare[dev] = nullptr;
+            cap_used[dev].store(0);
         }
-        return cap_chunk[dev] + cap_used[dev]++;
+        if (!cap_chunk[dev] || cap_used[dev].load() == kCapChunk) {
+            set_error("no capture-owned arrival counter left: run the captured sequence once eagerly before capturing "
+                      "(the library sets its counters up on eager calls)");
+            *rc = FX3D_ERR_HIP;
+            return nullptr;
+        }
+        return cap_chunk[dev] + cap_used[dev].fetch_add(1);
     }
     unsigned int *pool = pools[dev].load(std::memory_order_acquire);
-    if (!pool) {
+    if (!pool || !cap_chunk[dev] || (cap_used[dev].load() > kCapChunk / 2 && !cap_spare[dev])) {
         std::lock_guard<std::mutex> lk(mu);
         pool = pools[dev].load(std::memory_order_relaxed);
         if (!pool) {
             pool = fresh(kTickets);
             if (!pool) return nullptr;
             pools[dev].store(pool, std::memory_order_release);
+        }
+        if (!cap_chunk[dev]) {
+            cap_chunk[dev] = fresh(kCapChunk);
+            if (!cap_chunk[dev]) return nullptr;
+            cap_used[dev].store(0);
+        } else if (cap_used[dev].load() > kCapChunk / 2 && !cap_spare[dev]) {
+            cap_spare[dev] = fresh(kCapChunk);
+            if (!cap_spare[dev]) return nullptr;
         }
     }
     return pool + (next.fetch_add(1) % kTickets);

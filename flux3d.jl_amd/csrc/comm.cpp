@@ -329,6 +329,9 @@ fx3d_status fx3d_chamfer_fwd_sharded_async(fx3d_comm_t comm, const float *x, int
     FX3D_REQUIRE(B_global >= B_local && B_local >= 0, "fx3d_chamfer_fwd_sharded_async: bad batch sizes");
     FX3D_REQUIRE(comm_stream && comm_stream != s, "fx3d_chamfer_fwd_sharded_async: the collective needs a created stream of its own");
     fx3d_status rc;
+    // slot reuse: the kernel below overwrites sums_dev, which the slot's previous collective (marked by `done`) may
+    // still be reading on comm_stream.  Waiting on an event that was never recorded is a no-op.
+    FX3D_HIP(hipStreamWaitEvent(as_stream(s), reinterpret_cast<hipEvent_t>(done), 0));
     if (B_local > 0) {
         rc = fx3d_chamfer_sums(x, N, y, M, B_local, D, sums_dev, nullptr, nullptr, ws, ws_bytes, s);
         if (rc) return rc;

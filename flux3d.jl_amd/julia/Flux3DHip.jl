@@ -645,7 +645,6 @@ function chamfer_distance_sharded_async(comm, A::HipArray{Float32,3}, B::HipArra
     nb = Ref{Csize_t}(0)
     check(@ccall LIB.fx3d_chamfer_workspace_bytes(N::Int32, M::Int32, max(Bl, 1)::Int32, D::Int32, nb::Ref{Csize_t})::Int32)
     ws = workspace(nb[])
-    check(@ccall LIB.fx3d_stream_wait_event(stream::Stream, slot.done::Event)::Int32)   # the slot's previous use
     check(@ccall LIB.fx3d_chamfer_fwd_sharded_async(comm::Ptr{Cvoid}, A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32,
                                                     Bl::Int32, D::Int32, B_global::Int64, Float32(w1)::Float32,
                                                     Float32(w2)::Float32, slot.sums.ptr::Ptr{Cvoid}, slot.loss_dev.ptr::Ptr{Cvoid},
@@ -725,6 +724,7 @@ end
 event_destroy(e::Event) = check(@ccall LIB.fx3d_event_destroy(e::Event)::Int32)
 event_record(e::Event, s::Stream = DEFAULT_STREAM) = check(@ccall LIB.fx3d_event_record(e::Event, s::Stream)::Int32)
 event_synchronize(e::Event) = check(@ccall LIB.fx3d_event_sync(e::Event)::Int32)
+stream_wait_event(s::Stream, e::Event) = check(@ccall LIB.fx3d_stream_wait_event(s::Stream, e::Event)::Int32)  # device-side ordering
 function event_elapsed_ms(a::Event, b::Event)
     ms = Ref{Float32}(0); check(@ccall LIB.fx3d_event_elapsed_ms(a::Event, b::Event, ms::Ref{Float32})::Int32); return ms[]
 end

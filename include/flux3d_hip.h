@@ -345,7 +345,7 @@ FX3D_API fx3d_status fx3d_chamfer_fwd_sharded(fx3d_comm_t comm, const float *x, 
 /* The same with the collective off the compute stream: kernel on `s`, all-reduce + finalise on `comm_stream` behind
  * the event `ready` (recorded on s), `done` (recorded on comm_stream) marks the loss.  No host wait: the next
  * evaluation's kernel on `s` overlaps this one's collective.  The caller rotates (sums_dev, loss_dev, ready, done) over
- * a few slots and calls fx3d_stream_wait_event(s, done) before a slot is reused. */
+ * a few slots; the call itself makes `s` wait for the slot's previous `done` before the kernel overwrites sums_dev. */
 FX3D_API fx3d_status fx3d_chamfer_fwd_sharded_async(fx3d_comm_t comm, const float *x, int32_t N, const float *y,
                                                     int32_t M, int32_t B_local, int32_t D, int64_t B_global,
                                                     float w1, float w2, double *sums_dev, float *loss_dev,

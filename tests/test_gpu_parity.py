@@ -245,8 +245,8 @@ def test_invalid_arguments_raise(gpu_fx):
     fx.knn(x, 10)  # k == M is fine without drop_first
     with pytest.raises(fx.Flux3DHipError):
         fx.knn(x, 10, drop_first=True)  # k+1 > M
-    with pytest.raises(fx.Flux3DHipError):
-        fx.knn(_rand((3, 100, 1), 0), 64, drop_first=True)  # k+1 > 64 unsupported
+    idx, _ = fx.knn(_rand((3, 100, 1), 0), 64, drop_first=True)  # k+1 > 64: the general selection kernel (round 2)
+    assert idx.shape == (64, 100, 1)
     from flux3d_jl_amd import _lib
     import ctypes
     d = fx.gpu(x)
