@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""profiles/pmc_latest.json from the JSON tail of a tools/rocprof_summary.py `pmc` report (tools/profile_round.sh writes
+gpurun_out/<tag>/pmc.txt), stamped with the hash of the kernel sources so that bench.py can tell whether the counters
+belong to the library it is timing.   usage: make_pmc_latest.py gpurun_out/<tag>/pmc.txt profiles/<copy of it> """
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash  # noqa: E402
+
+
+def main():
+    src, kept_as = sys.argv[1], sys.argv[2]
+    txt = open(src).read()
+    data = json.loads(txt[txt.index("# json") + len("# json"):].strip().splitlines()[0])
+    name = [k for k in data if "nn1_f16_kernel<false>" in k or ("nn1_f16_kernel" in k and "ILb0" in k)]
+    k = data[name[0]]
+    fetch_kb, write_kb = k["FETCH_SIZE"]["avg"], k["WRITE_SIZE"]["avg"]
+    out = {
+        "source": f"{kept_as} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_*, separate passes of tools/pmc_driver.py nn1; tools/profile_round.sh)",
+        "kernel": "nn1_f16_kernel<false>",
+        "kernel_source_sha16": kernel_source_hash(),
+        "FETCH_SIZE_KB_raw_avg": fetch_kb, "WRITE_SIZE_KB_raw_avg": write_kb,
+        "correction": "gfx950 FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md HBM section): read side doubled; WRITE_SIZE uncorrected",
+        "nn1_hbm_bytes_per_launch": int(round(2 * fetch_kb * 1024 + write_kb * 1024)),
+        "algorithmic_bytes_per_launch": 4 * 3 * 32 * 8192 + 8 * 2 * 32 * 8,
+    }
+    for c in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES",
+              "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY"):
+        if c in k:
+            out[c] = k[c]["avg"]
+    with open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
