@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras"   # only the headline launches in the trace
 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o r -- $BENCH > "$OUT/bench_under_rocprof.log" 2>&1
 python "$ROOT/tools/rocprof_summary.py" stats "$OUT/kt/r_results.db" > "$OUT/kernel_trace_stats.txt" 2>&1
 rocprofv3 --kernel-trace --stats -d "$OUT/kt_ops" -o r -- python "$ROOT/tools/bench_ops.py" > "$OUT/ops_under_rocprof.jsonl" 2> "$OUT/ops_under_rocprof.err"
