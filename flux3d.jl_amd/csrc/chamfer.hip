@@ -301,12 +301,12 @@ constexpr int kHItemCap = 64 * kHFifo;      // the FIFO path never overflows the
 constexpr int kHGrid = 8;                   // sort grid: 8^3 cells over the cloud's bounding box, in Morton order
 constexpr int kHCells = kHGrid * kHGrid * kHGrid;
 static_assert(kHFifo <= 4 && kHMaxBlk < 255, "FIFO block ids are packed one byte each");
-// LDS behind the image: per wave 32 result slots (8 B), the item list (2 B each; the sort's 512 cell counters alias it)
-// and the query table (32 x 3 floats); one bounding box (6 floats) per 32-candidate block; per query of the block its
-// place in the sorted order (2 B) and its result for the fixed-order sum (4 B).
+// LDS behind the image: per wave 32 result slots (8 B), the item list (2 B each; the sort's 2 x 512 cell counters alias
+// it) and the query table (32 x 3 floats); one bounding box (6 floats) per 32-candidate block; per query of the block
+// the query behind its place in the sorted order (2 B).
 constexpr size_t kHFixedBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 2 + 32 * 3 * 4) + kHMaxBlk * 6 * 4;
-static_assert((kHThreads / 64) * kHItemCap * 2 >= kHCells * 4, "the cell counters alias the item lists");
-constexpr size_t nn1_f16_lds_bytes(int chunk, int tpb) { return (size_t)chunk * 32 + kHFixedBytes + (size_t)tpb * 512 * 6; }
+static_assert((kHThreads / 64) * kHItemCap * 2 >= 2 * kHCells * 4, "the cell counters alias the item lists");
+constexpr size_t nn1_f16_lds_bytes(int chunk, int tpb) { return (size_t)chunk * 32 + kHFixedBytes + (size_t)tpb * 512 * 2; }
 constexpr size_t kHLdsLimit = 160 * 1024 - 1280;  // the CU's LDS minus the kernel's static arrays
 
 // plain v_min_f32 (fminf() also emits a canonicalising v_max in IEEE mode; the filter values are never
@@ -352,6 +352,13 @@ __device__ __forceinline__ void make_pieces(float cx, float cy, float cz, unsign
     p1 = h8{lz, n1, n2, n3, lx, ly, lz, __builtin_bit_cast(_Float16, (unsigned short)tag)};
 }
 
+// a wave-uniform 64-bit value, stated as such (keeps block masks and the ids popped from them in scalar registers)
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // Morton code of a cell (3 bits per axis) -- consecutive cells are spatial neighbours, so 32 consecutive sorted
 // candidates (one MFMA block) occupy a compact box
 __device__ __forceinline__ int morton_cell(float x, float y, float z, const float (&lo)[3], const float (&inv)[3]) {
@@ -362,10 +369,13 @@ __device__ __forceinline__ int morton_cell(float x, float y, float z, const floa
     return spread(ix) | (spread(iy) << 1) | (spread(iz) << 2);
 }
 
-// exclusive scan of the kHCells counters in place (threads 0 .. kHCells-1 hold one counter each); two barriers
-__device__ __forceinline__ void scan_cells(unsigned int *hist, int *wave_tot, int tid, int lane, int wv) {
+// exclusive scan of TWO sets of kHCells counters in place: threads [0, kHCells) own set 0, [kHCells, 2 kHCells) set 1
+// (candidates and queries are counted in one phase); two barriers.  only1: leave set 0 alone (it already holds cursors).
+__device__ __forceinline__ void scan_cells2(unsigned int *hist, int *wave_tot, int tid, int lane, int wv, bool only1 = false) {
     unsigned int v = 0, incl = 0;
-    if (tid < kHCells) {
+    constexpr int WPS = kHCells / 64;  // waves per set
+    const bool mine = tid < 2 * kHCells && !(only1 && tid < kHCells);
+    if (mine) {
         v = hist[tid];
         incl = v;
 #pragma unroll
@@ -376,30 +386,62 @@ __device__ __forceinline__ void scan_cells(unsigned int *hist, int *wave_tot, in
         if (lane == 63) wave_tot[wv] = (int)incl;
     }
     __syncthreads();
-    if (tid < kHCells) {
+    if (mine) {
         unsigned int off = 0;
-        for (int w = 0; w < wv; ++w) off += (unsigned int)wave_tot[w];
+        for (int w = (wv / WPS) * WPS; w < wv; ++w) off += (unsigned int)wave_tot[w];
         hist[tid] = off + incl - v;
     }
     __syncthreads();
 }
 
+// Order-independent sum of the block's nearest squared distances: a fixed-point accumulator wide enough for any
+// Float32 (limbs of 32 bits at weights 2^(32 L - 149), 64-bit containers: 2^32 addends never overflow one).  Integer
+// additions commute, so the block's partial sum -- and with it the loss -- does not depend on the order in which the
+// sorted queries happen to be processed; its value is the EXACT sum, rounded once when it is read out.
+constexpr int kHLimbs = 10;
+__device__ __forceinline__ void exact_add(unsigned long long *limbs, int *flags, float d) {
+    const unsigned int bits = __builtin_bit_cast(unsigned int, d);
+    const unsigned int e = (bits >> 23) & 0xffu;
+    if (e == 0xffu) { atomicOr(flags, (bits & 0x7fffffu) ? 2 : 1); return; }  // +Inf / NaN: carried as flags
+    const unsigned long long mant = (unsigned long long)((bits & 0x7fffffu) | (e ? 0x800000u : 0u));
+    const unsigned int sh = (e ? e : 1u) - 1u;  // value = mant 2^(sh - 149)
+    const unsigned long long v = mant << (sh & 31u);
+    const unsigned int L = sh >> 5;
+    if (mant) {
+        atomicAdd(&limbs[L], v & 0xffffffffull);
+        if (v >> 32) atomicAdd(&limbs[L + 1], v >> 32);
+    }
+}
+__device__ __forceinline__ double exact_read(const unsigned long long *limbs, int flags) {
+    if (flags & 2) return __builtin_nan("");
+    if (flags & 1) return INFINITY;
+    double s = 0.0;
+    for (int L = kHLimbs - 1; L >= 0; --L) s += ldexp((double)limbs[L], 32 * L - 149);
+    return s;
+}
+
 // nn1_f16_kernel, round 2: the candidates of a chunk are SORTED by Morton cell while the image is staged (counting sort
 // in LDS: histogram, scan, scatter; the order inside a cell is whatever the atomics give -- results do not depend on it),
-// the block's queries likewise, and every 32-candidate block carries its bounding box.  A wave (32 sorted, hence
-// neighbouring, queries) then evaluates only the blocks whose box can hold a nearest neighbour:
+// and every 32-candidate block carries its bounding box.  The queries of a (cloud, direction) are split over its blocks
+// BY CELL RANGE (every block counts all of them: the ranges are a deterministic function of the counts), so a block owns
+// a compact region, and its queries are sorted the same way.  A wave (32 sorted, hence neighbouring, queries) evaluates
+// only the candidate blocks whose box can hold a nearest neighbour:
 //   1. blocks overlapping the wave's query box (or the nearest one); from their filter minima an upper bound of every
 //      query's nearest distance: d~^2 <= Umin + (1 + beta)|q~|^2 + floor (error model above);
 //   2. the other blocks whose box lies within the largest of those bounds.
 // A skipped block has every candidate STRICTLY farther (margins for the roundings of the boxes, of the bound and of the
 // oracle's own Float32 distance), so neither the nearest neighbour nor a candidate tied with it is lost: results stay
-// bit-identical to the oracle.  Uniform clouds visit ~1/5 of the tiles; data without locality degrades to every tile.
-// Clustered data, whose members used to sit in every lane tile's band, now sits in a few adjacent blocks.
+// bit-identical to the oracle.  Uniform clouds visit ~1/4 of the tiles; data without locality degrades to every tile;
+// clustered data, whose members used to sit in every lane tile's band, now sits in a few adjacent blocks.
+// Query groups (32 queries) are handed to the waves of a block dynamically: interior groups visit more blocks than
+// groups at the rim of the cloud.
 template <bool WANT_IDX>
 __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float red[3 * 4 * (kHThreads / 64)];  // per wave: min, max, sum (padded to 4 dims)
-    __shared__ int wave_tot[kHCells / 64];
+    __shared__ int wave_tot[kHThreads / 64];
+    __shared__ unsigned long long sacc[kHLimbs];
+    __shared__ int sflags, grp_ctr, part[4];  // part: first cell / end cell / first rank / number of queries of this block
     constexpr int QB = (kHThreads / 64) * 32;  // queries per tile pass
 
     const int L = blockIdx.x;
@@ -416,7 +458,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     const int b = dir ? c - p.B : c;
     const int NQ = dir ? p.M : p.N;
     const int NC = dir ? p.N : p.M;
-    if (tile >= (dir ? p.tiles_y : p.tiles_x)) return;
+    const int T = dir ? p.tiles_y : p.tiles_x;  // blocks sharing this direction's queries (per chunk subset)
+    if (tile >= T) return;
     if ((long long)split * p.chunk >= NC) return;  // this direction has fewer chunks than splits
     const float *__restrict__ qb = (dir ? p.y : p.x) + (size_t)b * NQ * 3;
     const float *__restrict__ cb = (dir ? p.x : p.y) + (size_t)b * NC * 3;
@@ -431,13 +474,15 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     unsigned short *witems = reinterpret_cast<unsigned short *>(wres + (kHThreads / 64) * 32);
     float *wq = reinterpret_cast<float *>(witems + (kHThreads / 64) * kHItemCap);
     float *boxes = wq + (kHThreads / 64) * 96;  // [block][lo xyz, hi xyz] in scaled, centred coordinates
-    unsigned short *qperm = reinterpret_cast<unsigned short *>(boxes + kHMaxBlk * 6);  // sorted slot -> query of the block
-    float *dres = reinterpret_cast<float *>(qperm + p.tpb * QB);                       // query of the block -> its result
+    unsigned short *qperm = reinterpret_cast<unsigned short *>(boxes + kHMaxBlk * 6);  // sorted slot -> query
     unsigned int *hist = reinterpret_cast<unsigned int *>(witems);                     // staging only (aliases the items)
+    unsigned int *qhist = hist + kHCells;
     unsigned long long *qres = wres + wv * 32;
     unsigned short *items = witems + wv * kHItemCap;
     float *qtab = wq + wv * 96;
     const bool vec = (reinterpret_cast<uintptr_t>(cb) & 15) == 0;
+    if (tid < kHLimbs) sacc[tid] = 0ull;
+    if (tid == 0) { sflags = 0; grp_ctr = 0; }
     FX3D_PROBE_MARK(0);
 
     // ---- bounding box and mean -> centre mu = the MEAN (a stray far point moves the box centre, hardly the mean), largest
@@ -507,94 +552,127 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     }
     FX3D_PROBE_MARK(1);
 
-    // ---- the block's queries, sorted by the same Morton cells: a wave's 32 queries are neighbours in space ----------
-    const int q_first = tile * p.tpb * QB;
-    const int nq_blk = (NQ - q_first) < p.tpb * QB ? (NQ - q_first) : p.tpb * QB;
-    {
-        for (int i = tid; i < kHCells; i += kHThreads) hist[i] = 0;
-        __syncthreads();
-        int qcell[4];  // tpb <= 8: at most four queries per thread
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ql = tid + k * kHThreads;
-            qcell[k] = 0;
-            if (ql < nq_blk) {
-                const float *src = qb + (size_t)(q_first + ql) * 3;
-                if (sane) qcell[k] = morton_cell(src[0], src[1], src[2], glo, ginv);  // (clamped: queries may lie outside the box)
-                atomicAdd(&hist[qcell[k]], 1u);
-            }
-        }
-        __syncthreads();
-        scan_cells(hist, wave_tot, tid, lane, wv);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ql = tid + k * kHThreads;
-            if (ql < nq_blk) qperm[atomicAdd(&hist[qcell[k]], 1u)] = (unsigned short)ql;
-        }
-        // (the first barrier of the chunk loop orders qperm before its readers)
-    }
+    // queries of this block: by cell range of the WHOLE direction's queries when that is balanced (spatial), else the index
+    // range [tile * tpb * 512, ...) sorted locally.  Either way `qperm[slot]` names the query of sorted slot `slot`.
+    const int cap = p.tpb * QB;
+    const bool try_spatial = sane && T > 1 && NQ <= 65536;
+    int q_first = tile * cap;                                       // index-range form: qperm holds q - q_first
+    int nq_blk = (NQ - q_first) < cap ? (NQ - q_first) : cap;
+    if (nq_blk < 0) nq_blk = 0;
+    bool spatial = false;
 
     float qr[3], da = 0.0f;  // band: a block qualifies while its minimum <= best * kBandB1 + da
     float qsx = 0.f, qsy = 0.f, qsz = 0.f, qnb = 0.f, qfl = 0.f;  // scaled query, (1 + beta)|q~|^2 and the floor of its bound
-    float wqlo[3] = {0.f, 0.f, 0.f}, wqhi[3] = {0.f, 0.f, 0.f};   // the wave's query box (scaled, centred)
-    int qi = 0, qloc = 0;
+    int qi = 0;
     bool qok = true, qvalid = false;
     h8 bq;
 
     const int jfirst = split * CH, jstep = p.nsplit * CH;
+    const bool single_chunk = jfirst + jstep >= NC;  // one chunk per block: query groups go to whichever wave is free
     for (int j0 = jfirst; j0 < NC; j0 += jstep) {
         const int cnt = (NC - j0) < CH ? (NC - j0) : CH;
         const int cnt_pad = (cnt + 31) / 32 * 32;
         const int nblk = cnt_pad / 32;
+        const bool first = j0 == jfirst;
         __syncthreads();
-        // ---- counting sort of the chunk by Morton cell, fp16 split image written at the sorted positions -------------
-        for (int i = tid; i < kHCells; i += kHThreads) hist[i] = 0;
+        // ---- counting sort of the chunk (and, the first time, of the queries) by Morton cell ---------------------------
+        for (int i = tid; i < 2 * kHCells; i += kHThreads) hist[i] = 0;
         __syncthreads();
         const bool have_regs = vec && NC <= CH && tid < nv;  // the four points loaded for the bounding box
         int cell[4];
-        {
-            const int p0 = 4 * tid;
-            if (!have_regs) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int pt = p0 + e < cnt ? p0 + e : cnt - 1;
-                    const float *src = cb + (size_t)(j0 + pt) * 3;
-                    ax[e] = src[0]; ay[e] = src[1]; az[e] = src[2];
-                }
-            }
+        const int p0 = 4 * tid;
+        if (!have_regs) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                cell[e] = 0;
-                if (p0 + e < cnt) {
-                    if (sane) cell[e] = morton_cell(ax[e], ay[e], az[e], glo, ginv);
-                    atomicAdd(&hist[cell[e]], 1u);
-                }
+                const int pt = p0 + e < cnt ? p0 + e : cnt - 1;
+                const float *src = cb + (size_t)(j0 + pt) * 3;
+                ax[e] = src[0]; ay[e] = src[1]; az[e] = src[2];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cell[e] = 0;
+            if (p0 + e < cnt) {
+                if (sane) cell[e] = morton_cell(ax[e], ay[e], az[e], glo, ginv);
+                atomicAdd(&hist[cell[e]], 1u);
+            }
+        }
+        if (first) {  // query counts: all NQ (spatial) or this block's index range
+            const int n = try_spatial ? NQ : nq_blk, base = try_spatial ? 0 : q_first;
+            for (int ql = tid; ql < n; ql += kHThreads) {
+                const float *src = qb + (size_t)(base + ql) * 3;
+                const int qc = sane ? morton_cell(src[0], src[1], src[2], glo, ginv) : 0;  // (clamped: queries may lie outside the box)
+                atomicAdd(&qhist[qc], 1u);
             }
         }
         __syncthreads();
-        scan_cells(hist, wave_tot, tid, lane, wv);
-        {
-            const int p0 = 4 * tid;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (p0 + e < cnt) {
-                    const int pos = (int)atomicAdd(&hist[cell[e]], 1u);
-                    h8 q0, q1;
-                    make_pieces((ax[e] - mu[0]) * sc, (ay[e] - mu[1]) * sc, (az[e] - mu[2]) * sc, (unsigned int)(p0 + e), q0, q1);
-                    const int i0 = ((pos >> 5) * 2) * 32 + (pos & 31);
-                    imgp[i0] = q0;
-                    imgp[i0 + 32] = q1;
+        scan_cells2(hist, wave_tot, tid, lane, wv);
+        if (first && try_spatial) {
+            // cell ranges: block t owns the cells whose first rank lies in [t, t + 1) * ceil(NQ / T); the ranges depend on the
+            // counts alone, so every block of this direction derives the same split.  Used if no block gets more than `cap`.
+            const int target = (NQ + T - 1) / T;
+            auto first_cell = [&](int rank) {  // smallest cell whose exclusive offset is >= rank (kHCells if none)
+                int lo = 0, hi = kHCells;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)qhist[mid] >= rank) hi = mid; else lo = mid + 1; }
+                return lo;
+            };
+            int over = 0;
+            for (int t = tid; t < T; t += kHThreads) {
+                const int c0 = t == 0 ? 0 : first_cell(t * target), c1 = t == T - 1 ? kHCells : first_cell((t + 1) * target);
+                const int r0 = c0 < kHCells ? (int)qhist[c0] : NQ, r1 = c1 < kHCells ? (int)qhist[c1] : NQ;
+                over |= (r1 - r0 > cap) ? 1 : 0;
+                if (t == tile) { part[0] = c0; part[1] = c1; part[2] = r0; part[3] = r1 - r0; }
+            }
+            spatial = __syncthreads_or(over) == 0;
+            if (spatial) { q_first = 0; nq_blk = part[3]; }
+        }
+        if (first) {
+            if (spatial) {
+                const int c0 = part[0], c1 = part[1], r0 = part[2];
+                for (int ql = tid; ql < NQ; ql += kHThreads) {
+                    const float *src = qb + (size_t)ql * 3;
+                    const int qc = morton_cell(src[0], src[1], src[2], glo, ginv);
+                    if (qc >= c0 && qc < c1) qperm[(int)atomicAdd(&qhist[qc], 1u) - r0] = (unsigned short)ql;
+                }
+            } else {
+                if (try_spatial) {  // unbalanced: recount this block's index range (rare)
+                    __syncthreads();
+                    for (int i = tid; i < kHCells; i += kHThreads) qhist[i] = 0;
+                    __syncthreads();
+                    for (int ql = tid; ql < nq_blk; ql += kHThreads) {
+                        const float *src = qb + (size_t)(q_first + ql) * 3;
+                        atomicAdd(&qhist[morton_cell(src[0], src[1], src[2], glo, ginv)], 1u);
+                    }
+                    __syncthreads();
+                    scan_cells2(hist, wave_tot, tid, lane, wv, true);  // (the candidates' cursors stay as they are)
+                }
+                for (int ql = tid; ql < nq_blk; ql += kHThreads) {
+                    const float *src = qb + (size_t)(q_first + ql) * 3;
+                    const int qc = sane ? morton_cell(src[0], src[1], src[2], glo, ginv) : 0;
+                    qperm[atomicAdd(&qhist[qc], 1u)] = (unsigned short)ql;
                 }
             }
-            if (tid < cnt_pad - cnt) {  // padding rows: n1 = +inf => t = +inf, never within any band; tag = cnt: not a candidate
-                const int pos = cnt + tid;
+        }
+        // ---- fp16 split image at the sorted positions ----------------------------------------------------------------
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (p0 + e < cnt) {
+                const int pos = (int)atomicAdd(&hist[cell[e]], 1u);
                 h8 q0, q1;
-                make_pieces(0.f, 0.f, 0.f, (unsigned int)cnt, q0, q1);
-                q1[1] = (_Float16)INFINITY;
+                make_pieces((ax[e] - mu[0]) * sc, (ay[e] - mu[1]) * sc, (az[e] - mu[2]) * sc, (unsigned int)(p0 + e), q0, q1);
                 const int i0 = ((pos >> 5) * 2) * 32 + (pos & 31);
                 imgp[i0] = q0;
                 imgp[i0 + 32] = q1;
             }
+        }
+        if (tid < cnt_pad - cnt) {  // padding rows: n1 = +inf => t = +inf, never within any band; tag = cnt: not a candidate
+            const int pos = cnt + tid;
+            h8 q0, q1;
+            make_pieces(0.f, 0.f, 0.f, (unsigned int)cnt, q0, q1);
+            q1[1] = (_Float16)INFINITY;
+            const int i0 = ((pos >> 5) * 2) * 32 + (pos & 31);
+            imgp[i0] = q0;
+            imgp[i0 + 32] = q1;
         }
         __syncthreads();
         // ---- bounding box of every 32-candidate block (eight threads per block, four rows each) ----------------------
@@ -624,15 +702,22 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             }
         }
         __syncthreads();
-        FX3D_PROBE_MARK(j0 == jfirst ? 2 : 6);
+        FX3D_PROBE_MARK(first ? 2 : 6);
 
-        for (int tp = 0; tp < p.tpb; ++tp) {
-            if (tp * QB >= nq_blk) break;  // uniform
-            if (j0 == jfirst) {
-                const int qs = tp * QB + wv * 32 + jq;   // slot in the sorted order
+        const int ngroups = (nq_blk + 31) / 32;
+        auto next_group = [&]() -> int {
+            int g = 0;
+            if (lane == 0) g = atomicAdd(&grp_ctr, 1);
+            return __builtin_amdgcn_readfirstlane(g);
+        };
+        // a block that walks several chunks keeps the group of a wave fixed (its result slots persist across the chunks)
+        int g = single_chunk ? next_group() : wv;
+        bool first_group = true;
+        while (g < ngroups) {
+            if (first) {
+                const int qs = g * 32 + jq;   // slot in the sorted order
                 qvalid = qs < nq_blk;
-                qloc = qperm[qvalid ? qs : nq_blk - 1];
-                qi = q_first + qloc;
+                qi = q_first + qperm[qvalid ? qs : nq_blk - 1];
 #pragma unroll
                 for (int d = 0; d < 3; ++d) qr[d] = qb[(size_t)qi * 3 + d];
                 qsx = (qr[0] - mu[0]) * sc; qsy = (qr[1] - mu[1]) * sc; qsz = (qr[2] - mu[2]) * sc;
@@ -647,14 +732,11 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 split2h(qok ? m0 : 0.f, hx, lx); split2h(qok ? m1 : 0.f, hy, ly); split2h(qok ? m2 : 0.f, hz, lz);
                 const _Float16 one = (_Float16)1.0f, z = (_Float16)0.0f;
                 bq = hh == 0 ? h8{hx, lx, hx, hy, ly, hy, hz, lz} : h8{hz, one, one, one, lx, ly, lz, z};
+                __builtin_amdgcn_wave_barrier();  // (the previous group's result slots have been read)
                 if (hh == 0) {
                     qres[jq] = ~0ull;
                     qtab[jq * 3 + 0] = qr[0]; qtab[jq * 3 + 1] = qr[1]; qtab[jq * 3 + 2] = qr[2];
                 }
-                // the wave's query box (lanes beyond the block's queries repeat its last query)
-                wqlo[0] = wave_min_f(qsx); wqhi[0] = wave_max_f(qsx);
-                wqlo[1] = wave_min_f(qsy); wqhi[1] = wave_max_f(qsy);
-                wqlo[2] = wave_min_f(qsz); wqhi[2] = wave_max_f(qsz);
             }
 
             float best = INFINITY, ft[kHFifo];
@@ -670,6 +752,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             //      (coordinates are < 2^7 with Float32 roundings of 2^-17 and a box built from the 22-bit split pieces: a
             //      margin of 2^-12 per axis covers both boxes; (1 - 2^-20) the squares and their sum)
             float lbv[2];
+            {
+            // the wave's query box (lanes beyond the block's queries repeat its last query)
+            const float wqlo[3] = {wave_min_f(qsx), wave_min_f(qsy), wave_min_f(qsz)};
+            const float wqhi[3] = {wave_max_f(qsx), wave_max_f(qsy), wave_max_f(qsz)};
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int bk = lane + 64 * i;
@@ -678,19 +764,20 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     float s2 = 0.0f;
 #pragma unroll
                     for (int d = 0; d < 3; ++d) {
-                        const float g = fmaxf(boxes[bk * 6 + d] - wqhi[d], wqlo[d] - boxes[bk * 6 + 3 + d]) - 0x1p-12f;
-                        const float gp = fmaxf(g, 0.0f);
+                        const float gg = fmaxf(boxes[bk * 6 + d] - wqhi[d], wqlo[d] - boxes[bk * 6 + 3 + d]) - 0x1p-12f;
+                        const float gp = fmaxf(gg, 0.0f);
                         s2 = s2 + gp * gp;
                     }
                     lbv[i] = s2 - 0x1p-20f * s2;  // (an all-padding block has an empty box: +inf, never visited)
                 }
             }
+            }
             const bool prune = sane && nblk > 2 && __ballot(qvalid && !qok) == 0;  // a query outside the fp16 range has no bound
             unsigned long long todo[2], seen[2] = {0ull, 0ull};
-            todo[0] = __ballot(lane < nblk);
-            todo[1] = __ballot(lane + 64 < nblk);
+            todo[0] = uni64(__ballot(lane < nblk));
+            todo[1] = uni64(__ballot(lane + 64 < nblk));
             float wbound = INFINITY;  // largest upper bound of a nearest distance over the wave's queries (scaled units)
-            if (j0 > jfirst && prune) {  // later chunks: the exact result of the earlier ones bounds the search
+            if (!first && prune) {    // later chunks: the exact result of the earlier ones bounds the search
                 const unsigned int hi = (unsigned int)(qres[jq] >> 32);
                 float ub = INFINITY;
                 if (hi < 0x7f800000u) { const float dprev = __builtin_bit_cast(float, hi) * sc * sc; ub = dprev + 0x1p-19f * dprev; }
@@ -715,37 +802,49 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                         else { mk[0] = todo[0]; mk[1] = todo[1]; }  // (no comparable box: everything)
                     }
                 }
+                mk[0] = uni64(mk[0]); mk[1] = uni64(mk[1]);
                 if ((mk[0] | mk[1]) == 0ull) break;
                 seen[0] |= mk[0]; seen[1] |= mk[1];
-                // ---- filter loop over the selected blocks, software-pipelined by one block ----------------------------
-                auto pop = [&]() -> int {
-                    if (mk[0]) { const int i = __builtin_ctzll(mk[0]); mk[0] &= mk[0] - 1; return i; }
-                    if (mk[1]) { const int i = __builtin_ctzll(mk[1]); mk[1] &= mk[1] - 1; return 64 + i; }
-                    return -1;
-                };
-                int b0 = pop(), b1 = pop();
-                h8 a1 = pa[(b1 >= 0 ? b1 : b0) * 64];
-                f32x16 accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[b0 * 64], bq, zero, 0, 0, 0);
-                while (b0 >= 0) {
-                    const int b2 = b1 >= 0 ? pop() : -1;
-                    const h8 a2 = pa[(b2 >= 0 ? b2 : (b1 >= 0 ? b1 : b0)) * 64];
-                    const f32x16 accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq, zero, 0, 0, 0);  // (idle on the last turn)
-                    // fold 16 values: 8 x v_min3, depth 3
-                    const float t0 = min3f(accC[0], accC[1], accC[2]), t1 = min3f(accC[3], accC[4], accC[5]);
-                    const float t2 = min3f(accC[6], accC[7], accC[8]), t3 = min3f(accC[9], accC[10], accC[11]);
-                    const float t4 = min3f(accC[12], accC[13], accC[14]);
-                    const float t5 = min3f(t0, t1, t2), t6 = min3f(t3, t4, accC[15]);
-                    const float tm = vmin(t5, t6);
-                    const bool qual = tm <= __builtin_fmaf(best, kBandB1, da);
+                // ---- filter loop over the selected blocks, two per turn, the next pair's operands in flight ----------------
+#pragma unroll 1
+                for (int w = 0; w < 2; ++w) {
+                    unsigned long long m = w ? mk[1] : mk[0];
+                    if (!m) continue;
+                    const h8 *pw = pa + w * (64 * 64);
+                    int b0 = __builtin_ctzll(m); m &= m - 1;
+                    int b1 = m ? __builtin_ctzll(m) : -1; if (m) m &= m - 1;
+                    h8 a0 = pw[b0 * 64], a1 = pw[(b1 >= 0 ? b1 : b0) * 64];
+                    for (;;) {
+                        const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq, zero, 0, 0, 0);
+                        const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq, zero, 0, 0, 0);
+                        const int c0 = b0, c1 = b1;
+                        const bool more = m != 0ull;
+                        if (more) {
+                            b0 = __builtin_ctzll(m); m &= m - 1;
+                            b1 = m ? __builtin_ctzll(m) : -1; if (m) m &= m - 1;
+                            a0 = pw[b0 * 64];
+                            a1 = pw[(b1 >= 0 ? b1 : b0) * 64];
+                        }
 #pragma unroll
-                    for (int s = kHFifo - 1; s > 0; --s) ft[s] = qual ? ft[s - 1] : ft[s];
-                    ft[0] = qual ? tm : ft[0];
-                    fis = qual ? ((fis << 8) | (unsigned int)b0) : fis;
-                    best = vmin(best, tm);
-                    accC = accN;
-                    a1 = a2;
-                    b0 = b1;
-                    b1 = b2;
+                        for (int u = 0; u < 2; ++u) {
+                            const f32x16 &ac = u ? acc1 : acc0;
+                            const int cb_ = u ? c1 : c0;
+                            // fold 16 values: 8 x v_min3, depth 3
+                            const float t0 = min3f(ac[0], ac[1], ac[2]), t1 = min3f(ac[3], ac[4], ac[5]);
+                            const float t2 = min3f(ac[6], ac[7], ac[8]), t3 = min3f(ac[9], ac[10], ac[11]);
+                            const float t4 = min3f(ac[12], ac[13], ac[14]);
+                            const float t5 = min3f(t0, t1, t2), t6 = min3f(t3, t4, ac[15]);
+                            float tm = vmin(t5, t6);
+                            if (u) tm = c1 >= 0 ? tm : INFINITY;  // an odd count: the pair's second block repeats the first, unseen
+                            const bool qual = tm <= __builtin_fmaf(best, kBandB1, da);
+#pragma unroll
+                            for (int s = kHFifo - 1; s > 0; --s) ft[s] = qual ? ft[s - 1] : ft[s];
+                            ft[0] = qual ? tm : ft[0];
+                            fis = qual ? ((fis << 8) | (unsigned int)(cb_ + 64 * w)) : fis;
+                            best = vmin(best, tm);
+                        }
+                        if (!more) break;
+                    }
                 }
                 if (!pr) break;
                 // ---- the bound after this phase: d~^2 of the nearest candidate <= Umin + (1 + beta)|q~|^2 + floor (error model
@@ -762,7 +861,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 const unsigned int id = (fis >> (8 * s)) & 0xffu;
                 fi[s] = id == 0xffu ? -1 : (int)id;
             }
-            FX3D_PROBE_MARK(tp == 0 ? 3 : 7);
+            if (first_group) FX3D_PROBE_MARK(3);
 
             // ---- exact phase, wave-cooperative ------------------------------------------------------------------------
             {
@@ -796,6 +895,9 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     } else {
 #pragma unroll 1
                         for (; lt2 < nblk && nitems <= kHItemCap - 64; ++lt2) {
+                            // (blocks this wave's bound excluded hold nothing inside a usable query's band)
+                            const bool was_seen = (lt2 < 64 ? seen[0] >> lt2 : seen[1] >> (lt2 - 64)) & 1ull;
+                            if (!was_seen) continue;
                             const f32x16 av = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[lt2 * 64], bq, zero, 0, 0, 0);
                             float t2 = INFINITY;
 #pragma unroll
@@ -841,9 +943,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     }
                 } while (lt2 < nblk);
             }
-            FX3D_PROBE_MARK(tp == 0 ? 4 : 8);
+            if (first_group) FX3D_PROBE_MARK(4);
+            first_group = false;
 
-            if (j0 + jstep >= NC) {  // last chunk of this block: results of this tile pass
+            if (j0 + jstep >= NC) {  // last chunk of this block: results of this query group
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();
                 if (hh == 0) {
@@ -855,20 +958,22 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     } else if (qvalid) {
                         if (WANT_IDX && idx_out) idx_out[(size_t)b * NQ + qi] = ii;
                         if (dmin_out) dmin_out[(size_t)b * NQ + qi] = dd;
-                        dres[qloc] = dd;  // summed below in the queries' own order: the loss does not depend on the sort
+                        if (p.partials) exact_add(sacc, &sflags, dd);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+            g = single_chunk ? next_group() : ngroups;
         }
     }
     FX3D_PROBE_MARK(11);
     if (p.partials) {
         __shared__ double sm[kHThreads / 64];
+        __shared__ double stot;
         __syncthreads();
-        double acc = 0.0;
-        for (int k = tid; k < nq_blk; k += kHThreads) acc += (double)dres[k];
-        const double tot = block_sum<kHThreads>(acc, sm);
+        if (tid == 0) stot = exact_read(sacc, sflags);
+        __syncthreads();
+        const double tot = stot;
         if (!p.ticket) {
             if (tid == 0) p.partials[(size_t)c * p.tiles + tile] = tot;
         } else {
@@ -1122,7 +1227,7 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
             for (int tpb = 1; tpb <= 8; tpb *= 2) {
                 if (!split && anch > 1 && tpb > 1) continue;
                 if (tpb_env > 0 && tpb != tpb_env && (split || anch == 1)) continue;
-                if (nn1_f16_lds_bytes(ch, tpb) > kHLdsLimit) continue;  // sorted-query tables: 6 bytes per query of the block
+                if (nn1_f16_lds_bytes(ch, tpb) > kHLdsLimit) continue;  // sorted-query table: 2 bytes per query of the block
                 const long long tiles = ((long long)maxc + 512 * tpb - 1) / (512 * tpb);
                 const long long blocks = 2ll * B * tiles * (split ? anch : 1);
                 const double per_chunk = 5.0 * ch / 4096.0 + 0.5 + tpb * (9.7 * ch / 4096.0 + 0.8);
