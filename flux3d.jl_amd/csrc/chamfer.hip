@@ -307,7 +307,7 @@ static_assert(kHFifo <= 4 && kHMaxBlk < 255, "FIFO block ids are packed one byte
 constexpr size_t kHFixedBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 2 + 32 * 3 * 4) + kHMaxBlk * 6 * 4;
 static_assert((kHThreads / 64) * kHItemCap * 2 >= 2 * kHCells * 4, "the cell counters alias the item lists");
 constexpr size_t nn1_f16_lds_bytes(int chunk, int tpb) { return (size_t)chunk * 32 + kHFixedBytes + (size_t)tpb * 512 * 2; }
-constexpr size_t kHLdsLimit = 160 * 1024 - 1280;  // the CU's LDS minus the kernel's static arrays
+constexpr size_t kHLdsLimit = 160 * 1024 - 2048;  // the CU's LDS minus the kernel's static arrays
 
 // plain v_min_f32 (fminf() also emits a canonicalising v_max in IEEE mode; the filter values are never
 // signalling NaNs, and a NaN filter value only sends the query down the exact path)
