@@ -306,7 +306,8 @@ static_assert(kHFifo <= 4 && kHMaxBlk < 255, "FIFO block ids are packed one byte
 // the query behind its place in the sorted order (2 B).
 constexpr size_t kHFixedBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 2 + 32 * 3 * 4) + kHMaxBlk * 6 * 4;
 static_assert((kHThreads / 64) * kHItemCap * 2 >= 2 * kHCells * 4, "the cell counters alias the item lists");
-constexpr size_t nn1_f16_lds_bytes(int chunk, int tpb) { return (size_t)chunk * 32 + kHFixedBytes + (size_t)tpb * 512 * 2; }
+constexpr int kHQSlack = 256;  // a block's cell range may hold this many queries more than its even share
+constexpr size_t nn1_f16_lds_bytes(int chunk, int tpb) { return (size_t)chunk * 32 + kHFixedBytes + (size_t)(tpb * 512 + kHQSlack) * 2; }
 constexpr size_t kHLdsLimit = 160 * 1024 - 2048;  // the CU's LDS minus the kernel's static arrays
 
 // plain v_min_f32 (fminf() also emits a canonicalising v_max in IEEE mode; the filter values are never
@@ -554,10 +555,13 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
 
     // queries of this block: by cell range of the WHOLE direction's queries when that is balanced (spatial), else the index
     // range [tile * tpb * 512, ...) sorted locally.  Either way `qperm[slot]` names the query of sorted slot `slot`.
-    const int cap = p.tpb * QB;
-    const bool try_spatial = sane && T > 1 && NQ <= 65536;
-    int q_first = tile * cap;                                       // index-range form: qperm holds q - q_first
-    int nq_blk = (NQ - q_first) < cap ? (NQ - q_first) : cap;
+    const int jfirst = split * CH, jstep = p.nsplit * CH;
+    const bool single_chunk = jfirst + jstep >= NC;  // one chunk per block: query groups go to whichever wave is free
+    const int share = p.tpb * QB, cap = share + kHQSlack;
+    // (a block that walks several chunks keeps one query group per wave across them: no room for an uneven share)
+    const bool try_spatial = sane && T > 1 && NQ <= 65536 && single_chunk;
+    int q_first = tile * share;                                     // index-range form: qperm holds q - q_first
+    int nq_blk = (NQ - q_first) < share ? (NQ - q_first) : share;
     if (nq_blk < 0) nq_blk = 0;
     bool spatial = false;
 
@@ -567,8 +571,6 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     bool qok = true, qvalid = false;
     h8 bq;
 
-    const int jfirst = split * CH, jstep = p.nsplit * CH;
-    const bool single_chunk = jfirst + jstep >= NC;  // one chunk per block: query groups go to whichever wave is free
     for (int j0 = jfirst; j0 < NC; j0 += jstep) {
         const int cnt = (NC - j0) < CH ? (NC - j0) : CH;
         const int cnt_pad = (cnt + 31) / 32 * 32;
