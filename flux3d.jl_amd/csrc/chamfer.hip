@@ -306,6 +306,7 @@ static_assert(kHFifo <= 4 && kHMaxBlk < 255, "FIFO block ids are packed one byte
 // the query behind its place in the sorted order (2 B).
 constexpr size_t kHFixedBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 2 + 32 * 3 * 4) + kHMaxBlk * 6 * 4;
 static_assert((kHThreads / 64) * kHItemCap * 2 >= 2 * kHCells * 4, "the cell counters alias the item lists");
+constexpr int kHSortMin = 1536;  // clouds below this many candidates are not sorted (no pruning, no extra barriers)
 constexpr int kHQSlack = 256;  // a block's cell range may hold this many queries more than its even share
 constexpr size_t nn1_f16_lds_bytes(int chunk, int tpb) { return (size_t)chunk * 32 + kHFixedBytes + (size_t)(tpb * 512 + kHQSlack) * 2; }
 constexpr size_t kHLdsLimit = 160 * 1024 - 2048;  // the CU's LDS minus the kernel's static arrays
@@ -559,7 +560,9 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     const bool single_chunk = jfirst + jstep >= NC;  // one chunk per block: query groups go to whichever wave is free
     const int share = p.tpb * QB, cap = share + kHQSlack;
     // (a block that walks several chunks keeps one query group per wave across them: no room for an uneven share)
-    const bool try_spatial = sane && T > 1 && NQ <= 65536 && single_chunk;
+    // small clouds stay in index order: the sort's barriers cost more than the tiles it saves (C1: 1024 points)
+    const bool sorted = sane && NC >= kHSortMin;
+    const bool try_spatial = sorted && T > 1 && NQ <= 65536 && single_chunk;
     int q_first = tile * share;                                     // index-range form: qperm holds q - q_first
     int nq_blk = (NQ - q_first) < share ? (NQ - q_first) : share;
     if (nq_blk < 0) nq_blk = 0;
@@ -578,8 +581,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         const bool first = j0 == jfirst;
         __syncthreads();
         // ---- counting sort of the chunk (and, the first time, of the queries) by Morton cell ---------------------------
-        for (int i = tid; i < 2 * kHCells; i += kHThreads) hist[i] = 0;
-        __syncthreads();
+        if (sorted) {
+            for (int i = tid; i < 2 * kHCells; i += kHThreads) hist[i] = 0;
+            __syncthreads();
+        }
         const bool have_regs = vec && NC <= CH && tid < nv;  // the four points loaded for the bounding box
         int cell[4];
         const int p0 = 4 * tid;
@@ -594,16 +599,19 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             cell[e] = 0;
-            if (p0 + e < cnt) {
-                if (sane) cell[e] = morton_cell(ax[e], ay[e], az[e], glo, ginv);
+            if (sorted && p0 + e < cnt) {
+                cell[e] = morton_cell(ax[e], ay[e], az[e], glo, ginv);
                 atomicAdd(&hist[cell[e]], 1u);
             }
         }
+        if (!sorted) {
+            if (first) for (int ql = tid; ql < nq_blk; ql += kHThreads) qperm[ql] = (unsigned short)ql;  // index order
+        } else {
         if (first) {  // query counts: all NQ (spatial) or this block's index range
             const int n = try_spatial ? NQ : nq_blk, base = try_spatial ? 0 : q_first;
             for (int ql = tid; ql < n; ql += kHThreads) {
                 const float *src = qb + (size_t)(base + ql) * 3;
-                const int qc = sane ? morton_cell(src[0], src[1], src[2], glo, ginv) : 0;  // (clamped: queries may lie outside the box)
+                const int qc = morton_cell(src[0], src[1], src[2], glo, ginv);  // (clamped: queries may lie outside the box)
                 atomicAdd(&qhist[qc], 1u);
             }
         }
@@ -650,16 +658,17 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 }
                 for (int ql = tid; ql < nq_blk; ql += kHThreads) {
                     const float *src = qb + (size_t)(q_first + ql) * 3;
-                    const int qc = sane ? morton_cell(src[0], src[1], src[2], glo, ginv) : 0;
+                    const int qc = morton_cell(src[0], src[1], src[2], glo, ginv);
                     qperm[atomicAdd(&qhist[qc], 1u)] = (unsigned short)ql;
                 }
             }
         }
+        }  // sorted
         // ---- fp16 split image at the sorted positions ----------------------------------------------------------------
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (p0 + e < cnt) {
-                const int pos = (int)atomicAdd(&hist[cell[e]], 1u);
+                const int pos = sorted ? (int)atomicAdd(&hist[cell[e]], 1u) : p0 + e;
                 h8 q0, q1;
                 make_pieces((ax[e] - mu[0]) * sc, (ay[e] - mu[1]) * sc, (az[e] - mu[2]) * sc, (unsigned int)(p0 + e), q0, q1);
                 const int i0 = ((pos >> 5) * 2) * 32 + (pos & 31);
@@ -678,7 +687,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         }
         __syncthreads();
         // ---- bounding box of every 32-candidate block (eight threads per block, four rows each) ----------------------
-        if (tid < nblk * 8) {
+        if (sorted && tid < nblk * 8) {
             const int bk = tid >> 3, sub = tid & 7;
             float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
@@ -774,7 +783,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 }
             }
             }
-            const bool prune = sane && nblk > 2 && __ballot(qvalid && !qok) == 0;  // a query outside the fp16 range has no bound
+            const bool prune = sorted && nblk > 2 && __ballot(qvalid && !qok) == 0;  // a query outside the fp16 range has no bound
             unsigned long long todo[2], seen[2] = {0ull, 0ull};
             todo[0] = uni64(__ballot(lane < nblk));
             todo[1] = uni64(__ballot(lane + 64 < nblk));
