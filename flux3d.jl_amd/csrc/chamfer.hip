@@ -306,6 +306,7 @@ static_assert(kHFifo <= 4 && kHMaxBlk < 255, "FIFO block ids are packed one byte
 // the query behind its place in the sorted order (2 B).
 constexpr size_t kHFixedBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 2 + 32 * 3 * 4) + kHMaxBlk * 6 * 4;
 static_assert((kHThreads / 64) * kHItemCap * 2 >= 2 * kHCells * 4, "the cell counters alias the item lists");
+constexpr int kHFarCap = 64;     // far candidates kept on the exact side list; more: the chunk falls back to exact scans
 constexpr int kHSortMin = 1536;  // clouds below this many candidates are not sorted (no pruning, no extra barriers)
 constexpr int kHQSlack = 256;  // a block's cell range may hold this many queries more than its even share
 constexpr size_t nn1_f16_lds_bytes(int chunk, int tpb) { return (size_t)chunk * 32 + kHFixedBytes + (size_t)(tpb * 512 + kHQSlack) * 2; }
@@ -443,6 +444,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     __shared__ float red[3 * 4 * (kHThreads / 64)];  // per wave: min, max, sum (padded to 4 dims)
     __shared__ int wave_tot[kHThreads / 64];
     __shared__ unsigned long long sacc[kHLimbs];
+    __shared__ int nfar;                        // candidates of the chunk beyond the robust range
+    __shared__ unsigned short farlist[kHFarCap];  // their indices within the chunk: compared exactly by every query
     __shared__ int sflags, grp_ctr, part[4];  // part: first cell / end cell / first rank / number of queries of this block
     constexpr int QB = (kHThreads / 64) * 32;  // queries per tile pass
 
@@ -538,18 +541,53 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             // a NaN or +-Inf coordinate makes the coordinate sum non-finite (fminf / fmaxf above skip NaNs)
             allfin = allfin && fabsf(st) < INFINITY;
             glo[d] = lo;
-            ginv[d] = hi > lo ? (float)kHGrid / (hi - lo) : 0.0f;  // sort grid over the cloud's box (any grid is correct)
+            ginv[d] = hi;  // (the box for now; turned into the sort grid below)
         }
         cinf = cinf * 1.000001f;
+    }
+    // ---- robust range: a few points far from the bulk must not set the scale (the bulk would sink below fp16's resolution and
+    //      the whole cloud fall back to exact scans).  rng = min(cinf, 16 x the mean max-norm deviation from mu): clouds without
+    //      outliers keep rng = cinf (uniform box: 16 x 0.375 of the half width; Gaussian: 21 sigma); candidates beyond the
+    //      range ("far") are left out of the filter (norm = +inf) and compared exactly by every query (side list below). ----
+    float rng = cinf;
+    if (allfin && cinf < 1.0e16f) {
+        float dev = 0.0f;
+        if (vec && NC <= CH) {
+            if (tid < nv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dev += fmaxf(fmaxf(fabsf(ax[e] - mu[0]), fabsf(ay[e] - mu[1])), fabsf(az[e] - mu[2]));
+            }
+            for (int pt = nv * 4 + tid; pt < NC; pt += kHThreads)
+                dev += fmaxf(fmaxf(fabsf(cb[(size_t)pt * 3] - mu[0]), fabsf(cb[(size_t)pt * 3 + 1] - mu[1])), fabsf(cb[(size_t)pt * 3 + 2] - mu[2]));
+        } else {
+            for (int pt = tid; pt < NC; pt += kHThreads)
+                dev += fmaxf(fmaxf(fabsf(cb[(size_t)pt * 3] - mu[0]), fabsf(cb[(size_t)pt * 3 + 1] - mu[1])), fabsf(cb[(size_t)pt * 3 + 2] - mu[2]));
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) dev = dev + __shfl_xor(dev, m, 64);
+        __syncthreads();  // (red is read above)
+        if (lane == 0) red[wv] = dev;
+        __syncthreads();
+        float tot = red[0];
+#pragma unroll
+        for (int w = 1; w < kHThreads / 64; ++w) tot = tot + red[w];
+        const float r16 = 16.0f * (tot / (float)NC);
+        if (r16 > 0.0f && r16 < cinf) rng = r16;
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {  // sort grid: the box clipped to the robust range around mu (any grid is correct; cells clamp)
+        const float lo = fmaxf(glo[d], mu[d] - rng), hi = fminf(ginv[d], mu[d] + rng);
+        glo[d] = lo;
+        ginv[d] = hi > lo ? (float)kHGrid / (hi - lo) : 0.0f;
     }
     // not sane (non-finite or huge coordinates): the filter is unusable, every query of the block scans every block
     // exactly, in the isless order (a finite cloud with cinf < 1e16 never produces an infinite or NaN distance
     // to a query inside the fp16 range)
     const bool sane = allfin && cinf < 1.0e16f;  // usable queries lie within 234 cinf of the centre: 3 (235 cinf)^2 stays finite
     float sc = 1.0f;
-    if (sane && cinf > 1.0e-30f) {
+    if (sane && rng > 1.0e-30f) {
         int e;
-        (void)frexpf(cinf, &e);  // cinf = m 2^e, m in [0.5,1)
+        (void)frexpf(rng, &e);  // rng = m 2^e, m in [0.5,1)
         sc = ldexpf(1.0f, 7 - e);
     }
     FX3D_PROBE_MARK(1);
@@ -580,6 +618,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         const int nblk = cnt_pad / 32;
         const bool first = j0 == jfirst;
         __syncthreads();
+        if (tid == 0) nfar = 0;
         // ---- counting sort of the chunk (and, the first time, of the queries) by Morton cell ---------------------------
         if (sorted) {
             for (int i = tid; i < 2 * kHCells; i += kHThreads) hist[i] = 0;
@@ -606,6 +645,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         }
         if (!sorted) {
             if (first) for (int ql = tid; ql < nq_blk; ql += kHThreads) qperm[ql] = (unsigned short)ql;  // index order
+            __syncthreads();  // (nfar is zero before the image's far candidates count up)
         } else {
         if (first) {  // query counts: all NQ (spatial) or this block's index range
             const int n = try_spatial ? NQ : nq_blk, base = try_spatial ? 0 : q_first;
@@ -670,7 +710,14 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             if (p0 + e < cnt) {
                 const int pos = sorted ? (int)atomicAdd(&hist[cell[e]], 1u) : p0 + e;
                 h8 q0, q1;
-                make_pieces((ax[e] - mu[0]) * sc, (ay[e] - mu[1]) * sc, (az[e] - mu[2]) * sc, (unsigned int)(p0 + e), q0, q1);
+                const float sx = (ax[e] - mu[0]) * sc, sy = (ay[e] - mu[1]) * sc, sz = (az[e] - mu[2]) * sc;
+                const bool far = sane && !(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)) < 128.0f);
+                make_pieces(far ? 0.f : sx, far ? 0.f : sy, far ? 0.f : sz, (unsigned int)(p0 + e), q0, q1);
+                if (far) {  // out of the filter (t = +inf), onto the side list
+                    q1[1] = (_Float16)INFINITY;
+                    const int f = atomicAdd(&nfar, 1);
+                    if (f < kHFarCap) farlist[f] = (unsigned short)(p0 + e);
+                }
                 const int i0 = ((pos >> 5) * 2) * 32 + (pos & 31);
                 imgp[i0] = q0;
                 imgp[i0 + 32] = q1;
@@ -715,6 +762,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         __syncthreads();
         FX3D_PROBE_MARK(first ? 2 : 6);
 
+        const int nf = nfar;                     // far candidates of this chunk (valid after the barrier above)
+        const bool far_ok = nf <= kHFarCap;      // more than the side list holds: this chunk's filter is not used
         const int ngroups = (nq_blk + 31) / 32;
         auto next_group = [&]() -> int {
             int g = 0;
@@ -783,7 +832,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 }
             }
             }
-            const bool prune = sorted && nblk > 2 && __ballot(qvalid && !qok) == 0;  // a query outside the fp16 range has no bound
+            const bool prune = sorted && far_ok && nblk > 2 && __ballot(qvalid && !qok) == 0;  // a query outside the fp16 range has no bound
             unsigned long long todo[2], seen[2] = {0ull, 0ull};
             todo[0] = uni64(__ballot(lane < nblk));
             todo[1] = uni64(__ballot(lane + 64 < nblk));
@@ -878,7 +927,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             {
                 const float m = fminf(best, __shfl_xor(best, 32, 64));
                 const float thr1 = __builtin_fmaf(m, kBandB1, da), thr2 = __builtin_fmaf(thr1, kBandB1, da);
-                const bool usable = sane && qok && m < INFINITY;        // filter meaningful for this query
+                const bool usable = sane && far_ok && qok && m < INFINITY;  // filter meaningful for this query
                 const bool slow = !usable || !(ft[kHFifo - 1] > thr2);  // FIFO may have dropped a block in band
                 // Common case (no slow lane in the wave): the items are the FIFO entries within the band.
                 // Rare case (degenerate / near-tied data, unusable filter): the wave re-runs its filter pass
@@ -953,6 +1002,18 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                         }
                     }
                 } while (lt2 < nblk);
+                // the far candidates (outside the filter): every query of the group against each of them, exactly
+                if (far_ok) {
+                    for (int t = lane; t < 32 * nf; t += 64) {
+                        const int qs = t & 31, jc = farlist[t >> 5];
+                        const float qq[3] = {qtab[qs * 3], qtab[qs * 3 + 1], qtab[qs * 3 + 2]};
+                        const float *src = cb + (size_t)(j0 + jc) * 3;
+                        const float cc3[3] = {src[0], src[1], src[2]};
+                        const float dd = sqd<3>(qq, cc3);
+                        const unsigned int kd = nonfinite ? dist_key(dd) : __builtin_bit_cast(unsigned int, dd);
+                        atomicMin(&qres[qs], ((unsigned long long)kd << 32) | (unsigned int)(j0 + jc));
+                    }
+                }
             }
             if (first_group) FX3D_PROBE_MARK(4);
             first_group = false;

@@ -424,3 +424,21 @@ def test_fused_mesh_losses_degenerate_mesh(gpu_fx, oracle):
     assert np.array_equal(fx.mesh_losses_grad(m, 0.0, 1.0, 1.0).to_host(), ref)
     lap, edge, _ = fx.mesh_losses(m)
     assert lap == fx.laplacian_loss(m) and edge == fx.edge_loss(m)
+
+
+# ------------------------------------------------------------------------------ far outliers: the side list
+@pytest.mark.parametrize("nout,fac", [(1, 1e3), (1, 1e5), (1, 1e7), (5, 1e4), (64, 1e5), (70, 1e5), (300, 1e6)])
+def test_far_outliers_take_the_exact_side_list(gpu_fx, oracle, nout, fac):
+    """one stray point used to set the fp16 scale for the whole cloud.  The scale now comes from a robust
+    range (16 x the mean deviation); candidates beyond it leave the filter and are compared exactly by every query (up to
+    64 per chunk, more: the chunk falls back to exact scans).  Indices, distances, loss: the oracle's."""
+    rng = np.random.default_rng(nout)
+    x = rng.standard_normal((3, 2500, 2)).astype(np.float32)
+    y = rng.standard_normal((3, 4096, 2)).astype(np.float32)
+    oi = rng.choice(4096, nout, replace=False)
+    y[:, oi, :] *= np.float32(fac)
+    x[:, :max(1, nout // 2), 0] *= np.float32(fac)          # far queries too, and a far point that is somebody's nearest
+    y[:, oi[0], 1] = x[:, 0, 1] * np.float32(1.0000001)
+    x, y = np.asfortranarray(x), np.asfortranarray(y)
+    _nn_equal(gpu_fx, oracle, x, y)
+    _chamfer_equal(gpu_fx, oracle, x, y)
