@@ -310,7 +310,7 @@ constexpr int kHFarCap = 64;     // far candidates kept on the exact side list; 
 constexpr int kHSortMin = 1536;  // clouds below this many candidates are not sorted (no pruning, no extra barriers)
 constexpr int kHQSlack = 256;  // a block's cell range may hold this many queries more than its even share
 constexpr size_t nn1_f16_lds_bytes(int chunk, int tpb) { return (size_t)chunk * 32 + kHFixedBytes + (size_t)(tpb * 512 + kHQSlack) * 2; }
-constexpr size_t kHLdsLimit = 160 * 1024 - 2048;  // the CU's LDS minus the kernel's static arrays
+constexpr size_t kHLdsLimit = 160 * 1024 - 4096;  // the CU's LDS minus the kernel's static arrays
 
 // plain v_min_f32 (fminf() also emits a canonicalising v_max in IEEE mode; the filter values are never
 // signalling NaNs, and a NaN filter value only sends the query down the exact path)
@@ -363,11 +363,16 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
 }
 
 // Morton code of a cell (3 bits per axis) -- consecutive cells are spatial neighbours, so 32 consecutive sorted
-// candidates (one MFMA block) occupy a compact box
-__device__ __forceinline__ int morton_cell(float x, float y, float z, const float (&lo)[3], const float (&inv)[3]) {
-    const int ix = min(kHGrid - 1, max(0, (int)((x - lo[0]) * inv[0])));
-    const int iy = min(kHGrid - 1, max(0, (int)((y - lo[1]) * inv[1])));
-    const int iz = min(kHGrid - 1, max(0, (int)((z - lo[2]) * inv[2])));
+// candidates (one MFMA block) occupy a compact box.  The cells are NOT equal boxes: per axis the range is cut into
+// kHAxisBins bins and `lut` maps a bin to one of 8 slabs holding about an eighth of the cloud each (quantiles of the
+// candidates' marginal distribution), so dense regions get small cells and sparse ones large cells.
+constexpr int kHAxisBins = 64;
+__device__ __forceinline__ int morton_cell(float x, float y, float z, const float (&lo)[3], const float (&inv)[3],
+                                           const unsigned char *lut) {
+    const int bx = min(kHAxisBins - 1, max(0, (int)((x - lo[0]) * inv[0])));
+    const int by = min(kHAxisBins - 1, max(0, (int)((y - lo[1]) * inv[1])));
+    const int bz = min(kHAxisBins - 1, max(0, (int)((z - lo[2]) * inv[2])));
+    const int ix = lut[bx], iy = lut[kHAxisBins + by], iz = lut[2 * kHAxisBins + bz];
     auto spread = [](int v) { return (v & 1) | ((v & 2) << 2) | ((v & 4) << 4); };
     return spread(ix) | (spread(iy) << 1) | (spread(iz) << 2);
 }
@@ -444,6 +449,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     __shared__ float red[3 * 4 * (kHThreads / 64)];  // per wave: min, max, sum (padded to 4 dims)
     __shared__ int wave_tot[kHThreads / 64];
     __shared__ unsigned long long sacc[kHLimbs];
+    __shared__ unsigned int axh[3 * kHAxisBins];       // per-axis histograms of the candidates (sort grid)
+    __shared__ unsigned char axlut[3 * kHAxisBins];    // bin -> slab (0..7) per axis
     __shared__ int nfar;                        // candidates of the chunk beyond the robust range
     __shared__ unsigned short farlist[kHFarCap];  // their indices within the chunk: compared exactly by every query
     __shared__ int sflags, grp_ctr, part[4];  // part: first cell / end cell / first rank / number of queries of this block
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     for (int d = 0; d < 3; ++d) {  // sort grid: the box clipped to the robust range around mu (any grid is correct; cells clamp)
         const float lo = fmaxf(glo[d], mu[d] - rng), hi = fminf(ginv[d], mu[d] + rng);
         glo[d] = lo;
-        ginv[d] = hi > lo ? (float)kHGrid / (hi - lo) : 0.0f;
+        ginv[d] = hi > lo ? (float)kHAxisBins / (hi - lo) : 0.0f;
     }
     // not sane (non-finite or huge coordinates): the filter is unusable, every query of the block scans every block
     // exactly, in the isless order (a finite cloud with cinf < 1e16 never produces an infinite or NaN distance
@@ -601,6 +608,39 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     // small clouds stay in index order: the sort's barriers cost more than the tiles it saves (C1: 1024 points)
     const bool sorted = sane && NC >= kHSortMin;
     const bool try_spatial = sorted && T > 1 && NQ <= 65536 && single_chunk;
+    if (sorted) {
+        // per-axis quantile slabs from the WHOLE candidate cloud (the same tables in every block of this direction, for
+        // every chunk, and for the queries: the cell of a point is a function of the cloud alone)
+        if (tid < 3 * kHAxisBins) axh[tid] = 0;
+        __syncthreads();
+        auto count = [&](float x, float y, float z) {
+            atomicAdd(&axh[min(kHAxisBins - 1, max(0, (int)((x - glo[0]) * ginv[0])))], 1u);
+            atomicAdd(&axh[kHAxisBins + min(kHAxisBins - 1, max(0, (int)((y - glo[1]) * ginv[1])))], 1u);
+            atomicAdd(&axh[2 * kHAxisBins + min(kHAxisBins - 1, max(0, (int)((z - glo[2]) * ginv[2])))], 1u);
+        };
+        if (vec && NC <= CH) {
+            if (tid < nv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) count(ax[e], ay[e], az[e]);
+            }
+            for (int pt = nv * 4 + tid; pt < NC; pt += kHThreads) count(cb[(size_t)pt * 3], cb[(size_t)pt * 3 + 1], cb[(size_t)pt * 3 + 2]);
+        } else {
+            for (int pt = tid; pt < NC; pt += kHThreads) count(cb[(size_t)pt * 3], cb[(size_t)pt * 3 + 1], cb[(size_t)pt * 3 + 2]);
+        }
+        __syncthreads();
+        if (wv < 3) {  // one wave per axis: slab of a bin = floor(8 x points below the bin / N)
+            const unsigned int v = axh[wv * kHAxisBins + lane];
+            unsigned int incl = v;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                const unsigned int o = (unsigned int)__shfl_up((int)incl, m, 64);
+                if (lane >= m) incl += o;
+            }
+            const unsigned long long below = incl - v;
+            axlut[wv * kHAxisBins + lane] = (unsigned char)min(kHGrid - 1, (int)(below * kHGrid / (unsigned long long)NC));
+        }
+        __syncthreads();
+    }
     int q_first = tile * share;                                     // index-range form: qperm holds q - q_first
     int nq_blk = (NQ - q_first) < share ? (NQ - q_first) : share;
     if (nq_blk < 0) nq_blk = 0;
@@ -639,7 +679,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         for (int e = 0; e < 4; ++e) {
             cell[e] = 0;
             if (sorted && p0 + e < cnt) {
-                cell[e] = morton_cell(ax[e], ay[e], az[e], glo, ginv);
+                cell[e] = morton_cell(ax[e], ay[e], az[e], glo, ginv, axlut);
                 atomicAdd(&hist[cell[e]], 1u);
             }
         }
@@ -651,7 +691,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             const int n = try_spatial ? NQ : nq_blk, base = try_spatial ? 0 : q_first;
             for (int ql = tid; ql < n; ql += kHThreads) {
                 const float *src = qb + (size_t)(base + ql) * 3;
-                const int qc = morton_cell(src[0], src[1], src[2], glo, ginv);  // (clamped: queries may lie outside the box)
+                const int qc = morton_cell(src[0], src[1], src[2], glo, ginv, axlut);  // (clamped: queries may lie outside the box)
                 atomicAdd(&qhist[qc], 1u);
             }
         }
@@ -681,7 +721,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 const int c0 = part[0], c1 = part[1], r0 = part[2];
                 for (int ql = tid; ql < NQ; ql += kHThreads) {
                     const float *src = qb + (size_t)ql * 3;
-                    const int qc = morton_cell(src[0], src[1], src[2], glo, ginv);
+                    const int qc = morton_cell(src[0], src[1], src[2], glo, ginv, axlut);
                     if (qc >= c0 && qc < c1) qperm[(int)atomicAdd(&qhist[qc], 1u) - r0] = (unsigned short)ql;
                 }
             } else {
@@ -691,14 +731,14 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     __syncthreads();
                     for (int ql = tid; ql < nq_blk; ql += kHThreads) {
                         const float *src = qb + (size_t)(q_first + ql) * 3;
-                        atomicAdd(&qhist[morton_cell(src[0], src[1], src[2], glo, ginv)], 1u);
+                        atomicAdd(&qhist[morton_cell(src[0], src[1], src[2], glo, ginv, axlut)], 1u);
                     }
                     __syncthreads();
                     scan_cells2(hist, wave_tot, tid, lane, wv, true);  // (the candidates' cursors stay as they are)
                 }
                 for (int ql = tid; ql < nq_blk; ql += kHThreads) {
                     const float *src = qb + (size_t)(q_first + ql) * 3;
-                    const int qc = morton_cell(src[0], src[1], src[2], glo, ginv);
+                    const int qc = morton_cell(src[0], src[1], src[2], glo, ginv, axlut);
                     qperm[atomicAdd(&qhist[qc], 1u)] = (unsigned short)ql;
                 }
             }
