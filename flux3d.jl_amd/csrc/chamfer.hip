@@ -288,29 +288,18 @@ __device__ __forceinline__ void load4pts(const float *__restrict__ base, int p0,
 //   Queries with |qm~| beyond the fp16 range take the exact path.
 //   Lane l of a wave holds query l&31 and the 16 candidate rows (r&3)+8(r>>2)+4(l>>5) of every
 //   32-candidate block; the two half-waves are merged through the per-query LDS slot.
-//   K slot 15 of the candidate side carries the row's tag (its index within the chunk) instead of 0: the image is sorted.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float chamfer_loss_from_sums(double sa, double sb, int N, int M, int D,
                                                         long long Bg, float w1, float w2);
 constexpr int kHThreads = 1024;   // 16 waves share one LDS image: 1 block per CU, 4 waves per SIMD
+constexpr int kHLT = 2;           // 32-candidate blocks per lane tile (lane sees 16 rows of each)
 constexpr int kHFifo = 3;
 constexpr int kHChunkMax = 4096;  // 32 B per candidate => 128 KiB
-constexpr int kHMaxBlk = kHChunkMax / 32;   // 32-candidate blocks (one MFMA each) per image
-constexpr int kHItemCap = 64 * kHFifo;      // the FIFO path never overflows the list
-constexpr int kHGrid = 8;                   // sort grid: 8^3 cells over the cloud's bounding box, in Morton order
-constexpr int kHCells = kHGrid * kHGrid * kHGrid;
-static_assert(kHFifo <= 4 && kHMaxBlk < 255, "FIFO block ids are packed one byte each");
-// LDS behind the image: per wave 32 result slots (8 B), the item list (2 B each; the sort's 2 x 512 cell counters alias
-// it) and the query table (32 x 3 floats); one bounding box (6 floats) per 32-candidate block; per query of the block
-// the query behind its place in the sorted order (2 B).
-constexpr size_t kHFixedBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 2 + 32 * 3 * 4) + kHMaxBlk * 6 * 4;
-static_assert((kHThreads / 64) * kHItemCap * 2 >= 2 * kHCells * 4, "the cell counters alias the item lists");
-constexpr int kHFarCap = 64;     // far candidates kept on the exact side list; more: the chunk falls back to exact scans
-constexpr int kHSortMin = 1536;  // clouds below this many candidates are not sorted (no pruning, no extra barriers)
-constexpr int kHQSlack = 256;  // a block's cell range may hold this many queries more than its even share
-constexpr size_t nn1_f16_lds_bytes(int chunk, int tpb) { return (size_t)chunk * 32 + kHFixedBytes + (size_t)(tpb * 512 + kHQSlack) * 2; }
-constexpr size_t kHLdsLimit = 160 * 1024 - 4096;  // the CU's LDS minus the kernel's static arrays
+constexpr int kHItemCap = 64 * kHFifo;  // the FIFO path never overflows the list
+constexpr int kHFarCap = 64;      // far candidates kept on the exact side list; more: the chunk falls back to exact scans
+static_assert(kHFifo <= 4 && kHChunkMax / (32 * kHLT) < 255, "FIFO lane-tile ids are packed one byte each");
+constexpr size_t kHScratchBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 4 + 32 * 3 * 4) + 64 * 32;  // + 2 pad blocks
 
 // plain v_min_f32 (fminf() also emits a canonicalising v_max in IEEE mode; the filter values are never
 // signalling NaNs, and a NaN filter value only sends the query down the exact path)
@@ -339,10 +328,7 @@ __device__ __forceinline__ void split2h(float v, _Float16 &h, _Float16 &l) {
 constexpr float kBetaC = 0x1.1p-18f;                       // beta (+6 %: rounding of n (1 + beta), subnormal share 2^-26 sqrt(3))
 constexpr float kBandB1 = 1.0f + 18.0f * kBetaC + 0x1p-20f;
 constexpr float kBandA = 22.3f * kBetaC + 0x1p-19f;
-// K slot 15 of the candidate side multiplies the query side's 0: it carries `tag`, the candidate's index within its chunk
-// (any bit pattern below 0x7c00 is a finite fp16, and finite x 0 = 0), which is how the sorted image remembers where a
-// row came from without a separate permutation array.
-__device__ __forceinline__ void make_pieces(float cx, float cy, float cz, unsigned int tag, h8 &p0, h8 &p1) {
+__device__ __forceinline__ void make_pieces(float cx, float cy, float cz, h8 &p0, h8 &p1) {
     _Float16 hx, lx, hy, ly, hz, lz, n1, n2, n3;
     split2h(cx, hx, lx); split2h(cy, hy, ly); split2h(cz, hz, lz);
     const float n0 = ((cx * cx) + (cy * cy)) + (cz * cz);
@@ -351,109 +337,17 @@ __device__ __forceinline__ void make_pieces(float cx, float cy, float cz, unsign
     const float r1 = n - (float)n1;
     n2 = (_Float16)r1;
     n3 = (_Float16)(r1 - (float)n2);
+    const _Float16 z = (_Float16)0.0f;
     p0 = h8{hx, hx, lx, hy, hy, ly, hz, hz};
-    p1 = h8{lz, n1, n2, n3, lx, ly, lz, __builtin_bit_cast(_Float16, (unsigned short)tag)};
+    p1 = h8{lz, n1, n2, n3, lx, ly, lz, z};
 }
 
-// a wave-uniform 64-bit value, stated as such (keeps block masks and the ids popped from them in scalar registers)
-__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v);
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-// Morton code of a cell (3 bits per axis) -- consecutive cells are spatial neighbours, so 32 consecutive sorted
-// candidates (one MFMA block) occupy a compact box.  The cells are NOT equal boxes: per axis the range is cut into
-// kHAxisBins bins and `lut` maps a bin to one of 8 slabs holding about an eighth of the cloud each (quantiles of the
-// candidates' marginal distribution), so dense regions get small cells and sparse ones large cells.
-constexpr int kHAxisBins = 64;
-__device__ __forceinline__ int morton_cell(float x, float y, float z, const float (&lo)[3], const float (&inv)[3],
-                                           const unsigned char *lut) {
-    const int bx = min(kHAxisBins - 1, max(0, (int)((x - lo[0]) * inv[0])));
-    const int by = min(kHAxisBins - 1, max(0, (int)((y - lo[1]) * inv[1])));
-    const int bz = min(kHAxisBins - 1, max(0, (int)((z - lo[2]) * inv[2])));
-    const int ix = lut[bx], iy = lut[kHAxisBins + by], iz = lut[2 * kHAxisBins + bz];
-    auto spread = [](int v) { return (v & 1) | ((v & 2) << 2) | ((v & 4) << 4); };
-    return spread(ix) | (spread(iy) << 1) | (spread(iz) << 2);
-}
-
-// exclusive scan of TWO sets of kHCells counters in place: threads [0, kHCells) own set 0, [kHCells, 2 kHCells) set 1
-// (candidates and queries are counted in one phase); two barriers.  only1: leave set 0 alone (it already holds cursors).
-__device__ __forceinline__ void scan_cells2(unsigned int *hist, int *wave_tot, int tid, int lane, int wv, bool only1 = false) {
-    unsigned int v = 0, incl = 0;
-    constexpr int WPS = kHCells / 64;  // waves per set
-    const bool mine = tid < 2 * kHCells && !(only1 && tid < kHCells);
-    if (mine) {
-        v = hist[tid];
-        incl = v;
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            const unsigned int o = (unsigned int)__shfl_up((int)incl, m, 64);
-            if (lane >= m) incl += o;
-        }
-        if (lane == 63) wave_tot[wv] = (int)incl;
-    }
-    __syncthreads();
-    if (mine) {
-        unsigned int off = 0;
-        for (int w = (wv / WPS) * WPS; w < wv; ++w) off += (unsigned int)wave_tot[w];
-        hist[tid] = off + incl - v;
-    }
-    __syncthreads();
-}
-
-// Order-independent sum of the block's nearest squared distances: a fixed-point accumulator wide enough for any
-// Float32 (limbs of 32 bits at weights 2^(32 L - 149), 64-bit containers: 2^32 addends never overflow one).  Integer
-// additions commute, so the block's partial sum -- and with it the loss -- does not depend on the order in which the
-// sorted queries happen to be processed; its value is the EXACT sum, rounded once when it is read out.
-constexpr int kHLimbs = 10;
-__device__ __forceinline__ void exact_add(unsigned long long *limbs, int *flags, float d) {
-    const unsigned int bits = __builtin_bit_cast(unsigned int, d);
-    const unsigned int e = (bits >> 23) & 0xffu;
-    if (e == 0xffu) { atomicOr(flags, (bits & 0x7fffffu) ? 2 : 1); return; }  // +Inf / NaN: carried as flags
-    const unsigned long long mant = (unsigned long long)((bits & 0x7fffffu) | (e ? 0x800000u : 0u));
-    const unsigned int sh = (e ? e : 1u) - 1u;  // value = mant 2^(sh - 149)
-    const unsigned long long v = mant << (sh & 31u);
-    const unsigned int L = sh >> 5;
-    if (mant) {
-        atomicAdd(&limbs[L], v & 0xffffffffull);
-        if (v >> 32) atomicAdd(&limbs[L + 1], v >> 32);
-    }
-}
-__device__ __forceinline__ double exact_read(const unsigned long long *limbs, int flags) {
-    if (flags & 2) return __builtin_nan("");
-    if (flags & 1) return INFINITY;
-    double s = 0.0;
-    for (int L = kHLimbs - 1; L >= 0; --L) s += ldexp((double)limbs[L], 32 * L - 149);
-    return s;
-}
-
-// nn1_f16_kernel, round 2: the candidates of a chunk are SORTED by Morton cell while the image is staged (counting sort
-// in LDS: histogram, scan, scatter; the order inside a cell is whatever the atomics give -- results do not depend on it),
-// and every 32-candidate block carries its bounding box.  The queries of a (cloud, direction) are split over its blocks
-// BY CELL RANGE (every block counts all of them: the ranges are a deterministic function of the counts), so a block owns
-// a compact region, and its queries are sorted the same way.  A wave (32 sorted, hence neighbouring, queries) evaluates
-// only the candidate blocks whose box can hold a nearest neighbour:
-//   1. blocks overlapping the wave's query box (or the nearest one); from their filter minima an upper bound of every
-//      query's nearest distance: d~^2 <= Umin + (1 + beta)|q~|^2 + floor (error model above);
-//   2. the other blocks whose box lies within the largest of those bounds.
-// A skipped block has every candidate STRICTLY farther (margins for the roundings of the boxes, of the bound and of the
-// oracle's own Float32 distance), so neither the nearest neighbour nor a candidate tied with it is lost: results stay
-// bit-identical to the oracle.  Uniform clouds visit ~1/4 of the tiles; data without locality degrades to every tile;
-// clustered data, whose members used to sit in every lane tile's band, now sits in a few adjacent blocks.
-// Query groups (32 queries) are handed to the waves of a block dynamically: interior groups visit more blocks than
-// groups at the rim of the cloud.
 template <bool WANT_IDX>
 __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float red[3 * 4 * (kHThreads / 64)];  // per wave: min, max, sum (padded to 4 dims)
-    __shared__ int wave_tot[kHThreads / 64];
-    __shared__ unsigned long long sacc[kHLimbs];
-    __shared__ unsigned int axh[3 * kHAxisBins];       // per-axis histograms of the candidates (sort grid)
-    __shared__ unsigned char axlut[3 * kHAxisBins];    // bin -> slab (0..7) per axis
-    __shared__ int nfar;                        // candidates of the chunk beyond the robust range
-    __shared__ unsigned short farlist[kHFarCap];  // their indices within the chunk: compared exactly by every query
-    __shared__ int sflags, grp_ctr, part[4];  // part: first cell / end cell / first rank / number of queries of this block
+    __shared__ int nfar;                             // candidates of the chunk beyond the robust range ...
+    __shared__ unsigned short farlist[kHFarCap];     // ... their indices within the chunk: compared exactly by every query
     constexpr int QB = (kHThreads / 64) * 32;  // queries per tile pass
 
     const int L = blockIdx.x;
@@ -470,8 +364,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     const int b = dir ? c - p.B : c;
     const int NQ = dir ? p.M : p.N;
     const int NC = dir ? p.N : p.M;
-    const int T = dir ? p.tiles_y : p.tiles_x;  // blocks sharing this direction's queries (per chunk subset)
-    if (tile >= T) return;
+    if (tile >= (dir ? p.tiles_y : p.tiles_x)) return;
     if ((long long)split * p.chunk >= NC) return;  // this direction has fewer chunks than splits
     const float *__restrict__ qb = (dir ? p.y : p.x) + (size_t)b * NQ * 3;
     const float *__restrict__ cb = (dir ? p.x : p.y) + (size_t)b * NC * 3;
@@ -482,31 +375,27 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     const int jq = lane & 31, hh = lane >> 5;
     const int CH = p.chunk;
     h8 *imgp = reinterpret_cast<h8 *>(lds);  // piece (blk, half, row) at (blk*2 + half)*32 + row, 16 B each
-    unsigned long long *wres = reinterpret_cast<unsigned long long *>(lds + 8 * CH);
-    unsigned short *witems = reinterpret_cast<unsigned short *>(wres + (kHThreads / 64) * 32);
+    float4 *imgf = reinterpret_cast<float4 *>(lds);
+    unsigned long long *wres = reinterpret_cast<unsigned long long *>(lds + 8 * (CH + 64));  // image + 2 pad blocks
+    unsigned int *witems = reinterpret_cast<unsigned int *>(wres + (kHThreads / 64) * 32);
     float *wq = reinterpret_cast<float *>(witems + (kHThreads / 64) * kHItemCap);
-    float *boxes = wq + (kHThreads / 64) * 96;  // [block][lo xyz, hi xyz] in scaled, centred coordinates
-    unsigned short *qperm = reinterpret_cast<unsigned short *>(boxes + kHMaxBlk * 6);  // sorted slot -> query
-    unsigned int *hist = reinterpret_cast<unsigned int *>(witems);                     // staging only (aliases the items)
-    unsigned int *qhist = hist + kHCells;
     unsigned long long *qres = wres + wv * 32;
-    unsigned short *items = witems + wv * kHItemCap;
+    unsigned int *items = witems + wv * kHItemCap;
     float *qtab = wq + wv * 96;
     const bool vec = (reinterpret_cast<uintptr_t>(cb) & 15) == 0;
-    if (tid < kHLimbs) sacc[tid] = 0ull;
-    if (tid == 0) { sflags = 0; grp_ctr = 0; }
+    const bool one_shot = vec && NC <= CH;
     FX3D_PROBE_MARK(0);
 
     // ---- bounding box and mean -> centre mu = the MEAN (a stray far point moves the box centre, hardly the mean), largest
     //      |c - mu| cinf, power-of-two scale sc with cinf*sc in [64,128): seven binades of fp16 range above 1, so that a bulk
     //      much smaller than the farthest point keeps its fp16 pieces out of the subnormals; |c~|^2 < 3 * 2^14 fits fp16 ----
-    float mu[3], cinf = 0.0f, glo[3], ginv[3];
+    float mu[3], cinf = 0.0f;
     bool allfin = true;
     const int nv = vec ? NC / 4 : 0;
-    float ax[4], ay[4], az[4];  // a one-chunk cloud: this thread's four points stay in registers for the image
     {
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sm3[3] = {0.f, 0.f, 0.f};
         for (int q4 = tid; q4 < nv; q4 += kHThreads) {
+            float ax[4], ay[4], az[4];
             load4pts(cb, q4 * 4, ax, ay, az);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -514,6 +403,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 mn[1] = fminf(mn[1], ay[e]); mx[1] = fmaxf(mx[1], ay[e]);
                 mn[2] = fminf(mn[2], az[e]); mx[2] = fmaxf(mx[2], az[e]);
                 sm3[0] = sm3[0] + ax[e]; sm3[1] = sm3[1] + ay[e]; sm3[2] = sm3[2] + az[e];
+                if (one_shot) {  // park the raw point in its own first piece
+                    const int pt = q4 * 4 + e;
+                    imgf[((pt >> 5) * 2) * 32 + (pt & 31)] = float4{ax[e], ay[e], az[e], 0.0f};
+                }
             }
         }
         for (int pt = nv * 4 + tid; pt < NC; pt += kHThreads) {
@@ -547,32 +440,37 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             cinf = fmaxf(cinf, fmaxf(hi - mu[d], mu[d] - lo));
             // a NaN or +-Inf coordinate makes the coordinate sum non-finite (fminf / fmaxf above skip NaNs)
             allfin = allfin && fabsf(st) < INFINITY;
-            glo[d] = lo;
-            ginv[d] = hi;  // (the box for now; turned into the sort grid below)
         }
         cinf = cinf * 1.000001f;
     }
     // ---- robust range: a few points far from the bulk must not set the scale (the bulk would sink below fp16's resolution and
-    //      the whole cloud fall back to exact scans).  rng = min(cinf, 16 x the mean max-norm deviation from mu): clouds without
-    //      outliers keep rng = cinf (uniform box: 16 x 0.375 of the half width; Gaussian: 21 sigma); candidates beyond the
-    //      range ("far") are left out of the filter (norm = +inf) and compared exactly by every query (side list below). ----
+    //      the whole cloud fall back to exact scans: one point 10^5 x out cost 11 x the uniform time in round 1).
+    //      rng = min(cinf, 16 x the mean max-norm deviation from mu): clouds without outliers keep rng = cinf (uniform box:
+    //      16 x 0.375 of the half width; Gaussian: 21 sigma); candidates beyond the range ("far") are left out of the filter
+    //      (norm = +inf) and compared exactly by every query through a side list of at most kHFarCap entries per chunk. ----
     float rng = cinf;
     if (allfin && cinf < 1.0e16f) {
         float dev = 0.0f;
-        if (vec && NC <= CH) {
-            if (tid < nv) {
+        for (int q4 = tid; q4 < nv; q4 += kHThreads) {
+            float ax[4], ay[4], az[4];
+            if (one_shot) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dev += fmaxf(fmaxf(fabsf(ax[e] - mu[0]), fabsf(ay[e] - mu[1])), fabsf(az[e] - mu[2]));
+                for (int e = 0; e < 4; ++e) {
+                    const int pt = q4 * 4 + e;
+                    const float4 r = imgf[((pt >> 5) * 2) * 32 + (pt & 31)];  // parked by this thread above
+                    ax[e] = r.x; ay[e] = r.y; az[e] = r.z;
+                }
+            } else {
+                load4pts(cb, q4 * 4, ax, ay, az);
             }
-            for (int pt = nv * 4 + tid; pt < NC; pt += kHThreads)
-                dev += fmaxf(fmaxf(fabsf(cb[(size_t)pt * 3] - mu[0]), fabsf(cb[(size_t)pt * 3 + 1] - mu[1])), fabsf(cb[(size_t)pt * 3 + 2] - mu[2]));
-        } else {
-            for (int pt = tid; pt < NC; pt += kHThreads)
-                dev += fmaxf(fmaxf(fabsf(cb[(size_t)pt * 3] - mu[0]), fabsf(cb[(size_t)pt * 3 + 1] - mu[1])), fabsf(cb[(size_t)pt * 3 + 2] - mu[2]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dev += fmaxf(fmaxf(fabsf(ax[e] - mu[0]), fabsf(ay[e] - mu[1])), fabsf(az[e] - mu[2]));
         }
+        for (int pt = nv * 4 + tid; pt < NC; pt += kHThreads)
+            dev += fmaxf(fmaxf(fabsf(cb[(size_t)pt * 3] - mu[0]), fabsf(cb[(size_t)pt * 3 + 1] - mu[1])), fabsf(cb[(size_t)pt * 3 + 2] - mu[2]));
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) dev = dev + __shfl_xor(dev, m, 64);
-        __syncthreads();  // (red is read above)
+        __syncthreads();  // (red was read above)
         if (lane == 0) red[wv] = dev;
         __syncthreads();
         float tot = red[0];
@@ -581,14 +479,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         const float r16 = 16.0f * (tot / (float)NC);
         if (r16 > 0.0f && r16 < cinf) rng = r16;
     }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {  // sort grid: the box clipped to the robust range around mu (any grid is correct; cells clamp)
-        const float lo = fmaxf(glo[d], mu[d] - rng), hi = fminf(ginv[d], mu[d] + rng);
-        glo[d] = lo;
-        ginv[d] = hi > lo ? (float)kHAxisBins / (hi - lo) : 0.0f;
-    }
-    // not sane (non-finite or huge coordinates): the filter is unusable, every query of the block scans every block
-    // exactly, in the isless order (a finite cloud with cinf < 1e16 never produces an infinite or NaN distance
+    // not sane (non-finite or huge coordinates): the filter is unusable, every query of the block scans every lane
+    // tile exactly, in the isless order (a finite cloud with cinf < 1e16 never produces an infinite or NaN distance
     // to a query inside the fp16 range)
     const bool sane = allfin && cinf < 1.0e16f;  // usable queries lie within 234 cinf of the centre: 3 (235 cinf)^2 stays finite
     float sc = 1.0f;
@@ -597,363 +489,139 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         (void)frexpf(rng, &e);  // rng = m 2^e, m in [0.5,1)
         sc = ldexpf(1.0f, 7 - e);
     }
+    // pieces of candidate `pt` (index within the chunk); a far one leaves the filter (t = +inf) for the side list
+    auto pieces = [&](float x, float y, float z, int pt, h8 &p0, h8 &p1) {
+        const float sx = (x - mu[0]) * sc, sy = (y - mu[1]) * sc, sz = (z - mu[2]) * sc;
+        const bool far = sane && !(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)) < 128.0f);
+        make_pieces(far ? 0.f : sx, far ? 0.f : sy, far ? 0.f : sz, p0, p1);
+        if (far) {
+            p1[1] = (_Float16)INFINITY;
+            const int f = atomicAdd(&nfar, 1);
+            if (f < kHFarCap) farlist[f] = (unsigned short)pt;
+        }
+    };
     FX3D_PROBE_MARK(1);
 
-    // queries of this block: by cell range of the WHOLE direction's queries when that is balanced (spatial), else the index
-    // range [tile * tpb * 512, ...) sorted locally.  Either way `qperm[slot]` names the query of sorted slot `slot`.
-    const int jfirst = split * CH, jstep = p.nsplit * CH;
-    const bool single_chunk = jfirst + jstep >= NC;  // one chunk per block: query groups go to whichever wave is free
-    const int share = p.tpb * QB, cap = share + kHQSlack;
-    // (a block that walks several chunks keeps one query group per wave across them: no room for an uneven share)
-    // small clouds stay in index order: the sort's barriers cost more than the tiles it saves (C1: 1024 points)
-    const bool sorted = sane && NC >= kHSortMin;
-    const bool try_spatial = sorted && T > 1 && NQ <= 65536 && single_chunk;
-    if (sorted) {
-        // per-axis quantile slabs from the WHOLE candidate cloud (the same tables in every block of this direction, for
-        // every chunk, and for the queries: the cell of a point is a function of the cloud alone)
-        if (tid < 3 * kHAxisBins) axh[tid] = 0;
-        __syncthreads();
-        auto count = [&](float x, float y, float z) {
-            atomicAdd(&axh[min(kHAxisBins - 1, max(0, (int)((x - glo[0]) * ginv[0])))], 1u);
-            atomicAdd(&axh[kHAxisBins + min(kHAxisBins - 1, max(0, (int)((y - glo[1]) * ginv[1])))], 1u);
-            atomicAdd(&axh[2 * kHAxisBins + min(kHAxisBins - 1, max(0, (int)((z - glo[2]) * ginv[2])))], 1u);
-        };
-        if (vec && NC <= CH) {
-            if (tid < nv) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) count(ax[e], ay[e], az[e]);
-            }
-            for (int pt = nv * 4 + tid; pt < NC; pt += kHThreads) count(cb[(size_t)pt * 3], cb[(size_t)pt * 3 + 1], cb[(size_t)pt * 3 + 2]);
-        } else {
-            for (int pt = tid; pt < NC; pt += kHThreads) count(cb[(size_t)pt * 3], cb[(size_t)pt * 3 + 1], cb[(size_t)pt * 3 + 2]);
-        }
-        __syncthreads();
-        if (wv < 3) {  // one wave per axis: slab of a bin = floor(8 x points below the bin / N)
-            const unsigned int v = axh[wv * kHAxisBins + lane];
-            unsigned int incl = v;
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) {
-                const unsigned int o = (unsigned int)__shfl_up((int)incl, m, 64);
-                if (lane >= m) incl += o;
-            }
-            const unsigned long long below = incl - v;
-            axlut[wv * kHAxisBins + lane] = (unsigned char)min(kHGrid - 1, (int)(below * kHGrid / (unsigned long long)NC));
-        }
-        __syncthreads();
-    }
-    int q_first = tile * share;                                     // index-range form: qperm holds q - q_first
-    int nq_blk = (NQ - q_first) < share ? (NQ - q_first) : share;
-    if (nq_blk < 0) nq_blk = 0;
-    bool spatial = false;
-
-    float qr[3], da = 0.0f;  // band: a block qualifies while its minimum <= best * kBandB1 + da
-    float qsx = 0.f, qsy = 0.f, qsz = 0.f, qnb = 0.f, qfl = 0.f;  // scaled query, (1 + beta)|q~|^2 and the floor of its bound
+    float qr[3], da = 0.0f;  // band: a tile qualifies while its minimum <= best * kBandB1 + da
     int qi = 0;
-    bool qok = true, qvalid = false;
+    bool qok = true;
     h8 bq;
+    double acc = 0.0;
 
+    const int jfirst = split * CH, jstep = p.nsplit * CH;
     for (int j0 = jfirst; j0 < NC; j0 += jstep) {
         const int cnt = (NC - j0) < CH ? (NC - j0) : CH;
-        const int cnt_pad = (cnt + 31) / 32 * 32;
-        const int nblk = cnt_pad / 32;
-        const bool first = j0 == jfirst;
+        const int cnt_pad = (cnt + 32 * kHLT - 1) / (32 * kHLT) * (32 * kHLT);
         __syncthreads();
         if (tid == 0) nfar = 0;
-        // ---- counting sort of the chunk (and, the first time, of the queries) by Morton cell ---------------------------
-        if (sorted) {
-            for (int i = tid; i < 2 * kHCells; i += kHThreads) hist[i] = 0;
-            __syncthreads();
-        }
-        const bool have_regs = vec && NC <= CH && tid < nv;  // the four points loaded for the bounding box
-        int cell[4];
-        const int p0 = 4 * tid;
-        if (!have_regs) {
+        __syncthreads();
+        // ---- stage the fp16 split image ------------------------------------------------------------------
+        if (one_shot) {
+            for (int q4 = tid; q4 < nv; q4 += kHThreads) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int pt = p0 + e < cnt ? p0 + e : cnt - 1;
-                const float *src = cb + (size_t)(j0 + pt) * 3;
-                ax[e] = src[0]; ay[e] = src[1]; az[e] = src[2];
+                for (int e = 0; e < 4; ++e) {
+                    const int pt = q4 * 4 + e;
+                    const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
+                    const float4 r = imgf[i0];
+                    h8 p0, p1;
+                    pieces(r.x, r.y, r.z, pt, p0, p1);
+                    imgp[i0] = p0;
+                    imgp[i0 + 32] = p1;
+                }
             }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            cell[e] = 0;
-            if (sorted && p0 + e < cnt) {
-                cell[e] = morton_cell(ax[e], ay[e], az[e], glo, ginv, axlut);
-                atomicAdd(&hist[cell[e]], 1u);
+            for (int pt = nv * 4 + tid; pt < cnt_pad + 64; pt += kHThreads) {
+                const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
+                h8 p0, p1;
+                if (pt < cnt) {
+                    const float *src = cb + (size_t)pt * 3;
+                    pieces(src[0], src[1], src[2], pt, p0, p1);
+                } else {  // padding: n1 = +inf => t = +inf, never within any band
+                    make_pieces(0.f, 0.f, 0.f, p0, p1);
+                    p1[1] = (_Float16)INFINITY;
+                }
+                imgp[i0] = p0;
+                imgp[i0 + 32] = p1;
             }
-        }
-        if (!sorted) {
-            if (first) for (int ql = tid; ql < nq_blk; ql += kHThreads) qperm[ql] = (unsigned short)ql;  // index order
-            __syncthreads();  // (nfar is zero before the image's far candidates count up)
         } else {
-        if (first) {  // query counts: all NQ (spatial) or this block's index range
-            const int n = try_spatial ? NQ : nq_blk, base = try_spatial ? 0 : q_first;
-            for (int ql = tid; ql < n; ql += kHThreads) {
-                const float *src = qb + (size_t)(base + ql) * 3;
-                const int qc = morton_cell(src[0], src[1], src[2], glo, ginv, axlut);  // (clamped: queries may lie outside the box)
-                atomicAdd(&qhist[qc], 1u);
+            for (int pt = tid; pt < cnt_pad + 64; pt += kHThreads) {
+                const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
+                h8 p0, p1;
+                if (pt < cnt) {
+                    const float *src = cb + (size_t)(j0 + pt) * 3;
+                    pieces(src[0], src[1], src[2], pt, p0, p1);
+                } else {
+                    make_pieces(0.f, 0.f, 0.f, p0, p1);
+                    p1[1] = (_Float16)INFINITY;
+                }
+                imgp[i0] = p0;
+                imgp[i0 + 32] = p1;
             }
         }
         __syncthreads();
-        scan_cells2(hist, wave_tot, tid, lane, wv);
-        if (first && try_spatial) {
-            // cell ranges: block t owns the cells whose first rank lies in [t, t + 1) * ceil(NQ / T); the ranges depend on the
-            // counts alone, so every block of this direction derives the same split.  Used if no block gets more than `cap`.
-            const int target = (NQ + T - 1) / T;
-            auto first_cell = [&](int rank) {  // smallest cell whose exclusive offset is >= rank (kHCells if none)
-                int lo = 0, hi = kHCells;
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)qhist[mid] >= rank) hi = mid; else lo = mid + 1; }
-                return lo;
-            };
-            int over = 0;
-            for (int t = tid; t < T; t += kHThreads) {
-                const int c0 = t == 0 ? 0 : first_cell(t * target), c1 = t == T - 1 ? kHCells : first_cell((t + 1) * target);
-                const int r0 = c0 < kHCells ? (int)qhist[c0] : NQ, r1 = c1 < kHCells ? (int)qhist[c1] : NQ;
-                over |= (r1 - r0 > cap) ? 1 : 0;
-                if (t == tile) { part[0] = c0; part[1] = c1; part[2] = r0; part[3] = r1 - r0; }
-            }
-            spatial = __syncthreads_or(over) == 0;
-            if (spatial) { q_first = 0; nq_blk = part[3]; }
-        }
-        if (first) {
-            if (spatial) {
-                const int c0 = part[0], c1 = part[1], r0 = part[2];
-                for (int ql = tid; ql < NQ; ql += kHThreads) {
-                    const float *src = qb + (size_t)ql * 3;
-                    const int qc = morton_cell(src[0], src[1], src[2], glo, ginv, axlut);
-                    if (qc >= c0 && qc < c1) qperm[(int)atomicAdd(&qhist[qc], 1u) - r0] = (unsigned short)ql;
-                }
-            } else {
-                if (try_spatial) {  // unbalanced: recount this block's index range (rare)
-                    __syncthreads();
-                    for (int i = tid; i < kHCells; i += kHThreads) qhist[i] = 0;
-                    __syncthreads();
-                    for (int ql = tid; ql < nq_blk; ql += kHThreads) {
-                        const float *src = qb + (size_t)(q_first + ql) * 3;
-                        atomicAdd(&qhist[morton_cell(src[0], src[1], src[2], glo, ginv, axlut)], 1u);
-                    }
-                    __syncthreads();
-                    scan_cells2(hist, wave_tot, tid, lane, wv, true);  // (the candidates' cursors stay as they are)
-                }
-                for (int ql = tid; ql < nq_blk; ql += kHThreads) {
-                    const float *src = qb + (size_t)(q_first + ql) * 3;
-                    const int qc = morton_cell(src[0], src[1], src[2], glo, ginv, axlut);
-                    qperm[atomicAdd(&qhist[qc], 1u)] = (unsigned short)ql;
-                }
-            }
-        }
-        }  // sorted
-        // ---- fp16 split image at the sorted positions ----------------------------------------------------------------
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (p0 + e < cnt) {
-                const int pos = sorted ? (int)atomicAdd(&hist[cell[e]], 1u) : p0 + e;
-                h8 q0, q1;
-                const float sx = (ax[e] - mu[0]) * sc, sy = (ay[e] - mu[1]) * sc, sz = (az[e] - mu[2]) * sc;
-                const bool far = sane && !(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)) < 128.0f);
-                make_pieces(far ? 0.f : sx, far ? 0.f : sy, far ? 0.f : sz, (unsigned int)(p0 + e), q0, q1);
-                if (far) {  // out of the filter (t = +inf), onto the side list
-                    q1[1] = (_Float16)INFINITY;
-                    const int f = atomicAdd(&nfar, 1);
-                    if (f < kHFarCap) farlist[f] = (unsigned short)(p0 + e);
-                }
-                const int i0 = ((pos >> 5) * 2) * 32 + (pos & 31);
-                imgp[i0] = q0;
-                imgp[i0 + 32] = q1;
-            }
-        }
-        if (tid < cnt_pad - cnt) {  // padding rows: n1 = +inf => t = +inf, never within any band; tag = cnt: not a candidate
-            const int pos = cnt + tid;
-            h8 q0, q1;
-            make_pieces(0.f, 0.f, 0.f, (unsigned int)cnt, q0, q1);
-            q1[1] = (_Float16)INFINITY;
-            const int i0 = ((pos >> 5) * 2) * 32 + (pos & 31);
-            imgp[i0] = q0;
-            imgp[i0 + 32] = q1;
-        }
-        __syncthreads();
-        // ---- bounding box of every 32-candidate block (eight threads per block, four rows each) ----------------------
-        if (sorted && tid < nblk * 8) {
-            const int bk = tid >> 3, sub = tid & 7;
-            float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const h8 a0 = imgp[(bk * 2) * 32 + sub * 4 + r], a1 = imgp[(bk * 2 + 1) * 32 + sub * 4 + r];
-                if ((float)a1[1] < INFINITY) {  // not a padding row
-                    const float v[3] = {(float)a0[0] + (float)a0[2], (float)a0[3] + (float)a0[5], (float)a0[6] + (float)a1[0]};
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) { lo3[d] = fminf(lo3[d], v[d]); hi3[d] = fmaxf(hi3[d], v[d]); }
-                }
-            }
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-#pragma unroll
-                for (int m = 1; m < 8; m <<= 1) {
-                    lo3[d] = fminf(lo3[d], __shfl_xor(lo3[d], m, 64));
-                    hi3[d] = fmaxf(hi3[d], __shfl_xor(hi3[d], m, 64));
-                }
-            }
-            if (sub == 0) {
-#pragma unroll
-                for (int d = 0; d < 3; ++d) { boxes[bk * 6 + d] = lo3[d]; boxes[bk * 6 + 3 + d] = hi3[d]; }
-            }
-        }
-        __syncthreads();
-        FX3D_PROBE_MARK(first ? 2 : 6);
+        FX3D_PROBE_MARK(j0 == jfirst ? 2 : 6);
 
-        const int nf = nfar;                     // far candidates of this chunk (valid after the barrier above)
-        const bool far_ok = nf <= kHFarCap;      // more than the side list holds: this chunk's filter is not used
-        const int ngroups = (nq_blk + 31) / 32;
-        auto next_group = [&]() -> int {
-            int g = 0;
-            if (lane == 0) g = atomicAdd(&grp_ctr, 1);
-            return __builtin_amdgcn_readfirstlane(g);
-        };
-        // a block that walks several chunks keeps the group of a wave fixed (its result slots persist across the chunks)
-        int g = single_chunk ? next_group() : wv;
-        bool first_group = true;
-        while (g < ngroups) {
-            if (first) {
-                const int qs = g * 32 + jq;   // slot in the sorted order
-                qvalid = qs < nq_blk;
-                qi = q_first + qperm[qvalid ? qs : nq_blk - 1];
+        const int nf = nfar;                 // far candidates of this chunk (valid after the barrier above)
+        const bool far_ok = nf <= kHFarCap;  // more than the side list holds: this chunk's filter is not used
+        for (int tp = 0; tp < p.tpb; ++tp) {
+            if ((tile * p.tpb + tp) * QB >= NQ) break;  // uniform
+            if (j0 == jfirst) {
+                qi = (tile * p.tpb + tp) * QB + wv * 32 + jq;
+                const int qc = qi < NQ ? qi : NQ - 1;
 #pragma unroll
-                for (int d = 0; d < 3; ++d) qr[d] = qb[(size_t)qi * 3 + d];
-                qsx = (qr[0] - mu[0]) * sc; qsy = (qr[1] - mu[1]) * sc; qsz = (qr[2] - mu[2]) * sc;
-                const float m0 = -2.0f * qsx, m1 = -2.0f * qsy, m2 = -2.0f * qsz;
+                for (int d = 0; d < 3; ++d) qr[d] = qb[(size_t)qc * 3 + d];
+                const float m0 = -2.0f * ((qr[0] - mu[0]) * sc), m1 = -2.0f * ((qr[1] - mu[1]) * sc),
+                            m2 = -2.0f * ((qr[2] - mu[2]) * sc);
                 const float S = (fabsf(m0) + fabsf(m1)) + fabsf(m2);
                 qok = S < 3.0e4f;  // inside the fp16 range (also false for NaN)
                 const float qn = 0.25f * ((m0 * m0 + m1 * m1) + m2 * m2);  // |q~|^2
                 da = kBandA * qn + 0x1p-24f * (S + 4.0f);
-                qnb = qn + (kBetaC + 0x1p-20f) * qn;    // (1 + beta)|q~|^2, + its own rounding
-                qfl = 0x1p-23f * (S + 4.0f);             // the filter's floor, doubled
                 _Float16 hx, lx, hy, ly, hz, lz;
                 split2h(qok ? m0 : 0.f, hx, lx); split2h(qok ? m1 : 0.f, hy, ly); split2h(qok ? m2 : 0.f, hz, lz);
                 const _Float16 one = (_Float16)1.0f, z = (_Float16)0.0f;
                 bq = hh == 0 ? h8{hx, lx, hx, hy, ly, hy, hz, lz} : h8{hz, one, one, one, lx, ly, lz, z};
-                __builtin_amdgcn_wave_barrier();  // (the previous group's result slots have been read)
                 if (hh == 0) {
                     qres[jq] = ~0ull;
                     qtab[jq * 3 + 0] = qr[0]; qtab[jq * 3 + 1] = qr[1]; qtab[jq * 3 + 2] = qr[2];
                 }
             }
 
-            float best = INFINITY, ft[kHFifo];
-            unsigned int fis = 0xffffffffu;  // the FIFO's block ids, one byte each (0xff = empty): a shift register
+            float best = INFINITY, tm = INFINITY, ft[kHFifo];
+            unsigned int fis = 0xffffffffu;  // the FIFO's lane-tile ids, one byte each (0xff = empty): a shift register
 #pragma unroll
             for (int s = 0; s < kHFifo; ++s) ft[s] = INFINITY;
+
+            // ---- main loop, software-pipelined by one 32-candidate block -----------------------------------
+            // (the image carries two padding blocks behind cnt_pad, so the prefetch never needs a clamp
+            //  and every ds_read_b128 is base + immediate offset: no address VALU in the loop)
+            const int nblk = cnt_pad / 32;  // multiple of kHLT
             f32x16 zero;
 #pragma unroll
             for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
             const h8 *pa = imgp + hh * 32 + jq;
-
-            // ---- which blocks can hold a nearest neighbour: squared distance box to box, rounded DOWN ------------------
-            //      (coordinates are < 2^7 with Float32 roundings of 2^-17 and a box built from the 22-bit split pieces: a
-            //      margin of 2^-12 per axis covers both boxes; (1 - 2^-20) the squares and their sum)
-            float lbv[2];
-            {
-            // the wave's query box (lanes beyond the block's queries repeat its last query)
-            const float wqlo[3] = {wave_min_f(qsx), wave_min_f(qsy), wave_min_f(qsz)};
-            const float wqhi[3] = {wave_max_f(qsx), wave_max_f(qsy), wave_max_f(qsz)};
+            f32x16 accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[0], bq, zero, 0, 0, 0);
+            h8 a_nxt = pa[64];
+            pa += 128;  // -> block 2
+            for (int lt = 0; lt < nblk / kHLT; ++lt) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int bk = lane + 64 * i;
-                lbv[i] = INFINITY;
-                if (bk < nblk) {
-                    float s2 = 0.0f;
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        const float gg = fmaxf(boxes[bk * 6 + d] - wqhi[d], wqlo[d] - boxes[bk * 6 + 3 + d]) - 0x1p-12f;
-                        const float gp = fmaxf(gg, 0.0f);
-                        s2 = s2 + gp * gp;
-                    }
-                    lbv[i] = s2 - 0x1p-20f * s2;  // (an all-padding block has an empty box: +inf, never visited)
+                for (int bb = 0; bb < kHLT; ++bb) {
+                    const h8 a_n2 = pa[bb * 64];
+                    const f32x16 accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_nxt, bq, zero, 0, 0, 0);
+                    // fold 16 values: 8 x v_min3, depth 3
+                    const float t0 = min3f(accC[0], accC[1], accC[2]), t1 = min3f(accC[3], accC[4], accC[5]);
+                    const float t2 = min3f(accC[6], accC[7], accC[8]), t3 = min3f(accC[9], accC[10], accC[11]);
+                    const float t4 = min3f(accC[12], accC[13], accC[14]);
+                    const float t5 = min3f(t0, t1, t2), t6 = min3f(t3, t4, accC[15]);
+                    tm = bb == 0 ? vmin(t5, t6) : min3f(tm, t5, t6);  // first block of the lane tile restarts tm
+                    accC = accN;
+                    a_nxt = a_n2;
                 }
-            }
-            }
-            const bool prune = sorted && far_ok && nblk > 2 && __ballot(qvalid && !qok) == 0;  // a query outside the fp16 range has no bound
-            unsigned long long todo[2], seen[2] = {0ull, 0ull};
-            todo[0] = uni64(__ballot(lane < nblk));
-            todo[1] = uni64(__ballot(lane + 64 < nblk));
-            float wbound = INFINITY;  // largest upper bound of a nearest distance over the wave's queries (scaled units)
-            if (!first && prune) {    // later chunks: the exact result of the earlier ones bounds the search
-                const unsigned int hi = (unsigned int)(qres[jq] >> 32);
-                float ub = INFINITY;
-                if (hi < 0x7f800000u) { const float dprev = __builtin_bit_cast(float, hi) * sc * sc; ub = dprev + 0x1p-19f * dprev; }
-                wbound = wave_max_f(ub);
-            }
-            bool pr = prune;
-            for (;;) {
-                unsigned long long mk[2];
-                if (!pr) {  // no bound to prune with: every block not yet visited
-                    mk[0] = todo[0] & ~seen[0]; mk[1] = todo[1] & ~seen[1];
-                } else if (wbound < INFINITY) {
-                    mk[0] = __ballot(lbv[0] <= wbound) & todo[0] & ~seen[0];
-                    mk[1] = __ballot(lbv[1] <= wbound) & todo[1] & ~seen[1];
-                } else {  // no bound yet: the blocks that overlap the query box, or else the nearest one
-                    mk[0] = __ballot(lbv[0] <= 0.0f) & todo[0];
-                    mk[1] = __ballot(lbv[1] <= 0.0f) & todo[1];
-                    if ((mk[0] | mk[1]) == 0ull) {
-                        const float lmin = wave_min_f(fminf(lbv[0], lbv[1]));
-                        const unsigned long long e0 = __ballot(lbv[0] == lmin) & todo[0], e1 = __ballot(lbv[1] == lmin) & todo[1];
-                        if (e0) mk[0] = e0 & (0ull - e0);
-                        else if (e1) mk[1] = e1 & (0ull - e1);
-                        else { mk[0] = todo[0]; mk[1] = todo[1]; }  // (no comparable box: everything)
-                    }
-                }
-                mk[0] = uni64(mk[0]); mk[1] = uni64(mk[1]);
-                if ((mk[0] | mk[1]) == 0ull) break;
-                seen[0] |= mk[0]; seen[1] |= mk[1];
-                // ---- filter loop over the selected blocks, two per turn, the next pair's operands in flight ----------------
-#pragma unroll 1
-                for (int w = 0; w < 2; ++w) {
-                    unsigned long long m = w ? mk[1] : mk[0];
-                    if (!m) continue;
-                    const h8 *pw = pa + w * (64 * 64);
-                    int b0 = __builtin_ctzll(m); m &= m - 1;
-                    int b1 = m ? __builtin_ctzll(m) : -1; if (m) m &= m - 1;
-                    h8 a0 = pw[b0 * 64], a1 = pw[(b1 >= 0 ? b1 : b0) * 64];
-                    for (;;) {
-                        const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq, zero, 0, 0, 0);
-                        const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq, zero, 0, 0, 0);
-                        const int c0 = b0, c1 = b1;
-                        const bool more = m != 0ull;
-                        if (more) {
-                            b0 = __builtin_ctzll(m); m &= m - 1;
-                            b1 = m ? __builtin_ctzll(m) : -1; if (m) m &= m - 1;
-                            a0 = pw[b0 * 64];
-                            a1 = pw[(b1 >= 0 ? b1 : b0) * 64];
-                        }
+                pa += kHLT * 64;
+                const bool qual = tm <= __builtin_fmaf(best, kBandB1, da);
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const f32x16 &ac = u ? acc1 : acc0;
-                            const int cb_ = u ? c1 : c0;
-                            // fold 16 values: 8 x v_min3, depth 3
-                            const float t0 = min3f(ac[0], ac[1], ac[2]), t1 = min3f(ac[3], ac[4], ac[5]);
-                            const float t2 = min3f(ac[6], ac[7], ac[8]), t3 = min3f(ac[9], ac[10], ac[11]);
-                            const float t4 = min3f(ac[12], ac[13], ac[14]);
-                            const float t5 = min3f(t0, t1, t2), t6 = min3f(t3, t4, ac[15]);
-                            float tm = vmin(t5, t6);
-                            if (u) tm = c1 >= 0 ? tm : INFINITY;  // an odd count: the pair's second block repeats the first, unseen
-                            const bool qual = tm <= __builtin_fmaf(best, kBandB1, da);
-#pragma unroll
-                            for (int s = kHFifo - 1; s > 0; --s) ft[s] = qual ? ft[s - 1] : ft[s];
-                            ft[0] = qual ? tm : ft[0];
-                            fis = qual ? ((fis << 8) | (unsigned int)(cb_ + 64 * w)) : fis;
-                            best = vmin(best, tm);
-                        }
-                        if (!more) break;
-                    }
-                }
-                if (!pr) break;
-                // ---- the bound after this phase: d~^2 of the nearest candidate <= Umin + (1 + beta)|q~|^2 + floor (error model
-                //      above), plus the roundings of this sum and of the oracle's own distance (2^-19 of the magnitudes) --------
-                const float m = fminf(best, __shfl_xor(best, 32, 64));
-                const float ub = ((m + qnb) + qfl) + 0x1p-19f * (fabsf(m) + qnb);
-                const float nb = wave_max_f(ub);
-                if (nb < INFINITY) wbound = fminf(wbound, nb);
-                else pr = false;  // a query without a finite filter value: no bound, the next turn takes every block left
+                for (int s = kHFifo - 1; s > 0; --s) ft[s] = qual ? ft[s - 1] : ft[s];
+                ft[0] = qual ? tm : ft[0];
+                fis = qual ? ((fis << 8) | (unsigned int)lt) : fis;  // one v_lshl_or + one v_cndmask
+                best = vmin(best, tm);
             }
             int fi[kHFifo];
 #pragma unroll
@@ -961,21 +629,22 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 const unsigned int id = (fis >> (8 * s)) & 0xffu;
                 fi[s] = id == 0xffu ? -1 : (int)id;
             }
-            if (first_group) FX3D_PROBE_MARK(3);
+            FX3D_PROBE_MARK(tp == 0 ? 3 : 7);
 
-            // ---- exact phase, wave-cooperative ------------------------------------------------------------------------
+            // ---- exact phase, wave-cooperative ----------------------------------------------------------------
             {
                 const float m = fminf(best, __shfl_xor(best, 32, 64));
                 const float thr1 = __builtin_fmaf(m, kBandB1, da), thr2 = __builtin_fmaf(thr1, kBandB1, da);
                 const bool usable = sane && far_ok && qok && m < INFINITY;  // filter meaningful for this query
-                const bool slow = !usable || !(ft[kHFifo - 1] > thr2);  // FIFO may have dropped a block in band
+                const bool slow = !usable || !(ft[kHFifo - 1] > thr2);  // FIFO may have dropped a tile in band
                 // Common case (no slow lane in the wave): the items are the FIFO entries within the band.
                 // Rare case (degenerate / near-tied data, unusable filter): the wave re-runs its filter pass
-                // with the now known threshold and enqueues exactly the blocks within the band (every
-                // block for lanes whose filter is unusable), draining the list whenever it is full.
+                // with the now known threshold and enqueues exactly the lane tiles within the band (every
+                // tile for lanes whose filter is unusable), draining the list whenever it is full.
                 const bool retry = __ballot(slow) != 0;
                 // a NaN distance needs a non-finite cloud or a non-finite query (wave-uniform switch of the task code)
                 const bool nonfinite = !sane || __ballot(!(fabsf(qr[0]) + fabsf(qr[1]) + fabsf(qr[2]) < INFINITY)) != 0;
+                const int nlt = nblk / kHLT;
                 int lt2 = 0;
                 do {
                     int nitems = 0;
@@ -987,62 +656,80 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                             if (bal) {
                                 const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
                                                          __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
-                                if (qual) items[pos] = (unsigned short)((jq << 9) | (hh << 8) | fi[s]);
+                                if (qual) items[pos] = ((unsigned int)jq << 16) | ((unsigned int)hh << 12) | (unsigned int)fi[s];
                                 nitems += __builtin_popcountll(bal);  // <= 64 * kHFifo == kHItemCap
                             }
                         }
-                        lt2 = nblk;
+                        lt2 = nlt;
                     } else {
+                        const h8 *pb = imgp + hh * 32 + jq;
 #pragma unroll 1
-                        for (; lt2 < nblk && nitems <= kHItemCap - 64; ++lt2) {
-                            // (blocks this wave's bound excluded hold nothing inside a usable query's band)
-                            const bool was_seen = (lt2 < 64 ? seen[0] >> lt2 : seen[1] >> (lt2 - 64)) & 1ull;
-                            if (!was_seen) continue;
-                            const f32x16 av = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[lt2 * 64], bq, zero, 0, 0, 0);
+                        for (; lt2 < nlt && nitems <= kHItemCap - 64; ++lt2) {
                             float t2 = INFINITY;
 #pragma unroll
-                            for (int r = 0; r < 16; r += 2) t2 = min3f(t2, av[r], av[r + 1]);
+                            for (int bb = 0; bb < kHLT; ++bb) {
+                                const f32x16 av = __builtin_amdgcn_mfma_f32_32x32x16_f16(pb[(lt2 * kHLT + bb) * 64], bq, zero, 0, 0, 0);
+#pragma unroll
+                                for (int r = 0; r < 16; r += 2) t2 = min3f(t2, av[r], av[r + 1]);
+                            }
                             const bool qual = !usable || t2 <= thr1;
                             const unsigned long long bal = __ballot(qual);
                             if (bal) {
                                 const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
                                                          __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
-                                if (qual) items[pos] = (unsigned short)((jq << 9) | (hh << 8) | lt2);
+                                if (qual) items[pos] = ((unsigned int)jq << 16) | ((unsigned int)hh << 12) | (unsigned int)lt2;
                                 nitems += __builtin_popcountll(bal);
                             }
                         }
                     }
-                    // all 64 lanes share the (item, run-of-4-rows) tasks: the rows' tags name the candidates
+                    // all 64 lanes share the (item, run-of-4-candidates) tasks
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_wave_barrier();
-                    const int ntask = nitems * 4;
+                    const int ntask = nitems * (kHLT * 4);
                     for (int t0 = 0; t0 < ntask; t0 += 64) {
                         const int t = t0 + lane;
                         if (t < ntask) {
-                            const unsigned int it = items[t >> 2];
-                            const int run = t & 3;
-                            const int qs = it >> 9, ih = (it >> 8) & 1, bk = it & 0xff;
-                            const unsigned short *tg = reinterpret_cast<const unsigned short *>(imgp + (bk * 2 + 1) * 32 + 8 * run + 4 * ih) + 7;
-                            const float qq[3] = {qtab[qs * 3], qtab[qs * 3 + 1], qtab[qs * 3 + 2]};
-                            unsigned long long kb = ~0ull;
+                            const unsigned int it = items[t / (kHLT * 4)];
+                            const int run = t % (kHLT * 4);
+                            const int qs = it >> 16, ih = (it >> 12) & 1, tl = it & 0xfff;
+                            const int jl0 = (tl * kHLT + (run >> 2)) * 32 + 8 * (run & 3) + 4 * ih;
+                            float cx[4], cy[4], cz[4];
+                            if (vec && jl0 + 4 <= cnt) {
+                                load4pts(cb, j0 + jl0, cx, cy, cz);
+                            } else {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int jc = tg[r * 8];  // index within the chunk; cnt marks a padding row
-                                if (jc < cnt) {
+                                for (int r = 0; r < 4; ++r) {
+                                    const int jc = jl0 + r < cnt ? jl0 + r : cnt - 1;
                                     const float *src = cb + (size_t)(j0 + jc) * 3;
-                                    const float cc3[3] = {src[0], src[1], src[2]};
-                                    const float dd = sqd<3>(qq, cc3);
-                                    // distances are >= 0, +Inf or (non-finite data only) NaN: the key order is the isless order
-                                    const unsigned int kd = nonfinite ? dist_key(dd) : __builtin_bit_cast(unsigned int, dd);
-                                    const unsigned long long key = ((unsigned long long)kd << 32) | (unsigned int)(j0 + jc);
-                                    kb = key < kb ? key : kb;  // (distance, index): rows are not in index order
+                                    cx[r] = src[0]; cy[r] = src[1]; cz[r] = src[2];
                                 }
                             }
-                            if (kb != ~0ull) atomicMin(&qres[qs], kb);
+                            const float qq[3] = {qtab[qs * 3], qtab[qs * 3 + 1], qtab[qs * 3 + 2]};
+                            unsigned int kb;
+                            int ib = j0 + jl0;  // an all-+Inf run still names a real candidate (its first)
+                            if (!nonfinite) {   // distances are >= 0 or +Inf: float order == key order
+                                float db = INFINITY;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float cc3[3] = {cx[r], cy[r], cz[r]};
+                                    const float dd = sqd<3>(qq, cc3);
+                                    if (jl0 + r < cnt && dd < db) { db = dd; ib = j0 + jl0 + r; }
+                                }
+                                kb = __builtin_bit_cast(unsigned int, db);
+                            } else {            // NaN distances possible: canonical keys, NaN after +Inf
+                                kb = 0xffffffffu;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float cc3[3] = {cx[r], cy[r], cz[r]};
+                                    const unsigned int kd = dist_key(sqd<3>(qq, cc3));
+                                    if (jl0 + r < cnt && kd < kb) { kb = kd; ib = j0 + jl0 + r; }
+                                }
+                            }
+                            if (jl0 < cnt) atomicMin(&qres[qs], ((unsigned long long)kb << 32) | (unsigned int)ib);
                         }
                     }
-                } while (lt2 < nblk);
-                // the far candidates (outside the filter): every query of the group against each of them, exactly
+                } while (lt2 < nlt);
+                // the far candidates (outside the filter): every query of the wave against each of them, exactly
                 if (far_ok) {
                     for (int t = lane; t < 32 * nf; t += 64) {
                         const int qs = t & 31, jc = farlist[t >> 5];
@@ -1055,10 +742,9 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     }
                 }
             }
-            if (first_group) FX3D_PROBE_MARK(4);
-            first_group = false;
+            FX3D_PROBE_MARK(tp == 0 ? 4 : 8);
 
-            if (j0 + jstep >= NC) {  // last chunk of this block: results of this query group
+            if (j0 + jstep >= NC) {  // last chunk of this block: results of this tile pass
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();
                 if (hh == 0) {
@@ -1066,26 +752,21 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     const float dd = __builtin_bit_cast(float, (unsigned int)(r >> 32));
                     const int ii = (int)(unsigned int)r;
                     if (p.nsplit > 1) {  // merge with the other chunk subsets; unpacked by the finalize kernel
-                        if (qvalid) atomicMin(&p.gres[(size_t)c * p.qstride + qi], r);
-                    } else if (qvalid) {
+                        if (qi < NQ) atomicMin(&p.gres[(size_t)c * p.qstride + qi], r);
+                    } else if (qi < NQ) {
                         if (WANT_IDX && idx_out) idx_out[(size_t)b * NQ + qi] = ii;
                         if (dmin_out) dmin_out[(size_t)b * NQ + qi] = dd;
-                        if (p.partials) exact_add(sacc, &sflags, dd);
+                        acc += (double)dd;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            g = single_chunk ? next_group() : ngroups;
         }
     }
     FX3D_PROBE_MARK(11);
     if (p.partials) {
         __shared__ double sm[kHThreads / 64];
-        __shared__ double stot;
-        __syncthreads();
-        if (tid == 0) stot = exact_read(sacc, sflags);
-        __syncthreads();
-        const double tot = stot;
+        const double tot = block_sum<kHThreads>(acc, sm);
         if (!p.ticket) {
             if (tid == 0) p.partials[(size_t)c * p.tiles + tile] = tot;
         } else {
@@ -1325,7 +1006,7 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
     // A block either walks all chunks serially (one pass per block: the per-query slot lives in LDS) or takes
     // ONE chunk of a split run (any number of passes; subsets merge through 64-bit atomicMin slots, +8 us of
     // extra launches).  Few large clouds want many small chunks, many small clouds want passes.
-    const int cmax = kHChunkMax, gran = 32;
+    const int cmax = kHChunkMax, gran = 32 * kHLT;
     const int cminc = (maxc + cmax - 1) / cmax;
     double best = 1e30;
     int b_chunk = (maxc + gran - 1) / gran * gran < cmax ? (maxc + gran - 1) / gran * gran : cmax, b_tpb = 1, b_split = 1;
@@ -1339,7 +1020,6 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
             for (int tpb = 1; tpb <= 8; tpb *= 2) {
                 if (!split && anch > 1 && tpb > 1) continue;
                 if (tpb_env > 0 && tpb != tpb_env && (split || anch == 1)) continue;
-                if (nn1_f16_lds_bytes(ch, tpb) > kHLdsLimit) continue;  // sorted-query table: 2 bytes per query of the block
                 const long long tiles = ((long long)maxc + 512 * tpb - 1) / (512 * tpb);
                 const long long blocks = 2ll * B * tiles * (split ? anch : 1);
                 const double per_chunk = 5.0 * ch / 4096.0 + 0.5 + tpb * (9.7 * ch / 4096.0 + 0.8);
@@ -1353,7 +1033,7 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
     pl.chunk = b_chunk;
     pl.tpb = b_tpb;
     pl.nsplit = b_split;
-    pl.lds_bytes = nn1_f16_lds_bytes(pl.chunk, pl.tpb);
+    pl.lds_bytes = (size_t)pl.chunk * 8 * sizeof(float) + kHScratchBytes;
     const int per_block3 = 512 * pl.tpb;
     pl.tiles_x = (N + per_block3 - 1) / per_block3;
     pl.tiles_y = (M + per_block3 - 1) / per_block3;
@@ -1371,7 +1051,7 @@ fx3d_status launch_small(const Nn1Params &p, const Plan &pl, hipStream_t st) {
         if (DIM == 3) {
             // > 64 KiB of dynamic LDS needs an explicit opt-in (static LDS of the kernel: < 1 KiB)
             const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&nn1_f16_kernel<WANT_IDX>),
-                                                       (int)kHLdsLimit, "nn1_f16_kernel");
+                                                       (int)(kHChunkMax * 32 + kHScratchBytes), "nn1_f16_kernel");
             if (arc != FX3D_OK) return arc;
             hipLaunchKernelGGL((nn1_f16_kernel<WANT_IDX>), dim3(pl.grid), dim3(kHThreads), pl.lds_bytes, st, p);
         }
