@@ -450,34 +450,59 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     //      (norm = +inf) and compared exactly by every query through a side list of at most kHFarCap entries per chunk. ----
     float rng = cinf;
     if (allfin && cinf < 1.0e16f) {
-        float dev = 0.0f;
-        for (int q4 = tid; q4 < nv; q4 += kHThreads) {
-            float ax[4], ay[4], az[4];
-            if (one_shot) {
+        // round 0: deviations from the mean of all points.  If that finds outliers (rng < cinf) the mean itself was pulled
+        // by them: round 1 re-centres on the points inside the range, round 2 measures the deviations about that centre.
+        for (int round = 0; round < 3; ++round) {
+            const bool trim = round > 0;
+            float dev = 0.0f, cntf = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
+            auto take = [&](float x, float y, float z) {
+                const float dv = fmaxf(fmaxf(fabsf(x - mu[0]), fabsf(y - mu[1])), fabsf(z - mu[2]));
+                if (!trim || dv <= rng) { dev += dv; cntf += 1.0f; sx += x; sy += y; sz += z; }
+            };
+            for (int q4 = tid; q4 < nv; q4 += kHThreads) {
+                float ax[4], ay[4], az[4];
+                if (one_shot) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int pt = q4 * 4 + e;
-                    const float4 r = imgf[((pt >> 5) * 2) * 32 + (pt & 31)];  // parked by this thread above
-                    ax[e] = r.x; ay[e] = r.y; az[e] = r.z;
+                    for (int e = 0; e < 4; ++e) {
+                        const int pt = q4 * 4 + e;
+                        const float4 r = imgf[((pt >> 5) * 2) * 32 + (pt & 31)];  // parked by this thread above
+                        ax[e] = r.x; ay[e] = r.y; az[e] = r.z;
+                    }
+                } else {
+                    load4pts(cb, q4 * 4, ax, ay, az);
                 }
-            } else {
-                load4pts(cb, q4 * 4, ax, ay, az);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) take(ax[e], ay[e], az[e]);
             }
+            for (int pt = nv * 4 + tid; pt < NC; pt += kHThreads) take(cb[(size_t)pt * 3], cb[(size_t)pt * 3 + 1], cb[(size_t)pt * 3 + 2]);
+            float v5[5] = {dev, cntf, sx, sy, sz};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dev += fmaxf(fmaxf(fabsf(ax[e] - mu[0]), fabsf(ay[e] - mu[1])), fabsf(az[e] - mu[2]));
+            for (int k = 0; k < 5; ++k) {
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) v5[k] = v5[k] + __shfl_xor(v5[k], m, 64);
+            }
+            __syncthreads();  // (red was read above)
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) red[wv * 5 + k] = v5[k];
+            }
+            __syncthreads();
+            float t5[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                t5[k] = red[k];
+#pragma unroll
+                for (int w = 1; w < kHThreads / 64; ++w) t5[k] = t5[k] + red[w * 5 + k];
+            }
+            if (!(t5[1] > 0.0f)) break;                      // (uniform)
+            if (round == 1) {  // re-centre on the points inside the range; measured again about the new centre next round
+                mu[0] = t5[2] / t5[1]; mu[1] = t5[3] / t5[1]; mu[2] = t5[4] / t5[1];
+                continue;
+            }
+            const float r16 = 16.0f * (t5[0] / t5[1]);
+            if (r16 > 0.0f && r16 < rng) rng = r16;
+            if (round == 0 && !(rng < cinf)) break;           // no outliers: the plain mean and cinf stand
         }
-        for (int pt = nv * 4 + tid; pt < NC; pt += kHThreads)
-            dev += fmaxf(fmaxf(fabsf(cb[(size_t)pt * 3] - mu[0]), fabsf(cb[(size_t)pt * 3 + 1] - mu[1])), fabsf(cb[(size_t)pt * 3 + 2] - mu[2]));
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) dev = dev + __shfl_xor(dev, m, 64);
-        __syncthreads();  // (red was read above)
-        if (lane == 0) red[wv] = dev;
-        __syncthreads();
-        float tot = red[0];
-#pragma unroll
-        for (int w = 1; w < kHThreads / 64; ++w) tot = tot + red[w];
-        const float r16 = 16.0f * (tot / (float)NC);
-        if (r16 > 0.0f && r16 < cinf) rng = r16;
     }
     // not sane (non-finite or huge coordinates): the filter is unusable, every query of the block scans every lane
     // tile exactly, in the isless order (a finite cloud with cinf < 1e16 never produces an infinite or NaN distance
