@@ -257,6 +257,17 @@ __device__ __forceinline__ float wave_min_f(float v) {
     return fminf(fminf(a, b), fminf(c, d));
 }
 __device__ __forceinline__ float wave_max_f(float v) { return -wave_min_f(-v); }
+__device__ __forceinline__ float wave_sum_f(float v) {  // the same butterfly with adds (fixed order: deterministic)
+    v = v + dpp_mov<0xB1>(v);
+    v = v + dpp_mov<0x4E>(v);
+    v = v + dpp_mov<0x141>(v);
+    v = v + dpp_mov<0x140>(v);
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (a + b) + (c + d);
+}
 
 // four consecutive points (12 floats) as three 16-byte loads; needs 16-B aligned base and p0 % 4 == 0
 __device__ __forceinline__ void load4pts(const float *__restrict__ base, int p0, float (&px)[4],
@@ -345,7 +356,7 @@ __device__ __forceinline__ void make_pieces(float cx, float cy, float cz, h8 &p0
 template <bool WANT_IDX>
 __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ float red[3 * 4 * (kHThreads / 64)];  // per wave: min, max, sum (padded to 4 dims)
+    __shared__ float red[4 * 4 * (kHThreads / 64)];  // per wave: min, max, sum, sum of squares (padded to 4 dims)
     __shared__ int nfar;                             // candidates of the chunk beyond the robust range ...
     __shared__ unsigned short farlist[kHFarCap];     // ... their indices within the chunk: compared exactly by every query
     constexpr int QB = (kHThreads / 64) * 32;  // queries per tile pass
@@ -389,11 +400,13 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     // ---- bounding box and mean -> centre mu = the MEAN (a stray far point moves the box centre, hardly the mean), largest
     //      |c - mu| cinf, power-of-two scale sc with cinf*sc in [64,128): seven binades of fp16 range above 1, so that a bulk
     //      much smaller than the farthest point keeps its fp16 pieces out of the subnormals; |c~|^2 < 3 * 2^14 fits fp16 ----
-    float mu[3], cinf = 0.0f;
+    float mu[3], cinf = 0.0f, varmax = 0.0f;
     bool allfin = true;
     const int nv = vec ? NC / 4 : 0;
     {
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sm3[3] = {0.f, 0.f, 0.f};
+        float sq3[3] = {0.f, 0.f, 0.f};                      // squares about the cloud's first point: the spread, in the same pass
+        const float pil[3] = {cb[0], cb[1], cb[2]};
         for (int q4 = tid; q4 < nv; q4 += kHThreads) {
             float ax[4], ay[4], az[4];
             load4pts(cb, q4 * 4, ax, ay, az);
@@ -403,6 +416,9 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 mn[1] = fminf(mn[1], ay[e]); mx[1] = fmaxf(mx[1], ay[e]);
                 mn[2] = fminf(mn[2], az[e]); mx[2] = fmaxf(mx[2], az[e]);
                 sm3[0] = sm3[0] + ax[e]; sm3[1] = sm3[1] + ay[e]; sm3[2] = sm3[2] + az[e];
+                sq3[0] = __builtin_fmaf(ax[e] - pil[0], ax[e] - pil[0], sq3[0]);
+                sq3[1] = __builtin_fmaf(ay[e] - pil[1], ay[e] - pil[1], sq3[1]);
+                sq3[2] = __builtin_fmaf(az[e] - pil[2], az[e] - pil[2], sq3[2]);
                 if (one_shot) {  // park the raw point in its own first piece
                     const int pt = q4 * 4 + e;
                     imgf[((pt >> 5) * 2) * 32 + (pt & 31)] = float4{ax[e], ay[e], az[e], 0.0f};
@@ -416,27 +432,31 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 mn[d] = fminf(mn[d], v);
                 mx[d] = fmaxf(mx[d], v);
                 sm3[d] = sm3[d] + v;
+                sq3[d] = __builtin_fmaf(v - pil[d], v - pil[d], sq3[d]);
             }
         }
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const float lo = wave_min_f(mn[d]), hi = wave_max_f(mx[d]);
-            float sw = sm3[d];
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) sw = sw + __shfl_xor(sw, m, 64);
-            if (lane == 0) { red[(wv * 3) * 4 + d] = lo; red[(wv * 3 + 1) * 4 + d] = hi; red[(wv * 3 + 2) * 4 + d] = sw; }
+            const float sw = wave_sum_f(sm3[d]), qw = wave_sum_f(sq3[d]);
+            if (lane == 0) { red[(wv * 4) * 4 + d] = lo; red[(wv * 4 + 1) * 4 + d] = hi; red[(wv * 4 + 2) * 4 + d] = sw; red[(wv * 4 + 3) * 4 + d] = qw; }
         }
         __syncthreads();
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            float lo = red[d], hi = red[4 + d], st = red[8 + d];
+            float lo = red[d], hi = red[4 + d], st = red[8 + d], sq = red[12 + d];
 #pragma unroll
             for (int w = 1; w < kHThreads / 64; ++w) {
-                lo = fminf(lo, red[(w * 3) * 4 + d]);
-                hi = fmaxf(hi, red[(w * 3 + 1) * 4 + d]);
-                st = st + red[(w * 3 + 2) * 4 + d];
+                lo = fminf(lo, red[(w * 4) * 4 + d]);
+                hi = fmaxf(hi, red[(w * 4 + 1) * 4 + d]);
+                st = st + red[(w * 4 + 2) * 4 + d];
+                sq = sq + red[(w * 4 + 3) * 4 + d];
             }
             mu[d] = fminf(fmaxf(st / (float)NC, lo), hi);  // (any centre is correct)
+            // variance about the mean from the second moment about the first point (a data point: no cancellation for clouds
+            // far from the origin); the largest of the three is what the farthest point is compared with below
+            const float off = st / (float)NC - pil[d];
+            varmax = fmaxf(varmax, sq / (float)NC - off * off);
             cinf = fmaxf(cinf, fmaxf(hi - mu[d], mu[d] - lo));
             // a NaN or +-Inf coordinate makes the coordinate sum non-finite (fminf / fmaxf above skip NaNs)
             allfin = allfin && fabsf(st) < INFINITY;
@@ -449,7 +469,9 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     //      16 x 0.375 of the half width; Gaussian: 21 sigma); candidates beyond the range ("far") are left out of the filter
     //      (norm = +inf) and compared exactly by every query through a side list of at most kHFarCap entries per chunk. ----
     float rng = cinf;
-    if (allfin && cinf < 1.0e16f) {
+    // (clean clouds never get here: uniform boxes have cinf^2 = 3 var, Gaussians of a million points 30 var; one point
+    //  far out among N makes it ~N var.  The measuring rounds cost two barriers each, 2.3 us at C2 when they always ran.)
+    if (allfin && cinf < 1.0e16f && cinf * cinf > 64.0f * varmax) {
         // round 0: deviations from the mean of all points.  If that finds outliers (rng < cinf) the mean itself was pulled
         // by them: round 1 re-centres on the points inside the range, round 2 measures the deviations about that centre.
         for (int round = 0; round < 3; ++round) {
@@ -475,11 +497,15 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 for (int e = 0; e < 4; ++e) take(ax[e], ay[e], az[e]);
             }
             for (int pt = nv * 4 + tid; pt < NC; pt += kHThreads) take(cb[(size_t)pt * 3], cb[(size_t)pt * 3 + 1], cb[(size_t)pt * 3 + 2]);
+            // (round 0 needs the deviation only: the count is NC; round 1 the count and the sums; round 2 deviation + count)
             float v5[5] = {dev, cntf, sx, sy, sz};
+            const int k0 = round == 1 ? 1 : 0, k1 = round == 0 ? 1 : (round == 1 ? 5 : 2);
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
+                if (k >= k0 && k < k1) {
 #pragma unroll
-                for (int m = 1; m < 64; m <<= 1) v5[k] = v5[k] + __shfl_xor(v5[k], m, 64);
+                    for (int m = 1; m < 64; m <<= 1) v5[k] = v5[k] + __shfl_xor(v5[k], m, 64);
+                }
             }
             __syncthreads();  // (red was read above)
             if (lane == 0) {
@@ -490,10 +516,14 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             float t5[5];
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                t5[k] = red[k];
+                t5[k] = 0.0f;
+                if (k >= k0 && k < k1) {
+                    t5[k] = red[k];
 #pragma unroll
-                for (int w = 1; w < kHThreads / 64; ++w) t5[k] = t5[k] + red[w * 5 + k];
+                    for (int w = 1; w < kHThreads / 64; ++w) t5[k] = t5[k] + red[w * 5 + k];
+                }
             }
+            if (round == 0) t5[1] = (float)NC;
             if (!(t5[1] > 0.0f)) break;                      // (uniform)
             if (round == 1) {  // re-centre on the points inside the range; measured again about the new centre next round
                 mu[0] = t5[2] / t5[1]; mu[1] = t5[3] / t5[1]; mu[2] = t5[4] / t5[1];
