@@ -357,7 +357,7 @@ template <bool WANT_IDX>
 __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float red[4 * 4 * (kHThreads / 64)];  // per wave: min, max, sum, sum of squares (padded to 4 dims)
-    __shared__ int nfar;                             // candidates of the chunk beyond the robust range ...
+    __shared__ int nfar[2];                          // candidates of the chunk beyond the robust range (chunks alternate) ...
     __shared__ unsigned short farlist[kHFarCap];     // ... their indices within the chunk: compared exactly by every query
     constexpr int QB = (kHThreads / 64) * 32;  // queries per tile pass
 
@@ -395,6 +395,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     float *qtab = wq + wv * 96;
     const bool vec = (reinterpret_cast<uintptr_t>(cb) & 15) == 0;
     const bool one_shot = vec && NC <= CH;
+    if (tid == 0) { nfar[0] = 0; nfar[1] = 0; }  // (ordered before their first use by the barrier of the bounding-box pass)
     FX3D_PROBE_MARK(0);
 
     // ---- bounding box and mean -> centre mu = the MEAN (a stray far point moves the box centre, hardly the mean), largest
@@ -545,13 +546,16 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         sc = ldexpf(1.0f, 7 - e);
     }
     // pieces of candidate `pt` (index within the chunk); a far one leaves the filter (t = +inf) for the side list
+    const bool has_far = sane && rng < cinf;  // (uniform) clean clouds skip the test below
+    int fslot = 0;                             // nfar[fslot] counts this chunk's far candidates
     auto pieces = [&](float x, float y, float z, int pt, h8 &p0, h8 &p1) {
         const float sx = (x - mu[0]) * sc, sy = (y - mu[1]) * sc, sz = (z - mu[2]) * sc;
-        const bool far = sane && !(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)) < 128.0f);
+        if (!has_far) { make_pieces(sx, sy, sz, p0, p1); return; }
+        const bool far = !(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)) < 128.0f);
         make_pieces(far ? 0.f : sx, far ? 0.f : sy, far ? 0.f : sz, p0, p1);
         if (far) {
             p1[1] = (_Float16)INFINITY;
-            const int f = atomicAdd(&nfar, 1);
+            const int f = atomicAdd(&nfar[fslot], 1);
             if (f < kHFarCap) farlist[f] = (unsigned short)pt;
         }
     };
@@ -567,9 +571,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     for (int j0 = jfirst; j0 < NC; j0 += jstep) {
         const int cnt = (NC - j0) < CH ? (NC - j0) : CH;
         const int cnt_pad = (cnt + 32 * kHLT - 1) / (32 * kHLT) * (32 * kHLT);
-        __syncthreads();
-        if (tid == 0) nfar = 0;
-        __syncthreads();
+        if (j0 > jfirst) __syncthreads();
         // ---- stage the fp16 split image ------------------------------------------------------------------
         if (one_shot) {
             for (int q4 = tid; q4 < nv; q4 += kHThreads) {
@@ -615,7 +617,9 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         __syncthreads();
         FX3D_PROBE_MARK(j0 == jfirst ? 2 : 6);
 
-        const int nf = nfar;                 // far candidates of this chunk (valid after the barrier above)
+        const int nf = nfar[fslot];          // far candidates of this chunk (valid after the barrier above)
+        if (tid == 0) nfar[fslot ^ 1] = 0;   // the next chunk's counter (its staging starts behind the barrier at the loop top)
+        fslot ^= 1;
         const bool far_ok = nf <= kHFarCap;  // more than the side list holds: this chunk's filter is not used
         for (int tp = 0; tp < p.tpb; ++tp) {
             if ((tile * p.tpb + tp) * QB >= NQ) break;  // uniform
