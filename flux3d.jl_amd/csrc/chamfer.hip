@@ -430,7 +430,7 @@ __device__ __noinline__ float4 nn1_robust_range(const float *__restrict__ cb, in
 template <bool WANT_IDX>
 __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ float red[4 * 4 * (kHThreads / 64)];  // per wave: min, max, sum, sum of squares (padded to 4 dims)
+    __shared__ __attribute__((aligned(16))) float red[4 * 4 * (kHThreads / 64)];  // per wave: min, max, sum, sum of squares (rows padded to 4 floats)
     __shared__ int nfar[2];                          // candidates of the chunk beyond the robust range (chunks alternate) ...
     __shared__ unsigned short farlist[kHFarCap];     // ... their indices within the chunk: compared exactly by every query
     constexpr int QB = (kHThreads / 64) * 32;  // queries per tile pass
@@ -517,24 +517,31 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             if (lane == 0) { red[(wv * 4) * 4 + d] = lo; red[(wv * 4 + 1) * 4 + d] = hi; red[(wv * 4 + 2) * 4 + d] = sw; red[(wv * 4 + 3) * 4 + d] = qw; }
         }
         __syncthreads();
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            float lo = red[d], hi = red[4 + d], st = red[8 + d], sq = red[12 + d];
+        {
+            // cross-wave reduction: one 16-byte LDS read per (wave, statistic) -- the rows are padded to four floats
+            const float4 *r4 = reinterpret_cast<const float4 *>(red);
+            float4 lo4 = r4[0], hi4 = r4[1], st4 = r4[2], sq4 = r4[3];
 #pragma unroll
             for (int w = 1; w < kHThreads / 64; ++w) {
-                lo = fminf(lo, red[(w * 4) * 4 + d]);
-                hi = fmaxf(hi, red[(w * 4 + 1) * 4 + d]);
-                st = st + red[(w * 4 + 2) * 4 + d];
-                sq = sq + red[(w * 4 + 3) * 4 + d];
+                const float4 a0 = r4[w * 4], a1 = r4[w * 4 + 1], a2 = r4[w * 4 + 2], a3 = r4[w * 4 + 3];
+                lo4.x = fminf(lo4.x, a0.x); lo4.y = fminf(lo4.y, a0.y); lo4.z = fminf(lo4.z, a0.z);
+                hi4.x = fmaxf(hi4.x, a1.x); hi4.y = fmaxf(hi4.y, a1.y); hi4.z = fmaxf(hi4.z, a1.z);
+                st4.x = st4.x + a2.x; st4.y = st4.y + a2.y; st4.z = st4.z + a2.z;
+                sq4.x = sq4.x + a3.x; sq4.y = sq4.y + a3.y; sq4.z = sq4.z + a3.z;
             }
-            mu[d] = fminf(fmaxf(st / (float)NC, lo), hi);  // (any centre is correct)
-            // variance about the mean from the second moment about the first point (a data point: no cancellation for clouds
-            // far from the origin); the largest of the three is what the farthest point is compared with below
-            const float off = st / (float)NC - pil[d];
-            varmax = fmaxf(varmax, sq / (float)NC - off * off);
-            cinf = fmaxf(cinf, fmaxf(hi - mu[d], mu[d] - lo));
-            // a NaN or +-Inf coordinate makes the coordinate sum non-finite (fminf / fmaxf above skip NaNs)
-            allfin = allfin && fabsf(st) < INFINITY;
+            const float lo3[3] = {lo4.x, lo4.y, lo4.z}, hi3[3] = {hi4.x, hi4.y, hi4.z}, st3[3] = {st4.x, st4.y, st4.z}, sq3t[3] = {sq4.x, sq4.y, sq4.z};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float lo = lo3[d], hi = hi3[d], st = st3[d], sq = sq3t[d];
+                mu[d] = fminf(fmaxf(st / (float)NC, lo), hi);  // (any centre is correct)
+                // variance about the mean from the second moment about the first point (a data point: no cancellation for clouds
+                // far from the origin); the largest of the three is what the farthest point is compared with below
+                const float off = st / (float)NC - pil[d];
+                varmax = fmaxf(varmax, sq / (float)NC - off * off);
+                cinf = fmaxf(cinf, fmaxf(hi - mu[d], mu[d] - lo));
+                // a NaN or +-Inf coordinate makes the coordinate sum non-finite (fminf / fmaxf above skip NaNs)
+                allfin = allfin && fabsf(st) < INFINITY;
+            }
         }
         cinf = cinf * 1.000001f;
     }
