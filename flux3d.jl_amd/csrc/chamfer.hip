@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     const int nv = vec ? NC / 4 : 0;
     {
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sm3[3] = {0.f, 0.f, 0.f};
-        float sq3[3] = {0.f, 0.f, 0.f};                      // squares about the cloud's first point: the spread, in the same pass
+        float sq3[3] = {0.f, 0.f, 0.f};  // second moment of a SAMPLE (every fourth point) about the cloud's first point: the spread
         const float pil[3] = {cb[0], cb[1], cb[2]};
         for (int q4 = tid; q4 < nv; q4 += kHThreads) {
             float ax[4], ay[4], az[4];
@@ -491,9 +491,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 mn[1] = fminf(mn[1], ay[e]); mx[1] = fmaxf(mx[1], ay[e]);
                 mn[2] = fminf(mn[2], az[e]); mx[2] = fmaxf(mx[2], az[e]);
                 sm3[0] = sm3[0] + ax[e]; sm3[1] = sm3[1] + ay[e]; sm3[2] = sm3[2] + az[e];
-                sq3[0] = __builtin_fmaf(ax[e] - pil[0], ax[e] - pil[0], sq3[0]);
-                sq3[1] = __builtin_fmaf(ay[e] - pil[1], ay[e] - pil[1], sq3[1]);
-                sq3[2] = __builtin_fmaf(az[e] - pil[2], az[e] - pil[2], sq3[2]);
+                if (e == 0) {  // every fourth point is sample enough for the spread (an outlier that is missed only lowers it)
+                    sq3[0] = __builtin_fmaf(ax[e] - pil[0], ax[e] - pil[0], sq3[0]); sq3[1] = __builtin_fmaf(ay[e] - pil[1], ay[e] - pil[1], sq3[1]);
+                    sq3[2] = __builtin_fmaf(az[e] - pil[2], az[e] - pil[2], sq3[2]);
+                }
                 if (one_shot) {  // park the raw point in its own first piece
                     const int pt = q4 * 4 + e;
                     imgf[((pt >> 5) * 2) * 32 + (pt & 31)] = float4{ax[e], ay[e], az[e], 0.0f};
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 // variance about the mean from the second moment about the first point (a data point: no cancellation for clouds
                 // far from the origin); the largest of the three is what the farthest point is compared with below
                 const float off = st / (float)NC - pil[d];
-                varmax = fmaxf(varmax, sq / (float)NC - off * off);
+                varmax = fmaxf(varmax, sq / (float)(NC - 3 * nv) - off * off);  // (nv sampled groups of four + the tail points)
                 cinf = fmaxf(cinf, fmaxf(hi - mu[d], mu[d] - lo));
                 // a NaN or +-Inf coordinate makes the coordinate sum non-finite (fminf / fmaxf above skip NaNs)
                 allfin = allfin && fabsf(st) < INFINITY;
