@@ -356,7 +356,7 @@ __device__ __forceinline__ void make_pieces(float cx, float cy, float cz, h8 &p0
 // The robust range of a cloud with outliers (nn1_f16_kernel, below): kept out of line so that clean clouds -- which never
 // call it -- do not pay for its registers and code.  Returns (mu, rng): the re-centred mean and 16 x the mean max-norm
 // deviation of the points within the previous range.  All threads of the block call it together (it synchronises).
-__device__ __noinline__ float4 nn1_robust_range(const float *__restrict__ cb, int NC, int nv, bool one_shot, const float4 *imgf,
+__device__ __forceinline__ float4 nn1_robust_range(const float *__restrict__ cb, int NC, int nv, bool one_shot, const float4 *imgf,
                                                 float *red, float mu0, float mu1, float mu2, float cinf) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float mu[3] = {mu0, mu1, mu2};
