@@ -480,6 +480,7 @@ __global__ __launch_bounds__(kThreads) void knn_gather_kernel(const float *__res
 
 // ---- shared by the matrix-core kNN kernels ------------------------------------------------------------
 typedef float f32x16v __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int kMWaves = 4;                       // consumer waves
 constexpr int kMThreads = 2 * kMWaves * 64;      // + as many producer waves
 constexpr int kMProd = kMWaves * 64;             // producer threads
@@ -1462,12 +1463,17 @@ __device__ __forceinline__ int knn_hpiece_off(int row, int c) {
 }
 // Converts and stores the units; the G = DP/8 consecutive lanes that hold one row also sum its scaled norm
 // (3..4 butterfly steps).  norms != nullptr: phase A, norms[row] and the running maximum are recorded.
+template <int CTRL>
+__device__ __forceinline__ float knn_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 template <int DK, bool SPLIT, int kMUnits>
 __device__ __forceinline__ void knn_f16_store_chunk(float *img, int CH, int cn, float sc, const float *mu_lds, int ptid,
                                                     const float4 (&reg)[kMUnits][2], float *norms, float *norms_m,
                                                     const float *acoef_lds, float &tmax, bool &tnan) {
     constexpr int DP = DK * 32, G = DP / 8, PPR = DK * 8;
     static_assert(kMProd % G == 0, "a producer thread always converts the same group of eight dimensions");
+    static_assert(G == 4 || G == 8 || G == 16, "the row sum below");
     // (centre and error coefficient are re-read from LDS per call: holding them in registers across the chunk loop spills)
     float mu8[8];
     {
@@ -1500,8 +1506,12 @@ __device__ __forceinline__ void knn_f16_store_chunk(float *img, int CH, int cn, 
             }
         }
         if (norms) {  // wave-uniform
-#pragma unroll
-            for (int m = 1; m < G; m <<= 1) part = part + __shfl_xor(part, m, 64);
+            // sum over the row's G lanes by DPP (VALU speed; the same tree as an xor butterfly in the row's first lane,
+            // the only one that uses it)
+            part = part + knn_dpp<0xB1>(part);                // quad_perm [1,0,3,2]
+            part = part + knn_dpp<0x4E>(part);                // quad_perm [2,3,0,1]
+            if (G >= 8) part = part + knn_dpp<0x141>(part);   // row_half_mirror
+            if (G >= 16) part = part + knn_dpp<0x140>(part);  // row_mirror
             if (un < CH * G && g == 0) {
                 const float t = row < cn ? part : INFINITY;  // rows beyond the cloud: F = +inf
                 // norms_m: the candidate's own share of the filter error is folded into its norm, upwards for the
@@ -1514,12 +1524,59 @@ __device__ __forceinline__ void knn_f16_store_chunk(float *img, int CH, int cn, 
     }
 }
 
+// staged exact phase: the oracle's squared distance of one query row (registers) to two staged candidate rows (LDS),
+// dimension by dimension in order.  Differences and squares two dimensions per instruction (v_pk_add/mul_f32 on the
+// natural register pairs), the sums one by one; the next four pieces of both rows are in flight while four are summed.
+// FULL: D == DP (no guards).
+template <int DP, bool FULL>
+__device__ __forceinline__ void knn_pair_dist(const f32x4v (&q)[DP / 4], const float *cp0, const float *cp1, int D, float &s0, float &s1) {
+    constexpr int NB = DP / 16;
+    f32x4v c0[2][4], c1[2][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (FULL || 4 * t < D) {
+            c0[0][t] = *reinterpret_cast<const f32x4v *>(cp0 + 4 * t);
+            c1[0][t] = *reinterpret_cast<const f32x4v *>(cp1 + 4 * t);
+        }
+#pragma unroll
+    for (int bk = 0; bk < NB; ++bk) {
+        if (bk + 1 < NB) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (FULL || 16 * (bk + 1) + 4 * t < D) {
+                    c0[(bk + 1) & 1][t] = *reinterpret_cast<const f32x4v *>(cp0 + 16 * (bk + 1) + 4 * t);
+                    c1[(bk + 1) & 1][t] = *reinterpret_cast<const f32x4v *>(cp1 + 16 * (bk + 1) + 4 * t);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (FULL || 16 * bk + 4 * t < D) {
+                const f32x4v d0 = q[4 * bk + t] - c0[bk & 1][t], d1 = q[4 * bk + t] - c1[bk & 1][t];
+                const f32x4v m0 = d0 * d0, m1 = d1 * d1;
+                s0 = s0 + m0.x; s0 = s0 + m0.y; s0 = s0 + m0.z; s0 = s0 + m0.w;
+                s1 = s1 + m1.x; s1 = s1 + m1.y; s1 = s1 + m1.z; s1 = s1 + m1.w;
+            }
+    }
+}
+
+// staged exact phase: a thread's share of one stage of candidate rows (8 pieces of 16 bytes, rows srow + i * RPI of
+// the stage that starts at row g0; clamped addresses: always valid, unused rows are never stored)
+__device__ __forceinline__ void knn_stage_fetch(const float *__restrict__ yb, int D, int M, int g0, int srow, int RPI, int scol,
+                                                f32x4v (&reg)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int g = g0 + srow + i * RPI;
+        g = g < M ? g : M - 1;
+        reg[i] = *reinterpret_cast<const f32x4v *>(yb + (size_t)g * D + scol);
+    }
+}
+
 template <int DK, bool F16, bool SPLIT>
 __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__restrict__ x, int N,
                                                              const float *__restrict__ y, int M, int B, int D,
                                                              int k, int drop, int32_t *__restrict__ idx,
                                                              float *__restrict__ dist, int CH, int img_floats,
-                                                             int keep_norms, int two_norms) {
+                                                             int keep_norms, int two_norms, int srl) {
     constexpr int DP = DK * 32;      // padded feature dimension
     constexpr int RS = DP + 4;       // row stride of the query rows staged in the prologue (floats)
     constexpr int PPR = DK * 8;      // 16-byte pieces per candidate row
@@ -1529,16 +1586,18 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     constexpr int PPI = RSI / 4;     // 16-byte pieces per image row
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int buf_floats = CH * RSI + CH;                                  // image [CH][RSI] + norms [CH]
-    int *lists = reinterpret_cast<int *>(sm + img_floats);                 // [kMWaves][kMLCap][64] mask words
-    int *lcnt = lists + kMWaves * kMLCap * 64;                             // [kMWaves][64]  list lengths
+    // fixed-size bookkeeping first, then lists | med | nall: from the lists on everything is dead once the survivors are
+    // decoded, so the staged exact phase uses that whole tail of the allocation for candidate rows
+    int *lcnt = reinterpret_cast<int *>(sm + img_floats);                  // [kMWaves][64]  list lengths
     int *qn_n = lcnt + kMWaves * 64;                                       // [kMWaves][32]  survivors per query
     int *qflag = qn_n + kMWaves * 32;                                      // [kMWaves][32]  1 = fast path
     int *qbelow = qflag + kMWaves * 32;                                    // [kMWaves][32]  entries with rank < kk
     unsigned int *cmax = reinterpret_cast<unsigned int *>(qbelow + kMWaves * 32);  // bits of max |c|^2 (>= 0)
     float *mu = reinterpret_cast<float *>(cmax + 4);                       // [DP] F16: per-dimension centre of the cloud
-    int *med = reinterpret_cast<int *>(mu + DP);                           // [2 kMWaves][kMMedCap + 128] medium path: ids + merge lists
+    unsigned long long *qstpk = reinterpret_cast<unsigned long long *>(mu + DP);  // [kMWaves][32] survivors per row stage (packed prefix)
+    int *lists = reinterpret_cast<int *>(qstpk + kMWaves * 32);            // [kMWaves][kMLCap][64] mask words
+    int *med = lists + kMWaves * kMLCap * 64;                              // [2 kMWaves][kMMedCap + 128] medium path: ids + merge lists
     float *nall = reinterpret_cast<float *>(med + 2 * kMWaves * (kMMedCap + 128));  // [nchunk*CH] all candidate norms (keep_norms)
-
     // block L runs on XCD L % 8: give every cloud's blocks ids with equal L % 8 so that its candidates stay in
     // one L2 (8 or more clouds; fewer: plain order, a cloud's blocks spread over all XCDs)
     const int nbx = (N + kMWaves * 32 - 1) / (kMWaves * 32);
@@ -1587,12 +1646,13 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         float poison = 0.0f;
         const float4 *c4 = reinterpret_cast<const float4 *>(yb);
         const int total4 = M * (D / 4);
-        for (int e0 = tid; e0 < total4; e0 += 8 * kMThreads) {
-            float4 v[8];
+        constexpr int kInFlight = 8;  // 16-byte loads in flight per thread (16 did not help: the pass is bound by the L2, every block reads its whole cloud)
+        for (int e0 = tid; e0 < total4; e0 += kInFlight * kMThreads) {
+            float4 v[kInFlight];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = c4[e0 + e * kMThreads < total4 ? e0 + e * kMThreads : e0];  // (clamped: same dimensions)
+            for (int e = 0; e < kInFlight; ++e) v[e] = c4[e0 + e * kMThreads < total4 ? e0 + e * kMThreads : e0];  // (clamped: same dimensions)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < kInFlight; ++e) {
                 // NaN or +-inf coordinates (x * 0 is NaN for them): no scale exists, every query takes the exact path
                 poison = __builtin_fmaf(v[e].x, 0.0f, poison); poison = __builtin_fmaf(v[e].y, 0.0f, poison);
                 poison = __builtin_fmaf(v[e].z, 0.0f, poison); poison = __builtin_fmaf(v[e].w, 0.0f, poison);
@@ -1983,6 +2043,12 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     const int n = qn_n[cw * 32 + jl];
     const bool fast = qflag[cw * 32 + jl] == 1;
     const bool handled = qflag[cw * 32 + jl] == 2;  // answered by the medium path
+    // staged exact phase (srl > 0): the thread's share of the first stage of candidate rows is requested here, so that
+    // it arrives while the lists are decoded
+    f32x4v sreg[8];
+    const int PR = D >> 2, RPI = srl > 0 ? kMThreads / PR : 0;  // rows per sweep of the block (PR divides the block size)
+    const int srow = srl > 0 ? tid / PR : 0, scol = (tid - srow * PR) * 4;
+    if (srl > 0) knn_stage_fetch(yb, D, M, 0, srow, RPI, scol, sreg);
     if (wave_active) {
         // ---- medium path (tight clusters, many duplicates: more candidates inside the band than the key arrays hold):
         //      the wave decodes the query's two lane lists into an id list and selects exactly among those ids,
@@ -2028,23 +2094,57 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             __builtin_amdgcn_wave_barrier();
         }
     }
-    // (2) consumers decode their mask words into candidate ids (integer work only)
+    // (2) consumers decode their mask words into candidate ids (integer work only).  srl > 0 (staged exact phase): the
+    //     ids of a query are grouped by row stage (2^srl candidate rows, at most 8 stages): per-stage counts of the two
+    //     half-wave lists in the bytes of a 64-bit word (n <= 60 < 256), prefix sums by one multiplication
     if (consumer && fast) {
         const int meta = lcnt[cw * 64 + lane];
-        int pos = meta & 0xffff;
         const int nv = meta >> 16;
-        for (int e0 = 0; e0 < nv; e0 += 4) {  // four list words in flight
-            unsigned int w[4];
+        if (srl > 0) {
+            const int tsh = srl - 5;  // tile -> stage
+            unsigned long long pk = 0;
+            for (int e = 0; e < nv; ++e) {
+                const unsigned int w = (unsigned int)mylist[e * 64];
+                pk += (unsigned long long)__builtin_popcount(w & 0xffffu) << (((w >> 16) >> tsh) * 8);
+            }
+            const unsigned long long pko = ((unsigned long long)(unsigned int)__shfl_xor((int)(pk >> 32), 32, 64) << 32) |
+                                           (unsigned int)__shfl_xor((int)pk, 32, 64);
+            const unsigned long long incl = (pk + pko) * 0x0101010101010101ull;  // byte s: survivors in stages 0..s
+            unsigned long long startpk = (incl << 8) + (h ? pko : 0ull);         // byte s: where this lane's ids of stage s go
+            if (h == 0) qstpk[cw * 32 + jl] = incl;
+            for (int e0 = 0; e0 < nv; e0 += 4) {  // four list words in flight
+                unsigned int w[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) w[u] = (unsigned int)mylist[(e0 + u < kMLCap ? e0 + u : kMLCap - 1) * 64];
+                for (int u = 0; u < 4; ++u) w[u] = (unsigned int)mylist[(e0 + u < kMLCap ? e0 + u : kMLCap - 1) * 64];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                unsigned int m = e0 + u < nv ? (w[u] & 0xffffu) : 0u;
-                const int rowbase = (int)(w[u] >> 16) * 32 + 4 * h;
-                while (m) {
-                    const int r = __builtin_ctz(m);
-                    m &= m - 1;
-                    qj[pos++] = rowbase + (r & 3) + 8 * (r >> 2);
+                for (int u = 0; u < 4; ++u) {
+                    unsigned int m = e0 + u < nv ? (w[u] & 0xffffu) : 0u;
+                    const int rowbase = (int)(w[u] >> 16) * 32 + 4 * h;
+                    const int sh = (int)((w[u] >> 16) >> tsh) * 8;
+                    int pos = (int)(startpk >> sh) & 0xff;
+                    startpk += (unsigned long long)__builtin_popcount(m) << sh;
+                    while (m) {
+                        const int r = __builtin_ctz(m);
+                        m &= m - 1;
+                        qj[pos++] = rowbase + (r & 3) + 8 * (r >> 2);
+                    }
+                }
+            }
+        } else {
+            int pos = meta & 0xffff;
+            for (int e0 = 0; e0 < nv; e0 += 4) {  // four list words in flight
+                unsigned int w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w[u] = (unsigned int)mylist[(e0 + u < kMLCap ? e0 + u : kMLCap - 1) * 64];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    unsigned int m = e0 + u < nv ? (w[u] & 0xffffu) : 0u;
+                    const int rowbase = (int)(w[u] >> 16) * 32 + 4 * h;
+                    while (m) {
+                        const int r = __builtin_ctz(m);
+                        m &= m - 1;
+                        qj[pos++] = rowbase + (r & 3) + 8 * (r >> 2);
+                    }
                 }
             }
         }
@@ -2059,7 +2159,52 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     const int mystart = part * per < n ? part * per : n;
     const int mycount = (mystart + per <= n ? per : n - mystart);
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(lists) + (size_t)(cw * 32 + jl) * 33;  // [..][32 + 1 pad]
-    if (wave_active && fast) {
+    if (srl > 0) {
+        // staged: the candidate rows come through LDS one stage (2^srl rows) at a time, loaded coalesced once per block
+        // (every row exactly once: M * 4D bytes from L2 instead of 4D per survivor), rows 16 bytes apart in the banks.
+        // Per stage the four lanes of a query split its survivors of that stage; the query row sits in registers.
+        // The oracle's distance of every id: same operations in the same order as the gather below.
+        const int SRW = 1 << srl, RSX = D + 4;
+        float *stg = reinterpret_cast<float *>(lists);
+        const int nstage = (M + SRW - 1) >> srl;
+        const bool act = wave_active && fast;
+        const unsigned long long incl = act ? qstpk[cw * 32 + jl] : 0ull;
+        f32x4v qreg[DP / 4];
+        {
+            const float *qrow = xb + (size_t)(act ? qi : 0) * D;
+#pragma unroll
+            for (int t = 0; t < DP / 4; ++t)
+                qreg[t] = 4 * t < D ? *reinterpret_cast<const f32x4v *>(qrow + 4 * t) : f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int s = 0; s < nstage; ++s) {
+            if (s) __syncthreads();  // every lane is done with the previous stage
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = srow + i * RPI;
+                if (row < SRW) *reinterpret_cast<f32x4v *>(stg + (size_t)row * RSX + scol) = sreg[i];
+            }
+            __syncthreads();
+            if (s < 3) KNN_PROBE_MARK(26 + 2 * s);
+            if (s + 1 < nstage) knn_stage_fetch(yb, D, M, (s + 1) << srl, srow, RPI, scol, sreg);  // in flight while this stage is evaluated
+            if (act) {
+                const int start = s ? (int)(incl >> (8 * (s - 1))) & 0xff : 0, end = (int)(incl >> (8 * s)) & 0xff;
+                const int per = (end - start + 3) >> 2;
+                const int a0 = start + part * per < end ? start + part * per : end;
+                const int a1 = a0 + per < end ? a0 + per : end;
+                for (int p0 = a0; p0 < a1; p0 += 2) {
+                    const bool two = p0 + 1 < a1;
+                    const float *cp0 = stg + (size_t)(qj[p0] - (s << srl)) * RSX;
+                    const float *cp1 = stg + (size_t)(qj[two ? p0 + 1 : p0] - (s << srl)) * RSX;
+                    float s0 = 0.0f, s1 = 0.0f;
+                    if (D == DP) knn_pair_dist<DP, true>(qreg, cp0, cp1, D, s0, s1);
+                    else knn_pair_dist<DP, false>(qreg, cp0, cp1, D, s0, s1);
+                    qd[p0] = __builtin_bit_cast(unsigned int, s0);
+                    if (two) qd[p0 + 1] = __builtin_bit_cast(unsigned int, s1);
+                }
+            }
+            if (s < 3) KNN_PROBE_MARK(27 + 2 * s);
+        }
+    } else if (wave_active && fast) {
         // the oracle's distance of every id.  The query row sits in registers; candidate rows are gathered from L2
         // one full 128-byte line per request (32 dimensions), two candidates in flight
         const float *qrow = xb + (size_t)qi * D;
@@ -2361,16 +2506,18 @@ template <int DK, bool F16, bool SPLIT>
 fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int B, int D, int k, int drop,
                                int32_t *idx, float *dist, hipStream_t st) {
     constexpr int DP = DK * 32, RS = DP + 4, RSI = (F16 && !SPLIT) ? DP / 2 : DP;
-    // lists (later the slots) + list lengths + per-query counters + cmax
-    size_t fixed = (size_t)kMWaves * kMLCap * 64 * 4 + (size_t)kMWaves * 64 * 4 + (size_t)3 * kMWaves * 32 * 4 + 64;
+    // list lengths + per-query counters + cmax + per-dimension centre + per-stage survivor counts ...
+    const size_t small = (size_t)kMWaves * 64 * 4 + (size_t)3 * kMWaves * 32 * 4 + 64 + (size_t)DP * 4 + (size_t)kMWaves * 32 * 8;
     static_assert(kMWaves * 32 * 33 * 8 + 2 * kMWaves * 128 * 4 <= kMWaves * kMLCap * 64 * 4, "rank slots + fallback scratch alias the mask lists");
     const int keep_norms = M <= 4096;  // all candidate norms stay in LDS: phase B does not recompute them
-    fixed += (size_t)DP * 4;  // per-dimension centre
-    fixed += (size_t)2 * kMWaves * (kMMedCap + 128) * 4;  // medium path: id lists + merge scratch, one per wave
-    if (keep_norms) fixed += (size_t)((M + 255) / 256 * 256 + 256) * 4;
+    // ... then the tail that is dead after the decode: lists (later the slots), medium path (id lists + merge scratch, one
+    // per wave), candidate norms
+    size_t tail = (size_t)kMWaves * kMLCap * 64 * 4 + (size_t)2 * kMWaves * (kMMedCap + 128) * 4;
+    if (keep_norms) tail += (size_t)((M + 255) / 256 * 256 + 256) * 4;
     // fp16 filter, room permitting: a second norms array (the candidate's error share folded in, upwards / downwards)
     const int two_norms = F16 && keep_norms && M <= 2048;
-    if (two_norms) fixed += (size_t)((M + 255) / 256 * 256 + 256) * 4;
+    if (two_norms) tail += (size_t)((M + 255) / 256 * 256 + 256) * 4;
+    const size_t fixed = small + tail;
     const size_t budget = 150 * 1024 - fixed;                                  // floats*4 for the two chunk buffers
     int CH = (int)(budget / 2 / ((size_t)RSI * 4 + 4)) / 64 * 64;
     if (CH > 256) CH = 256;
@@ -2384,7 +2531,24 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     if (img < qstage) img = qstage;
     if (img < exact) img = exact;
     img = (img + 3) & ~(size_t)3;
-    const size_t lds = img * 4 + fixed;
+    size_t lds = img * 4 + fixed;
+    // staged exact phase: candidate rows pass through the tail in stages of 2^srl rows of 4D + 16 bytes (at most 8 stages,
+    // at most 8 sweeps of the block per stage; the allocation may grow up to the limit for it).  0 = gather from L2.
+    int srl = 0;
+    const int PR = D / 4;
+    const bool stageable = D % 4 == 0 && (kMThreads % PR) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
+                           !getenv("FX3D_KNN_GATHER");
+    if (stageable) {
+        const size_t room = 152 * 1024 - (img * 4 + small);
+        for (int l = 8; l >= 5; --l) {
+            const size_t need = ((size_t)1 << l) * ((size_t)D * 4 + 16);
+            if (need <= room && ((size_t)1 << l) * PR <= 8 * (size_t)kMThreads && ((M + (1 << l) - 1) >> l) <= 8) {
+                srl = l;
+                if (img * 4 + small + need > lds) lds = img * 4 + small + need;
+                break;
+            }
+        }
+    }
     const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_mfma_kernel<DK, F16, SPLIT>), 152 * 1024, "knn_mfma_kernel");
     if (arc != FX3D_OK) return arc;
     FX3D_REQUIRE(lds <= 152 * 1024, "fx3d_knn: internal LDS plan exceeds the CU (D=%d)", D);
@@ -2392,7 +2556,7 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     const int nbx = (N + qpb - 1) / qpb;
     const int bpad = B >= 8 ? (B + 7) / 8 * 8 : B;
     hipLaunchKernelGGL((knn_mfma_kernel<DK, F16, SPLIT>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
-                       k, drop, idx, dist, CH, (int)img, keep_norms, two_norms);
+                       k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }

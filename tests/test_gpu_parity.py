@@ -427,6 +427,34 @@ def test_knn_fp16_filter_variants(gpu_fx, oracle, monkeypatch, env):
         assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
 
 
+@pytest.mark.parametrize("D,N,M,B,k,drop", [
+    (64, 300, 2048, 2, 20, False),   # 8 row stages of 256
+    (64, 257, 2047, 1, 20, True),    # ragged last stage (x is not y: N != M)
+    (64, 1024, 1024, 9, 20, True),   # the second EdgeConv's shape, B > 8 (clouds share an XCD)
+    (128, 130, 1024, 1, 16, False),  # stages of 128 rows (row = 528 bytes)
+    (32, 200, 2000, 2, 31, False),
+    (16, 100, 700, 1, 7, False),
+    (4, 333, 2048, 1, 32, False),    # smallest row (one 16-byte piece)
+    (64, 100, 4096, 1, 20, False),   # more than 8 stages: the gather from L2 stays
+])
+def test_knn_staged_exact_phase(gpu_fx, oracle, monkeypatch, D, N, M, B, k, drop):
+    """knn_mfma_kernel's exact phase with the candidate rows staged through LDS (default when D/4 divides the block and
+    the cloud makes at most 8 stages) and with the per-survivor gather from L2 (FX3D_KNN_GATHER=1): both are the
+    oracle's lists bit for bit, distances included."""
+    rng = np.random.default_rng(D * 7 + M)
+    x = np.asfortranarray(rng.standard_normal((D, N, B)).astype(np.float32))
+    y = x if drop else np.asfortranarray(rng.standard_normal((D, M, B)).astype(np.float32))
+    if drop:
+        x = y = np.asfortranarray(rng.standard_normal((D, M, B)).astype(np.float32))
+    oi, od = oracle.knn(x, k, y=None if y is x else y, drop_first=drop)
+    for gather in (False, True):
+        if gather:
+            monkeypatch.setenv("FX3D_KNN_GATHER", "1")
+        idx, dist = gpu_fx.knn(x, k, y=None if y is x else y, drop_first=drop)
+        assert np.array_equal(idx.to_host(), oi), f"gather={gather}"
+        assert np.array_equal(dist.to_host(), od), f"gather={gather}"
+
+
 @pytest.mark.parametrize("D,csize,spread", [(64, 80, 1e-3), (32, 200, 1e-4), (64, 700, 1e-3)])
 def test_knn_feature_space_clustered_data(gpu_fx, oracle, D, csize, spread):
     """Tight clusters put more candidates inside a query's band than the fast path's key arrays hold (60): the medium

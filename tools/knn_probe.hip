@@ -57,6 +57,12 @@ int main(int argc, char **argv) {
         for (int k = 1; k < 32; ++k) { if (!q[k]) continue; d[k] += (double)(q[k] - prev); c[k]++; prev = q[k]; }
     }
     for (int k = 1; k < 32; ++k) if (c[k]) printf("  mark %2d: avg +%9.1f ticks (n=%d)\n", k, d[k] / c[k], c[k]);
+    if (getenv("RAW"))  // stamps of a few blocks relative to their first one (marks need not be in index order)
+        for (int b = 0; b < 3; ++b) {
+            printf("block %d:", b);
+            for (int k = 1; k < 32; ++k) if (pr[b * 32 + k]) printf(" %d:%llu", k, pr[b * 32 + k] - pr[b * 32]);
+            printf("\n");
+        }
     unsigned long long tmin = ~0ull, tmax = 0;
     double bsum = 0, bmax = 0, smax = 0;
     int nbk = 0;
