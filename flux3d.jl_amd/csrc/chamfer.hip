@@ -35,7 +35,11 @@ using namespace fx3d;
 __device__ unsigned long long g_probe[4096 * 16];
 #define FX3D_PROBE_MARK(k)                                                                   \
     do {                                                                                     \
-        if (threadIdx.x == 0 && blockIdx.x < 4096) g_probe[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                         \
+            g_probe[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter();                   \
+            if ((k) == 0) g_probe[blockIdx.x * 16 + 13] = wall_clock64();                    \
+            if ((k) == 12) g_probe[blockIdx.x * 16 + 14] = wall_clock64();                   \
+        }                                                                                    \
     } while (0)
 #else
 #define FX3D_PROBE_MARK(k) do { } while (0)
@@ -257,6 +261,33 @@ __device__ __forceinline__ float wave_min_f(float v) {
     return fminf(fminf(a, b), fminf(c, d));
 }
 __device__ __forceinline__ float wave_max_f(float v) { return -wave_min_f(-v); }
+// the same reductions finished by DPP too (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3): the result is
+// in lane 63 only -- six VALU operations per value, no readlanes
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_keep(float v) {  // lanes outside ROWMASK (or without a source) keep v
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_min_l63(float v) {
+    v = fminf(v, dpp_mov<0xB1>(v));
+    v = fminf(v, dpp_mov<0x4E>(v));
+    v = fminf(v, dpp_mov<0x141>(v));
+    v = fminf(v, dpp_mov<0x140>(v));           // every lane of a row holds the row's minimum
+    v = fminf(v, dpp_keep<0x142, 0xA>(v));     // rows 1, 3 += rows 0, 2
+    v = fminf(v, dpp_keep<0x143, 0xC>(v));     // rows 2, 3 += row 1 (which holds rows 0..1)
+    return v;
+}
+__device__ __forceinline__ float wave_max_l63(float v) { return -wave_min_l63(-v); }
+__device__ __forceinline__ float wave_sum_l63(float v) {  // fixed order: deterministic
+    v = v + dpp_mov<0xB1>(v);
+    v = v + dpp_mov<0x4E>(v);
+    v = v + dpp_mov<0x141>(v);
+    v = v + dpp_mov<0x140>(v);
+    const float a = dpp_keep<0x142, 0xA>(v);
+    v = ((threadIdx.x >> 4) & 1) ? v + a : v;  // (rows 0 and 2 keep their own value: v + v must not happen)
+    const float b = dpp_keep<0x143, 0xC>(v);
+    v = ((threadIdx.x >> 5) & 1) ? v + b : v;
+    return v;
+}
 __device__ __forceinline__ float wave_sum_f(float v) {  // the same butterfly with adds (fixed order: deterministic)
     v = v + dpp_mov<0xB1>(v);
     v = v + dpp_mov<0x4E>(v);
@@ -301,6 +332,7 @@ __device__ __forceinline__ void load4pts(const float *__restrict__ base, int p0,
 //   32-candidate block; the two half-waves are merged through the per-query LDS slot.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct __attribute__((packed, aligned(4))) P3 { float x, y, z; };  // one point: a 12-byte load
 __device__ __forceinline__ float chamfer_loss_from_sums(double sa, double sb, int N, int M, int D,
                                                         long long Bg, float w1, float w2);
 constexpr int kHThreads = 1024;   // 16 waves share one LDS image: 1 block per CU, 4 waves per SIMD
@@ -356,7 +388,7 @@ __device__ __forceinline__ void make_pieces(float cx, float cy, float cz, h8 &p0
 // The robust range of a cloud with outliers (nn1_f16_kernel, below): kept out of line so that clean clouds -- which never
 // call it -- do not pay for its registers and code.  Returns (mu, rng): the re-centred mean and 16 x the mean max-norm
 // deviation of the points within the previous range.  All threads of the block call it together (it synchronises).
-__device__ __forceinline__ float4 nn1_robust_range(const float *__restrict__ cb, int NC, int nv, bool one_shot, const float4 *imgf,
+__device__ __forceinline__ float4 nn1_robust_range(const float *__restrict__ cb, int NC, bool one_shot, const float4 *imgf,
                                                 float *red, float mu0, float mu1, float mu2, float cinf) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float mu[3] = {mu0, mu1, mu2};
@@ -371,22 +403,15 @@ __device__ __forceinline__ float4 nn1_robust_range(const float *__restrict__ cb,
                 const float dv = fmaxf(fmaxf(fabsf(x - mu[0]), fabsf(y - mu[1])), fabsf(z - mu[2]));
                 if (!trim || dv <= rng) { dev += dv; cntf += 1.0f; sx += x; sy += y; sz += z; }
             };
-            for (int q4 = tid; q4 < nv; q4 += kHThreads) {
-                float ax[4], ay[4], az[4];
+            for (int pt = tid; pt < NC; pt += kHThreads) {
                 if (one_shot) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int pt = q4 * 4 + e;
-                        const float4 r = imgf[((pt >> 5) * 2) * 32 + (pt & 31)];  // parked by this thread above
-                        ax[e] = r.x; ay[e] = r.y; az[e] = r.z;
-                    }
+                    const float4 r = imgf[((pt >> 5) * 2) * 32 + (pt & 31)];  // parked by this thread above
+                    take(r.x, r.y, r.z);
                 } else {
-                    load4pts(cb, q4 * 4, ax, ay, az);
+                    const P3 r = *reinterpret_cast<const P3 *>(cb + (size_t)pt * 3);
+                    take(r.x, r.y, r.z);
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) take(ax[e], ay[e], az[e]);
             }
-            for (int pt = nv * 4 + tid; pt < NC; pt += kHThreads) take(cb[(size_t)pt * 3], cb[(size_t)pt * 3 + 1], cb[(size_t)pt * 3 + 2]);
             // (round 0 needs the deviation only: the count is NC; round 1 the count and the sums; round 2 deviation + count)
             float v5[5] = {dev, cntf, sx, sy, sz};
             const int k0 = round == 1 ? 1 : 0, k1 = round == 0 ? 1 : (round == 1 ? 5 : 2);
@@ -430,7 +455,7 @@ __device__ __forceinline__ float4 nn1_robust_range(const float *__restrict__ cb,
 template <bool WANT_IDX>
 __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ __attribute__((aligned(16))) float red[4 * 4 * (kHThreads / 64)];  // per wave: min, max, sum, sum of squares (rows padded to 4 floats)
+    __shared__ __attribute__((aligned(16))) float red[4 * 4 * (kHThreads / 64) + 8];  // per wave: min, max, sum, sum of squares (rows padded to 4 floats); + the block's result
     __shared__ int nfar[2];                          // candidates of the chunk beyond the robust range (chunks alternate) ...
     __shared__ unsigned short farlist[kHFarCap];     // ... their indices within the chunk: compared exactly by every query
     constexpr int QB = (kHThreads / 64) * 32;  // queries per tile pass
@@ -468,7 +493,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     unsigned int *items = witems + wv * kHItemCap;
     float *qtab = wq + wv * 96;
     const bool vec = (reinterpret_cast<uintptr_t>(cb) & 15) == 0;
-    const bool one_shot = vec && NC <= CH;
+    const bool one_shot = NC <= CH;
     if (tid == 0) { nfar[0] = 0; nfar[1] = 0; }  // (ordered before their first use by the barrier of the bounding-box pass)
     FX3D_PROBE_MARK(0);
 
@@ -477,74 +502,99 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     //      much smaller than the farthest point keeps its fp16 pieces out of the subnormals; |c~|^2 < 3 * 2^14 fits fp16 ----
     float mu[3], cinf = 0.0f, varmax = 0.0f;
     bool allfin = true;
-    const int nv = vec ? NC / 4 : 0;
     {
+        // thread t takes points t, t + 1024, ...: 12-byte loads, consecutive lanes on consecutive points (coalesced, and the
+        // 16-byte LDS slots of a wave's points are consecutive: no bank conflicts when they are parked and converted)
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sm3[3] = {0.f, 0.f, 0.f};
-        float sq3[3] = {0.f, 0.f, 0.f};  // second moment of a SAMPLE (every fourth point) about the cloud's first point: the spread
+        float sq3[3] = {0.f, 0.f, 0.f}, sqn = 0.0f;  // second moment of a SAMPLE about the cloud's first point (the spread): wave w
+                                                      // takes its points of every fourth sweep, 64-point runs all over the cloud
         const float pil[3] = {cb[0], cb[1], cb[2]};
-        for (int q4 = tid; q4 < nv; q4 += kHThreads) {
-            float ax[4], ay[4], az[4];
-            load4pts(cb, q4 * 4, ax, ay, az);
+        const int nsweep = (NC + kHThreads - 1) / kHThreads;
+        for (int i0 = 0; i0 < nsweep; i0 += 4) {
+            P3 v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                mn[0] = fminf(mn[0], ax[e]); mx[0] = fmaxf(mx[0], ax[e]);
-                mn[1] = fminf(mn[1], ay[e]); mx[1] = fmaxf(mx[1], ay[e]);
-                mn[2] = fminf(mn[2], az[e]); mx[2] = fmaxf(mx[2], az[e]);
-                sm3[0] = sm3[0] + ax[e]; sm3[1] = sm3[1] + ay[e]; sm3[2] = sm3[2] + az[e];
-                if (e == 0) {  // every fourth point is sample enough for the spread (an outlier that is missed only lowers it)
-                    sq3[0] = __builtin_fmaf(ax[e] - pil[0], ax[e] - pil[0], sq3[0]); sq3[1] = __builtin_fmaf(ay[e] - pil[1], ay[e] - pil[1], sq3[1]);
-                    sq3[2] = __builtin_fmaf(az[e] - pil[2], az[e] - pil[2], sq3[2]);
+                const int pt = (i0 + e) * kHThreads + tid;
+                v[e] = *reinterpret_cast<const P3 *>(cb + (size_t)(pt < NC ? pt : NC - 1) * 3);  // (clamped: always valid)
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int pt = (i0 + e) * kHThreads + tid;
+                mn[0] = fminf(mn[0], v[e].x); mx[0] = fmaxf(mx[0], v[e].x);
+                mn[1] = fminf(mn[1], v[e].y); mx[1] = fmaxf(mx[1], v[e].y);
+                mn[2] = fminf(mn[2], v[e].z); mx[2] = fmaxf(mx[2], v[e].z);
+                if (pt < NC) {
+                    sm3[0] = sm3[0] + v[e].x; sm3[1] = sm3[1] + v[e].y; sm3[2] = sm3[2] + v[e].z;
+                    if (one_shot) imgf[((pt >> 5) * 2) * 32 + (pt & 31)] = float4{v[e].x, v[e].y, v[e].z, 0.0f};  // parked in its own first piece
                 }
-                if (one_shot) {  // park the raw point in its own first piece
-                    const int pt = q4 * 4 + e;
-                    imgf[((pt >> 5) * 2) * 32 + (pt & 31)] = float4{ax[e], ay[e], az[e], 0.0f};
+                if (((i0 + e) & 3) == (wv & 3) && pt < NC) {  // (the first condition is wave-uniform)
+                    sq3[0] = __builtin_fmaf(v[e].x - pil[0], v[e].x - pil[0], sq3[0]); sq3[1] = __builtin_fmaf(v[e].y - pil[1], v[e].y - pil[1], sq3[1]);
+                    sq3[2] = __builtin_fmaf(v[e].z - pil[2], v[e].z - pil[2], sq3[2]);
+                    sqn += 1.0f;
                 }
             }
         }
-        for (int pt = nv * 4 + tid; pt < NC; pt += kHThreads) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const float v = cb[(size_t)pt * 3 + d];
-                mn[d] = fminf(mn[d], v);
-                mx[d] = fmaxf(mx[d], v);
-                sm3[d] = sm3[d] + v;
-                sq3[d] = __builtin_fmaf(v - pil[d], v - pil[d], sq3[d]);
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float lo = wave_min_f(mn[d]), hi = wave_max_f(mx[d]);
-            const float sw = wave_sum_f(sm3[d]), qw = wave_sum_f(sq3[d]);
-            if (lane == 0) { red[(wv * 4) * 4 + d] = lo; red[(wv * 4 + 1) * 4 + d] = hi; red[(wv * 4 + 2) * 4 + d] = sw; red[(wv * 4 + 3) * 4 + d] = qw; }
-        }
-        __syncthreads();
+        FX3D_PROBE_MARK(5);
         {
-            // cross-wave reduction: one 16-byte LDS read per (wave, statistic) -- the rows are padded to four floats
-            const float4 *r4 = reinterpret_cast<const float4 *>(red);
-            float4 lo4 = r4[0], hi4 = r4[1], st4 = r4[2], sq4 = r4[3];
-#pragma unroll
-            for (int w = 1; w < kHThreads / 64; ++w) {
-                const float4 a0 = r4[w * 4], a1 = r4[w * 4 + 1], a2 = r4[w * 4 + 2], a3 = r4[w * 4 + 3];
-                lo4.x = fminf(lo4.x, a0.x); lo4.y = fminf(lo4.y, a0.y); lo4.z = fminf(lo4.z, a0.z);
-                hi4.x = fmaxf(hi4.x, a1.x); hi4.y = fmaxf(hi4.y, a1.y); hi4.z = fmaxf(hi4.z, a1.z);
-                st4.x = st4.x + a2.x; st4.y = st4.y + a2.y; st4.z = st4.z + a2.z;
-                sq4.x = sq4.x + a3.x; sq4.y = sq4.y + a3.y; sq4.z = sq4.z + a3.z;
+            float4 lo4, hi4, st4, sq4;
+            lo4.x = wave_min_l63(mn[0]); lo4.y = wave_min_l63(mn[1]); lo4.z = wave_min_l63(mn[2]); lo4.w = 0.0f;
+            hi4.x = wave_max_l63(mx[0]); hi4.y = wave_max_l63(mx[1]); hi4.z = wave_max_l63(mx[2]); hi4.w = 0.0f;
+            st4.x = wave_sum_l63(sm3[0]); st4.y = wave_sum_l63(sm3[1]); st4.z = wave_sum_l63(sm3[2]); st4.w = 0.0f;
+            sq4.x = wave_sum_l63(sq3[0]); sq4.y = wave_sum_l63(sq3[1]); sq4.z = wave_sum_l63(sq3[2]); sq4.w = wave_sum_l63(sqn);
+            if (lane == 63) {
+                float4 *r4 = reinterpret_cast<float4 *>(red);
+                r4[wv * 4] = lo4; r4[wv * 4 + 1] = hi4; r4[wv * 4 + 2] = st4; r4[wv * 4 + 3] = sq4;
             }
+        }
+        FX3D_PROBE_MARK(9);
+        __syncthreads();
+        FX3D_PROBE_MARK(10);
+        static_assert(kHThreads / 64 == 16, "the cross-wave reduction below: one wave's row of 16 lanes, one lane per wave");
+        if (wv == 0) {
+            // cross-wave reduction by the first wave alone: lane l of each row reads wave l's four statistics (16-byte reads),
+            // four DPP steps reduce over the row; the result goes back through LDS (every other wave waits at the barrier
+            // instead of repeating 64 LDS reads and 190 operations)
+            const float4 *r4 = reinterpret_cast<const float4 *>(red);
+            const int w = lane & 15;
+            float4 lo4 = r4[w * 4], hi4 = r4[w * 4 + 1], st4 = r4[w * 4 + 2], sq4 = r4[w * 4 + 3];
+#define NN1_ROW_MIN(v) v = fminf(v, dpp_mov<0xB1>(v)); v = fminf(v, dpp_mov<0x4E>(v)); v = fminf(v, dpp_mov<0x141>(v)); v = fminf(v, dpp_mov<0x140>(v));
+#define NN1_ROW_MAX(v) v = fmaxf(v, dpp_mov<0xB1>(v)); v = fmaxf(v, dpp_mov<0x4E>(v)); v = fmaxf(v, dpp_mov<0x141>(v)); v = fmaxf(v, dpp_mov<0x140>(v));
+#define NN1_ROW_SUM(v) v = v + dpp_mov<0xB1>(v); v = v + dpp_mov<0x4E>(v); v = v + dpp_mov<0x141>(v); v = v + dpp_mov<0x140>(v);
+            NN1_ROW_MIN(lo4.x) NN1_ROW_MIN(lo4.y) NN1_ROW_MIN(lo4.z)
+            NN1_ROW_MAX(hi4.x) NN1_ROW_MAX(hi4.y) NN1_ROW_MAX(hi4.z)
+            NN1_ROW_SUM(st4.x) NN1_ROW_SUM(st4.y) NN1_ROW_SUM(st4.z)
+            NN1_ROW_SUM(sq4.x) NN1_ROW_SUM(sq4.y) NN1_ROW_SUM(sq4.z) NN1_ROW_SUM(sq4.w)
+#undef NN1_ROW_MIN
+#undef NN1_ROW_MAX
+#undef NN1_ROW_SUM
             const float lo3[3] = {lo4.x, lo4.y, lo4.z}, hi3[3] = {hi4.x, hi4.y, hi4.z}, st3[3] = {st4.x, st4.y, st4.z}, sq3t[3] = {sq4.x, sq4.y, sq4.z};
+            float m3[3], ci = 0.0f, vm = 0.0f;
+            bool fin = true;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 const float lo = lo3[d], hi = hi3[d], st = st3[d], sq = sq3t[d];
-                mu[d] = fminf(fmaxf(st / (float)NC, lo), hi);  // (any centre is correct)
+                m3[d] = fminf(fmaxf(st / (float)NC, lo), hi);  // (any centre is correct)
                 // variance about the mean from the second moment about the first point (a data point: no cancellation for clouds
                 // far from the origin); the largest of the three is what the farthest point is compared with below
                 const float off = st / (float)NC - pil[d];
-                varmax = fmaxf(varmax, sq / (float)(NC - 3 * nv) - off * off);  // (nv sampled groups of four + the tail points)
-                cinf = fmaxf(cinf, fmaxf(hi - mu[d], mu[d] - lo));
+                vm = fmaxf(vm, sq / sq4.w - off * off);
+                ci = fmaxf(ci, fmaxf(hi - m3[d], m3[d] - lo));
                 // a NaN or +-Inf coordinate makes the coordinate sum non-finite (fminf / fmaxf above skip NaNs)
-                allfin = allfin && fabsf(st) < INFINITY;
+                fin = fin && fabsf(st) < INFINITY;
+            }
+            if (lane == 0) {
+                float4 *o4 = reinterpret_cast<float4 *>(red) + 4 * (kHThreads / 64);
+                o4[0] = float4{m3[0], m3[1], m3[2], ci * 1.000001f};
+                o4[1] = float4{vm, fin ? 1.0f : 0.0f, 0.0f, 0.0f};
             }
         }
-        cinf = cinf * 1.000001f;
+        __syncthreads();
+        {
+            const float4 *o4 = reinterpret_cast<const float4 *>(red) + 4 * (kHThreads / 64);
+            const float4 a = o4[0], b2 = o4[1];
+            mu[0] = a.x; mu[1] = a.y; mu[2] = a.z; cinf = a.w;
+            varmax = b2.x; allfin = b2.y != 0.0f;
+        }
     }
     // ---- robust range: a few points far from the bulk must not set the scale (the bulk would sink below fp16's resolution and
     //      the whole cloud fall back to exact scans: one point 10^5 x out cost 11 x the uniform time in round 1).
@@ -555,7 +605,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     // (clean clouds never get here: uniform boxes have cinf^2 = 3 var, Gaussians of a million points 30 var; one point
     //  far out among N makes it ~N var.  The measuring rounds cost two barriers each, 2.3 us at C2 when they always ran.)
     if (allfin && cinf < 1.0e16f && cinf * cinf > 64.0f * varmax) {
-        const float4 r = nn1_robust_range(cb, NC, nv, one_shot, imgf, red, mu[0], mu[1], mu[2], cinf);
+        const float4 r = nn1_robust_range(cb, NC, one_shot, imgf, red, mu[0], mu[1], mu[2], cinf);
         mu[0] = r.x; mu[1] = r.y; mu[2] = r.z; rng = r.w;
     }
     // not sane (non-finite or huge coordinates): the filter is unusable, every query of the block scans every lane
@@ -596,46 +646,23 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         const int cnt_pad = (cnt + 32 * kHLT - 1) / (32 * kHLT) * (32 * kHLT);
         if (j0 > jfirst) __syncthreads();
         // ---- stage the fp16 split image ------------------------------------------------------------------
-        if (one_shot) {
-            for (int q4 = tid; q4 < nv; q4 += kHThreads) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int pt = q4 * 4 + e;
-                    const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
-                    const float4 r = imgf[i0];
-                    h8 p0, p1;
+        for (int pt = tid; pt < cnt_pad + 64; pt += kHThreads) {
+            const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
+            h8 p0, p1;
+            if (pt < cnt) {
+                if (one_shot) {
+                    const float4 r = imgf[i0];  // parked by this thread in the bounding-box pass
                     pieces(r.x, r.y, r.z, pt, p0, p1);
-                    imgp[i0] = p0;
-                    imgp[i0 + 32] = p1;
-                }
-            }
-            for (int pt = nv * 4 + tid; pt < cnt_pad + 64; pt += kHThreads) {
-                const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
-                h8 p0, p1;
-                if (pt < cnt) {
-                    const float *src = cb + (size_t)pt * 3;
-                    pieces(src[0], src[1], src[2], pt, p0, p1);
-                } else {  // padding: n1 = +inf => t = +inf, never within any band
-                    make_pieces(0.f, 0.f, 0.f, p0, p1);
-                    p1[1] = (_Float16)INFINITY;
-                }
-                imgp[i0] = p0;
-                imgp[i0 + 32] = p1;
-            }
-        } else {
-            for (int pt = tid; pt < cnt_pad + 64; pt += kHThreads) {
-                const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
-                h8 p0, p1;
-                if (pt < cnt) {
-                    const float *src = cb + (size_t)(j0 + pt) * 3;
-                    pieces(src[0], src[1], src[2], pt, p0, p1);
                 } else {
-                    make_pieces(0.f, 0.f, 0.f, p0, p1);
-                    p1[1] = (_Float16)INFINITY;
+                    const P3 r = *reinterpret_cast<const P3 *>(cb + (size_t)(j0 + pt) * 3);
+                    pieces(r.x, r.y, r.z, pt, p0, p1);
                 }
-                imgp[i0] = p0;
-                imgp[i0 + 32] = p1;
+            } else {  // padding: n1 = +inf => t = +inf, never within any band
+                make_pieces(0.f, 0.f, 0.f, p0, p1);
+                p1[1] = (_Float16)INFINITY;
             }
+            imgp[i0] = p0;
+            imgp[i0 + 32] = p1;
         }
         __syncthreads();
         FX3D_PROBE_MARK(j0 == jfirst ? 2 : 6);

@@ -48,6 +48,26 @@ int main(int argc, char **argv) {
     printf("kernel span (first block start -> last block end): %llu ticks\n", tmax - t0min);
     for (int k = 1; k <= 12; ++k) printf("  %-20s avg %10.1f ticks\n", names[k], d[k] / nb);
     printf("wave-passes %llu, with a slow lane %llu, slow lanes %llu (last launch x25 accumulated)\n", pr[4095 * 16], pr[4095 * 16 + 1], pr[4095 * 16 + 2]);
+    if (getenv("RAW"))  // stamps of a few blocks relative to their first one (marks need not be in index order)
+        for (int b = 0; b < 3; ++b) {
+            printf("block %d:", b);
+            for (int k = 1; k <= 12; ++k) if (pr[b * 16 + k]) printf(" %d:%llu", k, pr[b * 16 + k] - pr[b * 16]);
+            printf("\n");
+        }
+    {   // wall clock (constant rate, shared by all blocks): block durations and the launch's span
+        int wrate = 0; hipDeviceGetAttribute(&wrate, hipDeviceAttributeWallClockRate, 0);  // kHz
+        unsigned long long a = ~0ull, e = 0; double dsum = 0, dmax = 0, late = 0;
+        for (int b = 0; b < nb; ++b) { a = std::min(a, pr[b * 16 + 13]); e = std::max(e, pr[b * 16 + 14]); }
+        for (int b = 0; b < nb; ++b) { const double d = (double)(pr[b * 16 + 14] - pr[b * 16 + 13]); dsum += d; dmax = std::max(dmax, d); late = std::max(late, (double)(pr[b * 16 + 13] - a)); }
+        printf("wall clock %d kHz: block duration avg %.2f us max %.2f us; first start -> last end %.2f us; latest start +%.2f us\n", wrate,
+               dsum / nb * 1e3 / wrate, dmax * 1e3 / wrate, (double)(e - a) * 1e3 / wrate, late * 1e3 / wrate);
+    }
+    // per XCD (blocks L with equal L % 8 share a clock): span from the first start to the last end, and the starts
+    for (int x = 0; x < 8; ++x) {
+        unsigned long long a = ~0ull, e = 0, latest = 0;
+        for (int b = x; b < nb; b += 8) { a = std::min(a, pr[b * 16]); e = std::max(e, pr[b * 16 + 12]); latest = std::max(latest, pr[b * 16]); }
+        printf("xcd %d: first start -> last end %llu ticks, latest start +%llu\n", x, e - a, latest - a);
+    }
     // block start/end distribution
     std::vector<unsigned long long> st, en;
     for (int b = 0; b < nb; ++b) { st.push_back(pr[b * 16] - t0min); en.push_back(pr[b * 16 + 12] - t0min); }
