@@ -244,62 +244,6 @@ __global__ __launch_bounds__(kThreads) void nn1_small_d_kernel(Nn1Params p) {
     }
 }
 
-// wave64 min / max by DPP (VALU speed; __shfl_xor would go through the LDS crossbar)
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float wave_min_f(float v) {
-    v = fminf(v, dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
-    v = fminf(v, dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
-    v = fminf(v, dpp_mov<0x141>(v));  // row_half_mirror
-    v = fminf(v, dpp_mov<0x140>(v));  // row_mirror  -> every lane of a 16-lane row holds the row minimum
-    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-    return fminf(fminf(a, b), fminf(c, d));
-}
-__device__ __forceinline__ float wave_max_f(float v) { return -wave_min_f(-v); }
-// the same reductions finished by DPP too (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3): the result is
-// in lane 63 only -- six VALU operations per value, no readlanes
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ float dpp_keep(float v) {  // lanes outside ROWMASK (or without a source) keep v
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
-}
-__device__ __forceinline__ float wave_min_l63(float v) {
-    v = fminf(v, dpp_mov<0xB1>(v));
-    v = fminf(v, dpp_mov<0x4E>(v));
-    v = fminf(v, dpp_mov<0x141>(v));
-    v = fminf(v, dpp_mov<0x140>(v));           // every lane of a row holds the row's minimum
-    v = fminf(v, dpp_keep<0x142, 0xA>(v));     // rows 1, 3 += rows 0, 2
-    v = fminf(v, dpp_keep<0x143, 0xC>(v));     // rows 2, 3 += row 1 (which holds rows 0..1)
-    return v;
-}
-__device__ __forceinline__ float wave_max_l63(float v) { return -wave_min_l63(-v); }
-__device__ __forceinline__ float wave_sum_l63(float v) {  // fixed order: deterministic
-    v = v + dpp_mov<0xB1>(v);
-    v = v + dpp_mov<0x4E>(v);
-    v = v + dpp_mov<0x141>(v);
-    v = v + dpp_mov<0x140>(v);
-    const float a = dpp_keep<0x142, 0xA>(v);
-    v = ((threadIdx.x >> 4) & 1) ? v + a : v;  // (rows 0 and 2 keep their own value: v + v must not happen)
-    const float b = dpp_keep<0x143, 0xC>(v);
-    v = ((threadIdx.x >> 5) & 1) ? v + b : v;
-    return v;
-}
-__device__ __forceinline__ float wave_sum_f(float v) {  // the same butterfly with adds (fixed order: deterministic)
-    v = v + dpp_mov<0xB1>(v);
-    v = v + dpp_mov<0x4E>(v);
-    v = v + dpp_mov<0x141>(v);
-    v = v + dpp_mov<0x140>(v);
-    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-    return (a + b) + (c + d);
-}
-
 // four consecutive points (12 floats) as three 16-byte loads; needs 16-B aligned base and p0 % 4 == 0
 __device__ __forceinline__ void load4pts(const float *__restrict__ base, int p0, float (&px)[4],
                                          float (&py)[4], float (&pz)[4]) {
@@ -332,7 +276,6 @@ __device__ __forceinline__ void load4pts(const float *__restrict__ base, int p0,
 //   32-candidate block; the two half-waves are merged through the per-query LDS slot.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-struct __attribute__((packed, aligned(4))) P3 { float x, y, z; };  // one point: a 12-byte load
 __device__ __forceinline__ float chamfer_loss_from_sums(double sa, double sb, int N, int M, int D,
                                                         long long Bg, float w1, float w2);
 constexpr int kHThreads = 1024;   // 16 waves share one LDS image: 1 block per CU, 4 waves per SIMD
@@ -557,8 +500,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             const float4 *r4 = reinterpret_cast<const float4 *>(red);
             const int w = lane & 15;
             float4 lo4 = r4[w * 4], hi4 = r4[w * 4 + 1], st4 = r4[w * 4 + 2], sq4 = r4[w * 4 + 3];
-#define NN1_ROW_MIN(v) v = fminf(v, dpp_mov<0xB1>(v)); v = fminf(v, dpp_mov<0x4E>(v)); v = fminf(v, dpp_mov<0x141>(v)); v = fminf(v, dpp_mov<0x140>(v));
-#define NN1_ROW_MAX(v) v = fmaxf(v, dpp_mov<0xB1>(v)); v = fmaxf(v, dpp_mov<0x4E>(v)); v = fmaxf(v, dpp_mov<0x141>(v)); v = fmaxf(v, dpp_mov<0x140>(v));
+#define NN1_ROW_MIN(v) v = fkey_inv(row_mm_key<false>(fkey(v)));
+#define NN1_ROW_MAX(v) v = fkey_inv(row_mm_key<true>(fkey(v)));
 #define NN1_ROW_SUM(v) v = v + dpp_mov<0xB1>(v); v = v + dpp_mov<0x4E>(v); v = v + dpp_mov<0x141>(v); v = v + dpp_mov<0x140>(v);
             NN1_ROW_MIN(lo4.x) NN1_ROW_MIN(lo4.y) NN1_ROW_MIN(lo4.z)
             NN1_ROW_MAX(hi4.x) NN1_ROW_MAX(hi4.y) NN1_ROW_MAX(hi4.z)

@@ -101,6 +101,85 @@ __device__ inline double block_sum(double v, double *smem /* >= NT/64 doubles */
     return r;
 }
 
+struct __attribute__((packed, aligned(4))) P3 { float x, y, z; };  // one point of a (3, N) cloud: a 12-byte load
+
+// wave64 min / max by DPP (VALU speed; __shfl_xor would go through the LDS crossbar)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+    v = fminf(v, dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = fminf(v, dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = fminf(v, dpp_mov<0x141>(v));  // row_half_mirror
+    v = fminf(v, dpp_mov<0x140>(v));  // row_mirror  -> every lane of a 16-lane row holds the row minimum
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return fminf(fminf(a, b), fminf(c, d));
+}
+__device__ __forceinline__ float wave_max_f(float v) { return -wave_min_f(-v); }
+// the same reductions finished by DPP too (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3): the result is
+// in lane 63 only -- six VALU operations per value, no readlanes
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_keep(float v) {  // lanes outside ROWMASK (or without a source) keep v
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
+}
+// (minima and maxima on order-preserving integer keys: integer min / max take the DPP operand directly, float min / max
+//  would canonicalise both operands first -- three instructions per step instead of one)
+__device__ __forceinline__ int fkey(float v) {  // signed-integer order == float order (-0 < +0; NaNs beyond the infinities)
+    const int b = __builtin_bit_cast(int, v);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float fkey_inv(int k) { return __builtin_bit_cast(float, k ^ ((k >> 31) & 0x7fffffff)); }
+template <int CTRL>
+__device__ __forceinline__ int dpp_movi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_keepi(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xF, false); }
+template <bool MAX>
+__device__ __forceinline__ int imm(int a, int b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); }
+template <bool MAX>
+__device__ __forceinline__ int row_mm_key(int k) {  // every lane of a 16-lane row ends with the row's min / max
+    k = imm<MAX>(k, dpp_movi<0xB1>(k));
+    k = imm<MAX>(k, dpp_movi<0x4E>(k));
+    k = imm<MAX>(k, dpp_movi<0x141>(k));
+    k = imm<MAX>(k, dpp_movi<0x140>(k));
+    return k;
+}
+template <bool MAX>
+__device__ __forceinline__ float wave_mm_l63(float v) {
+    int k = row_mm_key<MAX>(fkey(v));
+    k = imm<MAX>(k, dpp_keepi<0x142, 0xA>(k));  // rows 1, 3 += rows 0, 2
+    k = imm<MAX>(k, dpp_keepi<0x143, 0xC>(k));  // rows 2, 3 += row 1 (which holds rows 0..1)
+    return fkey_inv(k);
+}
+__device__ __forceinline__ float wave_min_l63(float v) { return wave_mm_l63<false>(v); }
+__device__ __forceinline__ float wave_max_l63(float v) { return wave_mm_l63<true>(v); }
+__device__ __forceinline__ float wave_sum_l63(float v) {  // fixed order: deterministic
+    v = v + dpp_mov<0xB1>(v);
+    v = v + dpp_mov<0x4E>(v);
+    v = v + dpp_mov<0x141>(v);
+    v = v + dpp_mov<0x140>(v);
+    const float a = dpp_keep<0x142, 0xA>(v);
+    v = ((threadIdx.x >> 4) & 1) ? v + a : v;  // (rows 0 and 2 keep their own value: v + v must not happen)
+    const float b = dpp_keep<0x143, 0xC>(v);
+    v = ((threadIdx.x >> 5) & 1) ? v + b : v;
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {  // the same butterfly with adds (fixed order: deterministic)
+    v = v + dpp_mov<0xB1>(v);
+    v = v + dpp_mov<0x4E>(v);
+    v = v + dpp_mov<0x141>(v);
+    v = v + dpp_mov<0x140>(v);
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (a + b) + (c + d);
+}
+
+
 // Sum `n` doubles written by a previous kernel, single block of 256, fixed order.
 // (file-local copy per translation unit: no relocatable device code needed)
 __global__ static void reduce_partials_kernel(const double *__restrict__ partials, int64_t n,

@@ -845,7 +845,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                                                                float *__restrict__ dist, int CH, int img_bytes,
                                                                int raw_ok, float *__restrict__ feat, int layout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k3sm[];
-    __shared__ float red[3 * 4 * kTWaves];  // per wave: min, max, sum (padded to 4 dims)
+    __shared__ __attribute__((aligned(16))) float red[3 * 4 * kTWaves];  // per wave: min, max, sum (padded to 4 dims)
     kh8 *imgp = reinterpret_cast<kh8 *>(k3sm);  // piece (blk, half, row) at (blk*2 + half)*32 + row
     constexpr int kListBytes = kTWaves * kTCap * 64 * 4;      // lane lists; also the tau exchange and, later, the slots
     constexpr int kCtrInts = kTGroups * 32 * 8;               // per query: 4 part counts, overflow, n, fast, below
@@ -879,57 +879,57 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     {
         float4 *raww = reinterpret_cast<float4 *>(k3sm + img_bytes + kListBytes + kCtrInts * 4);
         float mn3[3] = {INFINITY, INFINITY, INFINITY}, mx3[3] = {-INFINITY, -INFINITY, -INFINITY}, sm3[3] = {0.f, 0.f, 0.f};
-        const bool vec = (reinterpret_cast<uintptr_t>(yb) & 15) == 0;
-        const int nv4 = vec ? M / 4 : 0;
-        for (int g = tid; g < nv4; g += kTThreads) {  // four points = three 16-byte loads
-            const float4 *s4 = reinterpret_cast<const float4 *>(yb + (size_t)g * 12);
-            const float4 f0 = s4[0], f1 = s4[1], f2 = s4[2];
-            const float px[4] = {f0.x, f0.w, f1.z, f2.y}, py[4] = {f0.y, f1.x, f1.w, f2.z}, pz[4] = {f0.z, f1.y, f2.x, f2.w};
+        // thread t takes points t, t + kTThreads, ...: 12-byte loads, consecutive lanes on consecutive points (coalesced,
+        // and the 16-byte LDS slots of a wave's points are consecutive: no bank conflicts)
+        const int nsweep = (M + kTThreads - 1) / kTThreads;
+        for (int i0 = 0; i0 < nsweep; i0 += 4) {
+            P3 v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                mn3[0] = fminf(mn3[0], px[e]); mx3[0] = fmaxf(mx3[0], px[e]);
-                mn3[1] = fminf(mn3[1], py[e]); mx3[1] = fmaxf(mx3[1], py[e]);
-                mn3[2] = fminf(mn3[2], pz[e]); mx3[2] = fmaxf(mx3[2], pz[e]);
-                sm3[0] = sm3[0] + px[e]; sm3[1] = sm3[1] + py[e]; sm3[2] = sm3[2] + pz[e];
-                if (raw_ok) raww[g * 4 + e] = float4{px[e], py[e], pz[e], 0.0f};
+                const int pt = (i0 + e) * kTThreads + tid;
+                v[e] = *reinterpret_cast<const P3 *>(yb + (size_t)(pt < M ? pt : M - 1) * 3);  // (clamped: always valid)
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int pt = (i0 + e) * kTThreads + tid;
+                mn3[0] = fminf(mn3[0], v[e].x); mx3[0] = fmaxf(mx3[0], v[e].x);
+                mn3[1] = fminf(mn3[1], v[e].y); mx3[1] = fmaxf(mx3[1], v[e].y);
+                mn3[2] = fminf(mn3[2], v[e].z); mx3[2] = fmaxf(mx3[2], v[e].z);
+                if (pt < M) {
+                    sm3[0] = sm3[0] + v[e].x; sm3[1] = sm3[1] + v[e].y; sm3[2] = sm3[2] + v[e].z;
+                    if (raw_ok) raww[pt] = float4{v[e].x, v[e].y, v[e].z, 0.0f};
+                }
             }
         }
-        for (int pt = nv4 * 4 + tid; pt < M; pt += kTThreads) {
-            float v[3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                v[d] = yb[(size_t)pt * 3 + d];
-                mn3[d] = fminf(mn3[d], v[d]);
-                mx3[d] = fmaxf(mx3[d], v[d]);
-                sm3[d] = sm3[d] + v[d];
+        {   // wave level by DPP (the result is in lane 63), one 16-byte row per (wave, statistic)
+            float4 lo4, hi4, st4;
+            lo4.x = wave_min_l63(mn3[0]); lo4.y = wave_min_l63(mn3[1]); lo4.z = wave_min_l63(mn3[2]); lo4.w = 0.0f;
+            hi4.x = wave_max_l63(mx3[0]); hi4.y = wave_max_l63(mx3[1]); hi4.z = wave_max_l63(mx3[2]); hi4.w = 0.0f;
+            st4.x = wave_sum_l63(sm3[0]); st4.y = wave_sum_l63(sm3[1]); st4.z = wave_sum_l63(sm3[2]); st4.w = 0.0f;
+            if (lane == 63) {
+                float4 *r4 = reinterpret_cast<float4 *>(red);
+                r4[wv * 3] = lo4; r4[wv * 3 + 1] = hi4; r4[wv * 3 + 2] = st4;
             }
-            if (raw_ok) raww[pt] = float4{v[0], v[1], v[2], 0.0f};
-        }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            float lo = mn3[d], hi = mx3[d], sw = sm3[d];
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) {
-                lo = fminf(lo, __shfl_xor(lo, m, 64));
-                hi = fmaxf(hi, __shfl_xor(hi, m, 64));
-                sw = sw + __shfl_xor(sw, m, 64);
-            }
-            if (lane == 0) { red[(wv * 3) * 4 + d] = lo; red[(wv * 3 + 1) * 4 + d] = hi; red[(wv * 3 + 2) * 4 + d] = sw; }
         }
         __syncthreads();
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            float lo = red[d], hi = red[4 + d], st = red[8 + d];
+        {
+            const float4 *r4 = reinterpret_cast<const float4 *>(red);
+            float4 lo4 = r4[0], hi4 = r4[1], st4 = r4[2];
 #pragma unroll
             for (int w = 1; w < kTWaves; ++w) {
-                lo = fminf(lo, red[(w * 3) * 4 + d]);
-                hi = fmaxf(hi, red[(w * 3 + 1) * 4 + d]);
-                st = st + red[(w * 3 + 2) * 4 + d];
+                const float4 a0 = r4[w * 3], a1 = r4[w * 3 + 1], a2 = r4[w * 3 + 2];
+                lo4.x = fminf(lo4.x, a0.x); lo4.y = fminf(lo4.y, a0.y); lo4.z = fminf(lo4.z, a0.z);
+                hi4.x = fmaxf(hi4.x, a1.x); hi4.y = fmaxf(hi4.y, a1.y); hi4.z = fmaxf(hi4.z, a1.z);
+                st4.x = st4.x + a2.x; st4.y = st4.y + a2.y; st4.z = st4.z + a2.z;
             }
-            // centre = the MEAN (a stray far point moves the box centre, hardly the mean); any centre is correct
-            mu[d] = fminf(fmaxf(st / (float)M, lo), hi);
-            cinf = fmaxf(cinf, fmaxf(hi - mu[d], mu[d] - lo));
-            allfin = allfin && fabsf(st) < INFINITY;  // a NaN / +-Inf coordinate makes the sum non-finite (fminf / fmaxf skip NaNs)
+            const float lo3[3] = {lo4.x, lo4.y, lo4.z}, hi3[3] = {hi4.x, hi4.y, hi4.z}, st3[3] = {st4.x, st4.y, st4.z};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                // centre = the MEAN (a stray far point moves the box centre, hardly the mean); any centre is correct
+                mu[d] = fminf(fmaxf(st3[d] / (float)M, lo3[d]), hi3[d]);
+                cinf = fmaxf(cinf, fmaxf(hi3[d] - mu[d], mu[d] - lo3[d]));
+                allfin = allfin && fabsf(st3[d]) < INFINITY;  // a NaN / +-Inf coordinate makes the sum non-finite (fminf / fmaxf skip NaNs)
+            }
         }
         cinf = cinf * 1.000001f;
     }
