@@ -882,7 +882,43 @@ __global__ __launch_bounds__(kThreads) void nn1_split_finalize_kernel(Nn1Params 
     if (p.partials) {
         __shared__ double sm[kThreads / 64];
         const double tot = block_sum<kThreads>(acc, sm);
-        if (threadIdx.x == 0) p.partials[(size_t)c * tiles_f + blockIdx.x] = tot;
+        if (!p.ticket) {
+            if (threadIdx.x == 0) p.partials[(size_t)c * tiles_f + blockIdx.x] = tot;
+            return;
+        }
+        // fused finalisation (as in nn1_f16_kernel): the last block to arrive sums the partials in the order of
+        // chamfer_finalize_partials_kernel and writes the sums / the loss -- one launch less per split run
+        __shared__ int is_last;
+        unsigned long long *pp = reinterpret_cast<unsigned long long *>(p.partials);
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&pp[(size_t)c * tiles_f + blockIdx.x], __builtin_bit_cast(unsigned long long, tot), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int old = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            is_last = old == p.nvalid - 1;
+        }
+        __syncthreads();
+        if (is_last) {
+            double tsum[2];
+            for (int dd = 0; dd < 2; ++dd) {
+                const int nt = dd ? p.tiles_y : p.tiles_x;
+                const long long n = (long long)p.B * nt;
+                double a = 0.0;
+                for (long long k = threadIdx.x; k < n; k += kThreads) {
+                    const int bb = (int)(k / nt), tt = (int)(k % nt);
+                    const unsigned long long v = __hip_atomic_load(&pp[((size_t)(dd * p.B + bb)) * tiles_f + tt], __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_AGENT);
+                    a += __builtin_bit_cast(double, v);
+                }
+                __syncthreads();
+                tsum[dd] = block_sum<kThreads>(a, sm);
+            }
+            if (threadIdx.x == 0) {
+                if (p.sums_out) { p.sums_out[0] = tsum[0]; p.sums_out[1] = tsum[1]; }
+                if (p.loss_out) *p.loss_out = chamfer_loss_from_sums(tsum[0], tsum[1], p.N, p.M, 3, p.Bg, p.w1, p.w2);
+                __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for reuse
+            }
+        }
     }
 }
 
@@ -1308,14 +1344,15 @@ static fx3d_status chamfer_common(const float *x, int N, const float *y, int M, 
         Nn1Params fp{};
         fp.N = N; fp.M = M; fp.B = B; fp.idx_x = idx_x; fp.idx_y = idx_y; fp.partials = partials;
         fp.gres = gres; fp.qstride = maxq; fp.nsplit = pl.nsplit;
+        // (split runs exist for D == 3 only) the last block of the unpack kernel reduces the partials: no finalize launch
+        fx3d_status trc = FX3D_OK;
+        unsigned int *ticket = ticket_slot(&trc, st);
+        if (!ticket) return trc;
+        fp.ticket = ticket; fp.nvalid = (unsigned int)((long long)tiles_f * 2 * B);
+        fp.tiles_x = (N + kThreads - 1) / kThreads; fp.tiles_y = (M + kThreads - 1) / kThreads;
+        fp.sums_out = sums_dev ? sums_dev : partials + (size_t)2 * B * tiles_f;
+        fp.loss_out = loss_dev; fp.w1 = w1; fp.w2 = w2; fp.Bg = Bg;
         hipLaunchKernelGGL(nn1_split_finalize_kernel, dim3(tiles_f, 2 * B), dim3(kThreads), 0, st, fp, tiles_f);
-        FX3D_LAUNCH_CHECK();
-        FinalizeParams f{};
-        f.partials = partials; f.B = B; f.tiles = tiles_f;
-        f.tiles_x = (N + kThreads - 1) / kThreads; f.tiles_y = (M + kThreads - 1) / kThreads;
-        f.sums = sums_dev ? sums_dev : partials + (size_t)2 * B * tiles_f;
-        f.loss = loss_dev; f.N = N; f.M = M; f.D = D; f.Bg = Bg; f.w1 = w1; f.w2 = w2;
-        hipLaunchKernelGGL(chamfer_finalize_partials_kernel, dim3(1), dim3(kThreads), 0, st, f);
         FX3D_LAUNCH_CHECK();
         return FX3D_OK;
     }
