@@ -359,26 +359,23 @@ __device__ __forceinline__ float4 nn1_robust_range(const float *__restrict__ cb,
             float v5[5] = {dev, cntf, sx, sy, sz};
             const int k0 = round == 1 ? 1 : 0, k1 = round == 0 ? 1 : (round == 1 ? 5 : 2);
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                if (k >= k0 && k < k1) {
-#pragma unroll
-                    for (int m = 1; m < 64; m <<= 1) v5[k] = v5[k] + __shfl_xor(v5[k], m, 64);
-                }
-            }
+            for (int k = 0; k < 5; ++k)
+                if (k >= k0 && k < k1) v5[k] = wave_sum_l63(v5[k]);  // DPP: the total is in lane 63
             __syncthreads();  // (red was read above)
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < 5; ++k) red[wv * 5 + k] = v5[k];
+            if (lane == 63) {
+                float4 *r4 = reinterpret_cast<float4 *>(red);
+                r4[wv * 2] = float4{v5[0], v5[1], v5[2], v5[3]};
+                r4[wv * 2 + 1] = float4{v5[4], 0.0f, 0.0f, 0.0f};
             }
             __syncthreads();
-            float t5[5];
+            float t5[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            {
+                const float4 *r4 = reinterpret_cast<const float4 *>(red);
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                t5[k] = 0.0f;
-                if (k >= k0 && k < k1) {
-                    t5[k] = red[k];
-#pragma unroll
-                    for (int w = 1; w < kHThreads / 64; ++w) t5[k] = t5[k] + red[w * 5 + k];
+                for (int w = 0; w < kHThreads / 64; ++w) {
+                    const float4 a = r4[w * 2];
+                    t5[0] = t5[0] + a.x; t5[1] = t5[1] + a.y; t5[2] = t5[2] + a.z; t5[3] = t5[3] + a.w;
+                    if (round == 1) t5[4] = t5[4] + r4[w * 2 + 1].x;
                 }
             }
             if (round == 0) t5[1] = (float)NC;
