@@ -47,6 +47,7 @@ SIGNATURES = {
     "fx3d_graph_destroy": [vp],
     "fx3d_counter_add": [vp, c_u64, vp],
     "fx3d_event_create": [C.POINTER(vp)],
+    "fx3d_event_create_sync": [C.POINTER(vp)],
     "fx3d_event_destroy": [vp],
     "fx3d_event_record": [vp, vp],
     "fx3d_event_sync": [vp],

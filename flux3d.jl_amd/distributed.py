@@ -187,8 +187,8 @@ class NativeShardedChamfer:
         if overlap:
             from .device import Event
             self.side = Stream.create()
-            self.ready = [Event() for _ in range(self.nslot)]
-            self.done = [Event() for _ in range(self.nslot)]
+            self.ready = [Event(timing=False) for _ in range(self.nslot)]  # ordering only: cheaper records
+            self.done = [Event(timing=False) for _ in range(self.nslot)]
 
     def __call__(self, x_shard, y_shard, B_global, w1=1.0, w2=1.0, sync=True):
         key = (id(x_shard), id(y_shard), getattr(x_shard, "shape", None), getattr(y_shard, "shape", None))

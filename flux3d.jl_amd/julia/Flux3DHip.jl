@@ -721,6 +721,9 @@ stream_synchronize(s::Stream = DEFAULT_STREAM) = check(@ccall LIB.fx3d_stream_sy
 function event_create()
     e = Ref{Event}(C_NULL); check(@ccall LIB.fx3d_event_create(e::Ref{Event})::Int32); return e[]
 end
+function event_create_sync()  # ordering only (stream_wait_event / event_synchronize): no timestamps, no system-scope fence
+    e = Ref{Event}(C_NULL); check(@ccall LIB.fx3d_event_create_sync(e::Ref{Event})::Int32); return e[]
+end
 event_destroy(e::Event) = check(@ccall LIB.fx3d_event_destroy(e::Event)::Int32)
 event_record(e::Event, s::Stream = DEFAULT_STREAM) = check(@ccall LIB.fx3d_event_record(e::Event, s::Stream)::Int32)
 event_synchronize(e::Event) = check(@ccall LIB.fx3d_event_sync(e::Event)::Int32)

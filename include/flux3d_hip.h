@@ -80,6 +80,9 @@ FX3D_API fx3d_status fx3d_graph_destroy(fx3d_graph_t g);
 /* *ctr += inc on the device, stream ordered: the per-replay part of a sampling seed (fx3d_sample_points_draw). */
 FX3D_API fx3d_status fx3d_counter_add(uint64_t *ctr, uint64_t inc, fx3d_stream_t s);
 FX3D_API fx3d_status fx3d_event_create(fx3d_event_t *e);
+/* An event for ordering only (fx3d_stream_wait_event between streams of ONE device, fx3d_event_sync from the host): no
+ * timestamps (fx3d_event_elapsed_ms is an error on it) and no system-scope fence at the record -- cheaper on the device. */
+FX3D_API fx3d_status fx3d_event_create_sync(fx3d_event_t *e);
 FX3D_API fx3d_status fx3d_event_destroy(fx3d_event_t e);
 FX3D_API fx3d_status fx3d_event_record(fx3d_event_t e, fx3d_stream_t s);
 FX3D_API fx3d_status fx3d_event_sync(fx3d_event_t e);
