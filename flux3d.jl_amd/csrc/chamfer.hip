@@ -328,70 +328,6 @@ __device__ __forceinline__ void make_pieces(float cx, float cy, float cz, h8 &p0
     p1 = h8{lz, n1, n2, n3, lx, ly, lz, z};
 }
 
-// The robust range of a cloud with outliers (nn1_f16_kernel, below): kept out of line so that clean clouds -- which never
-// call it -- do not pay for its registers and code.  Returns (mu, rng): the re-centred mean and 16 x the mean max-norm
-// deviation of the points within the previous range.  All threads of the block call it together (it synchronises).
-__device__ __forceinline__ float4 nn1_robust_range(const float *__restrict__ cb, int NC, bool one_shot, const float4 *imgf,
-                                                float *red, float mu0, float mu1, float mu2, float cinf) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    float mu[3] = {mu0, mu1, mu2};
-    float rng = cinf;
-    {
-        // round 0: deviations from the mean of all points.  If that finds outliers (rng < cinf) the mean itself was pulled
-        // by them: round 1 re-centres on the points inside the range, round 2 measures the deviations about that centre.
-        for (int round = 0; round < 3; ++round) {
-            const bool trim = round > 0;
-            float dev = 0.0f, cntf = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
-            auto take = [&](float x, float y, float z) {
-                const float dv = fmaxf(fmaxf(fabsf(x - mu[0]), fabsf(y - mu[1])), fabsf(z - mu[2]));
-                if (!trim || dv <= rng) { dev += dv; cntf += 1.0f; sx += x; sy += y; sz += z; }
-            };
-            for (int pt = tid; pt < NC; pt += kHThreads) {
-                if (one_shot) {
-                    const float4 r = imgf[((pt >> 5) * 2) * 32 + (pt & 31)];  // parked by this thread above
-                    take(r.x, r.y, r.z);
-                } else {
-                    const P3 r = *reinterpret_cast<const P3 *>(cb + (size_t)pt * 3);
-                    take(r.x, r.y, r.z);
-                }
-            }
-            // (round 0 needs the deviation only: the count is NC; round 1 the count and the sums; round 2 deviation + count)
-            float v5[5] = {dev, cntf, sx, sy, sz};
-            const int k0 = round == 1 ? 1 : 0, k1 = round == 0 ? 1 : (round == 1 ? 5 : 2);
-#pragma unroll
-            for (int k = 0; k < 5; ++k)
-                if (k >= k0 && k < k1) v5[k] = wave_sum_l63(v5[k]);  // DPP: the total is in lane 63
-            __syncthreads();  // (red was read above)
-            if (lane == 63) {
-                float4 *r4 = reinterpret_cast<float4 *>(red);
-                r4[wv * 2] = float4{v5[0], v5[1], v5[2], v5[3]};
-                r4[wv * 2 + 1] = float4{v5[4], 0.0f, 0.0f, 0.0f};
-            }
-            __syncthreads();
-            float t5[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            {
-                const float4 *r4 = reinterpret_cast<const float4 *>(red);
-#pragma unroll
-                for (int w = 0; w < kHThreads / 64; ++w) {
-                    const float4 a = r4[w * 2];
-                    t5[0] = t5[0] + a.x; t5[1] = t5[1] + a.y; t5[2] = t5[2] + a.z; t5[3] = t5[3] + a.w;
-                    if (round == 1) t5[4] = t5[4] + r4[w * 2 + 1].x;
-                }
-            }
-            if (round == 0) t5[1] = (float)NC;
-            if (!(t5[1] > 0.0f)) break;                      // (uniform)
-            if (round == 1) {  // re-centre on the points inside the range; measured again about the new centre next round
-                mu[0] = t5[2] / t5[1]; mu[1] = t5[3] / t5[1]; mu[2] = t5[4] / t5[1];
-                continue;
-            }
-            const float r16 = 16.0f * (t5[0] / t5[1]);
-            if (r16 > 0.0f && r16 < rng) rng = r16;
-            if (round == 0 && !(rng < cinf)) break;           // no outliers: the plain mean and cinf stand
-        }
-    }
-    return float4{mu[0], mu[1], mu[2], rng};
-}
-
 template <bool WANT_IDX>
 __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -542,10 +478,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     //      16 x 0.375 of the half width; Gaussian: 21 sigma); candidates beyond the range ("far") are left out of the filter
     //      (norm = +inf) and compared exactly by every query through a side list of at most kHFarCap entries per chunk. ----
     float rng = cinf;
-    // (clean clouds never get here: uniform boxes have cinf^2 = 3 var, Gaussians of a million points 30 var; one point
-    //  far out among N makes it ~N var.  The measuring rounds cost two barriers each, 2.3 us at C2 when they always ran.)
-    if (allfin && cinf < 1.0e16f && cinf * cinf > 64.0f * varmax) {
-        const float4 r = nn1_robust_range(cb, NC, one_shot, imgf, red, mu[0], mu[1], mu[2], cinf);
+    // (clean clouds never get here -- uniform boxes have cinf^2 = 3 var, Gaussians of a million points 30 var --; a round costs
+    //  two barriers, ~1.3 us at C2; all three run only when the first finds the bulk kRobustHarm x below the farthest point)
+    if (allfin && cinf < 1.0e16f && cinf * cinf > kRobustGate * varmax) {
+        const float4 r = robust_range3<kHThreads, false>(cb, NC, one_shot, imgf, red, mu[0], mu[1], mu[2], cinf);
         mu[0] = r.x; mu[1] = r.y; mu[2] = r.z; rng = r.w;
     }
     // not sane (non-finite or huge coordinates): the filter is unusable, every query of the block scans every lane

@@ -180,6 +180,79 @@ __device__ __forceinline__ float wave_sum_f(float v) {  // the same butterfly wi
 }
 
 
+// The robust-range rounds run when cinf^2 > kRobustGate * variance (the farthest point more than 8 sigma out; the sampled
+// variance contains the outliers themselves, so one far point among N makes the ratio ~N at most: the gate cannot be much higher),
+// and they stop after the first one unless the range it finds is kRobustHarm times below cinf: the folded norms keep the
+// filter sharp with a point up to ~10^3 x the extent away, only beyond that does the bulk sink below fp16's resolution.
+constexpr float kRobustGate = 64.0f;
+constexpr float kRobustHarm = 8.0f;  // (round 0 measures about a mean the outliers pulled: one extreme point among N gives cinf / rng ~ N / 32)
+
+// The robust range of a D = 3 cloud with outliers (nn1_f16_kernel, knn_f16_d3_kernel): clean clouds never call it.
+// NT threads per block; `parked`: the raw points sit in LDS as float4 (LINEAR: park[pt]; otherwise in the first piece
+// of their fp16-image slot, park[((pt >> 5) * 2) * 32 + (pt & 31)]), else they are read from `cb`; red: >= 8 NT/64 floats.  Returns (mu, rng): the re-centred mean and 16 x the mean max-norm
+// deviation of the points within the previous range.  All threads of the block call it together (it synchronises).
+template <int NT, bool LINEAR>
+__device__ __forceinline__ float4 robust_range3(const float *__restrict__ cb, int NC, bool parked, const float4 *park,
+                                               float *red, float mu0, float mu1, float mu2, float cinf) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float mu[3] = {mu0, mu1, mu2};
+    float rng = cinf;
+    {
+        // round 0: deviations from the mean of all points.  If that finds outliers (rng < cinf) the mean itself was pulled
+        // by them: round 1 re-centres on the points inside the range, round 2 measures the deviations about that centre.
+        for (int round = 0; round < 3; ++round) {
+            const bool trim = round > 0;
+            float dev = 0.0f, cntf = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
+            auto take = [&](float x, float y, float z) {
+                const float dv = fmaxf(fmaxf(fabsf(x - mu[0]), fabsf(y - mu[1])), fabsf(z - mu[2]));
+                if (!trim || dv <= rng) { dev += dv; cntf += 1.0f; sx += x; sy += y; sz += z; }
+            };
+            for (int pt = tid; pt < NC; pt += NT) {
+                if (parked) {
+                    const float4 r = park[LINEAR ? pt : ((pt >> 5) * 2) * 32 + (pt & 31)];  // parked by this thread in the cloud pass
+                    take(r.x, r.y, r.z);
+                } else {
+                    const P3 r = *reinterpret_cast<const P3 *>(cb + (size_t)pt * 3);
+                    take(r.x, r.y, r.z);
+                }
+            }
+            // (round 0 needs the deviation only: the count is NC; round 1 the count and the sums; round 2 deviation + count)
+            float v5[5] = {dev, cntf, sx, sy, sz};
+            const int k0 = round == 1 ? 1 : 0, k1 = round == 0 ? 1 : (round == 1 ? 5 : 2);
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                if (k >= k0 && k < k1) v5[k] = wave_sum_l63(v5[k]);  // DPP: the total is in lane 63
+            __syncthreads();  // (red was read above)
+            if (lane == 63) {
+                float4 *r4 = reinterpret_cast<float4 *>(red);
+                r4[wv * 2] = float4{v5[0], v5[1], v5[2], v5[3]};
+                r4[wv * 2 + 1] = float4{v5[4], 0.0f, 0.0f, 0.0f};
+            }
+            __syncthreads();
+            float t5[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            {
+                const float4 *r4 = reinterpret_cast<const float4 *>(red);
+#pragma unroll
+                for (int w = 0; w < NT / 64; ++w) {
+                    const float4 a = r4[w * 2];
+                    t5[0] = t5[0] + a.x; t5[1] = t5[1] + a.y; t5[2] = t5[2] + a.z; t5[3] = t5[3] + a.w;
+                    if (round == 1) t5[4] = t5[4] + r4[w * 2 + 1].x;
+                }
+            }
+            if (round == 0) t5[1] = (float)NC;
+            if (!(t5[1] > 0.0f)) break;                      // (uniform)
+            if (round == 1) {  // re-centre on the points inside the range; measured again about the new centre next round
+                mu[0] = t5[2] / t5[1]; mu[1] = t5[3] / t5[1]; mu[2] = t5[4] / t5[1];
+                continue;
+            }
+            const float r16 = 16.0f * (t5[0] / t5[1]);
+            if (r16 > 0.0f && r16 < rng) rng = r16;
+            if (round == 0 && !(rng * kRobustHarm < cinf)) { rng = cinf; break; }  // no (harmful) outliers: the plain mean and cinf stand
+        }
+    }
+    return float4{mu[0], mu[1], mu[2], rng};
+}
+
 // Sum `n` doubles written by a previous kernel, single block of 256, fixed order.
 // (file-local copy per translation unit: no relocatable device code needed)
 __global__ static void reduce_partials_kernel(const double *__restrict__ partials, int64_t n,

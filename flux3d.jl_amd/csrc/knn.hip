@@ -773,6 +773,7 @@ constexpr int kTKeyCap = 64;          // keys per query (the two lanes' survivor
 constexpr int kTKeyStride = kTKeyCap + 4;  // row stride in words: 32 queries x b128 reads without bank conflicts
 constexpr int kTChunk = 3072;         // candidates per LDS image (32 B each): image + lists + counters <= 152 KiB
 constexpr int kTRawMax = 2048;        // clouds up to this size also keep their raw coordinates in LDS
+constexpr int kK3FarCap = 16;         // far candidates (robust range, as in nn1_f16_kernel) kept on the exact side list
 
 __device__ __forceinline__ float vmax_f32(float a, float b) {
     float r;
@@ -796,6 +797,21 @@ __device__ __forceinline__ void k3_make_pieces(float cx, float cy, float cz, kh8
     n3 = (_Float16)(r1 - (float)n2);
     p0 = kh8{hx, hx, lx, hy, hy, ly, hz, hz};
     p1 = kh8{lz, n1, n2, n3, lx, ly, lz, (_Float16)1.0f};  // slot 15: times the query's -threshold in phase B
+}
+// ... of a candidate that may lie beyond the robust range (|c~|_inf >= 2^7): zero pieces, norm +inf (its filter value is
+// +inf for every query), recorded once (first staging of its chunk) on the block's side list
+__device__ __forceinline__ void k3_pieces_far(float sx, float sy, float sz, bool has_far, bool record, int index, int *nfar, int *farlist,
+                                              kh8 &p0, kh8 &p1) {
+    if (!has_far) { k3_make_pieces(sx, sy, sz, p0, p1); return; }
+    const bool far = !(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)) < 128.0f);
+    k3_make_pieces(far ? 0.f : sx, far ? 0.f : sy, far ? 0.f : sz, p0, p1);
+    if (far) {
+        p1[1] = (_Float16)INFINITY;
+        if (record) {
+            const int f = atomicAdd(nfar, 1);
+            if (f < kK3FarCap) farlist[f] = index;
+        }
+    }
 }
 // ascending sort of NV registers (compile-time indices only): Batcher's odd-even merge sort, 191 compare-exchanges
 // for 32 values (the bitonic network needs 240)
@@ -845,7 +861,9 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                                                                float *__restrict__ dist, int CH, int img_bytes,
                                                                int raw_ok, float *__restrict__ feat, int layout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k3sm[];
-    __shared__ __attribute__((aligned(16))) float red[3 * 4 * kTWaves];  // per wave: min, max, sum (padded to 4 dims)
+    __shared__ __attribute__((aligned(16))) float red[4 * 4 * kTWaves];  // per wave: min, max, sum, sampled second moment (padded to 4 dims)
+    __shared__ int nfar;                    // candidates of the cloud beyond the robust range ...
+    __shared__ int farlist[kK3FarCap];      // ... their indices: outside the filter, every query evaluates them exactly
     kh8 *imgp = reinterpret_cast<kh8 *>(k3sm);  // piece (blk, half, row) at (blk*2 + half)*32 + row
     constexpr int kListBytes = kTWaves * kTCap * 64 * 4;      // lane lists; also the tau exchange and, later, the slots
     constexpr int kCtrInts = kTGroups * 32 * 8;               // per query: 4 part counts, overflow, n, fast, below
@@ -867,6 +885,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     const int q0 = (bxq * kTGroups + grp) * 32;
     const bool wave_active = q0 < N;
     for (int e = tid; e < kCtrInts; e += kTThreads) ctr[e] = 0;
+    if (tid == 0) nfar = 0;  // (ordered before its first use by the barrier of the cloud pass)
     const int qi = q0 + jq;  // this lane's query (loaded here: the latency hides behind the pass over the cloud)
     const int qc = qi < N ? qi : N - 1;
     const float qr[3] = {xb[(size_t)qc * 3], xb[(size_t)qc * 3 + 1], xb[(size_t)qc * 3 + 2]};
@@ -874,11 +893,13 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
 
     // ---- one pass over the cloud: bounding box (-> centre mu, power-of-two scale sc with |c~| <= 1) and, for
     //      clouds up to kTRawMax points, the raw coordinates parked in LDS for the staging and the exact phase ----
-    float mu[3], cinf = 0.0f;
+    float mu[3], cinf = 0.0f, varmax = 0.0f;
     bool allfin = true;
     {
         float4 *raww = reinterpret_cast<float4 *>(k3sm + img_bytes + kListBytes + kCtrInts * 4);
         float mn3[3] = {INFINITY, INFINITY, INFINITY}, mx3[3] = {-INFINITY, -INFINITY, -INFINITY}, sm3[3] = {0.f, 0.f, 0.f};
+        float sq3[3] = {0.f, 0.f, 0.f}, sqn = 0.0f;  // second moment of a sample about the cloud's first point (the spread)
+        const float pil[3] = {yb[0], yb[1], yb[2]};
         // thread t takes points t, t + kTThreads, ...: 12-byte loads, consecutive lanes on consecutive points (coalesced,
         // and the 16-byte LDS slots of a wave's points are consecutive: no bank conflicts)
         const int nsweep = (M + kTThreads - 1) / kTThreads;
@@ -899,34 +920,43 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                     sm3[0] = sm3[0] + v[e].x; sm3[1] = sm3[1] + v[e].y; sm3[2] = sm3[2] + v[e].z;
                     if (raw_ok) raww[pt] = float4{v[e].x, v[e].y, v[e].z, 0.0f};
                 }
+                if (((i0 + e) & 3) == (wv & 3) && pt < M) {  // (wave-uniform first condition: 64-point runs all over the cloud)
+                    sq3[0] = __builtin_fmaf(v[e].x - pil[0], v[e].x - pil[0], sq3[0]); sq3[1] = __builtin_fmaf(v[e].y - pil[1], v[e].y - pil[1], sq3[1]);
+                    sq3[2] = __builtin_fmaf(v[e].z - pil[2], v[e].z - pil[2], sq3[2]);
+                    sqn += 1.0f;
+                }
             }
         }
         {   // wave level by DPP (the result is in lane 63), one 16-byte row per (wave, statistic)
-            float4 lo4, hi4, st4;
+            float4 lo4, hi4, st4, sq4;
             lo4.x = wave_min_l63(mn3[0]); lo4.y = wave_min_l63(mn3[1]); lo4.z = wave_min_l63(mn3[2]); lo4.w = 0.0f;
             hi4.x = wave_max_l63(mx3[0]); hi4.y = wave_max_l63(mx3[1]); hi4.z = wave_max_l63(mx3[2]); hi4.w = 0.0f;
             st4.x = wave_sum_l63(sm3[0]); st4.y = wave_sum_l63(sm3[1]); st4.z = wave_sum_l63(sm3[2]); st4.w = 0.0f;
+            sq4.x = wave_sum_l63(sq3[0]); sq4.y = wave_sum_l63(sq3[1]); sq4.z = wave_sum_l63(sq3[2]); sq4.w = wave_sum_l63(sqn);
             if (lane == 63) {
                 float4 *r4 = reinterpret_cast<float4 *>(red);
-                r4[wv * 3] = lo4; r4[wv * 3 + 1] = hi4; r4[wv * 3 + 2] = st4;
+                r4[wv * 4] = lo4; r4[wv * 4 + 1] = hi4; r4[wv * 4 + 2] = st4; r4[wv * 4 + 3] = sq4;
             }
         }
         __syncthreads();
         {
             const float4 *r4 = reinterpret_cast<const float4 *>(red);
-            float4 lo4 = r4[0], hi4 = r4[1], st4 = r4[2];
+            float4 lo4 = r4[0], hi4 = r4[1], st4 = r4[2], sq4 = r4[3];
 #pragma unroll
             for (int w = 1; w < kTWaves; ++w) {
-                const float4 a0 = r4[w * 3], a1 = r4[w * 3 + 1], a2 = r4[w * 3 + 2];
+                const float4 a0 = r4[w * 4], a1 = r4[w * 4 + 1], a2 = r4[w * 4 + 2], a3 = r4[w * 4 + 3];
                 lo4.x = fminf(lo4.x, a0.x); lo4.y = fminf(lo4.y, a0.y); lo4.z = fminf(lo4.z, a0.z);
                 hi4.x = fmaxf(hi4.x, a1.x); hi4.y = fmaxf(hi4.y, a1.y); hi4.z = fmaxf(hi4.z, a1.z);
                 st4.x = st4.x + a2.x; st4.y = st4.y + a2.y; st4.z = st4.z + a2.z;
+                sq4.x = sq4.x + a3.x; sq4.y = sq4.y + a3.y; sq4.z = sq4.z + a3.z; sq4.w = sq4.w + a3.w;
             }
-            const float lo3[3] = {lo4.x, lo4.y, lo4.z}, hi3[3] = {hi4.x, hi4.y, hi4.z}, st3[3] = {st4.x, st4.y, st4.z};
+            const float lo3[3] = {lo4.x, lo4.y, lo4.z}, hi3[3] = {hi4.x, hi4.y, hi4.z}, st3[3] = {st4.x, st4.y, st4.z}, sqt[3] = {sq4.x, sq4.y, sq4.z};
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 // centre = the MEAN (a stray far point moves the box centre, hardly the mean); any centre is correct
                 mu[d] = fminf(fmaxf(st3[d] / (float)M, lo3[d]), hi3[d]);
+                const float off = st3[d] / (float)M - pil[d];
+                varmax = fmaxf(varmax, sqt[d] / sq4.w - off * off);  // variance about the mean from the moment about a data point
                 cinf = fmaxf(cinf, fmaxf(hi3[d] - mu[d], mu[d] - lo3[d]));
                 allfin = allfin && fabsf(st3[d]) < INFINITY;  // a NaN / +-Inf coordinate makes the sum non-finite (fminf / fmaxf skip NaNs)
             }
@@ -936,10 +966,20 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     // not sane (non-finite or huge coordinates): every query takes the brute-force merge, which orders distances as the
     // oracle does (dist_key); a finite cloud with cinf < 1e16 has no infinite or NaN distance to a usable query
     const bool sane = allfin && cinf < 1.0e16f;  // usable queries lie within 234 cinf of the centre: 3 (235 cinf)^2 stays finite
+    // robust range, as in nn1_f16_kernel (chamfer.hip): a few points far from the bulk must not set the scale (one point 10^5 x
+    // the extent away sent every query to the exact merge: 143 vs 22 us).  rng = min(cinf, 16 x the mean max-norm deviation
+    // about the re-centred mean); gates: kRobustGate / kRobustHarm (fx3d_common.h).  Candidates beyond the range
+    // get norm +inf in the image (never below a threshold) and go on a side list that every query appends to its survivors.
+    float rng = cinf;
+    if (sane && cinf * cinf > kRobustGate * varmax) {
+        const float4 r = robust_range3<kTThreads, true>(yb, M, raw_ok != 0, rawc, red, mu[0], mu[1], mu[2], cinf);
+        mu[0] = r.x; mu[1] = r.y; mu[2] = r.z; rng = r.w;
+    }
+    const bool has_far = sane && rng < cinf;
     float sc = 1.0f;
-    if (sane && cinf > 1.0e-30f) {
+    if (sane && rng > 1.0e-30f) {
         int e;
-        (void)frexpf(cinf, &e);
+        (void)frexpf(rng, &e);
         sc = ldexpf(1.0f, 7 - e);  // |c~| < 2^7: a bulk far smaller than the farthest point stays out of fp16's subnormals
     }
     KNN_PROBE_MARK(1);
@@ -987,7 +1027,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                         kh8 p0, p1;
                         if (pt < cn) {
                             const float4 rc = rawc[j0 + pt];
-                            k3_make_pieces((rc.x - mu[0]) * sc, (rc.y - mu[1]) * sc, (rc.z - mu[2]) * sc, p0, p1);
+                            k3_pieces_far((rc.x - mu[0]) * sc, (rc.y - mu[1]) * sc, (rc.z - mu[2]) * sc, has_far, phase == 0, j0 + pt, &nfar, farlist, p0, p1);
                         } else {  // padding: n1 = +inf => t = +inf, never below a finite threshold
                             k3_make_pieces(0.f, 0.f, 0.f, p0, p1);
                             p1[1] = (_Float16)INFINITY;
@@ -1001,7 +1041,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                         kh8 p0, p1;
                         if (pt < cn) {
                             const float *src = yb + (size_t)(j0 + pt) * 3;
-                            k3_make_pieces((src[0] - mu[0]) * sc, (src[1] - mu[1]) * sc, (src[2] - mu[2]) * sc, p0, p1);
+                            k3_pieces_far((src[0] - mu[0]) * sc, (src[1] - mu[1]) * sc, (src[2] - mu[2]) * sc, has_far, phase == 0, j0 + pt, &nfar, farlist, p0, p1);
                         } else {
                             k3_make_pieces(0.f, 0.f, 0.f, p0, p1);
                             p1[1] = (_Float16)INFINITY;
@@ -1136,7 +1176,9 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     int *qctr = ctr + qslot * 8;  // [0..3] entries decoded by part, [4] overflow, [5] below
     const int need = kk < M ? kk : M;
     const int nv = cnt < kTCap - 1 ? cnt : kTCap - 1;
-    qctr[part] = tot;
+    const int nf = has_far ? nfar : 0;              // (complete: every chunk was staged before the last barrier)
+    const bool far_ok = nf <= kK3FarCap;             // more far candidates than the side list holds: no query is usable
+    qctr[part] = tot + (part == 3 && far_ok ? nf : 0);  // the query's last lane appends the far candidates to its own entries
     if (cnt > kTCap - 1) qctr[4] = 1;
     __syncthreads();  // every wave is done with the image: its space now holds the keys
     KNN_PROBE_MARK(6);
@@ -1145,7 +1187,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     const int c0 = qctr[0], c1 = qctr[1], c2 = qctr[2], c3 = qctr[3];
     const int n = c0 + c1 + c2 + c3;
     const int off = part == 0 ? 0 : (part == 1 ? c0 : (part == 2 ? c0 + c1 : c0 + c1 + c2));
-    const bool usable = sane && qok && thr < INFINITY;
+    const bool usable = sane && far_ok && qok && thr < INFINITY;
     const bool fast = wave_active && qi < N && usable && qctr[4] == 0 && n <= kTKeyCap - 4 && n >= need;
     if (fast) {
         // (1) decode the (tile, mask) words into candidate ids: integer work only, no memory latency in the chain
@@ -1165,6 +1207,8 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                 }
             }
         }
+        if (part == 3)
+            for (int f = 0; f < nf; ++f) qj[pos++] = farlist[f];  // (never inside a mask: their filter value is +inf)
         // (2) the oracle's distance of the ids this lane just wrote (its own LDS writes: no barrier), eight in flight
         for (int p0 = off; p0 < pos; p0 += 8) {
             int id[8];

@@ -442,3 +442,27 @@ def test_far_outliers_take_the_exact_side_list(gpu_fx, oracle, nout, fac):
     x, y = np.asfortranarray(x), np.asfortranarray(y)
     _nn_equal(gpu_fx, oracle, x, y)
     _chamfer_equal(gpu_fx, oracle, x, y)
+
+
+@pytest.mark.parametrize("M,nout,fac,k,drop", [(1024, 1, 1e5, 20, True), (1024, 1, 1e7, 20, True), (1500, 5, 1e4, 20, True),
+                                               (2048, 16, 1e5, 10, False), (2048, 17, 1e5, 10, False), (5000, 3, 1e6, 31, True),
+                                               (300, 2, 1e5, 20, False), (1024, 40, 1e5, 5, True)])
+def test_knn_d3_far_outliers_take_the_exact_side_list(gpu_fx, oracle, M, nout, fac, k, drop):
+    """The D = 3 kNN kernel's port of the robust range: candidates beyond it leave the filter (norm +inf) and every query
+    appends them to its survivors (up to 16; more: every query takes the exact merge).  One chunk with the raw points in LDS,
+    one chunk without, several chunks; far points as queries and as somebody's neighbours.  Lists and distances: the oracle's."""
+    rng = np.random.default_rng(M + nout)
+    B = 2
+    y = rng.standard_normal((3, M, B)).astype(np.float32)
+    oi = rng.choice(M, nout, replace=False)
+    y[:, oi, :] *= np.float32(fac)
+    if drop:
+        x = y
+    else:
+        x = rng.standard_normal((3, 200, B)).astype(np.float32)
+        x[:, :2, :] = y[:, oi[:1], :] * np.float32(1.0000001)   # queries next to a far candidate: it is their nearest
+    x, y = np.asfortranarray(x), np.asfortranarray(y)
+    idx, dist = gpu_fx.knn(x, k, y=None if drop else y, drop_first=drop)
+    oidx, od = oracle.knn(x, k, y=None if drop else y, drop_first=drop)
+    assert np.array_equal(idx.to_host(), oidx)
+    assert np.array_equal(dist.to_host(), od)
