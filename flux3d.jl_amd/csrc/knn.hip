@@ -1670,11 +1670,14 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
 
     if (tid == 0) {
         *cmax = 0u;
+        cmax[2] = 0u;  // F16: a mean far from the middle of its range was seen (scale pass)
+        cmax[3] = 0u;  // F16: bulk radius of a cloud centred on its medians (0: not in use)
         const float aq = 8.0f * (float)(4 * D + 8) * 0x1p-24f + (SPLIT ? 0x1p-18f : 0x1.01p-10f);
         // candidate side: + its share of the subnormal floor, + the rounding of n (1 +- A); parked in LDS (cmax[1])
         reinterpret_cast<float *>(cmax)[1] = aq * 1.01f + 0x1p-26f * sqrtf((float)D) + 0x1p-23f;
     }
     float sc = 1.0f;  // F16: power-of-two scale with |sc * c| < 1 for every candidate
+    float funit = 1.0f;  // F16: unit of the absolute error terms (see the scale pass)
     if (F16) {
         // ---- centre and scale: per-dimension MEAN mu (robust against a few far points, unlike the mid-range) and the
         //      largest |c - mu| of the cloud, one coalesced pass (F16 => 16-byte loads are legal).  Distances do not
@@ -1743,6 +1746,8 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                     m0 = fminf(fmaxf(m0, lo[c]), hi[c]);  // (rounding of the sum cannot leave the range)
                     mu[4 * tid + c] = m0;
                     amax = fmaxf(amax, fmaxf(hi[c] - m0, m0 - lo[c]));
+                    // a mean far from the middle of its range: skewed data or a few far points (checked below on a sample)
+                    if (fabsf(m0 - 0.5f * (lo[c] + hi[c])) > 0.25f * (hi[c] - lo[c])) cmax[2] = 1u;
                 }
             } else if (tid < DP / 4) {
                 mu[4 * tid] = 0.0f; mu[4 * tid + 1] = 0.0f; mu[4 * tid + 2] = 0.0f; mu[4 * tid + 3] = 0.0f;
@@ -1757,6 +1762,54 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m, 64));
         if (lane == 0) atomicMax(cmax, anynan ? 0x7fc00000u : __builtin_bit_cast(unsigned int, amax));
         __syncthreads();
+        if (centre && cmax[2] != 0u && !anynan) {  // (block-uniform)
+            // ---- robust centre.  A few points far from the bulk pull the mean towards them (one point 10^6 x the extent away
+            //      among 1024: by 10^3 extents), every query then sits |q~| >> extent from the centre and its band ~ 2^-10 |q~|^2
+            //      swallows the whole cloud (1.7 ms instead of 80 us).  Per-dimension MEDIAN and quartiles of 16 rows spread
+            //      over the cloud; when a mean lies more than 8 interquartile ranges from the median, every dimension is
+            //      centred on its median instead (any centre is correct) and the extent grows by the largest shift (an upper
+            //      bound, no second pass).  Skewed but clean data (one-sided features) keep their means.
+            if (wv == 0) {
+                float shiftmax = 0.0f, iqr2 = 0.0f;
+                bool sw = false;
+                float medv[DP / 64 > 0 ? DP / 64 : 1];
+#pragma unroll
+                for (int t = 0; t < (DP + 63) / 64; ++t) {
+                    const int d = lane + 64 * t;
+                    float v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = yb[(size_t)((long long)i * M / 16) * D + (d < D ? d : 0)];
+                    float med = v[0], q1 = v[0], q3 = v[0];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        int rk = 0;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) rk += (v[j] < v[i] || (v[j] == v[i] && j < i)) ? 1 : 0;
+                        med = rk == 8 ? v[i] : med; q1 = rk == 4 ? v[i] : q1; q3 = rk == 12 ? v[i] : q3;
+                    }
+                    const float shift = d < D ? fabsf(mu[d < D ? d : 0] - med) : 0.0f;
+                    sw = sw || (shift > 8.0f * (q3 - q1));
+                    shiftmax = fmaxf(shiftmax, shift);
+                    if (d < D) iqr2 = __builtin_fmaf(q3 - q1, q3 - q1, iqr2);
+                    medv[t] = med;
+                }
+                if (__ballot(sw) != 0ull) {
+#pragma unroll
+                    for (int m = 1; m < 64; m <<= 1) {
+                        shiftmax = fmaxf(shiftmax, __shfl_xor(shiftmax, m, 64));
+                        iqr2 = iqr2 + __shfl_xor(iqr2, m, 64);
+                    }
+#pragma unroll
+                    for (int t = 0; t < (DP + 63) / 64; ++t)
+                        if (lane + 64 * t < D) mu[lane + 64 * t] = medv[t];
+                    if (lane == 0) {
+                        *cmax = __builtin_bit_cast(unsigned int, __builtin_bit_cast(float, *cmax) + shiftmax);
+                        reinterpret_cast<float *>(cmax)[3] = sqrtf(iqr2);  // the bulk's radius (unscaled): the unit of the absolute error terms below
+                    }
+                }
+            }
+            __syncthreads();
+        }
         const float cinf = __builtin_bit_cast(float, *cmax);
         if (cinf > 1.0e-30f && cinf < 1.0e30f) {
             int e;
@@ -1765,7 +1818,19 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             // points) still sits in fp16's normal range; queries up to 30 x the cloud's extent stay below 6e4
             sc = ldexpf(1.0f, 10 - e);
         }
+        {
+            // unit s of the absolute (fp16 subnormal) error terms: |x| <= (x^2 / s + s) / 2 for any s > 0 turns the linear bound
+            // 2^-24 sqrt(D) (|q~| + |c~| / 2) into shares of the squared norms.  s = 1 unless the cloud was centred on its medians
+            // because of far points: then the bulk may sit far below 1 in scaled units, and with s = 1 the constant term
+            // 2^-23 sqrt(D) would dwarf its squared distances (the whole cloud inside every band).
+            const float rad = reinterpret_cast<const float *>(cmax)[3];
+            funit = rad > 0.0f ? fminf(1.0f, fmaxf(sc * rad, 0x1p-12f)) : 1.0f;
+        }
         __syncthreads();
+        if (tid == 0 && funit < 1.0f) {
+            const float aq = 8.0f * (float)(4 * D + 8) * 0x1p-24f + (SPLIT ? 0x1p-18f : 0x1.01p-10f);
+            reinterpret_cast<float *>(cmax)[1] = aq * 1.01f + 0x1p-26f * sqrtf((float)D) / funit + 0x1p-23f;
+        }
         // from here on: bits of the largest SCALED squared norm.  A cloud whose extent lets exact Float32 distances overflow
         // (D (61 cinf)^2 >= 3.4e38 for usable queries) is handled like a non-finite one: its +Inf ties are ordered by index in
         // the oracle, which only the brute-force merge reproduces.
@@ -2052,8 +2117,8 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                 // in phase B), the query keeps B_q = A qn + floor_q: a far candidate no longer widens everybody's
                 // band.  Otherwise n_c <= c2 for all of them.
                 const float acoef_q = 8.0f * (float)(4 * D + 8) * 0x1p-24f + (SPLIT ? 0x1p-18f : 0x1.01p-10f);
-                const float floor_q = 0x1p-24f * sqrtf((float)D) * (qn + 2.0f);
-                eps = two_norms ? acoef_q * qn + floor_q : acoef_q * (qn + c2) + floor_q + 0x1p-26f * sqrtf((float)D) * c2;
+                const float floor_q = 0x1p-24f * sqrtf((float)D) * (qn / funit + 2.0f * funit);
+                eps = two_norms ? acoef_q * qn + floor_q : acoef_q * (qn + c2) + floor_q + 0x1p-26f * sqrtf((float)D) * c2 / funit;
                 eps = (qok && c2 == c2) ? eps : INFINITY;  // c2 is NaN for a non-finite / overflow-prone cloud (scale pass)
             } else {
                 eps = (8.0f * (float)(D + 4) * 0x1p-24f) * (qn + c2);

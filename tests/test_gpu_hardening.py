@@ -466,3 +466,33 @@ def test_knn_d3_far_outliers_take_the_exact_side_list(gpu_fx, oracle, M, nout, f
     oidx, od = oracle.knn(x, k, y=None if drop else y, drop_first=drop)
     assert np.array_equal(idx.to_host(), oidx)
     assert np.array_equal(dist.to_host(), od)
+
+
+@pytest.mark.parametrize("D,M,kind", [(64, 1024, "one_1e6"), (64, 1024, "one_1e6_unsampled"), (64, 1000, "five_1e5"),
+                                      (32, 700, "one_1e8"), (128, 512, "one_1e6"), (64, 1024, "exponential"),
+                                      (64, 1024, "constant_dims"), (16, 2048, "one_1e6")])
+def test_knn_feature_space_robust_centre(gpu_fx, oracle, D, M, kind):
+    """knn_mfma_kernel: a few points far from the bulk pull the per-dimension mean away from it (every query then sits far from
+    the centre and its band swallows the cloud: 1.7 ms instead of 80 us).  The kernel switches to the medians of 16 sampled
+    rows when a mean lies 8 interquartile ranges off, and scales its absolute error terms to the bulk.  Whatever it decides,
+    the lists and distances are the oracle's: far points in a sampled row or not, several of them, beyond fp16's range,
+    skewed clean data (the means stay), constant dimensions (interquartile range 0)."""
+    rng = np.random.default_rng(D + M)
+    B, k = 2, 20
+    if kind == "exponential":
+        x = rng.exponential(1.0, (D, M, B))
+    else:
+        x = rng.random((D, M, B)) * 1e-2
+    if kind == "constant_dims":
+        x[: D // 2] = 0.37
+        x[:, 5, :] = 1e3
+    if kind.startswith("one_"):
+        fac = float(kind.split("_")[1])
+        x[:, 0 if "unsampled" not in kind else 3, :] = 1e-2 * fac
+    if kind == "five_1e5":
+        x[:, rng.choice(M, 5, replace=False), :] *= 1e5
+    x = np.asfortranarray(x.astype(np.float32))
+    idx, dist = gpu_fx.knn(x, k, drop_first=True)
+    oidx, od = oracle.knn(x, k, drop_first=True)
+    assert np.array_equal(idx.to_host(), oidx)
+    assert np.array_equal(dist.to_host(), od)
