@@ -371,6 +371,13 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     const bool vec = (reinterpret_cast<uintptr_t>(cb) & 15) == 0;
     const bool one_shot = NC <= CH;
     if (tid == 0) { nfar[0] = 0; nfar[1] = 0; }  // (ordered before their first use by the barrier of the bounding-box pass)
+    float qpre[3];  // this lane's query of the coming tile pass (the load's latency hides behind the prologue)
+    {
+        const int q0i = (tile * p.tpb) * QB + wv * 32 + jq;
+        const int qc0 = q0i < NQ ? q0i : NQ - 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) qpre[d] = qb[(size_t)qc0 * 3 + d];
+    }
     FX3D_PROBE_MARK(0);
 
     // ---- bounding box and mean -> centre mu = the MEAN (a stray far point moves the box centre, hardly the mean), largest
@@ -551,9 +558,14 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             if ((tile * p.tpb + tp) * QB >= NQ) break;  // uniform
             if (j0 == jfirst) {
                 qi = (tile * p.tpb + tp) * QB + wv * 32 + jq;
-                const int qc = qi < NQ ? qi : NQ - 1;
 #pragma unroll
-                for (int d = 0; d < 3; ++d) qr[d] = qb[(size_t)qc * 3 + d];
+                for (int d = 0; d < 3; ++d) qr[d] = qpre[d];  // requested before the bounding-box pass / during the previous tile pass
+                if (tp + 1 < p.tpb) {                          // the next pass's query: in flight behind this pass
+                    const int qn1 = (tile * p.tpb + tp + 1) * QB + wv * 32 + jq;
+                    const int qc1 = qn1 < NQ ? qn1 : NQ - 1;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) qpre[d] = qb[(size_t)qc1 * 3 + d];
+                }
                 const float m0 = -2.0f * ((qr[0] - mu[0]) * sc), m1 = -2.0f * ((qr[1] - mu[1]) * sc),
                             m2 = -2.0f * ((qr[2] - mu[2]) * sc);
                 const float S = (fabsf(m0) + fabsf(m1)) + fabsf(m2);
