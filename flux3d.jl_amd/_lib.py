@@ -83,6 +83,7 @@ SIGNATURES = {
     "fx3d_pointcloud_to_voxel": [vp, c_i32, c_i32, c_i32, vp, vp, sz, vp],
     "fx3d_lincomb": [c_i64, c_f32, vp, c_f32, vp, c_f32, vp, vp, vp],
     "fx3d_momentum_step": [c_i64, c_f32, c_f32, vp, vp, vp, vp],
+    "fx3d_momentum_step_offset": [c_i64, c_f32, c_f32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp],
     "fx3d_packed_to_padded": [vp, vp, c_i32, c_i32, vp, vp],
     "fx3d_padded_to_packed": [vp, vp, c_i32, c_i32, vp, vp],
     "fx3d_mesh_loss_workspace_bytes": [c_i64, C.POINTER(sz)],

@@ -318,6 +318,22 @@ __global__ __launch_bounds__(kThreads) void momentum_kernel(long long n, float r
     }
 }
 
+// ... and what the next iteration of the fit loop needs first, in the same pass: the offset mesh out = base + x
+// (offset(src, x), src/transforms/mesh_func.jl:435-438) and the sampling seed's device counter (two launches less per iteration)
+__global__ __launch_bounds__(kThreads) void momentum_offset_kernel(long long n, float rho, float eta, const float *__restrict__ g,
+                                                                  float *__restrict__ v, float *__restrict__ x,
+                                                                  const float *__restrict__ base, float *__restrict__ out,
+                                                                  unsigned long long *ctr, unsigned long long inc) {
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const float vn = (rho * v[i]) + (-eta * g[i]);
+        v[i] = vn;
+        const float xn = (1.0f * x[i]) + (1.0f * vn);
+        x[i] = xn;
+        out[i] = (1.0f * base[i]) + (1.0f * xn);
+    }
+    if (ctr && blockIdx.x == 0 && threadIdx.x == 0) *ctr += inc;
+}
+
 int grid_for(long long n) {
     long long g = (n + kThreads - 1) / kThreads;
     if (g < 1) g = 1;
@@ -372,6 +388,15 @@ fx3d_status fx3d_lincomb(int64_t n, float a, const float *x, float b, const floa
 fx3d_status fx3d_momentum_step(int64_t n, float rho, float eta, const float *g, float *v, float *x, fx3d_stream_t s) {
     FX3D_REQUIRE(g && v && x && n > 0, "fx3d_momentum_step: bad argument");
     hipLaunchKernelGGL(momentum_kernel, dim3(grid_for(n)), dim3(kThreads), 0, as_stream(s), (long long)n, rho, eta, g, v, x);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_momentum_step_offset(int64_t n, float rho, float eta, const float *g, float *v, float *x, const float *base,
+                                      float *out, uint64_t *ctr, uint64_t inc, fx3d_stream_t s) {
+    FX3D_REQUIRE(g && v && x && base && out && n > 0, "fx3d_momentum_step_offset: bad argument");
+    hipLaunchKernelGGL(momentum_offset_kernel, dim3(grid_for(n)), dim3(kThreads), 0, as_stream(s), (long long)n, rho, eta, g, v, x,
+                       base, out, reinterpret_cast<unsigned long long *>(ctr), (unsigned long long)inc);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }

@@ -15,12 +15,13 @@ from .transforms import lincomb, offset, sample_points, sample_points_grad
 
 
 def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_lap=0.1, w_edge=1.0, sync=True,
-                 seed_dev=None):
+                 seed_dev=None, m=None):
     """Returns the Float32 loss (and the gradient w.r.t. x, device (3,sumV), when with_grad).
     ``sync=False``: the loss stays a 1-element device array (the three terms are combined by fx3d_lincomb in
     the reference's order) and the call enqueues without a single host round trip.  ``seed_dev``: device uint64
     added to both sampling seeds by the kernels (FitStepGraph advances it between replays)."""
-    m = offset(src, x)
+    if m is None:  # (FitStepGraph passes the offset mesh the previous iteration's optimiser step already wrote)
+        m = offset(src, x)
     s1 = None if seed is None else seed
     s2 = None if seed is None else seed + 1
     A, fa, r1, r2 = sample_points(m, num_samples, seed=s1, return_draws=True, seed_dev=seed_dev)
@@ -58,6 +59,14 @@ class Momentum:
                   current_stream().handle)
         return x
 
+    def update_offset(self, x, g, base, out, counter=None, inc=0):
+        """update(x, g) and, in the same launch, out = base + x (the next iteration's offset mesh) and counter += inc."""
+        if self.v is None:
+            self.v = DeviceArray.zeros(x.shape, np.float32)
+        _lib.call("fx3d_momentum_step_offset", x.size, float(self.rho), float(self.eta), g.ptr, self.v.ptr, x.ptr, base.ptr,
+                  out.ptr, counter.ptr if counter is not None else None, int(inc), current_stream().handle)
+        return x
+
 
 class FitStepGraph:
     """One iteration of the fit_mesh loop (examples/fit_mesh.jl:98-110: loss, gradient, Momentum update) captured
@@ -75,11 +84,21 @@ class FitStepGraph:
         self.counter = DeviceArray.zeros((1,), np.uint64)
         self.iterations = 0
 
+        # one mesh and an optimiser that offers it: the Momentum launch also writes the next iteration's offset mesh and advances
+        # the seed counter (two launches less per iteration); the buffer is re-wrapped per body so that nothing derived from
+        # the vertices (padded form, sampling CDF) is cached across iterations
+        fused = src.N == 1 and hasattr(opt, "update_offset")
+        self.mverts = lincomb(1.0, src.dev("verts_packed"), 1.0, x) if fused else None
+
         def body():
+            m = src.with_verts_packed(self.mverts) if fused else None
             loss, g = loss_dolphin(x, src, tgt, num_samples, seed=seed, with_grad=True, w_lap=w_lap, w_edge=w_edge,
-                                   sync=False, seed_dev=self.counter)
-            opt.update(x, g)
-            _lib.call("fx3d_counter_add", self.counter.ptr, 2, current_stream().handle)
+                                   sync=False, seed_dev=self.counter, m=m)
+            if fused:
+                opt.update_offset(x, g, src.dev("verts_packed"), self.mverts, self.counter, 2)
+            else:
+                opt.update(x, g)
+                _lib.call("fx3d_counter_add", self.counter.ptr, 2, current_stream().handle)
             return loss
 
         current_stream().synchronize()  # x / optimiser state may still be in flight on the caller's stream

@@ -452,6 +452,16 @@ function momentum_step!(x::HipArray{Float32}, v::HipArray{Float32}, g::HipArray{
     return x
 end
 
+# ... fused with the next iteration's first steps: out = base + x (the offset mesh's packed vertices) and the seed counter
+function momentum_step_offset!(x::HipArray{Float32}, v::HipArray{Float32}, g::HipArray{Float32}, base::HipArray{Float32},
+                               out::HipArray{Float32}; eta = 1.0, rho = 0.9, counter = C_NULL, inc::Integer = 0)
+    check(@ccall LIB.fx3d_momentum_step_offset(length(x)::Int64, Float32(rho)::Float32, Float32(eta)::Float32, g.ptr::Ptr{Cvoid},
+                                               v.ptr::Ptr{Cvoid}, x.ptr::Ptr{Cvoid}, base.ptr::Ptr{Cvoid}, out.ptr::Ptr{Cvoid},
+                                               (counter isa HipArray ? counter.ptr : counter)::Ptr{Cvoid}, UInt64(inc)::UInt64,
+                                               DEFAULT_STREAM::Stream)::Int32)
+    return out
+end
+
 # Stream capture: record the loop body once, replay it with one launch (hipGraph).  `f()` must only enqueue on
 # `stream` (no host copies); run it once eagerly before capturing.
 struct HipGraph; handle::Ptr{Cvoid}; end

@@ -255,6 +255,11 @@ FX3D_API fx3d_status fx3d_lincomb(int64_t n, float a, const float *x, float b, c
  * x <- x + v, in one pass with the arithmetic of the two fx3d_lincomb calls it replaces. */
 FX3D_API fx3d_status fx3d_momentum_step(int64_t n, float rho, float eta, const float *g, float *v, float *x,
                                         fx3d_stream_t s);
+/* The same update plus what the next iteration of the fit loop starts with, in one launch: out <- base + x (the offset mesh,
+ * offset(src, x), src/transforms/mesh_func.jl:435-438, same unfused arithmetic as fx3d_lincomb(1, base, 1, x)) and, when ctr is
+ * not NULL, *ctr += inc (the sampling seeds' device counter, fx3d_counter_add). */
+FX3D_API fx3d_status fx3d_momentum_step_offset(int64_t n, float rho, float eta, const float *g, float *v, float *x,
+                                               const float *base, float *out, uint64_t *ctr, uint64_t inc, fx3d_stream_t s);
 /* _packed_to_padded / _padded_to_packed for (3,*) Float32 vertex arrays without leaving the device
  * (src/rep/utils.jl:119-181).  verts_len is a HOST array of B lengths. */
 FX3D_API fx3d_status fx3d_packed_to_padded(const float *packed, const int64_t *verts_len_host, int32_t B,
