@@ -769,7 +769,7 @@ constexpr int kTWaves = 2 * kTGroups; // two waves per group, each taking every 
                                       // two waves per SIMD overlap each other's LDS / shuffle latencies
 constexpr int kTThreads = kTWaves * 64;
 constexpr int kTCap = 24;             // rows of a lane's list (23 usable + the scratch head); a lane sees half the tiles
-constexpr int kTKeyCap = 64;          // keys per query (the two lanes' survivors + sentinels)
+constexpr int kTKeyCap = 64;          // keys per query (the four lanes' survivors; three sentinels follow them inside the stride)
 constexpr int kTKeyStride = kTKeyCap + 4;  // row stride in words: 32 queries x b128 reads without bank conflicts
 constexpr int kTChunk = 3072;         // candidates per LDS image (32 B each): image + lists + counters <= 152 KiB
 constexpr int kTRawMax = 2048;        // clouds up to this size also keep their raw coordinates in LDS
@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     const int n = c0 + c1 + c2 + c3;
     const int off = part == 0 ? 0 : (part == 1 ? c0 : (part == 2 ? c0 + c1 : c0 + c1 + c2));
     const bool usable = sane && far_ok && qok && thr < INFINITY;
-    const bool fast = wave_active && qi < N && usable && qctr[4] == 0 && n <= kTKeyCap - 4 && n >= need;
+    const bool fast = wave_active && qi < N && usable && qctr[4] == 0 && n <= kTKeyCap && n >= need;  // (+ 3 sentinels: inside the stride)
     if (fast) {
         // (1) decode the (tile, mask) words into candidate ids: integer work only, no memory latency in the chain
         int pos = off;
@@ -1460,7 +1460,7 @@ fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int 
 // Queries whose band holds more candidates than the key arrays (60) but whose lane lists are intact take the medium
 // path (exact selection among their own survivors, up to kMMedCap); the rest of the leftovers the full exact merge.
 constexpr int kMLCap = 40;        // rows of a lane's mask list (39 usable + the scratch head)
-constexpr int kMKeyCap = 60;      // survivors per query handled by the fast path
+constexpr int kMKeyCap = 64;      // survivors per query handled by the fast path (three sentinels follow them inside the stride of 68)
 constexpr int kMMedCap = 512;     // ... by the medium path: exact selection among the query's own survivors
 constexpr int kMKeyStride = 68;   // row stride of the key arrays in words: 32 queries x b128 reads without bank conflicts
 
