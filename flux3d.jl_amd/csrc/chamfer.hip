@@ -389,8 +389,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         // thread t takes points t, t + 1024, ...: 12-byte loads, consecutive lanes on consecutive points (coalesced, and the
         // 16-byte LDS slots of a wave's points are consecutive: no bank conflicts when they are parked and converted)
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sm3[3] = {0.f, 0.f, 0.f};
-        float sq3[3] = {0.f, 0.f, 0.f}, sqn = 0.0f;  // second moment of a SAMPLE about the cloud's first point (the spread): wave w
-                                                      // takes its points of every fourth sweep, 64-point runs all over the cloud
+        float sqt = 0.0f;  // second moment (all three coordinates) of a SAMPLE about the cloud's first point -- the spread: wave w
+                           // takes its points of every fourth sweep (64-point runs all over the cloud, ~NC/4 points)
         const float pil[3] = {cb[0], cb[1], cb[2]};
         const int nsweep = (NC + kHThreads - 1) / kHThreads;
         for (int i0 = 0; i0 < nsweep; i0 += 4) {
@@ -411,22 +411,20 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     if (one_shot) imgf[((pt >> 5) * 2) * 32 + (pt & 31)] = float4{v[e].x, v[e].y, v[e].z, 0.0f};  // parked in its own first piece
                 }
                 if (((i0 + e) & 3) == (wv & 3) && pt < NC) {  // (the first condition is wave-uniform)
-                    sq3[0] = __builtin_fmaf(v[e].x - pil[0], v[e].x - pil[0], sq3[0]); sq3[1] = __builtin_fmaf(v[e].y - pil[1], v[e].y - pil[1], sq3[1]);
-                    sq3[2] = __builtin_fmaf(v[e].z - pil[2], v[e].z - pil[2], sq3[2]);
-                    sqn += 1.0f;
+                    sqt = __builtin_fmaf(v[e].x - pil[0], v[e].x - pil[0], sqt); sqt = __builtin_fmaf(v[e].y - pil[1], v[e].y - pil[1], sqt);
+                    sqt = __builtin_fmaf(v[e].z - pil[2], v[e].z - pil[2], sqt);
                 }
             }
         }
         FX3D_PROBE_MARK(5);
         {
-            float4 lo4, hi4, st4, sq4;
+            float4 lo4, hi4, st4;
             lo4.x = wave_min_l63(mn[0]); lo4.y = wave_min_l63(mn[1]); lo4.z = wave_min_l63(mn[2]); lo4.w = 0.0f;
             hi4.x = wave_max_l63(mx[0]); hi4.y = wave_max_l63(mx[1]); hi4.z = wave_max_l63(mx[2]); hi4.w = 0.0f;
-            st4.x = wave_sum_l63(sm3[0]); st4.y = wave_sum_l63(sm3[1]); st4.z = wave_sum_l63(sm3[2]); st4.w = 0.0f;
-            sq4.x = wave_sum_l63(sq3[0]); sq4.y = wave_sum_l63(sq3[1]); sq4.z = wave_sum_l63(sq3[2]); sq4.w = wave_sum_l63(sqn);
+            st4.x = wave_sum_l63(sm3[0]); st4.y = wave_sum_l63(sm3[1]); st4.z = wave_sum_l63(sm3[2]); st4.w = wave_sum_l63(sqt);
             if (lane == 63) {
                 float4 *r4 = reinterpret_cast<float4 *>(red);
-                r4[wv * 4] = lo4; r4[wv * 4 + 1] = hi4; r4[wv * 4 + 2] = st4; r4[wv * 4 + 3] = sq4;
+                r4[wv * 4] = lo4; r4[wv * 4 + 1] = hi4; r4[wv * 4 + 2] = st4;
             }
         }
         FX3D_PROBE_MARK(9);
@@ -439,28 +437,27 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             // instead of repeating 64 LDS reads and 190 operations)
             const float4 *r4 = reinterpret_cast<const float4 *>(red);
             const int w = lane & 15;
-            float4 lo4 = r4[w * 4], hi4 = r4[w * 4 + 1], st4 = r4[w * 4 + 2], sq4 = r4[w * 4 + 3];
+            float4 lo4 = r4[w * 4], hi4 = r4[w * 4 + 1], st4 = r4[w * 4 + 2];
 #define NN1_ROW_MIN(v) v = fkey_inv(row_mm_key<false>(fkey(v)));
 #define NN1_ROW_MAX(v) v = fkey_inv(row_mm_key<true>(fkey(v)));
 #define NN1_ROW_SUM(v) v = v + dpp_mov<0xB1>(v); v = v + dpp_mov<0x4E>(v); v = v + dpp_mov<0x141>(v); v = v + dpp_mov<0x140>(v);
             NN1_ROW_MIN(lo4.x) NN1_ROW_MIN(lo4.y) NN1_ROW_MIN(lo4.z)
             NN1_ROW_MAX(hi4.x) NN1_ROW_MAX(hi4.y) NN1_ROW_MAX(hi4.z)
-            NN1_ROW_SUM(st4.x) NN1_ROW_SUM(st4.y) NN1_ROW_SUM(st4.z)
-            NN1_ROW_SUM(sq4.x) NN1_ROW_SUM(sq4.y) NN1_ROW_SUM(sq4.z) NN1_ROW_SUM(sq4.w)
+            NN1_ROW_SUM(st4.x) NN1_ROW_SUM(st4.y) NN1_ROW_SUM(st4.z) NN1_ROW_SUM(st4.w)
 #undef NN1_ROW_MIN
 #undef NN1_ROW_MAX
 #undef NN1_ROW_SUM
-            const float lo3[3] = {lo4.x, lo4.y, lo4.z}, hi3[3] = {hi4.x, hi4.y, hi4.z}, st3[3] = {st4.x, st4.y, st4.z}, sq3t[3] = {sq4.x, sq4.y, sq4.z};
-            float m3[3], ci = 0.0f, vm = 0.0f;
+            const float lo3[3] = {lo4.x, lo4.y, lo4.z}, hi3[3] = {hi4.x, hi4.y, hi4.z}, st3[3] = {st4.x, st4.y, st4.z};
+            // total variance about the mean from the sampled second moment about the first point (a data point: no cancellation for
+            // clouds far from the origin); the sample holds ~NC/4 points (the gate below is a heuristic: any estimate is correct)
+            float m3[3], ci = 0.0f, vm = st4.w / fmaxf(0.25f * (float)NC, 1.0f);
             bool fin = true;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const float lo = lo3[d], hi = hi3[d], st = st3[d], sq = sq3t[d];
+                const float lo = lo3[d], hi = hi3[d], st = st3[d];
                 m3[d] = fminf(fmaxf(st / (float)NC, lo), hi);  // (any centre is correct)
-                // variance about the mean from the second moment about the first point (a data point: no cancellation for clouds
-                // far from the origin); the largest of the three is what the farthest point is compared with below
                 const float off = st / (float)NC - pil[d];
-                vm = fmaxf(vm, sq / sq4.w - off * off);
+                vm = vm - off * off;
                 ci = fmaxf(ci, fmaxf(hi - m3[d], m3[d] - lo));
                 // a NaN or +-Inf coordinate makes the coordinate sum non-finite (fminf / fmaxf above skip NaNs)
                 fin = fin && fabsf(st) < INFINITY;
@@ -487,7 +484,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     float rng = cinf;
     // (clean clouds never get here -- uniform boxes have cinf^2 = 3 var, Gaussians of a million points 30 var --; a round costs
     //  two barriers, ~1.3 us at C2; all three run only when the first finds the bulk kRobustHarm x below the farthest point)
-    if (allfin && cinf < 1.0e16f && cinf * cinf > kRobustGate * varmax) {
+    if (allfin && cinf < 1.0e16f && 3.0f * cinf * cinf > kRobustGate * varmax) {  // (varmax: the TOTAL variance of the three coordinates)
         const float4 r = robust_range3<kHThreads, false>(cb, NC, one_shot, imgf, red, mu[0], mu[1], mu[2], cinf);
         mu[0] = r.x; mu[1] = r.y; mu[2] = r.z; rng = r.w;
     }

@@ -898,7 +898,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     {
         float4 *raww = reinterpret_cast<float4 *>(k3sm + img_bytes + kListBytes + kCtrInts * 4);
         float mn3[3] = {INFINITY, INFINITY, INFINITY}, mx3[3] = {-INFINITY, -INFINITY, -INFINITY}, sm3[3] = {0.f, 0.f, 0.f};
-        float sq3[3] = {0.f, 0.f, 0.f}, sqn = 0.0f;  // second moment of a sample about the cloud's first point (the spread)
+        float sqt = 0.0f;  // second moment (all three coordinates) of a sample (~M/4 points) about the cloud's first point: the spread
         const float pil[3] = {yb[0], yb[1], yb[2]};
         // thread t takes points t, t + kTThreads, ...: 12-byte loads, consecutive lanes on consecutive points (coalesced,
         // and the 16-byte LDS slots of a wave's points are consecutive: no bank conflicts)
@@ -921,42 +921,40 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                     if (raw_ok) raww[pt] = float4{v[e].x, v[e].y, v[e].z, 0.0f};
                 }
                 if (((i0 + e) & 3) == (wv & 3) && pt < M) {  // (wave-uniform first condition: 64-point runs all over the cloud)
-                    sq3[0] = __builtin_fmaf(v[e].x - pil[0], v[e].x - pil[0], sq3[0]); sq3[1] = __builtin_fmaf(v[e].y - pil[1], v[e].y - pil[1], sq3[1]);
-                    sq3[2] = __builtin_fmaf(v[e].z - pil[2], v[e].z - pil[2], sq3[2]);
-                    sqn += 1.0f;
+                    sqt = __builtin_fmaf(v[e].x - pil[0], v[e].x - pil[0], sqt); sqt = __builtin_fmaf(v[e].y - pil[1], v[e].y - pil[1], sqt);
+                    sqt = __builtin_fmaf(v[e].z - pil[2], v[e].z - pil[2], sqt);
                 }
             }
         }
         {   // wave level by DPP (the result is in lane 63), one 16-byte row per (wave, statistic)
-            float4 lo4, hi4, st4, sq4;
+            float4 lo4, hi4, st4;
             lo4.x = wave_min_l63(mn3[0]); lo4.y = wave_min_l63(mn3[1]); lo4.z = wave_min_l63(mn3[2]); lo4.w = 0.0f;
             hi4.x = wave_max_l63(mx3[0]); hi4.y = wave_max_l63(mx3[1]); hi4.z = wave_max_l63(mx3[2]); hi4.w = 0.0f;
-            st4.x = wave_sum_l63(sm3[0]); st4.y = wave_sum_l63(sm3[1]); st4.z = wave_sum_l63(sm3[2]); st4.w = 0.0f;
-            sq4.x = wave_sum_l63(sq3[0]); sq4.y = wave_sum_l63(sq3[1]); sq4.z = wave_sum_l63(sq3[2]); sq4.w = wave_sum_l63(sqn);
+            st4.x = wave_sum_l63(sm3[0]); st4.y = wave_sum_l63(sm3[1]); st4.z = wave_sum_l63(sm3[2]); st4.w = wave_sum_l63(sqt);
             if (lane == 63) {
                 float4 *r4 = reinterpret_cast<float4 *>(red);
-                r4[wv * 4] = lo4; r4[wv * 4 + 1] = hi4; r4[wv * 4 + 2] = st4; r4[wv * 4 + 3] = sq4;
+                r4[wv * 4] = lo4; r4[wv * 4 + 1] = hi4; r4[wv * 4 + 2] = st4;
             }
         }
         __syncthreads();
         {
             const float4 *r4 = reinterpret_cast<const float4 *>(red);
-            float4 lo4 = r4[0], hi4 = r4[1], st4 = r4[2], sq4 = r4[3];
+            float4 lo4 = r4[0], hi4 = r4[1], st4 = r4[2];
 #pragma unroll
             for (int w = 1; w < kTWaves; ++w) {
-                const float4 a0 = r4[w * 4], a1 = r4[w * 4 + 1], a2 = r4[w * 4 + 2], a3 = r4[w * 4 + 3];
+                const float4 a0 = r4[w * 4], a1 = r4[w * 4 + 1], a2 = r4[w * 4 + 2];
                 lo4.x = fminf(lo4.x, a0.x); lo4.y = fminf(lo4.y, a0.y); lo4.z = fminf(lo4.z, a0.z);
                 hi4.x = fmaxf(hi4.x, a1.x); hi4.y = fmaxf(hi4.y, a1.y); hi4.z = fmaxf(hi4.z, a1.z);
-                st4.x = st4.x + a2.x; st4.y = st4.y + a2.y; st4.z = st4.z + a2.z;
-                sq4.x = sq4.x + a3.x; sq4.y = sq4.y + a3.y; sq4.z = sq4.z + a3.z; sq4.w = sq4.w + a3.w;
+                st4.x = st4.x + a2.x; st4.y = st4.y + a2.y; st4.z = st4.z + a2.z; st4.w = st4.w + a2.w;
             }
-            const float lo3[3] = {lo4.x, lo4.y, lo4.z}, hi3[3] = {hi4.x, hi4.y, hi4.z}, st3[3] = {st4.x, st4.y, st4.z}, sqt[3] = {sq4.x, sq4.y, sq4.z};
+            const float lo3[3] = {lo4.x, lo4.y, lo4.z}, hi3[3] = {hi4.x, hi4.y, hi4.z}, st3[3] = {st4.x, st4.y, st4.z};
+            varmax = st4.w / fmaxf(0.25f * (float)M, 1.0f);  // TOTAL variance of the three coordinates, from ~M/4 sampled points (a heuristic's input)
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 // centre = the MEAN (a stray far point moves the box centre, hardly the mean); any centre is correct
                 mu[d] = fminf(fmaxf(st3[d] / (float)M, lo3[d]), hi3[d]);
                 const float off = st3[d] / (float)M - pil[d];
-                varmax = fmaxf(varmax, sqt[d] / sq4.w - off * off);  // variance about the mean from the moment about a data point
+                varmax = varmax - off * off;  // (variance about the mean from the moment about a data point)
                 cinf = fmaxf(cinf, fmaxf(hi3[d] - mu[d], mu[d] - lo3[d]));
                 allfin = allfin && fabsf(st3[d]) < INFINITY;  // a NaN / +-Inf coordinate makes the sum non-finite (fminf / fmaxf skip NaNs)
             }
@@ -971,7 +969,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     // about the re-centred mean); gates: kRobustGate / kRobustHarm (fx3d_common.h).  Candidates beyond the range
     // get norm +inf in the image (never below a threshold) and go on a side list that every query appends to its survivors.
     float rng = cinf;
-    if (sane && cinf * cinf > kRobustGate * varmax) {
+    if (sane && 3.0f * cinf * cinf > kRobustGate * varmax) {
         const float4 r = robust_range3<kTThreads, true>(yb, M, raw_ok != 0, rawc, red, mu[0], mu[1], mu[2], cinf);
         mu[0] = r.x; mu[1] = r.y; mu[2] = r.z; rng = r.w;
     }
