@@ -1613,12 +1613,305 @@ __device__ __forceinline__ void knn_stage_fetch(const float *__restrict__ yb, in
     }
 }
 
-template <int DK, bool F16, bool SPLIT>
+// ------------------------------------------------------------------------------------------------
+// Pre-pass of the feature-space kNN (fx3d_knn_ws): the per-cloud statistics and the fp16 image are built ONCE per cloud
+// instead of by every block of the cloud (8 blocks per cloud at C4': the scale pass alone was 8 us of the 78, bound by the
+// L2 -- every block read the whole cloud -- and the producers' conversion VALU delayed the consumers' MFMAs in both phases).
+//   knn_pre_stats_kernel   grid (kPreParts, B): minima / maxima / sums per dimension of one eighth of the cloud's rows
+//   knn_pre_image_kernel   grid (kPreParts, B): combines the eight parts (every block the same arithmetic: identical centre
+//                          and scale), robust centre as in knn_mfma_kernel, converts its rows: fp16 image [Mpad][DP], scaled
+//                          row norms (the candidate's error share folded in, upwards / downwards), largest norm of the part
+// knn_mfma_kernel then reads the header, and its producer waves bring image chunks and norms in with direct-to-LDS loads (no
+// VALU).  Workspace per cloud: KnnPre::cloud_bytes(M, DP).
+constexpr int kPreParts = 8;
+constexpr int kPreThreads = 256;
+struct KnnPre {
+    unsigned char *base;  // workspace
+    size_t stride;        // bytes per cloud
+    int Mpad;             // rows of the image (multiple of 256: chunks never need a clamp), DP halves per row
+    // offsets inside a cloud's slab (bytes)
+    size_t off_parts, off_hdr, off_cmax, off_nup, off_ndn, off_img;
+    __host__ __device__ static KnnPre make(void *ws, int M, int DP) {
+        KnnPre k{};
+        k.base = static_cast<unsigned char *>(ws);
+        k.Mpad = (M + 255) / 256 * 256;
+        size_t o = 0;
+        k.off_parts = o; o += (size_t)kPreParts * (3 * DP + 4) * 4;
+        k.off_hdr = o; o += (size_t)(8 + DP) * 4;
+        k.off_cmax = o; o += (size_t)kPreParts * 4;
+        o = (o + 15) & ~(size_t)15;
+        k.off_nup = o; o += (size_t)k.Mpad * 4;
+        k.off_ndn = o; o += (size_t)k.Mpad * 4;
+        k.off_img = o; o += (size_t)k.Mpad * DP * 2;
+        k.stride = (o + 255) & ~(size_t)255;
+        return k;
+    }
+    __host__ __device__ float *parts(int b) const { return reinterpret_cast<float *>(base + (size_t)b * stride + off_parts); }
+    __host__ __device__ float *hdr(int b) const { return reinterpret_cast<float *>(base + (size_t)b * stride + off_hdr); }
+    __host__ __device__ unsigned int *cmaxp(int b) const { return reinterpret_cast<unsigned int *>(base + (size_t)b * stride + off_cmax); }
+    __host__ __device__ float *nup(int b) const { return reinterpret_cast<float *>(base + (size_t)b * stride + off_nup); }
+    __host__ __device__ float *ndn(int b) const { return reinterpret_cast<float *>(base + (size_t)b * stride + off_ndn); }
+    __host__ __device__ _Float16 *img(int b) const { return reinterpret_cast<_Float16 *>(base + (size_t)b * stride + off_img); }
+};
+// header floats: [0] sc  [1] funit  [2] acoef (candidate side)  [3] bits: 1 = non-finite / overflow-prone cloud  [8 ...] mu[DP]
+
+__global__ __launch_bounds__(kPreThreads) void knn_pre_stats_kernel(const float *__restrict__ y, int M, int D, int DP, KnnPre pre) {
+    __shared__ float red[(kPreThreads / 64) * 32 * 12];
+    const int part = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float *yb = y + (size_t)b * M * D;
+    const int rq = D / 4;  // (kPreThreads % rq == 0: thread t always sees dimensions 4 (t % rq) ...)
+    const int per = (M + kPreParts - 1) / kPreParts;
+    const int r_lo = part * per < M ? part * per : M, r_hi = r_lo + per < M ? r_lo + per : M;
+    const float4 *c4 = reinterpret_cast<const float4 *>(yb) + (size_t)r_lo * rq;
+    const int total4 = (r_hi - r_lo) * rq;
+    float4 lo4 = float4{INFINITY, INFINITY, INFINITY, INFINITY}, hi4 = float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    float4 sum4 = float4{0.f, 0.f, 0.f, 0.f};
+    float poison = 0.0f;
+    for (int e0 = tid; e0 < total4; e0 += 8 * kPreThreads) {
+        float4 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = c4[e0 + e * kPreThreads < total4 ? e0 + e * kPreThreads : e0];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            poison = __builtin_fmaf(v[e].x, 0.0f, poison); poison = __builtin_fmaf(v[e].y, 0.0f, poison);
+            poison = __builtin_fmaf(v[e].z, 0.0f, poison); poison = __builtin_fmaf(v[e].w, 0.0f, poison);
+            lo4.x = fminf(lo4.x, v[e].x); lo4.y = fminf(lo4.y, v[e].y); lo4.z = fminf(lo4.z, v[e].z); lo4.w = fminf(lo4.w, v[e].w);
+            hi4.x = fmaxf(hi4.x, v[e].x); hi4.y = fmaxf(hi4.y, v[e].y); hi4.z = fmaxf(hi4.z, v[e].z); hi4.w = fmaxf(hi4.w, v[e].w);
+            if (e0 + e * kPreThreads < total4) {
+                sum4.x = sum4.x + v[e].x; sum4.y = sum4.y + v[e].y; sum4.z = sum4.z + v[e].z; sum4.w = sum4.w + v[e].w;
+            }
+        }
+    }
+    const bool anynan = __syncthreads_or(poison != poison) != 0;
+    for (int m = rq; m < 64; m <<= 1) {  // lanes with equal lane % rq hold the same dimensions
+        lo4.x = fminf(lo4.x, __shfl_xor(lo4.x, m, 64)); lo4.y = fminf(lo4.y, __shfl_xor(lo4.y, m, 64));
+        lo4.z = fminf(lo4.z, __shfl_xor(lo4.z, m, 64)); lo4.w = fminf(lo4.w, __shfl_xor(lo4.w, m, 64));
+        hi4.x = fmaxf(hi4.x, __shfl_xor(hi4.x, m, 64)); hi4.y = fmaxf(hi4.y, __shfl_xor(hi4.y, m, 64));
+        hi4.z = fmaxf(hi4.z, __shfl_xor(hi4.z, m, 64)); hi4.w = fmaxf(hi4.w, __shfl_xor(hi4.w, m, 64));
+        sum4.x = sum4.x + __shfl_xor(sum4.x, m, 64); sum4.y = sum4.y + __shfl_xor(sum4.y, m, 64);
+        sum4.z = sum4.z + __shfl_xor(sum4.z, m, 64); sum4.w = sum4.w + __shfl_xor(sum4.w, m, 64);
+    }
+    if (lane < rq) {
+        float *r8 = red + (size_t)(wv * 32 + lane) * 12;
+        r8[0] = lo4.x; r8[1] = lo4.y; r8[2] = lo4.z; r8[3] = lo4.w;
+        r8[4] = hi4.x; r8[5] = hi4.y; r8[6] = hi4.z; r8[7] = hi4.w;
+        r8[8] = sum4.x; r8[9] = sum4.y; r8[10] = sum4.z; r8[11] = sum4.w;
+    }
+    __syncthreads();
+    float *out = pre.parts(b) + (size_t)part * (3 * DP + 4);
+    if (tid < rq) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float lo = INFINITY, hi = -INFINITY, sm = 0.0f;
+            for (int w = 0; w < kPreThreads / 64; ++w) {
+                const float *r8 = red + (size_t)(w * 32 + tid) * 12;
+                lo = fminf(lo, r8[c]); hi = fmaxf(hi, r8[4 + c]); sm = sm + r8[8 + c];
+            }
+            out[4 * tid + c] = lo; out[DP + 4 * tid + c] = hi; out[2 * DP + 4 * tid + c] = sm;
+        }
+    }
+    if (tid == 0) reinterpret_cast<int *>(out)[3 * DP] = anynan ? 1 : 0;
+}
+
+template <int DK>
+__global__ __launch_bounds__(kPreThreads) void knn_pre_image_kernel(const float *__restrict__ y, int M, int D, int two_norms, KnnPre pre) {
+    constexpr int DP = DK * 32, G = DP / 8;
+    __shared__ float mu[DP];
+    __shared__ unsigned int sh[4];  // [0] bits of the extent  [1] skew flag  [2] bits of the bulk radius  [3] largest norm of the part
+    const int part = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float *yb = y + (size_t)b * M * D;
+    const int rq = D / 4;
+    const float *parts = pre.parts(b);
+    if (tid < 4) sh[tid] = 0u;
+    bool anynan = false;
+    for (int p = 0; p < kPreParts; ++p) anynan |= reinterpret_cast<const int *>(parts + (size_t)p * (3 * DP + 4))[3 * DP] != 0;
+    __syncthreads();
+    if (tid < rq) {
+        float amax = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float lo = INFINITY, hi = -INFINITY, sm = 0.0f;
+            for (int p = 0; p < kPreParts; ++p) {  // (fixed order: every block of the cloud gets the same centre)
+                const float *q = parts + (size_t)p * (3 * DP + 4);
+                lo = fminf(lo, q[4 * tid + c]); hi = fmaxf(hi, q[DP + 4 * tid + c]); sm = sm + q[2 * DP + 4 * tid + c];
+            }
+            float m0 = sm / (float)M;
+            m0 = fminf(fmaxf(m0, lo), hi);
+            mu[4 * tid + c] = m0;
+            amax = fmaxf(amax, fmaxf(hi - m0, m0 - lo));
+            if (fabsf(m0 - 0.5f * (lo + hi)) > 0.25f * (hi - lo)) sh[1] = 1u;
+        }
+        atomicMax(&sh[0], __builtin_bit_cast(unsigned int, amax));
+    } else if (tid < DP / 4) {
+        mu[4 * tid] = 0.0f; mu[4 * tid + 1] = 0.0f; mu[4 * tid + 2] = 0.0f; mu[4 * tid + 3] = 0.0f;
+    }
+    __syncthreads();
+    if (sh[1] != 0u && !anynan) {  // robust centre: see knn_mfma_kernel (the same rule on the same 16 sampled rows)
+        if (wv == 0) {
+            float shiftmax = 0.0f, iqr2 = 0.0f;
+            bool sw = false;
+            float medv[DP / 64 > 0 ? DP / 64 : 1];
+#pragma unroll
+            for (int t = 0; t < (DP + 63) / 64; ++t) {
+                const int d = lane + 64 * t;
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = yb[(size_t)((long long)i * M / 16) * D + (d < D ? d : 0)];
+                float med = v[0], q1 = v[0], q3 = v[0];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    int rk = 0;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) rk += (v[j] < v[i] || (v[j] == v[i] && j < i)) ? 1 : 0;
+                    med = rk == 8 ? v[i] : med; q1 = rk == 4 ? v[i] : q1; q3 = rk == 12 ? v[i] : q3;
+                }
+                const float shift = d < D ? fabsf(mu[d < D ? d : 0] - med) : 0.0f;
+                sw = sw || (shift > 8.0f * (q3 - q1));
+                shiftmax = fmaxf(shiftmax, shift);
+                if (d < D) iqr2 = __builtin_fmaf(q3 - q1, q3 - q1, iqr2);
+                medv[t] = med;
+            }
+            if (__ballot(sw) != 0ull) {
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) {
+                    shiftmax = fmaxf(shiftmax, __shfl_xor(shiftmax, m, 64));
+                    iqr2 = iqr2 + __shfl_xor(iqr2, m, 64);
+                }
+#pragma unroll
+                for (int t = 0; t < (DP + 63) / 64; ++t)
+                    if (lane + 64 * t < D) mu[lane + 64 * t] = medv[t];
+                if (lane == 0) {
+                    sh[0] = __builtin_bit_cast(unsigned int, __builtin_bit_cast(float, sh[0]) + shiftmax);
+                    sh[2] = __builtin_bit_cast(unsigned int, sqrtf(iqr2));
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const float cinf = __builtin_bit_cast(float, sh[0]);
+    float sc = 1.0f;
+    if (cinf > 1.0e-30f && cinf < 1.0e30f) {
+        int e;
+        (void)frexpf(cinf * 1.000001f, &e);
+        sc = ldexpf(1.0f, 10 - e);
+    }
+    const float rad = __builtin_bit_cast(float, sh[2]);
+    const float funit = rad > 0.0f ? fminf(1.0f, fmaxf(sc * rad, 0x1p-12f)) : 1.0f;
+    const float aq = 8.0f * (float)(4 * D + 8) * 0x1p-24f + 0x1.01p-10f;
+    const float acoef = aq * 1.01f + 0x1p-26f * sqrtf((float)D) / funit + 0x1p-23f;
+    const bool bad = anynan || !(cinf < 1.0e15f);
+    if (part == 0) {
+        float *h = pre.hdr(b);
+        if (tid == 0) { h[0] = sc; h[1] = funit; h[2] = acoef; h[3] = bad ? 1.0f : 0.0f; }
+        if (tid < DP) h[8 + tid] = mu[tid];
+    }
+    // ---- this part's rows -> image, norms
+    const int per = (M + kPreParts - 1) / kPreParts;
+    const int r_lo = part * per < M ? part * per : M, r_hi = r_lo + per < M ? r_lo + per : M;
+    _Float16 *img = pre.img(b);
+    float *nup = pre.nup(b), *ndn = pre.ndn(b);
+    const int g = tid % G;  // (kPreThreads % G == 0: a thread always converts the same eight dimensions)
+    float mu8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mu8[e] = mu[8 * g + e];
+    float tmax = 0.0f;
+    bool tnan = false;
+    constexpr int RPS = kPreThreads / G;  // rows per sweep of the block
+    for (int r0 = r_lo; r0 < r_hi; r0 += 4 * RPS) {
+        float4 a0[4], a1[4];
+        const int d0 = 8 * g < D ? 8 * g : 0, d1 = 8 * g + 4 < D ? 8 * g + 4 : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // every load of the four sweeps before the first use (a part is a few sweeps: latency, not bandwidth)
+            const int row = r0 + u * RPS + tid / G;
+            const float *src = yb + (size_t)(row < r_hi ? row : r_lo) * D;
+            a0[u] = *reinterpret_cast<const float4 *>(src + d0);
+            a1[u] = *reinterpret_cast<const float4 *>(src + d1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = r0 + u * RPS + tid / G;
+            const bool ok = row < r_hi;
+            if (!(8 * g < D)) a0[u] = float4{mu8[0], mu8[1], mu8[2], mu8[3]};       // padding dimensions: zero pieces
+            if (!(8 * g + 4 < D)) a1[u] = float4{mu8[4], mu8[5], mu8[6], mu8[7]};
+            const float v[8] = {(a0[u].x - mu8[0]) * sc, (a0[u].y - mu8[1]) * sc, (a0[u].z - mu8[2]) * sc, (a0[u].w - mu8[3]) * sc,
+                                (a1[u].x - mu8[4]) * sc, (a1[u].y - mu8[5]) * sc, (a1[u].z - mu8[6]) * sc, (a1[u].w - mu8[7]) * sc};
+            kh8 hi;
+            float pt = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                hi[e] = (_Float16)v[e];
+                pt = __builtin_fmaf(v[e], v[e], pt);
+            }
+            pt = pt + knn_dpp<0xB1>(pt);
+            pt = pt + knn_dpp<0x4E>(pt);
+            if (G >= 8) pt = pt + knn_dpp<0x141>(pt);
+            if (G >= 16) pt = pt + knn_dpp<0x140>(pt);
+            if (ok) {
+                *reinterpret_cast<kh8 *>(img + ((size_t)row * G + g) * 8) = hi;
+                if (g == 0) {
+                    nup[row] = two_norms ? pt + acoef * pt : pt;
+                    ndn[row] = two_norms ? pt - acoef * pt : pt;
+                    tnan |= (pt != pt);
+                    tmax = fmaxf(tmax, pt);
+                }
+            }
+        }
+    }
+    if (part == kPreParts - 1) {  // rows [M, Mpad): zero pieces, norm +inf (F = +inf: never selected)
+        kh8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
+        for (int un = tid; un < (pre.Mpad - M) * G; un += kPreThreads) *reinterpret_cast<kh8 *>(img + ((size_t)M * G + un) * 8) = z;
+        for (int r = M + tid; r < pre.Mpad; r += kPreThreads) { nup[r] = INFINITY; ndn[r] = INFINITY; }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, m, 64));
+    const bool anyn = __ballot(tnan) != 0;
+    if (lane == 0) atomicMax(&sh[3], anyn ? 0x7fc00000u : __builtin_bit_cast(unsigned int, tmax));
+    __syncthreads();
+    if (tid == 0) pre.cmaxp(b)[part] = bad ? 0x7fc00000u : sh[3];
+}
+
+// producer wave pw brings chunk [j0, j0 + CH) of the pre-pass image into `img` (single-piece layout of knn_hpiece_off: the
+// rotation sits on the source address) and, in phase A, its norms into the block's norm arrays -- direct-to-LDS loads only
+template <int DK>
+__device__ __forceinline__ void knn_pre_stage_chunk(const _Float16 *__restrict__ gimg, const float *__restrict__ gnup,
+                                                    const float *__restrict__ gndn, int j0, int CH, float *img, float *nup,
+                                                    float *ndn, bool norms, int pw, int lane) {
+    constexpr int PPI = DK * 4;                       // 16-byte pieces per image row (DP halves)
+    constexpr int RPB = PPI >= 16 ? 1 : 16 / PPI;
+    const int ninstr = CH * PPI / 64 / kMWaves;       // wave-instructions of this producer wave (CH is a multiple of 64)
+    for (int i = 0; i < ninstr; ++i) {
+        const int S0 = (pw * ninstr + i) * 64;        // first 16-byte slot of this wave-instruction
+        const int S = S0 + lane;
+        const int row = S / PPI, pos = S & (PPI - 1);
+        const int c = (pos - row / RPB) & (PPI - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gimg + ((size_t)(j0 + row) * PPI + c) * 8),
+                                         (__attribute__((address_space(3))) void *)(img + (size_t)S0 * 4), 16, 0, 0);
+    }
+    if (norms) {
+        const int nin = CH / 4 / 64;  // wave-instructions per norm array (CH / 4 pieces of four floats); CH = 64 -> a quarter wave
+        for (int i = pw; i < (nin > 0 ? nin : 1); i += kMWaves)
+            if (i * 64 + lane < CH / 4) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gnup + j0 + (size_t)(i * 64 + lane) * 4),
+                                                 (__attribute__((address_space(3))) void *)(nup + (size_t)i * 256), 16, 0, 0);
+                if (ndn)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gndn + j0 + (size_t)(i * 64 + lane) * 4),
+                                                     (__attribute__((address_space(3))) void *)(ndn + (size_t)i * 256), 16, 0, 0);
+            }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces have landed
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int DK, bool F16, bool SPLIT, bool PRE = false>
 __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__restrict__ x, int N,
                                                              const float *__restrict__ y, int M, int B, int D,
                                                              int k, int drop, int32_t *__restrict__ idx,
                                                              float *__restrict__ dist, int CH, int img_floats,
-                                                             int keep_norms, int two_norms, int srl) {
+                                                             int keep_norms, int two_norms, int srl, void *pre_ws) {
     constexpr int DP = DK * 32;      // padded feature dimension
     constexpr int RS = DP + 4;       // row stride of the query rows staged in the prologue (floats)
     constexpr int PPR = DK * 8;      // 16-byte pieces per candidate row
@@ -1648,6 +1941,14 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     const int b = by_xcd ? ((L >> 3) / nbx) * 8 + (L & 7) : L / nbx;
     const int bxq = by_xcd ? (L >> 3) % nbx : L % nbx;
     if (b >= B) return;
+    // pre-pass workspace (fx3d_knn_ws): this cloud's image and norms; the layout is a function of (M, DP)
+    constexpr bool use_pre = PRE;  // (a separate instantiation: the kernel without a pre-pass keeps its registers)
+    const _Float16 *pre_img = nullptr;
+    const float *pre_nup = nullptr, *pre_ndn = nullptr;
+    if (use_pre) {
+        const KnnPre pre = KnnPre::make(pre_ws, M, DP);
+        pre_img = pre.img(b); pre_nup = pre.nup(b); pre_ndn = pre.ndn(b);
+    }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool consumer = wv < kMWaves;
     const int cw = consumer ? wv : wv - kMWaves;   // the consumer wave this wave is paired with
@@ -1676,7 +1977,23 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     }
     float sc = 1.0f;  // F16: power-of-two scale with |sc * c| < 1 for every candidate
     float funit = 1.0f;  // F16: unit of the absolute error terms (see the scale pass)
-    if (F16) {
+    if (F16 && use_pre) {
+        // ---- the pre-pass (knn_pre_*_kernel) has the centre, the scale and the largest scaled norm of this cloud
+        __syncthreads();
+        const KnnPre pre = KnnPre::make(pre_ws, M, DP);
+        const float *h = pre.hdr(b);
+        sc = h[0];
+        funit = h[1];
+        if (tid < DP) mu[tid] = h[8 + tid];
+        if (tid == 0) {
+            reinterpret_cast<float *>(cmax)[1] = h[2];
+            unsigned int m = h[3] != 0.0f ? 0x7fc00000u : 0u;
+            const unsigned int *cp = pre.cmaxp(b);
+            for (int p = 0; p < kPreParts; ++p) m = cp[p] > m ? cp[p] : m;  // (NaN pattern > every finite norm)
+            *cmax = m;
+        }
+        __syncthreads();
+    } else if (F16) {
         // ---- centre and scale: per-dimension MEAN mu (robust against a few far points, unlike the mid-range) and the
         //      largest |c - mu| of the cloud, one coalesced pass (F16 => 16-byte loads are legal).  Distances do not
         //      depend on the origin, the fp16 band does: it grows with |q~|^2 + |c~|^2, so a common offset of a few
@@ -1908,7 +2225,10 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     bool pnan = false;
     int stage_ev = 0;                    // F16 producers: staging events done (chunks 0..n-1, n-2..0)
     const int nevents = 2 * nchunk - 1;
-    if (F16) {
+    if (F16 && use_pre) {
+        if (!consumer)
+            knn_pre_stage_chunk<DK>(pre_img, pre_nup, pre_ndn, 0, CH, sm, nall, nallm, true, wv - kMWaves, lane);
+    } else if (F16) {
         if (!consumer) {
             knn_f16_load_chunk<DK, kMUnits>(yb, D, 0, M < CH ? M : CH, CH, ptid, preg);
             knn_f16_store_chunk<DK, SPLIT, kMUnits>(sm, CH, M < CH ? M : CH, sc, mu, ptid, preg, nall, nallm, reinterpret_cast<const float *>(cmax + 1), pmax, pnan);
@@ -2054,7 +2374,11 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             const int j0n = ci_next * CH;
             const int cnn = (M - j0n) < CH ? (M - j0n) : CH;
             float *img = sm + (size_t)(1 - cur) * buf_floats;
-            if (F16) {
+            if (F16 && use_pre) {
+                const bool phase_a = nstep1 < nchunk;  // (the norms of all chunks stay in LDS: phase B brings the image only)
+                knn_pre_stage_chunk<DK>(pre_img, pre_nup, pre_ndn, j0n, CH, img, nall + (size_t)ci_next * CH,
+                                        nallm ? nallm + (size_t)ci_next * CH : nullptr, phase_a, wv - kMWaves, lane);
+            } else if (F16) {
                 // the registers hold chunk ci_next (loaded one step ago); then fetch the chunk after it
                 knn_f16_store_chunk<DK, SPLIT, kMUnits>(img, CH, cnn, sc, mu, ptid, preg, stage_ev < nchunk ? nall + (size_t)stage_ev * CH : nullptr,
                                         stage_ev < nchunk && nallm ? nallm + (size_t)stage_ev * CH : nullptr,
@@ -2609,9 +2933,19 @@ __global__ __launch_bounds__(kThreads) void edge_features_bwd_kernel(const float
 }
 
 
+// the shapes fx3d_knn_ws serves with the pre-pass: the single-piece fp16 filter (the default of knn_mfma_kernel)
+bool knn_pre_eligible(const float *x, const float *y, int M, int D, int kk) {
+    if (!(D >= 4 && D <= 128 && kk <= 32 && M >= 64 && M <= 4096 && D % 4 == 0)) return false;
+    const int rq = D / 4;
+    if (kPreThreads % rq != 0 || rq > 32) return false;
+    if (((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x)) & 15) != 0) return false;
+    const char *e1 = getenv("FX3D_KNN_F32"), *e2 = getenv("FX3D_KNN_F16_SPLIT"), *e3 = getenv("FX3D_KNN_NO_MFMA"), *e4 = getenv("FX3D_KNN_NO_PREPASS");
+    return !((e1 && atoi(e1)) || (e2 && atoi(e2)) || e3 || (e4 && atoi(e4)));
+}
+
 template <int DK, bool F16, bool SPLIT>
 fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int B, int D, int k, int drop,
-                               int32_t *idx, float *dist, hipStream_t st) {
+                               int32_t *idx, float *dist, hipStream_t st, void *pre_ws = nullptr) {
     constexpr int DP = DK * 32, RS = DP + 4, RSI = (F16 && !SPLIT) ? DP / 2 : DP;
     // list lengths + per-query counters + cmax + per-dimension centre + per-stage survivor counts ...
     const size_t small = (size_t)kMWaves * 64 * 4 + (size_t)3 * kMWaves * 32 * 4 + 64 + (size_t)DP * 4 + (size_t)kMWaves * 32 * 8;
@@ -2629,9 +2963,11 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     int CH = (int)(budget / 2 / ((size_t)RSI * 4 + 4)) / 64 * 64;
     if (CH > 256) CH = 256;
     constexpr int kMUnits = SPLIT ? kMUnitsSplit : kMUnitsSingle;
-    if (F16 && CH > kMUnits * kMProd * 8 / DP / 64 * 64) CH = kMUnits * kMProd * 8 / DP / 64 * 64;  // producer register budget
+    const bool use_pre = pre_ws != nullptr && F16 && !SPLIT;
+    if (F16 && !use_pre && CH > kMUnits * kMProd * 8 / DP / 64 * 64) CH = kMUnits * kMProd * 8 / DP / 64 * 64;  // producer register budget
     const int mpad = (M + 63) / 64 * 64;
     if (CH > mpad) CH = mpad;
+    if (use_pre) CH = CH >= 256 ? 256 : (CH >= 128 ? 128 : 64);  // chunks tile the image's 256-row padding exactly
     size_t img = 2 * ((size_t)CH * RSI + CH);                                  // floats
     const size_t qstage = (size_t)kMWaves * 32 * RS;                           // prologue: query rows
     const size_t exact = (size_t)2 * kMWaves * 32 * kMKeyStride;               // exact phase: distance bits + indices
@@ -2662,14 +2998,27 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     const int qpb = kMWaves * 32;
     const int nbx = (N + qpb - 1) / qpb;
     const int bpad = B >= 8 ? (B + 7) / 8 * 8 : B;
-    hipLaunchKernelGGL((knn_mfma_kernel<DK, F16, SPLIT>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
-                       k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl);
+    KnnPre pre{};
+    if (use_pre) {
+        pre = KnnPre::make(pre_ws, M, DP);
+        hipLaunchKernelGGL(knn_pre_stats_kernel, dim3(kPreParts, B), dim3(kPreThreads), 0, st, y, M, D, DP, pre);
+        hipLaunchKernelGGL((knn_pre_image_kernel<DK>), dim3(kPreParts, B), dim3(kPreThreads), 0, st, y, M, D, two_norms, pre);
+    }
+    if (use_pre) {
+        const fx3d_status arc2 = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_mfma_kernel<DK, F16, SPLIT, F16 && !SPLIT>), 152 * 1024,
+                                                    "knn_mfma_kernel<pre>");
+        if (arc2 != FX3D_OK) return arc2;
+        hipLaunchKernelGGL((knn_mfma_kernel<DK, F16, SPLIT, F16 && !SPLIT>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
+                           k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, pre_ws);
+    } else
+        hipLaunchKernelGGL((knn_mfma_kernel<DK, F16, SPLIT>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
+                           k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, nullptr);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }
 
 fx3d_status launch_knn_mfma(const float *x, int N, const float *y, int M, int B, int D, int k, int drop, int32_t *idx,
-                            float *dist, hipStream_t st) {
+                            float *dist, hipStream_t st, void *pre_ws = nullptr) {
     const int dk = (D + 31) / 32;
     // fp16-split filter: needs 16-byte loads (D % 4 == 0, aligned clouds) and all norms in LDS up front
     const char *f32_env = getenv("FX3D_KNN_F32");  // read per call: the tests flip it
@@ -2686,9 +3035,9 @@ fx3d_status launch_knn_mfma(const float *x, int N, const float *y, int M, int B,
     }
     if (f16) {
         switch (dk) {
-            case 1: return launch_knn_mfma_dk<1, true, false>(x, N, y, M, B, D, k, drop, idx, dist, st);
-            case 2: return launch_knn_mfma_dk<2, true, false>(x, N, y, M, B, D, k, drop, idx, dist, st);
-            default: return launch_knn_mfma_dk<4, true, false>(x, N, y, M, B, D, k, drop, idx, dist, st);
+            case 1: return launch_knn_mfma_dk<1, true, false>(x, N, y, M, B, D, k, drop, idx, dist, st, pre_ws);
+            case 2: return launch_knn_mfma_dk<2, true, false>(x, N, y, M, B, D, k, drop, idx, dist, st, pre_ws);
+            default: return launch_knn_mfma_dk<4, true, false>(x, N, y, M, B, D, k, drop, idx, dist, st, pre_ws);
         }
     }
     switch (dk) {
@@ -2714,7 +3063,7 @@ bool knn_needs_select(int M, int D, int kk) {
 }
 
 fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int D, int k, int drop,
-                       int32_t *idx, float *dist, hipStream_t st) {
+                       int32_t *idx, float *dist, hipStream_t st, void *pre_ws = nullptr) {
     ProfileScope prof("knn", st);
     const int kk = k + drop;
     const bool grid_y = knn_needs_select(M, D, kk) || (D == 3 ? !(kk <= 32 && M >= 64) : !knn_mfma_eligible(M, D, kk));
@@ -2736,7 +3085,7 @@ fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int 
         hipLaunchKernelGGL(knn_wave_d3_kernel, dim3((N + qpb - 1) / qpb, B), dim3(kWThreads), 0, st, x, N, y, M, B, k,
                            drop, idx, dist);
     } else if (!getenv("FX3D_KNN_NO_MFMA") && knn_mfma_eligible(M, D, kk)) {
-        return launch_knn_mfma(x, N, y, M, B, D, k, drop, idx, dist, st);
+        return launch_knn_mfma(x, N, y, M, B, D, k, drop, idx, dist, st, pre_ws);
     } else {
         const int qpb = (kWThreads / 64) * kGQ;
         hipLaunchKernelGGL(knn_wave_generic_kernel, dim3((N + qpb - 1) / qpb, B), dim3(kWThreads), knn_wave_generic_lds(D),
@@ -2764,6 +3113,34 @@ fx3d_status fx3d_knn(const float *x, int32_t N, const float *y, int32_t M, int32
         return FX3D_ERR_UNSUPPORTED;
     }
     return launch_knn(x, N, y, M, B, D, k, drop, idx, dist, as_stream(s));
+}
+
+size_t knn_pre_bytes(int M, int B, int D) {
+    const int DP = (D + 31) / 32 * 32 == 96 ? 128 : (D + 31) / 32 * 32;
+    return KnnPre::make(nullptr, M, DP).stride * (size_t)B;
+}
+
+fx3d_status fx3d_knn_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_t D, int32_t k, int32_t drop_first, size_t *bytes) {
+    FX3D_REQUIRE(bytes, "fx3d_knn_workspace_bytes: null output");
+    FX3D_REQUIRE(N > 0 && M > 0 && B > 0 && D > 0 && k > 0, "fx3d_knn_workspace_bytes: bad sizes");
+    const int kk = k + (drop_first ? 1 : 0);
+    // (alignment of x / y is checked at the call: an ineligible call simply does not use the workspace)
+    const bool shape_ok = D >= 4 && D <= 128 && kk <= 32 && M >= 64 && M <= 4096 && D % 4 == 0 && kPreThreads % (D / 4) == 0 && D / 4 <= 32;
+    *bytes = shape_ok ? knn_pre_bytes(M, B, D) : 0;
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_knn_ws(const float *x, int32_t N, const float *y, int32_t M, int32_t B, int32_t D, int32_t k,
+                        int32_t drop_first, int32_t *idx, float *dist, void *ws, size_t ws_bytes, fx3d_stream_t s) {
+    FX3D_REQUIRE(x && y && idx, "fx3d_knn_ws: null pointer");
+    FX3D_REQUIRE(N > 0 && M > 0 && B > 0 && D > 0 && k > 0, "fx3d_knn_ws: bad sizes (N=%d M=%d B=%d D=%d k=%d)", N, M, B, D, k);
+    const int drop = drop_first ? 1 : 0;
+    const int kk = k + drop;
+    FX3D_REQUIRE(kk <= M, "fx3d_knn_ws: k+drop_first=%d exceeds the number of candidates M=%d", kk, M);
+    const bool pre = ws && knn_pre_eligible(x, y, M, D, kk) && ws_bytes >= knn_pre_bytes(M, B, D) &&
+                     (reinterpret_cast<uintptr_t>(ws) & 255) == 0;
+    if (!pre) return fx3d_knn(x, N, y, M, B, D, k, drop_first, idx, dist, s);
+    return launch_knn(x, N, y, M, B, D, k, drop, idx, dist, as_stream(s), ws);
 }
 
 fx3d_status fx3d_knn_gather(const float *x, int32_t N, int32_t B, int32_t F, int32_t k,

@@ -1,8 +1,10 @@
 """k-NN graph construction for DGCNN's EdgeConv (src/models/dgcnn.jl:3-9,36)."""
 import numpy as np
 
+import ctypes as C
+
 from . import _lib
-from .device import DeviceArray, current_stream
+from .device import DeviceArray, current_stream, workspace
 from .metrics import _as_dev_points
 
 
@@ -19,8 +21,15 @@ def knn(x, k, y=None, drop_first=False, return_dist=True):
         raise ValueError("DimensionMismatch between x and y")
     idx = DeviceArray.empty((k, N, B), np.int32)
     dist = DeviceArray.empty((k, N, B), np.float32) if return_dist else None
-    _lib.call("fx3d_knn", x.ptr, N, y.ptr, M, B, D, int(k), int(bool(drop_first)), idx.ptr,
-              dist.ptr if dist else None, current_stream().handle)
+    nb = C.c_size_t(0)
+    _lib.call("fx3d_knn_workspace_bytes", N, M, B, D, int(k), int(bool(drop_first)), C.byref(nb))
+    if nb.value:  # feature space: statistics + fp16 image of the candidate clouds built once per cloud (pre-pass)
+        ws = workspace(nb.value, "knn")
+        _lib.call("fx3d_knn_ws", x.ptr, N, y.ptr, M, B, D, int(k), int(bool(drop_first)), idx.ptr,
+                  dist.ptr if dist else None, ws.ptr, ws.nbytes, current_stream().handle)
+    else:
+        _lib.call("fx3d_knn", x.ptr, N, y.ptr, M, B, D, int(k), int(bool(drop_first)), idx.ptr,
+                  dist.ptr if dist else None, current_stream().handle)
     return (idx, dist) if return_dist else idx
 
 

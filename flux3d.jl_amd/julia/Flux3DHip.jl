@@ -331,8 +331,17 @@ end
 function knn_graph(X::HipArray{Float32,3}, K::Int)
     F, N, B = size(X)
     idx = HipArray{Int32}(undef, K, N, B)
-    check(@ccall LIB.fx3d_knn(X.ptr::Ptr{Cvoid}, N::Int32, X.ptr::Ptr{Cvoid}, N::Int32, B::Int32, F::Int32,
-                              K::Int32, 1::Int32, idx.ptr::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    nb = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_knn_workspace_bytes(N::Int32, N::Int32, B::Int32, F::Int32, K::Int32, 1::Int32, nb::Ref{Csize_t})::Int32)
+    if nb[] > 0      # feature space: the candidate clouds' statistics + fp16 image are built once per cloud (pre-pass)
+        ws = workspace(nb[])
+        check(@ccall LIB.fx3d_knn_ws(X.ptr::Ptr{Cvoid}, N::Int32, X.ptr::Ptr{Cvoid}, N::Int32, B::Int32, F::Int32, K::Int32,
+                                     1::Int32, idx.ptr::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t,
+                                     DEFAULT_STREAM::Stream)::Int32)
+    else
+        check(@ccall LIB.fx3d_knn(X.ptr::Ptr{Cvoid}, N::Int32, X.ptr::Ptr{Cvoid}, N::Int32, B::Int32, F::Int32,
+                                  K::Int32, 1::Int32, idx.ptr::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    end
     out = HipArray{Float32}(undef, F, K, N, B)
     check(@ccall LIB.fx3d_knn_gather(X.ptr::Ptr{Cvoid}, N::Int32, B::Int32, F::Int32, K::Int32, idx.ptr::Ptr{Cvoid},
                                      out.ptr::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)

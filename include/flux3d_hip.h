@@ -165,6 +165,16 @@ FX3D_API fx3d_status fx3d_knn(const float *x, int32_t N, const float *y, int32_t
                               int32_t D, int32_t k, int32_t drop_first, int32_t *idx,
                               float *dist, fx3d_stream_t s);
 
+/* The same search with caller-provided scratch.  In feature space (4 <= D <= 128 with D/4 a divisor of 256, 64 <= M <= 4096,
+ * k+drop_first <= 32, 16-byte aligned clouds) the statistics and the fp16 image of every candidate cloud are then built once per
+ * cloud by two small pre-pass launches instead of by every block of the search kernel (C4': 78 -> see DESIGN.md 3.2).  Results
+ * are identical to fx3d_knn.  fx3d_knn_workspace_bytes returns 0 for shapes that have no use for scratch; a NULL, short or
+ * misaligned (256 bytes) workspace makes fx3d_knn_ws behave exactly like fx3d_knn. */
+FX3D_API fx3d_status fx3d_knn_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_t D, int32_t k, int32_t drop_first,
+                                              size_t *bytes);
+FX3D_API fx3d_status fx3d_knn_ws(const float *x, int32_t N, const float *y, int32_t M, int32_t B, int32_t D, int32_t k,
+                                 int32_t drop_first, int32_t *idx, float *dist, void *ws, size_t ws_bytes, fx3d_stream_t s);
+
 /* X[:, idxs] gather -> (F,k,N,B)  (src/models/dgcnn.jl:6 `X[:, knn(...)]`, cat at :36). */
 FX3D_API fx3d_status fx3d_knn_gather(const float *x, int32_t N, int32_t B, int32_t F, int32_t k,
                                      const int32_t *idx, float *out, fx3d_stream_t s);

@@ -471,7 +471,7 @@ def test_knn_d3_far_outliers_take_the_exact_side_list(gpu_fx, oracle, M, nout, f
 @pytest.mark.parametrize("D,M,kind", [(64, 1024, "one_1e6"), (64, 1024, "one_1e6_unsampled"), (64, 1000, "five_1e5"),
                                       (32, 700, "one_1e8"), (128, 512, "one_1e6"), (64, 1024, "exponential"),
                                       (64, 1024, "constant_dims"), (16, 2048, "one_1e6")])
-def test_knn_feature_space_robust_centre(gpu_fx, oracle, D, M, kind):
+def test_knn_feature_space_robust_centre(gpu_fx, oracle, monkeypatch, D, M, kind):
     """knn_mfma_kernel: a few points far from the bulk pull the per-dimension mean away from it (every query then sits far from
     the centre and its band swallows the cloud: 1.7 ms instead of 80 us).  The kernel switches to the medians of 16 sampled
     rows when a mean lies 8 interquartile ranges off, and scales its absolute error terms to the bulk.  Whatever it decides,
@@ -492,7 +492,40 @@ def test_knn_feature_space_robust_centre(gpu_fx, oracle, D, M, kind):
     if kind == "five_1e5":
         x[:, rng.choice(M, 5, replace=False), :] *= 1e5
     x = np.asfortranarray(x.astype(np.float32))
-    idx, dist = gpu_fx.knn(x, k, drop_first=True)
     oidx, od = oracle.knn(x, k, drop_first=True)
-    assert np.array_equal(idx.to_host(), oidx)
-    assert np.array_equal(dist.to_host(), od)
+    for nopre in ("0", "1"):  # the pre-pass (fx3d_knn_ws) and the in-kernel statistics apply the same rule
+        monkeypatch.setenv("FX3D_KNN_NO_PREPASS", nopre)
+        idx, dist = gpu_fx.knn(x, k, drop_first=True)
+        assert np.array_equal(idx.to_host(), oidx), f"nopre={nopre}"
+        assert np.array_equal(dist.to_host(), od), f"nopre={nopre}"
+
+
+def test_knn_ws_entry_point_contract(gpu_fx, oracle):
+    """fx3d_knn_ws: 0 bytes for shapes without a pre-pass (D = 3, D % 4 != 0, k + drop > 32, M > 4096); a NULL, short or
+    misaligned workspace behaves exactly like fx3d_knn; x != y (only the candidate cloud has an image); non-finite clouds."""
+    import ctypes as C
+    fx = gpu_fx
+    from flux3d_jl_amd import _lib
+    nb = C.c_size_t(1)
+    for (N, M, B, D, k, drop) in ((100, 1024, 2, 3, 20, 1), (100, 1024, 2, 5, 20, 0), (100, 1024, 2, 64, 40, 0), (100, 5000, 1, 64, 20, 0),
+                                  (100, 32, 1, 64, 5, 0)):
+        _lib.call("fx3d_knn_workspace_bytes", N, M, B, D, k, drop, C.byref(nb))
+        assert nb.value == 0
+    rng = np.random.default_rng(9)
+    N, M, B, D, k = 130, 700, 2, 32, 9
+    x = np.asfortranarray(rng.standard_normal((D, N, B)).astype(np.float32))
+    y = np.asfortranarray(rng.standard_normal((D, M, B)).astype(np.float32))
+    y[:, 17, 1] = np.nan                                    # one cloud non-finite: its queries take the exact merge
+    oi, od = oracle.knn(x, k, y=y)
+    dx, dy = fx.gpu(x), fx.gpu(y)
+    _lib.call("fx3d_knn_workspace_bytes", N, M, B, D, k, 0, C.byref(nb))
+    assert nb.value > 0
+    ws = fx.DeviceArray.empty((nb.value + 512,), np.uint8)
+    base = (ws.ptr + 255) // 256 * 256
+    for (ptr, nbytes) in ((base, nb.value), (None, 0), (base, nb.value - 1), (base + 16, nb.value)):
+        idx = fx.DeviceArray.empty((k, N, B), np.int32)
+        dist = fx.DeviceArray.empty((k, N, B), np.float32)
+        _lib.call("fx3d_knn_ws", dx.ptr, N, dy.ptr, M, B, D, k, 0, idx.ptr, dist.ptr, ptr, nbytes, None)
+        fx.synchronize()
+        assert np.array_equal(idx.to_host(), oi)
+        assert np.array_equal(dist.to_host(), od, equal_nan=True)

@@ -447,12 +447,13 @@ def test_knn_staged_exact_phase(gpu_fx, oracle, monkeypatch, D, N, M, B, k, drop
     if drop:
         x = y = np.asfortranarray(rng.standard_normal((D, M, B)).astype(np.float32))
     oi, od = oracle.knn(x, k, y=None if y is x else y, drop_first=drop)
-    for gather in (False, True):
-        if gather:
-            monkeypatch.setenv("FX3D_KNN_GATHER", "1")
+    # (default: fx3d_knn_ws with the pre-pass image; FX3D_KNN_NO_PREPASS=1: every block builds its own image, as fx3d_knn does)
+    for gather, nopre in ((False, False), (True, False), (False, True)):
+        monkeypatch.setenv("FX3D_KNN_GATHER", "1" if gather else "0")
+        monkeypatch.setenv("FX3D_KNN_NO_PREPASS", "1" if nopre else "0")
         idx, dist = gpu_fx.knn(x, k, y=None if y is x else y, drop_first=drop)
-        assert np.array_equal(idx.to_host(), oi), f"gather={gather}"
-        assert np.array_equal(dist.to_host(), od), f"gather={gather}"
+        assert np.array_equal(idx.to_host(), oi), f"gather={gather} nopre={nopre}"
+        assert np.array_equal(dist.to_host(), od), f"gather={gather} nopre={nopre}"
 
 
 @pytest.mark.parametrize("D,csize,spread", [(64, 80, 1e-3), (32, 200, 1e-4), (64, 700, 1e-3)])

@@ -24,6 +24,9 @@ int main(int argc, char **argv) {
     hipMalloc(&x, hx.size() * 4); hipMalloc(&idx, (size_t)K * N * B * 4);
     if (getenv("DIST")) hipMalloc(&dst, (size_t)K * N * B * 4);
     hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+    void *ws = nullptr; size_t wsb = 0;
+    if (getenv("WS")) { fx3d_knn_workspace_bytes(N, N, B, D, K, 1, &wsb); if (wsb) hipMalloc(&ws, wsb); printf("pre-pass workspace %zu bytes\n", wsb); }
+#define fx3d_knn(x_, N_, y_, M_, B_, D_, K_, dr_, idx_, dst_, s_) fx3d_knn_ws(x_, N_, y_, M_, B_, D_, K_, dr_, idx_, dst_, ws, wsb, s_)
     for (int it = 0; it < 3; ++it) fx3d_knn(x, N, x, N, B, D, K, 1, idx, dst, nullptr);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
