@@ -2282,7 +2282,57 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                 const float *cnorm = keep_norms ? (phase && nallm ? nallm : nall) + (size_t)ci * CH : cand + (size_t)CH * DP;
                 const int npair = cn_pad / 64;
                 const int tile0 = j0 / 32;
-                for (int pr = 0; pr < npair; ++pr) {
+                int pr_first = 0;
+                if (F16 && !SPLIT && PRE) {  // (without the pre-pass the producers' staging registers leave no room: 68 spills)
+                    // single-piece fp16 filter: TWO pairs of tiles per iteration -- the second pair's operand fetches and MFMAs are
+                    // issued before the first pair's results are folded, so the fold (VALU) of one overlaps the matrix work of the
+                    // other and one round of LDS latency serves four tiles (a lone consumer wave per SIMD hides nothing otherwise)
+                    constexpr int RPB2 = PPI >= 16 ? 1 : 16 / PPI;
+                    for (; pr_first + 1 < npair; pr_first += 2) {
+                        f32x16v accs[4];
+                        kh8 ops[4][NB16];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {  // q = 2 * (pair) + (tile of the pair)
+                            const int rbase = (pr_first + (q >> 1)) * 64 + 32 * (q & 1);
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const float4 n0 = *reinterpret_cast<const float4 *>(cnorm + rbase + 8 * g + 4 * h);
+                                accs[q][4 * g] = n0.x; accs[q][4 * g + 1] = n0.y; accs[q][4 * g + 2] = n0.z; accs[q][4 * g + 3] = n0.w;
+                            }
+                            const float *cq = cand + (size_t)(rbase + jl) * RSI;
+#pragma unroll
+                            for (int bb = 0; bb < NB16; ++bb)
+                                ops[q][bb] = *reinterpret_cast<const kh8 *>(cq + ((2 * bb + h + jl / RPB2) & (PPI - 1)) * 4);
+                        }
+#pragma unroll
+                        for (int bb = 0; bb < NB16; ++bb) {  // four independent accumulators in turn: no MFMA waits for its predecessor
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) accs[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ops[q][bb], ah[bb], accs[q], 0, 0, 0);
+                        }
+                        if (phase == 0) {
+                            KNN_MFMA_SETTLE4(accs[0], accs[1], accs[2], accs[3]);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) mn[r] = vmin_acc(mn[r], accs[0][r]);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) mn[16 + r] = vmin_acc(mn[16 + r], accs[1][r]);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) mn[r] = vmin_acc(mn[r], accs[2][r]);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) mn[16 + r] = vmin_acc(mn[16 + r], accs[3][r]);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                unsigned int m = 0;
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) m |= (accs[q][r] <= thr) ? (1u << r) : 0u;
+                                const int pp = cnt < kMLCap - 1 ? cnt : kMLCap - 1;
+                                mylist[pp * 64] = (int)((unsigned int)(tile0 + pr_first * 2 + q) << 16 | m);
+                                cnt += m != 0 ? 1 : 0;
+                            }
+                        }
+                    }
+                }
+                for (int pr = pr_first; pr < npair; ++pr) {
                     // rows pr*64 + jl and + 32 share (row mod PPR) = jl mod PPR: one rotated offset per fetch
                     const float *c0 = cand + (size_t)(pr * 64 + jl) * RSI, *c1 = c0 + (size_t)32 * RSI;
                     // accumulators start at the candidate norms: register r of half h is row (r&3) + 8(r>>2) + 4h
