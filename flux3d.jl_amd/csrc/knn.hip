@@ -1876,7 +1876,7 @@ __global__ __launch_bounds__(kPreThreads) void knn_pre_image_kernel(const float 
 
 // producer wave pw brings chunk [j0, j0 + CH) of the pre-pass image into `img` (single-piece layout of knn_hpiece_off: the
 // rotation sits on the source address) and, in phase A, its norms into the block's norm arrays -- direct-to-LDS loads only
-template <int DK>
+template <int DK, bool WAIT = true>
 __device__ __forceinline__ void knn_pre_stage_chunk(const _Float16 *__restrict__ gimg, const float *__restrict__ gnup,
                                                     const float *__restrict__ gndn, int j0, int CH, float *img, float *nup,
                                                     float *ndn, bool norms, int pw, int lane) {
@@ -1902,8 +1902,10 @@ __device__ __forceinline__ void knn_pre_stage_chunk(const _Float16 *__restrict__
                                                      (__attribute__((address_space(3))) void *)(ndn + (size_t)i * 256), 16, 0, 0);
             }
     }
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces have landed
-    __builtin_amdgcn_wave_barrier();
+    if (WAIT) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces have landed
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 template <int DK, bool F16, bool SPLIT, bool PRE = false>
@@ -1930,9 +1932,13 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     unsigned int *cmax = reinterpret_cast<unsigned int *>(qbelow + kMWaves * 32);  // bits of max |c|^2 (>= 0)
     float *mu = reinterpret_cast<float *>(cmax + 4);                       // [DP] F16: per-dimension centre of the cloud
     unsigned long long *qstpk = reinterpret_cast<unsigned long long *>(mu + DP);  // [kMWaves][32] survivors per row stage (packed prefix)
-    int *lists = reinterpret_cast<int *>(qstpk + kMWaves * 32);            // [kMWaves][kMLCap][64] mask words
+    unsigned short *lcnt2 = reinterpret_cast<unsigned short *>(lcnt);      // DUAL (below): [2 kMWaves][64] list lengths, in lcnt's space
+    int *lists = reinterpret_cast<int *>(qstpk + kMWaves * 32);            // [kMWaves][kMLCap][64] mask words (DUAL: [2 kMWaves][kMLCap / 2][64])
     int *med = lists + kMWaves * kMLCap * 64;                              // [2 kMWaves][kMMedCap + 128] medium path: ids + merge lists
     float *nall = reinterpret_cast<float *>(med + 2 * kMWaves * (kMMedCap + 128));  // [nchunk*CH] all candidate norms (keep_norms)
+    // DUAL: the four parts' packed stage counts per query [kMWaves][32][4] (4 KiB) live in the norm arrays, which are dead after
+    // the chunk loop and at least that large (one array of >= 2304 floats, or two of >= 512)
+    unsigned long long *qpk = reinterpret_cast<unsigned long long *>(nall);
     // block L runs on XCD L % 8: give every cloud's blocks ids with equal L % 8 so that its candidates stay in
     // one L2 (8 or more clouds; fewer: plain order, a cloud's blocks spread over all XCDs)
     const int nbx = (N + kMWaves * 32 - 1) / (kMWaves * 32);
@@ -1953,6 +1959,13 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     const bool consumer = wv < kMWaves;
     const int cw = consumer ? wv : wv - kMWaves;   // the consumer wave this wave is paired with
     const int ptid = tid - kMProd;                 // producer thread id (negative for consumers)
+    // PRE: the image arrives by direct-to-LDS loads, the "producer" waves are free -- BOTH waves of a pair (they share a SIMD)
+    // run the filter, on alternate double pairs of tiles: two waves per SIMD hide each other's LDS latencies and MFMA -> VALU
+    // dependencies (a lone consumer wave stalled for more than half of its cycles).  Per query 128 group minima instead of 64
+    // (a tighter tau), four lane lists instead of two (the decode is shared by four lanes).
+    constexpr bool DUAL = PRE;
+    constexpr int LCAP = DUAL ? kMLCap / 2 : kMLCap;  // rows of a lane's mask list
+    const int half = consumer ? 0 : 1;
     const int h = lane >> 5, jl = lane & 31;
     const int kk = k + drop;
     const float *xb = x + (size_t)b * N * D, *yb = y + (size_t)b * M * D;
@@ -2157,7 +2170,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     kh8 ah[NB16], al[NB16];  // fp16 filter: hi / lo halves of -2 sc q, 8 dimensions per K block and half-wave
     float qn = 0.0f;
     bool qok = true;
-    if (consumer) {
+    if (consumer || DUAL) {  // (DUAL: both waves of a pair stage the same rows -- identical values -- and derive the same operands)
         float *qs = sm + (size_t)cw * 32 * RS;
         const int nrow = wave_active ? ((N - q0) < 32 ? (N - q0) : 32) : 0;
         const float *src = xb + (size_t)q0 * D;
@@ -2264,7 +2277,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     for (int r = 0; r < 32; ++r) mn[r] = INFINITY;
     float thr = 0.0f;
     int cnt = 0;
-    int *mylist = lists + cw * kMLCap * 64 + lane;  // entry e at mylist[e * 64]
+    int *mylist = lists + (DUAL ? wv * LCAP : cw * kMLCap) * 64 + lane;  // entry e at mylist[e * 64]
 
     int cur = 0;  // buffer holding the chunk of this step
     for (int step = 0; step < nstep; ++step) {
@@ -2276,7 +2289,12 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         const int nstep1 = step + 1;
         const int ci_next = nstep1 >= nchunk ? nstep - 1 - nstep1 : nstep1;
         const bool stage_next = nstep1 < nstep && ci_next != ci;
-        if (consumer) {
+        if (DUAL && !consumer && stage_next) {  // the next chunk's direct loads first: they land while this wave computes
+            const int j0n = ci_next * CH;
+            knn_pre_stage_chunk<DK, false>(pre_img, pre_nup, pre_ndn, j0n, CH, sm + (size_t)(1 - cur) * buf_floats, nall + (size_t)ci_next * CH,
+                                           nallm ? nallm + (size_t)ci_next * CH : nullptr, nstep1 < nchunk, wv - kMWaves, lane);
+        }
+        if (consumer || DUAL) {
             if (wave_active) {
                 const float *cand = sm + (size_t)cur * buf_floats;
                 const float *cnorm = keep_norms ? (phase && nallm ? nallm : nall) + (size_t)ci * CH : cand + (size_t)CH * DP;
@@ -2289,6 +2307,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                     // other and one round of LDS latency serves four tiles (a lone consumer wave per SIMD hides nothing otherwise)
                     constexpr int RPB2 = PPI >= 16 ? 1 : 16 / PPI;
                     for (; pr_first + 1 < npair; pr_first += 2) {
+                        if (DUAL && ((pr_first >> 1) & 1) != half) continue;  // the pair's waves take alternate double pairs
                         f32x16v accs[4];
                         kh8 ops[4][NB16];
 #pragma unroll
@@ -2325,14 +2344,14 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                                 unsigned int m = 0;
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) m |= (accs[q][r] <= thr) ? (1u << r) : 0u;
-                                const int pp = cnt < kMLCap - 1 ? cnt : kMLCap - 1;
+                                const int pp = cnt < LCAP - 1 ? cnt : LCAP - 1;
                                 mylist[pp * 64] = (int)((unsigned int)(tile0 + pr_first * 2 + q) << 16 | m);
                                 cnt += m != 0 ? 1 : 0;
                             }
                         }
                     }
                 }
-                for (int pr = pr_first; pr < npair; ++pr) {
+                for (int pr = (DUAL && half) ? npair : pr_first; pr < npair; ++pr) {  // (DUAL: a last lone pair goes to the first wave)
                     // rows pr*64 + jl and + 32 share (row mod PPR) = jl mod PPR: one rotated offset per fetch
                     const float *c0 = cand + (size_t)(pr * 64 + jl) * RSI, *c1 = c0 + (size_t)32 * RSI;
                     // accumulators start at the candidate norms: register r of half h is row (r&3) + 8(r>>2) + 4h
@@ -2413,7 +2432,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                             unsigned int m = 0;
 #pragma unroll
                             for (int r = 0; r < 16; ++r) m |= ((tt ? acc1[r] : acc0[r]) <= thr) ? (1u << r) : 0u;
-                            const int pp = cnt < kMLCap - 1 ? cnt : kMLCap - 1;
+                            const int pp = cnt < LCAP - 1 ? cnt : LCAP - 1;
                             mylist[pp * 64] = (int)((unsigned int)(tile0 + pr * 2 + tt) << 16 | m);
                             cnt += m != 0 ? 1 : 0;
                         }
@@ -2424,7 +2443,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             const int j0n = ci_next * CH;
             const int cnn = (M - j0n) < CH ? (M - j0n) : CH;
             float *img = sm + (size_t)(1 - cur) * buf_floats;
-            if (F16 && use_pre) {
+            if (F16 && use_pre) {  // (not reached when DUAL: kept for a PRE build without it)
                 const bool phase_a = nstep1 < nchunk;  // (the norms of all chunks stay in LDS: phase B brings the image only)
                 knn_pre_stage_chunk<DK>(pre_img, pre_nup, pre_ndn, j0n, CH, img, nall + (size_t)ci_next * CH,
                                         nallm ? nallm + (size_t)ci_next * CH : nullptr, phase_a, wv - kMWaves, lane);
@@ -2450,10 +2469,14 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                                     cmax, phase_a, phase_a || !keep_norms, vec4y, wv - kMWaves, lane);
             }
         }
+        if (DUAL && !consumer && stage_next) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces of the next chunk have landed
+            __builtin_amdgcn_wave_barrier();
+        }
         __syncthreads();
         KNN_PROBE_MARK(3 + step);
         if (stage_next) cur = 1 - cur;
-        if (step == nchunk - 1 && consumer) {
+        if (step == nchunk - 1 && (consumer || DUAL)) {
             // ---- tau: kk-th smallest of the 64 group minima of every query (32 in this lane, 32 in its partner) ----
             const float c2 = __builtin_bit_cast(float, *cmax);
             k3_sort_regs<32>(mn);
@@ -2474,6 +2497,34 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                         mn[l] = hi;
                     }
                 }
+            }
+            if (DUAL) {
+                // the other wave of the pair holds the minima of the other tiles: the 32 smallest of the 128 through LDS (the
+                // lane lists are not in use yet), one more bitonic merge
+                float *xch = reinterpret_cast<float *>(lists);  // [2 kMWaves][32][33]
+                if (h == 0) {
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) xch[(wv * 32 + jl) * 33 + r] = mn[r];
+                }
+                __syncthreads();
+                {
+                    const float *po = xch + (((wv + kMWaves) % (2 * kMWaves)) * 32 + jl) * 33;
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) mn[r] = vmin_f32(mn[r], po[31 - r]);
+#pragma unroll
+                    for (int j = 16; j > 0; j >>= 1) {
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) {
+                            const int l = i ^ j;
+                            if (l > i) {
+                                const float lo = vmin_f32(mn[i], mn[l]), hi = vmax_f32(mn[i], mn[l]);
+                                mn[i] = lo;
+                                mn[l] = hi;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();  // the exchange space becomes the lane lists
             }
             float val = mn[0];
 #pragma unroll
@@ -2504,7 +2555,25 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     // ---- exact phase -----------------------------------------------------------------------------------------------
     // (1) consumers: list lengths, survivors per query, fast-path flag
     const int need = kk < M ? kk : M;
-    if (consumer) {
+    const int part = (consumer ? 0 : 2) + h;  // the query's four lanes: two half-waves x the pair's two waves
+    if (DUAL) {
+        // every lane publishes the per-stage counts of its own list (bytes of a 64-bit word; srl == 0: the total in byte 0)
+        // and whether the list overflowed (top bit: a stage holds < 128 survivors of the <= 64 that matter)
+        const int nv = cnt < LCAP - 1 ? cnt : LCAP - 1;
+        const int tsh = srl > 0 ? srl - 5 : 31;
+        unsigned long long pk = 0;
+        int totx = 0;
+        for (int e = 0; e < nv; ++e) {
+            const unsigned int w = (unsigned int)mylist[e * 64];
+            const int pc = __builtin_popcount(w & 0xffffu);
+            totx += pc;
+            pk += (unsigned long long)pc << (srl > 0 ? ((w >> 16) >> tsh) * 8 : 0);
+        }
+        // (the bytes are only meaningful while none can carry: a part with more than 63 survivors -- the query is not a fast one
+        //  then -- publishes its plain total behind a marker bit instead)
+        qpk[(cw * 32 + jl) * 4 + part] = (totx <= 63 ? pk : (1ull << 62) | (unsigned long long)totx) | (cnt > LCAP - 1 ? 1ull << 63 : 0ull);
+        lcnt2[wv * 64 + lane] = (unsigned short)nv;
+    } else if (consumer) {
         const int nv = cnt < kMLCap - 1 ? cnt : kMLCap - 1;
         int tot = 0;
         for (int e = 0; e < nv; ++e) tot += __builtin_popcount((unsigned int)mylist[e * 64] & 0xffffu);
@@ -2521,9 +2590,28 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     KNN_PROBE_MARK(21);
     unsigned int *qd = reinterpret_cast<unsigned int *>(sm) + (size_t)(cw * 32 + jl) * kMKeyStride;                       // distance bits
     int *qj = reinterpret_cast<int *>(sm) + (size_t)kMWaves * 32 * kMKeyStride + (size_t)(cw * 32 + jl) * kMKeyStride;     // indices
-    const int n = qn_n[cw * 32 + jl];
-    const bool fast = qflag[cw * 32 + jl] == 1;
-    const bool handled = qflag[cw * 32 + jl] == 2;  // answered by the medium path
+    int n = qn_n[cw * 32 + jl];
+    bool fast = qflag[cw * 32 + jl] == 1;
+    bool handled = qflag[cw * 32 + jl] == 2;  // answered by the medium path
+    unsigned long long dpk[4] = {0ull, 0ull, 0ull, 0ull};  // DUAL: the four parts' packed counts
+    if (DUAL) {
+        bool ovf = false, big = false;
+        int tot4 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned long long v = qpk[(cw * 32 + jl) * 4 + q];
+            ovf |= (v >> 63) != 0;
+            const bool bigp = ((v >> 62) & 1ull) != 0;  // more than 63 survivors in this part alone: its plain total
+            big |= bigp;
+            dpk[q] = bigp ? 0ull : v & ~(3ull << 62);
+            tot4 += bigp ? (int)(unsigned int)v : (int)((dpk[q] * 0x0101010101010101ull) >> 56);  // sum of the bytes
+        }
+        n = tot4;
+        const bool lists_ok = wave_active && qi < N && thr < INFINITY && !ovf && n >= need;
+        fast = lists_ok && !big && n <= kMKeyCap;
+        handled = lists_ok && !fast && n <= kMMedCap;
+        if (part == 0) { qn_n[cw * 32 + jl] = n; qflag[cw * 32 + jl] = fast ? 1 : (handled ? 2 : 0); qbelow[cw * 32 + jl] = 0; }
+    }
     // staged exact phase (srl > 0): the thread's share of the first stage of candidate rows is requested here, so that
     // it arrives while the lists are decoded
     f32x4v sreg[8];
@@ -2540,10 +2628,11 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             const int j = __builtin_ctz(bm);
             if ((j & 1) != (consumer ? 0 : 1)) continue;  // the pair's two waves share the queries
             int total = 0;
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const int src = h2 * 32 + j;
-                const int nv2 = lcnt[cw * 64 + src] >> 16;
-                const unsigned int w = lane < nv2 ? (unsigned int)lists[(cw * kMLCap + lane) * 64 + src] : 0u;  // nv2 < 64
+            for (int h2 = 0; h2 < (DUAL ? 4 : 2); ++h2) {  // (DUAL: h2 = 2 * (wave of the pair) + half-wave)
+                const int src = (h2 & 1) * 32 + j;
+                const int lw = DUAL ? cw + kMWaves * (h2 >> 1) : cw;  // the wave that holds the list
+                const int nv2 = DUAL ? lcnt2[lw * 64 + src] : lcnt[cw * 64 + src] >> 16;
+                const unsigned int w = lane < nv2 ? (unsigned int)lists[((DUAL ? lw * LCAP : cw * kMLCap) + lane) * 64 + src] : 0u;  // nv2 < 64
                 const int pc = __builtin_popcount(w & 0xffffu);
                 int incl = pc;
 #pragma unroll
@@ -2553,7 +2642,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                 }
                 int pos = total + incl - pc;
                 unsigned int m16 = w & 0xffffu;
-                const int rowbase = (int)(w >> 16) * 32 + 4 * h2;
+                const int rowbase = (int)(w >> 16) * 32 + 4 * (h2 & 1);
                 while (m16) {
                     const int r = __builtin_ctz(m16);
                     m16 &= m16 - 1;
@@ -2578,7 +2667,37 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     // (2) consumers decode their mask words into candidate ids (integer work only).  srl > 0 (staged exact phase): the
     //     ids of a query are grouped by row stage (2^srl candidate rows, at most 8 stages): per-stage counts of the two
     //     half-wave lists in the bytes of a 64-bit word (n <= 60 < 256), prefix sums by one multiplication
-    if (consumer && fast) {
+    if (DUAL) {
+        if (fast) {  // every one of the query's four lanes decodes its own list behind the lists of the parts before it
+            const int nv = lcnt2[wv * 64 + lane];
+            const unsigned long long incl = (dpk[0] + dpk[1] + dpk[2] + dpk[3]) * 0x0101010101010101ull;  // byte s: survivors in stages 0..s
+            unsigned long long before = 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) before += q < part ? dpk[q] : 0ull;
+            unsigned long long startpk = (srl > 0 ? incl << 8 : 0ull) + before;  // byte s: where this lane's ids of stage s go
+            const int tsh = srl > 0 ? srl - 5 : 31;
+            for (int e0 = 0; e0 < nv; e0 += 4) {  // four list words in flight
+                unsigned int w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w[u] = (unsigned int)mylist[(e0 + u < LCAP ? e0 + u : LCAP - 1) * 64];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    unsigned int m = e0 + u < nv ? (w[u] & 0xffffu) : 0u;
+                    const int rowbase = (int)(w[u] >> 16) * 32 + 4 * h;
+                    const int sh = srl > 0 ? (int)((w[u] >> 16) >> tsh) * 8 : 0;
+                    int pos = (int)(startpk >> sh) & 0xff;
+                    startpk += (unsigned long long)__builtin_popcount(m) << sh;
+                    while (m) {
+                        const int r = __builtin_ctz(m);
+                        m &= m - 1;
+                        qj[pos++] = rowbase + (r & 3) + 8 * (r >> 2);
+                    }
+                }
+            }
+            if (part == 3) { qd[n] = 0xffffffffu; qd[n + 1] = 0xffffffffu; qd[n + 2] = 0xffffffffu;
+                             qj[n] = 0x7fffffff; qj[n + 1] = 0x7fffffff; qj[n + 2] = 0x7fffffff; }  // sentinels for the b128 sweeps
+        }
+    } else if (consumer && fast) {
         const int meta = lcnt[cw * 64 + lane];
         const int nv = meta >> 16;
         if (srl > 0) {
@@ -2635,7 +2754,6 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     __syncthreads();  // ids visible to the producer partners; the lane lists are dead: their space holds the slots
     KNN_PROBE_MARK(22);
     // (3) the query's survivors are split over its four lanes (two halves x consumer / producer wave)
-    const int part = (consumer ? 0 : 2) + h;
     const int per = (n + 3) >> 2;
     const int mystart = part * per < n ? part * per : n;
     const int mycount = (mystart + per <= n ? per : n - mystart);
@@ -2649,7 +2767,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         float *stg = reinterpret_cast<float *>(lists);
         const int nstage = (M + SRW - 1) >> srl;
         const bool act = wave_active && fast;
-        const unsigned long long incl = act ? qstpk[cw * 32 + jl] : 0ull;
+        const unsigned long long incl = !act ? 0ull : (DUAL ? (dpk[0] + dpk[1] + dpk[2] + dpk[3]) * 0x0101010101010101ull : qstpk[cw * 32 + jl]);
         f32x4v qreg[DP / 4];
         {
             const float *qrow = xb + (size_t)(act ? qi : 0) * D;
@@ -2998,6 +3116,7 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
                                int32_t *idx, float *dist, hipStream_t st, void *pre_ws = nullptr) {
     constexpr int DP = DK * 32, RS = DP + 4, RSI = (F16 && !SPLIT) ? DP / 2 : DP;
     // list lengths + per-query counters + cmax + per-dimension centre + per-stage survivor counts ...
+    const bool use_pre = pre_ws != nullptr && F16 && !SPLIT;
     const size_t small = (size_t)kMWaves * 64 * 4 + (size_t)3 * kMWaves * 32 * 4 + 64 + (size_t)DP * 4 + (size_t)kMWaves * 32 * 8;
     static_assert(kMWaves * 32 * 33 * 8 + 2 * kMWaves * 128 * 4 <= kMWaves * kMLCap * 64 * 4, "rank slots + fallback scratch alias the mask lists");
     const int keep_norms = M <= 4096;  // all candidate norms stay in LDS: phase B does not recompute them
@@ -3013,7 +3132,6 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     int CH = (int)(budget / 2 / ((size_t)RSI * 4 + 4)) / 64 * 64;
     if (CH > 256) CH = 256;
     constexpr int kMUnits = SPLIT ? kMUnitsSplit : kMUnitsSingle;
-    const bool use_pre = pre_ws != nullptr && F16 && !SPLIT;
     if (F16 && !use_pre && CH > kMUnits * kMProd * 8 / DP / 64 * 64) CH = kMUnits * kMProd * 8 / DP / 64 * 64;  // producer register budget
     const int mpad = (M + 63) / 64 * 64;
     if (CH > mpad) CH = mpad;
