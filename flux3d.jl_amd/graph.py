@@ -81,6 +81,12 @@ def edgeconv_graph(X, K, layout="mlp", return_idx=False):
     X = _as_dev_points(X)
     F, N, B = X.shape
     lay = _LAYOUTS[layout]
+    nb = C.c_size_t(0)
+    _lib.call("fx3d_knn_workspace_bytes", N, N, B, F, int(K), 1, C.byref(nb))
+    if nb.value:  # feature space: the search with its pre-pass (fx3d_knn_ws), then the features -- what fx3d_edgeconv_graph
+        idx = knn(X, K, drop_first=True, return_dist=False)  # does in one call, minus the per-block image builds
+        out = edge_features(X, idx, layout)
+        return (out, idx) if return_idx else out
     idx = DeviceArray.empty((K, N, B), np.int32)
     out = DeviceArray.empty((2 * F, K, N, B) if lay == 0 else (K * N, 2 * F, B), np.float32)
     _lib.call("fx3d_edgeconv_graph", X.ptr, N, B, F, int(K), lay, idx.ptr, out.ptr, current_stream().handle)
