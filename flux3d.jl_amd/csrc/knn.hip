@@ -70,13 +70,25 @@ __device__ __forceinline__ float key_dist(unsigned int k) { return __builtin_bit
 __device__ __forceinline__ bool key_less(unsigned int d, int j, unsigned int od, int oj) { return d < od || (d == od && j < oj); }
 
 // ascending bitonic sort of one (key, j) pair per lane
+// lane ^ S exchange for the sorting networks: DPP quad permutes for S = 1, 2 (VALU speed), ds_swizzle in bit mode for S = 4, 8, 16
+// (no address register, half the latency of ds_bpermute), ds_bpermute for S = 32.  The networks below are 21 dependent stages,
+// eleven of them at S <= 2: the medium / slow paths of clustered or tied data spend most of their time here.
+template <int S>
+__device__ __forceinline__ int xor_lane(int v) {
+    if (S == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    if (S == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    if (S == 4 || S == 8 || S == 16) return __builtin_amdgcn_ds_swizzle(v, (S << 10) | 0x1F);  // and 0x1f, or 0, xor S
+    return __shfl_xor(v, S, 64);
+}
 __device__ __forceinline__ void bitonic64(unsigned int &d, int &j, int lane) {
 #pragma unroll
     for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
         for (int s = k >> 1; s > 0; s >>= 1) {
-            const unsigned int od = (unsigned int)__shfl_xor((int)d, s, 64);
-            const int oj = __shfl_xor(j, s, 64);
+            const unsigned int od = (unsigned int)(s == 1 ? xor_lane<1>((int)d) : s == 2 ? xor_lane<2>((int)d) : s == 4 ? xor_lane<4>((int)d) :
+                                                   s == 8 ? xor_lane<8>((int)d) : s == 16 ? xor_lane<16>((int)d) : xor_lane<32>((int)d));
+            const int oj = s == 1 ? xor_lane<1>(j) : s == 2 ? xor_lane<2>(j) : s == 4 ? xor_lane<4>(j) : s == 8 ? xor_lane<8>(j) :
+                           s == 16 ? xor_lane<16>(j) : xor_lane<32>(j);
             const bool up = (lane & k) == 0 || k == 64;   // final merge: ascending everywhere
             const bool lower = (lane & s) == 0;
             const bool take_min = lower == up;
@@ -92,7 +104,8 @@ __device__ __forceinline__ void bitonic64u(unsigned int &v, int lane) {
     for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
         for (int s = k >> 1; s > 0; s >>= 1) {
-            const unsigned int o = (unsigned int)__shfl_xor((int)v, s, 64);
+            const unsigned int o = (unsigned int)(s == 1 ? xor_lane<1>((int)v) : s == 2 ? xor_lane<2>((int)v) : s == 4 ? xor_lane<4>((int)v) :
+                                                  s == 8 ? xor_lane<8>((int)v) : s == 16 ? xor_lane<16>((int)v) : xor_lane<32>((int)v));
             const bool up = (lane & k) == 0 || k == 64;
             const bool lower = (lane & s) == 0;
             v = (lower == up) ? (v < o ? v : o) : (v > o ? v : o);
@@ -531,10 +544,15 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
     for (int j0 = 0; j0 < M; j0 += 1024) {
         unsigned int d[16];
         unsigned int lmin = kNoKey;
+        // (a short list -- a query's own survivors -- fills only the first sweeps: the others are skipped, wave-uniformly)
+        const int nsw = (M - j0 + 63) / 64 < 16 ? (M - j0 + 63) / 64 : 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = kNoKey;
         if (vec4) {
             // rows as 16-byte pieces, four candidates in flight (dimension order kept: x, y, z, w of every piece)
 #pragma unroll
             for (int i0 = 0; i0 < 16; i0 += 4) {
+                if (i0 >= nsw) continue;
                 const float *c[4];
                 float sacc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -567,8 +585,7 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int j = j0 + lane + 64 * i;
-                d[i] = kNoKey;
-                if (j < M) {
+                if (i < nsw && j < M) {
                     const float *c = yb + (size_t)(ids ? ids[j] : j) * D;
                     float s = 0.0f;
                     for (int dd = 0; dd < D; ++dd) {
@@ -587,8 +604,9 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
             tau = readlane_u(v, kk - 1);
         }
         int cnt = 0;
-#pragma unroll 1
+#pragma unroll  // (unrolled: d[] stays in registers -- indexed dynamically it lives in scratch memory, ~10 us per query)
         for (int i = 0; i < 16; ++i) {
+            if (i >= nsw) break;
             bool pred = d[i] <= tau && d[i] != kNoKey;
             unsigned long long bal = __ballot(pred);
             while (bal) {  // usually one pass; more only when > cap candidates qualify
@@ -859,7 +877,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                                                                const float *__restrict__ y, int M, int B, int k,
                                                                int drop, int32_t *__restrict__ idx,
                                                                float *__restrict__ dist, int CH, int img_bytes,
-                                                               int raw_ok, float *__restrict__ feat, int layout) {
+                                                               int raw_ok, float *__restrict__ feat, int layout, int med_cap, int med_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k3sm[];
     __shared__ __attribute__((aligned(16))) float red[4 * 4 * kTWaves];  // per wave: min, max, sum, sampled second moment (padded to 4 dims)
     __shared__ int nfar;                    // candidates of the cloud beyond the robust range ...
@@ -1178,6 +1196,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     const bool far_ok = nf <= kK3FarCap;             // more far candidates than the side list holds: no query is usable
     qctr[part] = tot + (part == 3 && far_ok ? nf : 0);  // the query's last lane appends the far candidates to its own entries
     if (cnt > kTCap - 1) qctr[4] = 1;
+    if (med_cap > 0) atomicOr(&qctr[6], nv << (8 * part));  // list lengths of the four parts (< 24 each): the medium path's decode
     __syncthreads();  // every wave is done with the image: its space now holds the keys
     KNN_PROBE_MARK(6);
     unsigned int *qd = reinterpret_cast<unsigned int *>(k3sm) + (size_t)qslot * kTKeyStride;                          // distance bits
@@ -1187,6 +1206,56 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     const int off = part == 0 ? 0 : (part == 1 ? c0 : (part == 2 ? c0 + c1 : c0 + c1 + c2));
     const bool usable = sane && far_ok && qok && thr < INFINITY;
     const bool fast = wave_active && qi < N && usable && qctr[4] == 0 && n <= kTKeyCap && n >= need;  // (+ 3 sentinels: inside the stride)
+    // ---- medium path (tight clusters, duplicated points, lattices: more candidates inside the band than the key arrays hold):
+    //      a wave decodes the query's four lane lists into an id list (+ the far candidates) and selects exactly among those,
+    //      instead of scanning all M candidates in the fallback.  The lists are intact until the barrier after the decode.
+    const bool medium = med_cap > 0 && wave_active && qi < N && usable && qctr[4] == 0 && n > kTKeyCap && n <= med_cap && n >= need;
+    if (med_cap > 0 && wave_active) {
+        const unsigned long long mm = __ballot(medium);
+        int *ids = reinterpret_cast<int *>(k3sm + med_off) + wv * (med_cap + 128);
+        for (unsigned int bm = (unsigned int)mm | (unsigned int)(mm >> 32); bm; bm &= bm - 1) {
+            const int j = __builtin_ctz(bm);
+            if ((j & 1) != half) continue;  // the group's two waves share the queries
+            const int *cj = ctr + (grp * 32 + j) * 8;
+            int total = 0;
+            for (int p2 = 0; p2 < 4; ++p2) {  // p2 = 2 * (wave of the group) + half-wave
+                const int src = (p2 & 1) * 32 + j;
+                const int nv2 = (cj[6] >> (8 * p2)) & 0xff;
+                const unsigned int w = lane < nv2 ? (unsigned int)lists_all[((grp + kTGroups * (p2 >> 1)) * kTCap + lane) * 64 + src] : 0u;
+                const int pc = __builtin_popcount(w & 0xffffu);
+                int incl = pc;
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) {
+                    const int t = __shfl_up(incl, m, 64);
+                    if (lane >= m) incl += t;
+                }
+                int pos = total + incl - pc;
+                unsigned int m16 = w & 0xffffu;
+                const int rowbase = (int)(w >> 16) * 32 + 4 * (p2 & 1);
+                while (m16) {
+                    const int r = 15 - __builtin_ctz(m16);  // (row r at bit 15 - r)
+                    m16 &= m16 - 1;
+                    ids[pos++] = rowbase + (r & 3) + 8 * (r >> 2);
+                }
+                total += __shfl(incl, 63, 64);
+            }
+            for (int f = lane; f < nf; f += 64) ids[total + f] = farlist[f];  // (nf = 0 unless far_ok and has_far: usable)
+            total += nf;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            float bd;
+            int bj;
+            knn_exact_bruteforce(xb + (size_t)(q0 + j) * 3, yb, total, 3, kk, lane, reinterpret_cast<float *>(ids + med_cap), ids + med_cap + 64,
+                                 bd, bj, ids);
+            const int r = lane - drop;
+            if (r >= 0 && r < k) {
+                idx[((size_t)b * N + q0 + j) * k + r] = bj;
+                if (dist) dist[((size_t)b * N + q0 + j) * k + r] = bd;
+                if (FEAT) knn_d3_feature_entry(feat, layout, b, N, k, q0 + j, r, xb + (size_t)(q0 + j) * 3, yb + (size_t)bj * 3);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
     if (fast) {
         // (1) decode the (tile, mask) words into candidate ids: integer work only, no memory latency in the chain
         int pos = off;
@@ -1369,13 +1438,15 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     }
     KNN_PROBE_MARK(10);
     if (!wave_active) return;
-    // ties are ranked again by the group's first wave; the leftovers (exact merge) are shared by its two waves
-    const bool slowq = qi < N && !fast;
-    const unsigned long long badmask = half == 0 ? __ballot(bad) : 0ull, slowmask = __ballot(slowq);
+    // ties are ranked again, and the leftovers (exact merge) answered, by the group's two waves on alternate queries
+    const bool slowq = qi < N && !fast && !medium;
+    const unsigned long long badmask = __ballot(bad), slowmask = __ballot(slowq);
     if ((badmask | slowmask) == 0) return;
     for (unsigned int bm = (unsigned int)badmask | (unsigned int)(badmask >> 32); bm; bm &= bm - 1) {
-        // a tie in the distance among the first kk of query j: the whole wave ranks its keys again, on (distance, index)
+        // a tie in the distance among the first kk of query j: the whole wave ranks its keys again, on (distance, index);
+        // the group's two waves take alternate queries (lattices and duplicated points tie in every query)
         const int j = __builtin_ctz(bm);
+        if ((j & 1) != half) continue;
         const int qs = grp * 32 + j;
         const int *cj = ctr + qs * 8;
         unsigned long long *sj = reinterpret_cast<unsigned long long *>(lists_all) + (size_t)qs * 33;
@@ -1419,7 +1490,14 @@ fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int 
     static_assert((size_t)kTWaves * 32 * 33 * 4 <= (size_t)kTWaves * kTCap * 64 * 4, "the tau exchange aliases the lists");
     static_assert((size_t)kTGroups * 32 * 33 * 8 + kTWaves * 128 * 4 <= (size_t)kTWaves * kTCap * 64 * 4, "slots + scratch alias the lists");
     const int raw_ok = M <= kTRawMax && img + fixed + (size_t)M * 16 <= 152 * 1024;
-    const size_t lds = img + fixed + (raw_ok ? (size_t)M * 16 : 0);
+    size_t lds = img + fixed + (raw_ok ? (size_t)M * 16 : 0);
+    // medium path scratch (id list + merge lists per wave), when it fits next to everything else
+    int med_cap = 0, med_off = 0;
+    for (int cap = 512; cap >= 128; cap >>= 1)
+        if (lds + (size_t)kTWaves * (cap + 128) * 4 <= 156 * 1024) {
+            med_cap = cap; med_off = (int)lds; lds += (size_t)kTWaves * (cap + 128) * 4;
+            break;
+        }
     const fx3d_status arc = feat ? ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_f16_d3_kernel<true>), 156 * 1024, "knn_f16_d3_kernel<feat>")
                                  : ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_f16_d3_kernel<false>), 156 * 1024, "knn_f16_d3_kernel");
     if (arc != FX3D_OK) return arc;
@@ -1427,10 +1505,10 @@ fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int 
     const int bpad = B >= 8 ? (B + 7) / 8 * 8 : B;
     if (feat)
         hipLaunchKernelGGL(knn_f16_d3_kernel<true>, dim3(nbx * bpad), dim3(kTThreads), lds, st, x, N, y, M, B, k, drop, idx, dist,
-                           CH, (int)img, raw_ok, feat, layout);
+                           CH, (int)img, raw_ok, feat, layout, med_cap, med_off);
     else
         hipLaunchKernelGGL(knn_f16_d3_kernel<false>, dim3(nbx * bpad), dim3(kTThreads), lds, st, x, N, y, M, B, k, drop, idx, dist,
-                           CH, (int)img, raw_ok, feat, layout);
+                           CH, (int)img, raw_ok, feat, layout, med_cap, med_off);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }
@@ -2928,12 +3006,13 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         }
     }
     if (!wave_active) return;
-    // tied queries are ranked again on the full keys by the consumer wave; the leftovers (exact merge) are shared by
-    // the consumer wave and its producer partner
+    // tied queries are ranked again on the full keys, and the leftovers (exact merge) answered, by the pair's two waves on
+    // alternate queries
     const bool slowq = qi < N && !fast && !handled;
-    const unsigned long long badmask = consumer ? __ballot(bad) : 0ull;
+    const unsigned long long badmask = __ballot(bad);
     for (unsigned int bm = (unsigned int)badmask | (unsigned int)(badmask >> 32); bm; bm &= bm - 1) {
         const int j = __builtin_ctz(bm);  // a tie in the distance among the first kk of query j
+        if ((j & 1) != (consumer ? 0 : 1)) continue;  // (the pair's two waves take alternate queries)
         const int qs = cw * 32 + j;
         unsigned long long *sj = reinterpret_cast<unsigned long long *>(lists) + (size_t)qs * 33;
         knn_rank_ties(reinterpret_cast<const unsigned int *>(sm) + (size_t)qs * kMKeyStride,
