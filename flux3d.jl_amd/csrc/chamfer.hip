@@ -72,7 +72,7 @@ struct Nn1Params {
     // candidate split (few, large clouds): blocks of one query tile take different chunk subsets and
     // merge per query through 64-bit atomics in global scratch; nn1_split_finalize_kernel unpacks
     int nsplit;                  // 1 = off
-    unsigned long long *gres;    // [2B][qstride] packed (d_bits << 32 | index), pre-filled with ~0
+    unsigned long long *gres;    // [nsplit][2B][qstride] packed (d_bits << 32 | index): every split block stores its own row (no init, no atomics)
     int qstride;
 };
 
@@ -745,8 +745,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     const unsigned long long r = qres[jq];
                     const float dd = __builtin_bit_cast(float, (unsigned int)(r >> 32));
                     const int ii = (int)(unsigned int)r;
-                    if (p.nsplit > 1) {  // merge with the other chunk subsets; unpacked by the finalize kernel
-                        if (qi < NQ) atomicMin(&p.gres[(size_t)c * p.qstride + qi], r);
+                    if (p.nsplit > 1) {  // this chunk subset's row; the finalize kernel takes the minimum over the subsets
+                        if (qi < NQ) p.gres[((size_t)split * 2 * p.B + c) * p.qstride + qi] = r;
                     } else if (qi < NQ) {
                         if (WANT_IDX && idx_out) idx_out[(size_t)b * NQ + qi] = ii;
                         if (dmin_out) dmin_out[(size_t)b * NQ + qi] = dd;
@@ -813,7 +813,17 @@ __global__ __launch_bounds__(kThreads) void nn1_split_finalize_kernel(Nn1Params 
     const int qi = blockIdx.x * kThreads + threadIdx.x;
     double acc = 0.0;
     if (qi < NQ) {
-        const unsigned long long r = p.gres[(size_t)c * p.qstride + qi];
+        // the chunk subsets that exist for this direction (nn1_f16_kernel: `split * chunk >= NC` blocks return at once)
+        const int NC = dir ? p.N : p.M;
+        const int ns = (NC + p.chunk - 1) / p.chunk < p.nsplit ? (NC + p.chunk - 1) / p.chunk : p.nsplit;
+        unsigned long long r = p.gres[(size_t)c * p.qstride + qi];
+        for (int sp = 1; sp < ns; sp += 4) {  // (distance bits, index): the 64-bit minimum is the `isless` + lowest-index winner
+            unsigned long long o[4];          // four rows in flight (a row index past the end re-reads row 0)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = p.gres[((size_t)(sp + e < ns ? sp + e : 0) * 2 * p.B + c) * p.qstride + qi];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r = o[e] < r ? o[e] : r;
+        }
         const float dd = __builtin_bit_cast(float, (unsigned int)(r >> 32));
         int32_t *idx_out = dir ? p.idx_y : p.idx_x;
         float *dmin_out = dir ? p.dmin_y : p.dmin_x;
@@ -1252,7 +1262,7 @@ fx3d_status fx3d_chamfer_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_
     if (pl.nsplit > 1) {  // split run: 256-query finalize tiles + the per-query merge slots
         const int maxq = N > M ? N : M;
         const int tiles_f = (maxq + kThreads - 1) / kThreads;
-        *bytes = ((size_t)2 * B * tiles_f + 2) * sizeof(double) + (size_t)2 * B * maxq * sizeof(unsigned long long);
+        *bytes = ((size_t)2 * B * tiles_f + 2) * sizeof(double) + (size_t)pl.nsplit * 2 * B * maxq * sizeof(unsigned long long);
     }
     return FX3D_OK;
 }
@@ -1271,21 +1281,21 @@ static fx3d_status chamfer_common(const float *x, int N, const float *y, int M, 
     const int maxq = N > M ? N : M;
     const int tiles_f = (maxq + kThreads - 1) / kThreads;
     if (pl.nsplit > 1)
-        need = ((size_t)2 * B * tiles_f + 2) * sizeof(double) + (size_t)2 * B * maxq * sizeof(unsigned long long);
+        need = ((size_t)2 * B * tiles_f + 2) * sizeof(double) + (size_t)pl.nsplit * 2 * B * maxq * sizeof(unsigned long long);
     if (!ws || ws_bytes < need) {
         set_error("%s: workspace too small (%zu < %zu bytes)", fn, ws ? ws_bytes : (size_t)0, need);
         return FX3D_ERR_WORKSPACE;
     }
     double *partials = reinterpret_cast<double *>(ws);
     if (pl.nsplit > 1) {
-        // few large clouds: chunk subsets run in parallel blocks and merge through gres
+        // few large clouds: chunk subsets run in parallel blocks, each stores its per-query result row in gres (plain
+        // stores: no memset node, no atomics), the finalize kernel merges the rows
         unsigned long long *gres = reinterpret_cast<unsigned long long *>(partials + (size_t)2 * B * tiles_f + 2);
-        FX3D_HIP(hipMemsetAsync(gres, 0xFF, (size_t)2 * B * maxq * sizeof(unsigned long long), st));
         rc = run_nn1(x, N, y, M, B, D, nullptr, nullptr, nullptr, nullptr, nullptr, pl, st, nullptr, gres, maxq);
         if (rc) return rc;
         Nn1Params fp{};
         fp.N = N; fp.M = M; fp.B = B; fp.idx_x = idx_x; fp.idx_y = idx_y; fp.partials = partials;
-        fp.gres = gres; fp.qstride = maxq; fp.nsplit = pl.nsplit;
+        fp.gres = gres; fp.qstride = maxq; fp.nsplit = pl.nsplit; fp.chunk = pl.chunk;
         // (split runs exist for D == 3 only) the last block of the unpack kernel reduces the partials: no finalize launch
         fx3d_status trc = FX3D_OK;
         unsigned int *ticket = ticket_slot(&trc, st);

@@ -25,6 +25,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kCdfThreads = 1024;  // one block per mesh: the area / division passes are the parallel part
 constexpr int kChunk = 32;  // FX_SCAN_CHUNK of the oracle
+constexpr int kCdfFaces = 6;  // faces per thread and sweep of the area pass
 
 // barycentric point, src/transforms/mesh_func.jl:67-71,:75-82
 __device__ __forceinline__ void bary_point(const float *__restrict__ vb, const int32_t *__restrict__ fc,
@@ -52,51 +53,121 @@ __global__ __launch_bounds__(kThreads) void sample_explicit_kernel(
 
 // One block per mesh.  ws layout per mesh: cdf[Fp] then tc[nchunks]  (doubles), Fp = roundup32.
 // The SUMMATION ORDER is fixed by the specification shared with the oracle (chunks of 32 summed
-// left to right, chunk totals summed left to right); everything order-free (the Float64 divisions, the
-// final offset add) runs on all 256 threads, the order-bound parts are 32- or nch-long add chains.
+// left to right, chunk totals summed left to right); everything order-free (the areas, the Float64 divisions, the
+// final offset add) runs on all threads, the order-bound parts are 32- or nch-long add chains.
 // The face areas are computed in place (compute_faces_areas_padded, src/rep/mesh.jl:799-808: pad faces -> 0).
-template <bool IN_LDS>
+//
+// One thread's left-to-right sum of t[0..n) (the specified order); EXCL: t[c] is replaced by the sum of the values
+// before it.  BATCH: t is zero-padded to a multiple of 32 and lives in LDS -- 32 values are loaded, then added: the
+// additions are the dependent chain, the LDS latency is paid once per 32 instead of once per 8 (+0.0 does not change a
+// sum of non-negative terms).
+template <bool EXCL, bool BATCH>
+__device__ __forceinline__ double chain_scan(double *t, int n) {
+    double s = 0.0;
+    if constexpr (BATCH) {
+        for (int c = 0; c < n; c += kChunk) {
+            double v[kChunk];
+#pragma unroll
+            for (int i = 0; i < kChunk; ++i) v[i] = t[c + i];
+#pragma unroll
+            for (int i = 0; i < kChunk; ++i) {
+                if (EXCL) t[c + i] = s;
+                s += v[i];
+            }
+        }
+    } else {
+#pragma unroll 8
+        for (int c = 0; c < n; ++c) {
+            const double v = t[c];
+            if (EXCL) t[c] = s;
+            s += v;
+        }
+    }
+    return s;
+}
+
+#ifdef FX3D_CDF_PROBE  // wall-clock stamps (10 ns) of block 0's phases in the unused chunk-total slots of ws (tools/face_cdf_ab.py)
+#define CDF_MARK(i) if (IN_LDS && threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<long long *>(out + Fp)[i] = (long long)wall_clock64()
+#else
+#define CDF_MARK(i)
+#endif
+// IN_LDS: the working copy (areas -> probabilities -> prefixes) and the chunk totals live in LDS (latency-bound chains).
+// VLDS (with IN_LDS): the mesh's vertices are staged in LDS first (coalesced loads, in flight together with the face
+// indices: ONE global round trip), the 3 gathers per face read LDS -- the block is alone on its mesh and one CU's
+// texture path takes ~1.4 ns per face for scattered 12-byte loads (7.6 us of 16 for the fit loop's 5 k-face sphere).
+template <bool IN_LDS, bool VLDS>
 __global__ __launch_bounds__(kCdfThreads) void face_cdf_kernel(const float *__restrict__ verts_padded, int Vmax,
                                                             const int32_t *__restrict__ faces_padded,
                                                             const int32_t *__restrict__ faces_len, int Fmax,
                                                             int Fp, double eps,
                                                             double *__restrict__ ws) {
-    extern __shared__ __attribute__((aligned(16))) double dsm[];  // IN_LDS: work[Fp] + tc[nch]
+    extern __shared__ __attribute__((aligned(16))) double dsm[];  // IN_LDS: work[Fp + nch] + tc[nchp] (+ float4 verts[Vmax])
     const int b = blockIdx.x;
-    const int nch = Fp / kChunk;
+    const int nch = Fp / kChunk, nchp = (nch + kChunk - 1) / kChunk * kChunk;
     const float *vb = verts_padded + (size_t)b * Vmax * 3;
     const int32_t *fb = faces_padded + (size_t)b * Fmax * 3;
-    const int flen = faces_len[b];
     double *out = ws + (size_t)b * (Fp + nch);
-    double *cdf = IN_LDS ? dsm : out;          // working copy: LDS when the mesh fits (latency-bound chains)
+    double *cdf = IN_LDS ? dsm : out;
     // LDS copy: one pad double per chunk of 32, so that thread c walking chunk c (stride 33 doubles) and its neighbours
     // hit different banks -- with the plain stride of 256 B all 64 lanes of a wave shared one bank (face_cdf 22.8 -> 18.9 us)
     auto P = [](int k) { return IN_LDS ? k + (k >> 5) : k; };
     double *tc = IN_LDS ? dsm + Fp + nch : out + Fp;
+    const int nct = IN_LDS ? nchp : nch;  // chunk totals walked by the chains (LDS copy: zero-padded)
+    float4 *vl = reinterpret_cast<float4 *>(dsm + ((Fp + nch + nchp + 1) & ~1));
     __shared__ double sh[2];
-
-    // The summation order is the oracle's "blocked" order (chunks of 32 summed sequentially, chunk totals summed
-    // sequentially); the passes are arranged so that every chain of that order is walked once:
     __shared__ double pF[kChunk];  // probabilities of the chunk that holds the fix-up column, before the fix-up
-    // areas: four faces per thread and sweep, all index loads first, then all vertex loads (one block per mesh: the two
-    // dependent global round trips of a face must overlap with those of the thread's other faces, not follow them)
-    for (int k0 = 0; k0 < Fp; k0 += 4 * kCdfThreads) {
+    CDF_MARK(0);
+
+    // areas: kCdfFaces faces per thread and sweep (one sweep for meshes of up to 6 k faces); the face-index loads do not
+    // wait for faces_len (the padded array is addressable up to Fmax; rows beyond the mesh's own faces are replaced by a
+    // valid face after the load)
+    if (VLDS) {
+        for (int v0 = 0; v0 < Vmax; v0 += 4 * kCdfThreads) {  // four loads in flight per thread, then the LDS writes
+            P3 q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int v = v0 + e * kCdfThreads + threadIdx.x;
+                q[e] = *reinterpret_cast<const P3 *>(vb + 3ll * (v < Vmax ? v : 0));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int v = v0 + e * kCdfThreads + threadIdx.x;
+                if (v < Vmax) vl[v] = make_float4(q[e].x, q[e].y, q[e].z, 0.0f);
+            }
+        }
+    }
+    const int flen = faces_len[b];
+    for (int k0 = 0; k0 < Fp; k0 += kCdfFaces * kCdfThreads) {
         struct __attribute__((packed, aligned(4))) I3 { int32_t a, b, c; };
-        I3 fi[4];
-        P3 va[4], vb3[4], vc[4];
+        I3 fi[kCdfFaces];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < kCdfFaces; ++e) {
             const int k = k0 + e * kCdfThreads + threadIdx.x;
-            fi[e] = flen > 0 ? *reinterpret_cast<const I3 *>(fb + 3ll * (k < flen ? k : 0)) : I3{0, 0, 0};  // (clamped: a valid face)
+            fi[e] = I3{0, 0, 0};
+            if (k0 + e * kCdfThreads < Fp) fi[e] = *reinterpret_cast<const I3 *>(fb + 3ll * (k < Fmax ? k : 0));  // (block-uniform)
         }
+        if (VLDS && k0 == 0) __syncthreads();  // (the vertex loads above and these index loads were in flight together)
+        CDF_MARK(8);
+        P3 va[kCdfFaces], vb3[kCdfFaces], vc[kCdfFaces];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            va[e] = *reinterpret_cast<const P3 *>(vb + 3ll * fi[e].a);
-            vb3[e] = *reinterpret_cast<const P3 *>(vb + 3ll * fi[e].b);
-            vc[e] = *reinterpret_cast<const P3 *>(vb + 3ll * fi[e].c);
+        for (int e = 0; e < kCdfFaces; ++e) {
+            const int k = k0 + e * kCdfThreads + threadIdx.x;
+            if (k >= flen) fi[e] = I3{0, 0, 0};  // padding rows: any in-range vertices (their area is set to 0 below)
+            va[e] = vb3[e] = vc[e] = P3{0.0f, 0.0f, 0.0f};
+            if (k0 + e * kCdfThreads < Fp) {
+                if (VLDS) {
+                    const float4 x = vl[fi[e].a], y = vl[fi[e].b], z = vl[fi[e].c];
+                    va[e] = P3{x.x, x.y, x.z}; vb3[e] = P3{y.x, y.y, y.z}; vc[e] = P3{z.x, z.y, z.z};
+                } else {
+                    va[e] = *reinterpret_cast<const P3 *>(vb + 3ll * fi[e].a);
+                    vb3[e] = *reinterpret_cast<const P3 *>(vb + 3ll * fi[e].b);
+                    vc[e] = *reinterpret_cast<const P3 *>(vb + 3ll * fi[e].c);
+                }
+            }
         }
+        CDF_MARK(9);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < kCdfFaces; ++e) {
             const int k = k0 + e * kCdfThreads + threadIdx.x;
             const float v1[3] = {va[e].x, va[e].y, va[e].z}, v2[3] = {vb3[e].x, vb3[e].y, vb3[e].z}, v3[3] = {vc[e].x, vc[e].y, vc[e].z};
             const float a = k < flen ? tri_area(v1, v2, v3) : 0.0f;
@@ -104,56 +175,67 @@ __global__ __launch_bounds__(kCdfThreads) void face_cdf_kernel(const float *__re
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < nch; c += kCdfThreads) {  // chunk totals of the areas
+    CDF_MARK(1);
+    for (int c = threadIdx.x; c < nct; c += kCdfThreads) {  // chunk totals of the areas (all loads first: the additions are the chain)
         double t = 0.0;
-#pragma unroll 8
-        for (int k = c * kChunk; k < (c + 1) * kChunk; ++k) t += cdf[P(k)];
+        if (c < nch) {
+            double v[kChunk];
+#pragma unroll
+            for (int i = 0; i < kChunk; ++i) v[i] = cdf[P(c * kChunk) + i];
+#pragma unroll
+            for (int i = 0; i < kChunk; ++i) t += v[i];
+        }
         tc[c] = t;
     }
     __syncthreads();
+    CDF_MARK(2);
     if (threadIdx.x == 0) {
-        double s = 0.0;
-#pragma unroll 8
-        for (int c = 0; c < nch; ++c) s += tc[c];
+        const double s = chain_scan<false, IN_LDS>(tc, nct);
         sh[0] = s > eps ? s : eps;  // max(sum, eps), :35
     }
     __syncthreads();
+    CDF_MARK(3);
     const double den = sh[0];
-    const int cF = (Fmax - 1) / kChunk;  // chunk of the last PADDED column, where the fix-up lands (:36-37)
+    const int cF = (Fmax - 1) / kChunk;  // chunk of the last PADDED column, where the fix-up lands (:36-37): the last chunk
     for (int k = threadIdx.x; k < Fmax; k += kCdfThreads) cdf[P(k)] = cdf[P(k)] / den;  // p, parallel (Float64 divisions)
     __syncthreads();
+    CDF_MARK(4);
     for (int c = threadIdx.x; c < nch; c += kCdfThreads) {
         // local inclusive prefixes of p in place; the last prefix of a chunk is its total of p
-        double l = 0.0;
-#pragma unroll 8
-        for (int k = c * kChunk; k < (c + 1) * kChunk; ++k) {
-            const double pk = cdf[P(k)];
-            if (c == cF) pF[k - c * kChunk] = pk;
-            l += pk;
-            cdf[P(k)] = l;
+        double l = 0.0, v[kChunk];
+#pragma unroll
+        for (int i = 0; i < kChunk; ++i) v[i] = cdf[P(c * kChunk) + i];
+#pragma unroll
+        for (int i = 0; i < kChunk; ++i) {
+            if (c == cF) pF[i] = v[i];
+            l += v[i];
+            cdf[P(c * kChunk) + i] = l;
         }
         tc[c] = l;
     }
     __syncthreads();
+    CDF_MARK(5);
     if (threadIdx.x == 0) {
-        double sp = 0.0;
-#pragma unroll 8
-        for (int c = 0; c < nch; ++c) sp += tc[c];
+        // sum of the chunk totals (left to right) and, in the same walk, their exclusive scan in place: the running value
+        // before chunk c IS its offset.  The fix-up column lies in the last chunk (Fp = roundup32(Fmax)), whose offset
+        // does not depend on its own total -- only its local prefixes change.
+        const double sp = chain_scan<true, IN_LDS>(tc, nct);
         const double fix = 1.0 - sp;
-        if (fix > 0.0) {  // p[Fmax-1] += fix: only this chunk's prefixes and total change
-            double l = 0.0;
-            for (int k = cF * kChunk; k < (cF + 1) * kChunk; ++k) {
-                l += pF[k - cF * kChunk] + (k == Fmax - 1 ? fix : 0.0);
-                cdf[P(k)] = l;
+        if (fix > 0.0) {  // p[Fmax-1] += fix
+            double l = 0.0, v[kChunk];
+#pragma unroll
+            for (int i = 0; i < kChunk; ++i) v[i] = pF[i];
+#pragma unroll
+            for (int i = 0; i < kChunk; ++i) {
+                l += v[i] + (cF * kChunk + i == Fmax - 1 ? fix : 0.0);
+                cdf[P(cF * kChunk) + i] = l;
             }
-            tc[cF] = l;
         }
-        double off = 0.0;  // exclusive scan of the chunk totals, in place
-#pragma unroll 8
-        for (int c = 0; c < nch; ++c) { const double t = tc[c]; tc[c] = off; off += t; }
     }
     __syncthreads();
+    CDF_MARK(6);
     for (int k = threadIdx.x; k < Fmax; k += kCdfThreads) out[k] = tc[k / kChunk] + cdf[P(k)];
+    CDF_MARK(7);
 }
 
 __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
@@ -274,13 +356,21 @@ fx3d_status fx3d_sample_points_cdf(const float *verts_padded, int32_t Vmax, cons
     const int Fp = roundup32(Fmax);
     double *cdf = reinterpret_cast<double *>(ws);
     ProfileScope prof("sample_cdf", st);
-    const size_t cdf_lds = sizeof(double) * (size_t)(Fp + 2 * (Fp / kChunk));  // + one pad per chunk (bank spread)
-    if (cdf_lds <= 60 * 1024)
-        hipLaunchKernelGGL(face_cdf_kernel<true>, dim3(B), dim3(kCdfThreads), cdf_lds, st, verts_padded, Vmax, faces_padded,
-                           faces_len, Fmax, Fp, eps, cdf);
-    else
-        hipLaunchKernelGGL(face_cdf_kernel<false>, dim3(B), dim3(kCdfThreads), 0, st, verts_padded, Vmax, faces_padded,
-                           faces_len, Fmax, Fp, eps, cdf);
+    const size_t cdf_lds = sizeof(double) * (size_t)(Fp + 2 * (Fp / kChunk) + kChunk + 2);  // + one pad per chunk (bank spread), chunk totals padded to 32
+    const size_t v_lds = sizeof(float) * 4 * (size_t)Vmax + 16;
+    if (cdf_lds <= 60 * 1024 && cdf_lds + v_lds <= 150 * 1024) {
+        const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&face_cdf_kernel<true, true>), 150 * 1024,
+                                                   "face_cdf_kernel");
+        if (arc != FX3D_OK) return arc;
+        hipLaunchKernelGGL((face_cdf_kernel<true, true>), dim3(B), dim3(kCdfThreads), cdf_lds + v_lds, st, verts_padded, Vmax,
+                           faces_padded, faces_len, Fmax, Fp, eps, cdf);
+    } else if (cdf_lds <= 60 * 1024) {
+        hipLaunchKernelGGL((face_cdf_kernel<true, false>), dim3(B), dim3(kCdfThreads), cdf_lds, st, verts_padded, Vmax,
+                           faces_padded, faces_len, Fmax, Fp, eps, cdf);
+    } else {
+        hipLaunchKernelGGL((face_cdf_kernel<false, false>), dim3(B), dim3(kCdfThreads), 0, st, verts_padded, Vmax,
+                           faces_padded, faces_len, Fmax, Fp, eps, cdf);
+    }
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }

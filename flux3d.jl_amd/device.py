@@ -148,6 +148,7 @@ class _Pool:
         self.cached = 0
         self.limit = limit_bytes
         self.steals = 0  # allocations served from another stream's cache (after synchronising it)
+        self.limbo = []  # blocks released across streams during a capture (no synchronisation there): freed by empty()
 
     @staticmethod
     def _cls(nbytes):
@@ -164,6 +165,8 @@ class _Pool:
             self.cached -= c
             return lst.pop(), c, sh
         for (osh, oc), olst in self.free.items():
+            if _capturing:
+                break  # a capturing stream cannot be synchronised: no block crosses streams inside a capture
             if oc == c and olst and osh != sh:
                 _sync_handle(osh)  # its pending work may still touch the block
                 self.cached -= c
@@ -179,6 +182,9 @@ class _Pool:
 
     def release(self, ptr, c, sh=0):
         cur = current_stream().handle or 0
+        if cur != sh and _capturing:  # two-branch capture: nothing may synchronise; the graph's pool keeps the block
+            self.limbo.append(ptr)
+            return
         if cur != sh:  # possibly used on both: neither may still be running on it when it is handed out again
             _sync_handle(cur)
             _sync_handle(sh)
@@ -193,10 +199,11 @@ class _Pool:
     def empty(self):
         lib = _lib.load()
         lib.fx3d_device_sync()
-        for lst in self.free.values():
+        for lst in list(self.free.values()) + [self.limbo]:
             for ptr in lst:
                 lib.fx3d_free(ptr)
         self.free.clear()
+        self.limbo = []
         self.cached = 0
 
 

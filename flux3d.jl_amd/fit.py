@@ -36,12 +36,14 @@ def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_la
     if not with_grad:
         return loss
     gA, _ = chamfer_distance_grad(A, Bp, ix, iy)
+    if m.N == 1:
+        # one mesh: padded == packed.  Both mesh-loss adjoints in ONE gather launch (no float atomics, reusing the forward's
+        # unit rows) WRITE the buffer, the sampling adjoint scatter-adds on top: no memset node in the iteration
+        g = mesh_losses_grad(m, 0.0, w_lap, w_edge, reuse_forward=True)
+        sample_points_grad(m, fa, r1, r2, gA, out=g.reshape(3, m.V, 1))
+        return loss, g
     gpad = sample_points_grad(m, fa, r1, r2, gA)           # (3,Vmax,B), zeroed + scatter-added
-    if m.N == 1:  # one mesh: padded == packed, the mesh-loss adjoints add into the same buffer
-        g = gpad.reshape(3, m.V)
-    else:
-        g = m.padded_to_packed_dev(gpad)                    # adjoint of _packed_to_padded
-    # both mesh-loss adjoints in ONE gather launch (no float atomics), reusing the forward's unit rows
+    g = m.padded_to_packed_dev(gpad)                        # adjoint of _packed_to_padded
     mesh_losses_grad(m, 0.0, w_lap, w_edge, out=g, reuse_forward=True)
     return loss, g
 
@@ -70,7 +72,7 @@ class Momentum:
 
 class FitStepGraph:
     """One iteration of the fit_mesh loop (examples/fit_mesh.jl:98-110: loss, gradient, Momentum update) captured
-    as a hipGraph: ~30 launch-bound kernels, memsets and copies replayed with one launch per iteration.
+    as a hipGraph: ten launch-bound kernels (no memset, no copy) replayed with one launch per iteration.
 
     The sampling seeds recorded in the graph are ``seed`` and ``seed + 1`` plus a device counter that the graph
     itself advances by two per replay, so every iteration draws fresh samples (the reference draws from the global

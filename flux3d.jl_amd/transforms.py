@@ -98,13 +98,14 @@ def sample_points(m, num_samples=5000, eps=EPS, seed=None, return_draws=False,
     return (out, fo, a, b) if return_draws else out
 
 
-def sample_points_grad(m, face_idx, r1, r2, gout):
-    """Adjoint of sample_points w.r.t. the padded verts for fixed draws: device (3,Vmax,B)."""
+def sample_points_grad(m, face_idx, r1, r2, gout, out=None):
+    """Adjoint of sample_points w.r.t. the padded verts for fixed draws: device (3,Vmax,B).
+    ``out``: scatter-add into this (3,Vmax,B) array instead of a zeroed one (no memset node)."""
     n, B = face_idx.shape
-    g = DeviceArray.empty((3, m.V, m.N), np.float32)
+    g = DeviceArray.empty((3, m.V, m.N), np.float32) if out is None else out
     gout = gout if isinstance(gout, DeviceArray) else DeviceArray.from_host(np.asarray(gout, np.float32))
     _lib.call("fx3d_sample_points_bwd", m.dev("faces_padded").ptr, m.V, m.F, B, n, face_idx.ptr,
-              r1.ptr, r2.ptr, gout.ptr, g.ptr, 0, current_stream().handle)
+              r1.ptr, r2.ptr, gout.ptr, g.ptr, int(out is not None), current_stream().handle)
     return g
 
 
