@@ -101,7 +101,7 @@ def test_nn1_and_chamfer_nonfinite(gpu_fx, oracle, case, N, M, B):
 
 @pytest.mark.parametrize("case", NONFINITE)
 def test_nn1_nonfinite_split_plan_and_exact_loop(gpu_fx, oracle, case):
-    """The candidate-split plan (global 64-bit merge slots) and the D = 2 exact loop see the same keys."""
+    """The candidate-split plan (per-subset rows of 64-bit keys, merged by the unpack kernel) and the D = 2 exact loop see the same keys."""
     with np.errstate(all="ignore"):
         x, y = _nonfinite_case(case, 5000, 9000, 1, 77)
         _chamfer_equal(gpu_fx, oracle, x, y)

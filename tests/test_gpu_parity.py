@@ -992,7 +992,7 @@ def test_c4_full_size_knn_properties(gpu_fx, oracle, D):
 @pytest.mark.parametrize("N,M,B", [(9000, 12000, 1), (5000, 5000, 8), (16384, 700, 2)])
 def test_chamfer_split_plans(gpu_fx, oracle, N, M, B):
     """Few large clouds: the launch plan splits the candidates into balanced chunks taken by different blocks
-    (merged through 64-bit atomicMin slots) and runs several query passes per block; fx3d_nn1 (no scratch) takes
+    (each stores its per-query row; the unpack kernel takes the 64-bit minimum over the chunk subsets) and runs several query passes per block; fx3d_nn1 (no scratch) takes
     the serial plan.  Both against the oracle."""
     x, y = _rand((3, N, B), N), _rand((3, M, B), M + 1)
     _check_nn(gpu_fx, oracle, x, y)           # fx3d_nn1: serial chunks
