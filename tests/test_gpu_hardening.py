@@ -529,3 +529,53 @@ def test_knn_ws_entry_point_contract(gpu_fx, oracle):
         fx.synchronize()
         assert np.array_equal(idx.to_host(), oi)
         assert np.array_equal(dist.to_host(), od, equal_nan=True)
+
+
+def _grid_mesh(nx, ny, seed, extra_verts=0):
+    """A jittered (nx x ny)-cell sheet: (nx+1)(ny+1) (+ extra unused) vertices, 2 nx ny triangles of uneven area."""
+    rng = np.random.default_rng(seed)
+    gx, gy = np.meshgrid(np.arange(nx + 1, dtype=np.float64), np.arange(ny + 1, dtype=np.float64), indexing="ij")
+    v = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], 0) + rng.uniform(-0.3, 0.3, (3, gx.size))
+    if extra_verts:
+        v = np.concatenate([v, rng.uniform(0, nx, (3, extra_verts))], 1)
+    idx = lambda i, j: i * (ny + 1) + j  # noqa: E731
+    f = []
+    for i in range(nx):
+        for j in range(ny):
+            f.append([idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)])
+            f.append([idx(i, j), idx(i + 1, j + 1), idx(i, j + 1)])
+    return np.asfortranarray(v.astype(np.float32)), np.asfortranarray((np.array(f, np.int64).T + 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["tiny", "two_sweeps", "global_cdf", "verts_not_staged", "ragged"])
+def test_face_cdf_bits_every_kernel_variant(gpu_fx, oracle, case):
+    """The sampling CDF itself (not only the draws made from it), bit for bit against the specified order
+    (oracle/flux3d_oracle.c: chunks of 32 left to right, chunk totals left to right), for every face_cdf_kernel
+    variant: one sweep / two sweeps of the area pass, working copy in LDS or in the workspace, vertices staged in
+    LDS or gathered from global memory, a ragged batch (fix-up column outside the shorter meshes)."""
+    fx = gpu_fx
+    from flux3d_jl_amd.transforms import EPS, _face_cdf, _verts_padded_dev
+    meshes = {"tiny": [_grid_mesh(7, 7, 1)],                             # 98 faces
+              "two_sweeps": [_grid_mesh(56, 56, 2)],                     # 6272 faces > 6 x 1024
+              "global_cdf": [_grid_mesh(62, 62, 3)],                     # 7688 faces: working copy > 60 KiB of LDS
+              "verts_not_staged": [_grid_mesh(50, 50, 4, extra_verts=6000)],   # 8601 vertices: 134 KiB of float4 slots
+              "ragged": [_grid_mesh(30, 30, 5), _grid_mesh(10, 10, 6), _grid_mesh(40, 40, 7)]}[case]
+    m = fx.gpu(fx.TriMesh([v for v, _ in meshes], [f for _, f in meshes]))
+    ws = _face_cdf(m, _verts_padded_dev(m), m.dev("faces_padded"), EPS)
+    Fmax, B = m.F, m.N
+    Fp = (Fmax + 31) // 32 * 32
+    got = ws.to_host().view(np.float64)[:B * (Fp + Fp // 32)].reshape(B, Fp + Fp // 32)[:, :Fmax]
+    vp, fp0 = m.get_verts_padded_host(), m.get_faces_padded().astype(np.int64) - 1
+    p = oracle.face_probs(oracle.faces_areas_padded(vp, fp0, m._faces_len), EPS)[0]     # (Fmax, B) Float64, fix-up applied
+    for b in range(B):
+        want, off = np.zeros(Fmax), 0.0
+        for c0 in range(0, Fmax, 32):
+            l = np.cumsum(p[c0:c0 + 32, b])          # sequential Float64 prefix sums of the chunk
+            want[c0:c0 + 32] = off + l
+            off = off + l[-1]
+        assert np.array_equal(got[b], want), (case, b, int(np.argmax(got[b] != want)))
+    # and the draws made from it
+    out, fi, r1, r2 = fx.sample_points(m, 3000, seed=99, return_draws=True)
+    eo, efi, er1, er2 = oracle.sample_points_seeded(vp, fp0, m._faces_len, 3000, 99, return_draws=True)
+    assert np.array_equal(fi.to_host(), efi) and np.array_equal(out.to_host(), eo)
