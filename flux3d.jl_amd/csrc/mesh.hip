@@ -118,12 +118,27 @@ __device__ __forceinline__ void lap_row(const float *__restrict__ verts,
                                         float &s1, float &s2) {
     s0 = 0.0f; s1 = 0.0f; s2 = 0.0f;
     const int k1 = rowptr[i + 1];
-    for (int k = rowptr[i]; k < k1; ++k) {
-        const float w = vals[k];
-        const float *v = verts + 3ll * colind[k];
-        s0 = s0 + w * v[0];
-        s1 = s1 + w * v[1];
-        s2 = s2 + w * v[2];
+    // eight entries per sweep (a mesh vertex has ~7: itself + 6 neighbours): every (weight, column) load first, then every
+    // vertex gather, then the sums in ascending column order -- two dependent round trips per row instead of two per entry
+    for (int k0 = rowptr[i]; k0 < k1; k0 += 8) {
+        float w[8];
+        int col[8];
+        P3 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e < k1 ? k0 + e : k1 - 1;
+            w[e] = vals[k];
+            col[e] = colind[k];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const P3 *>(verts + 3ll * col[e]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (k0 + e < k1) {
+                s0 = s0 + w[e] * v[e].x;
+                s1 = s1 + w[e] * v[e].y;
+                s2 = s2 + w[e] * v[e].z;
+            }
     }
 }
 
@@ -154,12 +169,23 @@ __global__ __launch_bounds__(kThreads) void laplacian_loss_bwd_kernel(
         if (!(nrm > 0.0f)) continue;
         const float u0 = s0 / nrm, u1 = s1 / nrm, u2 = s2 / nrm;
         const int k1 = rowptr[i + 1];
-        for (int k = rowptr[i]; k < k1; ++k) {
-            const float w = c * vals[k];
-            float *g = gverts + 3ll * colind[k];
-            atomicAdd(&g[0], w * u0);
-            atomicAdd(&g[1], w * u1);
-            atomicAdd(&g[2], w * u2);
+        for (int k0 = rowptr[i]; k0 < k1; k0 += 8) {  // (weights and columns of a sweep first: the atomics do not wait entry by entry)
+            float w[8];
+            int col[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e < k1 ? k0 + e : k1 - 1;
+                w[e] = c * vals[k];
+                col[e] = colind[k];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (k0 + e < k1) {
+                    float *g = gverts + 3ll * col[e];
+                    atomicAdd(&g[0], w[e] * u0);
+                    atomicAdd(&g[1], w[e] * u1);
+                    atomicAdd(&g[2], w[e] * u2);
+                }
         }
     }
 }
@@ -262,30 +288,44 @@ __global__ __launch_bounds__(kThreads) void mesh_losses_bwd_gather_kernel(
         const float v0 = verts[3 * i], v1 = verts[3 * i + 1], v2 = verts[3 * i + 2];
         float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
         const int k1 = rowptr[i + 1];
-        for (int k = rowptr[i]; k < k1; ++k) {
-            const int r = colind[k];
-            if (LAP) {  // row r of the oracle's scatter: gverts[i] += (c * L[r,i]) * u_r
-                const float4 ur = u[r];
-                const float w = c_lap * (r == (int)i ? -1.0f : ur.w);
-                l0 = l0 + w * ur.x;
-                l1 = l1 + w * ur.y;
-                l2 = l2 + w * ur.z;
+        for (int k0 = rowptr[i]; k0 < k1; k0 += 8) {  // eight entries per sweep: columns, then all gathers, then the sums in order
+            int col[8];
+            float4 urr[8];
+            P3 vrr[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) col[e] = colind[k0 + e < k1 ? k0 + e : k1 - 1];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (LAP) urr[e] = u[col[e]];
+                if (EDGE) vrr[e] = *reinterpret_cast<const P3 *>(verts + 3ll * col[e]);
             }
-            if (EDGE && r != (int)i) {
-                const float *vr = verts + 3ll * r;
-                if (r < (int)i) {  // edge (r, i): d = v_r - v_i, vertex i receives -= g d
-                    const float d0 = vr[0] - v0, d1 = vr[1] - v1, d2 = vr[2] - v2;
-                    const float nrm = sqrtf(((d0 * d0) + (d1 * d1)) + (d2 * d2));
-                    if (nrm > 0.0f) {
-                        const float g = c_edge * 2.0f * (nrm - target) / nrm;
-                        e0 = e0 - g * d0; e1 = e1 - g * d1; e2 = e2 - g * d2;
-                    }
-                } else {           // edge (i, r): d = v_i - v_r, vertex i receives += g d
-                    const float d0 = v0 - vr[0], d1 = v1 - vr[1], d2 = v2 - vr[2];
-                    const float nrm = sqrtf(((d0 * d0) + (d1 * d1)) + (d2 * d2));
-                    if (nrm > 0.0f) {
-                        const float g = c_edge * 2.0f * (nrm - target) / nrm;
-                        e0 = e0 + g * d0; e1 = e1 + g * d1; e2 = e2 + g * d2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (!(k0 + e < k1)) continue;
+                const int r = col[e];
+                if (LAP) {  // row r of the oracle's scatter: gverts[i] += (c * L[r,i]) * u_r
+                    const float4 ur = urr[e];
+                    const float w = c_lap * (r == (int)i ? -1.0f : ur.w);
+                    l0 = l0 + w * ur.x;
+                    l1 = l1 + w * ur.y;
+                    l2 = l2 + w * ur.z;
+                }
+                if (EDGE && r != (int)i) {
+                    const float vr[3] = {vrr[e].x, vrr[e].y, vrr[e].z};
+                    if (r < (int)i) {  // edge (r, i): d = v_r - v_i, vertex i receives -= g d
+                        const float d0 = vr[0] - v0, d1 = vr[1] - v1, d2 = vr[2] - v2;
+                        const float nrm = sqrtf(((d0 * d0) + (d1 * d1)) + (d2 * d2));
+                        if (nrm > 0.0f) {
+                            const float g = c_edge * 2.0f * (nrm - target) / nrm;
+                            e0 = e0 - g * d0; e1 = e1 - g * d1; e2 = e2 - g * d2;
+                        }
+                    } else {           // edge (i, r): d = v_i - v_r, vertex i receives += g d
+                        const float d0 = v0 - vr[0], d1 = v1 - vr[1], d2 = v2 - vr[2];
+                        const float nrm = sqrtf(((d0 * d0) + (d1 * d1)) + (d2 * d2));
+                        if (nrm > 0.0f) {
+                            const float g = c_edge * 2.0f * (nrm - target) / nrm;
+                            e0 = e0 + g * d0; e1 = e1 + g * d1; e2 = e2 + g * d2;
+                        }
                     }
                 }
             }
