@@ -765,6 +765,34 @@ def test_fit_step_graph_matches_eager_loop(gpu_fx):
     assert not any(isinstance(k, tuple) and k[0] == "face_cdf" for k in tgt._dev)
 
 
+def test_graph_capture_with_a_forked_stream_releases_without_synchronising(gpu_fx):
+    """A capture that forks onto a second stream (ordering-only events) and releases an array allocated under that
+    stream while the origin stream is current: the pool must not synchronise (a synchronised capturing stream
+    invalidates the capture) -- the block is parked with the graph's pool; the recording replays correctly."""
+    fx = gpu_fx
+    from flux3d_jl_amd import _lib
+    s1, s2 = fx.Stream.create(), fx.Stream.create()
+    a = fx.gpu(np.asfortranarray(np.arange(12, dtype=np.float32).reshape(3, 4)))
+    b = fx.gpu(np.asfortranarray(np.ones((3, 4), np.float32)))
+    out = fx.DeviceArray.zeros((3, 4), np.float32)
+    fx.synchronize()
+    g = fx.Graph()
+    with g.capture(s1):
+        e0, e1 = fx.Event(timing=False), fx.Event(timing=False)
+        e0.record(s1)
+        _lib.call("fx3d_stream_wait_event", s2.handle, e0.handle)
+        with fx.stream(s2):
+            t = fx.lincomb(2.0, a, 1.0, b)          # allocated under s2
+            e1.record(s2)
+        _lib.call("fx3d_stream_wait_event", s1.handle, e1.handle)
+        fx.lincomb(1.0, t, 3.0, b, out=out)         # consumed on s1
+        del t                                        # released while s1 is current: no synchronisation inside a capture
+    for _ in range(3):
+        g.launch()
+    s1.synchronize()
+    assert np.array_equal(out.to_host(), 2.0 * a.to_host() + 4.0)
+
+
 # ------------------------------------------------------------------- widened rows: EdgeConv features, voxels
 @pytest.mark.parametrize("F,N,B,K", [(3, 256, 3, 10), (64, 128, 2, 20), (6, 70, 2, 5)])
 def test_edge_features_parity(gpu_fx, oracle, F, N, B, K):
