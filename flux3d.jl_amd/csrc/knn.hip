@@ -2693,7 +2693,9 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     // staged exact phase (srl > 0): the thread's share of the first stage of candidate rows is requested here, so that
     // it arrives while the lists are decoded
     f32x4v sreg[8];
-    const int PR = D >> 2, RPI = srl > 0 ? kMThreads / PR : 0;  // rows per sweep of the block (PR divides the block size)
+    // (D > 64: the rows are staged and evaluated in two column halves of <= 64 dimensions -- see the exact phase below)
+    const int DS = DP > 64 && D > 64 ? 64 : D;                     // staged width of a row (half), floats
+    const int PR = DS >> 2, RPI = srl > 0 ? kMThreads / PR : 0;  // rows per sweep of the block (PR divides the block size)
     const int srow = srl > 0 ? tid / PR : 0, scol = (tid - srow * PR) * 4;
     if (srl > 0) knn_stage_fetch(yb, D, M, 0, srow, RPI, scol, sreg);
     if (wave_active) {
@@ -2841,55 +2843,111 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         // (every row exactly once: M * 4D bytes from L2 instead of 4D per survivor), rows 16 bytes apart in the banks.
         // Per stage the four lanes of a query split its survivors of that stage; the query row sits in registers.
         // The oracle's distance of every id: same operations in the same order as the gather below.
-        const int SRW = 1 << srl, RSX = D + 4;
+        const int SRW = 1 << srl, RSX = DS + 4;
         float *stg = reinterpret_cast<float *>(lists);
         const int nstage = (M + SRW - 1) >> srl;
         const bool act = wave_active && fast;
         const unsigned long long incl = !act ? 0ull : (DUAL ? (dpk[0] + dpk[1] + dpk[2] + dpk[3]) * 0x0101010101010101ull : qstpk[cw * 32 + jl]);
-        f32x4v qreg[DP / 4];
-        {
-            const float *qrow = xb + (size_t)(act ? qi : 0) * D;
+        if constexpr (DP <= 64) {
+            f32x4v qreg[DP / 4];
+            {
+                const float *qrow = xb + (size_t)(act ? qi : 0) * D;
 #pragma unroll
-            for (int t = 0; t < DP / 4; ++t)
-                qreg[t] = 4 * t < D ? *reinterpret_cast<const f32x4v *>(qrow + 4 * t) : f32x4v{0.f, 0.f, 0.f, 0.f};
-        }
-        for (int s = 0; s < nstage; ++s) {
-            if (s) __syncthreads();  // every lane is done with the previous stage
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = srow + i * RPI;
-                if (row < SRW) *reinterpret_cast<f32x4v *>(stg + (size_t)row * RSX + scol) = sreg[i];
+                for (int t = 0; t < DP / 4; ++t)
+                    qreg[t] = 4 * t < D ? *reinterpret_cast<const f32x4v *>(qrow + 4 * t) : f32x4v{0.f, 0.f, 0.f, 0.f};
             }
-            __syncthreads();
-            if (s < 3) KNN_PROBE_MARK(26 + 2 * s);
-            if (s + 1 < nstage) knn_stage_fetch(yb, D, M, (s + 1) << srl, srow, RPI, scol, sreg);  // in flight while this stage is evaluated
-            if (act) {
-                const int start = s ? (int)(incl >> (8 * (s - 1))) & 0xff : 0, end = (int)(incl >> (8 * s)) & 0xff;
-                const int per = (end - start + 3) >> 2;
-                const int a0 = start + part * per < end ? start + part * per : end;
-                const int a1 = a0 + per < end ? a0 + per : end;
-                for (int p0 = a0; p0 < a1; p0 += 2) {
-                    const bool two = p0 + 1 < a1;
-                    const float *cp0 = stg + (size_t)(qj[p0] - (s << srl)) * RSX;
-                    const float *cp1 = stg + (size_t)(qj[two ? p0 + 1 : p0] - (s << srl)) * RSX;
-                    float s0 = 0.0f, s1 = 0.0f;
-                    if (D == DP) knn_pair_dist<DP, true>(qreg, cp0, cp1, D, s0, s1);
-                    else knn_pair_dist<DP, false>(qreg, cp0, cp1, D, s0, s1);
-                    qd[p0] = __builtin_bit_cast(unsigned int, s0);
-                    if (two) qd[p0 + 1] = __builtin_bit_cast(unsigned int, s1);
+            for (int s = 0; s < nstage; ++s) {
+                if (s) __syncthreads();  // every lane is done with the previous stage
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = srow + i * RPI;
+                    if (row < SRW) *reinterpret_cast<f32x4v *>(stg + (size_t)row * RSX + scol) = sreg[i];
+                }
+                __syncthreads();
+                if (s < 3) KNN_PROBE_MARK(26 + 2 * s);
+                if (s + 1 < nstage) knn_stage_fetch(yb, D, M, (s + 1) << srl, srow, RPI, scol, sreg);  // in flight while this stage is evaluated
+                if (act) {
+                    const int start = s ? (int)(incl >> (8 * (s - 1))) & 0xff : 0, end = (int)(incl >> (8 * s)) & 0xff;
+                    const int per = (end - start + 3) >> 2;
+                    const int a0 = start + part * per < end ? start + part * per : end;
+                    const int a1 = a0 + per < end ? a0 + per : end;
+                    for (int p0 = a0; p0 < a1; p0 += 2) {
+                        const bool two = p0 + 1 < a1;
+                        const float *cp0 = stg + (size_t)(qj[p0] - (s << srl)) * RSX;
+                        const float *cp1 = stg + (size_t)(qj[two ? p0 + 1 : p0] - (s << srl)) * RSX;
+                        float s0 = 0.0f, s1 = 0.0f;
+                        if (D == DP) knn_pair_dist<DP, true>(qreg, cp0, cp1, D, s0, s1);
+                        else knn_pair_dist<DP, false>(qreg, cp0, cp1, D, s0, s1);
+                        qd[p0] = __builtin_bit_cast(unsigned int, s0);
+                        if (two) qd[p0 + 1] = __builtin_bit_cast(unsigned int, s1);
+                    }
+                }
+                if (s < 3) KNN_PROBE_MARK(27 + 2 * s);
+            }
+        } else {
+            // D > 64 (the fourth EdgeConv's 128 features): a 128-dimension query row is 128 registers -- with the stage registers
+            // and the pair buffers the kernel spilled 330-380 of them.  The exact phase runs once per column half instead:
+            // dimensions 0..63 of every row are staged and summed first (the partial sum waits in the pair's distance slot),
+            // then 64..D-1 continue it -- the oracle's order; each half is the D = 64 phase (same stage size, same traffic).
+            const int nhalf = D > 64 ? 2 : 1;
+            for (int hf = 0; hf < nhalf; ++hf) {
+                const int hoff = 64 * hf, wdt = hf ? D - 64 : DS;  // this half's first column and width
+                f32x4v qreg[16];
+                {
+                    const float *qrow = xb + (size_t)(act ? qi : 0) * D + hoff;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+                        qreg[t] = 4 * t < wdt ? *reinterpret_cast<const f32x4v *>(qrow + 4 * t) : f32x4v{0.f, 0.f, 0.f, 0.f};
+                }
+                for (int s = 0; s < nstage; ++s) {
+                    if (s || hf) __syncthreads();  // every lane is done with the previous stage
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int row = srow + i * RPI;
+                        if (row < SRW) *reinterpret_cast<f32x4v *>(stg + (size_t)row * RSX + scol) = sreg[i];
+                    }
+                    __syncthreads();
+                    if (s < 3 && hf == 0) KNN_PROBE_MARK(26 + 2 * s);
+                    // the next stage of this half, or the first stage of the second half, in flight while this one is evaluated
+                    // (a half narrower than 64 columns: the pieces beyond it re-read its last piece and are never used)
+                    if (s + 1 < nstage) {
+                        knn_stage_fetch(yb + hoff, D, M, (s + 1) << srl, srow, RPI, scol < wdt ? scol : wdt - 4, sreg);
+                    } else if (hf + 1 < nhalf) {
+                        knn_stage_fetch(yb + 64, D, M, 0, srow, RPI, scol < D - 64 ? scol : D - 68, sreg);
+                    }
+                    if (act) {
+                        const int start = s ? (int)(incl >> (8 * (s - 1))) & 0xff : 0, end = (int)(incl >> (8 * s)) & 0xff;
+                        const int per = (end - start + 3) >> 2;
+                        const int a0 = start + part * per < end ? start + part * per : end;
+                        const int a1 = a0 + per < end ? a0 + per : end;
+                        for (int p0 = a0; p0 < a1; p0 += 2) {
+                            const bool two = p0 + 1 < a1;
+                            const float *cp0 = stg + (size_t)(qj[p0] - (s << srl)) * RSX;
+                            const float *cp1 = stg + (size_t)(qj[two ? p0 + 1 : p0] - (s << srl)) * RSX;
+                            float s0 = hf ? __builtin_bit_cast(float, qd[p0]) : 0.0f;
+                            float s1 = hf && two ? __builtin_bit_cast(float, qd[p0 + 1]) : 0.0f;
+                            if (wdt == 64) knn_pair_dist<64, true>(qreg, cp0, cp1, wdt, s0, s1);
+                            else knn_pair_dist<64, false>(qreg, cp0, cp1, wdt, s0, s1);
+                            qd[p0] = __builtin_bit_cast(unsigned int, s0);
+                            if (two) qd[p0 + 1] = __builtin_bit_cast(unsigned int, s1);
+                        }
+                    }
+                    if (s < 3 && hf == 0) KNN_PROBE_MARK(27 + 2 * s);
                 }
             }
-            if (s < 3) KNN_PROBE_MARK(27 + 2 * s);
         }
     } else if (wave_active && fast) {
         // the oracle's distance of every id.  The query row sits in registers; candidate rows are gathered from L2
         // one full 128-byte line per request (32 dimensions), two candidates in flight
         const float *qrow = xb + (size_t)qi * D;
         if (vec4y && vec4x) {
-            float4 qreg[DP / 4];
+            constexpr int QR = DP > 64 ? 1 : DP / 4;  // D > 64: the query pieces are re-read (L1) with every 32-dimension block
+            float4 qreg[QR];
+            if (DP <= 64) {
 #pragma unroll
-            for (int t = 0; t < DP / 4; ++t)
-                qreg[t] = 4 * t < D ? *reinterpret_cast<const float4 *>(qrow + 4 * t) : float4{0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < QR; ++t)
+                    qreg[t] = 4 * t < D ? *reinterpret_cast<const float4 *>(qrow + 4 * t) : float4{0.f, 0.f, 0.f, 0.f};
+            }
             for (int p0 = mystart; p0 < mystart + mycount; p0 += 2) {
                 const bool two = p0 + 1 < mystart + mycount;
                 const float *cp0 = yb + (size_t)qj[p0] * D;
@@ -2898,17 +2956,18 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
 #pragma unroll
                 for (int d0 = 0; d0 < DP; d0 += 32) {
                     if (d0 < D) {
-                        float4 c0[8], c1[8];
+                        float4 c0[8], c1[8], q8[DP > 64 ? 8 : 1];
 #pragma unroll
                         for (int t = 0; t < 8; ++t)
                             if (d0 + 4 * t < D) {
                                 c0[t] = *reinterpret_cast<const float4 *>(cp0 + d0 + 4 * t);
                                 c1[t] = *reinterpret_cast<const float4 *>(cp1 + d0 + 4 * t);
+                                if (DP > 64) q8[t] = *reinterpret_cast<const float4 *>(qrow + d0 + 4 * t);
                             }
 #pragma unroll
                         for (int t = 0; t < 8; ++t)
                             if (d0 + 4 * t < D) {
-                                const float4 qv = qreg[d0 / 4 + t];
+                                const float4 qv = DP > 64 ? q8[DP > 64 ? t : 0] : qreg[DP > 64 ? 0 : d0 / 4 + t];
                                 float t0 = qv.x - c0[t].x, t1 = qv.y - c0[t].y, t2 = qv.z - c0[t].z, t3 = qv.w - c0[t].w;
                                 s0 = s0 + t0 * t0;
                                 s0 = s0 + t1 * t1;
@@ -3225,13 +3284,14 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     // staged exact phase: candidate rows pass through the tail in stages of 2^srl rows of 4D + 16 bytes (at most 8 stages,
     // at most 8 sweeps of the block per stage; the allocation may grow up to the limit for it).  0 = gather from L2.
     int srl = 0;
-    const int PR = D / 4;
+    const int DS = DP > 64 && D > 64 ? 64 : D;  // staged width of a row: D > 64 goes through in two column halves
+    const int PR = DS / 4;
     const bool stageable = D % 4 == 0 && (kMThreads % PR) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
                            !getenv("FX3D_KNN_GATHER");
     if (stageable) {
         const size_t room = 152 * 1024 - (img * 4 + small);
         for (int l = 8; l >= 5; --l) {
-            const size_t need = ((size_t)1 << l) * ((size_t)D * 4 + 16);
+            const size_t need = ((size_t)1 << l) * ((size_t)DS * 4 + 16);
             if (need <= room && ((size_t)1 << l) * PR <= 8 * (size_t)kMThreads && ((M + (1 << l) - 1) >> l) <= 8) {
                 srl = l;
                 if (img * 4 + small + need > lds) lds = img * 4 + small + need;

@@ -431,7 +431,10 @@ def test_knn_fp16_filter_variants(gpu_fx, oracle, monkeypatch, env):
     (64, 300, 2048, 2, 20, False),   # 8 row stages of 256
     (64, 257, 2047, 1, 20, True),    # ragged last stage (x is not y: N != M)
     (64, 1024, 1024, 9, 20, True),   # the second EdgeConv's shape, B > 8 (clouds share an XCD)
-    (128, 130, 1024, 1, 16, False),  # stages of 128 rows (row = 528 bytes)
+    (128, 130, 1024, 1, 16, False),  # D > 64: two column halves of 64, stages of 256 half rows
+    (128, 1024, 1024, 3, 20, True),  # C4's clouds with 128 features
+    (100, 200, 1500, 2, 20, False),  # second half 36 columns wide
+    (68, 150, 900, 1, 12, True),     # second half: a single 16-byte piece
     (32, 200, 2000, 2, 31, False),
     (16, 100, 700, 1, 7, False),
     (4, 333, 2048, 1, 32, False),    # smallest row (one 16-byte piece)
