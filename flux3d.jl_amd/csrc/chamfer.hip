@@ -61,7 +61,8 @@ struct Nn1Params {
     int tiles;               // max(tiles_x, tiles_y)
     int tiles_x, tiles_y;
     int chunk;               // LDS chunk capacity (multiple of kTile)
-    int tpb;                 // fp16 variant: query-tile passes per block (>1 only for one-chunk clouds)
+    int tpb;                 // fp16 variant: query-tile passes per block (>1 only for one-chunk clouds), x -> y direction
+    int tpb_y;               // ... y -> x direction (clouds of different sizes: the plan balances the two directions' blocks)
     // fused finalisation (fp16 variant): the last block to arrive reduces the partials in fixed order
     unsigned int *ticket;    // library-owned arrival counter, zero between launches; nullptr = no fusion
     unsigned int nvalid;     // number of blocks that deliver a partial
@@ -360,6 +361,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int jq = lane & 31, hh = lane >> 5;
     const int CH = p.chunk;
+    const int tpb = dir ? p.tpb_y : p.tpb;
     h8 *imgp = reinterpret_cast<h8 *>(lds);  // piece (blk, half, row) at (blk*2 + half)*32 + row, 16 B each
     float4 *imgf = reinterpret_cast<float4 *>(lds);
     unsigned long long *wres = reinterpret_cast<unsigned long long *>(lds + 8 * (CH + 64));  // image + 2 pad blocks
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     if (tid == 0) { nfar[0] = 0; nfar[1] = 0; }  // (ordered before their first use by the barrier of the bounding-box pass)
     float qpre[3];  // this lane's query of the coming tile pass (the load's latency hides behind the prologue)
     {
-        const int q0i = (tile * p.tpb) * QB + wv * 32 + jq;
+        const int q0i = (tile * tpb) * QB + wv * 32 + jq;
         const int qc0 = q0i < NQ ? q0i : NQ - 1;
 #pragma unroll
         for (int d = 0; d < 3; ++d) qpre[d] = qb[(size_t)qc0 * 3 + d];
@@ -551,14 +553,14 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         if (tid == 0) nfar[fslot ^ 1] = 0;   // the next chunk's counter (its staging starts behind the barrier at the loop top)
         fslot ^= 1;
         const bool far_ok = nf <= kHFarCap;  // more than the side list holds: this chunk's filter is not used
-        for (int tp = 0; tp < p.tpb; ++tp) {
-            if ((tile * p.tpb + tp) * QB >= NQ) break;  // uniform
+        for (int tp = 0; tp < tpb; ++tp) {
+            if ((tile * tpb + tp) * QB >= NQ) break;  // uniform
             if (j0 == jfirst) {
-                qi = (tile * p.tpb + tp) * QB + wv * 32 + jq;
+                qi = (tile * tpb + tp) * QB + wv * 32 + jq;
 #pragma unroll
                 for (int d = 0; d < 3; ++d) qr[d] = qpre[d];  // requested before the bounding-box pass / during the previous tile pass
-                if (tp + 1 < p.tpb) {                          // the next pass's query: in flight behind this pass
-                    const int qn1 = (tile * p.tpb + tp + 1) * QB + wv * 32 + jq;
+                if (tp + 1 < tpb) {                          // the next pass's query: in flight behind this pass
+                    const int qn1 = (tile * tpb + tp + 1) * QB + wv * 32 + jq;
                     const int qc1 = qn1 < NQ ? qn1 : NQ - 1;
 #pragma unroll
                     for (int d = 0; d < 3; ++d) qpre[d] = qb[(size_t)qc1 * 3 + d];
@@ -1000,7 +1002,7 @@ struct Plan {
     int R, tiles_x, tiles_y, tiles, chunk, grid;
     size_t lds_bytes;
     int variant;  // 0 = exact hot loop (D = 2, and D = 3 under FX3D_NN1_VARIANT=0), 3 = fp16-split MFMA filter + exact re-scan
-    int threads, tpb;
+    int threads, tpb, tpb_y;  // tpb: passes per block of the x -> y direction, tpb_y: of y -> x
     int nsplit;  // fp16 variant: chunk subsets per query tile (multi-chunk clouds with too few blocks)
 };
 
@@ -1024,7 +1026,7 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
     int R = 4;
     while (R > 1 && work / (kThreads * R) < 512) R >>= 1;
     pl.R = R;
-    pl.tpb = 1;
+    pl.tpb = pl.tpb_y = 1;
     const int maxc = N > M ? N : M;
     const int clouds8 = (2 * B + 7) / 8;
     pl.nsplit = 1;
@@ -1071,12 +1073,31 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
         }
     }
     pl.chunk = b_chunk;
-    pl.tpb = b_tpb;
+    pl.tpb = pl.tpb_y = b_tpb;
     pl.nsplit = b_split;
     pl.lds_bytes = (size_t)pl.chunk * 8 * sizeof(float) + kHScratchBytes;
-    const int per_block3 = 512 * pl.tpb;
-    pl.tiles_x = (N + per_block3 - 1) / per_block3;
-    pl.tiles_y = (M + per_block3 - 1) / per_block3;
+    if (N != M && b_split == 1 && maxc <= b_chunk && tpb_env <= 0) {
+        // clouds of different sizes, one chunk each: the direction whose CANDIDATES are the large cloud has few, heavy blocks
+        // (N = 4096 against M = 1024 at B = 32: 32 blocks as long as C2's on 32 CUs while the rest of the chip idles) -- the
+        // passes per block are chosen per direction: t = the slower direction's block, or the chip's throughput if the
+        // blocks of both do not fit at once (same unit costs as above)
+        double bt = 1e30;
+        for (int ta = 1; ta <= 8; ta *= 2)
+            for (int tb = 1; tb <= 8; tb *= 2) {
+                const double blk_a = 2.8 * M / 4096.0 + 5.0 * M / 4096.0 + 0.5 + ta * (9.7 * M / 4096.0 + 0.8);  // x -> y: candidates y
+                const double blk_b = 2.8 * N / 4096.0 + 5.0 * N / 4096.0 + 0.5 + tb * (9.7 * N / 4096.0 + 0.8);  // y -> x: candidates x
+                const double na = (double)B * ((N + 512 * ta - 1) / (512 * ta)), nb = (double)B * ((M + 512 * tb - 1) / (512 * tb));
+                const double thr = (na * blk_a + nb * blk_b) / 256.0;
+                double t = blk_a > blk_b ? blk_a : blk_b;
+                t = t > thr ? t : thr;
+                // the grid has max(tiles) slots per (cloud, direction): more than one round of them delays the heavy direction's blocks
+                const long long tmax = (N + 512 * ta - 1) / (512 * ta) > (M + 512 * tb - 1) / (512 * tb) ? (N + 512 * ta - 1) / (512 * ta) : (M + 512 * tb - 1) / (512 * tb);
+                t += 1.0 * (double)((2ll * B * tmax + 255) / 256 - 1);
+                if (t < bt - 1e-9) { bt = t; pl.tpb = ta; pl.tpb_y = tb; }
+            }
+    }
+    pl.tiles_x = (N + 512 * pl.tpb - 1) / (512 * pl.tpb);
+    pl.tiles_y = (M + 512 * pl.tpb_y - 1) / (512 * pl.tpb_y);
     pl.tiles = pl.tiles_x > pl.tiles_y ? pl.tiles_x : pl.tiles_y;
     pl.grid = clouds8 * 8 * pl.tiles * pl.nsplit;
     if (2 * B < 8) pl.grid = 2 * B * pl.tiles * pl.nsplit;  // plain block order (see kernel)
@@ -1146,7 +1167,7 @@ fx3d_status run_nn1(const float *x, int N, const float *y, int M, int B, int D, 
     p.idx_x = idx_x; p.idx_y = idx_y; p.dmin_x = dmin_x; p.dmin_y = dmin_y;
     p.partials = partials;
     p.tiles = pl.tiles; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.chunk = pl.chunk;
-    p.tpb = pl.tpb;
+    p.tpb = pl.tpb; p.tpb_y = pl.tpb_y;
     const bool want_idx = idx_x || idx_y;
     ProfileScope prof("nn1", st);
     if (D == 3) return want_idx ? launch_small<3, true>(p, pl, st) : launch_small<3, false>(p, pl, st);

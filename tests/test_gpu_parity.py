@@ -1020,6 +1020,15 @@ def test_c4_full_size_knn_properties(gpu_fx, oracle, D):
     assert np.array_equal(idx2.to_host(), gi) and np.array_equal(dist2.to_host(), gd)
 
 
+@pytest.mark.parametrize("N,M,B", [(4096, 1024, 32), (1024, 4096, 9), (513, 4000, 2), (3000, 1000, 5), (4096, 64, 3)])
+def test_chamfer_clouds_of_different_sizes(gpu_fx, oracle, N, M, B):
+    """One-chunk clouds of different sizes: the launch plan picks the query passes per block per DIRECTION (the direction
+    whose candidates are the large cloud gets more, lighter blocks).  Indices and loss against the oracle."""
+    x, y = _rand((3, N, B), N + 3), _rand((3, M, B), M + 4)
+    _check_nn(gpu_fx, oracle, x, y)
+    _check_chamfer(gpu_fx, oracle, x, y)
+
+
 @pytest.mark.parametrize("N,M,B", [(9000, 12000, 1), (5000, 5000, 8), (16384, 700, 2)])
 def test_chamfer_split_plans(gpu_fx, oracle, N, M, B):
     """Few large clouds: the launch plan splits the candidates into balanced chunks taken by different blocks
