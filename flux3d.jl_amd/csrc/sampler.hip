@@ -5,9 +5,9 @@
 // probability vector D2H, builds a Distributions.Categorical alias table and draws with the
 // host RNG (:43-55).  Here the whole batch is three launches, nothing leaves the device:
 //   1. faces_areas_padded (mesh.hip)                         -- gather, HBM/L2 bound
-//   2. face_cdf_kernel: Float64 probabilities (:32-39, incl. the last-padded-column fix-up) and
-//      their CDF, one block per mesh, summed in the order specified in oracle/flux3d_oracle.c
-//      ("blocked" order, chunks of 32) so oracle and device agree bit-for-bit
+//   2. face_cdf_kernel (one block per mesh up to 32 768 faces; five cdf_mb_* launches beyond): Float64 probabilities
+//      (:32-39, incl. the last-padded-column fix-up) and their CDF, summed in the order specified in
+//      oracle/flux3d_oracle.c (a radix-32 tree, every node left to right) so oracle and device agree bit-for-bit
 //   3. sample_kernel: one thread per sample: Philox4x32-10 draw -> binary search in the CDF ->
 //      barycentric point  (w1*v1 + w2*v2) + w3*v3, unfused Float32 (:67-71,:75-82)
 #include <cmath>
@@ -51,46 +51,65 @@ __global__ __launch_bounds__(kThreads) void sample_explicit_kernel(
     }
 }
 
-// One block per mesh.  ws layout per mesh: cdf[Fp] then tc[nchunks]  (doubles), Fp = roundup32.
-// The SUMMATION ORDER is fixed by the specification shared with the oracle (chunks of 32 summed
-// left to right, chunk totals summed left to right); everything order-free (the areas, the Float64 divisions, the
-// final offset add) runs on all threads, the order-bound parts are 32- or nch-long add chains.
-// The face areas are computed in place (compute_faces_areas_padded, src/rep/mesh.jl:799-808: pad faces -> 0).
-//
-// One thread's left-to-right sum of t[0..n) (the specified order); EXCL: t[c] is replaced by the sum of the values
-// before it.  BATCH: t is zero-padded to a multiple of 32 and lives in LDS -- 32 values are loaded, then added: the
-// additions are the dependent chain, the LDS latency is paid once per 32 instead of once per 8 (+0.0 does not change a
-// sum of non-negative terms).
-template <bool EXCL, bool BATCH>
-__device__ __forceinline__ double chain_scan(double *t, int n) {
-    double s = 0.0;
-    if constexpr (BATCH) {
-        for (int c = 0; c < n; c += kChunk) {
-            double v[kChunk];
+// ---- the sampling CDF ------------------------------------------------------------------------------------------------
+// SUMMATION ORDER = the specification shared with the oracle (oracle/flux3d_oracle.c): a radix-32 tree, every node summed
+// left to right -- chunks of 32 faces, groups of 32 chunks, blocks of 32 groups (32 768 faces), groups of 32 blocks, the top.
+// No chain is longer than 32 additions, so every level is one parallel pass; zero padding (+0.0 leaves a sum of non-negative
+// terms unchanged) lets every chain run its full 32 steps, and a level with a single entry equals the level below it.
+// Workspace per mesh (doubles): out[Fp] | E0[nchp] chunk offsets | E1[ngp] group offsets | T2[nbp] | BOFF[nbp] | E2[nbp] |
+// misc[64] (den, fix, the fix-up chunk's probabilities), nch = Fp / 32, ng = ceil(nch / 32), nb = ceil(ng / 32), *p = rounded
+// up to a multiple of 32.  The face areas are computed in place (compute_faces_areas_padded, src/rep/mesh.jl:799-808: pad -> 0).
+constexpr int kCdfBlockFaces = kChunk * kChunk * kChunk;  // faces per level-2 block
+struct CdfWs {
+    int Fp, nch, nchp, ngp, nbp;
+    size_t stride;  // doubles per mesh
+    __host__ __device__ static CdfWs make(int Fmax) {
+        CdfWs w{};
+        w.Fp = (Fmax + kChunk - 1) / kChunk * kChunk;
+        w.nch = w.Fp / kChunk;
+        w.nchp = (w.nch + kChunk - 1) / kChunk * kChunk;
+        const int ng = w.nchp / kChunk, nb = (ng + kChunk - 1) / kChunk;
+        w.ngp = (ng + kChunk - 1) / kChunk * kChunk + kChunk;  // (+ the groups of a last, partly filled 8192-face block)
+        w.nbp = (nb + kChunk - 1) / kChunk * kChunk;
+        w.stride = (size_t)w.Fp + w.nchp + w.ngp + 3 * (size_t)w.nbp + 64;
+        return w;
+    }
+    __host__ __device__ size_t e0() const { return (size_t)Fp; }
+    __host__ __device__ size_t e1() const { return e0() + nchp; }
+    __host__ __device__ size_t t2() const { return e1() + ngp; }
+    __host__ __device__ size_t boff() const { return t2() + nbp; }
+    __host__ __device__ size_t e2() const { return boff() + nbp; }
+    __host__ __device__ size_t misc() const { return e2() + nbp; }
+};
+
+// left-to-right sum of 32 consecutive values (all loads first: the additions are the dependent chain)
+__device__ __forceinline__ double chain32(const double *t) {
+    double v[kChunk], s = 0.0;
 #pragma unroll
-            for (int i = 0; i < kChunk; ++i) v[i] = t[c + i];
+    for (int i = 0; i < kChunk; ++i) v[i] = t[i];
 #pragma unroll
-            for (int i = 0; i < kChunk; ++i) {
-                if (EXCL) t[c + i] = s;
-                s += v[i];
-            }
-        }
-    } else {
-#pragma unroll 8
-        for (int c = 0; c < n; ++c) {
-            const double v = t[c];
-            if (EXCL) t[c] = s;
-            s += v;
-        }
+    for (int i = 0; i < kChunk; ++i) s += v[i];
+    return s;
+}
+// ... and the exclusive prefixes in place; returns the total
+__device__ __forceinline__ double chain32_excl(double *t) {
+    double v[kChunk], s = 0.0;
+#pragma unroll
+    for (int i = 0; i < kChunk; ++i) v[i] = t[i];
+#pragma unroll
+    for (int i = 0; i < kChunk; ++i) {
+        t[i] = s;
+        s += v[i];
     }
     return s;
 }
 
-#ifdef FX3D_CDF_PROBE  // wall-clock stamps (10 ns) of block 0's phases in the unused chunk-total slots of ws (tools/face_cdf_ab.py)
-#define CDF_MARK(i) if (IN_LDS && threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<long long *>(out + Fp)[i] = (long long)wall_clock64()
+#ifdef FX3D_CDF_PROBE  // wall-clock stamps (10 ns) of block 0's phases in the unused tail of the misc slots (tools/face_cdf_ab.py)
+#define CDF_MARK(i) if (threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<long long *>(out + W.misc() + 40)[i] = (long long)wall_clock64()
 #else
 #define CDF_MARK(i)
 #endif
+// One block per mesh of up to 32 768 faces (the fit loop's and C3's meshes), one launch.
 // IN_LDS: the working copy (areas -> probabilities -> prefixes) and the chunk totals live in LDS (latency-bound chains).
 // VLDS (with IN_LDS): the mesh's vertices are staged in LDS first (coalesced loads, in flight together with the face
 // indices: ONE global round trip), the 3 gathers per face read LDS -- the block is alone on its mesh and one CU's
@@ -98,22 +117,22 @@ __device__ __forceinline__ double chain_scan(double *t, int n) {
 template <bool IN_LDS, bool VLDS>
 __global__ __launch_bounds__(kCdfThreads) void face_cdf_kernel(const float *__restrict__ verts_padded, int Vmax,
                                                             const int32_t *__restrict__ faces_padded,
-                                                            const int32_t *__restrict__ faces_len, int Fmax,
-                                                            int Fp, double eps,
+                                                            const int32_t *__restrict__ faces_len, int Fmax, double eps,
                                                             double *__restrict__ ws) {
-    extern __shared__ __attribute__((aligned(16))) double dsm[];  // IN_LDS: work[Fp + nch] + tc[nchp] (+ float4 verts[Vmax])
+    extern __shared__ __attribute__((aligned(16))) double dsm[];  // IN_LDS: work[Fp + nch] + t0[nchp] (+ float4 verts[Vmax])
+    const CdfWs W = CdfWs::make(Fmax);
+    const int Fp = W.Fp, nch = W.nch, nchp = W.nchp, ng = nchp / kChunk;  // ng <= 32 (Fmax <= kCdfBlockFaces)
     const int b = blockIdx.x;
-    const int nch = Fp / kChunk, nchp = (nch + kChunk - 1) / kChunk * kChunk;
     const float *vb = verts_padded + (size_t)b * Vmax * 3;
     const int32_t *fb = faces_padded + (size_t)b * Fmax * 3;
-    double *out = ws + (size_t)b * (Fp + nch);
+    double *out = ws + (size_t)b * W.stride;
     double *cdf = IN_LDS ? dsm : out;
     // LDS copy: one pad double per chunk of 32, so that thread c walking chunk c (stride 33 doubles) and its neighbours
     // hit different banks -- with the plain stride of 256 B all 64 lanes of a wave shared one bank (face_cdf 22.8 -> 18.9 us)
     auto P = [](int k) { return IN_LDS ? k + (k >> 5) : k; };
-    double *tc = IN_LDS ? dsm + Fp + nch : out + Fp;
-    const int nct = IN_LDS ? nchp : nch;  // chunk totals walked by the chains (LDS copy: zero-padded)
+    double *t0 = IN_LDS ? dsm + Fp + nch : out + W.e0();  // chunk totals, then chunk offsets (zero-padded to nchp)
     float4 *vl = reinterpret_cast<float4 *>(dsm + ((Fp + nch + nchp + 1) & ~1));
+    __shared__ double t1[kChunk];  // group totals, then group offsets
     __shared__ double sh[2];
     __shared__ double pF[kChunk];  // probabilities of the chunk that holds the fix-up column, before the fix-up
     CDF_MARK(0);
@@ -176,21 +195,13 @@ __global__ __launch_bounds__(kCdfThreads) void face_cdf_kernel(const float *__re
     }
     __syncthreads();
     CDF_MARK(1);
-    for (int c = threadIdx.x; c < nct; c += kCdfThreads) {  // chunk totals of the areas (all loads first: the additions are the chain)
-        double t = 0.0;
-        if (c < nch) {
-            double v[kChunk];
-#pragma unroll
-            for (int i = 0; i < kChunk; ++i) v[i] = cdf[P(c * kChunk) + i];
-#pragma unroll
-            for (int i = 0; i < kChunk; ++i) t += v[i];
-        }
-        tc[c] = t;
-    }
+    for (int c = threadIdx.x; c < nchp; c += kCdfThreads) t0[c] = c < nch ? chain32(cdf + P(c * kChunk)) : 0.0;  // chunk totals of the areas
     __syncthreads();
     CDF_MARK(2);
+    if (threadIdx.x < kChunk) t1[threadIdx.x] = threadIdx.x < ng ? chain32(t0 + threadIdx.x * kChunk) : 0.0;  // group totals
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const double s = chain_scan<false, IN_LDS>(tc, nct);
+        const double s = chain32(t1);
         sh[0] = s > eps ? s : eps;  // max(sum, eps), :35
     }
     __syncthreads();
@@ -211,15 +222,16 @@ __global__ __launch_bounds__(kCdfThreads) void face_cdf_kernel(const float *__re
             l += v[i];
             cdf[P(c * kChunk) + i] = l;
         }
-        tc[c] = l;
+        t0[c] = l;
     }
     __syncthreads();
     CDF_MARK(5);
+    // chunk offsets inside their group (exclusive, in place) + the group totals; then the same one level up.  The fix-up column
+    // lies in the last chunk (Fp = roundup32(Fmax)): no offset depends on that chunk's own total -- only its local prefixes change.
+    if (threadIdx.x < kChunk) t1[threadIdx.x] = threadIdx.x < ng ? chain32_excl(t0 + threadIdx.x * kChunk) : 0.0;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        // sum of the chunk totals (left to right) and, in the same walk, their exclusive scan in place: the running value
-        // before chunk c IS its offset.  The fix-up column lies in the last chunk (Fp = roundup32(Fmax)), whose offset
-        // does not depend on its own total -- only its local prefixes change.
-        const double sp = chain_scan<true, IN_LDS>(tc, nct);
+        const double sp = chain32_excl(t1);
         const double fix = 1.0 - sp;
         if (fix > 0.0) {  // p[Fmax-1] += fix
             double l = 0.0, v[kChunk];
@@ -234,8 +246,174 @@ __global__ __launch_bounds__(kCdfThreads) void face_cdf_kernel(const float *__re
     }
     __syncthreads();
     CDF_MARK(6);
-    for (int k = threadIdx.x; k < Fmax; k += kCdfThreads) out[k] = tc[k / kChunk] + cdf[P(k)];
+    for (int k = threadIdx.x; k < Fmax; k += kCdfThreads) {
+        const int c = k / kChunk;
+        out[k] = (t1[c / kChunk] + t0[c]) + cdf[P(k)];  // off0 = off1 + e0, cdf = off0 + l
+    }
     CDF_MARK(7);
+}
+
+// ---- meshes beyond 32 768 faces: the same tree over many blocks and five launches (no chain longer than 32, every level a
+//      parallel pass; the one-block kernel above took 1.9 ms for 500 k faces and 8.5 ms for 2 M).  A block of the three
+//      face-parallel kernels takes 8192 faces = 256 chunks = 8 groups; the levels above the groups (<= 1024 level-2 nodes:
+//      33 M faces) belong to one block per mesh. -----------------------------------------------------------------------------
+constexpr int kCdfSub = 8192;                 // faces per block of K1 / K3 / K5
+constexpr int kCdfSubChunks = kCdfSub / kChunk, kCdfSubGroups = kCdfSubChunks / kChunk;
+// K1: areas of the block's faces -> out, chunk totals, group totals -> G (the E1 slots)
+__global__ __launch_bounds__(kCdfThreads) void cdf_mb_areas_kernel(const float *__restrict__ verts_padded, int Vmax,
+                                                                const int32_t *__restrict__ faces_padded,
+                                                                const int32_t *__restrict__ faces_len, int Fmax, double *__restrict__ ws) {
+    const CdfWs W = CdfWs::make(Fmax);
+    const int blk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float *vb = verts_padded + (size_t)b * Vmax * 3;
+    const int32_t *fb = faces_padded + (size_t)b * Fmax * 3;
+    double *out = ws + (size_t)b * W.stride;
+    const int flen = faces_len[b];
+    __shared__ double t0[kCdfSubChunks];
+    const int f0 = blk * kCdfSub;
+    for (int k0 = 0; k0 < kCdfSub; k0 += 4 * kCdfThreads) {  // four faces per thread in flight
+        struct __attribute__((packed, aligned(4))) I3 { int32_t a, b, c; };
+        I3 fi[4];
+        P3 va[4], vb3[4], vc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = f0 + k0 + e * kCdfThreads + tid;
+            fi[e] = *reinterpret_cast<const I3 *>(fb + 3ll * (k < Fmax ? k : 0));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = f0 + k0 + e * kCdfThreads + tid;
+            if (k >= flen) fi[e] = I3{0, 0, 0};
+            va[e] = *reinterpret_cast<const P3 *>(vb + 3ll * fi[e].a);
+            vb3[e] = *reinterpret_cast<const P3 *>(vb + 3ll * fi[e].b);
+            vc[e] = *reinterpret_cast<const P3 *>(vb + 3ll * fi[e].c);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = f0 + k0 + e * kCdfThreads + tid;
+            const float v1[3] = {va[e].x, va[e].y, va[e].z}, v2[3] = {vb3[e].x, vb3[e].y, vb3[e].z}, v3[3] = {vc[e].x, vc[e].y, vc[e].z};
+            if (k < W.Fp) out[k] = (double)(k < flen ? tri_area(v1, v2, v3) : 0.0f);
+        }
+    }
+    __syncthreads();
+    if (tid < kCdfSubChunks) {
+        const int c = blk * kCdfSubChunks + tid;  // this thread's chunk
+        t0[tid] = c < W.nch ? chain32(out + (size_t)c * kChunk) : 0.0;
+    }
+    __syncthreads();
+    if (tid < kCdfSubGroups) out[W.e1() + blk * kCdfSubGroups + tid] = chain32(t0 + tid * kChunk);
+}
+
+// K2 / K4: the levels above the groups, one block per mesh.  G = the group totals (ng of them in the E1 slots).
+// SCAN = false: den = max(total, eps) -> misc[0].  SCAN = true: G becomes the group offsets inside their level-2 node (E1),
+// BOFF[i] = off3[i / 32] + e2[i] the offsets of the level-2 nodes, fix = 1 - total -> misc[1].
+template <bool SCAN>
+__global__ __launch_bounds__(kCdfThreads) void cdf_mb_top_kernel(int Fmax, double eps, double *__restrict__ ws) {
+    const CdfWs W = CdfWs::make(Fmax);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double *out = ws + (size_t)b * W.stride;
+    const int ng = W.nchp / kChunk, nb = (ng + kChunk - 1) / kChunk;  // groups, level-2 nodes (<= 1024)
+    __shared__ double t2[kChunk * kChunk], t3[kChunk];
+    {
+        double v[kChunk], sum = 0.0;
+        double *G = out + W.e1() + (size_t)tid * kChunk;
+#pragma unroll
+        for (int i = 0; i < kChunk; ++i) v[i] = tid < nb && tid * kChunk + i < ng ? G[i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < kChunk; ++i) {
+            if (SCAN && tid < nb && tid * kChunk + i < ng) G[i] = sum;
+            sum += v[i];
+        }
+        t2[tid] = sum;
+    }
+    __syncthreads();
+    if (tid < kChunk) t3[tid] = SCAN ? chain32_excl(t2 + tid * kChunk) : chain32(t2 + tid * kChunk);
+    __syncthreads();
+    if (tid == 0) {
+        if (SCAN) {
+            const double sp = chain32_excl(t3);
+            out[W.misc() + 1] = 1.0 - sp;
+        } else {
+            const double sum = chain32(t3);
+            out[W.misc()] = sum > eps ? sum : eps;  // max(sum, eps), :35
+        }
+    }
+    __syncthreads();
+    if (SCAN && tid < nb) out[W.boff() + tid] = t3[tid / kChunk] + t2[tid];
+}
+
+// K3: probabilities (all threads), chunk-local inclusive prefixes in place, chunk offsets inside their group (E0), group totals (G)
+__global__ __launch_bounds__(kCdfThreads) void cdf_mb_prob_kernel(int Fmax, double *__restrict__ ws) {
+    const CdfWs W = CdfWs::make(Fmax);
+    const int blk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    double *out = ws + (size_t)b * W.stride;
+    const double den = out[W.misc()];
+    const int cF = (Fmax - 1) / kChunk;
+    __shared__ double t0[kCdfSubChunks];
+    const int f0 = blk * kCdfSub;
+#pragma unroll
+    for (int e = 0; e < kCdfSub / kCdfThreads; ++e) {
+        const int k = f0 + e * kCdfThreads + tid;
+        if (k < Fmax) out[k] = out[k] / den;  // (columns past Fmax hold area 0)
+    }
+    __syncthreads();
+    if (tid < kCdfSubChunks) {
+        const int c = blk * kCdfSubChunks + tid;
+        double l = 0.0;
+        if (c < W.nch) {
+            double v[kChunk];
+            double *pc = out + (size_t)c * kChunk;
+#pragma unroll
+            for (int i = 0; i < kChunk; ++i) v[i] = pc[i];
+            if (c == cF) {
+#pragma unroll
+                for (int i = 0; i < kChunk; ++i) out[W.misc() + 2 + i] = v[i];
+            }
+#pragma unroll
+            for (int i = 0; i < kChunk; ++i) {
+                l += v[i];
+                pc[i] = l;
+            }
+        }
+        t0[tid] = l;
+    }
+    __syncthreads();
+    if (tid < kCdfSubGroups) out[W.e1() + blk * kCdfSubGroups + tid] = chain32_excl(t0 + tid * kChunk);
+    __syncthreads();
+    if (tid < kCdfSubChunks && blk * kCdfSubChunks + tid < W.nchp) out[W.e0() + blk * kCdfSubChunks + tid] = t0[tid];
+}
+
+// K5: the fix-up chunk, then cdf = ((BOFF[node] + E1[g]) + E0[c]) + l
+__global__ __launch_bounds__(kCdfThreads) void cdf_mb_final_kernel(int Fmax, double *__restrict__ ws) {
+    const CdfWs W = CdfWs::make(Fmax);
+    const int blk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    double *out = ws + (size_t)b * W.stride;
+    const int cF = (Fmax - 1) / kChunk;
+    if (cF / kCdfSubChunks == blk) {
+        if (tid == 0) {
+            const double fix = out[W.misc() + 1];
+            if (fix > 0.0) {  // p[Fmax-1] += fix: only the last chunk's local prefixes change
+                double l = 0.0, v[kChunk];
+#pragma unroll
+                for (int i = 0; i < kChunk; ++i) v[i] = out[W.misc() + 2 + i];
+#pragma unroll
+                for (int i = 0; i < kChunk; ++i) {
+                    l += v[i] + (cF * kChunk + i == Fmax - 1 ? fix : 0.0);
+                    out[(size_t)cF * kChunk + i] = l;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int f0 = blk * kCdfSub;
+#pragma unroll
+    for (int e = 0; e < kCdfSub / kCdfThreads; ++e) {
+        const int k = f0 + e * kCdfThreads + tid;
+        if (k < Fmax) {
+            const int c = k / kChunk;
+            out[k] = ((out[W.boff() + c / (kChunk * kChunk)] + out[W.e1() + c / kChunk]) + out[W.e0() + c]) + out[k];
+        }
+    }
 }
 
 __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
@@ -255,12 +433,12 @@ __global__ __launch_bounds__(kThreads) void sample_seeded_kernel(
     const uint64_t *__restrict__ seed_dev, const double *__restrict__ ws, float *__restrict__ out,
     int32_t *__restrict__ face_out, float *__restrict__ r1_out, float *__restrict__ r2_out) {
     const long long total = (long long)B * n;
-    const int nch = Fp / kChunk;
+    const size_t cstride = CdfWs::make(Fmax).stride;
     const uint64_t seed = seed_host + (seed_dev ? *seed_dev : 0);  // device part: advanced between replays of a graph
     for (long long k = (long long)blockIdx.x * kThreads + threadIdx.x; k < total;
          k += (long long)gridDim.x * kThreads) {
         const int b = (int)(k / n), sidx = (int)(k % n);
-        const double *cdf = ws + (size_t)b * (Fp + nch);
+        const double *cdf = ws + (size_t)b * cstride;
         const int L = faces_len[b];
         uint32_t c[4] = {(uint32_t)sidx, (uint32_t)b, 0u, 0u};
         philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -312,8 +490,7 @@ int grid_for(long long n) {
 inline int roundup32(int v) { return (v + kChunk - 1) / kChunk * kChunk; }
 
 size_t ws_bytes_needed(int Fmax, int B) {
-    const int Fp = roundup32(Fmax);
-    const size_t cdf = sizeof(double) * (size_t)B * (Fp + Fp / kChunk);
+    const size_t cdf = sizeof(double) * (size_t)B * CdfWs::make(Fmax).stride;
     const size_t areas = sizeof(float) * (size_t)B * Fmax;
     return cdf + ((areas + 15) / 16) * 16;
 }
@@ -353,23 +530,38 @@ fx3d_status fx3d_sample_points_cdf(const float *verts_padded, int32_t Vmax, cons
         return FX3D_ERR_WORKSPACE;
     }
     hipStream_t st = as_stream(s);
-    const int Fp = roundup32(Fmax);
+    const CdfWs W = CdfWs::make(Fmax);
+    const int Fp = W.Fp;
     double *cdf = reinterpret_cast<double *>(ws);
     ProfileScope prof("sample_cdf", st);
-    const size_t cdf_lds = sizeof(double) * (size_t)(Fp + 2 * (Fp / kChunk) + kChunk + 2);  // + one pad per chunk (bank spread), chunk totals padded to 32
+    const char *mb_e = getenv("FX3D_CDF_MULTIBLOCK_FROM");  // (read per call: the tests lower the switch point)
+    const int mb_from = mb_e && atoi(mb_e) > 0 ? atoi(mb_e) : kCdfBlockFaces;
+    if (Fmax > mb_from || Fmax > kCdfBlockFaces) {
+        const int nb = (W.nchp / kChunk + kChunk - 1) / kChunk, nsub = (Fp + kCdfSub - 1) / kCdfSub;
+        FX3D_REQUIRE(nb <= kChunk * kChunk, "fx3d_sample_points_cdf: more than 33 554 432 faces per mesh");
+        FX3D_REQUIRE(B <= 65535, "fx3d_sample_points_cdf: more than 65535 meshes in one batch");
+        hipLaunchKernelGGL(cdf_mb_areas_kernel, dim3(nsub, B), dim3(kCdfThreads), 0, st, verts_padded, Vmax, faces_padded, faces_len, Fmax, cdf);
+        hipLaunchKernelGGL(cdf_mb_top_kernel<false>, dim3(B), dim3(kCdfThreads), 0, st, Fmax, eps, cdf);
+        hipLaunchKernelGGL(cdf_mb_prob_kernel, dim3(nsub, B), dim3(kCdfThreads), 0, st, Fmax, cdf);
+        hipLaunchKernelGGL(cdf_mb_top_kernel<true>, dim3(B), dim3(kCdfThreads), 0, st, Fmax, eps, cdf);
+        hipLaunchKernelGGL(cdf_mb_final_kernel, dim3(nsub, B), dim3(kCdfThreads), 0, st, Fmax, cdf);
+        FX3D_LAUNCH_CHECK();
+        return FX3D_OK;
+    }
+    const size_t cdf_lds = sizeof(double) * (size_t)(Fp + W.nch + W.nchp + 2);  // + one pad per chunk (bank spread), chunk totals padded to 32
     const size_t v_lds = sizeof(float) * 4 * (size_t)Vmax + 16;
     if (cdf_lds <= 60 * 1024 && cdf_lds + v_lds <= 150 * 1024) {
         const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&face_cdf_kernel<true, true>), 150 * 1024,
                                                    "face_cdf_kernel");
         if (arc != FX3D_OK) return arc;
         hipLaunchKernelGGL((face_cdf_kernel<true, true>), dim3(B), dim3(kCdfThreads), cdf_lds + v_lds, st, verts_padded, Vmax,
-                           faces_padded, faces_len, Fmax, Fp, eps, cdf);
+                           faces_padded, faces_len, Fmax, eps, cdf);
     } else if (cdf_lds <= 60 * 1024) {
         hipLaunchKernelGGL((face_cdf_kernel<true, false>), dim3(B), dim3(kCdfThreads), cdf_lds, st, verts_padded, Vmax,
-                           faces_padded, faces_len, Fmax, Fp, eps, cdf);
+                           faces_padded, faces_len, Fmax, eps, cdf);
     } else {
         hipLaunchKernelGGL((face_cdf_kernel<false, false>), dim3(B), dim3(kCdfThreads), 0, st, verts_padded, Vmax,
-                           faces_padded, faces_len, Fmax, Fp, eps, cdf);
+                           faces_padded, faces_len, Fmax, eps, cdf);
     }
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;

@@ -420,31 +420,72 @@ FX_API int fx3d_oracle_faces_areas_padded(const float *verts_padded, int Vmax,
     return 0;
 }
 
-/* Float64 summation order shared with the device sampler ("blocked" order, chunks of 32):
- *   t_c   = (((0.0 + v[32c]) + v[32c+1]) + ... + v[32c+31])        (elements past n count as 0)
- *   total = ((0.0 + t_0) + t_1) + ...
- *   scan[f] = off_c + l[f],  l = running inclusive sum inside chunk c, off_0 = 0.0,
- *             off_{c+1} = off_c + t_c
+/* Float64 summation order shared with the device sampler: a radix-32 tree, every node summed left to right.
+ *   level 0:  t0[c]   = (((0.0 + v[32c]) + v[32c+1]) + ... + v[32c+31])        (elements past n are absent)
+ *   level l:  t_l[g]  = ((0.0 + t_{l-1}[32g]) + t_{l-1}[32g+1]) + ...           until one value is left: the total
+ *   scan[f] = off0[c] + l[f],   l = running inclusive sum inside chunk c = f / 32,
+ *   off_l[i] = off_{l+1}[i / 32] + e_l[i],  e_l[i] = the left-to-right sum of the entries of i's group before i
+ *   (0.0 for the first), and off = e at the top level (one group).  Up to 1024 elements this is the plain "chunks of 32,
+ *   then the chunk totals in order"; beyond, no chain is longer than 32 additions, so a cloud of any size is a few
+ *   parallel passes on the device (round 2: the one-chain version made a 2 M-face mesh an 8 ms kernel).
  * The reference sums with Julia's pairwise `sum` (src/transforms/mesh_func.jl:35-37); any order
  * differs from it by O(1e-16) relative, far below what the Categorical draw can resolve, but the
  * oracle and the kernel must agree bit-for-bit, so the order is part of the specification. */
 #define FX_SCAN_CHUNK 32
-static double blocked_total(const double *v, int n) {
-    double tot = 0.0;
+/* totals of one level: t[g] = left-to-right sum of v[32g .. 32g+31]; returns the number of totals */
+static int level_totals(const double *v, int n, double *t) {
+    int m = 0;
     for (int c0 = 0; c0 < n; c0 += FX_SCAN_CHUNK) {
-        double t = 0.0;
-        for (int k = c0; k < c0 + FX_SCAN_CHUNK && k < n; ++k) t += v[k];
-        tot += t;
+        double s = 0.0;
+        for (int k = c0; k < c0 + FX_SCAN_CHUNK && k < n; ++k) s += v[k];
+        t[m++] = s;
     }
+    return m;
+}
+static double blocked_total(const double *v, int n) {
+    if (n <= 0) return 0.0;
+    double *a = (double *)malloc(sizeof(double) * (size_t)((n + FX_SCAN_CHUNK - 1) / FX_SCAN_CHUNK));
+    double *b2 = (double *)malloc(sizeof(double) * (size_t)((n + FX_SCAN_CHUNK - 1) / FX_SCAN_CHUNK));
+    int m = level_totals(v, n, a);
+    while (m > 1) {
+        m = level_totals(a, m, b2);
+        double *t = a; a = b2; b2 = t;
+    }
+    const double tot = a[0];
+    free(a); free(b2);
     return tot;
 }
-static void blocked_scan(const double *v, int n, double *out) {
-    double off = 0.0;
-    for (int c0 = 0; c0 < n; c0 += FX_SCAN_CHUNK) {
-        double l = 0.0;
-        for (int k = c0; k < c0 + FX_SCAN_CHUNK && k < n; ++k) { l += v[k]; out[k] = off + l; }
-        off += l;
+/* exclusive offsets of the n entries of one level (recursive over the levels above it) */
+static void level_offsets(const double *t, int n, double *off) {
+    int ng = (n + FX_SCAN_CHUNK - 1) / FX_SCAN_CHUNK;
+    double *goff = NULL;
+    if (ng > 1) {
+        double *u = (double *)malloc(sizeof(double) * (size_t)ng);
+        goff = (double *)malloc(sizeof(double) * (size_t)ng);
+        level_totals(t, n, u);
+        level_offsets(u, ng, goff);
+        free(u);
     }
+    for (int g = 0; g < ng; ++g) {
+        double e = 0.0;
+        for (int i = g * FX_SCAN_CHUNK; i < (g + 1) * FX_SCAN_CHUNK && i < n; ++i) {
+            off[i] = goff ? goff[g] + e : e;
+            e += t[i];
+        }
+    }
+    free(goff);
+}
+static void blocked_scan(const double *v, int n, double *out) {
+    if (n <= 0) return;
+    const int nch = (n + FX_SCAN_CHUNK - 1) / FX_SCAN_CHUNK;
+    double *t0 = (double *)malloc(sizeof(double) * (size_t)nch), *off0 = (double *)malloc(sizeof(double) * (size_t)nch);
+    level_totals(v, n, t0);
+    level_offsets(t0, nch, off0);
+    for (int c = 0; c < nch; ++c) {
+        double l = 0.0;
+        for (int k = c * FX_SCAN_CHUNK; k < (c + 1) * FX_SCAN_CHUNK && k < n; ++k) { l += v[k]; out[k] = off0[c] + l; }
+    }
+    free(t0); free(off0);
 }
 
 /* Face probabilities, src/transforms/mesh_func.jl:32-39 (Float64):

@@ -547,34 +547,67 @@ def _grid_mesh(nx, ny, seed, extra_verts=0):
     return np.asfortranarray(v.astype(np.float32)), np.asfortranarray((np.array(f, np.int64).T + 1))
 
 
+def _cdf_stride(Fmax):
+    """Doubles per mesh of the sampler's CDF workspace (csrc/sampler.hip: CdfWs)."""
+    up = lambda v: (v + 31) // 32 * 32  # noqa: E731
+    Fp = up(Fmax)
+    nchp = up(Fp // 32)
+    ng = nchp // 32
+    return Fp + nchp + up(ng) + 32 + 3 * up((ng + 31) // 32) + 64
+
+
+def _tree_offsets(t):
+    """Exclusive offsets of one level of the radix-32 summation tree (oracle/flux3d_oracle.c: level_offsets)."""
+    n = len(t)
+    ng = (n + 31) // 32
+    goff = _tree_offsets(np.array([np.cumsum(t[32 * g:32 * g + 32])[-1] for g in range(ng)])) if ng > 1 else None
+    off = np.zeros(n)
+    for g in range(ng):
+        seg = t[32 * g:32 * g + 32]
+        e = np.concatenate([[0.0], np.cumsum(seg)[:-1]])      # sequential Float64 prefix sums
+        off[32 * g:32 * g + len(seg)] = (goff[g] + e) if goff is not None else e
+    return off
+
+
+def _tree_scan(p):
+    """The specified inclusive scan: chunk-local sequential prefixes + the tree's chunk offsets."""
+    n = len(p)
+    loc = [np.cumsum(p[c0:c0 + 32]) for c0 in range(0, n, 32)]
+    off = _tree_offsets(np.array([l[-1] for l in loc]))
+    return np.concatenate([off[c] + l for c, l in enumerate(loc)])
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["tiny", "two_sweeps", "global_cdf", "verts_not_staged", "ragged"])
-def test_face_cdf_bits_every_kernel_variant(gpu_fx, oracle, case):
+@pytest.mark.parametrize("case", ["tiny", "two_sweeps", "global_cdf", "verts_not_staged", "ragged", "ragged_forced_multiblock",
+                                  "two_blocks", "three_levels_above_the_chunks"])
+def test_face_cdf_bits_every_kernel_variant(gpu_fx, oracle, case, monkeypatch):
     """The sampling CDF itself (not only the draws made from it), bit for bit against the specified order
-    (oracle/flux3d_oracle.c: chunks of 32 left to right, chunk totals left to right), for every face_cdf_kernel
-    variant: one sweep / two sweeps of the area pass, working copy in LDS or in the workspace, vertices staged in
-    LDS or gathered from global memory, a ragged batch (fix-up column outside the shorter meshes)."""
+    (oracle/flux3d_oracle.c: a radix-32 tree, every node summed left to right), for every variant: the one-block kernel
+    (one sweep / two sweeps of the area pass, working copy in LDS or in the workspace, vertices staged in LDS or gathered
+    from global memory, a ragged batch with the fix-up column outside the shorter meshes) and the five-launch path of
+    meshes beyond 32 768 faces (two blocks; 34 blocks: one more level; small meshes forced onto it)."""
     fx = gpu_fx
+    if case == "ragged_forced_multiblock":
+        monkeypatch.setenv("FX3D_CDF_MULTIBLOCK_FROM", "64")
     from flux3d_jl_amd.transforms import EPS, _face_cdf, _verts_padded_dev
     meshes = {"tiny": [_grid_mesh(7, 7, 1)],                             # 98 faces
               "two_sweeps": [_grid_mesh(56, 56, 2)],                     # 6272 faces > 6 x 1024
               "global_cdf": [_grid_mesh(62, 62, 3)],                     # 7688 faces: working copy > 60 KiB of LDS
               "verts_not_staged": [_grid_mesh(50, 50, 4, extra_verts=6000)],   # 8601 vertices: 134 KiB of float4 slots
-              "ragged": [_grid_mesh(30, 30, 5), _grid_mesh(10, 10, 6), _grid_mesh(40, 40, 7)]}[case]
+              "ragged": [_grid_mesh(30, 30, 5), _grid_mesh(10, 10, 6), _grid_mesh(40, 40, 7)],
+              "ragged_forced_multiblock": [_grid_mesh(30, 30, 5), _grid_mesh(10, 10, 6), _grid_mesh(40, 40, 7)],
+              "two_blocks": [_grid_mesh(140, 140, 8)],                   # 39 200 faces
+              "three_levels_above_the_chunks": [_grid_mesh(740, 740, 9)]}[case]   # 1 095 200 faces: 34 blocks
     m = fx.gpu(fx.TriMesh([v for v, _ in meshes], [f for _, f in meshes]))
     ws = _face_cdf(m, _verts_padded_dev(m), m.dev("faces_padded"), EPS)
     Fmax, B = m.F, m.N
-    Fp = (Fmax + 31) // 32 * 32
-    got = ws.to_host().view(np.float64)[:B * (Fp + Fp // 32)].reshape(B, Fp + Fp // 32)[:, :Fmax]
     vp, fp0 = m.get_verts_padded_host(), m.get_faces_padded().astype(np.int64) - 1
     p = oracle.face_probs(oracle.faces_areas_padded(vp, fp0, m._faces_len), EPS)[0]     # (Fmax, B) Float64, fix-up applied
+    want = np.stack([_tree_scan(p[:, b]) for b in range(B)])
+    stride = _cdf_stride(Fmax)
+    got = ws.to_host().view(np.float64)[:B * stride].reshape(B, stride)[:, :Fmax]
     for b in range(B):
-        want, off = np.zeros(Fmax), 0.0
-        for c0 in range(0, Fmax, 32):
-            l = np.cumsum(p[c0:c0 + 32, b])          # sequential Float64 prefix sums of the chunk
-            want[c0:c0 + 32] = off + l
-            off = off + l[-1]
-        assert np.array_equal(got[b], want), (case, b, int(np.argmax(got[b] != want)))
+        assert np.array_equal(got[b], want[b]), (case, b, int(np.argmax(got[b] != want[b])))
     # and the draws made from it
     out, fi, r1, r2 = fx.sample_points(m, 3000, seed=99, return_draws=True)
     eo, efi, er1, er2 = oracle.sample_points_seeded(vp, fp0, m._faces_len, 3000, 99, return_draws=True)

@@ -31,7 +31,9 @@ for name, m in cases.items():
     mn, md = gpu_time(run, reps=40, inner=16)
     print(f"{name}  F={m.F}  min {mn:.2f} us  median {md:.2f} us", flush=True)
     if os.environ.get("FX3D_CDF_PROBE_READ"):  # library built with -DFX3D_CDF_PROBE: wall-clock stamps (10 ns) of block 0
-        Fp = (m.F + 31) // 32 * 32
+        up = lambda v: (v + 31) // 32 * 32  # noqa: E731  (csrc/sampler.hip: CdfWs -- the stamps sit 40 doubles into the misc slots)
+        nchp = up(up(m.F) // 32)
+        Fp = up(m.F) + nchp + up(nchp // 32) + 32 + 3 * up((nchp // 32 + 31) // 32) + 40
         for _ in range(3):
             run()
         fx.synchronize()
