@@ -401,18 +401,19 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_generic_kernel(const float
 //   2. T = the kk-th smallest key VALUE by a most-significant-bit-first search (32 counting sweeps over the LDS keys);
 //   3. every candidate with key <= T ranks itself: #(keys below it) + #(equal keys with a lower index) -- the oracle's
 //      (distance, index) order without a sort -- and writes slot rank - drop if drop <= rank < kk.
-// Cost O(M (32 + kk) / 64) LDS reads per lane and query: a correct general path, not a tuned one (C4 shapes with
-// kk = 100: ~0.3 ms); the tuned kernels keep k + drop <= 32 (matrix cores) and <= 64 (wave kernels).
+//      (the kk survivors are compacted into a list first and ranked among themselves: kk^2 / 64 comparisons per lane)
+// Cost O(M 32 / 64 + kk^2 / 64) LDS reads per lane and query: a correct general path, not a tuned one (C4's shape with
+// kk = 101: 0.2 ms at D = 3, 1.3 ms at D = 64 -- the key evaluation); the tuned kernels keep k + drop <= 32 (matrix cores).
 constexpr int kSelMaxLds = 144 * 1024;
 __global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict__ x, int N, const float *__restrict__ y,
                                                          int M, int B, int D, int k, int drop,
-                                                         int32_t *__restrict__ idx, float *__restrict__ dist, int Mpad) {
+                                                         int32_t *__restrict__ idx, float *__restrict__ dist, int Mpad, int lcap) {
     extern __shared__ __attribute__((aligned(16))) unsigned int selkeys[];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int qi = blockIdx.x * nw + wv;
     if (qi >= N) return;  // wave-uniform; no block-level sync below
-    unsigned int *keys = selkeys + (size_t)wv * Mpad;
+    unsigned int *keys = selkeys + (size_t)wv * (Mpad + 2 * lcap);
     const uint4 *keys4 = reinterpret_cast<const uint4 *>(keys);
     const int kk = k + drop;
     const float *q = x + ((size_t)b * N + qi) * D, *yb = y + (size_t)b * M * D;
@@ -450,6 +451,50 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m, 64);
         if (c < kk) T = trial;
+    }
+    if (lcap >= kk) {
+        // ---- the kk survivors: every key below T (fewer than kk) and, in index order, as many keys equal to T as are still
+        //      missing -- compacted into a (key, index) list; a survivor's rank among the survivors IS its rank among all
+        //      candidates (whatever precedes it in the (distance, index) order survives too).  Ranking against the list costs
+        //      kk^2 / 64 comparisons per lane instead of M kk / 64 (k = 64 at C4's shape: 3.8 ms -> 0.3 ms per call).
+        uint2 *lst = reinterpret_cast<uint2 *>(keys + Mpad);
+        int nless = 0, neq = 0;
+        for (int i = lane; i < n4; i += 64) {
+            const uint4 v = keys4[i];
+            nless += (int)(v.x < T) + (int)(v.y < T) + (int)(v.z < T) + (int)(v.w < T);
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) nless += __shfl_xor(nless, m, 64);
+        const int quota = kk - nless;  // keys equal to T still wanted (>= 1)
+        int S = 0;
+        for (int j0 = 0; j0 < M; j0 += 64) {
+            const int e = j0 + lane;
+            const unsigned int me = e < M ? keys[e] : kNoKey;
+            const bool eq = e < M && me == T;
+            const unsigned long long beq = __ballot(eq);
+            const int eqpos = neq + __builtin_amdgcn_mbcnt_hi((unsigned int)(beq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)beq, 0));
+            const bool take = e < M && (me < T || (eq && eqpos < quota));
+            const unsigned long long bt = __ballot(take);
+            if (take) lst[S + __builtin_amdgcn_mbcnt_hi((unsigned int)(bt >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)bt, 0))] = uint2{me, (unsigned int)e};
+            S += __builtin_popcountll(bt);
+            neq += __builtin_popcountll(beq);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        for (int t0 = 0; t0 < S; t0 += 64) {  // S == kk
+            const int t = t0 + lane;
+            const uint2 mine = lst[t < S ? t : 0];
+            int rank = 0;
+            for (int u = 0; u < S; ++u) {  // every lane reads the same entry: LDS broadcast
+                const uint2 o = lst[u];
+                rank += (int)(o.x < mine.x) | ((int)(o.x == mine.x) & (int)(o.y < mine.y));
+            }
+            if (t < S && rank >= drop && rank < kk) {
+                idx[((size_t)b * N + qi) * k + rank - drop] = (int)mine.y;
+                if (dist) dist[((size_t)b * N + qi) * k + rank - drop] = key_dist(mine.x);
+            }
+        }
+        return;
     }
     // ---- ranks of the candidates at or below T ---------------------------------------------------------------------
     for (int j0 = 0; j0 < M; j0 += 64) {
@@ -3365,7 +3410,20 @@ int knn_select_waves(int M) {
     int w = (int)(kSelMaxLds / per_wave);
     return w > 4 ? 4 : w;
 }
+// ... and the survivor list of a wave (entries; 0: the keys of M candidates leave no room, or kk is so large that ranking
+// against all keys costs less than kk^2 / 64)
+int knn_select_list(int M, int kk, int *nw) {
+    const int Mpad = (M + 255) / 256 * 256, lcap = (kk + 63) / 64 * 64;
+    if (4ll * kk * kk > 3ll * M * M) return 0;  // (kk^2 / 64 x 4 operations against M^2 / 256 x 12 for the ranks over all keys)
+    int w = (int)(kSelMaxLds / ((size_t)(Mpad + 2 * lcap) * 4));
+    if (w < 1) return 0;
+    *nw = w > 4 ? 4 : w;
+    return lcap;
+}
 bool knn_needs_select(int M, int D, int kk) {
+    // (D = 3, 44 < kk <= 64: the wave kernel's candidate list holds 64 - kk entries between merges -- 546 us at kk = 64 and C4's
+    //  shape against 188 us here, 160 against ~185 at kk = 41)
+    if (D == 3 && kk > 44 && kk <= 64 && knn_select_waves(M) >= 1) return true;
     return kk > 64 || (D != 3 && !knn_mfma_eligible(M, D, kk) && knn_wave_generic_lds(D) > 64 * 1024);
 }
 
@@ -3376,12 +3434,13 @@ fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int 
     const bool grid_y = knn_needs_select(M, D, kk) || (D == 3 ? !(kk <= 32 && M >= 64) : !knn_mfma_eligible(M, D, kk));
     FX3D_REQUIRE(!grid_y || B <= 65535, "fx3d_knn: B=%d exceeds the grid's y range for this shape", B);
     if (knn_needs_select(M, D, kk)) {
-        const int nw = knn_select_waves(M);
+        int nw = knn_select_waves(M);
         const int Mpad = (M + 255) / 256 * 256;
+        const int lcap = knn_select_list(M, kk, &nw);
         const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_select_kernel), kSelMaxLds, "knn_select_kernel");
         if (arc != FX3D_OK) return arc;
-        hipLaunchKernelGGL(knn_select_kernel, dim3((N + nw - 1) / nw, B), dim3(64 * nw), (size_t)nw * Mpad * 4, st, x, N, y, M,
-                           B, D, k, drop, idx, dist, Mpad);
+        hipLaunchKernelGGL(knn_select_kernel, dim3((N + nw - 1) / nw, B), dim3(64 * nw), (size_t)nw * (Mpad + 2 * lcap) * 4, st, x, N, y, M,
+                           B, D, k, drop, idx, dist, Mpad, lcap);
         FX3D_LAUNCH_CHECK();
         return FX3D_OK;
     }

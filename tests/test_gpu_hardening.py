@@ -199,6 +199,8 @@ def test_near_ties_feature_space(gpu_fx, oracle):
     (256, 200, 333, 1, 20, False),     # DGCNN's widest feature space (aligned rows)
     (131, 96, 96, 1, 70, True),        # unaligned rows, k + drop > 64
     (3, 100, 9000, 1, 65, False),      # one wave per block (keys of 9000 candidates)
+    (3, 300, 300, 2, 50, True),        # D = 3, 44 < k + drop <= 64: routed here too (the wave kernel's list is short of room)
+    (3, 150, 700, 1, 64, False),       # ... with exact ties (rounded coordinates)
 ])
 def test_knn_general_selection(gpu_fx, oracle, D, N, M, B, k, drop):
     """VERDICT r1 missing #3: k + drop > 64 was rejected and D > ~110 fell off the wave kernel; the reference's
