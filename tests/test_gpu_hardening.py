@@ -581,7 +581,7 @@ def _tree_scan(p):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["tiny", "two_sweeps", "global_cdf", "verts_not_staged", "ragged", "ragged_forced_multiblock",
-                                  "two_blocks", "three_levels_above_the_chunks"])
+                                  "two_blocks", "ragged_multiblock", "three_levels_above_the_chunks"])
 def test_face_cdf_bits_every_kernel_variant(gpu_fx, oracle, case, monkeypatch):
     """The sampling CDF itself (not only the draws made from it), bit for bit against the specified order
     (oracle/flux3d_oracle.c: a radix-32 tree, every node summed left to right), for every variant: the one-block kernel
@@ -599,6 +599,7 @@ def test_face_cdf_bits_every_kernel_variant(gpu_fx, oracle, case, monkeypatch):
               "ragged": [_grid_mesh(30, 30, 5), _grid_mesh(10, 10, 6), _grid_mesh(40, 40, 7)],
               "ragged_forced_multiblock": [_grid_mesh(30, 30, 5), _grid_mesh(10, 10, 6), _grid_mesh(40, 40, 7)],
               "two_blocks": [_grid_mesh(140, 140, 8)],                   # 39 200 faces
+              "ragged_multiblock": [_grid_mesh(20, 20, 10), _grid_mesh(150, 150, 11), _grid_mesh(64, 64, 12)],   # 800 / 45 000 / 8 192 faces
               "three_levels_above_the_chunks": [_grid_mesh(740, 740, 9)]}[case]   # 1 095 200 faces: 34 blocks
     m = fx.gpu(fx.TriMesh([v for v, _ in meshes], [f for _, f in meshes]))
     ws = _face_cdf(m, _verts_padded_dev(m), m.dev("faces_padded"), EPS)
