@@ -234,7 +234,8 @@ FX3D_API fx3d_status fx3d_sample_points(const float *verts_padded, int32_t Vmax,
 /* The two halves of fx3d_sample_points.  The CDF (areas -> Float64 probabilities -> prefix sums, :27-39) depends
  * only on the mesh: a caller keeps it while the vertices do not change (the target mesh of a fitting loop).  The
  * draw (:41-58) uses seed + *seed_dev (seed_dev optional, device memory): a captured graph replays with fresh
- * samples when fx3d_counter_add advances the device part. */
+ * samples when fx3d_counter_add advances the device part.  The CDF is summed in a fixed radix-32 tree order (bit-identical to
+ * oracle/flux3d_oracle.c): one launch for meshes of up to 32 768 faces, five (all blocks of the chip) beyond, Fmax <= 33 554 432. */
 FX3D_API fx3d_status fx3d_sample_points_cdf(const float *verts_padded, int32_t Vmax,
                                             const int32_t *faces_padded, int32_t Fmax,
                                             const int32_t *faces_len, int32_t B, double eps, void *ws,
