@@ -593,7 +593,38 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
         const int nsw = (M - j0 + 63) / 64 < 16 ? (M - j0 + 63) / 64 : 16;
 #pragma unroll
         for (int i = 0; i < 16; ++i) d[i] = kNoKey;
-        if (vec4) {
+        if (vec4 && nsw <= 2) {
+            // a short list (a query's own survivors, <= 128): two candidates per lane, eight 16-byte steps of both rows in
+            // flight -- with one step at a time the D / 4 steps were a chain of L2 round trips (~7 us per query at D = 64)
+            const float *c[2];
+            float sacc[2] = {0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = j0 + lane + 64 * u;
+                const int jc = j < M ? j : M - 1;
+                c[u] = yb + (size_t)(ids ? ids[jc] : jc) * D;
+            }
+#pragma unroll 8
+            for (int dd = 0; dd < D; dd += 4) {
+                const float4 qv = *reinterpret_cast<const float4 *>(q + dd);
+                float4 cv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) cv[u] = *reinterpret_cast<const float4 *>(c[u] + dd);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float t0 = qv.x - cv[u].x, t1 = qv.y - cv[u].y, t2 = qv.z - cv[u].z, t3 = qv.w - cv[u].w;
+                    sacc[u] = sacc[u] + t0 * t0;
+                    sacc[u] = sacc[u] + t1 * t1;
+                    sacc[u] = sacc[u] + t2 * t2;
+                    sacc[u] = sacc[u] + t3 * t3;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                d[u] = j0 + lane + 64 * u < M ? dist_key(sacc[u]) : kNoKey;
+                lmin = lmin < d[u] ? lmin : d[u];
+            }
+        } else if (vec4) {
             // rows as 16-byte pieces, four candidates in flight (dimension order kept: x, y, z, w of every piece)
 #pragma unroll
             for (int i0 = 0; i0 < 16; i0 += 4) {
@@ -606,7 +637,8 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
                     const int jc = j < M ? j : M - 1;
                     c[u] = yb + (size_t)(ids ? ids[jc] : jc) * D;
                 }
-                for (int dd = 0; dd < D; dd += 4) {
+#pragma unroll 2
+                for (int dd = 0; dd < D; dd += 4) {  // (two steps' loads in flight: the loop is a chain of L2 round trips otherwise)
                     const float4 qv = *reinterpret_cast<const float4 *>(q + dd);
                     float4 cv[4];
 #pragma unroll
