@@ -424,7 +424,8 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict
             const float *c = yb + (size_t)j * D;
             float sacc = 0.0f;
             if (vec4) {
-                for (int dd = 0; dd < D; dd += 4) {
+#pragma unroll 8
+                for (int dd = 0; dd < D; dd += 4) {  // (eight 16-byte steps in flight: one at a time the row is a chain of round trips)
                     const float4 qv = *reinterpret_cast<const float4 *>(q + dd), cv = *reinterpret_cast<const float4 *>(c + dd);
                     const float t0 = qv.x - cv.x, t1 = qv.y - cv.y, t2 = qv.z - cv.z, t3 = qv.w - cv.w;
                     sacc = sacc + t0 * t0; sacc = sacc + t1 * t1; sacc = sacc + t2 * t2; sacc = sacc + t3 * t3;
