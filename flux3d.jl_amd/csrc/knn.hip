@@ -280,34 +280,63 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_generic_kernel(const float
         qs4[wv * D + d] = v;
     }
 
+    // staging geometry: D / 4 column groups; kWThreads % (D / 4) == 0 keeps a thread on one group
+    const int pr = D >> 2;
+    const bool vec_stage = (D & 3) == 0 && pr > 0 && kWThreads % pr == 0 && (reinterpret_cast<uintptr_t>(yb) & 15) == 0;
+    const int rows_step = vec_stage ? kWThreads / pr : 1, srow = vec_stage ? tid / pr : 0, scol = vec_stage ? (tid - srow * pr) * 4 : 0;
     for (int j0 = 0; j0 < M; j0 += kGT) {
         const int cntc = (M - j0) < kGT ? (M - j0) : kGT;
         __syncthreads();
-        for (int e = tid; e < cntc * D; e += kWThreads) {  // coalesced: the tile is contiguous in memory
-            const int r = e / D, d = e - r * D;
-            tile[r * RS + d] = yb[(size_t)j0 * D + e];
+        if (vec_stage) {
+            // 16-byte pieces, a thread keeps its column group and walks rows (no division in the loop; four loads in flight)
+            for (int r0 = srow; r0 < cntc; r0 += 4 * rows_step) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + u * rows_step;
+                    v[u] = *reinterpret_cast<const float4 *>(yb + (size_t)(j0 + (r < cntc ? r : cntc - 1)) * D + scol);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + u * rows_step;
+                    if (r < cntc) {
+                        float *t = tile + r * RS + scol;
+                        t[0] = v[u].x; t[1] = v[u].y; t[2] = v[u].z; t[3] = v[u].w;
+                    }
+                }
+            }
+        } else {
+            for (int e = tid; e < cntc * D; e += kWThreads) {  // coalesced: the tile is contiguous in memory
+                const int r = e / D, d = e - r * D;
+                tile[r * RS + d] = yb[(size_t)j0 * D + e];
+            }
         }
         __syncthreads();
         if (q0 < N) {
             // distances of the wave's 4 queries to its 2 tile rows per lane, all dims
             float acc0[kGQ], acc1[kGQ];
-#pragma unroll
-            for (int qq = 0; qq < kGQ; ++qq) { acc0[qq] = 0.0f; acc1[qq] = 0.0f; }
             {
+                // the two rows of a lane as one register pair: difference, square and sum are packed (v_pk_add / v_pk_mul_f32,
+                // each half the plain IEEE operation: same bits, half the instructions)
+                typedef float f32x2v __attribute__((ext_vector_type(2)));
+                f32x2v acc[kGQ];
+#pragma unroll
+                for (int qq = 0; qq < kGQ; ++qq) acc[qq] = f32x2v{0.0f, 0.0f};
                 const float *r0 = tile + lane * RS, *r1 = tile + (lane + 64) * RS;
                 const float4 *qw = qs4 + wv * D;
 #pragma unroll 4
                 for (int d = 0; d < D; ++d) {
                     const float4 qd = qw[d];
-                    const float c0 = r0[d], c1 = r1[d];
+                    const f32x2v c = f32x2v{r0[d], r1[d]};
                     const float qv4[4] = {qd.x, qd.y, qd.z, qd.w};
 #pragma unroll
                     for (int qq = 0; qq < kGQ; ++qq) {
-                        const float t0 = qv4[qq] - c0, t1 = qv4[qq] - c1;
-                        acc0[qq] = acc0[qq] + t0 * t0;
-                        acc1[qq] = acc1[qq] + t1 * t1;
+                        const f32x2v t = f32x2v{qv4[qq], qv4[qq]} - c;
+                        acc[qq] = acc[qq] + t * t;
                     }
                 }
+#pragma unroll
+                for (int qq = 0; qq < kGQ; ++qq) { acc0[qq] = acc[qq].x; acc1[qq] = acc[qq].y; }
             }
 #pragma unroll
             for (int qq = 0; qq < kGQ; ++qq) {

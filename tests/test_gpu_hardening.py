@@ -234,6 +234,10 @@ def test_near_ties_feature_space(gpu_fx, oracle):
     (131, 96, 96, 1, 70, True),        # unaligned rows, k + drop > 64
     (3, 100, 9000, 1, 65, False),      # one wave per block (keys of 9000 candidates)
     (3, 300, 300, 2, 50, True),        # D = 3, 44 < k + drop <= 64: routed here too (the wave kernel's list is short of room)
+    (64, 300, 512, 2, 40, True),       # feature space, 32 < k + drop <= 64: knn_wave_generic_kernel (16-byte staging, packed rows)
+    (16, 200, 300, 1, 63, False),      # ... its 64-key merge (k + drop = 64 has no candidate list)
+    (6, 150, 400, 2, 33, True),        # ... D % 4 != 0: scalar staging
+    (24, 100, 130, 1, 35, False),      # ... a last tile of 2 rows
     (3, 150, 700, 1, 64, False),       # ... with exact ties (rounded coordinates)
 ])
 def test_knn_general_selection(gpu_fx, oracle, D, N, M, B, k, drop):
