@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""kNN at C4's shape (B = 32 x 1024 points, D = 3 and D = 64) over k: where the matrix-core kernels (k + drop <= 32), the wave
+kernels (<= 64) and the general selection kernel take over."""
 import os, sys, numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
 import flux3d_jl_amd as fx

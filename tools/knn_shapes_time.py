@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Self-kNN graphs over a spread of (D, N, B, k) outside the BASELINE configs: per-call device time and pairs per second --
+a check for launch-plan cliffs (few clouds with many rows, wide features)."""
 import os, sys, numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
 import flux3d_jl_amd as fx
