@@ -65,6 +65,8 @@ SIGNATURES = {
                          vp, vp, vp, sz, vp],
     "fx3d_chamfer_bwd": [vp, c_i32, vp, c_i32, c_i32, c_i32, vp, vp, c_f32, c_f32, c_f32, c_i64,
                          vp, vp, vp],
+    "fx3d_chamfer_sampled_bwd": [vp, c_i32, vp, c_i32, c_i32, vp, vp, c_f32, c_f32, c_f32, c_i64,
+                                 vp, c_i32, c_i32, vp, vp, vp, vp, vp, c_i32, c_i32, vp, vp, vp, vp, c_i32, vp],
     "fx3d_knn": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, vp, vp],
     "fx3d_knn_workspace_bytes": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, C.POINTER(sz)],
     "fx3d_knn_ws": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, sz, vp],

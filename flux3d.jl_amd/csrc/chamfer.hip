@@ -1432,6 +1432,62 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_lds_kernel(
     __syncthreads();
     for (int e = threadIdx.x; e < (r1 - r0) * D; e += kBwdThreads) g[(size_t)r0 * D + e] = acc[e];
 }
+
+// Adjoint of chamfer_distance(sample_points(m_x), sample_points(m_y)) w.r.t. the meshes' vertices in one launch: the gradient
+// w.r.t. the sampled points is accumulated in LDS exactly as in chamfer_bwd_lds_kernel (D = 3), then every row is scattered onto
+// the three vertices of its sampled face with the barycentric weights of the draw (sample_bwd_kernel's arithmetic) instead
+// of being written out.  A side without a mesh gradient (gverts == nullptr) is skipped.
+struct SampledSide {
+    const int32_t *faces;     // (3, Fmax, B) mesh-local
+    const int32_t *face_idx;  // (n, B) the draws
+    const float *r1, *r2;
+    float *gverts;            // (3, Vmax, B), added to
+    int Vmax, Fmax;
+};
+__global__ __launch_bounds__(kBwdThreads) void chamfer_sampled_bwd_kernel(
+    const float *__restrict__ x, int N, const float *__restrict__ y, int M, const int32_t *__restrict__ idx_x,
+    const int32_t *__restrict__ idx_y, float ca, float cb, SampledSide sx, SampledSide sy, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];  // [rows of this block][3]
+    const int part = blockIdx.x % nsplit, bs = blockIdx.x / nsplit;
+    const int b = bs >> 1, side = bs & 1;
+    const SampledSide &S = side ? sy : sx;
+    if (!S.gverts) return;
+    const float *own = (side ? y : x) + (size_t)b * (side ? M : N) * 3;
+    const float *oth = (side ? x : y) + (size_t)b * (side ? N : M) * 3;
+    const int32_t *idx_own = (side ? idx_y : idx_x) + (size_t)b * (side ? M : N);
+    const int32_t *idx_oth = (side ? idx_x : idx_y) + (size_t)b * (side ? N : M);
+    const int R = side ? M : N, Sn = side ? N : M;
+    const float c_own = side ? cb : ca, c_oth = side ? ca : cb;
+    const int per = (R + nsplit - 1) / nsplit;
+    const int r0 = part * per < R ? part * per : R, r1 = r0 + per < R ? r0 + per : R;
+    for (int e = threadIdx.x; e < (r1 - r0) * 3; e += kBwdThreads) {
+        const int i = r0 + e / 3, d = e % 3;
+        acc[e] = c_own * (own[(size_t)i * 3 + d] - oth[(size_t)idx_own[i] * 3 + d]);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < Sn; j += kBwdThreads) {
+        const int i = idx_oth[j];
+        if (i >= r0 && i < r1)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float t = c_oth * (oth[(size_t)j * 3 + d] - own[(size_t)i * 3 + d]);
+                atomicAdd(&acc[(size_t)(i - r0) * 3 + d], -t);
+            }
+    }
+    __syncthreads();
+    float *gb = S.gverts + (size_t)b * S.Vmax * 3;
+    for (int i = r0 + threadIdx.x; i < r1; i += kBwdThreads) {  // row i = sample i of mesh b
+        const size_t k = (size_t)b * R + i;
+        const int32_t *fc = S.faces + ((size_t)b * S.Fmax + S.face_idx[k]) * 3;
+        const float u = sqrtf(S.r1[k]), v = S.r2[k];
+        const float w[3] = {1.0f - u, u * (1.0f - v), u * v};
+        const float *g = acc + (size_t)(i - r0) * 3;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) atomicAdd(&gb[3ll * fc[t] + d], w[t] * g[d]);
+    }
+}
 }  // namespace
 
 extern "C" {
@@ -1475,6 +1531,44 @@ fx3d_status fx3d_chamfer_bwd(const float *x, int32_t N, const float *y, int32_t 
         hipLaunchKernelGGL(chamfer_bwd_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0, st, x, N, y, M,
                            B, D, idx_x, idx_y, ca, cb, gx, gy);
     }
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_chamfer_sampled_bwd(const float *x, int32_t N, const float *y, int32_t M, int32_t B, const int32_t *idx_x,
+                                     const int32_t *idx_y, float w1, float w2, float gout, int64_t B_global,
+                                     const int32_t *faces_x, int32_t Vmax_x, int32_t Fmax_x, const int32_t *face_idx_x,
+                                     const float *r1_x, const float *r2_x, float *gverts_x, const int32_t *faces_y,
+                                     int32_t Vmax_y, int32_t Fmax_y, const int32_t *face_idx_y, const float *r1_y,
+                                     const float *r2_y, float *gverts_y, int32_t accumulate, fx3d_stream_t s) {
+    fx3d_status rc = check_shapes("fx3d_chamfer_sampled_bwd", x, N, y, M, B, 3);
+    if (rc) return rc;
+    FX3D_REQUIRE(idx_x && idx_y, "fx3d_chamfer_sampled_bwd: null index array");
+    FX3D_REQUIRE(gverts_x || gverts_y, "fx3d_chamfer_sampled_bwd: no gradient requested");
+    FX3D_REQUIRE(!gverts_x || (faces_x && face_idx_x && r1_x && r2_x && Vmax_x > 0 && Fmax_x > 0), "fx3d_chamfer_sampled_bwd: incomplete mesh of x");
+    FX3D_REQUIRE(!gverts_y || (faces_y && face_idx_y && r1_y && r2_y && Vmax_y > 0 && Fmax_y > 0), "fx3d_chamfer_sampled_bwd: incomplete mesh of y");
+    FX3D_REQUIRE(B_global >= B, "fx3d_chamfer_sampled_bwd: B_global < B");
+    hipStream_t st = as_stream(s);
+    if (!accumulate) {
+        if (gverts_x) FX3D_HIP(hipMemsetAsync(gverts_x, 0, sizeof(float) * 3 * (size_t)Vmax_x * B, st));
+        if (gverts_y) FX3D_HIP(hipMemsetAsync(gverts_y, 0, sizeof(float) * 3 * (size_t)Vmax_y * B, st));
+    }
+    const float ca = gout * w1 * (float)(6.0 / (3.0 * N * (double)B_global));
+    const float cb = gout * w2 * (float)(6.0 / (3.0 * M * (double)B_global));
+    const int maxr = N > M ? N : M;
+    int nsplit = 512 / (2 * B);  // as fx3d_chamfer_bwd: ~2 blocks per CU, a block never owns fewer than 256 rows nor more than fit in LDS
+    if (nsplit > maxr / 256) nsplit = maxr / 256;
+    if (nsplit < 1) nsplit = 1;
+    while ((size_t)((maxr + nsplit - 1) / nsplit) * 3 * sizeof(float) > 144 * 1024) ++nsplit;
+    const size_t lds = sizeof(float) * (size_t)((maxr + nsplit - 1) / nsplit) * 3;
+    FX3D_REQUIRE((long long)2 * B * nsplit < (1ll << 30), "fx3d_chamfer_sampled_bwd: batch too large");
+    const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&chamfer_sampled_bwd_kernel), 144 * 1024,
+                                               "chamfer_sampled_bwd_kernel");
+    if (arc != FX3D_OK) return arc;
+    const SampledSide sx{faces_x, face_idx_x, r1_x, r2_x, gverts_x, Vmax_x, Fmax_x}, sy{faces_y, face_idx_y, r1_y, r2_y, gverts_y, Vmax_y, Fmax_y};
+    ProfileScope prof("chamfer_sampled_bwd", st);
+    hipLaunchKernelGGL(chamfer_sampled_bwd_kernel, dim3(2 * B * nsplit), dim3(kBwdThreads), lds, st, x, N, y, M, idx_x, idx_y, ca, cb, sx,
+                       sy, nsplit);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib
 from .device import DeviceArray, Graph, Stream, current_stream, stream
-from .metrics import _chamfer_points, chamfer_distance_grad, mesh_losses, mesh_losses_grad
+from .metrics import _chamfer_points, chamfer_distance_grad, chamfer_sampled_grad, mesh_losses, mesh_losses_grad
 from .transforms import lincomb, offset, sample_points, sample_points_grad
 
 
@@ -35,13 +35,14 @@ def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_la
         _, _, loss = mesh_losses(m, 0.0, w_lap, w_edge, base=loss1, sync=False)
     if not with_grad:
         return loss
-    gA, _ = chamfer_distance_grad(A, Bp, ix, iy)
     if m.N == 1:
         # one mesh: padded == packed.  Both mesh-loss adjoints in ONE gather launch (no float atomics, reusing the forward's
-        # unit rows) WRITE the buffer, the sampling adjoint scatter-adds on top: no memset node in the iteration
+        # unit rows) WRITE the buffer; the chamfer adjoint and the sampling adjoint are ONE launch that scatter-adds on top
+        # (the target's half of the chamfer adjoint is not needed and not computed): no memset node in the iteration
         g = mesh_losses_grad(m, 0.0, w_lap, w_edge, reuse_forward=True)
-        sample_points_grad(m, fa, r1, r2, gA, out=g.reshape(3, m.V, 1))
+        chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=m, draws_a=(fa, r1, r2), out_a=g.reshape(3, m.V, 1))
         return loss, g
+    gA, _ = chamfer_distance_grad(A, Bp, ix, iy)
     gpad = sample_points_grad(m, fa, r1, r2, gA)           # (3,Vmax,B), zeroed + scatter-added
     g = m.padded_to_packed_dev(gpad)                        # adjoint of _packed_to_padded
     mesh_losses_grad(m, 0.0, w_lap, w_edge, out=g, reuse_forward=True)
@@ -72,7 +73,7 @@ class Momentum:
 
 class FitStepGraph:
     """One iteration of the fit_mesh loop (examples/fit_mesh.jl:98-110: loss, gradient, Momentum update) captured
-    as a hipGraph: ten launch-bound kernels (no memset, no copy) replayed with one launch per iteration.
+    as a hipGraph: nine launch-bound kernels (no memset, no copy) replayed with one launch per iteration.
 
     The sampling seeds recorded in the graph are ``seed`` and ``seed + 1`` plus a device counter that the graph
     itself advances by two per replay, so every iteration draws fresh samples (the reference draws from the global

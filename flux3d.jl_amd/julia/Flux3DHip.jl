@@ -327,6 +327,26 @@ Zygote.@adjoint function _chamfer_distance(A::HipArray{Float32,3}, B::HipArray{F
     return loss, back
 end
 
+# adjoint of chamfer_distance(m1::TriMesh, m2::TriMesh, n) (src/metrics/mesh.jl:34-44) w.r.t. the padded vertices of m1 and / or
+# m2 in one launch: A / B = the forward's samples, ix / iy its neighbour indices, draws_* = (face, r1, r2) of the sampler.
+# `nothing` for a mesh skips its side.  Returns (gverts1, gverts2), each (3, V, N) or nothing.
+function chamfer_sampled_grad(A::HipArray{Float32,3}, B::HipArray{Float32,3}, ix::HipArray{Int32,2}, iy::HipArray{Int32,2},
+                              m1, draws1, m2, draws2; w1::Number = 1.0, w2::Number = 1.0, gout::Number = 1)
+    _, N, Bn = size(A); _, M, _ = size(B)
+    side(m, d) = m === nothing ? (C_NULL, Int32(0), Int32(0), C_NULL, C_NULL, C_NULL, nothing) :
+        (faces_padded_dev(m).ptr, Int32(m.V), Int32(m.F), d[1].ptr, d[2].ptr, d[3].ptr, HipArray{Float32}(undef, 3, m.V, m.N))
+    f1, V1, F1, fi1, ra1, rb1, g1 = side(m1, draws1)
+    f2, V2, F2, fi2, ra2, rb2, g2 = side(m2, draws2)
+    check(@ccall LIB.fx3d_chamfer_sampled_bwd(A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32, Bn::Int32,
+                                              ix.ptr::Ptr{Cvoid}, iy.ptr::Ptr{Cvoid}, Float32(w1)::Float32, Float32(w2)::Float32,
+                                              Float32(gout)::Float32, Bn::Int64, f1::Ptr{Cvoid}, V1::Int32, F1::Int32,
+                                              fi1::Ptr{Cvoid}, ra1::Ptr{Cvoid}, rb1::Ptr{Cvoid},
+                                              (g1 === nothing ? C_NULL : g1.ptr)::Ptr{Cvoid}, f2::Ptr{Cvoid}, V2::Int32, F2::Int32,
+                                              fi2::Ptr{Cvoid}, ra2::Ptr{Cvoid}, rb2::Ptr{Cvoid},
+                                              (g2 === nothing ? C_NULL : g2.ptr)::Ptr{Cvoid}, 0::Int32, DEFAULT_STREAM::Stream)::Int32)
+    return g1, g2
+end
+
 # ---- k-NN graph: replaces CreateSingleKNNGraph + the per-batch loop (src/models/dgcnn.jl:3-7,36) --
 function knn_graph(X::HipArray{Float32,3}, K::Int)
     F, N, B = size(X)

@@ -107,6 +107,34 @@ def chamfer_distance_grad(A, B, idx_a, idx_b, w1=1.0, w2=1.0, gout=1.0, B_global
     return gx, gy
 
 
+def chamfer_sampled_grad(A, B, idx_a, idx_b, mesh_a=None, draws_a=None, mesh_b=None, draws_b=None, w1=1.0, w2=1.0,
+                         gout=1.0, B_global=None, out_a=None, out_b=None):
+    """Adjoint of ``chamfer_distance(m_a::TriMesh, m_b::TriMesh, n)`` (src/metrics/mesh.jl:34-44) w.r.t. the padded vertices of
+    ``mesh_a`` and / or ``mesh_b`` in ONE launch (fx3d_chamfer_sampled_bwd): ``A`` / ``B`` are the sampled clouds of the forward,
+    ``draws_*`` = (face_idx, r1, r2) of :func:`sample_points` (``return_draws=True``), ``idx_*`` the forward's neighbour indices.
+    A mesh that is None is skipped.  ``out_*``: (3,Vmax,B) device arrays the gradient is ADDED to (default: fresh, zeroed).
+    Returns (g_a, g_b) (None for a skipped side)."""
+    x, y = _as_dev_points(A), _as_dev_points(B)
+    D, N, M, Bn = _check_pair(x, y)
+    if D != 3:
+        raise ValueError("chamfer_sampled_grad: sampled clouds are (3, n, B)")
+    if (out_a is None) != (out_b is None) and mesh_a is not None and mesh_b is not None:
+        raise ValueError("chamfer_sampled_grad: pass both out arrays or neither")
+    accumulate = (out_a is not None) or (out_b is not None)
+
+    def side(m, draws, out):
+        if m is None:
+            return [None, 0, 0, None, None, None, None], None
+        fi, r1, r2 = draws
+        g = out if out is not None else DeviceArray.empty((3, m.V, m.N), np.float32)
+        return [m.dev("faces_padded").ptr, m.V, m.F, fi.ptr, r1.ptr, r2.ptr, g.ptr], g
+    sa, ga = side(mesh_a, draws_a, out_a)
+    sb, gb = side(mesh_b, draws_b, out_b)
+    _lib.call("fx3d_chamfer_sampled_bwd", x.ptr, N, y.ptr, M, Bn, idx_a.ptr, idx_b.ptr, float(w1), float(w2), float(gout),
+              int(B_global or Bn), *sa, *sb, int(accumulate), current_stream().handle)
+    return ga, gb
+
+
 def _mesh_ws(count):
     n = C.c_size_t(0)
     _lib.call("fx3d_mesh_loss_workspace_bytes", int(count), C.byref(n))

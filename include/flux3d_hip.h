@@ -152,6 +152,20 @@ FX3D_API fx3d_status fx3d_chamfer_bwd(const float *x, int32_t N, const float *y,
                                       const int32_t *idx_y, float w1, float w2, float gout,
                                       int64_t B_global, float *gx, float *gy, fx3d_stream_t s);
 
+/* Adjoint of chamfer_distance(m_x::TriMesh, m_y::TriMesh, n) (src/metrics/mesh.jl:34-44: both meshes sampled, then
+ * _chamfer_distance) w.r.t. the PADDED VERTICES of either mesh, for the forward's draws and nearest-neighbour indices, in one
+ * launch: fx3d_chamfer_bwd's gradient w.r.t. the sampled points (D = 3) is scattered onto the three vertices of every sampled
+ * face with the barycentric weights of its draw (fx3d_sample_points_bwd) instead of being written out.  x (3,N,B) / y (3,M,B):
+ * the samples; face_idx_*, r1_*, r2_* (n,B): their draws (n = N resp. M); gverts_* (3,Vmax_*,B).  A side whose gverts is NULL is
+ * skipped (a fitting loop differentiates w.r.t. the source mesh only).  accumulate = 0 zeroes gverts first. */
+FX3D_API fx3d_status fx3d_chamfer_sampled_bwd(const float *x, int32_t N, const float *y, int32_t M, int32_t B,
+                                              const int32_t *idx_x, const int32_t *idx_y, float w1, float w2, float gout,
+                                              int64_t B_global, const int32_t *faces_x, int32_t Vmax_x, int32_t Fmax_x,
+                                              const int32_t *face_idx_x, const float *r1_x, const float *r2_x,
+                                              float *gverts_x, const int32_t *faces_y, int32_t Vmax_y, int32_t Fmax_y,
+                                              const int32_t *face_idx_y, const float *r1_y, const float *r2_y,
+                                              float *gverts_y, int32_t accumulate, fx3d_stream_t s);
+
 /* ---- k-NN graph (src/models/dgcnn.jl:3-7,36) ---------------------------------------------------
  * knn(KDTree(y), x, k+drop_first, true)[1][1+drop_first:end] for every point of every batch
  * element: idx:(k,N,B) int32 0-based sorted by (distance, index); dist:(k,N,B) squared distances

@@ -768,6 +768,31 @@ def test_fit_step_graph_matches_eager_loop(gpu_fx):
     assert not any(isinstance(k, tuple) and k[0] == "face_cdf" for k in tgt._dev)
 
 
+def test_chamfer_sampled_adjoint_in_one_launch(gpu_fx, oracle):
+    """fx3d_chamfer_sampled_bwd = fx3d_chamfer_bwd followed by fx3d_sample_points_bwd (the pullback of
+    chamfer_distance(m1::TriMesh, m2::TriMesh, n), src/metrics/mesh.jl:34-44): both meshes, one mesh only, added onto an
+    existing buffer; ragged batch.  (Float atomics on both paths: equal up to their order.)"""
+    fx = gpu_fx
+    ma, mb = fx.gpu(_teapot_sphere(fx)), fx.gpu(fx.load_trimesh(os.path.join(GOLDEN, "sphere.obj"), os.path.join(GOLDEN, "teapot.obj")))
+    n = 3000
+    A, fa, ra1, ra2 = fx.sample_points(ma, n, seed=11, return_draws=True)
+    Bp, fb, rb1, rb2 = fx.sample_points(mb, n, seed=12, return_draws=True)
+    loss, ix, iy = fx.chamfer_distance(A, Bp, w1=0.7, w2=1.3, return_indices=True)
+    gA, gB = fx.chamfer_distance_grad(A, Bp, ix, iy, w1=0.7, w2=1.3, gout=2.0)
+    ref_a = fx.sample_points_grad(ma, fa, ra1, ra2, gA).to_host()
+    ref_b = fx.sample_points_grad(mb, fb, rb1, rb2, gB).to_host()
+    # against the oracle's chain as well
+    oga, ogb = oracle.chamfer_bwd(A.to_host(), Bp.to_host(), ix.to_host(), iy.to_host(), 0.7, 1.3, 2.0)
+    assert np.allclose(gA.to_host(), oga, rtol=1e-5, atol=1e-9)
+    ga, gb = fx.chamfer_sampled_grad(A, Bp, ix, iy, ma, (fa, ra1, ra2), mb, (fb, rb1, rb2), w1=0.7, w2=1.3, gout=2.0)
+    assert np.allclose(ga.to_host(), ref_a, rtol=2e-4, atol=1e-8) and np.allclose(gb.to_host(), ref_b, rtol=2e-4, atol=1e-8)
+    ga1, none = fx.chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=ma, draws_a=(fa, ra1, ra2), w1=0.7, w2=1.3, gout=2.0)
+    assert none is None and np.allclose(ga1.to_host(), ref_a, rtol=2e-4, atol=1e-8)
+    base = fx.gpu(np.asfortranarray(np.full(ref_b.shape, 0.25, np.float32)))
+    _, gb2 = fx.chamfer_sampled_grad(A, Bp, ix, iy, mesh_b=mb, draws_b=(fb, rb1, rb2), w1=0.7, w2=1.3, gout=2.0, out_b=base)
+    assert gb2 is base and np.allclose(base.to_host(), ref_b + 0.25, rtol=2e-4, atol=1e-7)
+
+
 def test_graph_capture_with_a_forked_stream_releases_without_synchronising(gpu_fx):
     """A capture that forks onto a second stream (ordering-only events) and releases an array allocated under that
     stream while the origin stream is current: the pool must not synchronise (a synchronised capturing stream
