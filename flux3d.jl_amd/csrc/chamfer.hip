@@ -1460,32 +1460,56 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_sampled_bwd_kernel(
     const float c_own = side ? cb : ca, c_oth = side ? ca : cb;
     const int per = (R + nsplit - 1) / nsplit;
     const int r0 = part * per < R ? part * per : R, r1 = r0 + per < R ? r0 + per : R;
+    // the kernel is a chain of dependent round trips (index -> row, draw -> face -> vertices): what does not depend on the
+    // LDS phases is requested first -- the first sweep of the scan's indices and this thread's first epilogue row
+    const int j_first = threadIdx.x < Sn ? idx_oth[threadIdx.x] : -1;
+    const int iE = r0 + threadIdx.x;
+    const size_t kE = (size_t)b * R + (iE < r1 ? iE : (r0 < R ? r0 : 0));
+    const int32_t *fcE = S.faces + ((size_t)b * S.Fmax + S.face_idx[kE]) * 3;
+    const int fE[3] = {fcE[0], fcE[1], fcE[2]};
+    const float r1E = S.r1[kE], r2E = S.r2[kE];
     for (int e = threadIdx.x; e < (r1 - r0) * 3; e += kBwdThreads) {
         const int i = r0 + e / 3, d = e % 3;
         acc[e] = c_own * (own[(size_t)i * 3 + d] - oth[(size_t)idx_own[i] * 3 + d]);
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < Sn; j += kBwdThreads) {
-        const int i = idx_oth[j];
-        if (i >= r0 && i < r1)
+    for (int j0 = threadIdx.x; j0 < Sn; j0 += 4 * kBwdThreads) {  // four sweeps' indices in flight, then the hits' rows
+        int ii[4];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const float t = c_oth * (oth[(size_t)j * 3 + d] - own[(size_t)i * 3 + d]);
-                atomicAdd(&acc[(size_t)(i - r0) * 3 + d], -t);
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * kBwdThreads;
+            ii[u] = j < Sn ? (j == (int)threadIdx.x ? j_first : idx_oth[j]) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * kBwdThreads, i = ii[u];
+            if (i >= r0 && i < r1) {
+                const P3 o = *reinterpret_cast<const P3 *>(oth + (size_t)j * 3), w = *reinterpret_cast<const P3 *>(own + (size_t)i * 3);
+                float *a = acc + (size_t)(i - r0) * 3;
+                atomicAdd(a + 0, -(c_oth * (o.x - w.x)));
+                atomicAdd(a + 1, -(c_oth * (o.y - w.y)));
+                atomicAdd(a + 2, -(c_oth * (o.z - w.z)));
             }
+        }
     }
     __syncthreads();
     float *gb = S.gverts + (size_t)b * S.Vmax * 3;
-    for (int i = r0 + threadIdx.x; i < r1; i += kBwdThreads) {  // row i = sample i of mesh b
+    for (int i = iE; i < r1; i += kBwdThreads) {  // row i = sample i of mesh b
         const size_t k = (size_t)b * R + i;
-        const int32_t *fc = S.faces + ((size_t)b * S.Fmax + S.face_idx[k]) * 3;
-        const float u = sqrtf(S.r1[k]), v = S.r2[k];
+        int f3[3] = {fE[0], fE[1], fE[2]};
+        float a1 = r1E, a2 = r2E;
+        if (i != iE) {  // (blocks of more than 1024 rows)
+            const int32_t *fc = S.faces + ((size_t)b * S.Fmax + S.face_idx[k]) * 3;
+            f3[0] = fc[0]; f3[1] = fc[1]; f3[2] = fc[2];
+            a1 = S.r1[k]; a2 = S.r2[k];
+        }
+        const float u = sqrtf(a1), v = a2;
         const float w[3] = {1.0f - u, u * (1.0f - v), u * v};
         const float *g = acc + (size_t)(i - r0) * 3;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int d = 0; d < 3; ++d) atomicAdd(&gb[3ll * fc[t] + d], w[t] * g[d]);
+            for (int d = 0; d < 3; ++d) atomicAdd(&gb[3ll * f3[t] + d], w[t] * g[d]);
     }
 }
 }  // namespace
