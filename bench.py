@@ -398,6 +398,9 @@ def config_one_liners(fx):
     a = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_A, 3, 1024, 2))
     b = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_B, 3, 1024, 2))
     out["C1 chamfer fwd B=2 N=M=1024"] = _per_call_ms(fx, lambda: fx.chamfer_distance(a, b, loss_out=loss_dev, sync=False))
+    a5 = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_A, 3, 1024, 32))  # C5 "also report 1024" (one rank's 32-cloud shard)
+    b5 = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_B, 3, 1024, 32))
+    out["C5 shard at N=M=1024: chamfer fwd B=32 per GPU"] = _per_call_ms(fx, lambda: fx.chamfer_distance(a5, b5, loss_out=loss_dev, sync=False))
     for n in (4096, 16384):  # benchmarks/metrics.jl:11-15,40: p_i = (i,i,i)/n, A == B, B = 1
         p = fx.gpu(fx.synth.reference_bench_cloud(n))
         out[f"reference harness chamfer fwd n={n} (A == B, collinear)"] = _per_call_ms(
