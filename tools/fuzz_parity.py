@@ -34,13 +34,22 @@ def cloud(rng, D, N, B, kind):
         x[:, N // 2:, :] = x[:, : N - N // 2, :]
     elif kind == "offset":
         x = rng.standard_normal((D, N, B)) + rng.choice([5.0, 50.0, 1000.0])
+    elif kind == "worstsplit":
+        # every coordinate a worst case of the 2-way fp16 split (24-bit mantissa = 11-bit head * 2^13 + an odd 12-bit residual:
+        # the low piece rounds at an exact tie), point-symmetric about 0 so that the centring keeps the bit patterns
+        h = (N + 1) // 2
+        head = rng.integers(1 << 10, 1 << 11, (D, h, B)).astype(np.int64)
+        r = (rng.integers(1 << 10, 1 << 11, (D, h, B)).astype(np.int64) * 2 + 1) * rng.choice([-1, 1], (D, h, B))
+        e = rng.integers(0, int(rng.integers(1, 6)), (D, h, B))
+        half = rng.choice([-1.0, 1.0], (D, h, B)) * (head * (1 << 13) + r) * np.exp2(e - 23.0)
+        x = np.concatenate([half, -half], 1)[:, rng.permutation(2 * h)[:N], :]
     else:  # "range": a few far outliers
         x = rng.standard_normal((D, N, B)) * 1e-2
         x[:, rng.integers(0, N, 3), :] *= 1e5
     return np.asfortranarray(x.astype(np.float32))
 
 
-KINDS = ["uniform", "normal", "clustered", "lattice", "dupes", "offset", "range"]
+KINDS = ["uniform", "normal", "clustered", "lattice", "dupes", "offset", "range", "worstsplit"]
 
 
 def mesh_batch(rng):
