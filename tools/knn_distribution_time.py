@@ -40,13 +40,16 @@ def make(kind, D):
 for D in (3, 64):
     for kind in ("uniform", "normal", "normal+100", "clusters", "lattice", "dupes", "outlier"):
         dx = fx.gpu(np.asfortranarray(make(kind, D).astype(np.float32)))
-        for _ in range(2):
-            fx.knn(dx, 20, drop_first=True, return_dist=False)
-        fx.synchronize()
-        e0, e1 = fx.Event(), fx.Event()
-        e0.record()
         for _ in range(5):
             fx.knn(dx, 20, drop_first=True, return_dist=False)
-        e1.record()
-        e1.synchronize()
-        print(f"D={D:3d} {kind:12s}: {e0.elapsed_ms(e1) * 200:10.1f} us", flush=True)
+        fx.synchronize()
+        best = 1e30
+        for _ in range(4):  # min of four groups of five back-to-back calls (the first group of a process pays one-time set-up)
+            e0, e1 = fx.Event(), fx.Event()
+            e0.record()
+            for _ in range(5):
+                fx.knn(dx, 20, drop_first=True, return_dist=False)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_ms(e1) * 200)
+        print(f"D={D:3d} {kind:12s}: {best:10.1f} us", flush=True)
