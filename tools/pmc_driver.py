@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A few launches of ONE op of the path, for rocprofv3 --pmc passes (counters go in their own runs: tools/profile_round.sh).
 
-  python tools/pmc_driver.py nn1 | knn3 | knn64 | edgeconv3 | fit [--reps 6]
+  python tools/pmc_driver.py nn1 | nn1_fullmantissa | knn3 | knn64 | edgeconv3 | fit [--reps 6]
 """
 import argparse
 import os
@@ -16,12 +16,17 @@ import flux3d_jl_amd as fx  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("op", choices=["nn1", "knn3", "knn64", "edgeconv3", "fit"])
+    ap.add_argument("op", choices=["nn1", "nn1_fullmantissa", "knn3", "knn64", "edgeconv3", "fit"])
     ap.add_argument("--reps", type=int, default=6)
     a = ap.parse_args()
     if a.op == "nn1":      # BASELINE config 2
         x = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_A, 3, 4096, 32))
         y = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_B, 3, 4096, 32))
+        out = fx.DeviceArray.empty((1,), np.float32)
+        fn = lambda: fx.chamfer_distance(x, y, loss_out=out, sync=False)  # noqa: E731
+    elif a.op == "nn1_fullmantissa":  # the same shape on Float64 -> Float32 rounded uniforms (all 24 mantissa bits in use, unlike the
+        rng = np.random.default_rng(7)  # documented (bits >> 8) * 2^-24 stream): same instruction counts, ~8 % longer kernel
+        x, y = (fx.gpu(np.asfortranarray(rng.random((3, 4096, 32)).astype(np.float32))) for _ in range(2))
         out = fx.DeviceArray.empty((1,), np.float32)
         fn = lambda: fx.chamfer_distance(x, y, loss_out=out, sync=False)  # noqa: E731
     elif a.op in ("knn3", "edgeconv3"):  # BASELINE config 4
