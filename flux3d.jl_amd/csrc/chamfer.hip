@@ -637,14 +637,55 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 // Rare case (degenerate / near-tied data, unusable filter): the wave re-runs its filter pass
                 // with the now known threshold and enqueues exactly the lane tiles within the band (every
                 // tile for lanes whose filter is unusable), draining the list whenever it is full.
-                const bool retry = __ballot(slow) != 0;
+                // A wave with ONE or TWO such queries does not re-run its pass (one wave's ~7 us would be the launch's tail: the
+                // 256 blocks are one round): after the FIFO items it scans the chunk exactly for each of them (every lane tile of
+                // both halves as items: ~2 us per query).  More slow queries (degenerate data): the retry pass.
+                const unsigned long long sb = __ballot(slow);
+                unsigned int qslow = (unsigned int)sb | (unsigned int)(sb >> 32);  // (a query's two half-wave lanes share bit jq)
+                const bool retry = __builtin_popcount(qslow) > 2;
+                bool fifo_done = false;
                 // a NaN distance needs a non-finite cloud or a non-finite query (wave-uniform switch of the task code)
                 const bool nonfinite = !sane || __ballot(!(fabsf(qr[0]) + fabsf(qr[1]) + fabsf(qr[2]) < INFINITY)) != 0;
                 const int nlt = nblk / kHLT;
                 int lt2 = 0;
                 do {
                     int nitems = 0;
-                    if (!retry) {
+                    if (!retry && fifo_done) {
+                        // one slow query against the whole chunk, exactly: runs of four candidates, two runs per lane in flight,
+                        // lane-local minimum (lowest index on ties: the runs of a lane ascend), one LDS atomic per lane
+                        const int qsl = __builtin_ctz(qslow);
+                        qslow &= qslow - 1;
+                        const float qq[3] = {qtab[qsl * 3], qtab[qsl * 3 + 1], qtab[qsl * 3 + 2]};
+                        unsigned long long kbest = ~0ull;
+                        for (int r0 = 4 * lane; r0 < cnt; r0 += 2 * 256) {
+                            float cx[2][4], cy[2][4], cz[2][4];
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const int jl0 = r0 + 256 * u;
+                                if (vec && jl0 + 4 <= cnt) {
+                                    load4pts(cb, j0 + jl0, cx[u], cy[u], cz[u]);
+                                } else {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const int jc = jl0 + r < cnt ? jl0 + r : cnt - 1;
+                                        const float *src = cb + (size_t)(j0 + jc) * 3;
+                                        cx[u][r] = src[0]; cy[u][r] = src[1]; cz[u][r] = src[2];
+                                    }
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int jc = r0 + 256 * u + r;
+                                    const float cc3[3] = {cx[u][r], cy[u][r], cz[u][r]};
+                                    const unsigned long long key = ((unsigned long long)dist_key(sqd<3>(qq, cc3)) << 32) | (unsigned int)(j0 + jc);
+                                    if (jc < cnt && key < kbest) kbest = key;
+                                }
+                        }
+                        atomicMin(&qres[qsl], kbest);
+                        lt2 = qslow ? 0 : nlt;
+                    } else if (!retry) {
 #pragma unroll
                         for (int s = 0; s < kHFifo; ++s) {
                             const bool qual = fi[s] >= 0 && ft[s] <= thr1;
@@ -656,7 +697,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                                 nitems += __builtin_popcountll(bal);  // <= 64 * kHFifo == kHItemCap
                             }
                         }
-                        lt2 = nlt;
+                        fifo_done = true;
+                        lt2 = qslow ? 0 : nlt;
                     } else {
                         const h8 *pb = imgp + hh * 32 + jq;
 #pragma unroll 1
