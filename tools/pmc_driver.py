@@ -24,8 +24,8 @@ def main():
         y = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_B, 3, 4096, 32))
         out = fx.DeviceArray.empty((1,), np.float32)
         fn = lambda: fx.chamfer_distance(x, y, loss_out=out, sync=False)  # noqa: E731
-    elif a.op == "nn1_fullmantissa":  # the same shape on numpy's Float64 -> Float32 uniforms instead of the
-        rng = np.random.default_rng(7)  # documented SplitMix stream: same instruction and cycle counts, ~11 % longer kernel
+    elif a.op == "nn1_fullmantissa":  # the same shape on numpy's default_rng(7) uniforms: a dataset with one slow query
+        rng = np.random.default_rng(7)  # (its wave is the launch's tail: same counters, longer kernel -- DESIGN.md 3.1)
         x, y = (fx.gpu(np.asfortranarray(rng.random((3, 4096, 32)).astype(np.float32))) for _ in range(2))
         out = fx.DeviceArray.empty((1,), np.float32)
         fn = lambda: fx.chamfer_distance(x, y, loss_out=out, sync=False)  # noqa: E731
