@@ -651,37 +651,42 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 do {
                     int nitems = 0;
                     if (!retry && fifo_done) {
-                        // one slow query against the whole chunk, exactly: runs of four candidates, two runs per lane in flight,
-                        // lane-local minimum (lowest index on ties: the runs of a lane ascend), one LDS atomic per lane
+                        // one slow query against the rows of its slow half-wave lane(s), exactly: a lane (jq, hh) sees the runs of
+                        // four rows 8 g + 4 hh of every 32-candidate block, so the scan takes every second run (both halves slow:
+                        // all of them); two runs per lane in flight, lane-local minimum (lowest index on ties: a lane's runs
+                        // ascend), one LDS atomic per lane
                         const int qsl = __builtin_ctz(qslow);
                         qslow &= qslow - 1;
                         const float qq[3] = {qtab[qsl * 3], qtab[qsl * 3 + 1], qtab[qsl * 3 + 2]};
                         unsigned long long kbest = ~0ull;
-                        for (int r0 = 4 * lane; r0 < cnt; r0 += 2 * 256) {
-                            float cx[2][4], cy[2][4], cz[2][4];
+                        for (int h = 0; h < 2; ++h) {
+                            if (!((sb >> (32 * h + qsl)) & 1ull)) continue;  // (wave-uniform)
+                            for (int r0 = 4 * (2 * lane + h); r0 < cnt; r0 += 2 * 512) {
+                                float cx[2][4], cy[2][4], cz[2][4];
 #pragma unroll
-                            for (int u = 0; u < 2; ++u) {
-                                const int jl0 = r0 + 256 * u;
-                                if (vec && jl0 + 4 <= cnt) {
-                                    load4pts(cb, j0 + jl0, cx[u], cy[u], cz[u]);
-                                } else {
+                                for (int u = 0; u < 2; ++u) {
+                                    const int jl0 = r0 + 512 * u;
+                                    if (vec && jl0 + 4 <= cnt) {
+                                        load4pts(cb, j0 + jl0, cx[u], cy[u], cz[u]);
+                                    } else {
 #pragma unroll
-                                    for (int r = 0; r < 4; ++r) {
-                                        const int jc = jl0 + r < cnt ? jl0 + r : cnt - 1;
-                                        const float *src = cb + (size_t)(j0 + jc) * 3;
-                                        cx[u][r] = src[0]; cy[u][r] = src[1]; cz[u][r] = src[2];
+                                        for (int r = 0; r < 4; ++r) {
+                                            const int jc = jl0 + r < cnt ? jl0 + r : cnt - 1;
+                                            const float *src = cb + (size_t)(j0 + jc) * 3;
+                                            cx[u][r] = src[0]; cy[u][r] = src[1]; cz[u][r] = src[2];
+                                        }
                                     }
                                 }
+#pragma unroll
+                                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const int jc = r0 + 512 * u + r;
+                                        const float cc3[3] = {cx[u][r], cy[u][r], cz[u][r]};
+                                        const unsigned long long key = ((unsigned long long)dist_key(sqd<3>(qq, cc3)) << 32) | (unsigned int)(j0 + jc);
+                                        if (jc < cnt && key < kbest) kbest = key;
+                                    }
                             }
-#pragma unroll
-                            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const int jc = r0 + 256 * u + r;
-                                    const float cc3[3] = {cx[u][r], cy[u][r], cz[u][r]};
-                                    const unsigned long long key = ((unsigned long long)dist_key(sqd<3>(qq, cc3)) << 32) | (unsigned int)(j0 + jc);
-                                    if (jc < cnt && key < kbest) kbest = key;
-                                }
                         }
                         atomicMin(&qres[qsl], kbest);
                         lt2 = qslow ? 0 : nlt;
