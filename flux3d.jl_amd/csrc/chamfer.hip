@@ -280,12 +280,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float chamfer_loss_from_sums(double sa, double sb, int N, int M, int D,
                                                         long long Bg, float w1, float w2);
 constexpr int kHThreads = 1024;   // 16 waves share one LDS image: 1 block per CU, 4 waves per SIMD
-constexpr int kHLT = 2;           // 32-candidate blocks per lane tile (lane sees 16 rows of each)
-constexpr int kHFifo = 3;
+#ifndef FX3D_HLT
+#define FX3D_HLT 2
+#endif
+constexpr int kHLT = FX3D_HLT;    // 32-candidate blocks per lane tile (lane sees 16 rows of each)
+constexpr int kHFifo = 3;         // lane tiles tracked per lane and pass: the three smallest tile minima
 constexpr int kHChunkMax = 4096;  // 32 B per candidate => 128 KiB
 constexpr int kHItemCap = 64 * kHFifo;  // the FIFO path never overflows the list
 constexpr int kHFarCap = 64;      // far candidates kept on the exact side list; more: the chunk falls back to exact scans
-static_assert(kHFifo <= 4 && kHChunkMax / (32 * kHLT) < 255, "FIFO lane-tile ids are packed one byte each");
+static_assert(kHChunkMax / (32 * kHLT) <= 64, "lane-tile ids live in the six low mantissa bits of the tracked keys");
+// Tracking keys: a lane tile's minimum with the tile's id in its six low mantissa bits (one v_and_or): |key - t| < 2^-17 |t|.
+// kKeyUp turns a key into an upper bound of the value it came from (and a threshold on values into one on keys).
+constexpr float kKeyUp = 0x1.2p-17f;
+constexpr float kPadF16 = 65504.0f;  // K slot 15: padding / far candidates get 65504 x 65504 = 4.3e9, finite and above every real
+                                     // filter value (|t| <= 3 2^14 (1 + beta) + 128 S, S < 3e4): no +Inf in the image, no NaN keys
 constexpr size_t kHScratchBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 4 + 32 * 3 * 4) + 64 * 32;  // + 2 pad blocks
 
 // plain v_min_f32 (fminf() also emits a canonicalising v_max in IEEE mode; the filter values are never
@@ -371,7 +379,11 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     unsigned int *items = witems + wv * kHItemCap;
     float *qtab = wq + wv * 96;
     const bool vec = (reinterpret_cast<uintptr_t>(cb) & 15) == 0;
+#ifdef FX3D_KO_STATS
+    const bool one_shot = false;
+#else
     const bool one_shot = NC <= CH;
+#endif
     if (tid == 0) { nfar[0] = 0; nfar[1] = 0; }  // (ordered before their first use by the barrier of the bounding-box pass)
     float qpre[3];  // this lane's query of the coming tile pass (the load's latency hides behind the prologue)
     {
@@ -387,6 +399,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     //      much smaller than the farthest point keeps its fp16 pieces out of the subnormals; |c~|^2 < 3 * 2^14 fits fp16 ----
     float mu[3], cinf = 0.0f, varmax = 0.0f;
     bool allfin = true;
+#ifdef FX3D_KO_STATS
+    mu[0] = mu[1] = mu[2] = 0.5f; cinf = 0.5f; varmax = 0.25f;
+    if (p.N < 0)
+#endif
     {
         // thread t takes points t, t + 1024, ...: 12-byte loads, consecutive lanes on consecutive points (coalesced, and the
         // 16-byte LDS slots of a wave's points are consecutive: no bank conflicts when they are parked and converted)
@@ -509,7 +525,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         const bool far = !(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)) < 128.0f);
         make_pieces(far ? 0.f : sx, far ? 0.f : sy, far ? 0.f : sz, p0, p1);
         if (far) {
-            p1[1] = (_Float16)INFINITY;
+            p1[7] = (_Float16)kPadF16;
             const int f = atomicAdd(&nfar[fslot], 1);
             if (f < kHFarCap) farlist[f] = (unsigned short)pt;
         }
@@ -539,9 +555,9 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     const P3 r = *reinterpret_cast<const P3 *>(cb + (size_t)(j0 + pt) * 3);
                     pieces(r.x, r.y, r.z, pt, p0, p1);
                 }
-            } else {  // padding: n1 = +inf => t = +inf, never within any band
+            } else {  // padding: t = 4.3e9 (K slot 15), above every real value; the exact phase skips rows >= cnt
                 make_pieces(0.f, 0.f, 0.f, p0, p1);
-                p1[1] = (_Float16)INFINITY;
+                p1[7] = (_Float16)kPadF16;
             }
             imgp[i0] = p0;
             imgp[i0 + 32] = p1;
@@ -573,18 +589,19 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 da = kBandA * qn + 0x1p-24f * (S + 4.0f);
                 _Float16 hx, lx, hy, ly, hz, lz;
                 split2h(qok ? m0 : 0.f, hx, lx); split2h(qok ? m1 : 0.f, hy, ly); split2h(qok ? m2 : 0.f, hz, lz);
-                const _Float16 one = (_Float16)1.0f, z = (_Float16)0.0f;
-                bq = hh == 0 ? h8{hx, lx, hx, hy, ly, hy, hz, lz} : h8{hz, one, one, one, lx, ly, lz, z};
+                const _Float16 one = (_Float16)1.0f, pad = (_Float16)kPadF16;
+                bq = hh == 0 ? h8{hx, lx, hx, hy, ly, hy, hz, lz} : h8{hz, one, one, one, lx, ly, lz, pad};
                 if (hh == 0) {
                     qres[jq] = ~0ull;
                     qtab[jq * 3 + 0] = qr[0]; qtab[jq * 3 + 1] = qr[1]; qtab[jq * 3 + 2] = qr[2];
                 }
             }
 
-            float best = INFINITY, tm = INFINITY, ft[kHFifo];
-            unsigned int fis = 0xffffffffu;  // the FIFO's lane-tile ids, one byte each (0xff = empty): a shift register
-#pragma unroll
-            for (int s = 0; s < kHFifo; ++s) ft[s] = INFINITY;
+            // the three smallest lane-tile minima of this lane, as keys (tile id in the six low mantissa bits): ka <= kb <= kc.
+            // Four VALU operations per lane tile (v_and_or, 2 x v_med3, v_min) -- the FIFO of the first two rounds (threshold fma,
+            // compare, five selects / shifts, min: nine) is gone, and "may the lane have missed a tile" is exact now (kc in band).
+            float tm = INFINITY, ka = INFINITY, kb = INFINITY, kc = INFINITY;
+            const unsigned int keymask = ~63u;
 
             // ---- main loop, software-pipelined by one 32-candidate block -----------------------------------
             // (the image carries two padding blocks behind cnt_pad, so the prefetch never needs a clamp
@@ -612,27 +629,28 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     a_nxt = a_n2;
                 }
                 pa += kHLT * 64;
-                const bool qual = tm <= __builtin_fmaf(best, kBandB1, da);
-#pragma unroll
-                for (int s = kHFifo - 1; s > 0; --s) ft[s] = qual ? ft[s - 1] : ft[s];
-                ft[0] = qual ? tm : ft[0];
-                fis = qual ? ((fis << 8) | (unsigned int)lt) : fis;  // one v_lshl_or + one v_cndmask
-                best = vmin(best, tm);
+#ifdef FX3D_KO_TRACK
+                ka = vmin(ka, tm);
+#else
+                float key;
+                asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(tm), "v"(keymask), "s"(lt));
+                kc = __builtin_amdgcn_fmed3f(kb, kc, key);
+                kb = __builtin_amdgcn_fmed3f(ka, kb, key);
+                ka = vmin(ka, key);
+#endif
             }
-            int fi[kHFifo];
-#pragma unroll
-            for (int s = 0; s < kHFifo; ++s) {
-                const unsigned int id = (fis >> (8 * s)) & 0xffu;
-                fi[s] = id == 0xffu ? -1 : (int)id;
-            }
+            const float ft[kHFifo] = {ka, kb, kc};
+            // this lane's smallest tile minimum is <= best (an upper bound of it: the key of the smallest VALUE is >= ka)
+            const float best = __builtin_fmaf(fabsf(ka), kKeyUp, ka);
             FX3D_PROBE_MARK(tp == 0 ? 3 : 7);
 
             // ---- exact phase, wave-cooperative ----------------------------------------------------------------
             {
                 const float m = fminf(best, __shfl_xor(best, 32, 64));
-                const float thr1 = __builtin_fmaf(m, kBandB1, da), thr2 = __builtin_fmaf(thr1, kBandB1, da);
+                const float thr1 = __builtin_fmaf(m, kBandB1, da);                  // on tile minima (m >= the true minimum)
+                const float thr1k = __builtin_fmaf(fabsf(thr1), kKeyUp, thr1);      // on keys: t <= thr1  =>  key(t) <= thr1k
                 const bool usable = sane && far_ok && qok && m < INFINITY;  // filter meaningful for this query
-                const bool slow = !usable || !(ft[kHFifo - 1] > thr2);  // FIFO may have dropped a tile in band
+                const bool slow = !usable || !(kc > thr1k);  // a fourth lane tile may lie within the band
                 // Common case (no slow lane in the wave): the items are the FIFO entries within the band.
                 // Rare case (degenerate / near-tied data, unusable filter): the wave re-runs its filter pass
                 // with the now known threshold and enqueues exactly the lane tiles within the band (every
@@ -648,6 +666,9 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 const bool nonfinite = !sane || __ballot(!(fabsf(qr[0]) + fabsf(qr[1]) + fabsf(qr[2]) < INFINITY)) != 0;
                 const int nlt = nblk / kHLT;
                 int lt2 = 0;
+#ifdef FX3D_KO_EXACT
+                if (p.N < 0)
+#endif
                 do {
                     int nitems = 0;
                     if (!retry && fifo_done) {
@@ -693,12 +714,12 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     } else if (!retry) {
 #pragma unroll
                         for (int s = 0; s < kHFifo; ++s) {
-                            const bool qual = fi[s] >= 0 && ft[s] <= thr1;
+                            const bool qual = ft[s] <= thr1k;  // (finite: the key's low bits are its lane tile)
                             const unsigned long long bal = __ballot(qual);
                             if (bal) {
                                 const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
                                                          __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
-                                if (qual) items[pos] = ((unsigned int)jq << 16) | ((unsigned int)hh << 12) | (unsigned int)fi[s];
+                                if (qual) items[pos] = ((unsigned int)jq << 16) | ((unsigned int)hh << 12) | (__builtin_bit_cast(unsigned int, ft[s]) & 63u);
                                 nitems += __builtin_popcountll(bal);  // <= 64 * kHFifo == kHItemCap
                             }
                         }

@@ -2,7 +2,10 @@
 // with FX3D_PROBE so the kernel stores s_memtime stamps per block.  Build:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DFX3D_PROBE -I include -I flux3d.jl_amd/csrc \
 //         tools/nn1_probe.hip flux3d.jl_amd/csrc/runtime.hip -o tools/nn1_probe
-#include "../flux3d.jl_amd/csrc/chamfer.hip"
+#ifndef FX3D_CHAMFER_SRC  // (A/B builds point this at another revision of the kernel source)
+#define FX3D_CHAMFER_SRC "../flux3d.jl_amd/csrc/chamfer.hip"
+#endif
+#include FX3D_CHAMFER_SRC
 
 #include <algorithm>
 #include <cstdio>
@@ -24,12 +27,17 @@ int main(int argc, char **argv) {
     void *ws; hipMalloc(&ws, wsb); hipMalloc(&loss, 4);
     float hl = 0;
     for (int it = 0; it < 5; ++it) fx3d_chamfer_fwd(x, N, y, M, B, 3, 1.f, 1.f, loss, &hl, nullptr, nullptr, ws, wsb, nullptr);
+    const int warm = argc > 1 ? atoi(argv[1]) : 0, reps = argc > 2 ? atoi(argv[2]) : 20;  // (warm: launches before the timed ones -- steady clocks)
+    for (int it = 0; it < warm; ++it) fx3d_chamfer_fwd(x, N, y, M, B, 3, 1.f, 1.f, loss, nullptr, nullptr, nullptr, ws, wsb, nullptr);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0);
-    for (int it = 0; it < 20; ++it) fx3d_chamfer_fwd(x, N, y, M, B, 3, 1.f, 1.f, loss, nullptr, nullptr, nullptr, ws, wsb, nullptr);
-    hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("loss %.8f  avg per call %.3f us\n", hl, ms * 1000 / 20);
+    float ms = 0;
+    for (int rnd = 0; rnd < (argc > 1 ? 3 : 1); ++rnd) {
+        hipEventRecord(e0);
+        for (int it = 0; it < reps; ++it) fx3d_chamfer_fwd(x, N, y, M, B, 3, 1.f, 1.f, loss, nullptr, nullptr, nullptr, ws, wsb, nullptr);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("loss %.8f  avg per call %.3f us (%d calls)\n", hl, ms * 1000 / reps, reps);
+    }
     std::vector<unsigned long long> pr(4096 * 16);
     hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_probe), pr.size() * 8);
     // s_memtime runs at 100 MHz on gfx9 (constant), report in ns*10 -> convert: ticks * 10 ns
@@ -61,6 +69,20 @@ int main(int argc, char **argv) {
         for (int b = 0; b < nb; ++b) { const double d = (double)(pr[b * 16 + 14] - pr[b * 16 + 13]); dsum += d; dmax = std::max(dmax, d); late = std::max(late, (double)(pr[b * 16 + 13] - a)); }
         printf("wall clock %d kHz: block duration avg %.2f us max %.2f us; first start -> last end %.2f us; latest start +%.2f us\n", wrate,
                dsum / nb * 1e3 / wrate, dmax * 1e3 / wrate, (double)(e - a) * 1e3 / wrate, late * 1e3 / wrate);
+    }
+    {   // block durations (wall clock): quantiles, per XCD, per direction
+        int wrate = 0; hipDeviceGetAttribute(&wrate, hipDeviceAttributeWallClockRate, 0);
+        std::vector<double> du;
+        double xs[8] = {0}, ds[2] = {0};
+        for (int b = 0; b < nb; ++b) {
+            const double d = (double)(pr[b * 16 + 14] - pr[b * 16 + 13]) * 1e3 / wrate;
+            du.push_back(d); xs[b & 7] += d / (nb / 8);
+            const int c = ((b >> 3) / 4) * 8 + (b & 7);  // (C2 plan: 4 blocks per cloud and direction)
+            ds[c >= B ? 1 : 0] += d / (nb / 2);
+        }
+        std::sort(du.begin(), du.end());
+        printf("block duration us: p0 %.2f p10 %.2f p50 %.2f p90 %.2f p99 %.2f p100 %.2f\n", du[0], du[nb / 10], du[nb / 2], du[nb * 9 / 10], du[nb * 99 / 100], du[nb - 1]);
+        printf("per XCD mean us:"); for (int x = 0; x < 8; ++x) printf(" %.2f", xs[x]); printf("  per direction: %.2f %.2f\n", ds[0], ds[1]);
     }
     // per XCD (blocks L with equal L % 8 share a clock): span from the first start to the last end, and the starts
     for (int x = 0; x < 8; ++x) {

@@ -51,6 +51,7 @@ __global__ void k(float *out, int iters, float b, float c) {
         if (OP == 14) { REP8(PKFMA) REP8(MIN3) }   // mix: pk_fma + min3
         if (OP == 15) { REP8(PKMOV) REP8(PKMOV) }
         if (OP == 16) { REP8(MIN3U) REP8(MIN3U) }
+        if (OP == 17) { REP8(MED3) REP8(MED3) }
     }
     float s = 0;
     for (int i = 0; i < 8; ++i) s += a[i] + p[i].x + p[i].y;
@@ -88,5 +89,6 @@ int main() {
     run<8>("v_cmp+v_cndmask (pair)", d, 16); run<9>("v_mov_b32", d, 16); run<10>("v_sub_f32 sgpr", d, 16);
     run<12>("v_max_u32", d, 16); run<13>("v_and_or_b32", d, 16);
     run<14>("pk_fma + min3 mix", d, 16); run<15>("v_pk_mov_b32", d, 16); run<16>("v_min3_u32", d, 16);
+    run<17>("v_med3_f32", d, 16);
     return 0;
 }
