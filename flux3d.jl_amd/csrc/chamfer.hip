@@ -837,35 +837,51 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             // ---- fused finalisation: placement-independent hand-off through 8-byte agent-scope atomics
             //      (write-through store -> drain -> relaxed ticket; the last arriver reads with agent-scope
             //      loads), MI355X_MICROARCH.md "valid forms".  Fixed summation order => deterministic.
-            __shared__ int is_last;
+            // Only the first wave goes on (the block's sum is in its lane 0).  The last arriver's reduction is the launch's tail
+            // -- every other CU is idle by then --: one wave, all its loads in flight together, DPP adds, no barrier (the
+            // block-wide version, two barrier rounds and shuffle trees through LDS, took 6 k cycles = 2.7 us at C2).
             unsigned long long *pp = reinterpret_cast<unsigned long long *>(p.partials);
-            if (tid == 0) {
-                __hip_atomic_store(&pp[(size_t)c * p.tiles + tile], __builtin_bit_cast(unsigned long long, tot),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned int old = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                is_last = old == p.nvalid - 1;
-            }
-            __syncthreads();
-            if (is_last) {
-                double tsum[2];
-                for (int dd = 0; dd < 2; ++dd) {
-                    const int nt = dd ? p.tiles_y : p.tiles_x;
-                    const long long n = (long long)p.B * nt;
-                    double a = 0.0;
-                    for (long long k = tid; k < n; k += kHThreads) {
-                        const int bb = (int)(k / nt), tt = (int)(k % nt);
-                        const unsigned long long v = __hip_atomic_load(&pp[((size_t)(dd * p.B + bb)) * p.tiles + tt],
-                                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        a += __builtin_bit_cast(double, v);
-                    }
-                    __syncthreads();
-                    tsum[dd] = block_sum<kHThreads>(a, sm);
+            if (wv == 0) {
+                int last = 0;
+                if (lane == 0) {
+                    __hip_atomic_store(&pp[(size_t)c * p.tiles + tile], __builtin_bit_cast(unsigned long long, tot),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned int old = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last = old == p.nvalid - 1;
                 }
-                if (tid == 0) {
-                    if (p.sums_out) { p.sums_out[0] = tsum[0]; p.sums_out[1] = tsum[1]; }
-                    if (p.loss_out) *p.loss_out = chamfer_loss_from_sums(tsum[0], tsum[1], p.N, p.M, 3, p.Bg, p.w1, p.w2);
-                    __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for reuse
+                last = __builtin_amdgcn_readfirstlane(last);
+#ifdef FX3D_PROBE
+                if (tid == 0 && blockIdx.x < 4096) { g_probe[blockIdx.x * 16 + 15] = last; g_probe[blockIdx.x * 16 + 9] = __builtin_readcyclecounter(); }
+#endif
+                if (last) {
+                    // lane l sums entries l, l + 64, ... of a direction in order (four of each direction in flight), then the DPP tree
+                    double a[2] = {0.0, 0.0};
+                    const unsigned int n0 = (unsigned int)p.B * (unsigned int)p.tiles_x, n1 = (unsigned int)p.B * (unsigned int)p.tiles_y;  // (< 2^30: check_shapes)
+                    for (unsigned int k0 = lane; k0 < n0 || k0 < n1; k0 += 64 * 4) {
+                        unsigned long long v[2][4];
+#pragma unroll
+                        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const unsigned int nt = dd ? p.tiles_y : p.tiles_x;
+                                const unsigned int k = k0 + 64 * u, kc = k < (dd ? n1 : n0) ? k : 0;
+                                // (clouds of equal tile counts -- the usual case -- : rows are dense, no division)
+                                const size_t e = nt == (unsigned int)p.tiles ? (size_t)dd * n0 + kc : ((size_t)(dd * p.B) + kc / nt) * p.tiles + kc % nt;
+                                v[dd][u] = __hip_atomic_load(&pp[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+#pragma unroll
+                        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (k0 + 64 * u < (dd ? n1 : n0)) a[dd] += __builtin_bit_cast(double, v[dd][u]);
+                    }
+                    const double t0 = wave_sum_l63_f64(a[0]), t1 = wave_sum_l63_f64(a[1]);
+                    if (lane == 63) {
+                        if (p.sums_out) { p.sums_out[0] = t0; p.sums_out[1] = t1; }
+                        if (p.loss_out) *p.loss_out = chamfer_loss_from_sums(t0, t1, p.N, p.M, 3, p.Bg, p.w1, p.w2);
+                        __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for reuse
+                    }
                 }
             }
         }

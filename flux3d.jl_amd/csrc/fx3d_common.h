@@ -167,6 +167,33 @@ __device__ __forceinline__ float wave_sum_l63(float v) {  // fixed order: determ
     v = ((threadIdx.x >> 5) & 1) ? v + b : v;
     return v;
 }
+// the same for a double (two 32-bit DPP moves per step; __shfl_down would be two ds_bpermute round trips per step): lane 63
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov64(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)b, CTRL, 0xF, 0xF, true);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_keep64(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int l0 = (int)(unsigned int)b, h0 = (int)(unsigned int)(b >> 32);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(l0, l0, CTRL, ROWMASK, 0xF, false);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(h0, h0, CTRL, ROWMASK, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum_l63_f64(double v) {  // fixed order: deterministic
+    v = v + dpp_mov64<0xB1>(v);
+    v = v + dpp_mov64<0x4E>(v);
+    v = v + dpp_mov64<0x141>(v);
+    v = v + dpp_mov64<0x140>(v);
+    const double a = dpp_keep64<0x142, 0xA>(v);
+    v = ((threadIdx.x >> 4) & 1) ? v + a : v;
+    const double b = dpp_keep64<0x143, 0xC>(v);
+    v = ((threadIdx.x >> 5) & 1) ? v + b : v;
+    return v;
+}
 __device__ __forceinline__ float wave_sum_f(float v) {  // the same butterfly with adds (fixed order: deterministic)
     v = v + dpp_mov<0xB1>(v);
     v = v + dpp_mov<0x4E>(v);

@@ -70,6 +70,15 @@ int main(int argc, char **argv) {
         printf("wall clock %d kHz: block duration avg %.2f us max %.2f us; first start -> last end %.2f us; latest start +%.2f us\n", wrate,
                dsum / nb * 1e3 / wrate, dmax * 1e3 / wrate, (double)(e - a) * 1e3 / wrate, late * 1e3 / wrate);
     }
+    {   // the end of a block: mark 11 (passes done) -> mark 9 (ticket returned) -> mark 12 (end), ordinary blocks vs the last arriver
+        double a = 0, b2 = 0; int n = 0;
+        for (int b = 0; b < nb; ++b) {
+            const unsigned long long *q = &pr[b * 16];
+            if (q[15]) printf("last arriver: block %d, passes done -> ticket %llu cycles, ticket -> end %llu cycles\n", b, q[9] - q[11], q[12] - q[9]);
+            else { a += (double)(q[9] - q[11]); b2 += (double)(q[12] - q[9]); ++n; }
+        }
+        printf("other blocks: passes done -> ticket %.0f cycles, ticket -> end %.0f cycles\n", a / n, b2 / n);
+    }
     {   // block durations (wall clock): quantiles, per XCD, per direction
         int wrate = 0; hipDeviceGetAttribute(&wrate, hipDeviceAttributeWallClockRate, 0);
         std::vector<double> du;
