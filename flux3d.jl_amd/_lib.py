@@ -27,6 +27,10 @@ vp, sz = C.c_void_p, C.c_size_t
 SIGNATURES = {
     "fx3d_version": [],
     "fx3d_last_error": [C.c_char_p, sz],
+    "fx3d_set_option": [C.c_char_p, c_i32],
+    "fx3d_get_option": [C.c_char_p, C.POINTER(c_i32)],
+    "fx3d_option_count": [],
+    "fx3d_option_name": [c_i32],
     "fx3d_device_count": [C.POINTER(c_i32)],
     "fx3d_set_device": [c_i32],
     "fx3d_get_device": [C.POINTER(c_i32)],
@@ -105,6 +109,13 @@ SIGNATURES = {
     "fx3d_comm_info": [vp, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32)],
     "fx3d_comm_destroy": [vp],
     "fx3d_comm_allreduce_sum_f64": [vp, vp, c_i64, vp],
+    "fx3d_comm_allreduce_max_f64": [vp, vp, c_i64, vp],
+    "fx3d_comm_init_all": [C.POINTER(vp), c_i32, vp],
+    "fx3d_multi_destroy": [vp],
+    "fx3d_multi_info": [vp, C.POINTER(c_i32), vp, C.POINTER(c_i32)],
+    "fx3d_multi_sync": [vp],
+    "fx3d_chamfer_fwd_multi": [vp, C.POINTER(vp), c_i32, C.POINTER(vp), c_i32, vp, c_i32, c_i64, c_f32, c_f32,
+                               C.POINTER(c_f32), C.POINTER(vp)],
     "fx3d_chamfer_fwd_sharded": [vp, vp, c_i32, vp, c_i32, c_i32, c_i32, c_i64, c_f32, c_f32, vp, vp,
                                  C.POINTER(c_f32), vp, sz, vp],
     "fx3d_chamfer_fwd_sharded_async": [vp, vp, c_i32, vp, c_i32, c_i32, c_i32, c_i64, c_f32, c_f32, vp, vp, vp, sz,
@@ -112,7 +123,7 @@ SIGNATURES = {
     "fx3d_build_edges_packed": [vp, c_i64, c_i64, c_i32, vp, vp, C.POINTER(c_i64)],
     "fx3d_build_laplacian_csr": [vp, c_i64, c_i64, c_i32, vp, vp, vp, C.POINTER(c_i64)],
 }
-_RESTYPES = {"fx3d_version": C.c_char_p, "fx3d_last_error": sz}
+_RESTYPES = {"fx3d_version": C.c_char_p, "fx3d_last_error": sz, "fx3d_option_count": c_i32, "fx3d_option_name": C.c_char_p}
 
 _lib = None
 
@@ -149,3 +160,36 @@ def check(rc):
 
 def call(name, *args):
     check(getattr(load(), name)(*args))
+
+
+def set_option(name, value):
+    """fx3d_set_option: choose one of the kernels' alternative code paths (include/flux3d_hip.h "variant switches")."""
+    call("fx3d_set_option", name.encode(), int(value))
+
+
+def get_option(name):
+    v = c_i32(0)
+    call("fx3d_get_option", name.encode(), C.byref(v))
+    return v.value
+
+
+def options():
+    """{name: value} of every option the library knows."""
+    lib = load()
+    return {lib.fx3d_option_name(i).decode(): get_option(lib.fx3d_option_name(i).decode()) for i in range(lib.fx3d_option_count())}
+
+
+class option:
+    """``with option("knn_f32", 1): ...`` -- set for the block, restored afterwards (process-wide: not for concurrent use)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.prev = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.prev)
+        return False

@@ -1090,15 +1090,9 @@ struct Plan {
     int nsplit;  // fp16 variant: chunk subsets per query tile (multi-chunk clouds with too few blocks)
 };
 
-// FX3D_NN1_VARIANT=0 selects the exact VALU loop for D = 3 (A/B measurements; the f32 VALU / MFMA filter variants
+// option nn1_variant = 0 selects the exact VALU loop for D = 3 (A/B measurements; the f32 VALU / MFMA filter variants
 // of round 1 are in the history: DESIGN.md 3.1 "ladder").
-int nn1_variant() {
-    static const int v = [] {
-        const char *e = getenv("FX3D_NN1_VARIANT");
-        return e && atoi(e) == 0 ? 0 : 3;
-    }();
-    return v;
-}
+int nn1_variant() { return opt(OPT_NN1_VARIANT) == 0 ? 0 : 3; }
 
 Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
     Plan pl{};
@@ -1136,13 +1130,13 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
     const int cminc = (maxc + cmax - 1) / cmax;
     double best = 1e30;
     int b_chunk = (maxc + gran - 1) / gran * gran < cmax ? (maxc + gran - 1) / gran * gran : cmax, b_tpb = 1, b_split = 1;
-    static const int tpb_env = [] { const char *e = getenv("FX3D_NN1_TPB"); return e ? atoi(e) : 0; }();
+    const int tpb_env = opt(OPT_NN1_TPB);
     for (int nch = cminc; nch <= cminc * 8 && nch <= 64; ++nch) {
         int ch = ((maxc + nch - 1) / nch + gran - 1) / gran * gran;
         if (ch > cmax) continue;
         const int anch = (maxc + ch - 1) / ch;
         for (int split = 0; split < 2; ++split) {
-            if (split && (!allow_split || anch == 1 || getenv("FX3D_NN1_NOSPLIT"))) continue;
+            if (split && (!allow_split || anch == 1 || opt(OPT_NN1_NOSPLIT))) continue;
             for (int tpb = 1; tpb <= 8; tpb *= 2) {
                 if (!split && anch > 1 && tpb > 1) continue;
                 if (tpb_env > 0 && tpb != tpb_env && (split || anch == 1)) continue;
@@ -1614,8 +1608,7 @@ fx3d_status fx3d_chamfer_bwd(const float *x, int32_t N, const float *y, int32_t 
     const long long total = (long long)B * (N + M);
     long long blocks = (total + kThreads - 1) / kThreads;
     if (blocks > 4096) blocks = 4096;
-    const char *glob_env = getenv("FX3D_BWD_GLOBAL_ATOMICS");  // read per call: the tests flip it
-    const bool no_lds = glob_env && atoi(glob_env);
+    const bool no_lds = opt(OPT_BWD_GLOBAL_ATOMICS) != 0;  // (fx3d_set_option: the tests flip it)
     const int maxr = N > M ? N : M;
     int nsplit = 512 / (2 * B);  // aim at ~2 blocks per CU; a block never owns fewer than 256 rows ...
     if (nsplit > maxr / 256) nsplit = maxr / 256;

@@ -7,6 +7,7 @@
 // travels through whatever the host already has (MPI, a file, torch.distributed, Julia Distributed).
 #include <arpa/inet.h>
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <netdb.h>
 #include <netinet/in.h>
 #include <sys/socket.h>
@@ -14,11 +15,15 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "fx3d_common.h"
 
@@ -36,6 +41,8 @@ typedef const char *(*GetErrorString_fn)(int);
 typedef int (*GetVersion_fn)(int *);
 typedef int (*CommCount_fn)(ncclComm_t_, int *);
 typedef int (*CommUserRank_fn)(ncclComm_t_, int *);
+typedef int (*CommInitAll_fn)(ncclComm_t_ *, int, const int *);
+typedef int (*Group_fn)(void);
 
 struct Rccl {
     void *h = nullptr;
@@ -47,6 +54,8 @@ struct Rccl {
     GetVersion_fn version = nullptr;
     CommCount_fn count = nullptr;
     CommUserRank_fn user_rank = nullptr;
+    CommInitAll_fn init_all = nullptr;
+    Group_fn group_start = nullptr, group_end = nullptr;
 };
 
 Rccl *rccl() {
@@ -67,6 +76,9 @@ Rccl *rccl() {
             r.version = (GetVersion_fn)dlsym(r.h, "ncclGetVersion");
             r.count = (CommCount_fn)dlsym(r.h, "ncclCommCount");
             r.user_rank = (CommUserRank_fn)dlsym(r.h, "ncclCommUserRank");
+            r.init_all = (CommInitAll_fn)dlsym(r.h, "ncclCommInitAll");
+            r.group_start = (Group_fn)dlsym(r.h, "ncclGroupStart");
+            r.group_end = (Group_fn)dlsym(r.h, "ncclGroupEnd");
         }
     });
     return (r.h && r.get_id && r.init_rank && r.destroy && r.allreduce) ? &r : nullptr;
@@ -78,14 +90,47 @@ fx3d_status rccl_fail(int rc, const char *what) {
     return FX3D_ERR_RCCL;
 }
 
-constexpr int kNcclSum = 0, kNcclFloat64 = 8;  // rccl.h: ncclSum = 0, ncclFloat64 = 8
+constexpr int kNcclSum = 0, kNcclMax = 2, kNcclFloat64 = 8;  // rccl.h: ncclSum = 0, ncclMax = 2, ncclFloat64 = 8
 
 // ---- unique-id exchange without torch / MPI: rank 0 hands the 128 bytes to the other ranks over a rendezvous ----------
-//   "tcp://host:port"  rank 0 listens on `port` (all interfaces) and serves nranks-1 connections; the others connect to
-//                      host:port, retrying while rank 0 is not up yet.  Nothing persists, a re-run cannot see stale state.
-//   "file://path"      rank 0 writes path.tmp and renames it to `path`; the others poll for `path`.  Rank 0 removes the
-//                      file again once every rank has confirmed (path.<rank> markers), so the next job starts clean.
+//   "tcp://host:port"  rank 0 listens on `port` (loopback only when `host` is a loopback name, else all interfaces) until every
+//                      rank 1..n-1 has been served once; the others connect to host:port, retrying while rank 0 is not up
+//                      yet.  Nothing persists, a re-run cannot see stale state.  Hand-shake: {magic, token, nranks, rank}
+//                      -> {magic, id}; a connection that does not speak it (a port scanner, a health probe, a peer of
+//                      another job: wrong token / nranks) is dropped and rank 0 keeps accepting; a rank that connects twice
+//                      is served again but counted once.  The token is FX3D_COMM_TOKEN (any string the launcher exports to
+//                      all ranks), 0 without it.
+//   "file://path"      single node.  Rank 0 removes whatever an earlier job left at `path` / `path.<r>`, writes
+//                      {magic, nonce, wall-clock, nranks, id} to a fresh temp file (O_EXCL | O_NOFOLLOW, 0600) and renames it
+//                      to `path`; the others poll for `path`, refuse payloads older than kStaleS or for another world
+//                      size, and confirm with a marker `path.<r>` that carries the nonce.  Rank 0 waits for every marker
+//                      OF THIS NONCE (a stale one is unlinked and waited for again), then removes all of it -- also when it
+//                      gives up.  (A reader that beats rank 0 to a younger-than-kStaleS leftover of a crashed job with the
+//                      same path still gets that job's id: keep the path unique per job -- default_rendezvous keys it by
+//                      launcher pid and port -- or use tcp://.)
 constexpr int kBootTimeoutS = 120;
+constexpr int kStaleS = 300;
+constexpr uint64_t kMagic = 0x3144495544335846ull;  // "FX3DUID1"
+
+struct Hello { uint64_t magic, token; int32_t nranks, rank; };
+struct FilePayload { uint64_t magic, nonce; int64_t wall; int32_t nranks, pad; uint8_t id[128]; };
+
+uint64_t job_token() {
+    const char *e = getenv("FX3D_COMM_TOKEN");
+    uint64_t h = 1469598103934665603ull;  // FNV-1a of the string; 0 when unset
+    if (!e || !*e) return 0;
+    for (; *e; ++e) { h ^= (unsigned char)*e; h *= 1099511628211ull; }
+    return h;
+}
+
+uint64_t fresh_nonce() {
+    uint64_t n = 0;
+    const int fd = ::open("/dev/urandom", O_RDONLY | O_CLOEXEC);
+    if (fd >= 0) { if (::read(fd, &n, sizeof(n)) != (ssize_t)sizeof(n)) n = 0; ::close(fd); }
+    n ^= (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9E3779B97F4A7C15ull;
+    n ^= (uint64_t)::getpid() << 32;
+    return n ? n : 1;
+}
 
 bool send_all(int fd, const void *buf, size_t n) {
     const char *p = static_cast<const char *>(buf);
@@ -108,29 +153,45 @@ bool recv_all(int fd, void *buf, size_t n) {
 
 fx3d_status boot_tcp(const std::string &host, int port, int nranks, int rank, uint8_t *id128) {
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(kBootTimeoutS);
+    const uint64_t token = job_token();
     if (rank == 0) {
         const int ls = ::socket(AF_INET, SOCK_STREAM, 0);
         if (ls < 0) { set_error("fx3d_comm_exchange_id: socket() failed"); return FX3D_ERR_RCCL; }
         int one = 1;
         ::setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
         sockaddr_in a{};
-        a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(INADDR_ANY); a.sin_port = htons((uint16_t)port);
-        if (::bind(ls, reinterpret_cast<sockaddr *>(&a), sizeof(a)) != 0 || ::listen(ls, nranks) != 0) {
+        const bool loopback = host == "127.0.0.1" || host == "localhost";
+        a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(loopback ? INADDR_LOOPBACK : INADDR_ANY); a.sin_port = htons((uint16_t)port);
+        if (::bind(ls, reinterpret_cast<sockaddr *>(&a), sizeof(a)) != 0 || ::listen(ls, nranks + 8) != 0) {
             ::close(ls);
             set_error("fx3d_comm_exchange_id: cannot listen on port %d", port);
             return FX3D_ERR_RCCL;
         }
-        timeval tv{kBootTimeoutS, 0};
-        ::setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));  // accept() honours it
-        for (int served = 0; served < nranks - 1; ++served) {
+        std::vector<char> served((size_t)nranks, 0);
+        int nserved = 0;
+        while (nserved < nranks - 1) {
+            const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
+            if (left <= 0) break;
+            timeval tv{(time_t)(left / 1000), (suseconds_t)((left % 1000) * 1000)};
+            ::setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));  // accept() honours it
             const int c = ::accept(ls, nullptr, nullptr);
-            if (c < 0) { ::close(ls); set_error("fx3d_comm_exchange_id: %d of %d ranks connected within %d s", served, nranks - 1, kBootTimeoutS); return FX3D_ERR_RCCL; }
-            int32_t peer = -1;
-            const bool ok = recv_all(c, &peer, sizeof(peer)) && send_all(c, id128, 128);
-            ::close(c);
-            if (!ok || peer <= 0 || peer >= nranks) { ::close(ls); set_error("fx3d_comm_exchange_id: bad hand-shake from a peer"); return FX3D_ERR_RCCL; }
+            if (c < 0) continue;  // timed out or interrupted: the loop head decides
+            timeval ptv{5, 0};    // a peer that connects and stays silent must not hold the others up
+            ::setsockopt(c, SOL_SOCKET, SO_RCVTIMEO, &ptv, sizeof(ptv));
+            Hello h{};
+            const bool ok = recv_all(c, &h, sizeof(h)) && h.magic == kMagic && h.token == token && h.nranks == nranks &&
+                            h.rank > 0 && h.rank < nranks;
+            if (ok && send_all(c, &kMagic, sizeof(kMagic)) && send_all(c, id128, 128) && !served[(size_t)h.rank]) {
+                served[(size_t)h.rank] = 1;
+                ++nserved;
+            }
+            ::close(c);  // (anything else: dropped, keep accepting)
         }
         ::close(ls);
+        if (nserved < nranks - 1) {
+            set_error("fx3d_comm_exchange_id: %d of %d ranks connected within %d s", nserved, nranks - 1, kBootTimeoutS);
+            return FX3D_ERR_RCCL;
+        }
         return FX3D_OK;
     }
     addrinfo hints{}, *res = nullptr;
@@ -143,52 +204,108 @@ fx3d_status boot_tcp(const std::string &host, int port, int nranks, int rank, ui
     while (std::chrono::steady_clock::now() < deadline) {
         const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
         if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
-            const int32_t me = rank;
-            const bool ok = send_all(fd, &me, sizeof(me)) && recv_all(fd, id128, 128);
+            const Hello h{kMagic, token, nranks, rank};
+            uint64_t magic = 0;
+            const bool ok = send_all(fd, &h, sizeof(h)) && recv_all(fd, &magic, sizeof(magic)) && magic == kMagic && recv_all(fd, id128, 128);
             ::close(fd);
             if (ok) { rc = FX3D_OK; break; }
         } else if (fd >= 0) {
             ::close(fd);
         }
-        std::this_thread::sleep_for(std::chrono::milliseconds(50));  // rank 0 is not listening yet
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));  // rank 0 is not listening yet (or refused us: another job's port)
     }
     ::freeaddrinfo(res);
     if (rc != FX3D_OK) set_error("fx3d_comm_exchange_id: rank %d could not reach rank 0 at %s:%d within %d s", rank, host.c_str(), port, kBootTimeoutS);
     return rc;
 }
 
+bool write_new_file(const std::string &f, const void *buf, size_t n) {  // never through a symlink, never over an existing file
+    ::unlink(f.c_str());
+    const int fd = ::open(f.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return false;
+    const bool ok = ::write(fd, buf, n) == (ssize_t)n;
+    ::close(fd);
+    if (!ok) ::unlink(f.c_str());
+    return ok;
+}
+bool read_file(const std::string &f, void *buf, size_t n) {
+    const int fd = ::open(f.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return false;
+    const bool ok = ::read(fd, buf, n) == (ssize_t)n;
+    ::close(fd);
+    return ok;
+}
+
 fx3d_status boot_file(const std::string &path, int nranks, int rank, uint8_t *id128) {
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(kBootTimeoutS);
-    auto exists = [](const std::string &f) { struct stat st; return ::stat(f.c_str(), &st) == 0; };
+    auto marker = [&](int r) { return path + "." + std::to_string(r); };
+    auto okfile = [&](int r) { return path + "." + std::to_string(r) + ".ok"; };
+    auto gone = [](const std::string &f) { struct stat st; return ::lstat(f.c_str(), &st) != 0; };
     if (rank == 0) {
+        auto cleanup = [&] {
+            ::unlink(path.c_str());
+            ::unlink((path + ".tmp").c_str());
+            for (int r = 1; r < nranks; ++r) { ::unlink(marker(r).c_str()); ::unlink(okfile(r).c_str()); }
+        };
+        cleanup();  // whatever an earlier job left behind
+        FilePayload pl{};
+        pl.magic = kMagic; pl.nonce = fresh_nonce(); pl.wall = (int64_t)::time(nullptr); pl.nranks = nranks;
+        memcpy(pl.id, id128, 128);
         const std::string tmp = path + ".tmp";
-        FILE *fh = ::fopen(tmp.c_str(), "wb");
-        if (!fh || ::fwrite(id128, 1, 128, fh) != 128) { if (fh) ::fclose(fh); set_error("fx3d_comm_exchange_id: cannot write %s", tmp.c_str()); return FX3D_ERR_RCCL; }
-        ::fclose(fh);
-        if (::rename(tmp.c_str(), path.c_str()) != 0) { set_error("fx3d_comm_exchange_id: cannot publish %s", path.c_str()); return FX3D_ERR_RCCL; }
-        for (int r = 1; r < nranks; ++r) {  // wait for every reader, then leave nothing behind
-            const std::string mark = path + "." + std::to_string(r);
-            while (!exists(mark)) {
-                if (std::chrono::steady_clock::now() > deadline) { set_error("fx3d_comm_exchange_id: rank %d never read %s", r, path.c_str()); return FX3D_ERR_RCCL; }
-                std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        if (!write_new_file(tmp, &pl, sizeof(pl))) { set_error("fx3d_comm_exchange_id: cannot write %s", tmp.c_str()); return FX3D_ERR_RCCL; }
+        if (::rename(tmp.c_str(), path.c_str()) != 0) { cleanup(); set_error("fx3d_comm_exchange_id: cannot publish %s", path.c_str()); return FX3D_ERR_RCCL; }
+        for (int r = 1; r < nranks; ++r) {  // every reader confirms with THIS job's nonce ...
+            for (;;) {
+                uint64_t got = 0;
+                if (read_file(marker(r), &got, sizeof(got))) {
+                    if (got == pl.nonce) break;
+                    ::unlink(marker(r).c_str());  // a marker of another job (its reader saw a stale file): the reader starts over
+                }
+                if (std::chrono::steady_clock::now() > deadline) {
+                    cleanup();
+                    set_error("fx3d_comm_exchange_id: rank %d never confirmed %s", r, path.c_str());
+                    return FX3D_ERR_RCCL;
+                }
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
             }
-            ::unlink(mark.c_str());
         }
-        ::unlink(path.c_str());
+        // ... is told so (only now may it use the id), takes its two files away, and rank 0 removes the rest
+        for (int r = 1; r < nranks; ++r)
+            if (!write_new_file(okfile(r), &pl.nonce, sizeof(pl.nonce))) { cleanup(); set_error("fx3d_comm_exchange_id: cannot write %s", okfile(r).c_str()); return FX3D_ERR_RCCL; }
+        for (int r = 1; r < nranks; ++r)
+            while (!gone(okfile(r))) {
+                if (std::chrono::steady_clock::now() > deadline) { cleanup(); set_error("fx3d_comm_exchange_id: rank %d never picked its acknowledgement up", r); return FX3D_ERR_RCCL; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            }
+        cleanup();
         return FX3D_OK;
     }
-    while (!exists(path)) {
-        if (std::chrono::steady_clock::now() > deadline) { set_error("fx3d_comm_exchange_id: %s did not appear within %d s", path.c_str(), kBootTimeoutS); return FX3D_ERR_RCCL; }
-        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    uint64_t confirmed = 0;
+    for (;;) {
+        FilePayload pl{};
+        if (read_file(path, &pl, sizeof(pl)) && pl.magic == kMagic && pl.nranks == nranks &&
+            (int64_t)::time(nullptr) - pl.wall <= kStaleS && pl.nonce != confirmed) {
+            // a first payload, or rank 0 replaced a stale one after we had confirmed that
+            memcpy(id128, pl.id, 128);
+            if (!write_new_file(marker(rank), &pl.nonce, sizeof(pl.nonce))) { set_error("fx3d_comm_exchange_id: cannot write %s", marker(rank).c_str()); return FX3D_ERR_RCCL; }
+            confirmed = pl.nonce;
+        }
+        if (confirmed) {
+            uint64_t ack = 0;
+            if (read_file(okfile(rank), &ack, sizeof(ack)) && ack == confirmed) {
+                ::unlink(marker(rank).c_str());
+                ::unlink(okfile(rank).c_str());
+                return FX3D_OK;
+            }
+            if (gone(marker(rank))) confirmed = 0;  // rank 0 wiped it (it belonged to a stale payload): confirm again
+        }
+        if (std::chrono::steady_clock::now() > deadline) {
+            ::unlink(marker(rank).c_str());
+            set_error("fx3d_comm_exchange_id: %s: no (fresh) unique id from rank 0 within %d s", path.c_str(), kBootTimeoutS);
+            return FX3D_ERR_RCCL;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(10));
     }
-    FILE *fh = ::fopen(path.c_str(), "rb");
-    const bool ok = fh && ::fread(id128, 1, 128, fh) == 128;
-    if (fh) ::fclose(fh);
-    if (!ok) { set_error("fx3d_comm_exchange_id: short read of %s", path.c_str()); return FX3D_ERR_RCCL; }
-    const std::string mark = path + "." + std::to_string(rank);
-    fh = ::fopen(mark.c_str(), "wb");
-    if (fh) ::fclose(fh);
-    return FX3D_OK;
 }
 
 }  // namespace
@@ -289,6 +406,14 @@ fx3d_status fx3d_comm_allreduce_sum_f64(fx3d_comm_t comm, double *buf_dev, int64
     return rc ? rccl_fail(rc, "ncclAllReduce") : FX3D_OK;
 }
 
+fx3d_status fx3d_comm_allreduce_max_f64(fx3d_comm_t comm, double *buf_dev, int64_t count, fx3d_stream_t s) {
+    FX3D_REQUIRE(comm && buf_dev && count > 0, "fx3d_comm_allreduce_max_f64: bad argument");
+    Rccl *r = rccl();
+    if (!r) { set_error("librccl could not be loaded"); return FX3D_ERR_RCCL; }
+    const int rc = r->allreduce(buf_dev, buf_dev, (size_t)count, kNcclFloat64, kNcclMax, comm, as_stream(s));
+    return rc ? rccl_fail(rc, "ncclAllReduce") : FX3D_OK;
+}
+
 // chamfer_distance over a batch sharded across the ranks of `comm`: this rank's shard in, the GLOBAL
 // loss out on every rank.  kernel (partials reduced in-launch) -> all-reduce(sum) of 2 Float64 ->
 // finalise with the global batch size; all on `s`.
@@ -346,6 +471,211 @@ fx3d_status fx3d_chamfer_fwd_sharded_async(fx3d_comm_t comm, const float *x, int
     if (rc) return rc;
     FX3D_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(done), as_stream(comm_stream)));
     return FX3D_OK;
+}
+
+}  // extern "C"
+
+// ---- one process, several devices (fx3d_comm_init_all) ---------------------------------------------------
+// The reference is ONE Julia process (src/metrics/pcloud.jl:54-70); with the per-rank entry points above such a host
+// would have to spawn a process per GPU to shard a batch.  fx3d_comm_init_all builds the communicators of `ndev` devices
+// of this process (ncclCommInitAll) plus one worker thread, one stream and the scratch of a sharded evaluation per device;
+// fx3d_chamfer_fwd_multi hands every worker its shard: kernel -> all-reduce(sum) of the two Float64 -> finalise with the
+// global batch size, each on its device's stream, the host thread of the caller only waits for the enqueues (one thread
+// per device: eight launches of ~10 us each from a single thread would make a 50 us evaluation host bound; one thread per
+// communicator is RCCL's supported single-process form, no group call needed).
+namespace {
+
+struct Worker {
+    int dev = 0;
+    ncclComm_t_ comm = nullptr;
+    hipStream_t stream = nullptr;
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    double *sums = nullptr;
+    float *loss = nullptr;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<fx3d_status()> job;
+    bool has_job = false, busy = false, quit = false;
+    fx3d_status rc = FX3D_OK;
+    std::string err;
+
+    void loop() {
+        fx3d_status rc0 = FX3D_OK;
+        if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&sums), 2 * sizeof(double)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&loss), sizeof(float)) != hipSuccess)
+            rc0 = FX3D_ERR_HIP;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return has_job || quit; });
+            if (quit) break;
+            std::function<fx3d_status()> j = std::move(job);
+            has_job = false;
+            lk.unlock();
+            fx3d_status r = rc0 ? rc0 : j();
+            std::string e;
+            if (r) {
+                char buf[512];
+                buf[0] = 0;
+                if (rc0) snprintf(buf, sizeof(buf), "device %d: stream / scratch setup failed", dev);
+                else fx3d_last_error(buf, sizeof(buf));
+                e = buf;
+            }
+            lk.lock();
+            rc = r; err = std::move(e); busy = false;
+            cv.notify_all();
+        }
+        if (ws) (void)hipFree(ws);
+        if (sums) (void)hipFree(sums);
+        if (loss) (void)hipFree(loss);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    void post(std::function<fx3d_status()> j) {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(j); has_job = true; busy = true;
+        cv.notify_all();
+    }
+    fx3d_status wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !busy; });
+        return rc;
+    }
+};
+
+struct Multi {
+    std::vector<Worker *> w;
+};
+
+fx3d_status run_all(Multi *m, const std::function<fx3d_status(Worker &, int)> &f) {
+    for (size_t d = 0; d < m->w.size(); ++d) {
+        Worker *w = m->w[d];
+        const int di = (int)d;
+        w->post([w, di, &f] { return f(*w, di); });
+    }
+    fx3d_status rc = FX3D_OK;
+    std::string err;
+    for (Worker *w : m->w) {  // (every worker is waited for: `f` is referenced until the last one returns)
+        const fx3d_status r = w->wait();
+        if (r && !rc) { rc = r; err = w->err; }
+    }
+    if (rc) set_error("%s", err.c_str());
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+fx3d_status fx3d_comm_init_all(fx3d_multi_t *multi, int32_t ndev, const int32_t *devices) {
+    FX3D_REQUIRE(multi && ndev > 0 && ndev <= 64, "fx3d_comm_init_all: bad argument (ndev=%d)", ndev);
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) { set_error("fx3d_comm_init_all: no HIP device"); return FX3D_ERR_NO_DEVICE; }
+    std::vector<int> devs((size_t)ndev);
+    for (int d = 0; d < ndev; ++d) {
+        devs[(size_t)d] = devices ? devices[d] : d;
+        FX3D_REQUIRE(devs[(size_t)d] >= 0 && devs[(size_t)d] < have, "fx3d_comm_init_all: device %d of %d", devs[(size_t)d], have);
+        for (int e = 0; e < d; ++e) FX3D_REQUIRE(devs[(size_t)e] != devs[(size_t)d], "fx3d_comm_init_all: device %d listed twice", devs[(size_t)d]);
+    }
+    Rccl *r = rccl();
+    if (!r || !r->init_all) { set_error("librccl (ncclCommInitAll) could not be loaded"); return FX3D_ERR_RCCL; }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    std::vector<ncclComm_t_> comms((size_t)ndev, nullptr);
+    const int rc = r->init_all(comms.data(), ndev, devs.data());
+    (void)hipSetDevice(prev);  // (ncclCommInitAll walks the devices)
+    if (rc) return rccl_fail(rc, "ncclCommInitAll");
+    Multi *m = new Multi;
+    for (int d = 0; d < ndev; ++d) {
+        Worker *w = new Worker;
+        w->dev = devs[(size_t)d];
+        w->comm = comms[(size_t)d];
+        w->th = std::thread([w] { w->loop(); });
+        m->w.push_back(w);
+    }
+    *multi = m;
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_multi_destroy(fx3d_multi_t multi) {
+    if (!multi) return FX3D_OK;
+    Multi *m = static_cast<Multi *>(multi);
+    Rccl *r = rccl();
+    for (Worker *w : m->w) {
+        (void)w->wait();
+        { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; w->cv.notify_all(); }
+        if (w->th.joinable()) w->th.join();
+        if (r && w->comm) (void)r->destroy(w->comm);
+        delete w;
+    }
+    delete m;
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_multi_info(fx3d_multi_t multi, int32_t *ndev, int32_t *devices, int32_t *rccl_version) {
+    FX3D_REQUIRE(multi, "fx3d_multi_info: null handle");
+    Multi *m = static_cast<Multi *>(multi);
+    if (ndev) *ndev = (int32_t)m->w.size();
+    if (devices) for (size_t d = 0; d < m->w.size(); ++d) devices[d] = m->w[d]->dev;
+    if (rccl_version) return fx3d_comm_info(nullptr, nullptr, nullptr, rccl_version);
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_multi_sync(fx3d_multi_t multi) {
+    FX3D_REQUIRE(multi, "fx3d_multi_sync: null handle");
+    return run_all(static_cast<Multi *>(multi), [](Worker &w, int) -> fx3d_status {
+        FX3D_HIP(hipStreamSynchronize(w.stream));
+        return FX3D_OK;
+    });
+}
+
+// x[d], y[d]: device d's shard ((D,N,B_local[d]) / (D,M,B_local[d]) in ITS memory; ignored where B_local[d] == 0).
+// loss_host (optional): the global loss, read back from the first device (blocks until it is there); losses_dev
+// (optional, [ndev] device pointers in each device's memory): every device's copy of it, valid after fx3d_multi_sync.
+fx3d_status fx3d_chamfer_fwd_multi(fx3d_multi_t multi, const float *const *x, int32_t N, const float *const *y, int32_t M,
+                                   const int32_t *B_local, int32_t D, int64_t B_global, float w1, float w2,
+                                   float *loss_host, float *const *losses_dev) {
+    FX3D_REQUIRE(multi && x && y && B_local, "fx3d_chamfer_fwd_multi: null pointer");
+    FX3D_REQUIRE(N > 0 && M > 0 && D > 0 && B_global > 0, "fx3d_chamfer_fwd_multi: bad sizes");
+    Multi *m = static_cast<Multi *>(multi);
+    long long tot = 0;
+    for (size_t d = 0; d < m->w.size(); ++d) {
+        FX3D_REQUIRE(B_local[d] >= 0, "fx3d_chamfer_fwd_multi: negative shard size on device slot %zu", d);
+        FX3D_REQUIRE(B_local[d] == 0 || (x[d] && y[d]), "fx3d_chamfer_fwd_multi: null shard on device slot %zu", d);
+        tot += B_local[d];
+    }
+    FX3D_REQUIRE(tot <= B_global, "fx3d_chamfer_fwd_multi: the shards hold %lld clouds, B_global = %lld", tot, (long long)B_global);
+    return run_all(m, [&](Worker &w, int d) -> fx3d_status {
+        const int Bl = B_local[d];
+        fx3d_stream_t st = reinterpret_cast<fx3d_stream_t>(w.stream);
+        if (Bl > 0) {
+            size_t need = 0;
+            fx3d_status rc = fx3d_chamfer_workspace_bytes(N, M, Bl, D, &need);
+            if (rc) return rc;
+            if (need > w.ws_bytes) {
+                FX3D_HIP(hipStreamSynchronize(w.stream));  // (an earlier evaluation may still use the old scratch)
+                if (w.ws) FX3D_HIP(hipFree(w.ws));
+                w.ws = nullptr; w.ws_bytes = 0;
+                FX3D_HIP(hipMalloc(&w.ws, need));
+                w.ws_bytes = need;
+            }
+            rc = fx3d_chamfer_sums(x[d], N, y[d], M, Bl, D, w.sums, nullptr, nullptr, w.ws, w.ws_bytes, st);
+            if (rc) return rc;
+        } else {
+            FX3D_HIP(hipMemsetAsync(w.sums, 0, 2 * sizeof(double), w.stream));
+        }
+        fx3d_status rc = fx3d_comm_allreduce_sum_f64(w.comm, w.sums, 2, st);
+        if (rc) return rc;
+        float *out = losses_dev && losses_dev[d] ? losses_dev[d] : w.loss;
+        rc = fx3d_chamfer_finalize(w.sums, N, M, B_global, D, w1, w2, out, st);
+        if (rc) return rc;
+        if (d == 0 && loss_host) {
+            FX3D_HIP(hipMemcpyAsync(loss_host, out, sizeof(float), hipMemcpyDeviceToHost, w.stream));
+            FX3D_HIP(hipStreamSynchronize(w.stream));
+        }
+        return FX3D_OK;
+    });
 }
 
 }  // extern "C"

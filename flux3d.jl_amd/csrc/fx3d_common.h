@@ -61,6 +61,27 @@ struct ProfileScope {  // brackets one dominant-kernel launch when profiling is 
     }
 };
 
+// ---- variant switches (runtime.hip): explicit options instead of environment reads on the launch path.  The FX3D_*
+//      environment variables of the same names only seed the defaults, once, at the first use of the library;
+//      fx3d_set_option / fx3d_get_option (flux3d_hip.h) change / read them afterwards.  Process-wide, atomic.
+enum Opt {
+    OPT_NN1_VARIANT,          // 3 = fp16-split MFMA filter + exact re-scan (default), 0 = the exact VALU loop (A/B)
+    OPT_NN1_TPB,              // > 0: query passes per block forced (launch-plan experiments)
+    OPT_NN1_NOSPLIT,          // 1: never split the candidates of a cloud over blocks
+    OPT_BWD_GLOBAL_ATOMICS,   // 1: chamfer adjoint with global float atomics instead of the LDS accumulator
+    OPT_KNN_F32,              // 1: feature-space kNN filter as the Float32 GEMM
+    OPT_KNN_F16_SPLIT,        // 1: feature-space kNN filter on 2-way fp16 splits
+    OPT_KNN_NO_MFMA,          // 1: wave-per-query kernels only
+    OPT_KNN_NO_PREPASS,       // 1: fx3d_knn_ws ignores its scratch (no per-cloud pre-pass)
+    OPT_KNN_GATHER,           // 1: exact phase gathers candidate rows from L2 instead of staging them through LDS
+    OPT_KNN_D3_WAVE,          // 1: D = 3 kNN on the wave-per-query kernel
+    OPT_EDGE_SCALAR_STORES,   // 1: edge features written with 4-byte stores
+    OPT_EDGECONV_UNFUSED,     // 1: EdgeConv graph build as search + feature kernels
+    OPT_CDF_MULTIBLOCK_FROM,  // faces per mesh from which the sampling CDF takes the multi-block path (0 = the built-in limit)
+    OPT_COUNT
+};
+int opt(Opt o);
+
 constexpr int kWave = 64;  // gfx950 wavefront
 
 // ||(v2-v1) x (v3-v1)|| / 2 : _lg_cross (src/rep/utils.jl:4-21), _norm (:29),

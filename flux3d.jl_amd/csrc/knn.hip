@@ -3352,8 +3352,7 @@ bool knn_pre_eligible(const float *x, const float *y, int M, int D, int kk) {
     const int rq = D / 4;
     if (kPreThreads % rq != 0 || rq > 32) return false;
     if (((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x)) & 15) != 0) return false;
-    const char *e1 = getenv("FX3D_KNN_F32"), *e2 = getenv("FX3D_KNN_F16_SPLIT"), *e3 = getenv("FX3D_KNN_NO_MFMA"), *e4 = getenv("FX3D_KNN_NO_PREPASS");
-    return !((e1 && atoi(e1)) || (e2 && atoi(e2)) || e3 || (e4 && atoi(e4)));
+    return !(opt(OPT_KNN_F32) || opt(OPT_KNN_F16_SPLIT) || opt(OPT_KNN_NO_MFMA) || opt(OPT_KNN_NO_PREPASS));
 }
 
 template <int DK, bool F16, bool SPLIT>
@@ -3394,7 +3393,7 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     const int DS = DP > 64 && D > 64 ? 64 : D;  // staged width of a row: D > 64 goes through in two column halves
     const int PR = DS / 4;
     const bool stageable = D % 4 == 0 && (kMThreads % PR) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
-                           !getenv("FX3D_KNN_GATHER");
+                           !opt(OPT_KNN_GATHER);
     if (stageable) {
         const size_t room = 152 * 1024 - (img * 4 + small);
         for (int l = 8; l >= 5; --l) {
@@ -3435,12 +3434,10 @@ fx3d_status launch_knn_mfma(const float *x, int N, const float *y, int M, int B,
                             float *dist, hipStream_t st, void *pre_ws = nullptr) {
     const int dk = (D + 31) / 32;
     // fp16-split filter: needs 16-byte loads (D % 4 == 0, aligned clouds) and all norms in LDS up front
-    const char *f32_env = getenv("FX3D_KNN_F32");  // read per call: the tests flip it
-    const bool f32_only = f32_env && atoi(f32_env);
+    const bool f32_only = opt(OPT_KNN_F32) != 0;  // (fx3d_set_option: the tests flip it)
     const bool f16 = !f32_only && D % 4 == 0 && M <= 4096 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
                      ((size_t)M * D * 4) % 16 == 0;
-    const char *split_env = getenv("FX3D_KNN_F16_SPLIT");
-    if (f16 && split_env && atoi(split_env)) {  // 2-way split operands: 3 MFMAs per K block, band 2^-18 instead of 2^-10
+    if (f16 && opt(OPT_KNN_F16_SPLIT)) {  // 2-way split operands: 3 MFMAs per K block, band 2^-18 instead of 2^-10
         switch (dk) {
             case 1: return launch_knn_mfma_dk<1, true, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
             case 2: return launch_knn_mfma_dk<2, true, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
@@ -3506,13 +3503,13 @@ fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int 
         FX3D_LAUNCH_CHECK();
         return FX3D_OK;
     }
-    if (D == 3 && !getenv("FX3D_KNN_D3_WAVE") && kk <= 32 && M >= 64 && M < (1 << 21))
+    if (D == 3 && !opt(OPT_KNN_D3_WAVE) && kk <= 32 && M >= 64 && M < (1 << 21))
         return launch_knn_f16_d3(x, N, y, M, B, k, drop, idx, dist, st);
     if (D == 3) {
         const int qpb = (kWThreads / 64) * kWQ;
         hipLaunchKernelGGL(knn_wave_d3_kernel, dim3((N + qpb - 1) / qpb, B), dim3(kWThreads), 0, st, x, N, y, M, B, k,
                            drop, idx, dist);
-    } else if (!getenv("FX3D_KNN_NO_MFMA") && knn_mfma_eligible(M, D, kk)) {
+    } else if (!opt(OPT_KNN_NO_MFMA) && knn_mfma_eligible(M, D, kk)) {
         return launch_knn_mfma(x, N, y, M, B, D, k, drop, idx, dist, st, pre_ws);
     } else {
         const int qpb = (kWThreads / 64) * kGQ;
@@ -3610,7 +3607,7 @@ fx3d_status fx3d_edge_features(const float *x, int32_t N, int32_t B, int32_t F, 
         const long long KN = (long long)k * N;
         dim3 grid((unsigned)((KN + kThreads - 1) / kThreads), B);
         const bool al16 = (((uintptr_t)x | (uintptr_t)out | (uintptr_t)idx) & 15) == 0;
-        if (F % 4 == 0 && KN % 4 == 0 && al16 && !getenv("FX3D_EDGE_SCALAR_STORES"))
+        if (F % 4 == 0 && KN % 4 == 0 && al16 && !opt(OPT_EDGE_SCALAR_STORES))
             hipLaunchKernelGGL(edge_features_mlp4_kernel, dim3((unsigned)((KN / 4 + kThreads - 1) / kThreads), B), dim3(kThreads),
                                0, as_stream(s), x, N, B, F, k, idx, out);
         else if (F % 4 == 0 && ((uintptr_t)x & 15) == 0)
@@ -3641,8 +3638,8 @@ fx3d_status fx3d_edgeconv_graph(const float *x, int32_t N, int32_t B, int32_t F,
     FX3D_REQUIRE(idx, "fx3d_edgeconv_graph: idx (k,N,B) is required (it is also the adjoint's side input)");
     FX3D_REQUIRE(x && out && N > 0 && B > 0 && F > 0 && k > 0, "fx3d_edgeconv_graph: bad argument");
     FX3D_REQUIRE(layout == 0 || layout == 1, "fx3d_edgeconv_graph: layout must be 0 (2F,K,N,B) or 1 (K*N,2F,B)");
-    if (F == 3 && k + 1 <= 32 && k + 1 <= N && N >= 64 && N < (1 << 21) && !getenv("FX3D_KNN_D3_WAVE") &&
-        !getenv("FX3D_EDGECONV_UNFUSED")) {
+    if (F == 3 && k + 1 <= 32 && k + 1 <= N && N >= 64 && N < (1 << 21) && !opt(OPT_KNN_D3_WAVE) &&
+        !opt(OPT_EDGECONV_UNFUSED)) {
         // first EdgeConv (coordinates): neighbour search and features in ONE kernel
         ProfileScope prof("edgeconv_graph", as_stream(s));
         return launch_knn_f16_d3(x, N, x, N, B, k, 1, idx, nullptr, as_stream(s), out, layout);

@@ -22,6 +22,48 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// ---- variant switches ---------------------------------------------------------------------------
+namespace {
+struct OptDef { const char *name, *env; int dflt; };
+// (order = enum Opt)
+const OptDef kOptDefs[OPT_COUNT] = {
+    {"nn1_variant", "FX3D_NN1_VARIANT", 3},
+    {"nn1_tpb", "FX3D_NN1_TPB", 0},
+    {"nn1_nosplit", "FX3D_NN1_NOSPLIT", 0},
+    {"bwd_global_atomics", "FX3D_BWD_GLOBAL_ATOMICS", 0},
+    {"knn_f32", "FX3D_KNN_F32", 0},
+    {"knn_f16_split", "FX3D_KNN_F16_SPLIT", 0},
+    {"knn_no_mfma", "FX3D_KNN_NO_MFMA", 0},
+    {"knn_no_prepass", "FX3D_KNN_NO_PREPASS", 0},
+    {"knn_gather", "FX3D_KNN_GATHER", 0},
+    {"knn_d3_wave", "FX3D_KNN_D3_WAVE", 0},
+    {"edge_scalar_stores", "FX3D_EDGE_SCALAR_STORES", 0},
+    {"edgeconv_unfused", "FX3D_EDGECONV_UNFUSED", 0},
+    {"cdf_multiblock_from", "FX3D_CDF_MULTIBLOCK_FROM", 0},
+};
+std::atomic<int> g_opt[OPT_COUNT];
+std::once_flag g_opt_once;
+void opt_init() {
+    std::call_once(g_opt_once, [] {
+        for (int i = 0; i < OPT_COUNT; ++i) {
+            const char *e = getenv(kOptDefs[i].env);  // the environment seeds the defaults, once
+            g_opt[i].store(e && *e ? atoi(e) : kOptDefs[i].dflt, std::memory_order_relaxed);
+        }
+    });
+}
+int opt_index(const char *name) {
+    if (!name) return -1;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(name, kOptDefs[i].name) || !strcmp(name, kOptDefs[i].env)) return i;
+    return -1;
+}
+}  // namespace
+
+int opt(Opt o) {
+    opt_init();
+    return g_opt[o].load(std::memory_order_relaxed);
+}
+
 // ---- per-kernel event timing -------------------------------------------------------------------
 namespace {
 struct ProfRec { const char *name; hipEvent_t e0, e1; };
@@ -68,6 +110,27 @@ using namespace fx3d;
 extern "C" {
 
 const char *fx3d_version(void) { return "flux3d_hip 0.1.0 (gfx950)"; }
+
+fx3d_status fx3d_set_option(const char *name, int32_t value) {
+    const int i = fx3d::opt_index(name);
+    if (i < 0) { fx3d::set_error("fx3d_set_option: unknown option %s", name ? name : "(null)"); return FX3D_ERR_INVALID_ARG; }
+    fx3d::opt_init();
+    fx3d::g_opt[i].store(value, std::memory_order_relaxed);
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_get_option(const char *name, int32_t *value) {
+    const int i = fx3d::opt_index(name);
+    if (i < 0 || !value) { fx3d::set_error("fx3d_get_option: unknown option %s", name ? name : "(null)"); return FX3D_ERR_INVALID_ARG; }
+    *value = fx3d::opt(static_cast<fx3d::Opt>(i));
+    return FX3D_OK;
+}
+
+int32_t fx3d_option_count(void) { return fx3d::OPT_COUNT; }
+
+const char *fx3d_option_name(int32_t index) {
+    return index >= 0 && index < fx3d::OPT_COUNT ? fx3d::kOptDefs[index].name : nullptr;
+}
 
 size_t fx3d_last_error(char *buf, size_t n) {
     size_t len = strlen(g_err);

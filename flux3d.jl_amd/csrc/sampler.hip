@@ -534,8 +534,8 @@ fx3d_status fx3d_sample_points_cdf(const float *verts_padded, int32_t Vmax, cons
     const int Fp = W.Fp;
     double *cdf = reinterpret_cast<double *>(ws);
     ProfileScope prof("sample_cdf", st);
-    const char *mb_e = getenv("FX3D_CDF_MULTIBLOCK_FROM");  // (read per call: the tests lower the switch point)
-    const int mb_from = mb_e && atoi(mb_e) > 0 ? atoi(mb_e) : kCdfBlockFaces;
+    const int mb_opt = opt(OPT_CDF_MULTIBLOCK_FROM);  // (fx3d_set_option: the tests lower the switch point)
+    const int mb_from = mb_opt > 0 ? mb_opt : kCdfBlockFaces;
     if (Fmax > mb_from || Fmax > kCdfBlockFaces) {
         const int nb = (W.nchp / kChunk + kChunk - 1) / kChunk, nsub = (Fp + kCdfSub - 1) / kCdfSub;
         FX3D_REQUIRE(nb <= kChunk * kChunk, "fx3d_sample_points_cdf: more than 33 554 432 faces per mesh");

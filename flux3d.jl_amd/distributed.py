@@ -113,16 +113,21 @@ class ShardedChamfer:
 
 
 def default_rendezvous():
-    """Where the ranks of one node meet to pass the RCCL unique id (fx3d_comm_bootstrap).  ``FX3D_COMM_RENDEZVOUS``
-    if set (``tcp://host:port`` or ``file://path``); otherwise a file in the temp directory keyed by the launcher's
-    pid and MASTER_PORT -- every rank of one torchrun shares both, a later job shares neither, and rank 0 removes
-    the file once all ranks have read it."""
+    """Where the ranks meet to pass the RCCL unique id (fx3d_comm_bootstrap).  ``FX3D_COMM_RENDEZVOUS`` if set
+    (``tcp://host:port`` or ``file://path``).  Under a launcher that exports MASTER_ADDR / MASTER_PORT (torchrun):
+    ``tcp://MASTER_ADDR:(MASTER_PORT + 1)`` -- the launcher's own store owns MASTER_PORT; nothing persists, a crashed
+    earlier job cannot leave state behind, and it works across nodes.  Without one: a file in the temp directory keyed
+    by the launcher's pid (single node; the library removes stale files, confirms a per-job nonce and cleans up)."""
     import os
     import tempfile
     r = os.environ.get("FX3D_COMM_RENDEZVOUS")
     if r:
         return r
-    return "file://" + os.path.join(tempfile.gettempdir(), f"fx3d_uid_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}")
+    addr, port = os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")
+    if addr and port and port.isdigit():
+        p = int(port) + 1
+        return f"tcp://{addr}:{p if p < 65536 else int(port) - 1}"
+    return "file://" + os.path.join(tempfile.gettempdir(), f"fx3d_uid_{os.getuid()}_{os.getppid()}")
 
 
 class NativeComm:
@@ -155,6 +160,20 @@ class NativeComm:
 
     def allreduce_sum(self, buf):
         _lib.call("fx3d_comm_allreduce_sum_f64", self.handle, buf.ptr, buf.size, current_stream().handle)
+
+    def allreduce_max(self, buf):
+        _lib.call("fx3d_comm_allreduce_max_f64", self.handle, buf.ptr, buf.size, current_stream().handle)
+
+    def max_over_ranks(self, value):
+        """Host float -> its maximum over the ranks (one 8-byte all-reduce(max) on the current stream; also a barrier)."""
+        if getattr(self, "_scalar", None) is None:
+            self._scalar = DeviceArray.empty((1,), np.float64)
+        self._scalar.copy_(np.array([float(value)], np.float64))
+        self.allreduce_max(self._scalar)
+        return float(self._scalar.to_host()[0])
+
+    def barrier(self):
+        self.max_over_ranks(0.0)
 
     def __del__(self):
         if getattr(self, "handle", None):
@@ -191,14 +210,25 @@ class NativeShardedChamfer:
             self.done = [Event(timing=False) for _ in range(self.nslot)]
 
     def __call__(self, x_shard, y_shard, B_global, w1=1.0, w2=1.0, sync=True):
-        key = (id(x_shard), id(y_shard), getattr(x_shard, "shape", None), getattr(y_shard, "shape", None))
-        plan = self._plan if self._plan_key == key else None
-        if plan is None:  # shape checks and the workspace query once per (arrays, shapes): the step is host-bound otherwise
-            x, y = _as_dev_points(x_shard), _as_dev_points(y_shard)
+        # The plan (shape checks + workspace query: the step is host bound otherwise) is cached for DEVICE inputs only, keyed
+        # by what the kernel will actually read -- (pointer, shape) of both arrays -- and by the current stream (the
+        # workspace pool is per stream).  Host inputs (numpy, a host PointCloud) are uploaded on every call: a cached
+        # device copy of an array that was mutated in place, or whose id() a new array reuses, would silently return
+        # the old data's loss.
+        from .device import is_device
+        from .rep import PointCloud
+        xs = x_shard.points if isinstance(x_shard, PointCloud) else x_shard
+        ys = y_shard.points if isinstance(y_shard, PointCloud) else y_shard
+        key = None
+        if is_device(xs) and is_device(ys):
+            key = (xs.ptr, tuple(xs.shape), ys.ptr, tuple(ys.shape), current_stream().handle)
+        plan = self._plan if (key is not None and self._plan_key == key) else None
+        if plan is None:
+            x, y = _as_dev_points(xs), _as_dev_points(ys)
             D, N, M, Bs = _check_pair(x, y)
             ws = chamfer_workspace(N, M, max(Bs, 1), D)
-            plan = self._plan = (x, y, D, N, M, Bs, ws)
-            self._plan_key = key
+            plan = (x, y, D, N, M, Bs, ws)
+            self._plan, self._plan_key = (plan, key) if key is not None else (None, None)
         x, y, D, N, M, Bs, ws = plan
         i = self.k % self.nslot
         self.k += 1
@@ -228,6 +258,77 @@ class NativeShardedChamfer:
             with stream(self.side):
                 return np.float32(self.loss.item())
         return np.float32(self.loss.item())
+
+
+class MultiDevice:
+    """ONE process, several GPUs (fx3d_comm_init_all / fx3d_chamfer_fwd_multi): what a single Julia process -- the
+    reference's shape, src/metrics/pcloud.jl:54-70 -- uses instead of one process per GPU.  ``shard(a, d)`` uploads a
+    host slab to device ``d``; ``chamfer_distance(xs, ys, B_global)`` takes one device slab (or None) per device and
+    returns the global loss: every device runs kernel -> all-reduce(2 Float64) -> finalise on a worker thread and
+    stream owned by the library."""
+
+    def __init__(self, ndev=None, devices=None):
+        from .device import device_count
+        if devices is None:
+            ndev = device_count() if ndev is None else int(ndev)
+            devices = list(range(ndev))
+        self.devices = [int(d) for d in devices]
+        h = C.c_void_p()
+        arr = (C.c_int32 * len(self.devices))(*self.devices)
+        _lib.call("fx3d_comm_init_all", C.byref(h), len(self.devices), arr)
+        self.handle = h.value
+
+    @property
+    def ndev(self):
+        return len(self.devices)
+
+    def info(self):
+        n, v = C.c_int32(0), C.c_int32(0)
+        devs = (C.c_int32 * self.ndev)()
+        _lib.call("fx3d_multi_info", self.handle, C.byref(n), devs, C.byref(v))
+        return {"ndev": n.value, "devices": list(devs), "rccl_version": v.value}
+
+    def shard(self, host_array, slot):
+        """Upload a host (D,N,Bs) slab to the memory of device ``devices[slot]``."""
+        from .device import set_device
+        import contextlib
+        prev = C.c_int32(0)
+        _lib.call("fx3d_get_device", C.byref(prev))
+        set_device(self.devices[slot])
+        try:
+            return _as_dev_points(np.asfortranarray(host_array, dtype=np.float32))
+        finally:
+            set_device(prev.value)
+
+    def chamfer_distance(self, xs, ys, B_global, w1=1.0, w2=1.0):
+        if len(xs) != self.ndev or len(ys) != self.ndev:
+            raise ValueError("one shard (or None) per device")
+        k = next((i for i, a in enumerate(xs) if a is not None), None)
+        if k is None:
+            raise ValueError("no shard at all")
+        D, N, _ = xs[k].shape
+        M = ys[k].shape[1]
+        px = (C.c_void_p * self.ndev)(*[a.ptr if a is not None else None for a in xs])
+        py = (C.c_void_p * self.ndev)(*[a.ptr if a is not None else None for a in ys])
+        bl = (C.c_int32 * self.ndev)(*[a.shape[2] if a is not None else 0 for a in xs])
+        loss = C.c_float(0)
+        _lib.call("fx3d_chamfer_fwd_multi", self.handle, px, N, py, M, bl, D, int(B_global), float(w1), float(w2),
+                  C.byref(loss), None)
+        return np.float32(loss.value)
+
+    def synchronize(self):
+        _lib.call("fx3d_multi_sync", self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.load().fx3d_multi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- per-mesh losses over a batch sharded BY MESH (SURVEY.md 8e) ------------------------------------------

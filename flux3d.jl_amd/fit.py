@@ -79,7 +79,8 @@ class FitStepGraph:
     itself advances by two per replay, so every iteration draws fresh samples (the reference draws from the global
     RNG).  The constructor runs iteration 1 eagerly (``first_loss``) and records iteration 2; ``loss`` is the
     1-element device array every replay writes -- read it whenever a host value is wanted
-    (``float(step.loss.item())`` after ``synchronize()``): the only host round trip."""
+    (``float(step.loss.item())`` after ``synchronize()``): the only host round trip.  ``x`` belongs to the graph while
+    it is in use: after an external write to it call :meth:`resync`."""
 
     def __init__(self, x, src, tgt, opt, num_samples=5000, seed=0x5EED0C3, w_lap=0.1, w_edge=1.0):
         self.x, self.opt = x, opt
@@ -91,7 +92,8 @@ class FitStepGraph:
         # the seed counter (two launches less per iteration); the buffer is re-wrapped per body so that nothing derived from
         # the vertices (padded form, sampling CDF) is cached across iterations
         fused = src.N == 1 and hasattr(opt, "update_offset")
-        self.mverts = lincomb(1.0, src.dev("verts_packed"), 1.0, x) if fused else None
+        self._src_verts = src.dev("verts_packed")
+        self.mverts = lincomb(1.0, self._src_verts, 1.0, x) if fused else None
 
         def body():
             m = src.with_verts_packed(self.mverts) if fused else None
@@ -117,6 +119,16 @@ class FitStepGraph:
         self.graph.launch(self.stream)
         self.iterations += 1
         return self.loss
+
+    def resync(self):
+        """Call after writing ``x`` from outside (a reset, a projection, a checkpoint restore): the fused graph keeps the
+        offset mesh ``src + x`` in a buffer of its own that only its Momentum launch updates, so an external write to x
+        would otherwise leave the replays optimising from the old vertex positions.  Recomputes that buffer on
+        the graph's stream; a no-op for the unfused graph, whose body recomputes the offset every iteration."""
+        if self.mverts is not None:
+            current_stream().synchronize()  # the caller's write to x
+            with stream(self.stream):
+                lincomb(1.0, self._src_verts, 1.0, self.x, out=self.mverts)
 
     def synchronize(self):
         self.stream.synchronize()

@@ -658,6 +658,44 @@ function comm_info(c)
     return (nranks = Int(n[]), rank = Int(r[]), rccl_version = Int(v[]))
 end
 comm_destroy(c) = check(@ccall LIB.fx3d_comm_destroy(c::Ptr{Cvoid})::Int32)
+# all-reduce(max) of a Float64 device buffer: the control plane of a timing harness (max over ranks; any buffer: a barrier)
+comm_allreduce_max!(c, buf::HipArray{Float64}; stream::Stream = DEFAULT_STREAM) =
+    check(@ccall LIB.fx3d_comm_allreduce_max_f64(c::Ptr{Cvoid}, buf.ptr::Ptr{Cvoid}, length(buf)::Int64, stream::Stream)::Int32)
+
+# ---- ONE Julia process, several GPUs (the reference is one process: src/metrics/pcloud.jl:54-70) --------------------
+# m = comm_init_all(8); shards: set_device(d - 1) before hip(...) so that slab d lives on device d - 1;
+# loss = chamfer_distance_multi(m, As, Bs, B_global): every device runs kernel -> all-reduce(2 x Float64) -> finalise on a
+# worker thread + stream of the library; the call returns the global loss (read back from the first device).
+struct MultiDevice; handle::Ptr{Cvoid}; ndev::Int; end
+function comm_init_all(ndev::Integer, devices::Union{Nothing,Vector{Int32}} = nothing)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    devs = devices === nothing ? Ptr{Int32}(C_NULL) : pointer(devices)
+    GC.@preserve devices check(@ccall LIB.fx3d_comm_init_all(h::Ref{Ptr{Cvoid}}, ndev::Int32, devs::Ptr{Int32})::Int32)
+    return MultiDevice(h[], Int(ndev))
+end
+multi_destroy(m::MultiDevice) = check(@ccall LIB.fx3d_multi_destroy(m.handle::Ptr{Cvoid})::Int32)
+multi_synchronize(m::MultiDevice) = check(@ccall LIB.fx3d_multi_sync(m.handle::Ptr{Cvoid})::Int32)
+function multi_info(m::MultiDevice)
+    n = Ref{Int32}(0); v = Ref{Int32}(0); devs = Vector{Int32}(undef, m.ndev)
+    check(@ccall LIB.fx3d_multi_info(m.handle::Ptr{Cvoid}, n::Ref{Int32}, devs::Ptr{Int32}, v::Ref{Int32})::Int32)
+    return (ndev = Int(n[]), devices = Int.(devs), rccl_version = Int(v[]))
+end
+function chamfer_distance_multi(m::MultiDevice, As::Vector{<:Union{Nothing,HipArray{Float32,3}}},
+                                Bs::Vector{<:Union{Nothing,HipArray{Float32,3}}}, B_global::Integer;
+                                w1::Number = 1.0, w2::Number = 1.0)
+    length(As) == m.ndev && length(Bs) == m.ndev || error("one shard (or nothing) per device")
+    k = findfirst(!isnothing, As)
+    k === nothing && error("no shard at all")
+    D, N, _ = size(As[k]); M = size(Bs[k], 2)
+    xs = Ptr{Cvoid}[a === nothing ? C_NULL : a.ptr for a in As]
+    ys = Ptr{Cvoid}[b === nothing ? C_NULL : b.ptr for b in Bs]
+    bl = Int32[a === nothing ? 0 : size(a, 3) for a in As]
+    loss = Ref{Float32}(0)
+    GC.@preserve As Bs check(@ccall LIB.fx3d_chamfer_fwd_multi(m.handle::Ptr{Cvoid}, xs::Ptr{Ptr{Cvoid}}, N::Int32, ys::Ptr{Ptr{Cvoid}},
+                                                               M::Int32, bl::Ptr{Int32}, D::Int32, B_global::Int64, Float32(w1)::Float32,
+                                                               Float32(w2)::Float32, loss::Ref{Float32}, C_NULL::Ptr{Ptr{Cvoid}})::Int32)
+    return loss[]
+end
 
 # chamfer_distance of a batch whose slab [start, start+B_local) lives on this rank; every rank gets the
 # global loss (kernel -> all-reduce of 2 Float64 -> finalise with B_global), cf. src/metrics/pcloud.jl:39-52
@@ -743,6 +781,16 @@ set_device(dev::Integer) = check(@ccall LIB.fx3d_set_device(dev::Int32)::Int32)
 
 # ---- the rest of the ABI: device / stream / event utilities, explicit-draw sampling, face areas, host topology ----
 version() = unsafe_string(@ccall LIB.fx3d_version()::Cstring)
+# variant switches (include/flux3d_hip.h): named integer options instead of environment reads on the launch path
+set_option(name::AbstractString, value::Integer) = check(@ccall LIB.fx3d_set_option(name::Cstring, value::Int32)::Int32)
+function get_option(name::AbstractString)
+    v = Ref{Int32}(0); check(@ccall LIB.fx3d_get_option(name::Cstring, v::Ref{Int32})::Int32); return Int(v[])
+end
+function options()
+    n = @ccall LIB.fx3d_option_count()::Int32
+    names = [unsafe_string(@ccall LIB.fx3d_option_name(i::Int32)::Cstring) for i in 0:n-1]
+    return Dict(k => get_option(k) for k in names)
+end
 function current_device()
     d = Ref{Int32}(0); check(@ccall LIB.fx3d_get_device(d::Ref{Int32})::Int32); return Int(d[])
 end

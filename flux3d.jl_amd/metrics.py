@@ -190,11 +190,16 @@ def edge_loss_grad(m, target_length=0.0, gout=1.0, out=None):
     return g
 
 
-def _mesh_fused_ws(m, V, E):
+def _mesh_fused_ws(m, V, E, must_exist=False):
     """Scratch of the fused mesh-loss pair, owned by the mesh object: the forward leaves the Laplacian's unit rows
-    in it and the adjoint of the SAME mesh (same vertices) reads them back."""
+    in it and the adjoint of the SAME mesh (same vertices) reads them back.  A host mesh has no such cache (its
+    vertices are uploaded per call, the scratch comes fresh from the pool): ``must_exist`` -- the adjoint's
+    ``reuse_forward`` -- is an error there instead of a read of uninitialised rows."""
     ws = m._dev.get("mesh_fused_ws") if m.on_device else None
     if ws is None:
+        if must_exist:
+            raise ValueError("mesh_losses_grad(reuse_forward=True) needs the forward's scratch: call mesh_losses on this very "
+                             "DEVICE mesh first (gpu(m)); a host mesh keeps nothing between calls")
         n = C.c_size_t(0)
         _lib.call("fx3d_mesh_losses_workspace_bytes", int(V), int(E), C.byref(n))
         ws = DeviceArray.empty((n.value,), np.uint8)
@@ -231,7 +236,7 @@ def mesh_losses_grad(m, target_length=0.0, g_lap=0.1, g_edge=1.0, out=None, reus
     verts = m.dev("verts_packed")
     V = verts.shape[1]
     E = m.dev("edges").shape[0]
-    ws = _mesh_fused_ws(m, V, E)
+    ws = _mesh_fused_ws(m, V, E, must_exist=bool(reuse_forward))
     g = DeviceArray.empty((3, V), np.float32) if out is None else out
     _lib.call("fx3d_mesh_losses_bwd", verts.ptr, V, m.dev("lap_rowptr").ptr, m.dev("lap_colind").ptr, m.dev("lap_vals").ptr,
               E, float(target_length), float(g_lap), float(g_edge), int(bool(reuse_forward)), g.ptr, int(out is not None),

@@ -49,11 +49,24 @@ typedef int32_t fx3d_status;
 typedef void *fx3d_stream_t; /* hipStream_t */
 typedef void *fx3d_event_t;  /* hipEvent_t  */
 typedef void *fx3d_comm_t;   /* ncclComm_t (RCCL) */
+typedef void *fx3d_multi_t;  /* the communicators + worker threads of several devices of ONE process (fx3d_comm_init_all) */
 
 /* ---- library / device management (replaces Flux3D.use_cuda + CUDA.jl plumbing,
  *      src/Flux3D.jl:52-61; `gpu`/`cpu` functor walkers src/rep/pcloud.jl:57) -------------- */
 FX3D_API const char *fx3d_version(void);
 FX3D_API size_t fx3d_last_error(char *buf, size_t n); /* thread-local message; returns strlen */
+
+/* ---- variant switches --------------------------------------------------------------------------------------------
+ * The kernels' alternative code paths (A/B measurements, tests) are chosen by named integer options, process-wide and
+ * atomic: nn1_variant (3 | 0), nn1_tpb, nn1_nosplit, bwd_global_atomics, knn_f32, knn_f16_split, knn_no_mfma,
+ * knn_no_prepass, knn_gather, knn_d3_wave, edge_scalar_stores, edgeconv_unfused, cdf_multiblock_from
+ * (fx3d_option_count / fx3d_option_name enumerate them).  The environment variables FX3D_<NAME> only seed the defaults,
+ * once, at the first use of the library; no entry point reads the environment on its launch path.  A host that runs two
+ * configurations in one process sets the option before the calls that need it. */
+FX3D_API fx3d_status fx3d_set_option(const char *name, int32_t value);
+FX3D_API fx3d_status fx3d_get_option(const char *name, int32_t *value);
+FX3D_API int32_t fx3d_option_count(void);
+FX3D_API const char *fx3d_option_name(int32_t index); /* NULL past the end */
 FX3D_API fx3d_status fx3d_device_count(int32_t *n);
 FX3D_API fx3d_status fx3d_set_device(int32_t dev);
 FX3D_API fx3d_status fx3d_get_device(int32_t *dev);
@@ -353,8 +366,11 @@ FX3D_API fx3d_status fx3d_pointcloud_to_voxel(const float *points, int32_t N, in
 FX3D_API fx3d_status fx3d_comm_unique_id(uint8_t *id128);
 FX3D_API fx3d_status fx3d_comm_init_rank(fx3d_comm_t *comm, int32_t nranks, const uint8_t *id128,
                                          int32_t rank);
-/* rendezvous: "tcp://host:port" (rank 0 listens on `port`, the others connect to host:port and retry until it is up;
- * nothing persists) or "file://path" (rank 0 publishes path by rename, removes it once every rank has read it).
+/* rendezvous: "tcp://host:port" (rank 0 listens on `port` -- loopback only when host is 127.0.0.1 / localhost --, the
+ * others connect to host:port and retry until it is up; connections that do not speak the hand-shake {magic,
+ * FX3D_COMM_TOKEN hash, nranks, rank} are dropped; nothing persists) or "file://path" (single node: rank 0 removes an
+ * earlier job's leftovers, publishes {nonce, time, nranks, id} by rename of an O_EXCL | O_NOFOLLOW file, every reader
+ * confirms the nonce and is acknowledged before it uses the id, rank 0 removes everything -- also when it gives up).
  * Under torchrun: tcp://$MASTER_ADDR:<a free port, e.g. $MASTER_PORT + 1>.  Blocks until all ranks have joined (120 s). */
 FX3D_API fx3d_status fx3d_comm_bootstrap(fx3d_comm_t *comm, int32_t nranks, int32_t rank, const char *rendezvous);
 /* The rendezvous alone: rank 0's 128 bytes arrive in every other rank's id128 (what fx3d_comm_bootstrap does between
@@ -365,6 +381,9 @@ FX3D_API fx3d_status fx3d_comm_exchange_id(uint8_t *id128, int32_t nranks, int32
 FX3D_API fx3d_status fx3d_comm_info(fx3d_comm_t comm, int32_t *nranks, int32_t *rank, int32_t *rccl_version);
 FX3D_API fx3d_status fx3d_comm_destroy(fx3d_comm_t comm);
 FX3D_API fx3d_status fx3d_comm_allreduce_sum_f64(fx3d_comm_t comm, double *buf_dev, int64_t count,
+                                                 fx3d_stream_t s);
+/* all-reduce(max): the control plane of a timing harness (max over ranks of an elapsed time; with any buffer: a barrier) */
+FX3D_API fx3d_status fx3d_comm_allreduce_max_f64(fx3d_comm_t comm, double *buf_dev, int64_t count,
                                                  fx3d_stream_t s);
 /* chamfer_distance of a batch sharded over the ranks of comm: kernel -> all-reduce(2 x f64) ->
  * finalise with B_global.  x:(D,N,B_local) y:(D,M,B_local) are THIS rank's slab (B_local may be 0);
@@ -384,6 +403,24 @@ FX3D_API fx3d_status fx3d_chamfer_fwd_sharded_async(fx3d_comm_t comm, const floa
                                                     float w1, float w2, double *sums_dev, float *loss_dev,
                                                     void *ws, size_t ws_bytes, fx3d_stream_t s,
                                                     fx3d_stream_t comm_stream, fx3d_event_t ready, fx3d_event_t done);
+
+/* ---- one process, several devices (SURVEY.md 8b "fx3d_comm_init_all(ndev)") ---------------------------------------
+ * The reference is ONE Julia process (src/metrics/pcloud.jl:54-70): fx3d_comm_init_all gives such a host the
+ * communicators of `ndev` of its devices (ncclCommInitAll; devices == NULL: 0..ndev-1) and, per device, a worker thread,
+ * a stream and the scratch of a sharded evaluation.  fx3d_chamfer_fwd_multi: x[d] / y[d] are device d's slab
+ * ((D,N,B_local[d]) / (D,M,B_local[d]) in ITS memory -- fx3d_set_device(d) + fx3d_malloc --, ignored where
+ * B_local[d] == 0); every worker runs kernel -> all-reduce(sum) of 2 Float64 -> finalise with B_global on its stream; the
+ * call returns when all of it is enqueued.  loss_host (optional): the global loss, read back from the first device
+ * (blocks until it is there); losses_dev (optional, one device pointer per device, entries may be NULL): where each
+ * device keeps its copy, valid after fx3d_multi_sync.  Calls on one handle must not overlap (one caller thread). */
+FX3D_API fx3d_status fx3d_comm_init_all(fx3d_multi_t *multi, int32_t ndev, const int32_t *devices);
+FX3D_API fx3d_status fx3d_multi_destroy(fx3d_multi_t multi);
+FX3D_API fx3d_status fx3d_multi_info(fx3d_multi_t multi, int32_t *ndev, int32_t *devices, int32_t *rccl_version);
+FX3D_API fx3d_status fx3d_multi_sync(fx3d_multi_t multi);
+FX3D_API fx3d_status fx3d_chamfer_fwd_multi(fx3d_multi_t multi, const float *const *x, int32_t N,
+                                            const float *const *y, int32_t M, const int32_t *B_local, int32_t D,
+                                            int64_t B_global, float w1, float w2, float *loss_host,
+                                            float *const *losses_dev);
 
 /* ---- host-side topology (integer work; the reference keeps faces/edges/Laplacian on the host,
  *      src/rep/mesh.jl:87-97, and caches them forever) ------------------------------------------

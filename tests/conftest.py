@@ -39,3 +39,19 @@ def known():
     import json
     with open(os.path.join(GOLDEN, "ref_known_answers.json")) as fh:
         return json.load(fh)
+
+
+@pytest.fixture
+def fx_option(fx):
+    """set(name, value): fx3d_set_option for the duration of one test (restored at teardown).  The library reads no
+    environment variable on its launch path: the tests that exercise the kernels' alternative code paths go through the
+    explicit option API (include/flux3d_hip.h "variant switches")."""
+    from flux3d_jl_amd import _lib
+    saved = {}
+
+    def set(name, value):
+        saved.setdefault(name, _lib.get_option(name))
+        _lib.set_option(name, int(value))
+    yield set
+    for name, v in saved.items():
+        _lib.set_option(name, v)

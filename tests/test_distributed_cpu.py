@@ -100,3 +100,110 @@ def test_rendezvous_argument_errors(fx):
     assert lib.fx3d_comm_bootstrap(C.byref(h), 0, 0, b"tcp://127.0.0.1:1") == -1
     v = C.c_int32(0)
     assert lib.fx3d_comm_info(None, None, None, C.byref(v)) == 0 and v.value > 20000   # RCCL version code, no communicator needed
+
+
+_RDV_PROC = r"""
+import ctypes as C, sys
+sys.path.insert(0, {root!r})
+from flux3d_jl_amd import _lib
+lib = _lib.load()
+rank, n, rdv = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+secret = bytes((11 * i + 5) % 256 for i in range(128))
+buf = (C.c_uint8 * 128)(*(secret if rank == 0 else [0] * 128))
+rc = lib.fx3d_comm_exchange_id(buf, n, rank, rdv.encode())
+assert rc == 0, (rank, _lib.last_error())
+assert bytes(buf) == secret, rank
+print("RDV_OK", rank)
+"""
+
+
+def _exchange_processes(rendezvous, nranks, delay_rank0=0.0):
+    """The rendezvous from `nranks` separate PROCESSES (what torchrun starts), rank 0 optionally last."""
+    import time
+    code = _RDV_PROC.format(root=ROOT)
+    procs = []
+    for r in list(range(1, nranks)) + [0]:
+        if r == 0 and delay_rank0:
+            time.sleep(delay_rank0)
+        procs.append((r, subprocess.Popen([sys.executable, "-c", code, str(r), str(nranks), rendezvous],
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)))
+    for r, p in procs:
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0 and f"RDV_OK {r}" in out, (r, out, err[-2000:])
+
+
+def test_file_rendezvous_eight_processes_with_stale_leftovers(fx, tmp_path):
+    """a crashed earlier job with the same path used to poison the next one (readers took its id at once, a
+    stale marker made rank 0 unlink the id before its reader had read it).  Now: an OLD payload is refused by the
+    readers, a FRESH foreign one (a job that died seconds ago) is replaced by rank 0 and its readers start over, stale
+    markers / acknowledgements are removed, and nothing is left behind -- with 8 concurrent processes (config 5's size)."""
+    import struct
+    import time
+    path = tmp_path / "fx3d_uid"
+    magic = 0x3144495544335846
+    # leftovers of a job that died long ago: payload older than the staleness window, a marker and an acknowledgement
+    path.write_bytes(struct.pack("<QQqii", magic, 0xDEAD, int(time.time()) - 100000, 8, 0) + bytes(128))
+    (tmp_path / "fx3d_uid.3").write_bytes(struct.pack("<Q", 0xDEAD))
+    (tmp_path / "fx3d_uid.5.ok").write_bytes(struct.pack("<Q", 0xDEAD))
+    _exchange_processes(f"file://{path}", 8, delay_rank0=0.5)
+    assert list(tmp_path.iterdir()) == []
+    # leftovers of a job that died a moment ago (fresh timestamp, same world size): the readers confirm it first, rank 0
+    # then wipes it and publishes its own -- every rank must still end with rank 0's id
+    path.write_bytes(struct.pack("<QQqii", magic, 0xBEEF, int(time.time()), 8, 0) + bytes([0xEE] * 128))
+    _exchange_processes(f"file://{path}", 8, delay_rank0=1.0)
+    assert list(tmp_path.iterdir()) == []
+
+
+def test_file_rendezvous_refuses_symlinks(fx, tmp_path):
+    """The payload is created with O_EXCL | O_NOFOLLOW: a symlink planted at the predictable temp name is replaced, never
+    written through."""
+    target = tmp_path / "victim"
+    target.write_bytes(b"precious")
+    (tmp_path / "fx3d_uid.tmp").symlink_to(target)
+    _exchange(f"file://{tmp_path / 'fx3d_uid'}", nranks=2)
+    assert target.read_bytes() == b"precious"
+
+
+def test_tcp_rendezvous_survives_foreign_connections(fx):
+    """rank 0 used to abort the bootstrap on the first connection with a bad hand-shake (a port scanner, a
+    health probe) and counted a rank that connected twice as two.  Now such connections are dropped and it keeps
+    accepting until every rank has been served once."""
+    import socket
+    import threading
+    import time
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    stop = threading.Event()
+
+    def pest():  # garbage, silence and an immediate close, again and again
+        while not stop.is_set():
+            for payload in (b"GET / HTTP/1.0\r\n\r\n", b"", b"\x00" * 24):
+                try:
+                    with socket.create_connection(("127.0.0.1", port), timeout=0.2) as c:
+                        if payload:
+                            c.sendall(payload)
+                        time.sleep(0.02)
+                except OSError:
+                    pass
+            time.sleep(0.01)
+
+    t = threading.Thread(target=pest, daemon=True)
+    t.start()
+    try:
+        _exchange(f"tcp://127.0.0.1:{port}", nranks=4)
+    finally:
+        stop.set()
+        t.join(5)
+
+
+def test_default_rendezvous_prefers_tcp_under_a_launcher(fx, monkeypatch):
+    from flux3d_jl_amd.distributed import default_rendezvous
+    monkeypatch.delenv("FX3D_COMM_RENDEZVOUS", raising=False)
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29500")
+    assert default_rendezvous() == "tcp://127.0.0.1:29501"
+    monkeypatch.delenv("MASTER_ADDR")
+    assert default_rendezvous().startswith("file://")
+    monkeypatch.setenv("FX3D_COMM_RENDEZVOUS", "tcp://10.0.0.1:7")
+    assert default_rendezvous() == "tcp://10.0.0.1:7"

@@ -511,7 +511,7 @@ def test_knn_d3_far_outliers_take_the_exact_side_list(gpu_fx, oracle, M, nout, f
 @pytest.mark.parametrize("D,M,kind", [(64, 1024, "one_1e6"), (64, 1024, "one_1e6_unsampled"), (64, 1000, "five_1e5"),
                                       (32, 700, "one_1e8"), (128, 512, "one_1e6"), (64, 1024, "exponential"),
                                       (64, 1024, "constant_dims"), (16, 2048, "one_1e6")])
-def test_knn_feature_space_robust_centre(gpu_fx, oracle, monkeypatch, D, M, kind):
+def test_knn_feature_space_robust_centre(gpu_fx, oracle, fx_option, D, M, kind):
     """knn_mfma_kernel: a few points far from the bulk pull the per-dimension mean away from it (every query then sits far from
     the centre and its band swallows the cloud: 1.7 ms instead of 80 us).  The kernel switches to the medians of 16 sampled
     rows when a mean lies 8 interquartile ranges off, and scales its absolute error terms to the bulk.  Whatever it decides,
@@ -534,7 +534,7 @@ def test_knn_feature_space_robust_centre(gpu_fx, oracle, monkeypatch, D, M, kind
     x = np.asfortranarray(x.astype(np.float32))
     oidx, od = oracle.knn(x, k, drop_first=True)
     for nopre in ("0", "1"):  # the pre-pass (fx3d_knn_ws) and the in-kernel statistics apply the same rule
-        monkeypatch.setenv("FX3D_KNN_NO_PREPASS", nopre)
+        fx_option("knn_no_prepass", nopre)
         idx, dist = gpu_fx.knn(x, k, drop_first=True)
         assert np.array_equal(idx.to_host(), oidx), f"nopre={nopre}"
         assert np.array_equal(dist.to_host(), od), f"nopre={nopre}"
@@ -620,7 +620,7 @@ def _tree_scan(p):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["tiny", "two_sweeps", "global_cdf", "verts_not_staged", "ragged", "ragged_forced_multiblock",
                                   "two_blocks", "ragged_multiblock", "three_levels_above_the_chunks"])
-def test_face_cdf_bits_every_kernel_variant(gpu_fx, oracle, case, monkeypatch):
+def test_face_cdf_bits_every_kernel_variant(gpu_fx, oracle, case, fx_option):
     """The sampling CDF itself (not only the draws made from it), bit for bit against the specified order
     (oracle/flux3d_oracle.c: a radix-32 tree, every node summed left to right), for every variant: the one-block kernel
     (one sweep / two sweeps of the area pass, working copy in LDS or in the workspace, vertices staged in LDS or gathered
@@ -628,7 +628,7 @@ def test_face_cdf_bits_every_kernel_variant(gpu_fx, oracle, case, monkeypatch):
     meshes beyond 32 768 faces (two blocks; 34 blocks: one more level; small meshes forced onto it)."""
     fx = gpu_fx
     if case == "ragged_forced_multiblock":
-        monkeypatch.setenv("FX3D_CDF_MULTIBLOCK_FROM", "64")
+        fx_option("cdf_multiblock_from", "64")
     from flux3d_jl_amd.transforms import EPS, _face_cdf, _verts_padded_dev
     meshes = {"tiny": [_grid_mesh(7, 7, 1)],                             # 98 faces
               "two_sweeps": [_grid_mesh(56, 56, 2)],                     # 6272 faces > 6 x 1024
@@ -653,3 +653,69 @@ def test_face_cdf_bits_every_kernel_variant(gpu_fx, oracle, case, monkeypatch):
     out, fi, r1, r2 = fx.sample_points(m, 3000, seed=99, return_draws=True)
     eo, efi, er1, er2 = oracle.sample_points_seeded(vp, fp0, m._faces_len, 3000, 99, return_draws=True)
     assert np.array_equal(fi.to_host(), efi) and np.array_equal(out.to_host(), eo)
+
+
+# ------------------------------------------------------------------------------ round 3: one process / several devices, options
+@pytest.mark.gpu
+def test_single_process_multi_device_entry_points(gpu_fx):
+    """fx3d_comm_init_all + fx3d_chamfer_fwd_multi (the single-process form a Julia host needs) on the
+    devices this box has -- one here, so ndev = 1: communicator from ncclCommInitAll, a worker thread + stream +
+    scratch per device, the global loss equals the plain call, an empty device slot contributes zeros, shapes that
+    need a larger scratch re-allocate it, and argument errors come back as status codes with a message."""
+    fx = gpu_fx
+    from flux3d_jl_amd.distributed import MultiDevice
+    md = MultiDevice(ndev=1)
+    info = md.info()
+    assert info["ndev"] == 1 and info["devices"] == [0] and info["rccl_version"] > 20000
+    for (B, N, M) in ((5, 300, 200), (32, 4096, 4096), (3, 64, 5000)):
+        x, y = fx.synth.uniform_cloud(21, 3, N, B), fx.synth.uniform_cloud(22, 3, M, B)
+        dx, dy = md.shard(x, 0), md.shard(y, 0)
+        full = fx.chamfer_distance(dx, dy, w1=0.5, w2=2.0)
+        assert md.chamfer_distance([dx], [dy], B, w1=0.5, w2=2.0) == full
+        # the shard as 5 of a global batch of 8: the divisor is the GLOBAL batch size
+        assert np.isclose(md.chamfer_distance([dx], [dy], B + 3, w1=0.5, w2=2.0), full * B / (B + 3), rtol=1e-6)
+    md.synchronize()
+    with pytest.raises(fx.Flux3DHipError, match="B_global"):
+        md.chamfer_distance([dx], [dy], 1)
+    with pytest.raises(ValueError):
+        md.chamfer_distance([None], [None], 4)
+    md.close()
+    with pytest.raises(fx.Flux3DHipError, match="device"):
+        MultiDevice(devices=[0, 0])
+    with pytest.raises(fx.Flux3DHipError):
+        MultiDevice(devices=[fx.device_count()])
+
+
+@pytest.mark.gpu
+def test_option_api_replaces_environment_reads(gpu_fx, oracle, monkeypatch):
+    """the variant switches are explicit options (fx3d_set_option), the environment only seeds their
+    defaults when the library is first used.  Setting FX3D_NN1_VARIANT in the environment of a RUNNING process changes
+    nothing; the option does, per call, and both variants give the oracle's indices."""
+    fx = gpu_fx
+    from flux3d_jl_amd import _lib
+    opts = _lib.options()
+    assert set(opts) >= {"nn1_variant", "knn_f32", "knn_no_prepass", "bwd_global_atomics", "cdf_multiblock_from"}
+    assert opts["nn1_variant"] == 3
+    with pytest.raises(fx.Flux3DHipError, match="unknown option"):
+        _lib.set_option("no_such_switch", 1)
+    x, y = fx.synth.uniform_cloud(31, 3, 700, 2), fx.synth.uniform_cloud(32, 3, 900, 2)
+    oix, oiy = oracle.nn1(x, y)[:2]
+    monkeypatch.setenv("FX3D_NN1_VARIANT", "0")            # no effect: not read on the launch path
+    assert _lib.get_option("nn1_variant") == 3
+    _lib.load().fx3d_profile_enable(1)
+    ix, iy = fx.nearest_neighbors(x, y)
+    assert np.array_equal(ix.to_host(), oix) and np.array_equal(iy.to_host(), oiy)
+    with _lib.option("nn1_variant", 0):                    # the exact VALU loop, for these calls only
+        assert _lib.get_option("FX3D_NN1_VARIANT") == 0    # (the environment-style name is accepted as an alias)
+        ix, iy = fx.nearest_neighbors(x, y)
+        assert np.array_equal(ix.to_host(), oix) and np.array_equal(iy.to_host(), oiy)
+    assert _lib.get_option("nn1_variant") == 3
+    _lib.load().fx3d_profile_enable(0)
+
+
+def test_option_api_without_a_gpu(fx):
+    from flux3d_jl_amd import _lib
+    assert _lib.load().fx3d_option_count() == len(_lib.options()) >= 13
+    with _lib.option("knn_gather", 1):
+        assert _lib.get_option("knn_gather") == 1
+    assert _lib.get_option("knn_gather") == 0

@@ -221,7 +221,7 @@ def test_chamfer_backward(gpu_fx, oracle):
 
 
 @pytest.mark.parametrize("N,M,B", [(4096, 4096, 3), (700, 5000, 1), (14000, 300, 1), (1, 9, 2), (257, 256, 40)])
-def test_chamfer_backward_shapes(gpu_fx, oracle, monkeypatch, N, M, B):
+def test_chamfer_backward_shapes(gpu_fx, oracle, fx_option, N, M, B):
     """LDS-accumulating adjoint (row ranges split over blocks, clouds beyond one LDS image) and the global-atomics
     variant against the oracle's adjoint."""
     fx = gpu_fx
@@ -229,7 +229,7 @@ def test_chamfer_backward_shapes(gpu_fx, oracle, monkeypatch, N, M, B):
     _, ix, iy = fx.chamfer_distance(x, y, return_indices=True)
     ogx, ogy = oracle.chamfer_bwd(x, y, ix.to_host(), iy.to_host(), 1.0, 0.5, 1.5)
     for glob in ("0", "1"):
-        monkeypatch.setenv("FX3D_BWD_GLOBAL_ATOMICS", glob)
+        fx_option("bwd_global_atomics", glob)
         gx, gy = fx.chamfer_distance_grad(x, y, ix, iy, w1=1.0, w2=0.5, gout=1.5)
         assert np.allclose(gx.to_host(), ogx, rtol=1e-5, atol=1e-9)
         assert np.allclose(gy.to_host(), ogy, rtol=1e-5, atol=1e-9)
@@ -396,10 +396,10 @@ def test_knn_matrix_core_path(gpu_fx, oracle, D, N, M, B, k, drop, kind):
     assert np.array_equal(dist.to_host(), od)
 
 
-def test_knn_float32_filter_variant(gpu_fx, oracle, monkeypatch):
+def test_knn_float32_filter_variant(gpu_fx, oracle, fx_option):
     """FX3D_KNN_F32=1 keeps the Float32 GEMM filter (the default for D % 4 == 0, M <= 4096 is the fp16 split):
     both must give the oracle's lists."""
-    monkeypatch.setenv("FX3D_KNN_F32", "1")
+    fx_option("knn_f32", "1")
     rng = np.random.default_rng(77)
     for (D, N, M, k) in ((64, 300, 1024, 20), (32, 100, 200, 9), (128, 64, 96, 5)):
         x = np.asfortranarray(rng.standard_normal((D, N, 2)).astype(np.float32))
@@ -409,14 +409,14 @@ def test_knn_float32_filter_variant(gpu_fx, oracle, monkeypatch):
         assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
 
 
-@pytest.mark.parametrize("env", [None, "FX3D_KNN_F16_SPLIT"])
-def test_knn_fp16_filter_variants(gpu_fx, oracle, monkeypatch, env):
+@pytest.mark.parametrize("env", [None, "knn_f16_split"])
+def test_knn_fp16_filter_variants(gpu_fx, oracle, fx_option, env):
     """The default feature-space filter uses the fp16-rounded operands alone (one MFMA per K block, band 2^-10);
     FX3D_KNN_F16_SPLIT=1 selects the 2-way split (three MFMAs, band 2^-18).  Both must give the oracle's lists, on
     centred data and on data with a large common offset (the band grows with |q|^2 + |c|^2: more survivors, and
     past the list capacity the exact fallback)."""
     if env:
-        monkeypatch.setenv(env, "1")
+        fx_option(env, 1)
     rng = np.random.default_rng(78)
     for (D, N, M, k, shift) in ((64, 300, 1024, 20, 0.0), (64, 200, 512, 20, 3.0), (32, 100, 200, 9, 0.0),
                                 (128, 64, 96, 5, 0.5), (16, 130, 700, 31, 10.0), (64, 96, 1024, 12, 40.0)):
@@ -440,7 +440,7 @@ def test_knn_fp16_filter_variants(gpu_fx, oracle, monkeypatch, env):
     (4, 333, 2048, 1, 32, False),    # smallest row (one 16-byte piece)
     (64, 100, 4096, 1, 20, False),   # more than 8 stages: the gather from L2 stays
 ])
-def test_knn_staged_exact_phase(gpu_fx, oracle, monkeypatch, D, N, M, B, k, drop):
+def test_knn_staged_exact_phase(gpu_fx, oracle, fx_option, D, N, M, B, k, drop):
     """knn_mfma_kernel's exact phase with the candidate rows staged through LDS (default when D/4 divides the block and
     the cloud makes at most 8 stages) and with the per-survivor gather from L2 (FX3D_KNN_GATHER=1): both are the
     oracle's lists bit for bit, distances included."""
@@ -452,8 +452,8 @@ def test_knn_staged_exact_phase(gpu_fx, oracle, monkeypatch, D, N, M, B, k, drop
     oi, od = oracle.knn(x, k, y=None if y is x else y, drop_first=drop)
     # (default: fx3d_knn_ws with the pre-pass image; FX3D_KNN_NO_PREPASS=1: every block builds its own image, as fx3d_knn does)
     for gather, nopre in ((False, False), (True, False), (False, True)):
-        monkeypatch.setenv("FX3D_KNN_GATHER", "1" if gather else "0")
-        monkeypatch.setenv("FX3D_KNN_NO_PREPASS", "1" if nopre else "0")
+        fx_option("knn_gather", "1" if gather else "0")
+        fx_option("knn_no_prepass", "1" if nopre else "0")
         idx, dist = gpu_fx.knn(x, k, y=None if y is x else y, drop_first=drop)
         assert np.array_equal(idx.to_host(), oi), f"gather={gather} nopre={nopre}"
         assert np.array_equal(dist.to_host(), od), f"gather={gather} nopre={nopre}"
@@ -844,7 +844,7 @@ def test_edge_features_parity(gpu_fx, oracle, F, N, B, K):
 
 @pytest.mark.parametrize("N,B,K,kind", [(1024, 3, 20, "uniform"), (200, 2, 10, "uniform"), (333, 2, 7, "lattice"),
                                          (96, 1, 31, "uniform"), (300, 2, 12, "outlier"), (70, 2, 4, "same")])
-def test_edgeconv_graph_fused_first_layer(gpu_fx, oracle, N, B, K, kind, monkeypatch):
+def test_edgeconv_graph_fused_first_layer(gpu_fx, oracle, N, B, K, kind, fx_option):
     """F = 3: fx3d_edgeconv_graph runs the neighbour search and cat(X, KNN - X) in ONE kernel.  Vector and scalar
     rank stores (K % 4), distance ties re-ranked by the wave (lattice), lists overflowing into the exact fallback
     (outlier / identical points): indices and features bit-identical to the oracle and to the two-kernel path."""
@@ -864,7 +864,7 @@ def test_edgeconv_graph_fused_first_layer(gpu_fx, oracle, N, B, K, kind, monkeyp
         exp = oracle.edge_features(x, oi, layout=lay)
         out, idx = gpu_fx.edgeconv_graph(dx, K, layout=layout, return_idx=True)
         assert np.array_equal(idx.to_host(), oi) and np.array_equal(out.to_host(), exp)
-    monkeypatch.setenv("FX3D_EDGECONV_UNFUSED", "1")
+    fx_option("edgeconv_unfused", "1")
     out2, idx2 = gpu_fx.edgeconv_graph(dx, K, layout="mlp", return_idx=True)
     assert np.array_equal(idx2.to_host(), oi) and np.array_equal(out2.to_host(), exp)
 

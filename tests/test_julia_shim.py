@@ -30,7 +30,7 @@ def _strip_c_comments(txt):
     return re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
 
 
-HANDLES = {"fx3d_stream_t", "fx3d_event_t", "fx3d_comm_t", "fx3d_graph_t"}  # all `void *`
+HANDLES = {"fx3d_stream_t", "fx3d_event_t", "fx3d_comm_t", "fx3d_graph_t", "fx3d_multi_t"}  # all `void *`
 
 
 def _norm_ctype(decl):
@@ -167,9 +167,9 @@ def _jl_matches(jt, ct):
         if inner == "UInt8":
             return base in ("char", "uint8_t", "void")
         return JL_VAL.get(inner) == base
-    if kind == "ptrptr":  # out-parameter receiving a pointer / handle
-        m = re.fullmatch(r"Ref\{(.+)\}", jt)
-        return bool(m) and JL_ALIASES.get(m.group(1), m.group(1)) == "Ptr{Cvoid}"
+    if kind == "ptrptr":  # out-parameter receiving a pointer / handle, or a host array of device pointers (one per device)
+        m = re.fullmatch(r"(Ref|Ptr)\{(.+)\}", jt)
+        return bool(m) and JL_ALIASES.get(m.group(2), m.group(2)) == "Ptr{Cvoid}"
     return False
 
 
