@@ -9,22 +9,35 @@ HBM: BASELINE.json configs[1] (B=32, N=M=4096, Float32) per GPU.  With N GPUs th
 32*N (configs[4]: B=256 sharded 32/GPU on 8), each rank runs the kernel on its shard and the two
 Float64 partial sums are all-reduced over RCCL (weak scaling).  value = global pairs / max-rank time.
 
+Protocol: [K cold steps, timed separately -> cold_ms_per_step] -> burn-in (>= --burn-ms of the same launches, so that the
+counted steps run at the clocks a training loop sees, not at the clocks of an idle device) -> W warm-up
+steps -> barrier + device sync -> EXACTLY K timed steps -> device sync + barrier; max over ranks.
+
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline             -- dominant kernel (nn1) against what limits it: SIMD issue slots (VALU + MFMA issue), from the
-                          SQ counters of a rocprofv3 pass of THIS kernel source (profiles/pmc_latest.json, hash-checked)
-  roofline_mfma_pipe   -- matrix-pipe busy fraction, analytic (2*B*N*M/1024 MFMAs of 32 cycles on 1024 SIMDs)
-  roofline_algorithmic_fp32 / roofline_hbm -- the exact-Float32 algorithm's flops vs the fp32 peak, and the HBM fraction
-                          BASELINE.json's metric asks for (neither is the bound)
-  protocol             -- benchmarks/metrics.jl:24-38 style numbers: min / median per step, forward and forward+backward
-  configs              -- one-liners for BASELINE configs C1 / C3 / C4 and the reference harness's own input
+  roofline             -- SURVEY.md 8(d): the dominant kernel's ALGORITHMIC flops (16 per pair: the exact Float32 form,
+                          both directions) / its average duration in THIS run (HIP events on its stream) against the
+                          fp32 peak (vector == fp32-input MFMA, 157.3 TF): `achieved`, `frac` (= achieved_valu);
+                          `achieved_hbm` / `hbm_frac` (algorithmic bytes / time against 8 TB/s: BASELINE.json asks; not
+                          the bound); `mfma_pipe_frac` (matrix-pipe busy cycles / kernel cycles); `traffic` (HBM bytes
+                          per launch, PMC); `valu_per_mfma` (PMC); hardware-executed f16 MFMA TF as `mfma_hw_tflops`
+  issue_occupancy      -- a named extra, NOT a roofline fraction: SIMD issue cycles ((VALU - MFMA) x 4 + MFMA busy) per
+                          kernel cycle; it goes UP when a kernel wastes instructions
+  protocol             -- benchmarks/metrics.jl:24-38 style numbers: min / median per call, forward and forward+backward
+  configs              -- the other BASELINE configs (C1, C3 with the CDFs rebuilt per call + cached, C4, C4', C5's
+                          N=1024 shard, C2's shape on surface samples of real meshes), each with its own SURVEY 8(d)
+                          roofline; reference_harness: benchmarks/metrics.jl's full sweep n = 2^6 .. 2^14 (chamfer,
+                          edge_loss, laplacian_loss; forward and forward+backward)
   cpu_baseline         -- the oracle's KD-tree twin of the reference CPU path, timed on this host (N=1 only)
 Everything beyond the timed K steps runs after them (N=1, rank 0) and does not enter `value`.
 
-N > 1 (one process per GPU): the data-plane collective is the library's own RCCL communicator (fx3d_comm_bootstrap:
-unique id over a file rendezvous, no torch); torch.distributed is the control plane only (barrier, max over ranks).
-Default mode `overlap`: one all-reduce of 2 Float64 PER EVALUATION, issued on a second stream so that it overlaps the
-next evaluation's kernel (north_star: "RCCL all-reduce of the scalar loss").  `serial` (same, on the compute stream) and
-`deferred` (one collective per 32 evaluations) are timed right after and printed as `modes`.
+N > 1 (one process per GPU): NO torch in this file.  torchrun only exports RANK / WORLD_SIZE / MASTER_*; the library
+bootstraps its own RCCL communicator (fx3d_comm_bootstrap over tcp://MASTER_ADDR:MASTER_PORT+1), the data-plane
+collective is its all-reduce(sum) of 2 Float64 per evaluation, and the control plane (barrier, max over ranks of the
+elapsed time) is its all-reduce(max).  The run fails loudly unless the communicator reports exactly N ranks.
+`--comm torch` keeps the torch.distributed variant of round 1.  Default mode `overlap`: the all-reduce is issued on a
+second stream so that it overlaps the next evaluation's kernel (north_star: "RCCL all-reduce of the scalar loss");
+`serial` (same, on the compute stream) and `deferred` (one collective per 32 evaluations) are timed right after and
+printed as `modes`.
 """
 import argparse
 import hashlib
@@ -59,8 +72,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the protocol / configs measurements after the timed steps")
+    ap.add_argument("--burn-ms", type=float, default=80.0,
+                    help="milliseconds of the same launches before the counted warm-up (steady clocks); 0 = none")
     ap.add_argument("--comm", choices=["torch", "native"], default="native",
-                    help="multi-GPU all-reduce through torch.distributed (RCCL) or the library's own RCCL communicator")
+                    help="multi-GPU: the library's own RCCL communicator for data AND control plane (default, no torch), or "
+                         "torch.distributed for both")
     ap.add_argument("--mode", choices=["overlap", "serial", "deferred"], default="overlap",
                     help="multi-GPU: per-evaluation all-reduce overlapped on a second stream (default), on the compute "
                          "stream, or one collective per --allreduce-every evaluations")
@@ -79,13 +95,15 @@ def main():
     dist = None
     torch = None
     use_dist = world > 1 or args.force_dist
+    use_torch = use_dist and args.comm == "torch"
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if use_torch:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
@@ -104,26 +122,23 @@ def main():
 
     native_comm = None
     comm_info = None
-    if use_dist and args.comm == "native":
-        # the library's own RCCL communicator, bootstrapped without torch (file rendezvous keyed by the launcher's pid).
-        # Any failure to set it up (all ranks agree through a control-plane all-reduce) falls back to torch's all_reduce.
+    if use_dist and not use_torch:
+        # the library's own RCCL communicator, bootstrapped without torch: data plane AND control plane.  No fallback: a
+        # rank that cannot join, or a communicator of the wrong size, ends the run (the driver must not record a
+        # single-GPU number as an N-GPU one).
         rdv = default_rendezvous()
-        try:
-            native_comm = NativeComm(rank, world, rendezvous=rdv)
-            comm_info = dict(native_comm.info(), backend="fx3d_comm (RCCL behind the C ABI)", bootstrap=rdv.split(":", 1)[0])
-            ok = 1
-        except Exception as e:  # noqa: BLE001
-            print(f"[bench] native RCCL communicator unavailable on rank {rank}: {e}", file=sys.stderr)
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            native_comm = None
-    if use_dist and native_comm is None:
+        native_comm = NativeComm(rank, world, rendezvous=rdv)
+        comm_info = dict(native_comm.info(), backend="fx3d_comm (RCCL behind the C ABI): data + control plane, no torch",
+                         bootstrap=rdv.split(":", 1)[0])
+        if comm_info["nranks"] != args.gpus or comm_info["nranks"] != world:
+            raise SystemExit(f"[bench] communicator has {comm_info['nranks']} ranks, --gpus {args.gpus}, WORLD_SIZE {world}")
+    if use_torch:
         v = C.c_int32(0)
         _lib.load().fx3d_comm_info(None, None, None, C.byref(v))
         comm_info = {"nranks": dist.get_world_size(), "rank": dist.get_rank(), "rccl_version": v.value,
                      "backend": "torch.distributed nccl (RCCL)", "bootstrap": "torch"}
+        if comm_info["nranks"] != args.gpus:
+            raise SystemExit(f"[bench] process group has {comm_info['nranks']} ranks, --gpus {args.gpus}")
 
     def make_runner(mode):
         """(step, sync_all, read_loss, stream, description) for one way of running a step."""
@@ -199,13 +214,24 @@ def main():
             (" on a second stream, overlapping the next step's kernel" if mode == "overlap" else " on the compute stream")
 
     def barrier():
-        if dist is not None:
-            torch.cuda.synchronize()
+        fx.synchronize()
+        if native_comm is not None:
+            native_comm.barrier()           # 8-byte all-reduce(max) on the default stream + read-back
+        elif dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+        fx.synchronize()
 
-    def timed(mode, steps, warmup, profile_every=0):
-        step, sync_all, read_loss, s, desc = make_runner(mode)
+    def max_over_ranks(v):
+        if native_comm is not None:
+            return native_comm.max_over_ranks(v)
+        if dist is not None:
+            t = torch.tensor([v], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return v
+
+    def run_timed(runner, steps, warmup, profile_every=0):
+        step, sync_all, read_loss, s, desc = runner
         for _ in range(warmup):
             step()
         sync_all()
@@ -222,18 +248,32 @@ def main():
         sync_all()
         barrier()
         t1 = time.perf_counter()
-        elapsed = t1 - t0
-        if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        _lib.call("fx3d_profile_enable", 0)
+        elapsed = max_over_ranks(t1 - t0)
         return {"elapsed": elapsed, "loss": read_loss(), "event_ms": e0.elapsed_ms(e1), "desc": desc,
                 "runner": (step, sync_all, s)}
+
+    def timed(mode, steps, warmup, profile_every=0, burn_ms=0.0, cold=False):
+        runner = make_runner(mode)
+        out = {}
+        if cold:  # the first K steps this process ever runs (after ONE launch that loads the code object): idle-device clocks
+            runner[0]()
+            runner[1]()
+            out["cold_ms_per_step"] = run_timed(runner, steps, 0)["elapsed"] * 1e3 / steps
+        if burn_ms > 0:
+            n = int(burn_ms / 0.045) + 1  # a step is >= 45 us of GPU work: >= burn_ms in total
+            for _ in range(n):
+                runner[0]()
+            runner[1]()
+            out["burn_steps"] = n
+        out.update(run_timed(runner, steps, warmup, profile_every))
+        return out
 
     # HIP events around every 5th nn1 launch, on the launch's own stream (bracketing every launch
     # costs ~5 us per step in event records; measured)
     main_mode = args.mode if use_dist else "single"
-    res = timed(main_mode, args.steps, args.warmup, 0 if os.environ.get("FX3D_BENCH_NOPROFILE") else 5)
+    res = timed(main_mode, args.steps, args.warmup, 0 if os.environ.get("FX3D_BENCH_NOPROFILE") else 5,
+                burn_ms=args.burn_ms, cold=True)
     avg, mn, mx, cnt = C.c_double(0), C.c_double(0), C.c_double(0), C.c_int64(0)
     _lib.call("fx3d_profile_kernel_stats", b"nn1", C.byref(avg), C.byref(mn), C.byref(mx), C.byref(cnt))
     _lib.call("fx3d_profile_enable", 0)
@@ -266,53 +306,52 @@ def main():
     value = pairs_per_step * args.steps / elapsed
     ms_per_step = elapsed * 1e3 / args.steps
     kern_s = avg.value * 1e-3
-    # algorithmic work of ONE nn1 launch on one GPU (DESIGN.md "Roofline"):
+    # algorithmic work of ONE nn1 launch on one GPU:
     #   flops: 8 per ordered pair evaluation (3 sub, 3 mul, 2 add), both directions = 16*B*N*M
     #   bytes: read both clouds once (4*D*B*(N+M)) + the per-block partial sums written
     flops = 16.0 * B_PER_GPU * NPTS * MPTS
     abytes = 4.0 * DIM * B_PER_GPU * (NPTS + MPTS) + 8.0 * 2 * B_PER_GPU * 8
     n_mfma = 2.0 * B_PER_GPU * NPTS * MPTS / 1024.0            # one v_mfma_f32_32x32x16_f16 per 32 x 32 pairs and direction
-    mfma_busy = n_mfma * 32.0 / N_SIMD                           # cycles per SIMD
-    pipe = {"bound": "mfma", "achieved": mfma_busy / kern_s / 1e9 if kern_s else None, "peak": PEAK_CLOCK_GHZ, "unit": "GHz",
-            "frac": (mfma_busy / kern_s / 1e9 / PEAK_CLOCK_GHZ) if kern_s else None,
-            "note": "matrix-pipe busy cycles per SIMD and launch (2*B*N*M/1024 MFMAs x 32 cycles / 1024 SIMDs, analytic: every "
-                    "pair is evaluated) / kernel time, against the 2.4 GHz peak clock; hardware MFMA flops = "
-                    f"{2.0 * 16 * 2 * B_PER_GPU * NPTS * MPTS / kern_s / 1e12 if kern_s else 0:.0f} TF of the 2500 TF dense f16 peak"}
-    traffic = None
-    roof = None
+    mfma_busy = n_mfma * 32.0 / N_SIMD                           # matrix-pipe cycles per SIMD and launch
+    roof = {
+        "bound": "mfma", "achieved": flops / kern_s / 1e12 if kern_s else None, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": (flops / kern_s / 1e12 / FP32_PEAK_TFLOPS) if kern_s else None, "traffic": None,
+        "achieved_valu": (flops / kern_s / 1e12 / FP32_PEAK_TFLOPS) if kern_s else None,
+        "achieved_hbm": abytes / kern_s / 1e9 if kern_s else None, "hbm_peak": HBM_PEAK_GBS,
+        "hbm_frac": (abytes / kern_s / 1e9 / HBM_PEAK_GBS) if kern_s else None,
+        "mfma_pipe_frac": (mfma_busy / kern_s / 1e9 / PEAK_CLOCK_GHZ) if kern_s else None,
+        "mfma_hw_tflops": 2.0 * 16 * 2 * B_PER_GPU * NPTS * MPTS / kern_s / 1e12 if kern_s else None,
+        "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": abytes,
+        "kernel": "nn1_f16_kernel<false>", "kernel_avg_ms": avg.value, "kernel_min_ms": mn.value, "launches_timed": cnt.value,
+        "note": "SURVEY.md 8(d): achieved = ALGORITHMIC flops per launch (16 per pair: the exact Float32 form of the reference CPU "
+                "path, both directions) / the kernel's average duration in this run (HIP events on its stream), against the fp32 "
+                "peak (vector == fp32-input MFMA).  The kernel does not execute those flops: the fp16-split filter runs on the "
+                "matrix cores (mfma_hw_tflops of the 2500 TF dense f16 peak; mfma_pipe_frac = matrix-pipe busy cycles, "
+                "2*B*N*M/1024 MFMAs x 32 cycles / 1024 SIMDs, per kernel cycle at 2.4 GHz) and only surviving tiles are "
+                "re-evaluated exactly.  achieved_hbm / hbm_frac: algorithmic bytes / time against 8 TB/s (BASELINE.json asks; a "
+                "brute-force NN cannot approach it: 70 % would be 0.56 us)"}
+    issue = None
     pmc_note = "no profiles/pmc_latest.json"
     try:  # PMC-derived numbers per launch, collected by separate rocprofv3 --pmc passes (tools/profile_round.sh)
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
             pmc = json.load(fh)
         stale = pmc.get("kernel_source_sha16") != kernel_source_hash()
-        traffic = pmc.get("nn1_hbm_bytes_per_launch")
-        # SIMD issue time of one launch from the SQ counters: a wave64 VALU instruction holds its SIMD's issue port for
-        # 4 cycles, v_mfma_f32_32x32x16_f16 for 32 (SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA), and the two do not overlap
-        # on one SIMD (measured).
         valu, mfma = float(pmc["SQ_INSTS_VALU"]), float(pmc["SQ_INSTS_MFMA"])
+        roof.update({"traffic": pmc.get("nn1_hbm_bytes_per_launch"), "valu_per_mfma": (valu - mfma) / mfma,
+                     "counters_from": pmc.get("source"), "counters_stale": stale})
         cyc = ((valu - mfma) * 4.0 + float(pmc["SQ_VALU_MFMA_BUSY_CYCLES"])) / N_SIMD
-        roof = {"bound": "simd-issue", "achieved": cyc / kern_s / 1e9 if kern_s else None, "peak": PEAK_CLOCK_GHZ, "unit": "GHz",
-                "frac": (cyc / kern_s / 1e9 / PEAK_CLOCK_GHZ) if kern_s else None, "traffic": traffic,
-                "valu_per_mfma": (valu - mfma) / mfma,
-                "counters_from": pmc.get("source"), "counters_stale": stale,
-                "note": "what limits nn1: issue cycles per SIMD and launch ((SQ_INSTS_VALU - SQ_INSTS_MFMA) x 4 + MFMA busy cycles) / "
-                        "kernel time of THIS run, against the 2.4 GHz peak clock (the part sustains ~2.0 GHz under this load). The "
-                        "instruction counts come from a separate rocprofv3 --pmc pass of the same kernel source (sha16 checked: "
-                        "counters_stale), not from this run; they do not depend on timing"}
-        # the same binary issues at 1.80-1.90 GHz on a healthy box (profiles/r02_v2..v9: eight boxes, 56.8-58.8 us per step); one
-        # box of the round ran it at 1.43 GHz (75.5 us) while latency-bound kernels kept their times: flag that, do not hide it
-        if roof["achieved"] is not None and not stale:
-            roof["usual_achieved"] = [1.80, 1.90]
-            if roof["achieved"] < 1.65:
-                roof["box_note"] = ("issue rate well below what this binary reaches on other MI355X boxes (1.80-1.90 GHz): "
-                                    "the device was probably clock- or power-limited during this run")
+        issue = {"value": (cyc / kern_s / 1e9 / PEAK_CLOCK_GHZ) if kern_s else None, "unit": "SIMD issue cycles per kernel cycle at 2.4 GHz",
+                 "counters_stale": stale,
+                 "note": "NOT a roofline fraction (VERDICT r2): ((SQ_INSTS_VALU - SQ_INSTS_MFMA) x 4 + MFMA busy cycles) / 1024 SIMDs "
+                         "/ kernel time.  An occupancy of the issue ports that goes UP when the kernel issues more instructions for "
+                         "the same work; kept because it shows how little idle time is left (the loop is issue bound: a SIMD's VALU "
+                         "and matrix pipe mostly serialise, tools/ubench_overlap.hip)"}
         pmc_note = None
     except Exception as e:  # noqa: BLE001
         pmc_note = f"profiles/pmc_latest.json unusable: {e}"
-    if roof is None:  # no counters for this source: the analytic matrix-pipe figure is the hardware-side fraction
-        roof = dict(pipe, traffic=None, note=pipe["note"] + f" ({pmc_note}: SIMD-issue fraction not available)")
-    roof.update({"kernel": "nn1_f16_kernel<false>", "kernel_avg_ms": avg.value, "kernel_min_ms": mn.value,
-                 "launches_timed": cnt.value})
+    if pmc_note:
+        roof["counters_note"] = pmc_note
+    pipe = None
     out = {
         "metric": "chamfer_point_pairs_per_sec", "value": value, "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -323,17 +362,8 @@ def main():
                    "parallelism": f"batch-sharded x{world}, " + (res["desc"] if use_dist else "no collective")},
         "loss": loss,
         "roofline": roof,
-        "roofline_mfma_pipe": pipe,
-        "roofline_algorithmic_fp32": {
-            "bound": "mfma", "achieved": flops / kern_s / 1e12 if kern_s else None, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": (flops / kern_s / 1e12 / FP32_PEAK_TFLOPS) if kern_s else None,
-            "note": "ALGORITHMIC flops (16 per unordered pair: the exact Float32 form, both directions) vs the fp32 peak "
-                    "(vector == fp32-input MFMA). The kernel does NOT execute these flops (fp16-split filter on the matrix cores + "
-                    "exact Float32 re-scan of the surviving tiles): a throughput equivalence, not a hardware fraction"},
-        "roofline_hbm": {"bound": "hbm", "achieved": abytes / kern_s / 1e9 if kern_s else None,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (abytes / kern_s / 1e9 / HBM_PEAK_GBS) if kern_s else None,
-                         "note": "reported because BASELINE.json asks; brute-force NN cannot approach it"},
+        "issue_occupancy": issue,
+        "cold_ms_per_step": res.get("cold_ms_per_step"), "burn_in_steps": res.get("burn_steps"),
         "stream_event_ms_per_step": res["event_ms"] / args.steps,
     }
     if comm_info is not None:
@@ -343,6 +373,7 @@ def main():
     if world == 1 and not use_dist and not args.no_extras:
         out["protocol"] = protocol_numbers(fx, x, y)
         out["configs"] = config_one_liners(fx)
+        out["reference_harness"] = reference_harness(fx)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(fx)
     try:  # C stdio of the loaded libraries first (RCCL prints its NCCL_DEBUG=VERSION banner there): the JSON goes last
@@ -390,36 +421,141 @@ def protocol_numbers(fx, x, y):
             "note": "single calls between HIP events on one stream (event records included); `value` above is K back-to-back steps"}
 
 
+def _roof(ms_min, flops=None, nbytes=None):
+    """SURVEY.md 8(d) per config: algorithmic flops (and / or bytes) per call / the call's minimum time, against the fp32
+    peak (and / or the 8 TB/s HBM peak)."""
+    t = ms_min * 1e-3
+    out = {}
+    if flops is not None:
+        out.update({"algorithmic_flops": flops, "achieved_tflops": flops / t / 1e12, "frac_fp32_peak": flops / t / 1e12 / FP32_PEAK_TFLOPS})
+    if nbytes is not None:
+        out.update({"algorithmic_bytes": nbytes, "achieved_gbs": nbytes / t / 1e9, "frac_hbm_peak": nbytes / t / 1e9 / HBM_PEAK_GBS})
+    return out
+
+
+def surface_clouds(fx, n=4096, B=32, seed=0x5EED0C2, normalise=True):
+    """C2's shape (B = 32, N = M = 4096) on SURFACE samples of real meshes instead of U[0,1)^3: cloud b of A is sampled from
+    mesh b mod 10 of {teapot, sphere, the 8 ModelNet OFF files of tests/golden/modelnet}, cloud b of B from mesh (b + 3) mod 10
+    -- points on 2-D manifolds, the geometry chamfer_distance sees in fit_mesh / ModelNet evaluation.  ``normalise``: every
+    mesh scaled to the unit sphere first (an evaluation pipeline's preprocessing); False keeps the files' own units, which
+    pairs clouds whose extents differ by up to 250 x (teapot: 3, one ModelNet table: 825)."""
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import modelnet_chamfer_eval as ev
+    tmp = tempfile.mkdtemp(prefix="fx3d_bench_mn_")
+    try:
+        for z in ("ModelNet10.zip", "ModelNet40.zip"):
+            shutil.copy(os.path.join(ROOT, "tests", "golden", "modelnet", z), tmp)
+        meshes = [(m[1], m[2]) for m in ev.listing(tmp)]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    meshes = [fx.load_obj(os.path.join(ROOT, "tests", "golden", f)) for f in ("teapot.obj", "sphere.obj")] + meshes
+    if normalise:
+        meshes = [(ev.unit_sphere(v), f) for v, f in meshes]
+    ia = [b % len(meshes) for b in range(B)]
+    ib = [(b + 3) % len(meshes) for b in range(B)]
+    ta = fx.gpu(fx.TriMesh([meshes[i][0] for i in ia], [meshes[i][1] for i in ia]))
+    tb = fx.gpu(fx.TriMesh([meshes[i][0] for i in ib], [meshes[i][1] for i in ib]))
+    return fx.sample_points(ta, n, seed=seed), fx.sample_points(tb, n, seed=seed + 1)
+
+
 def config_one_liners(fx):
-    """The other BASELINE configs and the reference harness's own input, one number each (min over 100 calls, ms)."""
+    """The other BASELINE configs, one entry each: min / median over 100 single calls (ms) + the config's own SURVEY 8(d)
+    roofline (algorithmic flops / bytes of the call / its minimum time)."""
     import numpy as np
     out = {}
     loss_dev = fx.DeviceArray.empty((1,), np.float32)
+
+    def chamfer_entry(a, b, n, m, B):
+        r = _per_call_ms(fx, lambda: fx.chamfer_distance(a, b, loss_out=loss_dev, sync=False))
+        r["pairs_per_s_at_min"] = B * n * m / (r["min_ms"] * 1e-3)
+        r["roofline"] = _roof(r["min_ms"], flops=16.0 * B * n * m, nbytes=4.0 * 3 * B * (n + m))
+        return r
+
     a = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_A, 3, 1024, 2))
     b = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_B, 3, 1024, 2))
-    out["C1 chamfer fwd B=2 N=M=1024"] = _per_call_ms(fx, lambda: fx.chamfer_distance(a, b, loss_out=loss_dev, sync=False))
+    out["C1 chamfer fwd B=2 N=M=1024"] = chamfer_entry(a, b, 1024, 1024, 2)
     # the headline's shape on numpy's default_rng(7) uniforms: this dataset has a query whose wave takes the exact fall-back, and
     # in a one-round launch that wave is the tail (DESIGN.md 3.1)
     rng = np.random.default_rng(7)
     af, bf = (fx.gpu(np.asfortranarray(rng.random((3, 4096, 32)).astype(np.float32))) for _ in range(2))
-    out["C2 shape, numpy default_rng(7) uniforms: one slow query (B=32 N=M=4096)"] = _per_call_ms(fx, lambda: fx.chamfer_distance(af, bf, loss_out=loss_dev, sync=False))
+    out["C2 shape, numpy default_rng(7) uniforms: one slow query (B=32 N=M=4096)"] = chamfer_entry(af, bf, 4096, 4096, 32)
     del af, bf
+    sa, sb = surface_clouds(fx)
+    out["C2 shape on surface-sampled clouds (teapot, sphere, 8 ModelNet OFF meshes, each normalised to the unit sphere; B=32 N=M=4096)"] = \
+        chamfer_entry(sa, sb, 4096, 4096, 32)
+    sa, sb = surface_clouds(fx, normalise=False)
+    out["C2 shape on surface-sampled clouds, the files' own units (extent ratios up to 250 within a pair; B=32 N=M=4096)"] = \
+        chamfer_entry(sa, sb, 4096, 4096, 32)
+    del sa, sb
     a5 = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_A, 3, 1024, 32))  # SURVEY 8(d): C5 "also report 1024" (one rank's 32-cloud shard)
     b5 = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_B, 3, 1024, 32))
-    out["C5 shard at N=M=1024: chamfer fwd B=32 per GPU"] = _per_call_ms(fx, lambda: fx.chamfer_distance(a5, b5, loss_out=loss_dev, sync=False))
-    for n in (4096, 16384):  # benchmarks/metrics.jl:11-15,40: p_i = (i,i,i)/n, A == B, B = 1
-        p = fx.gpu(fx.synth.reference_bench_cloud(n))
-        out[f"reference harness chamfer fwd n={n} (A == B, collinear)"] = _per_call_ms(
-            fx, lambda: fx.chamfer_distance(p, p, loss_out=loss_dev, sync=False))
+    out["C5 shard at N=M=1024: chamfer fwd B=32 per GPU"] = chamfer_entry(a5, b5, 1024, 1024, 32)
+    # C3: chamfer_distance(mesh, mesh, 5000) = 2 x (areas -> probabilities -> CDF -> 5000 draws) + chamfer.  The reference redoes the
+    # CDFs on every call (src/transforms/mesh_func.jl:27-47): that is the figure of record; `cdf_cached` = the same call when the mesh
+    # objects still hold their CDFs (vertices unchanged since the last call, e.g. the target of a fitting loop)
     t = os.path.join(ROOT, "tests", "golden", "teapot.obj")
     m8, m8b = fx.gpu(fx.load_trimesh(*[t] * 8)), fx.gpu(fx.load_trimesh(*[t] * 8))
-    out["C3 chamfer_distance(mesh, mesh, 5000) B=8 teapots (2 samplings + chamfer)"] = _per_call_ms(
-        fx, lambda: fx.chamfer_distance(m8, m8b, 5000, seed=5, loss_out=loss_dev, sync=False))
+    V, F, n3 = m8.V, m8.F, 5000
+    c3_bytes = 2 * (12.0 * V * 8 + 12.0 * F * 8 + 8.0 * F * 8 + 12.0 * n3 * 8)  # SURVEY 8(d): verts + faces in, Float64 CDF, samples out
+    r = _per_call_ms(fx, lambda: fx.chamfer_distance(m8, m8b, n3, seed=5, loss_out=loss_dev, sync=False, reuse_cdf=False))
+    r["roofline"] = _roof(r["min_ms"], flops=16.0 * 8 * n3 * n3, nbytes=c3_bytes + 4.0 * 3 * 8 * 2 * n3)
+    r["cdf_cached"] = _per_call_ms(fx, lambda: fx.chamfer_distance(m8, m8b, n3, seed=5, loss_out=loss_dev, sync=False))
+    out["C3 chamfer_distance(mesh, mesh, 5000) B=8 teapots, CDFs rebuilt per call (2 x (CDF + draw) + chamfer)"] = r
     c4 = fx.gpu(fx.synth.uniform_cloud(0x5EED0004, 3, 1024, 32))
-    out["C4 kNN k=20 self graph B=32 N=1024 D=3"] = _per_call_ms(fx, lambda: fx.knn(c4, 20, drop_first=True))
+    r = _per_call_ms(fx, lambda: fx.knn(c4, 20, drop_first=True))
+    r["roofline"] = _roof(r["min_ms"], flops=8.0 * 32 * 1024 * 1024, nbytes=4.0 * 3 * 1024 * 32 + 2 * 4.0 * 20 * 1024 * 32)
+    out["C4 kNN k=20 self graph B=32 N=1024 D=3"] = r
     f64 = fx.gpu(np.asfortranarray(np.random.default_rng(1).standard_normal((64, 1024, 32)).astype(np.float32)))
-    out["C4' kNN k=20 self graph B=32 N=1024 D=64 (second EdgeConv)"] = _per_call_ms(fx, lambda: fx.knn(f64, 20, drop_first=True))
+    r = _per_call_ms(fx, lambda: fx.knn(f64, 20, drop_first=True))
+    r["roofline"] = _roof(r["min_ms"], flops=3.0 * 64 * 32 * 1024 * 1024, nbytes=4.0 * 64 * 1024 * 32 + 2 * 4.0 * 20 * 1024 * 32)
+    out["C4' kNN k=20 self graph B=32 N=1024 D=64 (second EdgeConv)"] = r
     return out
+
+
+def reference_harness(fx):
+    """benchmarks/metrics.jl:17-63 in full: n = 2^6 .. 2^14; chamfer_distance on generate_pcloud(n) (p_i = (i,i,i)/n, A == B,
+    B = 1), edge_loss and laplacian_loss on generate_trimesh(n) (the same points as vertices, faces (i,i,i)); forward, and
+    forward + backward (the harness times `gradient`: total - forward = its "back" column).  min over 100 single calls, ms."""
+    import numpy as np
+    rows = {}
+    loss_dev = fx.DeviceArray.empty((1,), np.float32)
+    for n in (64, 256, 1024, 4096, 16384):
+        p = fx.gpu(fx.synth.reference_bench_cloud(n))
+        row = {}
+        f = _per_call_ms(fx, lambda: fx.chamfer_distance(p, p, loss_out=loss_dev, sync=False))
+
+        def cfb():
+            _, ix, iy = fx.chamfer_distance(p, p, return_indices=True, loss_out=loss_dev, sync=False)
+            fx.chamfer_distance_grad(p, p, ix, iy)
+        t = _per_call_ms(fx, cfb)
+        row["chamfer_distance"] = {"forward_ms": f["min_ms"], "total_ms": t["min_ms"], "back_ms": t["min_ms"] - f["min_ms"],
+                                   "roofline": _roof(f["min_ms"], flops=16.0 * n * n, nbytes=4.0 * 3 * 2 * n)}
+        v = fx.synth.reference_bench_cloud(n)
+        faces = np.asfortranarray(np.tile(np.arange(1, n + 1, dtype=np.int32), (3, 1)))
+        m = fx.gpu(fx.TriMesh([v], [faces]))
+        E = int(fx.get_edges_packed(m).shape[0])
+        nnz = 2 * E + n
+        f = _per_call_ms(fx, lambda: fx.edge_loss(m, sync=False))
+
+        def efb():
+            fx.edge_loss(m, sync=False)
+            fx.edge_loss_grad(m)
+        t = _per_call_ms(fx, efb)
+        row["edge_loss"] = {"forward_ms": f["min_ms"], "total_ms": t["min_ms"], "back_ms": t["min_ms"] - f["min_ms"], "edges": E,
+                            "roofline": _roof(f["min_ms"], nbytes=12.0 * n + 8.0 * E)}
+        f = _per_call_ms(fx, lambda: fx.laplacian_loss(m, sync=False))
+
+        def lfb():
+            fx.laplacian_loss(m, sync=False)
+            fx.laplacian_loss_grad(m)
+        t = _per_call_ms(fx, lfb)
+        row["laplacian_loss"] = {"forward_ms": f["min_ms"], "total_ms": t["min_ms"], "back_ms": t["min_ms"] - f["min_ms"], "nnz": nnz,
+                                 "roofline": _roof(f["min_ms"], nbytes=12.0 * n + 8.0 * nnz + 4.0 * n)}
+        rows[str(n)] = row
+    return {"protocol": "benchmarks/metrics.jl:24-38: minimum over samples; here 100 single calls between HIP events per entry",
+            "npoints": rows}
 
 
 def cpu_baseline(fx):

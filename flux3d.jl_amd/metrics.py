@@ -77,7 +77,7 @@ def _chamfer_points(x, y, w1, w2, return_indices=False, loss_out=None, sync=True
 
 
 def chamfer_distance(A, B, num_samples=5000, w1=1.0, w2=1.0, return_indices=False, seed=None,
-                     loss_out=None, sync=True):
+                     loss_out=None, sync=True, reuse_cdf=True):
     """chamfer_distance(A, B; w1, w2) for PointCloud / arrays (src/metrics/pcloud.jl:11-26) and
     chamfer_distance(m1::TriMesh, m2::TriMesh, num_samples=5000; w1, w2) (src/metrics/mesh.jl:34-44).
 
@@ -89,8 +89,8 @@ def chamfer_distance(A, B, num_samples=5000, w1=1.0, w2=1.0, return_indices=Fals
         from .transforms import sample_points
         s1 = None if seed is None else seed
         s2 = None if seed is None else seed + 1
-        PA = sample_points(A, num_samples, seed=s1)
-        PB = sample_points(B, num_samples, seed=s2)
+        PA = sample_points(A, num_samples, seed=s1, reuse_cdf=reuse_cdf)
+        PB = sample_points(B, num_samples, seed=s2, reuse_cdf=reuse_cdf)
         return _chamfer_points(PA, PB, w1, w2, return_indices, loss_out, sync)
     return _chamfer_points(A, B, w1, w2, return_indices, loss_out, sync)
 

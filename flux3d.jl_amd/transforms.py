@@ -44,13 +44,13 @@ def _verts_padded_dev(m):
     return m.get_verts_padded() if m.on_device else m.dev("verts_padded")
 
 
-def _face_cdf(m, verts, faces, eps):
+def _face_cdf(m, verts, faces, eps, reuse=True):
     """The mesh's sampling CDF (areas -> Float64 probabilities -> prefix sums, src/transforms/mesh_func.jl:27-39)
     on the device.  It depends only on the vertices, so it is kept with the mesh's device vertex mirrors:
     computed once for a mesh that is sampled again and again (the target of a fitting loop), dropped with them
     when the vertices are replaced (set_verts_packed; offset / with_verts_packed start from empty mirrors)."""
     key = ("face_cdf", float(eps))
-    ws = m._dev.get(key) if m.on_device else None
+    ws = m._dev.get(key) if (m.on_device and reuse) else None
     if ws is None:
         nb = C.c_size_t(0)
         _lib.call("fx3d_sample_points_workspace_bytes", m.F, m.N, C.byref(nb))
@@ -63,7 +63,7 @@ def _face_cdf(m, verts, faces, eps):
 
 
 def sample_points(m, num_samples=5000, eps=EPS, seed=None, return_draws=False,
-                  face_idx=None, r1=None, r2=None, seed_dev=None):
+                  face_idx=None, r1=None, r2=None, seed_dev=None, reuse_cdf=True):
     """sample_points(m::TriMesh, num_samples=5000; eps) (src/transforms/mesh_func.jl:21-58).
 
     Returns a device ``(3, num_samples, B)`` Float32 array (the mesh's storage type in the
@@ -72,7 +72,8 @@ def sample_points(m, num_samples=5000, eps=EPS, seed=None, return_draws=False,
     0-based mesh-local, ``r1``, ``r2`` (n,B) to reproduce `_sample_points` for given draws.
     ``return_draws=True`` also returns (face_idx, r1, r2) device arrays for the adjoint.
     ``seed_dev``: optional device uint64 added to ``seed`` by the kernel (a captured graph advances it between
-    replays, see fit.FitStepGraph)."""
+    replays, see fit.FitStepGraph).  ``reuse_cdf=False``: recompute areas -> probabilities -> CDF on this call even
+    if the mesh object still holds them from an earlier one (what the reference does on every call; same result)."""
     verts = _verts_padded_dev(m)
     faces = m.dev("faces_padded")
     n, B = int(num_samples), m.N
@@ -88,7 +89,7 @@ def sample_points(m, num_samples=5000, eps=EPS, seed=None, return_draws=False,
     if seed is None:
         _seed_counter[0] = (_seed_counter[0] * 6364136223846793005 + 1442695040888963407) % (1 << 64)
         seed = _seed_counter[0]
-    ws = _face_cdf(m, verts, faces, eps)
+    ws = _face_cdf(m, verts, faces, eps, reuse=reuse_cdf)
     fo = DeviceArray.empty((n, B), np.int32) if return_draws else None
     a = DeviceArray.empty((n, B), np.float32) if return_draws else None
     b = DeviceArray.empty((n, B), np.float32) if return_draws else None

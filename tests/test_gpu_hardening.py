@@ -5,11 +5,12 @@ Order of distances everywhere: Julia's isless on the Float32 squared distance (N
 (oracle/flux3d_oracle.c: fless).  Every index a kernel returns must be a valid index -- the adjoint and the gathers
 dereference it."""
 import os
+import sys
 
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -656,7 +657,6 @@ def test_face_cdf_bits_every_kernel_variant(gpu_fx, oracle, case, fx_option):
 
 
 # ------------------------------------------------------------------------------ round 3: one process / several devices, options
-@pytest.mark.gpu
 def test_single_process_multi_device_entry_points(gpu_fx):
     """fx3d_comm_init_all + fx3d_chamfer_fwd_multi (the single-process form a Julia host needs) on the
     devices this box has -- one here, so ndev = 1: communicator from ncclCommInitAll, a worker thread + stream +
@@ -686,7 +686,6 @@ def test_single_process_multi_device_entry_points(gpu_fx):
         MultiDevice(devices=[fx.device_count()])
 
 
-@pytest.mark.gpu
 def test_option_api_replaces_environment_reads(gpu_fx, oracle, monkeypatch):
     """the variant switches are explicit options (fx3d_set_option), the environment only seeds their
     defaults when the library is first used.  Setting FX3D_NN1_VARIANT in the environment of a RUNNING process changes
@@ -713,9 +712,79 @@ def test_option_api_replaces_environment_reads(gpu_fx, oracle, monkeypatch):
     _lib.load().fx3d_profile_enable(0)
 
 
-def test_option_api_without_a_gpu(fx):
-    from flux3d_jl_amd import _lib
-    assert _lib.load().fx3d_option_count() == len(_lib.options()) >= 13
-    with _lib.option("knn_gather", 1):
-        assert _lib.get_option("knn_gather") == 1
-    assert _lib.get_option("knn_gather") == 0
+def _modelnet_root(tmp_path):
+    import shutil
+    for z in ("ModelNet10.zip", "ModelNet40.zip"):
+        shutil.copy(os.path.join(GOLDEN, "modelnet", z), tmp_path)
+    return str(tmp_path)
+
+
+def test_modelnet_off_files_sample_and_chamfer_against_the_oracle(gpu_fx, oracle, tmp_path):
+    """SURVEY 8 f.4, the real-data half: the reference's ModelNet10 / ModelNet40 test archives (OFF files, 138 ... 27 438
+    faces, listed as src/datasets/modelnet/base.jl:30-108 does) -> load_off -> a ragged TriMesh batch -> sample_points(4096)
+    -> chamfer_distance, against the oracle on the same meshes: draws and points bit for bit, NN indices bit for bit, loss
+    to 1e-5."""
+    fx = gpu_fx
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import modelnet_chamfer_eval as ev
+    meshes = ev.listing(_modelnet_root(tmp_path))
+    assert len(meshes) == 8 and sorted(m[2].shape[1] for m in meshes)[::7] == [138, 27438]
+    ia, ib = zip(*[ev.pair_of(k, 8) for k in range(8)])
+    assert all(a != b for a, b in zip(ia, ib))
+    ta = fx.gpu(fx.TriMesh([meshes[i][1] for i in ia], [meshes[i][2] for i in ia]))
+    tb = fx.gpu(fx.TriMesh([meshes[i][1] for i in ib], [meshes[i][2] for i in ib]))
+    n, seed = 4096, 77
+    A, *draws = fx.sample_points(ta, n, seed=seed, return_draws=True)
+    Bp = fx.sample_points(tb, n, seed=seed + 1)
+    oA, ofa, or1, or2 = oracle.sample_points_seeded(ta.get_verts_padded_host(), ta.get_faces_padded().astype(np.int64) - 1,
+                                                    ta._faces_len, n, seed, return_draws=True)
+    oB = oracle.sample_points_seeded(tb.get_verts_padded_host(), tb.get_faces_padded().astype(np.int64) - 1, tb._faces_len, n, seed + 1)
+    assert np.array_equal(draws[0].to_host(), ofa) and np.array_equal(draws[1].to_host(), or1) and np.array_equal(draws[2].to_host(), or2)
+    assert np.array_equal(A.to_host(), oA) and np.array_equal(Bp.to_host(), oB)
+    loss, ix, iy = fx.chamfer_distance(A, Bp, return_indices=True)
+    oloss, ox, oy, _ = oracle.chamfer_distance(oA, oB, return_all=True)
+    assert np.array_equal(ix.to_host(), ox) and np.array_equal(iy.to_host(), oy)
+    assert np.isclose(loss, oloss, rtol=LOSS_RTOL, atol=0)
+    assert float(fx.chamfer_distance(ta, tb, n, seed=seed)) == loss
+
+
+def test_modelnet_eval_driver_world_size_1_all_forms(gpu_fx, tmp_path):
+    """examples/modelnet_chamfer_eval.py end to end on this box's one GPU: the per-GPU-process form in its three collective
+    placements and the single-process form (fx3d_chamfer_fwd_multi) give the same per-evaluation losses."""
+    import json
+    import subprocess
+    root = _modelnet_root(tmp_path)
+    res = {}
+    for tag, extra in (("overlap", ["--mode", "overlap"]), ("serial", ["--mode", "serial"]), ("deferred", ["--mode", "deferred"]),
+                       ("multi", ["--single-process", "1"])):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "modelnet_chamfer_eval.py"), "--root", root,
+                            "--batch", "64", "--points", "2048"] + extra, capture_output=True, text=True, timeout=600, cwd=ROOT,
+                           env=dict(os.environ, MASTER_ADDR="", MASTER_PORT=""))
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[tag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert res[tag]["evaluations"] == 2 and res[tag]["pairs_of_clouds"] == 64 and len(res[tag]["meshes"]) == 8
+    ref = res["serial"]["loss_per_evaluation"]
+    assert all(np.isfinite(ref)) and min(ref) > 0
+    for tag in ("overlap", "deferred", "multi"):
+        assert res[tag]["loss_per_evaluation"] == ref, tag
+
+
+@pytest.mark.parametrize("ratio", [30.0, 250.0, 4.0e3, 1.0e5, 3.0e6, 1.0e9])
+@pytest.mark.parametrize("offset", [0.0, 3.0])
+def test_nn1_clouds_of_very_different_extent(gpu_fx, oracle, ratio, offset):
+    """A query far outside the candidate cloud (a unit teapot against a ModelNet table in millimetres: found with the
+    surface-sampled bench line, 690 us instead of 58) used to leave the fp16 range of the filter's query operand and scan
+    the cloud exactly; it now carries a power-of-two scale of its own (up to 2^14, i.e. |qm~| < 2^28), beyond that the
+    exact path remains.  Indices and distances against the oracle, both directions, flat faces included (a far query
+    sees the points of a face at nearly equal distances)."""
+    fx = gpu_fx
+    rng = np.random.default_rng(int(ratio) % 1000 + int(offset))
+    N, M, B = 1300, 1700, 2
+    x = rng.random((3, N, B)).astype(np.float32)
+    y = (rng.random((3, M, B)).astype(np.float32) - np.float32(0.5)) * np.float32(ratio) + np.float32(offset * ratio)
+    y[2, : M // 2, :] = np.float32(0.25 * ratio)           # half of the big cloud on one flat face
+    x, y = np.asfortranarray(x), np.asfortranarray(y)
+    ix, iy, dx, dy = fx.nearest_neighbors(x, y, return_dist=True)
+    oix, oiy, odx, ody = oracle.nn1(x, y, want_dist=True)
+    assert np.array_equal(ix.to_host(), oix) and np.array_equal(iy.to_host(), oiy)
+    assert np.array_equal(dx.to_host(), odx) and np.array_equal(dy.to_host(), ody)

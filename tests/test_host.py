@@ -227,3 +227,11 @@ def test_header_is_plain_c_and_links_from_c(fx, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "flux3d_hip" in r.stdout and ("chamfer_distance(A, B)" in r.stdout or "no MI355X visible" in r.stdout)
+
+
+def test_option_api_without_a_gpu(fx):
+    from flux3d_jl_amd import _lib
+    assert _lib.load().fx3d_option_count() == len(_lib.options()) >= 13
+    with _lib.option("knn_gather", 1):
+        assert _lib.get_option("knn_gather") == 1
+    assert _lib.get_option("knn_gather") == 0
