@@ -67,6 +67,9 @@ SIGNATURES = {
     "fx3d_chamfer_finalize_many": [vp, c_i32, c_i32, c_i32, c_i64, c_i32, c_f32, c_f32, vp, vp],
     "fx3d_chamfer_fwd": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_f32, c_f32, vp, C.POINTER(c_f32),
                          vp, vp, vp, sz, vp],
+    "fx3d_chamfer_pairwise_workspace_bytes": [c_i32, c_i32, c_i32, c_i32, C.POINTER(sz)],
+    "fx3d_chamfer_loss_pairwise_f32": [vp, c_i32, vp, c_i32, c_i32, c_i32, vp, vp, c_f32, c_f32, vp, C.POINTER(c_f32),
+                                       vp, sz, vp],
     "fx3d_chamfer_bwd": [vp, c_i32, vp, c_i32, c_i32, c_i32, vp, vp, c_f32, c_f32, c_f32, c_i64,
                          vp, vp, vp],
     "fx3d_chamfer_sampled_bwd": [vp, c_i32, vp, c_i32, c_i32, vp, vp, c_f32, c_f32, c_f32, c_i64,

@@ -330,6 +330,22 @@ end
 # adjoint of chamfer_distance(m1::TriMesh, m2::TriMesh, n) (src/metrics/mesh.jl:34-44) w.r.t. the padded vertices of m1 and / or
 # m2 in one launch: A / B = the forward's samples, ix / iy its neighbour indices, draws_* = (face, r1, r2) of the sampler.
 # `nothing` for a mesh skips its side.  Returns (gverts1, gverts2), each (3, V, N) or nothing.
+# The loss with the reference's own Float32 pairwise `mean` (src/metrics/pcloud.jl:47-50), from the forward's indices
+# (0-based Int32 device arrays as _chamfer_fwd(...; indices = true) returns them): identical bits to the CPU path's `mean`.
+function chamfer_loss_pairwise(A::HipArray{Float32,3}, B::HipArray{Float32,3}, ix::HipArray{Int32,2}, iy::HipArray{Int32,2},
+                               w1::Float32 = 1.0f0, w2::Float32 = 1.0f0)
+    D, N, Bn = size(A); M = size(B, 2)
+    nb = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_chamfer_pairwise_workspace_bytes(N::Int32, M::Int32, Bn::Int32, D::Int32, nb::Ref{Csize_t})::Int32)
+    ws = workspace(nb[])
+    loss_dev = HipArray{Float32,1}(undef, (1,)); host = Ref{Float32}(0)
+    check(@ccall LIB.fx3d_chamfer_loss_pairwise_f32(A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32, Bn::Int32, D::Int32,
+                                                    ix.ptr::Ptr{Cvoid}, iy.ptr::Ptr{Cvoid}, w1::Float32, w2::Float32,
+                                                    loss_dev.ptr::Ptr{Cvoid}, host::Ref{Float32}, ws.ptr::Ptr{Cvoid},
+                                                    length(ws)::Csize_t, DEFAULT_STREAM::Stream)::Int32)
+    return host[]
+end
+
 function chamfer_sampled_grad(A::HipArray{Float32,3}, B::HipArray{Float32,3}, ix::HipArray{Int32,2}, iy::HipArray{Int32,2},
                               m1, draws1, m2, draws2; w1::Number = 1.0, w2::Number = 1.0, gout::Number = 1)
     _, N, Bn = size(A); _, M, _ = size(B)

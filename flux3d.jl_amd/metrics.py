@@ -95,6 +95,23 @@ def chamfer_distance(A, B, num_samples=5000, w1=1.0, w2=1.0, return_indices=Fals
     return _chamfer_points(A, B, w1, w2, return_indices, loss_out, sync)
 
 
+def chamfer_loss_pairwise_f32(A, B, idx_a, idx_b, w1=1.0, w2=1.0, sync=True):
+    """The chamfer loss in the reference's own arithmetic -- Float32 pairwise `mean` (Base, blocks of 1024) over the
+    materialised squared differences, src/metrics/pcloud.jl:47-50 -- from the forward's indices
+    (``chamfer_distance(..., return_indices=True)``).  :func:`chamfer_distance` itself sums in Float64 (within 1e-6 of
+    this); use this one where the reference's last bit matters."""
+    x, y = _as_dev_points(A), _as_dev_points(B)
+    D, N, M, Bn = _check_pair(x, y)
+    n = C.c_size_t(0)
+    _lib.call("fx3d_chamfer_pairwise_workspace_bytes", N, M, Bn, D, C.byref(n))
+    ws = workspace(n.value, "chamfer_pairwise")
+    loss_dev = DeviceArray.empty((1,), np.float32)
+    host = C.c_float(0)
+    _lib.call("fx3d_chamfer_loss_pairwise_f32", x.ptr, N, y.ptr, M, Bn, D, idx_a.ptr, idx_b.ptr, float(w1), float(w2),
+              loss_dev.ptr, C.byref(host) if sync else None, ws.ptr, ws.nbytes, current_stream().handle)
+    return np.float32(host.value) if sync else loss_dev
+
+
 def chamfer_distance_grad(A, B, idx_a, idx_b, w1=1.0, w2=1.0, gout=1.0, B_global=None):
     """Adjoint of _chamfer_distance w.r.t. both clouds with the indices held constant
     (Zygote through src/metrics/pcloud.jl:47-48; `@ignore` at :45).  Returns device (D,N,B), (D,M,B)."""

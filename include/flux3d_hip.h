@@ -356,6 +356,17 @@ FX3D_API fx3d_status fx3d_voxel_workspace_bytes(int32_t B, size_t *bytes);
 FX3D_API fx3d_status fx3d_pointcloud_to_voxel(const float *points, int32_t N, int32_t B, int32_t res,
                                               float *voxels, void *ws, size_t ws_bytes, fx3d_stream_t s);
 
+/* The loss in the REFERENCE's own arithmetic, from the forward's NN indices: `mean((A .- B[:, nn]).^2) * 3.0f0` with
+ * Base's Float32 pairwise sum (blocks of 1024, the materialised (D,N,B) array in column-major order;
+ * src/metrics/pcloud.jl:47-50) -- bit for bit oracle/flux3d_oracle.c: fx3d_oracle_chamfer_loss_pairwise.  fx3d_chamfer_fwd
+ * sums in Float64 (one rounding, order independent); this entry point is for a host that wants the reference's last bit.
+ * Three small launches on `s`; loss_host optional (blocks).  ws: fx3d_chamfer_pairwise_workspace_bytes. */
+FX3D_API fx3d_status fx3d_chamfer_pairwise_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_t D, size_t *bytes);
+FX3D_API fx3d_status fx3d_chamfer_loss_pairwise_f32(const float *x, int32_t N, const float *y, int32_t M, int32_t B,
+                                                    int32_t D, const int32_t *idx_x, const int32_t *idx_y, float w1,
+                                                    float w2, float *loss_dev, float *loss_host, void *ws,
+                                                    size_t ws_bytes, fx3d_stream_t s);
+
 /* ---- multi-GPU: one process per GPU, batch sharded contiguously -------------------
  * The reference is single-device; the only collective the sharded path needs is all-reduce(sum) of
  * the two Float64 chamfer partial sums (RCCL over xGMI).  librccl is loaded at run time.

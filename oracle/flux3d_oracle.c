@@ -116,6 +116,53 @@ FX_API int fx3d_oracle_chamfer_fwd(const float *x, int N, const float *y, int M,
     return 0;
 }
 
+/* The same loss in the REFERENCE's own arithmetic: `mean(T)` of the materialised Float32 array
+ * T = (A .- B[:, nn_for_A]) .^ 2, size (D, N, B), column-major, is `sum(T) / length(T)` with Base's pairwise sum
+ * (base/reduce.jl mapreduce_impl, pairwise_blocksize = 1024): a range [ifirst, ilast] with ilast - ifirst < 1024 is summed
+ * left to right starting from T[ifirst] + T[ifirst + 1], a longer one is split at imid = ifirst + (ilast - ifirst) >> 1 and
+ * its halves are added.  Everything in Float32: v / Float32(length) * 3.0f0, then w1 * dA + w2 * dB.
+ * Caveat (stated, not hidden): the leaf loop of Base carries @simd, so a Julia build may re-associate a leaf's sum into as
+ * many partial sums as its target's vector width x unroll factor; this restatement is the un-vectorised definition, which is
+ * what `julia -O0` / a scalar target computes.  The PRODUCT's default (fx3d_chamfer_fwd) stays the Float64 sum above -- one
+ * rounding, order independent to 2^-53 --; fx3d_chamfer_loss_pairwise_f32 (csrc/chamfer.hip) reproduces THIS function bit
+ * for bit from the indices. */
+static float pairwise_sum_f32(const float *a, size_t ifirst, size_t ilast) { /* inclusive, 0-based */
+    if (ifirst == ilast) return a[ifirst];
+    if (ilast - ifirst < 1024) {
+        float v = a[ifirst] + a[ifirst + 1];
+        for (size_t i = ifirst + 2; i <= ilast; ++i) v = v + a[i];
+        return v;
+    }
+    const size_t imid = ifirst + ((ilast - ifirst) >> 1);
+    const float v1 = pairwise_sum_f32(a, ifirst, imid);
+    const float v2 = pairwise_sum_f32(a, imid + 1, ilast);
+    return v1 + v2;
+}
+
+FX_API int fx3d_oracle_chamfer_loss_pairwise(const float *x, int N, const float *y, int M, int B, int D,
+                                             const int32_t *idx_x, const int32_t *idx_y, float w1, float w2, float *loss) {
+    if (N <= 0 || M <= 0 || B <= 0 || D <= 0 || !idx_x || !idx_y) return -1;
+    float mean2[2];
+    for (int dir = 0; dir < 2; ++dir) {
+        const float *a = dir ? y : x, *c = dir ? x : y;
+        const int32_t *idx = dir ? idx_y : idx_x;
+        const int R = dir ? M : N, S = dir ? N : M;
+        const size_t len = (size_t)D * R * B;
+        float *T = (float *)malloc(sizeof(float) * len);
+        if (!T) return -2;
+        for (int b = 0; b < B; ++b)
+            for (int i = 0; i < R; ++i)
+                for (int d = 0; d < D; ++d) {
+                    const float t = a[((size_t)b * R + i) * D + d] - c[((size_t)b * S + idx[(size_t)b * R + i]) * D + d];
+                    T[((size_t)b * R + i) * D + d] = t * t;
+                }
+        mean2[dir] = pairwise_sum_f32(T, 0, len - 1) / (float)len;
+        free(T);
+    }
+    *loss = (w1 * (mean2[0] * 3.0f)) + (w2 * (mean2[1] * 3.0f));
+    return 0;
+}
+
 /* Zygote adjoint of src/metrics/pcloud.jl:47-48 with the indices held constant (@ignore,:45):
  *   gA = g*w1*(6/(D*N*B))*(A - B[nn_A])  -  scatter_add_{nn_B}( g*w2*(6/(D*M*B))*(B - A[nn_B]) )
  * and symmetrically for gB.   */

@@ -120,6 +120,20 @@ def chamfer_distance(x, y, w1=1.0, w2=1.0, return_all=False, kdtree=False):
     return np.float32(loss.value)
 
 
+def chamfer_loss_pairwise(x, y, ix, iy, w1=1.0, w2=1.0):
+    """The loss in the reference's own arithmetic: Float32 pairwise `mean` (block 1024) of the materialised squared
+    differences, from given NN indices (src/metrics/pcloud.jl:47-50)."""
+    x, D, N, B = _dims(x)
+    y, _, M, _ = _dims(y)
+    ix = np.asfortranarray(ix, dtype=np.int32)
+    iy = np.asfortranarray(iy, dtype=np.int32)
+    out = C.c_float(0)
+    rc = lib().fx3d_oracle_chamfer_loss_pairwise(_p(x), N, _p(y), M, B, D, _p(ix), _p(iy), C.c_float(w1), C.c_float(w2),
+                                                 C.byref(out))
+    assert rc == 0
+    return np.float32(out.value)
+
+
 def chamfer_bwd(x, y, ix, iy, w1=1.0, w2=1.0, gout=1.0):
     x, D, N, B = _dims(x)
     y, _, M, _ = _dims(y)

@@ -788,3 +788,21 @@ def test_nn1_clouds_of_very_different_extent(gpu_fx, oracle, ratio, offset):
     oix, oiy, odx, ody = oracle.nn1(x, y, want_dist=True)
     assert np.array_equal(ix.to_host(), oix) and np.array_equal(iy.to_host(), oiy)
     assert np.array_equal(dx.to_host(), odx) and np.array_equal(dy.to_host(), ody)
+
+
+@pytest.mark.parametrize("N,M,B,D", [(1, 1, 1, 3), (341, 342, 1, 3), (1000, 500, 2, 3), (4096, 4096, 32, 3), (700, 900, 3, 2), (300, 200, 2, 7)])
+def test_chamfer_loss_in_the_reference_float32_pairwise_arithmetic(gpu_fx, oracle, N, M, B, D):
+    """the one float output of the path in the reference's own arithmetic.  `mean((A .- B[:, nn]).^2) * 3f0`
+    with Base's Float32 pairwise sum (blocks of 1024 over the materialised column-major array, src/metrics/pcloud.jl:47-50):
+    fx3d_chamfer_loss_pairwise_f32 == the oracle's restatement bit for bit (lengths below, at and above the block size, leaf
+    boundaries that are not multiples of D), and both within 1e-6 of the Float64 sum the default forward uses."""
+    fx = gpu_fx
+    rng = np.random.default_rng(N + M)
+    x = np.asfortranarray(rng.random((D, N, B)).astype(np.float32))
+    y = np.asfortranarray(rng.random((D, M, B)).astype(np.float32))
+    dx, dy = fx.gpu(x), fx.gpu(y)
+    loss, ix, iy = fx.chamfer_distance(dx, dy, w1=0.75, w2=1.5, return_indices=True)
+    pw = fx.chamfer_loss_pairwise_f32(dx, dy, ix, iy, w1=0.75, w2=1.5)
+    opw = oracle.chamfer_loss_pairwise(x, y, ix.to_host(), iy.to_host(), 0.75, 1.5)
+    assert pw == opw, (pw, opw)
+    assert np.isclose(pw, loss, rtol=2e-6, atol=0)

@@ -353,3 +353,35 @@ def test_pointcloud_to_voxel_vs_kdtree(oracle):
         ref = (d * d <= 0.6 / res ** 2).astype(np.float32)
         got = vox[:, :, :, b].ravel(order="F")                     # first dim (fastest) = z
         assert np.array_equal(got[~near_thr], ref[~near_thr])
+
+
+def test_pairwise_float32_mean_follows_base_mapreduce(oracle):
+    """The oracle's restatement of the reference's `mean` (Base.mapreduce_impl: ranges of < 1024 + 1 elements summed left to
+    right from a[i] + a[i+1], longer ones split at ifirst + (ilast - ifirst) >> 1) against an independent numpy recursion, at
+    lengths around the block size and for a (3, N, B) problem whose leaves do not start at multiples of 3."""
+    rng = np.random.default_rng(5)
+
+    def psum(a, i, j):
+        if i == j:
+            return a[i]
+        if j - i < 1024:
+            v = np.float32(a[i] + a[i + 1])
+            for k in range(i + 2, j + 1):
+                v = np.float32(v + a[k])
+            return v
+        m = i + ((j - i) >> 1)
+        return np.float32(psum(a, i, m) + psum(a, m + 1, j))
+
+    for (N, M, B) in ((341, 342, 1), (1000, 500, 2), (5, 2049, 3)):
+        x = np.asfortranarray(rng.random((3, N, B)).astype(np.float32))
+        y = np.asfortranarray(rng.random((3, M, B)).astype(np.float32))
+        loss64, ix, iy, _ = oracle.chamfer_distance(x, y, 0.5, 2.0, return_all=True)
+        got = oracle.chamfer_loss_pairwise(x, y, ix, iy, 0.5, 2.0)
+        parts = []
+        for a, c, idx in ((x, y, ix), (y, x, iy)):
+            T = np.stack([(a[:, :, b] - c[:, idx[:, b], b]) ** 2 for b in range(B)], axis=2).astype(np.float32)
+            t = T.reshape(-1, order="F")
+            parts.append(np.float32(np.float32(psum(t, 0, t.size - 1) / np.float32(t.size)) * np.float32(3.0)))
+        want = np.float32(np.float32(np.float32(0.5) * parts[0]) + np.float32(np.float32(2.0) * parts[1]))
+        assert got == want
+        assert np.isclose(got, loss64, rtol=2e-6, atol=0)
