@@ -75,6 +75,7 @@ struct Nn1Params {
     int nsplit;                  // 1 = off
     unsigned long long *gres;    // [nsplit][2B][qstride] packed (d_bits << 32 | index): every split block stores its own row (no init, no atomics)
     int qstride;
+    int tail;                    // > 0: a cloud of chunk + (1 .. tail) points is ONE chunk + a tail every query evaluates exactly
 };
 
 __device__ __forceinline__ float min3f(float a, float b, float c) {
@@ -288,6 +289,9 @@ constexpr int kHFifo = 3;         // lane tiles tracked per lane and pass: the t
 constexpr int kHChunkMax = 4096;  // 32 B per candidate => 128 KiB
 constexpr int kHItemCap = 64 * kHFifo;  // the FIFO path never overflows the list
 constexpr int kHFarCap = 64;      // far candidates kept on the exact side list; more: the chunk falls back to exact scans
+constexpr int kHTail = 64;        // a cloud of up to kHChunkMax + kHTail points stays one LDS image: the last <= 64 candidates are
+                                  // compared exactly by every query (N = M = 4097 was 2.1 x N = M = 4096: two half-empty chunks,
+                                  // three rounds of blocks), and <= 64 queries beyond a block's passes are one more pass of one wave
 static_assert(kHChunkMax / (32 * kHLT) <= 64, "lane-tile ids live in the six low mantissa bits of the tracked keys");
 // Tracking keys: a lane tile's minimum with the tile's id in its six low mantissa bits (one v_and_or): |key - t| < 2^-17 |t|.
 // kKeyUp turns a key into an upper bound of the value it came from (and a threshold on values into one on keys).
@@ -361,6 +365,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     const int NC = dir ? p.N : p.M;
     if (tile >= (dir ? p.tiles_y : p.tiles_x)) return;
     if ((long long)split * p.chunk >= NC) return;  // this direction has fewer chunks than splits
+    const int ctail = (p.tail > 0 && p.nsplit == 1 && NC > p.chunk && NC - p.chunk <= p.tail) ? NC - p.chunk : 0;
+    const int NCm = NC - ctail;                    // candidates that go through the filter (the chunk loop)
     const float *__restrict__ qb = (dir ? p.y : p.x) + (size_t)b * NQ * 3;
     const float *__restrict__ cb = (dir ? p.x : p.y) + (size_t)b * NC * 3;
     int32_t *idx_out = dir ? p.idx_y : p.idx_x;
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
 #ifdef FX3D_KO_STATS
     const bool one_shot = false;
 #else
-    const bool one_shot = NC <= CH;
+    const bool one_shot = NCm <= CH;
 #endif
     if (tid == 0) { nfar[0] = 0; nfar[1] = 0; }  // (ordered before their first use by the barrier of the bounding-box pass)
     float qpre[3];  // this lane's query of the coming tile pass (the load's latency hides behind the prologue)
@@ -539,8 +545,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     double acc = 0.0;
 
     const int jfirst = split * CH, jstep = p.nsplit * CH;
-    for (int j0 = jfirst; j0 < NC; j0 += jstep) {
-        const int cnt = (NC - j0) < CH ? (NC - j0) : CH;
+    for (int j0 = jfirst; j0 < NCm; j0 += jstep) {
+        const int cnt = (NCm - j0) < CH ? (NCm - j0) : CH;
         const int cnt_pad = (cnt + 32 * kHLT - 1) / (32 * kHLT) * (32 * kHLT);
         if (j0 > jfirst) __syncthreads();
         // ---- stage the fp16 split image ------------------------------------------------------------------
@@ -569,13 +575,16 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         if (tid == 0) nfar[fslot ^ 1] = 0;   // the next chunk's counter (its staging starts behind the barrier at the loop top)
         fslot ^= 1;
         const bool far_ok = nf <= kHFarCap;  // more than the side list holds: this chunk's filter is not used
-        for (int tp = 0; tp < tpb; ++tp) {
+        // (the last tile of a direction goes on past tpb passes while queries are left: the planner folds a remainder of <= 64
+        //  queries into it instead of giving them a block of their own)
+        const bool last_tile = tile == (dir ? p.tiles_y : p.tiles_x) - 1;
+        for (int tp = 0; tp < tpb || (last_tile && one_shot); ++tp) {
             if ((tile * tpb + tp) * QB >= NQ) break;  // uniform
             if (j0 == jfirst) {
                 qi = (tile * tpb + tp) * QB + wv * 32 + jq;
 #pragma unroll
                 for (int d = 0; d < 3; ++d) qr[d] = qpre[d];  // requested before the bounding-box pass / during the previous tile pass
-                if (tp + 1 < tpb) {                          // the next pass's query: in flight behind this pass
+                if (tp + 1 < tpb || (last_tile && one_shot)) {  // the next pass's query: in flight behind this pass (clamped if there is none)
                     const int qn1 = (tile * tpb + tp + 1) * QB + wv * 32 + jq;
                     const int qc1 = qn1 < NQ ? qn1 : NQ - 1;
 #pragma unroll
@@ -818,10 +827,20 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                         atomicMin(&qres[qs], ((unsigned long long)kd << 32) | (unsigned int)(j0 + jc));
                     }
                 }
+                // the cloud's tail beyond the LDS image (<= kHTail candidates): every query of the wave against each, exactly
+                if (ctail && j0 + jstep >= NCm) {
+                    for (int t = lane; t < 32 * ctail; t += 64) {
+                        const int qs = t & 31, jc = NCm + (t >> 5);
+                        const float qq[3] = {qtab[qs * 3], qtab[qs * 3 + 1], qtab[qs * 3 + 2]};
+                        const float *src = cb + (size_t)jc * 3;
+                        const float cc3[3] = {src[0], src[1], src[2]};
+                        atomicMin(&qres[qs], ((unsigned long long)dist_key(sqd<3>(qq, cc3)) << 32) | (unsigned int)jc);
+                    }
+                }
             }
             FX3D_PROBE_MARK(tp == 0 ? 4 : 8);
 
-            if (j0 + jstep >= NC) {  // last chunk of this block: results of this tile pass
+            if (j0 + jstep >= NCm) {  // last chunk of this block: results of this tile pass
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();
                 if (hh == 0) {
@@ -1101,6 +1120,7 @@ struct Plan {
     int variant;  // 0 = exact hot loop (D = 2, and D = 3 under FX3D_NN1_VARIANT=0), 3 = fp16-split MFMA filter + exact re-scan
     int threads, tpb, tpb_y;  // tpb: passes per block of the x -> y direction, tpb_y: of y -> x
     int nsplit;  // fp16 variant: chunk subsets per query tile (multi-chunk clouds with too few blocks)
+    int tail;    // fp16 variant: kHTail when clouds of chunk + (1 .. kHTail) points run as one chunk + an exact tail
 };
 
 // option nn1_variant = 0 selects the exact VALU loop for D = 3 (A/B measurements; the f32 VALU / MFMA filter variants
@@ -1118,7 +1138,7 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
     while (R > 1 && work / (kThreads * R) < 512) R >>= 1;
     pl.R = R;
     pl.tpb = pl.tpb_y = 1;
-    const int maxc = N > M ? N : M;
+    const int maxc0 = N > M ? N : M;
     const int clouds8 = (2 * B + 7) / 8;
     pl.nsplit = 1;
     if (pl.variant == 0) {
@@ -1126,7 +1146,7 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
         pl.tiles_x = (N + per_block - 1) / per_block;
         pl.tiles_y = (M + per_block - 1) / per_block;
         pl.tiles = pl.tiles_x > pl.tiles_y ? pl.tiles_x : pl.tiles_y;
-        int chunk = (maxc + kTile - 1) / kTile * kTile;
+        int chunk = (maxc0 + kTile - 1) / kTile * kTile;
         if (chunk > kChunkMax) chunk = kChunkMax;
         pl.chunk = chunk;
         pl.lds_bytes = (size_t)chunk * (D <= 3 ? D : 0) * sizeof(float);
@@ -1140,29 +1160,42 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
     // ONE chunk of a split run (any number of passes; subsets merge through 64-bit atomicMin slots, +8 us of
     // extra launches).  Few large clouds want many small chunks, many small clouds want passes.
     const int cmax = kHChunkMax, gran = 32 * kHLT;
-    const int cminc = (maxc + cmax - 1) / cmax;
-    double best = 1e30;
-    int b_chunk = (maxc + gran - 1) / gran * gran < cmax ? (maxc + gran - 1) / gran * gran : cmax, b_tpb = 1, b_split = 1;
+    // a larger cloud of at most cmax + kHTail points is planned (and run) as ONE chunk of cmax with an exact tail
     const int tpb_env = opt(OPT_NN1_TPB);
-    for (int nch = cminc; nch <= cminc * 8 && nch <= 64; ++nch) {
-        int ch = ((maxc + nch - 1) / nch + gran - 1) / gran * gran;
-        if (ch > cmax) continue;
-        const int anch = (maxc + ch - 1) / ch;
-        for (int split = 0; split < 2; ++split) {
-            if (split && (!allow_split || anch == 1 || opt(OPT_NN1_NOSPLIT))) continue;
-            for (int tpb = 1; tpb <= 8; tpb *= 2) {
-                if (!split && anch > 1 && tpb > 1) continue;
-                if (tpb_env > 0 && tpb != tpb_env && (split || anch == 1)) continue;
-                const long long tiles = ((long long)maxc + 512 * tpb - 1) / (512 * tpb);
-                const long long blocks = 2ll * B * tiles * (split ? anch : 1);
-                const double per_chunk = 5.0 * ch / 4096.0 + 0.5 + tpb * (9.7 * ch / 4096.0 + 0.8);
-                const double t_block = 2.8 * maxc / 4096.0 + (split ? 1 : anch) * per_chunk;
-                const double rounds = (double)((blocks + 255) / 256);
-                const double t = rounds * t_block + (split ? 8.0 : 0.0);
-                if (t < best - 1e-9) { best = t; b_chunk = ch; b_tpb = tpb; b_split = split ? anch : 1; }
+    int maxc = maxc0, b_chunk = 0, b_tpb = 1, b_split = 1;
+    auto search = [&](int mc) {  // mc: the candidates that go through LDS images
+        maxc = mc;
+        const int cminc = (maxc + cmax - 1) / cmax;
+        double best = 1e30;
+        b_chunk = (maxc + gran - 1) / gran * gran < cmax ? (maxc + gran - 1) / gran * gran : cmax; b_tpb = 1; b_split = 1;
+        for (int nch = cminc; nch <= cminc * 8 && nch <= 64; ++nch) {
+            int ch = ((maxc + nch - 1) / nch + gran - 1) / gran * gran;
+            if (ch > cmax) continue;
+            const int anch = (maxc + ch - 1) / ch;
+            for (int split = 0; split < 2; ++split) {
+                if (split && (!allow_split || anch == 1 || opt(OPT_NN1_NOSPLIT))) continue;
+                for (int tpb = 1; tpb <= 8; tpb *= 2) {
+                    if (!split && anch > 1 && tpb > 1) continue;
+                    if (tpb_env > 0 && tpb != tpb_env && (split || anch == 1)) continue;
+                    const long long tiles = ((long long)maxc + 512 * tpb - 1) / (512 * tpb);
+                    const long long blocks = 2ll * B * tiles * (split ? anch : 1);
+                    const double per_chunk = 5.0 * ch / 4096.0 + 0.5 + tpb * (9.7 * ch / 4096.0 + 0.8);
+                    const double t_block = 2.8 * maxc / 4096.0 + (split ? 1 : anch) * per_chunk;
+                    const double rounds = (double)((blocks + 255) / 256);
+                    const double t = rounds * t_block + (split ? 8.0 : 0.0);
+                    if (t < best - 1e-9) { best = t; b_chunk = ch; b_tpb = tpb; b_split = split ? anch : 1; }
+                }
             }
         }
+    };
+    // a cloud of cmax + (1 .. kHTail) points: planned as cmax; kept if that plan is ONE chunk of cmax per block (then the kernel
+    // runs the tail exactly), otherwise planned again at its true size
+    pl.tail = 0;
+    if (maxc0 > cmax && maxc0 - cmax <= kHTail) {
+        search(cmax);
+        if (b_split == 1 && b_chunk == cmax) pl.tail = kHTail;
     }
+    if (!pl.tail) search(maxc0);
     pl.chunk = b_chunk;
     pl.tpb = pl.tpb_y = b_tpb;
     pl.nsplit = b_split;
@@ -1187,8 +1220,17 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
                 if (t < bt - 1e-9) { bt = t; pl.tpb = ta; pl.tpb_y = tb; }
             }
     }
-    pl.tiles_x = (N + 512 * pl.tpb - 1) / (512 * pl.tpb);
-    pl.tiles_y = (M + 512 * pl.tpb_y - 1) / (512 * pl.tpb_y);
+    // one-chunk plans: a remainder of <= kHTail queries beyond a direction's last full tile is one more pass of that tile's block
+    // (one wave busy for ~6 us) instead of a block of its own (prologue + a pass: a second round of blocks at N = 4097)
+    const bool fold = b_split == 1 && maxc <= b_chunk;
+    auto ntiles = [&](int nq, int tpb) {
+        const int per = 512 * tpb;
+        int t = (nq + per - 1) / per;
+        if (fold && t > 1 && nq - (t - 1) * per <= kHTail) --t;
+        return t;
+    };
+    pl.tiles_x = ntiles(N, pl.tpb);
+    pl.tiles_y = ntiles(M, pl.tpb_y);
     pl.tiles = pl.tiles_x > pl.tiles_y ? pl.tiles_x : pl.tiles_y;
     pl.grid = clouds8 * 8 * pl.tiles * pl.nsplit;
     if (2 * B < 8) pl.grid = 2 * B * pl.tiles * pl.nsplit;  // plain block order (see kernel)
@@ -1259,6 +1301,7 @@ fx3d_status run_nn1(const float *x, int N, const float *y, int M, int B, int D, 
     p.partials = partials;
     p.tiles = pl.tiles; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.chunk = pl.chunk;
     p.tpb = pl.tpb; p.tpb_y = pl.tpb_y;
+    p.tail = pl.tail;
     const bool want_idx = idx_x || idx_y;
     ProfileScope prof("nn1", st);
     if (D == 3) return want_idx ? launch_small<3, true>(p, pl, st) : launch_small<3, false>(p, pl, st);

@@ -806,3 +806,25 @@ def test_chamfer_loss_in_the_reference_float32_pairwise_arithmetic(gpu_fx, oracl
     opw = oracle.chamfer_loss_pairwise(x, y, ix.to_host(), iy.to_host(), 0.75, 1.5)
     assert pw == opw, (pw, opw)
     assert np.isclose(pw, loss, rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("N,M,B", [(4097, 4097, 3), (4160, 4100, 2), (4161, 4096, 2), (4159, 60, 2), (70, 4130, 1), (4097, 4097, 32),
+                                   (1030, 700, 8), (1088, 1088, 32), (2050, 2049, 16), (577, 513, 32), (4096 + 64, 4096 + 64, 9)])
+def test_nn1_just_above_an_lds_image_and_query_remainders(gpu_fx, oracle, N, M, B):
+    """N = M = 4097 cost 2.1 x N = M = 4096.  A cloud of up to 4096 + 64 points is ONE LDS image now plus a tail
+    that every query compares exactly, and a remainder of <= 64 queries beyond a direction's last full tile is one more pass of
+    that tile's block.  Indices, distances and the loss against the oracle at the boundaries of both rules (4160 / 4161
+    candidates; remainders of 1, 6, 64, 65 queries; clouds of different sizes; the tail holding the nearest neighbour)."""
+    fx = gpu_fx
+    rng = np.random.default_rng(N * 7 + M)
+    x = np.asfortranarray(rng.random((3, N, B)).astype(np.float32))
+    y = np.asfortranarray(rng.random((3, M, B)).astype(np.float32))
+    if M > 4096:   # make tail candidates the nearest neighbours of some queries (and exact duplicates of earlier candidates: ties -> lower index)
+        y[:, 4096:, :] = x[:, : M - 4096, :]
+        y[:, -1, :] = y[:, 5, :]
+    ix, iy, dx, dy = fx.nearest_neighbors(x, y, return_dist=True)
+    oix, oiy, odx, ody = oracle.nn1(x, y, want_dist=True)
+    assert np.array_equal(ix.to_host(), oix) and np.array_equal(iy.to_host(), oiy)
+    assert np.array_equal(dx.to_host(), odx) and np.array_equal(dy.to_host(), ody)
+    loss = fx.chamfer_distance(x, y, w1=0.5, w2=1.5)
+    assert np.isclose(loss, oracle.chamfer_distance(x, y, 0.5, 1.5), rtol=LOSS_RTOL, atol=0)
