@@ -123,6 +123,11 @@ SIGNATURES = {
                                  C.POINTER(c_f32), vp, sz, vp],
     "fx3d_chamfer_fwd_sharded_async": [vp, vp, c_i32, vp, c_i32, c_i32, c_i32, c_i64, c_f32, c_f32, vp, vp, vp, sz,
                                        vp, vp, vp, vp],
+    "fx3d_chamfer_distance_host": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_f32, c_f32, C.POINTER(c_f32), vp, vp],
+    "fx3d_knn_host": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, vp],
+    "fx3d_sample_points_host": [vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_f64, c_u64, vp],
+    "fx3d_edge_loss_host": [vp, c_i64, vp, c_i64, c_f32, C.POINTER(c_f32)],
+    "fx3d_laplacian_loss_host": [vp, c_i64, vp, vp, vp, C.POINTER(c_f32)],
     "fx3d_build_edges_packed": [vp, c_i64, c_i64, c_i32, vp, vp, C.POINTER(c_i64)],
     "fx3d_build_laplacian_csr": [vp, c_i64, c_i64, c_i32, vp, vp, vp, C.POINTER(c_i64)],
 }

@@ -795,6 +795,45 @@ function edge_features(X::HipArray{Float32,3}, idx::HipArray{Int32,3}; layout::I
 end
 set_device(dev::Integer) = check(@ccall LIB.fx3d_set_device(dev::Int32)::Int32)
 
+# ---- host-array convenience methods (SURVEY 8b): plain `Array`s in, host results out; the device path runs underneath ----
+# (for callers that have not moved their data to HipArray: same results as the HipArray methods, PCIe copies included)
+function chamfer_distance_host(A::Array{Float32,3}, B::Array{Float32,3}; w1::Number = 1.0, w2::Number = 1.0)
+    D, N, Bn = size(A); M = size(B, 2)
+    loss = Ref{Float32}(0)
+    check(@ccall LIB.fx3d_chamfer_distance_host(A::Ptr{Float32}, N::Int32, B::Ptr{Float32}, M::Int32, Bn::Int32, D::Int32,
+                                                Float32(w1)::Float32, Float32(w2)::Float32, loss::Ref{Float32},
+                                                C_NULL::Ptr{Int32}, C_NULL::Ptr{Int32})::Int32)
+    return loss[]
+end
+function knn_host(X::Array{Float32,3}, K::Int; drop_first::Bool = true)
+    D, N, Bn = size(X)
+    idx = Array{Int32,3}(undef, K, N, Bn)
+    check(@ccall LIB.fx3d_knn_host(X::Ptr{Float32}, N::Int32, C_NULL::Ptr{Float32}, N::Int32, Bn::Int32, D::Int32, K::Int32,
+                                   Int32(drop_first)::Int32, idx::Ptr{Int32}, C_NULL::Ptr{Float32})::Int32)
+    return idx .+ Int32(1)
+end
+function sample_points_host(verts_padded::Array{Float32,3}, faces_padded0::Array{Int32,3}, faces_len::Vector{Int32}, n::Int;
+                            eps::Number = 1e-6, seed::UInt64 = rand(UInt64))
+    _, V, Bn = size(verts_padded); F = size(faces_padded0, 2)
+    out = Array{Float32,3}(undef, 3, n, Bn)
+    check(@ccall LIB.fx3d_sample_points_host(verts_padded::Ptr{Float32}, V::Int32, faces_padded0::Ptr{Int32}, F::Int32,
+                                             faces_len::Ptr{Int32}, Bn::Int32, n::Int32, Float64(eps)::Float64, seed::UInt64,
+                                             out::Ptr{Float32})::Int32)
+    return out
+end
+function edge_loss_host(verts::Array{Float32,2}, edges0::Array{Int32,2}, target::Number = 0)
+    loss = Ref{Float32}(0)
+    check(@ccall LIB.fx3d_edge_loss_host(verts::Ptr{Float32}, size(verts, 2)::Int64, edges0::Ptr{Int32}, size(edges0, 1)::Int64,
+                                         Float32(target)::Float32, loss::Ref{Float32})::Int32)
+    return loss[]
+end
+function laplacian_loss_host(verts::Array{Float32,2}, rowptr::Vector{Int32}, colind::Vector{Int32}, vals::Vector{Float32})
+    loss = Ref{Float32}(0)
+    check(@ccall LIB.fx3d_laplacian_loss_host(verts::Ptr{Float32}, size(verts, 2)::Int64, rowptr::Ptr{Int32}, colind::Ptr{Int32},
+                                              vals::Ptr{Float32}, loss::Ref{Float32})::Int32)
+    return loss[]
+end
+
 # ---- the rest of the ABI: device / stream / event utilities, explicit-draw sampling, face areas, host topology ----
 version() = unsafe_string(@ccall LIB.fx3d_version()::Cstring)
 # variant switches (include/flux3d_hip.h): named integer options instead of environment reads on the launch path

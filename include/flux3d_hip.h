@@ -415,6 +415,26 @@ FX3D_API fx3d_status fx3d_chamfer_fwd_sharded_async(fx3d_comm_t comm, const floa
                                                     void *ws, size_t ws_bytes, fx3d_stream_t s,
                                                     fx3d_stream_t comm_stream, fx3d_event_t ready, fx3d_event_t done);
 
+/* ---- host-pointer convenience variants --------------------------------------------------------------
+ * The reference's CPU methods take plain `Array`s (src/metrics/pcloud.jl:54-70, src/models/dgcnn.jl:3-7,
+ * src/transforms/mesh_func.jl:21-58, src/metrics/mesh.jl:9-32).  These take HOST buffers in Julia's column-major layout and
+ * return host results: inputs are staged into device scratch owned by the calling thread (grow-only, reused), the SAME
+ * device entry points run (there is no CPU code path), outputs are copied back, the call synchronises.  Convenient, not
+ * fast: the PCIe copies are inside the call.  Indices 0-based int32 as everywhere at this boundary.
+ * fx3d_chamfer_distance_host: any of loss / idx_x / idx_y may be NULL (not all).  fx3d_knn_host: y == NULL -> self
+ * search (M ignored); dist optional.  Faces / edges / CSR as for the device entry points above. */
+FX3D_API fx3d_status fx3d_chamfer_distance_host(const float *x, int32_t N, const float *y, int32_t M, int32_t B, int32_t D,
+                                                float w1, float w2, float *loss, int32_t *idx_x, int32_t *idx_y);
+FX3D_API fx3d_status fx3d_knn_host(const float *x, int32_t N, const float *y, int32_t M, int32_t B, int32_t D, int32_t k,
+                                   int32_t drop_first, int32_t *idx, float *dist);
+FX3D_API fx3d_status fx3d_sample_points_host(const float *verts_padded, int32_t Vmax, const int32_t *faces_padded,
+                                             int32_t Fmax, const int32_t *faces_len, int32_t B, int32_t n, double eps,
+                                             uint64_t seed, float *out);
+FX3D_API fx3d_status fx3d_edge_loss_host(const float *verts, int64_t V, const int32_t *edges, int64_t E, float target,
+                                         float *loss);
+FX3D_API fx3d_status fx3d_laplacian_loss_host(const float *verts, int64_t V, const int32_t *rowptr, const int32_t *colind,
+                                              const float *vals, float *loss);
+
 /* ---- one process, several devices (SURVEY.md 8b "fx3d_comm_init_all(ndev)") ---------------------------------------
  * The reference is ONE Julia process (src/metrics/pcloud.jl:54-70): fx3d_comm_init_all gives such a host the
  * communicators of `ndev` of its devices (ncclCommInitAll; devices == NULL: 0..ndev-1) and, per device, a worker thread,

@@ -828,3 +828,52 @@ def test_nn1_just_above_an_lds_image_and_query_remainders(gpu_fx, oracle, N, M, 
     assert np.array_equal(dx.to_host(), odx) and np.array_equal(dy.to_host(), ody)
     loss = fx.chamfer_distance(x, y, w1=0.5, w2=1.5)
     assert np.isclose(loss, oracle.chamfer_distance(x, y, 0.5, 1.5), rtol=LOSS_RTOL, atol=0)
+
+
+def test_host_pointer_convenience_variants(gpu_fx, oracle):
+    """host-pointer variants of the ops -- plain host buffers in Julia's layout in, host results out, the device
+    path underneath (per-thread device scratch, the same entry points, a synchronous call).  Against the oracle: chamfer
+    loss + both index arrays, kNN lists + distances (self and cross), seeded samples, both mesh losses on the teapot."""
+    import ctypes as C
+    fx = gpu_fx
+    from flux3d_jl_amd import _lib
+    lib = _lib.load()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rng = np.random.default_rng(12)
+    for rep in range(2):  # second round: the scratch is reused / grown
+        N, M, B = (700, 900, 3) if rep == 0 else (4096, 2000, 5)
+        x = np.asfortranarray(rng.random((3, N, B)).astype(np.float32))
+        y = np.asfortranarray(rng.random((3, M, B)).astype(np.float32))
+        loss = C.c_float(0)
+        ix, iy = np.zeros((N, B), np.int32, order="F"), np.zeros((M, B), np.int32, order="F")
+        _lib.check(lib.fx3d_chamfer_distance_host(p(x), N, p(y), M, B, 3, 0.5, 2.0, C.byref(loss), p(ix), p(iy)))
+        oloss, ox, oy, _ = oracle.chamfer_distance(x, y, 0.5, 2.0, return_all=True)
+        assert np.array_equal(ix, ox) and np.array_equal(iy, oy) and np.isclose(loss.value, oloss, rtol=LOSS_RTOL, atol=0)
+        _lib.check(lib.fx3d_chamfer_distance_host(p(x), N, p(y), M, B, 3, 0.5, 2.0, C.byref(loss), None, None))
+        assert np.isclose(loss.value, oloss, rtol=LOSS_RTOL, atol=0)
+    k = 20
+    for D, y in ((3, None), (64, None), (3, np.asfortranarray(rng.random((3, 333, 2)).astype(np.float32)))):
+        x = np.asfortranarray(rng.standard_normal((D, 1024 if y is None else 200, 2)).astype(np.float32))
+        N = x.shape[1]
+        idx, dist = np.zeros((k, N, 2), np.int32, order="F"), np.zeros((k, N, 2), np.float32, order="F")
+        _lib.check(lib.fx3d_knn_host(p(x), N, p(y) if y is not None else None, y.shape[1] if y is not None else 0, 2, D, k,
+                                     int(y is None), p(idx), p(dist)))
+        oi, od = oracle.knn(x, k, y=y, drop_first=y is None)
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    m = fx.load_trimesh(os.path.join(GOLDEN, "teapot.obj"), os.path.join(GOLDEN, "sphere.obj"))
+    vp = m.get_verts_padded_host()
+    fp0 = np.asfortranarray(m.get_faces_padded().astype(np.int32) - 1)
+    fl = m._faces_len.astype(np.int32)
+    out = np.zeros((3, 3000, 2), np.float32, order="F")
+    _lib.check(lib.fx3d_sample_points_host(p(vp), m.V, p(fp0), m.F, p(fl), 2, 3000, 1e-6, 99, p(out)))
+    assert np.array_equal(out, oracle.sample_points_seeded(vp, fp0.astype(np.int64), m._faces_len, 3000, 99))
+    vpk = fx.get_verts_packed(m)
+    edges0 = np.asfortranarray(fx.get_edges_packed(m).astype(np.int32) - 1)
+    l = C.c_float(0)
+    _lib.check(lib.fx3d_edge_loss_host(p(vpk), vpk.shape[1], p(edges0), edges0.shape[0], 0.05, C.byref(l)))
+    assert np.isclose(l.value, oracle.edge_loss(vpk, edges0.astype(np.int64), 0.05), rtol=LOSS_RTOL)
+    rowptr, colind, vals = oracle.laplacian_csr(edges0.astype(np.int64), vpk.shape[1])
+    r32, c32 = rowptr.astype(np.int32), colind.astype(np.int32)
+    _lib.check(lib.fx3d_laplacian_loss_host(p(vpk), vpk.shape[1], p(r32), p(c32), p(vals), C.byref(l)))
+    assert np.isclose(l.value, oracle.laplacian_loss(vpk, rowptr, colind, vals), rtol=LOSS_RTOL)
+    assert lib.fx3d_chamfer_distance_host(p(x), 0, p(x), 5, 1, 3, 1.0, 1.0, C.byref(l), None, None) == -1
