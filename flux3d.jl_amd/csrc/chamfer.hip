@@ -372,7 +372,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     int32_t *idx_out = dir ? p.idx_y : p.idx_x;
     float *dmin_out = dir ? p.dmin_y : p.dmin_x;
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: everything derived from it lives in scalar registers
     const int jq = lane & 31, hh = lane >> 5;
     const int CH = p.chunk;
     const int tpb = dir ? p.tpb_y : p.tpb;
@@ -385,11 +386,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     unsigned int *items = witems + wv * kHItemCap;
     float *qtab = wq + wv * 96;
     const bool vec = (reinterpret_cast<uintptr_t>(cb) & 15) == 0;
-#ifdef FX3D_KO_STATS
-    const bool one_shot = false;
-#else
     const bool one_shot = NCm <= CH;
-#endif
     if (tid == 0) { nfar[0] = 0; nfar[1] = 0; }  // (ordered before their first use by the barrier of the bounding-box pass)
     float qpre[3];  // this lane's query of the coming tile pass (the load's latency hides behind the prologue)
     {
@@ -405,10 +402,6 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     //      much smaller than the farthest point keeps its fp16 pieces out of the subnormals; |c~|^2 < 3 * 2^14 fits fp16 ----
     float mu[3], cinf = 0.0f, varmax = 0.0f;
     bool allfin = true;
-#ifdef FX3D_KO_STATS
-    mu[0] = mu[1] = mu[2] = 0.5f; cinf = 0.5f; varmax = 0.25f;
-    if (p.N < 0)
-#endif
     {
         // thread t takes points t, t + 1024, ...: 12-byte loads, consecutive lanes on consecutive points (coalesced, and the
         // 16-byte LDS slots of a wave's points are consecutive: no bank conflicts when they are parked and converted)
@@ -522,6 +515,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         (void)frexpf(rng, &e);  // rng = m 2^e, m in [0.5,1)
         sc = ldexpf(1.0f, 7 - e);
     }
+    // (block-uniform values the compiler cannot prove uniform -- they came through LDS --: into scalar registers, the main
+    //  loop needs the vector ones; a kernel that spills pays ~1.2 us per launch for the scratch set-up)
+    auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    mu[0] = uni(mu[0]); mu[1] = uni(mu[1]); mu[2] = uni(mu[2]); sc = uni(sc); rng = uni(rng); cinf = uni(cinf);
     // pieces of candidate `pt` (index within the chunk); a far one leaves the filter (t = +inf) for the side list
     const bool has_far = sane && rng < cinf;  // (uniform) clean clouds skip the test below
     int fslot = 0;                             // nfar[fslot] counts this chunk's far candidates
@@ -539,6 +536,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     FX3D_PROBE_MARK(1);
 
     float qr[3], da = 0.0f;  // band: a tile qualifies while its minimum <= best * kBandB1 + da
+    bool qfin = true;        // this lane's query has finite coordinates
     int qi = 0;
     bool qok = true;
     h8 bq;
@@ -582,13 +580,13 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             if ((tile * tpb + tp) * QB >= NQ) break;  // uniform
             if (j0 == jfirst) {
                 qi = (tile * tpb + tp) * QB + wv * 32 + jq;
+                if (tp == 0) {  // requested before the bounding-box pass
 #pragma unroll
-                for (int d = 0; d < 3; ++d) qr[d] = qpre[d];  // requested before the bounding-box pass / during the previous tile pass
-                if (tp + 1 < tpb || (last_tile && one_shot)) {  // the next pass's query: in flight behind this pass (clamped if there is none)
-                    const int qn1 = (tile * tpb + tp + 1) * QB + wv * 32 + jq;
-                    const int qc1 = qn1 < NQ ? qn1 : NQ - 1;
+                    for (int d = 0; d < 3; ++d) qr[d] = qpre[d];
+                } else {        // (not prefetched behind the previous pass: three registers live across the main loop would spill)
+                    const int qc1 = qi < NQ ? qi : NQ - 1;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) qpre[d] = qb[(size_t)qc1 * 3 + d];
+                    for (int d = 0; d < 3; ++d) qr[d] = qb[(size_t)qc1 * 3 + d];
                 }
                 float m0 = -2.0f * ((qr[0] - mu[0]) * sc), m1 = -2.0f * ((qr[1] - mu[1]) * sc), m2 = -2.0f * ((qr[2] - mu[2]) * sc);
                 float S = (fabsf(m0) + fabsf(m1)) + fabsf(m2);
@@ -607,6 +605,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     fl_s = 0x1p-15f;              // fp16 subnormal quantum of a scaled-down small component x |c~_d| <= 2^-25 x 3 x 128
                 }
                 qok = S < 3.0e4f;  // inside the fp16 range (also false for NaN)
+                qfin = fabsf(qr[0]) + fabsf(qr[1]) + fabsf(qr[2]) < INFINITY;
                 const float qn = 0.25f * ((m0 * m0 + m1 * m1) + m2 * m2) / sq;  // sq |q~|^2: the band in the query's unit
                 da = kBandA * qn + 0x1p-24f * (S + 4.0f) + fl_s;
                 _Float16 hx, lx, hy, ly, hz, lz;
@@ -625,42 +624,67 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             float tm = INFINITY, ka = INFINITY, kb = INFINITY, kc = INFINITY;
             const unsigned int keymask = ~63u;
 
-            // ---- main loop, software-pipelined by one 32-candidate block -----------------------------------
-            // (the image carries two padding blocks behind cnt_pad, so the prefetch never needs a clamp
-            //  and every ds_read_b128 is base + immediate offset: no address VALU in the loop)
-            const int nblk = cnt_pad / 32;  // multiple of kHLT
+            // ---- main loop, software-pipelined by TWO 32-candidate blocks ---------------------------------------
+            // Block b's MFMA is issued two steps before its 16 accumulators are folded (three accumulator sets in rotation):
+            // with one step of distance the fold of a block sat right behind its own MFMA's latency (the compiler filled
+            // the gap with s_nop 6), and tools/ubench_overlap.hip puts a fold of the block before last 5 cycles per tile
+            // under a fold of the last one at this instruction mix.  Six blocks (three lane tiles) per iteration keep every
+            // register index static.  (The image carries two padding blocks behind cnt_pad, so the operand prefetch never
+            // needs a clamp and every ds_read_b128 is base + immediate offset: no address VALU in the loop.)
+            static_assert(kHLT == 2, "the rotation below is written for lane tiles of two blocks");
+            const int nblk = cnt_pad / 32;  // even
             f32x16 zero;
 #pragma unroll
             for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
             const h8 *pa = imgp + hh * 32 + jq;
-            f32x16 accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[0], bq, zero, 0, 0, 0);
-            h8 a_nxt = pa[64];
-            pa += 128;  // -> block 2
-            for (int lt = 0; lt < nblk / kHLT; ++lt) {
-#pragma unroll
-                for (int bb = 0; bb < kHLT; ++bb) {
-                    const h8 a_n2 = pa[bb * 64];
-                    const f32x16 accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_nxt, bq, zero, 0, 0, 0);
-                    // fold 16 values: 8 x v_min3, depth 3
-                    const float t0 = min3f(accC[0], accC[1], accC[2]), t1 = min3f(accC[3], accC[4], accC[5]);
-                    const float t2 = min3f(accC[6], accC[7], accC[8]), t3 = min3f(accC[9], accC[10], accC[11]);
-                    const float t4 = min3f(accC[12], accC[13], accC[14]);
-                    const float t5 = min3f(t0, t1, t2), t6 = min3f(t3, t4, accC[15]);
-                    tm = bb == 0 ? vmin(t5, t6) : min3f(tm, t5, t6);  // first block of the lane tile restarts tm
-                    accC = accN;
-                    a_nxt = a_n2;
-                }
-                pa += kHLT * 64;
-#ifdef FX3D_KO_TRACK
-                ka = vmin(ka, tm);
-#else
-                float key;
-                asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(tm), "v"(keymask), "s"(lt));
-                kc = __builtin_amdgcn_fmed3f(kb, kc, key);
-                kb = __builtin_amdgcn_fmed3f(ka, kb, key);
-                ka = vmin(ka, key);
-#endif
+            f32x16 acc0, acc1, acc2;
+            h8 an = pa[0];                     // operand of the next block to issue (one ds_read_b128 in flight per step)
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, bq, zero, 0, 0, 0); an = pa[1 * 64];
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, bq, zero, 0, 0, 0); an = pa[2 * 64];
+            pa += 3 * 64;                      // -> the operand one block past the next issue
+            int lt = 0;                        // lane tile of the next fold
+#define NN1_FOLD(ACC, FIRST)                                                                                         \
+            {                                                                                                        \
+                const float t0 = min3f(ACC[0], ACC[1], ACC[2]), t1 = min3f(ACC[3], ACC[4], ACC[5]);                  \
+                const float t2 = min3f(ACC[6], ACC[7], ACC[8]), t3 = min3f(ACC[9], ACC[10], ACC[11]);                \
+                const float t4 = min3f(ACC[12], ACC[13], ACC[14]);                                                   \
+                const float t5 = min3f(t0, t1, t2), t6 = min3f(t3, t4, ACC[15]);                                     \
+                tm = (FIRST) ? vmin(t5, t6) : min3f(tm, t5, t6); /* first block of the lane tile restarts tm */      \
             }
+#define NN1_TRACK()                                                                                                  \
+            {                                                                                                        \
+                float key;                                                                                           \
+                asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(tm), "v"(keymask), "s"(lt));                     \
+                kc = __builtin_amdgcn_fmed3f(kb, kc, key);                                                           \
+                kb = __builtin_amdgcn_fmed3f(ka, kb, key);                                                           \
+                ka = vmin(ka, key);                                                                                  \
+                ++lt;                                                                                                \
+            }
+            // one step: issue the next block into ISSUE, fold FOLD (issued two steps ago); an odd fold closes its lane tile
+#define NN1_STEP(ISSUE, FOLD, ODD, OFF)                                                                              \
+            ISSUE = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, bq, zero, 0, 0, 0);                                   \
+            an = pa[(OFF) * 64];                                                                                     \
+            NN1_FOLD(FOLD, !(ODD))                                                                                   \
+            if (ODD) NN1_TRACK()
+            int nb = 2;                        // next block to issue (even); blocks nb - 2, nb - 1 are in acc0, acc1
+            for (; nb + 6 <= nblk; nb += 6) {
+                NN1_STEP(acc2, acc0, 0, 0) NN1_STEP(acc0, acc1, 1, 1) NN1_STEP(acc1, acc2, 0, 2)
+                NN1_STEP(acc2, acc0, 1, 3) NN1_STEP(acc0, acc1, 0, 4) NN1_STEP(acc1, acc2, 1, 5)
+                pa += 6 * 64;
+            }
+            // the last 0, 2 or 4 blocks, then the two folds still pending
+            if (nblk - nb == 4) {
+                NN1_STEP(acc2, acc0, 0, 0) NN1_STEP(acc0, acc1, 1, 1) NN1_STEP(acc1, acc2, 0, 2) NN1_STEP(acc2, acc0, 1, 3)
+                NN1_FOLD(acc1, true) NN1_FOLD(acc2, false) NN1_TRACK()
+            } else if (nblk - nb == 2) {
+                NN1_STEP(acc2, acc0, 0, 0) NN1_STEP(acc0, acc1, 1, 1)
+                NN1_FOLD(acc2, true) NN1_FOLD(acc0, false) NN1_TRACK()
+            } else {
+                NN1_FOLD(acc0, true) NN1_FOLD(acc1, false) NN1_TRACK()
+            }
+#undef NN1_STEP
+#undef NN1_TRACK
+#undef NN1_FOLD
             const float ft[kHFifo] = {ka, kb, kc};
             // this lane's smallest tile minimum is <= best (an upper bound of it: the key of the smallest VALUE is >= ka)
             const float best = __builtin_fmaf(fabsf(ka), kKeyUp, ka);
@@ -668,6 +692,11 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
 
             // ---- exact phase, wave-cooperative ----------------------------------------------------------------
             {
+                // (the lane index through an opaque zero: otherwise every lane-derived address and mask of this phase is hoisted
+                //  out of the pass / chunk loops and stays live across the main loop -- ~40 vector registers -- and the kernel spills)
+                int opq;
+                asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
+                const int lane = (int)(threadIdx.x & 63) + opq, jq = lane & 31, hh = lane >> 5;
                 const float m = fminf(best, __shfl_xor(best, 32, 64));
                 const float thr1 = __builtin_fmaf(m, kBandB1, da);                  // on tile minima (m >= the true minimum)
                 const float thr1k = __builtin_fmaf(fabsf(thr1), kKeyUp, thr1);      // on keys: t <= thr1  =>  key(t) <= thr1k
@@ -685,12 +714,9 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 const bool retry = __builtin_popcount(qslow) > 2;
                 bool fifo_done = false;
                 // a NaN distance needs a non-finite cloud or a non-finite query (wave-uniform switch of the task code)
-                const bool nonfinite = !sane || __ballot(!(fabsf(qr[0]) + fabsf(qr[1]) + fabsf(qr[2]) < INFINITY)) != 0;
+                const bool nonfinite = !sane || __ballot(!qfin) != 0;
                 const int nlt = nblk / kHLT;
                 int lt2 = 0;
-#ifdef FX3D_KO_EXACT
-                if (p.N < 0)
-#endif
                 do {
                     int nitems = 0;
                     if (!retry && fifo_done) {
@@ -1160,6 +1186,7 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
     // ONE chunk of a split run (any number of passes; subsets merge through 64-bit atomicMin slots, +8 us of
     // extra launches).  Few large clouds want many small chunks, many small clouds want passes.
     const int cmax = kHChunkMax, gran = 32 * kHLT;
+    const int ncu = device_cus();  // blocks resident at once: one per CU (256 on an MI355X in SPX mode)
     // a larger cloud of at most cmax + kHTail points is planned (and run) as ONE chunk of cmax with an exact tail
     const int tpb_env = opt(OPT_NN1_TPB);
     int maxc = maxc0, b_chunk = 0, b_tpb = 1, b_split = 1;
@@ -1181,7 +1208,7 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
                     const long long blocks = 2ll * B * tiles * (split ? anch : 1);
                     const double per_chunk = 5.0 * ch / 4096.0 + 0.5 + tpb * (9.7 * ch / 4096.0 + 0.8);
                     const double t_block = 2.8 * maxc / 4096.0 + (split ? 1 : anch) * per_chunk;
-                    const double rounds = (double)((blocks + 255) / 256);
+                    const double rounds = (double)((blocks + ncu - 1) / ncu);
                     const double t = rounds * t_block + (split ? 8.0 : 0.0);
                     if (t < best - 1e-9) { best = t; b_chunk = ch; b_tpb = tpb; b_split = split ? anch : 1; }
                 }
@@ -1211,12 +1238,12 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
                 const double blk_a = 2.8 * M / 4096.0 + 5.0 * M / 4096.0 + 0.5 + ta * (9.7 * M / 4096.0 + 0.8);  // x -> y: candidates y
                 const double blk_b = 2.8 * N / 4096.0 + 5.0 * N / 4096.0 + 0.5 + tb * (9.7 * N / 4096.0 + 0.8);  // y -> x: candidates x
                 const double na = (double)B * ((N + 512 * ta - 1) / (512 * ta)), nb = (double)B * ((M + 512 * tb - 1) / (512 * tb));
-                const double thr = (na * blk_a + nb * blk_b) / 256.0;
+                const double thr = (na * blk_a + nb * blk_b) / (double)ncu;
                 double t = blk_a > blk_b ? blk_a : blk_b;
                 t = t > thr ? t : thr;
                 // the grid has max(tiles) slots per (cloud, direction): more than one round of them delays the heavy direction's blocks
                 const long long tmax = (N + 512 * ta - 1) / (512 * ta) > (M + 512 * tb - 1) / (512 * tb) ? (N + 512 * ta - 1) / (512 * ta) : (M + 512 * tb - 1) / (512 * tb);
-                t += 1.0 * (double)((2ll * B * tmax + 255) / 256 - 1);
+                t += 1.0 * (double)((2ll * B * tmax + ncu - 1) / ncu - 1);
                 if (t < bt - 1e-9) { bt = t; pl.tpb = ta; pl.tpb_y = tb; }
             }
     }
@@ -1666,7 +1693,7 @@ fx3d_status fx3d_chamfer_bwd(const float *x, int32_t N, const float *y, int32_t 
     if (blocks > 4096) blocks = 4096;
     const bool no_lds = opt(OPT_BWD_GLOBAL_ATOMICS) != 0;  // (fx3d_set_option: the tests flip it)
     const int maxr = N > M ? N : M;
-    int nsplit = 512 / (2 * B);  // aim at ~2 blocks per CU; a block never owns fewer than 256 rows ...
+    int nsplit = 2 * device_cus() / (2 * B);  // aim at ~2 blocks per CU; a block never owns fewer than 256 rows ...
     if (nsplit > maxr / 256) nsplit = maxr / 256;
     if (nsplit < 1) nsplit = 1;
     while ((size_t)((maxr + nsplit - 1) / nsplit) * D * sizeof(float) > 144 * 1024) ++nsplit;  // ... nor more than fit in LDS
@@ -1713,7 +1740,7 @@ fx3d_status fx3d_chamfer_sampled_bwd(const float *x, int32_t N, const float *y, 
     const float ca = gout * w1 * (float)(6.0 / (3.0 * N * (double)B_global));
     const float cb = gout * w2 * (float)(6.0 / (3.0 * M * (double)B_global));
     const int maxr = N > M ? N : M;
-    int nsplit = 512 / (2 * B);  // as fx3d_chamfer_bwd: ~2 blocks per CU, a block never owns fewer than 256 rows nor more than fit in LDS
+    int nsplit = 2 * device_cus() / (2 * B);  // as fx3d_chamfer_bwd: ~2 blocks per CU, a block never owns fewer than 256 rows nor more than fit in LDS
     if (nsplit > maxr / 256) nsplit = maxr / 256;
     if (nsplit < 1) nsplit = 1;
     while ((size_t)((maxr + nsplit - 1) / nsplit) * 3 * sizeof(float) > 144 * 1024) ++nsplit;

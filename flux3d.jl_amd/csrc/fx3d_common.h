@@ -45,6 +45,9 @@ inline hipStream_t as_stream(fx3d_stream_t s) { return reinterpret_cast<hipStrea
 // nullptr + *rc on allocation failure.
 unsigned int *ticket_slot(fx3d_status *rc, hipStream_t st);
 fx3d_status ensure_dynamic_lds(const void *kernel, int bytes, const char *name);
+// compute units of the calling thread's current device (cached per device; 256 on an MI355X in SPX mode, fewer in the
+// partitioned modes): the launch plans size their rounds of blocks with it instead of a constant
+int device_cus();
 
 // ---- optional per-kernel event timing (runtime.hip) -------------------------------------------
 bool profile_on();
