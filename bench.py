@@ -34,10 +34,12 @@ N > 1 (one process per GPU): NO torch in this file.  torchrun only exports RANK 
 bootstraps its own RCCL communicator (fx3d_comm_bootstrap over tcp://MASTER_ADDR:MASTER_PORT+1), the data-plane
 collective is its all-reduce(sum) of 2 Float64 per evaluation, and the control plane (barrier, max over ranks of the
 elapsed time) is its all-reduce(max).  The run fails loudly unless the communicator reports exactly N ranks.
-`--comm torch` keeps the torch.distributed variant of round 1.  Default mode `overlap`: the all-reduce is issued on a
-second stream so that it overlaps the next evaluation's kernel (north_star: "RCCL all-reduce of the scalar loss");
-`serial` (same, on the compute stream) and `deferred` (one collective per 32 evaluations) are timed right after and
-printed as `modes`.
+`--comm torch` keeps the torch.distributed variant of round 1.  The collective is one all-reduce of 2 Float64 PER
+EVALUATION (north_star: "RCCL all-reduce of the scalar loss"), either on a second stream behind an event so that it
+overlaps the next evaluation's kernel (`overlap`) or on the compute stream (`serial`); the default `auto` times 40 steps
+of each before the protocol starts and runs the faster one on this node (the overlapped form needs more host work per
+step and loses on a host with few free cores; world size 1: serial 50.6 vs overlap 57.6 us).  The other placements and
+`deferred` (one collective per 32 evaluations) are timed right after the K steps and printed as `modes`.
 """
 import argparse
 import hashlib
@@ -77,9 +79,12 @@ def main():
     ap.add_argument("--comm", choices=["torch", "native"], default="native",
                     help="multi-GPU: the library's own RCCL communicator for data AND control plane (default, no torch), or "
                          "torch.distributed for both")
-    ap.add_argument("--mode", choices=["overlap", "serial", "deferred"], default="overlap",
-                    help="multi-GPU: per-evaluation all-reduce overlapped on a second stream (default), on the compute "
-                         "stream, or one collective per --allreduce-every evaluations")
+    ap.add_argument("--mode", choices=["auto", "overlap", "serial", "deferred"], default="auto",
+                    help="multi-GPU: where the per-evaluation all-reduce of the two Float64 sums runs -- `overlap`: on a second "
+                         "stream behind an event (hides the collective's latency behind the next evaluation's kernel, costs "
+                         "two cross-stream events per step and more host work), `serial`: on the compute stream; `auto` "
+                         "(default) times 40 untimed steps of each before the protocol starts and takes the faster one on "
+                         "this node; `deferred`: one collective per --allreduce-every evaluations (opt-in: an eval loop's shape)")
     ap.add_argument("--allreduce-every", type=int, default=32, help="evaluations per collective in mode `deferred`")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the multi-GPU code path (RCCL communicator, collectives) even at world size 1")
@@ -272,6 +277,10 @@ def main():
     # HIP events around every 5th nn1 launch, on the launch's own stream (bracketing every launch
     # costs ~5 us per step in event records; measured)
     main_mode = args.mode if use_dist else "single"
+    calibration = None
+    if main_mode == "auto":  # both per-evaluation placements, 40 steps each after 10 of warm-up, max over ranks: outside the protocol
+        calibration = {m: run_timed(make_runner(m), 40, 10)["elapsed"] * 1e3 / 40 for m in ("overlap", "serial")}
+        main_mode = min(calibration, key=calibration.get)   # (max-over-ranks times: every rank picks the same one)
     res = timed(main_mode, args.steps, args.warmup, 0 if os.environ.get("FX3D_BENCH_NOPROFILE") else 5,
                 burn_ms=args.burn_ms, cold=True)
     avg, mn, mx, cnt = C.c_double(0), C.c_double(0), C.c_double(0), C.c_int64(0)
@@ -290,6 +299,8 @@ def main():
     modes = None
     if use_dist:  # the other ways of placing the collective, same steps, right after (every rank takes part)
         modes = {main_mode: {"ms_per_step": res["elapsed"] * 1e3 / args.steps, "collective": res["desc"]}}
+        if calibration is not None:
+            modes["auto_calibration_ms_per_step"] = calibration
         for m in ("overlap", "serial", "deferred"):
             if m != main_mode:
                 r2 = timed(m, args.steps, min(args.warmup, 20))
