@@ -207,3 +207,13 @@ def test_default_rendezvous_prefers_tcp_under_a_launcher(fx, monkeypatch):
     assert default_rendezvous().startswith("file://")
     monkeypatch.setenv("FX3D_COMM_RENDEZVOUS", "tcp://10.0.0.1:7")
     assert default_rendezvous() == "tcp://10.0.0.1:7"
+
+
+def test_tcp_rendezvous_eight_processes(fx):
+    """What bench.py --gpus 8 does under torchrun before the first launch: eight separate processes meet at
+    tcp://127.0.0.1:(MASTER_PORT + 1), rank 0 last (it is the slowest to come up when it also prints)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    _exchange_processes(f"tcp://127.0.0.1:{port}", 8, delay_rank0=0.7)
