@@ -22,7 +22,7 @@ from .rep import (PointCloud, TriMesh, get_edges_packed, get_edges_to_key, get_f
 from .metrics import (chamfer_distance, chamfer_distance_grad, chamfer_loss_pairwise_f32, chamfer_sampled_grad, edge_loss, edge_loss_grad,  # noqa: E402
                       laplacian_loss, laplacian_loss_grad, mesh_losses, mesh_losses_grad, nearest_neighbors)
 from .transforms import (EPS, compute_faces_areas_list, compute_faces_areas_packed,  # noqa: E402
-                         compute_faces_areas_padded, lincomb, offset, sample_points, sample_points_grad)
+                         compute_faces_areas_padded, lincomb, offset, sample_points, sample_points_grad, sample_points_pair)
 from .fit import FitStepGraph, Momentum, loss_dolphin  # noqa: E402
 from .graph import (create_knn_graph, edge_features, edge_features_grad, edgeconv_graph, knn,  # noqa: E402
                     knn_gather)

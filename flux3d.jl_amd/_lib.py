@@ -89,6 +89,9 @@ SIGNATURES = {
                            vp, sz, vp],
     "fx3d_sample_points_cdf": [vp, c_i32, vp, c_i32, vp, c_i32, c_f64, vp, sz, vp],
     "fx3d_sample_points_draw": [vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_u64, vp, vp, sz, vp, vp, vp, vp, vp],
+    "fx3d_sample_points_cdf_pair": [vp, c_i32, vp, c_i32, vp, c_i32, vp, sz, vp, c_i32, vp, c_i32, vp, c_i32, vp, sz, c_f64, vp],
+    "fx3d_sample_points_draw_pair": [vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_u64, vp, sz, vp, vp, vp, vp,
+                                     vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_u64, vp, sz, vp, vp, vp, vp, vp, vp],
     "fx3d_sample_points_bwd": [vp, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp, c_i32, vp],
     "fx3d_voxel_workspace_bytes": [c_i32, C.POINTER(sz)],
     "fx3d_pointcloud_to_voxel": [vp, c_i32, c_i32, c_i32, vp, vp, sz, vp],

@@ -114,15 +114,27 @@ __device__ __forceinline__ double chain32_excl(double *t) {
 // VLDS (with IN_LDS): the mesh's vertices are staged in LDS first (coalesced loads, in flight together with the face
 // indices: ONE global round trip), the 3 gathers per face read LDS -- the block is alone on its mesh and one CU's
 // texture path takes ~1.4 ns per face for scattered 12-byte loads (7.6 us of 16 for the fit loop's 5 k-face sphere).
+// A second mesh batch in the same launch (chamfer_distance(m1, m2, n) samples both meshes: src/metrics/mesh.jl:41-42): blocks
+// [0, B1) work on the first batch, blocks [B1, gridDim.x) on `o` -- two launches of a handful of blocks each become one.
+struct CdfOther {
+    const float *verts_padded;
+    const int32_t *faces_padded, *faces_len;
+    double *ws;
+    int Vmax, Fmax;
+};
 template <bool IN_LDS, bool VLDS>
 __global__ __launch_bounds__(kCdfThreads) void face_cdf_kernel(const float *__restrict__ verts_padded, int Vmax,
                                                             const int32_t *__restrict__ faces_padded,
                                                             const int32_t *__restrict__ faces_len, int Fmax, double eps,
-                                                            double *__restrict__ ws) {
+                                                            double *__restrict__ ws, int B1, CdfOther o) {
     extern __shared__ __attribute__((aligned(16))) double dsm[];  // IN_LDS: work[Fp + nch] + t0[nchp] (+ float4 verts[Vmax])
+    int b = blockIdx.x;
+    if (b >= B1) {  // (block-uniform)
+        b -= B1;
+        verts_padded = o.verts_padded; faces_padded = o.faces_padded; faces_len = o.faces_len; ws = o.ws; Vmax = o.Vmax; Fmax = o.Fmax;
+    }
     const CdfWs W = CdfWs::make(Fmax);
     const int Fp = W.Fp, nch = W.nch, nchp = W.nchp, ng = nchp / kChunk;  // ng <= 32 (Fmax <= kCdfBlockFaces)
-    const int b = blockIdx.x;
     const float *vb = verts_padded + (size_t)b * Vmax * 3;
     const int32_t *fb = faces_padded + (size_t)b * Fmax * 3;
     double *out = ws + (size_t)b * W.stride;
@@ -427,16 +439,31 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
     }
 }
 
-__global__ __launch_bounds__(kThreads) void sample_seeded_kernel(
-    const float *__restrict__ verts_padded, int Vmax, const int32_t *__restrict__ faces_padded,
-    int Fmax, int Fp, const int32_t *__restrict__ faces_len, int B, int n, uint64_t seed_host,
-    const uint64_t *__restrict__ seed_dev, const double *__restrict__ ws, float *__restrict__ out,
-    int32_t *__restrict__ face_out, float *__restrict__ r1_out, float *__restrict__ r2_out) {
-    const long long total = (long long)B * n;
+struct DrawSide {
+    const float *verts_padded;
+    const int32_t *faces_padded, *faces_len;
+    const double *ws;
+    float *out, *r1_out, *r2_out;
+    int32_t *face_out;
+    uint64_t seed_host;
+    int Vmax, Fmax, B, n;
+};
+// (two sides: the draws of both meshes of chamfer_distance(m1, m2, n) in one launch; nb0 = blocks of side 0, each side's blocks
+//  stride over their own samples)
+__global__ __launch_bounds__(kThreads) void sample_seeded_kernel(DrawSide s0, DrawSide s1, int nb0, const uint64_t *__restrict__ seed_dev) {
+    const bool second = (int)blockIdx.x >= nb0;
+    const DrawSide &S = second ? s1 : s0;
+    const float *__restrict__ verts_padded = S.verts_padded;
+    const int32_t *__restrict__ faces_padded = S.faces_padded, *__restrict__ faces_len = S.faces_len;
+    const double *__restrict__ ws = S.ws;
+    float *__restrict__ out = S.out, *__restrict__ r1_out = S.r1_out, *__restrict__ r2_out = S.r2_out;
+    int32_t *__restrict__ face_out = S.face_out;
+    const int Vmax = S.Vmax, Fmax = S.Fmax, n = S.n;
+    const long long total = (long long)S.B * n;
     const size_t cstride = CdfWs::make(Fmax).stride;
-    const uint64_t seed = seed_host + (seed_dev ? *seed_dev : 0);  // device part: advanced between replays of a graph
-    for (long long k = (long long)blockIdx.x * kThreads + threadIdx.x; k < total;
-         k += (long long)gridDim.x * kThreads) {
+    const uint64_t seed = S.seed_host + (seed_dev ? *seed_dev : 0);  // device part: advanced between replays of a graph
+    const long long blk = second ? (long long)blockIdx.x - nb0 : (long long)blockIdx.x, nblk = second ? (long long)gridDim.x - nb0 : (long long)nb0;
+    for (long long k = blk * kThreads + threadIdx.x; k < total; k += nblk * kThreads) {
         const int b = (int)(k / n), sidx = (int)(k % n);
         const double *cdf = ws + (size_t)b * cstride;
         const int L = faces_len[b];
@@ -519,72 +546,166 @@ fx3d_status fx3d_sample_points_workspace_bytes(int32_t Fmax, int32_t B, size_t *
     return FX3D_OK;
 }
 
-fx3d_status fx3d_sample_points_cdf(const float *verts_padded, int32_t Vmax, const int32_t *faces_padded,
-                                   int32_t Fmax, const int32_t *faces_len, int32_t B, double eps, void *ws,
-                                   size_t ws_bytes, fx3d_stream_t s) {
-    FX3D_REQUIRE(verts_padded && faces_padded && faces_len, "fx3d_sample_points_cdf: null pointer");
-    FX3D_REQUIRE(Vmax > 0 && Fmax > 0 && B > 0, "fx3d_sample_points_cdf: bad sizes");
-    if (!ws || ws_bytes < ws_bytes_needed(Fmax, B)) {
-        set_error("fx3d_sample_points_cdf: workspace too small (%zu < %zu)", ws ? ws_bytes : (size_t)0,
-                  ws_bytes_needed(Fmax, B));
-        return FX3D_ERR_WORKSPACE;
-    }
-    hipStream_t st = as_stream(s);
-    const CdfWs W = CdfWs::make(Fmax);
-    const int Fp = W.Fp;
-    double *cdf = reinterpret_cast<double *>(ws);
-    ProfileScope prof("sample_cdf", st);
+}  // extern "C"
+
+namespace {
+struct CdfArgs {
+    const float *verts_padded;
+    const int32_t *faces_padded, *faces_len;
+    void *ws;
+    size_t ws_bytes;
+    int Vmax, Fmax, B;
+};
+// which one-block variant a batch takes (0: multi-block path, 1: LDS copy + staged vertices, 2: LDS copy, 3: global working copy)
+int cdf_variant(int Vmax, int Fmax, size_t *lds) {
     const int mb_opt = opt(OPT_CDF_MULTIBLOCK_FROM);  // (fx3d_set_option: the tests lower the switch point)
     const int mb_from = mb_opt > 0 ? mb_opt : kCdfBlockFaces;
-    if (Fmax > mb_from || Fmax > kCdfBlockFaces) {
-        const int nb = (W.nchp / kChunk + kChunk - 1) / kChunk, nsub = (Fp + kCdfSub - 1) / kCdfSub;
+    if (Fmax > mb_from || Fmax > kCdfBlockFaces) return 0;
+    const CdfWs W = CdfWs::make(Fmax);
+    const size_t cdf_lds = sizeof(double) * (size_t)(W.Fp + W.nch + W.nchp + 2);  // + one pad per chunk (bank spread), chunk totals padded to 32
+    const size_t v_lds = sizeof(float) * 4 * (size_t)Vmax + 16;
+    if (cdf_lds <= 60 * 1024 && cdf_lds + v_lds <= 150 * 1024) { *lds = cdf_lds + v_lds; return 1; }
+    if (cdf_lds <= 60 * 1024) { *lds = cdf_lds; return 2; }
+    *lds = 0;
+    return 3;
+}
+
+fx3d_status cdf_check(const CdfArgs &a, const char *fn) {
+    FX3D_REQUIRE(a.verts_padded && a.faces_padded && a.faces_len, "%s: null pointer", fn);
+    FX3D_REQUIRE(a.Vmax > 0 && a.Fmax > 0 && a.B > 0, "%s: bad sizes", fn);
+    if (!a.ws || a.ws_bytes < ws_bytes_needed(a.Fmax, a.B)) {
+        set_error("%s: workspace too small (%zu < %zu)", fn, a.ws ? a.ws_bytes : (size_t)0, ws_bytes_needed(a.Fmax, a.B));
+        return FX3D_ERR_WORKSPACE;
+    }
+    return FX3D_OK;
+}
+
+// one batch, or two in ONE launch when both take the same one-block variant (`b` may be null)
+fx3d_status cdf_launch(const CdfArgs &a, const CdfArgs *b, double eps, hipStream_t st) {
+    size_t la = 0, lb = 0;
+    const int va = cdf_variant(a.Vmax, a.Fmax, &la), vb = b ? cdf_variant(b->Vmax, b->Fmax, &lb) : va;
+    if (b && (va == 0 || va != vb)) {  // different kernels: one after the other
+        const fx3d_status rc = cdf_launch(a, nullptr, eps, st);
+        return rc ? rc : cdf_launch(*b, nullptr, eps, st);
+    }
+    double *cdf = reinterpret_cast<double *>(a.ws);
+    ProfileScope prof("sample_cdf", st);
+    if (va == 0) {
+        const CdfWs W = CdfWs::make(a.Fmax);
+        const int nb = (W.nchp / kChunk + kChunk - 1) / kChunk, nsub = (W.Fp + kCdfSub - 1) / kCdfSub;
         FX3D_REQUIRE(nb <= kChunk * kChunk, "fx3d_sample_points_cdf: more than 33 554 432 faces per mesh");
-        FX3D_REQUIRE(B <= 65535, "fx3d_sample_points_cdf: more than 65535 meshes in one batch");
-        hipLaunchKernelGGL(cdf_mb_areas_kernel, dim3(nsub, B), dim3(kCdfThreads), 0, st, verts_padded, Vmax, faces_padded, faces_len, Fmax, cdf);
-        hipLaunchKernelGGL(cdf_mb_top_kernel<false>, dim3(B), dim3(kCdfThreads), 0, st, Fmax, eps, cdf);
-        hipLaunchKernelGGL(cdf_mb_prob_kernel, dim3(nsub, B), dim3(kCdfThreads), 0, st, Fmax, cdf);
-        hipLaunchKernelGGL(cdf_mb_top_kernel<true>, dim3(B), dim3(kCdfThreads), 0, st, Fmax, eps, cdf);
-        hipLaunchKernelGGL(cdf_mb_final_kernel, dim3(nsub, B), dim3(kCdfThreads), 0, st, Fmax, cdf);
+        FX3D_REQUIRE(a.B <= 65535, "fx3d_sample_points_cdf: more than 65535 meshes in one batch");
+        hipLaunchKernelGGL(cdf_mb_areas_kernel, dim3(nsub, a.B), dim3(kCdfThreads), 0, st, a.verts_padded, a.Vmax, a.faces_padded, a.faces_len, a.Fmax, cdf);
+        hipLaunchKernelGGL(cdf_mb_top_kernel<false>, dim3(a.B), dim3(kCdfThreads), 0, st, a.Fmax, eps, cdf);
+        hipLaunchKernelGGL(cdf_mb_prob_kernel, dim3(nsub, a.B), dim3(kCdfThreads), 0, st, a.Fmax, cdf);
+        hipLaunchKernelGGL(cdf_mb_top_kernel<true>, dim3(a.B), dim3(kCdfThreads), 0, st, a.Fmax, eps, cdf);
+        hipLaunchKernelGGL(cdf_mb_final_kernel, dim3(nsub, a.B), dim3(kCdfThreads), 0, st, a.Fmax, cdf);
         FX3D_LAUNCH_CHECK();
         return FX3D_OK;
     }
-    const size_t cdf_lds = sizeof(double) * (size_t)(Fp + W.nch + W.nchp + 2);  // + one pad per chunk (bank spread), chunk totals padded to 32
-    const size_t v_lds = sizeof(float) * 4 * (size_t)Vmax + 16;
-    if (cdf_lds <= 60 * 1024 && cdf_lds + v_lds <= 150 * 1024) {
+    const CdfOther o = b ? CdfOther{b->verts_padded, b->faces_padded, b->faces_len, reinterpret_cast<double *>(b->ws), b->Vmax, b->Fmax}
+                         : CdfOther{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    const int grid = a.B + (b ? b->B : 0);
+    const size_t lds = la > lb ? la : lb;
+    if (va == 1) {
         const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&face_cdf_kernel<true, true>), 150 * 1024,
                                                    "face_cdf_kernel");
         if (arc != FX3D_OK) return arc;
-        hipLaunchKernelGGL((face_cdf_kernel<true, true>), dim3(B), dim3(kCdfThreads), cdf_lds + v_lds, st, verts_padded, Vmax,
-                           faces_padded, faces_len, Fmax, eps, cdf);
-    } else if (cdf_lds <= 60 * 1024) {
-        hipLaunchKernelGGL((face_cdf_kernel<true, false>), dim3(B), dim3(kCdfThreads), cdf_lds, st, verts_padded, Vmax,
-                           faces_padded, faces_len, Fmax, eps, cdf);
+        hipLaunchKernelGGL((face_cdf_kernel<true, true>), dim3(grid), dim3(kCdfThreads), lds, st, a.verts_padded, a.Vmax,
+                           a.faces_padded, a.faces_len, a.Fmax, eps, cdf, a.B, o);
+    } else if (va == 2) {
+        hipLaunchKernelGGL((face_cdf_kernel<true, false>), dim3(grid), dim3(kCdfThreads), lds, st, a.verts_padded, a.Vmax,
+                           a.faces_padded, a.faces_len, a.Fmax, eps, cdf, a.B, o);
     } else {
-        hipLaunchKernelGGL((face_cdf_kernel<false, false>), dim3(B), dim3(kCdfThreads), 0, st, verts_padded, Vmax,
-                           faces_padded, faces_len, Fmax, eps, cdf);
+        hipLaunchKernelGGL((face_cdf_kernel<false, false>), dim3(grid), dim3(kCdfThreads), 0, st, a.verts_padded, a.Vmax,
+                           a.faces_padded, a.faces_len, a.Fmax, eps, cdf, a.B, o);
     }
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
+}
+
+struct DrawArgs {
+    const float *verts_padded;
+    const int32_t *faces_padded, *faces_len;
+    const void *cdf_ws;
+    size_t ws_bytes;
+    float *out, *r1_out, *r2_out;
+    int32_t *face_out;
+    uint64_t seed;
+    int Vmax, Fmax, B, n;
+};
+fx3d_status draw_check(const DrawArgs &a, const char *fn) {
+    FX3D_REQUIRE(a.verts_padded && a.faces_padded && a.faces_len && a.out, "%s: null pointer", fn);
+    FX3D_REQUIRE(a.Vmax > 0 && a.Fmax > 0 && a.B > 0 && a.n > 0, "%s: bad sizes", fn);
+    if (!a.cdf_ws || a.ws_bytes < ws_bytes_needed(a.Fmax, a.B)) {
+        set_error("%s: CDF workspace too small (%zu < %zu)", fn, a.cdf_ws ? a.ws_bytes : (size_t)0, ws_bytes_needed(a.Fmax, a.B));
+        return FX3D_ERR_WORKSPACE;
+    }
+    return FX3D_OK;
+}
+DrawSide draw_side(const DrawArgs &a) {
+    return DrawSide{a.verts_padded, a.faces_padded, a.faces_len, reinterpret_cast<const double *>(a.cdf_ws), a.out, a.r1_out, a.r2_out,
+                    a.face_out, a.seed, a.Vmax, a.Fmax, a.B, a.n};
+}
+fx3d_status draw_launch(const DrawArgs &a, const DrawArgs *b, const uint64_t *seed_dev, hipStream_t st) {
+    ProfileScope prof("sample_draw", st);
+    const int g0 = grid_for((long long)a.B * a.n), g1 = b ? grid_for((long long)b->B * b->n) : 0;
+    hipLaunchKernelGGL(sample_seeded_kernel, dim3(g0 + g1), dim3(kThreads), 0, st, draw_side(a), draw_side(b ? *b : a), g0, seed_dev);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+}  // namespace
+
+extern "C" {
+
+fx3d_status fx3d_sample_points_cdf(const float *verts_padded, int32_t Vmax, const int32_t *faces_padded,
+                                   int32_t Fmax, const int32_t *faces_len, int32_t B, double eps, void *ws,
+                                   size_t ws_bytes, fx3d_stream_t s) {
+    const CdfArgs a{verts_padded, faces_padded, faces_len, ws, ws_bytes, Vmax, Fmax, B};
+    const fx3d_status rc = cdf_check(a, "fx3d_sample_points_cdf");
+    if (rc) return rc;
+    return cdf_launch(a, nullptr, eps, as_stream(s));
+}
+
+// Both meshes of chamfer_distance(m1, m2, n) (src/metrics/mesh.jl:41-42) in ONE launch each: the two CDF builds, the two draws.
+// Results are bit-identical to two separate fx3d_sample_points_cdf / _draw calls (every block works on its own batch).
+fx3d_status fx3d_sample_points_cdf_pair(const float *verts0, int32_t Vmax0, const int32_t *faces0, int32_t Fmax0,
+                                        const int32_t *faces_len0, int32_t B0, void *ws0, size_t ws_bytes0,
+                                        const float *verts1, int32_t Vmax1, const int32_t *faces1, int32_t Fmax1,
+                                        const int32_t *faces_len1, int32_t B1, void *ws1, size_t ws_bytes1, double eps,
+                                        fx3d_stream_t s) {
+    const CdfArgs a{verts0, faces0, faces_len0, ws0, ws_bytes0, Vmax0, Fmax0, B0}, b{verts1, faces1, faces_len1, ws1, ws_bytes1, Vmax1, Fmax1, B1};
+    fx3d_status rc = cdf_check(a, "fx3d_sample_points_cdf_pair");
+    if (rc) return rc;
+    rc = cdf_check(b, "fx3d_sample_points_cdf_pair");
+    if (rc) return rc;
+    return cdf_launch(a, &b, eps, as_stream(s));
+}
+
+fx3d_status fx3d_sample_points_draw_pair(const float *verts0, int32_t Vmax0, const int32_t *faces0, int32_t Fmax0,
+                                         const int32_t *faces_len0, int32_t B0, int32_t n0, uint64_t seed0, const void *cdf_ws0,
+                                         size_t ws_bytes0, float *out0, int32_t *face_out0, float *r1_out0, float *r2_out0,
+                                         const float *verts1, int32_t Vmax1, const int32_t *faces1, int32_t Fmax1,
+                                         const int32_t *faces_len1, int32_t B1, int32_t n1, uint64_t seed1, const void *cdf_ws1,
+                                         size_t ws_bytes1, float *out1, int32_t *face_out1, float *r1_out1, float *r2_out1,
+                                         const uint64_t *seed_dev, fx3d_stream_t s) {
+    const DrawArgs a{verts0, faces0, faces_len0, cdf_ws0, ws_bytes0, out0, r1_out0, r2_out0, face_out0, seed0, Vmax0, Fmax0, B0, n0};
+    const DrawArgs b{verts1, faces1, faces_len1, cdf_ws1, ws_bytes1, out1, r1_out1, r2_out1, face_out1, seed1, Vmax1, Fmax1, B1, n1};
+    fx3d_status rc = draw_check(a, "fx3d_sample_points_draw_pair");
+    if (rc) return rc;
+    rc = draw_check(b, "fx3d_sample_points_draw_pair");
+    if (rc) return rc;
+    return draw_launch(a, &b, seed_dev, as_stream(s));
 }
 
 fx3d_status fx3d_sample_points_draw(const float *verts_padded, int32_t Vmax, const int32_t *faces_padded,
                                     int32_t Fmax, const int32_t *faces_len, int32_t B, int32_t n, uint64_t seed,
                                     const uint64_t *seed_dev, const void *cdf_ws, size_t ws_bytes, float *out,
                                     int32_t *face_out, float *r1_out, float *r2_out, fx3d_stream_t s) {
-    FX3D_REQUIRE(verts_padded && faces_padded && faces_len && out, "fx3d_sample_points_draw: null pointer");
-    FX3D_REQUIRE(Vmax > 0 && Fmax > 0 && B > 0 && n > 0, "fx3d_sample_points_draw: bad sizes");
-    if (!cdf_ws || ws_bytes < ws_bytes_needed(Fmax, B)) {
-        set_error("fx3d_sample_points_draw: CDF workspace too small (%zu < %zu)", cdf_ws ? ws_bytes : (size_t)0,
-                  ws_bytes_needed(Fmax, B));
-        return FX3D_ERR_WORKSPACE;
-    }
-    hipStream_t st = as_stream(s);
-    ProfileScope prof("sample_draw", st);
-    hipLaunchKernelGGL(sample_seeded_kernel, dim3(grid_for((long long)B * n)), dim3(kThreads), 0, st,
-                       verts_padded, Vmax, faces_padded, Fmax, roundup32(Fmax), faces_len, B, n, seed, seed_dev,
-                       reinterpret_cast<const double *>(cdf_ws), out, face_out, r1_out, r2_out);
-    FX3D_LAUNCH_CHECK();
-    return FX3D_OK;
+    const DrawArgs a{verts_padded, faces_padded, faces_len, cdf_ws, ws_bytes, out, r1_out, r2_out, face_out, seed, Vmax, Fmax, B, n};
+    const fx3d_status rc = draw_check(a, "fx3d_sample_points_draw");
+    if (rc) return rc;
+    return draw_launch(a, nullptr, seed_dev, as_stream(s));
 }
 
 fx3d_status fx3d_sample_points(const float *verts_padded, int32_t Vmax, const int32_t *faces_padded,

@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 from .device import DeviceArray, Graph, Stream, current_stream, stream
 from .metrics import _chamfer_points, chamfer_distance_grad, chamfer_sampled_grad, mesh_losses, mesh_losses_grad
-from .transforms import lincomb, offset, sample_points, sample_points_grad
+from .transforms import lincomb, offset, sample_points_grad, sample_points_pair
 
 
 def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_lap=0.1, w_edge=1.0, sync=True,
@@ -24,8 +24,8 @@ def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_la
         m = offset(src, x)
     s1 = None if seed is None else seed
     s2 = None if seed is None else seed + 1
-    A, fa, r1, r2 = sample_points(m, num_samples, seed=s1, return_draws=True, seed_dev=seed_dev)
-    Bp = sample_points(tgt, num_samples, seed=s2, seed_dev=seed_dev)
+    # (the source's fresh CDF, then BOTH draws in one launch; the target keeps its CDF while its vertices do not change)
+    A, Bp, fa, r1, r2 = sample_points_pair(m, tgt, num_samples, seed_a=s1, seed_b=s2, seed_dev=seed_dev, return_draws_a=True)
     loss1, ix, iy = _chamfer_points(A, Bp, 1.0, 1.0, return_indices=True, sync=sync)
     # both regularisers and the tutorial's sum fl(fl(l1 + fl(w_lap*l2)) + fl(w_edge*l3)) in ONE launch (unfused Float32)
     if sync:

@@ -451,6 +451,31 @@ function sample_points(m::TriMesh{Float32,R,HipArray}, num_samples::Int = 5000; 
 end
 
 # ---- mesh losses: replace src/metrics/mesh.jl:9-32 (no `cpu(transpose(verts))` round trip) -------
+# chamfer_distance(m1, m2, n) (src/metrics/mesh.jl:34-44) draws from both meshes: the two CDF builds in one launch, the two
+# draws in one launch (identical samples to two sample_points calls with the same seeds)
+function sample_points_pair(m1::TriMesh{Float32,R1,HipArray}, m2::TriMesh{Float32,R2,HipArray}, n::Int = 5000;
+                            eps::Number = Flux3D.EPS, seed1::UInt64 = rand(UInt64), seed2::UInt64 = seed1 + 1) where {R1,R2}
+    v1 = get_verts_padded(m1); v2 = get_verts_padded(m2)
+    f1 = faces_padded_dev(m1); l1 = faces_len_dev(m1); f2 = faces_padded_dev(m2); l2 = faces_len_dev(m2)
+    nb1 = Ref{Csize_t}(0); nb2 = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_sample_points_workspace_bytes(m1.F::Int32, m1.N::Int32, nb1::Ref{Csize_t})::Int32)
+    check(@ccall LIB.fx3d_sample_points_workspace_bytes(m2.F::Int32, m2.N::Int32, nb2::Ref{Csize_t})::Int32)
+    w1 = HipArray{UInt8,1}(undef, (Int(nb1[]),)); w2 = HipArray{UInt8,1}(undef, (Int(nb2[]),))
+    check(@ccall LIB.fx3d_sample_points_cdf_pair(v1.ptr::Ptr{Cvoid}, m1.V::Int32, f1.ptr::Ptr{Cvoid}, m1.F::Int32, l1.ptr::Ptr{Cvoid},
+                                                 m1.N::Int32, w1.ptr::Ptr{Cvoid}, length(w1)::Csize_t, v2.ptr::Ptr{Cvoid}, m2.V::Int32,
+                                                 f2.ptr::Ptr{Cvoid}, m2.F::Int32, l2.ptr::Ptr{Cvoid}, m2.N::Int32, w2.ptr::Ptr{Cvoid},
+                                                 length(w2)::Csize_t, Float64(eps)::Float64, DEFAULT_STREAM::Stream)::Int32)
+    o1 = HipArray{Float32,3}(undef, (3, n, m1.N)); o2 = HipArray{Float32,3}(undef, (3, n, m2.N))
+    check(@ccall LIB.fx3d_sample_points_draw_pair(v1.ptr::Ptr{Cvoid}, m1.V::Int32, f1.ptr::Ptr{Cvoid}, m1.F::Int32, l1.ptr::Ptr{Cvoid},
+                                                  m1.N::Int32, n::Int32, seed1::UInt64, w1.ptr::Ptr{Cvoid}, length(w1)::Csize_t,
+                                                  o1.ptr::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
+                                                  v2.ptr::Ptr{Cvoid}, m2.V::Int32, f2.ptr::Ptr{Cvoid}, m2.F::Int32, l2.ptr::Ptr{Cvoid},
+                                                  m2.N::Int32, n::Int32, seed2::UInt64, w2.ptr::Ptr{Cvoid}, length(w2)::Csize_t,
+                                                  o2.ptr::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
+                                                  C_NULL::Ptr{Cvoid}, DEFAULT_STREAM::Stream)::Int32)
+    return o1, o2
+end
+
 function laplacian_loss(m::TriMesh{Float32,R,HipArray}) where {R}
     verts = get_verts_packed(m)::HipArray{Float32,2}
     rowptr, colind, vals = laplacian_csr_dev(m)

@@ -86,11 +86,10 @@ def chamfer_distance(A, B, num_samples=5000, w1=1.0, w2=1.0, return_indices=Fals
     if isinstance(A, TriMesh) or isinstance(B, TriMesh):
         if not (isinstance(A, TriMesh) and isinstance(B, TriMesh)):
             raise TypeError("chamfer_distance: both arguments must be TriMesh")
-        from .transforms import sample_points
+        from .transforms import sample_points_pair
         s1 = None if seed is None else seed
         s2 = None if seed is None else seed + 1
-        PA = sample_points(A, num_samples, seed=s1, reuse_cdf=reuse_cdf)
-        PB = sample_points(B, num_samples, seed=s2, reuse_cdf=reuse_cdf)
+        PA, PB = sample_points_pair(A, B, num_samples, seed_a=s1, seed_b=s2, reuse_cdf=reuse_cdf)  # one CDF launch, one draw launch
         return _chamfer_points(PA, PB, w1, w2, return_indices, loss_out, sync)
     return _chamfer_points(A, B, w1, w2, return_indices, loss_out, sync)
 

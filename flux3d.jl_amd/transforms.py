@@ -99,6 +99,52 @@ def sample_points(m, num_samples=5000, eps=EPS, seed=None, return_draws=False,
     return (out, fo, a, b) if return_draws else out
 
 
+def sample_points_pair(ma, mb, num_samples=5000, eps=EPS, seed_a=None, seed_b=None, reuse_cdf=True, seed_dev=None,
+                       return_draws_a=False):
+    """``(sample_points(ma, n; seed_a), sample_points(mb, n; seed_b))`` -- what chamfer_distance(m1, m2, n) draws
+    (src/metrics/mesh.jl:41-42) -- with both CDF builds in one launch and both draws in one launch
+    (fx3d_sample_points_cdf_pair / _draw_pair): identical results, two launch-bound kernels less per evaluation.
+    ``return_draws_a``: also (face_idx, r1, r2) of the first mesh's draws (the fitting loop's adjoint needs them)."""
+    if seed_a is None or seed_b is None:
+        _seed_counter[0] = (_seed_counter[0] * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        seed_a = _seed_counter[0] if seed_a is None else seed_a
+        seed_b = (_seed_counter[0] + 1) % (1 << 64) if seed_b is None else seed_b
+    n = int(num_samples)
+    st = current_stream().handle
+    sides = []
+    for m in (ma, mb):
+        verts, faces = _verts_padded_dev(m), m.dev("faces_padded")
+        key = ("face_cdf", float(eps))
+        ws = m._dev.get(key) if (m.on_device and reuse_cdf) else None
+        sides.append([m, verts, faces, ws, key])
+    need = [sd for sd in sides if sd[3] is None]
+    for sd in need:
+        nb = C.c_size_t(0)
+        _lib.call("fx3d_sample_points_workspace_bytes", sd[0].F, sd[0].N, C.byref(nb))
+        sd[3] = DeviceArray.empty((nb.value,), np.uint8)
+    if len(need) == 2:
+        (m0, v0, f0, w0, _), (m1, v1, f1, w1, _) = need
+        _lib.call("fx3d_sample_points_cdf_pair", v0.ptr, m0.V, f0.ptr, m0.F, m0.dev("faces_len").ptr, m0.N, w0.ptr, w0.nbytes,
+                  v1.ptr, m1.V, f1.ptr, m1.F, m1.dev("faces_len").ptr, m1.N, w1.ptr, w1.nbytes, float(eps), st)
+    elif len(need) == 1:
+        m0, v0, f0, w0, _ = need[0]
+        _lib.call("fx3d_sample_points_cdf", v0.ptr, m0.V, f0.ptr, m0.F, m0.dev("faces_len").ptr, m0.N, float(eps), w0.ptr, w0.nbytes, st)
+    for sd in need:
+        if sd[0].on_device:
+            sd[0]._dev[sd[4]] = sd[3]
+    outs = [DeviceArray.empty((3, n, sd[0].N), np.float32) for sd in sides]
+    (m0, v0, f0, w0, _), (m1, v1, f1, w1, _) = sides
+    mask = (1 << 64) - 1
+    fo = DeviceArray.empty((n, m0.N), np.int32) if return_draws_a else None
+    ra = DeviceArray.empty((n, m0.N), np.float32) if return_draws_a else None
+    rb = DeviceArray.empty((n, m0.N), np.float32) if return_draws_a else None
+    _lib.call("fx3d_sample_points_draw_pair", v0.ptr, m0.V, f0.ptr, m0.F, m0.dev("faces_len").ptr, m0.N, n, int(seed_a) & mask,
+              w0.ptr, w0.nbytes, outs[0].ptr, fo.ptr if fo else None, ra.ptr if ra else None, rb.ptr if rb else None,
+              v1.ptr, m1.V, f1.ptr, m1.F, m1.dev("faces_len").ptr, m1.N, n, int(seed_b) & mask, w1.ptr, w1.nbytes, outs[1].ptr,
+              None, None, None, seed_dev.ptr if seed_dev is not None else None, st)
+    return (outs[0], outs[1], fo, ra, rb) if return_draws_a else (outs[0], outs[1])
+
+
 def sample_points_grad(m, face_idx, r1, r2, gout, out=None):
     """Adjoint of sample_points w.r.t. the padded verts for fixed draws: device (3,Vmax,B).
     ``out``: scatter-add into this (3,Vmax,B) array instead of a zeroed one (no memset node)."""

@@ -274,6 +274,24 @@ FX3D_API fx3d_status fx3d_sample_points_draw(const float *verts_padded, int32_t 
                                              float *out, int32_t *face_out, float *r1_out, float *r2_out,
                                              fx3d_stream_t s);
 
+/* Both meshes of chamfer_distance(m1::TriMesh, m2::TriMesh, n) (src/metrics/mesh.jl:41-42) in ONE launch per half: the two
+ * CDF builds (when both batches take the same one-block kernel variant; otherwise one after the other) and the two draws.
+ * Bit-identical to two separate fx3d_sample_points_cdf / fx3d_sample_points_draw calls; saves two launch-bound kernels per
+ * evaluation (C3: 66 -> 57 us).  seed_dev (optional) is added to both seeds. */
+FX3D_API fx3d_status fx3d_sample_points_cdf_pair(const float *verts0, int32_t Vmax0, const int32_t *faces0, int32_t Fmax0,
+                                                 const int32_t *faces_len0, int32_t B0, void *ws0, size_t ws_bytes0,
+                                                 const float *verts1, int32_t Vmax1, const int32_t *faces1, int32_t Fmax1,
+                                                 const int32_t *faces_len1, int32_t B1, void *ws1, size_t ws_bytes1,
+                                                 double eps, fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_sample_points_draw_pair(const float *verts0, int32_t Vmax0, const int32_t *faces0, int32_t Fmax0,
+                                                  const int32_t *faces_len0, int32_t B0, int32_t n0, uint64_t seed0,
+                                                  const void *cdf_ws0, size_t ws_bytes0, float *out0, int32_t *face_out0,
+                                                  float *r1_out0, float *r2_out0, const float *verts1, int32_t Vmax1,
+                                                  const int32_t *faces1, int32_t Fmax1, const int32_t *faces_len1, int32_t B1,
+                                                  int32_t n1, uint64_t seed1, const void *cdf_ws1, size_t ws_bytes1,
+                                                  float *out1, int32_t *face_out1, float *r1_out1, float *r2_out1,
+                                                  const uint64_t *seed_dev, fx3d_stream_t s);
+
 /* Adjoint of sample_points w.r.t. verts_padded for the same draws (Zygote through :67-71):
  * gverts_padded (3,Vmax,B) = scatter of w_k * gout over the sampled faces.  accumulate = 0 overwrites gverts;
  * accumulate != 0 adds to it (this and the two mesh-loss adjoints then sum into one gradient buffer: the fit_mesh

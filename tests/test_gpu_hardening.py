@@ -877,3 +877,33 @@ def test_host_pointer_convenience_variants(gpu_fx, oracle):
     _lib.check(lib.fx3d_laplacian_loss_host(p(vpk), vpk.shape[1], p(r32), p(c32), p(vals), C.byref(l)))
     assert np.isclose(l.value, oracle.laplacian_loss(vpk, rowptr, colind, vals), rtol=LOSS_RTOL)
     assert lib.fx3d_chamfer_distance_host(p(x), 0, p(x), 5, 1, 3, 1.0, 1.0, C.byref(l), None, None) == -1
+
+
+def test_sample_points_pair_is_two_sample_points(gpu_fx):
+    """chamfer_distance(m1, m2, n) draws from both meshes (src/metrics/mesh.jl:41-42): fx3d_sample_points_cdf_pair / _draw_pair
+    put the two CDF builds and the two draws in one launch each.  Same bits as two sample_points calls -- batches of different
+    sizes and paddings, batches that take different CDF kernels (one of them forced onto the multi-block path), a cached CDF on
+    one side, and the whole mesh-to-mesh chamfer call."""
+    fx = gpu_fx
+    from flux3d_jl_amd import _lib
+    t, sph = os.path.join(GOLDEN, "teapot.obj"), os.path.join(GOLDEN, "sphere.obj")
+    a = fx.gpu(fx.load_trimesh(t, sph, t))            # ragged, 3 meshes
+    b = fx.gpu(fx.load_trimesh(*[sph] * 5))           # 5 meshes, other padding
+    for reuse in (False, True, True):                 # (third round: both CDFs cached)
+        pa, pb = fx.sample_points_pair(a, b, 3000, seed_a=41, seed_b=97, reuse_cdf=reuse)
+        ea = fx.sample_points(fx.gpu(fx.load_trimesh(t, sph, t)), 3000, seed=41)
+        eb = fx.sample_points(fx.gpu(fx.load_trimesh(*[sph] * 5)), 3000, seed=97)
+        assert np.array_equal(pa.to_host(), ea.to_host()) and np.array_equal(pb.to_host(), eb.to_host())
+    c = fx.gpu(fx.load_trimesh(t))                    # one side with a cached CDF, the other without
+    fx.sample_points(c, 10, seed=1)
+    pc, pd = fx.sample_points_pair(c, fx.gpu(fx.load_trimesh(sph)), 777, seed_a=5, seed_b=6)
+    assert np.array_equal(pc.to_host(), fx.sample_points(fx.gpu(fx.load_trimesh(t)), 777, seed=5).to_host())
+    assert np.array_equal(pd.to_host(), fx.sample_points(fx.gpu(fx.load_trimesh(sph)), 777, seed=6).to_host())
+    with _lib.option("cdf_multiblock_from", 3000):    # the sphere (5120 faces) takes the five-launch path, the teapot (2256) the one-block kernel
+        pe, pf = fx.sample_points_pair(fx.gpu(fx.load_trimesh(t)), fx.gpu(fx.load_trimesh(sph)), 500, seed_a=8, seed_b=9)
+    assert np.array_equal(pe.to_host(), fx.sample_points(fx.gpu(fx.load_trimesh(t)), 500, seed=8).to_host())
+    assert np.array_equal(pf.to_host(), fx.sample_points(fx.gpu(fx.load_trimesh(sph)), 500, seed=9).to_host())
+    m1, m2 = fx.gpu(fx.load_trimesh(*[t] * 8)), fx.gpu(fx.load_trimesh(*[sph] * 8))
+    whole = fx.chamfer_distance(m1, m2, 5000, seed=123)
+    parts = fx.chamfer_distance(fx.sample_points(m1, 5000, seed=123), fx.sample_points(m2, 5000, seed=124))
+    assert whole == parts
