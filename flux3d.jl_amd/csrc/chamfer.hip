@@ -280,6 +280,64 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float chamfer_loss_from_sums(double sa, double sb, int N, int M, int D,
                                                         long long Bg, float w1, float w2);
+
+// The tail of a launch with fused finalisation, run by the FIRST WAVE of every block after the block's sum `tot` has
+// arrived in its lane 0: publish the partial (8-byte agent-scope store -> drain -> relaxed ticket), and the last arriver
+// reduces all partials in a fixed order and writes the sums / the loss.  That reduction is the launch's tail -- every
+// other CU is idle by then --, so it is one wave, all its loads in flight together (four per lane and direction), DPP
+// double adds, no barrier, 32-bit index math (the block-wide version with two barrier rounds and 64-bit divisions took
+// 6.0 k cycles from ticket to end at C2; this one 2.3 k).  `slot`: this block's entry; rows of `stride` entries per
+// (direction, cloud), the first tiles_x / tiles_y of a row are valid.
+struct FinalizeArgs {
+    unsigned long long *pp;
+    unsigned int *ticket;
+    unsigned int nvalid;
+    int B, stride, tiles_x, tiles_y;
+    double *sums_out;
+    float *loss_out;
+    int N, M;
+    long long Bg;
+    float w1, w2;
+};
+__device__ __forceinline__ int fused_finalize_wave0(const FinalizeArgs &f, size_t slot, double tot, int lane) {
+    int last = 0;
+    if (lane == 0) {
+        __hip_atomic_store(&f.pp[slot], __builtin_bit_cast(unsigned long long, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int old = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = old == f.nvalid - 1;
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return 0;
+    // lane l sums entries l, l + 64, ... of a direction in order (four of each direction in flight), then the DPP tree
+    double a[2] = {0.0, 0.0};
+    const unsigned int n0 = (unsigned int)f.B * (unsigned int)f.tiles_x, n1 = (unsigned int)f.B * (unsigned int)f.tiles_y;  // (< 2^30: check_shapes)
+    for (unsigned int k0 = lane; k0 < n0 || k0 < n1; k0 += 64 * 4) {
+        unsigned long long v[2][4];
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned int nt = dd ? f.tiles_y : f.tiles_x;
+                const unsigned int k = k0 + 64 * u, kc = k < (dd ? n1 : n0) ? k : 0;
+                // (directions of equal tile counts -- the usual case -- : rows are dense, no division)
+                const size_t e = nt == (unsigned int)f.stride ? (size_t)dd * f.B * f.stride + kc : ((size_t)(dd * f.B) + kc / nt) * f.stride + kc % nt;
+                v[dd][u] = __hip_atomic_load(&f.pp[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k0 + 64 * u < (dd ? n1 : n0)) a[dd] += __builtin_bit_cast(double, v[dd][u]);
+    }
+    const double t0 = wave_sum_l63_f64(a[0]), t1 = wave_sum_l63_f64(a[1]);
+    if (lane == 63) {
+        if (f.sums_out) { f.sums_out[0] = t0; f.sums_out[1] = t1; }
+        if (f.loss_out) *f.loss_out = chamfer_loss_from_sums(t0, t1, f.N, f.M, 3, f.Bg, f.w1, f.w2);
+        __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for reuse
+    }
+    return 1;
+}
 constexpr int kHThreads = 1024;   // 16 waves share one LDS image: 1 block per CU, 4 waves per SIMD
 #ifndef FX3D_HLT
 #define FX3D_HLT 2
@@ -895,52 +953,16 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             // ---- fused finalisation: placement-independent hand-off through 8-byte agent-scope atomics
             //      (write-through store -> drain -> relaxed ticket; the last arriver reads with agent-scope
             //      loads), MI355X_MICROARCH.md "valid forms".  Fixed summation order => deterministic.
-            // Only the first wave goes on (the block's sum is in its lane 0).  The last arriver's reduction is the launch's tail
-            // -- every other CU is idle by then --: one wave, all its loads in flight together, DPP adds, no barrier (the
-            // block-wide version, two barrier rounds and shuffle trees through LDS, took 6 k cycles = 2.7 us at C2).
-            unsigned long long *pp = reinterpret_cast<unsigned long long *>(p.partials);
+            // (only the first wave goes on: the block's sum is in its lane 0)
             if (wv == 0) {
-                int last = 0;
-                if (lane == 0) {
-                    __hip_atomic_store(&pp[(size_t)c * p.tiles + tile], __builtin_bit_cast(unsigned long long, tot),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const unsigned int old = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    last = old == p.nvalid - 1;
-                }
-                last = __builtin_amdgcn_readfirstlane(last);
+                const FinalizeArgs fa{reinterpret_cast<unsigned long long *>(p.partials), p.ticket, p.nvalid, p.B, p.tiles, p.tiles_x, p.tiles_y,
+                                      p.sums_out, p.loss_out, p.N, p.M, p.Bg, p.w1, p.w2};
+                const int was_last = fused_finalize_wave0(fa, (size_t)c * p.tiles + tile, tot, lane);
 #ifdef FX3D_PROBE
-                if (tid == 0 && blockIdx.x < 4096) { g_probe[blockIdx.x * 16 + 15] = last; g_probe[blockIdx.x * 16 + 9] = __builtin_readcyclecounter(); }
+                if (tid == 0 && blockIdx.x < 4096) { g_probe[blockIdx.x * 16 + 15] = was_last; g_probe[blockIdx.x * 16 + 9] = __builtin_readcyclecounter(); }
+#else
+                (void)was_last;
 #endif
-                if (last) {
-                    // lane l sums entries l, l + 64, ... of a direction in order (four of each direction in flight), then the DPP tree
-                    double a[2] = {0.0, 0.0};
-                    const unsigned int n0 = (unsigned int)p.B * (unsigned int)p.tiles_x, n1 = (unsigned int)p.B * (unsigned int)p.tiles_y;  // (< 2^30: check_shapes)
-                    for (unsigned int k0 = lane; k0 < n0 || k0 < n1; k0 += 64 * 4) {
-                        unsigned long long v[2][4];
-#pragma unroll
-                        for (int dd = 0; dd < 2; ++dd)
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const unsigned int nt = dd ? p.tiles_y : p.tiles_x;
-                                const unsigned int k = k0 + 64 * u, kc = k < (dd ? n1 : n0) ? k : 0;
-                                // (clouds of equal tile counts -- the usual case -- : rows are dense, no division)
-                                const size_t e = nt == (unsigned int)p.tiles ? (size_t)dd * p.B * p.tiles + kc : ((size_t)(dd * p.B) + kc / nt) * p.tiles + kc % nt;
-                                v[dd][u] = __hip_atomic_load(&pp[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-#pragma unroll
-                        for (int dd = 0; dd < 2; ++dd)
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (k0 + 64 * u < (dd ? n1 : n0)) a[dd] += __builtin_bit_cast(double, v[dd][u]);
-                    }
-                    const double t0 = wave_sum_l63_f64(a[0]), t1 = wave_sum_l63_f64(a[1]);
-                    if (lane == 63) {
-                        if (p.sums_out) { p.sums_out[0] = t0; p.sums_out[1] = t1; }
-                        if (p.loss_out) *p.loss_out = chamfer_loss_from_sums(t0, t1, p.N, p.M, 3, p.Bg, p.w1, p.w2);
-                        __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for reuse
-                    }
-                }
             }
         }
     }
@@ -982,38 +1004,12 @@ __global__ __launch_bounds__(kThreads) void nn1_split_finalize_kernel(Nn1Params 
             if (threadIdx.x == 0) p.partials[(size_t)c * tiles_f + blockIdx.x] = tot;
             return;
         }
-        // fused finalisation (as in nn1_f16_kernel): the last block to arrive sums the partials in the order of
-        // chamfer_finalize_partials_kernel and writes the sums / the loss -- one launch less per split run
-        __shared__ int is_last;
-        unsigned long long *pp = reinterpret_cast<unsigned long long *>(p.partials);
-        if (threadIdx.x == 0) {
-            __hip_atomic_store(&pp[(size_t)c * tiles_f + blockIdx.x], __builtin_bit_cast(unsigned long long, tot), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned int old = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            is_last = old == p.nvalid - 1;
-        }
-        __syncthreads();
-        if (is_last) {
-            double tsum[2];
-            for (int dd = 0; dd < 2; ++dd) {
-                const int nt = dd ? p.tiles_y : p.tiles_x;
-                const long long n = (long long)p.B * nt;
-                double a = 0.0;
-                for (long long k = threadIdx.x; k < n; k += kThreads) {
-                    const int bb = (int)(k / nt), tt = (int)(k % nt);
-                    const unsigned long long v = __hip_atomic_load(&pp[((size_t)(dd * p.B + bb)) * tiles_f + tt], __ATOMIC_RELAXED,
-                                                                   __HIP_MEMORY_SCOPE_AGENT);
-                    a += __builtin_bit_cast(double, v);
-                }
-                __syncthreads();
-                tsum[dd] = block_sum<kThreads>(a, sm);
-            }
-            if (threadIdx.x == 0) {
-                if (p.sums_out) { p.sums_out[0] = tsum[0]; p.sums_out[1] = tsum[1]; }
-                if (p.loss_out) *p.loss_out = chamfer_loss_from_sums(tsum[0], tsum[1], p.N, p.M, 3, p.Bg, p.w1, p.w2);
-                __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for reuse
-            }
+        // fused finalisation (as in nn1_f16_kernel): the last block to arrive sums the partials and writes the sums / the loss --
+        // one launch less per split run; by its first wave alone (fused_finalize_wave0)
+        if (threadIdx.x < 64) {
+            const FinalizeArgs fa{reinterpret_cast<unsigned long long *>(p.partials), p.ticket, p.nvalid, p.B, tiles_f, p.tiles_x, p.tiles_y,
+                                  p.sums_out, p.loss_out, p.N, p.M, p.Bg, p.w1, p.w2};
+            (void)fused_finalize_wave0(fa, (size_t)c * tiles_f + blockIdx.x, tot, (int)threadIdx.x);
         }
     }
 }

@@ -104,8 +104,19 @@ def main():
             ok, desc = mesh_case(rng)
         elif what == 0:  # 1-NN both directions + chamfer
             N, M = int(rng.integers(1, 3000)), int(rng.integers(1, 3000))
+            if rng.random() < 0.35:  # (round 3) sizes around the launch plan's boundaries: one LDS image + an exact tail of <= 64
+                def edge():          # candidates, query remainders of <= 64 folded into the last tile, several chunks
+                    base = int(rng.choice([512, 1024, 2048, 4096, 4096, 4096, 6144, 8192]))
+                    return max(1, base + int(rng.integers(-3, 70)))
+                N, M = edge(), (edge() if rng.random() < 0.6 else int(rng.integers(1, 3000)))
+                B = int(rng.integers(1, 3))
             x, y = cloud(rng, 3, N, B, kind), cloud(rng, 3, M, B, kind)
             desc = f"nn1 {kind} N={N} M={M} B={B}"
+            if rng.random() < 0.3:   # (round 3) clouds of different extent / position: far queries carry a scale of their own
+                ratio = float(np.exp(rng.uniform(0.0, np.log(1e7))))
+                shift = float(rng.choice([0.0, 0.0, 1.0, 30.0])) * ratio
+                y = np.asfortranarray((y * np.float32(ratio) + np.float32(shift)).astype(np.float32))
+                desc += f" y*{ratio:.3g}+{shift:.3g}"
             ix, iy = fx.nearest_neighbors(fx.gpu(x), fx.gpu(y))
             ox, oy = orc.nn1(x, y)
             ok = np.array_equal(ix.to_host(), ox) and np.array_equal(iy.to_host(), oy)
