@@ -603,10 +603,12 @@ __device__ __forceinline__ int key_less_bf(float d, int j, float od, int oj) {
 // unusable or whose survivor lists overflow: heavy ties, degenerate clouds).  Same scheme as knn_wave_d3_kernel:
 // per 1024-candidate chunk 16 exact distances per lane, threshold = kk-th smallest lane minimum (first chunk) or the
 // current kk-th best, candidates <= threshold compacted into a 64-entry LDS list (flushed into the best list
-// whenever it is full), one 64-lane bitonic sort on (distance, index) per merge.  kk <= 32.
+// whenever it is full), one 64-lane bitonic sort on (distance, index) per merge.  kk <= 63; FULL64 instantiations also take
+// kk = 64 (no room for a pending list: 64 candidates at a time are sorted and merged into the best list).
 // lst_d / lst_j: 64 floats / ints of wave-private LDS.  Result: lanes 0..kk-1 hold the answer in order.
 // ids == nullptr: all M candidates; else the M candidates ids[0..M) (LDS): a query's own survivors when they exceed the
 // fast path's key capacity.
+template <bool FULL64 = false>
 __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q, const float *__restrict__ yb, int M,
                                                       int D, int kk, int lane, float *lst_f, int *lst_j, float &bd_out,
                                                       int &bj, const int *ids = nullptr) {
@@ -615,6 +617,33 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
     unsigned int bd = kNoKey;
     bj = 0x7fffffff;
     const int cap = 64 - kk;
+    if (FULL64 && cap == 0) {
+#pragma unroll 1
+        for (int j0 = 0; j0 < M; j0 += 64) {
+            const int j = j0 + lane;
+            unsigned int nd = kNoKey;
+            int nj = 0x7fffffff;
+            if (j < M) {
+                nj = ids ? ids[j] : j;
+                const float *c = yb + (size_t)nj * D;
+                float s = 0.0f;
+                for (int dd = 0; dd < D; ++dd) {
+                    const float t = q[dd] - c[dd];
+                    s = s + t * t;
+                }
+                nd = dist_key(s);
+            }
+            bitonic64(nd, nj, lane);                                             // ascending new batch
+            const unsigned int rd = (unsigned int)__shfl((int)nd, 63 - lane, 64);  // reversed
+            const int rj = __shfl(nj, 63 - lane, 64);
+            const bool o_less = key_less(rd, rj, bd, bj);
+            bd = o_less ? rd : bd;                                               // lower half of the union (bitonic)
+            bj = o_less ? rj : bj;
+            bitonic64(bd, bj, lane);
+        }
+        bd_out = key_dist(bd);
+        return;
+    }
     const bool vec4 = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(yb)) & 15) == 0;
     for (int j0 = 0; j0 < M; j0 += 1024) {
         unsigned int d[16];
@@ -889,13 +918,19 @@ __device__ __forceinline__ void knn_rank_ties(const unsigned int *qd, const int 
 //            index).  Bit-identical to fx3d_oracle_knn.
 //   Queries outside the fp16 range, with overflowing lists or non-finite thresholds take the brute-force merge.
 typedef _Float16 kh8 __attribute__((ext_vector_type(8)));
-constexpr int kTGroups = 4;           // query groups (32 queries each) per block: C4 gets 256 blocks, one per CU
-constexpr int kTWaves = 2 * kTGroups; // two waves per group, each taking every other pair of candidate tiles:
-                                      // two waves per SIMD overlap each other's LDS / shuffle latencies
-constexpr int kTThreads = kTWaves * 64;
-constexpr int kTCap = 24;             // rows of a lane's list (23 usable + the scratch head); a lane sees half the tiles
-constexpr int kTKeyCap = 64;          // keys per query (the four lanes' survivors; three sentinels follow them inside the stride)
-constexpr int kTKeyStride = kTKeyCap + 4;  // row stride in words: 32 queries x b128 reads without bank conflicts
+// Geometry of one instantiation: G query groups (32 queries each) per block, two waves per group (each taking every other pair of
+// candidate tiles: two waves per SIMD overlap each other's LDS / shuffle latencies), CAP rows per lane list (CAP - 1 usable + the
+// scratch head; a lane sees half the tiles), KCAP keys per query (the four lanes' survivors; three sentinels follow them inside the
+// stride KS: 32 queries x b128 reads without bank conflicts), KKMAX = the largest k + drop (SS - 1 rank slots per query).
+template <int G_, int CAP_, int KCAP_, int KKMAX_>
+struct K3Geom {
+    static constexpr int G = G_, W = 2 * G_, T = W * 64, CAP = CAP_, KCAP = KCAP_, KS = KCAP_ + 4, KKMAX = KKMAX_, SS = KKMAX_ + 1;
+    static_assert((size_t)W * 32 * 33 * 4 <= (size_t)W * CAP * 64 * 4, "the tau exchange aliases the lists");
+    static_assert((size_t)G * 32 * SS * 8 + W * 128 * 4 <= (size_t)W * CAP * 64 * 4, "slots + scratch alias the lists");
+    static_assert(CAP <= 64 && KKMAX <= 64 && KKMAX % 16 == 0 && KCAP % 4 == 0, "one list word per lane in the medium path; 16-byte key rows");
+};
+using K3Base = K3Geom<4, 24, 64, 32>;    // k + drop <= 32: C4 gets 256 blocks of 128 queries, one per CU
+using K3Wide = K3Geom<2, 40, 128, 64>;   // 32 < k + drop <= 64: twice the keys and longer lists per query, half the queries per block
 constexpr int kTChunk = 3072;         // candidates per LDS image (32 B each): image + lists + counters <= 152 KiB
 constexpr int kTRawMax = 2048;        // clouds up to this size also keep their raw coordinates in LDS
 constexpr int kK3FarCap = 16;         // far candidates (robust range, as in nn1_f16_kernel) kept on the exact side list
@@ -979,24 +1014,24 @@ __device__ __forceinline__ void knn_d3_feature_entry(float *__restrict__ feat, i
 }
 
 // FEAT: EdgeConv's graph build in one kernel (self-kNN, x == y): the epilogue also writes cat(x_i, x_j - x_i).
-template <bool FEAT>
-__global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__restrict__ x, int N,
+template <bool FEAT, class C>
+__global__ __launch_bounds__(C::T) void knn_f16_d3_kernel(const float *__restrict__ x, int N,
                                                                const float *__restrict__ y, int M, int B, int k,
                                                                int drop, int32_t *__restrict__ idx,
                                                                float *__restrict__ dist, int CH, int img_bytes,
                                                                int raw_ok, float *__restrict__ feat, int layout, int med_cap, int med_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k3sm[];
-    __shared__ __attribute__((aligned(16))) float red[4 * 4 * kTWaves];  // per wave: min, max, sum, sampled second moment (padded to 4 dims)
+    __shared__ __attribute__((aligned(16))) float red[4 * 4 * C::W];  // per wave: min, max, sum, sampled second moment (padded to 4 dims)
     __shared__ int nfar;                    // candidates of the cloud beyond the robust range ...
     __shared__ int farlist[kK3FarCap];      // ... their indices: outside the filter, every query evaluates them exactly
     kh8 *imgp = reinterpret_cast<kh8 *>(k3sm);  // piece (blk, half, row) at (blk*2 + half)*32 + row
-    constexpr int kListBytes = kTWaves * kTCap * 64 * 4;      // lane lists; also the tau exchange and, later, the slots
-    constexpr int kCtrInts = kTGroups * 32 * 8;               // per query: 4 part counts, overflow, n, fast, below
-    int *lists_all = reinterpret_cast<int *>(k3sm + img_bytes);                                  // [kTWaves][kTCap][64]
-    int *ctr = reinterpret_cast<int *>(k3sm + img_bytes + kListBytes);                           // [kTGroups*32][8]
+    constexpr int kListBytes = C::W * C::CAP * 64 * 4;      // lane lists; also the tau exchange and, later, the slots
+    constexpr int kCtrInts = C::G * 32 * 8;               // per query: 4 part counts, overflow, n, fast, below
+    int *lists_all = reinterpret_cast<int *>(k3sm + img_bytes);                                  // [C::W][C::CAP][64]
+    int *ctr = reinterpret_cast<int *>(k3sm + img_bytes + kListBytes);                           // [C::G*32][8]
     const float4 *rawc = reinterpret_cast<const float4 *>(k3sm + img_bytes + kListBytes + kCtrInts * 4);  // [M] when raw_ok
 
-    const int nbx = (N + kTGroups * 32 - 1) / (kTGroups * 32);
+    const int nbx = (N + C::G * 32 - 1) / (C::G * 32);
     const int L = blockIdx.x;
     const bool by_xcd = B >= 8;
     const int b = by_xcd ? ((L >> 3) / nbx) * 8 + (L & 7) : L / nbx;
@@ -1006,10 +1041,10 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     const int jq = lane & 31, hh = lane >> 5;
     const int kk = k + drop;
     const float *xb = x + (size_t)b * N * 3, *yb = y + (size_t)b * M * 3;
-    const int grp = wv % kTGroups, half = wv / kTGroups;  // query group; which pairs of tiles this wave takes
-    const int q0 = (bxq * kTGroups + grp) * 32;
+    const int grp = wv % C::G, half = wv / C::G;  // query group; which pairs of tiles this wave takes
+    const int q0 = (bxq * C::G + grp) * 32;
     const bool wave_active = q0 < N;
-    for (int e = tid; e < kCtrInts; e += kTThreads) ctr[e] = 0;
+    for (int e = tid; e < kCtrInts; e += C::T) ctr[e] = 0;
     if (tid == 0) nfar = 0;  // (ordered before its first use by the barrier of the cloud pass)
     const int qi = q0 + jq;  // this lane's query (loaded here: the latency hides behind the pass over the cloud)
     const int qc = qi < N ? qi : N - 1;
@@ -1025,19 +1060,19 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
         float mn3[3] = {INFINITY, INFINITY, INFINITY}, mx3[3] = {-INFINITY, -INFINITY, -INFINITY}, sm3[3] = {0.f, 0.f, 0.f};
         float sqt = 0.0f;  // second moment (all three coordinates) of a sample (~M/4 points) about the cloud's first point: the spread
         const float pil[3] = {yb[0], yb[1], yb[2]};
-        // thread t takes points t, t + kTThreads, ...: 12-byte loads, consecutive lanes on consecutive points (coalesced,
+        // thread t takes points t, t + C::T, ...: 12-byte loads, consecutive lanes on consecutive points (coalesced,
         // and the 16-byte LDS slots of a wave's points are consecutive: no bank conflicts)
-        const int nsweep = (M + kTThreads - 1) / kTThreads;
+        const int nsweep = (M + C::T - 1) / C::T;
         for (int i0 = 0; i0 < nsweep; i0 += 4) {
             P3 v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int pt = (i0 + e) * kTThreads + tid;
+                const int pt = (i0 + e) * C::T + tid;
                 v[e] = *reinterpret_cast<const P3 *>(yb + (size_t)(pt < M ? pt : M - 1) * 3);  // (clamped: always valid)
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int pt = (i0 + e) * kTThreads + tid;
+                const int pt = (i0 + e) * C::T + tid;
                 mn3[0] = fminf(mn3[0], v[e].x); mx3[0] = fmaxf(mx3[0], v[e].x);
                 mn3[1] = fminf(mn3[1], v[e].y); mx3[1] = fmaxf(mx3[1], v[e].y);
                 mn3[2] = fminf(mn3[2], v[e].z); mx3[2] = fmaxf(mx3[2], v[e].z);
@@ -1066,7 +1101,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
             const float4 *r4 = reinterpret_cast<const float4 *>(red);
             float4 lo4 = r4[0], hi4 = r4[1], st4 = r4[2];
 #pragma unroll
-            for (int w = 1; w < kTWaves; ++w) {
+            for (int w = 1; w < C::W; ++w) {
                 const float4 a0 = r4[w * 4], a1 = r4[w * 4 + 1], a2 = r4[w * 4 + 2];
                 lo4.x = fminf(lo4.x, a0.x); lo4.y = fminf(lo4.y, a0.y); lo4.z = fminf(lo4.z, a0.z);
                 hi4.x = fmaxf(hi4.x, a1.x); hi4.y = fmaxf(hi4.y, a1.y); hi4.z = fmaxf(hi4.z, a1.z);
@@ -1095,7 +1130,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     // get norm +inf in the image (never below a threshold) and go on a side list that every query appends to its survivors.
     float rng = cinf;
     if (sane && 3.0f * cinf * cinf > kRobustGate * varmax) {
-        const float4 r = robust_range3<kTThreads, true>(yb, M, raw_ok != 0, rawc, red, mu[0], mu[1], mu[2], cinf);
+        const float4 r = robust_range3<C::T, true>(yb, M, raw_ok != 0, rawc, red, mu[0], mu[1], mu[2], cinf);
         mu[0] = r.x; mu[1] = r.y; mu[2] = r.z; rng = r.w;
     }
     const bool has_far = sane && rng < cinf;
@@ -1130,7 +1165,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     for (int r = 0; r < 32; ++r) mn[r] = INFINITY;
     float thr = 0.0f;
     int cnt = 0, tot = 0;
-    int *mylist = lists_all + wv * kTCap * 64 + lane;  // entry e at mylist[e * 64]
+    int *mylist = lists_all + wv * C::CAP * 64 + lane;  // entry e at mylist[e * 64]
     f32x16v zero;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
@@ -1145,7 +1180,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                 __syncthreads();
                 // (two separate loops: a select between an LDS and a global pointer trips the compiler)
                 if (raw_ok) {
-                    for (int pt = tid; pt < cn_pad; pt += kTThreads) {
+                    for (int pt = tid; pt < cn_pad; pt += C::T) {
                         const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
                         kh8 p0, p1;
                         if (pt < cn) {
@@ -1159,7 +1194,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                         imgp[i0 + 32] = p1;
                     }
                 } else {
-                    for (int pt = tid; pt < cn_pad; pt += kTThreads) {
+                    for (int pt = tid; pt < cn_pad; pt += C::T) {
                         const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
                         kh8 p0, p1;
                         if (pt < cn) {
@@ -1213,7 +1248,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
 #pragma unroll
                             for (int r = 0; r < 16; ++r)
                                 m = __builtin_amdgcn_alignbit(m, __builtin_bit_cast(unsigned int, tt ? acc1[r] : acc0[r]), 31);
-                            const int pp = cnt < kTCap - 1 ? cnt : kTCap - 1;
+                            const int pp = cnt < C::CAP - 1 ? cnt : C::CAP - 1;
                             mylist[pp * 64] = (int)((unsigned int)(tile0 + pr * 2 + tt) << 16 | m);
                             cnt += m != 0 ? 1 : 0;
                             tot += __builtin_popcount(m);
@@ -1250,14 +1285,20 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                     }
                 }
             }
-            float *xch = reinterpret_cast<float *>(lists_all);  // [kTWaves][32][33]: the lists are not in use yet
+            float *xch = reinterpret_cast<float *>(lists_all);  // [C::W][32][33]: the lists are not in use yet
             if (hh == 0) {
 #pragma unroll
                 for (int r = 0; r < 32; ++r) xch[(wv * 32 + jq) * 33 + r] = mn[r];
             }
             __syncthreads();
-            {
-                const float *po = xch + (((wv + kTGroups) % kTWaves) * 32 + jq) * 33;  // the group's other wave
+            // the kk-th smallest of the union of this wave's 32 smallest X and the other wave's Y (both ascending) without merging
+            // them: min over the splits (i values from X, kk - i from Y) of max(X[i-1], Y[kk-i-1]).  For kk <= 32 that is the kk-th
+            // smallest of all 128 group minima; for 32 < kk <= 64 the kk-th smallest of these 64 -- an upper bound of it (equal unless
+            // one wave holds more than 32 of the kk smallest).  ~3 VALU + one LDS read per split instead of 32 reads + a 32-value
+            // bitonic merge (192 VALU).
+            float tau = INFINITY;
+            if (C::KKMAX <= 32) {
+                const float *po = xch + (((wv + C::G) % C::W) * 32 + jq) * 33;  // the group's other wave
 #pragma unroll
                 for (int r = 0; r < 32; ++r) mn[r] = vmin_f32(mn[r], po[31 - r]);     // the 32 smallest of the 128
 #pragma unroll
@@ -1272,10 +1313,26 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
                         }
                     }
                 }
-            }
-            float tau = mn[0];  // kk <= 32: among the 32 smallest
+                tau = mn[0];  // kk <= 32: among the 32 smallest
 #pragma unroll
-            for (int r = 1; r < 32; ++r) tau = (kk - 1) == r ? mn[r] : tau;
+                for (int r = 1; r < 32; ++r) tau = (kk - 1) == r ? mn[r] : tau;
+            } else
+            {
+                const float *po = xch + (((wv + C::G) % C::W) * 32 + jq) * 33;  // the group's other wave
+                float yv[33];  // (all reads first, clamped addresses: a branch per split made them a chain of LDS round trips)
+#pragma unroll
+                for (int i = 0; i <= 32; ++i) {
+                    const int yi = kk - i - 1;
+                    yv[i] = po[yi < 0 ? 0 : (yi > 31 ? 31 : yi)];
+                }
+#pragma unroll
+                for (int i = 0; i <= 32; ++i) {
+                    const int ny = kk - i;  // (uniform: the selects below take scalar conditions)
+                    const float a = i >= 1 ? mn[i >= 1 ? i - 1 : 0] : -INFINITY;
+                    const float t = vmax_f32(a, ny >= 1 ? yv[i] : -INFINITY);
+                    tau = vmin_f32(tau, (ny >= 0 && ny <= 32) ? t : INFINITY);
+                }
+            }
             thr = __builtin_fmaf(tau, band_b1, band_a);
             {
                 // phase B subtracts the threshold inside the MFMA (K slot 15: candidate side 1, query side -thr16)
@@ -1298,25 +1355,25 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     const int qslot = grp * 32 + jq;
     int *qctr = ctr + qslot * 8;  // [0..3] entries decoded by part, [4] overflow, [5] below
     const int need = kk < M ? kk : M;
-    const int nv = cnt < kTCap - 1 ? cnt : kTCap - 1;
+    const int nv = cnt < C::CAP - 1 ? cnt : C::CAP - 1;
     const int nf = has_far ? nfar : 0;              // (complete: every chunk was staged before the last barrier)
     const bool far_ok = nf <= kK3FarCap;             // more far candidates than the side list holds: no query is usable
     qctr[part] = tot + (part == 3 && far_ok ? nf : 0);  // the query's last lane appends the far candidates to its own entries
-    if (cnt > kTCap - 1) qctr[4] = 1;
+    if (cnt > C::CAP - 1) qctr[4] = 1;
     if (med_cap > 0) atomicOr(&qctr[6], nv << (8 * part));  // list lengths of the four parts (< 24 each): the medium path's decode
     __syncthreads();  // every wave is done with the image: its space now holds the keys
     KNN_PROBE_MARK(6);
-    unsigned int *qd = reinterpret_cast<unsigned int *>(k3sm) + (size_t)qslot * kTKeyStride;                          // distance bits
-    int *qj = reinterpret_cast<int *>(k3sm) + (size_t)kTGroups * 32 * kTKeyStride + (size_t)qslot * kTKeyStride;     // indices
+    unsigned int *qd = reinterpret_cast<unsigned int *>(k3sm) + (size_t)qslot * C::KS;                          // distance bits
+    int *qj = reinterpret_cast<int *>(k3sm) + (size_t)C::G * 32 * C::KS + (size_t)qslot * C::KS;     // indices
     const int c0 = qctr[0], c1 = qctr[1], c2 = qctr[2], c3 = qctr[3];
     const int n = c0 + c1 + c2 + c3;
     const int off = part == 0 ? 0 : (part == 1 ? c0 : (part == 2 ? c0 + c1 : c0 + c1 + c2));
     const bool usable = sane && far_ok && qok && thr < INFINITY;
-    const bool fast = wave_active && qi < N && usable && qctr[4] == 0 && n <= kTKeyCap && n >= need;  // (+ 3 sentinels: inside the stride)
+    const bool fast = wave_active && qi < N && usable && qctr[4] == 0 && n <= C::KCAP && n >= need;  // (+ 3 sentinels: inside the stride)
     // ---- medium path (tight clusters, duplicated points, lattices: more candidates inside the band than the key arrays hold):
     //      a wave decodes the query's four lane lists into an id list (+ the far candidates) and selects exactly among those,
     //      instead of scanning all M candidates in the fallback.  The lists are intact until the barrier after the decode.
-    const bool medium = med_cap > 0 && wave_active && qi < N && usable && qctr[4] == 0 && n > kTKeyCap && n <= med_cap && n >= need;
+    const bool medium = med_cap > 0 && wave_active && qi < N && usable && qctr[4] == 0 && n > C::KCAP && n <= med_cap && n >= need;
     if (med_cap > 0 && wave_active) {
         const unsigned long long mm = __ballot(medium);
         int *ids = reinterpret_cast<int *>(k3sm + med_off) + wv * (med_cap + 128);
@@ -1328,7 +1385,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
             for (int p2 = 0; p2 < 4; ++p2) {  // p2 = 2 * (wave of the group) + half-wave
                 const int src = (p2 & 1) * 32 + j;
                 const int nv2 = (cj[6] >> (8 * p2)) & 0xff;
-                const unsigned int w = lane < nv2 ? (unsigned int)lists_all[((grp + kTGroups * (p2 >> 1)) * kTCap + lane) * 64 + src] : 0u;
+                const unsigned int w = lane < nv2 ? (unsigned int)lists_all[((grp + C::G * (p2 >> 1)) * C::CAP + lane) * 64 + src] : 0u;
                 const int pc = __builtin_popcount(w & 0xffffu);
                 int incl = pc;
 #pragma unroll
@@ -1352,7 +1409,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
             __builtin_amdgcn_wave_barrier();
             float bd;
             int bj;
-            knn_exact_bruteforce(xb + (size_t)(q0 + j) * 3, yb, total, 3, kk, lane, reinterpret_cast<float *>(ids + med_cap), ids + med_cap + 64,
+            knn_exact_bruteforce<(C::KKMAX > 32)>(xb + (size_t)(q0 + j) * 3, yb, total, 3, kk, lane, reinterpret_cast<float *>(ids + med_cap), ids + med_cap + 64,
                                  bd, bj, ids);
             const int r = lane - drop;
             if (r >= 0 && r < k) {
@@ -1369,7 +1426,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
         for (int e0 = 0; e0 < nv; e0 += 4) {  // four list words in flight
             unsigned int w[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) w[u] = (unsigned int)mylist[(e0 + u < kTCap ? e0 + u : kTCap - 1) * 64];
+            for (int u = 0; u < 4; ++u) w[u] = (unsigned int)mylist[(e0 + u < C::CAP ? e0 + u : C::CAP - 1) * 64];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 unsigned int m = e0 + u < nv ? (w[u] & 0xffffu) : 0u;
@@ -1421,7 +1478,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     const int per = (n + 3) >> 2;  // the ranking is shared evenly
     const int mystart = part * per < n ? part * per : n;
     const int mycount = mystart + per <= n ? per : n - mystart;
-    unsigned long long *slots = reinterpret_cast<unsigned long long *>(lists_all) + (size_t)qslot * 33;  // [..][32 + 1 pad]
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(lists_all) + (size_t)qslot * C::SS;  // [..][KKMAX + 1 pad]
     // ---- order: rank of a survivor = number of survivors of its query with a smaller distance (squared distances
     //      are >= +0: unsigned order of the bits).  Ties in the distance are resolved by the index in the
     //      reference; they are rare, so the ranks are computed on the distances alone and VERIFIED: the ranks below
@@ -1465,6 +1522,10 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     if (part == 0 && wave_active && qi < N) {
         KNN_PROBE_STAT(0, 1);
         KNN_PROBE_STAT(1, !fast);
+        KNN_PROBE_STAT(2, !usable);
+        KNN_PROBE_STAT(3, qctr[4] != 0);
+        KNN_PROBE_STAT(4, n > C::KCAP);
+        KNN_PROBE_STAT(5, n < need);
         KNN_PROBE_STAT(6, n);
         KNN_PROBE_STAT(8, bad);
     }
@@ -1473,7 +1534,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
         const size_t obase = ((size_t)b * N + qi) * k;
         if ((k & 3) == 0 && ((reinterpret_cast<uintptr_t>(idx) | (dist ? reinterpret_cast<uintptr_t>(dist) : 0)) & 15) == 0) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < C::KKMAX / 16; ++u) {
                 const int v = part + 4 * u;
                 if (4 * v < k) {
                     unsigned long long key[4];
@@ -1532,7 +1593,7 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
             }
         } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < C::KKMAX / 4; ++u) {
                 const int r = drop + part + 4 * u;
                 if (r < kk) {
                     const unsigned long long key = slots[r];
@@ -1556,9 +1617,9 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
         if ((j & 1) != half) continue;
         const int qs = grp * 32 + j;
         const int *cj = ctr + qs * 8;
-        unsigned long long *sj = reinterpret_cast<unsigned long long *>(lists_all) + (size_t)qs * 33;
-        knn_rank_ties(reinterpret_cast<const unsigned int *>(k3sm) + (size_t)qs * kTKeyStride,
-                      reinterpret_cast<const int *>(k3sm) + (size_t)kTGroups * 32 * kTKeyStride + (size_t)qs * kTKeyStride,
+        unsigned long long *sj = reinterpret_cast<unsigned long long *>(lists_all) + (size_t)qs * C::SS;
+        knn_rank_ties(reinterpret_cast<const unsigned int *>(k3sm) + (size_t)qs * C::KS,
+                      reinterpret_cast<const int *>(k3sm) + (size_t)C::G * 32 * C::KS + (size_t)qs * C::KS,
                       cj[0] + cj[1] + cj[2] + cj[3], kk, sj, lane);
         for (int r = drop + lane; r < kk; r += 64) {
             const unsigned long long key = sj[r];
@@ -1568,14 +1629,14 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
         }
     }
     // leftovers, wave-cooperative (scratch: behind the slots)
-    int *wscratch = lists_all + kTGroups * 32 * 33 * 2 + wv * 128;
+    int *wscratch = lists_all + C::G * 32 * C::SS * 2 + wv * 128;
     const unsigned int slow32 = (unsigned int)slowmask | (unsigned int)(slowmask >> 32);
     for (int j = half; j < 32; j += 2) {
         if (!((slow32 >> j) & 1u) || q0 + j >= N) continue;
         float bd;
         int bj;
         __builtin_amdgcn_wave_barrier();
-        knn_exact_bruteforce(xb + (size_t)(q0 + j) * 3, yb, M, 3, kk, lane, reinterpret_cast<float *>(wscratch), wscratch + 64, bd, bj);
+        knn_exact_bruteforce<(C::KKMAX > 32)>(xb + (size_t)(q0 + j) * 3, yb, M, 3, kk, lane, reinterpret_cast<float *>(wscratch), wscratch + 64, bd, bj);
         const int r = lane - drop;
         if (r >= 0 && r < k) {
             idx[((size_t)b * N + q0 + j) * k + r] = bj;
@@ -1586,38 +1647,47 @@ __global__ __launch_bounds__(kTThreads) void knn_f16_d3_kernel(const float *__re
     KNN_PROBE_MARK(11);
 }
 
-fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int B, int k, int drop, int32_t *idx,
-                              float *dist, hipStream_t st, float *feat = nullptr, int layout = 0) {
+template <class C>
+fx3d_status launch_knn_f16_d3_geom(const float *x, int N, const float *y, int M, int B, int k, int drop, int32_t *idx,
+                                   float *dist, hipStream_t st, float *feat, int layout) {
     int CH = (M + 63) / 64 * 64;
     if (CH > kTChunk) CH = kTChunk;
     size_t img = (size_t)CH * 32;
-    const size_t keys = (size_t)kTGroups * 32 * kTKeyStride * 8;  // distance bits + indices
+    const size_t keys = (size_t)C::G * 32 * C::KS * 8;  // distance bits + indices
     if (img < keys) img = keys;
-    const size_t fixed = (size_t)kTWaves * kTCap * 64 * 4 + (size_t)kTGroups * 32 * 8 * 4;  // lists (exchange, slots) + counters
-    static_assert((size_t)kTWaves * 32 * 33 * 4 <= (size_t)kTWaves * kTCap * 64 * 4, "the tau exchange aliases the lists");
-    static_assert((size_t)kTGroups * 32 * 33 * 8 + kTWaves * 128 * 4 <= (size_t)kTWaves * kTCap * 64 * 4, "slots + scratch alias the lists");
+    const size_t fixed = (size_t)C::W * C::CAP * 64 * 4 + (size_t)C::G * 32 * 8 * 4;  // lists (exchange, slots) + counters
     const int raw_ok = M <= kTRawMax && img + fixed + (size_t)M * 16 <= 152 * 1024;
     size_t lds = img + fixed + (raw_ok ? (size_t)M * 16 : 0);
     // medium path scratch (id list + merge lists per wave), when it fits next to everything else
     int med_cap = 0, med_off = 0;
     for (int cap = 512; cap >= 128; cap >>= 1)
-        if (lds + (size_t)kTWaves * (cap + 128) * 4 <= 156 * 1024) {
-            med_cap = cap; med_off = (int)lds; lds += (size_t)kTWaves * (cap + 128) * 4;
+        if (lds + (size_t)C::W * (cap + 128) * 4 <= 156 * 1024) {
+            med_cap = cap; med_off = (int)lds; lds += (size_t)C::W * (cap + 128) * 4;
             break;
         }
-    const fx3d_status arc = feat ? ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_f16_d3_kernel<true>), 156 * 1024, "knn_f16_d3_kernel<feat>")
-                                 : ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_f16_d3_kernel<false>), 156 * 1024, "knn_f16_d3_kernel");
+    const fx3d_status arc = feat ? ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_f16_d3_kernel<true, C>), 156 * 1024, "knn_f16_d3_kernel<feat>")
+                                 : ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_f16_d3_kernel<false, C>), 156 * 1024, "knn_f16_d3_kernel");
     if (arc != FX3D_OK) return arc;
-    const int nbx = (N + kTGroups * 32 - 1) / (kTGroups * 32);
+    const int nbx = (N + C::G * 32 - 1) / (C::G * 32);
     const int bpad = B >= 8 ? (B + 7) / 8 * 8 : B;
     if (feat)
-        hipLaunchKernelGGL(knn_f16_d3_kernel<true>, dim3(nbx * bpad), dim3(kTThreads), lds, st, x, N, y, M, B, k, drop, idx, dist,
+        hipLaunchKernelGGL((knn_f16_d3_kernel<true, C>), dim3(nbx * bpad), dim3(C::T), lds, st, x, N, y, M, B, k, drop, idx, dist,
                            CH, (int)img, raw_ok, feat, layout, med_cap, med_off);
     else
-        hipLaunchKernelGGL(knn_f16_d3_kernel<false>, dim3(nbx * bpad), dim3(kTThreads), lds, st, x, N, y, M, B, k, drop, idx, dist,
+        hipLaunchKernelGGL((knn_f16_d3_kernel<false, C>), dim3(nbx * bpad), dim3(C::T), lds, st, x, N, y, M, B, k, drop, idx, dist,
                            CH, (int)img, raw_ok, feat, layout, med_cap, med_off);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
+}
+// k + drop <= 32: the base geometry; 33 ... 64: the wide one (both waves of a group bound tau by their own ceil(kk / 2)-th group minimum)
+constexpr int kK3WideMinM = 128;  // every wave of a group needs >= 32 finite group minima: two pairs of tiles
+__host__ inline bool knn_f16_d3_shape_ok(int M, int kk) {
+    return M < (1 << 21) && (kk <= 32 ? M >= 64 : (kk <= 64 && M >= kK3WideMinM));
+}
+fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int B, int k, int drop, int32_t *idx,
+                              float *dist, hipStream_t st, float *feat = nullptr, int layout = 0) {
+    if (k + drop <= 32) return launch_knn_f16_d3_geom<K3Base>(x, N, y, M, B, k, drop, idx, dist, st, feat, layout);
+    return launch_knn_f16_d3_geom<K3Wide>(x, N, y, M, B, k, drop, idx, dist, st, feat, layout);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3482,6 +3552,7 @@ int knn_select_list(int M, int kk, int *nw) {
 bool knn_needs_select(int M, int D, int kk) {
     // (D = 3, 44 < kk <= 64: the wave kernel's candidate list holds 64 - kk entries between merges -- 546 us at kk = 64 and C4's
     //  shape against 188 us here, 160 against ~185 at kk = 41)
+    if (D == 3 && !opt(OPT_KNN_D3_WAVE) && knn_f16_d3_shape_ok(M, kk)) return false;  // (round 3: the matrix-core kernel up to kk = 64)
     if (D == 3 && kk > 44 && kk <= 64 && knn_select_waves(M) >= 1) return true;
     return kk > 64 || (D != 3 && !knn_mfma_eligible(M, D, kk) && knn_wave_generic_lds(D) > 64 * 1024);
 }
@@ -3490,7 +3561,7 @@ fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int 
                        int32_t *idx, float *dist, hipStream_t st, void *pre_ws = nullptr) {
     ProfileScope prof("knn", st);
     const int kk = k + drop;
-    const bool grid_y = knn_needs_select(M, D, kk) || (D == 3 ? !(kk <= 32 && M >= 64) : !knn_mfma_eligible(M, D, kk));
+    const bool grid_y = knn_needs_select(M, D, kk) || (D == 3 ? !(!opt(OPT_KNN_D3_WAVE) && knn_f16_d3_shape_ok(M, kk)) : !knn_mfma_eligible(M, D, kk));
     FX3D_REQUIRE(!grid_y || B <= 65535, "fx3d_knn: B=%d exceeds the grid's y range for this shape", B);
     if (knn_needs_select(M, D, kk)) {
         int nw = knn_select_waves(M);
@@ -3503,7 +3574,7 @@ fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int 
         FX3D_LAUNCH_CHECK();
         return FX3D_OK;
     }
-    if (D == 3 && !opt(OPT_KNN_D3_WAVE) && kk <= 32 && M >= 64 && M < (1 << 21))
+    if (D == 3 && !opt(OPT_KNN_D3_WAVE) && knn_f16_d3_shape_ok(M, kk))
         return launch_knn_f16_d3(x, N, y, M, B, k, drop, idx, dist, st);
     if (D == 3) {
         const int qpb = (kWThreads / 64) * kWQ;
@@ -3638,7 +3709,7 @@ fx3d_status fx3d_edgeconv_graph(const float *x, int32_t N, int32_t B, int32_t F,
     FX3D_REQUIRE(idx, "fx3d_edgeconv_graph: idx (k,N,B) is required (it is also the adjoint's side input)");
     FX3D_REQUIRE(x && out && N > 0 && B > 0 && F > 0 && k > 0, "fx3d_edgeconv_graph: bad argument");
     FX3D_REQUIRE(layout == 0 || layout == 1, "fx3d_edgeconv_graph: layout must be 0 (2F,K,N,B) or 1 (K*N,2F,B)");
-    if (F == 3 && k + 1 <= 32 && k + 1 <= N && N >= 64 && N < (1 << 21) && !opt(OPT_KNN_D3_WAVE) &&
+    if (F == 3 && k + 1 <= N && knn_f16_d3_shape_ok(N, k + 1) && !opt(OPT_KNN_D3_WAVE) &&
         !opt(OPT_EDGECONV_UNFUSED)) {
         // first EdgeConv (coordinates): neighbour search and features in ONE kernel
         ProfileScope prof("edgeconv_graph", as_stream(s));

@@ -843,7 +843,8 @@ def test_edge_features_parity(gpu_fx, oracle, F, N, B, K):
 
 
 @pytest.mark.parametrize("N,B,K,kind", [(1024, 3, 20, "uniform"), (200, 2, 10, "uniform"), (333, 2, 7, "lattice"),
-                                         (96, 1, 31, "uniform"), (300, 2, 12, "outlier"), (70, 2, 4, "same")])
+                                         (96, 1, 31, "uniform"), (300, 2, 12, "outlier"), (70, 2, 4, "same"),
+                                         (1024, 2, 40, "uniform"), (333, 2, 33, "lattice"), (200, 1, 63, "uniform"), (160, 1, 38, "same")])
 def test_edgeconv_graph_fused_first_layer(gpu_fx, oracle, N, B, K, kind, fx_option):
     """F = 3: fx3d_edgeconv_graph runs the neighbour search and cat(X, KNN - X) in ONE kernel.  Vector and scalar
     rank stores (K % 4), distance ties re-ranked by the wave (lattice), lists overflowing into the exact fallback
@@ -1128,6 +1129,43 @@ def test_knn_d3_wave_split_cases(gpu_fx, oracle, M, k, drop):
     idx, dist = gpu_fx.knn(x, k, y=y, drop_first=drop)
     oi, od = oracle.knn(x, k, y=y, drop_first=drop)
     assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+
+
+@pytest.mark.parametrize("M,k,drop,kind", [(128, 33, False, "uniform"), (128, 64, False, "uniform"), (129, 63, True, "uniform"),
+                                           (200, 40, True, "lattice"), (1024, 40, True, "uniform"), (1024, 64, False, "uniform"),
+                                           (1024, 47, False, "lattice"), (3072 + 64 * 3 + 5, 50, True, "uniform"), (7777, 33, False, "uniform"),
+                                           (640, 64, False, "equal"), (640, 63, True, "clusters"), (2100, 36, True, "uniform")])
+def test_knn_d3_wide_selection(gpu_fx, oracle, M, k, drop, kind):
+    """32 < k + drop <= 64 at D = 3 on the matrix-core kernel (round 3: the wide geometry -- 64 queries per block, 128 keys per
+    query, tau = the larger of the two waves' ceil(kk/2)-th group minimum): the smallest cloud it takes (two pairs of tiles), odd
+    tile counts, several LDS images, k not a multiple of four, exact ties (lattice: the tie re-rank with up to 128 keys), all
+    points equal and tight clusters (medium path / exact merge with kk = 64: the FULL64 fallback)."""
+    rng = np.random.default_rng(M * 131 + k)
+    x = rng.random((3, 150, 3), dtype=np.float32)
+    y = rng.random((3, M, 3), dtype=np.float32)
+    if kind == "lattice":
+        x[:, :60, :] = np.round(x[:, :60, :] * 4) / 4
+        y[:, : 2 * M // 3, :] = np.round(y[:, : 2 * M // 3, :] * 4) / 4
+    elif kind == "equal":
+        y[:] = np.float32(0.25)
+    elif kind == "clusters":
+        c = rng.random((3, 8, 3), dtype=np.float32)
+        y = c[:, rng.integers(0, 8, M), :] + rng.standard_normal((3, M, 3)).astype(np.float32) * np.float32(1e-4)
+        y = np.ascontiguousarray(y.astype(np.float32))
+    x, y = np.asfortranarray(x), np.asfortranarray(y)
+    idx, dist = gpu_fx.knn(x, k, y=y, drop_first=drop)
+    oi, od = oracle.knn(x, k, y=y, drop_first=drop)
+    assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+
+
+def test_knn_d3_wide_selection_full_shape(gpu_fx, oracle):
+    """C4's shape with k = 40 (the segmentation networks' neighbourhood): sampled queries against the oracle."""
+    rng = np.random.default_rng(77)
+    x = np.asfortranarray(rng.standard_normal((3, 1024, 32)).astype(np.float32))
+    idx, dist = gpu_fx.knn(x, 40, drop_first=True)
+    for b in (0, 17, 31):
+        oi, od = oracle.knn(np.asfortranarray(x[:, :, b:b + 1]), 40, drop_first=True)
+        assert np.array_equal(idx.to_host()[:, :, b:b + 1], oi) and np.array_equal(dist.to_host()[:, :, b:b + 1], od)
 
 
 def test_c_abi_example_runs_on_the_device(gpu_fx, oracle, tmp_path):

@@ -131,7 +131,9 @@ def main():
         elif what == 1:  # kNN D = 3
             N, M = int(rng.integers(1, 1500)), int(rng.integers(2, 6000))
             k = int(rng.integers(1, min(33, M)))
-            drop = bool(rng.integers(0, 2)) and k + 1 <= min(32, M)
+            if rng.random() < 0.4:  # (round 3) 32 < k + drop <= 64: the wide geometry of the matrix-core kernel (M >= 128), below that the wave kernels
+                k = int(rng.integers(1, min(65, M)))
+            drop = bool(rng.integers(0, 2)) and k + 1 <= min(64, M)
             x, y = cloud(rng, 3, N, B, kind), cloud(rng, 3, M, B, kind)
             desc = f"knn3 {kind} N={N} M={M} B={B} k={k} drop={drop}"
             gi, gd = fx.knn(fx.gpu(x), k, y=fx.gpu(y), drop_first=drop)
@@ -150,6 +152,8 @@ def main():
             F = int(rng.choice([3, 3, 16, 64]))
             N = int(rng.integers(70, 700))
             K = int(rng.integers(1, 31))
+            if F == 3 and rng.random() < 0.3:
+                K = int(rng.integers(31, 64))
             x = cloud(rng, F, N, B, kind)
             desc = f"edgeconv {kind} F={F} N={N} B={B} K={K}"
             lay = int(rng.integers(0, 2))

@@ -14,7 +14,7 @@ __global__ __launch_bounds__(512) void probe_empty_kernel(int *p) {
 }
 
 int main(int argc, char **argv) {
-    const int B = 32, N = 1024, D = argc > 1 ? atoi(argv[1]) : 64, K = 20;
+    const int B = 32, N = 1024, D = argc > 1 ? atoi(argv[1]) : 64, K = getenv("K") ? atoi(getenv("K")) : 20;
     std::vector<float> hx((size_t)D * N * B);
     unsigned s = 12345;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return getenv("UNIT") ? ((s >> 8) * (1.0f / 16777216.0f)) : ((s >> 8) * (1.0f / 16777216.0f)) * 4.0f - 2.0f; };
@@ -51,7 +51,7 @@ int main(int argc, char **argv) {
     }
     std::vector<unsigned long long> pr(4096 * 32);
     hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_kprobe), pr.size() * 8);
-    const int nb = D == 3 ? 512 : 256;
+    const int nb = D == 3 ? (K + 1 > 32 ? 1024 : 512) : 256;
     std::vector<double> d(32, 0.0);
     std::vector<int> c(32, 0);
     for (int b = 0; b < nb; ++b) {
