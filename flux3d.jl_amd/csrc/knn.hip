@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(C::T) void knn_f16_d3_kernel(const float *__restric
                                                                const float *__restrict__ y, int M, int B, int k,
                                                                int drop, int32_t *__restrict__ idx,
                                                                float *__restrict__ dist, int CH, int img_bytes,
-                                                               int raw_ok, float *__restrict__ feat, int layout, int med_cap, int med_off) {
+                                                               int raw_ok, float *__restrict__ feat, int layout, int med_cap, int med_off, int xdiv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char k3sm[];
     __shared__ __attribute__((aligned(16))) float red[4 * 4 * C::W];  // per wave: min, max, sum, sampled second moment (padded to 4 dims)
     __shared__ int nfar;                    // candidates of the cloud beyond the robust range ...
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(C::T) void knn_f16_d3_kernel(const float *__restric
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int jq = lane & 31, hh = lane >> 5;
     const int kk = k + drop;
-    const float *xb = x + (size_t)b * N * 3, *yb = y + (size_t)b * M * 3;
+    const float *xb = x + (size_t)(b / xdiv) * N * 3, *yb = y + (size_t)b * M * 3;  // (xdiv > 1: candidate slices as virtual clouds share their queries)
     const int grp = wv % C::G, half = wv / C::G;  // query group; which pairs of tiles this wave takes
     const int q0 = (bxq * C::G + grp) * 32;
     const bool wave_active = q0 < N;
@@ -1649,7 +1649,7 @@ __global__ __launch_bounds__(C::T) void knn_f16_d3_kernel(const float *__restric
 
 template <class C>
 fx3d_status launch_knn_f16_d3_geom(const float *x, int N, const float *y, int M, int B, int k, int drop, int32_t *idx,
-                                   float *dist, hipStream_t st, float *feat, int layout) {
+                                   float *dist, hipStream_t st, float *feat, int layout, int xdiv) {
     int CH = (M + 63) / 64 * 64;
     if (CH > kTChunk) CH = kTChunk;
     size_t img = (size_t)CH * 32;
@@ -1672,10 +1672,10 @@ fx3d_status launch_knn_f16_d3_geom(const float *x, int N, const float *y, int M,
     const int bpad = B >= 8 ? (B + 7) / 8 * 8 : B;
     if (feat)
         hipLaunchKernelGGL((knn_f16_d3_kernel<true, C>), dim3(nbx * bpad), dim3(C::T), lds, st, x, N, y, M, B, k, drop, idx, dist,
-                           CH, (int)img, raw_ok, feat, layout, med_cap, med_off);
+                           CH, (int)img, raw_ok, feat, layout, med_cap, med_off, xdiv);
     else
         hipLaunchKernelGGL((knn_f16_d3_kernel<false, C>), dim3(nbx * bpad), dim3(C::T), lds, st, x, N, y, M, B, k, drop, idx, dist,
-                           CH, (int)img, raw_ok, feat, layout, med_cap, med_off);
+                           CH, (int)img, raw_ok, feat, layout, med_cap, med_off, xdiv);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }
@@ -1685,9 +1685,9 @@ __host__ inline bool knn_f16_d3_shape_ok(int M, int kk) {
     return M < (1 << 21) && (kk <= 32 ? M >= 64 : (kk <= 64 && M >= kK3WideMinM));
 }
 fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int B, int k, int drop, int32_t *idx,
-                              float *dist, hipStream_t st, float *feat = nullptr, int layout = 0) {
-    if (k + drop <= 32) return launch_knn_f16_d3_geom<K3Base>(x, N, y, M, B, k, drop, idx, dist, st, feat, layout);
-    return launch_knn_f16_d3_geom<K3Wide>(x, N, y, M, B, k, drop, idx, dist, st, feat, layout);
+                              float *dist, hipStream_t st, float *feat = nullptr, int layout = 0, int xdiv = 1) {
+    if (k + drop <= 32) return launch_knn_f16_d3_geom<K3Base>(x, N, y, M, B, k, drop, idx, dist, st, feat, layout, xdiv);
+    return launch_knn_f16_d3_geom<K3Wide>(x, N, y, M, B, k, drop, idx, dist, st, feat, layout, xdiv);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2168,7 +2168,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                                                              const float *__restrict__ y, int M, int B, int D,
                                                              int k, int drop, int32_t *__restrict__ idx,
                                                              float *__restrict__ dist, int CH, int img_floats,
-                                                             int keep_norms, int two_norms, int srl, void *pre_ws) {
+                                                             int keep_norms, int two_norms, int srl, void *pre_ws, int xdiv) {
     constexpr int DP = DK * 32;      // padded feature dimension
     constexpr int RS = DP + 4;       // row stride of the query rows staged in the prologue (floats)
     constexpr int PPR = DK * 8;      // 16-byte pieces per candidate row
@@ -2223,7 +2223,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     const int half = consumer ? 0 : 1;
     const int h = lane >> 5, jl = lane & 31;
     const int kk = k + drop;
-    const float *xb = x + (size_t)b * N * D, *yb = y + (size_t)b * M * D;
+    const float *xb = x + (size_t)(b / xdiv) * N * D, *yb = y + (size_t)b * M * D;  // (xdiv > 1: candidate slices as virtual clouds share their queries)
     const int q0 = (bxq * kMWaves + cw) * 32;
     const bool wave_active = q0 < N;
     const int qi = q0 + jl;
@@ -3416,18 +3416,17 @@ __global__ __launch_bounds__(kThreads) void edge_features_bwd_kernel(const float
 }
 
 
+bool knn_pre_shape_ok(int M, int D, int kk);
 // the shapes fx3d_knn_ws serves with the pre-pass: the single-piece fp16 filter (the default of knn_mfma_kernel)
 bool knn_pre_eligible(const float *x, const float *y, int M, int D, int kk) {
-    if (!(D >= 4 && D <= 128 && kk <= 32 && M >= 64 && M <= 4096 && D % 4 == 0)) return false;
-    const int rq = D / 4;
-    if (kPreThreads % rq != 0 || rq > 32) return false;
+    if (!knn_pre_shape_ok(M, D, kk)) return false;
     if (((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x)) & 15) != 0) return false;
     return !(opt(OPT_KNN_F32) || opt(OPT_KNN_F16_SPLIT) || opt(OPT_KNN_NO_MFMA) || opt(OPT_KNN_NO_PREPASS));
 }
 
 template <int DK, bool F16, bool SPLIT>
 fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int B, int D, int k, int drop,
-                               int32_t *idx, float *dist, hipStream_t st, void *pre_ws = nullptr) {
+                               int32_t *idx, float *dist, hipStream_t st, void *pre_ws = nullptr, int xdiv = 1) {
     constexpr int DP = DK * 32, RS = DP + 4, RSI = (F16 && !SPLIT) ? DP / 2 : DP;
     // list lengths + per-query counters + cmax + per-dimension centre + per-stage survivor counts ...
     const bool use_pre = pre_ws != nullptr && F16 && !SPLIT;
@@ -3492,16 +3491,16 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
                                                     "knn_mfma_kernel<pre>");
         if (arc2 != FX3D_OK) return arc2;
         hipLaunchKernelGGL((knn_mfma_kernel<DK, F16, SPLIT, F16 && !SPLIT>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
-                           k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, pre_ws);
+                           k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, pre_ws, xdiv);
     } else
         hipLaunchKernelGGL((knn_mfma_kernel<DK, F16, SPLIT>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
-                           k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, nullptr);
+                           k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, nullptr, xdiv);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }
 
 fx3d_status launch_knn_mfma(const float *x, int N, const float *y, int M, int B, int D, int k, int drop, int32_t *idx,
-                            float *dist, hipStream_t st, void *pre_ws = nullptr) {
+                            float *dist, hipStream_t st, void *pre_ws = nullptr, int xdiv = 1) {
     const int dk = (D + 31) / 32;
     // fp16-split filter: needs 16-byte loads (D % 4 == 0, aligned clouds) and all norms in LDS up front
     const bool f32_only = opt(OPT_KNN_F32) != 0;  // (fx3d_set_option: the tests flip it)
@@ -3509,22 +3508,22 @@ fx3d_status launch_knn_mfma(const float *x, int N, const float *y, int M, int B,
                      ((size_t)M * D * 4) % 16 == 0;
     if (f16 && opt(OPT_KNN_F16_SPLIT)) {  // 2-way split operands: 3 MFMAs per K block, band 2^-18 instead of 2^-10
         switch (dk) {
-            case 1: return launch_knn_mfma_dk<1, true, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
-            case 2: return launch_knn_mfma_dk<2, true, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
-            default: return launch_knn_mfma_dk<4, true, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
+            case 1: return launch_knn_mfma_dk<1, true, true>(x, N, y, M, B, D, k, drop, idx, dist, st, nullptr, xdiv);
+            case 2: return launch_knn_mfma_dk<2, true, true>(x, N, y, M, B, D, k, drop, idx, dist, st, nullptr, xdiv);
+            default: return launch_knn_mfma_dk<4, true, true>(x, N, y, M, B, D, k, drop, idx, dist, st, nullptr, xdiv);
         }
     }
     if (f16) {
         switch (dk) {
-            case 1: return launch_knn_mfma_dk<1, true, false>(x, N, y, M, B, D, k, drop, idx, dist, st, pre_ws);
-            case 2: return launch_knn_mfma_dk<2, true, false>(x, N, y, M, B, D, k, drop, idx, dist, st, pre_ws);
-            default: return launch_knn_mfma_dk<4, true, false>(x, N, y, M, B, D, k, drop, idx, dist, st, pre_ws);
+            case 1: return launch_knn_mfma_dk<1, true, false>(x, N, y, M, B, D, k, drop, idx, dist, st, pre_ws, xdiv);
+            case 2: return launch_knn_mfma_dk<2, true, false>(x, N, y, M, B, D, k, drop, idx, dist, st, pre_ws, xdiv);
+            default: return launch_knn_mfma_dk<4, true, false>(x, N, y, M, B, D, k, drop, idx, dist, st, pre_ws, xdiv);
         }
     }
     switch (dk) {
-        case 1: return launch_knn_mfma_dk<1, false, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
-        case 2: return launch_knn_mfma_dk<2, false, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
-        default: return launch_knn_mfma_dk<4, false, true>(x, N, y, M, B, D, k, drop, idx, dist, st);
+        case 1: return launch_knn_mfma_dk<1, false, true>(x, N, y, M, B, D, k, drop, idx, dist, st, nullptr, xdiv);
+        case 2: return launch_knn_mfma_dk<2, false, true>(x, N, y, M, B, D, k, drop, idx, dist, st, nullptr, xdiv);
+        default: return launch_knn_mfma_dk<4, false, true>(x, N, y, M, B, D, k, drop, idx, dist, st, nullptr, xdiv);
     }
 }
 
@@ -3557,8 +3556,98 @@ bool knn_needs_select(int M, int D, int kk) {
     return kk > 64 || (D != 3 && !knn_mfma_eligible(M, D, kk) && knn_wave_generic_lds(D) > 64 * 1024);
 }
 
+// ---- candidate slices (few clouds with many rows; fx3d_knn_ws) -----------------------------------------------------------------
+// A block of the matrix-core kernels takes 128 (64) queries against ALL candidates of their cloud: B = 1, N = M = 8192 is 64
+// blocks on 256 CUs, each sweeping 8192 candidates (D = 64: 758 us, and beyond the sizes the fp16 filter / the staged exact phase
+// take).  With scratch the search runs on S contiguous slices of every cloud as B x S virtual clouds of M / S rows -- the same
+// kernels, the queries' batch index is b / S --, each slice's kk = k + drop nearest land, in order, in the scratch, and one wave
+// per query merges the S lists on the full (distance, index) keys: the exact answer (a slice's kk nearest contain every member of
+// the cloud's kk nearest that lies in the slice; the global index = slice offset + local index keeps the oracle's tie order).
+__global__ __launch_bounds__(256) void knn_merge_slices_kernel(const int32_t *__restrict__ widx, const float *__restrict__ wdist, int N, int B,
+                                                               int S, int Ms, int kk, int k, int drop, int32_t *__restrict__ idx,
+                                                               float *__restrict__ dist) {
+    __shared__ unsigned long long keys[4][512];  // (distance key, global index): unique, their unsigned order is the oracle's
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long q = (long long)blockIdx.x * 4 + wv;  // query b * N + i
+    if (q >= (long long)B * N) return;                   // (wave-uniform; no block-level synchronisation below)
+    const int b = (int)(q / N), i = (int)(q - (long long)b * N);
+    const int n = S * kk;
+    for (int e = lane; e < n; e += 64) {
+        const int sl = e / kk, r = e - sl * kk;
+        const size_t src = (((size_t)b * S + sl) * N + i) * kk + r;
+        keys[wv][e] = ((unsigned long long)dist_key(wdist[src]) << 32) | (unsigned int)(widx[src] + sl * Ms);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < n; e += 64) {
+        const unsigned long long me = keys[wv][e];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += keys[wv][j] < me ? 1 : 0;
+        if (rank >= drop && rank < kk) {
+            const int sl = e / kk, r = e - sl * kk;
+            idx[(size_t)q * k + rank - drop] = (int)(unsigned int)me;
+            if (dist) dist[(size_t)q * k + rank - drop] = wdist[(((size_t)b * S + sl) * N + i) * kk + r];  // (the slice's own bits)
+        }
+    }
+}
+
+bool knn_mfma_eligible(int M, int D, int kk);
+// number of slices for a shape (1 = none): a function of the shape alone, so that fx3d_knn_workspace_bytes and the call agree
+int knn_slices(int N, int M, int B, int D, int kk) {
+    const int force = opt(OPT_KNN_SLICES);  // 0 = automatic, 1 = never, 2 / 4 / 8 = forced (when the shape allows it)
+    if (force == 1) return 1;
+    const bool d3 = D == 3;
+    if (d3 ? (opt(OPT_KNN_D3_WAVE) || !knn_f16_d3_shape_ok(M, kk)) : (opt(OPT_KNN_NO_MFMA) || !knn_mfma_eligible(M, D, kk))) return 1;
+    const int qpb = d3 && kk > 32 ? 64 : 128;
+    const long long blocks = (long long)B * ((N + qpb - 1) / qpb);
+    const int ncu = device_cus();
+    auto fits = [&](int S) {
+        if (M % S) return false;
+        const int Ms = M / S;
+        if (Ms < (d3 ? 1024 : 512) || Ms < 4 * kk || S * kk > 512) return false;
+        if (!d3 && ((size_t)Ms * D * 4) % 16 != 0) return false;  // the slices keep the clouds' 16-byte alignment
+        return (long long)B * S <= 65535;
+    };
+    if (force > 1) return (force == 2 || force == 4 || force == 8) && fits(force) ? force : 1;
+    // automatic (tools/knn_slices_time.py): slice until the grid fills the chip; in feature space also down to the size the fp16
+    // filter takes (4096 rows)
+    int best = 1;
+    for (int S = 2; S <= 8; S *= 2) {
+        if (!fits(S)) continue;
+        if (d3) {  // (measured, tools/knn_slices_time.py: only long sweeps on an under-filled chip pay for the second exact phase)
+            if (S == 2 && blocks < ncu && M >= 8192) best = S;
+            continue;
+        }
+        const bool underfilled = blocks * (S / 2) < ncu;
+        const bool too_long = M / (S / 2) > 4096;  // beyond the fp16 filter: the Float32 GEMM + the L2 gather cost 2.7x even on a full grid
+        if (underfilled || too_long) best = S;
+    }
+    return best;
+}
+size_t knn_pre_bytes(int M, int B, int D) {
+    const int DP = (D + 31) / 32 * 32 == 96 ? 128 : (D + 31) / 32 * 32;
+    return KnnPre::make(nullptr, M, DP).stride * (size_t)B;
+}
+bool knn_pre_shape_ok(int M, int D, int kk) {
+    return D >= 4 && D <= 128 && kk <= 32 && M >= 64 && M <= 4096 && D % 4 == 0 && kPreThreads % (D / 4) == 0 && D / 4 <= 32;
+}
+// scratch of a call: [pre-pass slabs of the (virtual) clouds][slice results: indices, distances], 256-byte aligned parts
+struct KnnScratch {
+    int S;
+    size_t pre_bytes, list_bytes, total;
+    static KnnScratch plan(int N, int M, int B, int D, int kk) {
+        KnnScratch p{};
+        p.S = knn_slices(N, M, B, D, kk);
+        const int Ms = M / p.S;
+        p.pre_bytes = knn_pre_shape_ok(Ms, D, kk) ? (knn_pre_bytes(Ms, B * p.S, D) + 255) & ~(size_t)255 : 0;
+        p.list_bytes = p.S > 1 ? (((size_t)kk * N * B * p.S * 4 + 255) & ~(size_t)255) : 0;
+        p.total = p.pre_bytes + 2 * p.list_bytes;
+        return p;
+    }
+};
+
 fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int D, int k, int drop,
-                       int32_t *idx, float *dist, hipStream_t st, void *pre_ws = nullptr) {
+                       int32_t *idx, float *dist, hipStream_t st, void *pre_ws = nullptr, int xdiv = 1) {
     ProfileScope prof("knn", st);
     const int kk = k + drop;
     const bool grid_y = knn_needs_select(M, D, kk) || (D == 3 ? !(!opt(OPT_KNN_D3_WAVE) && knn_f16_d3_shape_ok(M, kk)) : !knn_mfma_eligible(M, D, kk));
@@ -3575,13 +3664,15 @@ fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int 
         return FX3D_OK;
     }
     if (D == 3 && !opt(OPT_KNN_D3_WAVE) && knn_f16_d3_shape_ok(M, kk))
-        return launch_knn_f16_d3(x, N, y, M, B, k, drop, idx, dist, st);
+        return launch_knn_f16_d3(x, N, y, M, B, k, drop, idx, dist, st, nullptr, 0, xdiv);
+    FX3D_REQUIRE(xdiv == 1 || (D != 3 && !opt(OPT_KNN_NO_MFMA) && knn_mfma_eligible(M, D, kk)),
+                 "fx3d_knn: internal: candidate slices on a kernel without them");
     if (D == 3) {
         const int qpb = (kWThreads / 64) * kWQ;
         hipLaunchKernelGGL(knn_wave_d3_kernel, dim3((N + qpb - 1) / qpb, B), dim3(kWThreads), 0, st, x, N, y, M, B, k,
                            drop, idx, dist);
     } else if (!opt(OPT_KNN_NO_MFMA) && knn_mfma_eligible(M, D, kk)) {
-        return launch_knn_mfma(x, N, y, M, B, D, k, drop, idx, dist, st, pre_ws);
+        return launch_knn_mfma(x, N, y, M, B, D, k, drop, idx, dist, st, pre_ws, xdiv);
     } else {
         const int qpb = (kWThreads / 64) * kGQ;
         hipLaunchKernelGGL(knn_wave_generic_kernel, dim3((N + qpb - 1) / qpb, B), dim3(kWThreads), knn_wave_generic_lds(D),
@@ -3611,18 +3702,12 @@ fx3d_status fx3d_knn(const float *x, int32_t N, const float *y, int32_t M, int32
     return launch_knn(x, N, y, M, B, D, k, drop, idx, dist, as_stream(s));
 }
 
-size_t knn_pre_bytes(int M, int B, int D) {
-    const int DP = (D + 31) / 32 * 32 == 96 ? 128 : (D + 31) / 32 * 32;
-    return KnnPre::make(nullptr, M, DP).stride * (size_t)B;
-}
-
 fx3d_status fx3d_knn_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_t D, int32_t k, int32_t drop_first, size_t *bytes) {
     FX3D_REQUIRE(bytes, "fx3d_knn_workspace_bytes: null output");
     FX3D_REQUIRE(N > 0 && M > 0 && B > 0 && D > 0 && k > 0, "fx3d_knn_workspace_bytes: bad sizes");
     const int kk = k + (drop_first ? 1 : 0);
     // (alignment of x / y is checked at the call: an ineligible call simply does not use the workspace)
-    const bool shape_ok = D >= 4 && D <= 128 && kk <= 32 && M >= 64 && M <= 4096 && D % 4 == 0 && kPreThreads % (D / 4) == 0 && D / 4 <= 32;
-    *bytes = shape_ok ? knn_pre_bytes(M, B, D) : 0;
+    *bytes = kk <= M ? KnnScratch::plan(N, M, B, D, kk).total : 0;
     return FX3D_OK;
 }
 
@@ -3633,8 +3718,24 @@ fx3d_status fx3d_knn_ws(const float *x, int32_t N, const float *y, int32_t M, in
     const int drop = drop_first ? 1 : 0;
     const int kk = k + drop;
     FX3D_REQUIRE(kk <= M, "fx3d_knn_ws: k+drop_first=%d exceeds the number of candidates M=%d", kk, M);
-    const bool pre = ws && knn_pre_eligible(x, y, M, D, kk) && ws_bytes >= knn_pre_bytes(M, B, D) &&
-                     (reinterpret_cast<uintptr_t>(ws) & 255) == 0;
+    const bool ws_ok = ws && (reinterpret_cast<uintptr_t>(ws) & 255) == 0;
+    const KnnScratch p = KnnScratch::plan(N, M, B, D, kk);
+    if (p.S > 1 && ws_ok && ws_bytes >= p.total) {
+        // candidate slices: the search on B x S virtual clouds of M / S rows (no drop: the merge drops), then the merge
+        const int Ms = M / p.S;
+        unsigned char *w8 = static_cast<unsigned char *>(ws);
+        void *pre_ws = p.pre_bytes && knn_pre_eligible(x, y, Ms, D, kk) ? ws : nullptr;
+        int32_t *widx = reinterpret_cast<int32_t *>(w8 + p.pre_bytes);
+        float *wdist = reinterpret_cast<float *>(w8 + p.pre_bytes + p.list_bytes);
+        const fx3d_status rc = launch_knn(x, N, y, Ms, B * p.S, D, kk, 0, widx, wdist, as_stream(s), pre_ws, p.S);
+        if (rc != FX3D_OK) return rc;
+        const long long nq = (long long)B * N;
+        hipLaunchKernelGGL(knn_merge_slices_kernel, dim3((unsigned int)((nq + 3) / 4)), dim3(256), 0, as_stream(s), widx, wdist, N, B, p.S, Ms,
+                           kk, k, drop, idx, dist);
+        FX3D_LAUNCH_CHECK();
+        return FX3D_OK;
+    }
+    const bool pre = ws_ok && knn_pre_eligible(x, y, M, D, kk) && ws_bytes >= knn_pre_bytes(M, B, D);
     if (!pre) return fx3d_knn(x, N, y, M, B, D, k, drop_first, idx, dist, s);
     return launch_knn(x, N, y, M, B, D, k, drop, idx, dist, as_stream(s), ws);
 }

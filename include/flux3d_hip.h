@@ -59,7 +59,7 @@ FX3D_API size_t fx3d_last_error(char *buf, size_t n); /* thread-local message; r
 /* ---- variant switches --------------------------------------------------------------------------------------------
  * The kernels' alternative code paths (A/B measurements, tests) are chosen by named integer options, process-wide and
  * atomic: nn1_variant (3 | 0), nn1_tpb, nn1_nosplit, bwd_global_atomics, knn_f32, knn_f16_split, knn_no_mfma,
- * knn_no_prepass, knn_gather, knn_d3_wave, edge_scalar_stores, edgeconv_unfused, cdf_multiblock_from
+ * knn_no_prepass, knn_gather, knn_d3_wave, knn_slices, edge_scalar_stores, edgeconv_unfused, cdf_multiblock_from
  * (fx3d_option_count / fx3d_option_name enumerate them).  The environment variables FX3D_<NAME> only seed the defaults,
  * once, at the first use of the library; no entry point reads the environment on its launch path.  A host that runs two
  * configurations in one process sets the option before the calls that need it. */
@@ -184,7 +184,8 @@ FX3D_API fx3d_status fx3d_chamfer_sampled_bwd(const float *x, int32_t N, const f
  * element: idx:(k,N,B) int32 0-based sorted by (distance, index); dist:(k,N,B) squared distances
  * (optional).  y may equal x (self graph; drop_first=1 drops the rank-0 hit as the reference
  * does).  Any k+drop_first <= M and any D: the matrix-core kernels take k+drop_first <= 32 with M >= 64 (D = 3 and
- * 4 <= D <= 128), wave-per-query kernels k+drop_first <= 64 (D up to ~110), a general selection kernel everything else
+ * 4 <= D <= 128) and, at D = 3, k+drop_first <= 64 with M >= 128; wave-per-query kernels k+drop_first <= 64 (D up to ~110),
+ * a general selection kernel everything else
  * (k+drop_first up to M, any D) for M <= 36864 candidates; beyond that FX3D_ERR_UNSUPPORTED.
  * Order = Julia's isless on the Float32 squared distance, then the lower index: NaN distances (non-finite coordinates)
  * sort after +Inf, so every returned index is valid; fx3d_nn1 / the chamfer entry points use the same order. */
@@ -194,9 +195,13 @@ FX3D_API fx3d_status fx3d_knn(const float *x, int32_t N, const float *y, int32_t
 
 /* The same search with caller-provided scratch.  In feature space (4 <= D <= 128 with D/4 a divisor of 256, 64 <= M <= 4096,
  * k+drop_first <= 32, 16-byte aligned clouds) the statistics and the fp16 image of every candidate cloud are then built once per
- * cloud by two small pre-pass launches instead of by every block of the search kernel (C4': 78 -> see DESIGN.md 3.2).  Results
- * are identical to fx3d_knn.  fx3d_knn_workspace_bytes returns 0 for shapes that have no use for scratch; a NULL, short or
- * misaligned (256 bytes) workspace makes fx3d_knn_ws behave exactly like fx3d_knn. */
+ * cloud by two small pre-pass launches instead of by every block of the search kernel (C4': 78 -> see DESIGN.md 3.2).
+ * Few clouds with many rows (the grid of the matrix-core kernels would not fill the chip, or M > 4096 in feature space): the
+ * search runs on 2 / 4 / 8 contiguous slices of every candidate cloud as so many virtual clouds and one wave per query merges the
+ * slices' lists from the scratch (B = 1, N = M = 8192, D = 64: 758 -> 109 us; option "knn_slices": 0 automatic, 1 never, 2 / 4 / 8
+ * forced).  Results are identical to fx3d_knn.  fx3d_knn_workspace_bytes returns 0 for shapes that have no use for scratch (it is a
+ * function of the shape, the device's CU count and the options alone); a NULL, short or misaligned (256 bytes) workspace makes
+ * fx3d_knn_ws behave exactly like fx3d_knn. */
 FX3D_API fx3d_status fx3d_knn_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_t D, int32_t k, int32_t drop_first,
                                               size_t *bytes);
 FX3D_API fx3d_status fx3d_knn_ws(const float *x, int32_t N, const float *y, int32_t M, int32_t B, int32_t D, int32_t k,

@@ -542,13 +542,14 @@ def test_knn_feature_space_robust_centre(gpu_fx, oracle, fx_option, D, M, kind):
 
 
 def test_knn_ws_entry_point_contract(gpu_fx, oracle):
-    """fx3d_knn_ws: 0 bytes for shapes without a pre-pass (D = 3, D % 4 != 0, k + drop > 32, M > 4096); a NULL, short or
-    misaligned workspace behaves exactly like fx3d_knn; x != y (only the candidate cloud has an image); non-finite clouds."""
+    """fx3d_knn_ws: 0 bytes for shapes with neither a pre-pass (D = 3, D % 4 != 0, k + drop > 32, M > 4096) nor candidate slices
+    (an odd M, slices below 512 rows); a NULL, short or misaligned workspace behaves exactly like fx3d_knn; x != y (only the
+    candidate cloud has an image); non-finite clouds."""
     import ctypes as C
     fx = gpu_fx
     from flux3d_jl_amd import _lib
     nb = C.c_size_t(1)
-    for (N, M, B, D, k, drop) in ((100, 1024, 2, 3, 20, 1), (100, 1024, 2, 5, 20, 0), (100, 1024, 2, 64, 40, 0), (100, 5000, 1, 64, 20, 0),
+    for (N, M, B, D, k, drop) in ((100, 1024, 2, 3, 20, 1), (100, 1000, 2, 5, 20, 0), (100, 1024, 2, 64, 40, 0), (100, 5001, 1, 64, 20, 0),
                                   (100, 32, 1, 64, 5, 0)):
         _lib.call("fx3d_knn_workspace_bytes", N, M, B, D, k, drop, C.byref(nb))
         assert nb.value == 0

@@ -1168,6 +1168,49 @@ def test_knn_d3_wide_selection_full_shape(gpu_fx, oracle):
         assert np.array_equal(idx.to_host()[:, :, b:b + 1], oi) and np.array_equal(dist.to_host()[:, :, b:b + 1], od)
 
 
+@pytest.mark.parametrize("D,N,M,B,k,drop,slices", [(64, 300, 2048, 1, 20, True, 0), (64, 257, 4096, 2, 7, False, 2), (16, 200, 4096, 1, 31, True, 8),
+                                                    (3, 500, 8192, 1, 20, True, 0), (3, 300, 4096, 2, 40, False, 2), (3, 129, 8192, 1, 63, True, 4),
+                                                    (32, 130, 2048, 3, 12, False, 4), (64, 100, 1536, 1, 20, True, 2), (20, 150, 2048, 1, 9, True, 0)])
+def test_knn_candidate_slices(gpu_fx, oracle, fx_option, D, N, M, B, k, drop, slices):
+    """fx3d_knn_ws on few clouds with many rows: the search runs on S slices of every cloud as B x S virtual clouds, one wave per
+    query merges the slices' lists (round 3).  Forced and automatic slice counts, both matrix-core kernels (and the wide D = 3
+    geometry), cross sets with exact ties across slice borders (lattice candidates: equal distances in different slices must come
+    out in index order), drop_first handled by the merge: bit-identical to the oracle and to the unsliced call."""
+    rng = np.random.default_rng(D * 1000 + M + k)
+    x = rng.standard_normal((D, N, B)).astype(np.float32)
+    y = rng.standard_normal((D, M, B)).astype(np.float32)
+    y[:, ::3, :] = np.round(y[:, ::3, :] * 2) / 2          # ties across the whole cloud
+    x[:, : N // 2, :] = y[:, rng.integers(0, M, N // 2), :]  # queries that are candidates (distance 0, duplicates of lattice points)
+    x, y = np.asfortranarray(x), np.asfortranarray(y)
+    fx_option("knn_slices", str(slices))
+    idx, dist = gpu_fx.knn(x, k, y=y, drop_first=drop)
+    oi, od = oracle.knn(x, k, y=y, drop_first=drop)
+    assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+    fx_option("knn_slices", "1")
+    idx1, dist1 = gpu_fx.knn(x, k, y=y, drop_first=drop)
+    assert np.array_equal(idx1.to_host(), oi) and np.array_equal(dist1.to_host(), od)
+
+
+def test_knn_candidate_slices_plan_is_a_function_of_the_shape(gpu_fx):
+    """fx3d_knn_workspace_bytes and the call agree: scratch for the slices is asked for exactly when the call would use it; a short
+    workspace falls back to the unsliced search (same result)."""
+    import ctypes as C
+    from flux3d_jl_amd import _lib
+    lib = _lib.load()
+    nb = C.c_size_t(0)
+    lib.fx3d_knn_workspace_bytes(8192, 8192, 1, 64, 20, 1, C.byref(nb))
+    assert nb.value > 2 * 21 * 8192 * 4 * 2       # slice lists (indices + distances, S >= 2) + pre-pass slabs
+    lib.fx3d_knn_workspace_bytes(1024, 1024, 32, 3, 20, 1, C.byref(nb))
+    assert nb.value == 0                           # C4: nothing to slice, no pre-pass at D = 3
+    rng = np.random.default_rng(3)
+    x = gpu_fx.gpu(np.asfortranarray(rng.standard_normal((64, 2048, 1)).astype(np.float32)))
+    ref = gpu_fx.knn(x, 20, drop_first=True, return_dist=False).to_host()
+    idx = gpu_fx.DeviceArray.empty((20, 2048, 1), np.int32)
+    ws = gpu_fx.DeviceArray.empty((4096,), np.uint8)  # far too short
+    _lib.call("fx3d_knn_ws", x.ptr, 2048, x.ptr, 2048, 1, 64, 20, 1, idx.ptr, None, ws.ptr, ws.nbytes, None)
+    assert np.array_equal(idx.to_host(), ref)
+
+
 def test_c_abi_example_runs_on_the_device(gpu_fx, oracle, tmp_path):
     """examples/c_abi_example.c (plain C against the shared library, no Python in the call path) prints the oracle's
     loss for its LCG clouds."""
