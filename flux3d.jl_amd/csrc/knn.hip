@@ -436,12 +436,14 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_generic_kernel(const float
 constexpr int kSelMaxLds = 144 * 1024;
 __global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict__ x, int N, const float *__restrict__ y,
                                                          int M, int B, int D, int k, int drop,
-                                                         int32_t *__restrict__ idx, float *__restrict__ dist, int Mpad, int lcap) {
+                                                         int32_t *__restrict__ idx, float *__restrict__ dist, int Mpad, int lcap,
+                                                         const unsigned char *__restrict__ only) {
     extern __shared__ __attribute__((aligned(16))) unsigned int selkeys[];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int qi = blockIdx.x * nw + wv;
     if (qi >= N) return;  // wave-uniform; no block-level sync below
+    if (only && !only[(size_t)b * N + qi]) return;  // (the verified slice merge flags the few queries it could not answer)
     unsigned int *keys = selkeys + (size_t)wv * (Mpad + 2 * lcap);
     const uint4 *keys4 = reinterpret_cast<const uint4 *>(keys);
     const int kk = k + drop;
@@ -3564,17 +3566,18 @@ bool knn_needs_select(int M, int D, int kk) {
 // per query merges the S lists on the full (distance, index) keys: the exact answer (a slice's kk nearest contain every member of
 // the cloud's kk nearest that lies in the slice; the global index = slice offset + local index keeps the oracle's tie order).
 __global__ __launch_bounds__(256) void knn_merge_slices_kernel(const int32_t *__restrict__ widx, const float *__restrict__ wdist, int N, int B,
-                                                               int S, int Ms, int kk, int k, int drop, int32_t *__restrict__ idx,
-                                                               float *__restrict__ dist) {
+                                                               int S, int Ms, int kl, int kk, int k, int drop, int32_t *__restrict__ idx,
+                                                               float *__restrict__ dist, unsigned char *__restrict__ flags) {
     __shared__ unsigned long long keys[4][512];  // (distance key, global index): unique, their unsigned order is the oracle's
+    __shared__ unsigned long long tkey[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long q = (long long)blockIdx.x * 4 + wv;  // query b * N + i
     if (q >= (long long)B * N) return;                   // (wave-uniform; no block-level synchronisation below)
     const int b = (int)(q / N), i = (int)(q - (long long)b * N);
-    const int n = S * kk;
+    const int n = S * kl;  // kl entries per slice: kk, or 32 < kk with `flags` (verified below)
     for (int e = lane; e < n; e += 64) {
-        const int sl = e / kk, r = e - sl * kk;
-        const size_t src = (((size_t)b * S + sl) * N + i) * kk + r;
+        const int sl = e / kl, r = e - sl * kl;
+        const size_t src = (((size_t)b * S + sl) * N + i) * kl + r;
         keys[wv][e] = ((unsigned long long)dist_key(wdist[src]) << 32) | (unsigned int)(widx[src] + sl * Ms);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -3584,10 +3587,21 @@ __global__ __launch_bounds__(256) void knn_merge_slices_kernel(const int32_t *__
         int rank = 0;
         for (int j = 0; j < n; ++j) rank += keys[wv][j] < me ? 1 : 0;
         if (rank >= drop && rank < kk) {
-            const int sl = e / kk, r = e - sl * kk;
+            const int sl = e / kl, r = e - sl * kl;
             idx[(size_t)q * k + rank - drop] = (int)(unsigned int)me;
-            if (dist) dist[(size_t)q * k + rank - drop] = wdist[(((size_t)b * S + sl) * N + i) * kk + r];  // (the slice's own bits)
+            if (dist) dist[(size_t)q * k + rank - drop] = wdist[(((size_t)b * S + sl) * N + i) * kl + r];  // (the slice's own bits)
         }
+        if (flags && rank == kk - 1) tkey[wv] = me;  // (exactly one entry: the keys are unique and n >= kk)
+    }
+    if (flags) {
+        // lists shorter than kk: the answer stands iff no slice can hide a candidate below the kk-th merged key T -- a slice's
+        // unlisted candidates lie above its last listed key, so a slice whose last key is >= T hides nothing
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long T = tkey[wv];
+        const bool hides = lane < S && keys[wv][lane * kl + kl - 1] < T;
+        const unsigned long long any = __ballot(hides);
+        if (lane == 0) flags[q] = any ? 1 : 0;
     }
 }
 
@@ -3631,17 +3645,36 @@ size_t knn_pre_bytes(int M, int B, int D) {
 bool knn_pre_shape_ok(int M, int D, int kk) {
     return D >= 4 && D <= 128 && kk <= 32 && M >= 64 && M <= 4096 && D % 4 == 0 && kPreThreads % (D / 4) == 0 && D / 4 <= 32;
 }
-// scratch of a call: [pre-pass slabs of the (virtual) clouds][slice results: indices, distances], 256-byte aligned parts
+// 32 < k + drop <= 64 in feature space (the matrix-core kernel selects up to 32): S slices, each slice's 32 nearest, a VERIFIED
+// merge -- the kk nearest of the cloud spread over the slices (~kk / S each), so 32 per slice almost always hold them all; the merge
+// checks it per query (knn_merge_slices_kernel) and the flagged queries are answered again by the general selection kernel.
+int knn_wide_slices(int M, int D, int kk) {
+    if (D < 4 || D > 128 || kk <= 32 || kk > 64 || opt(OPT_KNN_NO_MFMA) || opt(OPT_KNN_SLICES) == 1) return 0;
+    const int force = opt(OPT_KNN_SLICES);
+    const int S = force == 2 || force == 4 || force == 8 ? force : (kk <= 45 ? 2 : 4);  // (measured at C4's shape, D = 64, us: kk = 41 / 45 / 49 / 53
+                                                                                         //  S = 2: 180 / 188 / 219 / 342 -- the flagged queries --, S = 4: 228 flat)
+    if (M % S || M / S < 64 || ((size_t)(M / S) * D * 4) % 16 != 0 || knn_select_waves(M) < 1) return 0;
+    return S;
+}
+// scratch of a call: [pre-pass slabs of the (virtual) clouds][slice results: indices, distances][flags], 256-byte aligned parts
 struct KnnScratch {
-    int S;
-    size_t pre_bytes, list_bytes, total;
+    int S;        // candidate slices per cloud (1 = none)
+    int kl;       // entries per slice list: k + drop, or 32 with `verify`
+    bool verify;  // the slices' lists are shorter than k + drop: verified merge + fallback for the flagged queries
+    size_t pre_bytes, list_bytes, flag_bytes, total;
     static KnnScratch plan(int N, int M, int B, int D, int kk) {
         KnnScratch p{};
         p.S = knn_slices(N, M, B, D, kk);
+        p.kl = kk;
+        if (p.S == 1) {
+            const int W = knn_wide_slices(M, D, kk);
+            if (W > 1 && (long long)B * W <= 65535) { p.S = W; p.kl = 32; p.verify = true; }
+        }
         const int Ms = M / p.S;
-        p.pre_bytes = knn_pre_shape_ok(Ms, D, kk) ? (knn_pre_bytes(Ms, B * p.S, D) + 255) & ~(size_t)255 : 0;
-        p.list_bytes = p.S > 1 ? (((size_t)kk * N * B * p.S * 4 + 255) & ~(size_t)255) : 0;
-        p.total = p.pre_bytes + 2 * p.list_bytes;
+        p.pre_bytes = knn_pre_shape_ok(Ms, D, p.kl) ? (knn_pre_bytes(Ms, B * p.S, D) + 255) & ~(size_t)255 : 0;
+        p.list_bytes = p.S > 1 ? (((size_t)p.kl * N * B * p.S * 4 + 255) & ~(size_t)255) : 0;
+        p.flag_bytes = p.verify ? (((size_t)N * B + 255) & ~(size_t)255) : 0;
+        p.total = p.pre_bytes + 2 * p.list_bytes + p.flag_bytes;
         return p;
     }
 };
@@ -3659,7 +3692,7 @@ fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int 
         const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_select_kernel), kSelMaxLds, "knn_select_kernel");
         if (arc != FX3D_OK) return arc;
         hipLaunchKernelGGL(knn_select_kernel, dim3((N + nw - 1) / nw, B), dim3(64 * nw), (size_t)nw * (Mpad + 2 * lcap) * 4, st, x, N, y, M,
-                           B, D, k, drop, idx, dist, Mpad, lcap);
+                           B, D, k, drop, idx, dist, Mpad, lcap, nullptr);
         FX3D_LAUNCH_CHECK();
         return FX3D_OK;
     }
@@ -3724,15 +3757,27 @@ fx3d_status fx3d_knn_ws(const float *x, int32_t N, const float *y, int32_t M, in
         // candidate slices: the search on B x S virtual clouds of M / S rows (no drop: the merge drops), then the merge
         const int Ms = M / p.S;
         unsigned char *w8 = static_cast<unsigned char *>(ws);
-        void *pre_ws = p.pre_bytes && knn_pre_eligible(x, y, Ms, D, kk) ? ws : nullptr;
+        void *pre_ws = p.pre_bytes && knn_pre_eligible(x, y, Ms, D, p.kl) ? ws : nullptr;
         int32_t *widx = reinterpret_cast<int32_t *>(w8 + p.pre_bytes);
         float *wdist = reinterpret_cast<float *>(w8 + p.pre_bytes + p.list_bytes);
-        const fx3d_status rc = launch_knn(x, N, y, Ms, B * p.S, D, kk, 0, widx, wdist, as_stream(s), pre_ws, p.S);
+        unsigned char *flags = p.verify ? w8 + p.pre_bytes + 2 * p.list_bytes : nullptr;
+        const fx3d_status rc = launch_knn(x, N, y, Ms, B * p.S, D, p.kl, 0, widx, wdist, as_stream(s), pre_ws, p.S);
         if (rc != FX3D_OK) return rc;
         const long long nq = (long long)B * N;
         hipLaunchKernelGGL(knn_merge_slices_kernel, dim3((unsigned int)((nq + 3) / 4)), dim3(256), 0, as_stream(s), widx, wdist, N, B, p.S, Ms,
-                           kk, k, drop, idx, dist);
+                           p.kl, kk, k, drop, idx, dist, flags);
         FX3D_LAUNCH_CHECK();
+        if (p.verify) {  // the flagged queries (a slice held more than 32 of their kk nearest) again, on all M candidates
+            int nw = knn_select_waves(M);
+            const int Mpad = (M + 255) / 256 * 256;
+            const int lcap = knn_select_list(M, kk, &nw);
+            const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_select_kernel), kSelMaxLds, "knn_select_kernel");
+            if (arc != FX3D_OK) return arc;
+            FX3D_REQUIRE(B <= 65535, "fx3d_knn_ws: B=%d exceeds the grid's y range for this shape", B);
+            hipLaunchKernelGGL(knn_select_kernel, dim3((N + nw - 1) / nw, B), dim3(64 * nw), (size_t)nw * (Mpad + 2 * lcap) * 4, as_stream(s), x, N,
+                               y, M, B, D, k, drop, idx, dist, Mpad, lcap, flags);
+            FX3D_LAUNCH_CHECK();
+        }
         return FX3D_OK;
     }
     const bool pre = ws_ok && knn_pre_eligible(x, y, M, D, kk) && ws_bytes >= knn_pre_bytes(M, B, D);

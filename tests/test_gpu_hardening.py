@@ -549,7 +549,7 @@ def test_knn_ws_entry_point_contract(gpu_fx, oracle):
     fx = gpu_fx
     from flux3d_jl_amd import _lib
     nb = C.c_size_t(1)
-    for (N, M, B, D, k, drop) in ((100, 1024, 2, 3, 20, 1), (100, 1000, 2, 5, 20, 0), (100, 1024, 2, 64, 40, 0), (100, 5001, 1, 64, 20, 0),
+    for (N, M, B, D, k, drop) in ((100, 1024, 2, 3, 20, 1), (100, 1000, 2, 5, 20, 0), (100, 1023, 2, 64, 40, 0), (100, 5001, 1, 64, 20, 0),
                                   (100, 32, 1, 64, 5, 0)):
         _lib.call("fx3d_knn_workspace_bytes", N, M, B, D, k, drop, C.byref(nb))
         assert nb.value == 0

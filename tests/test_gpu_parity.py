@@ -1211,6 +1211,32 @@ def test_knn_candidate_slices_plan_is_a_function_of_the_shape(gpu_fx):
     assert np.array_equal(idx.to_host(), ref)
 
 
+@pytest.mark.parametrize("D,N,M,B,k,drop,kind", [(64, 300, 1024, 2, 40, True, "normal"), (64, 257, 512, 1, 63, True, "normal"), (16, 200, 2048, 2, 33, False, "normal"),
+                                                  (128, 130, 256, 1, 64, False, "normal"), (64, 200, 1024, 1, 40, False, "sorted"), (32, 150, 1024, 2, 50, True, "sorted"),
+                                                  (8, 300, 768, 1, 36, True, "lattice"), (64, 100, 1024, 1, 48, True, "dupes"), (20, 90, 640, 1, 41, False, "normal")])
+def test_knn_feature_space_wide_selection(gpu_fx, oracle, D, N, M, B, k, drop, kind):
+    """32 < k + drop <= 64 in feature space (round 3): 2 / 4 candidate slices on the matrix-core kernel (32 nearest per slice), the
+    verified merge, and the general selection kernel for the flagged queries.  "sorted": the candidates are ordered along the first
+    coordinate, so a query's neighbours sit in ONE slice and the verification must flag it (every answer then comes from the
+    fallback); lattice / duplicated candidates: ties inside and across slices in index order."""
+    rng = np.random.default_rng(D * 77 + M + k)
+    x = rng.standard_normal((D, N, B)).astype(np.float32)
+    y = rng.standard_normal((D, M, B)).astype(np.float32)
+    if kind == "sorted":
+        for b in range(B):
+            y[:, :, b] = y[:, np.argsort(y[0, :, b]), b]
+            y[1:, :, b] *= np.float32(0.05)        # the first coordinate decides: neighbours are index neighbours
+        x[1:] *= np.float32(0.05)
+    elif kind == "lattice":
+        x, y = np.round(x), np.round(y)
+    elif kind == "dupes":
+        y[:, M // 2:, :] = y[:, : M // 2, :]       # every candidate twice, the copies in different slices
+    x, y = np.asfortranarray(x.astype(np.float32)), np.asfortranarray(y.astype(np.float32))
+    idx, dist = gpu_fx.knn(x, k, y=y, drop_first=drop)
+    oi, od = oracle.knn(x, k, y=y, drop_first=drop)
+    assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+
+
 def test_c_abi_example_runs_on_the_device(gpu_fx, oracle, tmp_path):
     """examples/c_abi_example.c (plain C against the shared library, no Python in the call path) prints the oracle's
     loss for its LCG clouds."""

@@ -143,6 +143,9 @@ def main():
             D = int(rng.choice([4, 8, 16, 32, 64, 64, 96, 128, 20, 7]))
             N, M = int(rng.integers(1, 400)), int(rng.integers(64, 1500))
             k = int(rng.integers(1, 32))
+            if rng.random() < 0.3:  # (round 3) 32 < k <= 64: candidate slices + verified merge (even M), the wave kernels otherwise
+                k = int(rng.integers(32, min(65, M)))
+                M += int(rng.integers(0, 2)) * (M & 1)
             x, y = cloud(rng, D, N, B, kind), cloud(rng, D, M, B, kind)
             desc = f"knnF {kind} D={D} N={N} M={M} B={B} k={k}"
             gi, gd = fx.knn(fx.gpu(x), k, y=fx.gpu(y))
