@@ -3565,9 +3565,43 @@ bool knn_needs_select(int M, int D, int kk) {
 // kernels, the queries' batch index is b / S --, each slice's kk = k + drop nearest land, in order, in the scratch, and one wave
 // per query merges the S lists on the full (distance, index) keys: the exact answer (a slice's kk nearest contain every member of
 // the cloud's kk nearest that lies in the slice; the global index = slice offset + local index keeps the oracle's tie order).
+// y (D, M, B) -> (D, M / S, B x S) with slice s of cloud b = its rows s, s + S, s + 2S, ...: the verified merge's slices must be
+// samples of the whole cloud -- contiguous slices of a cloud whose index neighbours are spatial neighbours (a scan line, a sorted
+// mesh) hold ALL of a query's neighbours in one slice, and every query would be flagged.
+__global__ __launch_bounds__(256) void knn_interleave_kernel(const float *__restrict__ y, int M, int D, int B, int S, float *__restrict__ out,
+                                                             int vec4) {
+    const int Ms = M / S;
+    if (vec4) {
+        const int D4 = D / 4;
+        const long long total = (long long)B * M * D4;
+        const float4 *y4 = reinterpret_cast<const float4 *>(y);
+        float4 *o4 = reinterpret_cast<float4 *>(out);
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+            const long long row = e / D4;  // output row: (b * S + sl) * Ms + l
+            const int f = (int)(e - row * D4);
+            const int l = (int)(row % Ms);
+            const long long bs = row / Ms;
+            const int sl = (int)(bs % S);
+            const long long b = bs / S;
+            o4[e] = y4[(b * M + (long long)l * S + sl) * D4 + f];
+        }
+    } else {
+        const long long total = (long long)B * M * D;
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+            const long long row = e / D;
+            const int f = (int)(e - row * D);
+            const int l = (int)(row % Ms);
+            const long long bs = row / Ms;
+            const int sl = (int)(bs % S);
+            const long long b = bs / S;
+            out[e] = y[(b * M + (long long)l * S + sl) * D + f];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void knn_merge_slices_kernel(const int32_t *__restrict__ widx, const float *__restrict__ wdist, int N, int B,
                                                                int S, int Ms, int kl, int kk, int k, int drop, int32_t *__restrict__ idx,
-                                                               float *__restrict__ dist, unsigned char *__restrict__ flags) {
+                                                               float *__restrict__ dist, unsigned char *__restrict__ flags, int interleaved) {
     __shared__ unsigned long long keys[4][512];  // (distance key, global index): unique, their unsigned order is the oracle's
     __shared__ unsigned long long tkey[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -3578,7 +3612,9 @@ __global__ __launch_bounds__(256) void knn_merge_slices_kernel(const int32_t *__
     for (int e = lane; e < n; e += 64) {
         const int sl = e / kl, r = e - sl * kl;
         const size_t src = (((size_t)b * S + sl) * N + i) * kl + r;
-        keys[wv][e] = ((unsigned long long)dist_key(wdist[src]) << 32) | (unsigned int)(widx[src] + sl * Ms);
+        // global index: contiguous slices -- offset + local; interleaved slices (slice sl = rows sl, sl + S, ...) -- local * S + sl;
+        // either way increasing with the local index inside a slice, so the slices' own tie order is the global one
+        keys[wv][e] = ((unsigned long long)dist_key(wdist[src]) << 32) | (unsigned int)(interleaved ? widx[src] * S + sl : widx[src] + sl * Ms);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
@@ -3656,12 +3692,12 @@ int knn_wide_slices(int M, int D, int kk) {
     if (M % S || M / S < 64 || ((size_t)(M / S) * D * 4) % 16 != 0 || knn_select_waves(M) < 1) return 0;
     return S;
 }
-// scratch of a call: [pre-pass slabs of the (virtual) clouds][slice results: indices, distances][flags], 256-byte aligned parts
+// scratch of a call: [pre-pass slabs of the (virtual) clouds][slice results: indices, distances][flags][interleaved clouds], 256-byte aligned parts
 struct KnnScratch {
     int S;        // candidate slices per cloud (1 = none)
     int kl;       // entries per slice list: k + drop, or 32 with `verify`
     bool verify;  // the slices' lists are shorter than k + drop: verified merge + fallback for the flagged queries
-    size_t pre_bytes, list_bytes, flag_bytes, total;
+    size_t pre_bytes, list_bytes, flag_bytes, copy_bytes, total;
     static KnnScratch plan(int N, int M, int B, int D, int kk) {
         KnnScratch p{};
         p.S = knn_slices(N, M, B, D, kk);
@@ -3674,7 +3710,8 @@ struct KnnScratch {
         p.pre_bytes = knn_pre_shape_ok(Ms, D, p.kl) ? (knn_pre_bytes(Ms, B * p.S, D) + 255) & ~(size_t)255 : 0;
         p.list_bytes = p.S > 1 ? (((size_t)p.kl * N * B * p.S * 4 + 255) & ~(size_t)255) : 0;
         p.flag_bytes = p.verify ? (((size_t)N * B + 255) & ~(size_t)255) : 0;
-        p.total = p.pre_bytes + 2 * p.list_bytes + p.flag_bytes;
+        p.copy_bytes = p.verify ? (((size_t)M * D * B * 4 + 255) & ~(size_t)255) : 0;  // the interleaved copy of the candidate clouds
+        p.total = p.pre_bytes + 2 * p.list_bytes + p.flag_bytes + p.copy_bytes;
         return p;
     }
 };
@@ -3757,15 +3794,25 @@ fx3d_status fx3d_knn_ws(const float *x, int32_t N, const float *y, int32_t M, in
         // candidate slices: the search on B x S virtual clouds of M / S rows (no drop: the merge drops), then the merge
         const int Ms = M / p.S;
         unsigned char *w8 = static_cast<unsigned char *>(ws);
-        void *pre_ws = p.pre_bytes && knn_pre_eligible(x, y, Ms, D, p.kl) ? ws : nullptr;
         int32_t *widx = reinterpret_cast<int32_t *>(w8 + p.pre_bytes);
         float *wdist = reinterpret_cast<float *>(w8 + p.pre_bytes + p.list_bytes);
         unsigned char *flags = p.verify ? w8 + p.pre_bytes + 2 * p.list_bytes : nullptr;
-        const fx3d_status rc = launch_knn(x, N, y, Ms, B * p.S, D, p.kl, 0, widx, wdist, as_stream(s), pre_ws, p.S);
+        const float *ys = y;  // the clouds the slices are cut from
+        if (p.verify) {       // 32 per slice must hold the cloud's kk nearest: interleaved slices (samples of the whole cloud)
+            float *yc = reinterpret_cast<float *>(w8 + p.pre_bytes + 2 * p.list_bytes + p.flag_bytes);
+            const int vec4 = D % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+            const long long items = (long long)B * M * (vec4 ? D / 4 : D);
+            const long long nb = (items + 255) / 256;
+            hipLaunchKernelGGL(knn_interleave_kernel, dim3((unsigned int)(nb < 8192 ? nb : 8192)), dim3(256), 0, as_stream(s), y, M, D, B, p.S, yc, vec4);
+            FX3D_LAUNCH_CHECK();
+            ys = yc;
+        }
+        void *pre_ws = p.pre_bytes && knn_pre_eligible(x, ys, Ms, D, p.kl) ? ws : nullptr;
+        const fx3d_status rc = launch_knn(x, N, ys, Ms, B * p.S, D, p.kl, 0, widx, wdist, as_stream(s), pre_ws, p.S);
         if (rc != FX3D_OK) return rc;
         const long long nq = (long long)B * N;
         hipLaunchKernelGGL(knn_merge_slices_kernel, dim3((unsigned int)((nq + 3) / 4)), dim3(256), 0, as_stream(s), widx, wdist, N, B, p.S, Ms,
-                           p.kl, kk, k, drop, idx, dist, flags);
+                           p.kl, kk, k, drop, idx, dist, flags, p.verify ? 1 : 0);
         FX3D_LAUNCH_CHECK();
         if (p.verify) {  // the flagged queries (a slice held more than 32 of their kk nearest) again, on all M candidates
             int nw = knn_select_waves(M);
