@@ -1887,7 +1887,7 @@ struct KnnPre {
     size_t stride;        // bytes per cloud
     int Mpad;             // rows of the image (multiple of 256: chunks never need a clamp), DP halves per row
     // offsets inside a cloud's slab (bytes)
-    size_t off_parts, off_hdr, off_cmax, off_nup, off_ndn, off_img;
+    size_t off_parts, off_hdr, off_cmax, off_sync, off_nup, off_ndn, off_img;
     __host__ __device__ static KnnPre make(void *ws, int M, int DP) {
         KnnPre k{};
         k.base = static_cast<unsigned char *>(ws);
@@ -1896,6 +1896,8 @@ struct KnnPre {
         k.off_parts = o; o += (size_t)kPreParts * (3 * DP + 4) * 4;
         k.off_hdr = o; o += (size_t)(8 + DP) * 4;
         k.off_cmax = o; o += (size_t)kPreParts * 4;
+        o = (o + 63) & ~(size_t)63;
+        k.off_sync = o; o += (size_t)(kPreParts + 8) * 8;  // the fused pre-pass kernel's meeting point: 8 slots + the generation word
         o = (o + 15) & ~(size_t)15;
         k.off_nup = o; o += (size_t)k.Mpad * 4;
         k.off_ndn = o; o += (size_t)k.Mpad * 4;
@@ -1905,6 +1907,7 @@ struct KnnPre {
     }
     __host__ __device__ float *parts(int b) const { return reinterpret_cast<float *>(base + (size_t)b * stride + off_parts); }
     __host__ __device__ float *hdr(int b) const { return reinterpret_cast<float *>(base + (size_t)b * stride + off_hdr); }
+    __host__ __device__ unsigned long long *sync(int b) const { return reinterpret_cast<unsigned long long *>(base + (size_t)b * stride + off_sync); }
     __host__ __device__ unsigned int *cmaxp(int b) const { return reinterpret_cast<unsigned int *>(base + (size_t)b * stride + off_cmax); }
     __host__ __device__ float *nup(int b) const { return reinterpret_cast<float *>(base + (size_t)b * stride + off_nup); }
     __host__ __device__ float *ndn(int b) const { return reinterpret_cast<float *>(base + (size_t)b * stride + off_ndn); }
@@ -1912,9 +1915,14 @@ struct KnnPre {
 };
 // header floats: [0] sc  [1] funit  [2] acoef (candidate side)  [3] bits: 1 = non-finite / overflow-prone cloud  [8 ...] mu[DP]
 
-__global__ __launch_bounds__(kPreThreads) void knn_pre_stats_kernel(const float *__restrict__ y, int M, int D, int DP, KnnPre pre) {
-    __shared__ float red[(kPreThreads / 64) * 32 * 12];
-    const int part = blockIdx.x, b = blockIdx.y;
+// The parts' statistics travel between the blocks of a cloud INSIDE the fused pre-pass kernel: device-coherent accesses (relaxed
+// atomics at agent scope: write-through stores, loads that do not hit a stale line -- the blocks may sit on different XCDs, each
+// with its own L2) instead of agent-scope fences, which write back / invalidate a whole L2 per block (measured: + 0.1 us per block
+// of the grid, serialised per XCD: C4' 76 -> 104 us).
+__device__ __forceinline__ void knn_pre_put(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float knn_pre_get(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void knn_pre_stats_body(const float *__restrict__ y, int M, int D, int DP, const KnnPre &pre, int part, int b,
+                                                   float *red) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float *yb = y + (size_t)b * M * D;
     const int rq = D / 4;  // (kPreThreads % rq == 0: thread t always sees dimensions 4 (t % rq) ...)
@@ -1965,25 +1973,28 @@ __global__ __launch_bounds__(kPreThreads) void knn_pre_stats_kernel(const float 
                 const float *r8 = red + (size_t)(w * 32 + tid) * 12;
                 lo = fminf(lo, r8[c]); hi = fmaxf(hi, r8[4 + c]); sm = sm + r8[8 + c];
             }
-            out[4 * tid + c] = lo; out[DP + 4 * tid + c] = hi; out[2 * DP + 4 * tid + c] = sm;
+            knn_pre_put(out + 4 * tid + c, lo); knn_pre_put(out + DP + 4 * tid + c, hi); knn_pre_put(out + 2 * DP + 4 * tid + c, sm);
         }
     }
-    if (tid == 0) reinterpret_cast<int *>(out)[3 * DP] = anynan ? 1 : 0;
+    if (tid == 0) knn_pre_put(out + 3 * DP, __builtin_bit_cast(float, anynan ? 1 : 0));
+}
+__global__ __launch_bounds__(kPreThreads) void knn_pre_stats_kernel(const float *__restrict__ y, int M, int D, int DP, KnnPre pre) {
+    __shared__ float red[(kPreThreads / 64) * 32 * 12];
+    knn_pre_stats_body(y, M, D, DP, pre, blockIdx.x, blockIdx.y, red);
 }
 
+// mu: [DP] floats, sh: 4 words of LDS ([0] bits of the extent  [1] skew flag  [2] bits of the bulk radius  [3] largest norm of the part)
 template <int DK>
-__global__ __launch_bounds__(kPreThreads) void knn_pre_image_kernel(const float *__restrict__ y, int M, int D, int two_norms, KnnPre pre) {
+__device__ __forceinline__ void knn_pre_image_body(const float *__restrict__ y, int M, int D, int two_norms, const KnnPre &pre, int part, int b,
+                                                   float *mu, unsigned int *sh) {
     constexpr int DP = DK * 32, G = DP / 8;
-    __shared__ float mu[DP];
-    __shared__ unsigned int sh[4];  // [0] bits of the extent  [1] skew flag  [2] bits of the bulk radius  [3] largest norm of the part
-    const int part = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float *yb = y + (size_t)b * M * D;
     const int rq = D / 4;
     const float *parts = pre.parts(b);
     if (tid < 4) sh[tid] = 0u;
     bool anynan = false;
-    for (int p = 0; p < kPreParts; ++p) anynan |= reinterpret_cast<const int *>(parts + (size_t)p * (3 * DP + 4))[3 * DP] != 0;
+    for (int p = 0; p < kPreParts; ++p) anynan |= __builtin_bit_cast(int, knn_pre_get(parts + (size_t)p * (3 * DP + 4) + 3 * DP)) != 0;
     __syncthreads();
     if (tid < rq) {
         float amax = 0.0f;
@@ -1992,7 +2003,7 @@ __global__ __launch_bounds__(kPreThreads) void knn_pre_image_kernel(const float 
             float lo = INFINITY, hi = -INFINITY, sm = 0.0f;
             for (int p = 0; p < kPreParts; ++p) {  // (fixed order: every block of the cloud gets the same centre)
                 const float *q = parts + (size_t)p * (3 * DP + 4);
-                lo = fminf(lo, q[4 * tid + c]); hi = fmaxf(hi, q[DP + 4 * tid + c]); sm = sm + q[2 * DP + 4 * tid + c];
+                lo = fminf(lo, knn_pre_get(q + 4 * tid + c)); hi = fmaxf(hi, knn_pre_get(q + DP + 4 * tid + c)); sm = sm + knn_pre_get(q + 2 * DP + 4 * tid + c);
             }
             float m0 = sm / (float)M;
             m0 = fminf(fmaxf(m0, lo), hi);
@@ -2129,6 +2140,39 @@ __global__ __launch_bounds__(kPreThreads) void knn_pre_image_kernel(const float 
     if (lane == 0) atomicMax(&sh[3], anyn ? 0x7fc00000u : __builtin_bit_cast(unsigned int, tmax));
     __syncthreads();
     if (tid == 0) pre.cmaxp(b)[part] = bad ? 0x7fc00000u : sh[3];
+}
+template <int DK>
+__global__ __launch_bounds__(kPreThreads) void knn_pre_image_kernel(const float *__restrict__ y, int M, int D, int two_norms, KnnPre pre) {
+    __shared__ float mu[DK * 32];
+    __shared__ unsigned int sh[4];
+    knn_pre_image_body<DK>(y, M, D, two_norms, pre, blockIdx.x, blockIdx.y, mu, sh);
+}
+// Both steps in ONE launch (round 3): the eight blocks of a cloud meet between them -- a cloud-local barrier through the slab's sync
+// words (a launch costs ~5 us of dependent start-up here; the meeting of eight neighbouring blocks well under one).  Every block
+// reads the cloud's generation word g at its start, publishes g + 1 in its own slot after its statistics are out, and waits for the
+// eight slots; part 0 then advances the generation.  No initialisation needed (arbitrary workspace contents: stale slots equal
+// g + 1 with probability 2^-64), replay-safe under hipGraph (the state lives in the workspace), and the eight blocks of a cloud
+// are consecutive in dispatch order, so a waiting block never waits for one that cannot be scheduled.
+template <int DK>
+__global__ __launch_bounds__(kPreThreads) void knn_pre_fused_kernel(const float *__restrict__ y, int M, int D, int two_norms, KnnPre pre) {
+    __shared__ float red[(kPreThreads / 64) * 32 * 12];
+    __shared__ float mu[DK * 32];
+    __shared__ unsigned int sh[4];
+    __shared__ unsigned long long gen_s;
+    const int part = blockIdx.x, b = blockIdx.y;
+    unsigned long long *sync = pre.sync(b);  // [0..7] slots, [8] generation
+    if (threadIdx.x == 0) gen_s = __hip_atomic_load(sync + kPreParts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    knn_pre_stats_body(y, M, D, DK * 32, pre, part, b, red);
+    __builtin_amdgcn_s_waitcnt(0);  // this thread's (coherent) stores of the part are performed ...
+    __syncthreads();                // ... every thread's; gen_s is read
+    const unsigned long long want = gen_s + 1;
+    if (threadIdx.x == 0) __hip_atomic_store(sync + part, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < kPreParts)
+        while (__hip_atomic_load(sync + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(1);  // (relaxed: an
+                                                                     // acquire per poll invalidates the caches under the blocks still working)
+    __syncthreads();  // (the parts are read with coherent loads: knn_pre_get)
+    if (part == 0 && threadIdx.x == 0) __hip_atomic_store(sync + kPreParts, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    knn_pre_image_body<DK>(y, M, D, two_norms, pre, part, b, mu, sh);
 }
 
 // producer wave pw brings chunk [j0, j0 + CH) of the pre-pass image into `img` (single-piece layout of knn_hpiece_off: the
@@ -3485,8 +3529,11 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     KnnPre pre{};
     if (use_pre) {
         pre = KnnPre::make(pre_ws, M, DP);
-        hipLaunchKernelGGL(knn_pre_stats_kernel, dim3(kPreParts, B), dim3(kPreThreads), 0, st, y, M, D, DP, pre);
-        hipLaunchKernelGGL((knn_pre_image_kernel<DK>), dim3(kPreParts, B), dim3(kPreThreads), 0, st, y, M, D, two_norms, pre);
+        if (!opt(OPT_KNN_PREPASS_FUSED)) {  // (the one-launch form measured the same: DESIGN.md 3.2)
+            hipLaunchKernelGGL(knn_pre_stats_kernel, dim3(kPreParts, B), dim3(kPreThreads), 0, st, y, M, D, DP, pre);
+            hipLaunchKernelGGL((knn_pre_image_kernel<DK>), dim3(kPreParts, B), dim3(kPreThreads), 0, st, y, M, D, two_norms, pre);
+        } else
+            hipLaunchKernelGGL((knn_pre_fused_kernel<DK>), dim3(kPreParts, B), dim3(kPreThreads), 0, st, y, M, D, two_norms, pre);
     }
     if (use_pre) {
         const fx3d_status arc2 = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_mfma_kernel<DK, F16, SPLIT, F16 && !SPLIT>), 152 * 1024,

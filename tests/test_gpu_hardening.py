@@ -573,6 +573,24 @@ def test_knn_ws_entry_point_contract(gpu_fx, oracle):
         assert np.array_equal(dist.to_host(), od, equal_nan=True)
 
 
+def test_knn_prepass_one_launch_form(gpu_fx, oracle, fx_option):
+    """Option knn_prepass_fused: statistics and image of the pre-pass in one launch, the eight part blocks of a cloud meeting through
+    the slab's generation word and slots (device-coherent accesses, no fences).  Same results as the two-launch form, call after
+    call on the same workspace (the meeting state lives there) and on a fresh, dirty one."""
+    rng = np.random.default_rng(21)
+    x = np.asfortranarray(rng.standard_normal((32, 700, 5)).astype(np.float32))
+    oi, od = oracle.knn(x, 12, drop_first=True)
+    fx_option("knn_prepass_fused", "1")
+    for _ in range(4):
+        idx, dist = gpu_fx.knn(x, 12, drop_first=True)
+        assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+    y = np.asfortranarray(rng.standard_normal((64, 1024, 9)).astype(np.float32))   # another shape on the same (reused, now dirty) scratch
+    oi2, od2 = oracle.knn(y[:, :200, :], 20, y=y)
+    for _ in range(2):
+        idx, dist = gpu_fx.knn(np.asfortranarray(y[:, :200, :]), 20, y=y)
+        assert np.array_equal(idx.to_host(), oi2) and np.array_equal(dist.to_host(), od2)
+
+
 def _grid_mesh(nx, ny, seed, extra_verts=0):
     """A jittered (nx x ny)-cell sheet: (nx+1)(ny+1) (+ extra unused) vertices, 2 nx ny triangles of uneven area."""
     rng = np.random.default_rng(seed)
