@@ -522,6 +522,13 @@ def config_one_liners(fx):
     r = _per_call_ms(fx, lambda: fx.knn(f64, 20, drop_first=True))
     r["roofline"] = _roof(r["min_ms"], flops=3.0 * 64 * 32 * 1024 * 1024, nbytes=4.0 * 64 * 1024 * 32 + 2 * 4.0 * 20 * 1024 * 32)
     out["C4' kNN k=20 self graph B=32 N=1024 D=64 (second EdgeConv)"] = r
+    # off the BASELINE shapes (round 3): k + drop in 33..64 stays on the matrix cores; one large cloud runs as candidate slices
+    out["kNN k=40 self graph at C4's / C4''s shape (D=3 / D=64)"] = {
+        "D3": _per_call_ms(fx, lambda: fx.knn(c4, 40, drop_first=True)), "D64": _per_call_ms(fx, lambda: fx.knn(f64, 40, drop_first=True))}
+    one = fx.gpu(np.asfortranarray(np.random.default_rng(2).standard_normal((64, 8192, 1)).astype(np.float32)))
+    r = _per_call_ms(fx, lambda: fx.knn(one, 20, drop_first=True))
+    r["roofline"] = _roof(r["min_ms"], flops=3.0 * 64 * 8192 * 8192, nbytes=4.0 * 64 * 8192 + 2 * 4.0 * 20 * 8192)
+    out["kNN k=20 self graph, ONE cloud of 8192 points, D=64 (candidate slices of fx3d_knn_ws)"] = r
     return out
 
 

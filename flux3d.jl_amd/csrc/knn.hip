@@ -933,6 +933,15 @@ struct K3Geom {
 };
 using K3Base = K3Geom<4, 24, 64, 32>;    // k + drop <= 32: C4 gets 256 blocks of 128 queries, one per CU
 using K3Wide = K3Geom<2, 40, 128, 64>;   // 32 < k + drop <= 64: twice the keys and longer lists per query, half the queries per block
+// ... and a compact one (round 3) for 32 < k + drop <= 48: an allocation below half a CU's LDS, so that TWO blocks (eight waves) share a
+// CU as in the base geometry -- the wide geometry's four waves leave half of every CU's issue slots empty (C4's shape, k = 40:
+// 52.4 -> 34.8 us) -- for clouds whose image fits next to the keys (<= ~1500 candidates; the raw coordinates stay in L2).  The same
+// form of the base geometry (K3Geom<2, 24, 64, 32>, two blocks per CU) measured equal to it (k = 20: 24.8 vs 25.0 us): not kept.
+using K3Mid = K3Geom<2, 28, 88, 48>;
+// (48 < k + drop <= 64 as K3Geom<1, 35, 120, 64>, 32 queries per block and three blocks per CU, measured equal to the wide geometry
+//  up to k = 56 -- four times the prologues -- and worse beyond, where 120 keys overflow: not kept)
+// dynamic LDS limit of a compact block: NB of them (+ ~0.7 KiB static each) fit in a CU's 160 KiB
+constexpr size_t k3_compact_lds(int nb) { return (size_t)160 * 1024 / nb - 1024; }
 constexpr int kTChunk = 3072;         // candidates per LDS image (32 B each): image + lists + counters <= 152 KiB
 constexpr int kTRawMax = 2048;        // clouds up to this size also keep their raw coordinates in LDS
 constexpr int kK3FarCap = 16;         // far candidates (robust range, as in nn1_f16_kernel) kept on the exact side list
@@ -1649,7 +1658,17 @@ __global__ __launch_bounds__(C::T) void knn_f16_d3_kernel(const float *__restric
     KNN_PROBE_MARK(11);
 }
 
+// dynamic LDS of geometry C for a cloud of M candidates without the optional parts (raw coordinates, medium-path scratch)
 template <class C>
+size_t knn_f16_d3_core_lds(int M) {
+    int CH = (M + 63) / 64 * 64;
+    if (CH > kTChunk) CH = kTChunk;
+    size_t img = (size_t)CH * 32;
+    const size_t keys = (size_t)C::G * 32 * C::KS * 8;
+    if (img < keys) img = keys;
+    return img + (size_t)C::W * C::CAP * 64 * 4 + (size_t)C::G * 32 * 8 * 4;
+}
+template <class C, int COMPACT = 0>  // COMPACT = blocks per CU the allocation is held to (0: one block, the whole CU)
 fx3d_status launch_knn_f16_d3_geom(const float *x, int N, const float *y, int M, int B, int k, int drop, int32_t *idx,
                                    float *dist, hipStream_t st, float *feat, int layout, int xdiv) {
     int CH = (M + 63) / 64 * 64;
@@ -1658,12 +1677,14 @@ fx3d_status launch_knn_f16_d3_geom(const float *x, int N, const float *y, int M,
     const size_t keys = (size_t)C::G * 32 * C::KS * 8;  // distance bits + indices
     if (img < keys) img = keys;
     const size_t fixed = (size_t)C::W * C::CAP * 64 * 4 + (size_t)C::G * 32 * 8 * 4;  // lists (exchange, slots) + counters
-    const int raw_ok = M <= kTRawMax && img + fixed + (size_t)M * 16 <= 152 * 1024;
+    // COMPACT: the whole allocation stays below half a CU's LDS (two blocks per CU); the optional parts only if they fit under that
+    const size_t raw_limit = COMPACT ? k3_compact_lds(COMPACT ? COMPACT : 1) : 152 * 1024, all_limit = COMPACT ? k3_compact_lds(COMPACT ? COMPACT : 1) : 156 * 1024;
+    const int raw_ok = M <= kTRawMax && img + fixed + (size_t)M * 16 <= raw_limit;
     size_t lds = img + fixed + (raw_ok ? (size_t)M * 16 : 0);
     // medium path scratch (id list + merge lists per wave), when it fits next to everything else
     int med_cap = 0, med_off = 0;
     for (int cap = 512; cap >= 128; cap >>= 1)
-        if (lds + (size_t)C::W * (cap + 128) * 4 <= 156 * 1024) {
+        if (lds + (size_t)C::W * (cap + 128) * 4 <= all_limit) {
             med_cap = cap; med_off = (int)lds; lds += (size_t)C::W * (cap + 128) * 4;
             break;
         }
@@ -1688,7 +1709,10 @@ __host__ inline bool knn_f16_d3_shape_ok(int M, int kk) {
 }
 fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int B, int k, int drop, int32_t *idx,
                               float *dist, hipStream_t st, float *feat = nullptr, int layout = 0, int xdiv = 1) {
+    const bool compact = !opt(OPT_KNN_D3_NO_COMPACT);
     if (k + drop <= 32) return launch_knn_f16_d3_geom<K3Base>(x, N, y, M, B, k, drop, idx, dist, st, feat, layout, xdiv);
+    if (k + drop <= K3Mid::KKMAX && compact && knn_f16_d3_core_lds<K3Mid>(M) <= k3_compact_lds(2))
+        return launch_knn_f16_d3_geom<K3Mid, 2>(x, N, y, M, B, k, drop, idx, dist, st, feat, layout, xdiv);
     return launch_knn_f16_d3_geom<K3Wide>(x, N, y, M, B, k, drop, idx, dist, st, feat, layout, xdiv);
 }
 

@@ -37,6 +37,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"knn_no_prepass", "FX3D_KNN_NO_PREPASS", 0},
     {"knn_gather", "FX3D_KNN_GATHER", 0},
     {"knn_d3_wave", "FX3D_KNN_D3_WAVE", 0},
+    {"knn_d3_no_compact", "FX3D_KNN_D3_NO_COMPACT", 0},
     {"knn_prepass_fused", "FX3D_KNN_PREPASS_FUSED", 0},
     {"knn_slices", "FX3D_KNN_SLICES", 0},
     {"edge_scalar_stores", "FX3D_EDGE_SCALAR_STORES", 0},

@@ -1158,6 +1158,23 @@ def test_knn_d3_wide_selection(gpu_fx, oracle, M, k, drop, kind):
     assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
 
 
+@pytest.mark.parametrize("M,k,drop", [(1024, 40, True), (1472, 47, False), (1473, 47, True), (130, 33, False), (1024, 48, True)])
+def test_knn_d3_compact_geometry_against_the_wide_one(gpu_fx, oracle, fx_option, M, k, drop):
+    """32 < k + drop <= 48 on clouds of one small image run the compact geometry (two blocks per CU, raw coordinates from L2, no
+    medium path); the option knn_d3_no_compact keeps the wide one: both bit-identical to the oracle, on both sides of the image
+    limit (1472 candidates) and of k + drop = 48."""
+    rng = np.random.default_rng(M + k)
+    x = np.asfortranarray(rng.random((3, 200, 2), dtype=np.float32))
+    y = rng.random((3, M, 2), dtype=np.float32)
+    y[:, ::5, :] = np.round(y[:, ::5, :] * 8) / 8
+    y = np.asfortranarray(y)
+    oi, od = oracle.knn(x, k, y=y, drop_first=drop)
+    for no_compact in (0, 1):
+        fx_option("knn_d3_no_compact", str(no_compact))
+        idx, dist = gpu_fx.knn(x, k, y=y, drop_first=drop)
+        assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od), no_compact
+
+
 def test_knn_d3_wide_selection_full_shape(gpu_fx, oracle):
     """C4's shape with k = 40 (the segmentation networks' neighbourhood): sampled queries against the oracle."""
     rng = np.random.default_rng(77)

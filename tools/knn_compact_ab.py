@@ -1,0 +1,18 @@
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+import flux3d_jl_amd as fx
+from flux3d_jl_amd import _lib
+from bench_ops import gpu_time
+rng = np.random.default_rng(5)
+x = fx.gpu(np.asfortranarray(rng.standard_normal((3, 1024, 32)).astype(np.float32)))
+for k in (40, 47, 48, 52, 56, 60, 63):
+    row = []
+    ref = None
+    for nomid in (1, 0, 1, 0):
+        _lib.set_option("knn_d3_no_compact", nomid)
+        idx = fx.knn(x, k, drop_first=True, return_dist=False).to_host()
+        if ref is None: ref = idx
+        mn, md = gpu_time(lambda: fx.knn(x, k, drop_first=True, return_dist=False), reps=8, inner=4)
+        row.append(f"{'wide' if nomid else 'mid '}: {mn:6.1f}{'' if np.array_equal(idx, ref) else ' MISMATCH'}")
+    print(f"D=3 k={k}: " + "  ".join(row), flush=True)
+_lib.set_option("knn_d3_no_compact", 0)
