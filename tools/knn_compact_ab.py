@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""D = 3 kNN, 32 < k + drop <= 48: the wide geometry (one block of four waves per CU) against the compact one (two blocks per CU),
+same box, alternating (option knn_d3_no_compact)."""
 import os, sys, numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
 import flux3d_jl_amd as fx
