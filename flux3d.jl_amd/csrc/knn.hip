@@ -3670,45 +3670,75 @@ __global__ __launch_bounds__(256) void knn_interleave_kernel(const float *__rest
     }
 }
 
+// Block of 256 threads = 4 / wpq queries x wpq waves per query (wpq = 1, 2, 4: n <= 64, 128, more -- every entry its own thread up to
+// n = 256, two per thread beyond): the chain load -> LDS -> searches -> store runs once per thread (a wave per query with n / 64
+// entries per lane ran it n / 64 times back to back: 17 / 44 us at n = 64 / 128 and C4's shape).  Dynamic LDS: (4 / wpq) x n keys.
 __global__ __launch_bounds__(256) void knn_merge_slices_kernel(const int32_t *__restrict__ widx, const float *__restrict__ wdist, int N, int B,
                                                                int S, int Ms, int kl, int kk, int k, int drop, int32_t *__restrict__ idx,
-                                                               float *__restrict__ dist, unsigned char *__restrict__ flags, int interleaved) {
-    __shared__ unsigned long long keys[4][512];  // (distance key, global index): unique, their unsigned order is the oracle's
+                                                               float *__restrict__ dist, unsigned char *__restrict__ flags, int interleaved,
+                                                               int wpq) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long mkeys[];  // [4 / wpq][n] (distance key, global index): unique,
+                                                                                // their unsigned order is the oracle's
     __shared__ unsigned long long tkey[4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long q = (long long)blockIdx.x * 4 + wv;  // query b * N + i
-    if (q >= (long long)B * N) return;                   // (wave-uniform; no block-level synchronisation below)
-    const int b = (int)(q / N), i = (int)(q - (long long)b * N);
     const int n = S * kl;  // kl entries per slice: kk, or 32 < kk with `flags` (verified below)
-    for (int e = lane; e < n; e += 64) {
-        const int sl = e / kl, r = e - sl * kl;
-        const size_t src = (((size_t)b * S + sl) * N + i) * kl + r;
-        // global index: contiguous slices -- offset + local; interleaved slices (slice sl = rows sl, sl + S, ...) -- local * S + sl;
-        // either way increasing with the local index inside a slice, so the slices' own tie order is the global one
-        keys[wv][e] = ((unsigned long long)dist_key(wdist[src]) << 32) | (unsigned int)(interleaved ? widx[src] * S + sl : widx[src] + sl * Ms);
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    for (int e = lane; e < n; e += 64) {
-        const unsigned long long me = keys[wv][e];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) rank += keys[wv][j] < me ? 1 : 0;
-        if (rank >= drop && rank < kk) {
-            const int sl = e / kl, r = e - sl * kl;
-            idx[(size_t)q * k + rank - drop] = (int)(unsigned int)me;
-            if (dist) dist[(size_t)q * k + rank - drop] = wdist[(((size_t)b * S + sl) * N + i) * kl + r];  // (the slice's own bits)
+    const int qpb = 4 / wpq;
+    const int qs = (threadIdx.x >> 6) / wpq;                       // query slot of this thread's wave
+    const int t0 = threadIdx.x - qs * wpq * 64;                    // thread index within the query's wpq waves
+    const int i = blockIdx.x * qpb + qs, b = blockIdx.y;
+    const bool live = i < N;                                        // (uniform per wave; every thread reaches the barriers)
+    unsigned long long *keys = mkeys + (size_t)qs * n;
+    const size_t q = (size_t)b * N + (live ? i : 0);
+    const int nt = wpq * 64;
+    unsigned long long me[2] = {0ull, 0ull};
+    int sl2[2] = {0, 0}, r2[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = t0 + u * nt;
+        if (live && e < n) {
+            const int sl = (int)((unsigned int)e / (unsigned int)kl), r = e - sl * kl;
+            const size_t src = (((size_t)b * S + sl) * N + i) * kl + r;
+            // global index: contiguous slices -- offset + local; interleaved slices (slice sl = rows sl, sl + S, ...) -- local * S + sl;
+            // either way increasing with the local index inside a slice, so the slices' own tie order is the global one
+            me[u] = ((unsigned long long)dist_key(wdist[src]) << 32) | (unsigned int)(interleaved ? widx[src] * S + sl : widx[src] + sl * Ms);
+            keys[e] = me[u];
+            sl2[u] = sl; r2[u] = r;
         }
-        if (flags && rank == kk - 1) tkey[wv] = me;  // (exactly one entry: the keys are unique and n >= kk)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = t0 + u * nt;
+        if (live && e < n) {
+            // every slice's list is ascending in these keys (the search kernels' order): the rank is the position in the own list
+            // plus, per other slice, the number of its keys below `me` -- a binary search each
+            int rank = r2[u];
+            for (int t = 0; t < S; ++t) {
+                if (t == sl2[u]) continue;
+                const unsigned long long *L = keys + t * kl;
+                int lo = 0, hi = kl;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (L[mid] < me[u]) lo = mid + 1; else hi = mid;
+                }
+                rank += lo;
+            }
+            if (rank >= drop && rank < kk) {
+                idx[q * k + rank - drop] = (int)(unsigned int)me[u];
+                if (dist) dist[q * k + rank - drop] = wdist[(((size_t)b * S + sl2[u]) * N + i) * kl + r2[u]];  // (the slice's own bits)
+            }
+            if (flags && rank == kk - 1) tkey[qs] = me[u];  // (exactly one entry: the keys are unique and n >= kk)
+        }
     }
     if (flags) {
         // lists shorter than kk: the answer stands iff no slice can hide a candidate below the kk-th merged key T -- a slice's
         // unlisted candidates lie above its last listed key, so a slice whose last key is >= T hides nothing
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        const unsigned long long T = tkey[wv];
-        const bool hides = lane < S && keys[wv][lane * kl + kl - 1] < T;
-        const unsigned long long any = __ballot(hides);
-        if (lane == 0) flags[q] = any ? 1 : 0;
+        __syncthreads();
+        if (live && t0 < 64) {  // the query's first wave
+            const unsigned long long T = tkey[qs];
+            const bool hides = t0 < S && keys[t0 * kl + kl - 1] < T;
+            const unsigned long long any = __ballot(hides);
+            if (t0 == 0) flags[q] = any ? 1 : 0;
+        }
     }
 }
 
@@ -3881,9 +3911,11 @@ fx3d_status fx3d_knn_ws(const float *x, int32_t N, const float *y, int32_t M, in
         void *pre_ws = p.pre_bytes && knn_pre_eligible(x, ys, Ms, D, p.kl) ? ws : nullptr;
         const fx3d_status rc = launch_knn(x, N, ys, Ms, B * p.S, D, p.kl, 0, widx, wdist, as_stream(s), pre_ws, p.S);
         if (rc != FX3D_OK) return rc;
-        const long long nq = (long long)B * N;
-        hipLaunchKernelGGL(knn_merge_slices_kernel, dim3((unsigned int)((nq + 3) / 4)), dim3(256), 0, as_stream(s), widx, wdist, N, B, p.S, Ms,
-                           p.kl, kk, k, drop, idx, dist, flags, p.verify ? 1 : 0);
+        const int nent = p.S * p.kl;                                     // entries per query (<= 512)
+        const int wpq = nent <= 64 ? 1 : (nent <= 128 ? 2 : 4), qpb = 4 / wpq;
+        FX3D_REQUIRE(B <= 65535, "fx3d_knn_ws: B=%d exceeds the grid's y range for this shape", B);
+        hipLaunchKernelGGL(knn_merge_slices_kernel, dim3((unsigned int)((N + qpb - 1) / qpb), (unsigned int)B), dim3(256), (size_t)qpb * nent * 8,
+                           as_stream(s), widx, wdist, N, B, p.S, Ms, p.kl, kk, k, drop, idx, dist, flags, p.verify ? 1 : 0, wpq);
         FX3D_LAUNCH_CHECK();
         if (p.verify) {  // the flagged queries (a slice held more than 32 of their kk nearest) again, on all M candidates
             int nw = knn_select_waves(M);
