@@ -434,22 +434,12 @@ __global__ __launch_bounds__(kWThreads) void knn_wave_generic_kernel(const float
 // Cost O(M 32 / 64 + kk^2 / 64) LDS reads per lane and query: a correct general path, not a tuned one (C4's shape with
 // kk = 101: 0.2 ms at D = 3, 1.3 ms at D = 64 -- the key evaluation); the tuned kernels keep k + drop <= 32 (matrix cores).
 constexpr int kSelMaxLds = 144 * 1024;
-__global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict__ x, int N, const float *__restrict__ y,
-                                                         int M, int B, int D, int k, int drop,
-                                                         int32_t *__restrict__ idx, float *__restrict__ dist, int Mpad, int lcap,
-                                                         const unsigned char *__restrict__ only) {
-    extern __shared__ __attribute__((aligned(16))) unsigned int selkeys[];
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int qi = blockIdx.x * nw + wv;
-    if (qi >= N) return;  // wave-uniform; no block-level sync below
-    if (only && !only[(size_t)b * N + qi]) return;  // (the verified slice merge flags the few queries it could not answer)
-    unsigned int *keys = selkeys + (size_t)wv * (Mpad + 2 * lcap);
-    const uint4 *keys4 = reinterpret_cast<const uint4 *>(keys);
-    const int kk = k + drop;
+// keys[j] = canonical distance key of candidate j (kNoKey for j >= M) for j = start, start + stride, ... < Mpad
+__device__ __forceinline__ void knn_select_keys(const float *__restrict__ x, int N, const float *__restrict__ y, int M, int D, int b, int qi,
+                                                int Mpad, unsigned int *keys, int start, int stride) {
     const float *q = x + ((size_t)b * N + qi) * D, *yb = y + (size_t)b * M * D;
     const bool vec4 = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(yb)) & 15) == 0;
-    for (int j = lane; j < Mpad; j += 64) {
+    for (int j = start; j < Mpad; j += stride) {
         unsigned int key = kNoKey;
         if (j < M) {
             const float *c = yb + (size_t)j * D;
@@ -468,20 +458,23 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict
         }
         keys[j] = key;
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
+}
+// selection + ranking of ONE query by one wave from its keys in LDS (steps 2 and 3 above)
+__device__ __forceinline__ void knn_select_wave(unsigned int *keys, int M, int Mpad, int lcap, int N, int b, int qi, int k, int drop, int lane,
+                                                int32_t *__restrict__ idx, float *__restrict__ dist) {
+    const uint4 *keys4 = reinterpret_cast<const uint4 *>(keys);
+    const int kk = k + drop;
     const int n4 = Mpad / 4;
     // ---- T: largest value with #(keys < T) < kk, i.e. the kk-th smallest key (bit by bit, most significant first) ----
     unsigned int T = 0;
     for (int bit = 31; bit >= 0; --bit) {
         const unsigned int trial = T | (1u << bit);
-        int c = 0;
+        int c = 0;  // (wave-uniform: counted with ballots -- no cross-lane reduction per bit; Mpad % 256 == 0: every lane in every sweep)
         for (int i = lane; i < n4; i += 64) {
             const uint4 v = keys4[i];
-            c += (int)(v.x < trial) + (int)(v.y < trial) + (int)(v.z < trial) + (int)(v.w < trial);
+            c += __builtin_popcountll(__ballot(v.x < trial)) + __builtin_popcountll(__ballot(v.y < trial)) +
+                 __builtin_popcountll(__ballot(v.z < trial)) + __builtin_popcountll(__ballot(v.w < trial));
         }
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m, 64);
         if (c < kk) T = trial;
     }
     if (lcap >= kk) {
@@ -493,10 +486,9 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict
         int nless = 0, neq = 0;
         for (int i = lane; i < n4; i += 64) {
             const uint4 v = keys4[i];
-            nless += (int)(v.x < T) + (int)(v.y < T) + (int)(v.z < T) + (int)(v.w < T);
+            nless += __builtin_popcountll(__ballot(v.x < T)) + __builtin_popcountll(__ballot(v.y < T)) +
+                     __builtin_popcountll(__ballot(v.z < T)) + __builtin_popcountll(__ballot(v.w < T));
         }
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) nless += __shfl_xor(nless, m, 64);
         const int quota = kk - nless;  // keys equal to T still wanted (>= 1)
         int S = 0;
         for (int j0 = 0; j0 < M; j0 += 64) {
@@ -548,6 +540,53 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict__ x, int N, const float *__restrict__ y,
+                                                         int M, int B, int D, int k, int drop,
+                                                         int32_t *__restrict__ idx, float *__restrict__ dist, int Mpad, int lcap,
+                                                         const unsigned char *__restrict__ only, int only_regions) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int selkeys[];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (only) {
+        // the verified slice merge's flagged queries: a block looks at 32 consecutive queries of a cloud and answers the flagged ones
+        // one after the other, ALL its waves evaluating the keys, wave 0 selecting (a flagged query on one wave was 45 us -- the whole
+        // duration of the launch; a block per query made the launch itself 30 us: 32768 blocks that only read a flag)
+        const int base = blockIdx.x * 32;
+        const bool f = lane < 32 && base + lane < N && only[(size_t)b * N + base + lane] != 0;
+        unsigned int m = (unsigned int)__ballot(f);  // (every wave computes the same mask)
+        if (__builtin_popcount(m) >= nw && only_regions >= nw) {
+            // many flagged queries (a binomial tail at larger k, or data that defeat the interleaving): a wave per query again
+            unsigned int *keys = selkeys + (size_t)wv * (Mpad + 2 * lcap);
+            int t = 0;
+            for (; m; m &= m - 1, ++t) {
+                if (t % nw != wv) continue;
+                const int qi = base + __builtin_ctz(m);
+                knn_select_keys(x, N, y, M, D, b, qi, Mpad, keys, lane, 64);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                knn_select_wave(keys, M, Mpad, lcap, N, b, qi, k, drop, lane, idx, dist);
+                __builtin_amdgcn_wave_barrier();
+            }
+            return;
+        }
+        for (; m; m &= m - 1) {
+            const int qi = base + __builtin_ctz(m);
+            knn_select_keys(x, N, y, M, D, b, qi, Mpad, selkeys, (int)threadIdx.x, (int)blockDim.x);
+            __syncthreads();
+            if (wv == 0) knn_select_wave(selkeys, M, Mpad, lcap, N, b, qi, k, drop, lane, idx, dist);
+            __syncthreads();  // (the next query's keys overwrite these)
+        }
+        return;
+    }
+    const int qi = blockIdx.x * nw + wv;
+    if (qi >= N) return;  // wave-uniform; no block-level sync below
+    unsigned int *keys = selkeys + (size_t)wv * (Mpad + 2 * lcap);
+    knn_select_keys(x, N, y, M, D, b, qi, Mpad, keys, lane, 64);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    knn_select_wave(keys, M, Mpad, lcap, N, b, qi, k, drop, lane, idx, dist);
 }
 
 // out[(((b*N+i)*k + r)*F + f] = x[(b*N + idx[(b*N+i)*k + r])*F + f]
@@ -3830,7 +3869,7 @@ fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int 
         const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_select_kernel), kSelMaxLds, "knn_select_kernel");
         if (arc != FX3D_OK) return arc;
         hipLaunchKernelGGL(knn_select_kernel, dim3((N + nw - 1) / nw, B), dim3(64 * nw), (size_t)nw * (Mpad + 2 * lcap) * 4, st, x, N, y, M,
-                           B, D, k, drop, idx, dist, Mpad, lcap, nullptr);
+                           B, D, k, drop, idx, dist, Mpad, lcap, nullptr, 0);
         FX3D_LAUNCH_CHECK();
         return FX3D_OK;
     }
@@ -3924,8 +3963,9 @@ fx3d_status fx3d_knn_ws(const float *x, int32_t N, const float *y, int32_t M, in
             const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_select_kernel), kSelMaxLds, "knn_select_kernel");
             if (arc != FX3D_OK) return arc;
             FX3D_REQUIRE(B <= 65535, "fx3d_knn_ws: B=%d exceeds the grid's y range for this shape", B);
-            hipLaunchKernelGGL(knn_select_kernel, dim3((N + nw - 1) / nw, B), dim3(64 * nw), (size_t)nw * (Mpad + 2 * lcap) * 4, as_stream(s), x, N,
-                               y, M, B, D, k, drop, idx, dist, Mpad, lcap, flags);
+            const int regions = nw >= 4 ? 4 : 1;  // key arrays in LDS: one per wave when they fit (many flagged queries), else one
+            hipLaunchKernelGGL(knn_select_kernel, dim3((N + 31) / 32, B), dim3(256), (size_t)regions * (Mpad + 2 * lcap) * 4, as_stream(s), x, N,
+                               y, M, B, D, k, drop, idx, dist, Mpad, lcap, flags, regions);
             FX3D_LAUNCH_CHECK();
         }
         return FX3D_OK;
