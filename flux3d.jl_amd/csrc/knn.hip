@@ -3825,9 +3825,9 @@ bool knn_pre_shape_ok(int M, int D, int kk) {
 // merge -- the kk nearest of the cloud spread over the slices (~kk / S each), so 32 per slice almost always hold them all; the merge
 // checks it per query (knn_merge_slices_kernel) and the flagged queries are answered again by the general selection kernel.
 int knn_wide_slices(int M, int D, int kk) {
-    if (D < 4 || D > 128 || kk <= 32 || kk > 64 || opt(OPT_KNN_NO_MFMA) || opt(OPT_KNN_SLICES) == 1) return 0;
+    if (D < 4 || D > 128 || kk <= 32 || kk > 128 || opt(OPT_KNN_NO_MFMA) || opt(OPT_KNN_SLICES) == 1) return 0;
     const int force = opt(OPT_KNN_SLICES);
-    const int S = force == 2 || force == 4 || force == 8 ? force : (kk <= 45 ? 2 : 4);  // (measured at C4's shape, D = 64, us: kk = 41 / 45 / 49 / 53
+    const int S = kk > 64 ? 8 : (force == 2 || force == 4 || force == 8 ? force : (kk <= 45 ? 2 : 4));  // (65 ... 128: eight slices, ~kk / 8 each)  // (measured at C4's shape, D = 64, us: kk = 41 / 45 / 49 / 53
                                                                                          //  S = 2: 180 / 188 / 219 / 342 -- the flagged queries --, S = 4: 228 flat)
     if (M % S || M / S < 64 || ((size_t)(M / S) * D * 4) % 16 != 0 || knn_select_waves(M) < 1) return 0;
     return S;

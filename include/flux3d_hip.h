@@ -184,7 +184,8 @@ FX3D_API fx3d_status fx3d_chamfer_sampled_bwd(const float *x, int32_t N, const f
  * element: idx:(k,N,B) int32 0-based sorted by (distance, index); dist:(k,N,B) squared distances
  * (optional).  y may equal x (self graph; drop_first=1 drops the rank-0 hit as the reference
  * does).  Any k+drop_first <= M and any D: the matrix-core kernels take k+drop_first <= 32 with M >= 64 (D = 3 and
- * 4 <= D <= 128) and, at D = 3, k+drop_first <= 64 with M >= 128; wave-per-query kernels k+drop_first <= 64 (D up to ~110),
+ * 4 <= D <= 128) and, at D = 3, k+drop_first <= 64 with M >= 128 (fx3d_knn_ws also takes 4 <= D <= 128 up to k+drop_first = 128
+ * there: candidate slices, see below); wave-per-query kernels k+drop_first <= 64 (D up to ~110),
  * a general selection kernel everything else
  * (k+drop_first up to M, any D) for M <= 36864 candidates; beyond that FX3D_ERR_UNSUPPORTED.
  * Order = Julia's isless on the Float32 squared distance, then the lower index: NaN distances (non-finite coordinates)

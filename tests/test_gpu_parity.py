@@ -1231,12 +1231,14 @@ def test_knn_candidate_slices_plan_is_a_function_of_the_shape(gpu_fx):
 @pytest.mark.parametrize("D,N,M,B,k,drop,kind", [(64, 300, 1024, 2, 40, True, "normal"), (64, 257, 512, 1, 63, True, "normal"), (16, 200, 2048, 2, 33, False, "normal"),
                                                   (128, 130, 256, 1, 64, False, "normal"), (64, 200, 1024, 1, 40, False, "sorted"), (32, 150, 1024, 2, 50, True, "sorted"),
                                                   (8, 300, 768, 1, 36, True, "lattice"), (64, 100, 1024, 1, 48, True, "dupes"), (20, 90, 640, 1, 41, False, "normal"),
-                                                  (64, 120, 1024, 1, 40, True, "residue"), (16, 100, 512, 2, 60, False, "residue")])
+                                                  (64, 120, 1024, 1, 40, True, "residue"), (16, 100, 512, 2, 60, False, "residue"),
+                                                  (64, 130, 1024, 2, 64, True, "normal"), (32, 90, 2048, 1, 100, False, "normal"), (16, 70, 512, 1, 128, False, "sorted"),
+                                                  (64, 60, 1024, 1, 127, True, "residue")])
 def test_knn_feature_space_wide_selection(gpu_fx, oracle, D, N, M, B, k, drop, kind):
-    """32 < k + drop <= 64 in feature space (round 3): 2 / 4 candidate slices on the matrix-core kernel (32 nearest per slice), the
+    """32 < k + drop <= 128 in feature space (round 3): 2 / 4 / 8 candidate slices on the matrix-core kernel (32 nearest per slice), the
     verified merge, and the general selection kernel for the flagged queries.  "sorted": the candidates are ordered along the first
     coordinate (index neighbours are spatial neighbours: the slices are interleaved so that each still samples the whole cloud);
-    "residue": the near candidates are exactly the rows with index = 0 mod 4, so ONE interleaved slice holds all of a query's
+    "residue": the near candidates are exactly the rows with index = 0 mod 8, so ONE interleaved slice holds all of a query's
     neighbours and the verification must flag it (every answer then comes from the fallback); lattice / duplicated candidates:
     ties inside and across slices in index order."""
     rng = np.random.default_rng(D * 77 + M + k)
@@ -1248,7 +1250,7 @@ def test_knn_feature_space_wide_selection(gpu_fx, oracle, D, N, M, B, k, drop, k
             y[1:, :, b] *= np.float32(0.05)        # the first coordinate decides: neighbours are index neighbours
         x[1:] *= np.float32(0.05)
     elif kind == "residue":
-        y[:, 0::4, :] *= np.float32(0.01)          # a tight blob around the origin in rows 0, 4, 8, ...; the queries sit there too
+        y[:, 0::8, :] *= np.float32(0.01)          # a tight blob around the origin in rows 0, 8, 16, ... (one slice for S = 2, 4, 8); the queries sit there too
         x *= np.float32(0.01)
     elif kind == "lattice":
         x, y = np.round(x), np.round(y)

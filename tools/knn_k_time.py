@@ -8,6 +8,6 @@ from bench_ops import gpu_time
 rng = np.random.default_rng(5)
 for D in (3, 64):
     x = fx.gpu(np.asfortranarray(rng.standard_normal((D, 1024, 32)).astype(np.float32)))
-    for k in (5, 10, 20, 31, 32, 40, 63, 64, 100):
+    for k in (5, 10, 20, 31, 32, 40, 63, 64, 100, 127, 128):
         mn, md = gpu_time(lambda: fx.knn(x, k, drop_first=True, return_dist=False), reps=8, inner=4)
         print(f"D={D:<3d} B=32 N=1024 k={k:<4d} min {mn:9.1f} us", flush=True)
