@@ -974,7 +974,8 @@ using K3Base = K3Geom<4, 24, 64, 32>;    // k + drop <= 32: C4 gets 256 blocks o
 using K3Wide = K3Geom<2, 40, 128, 64>;   // 32 < k + drop <= 64: twice the keys and longer lists per query, half the queries per block
 // ... and a compact one (round 3) for 32 < k + drop <= 48: an allocation below half a CU's LDS, so that TWO blocks (eight waves) share a
 // CU as in the base geometry -- the wide geometry's four waves leave half of every CU's issue slots empty (C4's shape, k = 40:
-// 52.4 -> 34.8 us) -- for clouds whose image fits next to the keys (<= ~1500 candidates; the raw coordinates stay in L2).  The same
+// 52.4 -> 34.8 us); the LDS image is held to the size of the key arrays (1472 candidates; larger clouds pass through it in
+// chunks), the raw coordinates stay in L2.  The same
 // form of the base geometry (K3Geom<2, 24, 64, 32>, two blocks per CU) measured equal to it (k = 20: 24.8 vs 25.0 us): not kept.
 using K3Mid = K3Geom<2, 28, 88, 48>;
 // (48 < k + drop <= 64 as K3Geom<1, 35, 120, 64>, 32 queries per block and three blocks per CU, measured equal to the wide geometry
@@ -1712,8 +1713,10 @@ fx3d_status launch_knn_f16_d3_geom(const float *x, int N, const float *y, int M,
                                    float *dist, hipStream_t st, float *feat, int layout, int xdiv) {
     int CH = (M + 63) / 64 * 64;
     if (CH > kTChunk) CH = kTChunk;
-    size_t img = (size_t)CH * 32;
     const size_t keys = (size_t)C::G * 32 * C::KS * 8;  // distance bits + indices
+    // (COMPACT: the LDS image no larger than the key arrays -- larger clouds go through it in several chunks)
+    if (COMPACT && (size_t)CH * 32 > keys) CH = (int)(keys / 32 / 64 * 64);
+    size_t img = (size_t)CH * 32;
     if (img < keys) img = keys;
     const size_t fixed = (size_t)C::W * C::CAP * 64 * 4 + (size_t)C::G * 32 * 8 * 4;  // lists (exchange, slots) + counters
     // COMPACT: the whole allocation stays below half a CU's LDS (two blocks per CU); the optional parts only if they fit under that
@@ -1750,7 +1753,9 @@ fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int 
                               float *dist, hipStream_t st, float *feat = nullptr, int layout = 0, int xdiv = 1) {
     const bool compact = !opt(OPT_KNN_D3_NO_COMPACT);
     if (k + drop <= 32) return launch_knn_f16_d3_geom<K3Base>(x, N, y, M, B, k, drop, idx, dist, st, feat, layout, xdiv);
-    if (k + drop <= K3Mid::KKMAX && compact && knn_f16_d3_core_lds<K3Mid>(M) <= k3_compact_lds(2))
+    // (measured, tools/knn_compact_ab.py: 1.3-1.6 x over the wide geometry at M = 1600 ... 8192 too -- several image chunks --, except
+    //  where many queries overflow the 88 keys and fall to the exact merge over a large cloud: k + drop > 44 with M > 4096)
+    if (k + drop <= K3Mid::KKMAX && compact && (k + drop <= 44 || M <= 4096))
         return launch_knn_f16_d3_geom<K3Mid, 2>(x, N, y, M, B, k, drop, idx, dist, st, feat, layout, xdiv);
     return launch_knn_f16_d3_geom<K3Wide>(x, N, y, M, B, k, drop, idx, dist, st, feat, layout, xdiv);
 }

@@ -1158,11 +1158,13 @@ def test_knn_d3_wide_selection(gpu_fx, oracle, M, k, drop, kind):
     assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
 
 
-@pytest.mark.parametrize("M,k,drop", [(1024, 40, True), (1472, 47, False), (1473, 47, True), (130, 33, False), (1024, 48, True)])
+@pytest.mark.parametrize("M,k,drop", [(1024, 40, True), (1472, 47, False), (1473, 47, True), (130, 33, False), (1024, 48, True),
+                                      (3000, 40, True), (5000, 43, True), (5000, 47, False), (4096, 47, True)])
 def test_knn_d3_compact_geometry_against_the_wide_one(gpu_fx, oracle, fx_option, M, k, drop):
-    """32 < k + drop <= 48 on clouds of one small image run the compact geometry (two blocks per CU, raw coordinates from L2, no
-    medium path); the option knn_d3_no_compact keeps the wide one: both bit-identical to the oracle, on both sides of the image
-    limit (1472 candidates) and of k + drop = 48."""
+    """32 < k + drop <= 48 runs the compact geometry (two blocks per CU, raw coordinates from L2, no medium path; clouds beyond 1472
+    candidates pass through its LDS image in chunks; k + drop > 44 on clouds beyond 4096 stays on the wide one); the option
+    knn_d3_no_compact keeps the wide one: both bit-identical to the oracle, on both sides of the chunk limit, of k + drop = 44 / 48
+    and of M = 4096."""
     rng = np.random.default_rng(M + k)
     x = np.asfortranarray(rng.random((3, 200, 2), dtype=np.float32))
     y = rng.random((3, M, 2), dtype=np.float32)

@@ -1,4 +1,4 @@
-"""kNN (k = 20, self, drop first) at the C4 shapes (B = 32 x 1024; D = 3 and D = 64) on data distributions that stress
+"""kNN (k = 20 -- or env K --, self, drop first) at the C4 shapes (B = 32 x 1024; D = 3 and D = 64) on data distributions that stress
 the filter's band and the survivor lists: uniform / Gaussian, offset, tight clusters, lattice (exact ties), duplicated
 points, a far outlier.  Prints microseconds per call.   python tools/knn_distribution_time.py"""
 import os
@@ -9,9 +9,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import flux3d_jl_amd as fx  # noqa: E402
+from flux3d_jl_amd import _lib  # noqa: E402
+K = int(os.environ.get("K", "20"))
 
 rng = np.random.default_rng(9)
-B, N = 32, 1024
+B, N = int(os.environ.get("B", "32")), int(os.environ.get("N", "1024"))
 
 
 def make(kind, D):
@@ -41,14 +43,14 @@ for D in (3, 64):
     for kind in ("uniform", "normal", "normal+100", "clusters", "lattice", "dupes", "outlier"):
         dx = fx.gpu(np.asfortranarray(make(kind, D).astype(np.float32)))
         for _ in range(5):
-            fx.knn(dx, 20, drop_first=True, return_dist=False)
+            fx.knn(dx, K, drop_first=True, return_dist=False)
         fx.synchronize()
         best = 1e30
         for _ in range(4):  # min of four groups of five back-to-back calls (the first group of a process pays one-time set-up)
             e0, e1 = fx.Event(), fx.Event()
             e0.record()
             for _ in range(5):
-                fx.knn(dx, 20, drop_first=True, return_dist=False)
+                fx.knn(dx, K, drop_first=True, return_dist=False)
             e1.record()
             e1.synchronize()
             best = min(best, e0.elapsed_ms(e1) * 200)
