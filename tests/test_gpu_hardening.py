@@ -128,6 +128,24 @@ def test_knn_nonfinite(gpu_fx, oracle, case, D, N, k, drop):
         assert np.array_equal(dist.to_host(), od, equal_nan=True)
 
 
+@pytest.mark.parametrize("case", NONFINITE)
+@pytest.mark.parametrize("D,N,k,drop,slices", [(64, 1024, 20, True, 2), (64, 1024, 40, True, 0), (16, 512, 100, False, 0), (3, 8192, 20, True, 2),
+                                                (3, 1024, 40, True, 0), (3, 2048, 47, False, 0)])
+def test_knn_nonfinite_through_slices_and_wide_geometries(gpu_fx, oracle, fx_option, case, D, N, k, drop, slices):
+    """Non-finite clouds through the round-3 paths: candidate slices (the merge compares canonical distance keys: NaN after +Inf,
+    then the index), the verified merge with its selection fallback (k + drop > 32 in feature space), the wide / compact D = 3
+    geometries.  Bit-identical to the oracle, every index valid."""
+    with np.errstate(all="ignore"):
+        x, _ = _nonfinite_case(case, N, N, 1, 7 * D + k, D=D)
+        fx_option("knn_slices", str(slices))
+        idx, dist = gpu_fx.knn(x, k, drop_first=drop)
+        oi, od = oracle.knn(x, k, drop_first=drop)
+        gi = idx.to_host()
+        assert gi.min() >= 0 and gi.max() < N
+        assert np.array_equal(gi, oi), np.argwhere(gi != oi)[:5]
+        assert np.array_equal(dist.to_host(), od, equal_nan=True)
+
+
 # ------------------------------------------------------------------------------ directed near-ties at the band edge
 def _near_tie_clouds(scale_exp, offset, M=4096, nq=512, seed=0):
     """Queries with two nearest candidates whose EXACT Float32 distances differ by 0, 1, 2 ulp (and by relative 2^-18 ..
