@@ -235,3 +235,30 @@ def test_option_api_without_a_gpu(fx):
     with _lib.option("knn_gather", 1):
         assert _lib.get_option("knn_gather") == 1
     assert _lib.get_option("knn_gather") == 0
+
+
+def test_knn_scratch_plan_without_a_gpu(fx):
+    """fx3d_knn_workspace_bytes is a function of the shape, the CU count (256 when no device is visible) and the options: zero for the
+    BASELINE D = 3 shape, the pre-pass slabs for C4', slice lists for few clouds with many rows, slices + flags + the interleaved copy
+    for k + drop in 33 ... 128 in feature space; option knn_slices = 1 switches every slicing off."""
+    import ctypes as C
+    from flux3d_jl_amd import _lib
+    lib = _lib.load()
+
+    def ws(N, M, B, D, k, drop):
+        nb = C.c_size_t(0)
+        assert lib.fx3d_knn_workspace_bytes(N, M, B, D, k, drop, C.byref(nb)) == 0
+        return nb.value
+
+    assert ws(1024, 1024, 32, 3, 20, 1) == 0
+    c4p = ws(1024, 1024, 32, 64, 20, 1)
+    assert 32 * 1024 * 64 * 2 < c4p < 3 * 32 * 1024 * 64 * 2                    # the fp16 images + norms + statistics
+    one = ws(8192, 8192, 1, 64, 20, 1)
+    assert one > 8192 * 64 * 2 + 2 * 2 * 21 * 8192 * 4                          # images of the virtual clouds + >= 2 slices' lists
+    wide = ws(1024, 1024, 32, 64, 40, 1)
+    assert wide > 1024 * 64 * 32 * 4 + 2 * 2 * 32 * 1024 * 32 * 4               # interleaved copy + two slices' lists of 32
+    assert ws(1024, 1023, 32, 64, 40, 1) == 0                                    # an odd cloud cannot be sliced: the wave kernels
+    with _lib.option("knn_slices", 1):
+        assert ws(8192, 8192, 1, 64, 20, 1) == 0                                 # M > 4096 without slices: no pre-pass either
+        assert ws(1024, 1024, 32, 64, 40, 1) == 0
+        assert ws(1024, 1024, 32, 64, 20, 1) == c4p
