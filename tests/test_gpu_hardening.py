@@ -897,6 +897,14 @@ def test_host_pointer_convenience_variants(gpu_fx, oracle):
                                      int(y is None), p(idx), p(dist)))
         oi, od = oracle.knn(x, k, y=y, drop_first=y is None)
         assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    # ... and through the scratch-fed paths of fx3d_knn_ws (the host variant brings its own scratch): candidate slices of one large
+    # cloud, k + drop > 32 in feature space (interleaved slices, verified merge), the wide D = 3 geometry
+    for D, N, B, k2 in ((64, 4096, 1, 20), (32, 1024, 2, 50), (3, 1024, 2, 60)):
+        x = np.asfortranarray(rng.standard_normal((D, N, B)).astype(np.float32))
+        idx, dist = np.zeros((k2, N, B), np.int32, order="F"), np.zeros((k2, N, B), np.float32, order="F")
+        _lib.check(lib.fx3d_knn_host(p(x), N, None, 0, B, D, k2, 1, p(idx), p(dist)))
+        oi, od = oracle.knn(x, k2, drop_first=True)
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od)
     m = fx.load_trimesh(os.path.join(GOLDEN, "teapot.obj"), os.path.join(GOLDEN, "sphere.obj"))
     vp = m.get_verts_padded_host()
     fp0 = np.asfortranarray(m.get_faces_padded().astype(np.int32) - 1)
