@@ -155,7 +155,7 @@ def main():
             F = int(rng.choice([3, 3, 16, 64]))
             N = int(rng.integers(70, 700))
             K = int(rng.integers(1, 31))
-            if F == 3 and rng.random() < 0.3:
+            if rng.random() < 0.3:  # (round 3) k + 1 in 33 ... 64: the wide / compact D = 3 geometries, the verified slices in feature space
                 K = int(rng.integers(31, 64))
             x = cloud(rng, F, N, B, kind)
             desc = f"edgeconv {kind} F={F} N={N} B={B} K={K}"
