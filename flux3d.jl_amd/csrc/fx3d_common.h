@@ -83,6 +83,7 @@ enum Opt {
     OPT_KNN_SLICES,           // fx3d_knn_ws: candidate slices per cloud: 0 = automatic, 1 = never, 2 / 4 / 8 = forced
     OPT_EDGE_SCALAR_STORES,   // 1: edge features written with 4-byte stores
     OPT_EDGECONV_UNFUSED,     // 1: EdgeConv graph build as search + feature kernels
+    OPT_LAP_BWD_SCATTER,      // 1: fx3d_laplacian_loss_bwd as the scatter with float atomics (any CSR) instead of the gather (symmetric structure)
     OPT_CDF_MULTIBLOCK_FROM,  // faces per mesh from which the sampling CDF takes the multi-block path (0 = the built-in limit)
     OPT_COUNT
 };

@@ -190,6 +190,90 @@ __global__ __launch_bounds__(kThreads) void laplacian_loss_bwd_kernel(
     }
 }
 
+// The same adjoint WITHOUT float atomics and without scratch (round 3), bit-identical to the oracle's row-by-row scatter.  Vertex i
+// receives (c L[r,i]) u_r from every row r that holds column i -- for a structurally symmetric L (the Laplacian of an undirected
+// edge list) these are the columns of ITS OWN row, and ascending columns are the order in which the scatter reaches it.  A block takes
+// kLapRows consecutive vertices; one THREAD PER ENTRY (i, r) of their rows recomputes u_r (the row sum of r: two dependent round
+// trips, as in the forward) and picks L[r,i] up on the way, the contributions wait in LDS, and one thread per vertex adds its
+// row's contributions in column order.  (A thread per vertex walking its neighbours' rows one after the other took 38 us on eight
+// teapots -- a chain of ~20 round trips --, the scatter with its memset 14.7.)
+constexpr int kLapRows = 32;
+__global__ __launch_bounds__(kThreads) void laplacian_loss_bwd_gather_kernel(
+    const float *__restrict__ verts, long long V, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+    const float *__restrict__ vals, float c, float *gverts, int accumulate) {
+    __shared__ float contrib[kThreads][3];
+    __shared__ int erow[kThreads];      // row (relative to the block's first) of the entry a thread handles
+    __shared__ float acc[kLapRows][3];
+    const long long i0 = (long long)blockIdx.x * kLapRows;
+    const int nr = V - i0 < kLapRows ? (int)(V - i0) : kLapRows;
+    const int tid = threadIdx.x;
+    const int e_lo = rowptr[i0], e_hi = rowptr[i0 + nr];
+    if (tid < kLapRows) { acc[tid][0] = 0.0f; acc[tid][1] = 0.0f; acc[tid][2] = 0.0f; }
+    for (int base = e_lo; base < e_hi; base += kThreads) {  // (one pass unless the rows are unusually long)
+        __syncthreads();
+        if (tid < nr) {  // the rows mark their entries of this pass
+            const int k0 = rowptr[i0 + tid] > base ? rowptr[i0 + tid] : base;
+            const int k1 = rowptr[i0 + tid + 1] < base + kThreads ? rowptr[i0 + tid + 1] : base + kThreads;
+            for (int k = k0; k < k1; ++k) erow[k - base] = tid;
+        }
+        __syncthreads();
+        const int k = base + tid;
+        float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f;
+        if (k < e_hi) {
+            const long long i = i0 + erow[tid], r = colind[k];
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, wri = 0.0f;
+            bool has = false;
+            const int q1 = rowptr[r + 1];
+            for (int q0 = rowptr[r]; q0 < q1; q0 += 8) {  // row r as in lap_row: weights and columns, then the gathers, then the sums
+                float w[8];
+                int col[8];
+                P3 v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int q = q0 + e < q1 ? q0 + e : q1 - 1;
+                    w[e] = vals[q];
+                    col[e] = colind[q];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const P3 *>(verts + 3ll * col[e]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (q0 + e < q1) {
+                        s0 = s0 + w[e] * v[e].x;
+                        s1 = s1 + w[e] * v[e].y;
+                        s2 = s2 + w[e] * v[e].z;
+                        if (col[e] == (int)i) { wri = w[e]; has = true; }
+                    }
+            }
+            const float nrm = sqrtf(((s0 * s0) + (s1 * s1)) + (s2 * s2));
+            if (has && nrm > 0.0f) {
+                const float cw = c * wri;
+                x0 = cw * (s0 / nrm); x1 = cw * (s1 / nrm); x2 = cw * (s2 / nrm);
+            } else {
+                has = false;
+            }
+            erow[tid] = has ? erow[tid] : -1 - erow[tid];  // (a row of zero norm / a missing transpose entry contributes nothing: skipped, not added as 0)
+        }
+        contrib[tid][0] = x0; contrib[tid][1] = x1; contrib[tid][2] = x2;
+        __syncthreads();
+        if (tid < nr) {  // in column order
+            const int k0 = rowptr[i0 + tid] > base ? rowptr[i0 + tid] : base;
+            const int k1 = rowptr[i0 + tid + 1] < base + kThreads ? rowptr[i0 + tid + 1] : base + kThreads;
+            float a0 = acc[tid][0], a1 = acc[tid][1], a2 = acc[tid][2];
+            for (int kk = k0; kk < k1; ++kk)
+                if (erow[kk - base] >= 0) { a0 = a0 + contrib[kk - base][0]; a1 = a1 + contrib[kk - base][1]; a2 = a2 + contrib[kk - base][2]; }
+            acc[tid][0] = a0; acc[tid][1] = a1; acc[tid][2] = a2;
+        }
+    }
+    __syncthreads();
+    if (tid < nr) {
+        const long long i = i0 + tid;
+        gverts[3 * i] = accumulate ? gverts[3 * i] + acc[tid][0] : acc[tid][0];
+        gverts[3 * i + 1] = accumulate ? gverts[3 * i + 1] + acc[tid][1] : acc[tid][1];
+        gverts[3 * i + 2] = accumulate ? gverts[3 * i + 2] + acc[tid][2] : acc[tid][2];
+    }
+}
+
 // ---- both mesh losses in ONE launch, both adjoints in ONE gather launch (the fit_mesh regularisers,
 //      examples/fit_mesh.jl:80-83: 0.1 laplacian_loss + edge_loss, launch bound at teapot scale) -----------------------
 // Forward: blocks [0, gV) take Laplacian rows, blocks [gV, gV + gE) take edges; every block publishes one Float64
@@ -599,8 +683,13 @@ fx3d_status fx3d_laplacian_loss_bwd(const float *verts, int64_t V, const int32_t
     FX3D_REQUIRE(verts && rowptr && colind && vals && gverts, "fx3d_laplacian_loss_bwd: null pointer");
     FX3D_REQUIRE(V > 0, "fx3d_laplacian_loss_bwd: bad V");
     hipStream_t st = as_stream(s);
-    // scatter form (float atomics): this entry point has no scratch for the unit rows the gather form needs;
-    // fx3d_mesh_losses_bwd is the atomic-free, bit-reproducible route
+    if (!opt(OPT_LAP_BWD_SCATTER)) {  // gather form: one launch, no atomics, bit-identical to the oracle (structurally symmetric L)
+        hipLaunchKernelGGL(laplacian_loss_bwd_gather_kernel, dim3((unsigned int)((V + kLapRows - 1) / kLapRows)), dim3(kThreads), 0, st, verts,
+                           (long long)V, rowptr, colind, vals, gout / (float)V, gverts, accumulate);
+        FX3D_LAUNCH_CHECK();
+        return FX3D_OK;
+    }
+    // scatter form (float atomics; any CSR): the last bit depends on the atomics' arrival order
     if (!accumulate) FX3D_HIP(hipMemsetAsync(gverts, 0, sizeof(float) * 3 * (size_t)V, st));
     hipLaunchKernelGGL(laplacian_loss_bwd_kernel, dim3(grid_for(V)), dim3(kThreads), 0, st, verts,
                        (long long)V, rowptr, colind, vals, gout / (float)V, gverts);

@@ -42,6 +42,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"knn_slices", "FX3D_KNN_SLICES", 0},
     {"edge_scalar_stores", "FX3D_EDGE_SCALAR_STORES", 0},
     {"edgeconv_unfused", "FX3D_EDGECONV_UNFUSED", 0},
+    {"lap_bwd_scatter", "FX3D_LAP_BWD_SCATTER", 0},
     {"cdf_multiblock_from", "FX3D_CDF_MULTIBLOCK_FROM", 0},
 };
 std::atomic<int> g_opt[OPT_COUNT];

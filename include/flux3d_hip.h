@@ -59,7 +59,7 @@ FX3D_API size_t fx3d_last_error(char *buf, size_t n); /* thread-local message; r
 /* ---- variant switches --------------------------------------------------------------------------------------------
  * The kernels' alternative code paths (A/B measurements, tests) are chosen by named integer options, process-wide and
  * atomic: nn1_variant (3 | 0), nn1_tpb, nn1_nosplit, bwd_global_atomics, knn_f32, knn_f16_split, knn_no_mfma,
- * knn_no_prepass, knn_prepass_fused, knn_gather, knn_d3_wave, knn_d3_no_compact, knn_slices, edge_scalar_stores, edgeconv_unfused, cdf_multiblock_from
+ * knn_no_prepass, knn_prepass_fused, knn_gather, knn_d3_wave, knn_d3_no_compact, knn_slices, lap_bwd_scatter, edge_scalar_stores, edgeconv_unfused, cdf_multiblock_from
  * (fx3d_option_count / fx3d_option_name enumerate them).  The environment variables FX3D_<NAME> only seed the defaults,
  * once, at the first use of the library; no entry point reads the environment on its launch path.  A host that runs two
  * configurations in one process sets the option before the calls that need it. */
@@ -347,6 +347,10 @@ FX3D_API fx3d_status fx3d_laplacian_loss(const float *verts, int64_t V, const in
                                          const int32_t *colind, const float *vals,
                                          float *loss_dev, float *loss_host, void *ws,
                                          size_t ws_bytes, fx3d_stream_t s);
+/* d laplacian_loss / d verts * gout -> gverts (3,V) (added when accumulate != 0).  Gathered per vertex in the order of the
+ * reference's row-by-row accumulation: one launch, no float atomics, bit-identical run to run and to the CPU restatement.  The
+ * gather needs a structurally symmetric L (i in row r <=> r in row i: the Laplacian of an undirected edge list is); option
+ * "lap_bwd_scatter" = 1 selects the scatter with float atomics, which takes any CSR. */
 FX3D_API fx3d_status fx3d_laplacian_loss_bwd(const float *verts, int64_t V, const int32_t *rowptr,
                                              const int32_t *colind, const float *vals, float gout,
                                              float *gverts, int32_t accumulate, fx3d_stream_t s);

@@ -591,6 +591,25 @@ def test_knn_ws_entry_point_contract(gpu_fx, oracle):
         assert np.array_equal(dist.to_host(), od, equal_nan=True)
 
 
+def test_laplacian_loss_grad_gather_is_bit_identical_to_the_oracle(gpu_fx, oracle, fx_option):
+    """fx3d_laplacian_loss_bwd (round 3): the gather form -- one launch, no float atomics -- returns the oracle's bits (the order in
+    which its row-by-row scatter reaches a vertex) on a ragged batch with isolated and degenerate vertices, and the same bits
+    run after run; the scatter form (option lap_bwd_scatter) stays within rounding of it."""
+    fx = gpu_fx
+    m = fx.load_trimesh(os.path.join(GOLDEN, "teapot.obj"), os.path.join(GOLDEN, "sphere.obj"), os.path.join(GOLDEN, "teapot.obj"))
+    v = m.get_verts_packed_host()
+    rp, ci, va = m.get_laplacian_packed()
+    ol = oracle.laplacian_loss_bwd(v, rp.astype(np.int64), ci.astype(np.int64), va, 0.7)
+    md = fx.gpu(m)
+    g1 = fx.laplacian_loss_grad(md, 0.7).to_host()
+    assert np.array_equal(g1, ol)
+    for _ in range(3):
+        assert np.array_equal(fx.laplacian_loss_grad(md, 0.7).to_host(), g1)
+    fx_option("lap_bwd_scatter", "1")
+    gs = fx.laplacian_loss_grad(md, 0.7).to_host()
+    assert np.allclose(gs, ol, rtol=1e-4, atol=1e-9)
+
+
 def test_knn_prepass_one_launch_form(gpu_fx, oracle, fx_option):
     """Option knn_prepass_fused: statistics and image of the pre-pass in one launch, the eight part blocks of a cloud meeting through
     the slab's generation word and slots (device-coherent accesses, no fences).  Same results as the two-launch form, call after
