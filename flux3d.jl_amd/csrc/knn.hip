@@ -10,11 +10,17 @@
 //   knn_wave_d3_kernel / knn_wave_generic_kernel   one wave per query, exact distances: every shape the two below do not take
 //   knn_exact_bruteforce / knn_rank_ties           wave-cooperative exact selection / tie re-rank shared by all kernels
 //   knn_gather[4]_kernel                           X[:, idx] (src/models/dgcnn.jl:6)
-//   knn_f16_d3_kernel<FEAT>                        D = 3, k+drop <= 32, M >= 64: fp16-split matrix-core filter + exact re-scan;
+//   knn_select_kernel                              any k + drop <= M, any D (M <= 36864): all keys of a query in LDS, radix select;
+//                                                  also the fallback of the verified slice merge (flagged queries only)
+//   knn_f16_d3_kernel<FEAT, K3Geom>                D = 3: fp16-split matrix-core filter + exact re-scan in three geometries --
+//                                                  base (k+drop <= 32, M >= 64), compact (<= 48, two blocks per CU), wide (<= 64);
 //                                                  FEAT: EdgeConv's cat(X, KNN - X) written by the same kernel
-//   knn_mfma_kernel<DK, F16, SPLIT>                4 <= D <= 128, k+drop <= 32, M >= 64: GEMM filter (fp16 rounded halves, 2-way
+//   knn_pre_*_kernel                               fx3d_knn_ws: per-cloud statistics + fp16 image built once (feature space)
+//   knn_mfma_kernel<DK, F16, SPLIT, PRE>           4 <= D <= 128, k+drop <= 32, M >= 64: GEMM filter (fp16 rounded halves, 2-way
 //                                                  fp16 split, or Float32) + exact re-scan, medium path for crowded bands
 //   edge_features_*_kernel                         cat(X, KNN - X) + permute for any F, and the @nograd adjoint
+//   knn_interleave_kernel / knn_merge_slices_kernel  fx3d_knn_ws: candidate slices as virtual clouds (few clouds with many rows;
+//                                                  k+drop in 33 ... 128 in feature space: 32 nearest per slice, verified merge)
 #include <cmath>
 #include <cstdlib>
 
