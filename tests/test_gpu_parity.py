@@ -821,6 +821,43 @@ def test_graph_capture_with_a_forked_stream_releases_without_synchronising(gpu_f
     assert np.array_equal(out.to_host(), 2.0 * a.to_host() + 4.0)
 
 
+def test_knn_scratch_paths_replay_in_a_graph(gpu_fx, oracle):
+    """The multi-kernel kNN paths of fx3d_knn_ws -- pre-pass + search, candidate slices + merge, interleave + slices + verified
+    merge + selection fallback -- recorded into a hipGraph after one eager call (workspaces and kernel attributes in place) and
+    replayed: the same neighbour lists as the oracle, replay after replay (the pre-pass meeting words, the flags and the slice
+    lists live in the scratch the recording owns)."""
+    fx = gpu_fx
+    rng = np.random.default_rng(41)
+    cases = [(np.asfortranarray(rng.standard_normal((64, 512, 3)).astype(np.float32)), 20),    # pre-pass
+             (np.asfortranarray(rng.standard_normal((32, 2048, 1)).astype(np.float32)), 12),   # candidate slices
+             (np.asfortranarray(rng.standard_normal((16, 512, 2)).astype(np.float32)), 40),    # verified merge
+             (np.asfortranarray(rng.random((3, 700, 2), dtype=np.float32)), 40)]               # compact D = 3 geometry
+    s = fx.Stream.create()
+    with fx.stream(s):
+        devs = [fx.gpu(x) for x, _ in cases]
+        outs = [fx.DeviceArray.empty((k, x.shape[1], x.shape[2]), np.int32) for x, k in cases]
+
+        from flux3d_jl_amd import _lib
+
+        def step():
+            for d, (x, k), o in zip(devs, cases, outs):
+                idx = fx.knn(d, k, drop_first=True, return_dist=False)
+                _lib.call("fx3d_memcpy_d2d", o.ptr, idx.ptr, o.nbytes, s.handle)
+
+        step()
+        s.synchronize()
+        g = fx.Graph()
+        with g.capture(s):
+            step()
+        for _ in range(3):
+            for o in outs:
+                _lib.call("fx3d_memset", o.ptr, 0, o.nbytes, s.handle)
+            g.launch()
+            s.synchronize()
+            for (x, k), o in zip(cases, outs):
+                assert np.array_equal(o.to_host(), oracle.knn(x, k, drop_first=True, want_dist=False))
+
+
 # ------------------------------------------------------------------- widened rows: EdgeConv features, voxels
 @pytest.mark.parametrize("F,N,B,K", [(3, 256, 3, 10), (64, 128, 2, 20), (6, 70, 2, 5)])
 def test_edge_features_parity(gpu_fx, oracle, F, N, B, K):
