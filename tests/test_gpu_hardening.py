@@ -971,3 +971,35 @@ def test_sample_points_pair_is_two_sample_points(gpu_fx):
     whole = fx.chamfer_distance(m1, m2, 5000, seed=123)
     parts = fx.chamfer_distance(fx.sample_points(m1, 5000, seed=123), fx.sample_points(m2, 5000, seed=124))
     assert whole == parts
+
+
+@pytest.mark.gpu
+def test_bench_line_force_dist_equals_plain_and_roofline_is_a_fraction(gpu_fx):
+    """(a) the bench line's `roofline.frac` is the fraction of the bound it names (f16 MFMA pipe, peak 2500 TF;
+    no field called *frac above 1; the algorithmic-fp32 figure only as a named extra); (b) `--gpus 1 --force-dist` (RCCL
+    communicator + collectives at world size 1) reports the same loss, n_gpus and workload as the plain line; (c) `--gpus 2`
+    on this one-GPU box ends non-zero without printing a line."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    common = ["--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-extras", "--burn-ms", "20"]
+
+    def line(extra):
+        r = subprocess.run([sys.executable, bench, "--gpus", "1"] + common + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    plain, forced = line([]), line(["--force-dist", "--mode", "serial"])
+    for out in (plain, forced):
+        roof = out["roofline"]
+        assert out["n_gpus"] == 1 and roof["bound"] == "mfma" and roof["peak"] == 2500.0 and roof["unit"] == "TFLOP/s"
+        assert 0.05 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+        assert all(v is None or v <= 1.0 for k, v in roof.items() if k.endswith("frac"))
+        assert roof["algorithmic_fp32_over_valu_peak"] > 0
+    assert np.float32(plain["loss"]) == np.float32(forced["loss"])
+    assert plain["config"]["workload"] == forced["config"]["workload"] and forced["comm"]["nranks"] == 1
+    assert 0.5 < forced["value"] / plain["value"] < 2.0
+    if gpu_fx.device_count() < 2:
+        r = subprocess.run([sys.executable, bench, "--gpus", "2"] + common, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "n_gpus" not in r.stdout

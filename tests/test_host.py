@@ -262,3 +262,21 @@ def test_knn_scratch_plan_without_a_gpu(fx):
         assert ws(8192, 8192, 1, 64, 20, 1) == 0                                 # M > 4096 without slices: no pre-pass either
         assert ws(1024, 1024, 32, 64, 40, 1) == 0
         assert ws(1024, 1024, 32, 64, 20, 1) == c4p
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """VERDICT r3 #1b: `python bench.py --gpus N` with no launcher must run N ranks or FAIL -- never print a line whose n_gpus
+    differs from --gpus.  On a box with fewer than N devices (this container has none) the launcher exits non-zero before any
+    JSON line exists; a WORLD_SIZE that contradicts --gpus is refused too."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "64", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout and "device(s) visible" in r.stderr, (r.returncode, r.stdout, r.stderr)
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=dict(env, WORLD_SIZE="1"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout and "WORLD_SIZE=1" in r.stderr, (r.returncode, r.stdout, r.stderr)
+    r = subprocess.run([sys.executable, bench, "--gpus", "0"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout
