@@ -493,8 +493,7 @@ def protocol_numbers(fx, x, y):
     fwd = _per_call_ms(fx, lambda: fx.chamfer_distance(x, y, loss_out=loss_dev, sync=False))
 
     def fb():
-        _, ix, iy = fx.chamfer_distance(x, y, return_indices=True, loss_out=loss_dev, sync=False)
-        fx.chamfer_distance_grad(x, y, ix, iy)
+        fx.chamfer_value_and_grad(x, y, loss_out=loss_dev, sync=False)   # one ABI call: forward with indices + adjoint
     fwdbwd = _per_call_ms(fx, fb)
     pairs = B_PER_GPU * NPTS * MPTS
     return {"forward": dict(fwd, pairs_per_s_at_min=pairs / (fwd["min_ms"] * 1e-3)),
@@ -614,9 +613,8 @@ def reference_harness(fx):
         row = {}
         f = _per_call_ms(fx, lambda: fx.chamfer_distance(p, p, loss_out=loss_dev, sync=False))
 
-        def cfb():
-            _, ix, iy = fx.chamfer_distance(p, p, return_indices=True, loss_out=loss_dev, sync=False)
-            fx.chamfer_distance_grad(p, p, ix, iy)
+        def cfb():  # `gradient(...)`: value and gradient in ONE ABI call (fx3d_chamfer_fwd_bwd; two calls left the device idle
+            fx.chamfer_value_and_grad(p, p, loss_out=loss_dev, sync=False)   # between the launches: "back" 25-31 us in round 3)
         t = _per_call_ms(fx, cfb)
         row["chamfer_distance"] = {"forward_ms": f["min_ms"], "total_ms": t["min_ms"], "back_ms": t["min_ms"] - f["min_ms"],
                                    "roofline": _roof(f["min_ms"], flops=16.0 * n * n, nbytes=4.0 * 3 * 2 * n)}

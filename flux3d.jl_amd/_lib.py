@@ -72,6 +72,9 @@ SIGNATURES = {
                                        vp, sz, vp],
     "fx3d_chamfer_bwd": [vp, c_i32, vp, c_i32, c_i32, c_i32, vp, vp, c_f32, c_f32, c_f32, c_i64,
                          vp, vp, vp],
+    "fx3d_chamfer_fwd_bwd_workspace_bytes": [c_i32, c_i32, c_i32, c_i32, C.POINTER(sz)],
+    "fx3d_chamfer_fwd_bwd": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_i64, vp, C.POINTER(c_f32),
+                             vp, vp, vp, vp, vp, sz, vp],
     "fx3d_chamfer_sampled_bwd": [vp, c_i32, vp, c_i32, c_i32, vp, vp, c_f32, c_f32, c_f32, c_i64,
                                  vp, c_i32, c_i32, vp, vp, vp, vp, vp, c_i32, c_i32, vp, vp, vp, vp, c_i32, vp],
     "fx3d_knn": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, vp, vp],
@@ -103,8 +106,10 @@ SIGNATURES = {
     "fx3d_mesh_loss_workspace_bytes": [c_i64, C.POINTER(sz)],
     "fx3d_edge_loss": [vp, c_i64, vp, c_i64, c_f32, vp, C.POINTER(c_f32), vp, sz, vp],
     "fx3d_edge_loss_bwd": [vp, c_i64, vp, c_i64, c_f32, c_f32, vp, c_i32, vp],
+    "fx3d_edge_loss_bwd_adj": [vp, c_i64, vp, vp, c_i64, c_f32, c_f32, vp, c_i32, vp],
     "fx3d_laplacian_loss": [vp, c_i64, vp, vp, vp, vp, C.POINTER(c_f32), vp, sz, vp],
     "fx3d_laplacian_loss_bwd": [vp, c_i64, vp, vp, vp, c_f32, vp, c_i32, vp],
+    "fx3d_laplacian_loss_bwd_sym": [vp, c_i64, vp, vp, vp, c_f32, vp, c_i32, vp, vp],
     "fx3d_mesh_losses_workspace_bytes": [c_i64, c_i64, C.POINTER(sz)],
     "fx3d_mesh_losses": [vp, c_i64, vp, vp, vp, vp, c_i64, c_f32, c_f32, c_f32, vp, vp, vp, vp, vp, sz, vp],
     "fx3d_mesh_losses_bwd": [vp, c_i64, vp, vp, vp, c_i64, c_f32, c_f32, c_f32, c_i32, vp, c_i32, vp, sz, vp],

@@ -1753,6 +1753,52 @@ fx3d_status fx3d_chamfer_sampled_bwd(const float *x, int32_t N, const float *y, 
     return FX3D_OK;
 }
 
+// Value AND gradient in one ABI call (the shape of `gradient(() -> chamfer_distance(A, B), ...)`, benchmarks/metrics.jl:24-38,
+// examples/fit_mesh.jl:106-110): the forward with indices and the adjoint are queued back to back on the stream, the
+// nearest-neighbour indices stay in the caller's scratch (or go to idx_x / idx_y when the caller wants them).  Two ABI calls
+// leave the device idle between the launches for as long as the host needs for the second call.
+fx3d_status fx3d_chamfer_fwd_bwd_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_t D, size_t *bytes) {
+    FX3D_REQUIRE(bytes, "fx3d_chamfer_fwd_bwd_workspace_bytes: null output");
+    size_t fwd = 0;
+    const fx3d_status rc = fx3d_chamfer_workspace_bytes(N, M, B, D, &fwd);
+    if (rc) return rc;
+    fwd = (fwd + 255) & ~(size_t)255;
+    *bytes = fwd + ((sizeof(int32_t) * (size_t)B * ((size_t)N + M) + 255) & ~(size_t)255);
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_chamfer_fwd_bwd(const float *x, int32_t N, const float *y, int32_t M, int32_t B, int32_t D, float w1,
+                                 float w2, float gout, int64_t B_global, float *loss_dev, float *loss_host, float *gx,
+                                 float *gy, int32_t *idx_x, int32_t *idx_y, void *ws, size_t ws_bytes, fx3d_stream_t s) {
+    fx3d_status rc = check_shapes("fx3d_chamfer_fwd_bwd", x, N, y, M, B, D);
+    if (rc) return rc;
+    FX3D_REQUIRE(loss_dev && gx && gy, "fx3d_chamfer_fwd_bwd: null output pointer");
+    FX3D_REQUIRE(B_global >= B, "fx3d_chamfer_fwd_bwd: B_global < B");
+    size_t fwd = 0, need = 0;
+    rc = fx3d_chamfer_workspace_bytes(N, M, B, D, &fwd);
+    if (rc) return rc;
+    fx3d_chamfer_fwd_bwd_workspace_bytes(N, M, B, D, &need);
+    fwd = (fwd + 255) & ~(size_t)255;
+    if (!ws || ws_bytes < need) {
+        set_error("fx3d_chamfer_fwd_bwd: workspace too small (%zu < %zu bytes)", ws ? ws_bytes : (size_t)0, need);
+        return FX3D_ERR_WORKSPACE;
+    }
+    int32_t *ix = reinterpret_cast<int32_t *>(static_cast<char *>(ws) + fwd);
+    int32_t *iy = ix + (size_t)B * N;
+    if (idx_x) ix = idx_x;
+    if (idx_y) iy = idx_y;
+    rc = chamfer_common(x, N, y, M, B, D, nullptr, loss_dev, (long long)B_global, w1, w2, ix, iy, ws, fwd, as_stream(s),
+                        "fx3d_chamfer_fwd_bwd");
+    if (rc) return rc;
+    rc = fx3d_chamfer_bwd(x, N, y, M, B, D, ix, iy, w1, w2, gout, B_global, gx, gy, s);
+    if (rc) return rc;
+    if (loss_host) {
+        FX3D_HIP(hipMemcpyAsync(loss_host, loss_dev, sizeof(float), hipMemcpyDeviceToHost, as_stream(s)));
+        FX3D_HIP(hipStreamSynchronize(as_stream(s)));
+    }
+    return FX3D_OK;
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------

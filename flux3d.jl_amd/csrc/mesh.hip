@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kThreads) void laplacian_loss_bwd_kernel(
 constexpr int kLapRows = 32;
 __global__ __launch_bounds__(kThreads) void laplacian_loss_bwd_gather_kernel(
     const float *__restrict__ verts, long long V, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
-    const float *__restrict__ vals, float c, float *gverts, int accumulate) {
+    const float *__restrict__ vals, float c, float *gverts, int accumulate, unsigned int *missing) {
     __shared__ float contrib[kThreads][3];
     __shared__ int erow[kThreads];      // row (relative to the block's first) of the entry a thread handles
     __shared__ float acc[kLapRows][3];
@@ -246,6 +246,9 @@ __global__ __launch_bounds__(kThreads) void laplacian_loss_bwd_gather_kernel(
                     }
             }
             const float nrm = sqrtf(((s0 * s0) + (s1 * s1)) + (s2 * s2));
+            // L[i,r] is stored but L[r,i] is not: the precondition (structural symmetry) does not hold; the contribution this
+            // form cannot see is counted (an integer atomic: the count is deterministic) so that the caller can tell
+            if (!has && missing) atomicAdd(missing, 1u);
             if (has && nrm > 0.0f) {
                 const float cw = c * wri;
                 x0 = cw * (s0 / nrm); x1 = cw * (s1 / nrm); x2 = cw * (s2 / nrm);
@@ -588,12 +591,28 @@ fx3d_status fx3d_edge_loss(const float *verts, int64_t V, const int32_t *edges, 
 
 fx3d_status fx3d_edge_loss_bwd(const float *verts, int64_t V, const int32_t *edges, int64_t E,
                                float target, float gout, float *gverts, int32_t accumulate, fx3d_stream_t s) {
+    // scatter form for a caller that holds nothing but an edge list (any list: duplicates, any order): float atomics, the last
+    // bit depends on their arrival order.  The wrappers use fx3d_edge_loss_bwd_adj.
     FX3D_REQUIRE(verts && edges && gverts, "fx3d_edge_loss_bwd: null pointer");
     FX3D_REQUIRE(V > 0 && E > 0, "fx3d_edge_loss_bwd: bad sizes");
     hipStream_t st = as_stream(s);
     if (!accumulate) FX3D_HIP(hipMemsetAsync(gverts, 0, sizeof(float) * 3 * (size_t)V, st));
     hipLaunchKernelGGL(edge_loss_bwd_kernel, dim3(grid_for(E)), dim3(kThreads), 0, st, verts, edges,
                        edges + E, (long long)E, target, gout / (float)E, gverts);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_edge_loss_bwd_adj(const float *verts, int64_t V, const int32_t *rowptr, const int32_t *colind, int64_t E,
+                                   float target, float gout, float *gverts, int32_t accumulate, fx3d_stream_t s) {
+    // gather form: vertex i walks its neighbours (the Laplacian's CSR row, ascending; the diagonal is skipped) -- the order in
+    // which the oracle's edge-by-edge scatter over the sorted edge list reaches it.  One launch, no atomics, no memset node.
+    FX3D_REQUIRE(verts && rowptr && colind && gverts, "fx3d_edge_loss_bwd_adj: null pointer");
+    FX3D_REQUIRE(V > 0 && E > 0 && V < (1ll << 31), "fx3d_edge_loss_bwd_adj: bad sizes");
+    hipStream_t st = as_stream(s);
+    ProfileScope prof("edge_loss_bwd", st);
+    hipLaunchKernelGGL((mesh_losses_bwd_gather_kernel<false, true>), dim3(grid_for(V)), dim3(kThreads), 0, st, verts, (long long)V,
+                       rowptr, colind, static_cast<const float4 *>(nullptr), 0.0f, gout / (float)E, target, gverts, accumulate);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }
@@ -680,19 +699,34 @@ fx3d_status fx3d_mesh_losses_bwd(const float *verts, int64_t V, const int32_t *r
 fx3d_status fx3d_laplacian_loss_bwd(const float *verts, int64_t V, const int32_t *rowptr,
                                     const int32_t *colind, const float *vals, float gout,
                                     float *gverts, int32_t accumulate, fx3d_stream_t s) {
+    // ANY CSR (asymmetric, pruned, directed, duplicate columns): the row-by-row scatter with float atomics -- always the
+    // adjoint of the forward, the last bit depends on the atomics' arrival order (the raw entry point must not
+    // assume a structure it cannot check).  Callers whose L is the Laplacian of an undirected edge list -- the Python and
+    // Julia wrappers -- use fx3d_laplacian_loss_bwd_sym.
     FX3D_REQUIRE(verts && rowptr && colind && vals && gverts, "fx3d_laplacian_loss_bwd: null pointer");
     FX3D_REQUIRE(V > 0, "fx3d_laplacian_loss_bwd: bad V");
     hipStream_t st = as_stream(s);
-    if (!opt(OPT_LAP_BWD_SCATTER)) {  // gather form: one launch, no atomics, bit-identical to the oracle (structurally symmetric L)
-        hipLaunchKernelGGL(laplacian_loss_bwd_gather_kernel, dim3((unsigned int)((V + kLapRows - 1) / kLapRows)), dim3(kThreads), 0, st, verts,
-                           (long long)V, rowptr, colind, vals, gout / (float)V, gverts, accumulate);
-        FX3D_LAUNCH_CHECK();
-        return FX3D_OK;
-    }
-    // scatter form (float atomics; any CSR): the last bit depends on the atomics' arrival order
     if (!accumulate) FX3D_HIP(hipMemsetAsync(gverts, 0, sizeof(float) * 3 * (size_t)V, st));
     hipLaunchKernelGGL(laplacian_loss_bwd_kernel, dim3(grid_for(V)), dim3(kThreads), 0, st, verts,
                        (long long)V, rowptr, colind, vals, gout / (float)V, gverts);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_laplacian_loss_bwd_sym(const float *verts, int64_t V, const int32_t *rowptr, const int32_t *colind,
+                                        const float *vals, float gout, float *gverts, int32_t accumulate,
+                                        uint32_t *missing_dev, fx3d_stream_t s) {
+    // gather form: one launch, no atomics, bit-identical to the oracle.  PRECONDITION: L structurally symmetric (column i
+    // in row r iff column r in row i), no duplicate columns in a row.  missing_dev (optional, caller-zeroed device counter)
+    // receives the number of stored entries L[i,r] whose transpose L[r,i] is absent: non-zero means the precondition did
+    // not hold and the gradient lacks those contributions -- use fx3d_laplacian_loss_bwd.
+    FX3D_REQUIRE(verts && rowptr && colind && vals && gverts, "fx3d_laplacian_loss_bwd_sym: null pointer");
+    FX3D_REQUIRE(V > 0, "fx3d_laplacian_loss_bwd_sym: bad V");
+    if (opt(OPT_LAP_BWD_SCATTER)) return fx3d_laplacian_loss_bwd(verts, V, rowptr, colind, vals, gout, gverts, accumulate, s);
+    hipStream_t st = as_stream(s);
+    ProfileScope prof("laplacian_loss_bwd", st);
+    hipLaunchKernelGGL(laplacian_loss_bwd_gather_kernel, dim3((unsigned int)((V + kLapRows - 1) / kLapRows)), dim3(kThreads), 0, st, verts,
+                       (long long)V, rowptr, colind, vals, gout / (float)V, gverts, accumulate, missing_dev);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }

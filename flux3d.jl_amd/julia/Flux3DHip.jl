@@ -327,6 +327,25 @@ Zygote.@adjoint function _chamfer_distance(A::HipArray{Float32,3}, B::HipArray{F
     return loss, back
 end
 
+# value and gradient in ONE ABI call (`Zygote.withgradient(chamfer_distance, A, B)`; what benchmarks/metrics.jl:24-38 times as
+# "total" and examples/fit_mesh.jl:106-110 runs per iteration): forward with indices + adjoint queued back to back, the
+# indices stay in the scratch.  Returns (loss, gA, gB).
+function chamfer_value_and_grad(A::HipArray{Float32,3}, B::HipArray{Float32,3}, w1::Float32 = 1.0f0, w2::Float32 = 1.0f0;
+                                gout::Float32 = 1.0f0)
+    D, N, Bn = size(A); _, M, _ = size(B)
+    nb = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_chamfer_fwd_bwd_workspace_bytes(N::Int32, M::Int32, Bn::Int32, D::Int32, nb::Ref{Csize_t})::Int32)
+    ws = workspace(nb[])
+    loss_dev = HipArray{Float32}(undef, 1); loss = Ref{Float32}(0)
+    gA = HipArray{Float32}(undef, D, N, Bn); gB = HipArray{Float32}(undef, D, M, Bn)
+    check(@ccall LIB.fx3d_chamfer_fwd_bwd(A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32, Bn::Int32, D::Int32,
+                                          w1::Float32, w2::Float32, gout::Float32, Bn::Int64, loss_dev.ptr::Ptr{Cvoid},
+                                          loss::Ref{Float32}, gA.ptr::Ptr{Cvoid}, gB.ptr::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
+                                          C_NULL::Ptr{Cvoid}, ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t,
+                                          DEFAULT_STREAM::Stream)::Int32)
+    return loss[], gA, gB
+end
+
 # adjoint of chamfer_distance(m1::TriMesh, m2::TriMesh, n) (src/metrics/mesh.jl:34-44) w.r.t. the padded vertices of m1 and / or
 # m2 in one launch: A / B = the forward's samples, ix / iy its neighbour indices, draws_* = (face, r1, r2) of the sampler.
 # `nothing` for a mesh skips its side.  Returns (gverts1, gverts2), each (3, V, N) or nothing.
@@ -619,13 +638,35 @@ end
 function laplacian_loss_grad(m::TriMesh{Float32,R,HipArray}, verts::HipArray{Float32,2}, gout::Number = 1) where {R}
     rowptr, colind, vals = laplacian_csr_dev(m)
     g = HipArray{Float32}(undef, size(verts)...)
+    # the mesh's L is the Laplacian of an undirected edge list (src/rep/mesh.jl:957-1002): structurally symmetric, so the
+    # atomic-free gather form applies; fx3d_laplacian_loss_bwd (any CSR, scatter) is bound below for raw matrices
+    check(@ccall LIB.fx3d_laplacian_loss_bwd_sym(verts.ptr::Ptr{Cvoid}, size(verts, 2)::Int64, rowptr.ptr::Ptr{Cvoid},
+                                                 colind.ptr::Ptr{Cvoid}, vals.ptr::Ptr{Cvoid}, Float32(gout)::Float32,
+                                                 g.ptr::Ptr{Cvoid}, 0::Int32, C_NULL::Ptr{Cvoid},
+                                                 DEFAULT_STREAM::Stream)::Int32)
+    return g
+end
+# the same adjoint for ANY CSR (asymmetric / pruned / directed): row-by-row scatter with float atomics
+function laplacian_loss_grad_csr(verts::HipArray{Float32,2}, rowptr::HipArray{Int32,1}, colind::HipArray{Int32,1},
+                                 vals::HipArray{Float32,1}, gout::Number = 1)
+    g = HipArray{Float32}(undef, size(verts)...)
     check(@ccall LIB.fx3d_laplacian_loss_bwd(verts.ptr::Ptr{Cvoid}, size(verts, 2)::Int64, rowptr.ptr::Ptr{Cvoid},
                                              colind.ptr::Ptr{Cvoid}, vals.ptr::Ptr{Cvoid}, Float32(gout)::Float32,
                                              g.ptr::Ptr{Cvoid}, 0::Int32, DEFAULT_STREAM::Stream)::Int32)
     return g
 end
 function edge_loss_grad(m::TriMesh{Float32,R,HipArray}, verts::HipArray{Float32,2}, target::Number = 0, gout::Number = 1) where {R}
-    edges = edges_dev(m)
+    # gather over the vertex adjacency (the Laplacian's rowptr / colind of the same edge list): one launch, no float atomics
+    rowptr, colind, _ = laplacian_csr_dev(m)
+    g = HipArray{Float32}(undef, size(verts)...)
+    check(@ccall LIB.fx3d_edge_loss_bwd_adj(verts.ptr::Ptr{Cvoid}, size(verts, 2)::Int64, rowptr.ptr::Ptr{Cvoid},
+                                            colind.ptr::Ptr{Cvoid}, size(get_edges_packed(m), 1)::Int64,
+                                            Float32(target)::Float32, Float32(gout)::Float32, g.ptr::Ptr{Cvoid}, 0::Int32,
+                                            DEFAULT_STREAM::Stream)::Int32)
+    return g
+end
+# the same adjoint from a bare (E,2) edge list on the device (scatter, float atomics)
+function edge_loss_grad_edges(verts::HipArray{Float32,2}, edges::HipArray{Int32,2}, target::Number = 0, gout::Number = 1)
     g = HipArray{Float32}(undef, size(verts)...)
     check(@ccall LIB.fx3d_edge_loss_bwd(verts.ptr::Ptr{Cvoid}, size(verts, 2)::Int64, edges.ptr::Ptr{Cvoid},
                                         size(edges, 1)::Int64, Float32(target)::Float32, Float32(gout)::Float32,

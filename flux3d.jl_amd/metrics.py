@@ -123,6 +123,30 @@ def chamfer_distance_grad(A, B, idx_a, idx_b, w1=1.0, w2=1.0, gout=1.0, B_global
     return gx, gy
 
 
+def chamfer_value_and_grad(A, B, w1=1.0, w2=1.0, gout=1.0, B_global=None, return_indices=False, loss_out=None, sync=True,
+                           out=None):
+    """``loss, (gA, gB) = withgradient(chamfer_distance, A, B)`` in ONE ABI call (fx3d_chamfer_fwd_bwd): the forward with its
+    nearest-neighbour indices and the adjoint are queued back to back, the indices stay in scratch (benchmarks/metrics.jl:24-38
+    times exactly this as "total"; examples/fit_mesh.jl:106-110).  ``out``: (gA, gB) device arrays to overwrite.  Returns
+    (loss, gA, gB) (+ idx_a, idx_b with ``return_indices``); loss is a host Float32, or the 1-element device array with
+    ``sync=False``."""
+    x, y = _as_dev_points(A), _as_dev_points(B)
+    D, N, M, Bn = _check_pair(x, y)
+    n = C.c_size_t(0)
+    _lib.call("fx3d_chamfer_fwd_bwd_workspace_bytes", N, M, Bn, D, C.byref(n))
+    ws = workspace(n.value, "chamfer_fwd_bwd")
+    loss_dev = loss_out if loss_out is not None else DeviceArray.empty((1,), np.float32)
+    gx, gy = out if out is not None else (DeviceArray.empty(x.shape, np.float32), DeviceArray.empty(y.shape, np.float32))
+    ix = DeviceArray.empty((N, Bn), np.int32) if return_indices else None
+    iy = DeviceArray.empty((M, Bn), np.int32) if return_indices else None
+    host = C.c_float(0)
+    _lib.call("fx3d_chamfer_fwd_bwd", x.ptr, N, y.ptr, M, Bn, D, float(w1), float(w2), float(gout), int(B_global or Bn),
+              loss_dev.ptr, C.byref(host) if sync else None, gx.ptr, gy.ptr, ix.ptr if ix else None, iy.ptr if iy else None,
+              ws.ptr, ws.nbytes, current_stream().handle)
+    loss = np.float32(host.value) if sync else loss_dev
+    return (loss, gx, gy, ix, iy) if return_indices else (loss, gx, gy)
+
+
 def chamfer_sampled_grad(A, B, idx_a, idx_b, mesh_a=None, draws_a=None, mesh_b=None, draws_b=None, w1=1.0, w2=1.0,
                          gout=1.0, B_global=None, out_a=None, out_b=None):
     """Adjoint of ``chamfer_distance(m_a::TriMesh, m_b::TriMesh, n)`` (src/metrics/mesh.jl:34-44) w.r.t. the padded vertices of
@@ -175,9 +199,11 @@ def laplacian_loss_grad(m, gout=1.0, out=None):
     verts = m.dev("verts_packed")
     V = verts.shape[1]
     g = DeviceArray.empty((3, V), np.float32) if out is None else out
-    _lib.call("fx3d_laplacian_loss_bwd", verts.ptr, V, m.dev("lap_rowptr").ptr,
+    # the mesh's L is the Laplacian of an undirected edge list (src/rep/mesh.jl:957-1002): structurally symmetric, so the
+    # atomic-free gather form applies (fx3d_laplacian_loss_bwd itself takes any CSR and scatters)
+    _lib.call("fx3d_laplacian_loss_bwd_sym", verts.ptr, V, m.dev("lap_rowptr").ptr,
               m.dev("lap_colind").ptr, m.dev("lap_vals").ptr, float(gout), g.ptr, int(out is not None),
-              current_stream().handle)
+              None, current_stream().handle)
     return g
 
 
@@ -201,8 +227,10 @@ def edge_loss_grad(m, target_length=0.0, gout=1.0, out=None):
     V = verts.shape[1]
     edges = m.dev("edges")
     g = DeviceArray.empty((3, V), np.float32) if out is None else out
-    _lib.call("fx3d_edge_loss_bwd", verts.ptr, V, edges.ptr, edges.shape[0], float(target_length),
-              float(gout), g.ptr, int(out is not None), current_stream().handle)
+    # gather over the vertex adjacency (the Laplacian's rowptr / colind of the same edge list): one launch, no float
+    # atomics, no memset node, bit-identical to the oracle (fx3d_edge_loss_bwd is the scatter for a bare edge list)
+    _lib.call("fx3d_edge_loss_bwd_adj", verts.ptr, V, m.dev("lap_rowptr").ptr, m.dev("lap_colind").ptr, edges.shape[0],
+              float(target_length), float(gout), g.ptr, int(out is not None), current_stream().handle)
     return g
 
 

@@ -165,6 +165,17 @@ FX3D_API fx3d_status fx3d_chamfer_bwd(const float *x, int32_t N, const float *y,
                                       const int32_t *idx_y, float w1, float w2, float gout,
                                       int64_t B_global, float *gx, float *gy, fx3d_stream_t s);
 
+/* Value and gradient of _chamfer_distance in ONE call -- the shape of `gradient(() -> chamfer_distance(A, B), ...)`
+ * (benchmarks/metrics.jl:24-38 "total", examples/fit_mesh.jl:106-110): fx3d_chamfer_fwd (loss with the batch size B_global)
+ * and fx3d_chamfer_bwd are queued back to back on the stream; the nearest-neighbour indices stay in the scratch unless
+ * idx_x (N,B) / idx_y (M,B) are given.  gx (D,N,B), gy (D,M,B) overwritten.  loss_host non-NULL => the stream is
+ * synchronised.  ws: fx3d_chamfer_fwd_bwd_workspace_bytes. */
+FX3D_API fx3d_status fx3d_chamfer_fwd_bwd_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_t D, size_t *bytes);
+FX3D_API fx3d_status fx3d_chamfer_fwd_bwd(const float *x, int32_t N, const float *y, int32_t M, int32_t B, int32_t D,
+                                          float w1, float w2, float gout, int64_t B_global, float *loss_dev,
+                                          float *loss_host, float *gx, float *gy, int32_t *idx_x, int32_t *idx_y,
+                                          void *ws, size_t ws_bytes, fx3d_stream_t s);
+
 /* Adjoint of chamfer_distance(m_x::TriMesh, m_y::TriMesh, n) (src/metrics/mesh.jl:34-44: both meshes sampled, then
  * _chamfer_distance) w.r.t. the PADDED VERTICES of either mesh, for the forward's draws and nearest-neighbour indices, in one
  * launch: fx3d_chamfer_bwd's gradient w.r.t. the sampled points (D = 3) is scattered onto the three vertices of every sampled
@@ -337,9 +348,20 @@ FX3D_API fx3d_status fx3d_mesh_loss_workspace_bytes(int64_t count, size_t *bytes
 FX3D_API fx3d_status fx3d_edge_loss(const float *verts, int64_t V, const int32_t *edges,
                                     int64_t E, float target, float *loss_dev, float *loss_host,
                                     void *ws, size_t ws_bytes, fx3d_stream_t s);
+/* d edge_loss / d verts * gout -> gverts (3,V) (added when accumulate != 0; Zygote through src/metrics/mesh.jl:27-31).
+ * fx3d_edge_loss_bwd: SCATTER form for a caller that holds only an edge list (any list): float atomics (+ a memset when
+ * accumulate == 0), the last bit depends on their arrival order.
+ * fx3d_edge_loss_bwd_adj: GATHER form over the vertex adjacency in CSR (rowptr (V+1), colind: neighbours ascending; a
+ * diagonal entry is skipped, so the Laplacian's rowptr / colind of the same edge list serve as they are,
+ * src/rep/mesh.jl:957-1002): vertex i adds its edges' terms in the order in which the reference's edge-by-edge
+ * accumulation over the sorted edge list reaches it -- one launch, no float atomics, no memset, bit-identical run to run
+ * and to the CPU restatement.  E = number of edges (the mean's denominator).  The wrappers use this one. */
 FX3D_API fx3d_status fx3d_edge_loss_bwd(const float *verts, int64_t V, const int32_t *edges,
                                         int64_t E, float target, float gout, float *gverts,
                                         int32_t accumulate, fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_edge_loss_bwd_adj(const float *verts, int64_t V, const int32_t *rowptr,
+                                            const int32_t *colind, int64_t E, float target, float gout,
+                                            float *gverts, int32_t accumulate, fx3d_stream_t s);
 
 /* laplacian_loss(m) (src/metrics/mesh.jl:9-15) with L in CSR (rows = vertices, columns
  * ascending, values Float32 as built by _compute_laplacian_packed, src/rep/mesh.jl:957-1002). */
@@ -347,13 +369,23 @@ FX3D_API fx3d_status fx3d_laplacian_loss(const float *verts, int64_t V, const in
                                          const int32_t *colind, const float *vals,
                                          float *loss_dev, float *loss_host, void *ws,
                                          size_t ws_bytes, fx3d_stream_t s);
-/* d laplacian_loss / d verts * gout -> gverts (3,V) (added when accumulate != 0).  Gathered per vertex in the order of the
- * reference's row-by-row accumulation: one launch, no float atomics, bit-identical run to run and to the CPU restatement.  The
- * gather needs a structurally symmetric L (i in row r <=> r in row i: the Laplacian of an undirected edge list is); option
- * "lap_bwd_scatter" = 1 selects the scatter with float atomics, which takes any CSR. */
+/* d laplacian_loss / d verts * gout -> gverts (3,V) (added when accumulate != 0).
+ * fx3d_laplacian_loss_bwd: ANY CSR (asymmetric, pruned, directed, duplicate columns): the row-by-row scatter with float
+ * atomics (+ a memset when accumulate == 0) -- always the adjoint of fx3d_laplacian_loss; the last bit depends on the
+ * atomics' arrival order.
+ * fx3d_laplacian_loss_bwd_sym: gathered per vertex in the order of the reference's row-by-row accumulation: one launch,
+ * no float atomics, bit-identical run to run and to the CPU restatement.  PRECONDITION: L structurally symmetric (i in
+ * row r <=> r in row i: the Laplacian of an undirected edge list is, src/rep/mesh.jl:957-1002) without duplicate columns.
+ * missing_dev (optional): a caller-zeroed device counter that receives the number of stored entries whose transpose is
+ * absent -- non-zero means the precondition did not hold and those contributions are missing from gverts.  Option
+ * "lap_bwd_scatter" = 1 routes this entry point to the scatter (A/B).  The wrappers use this one. */
 FX3D_API fx3d_status fx3d_laplacian_loss_bwd(const float *verts, int64_t V, const int32_t *rowptr,
                                              const int32_t *colind, const float *vals, float gout,
                                              float *gverts, int32_t accumulate, fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_laplacian_loss_bwd_sym(const float *verts, int64_t V, const int32_t *rowptr,
+                                                 const int32_t *colind, const float *vals, float gout,
+                                                 float *gverts, int32_t accumulate, uint32_t *missing_dev,
+                                                 fx3d_stream_t s);
 
 /* Both mesh losses in ONE launch and both adjoints in ONE gather launch -- the regularisers of the fit_mesh objective
  * (examples/fit_mesh.jl:80-83), launch bound at teapot scale.  rowptr/colind/vals: the Laplacian CSR of the SAME edge

@@ -1003,3 +1003,90 @@ def test_bench_line_force_dist_equals_plain_and_roofline_is_a_fraction(gpu_fx):
     if gpu_fx.device_count() < 2:
         r = subprocess.run([sys.executable, bench, "--gpus", "2"] + common, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode != 0 and "n_gpus" not in r.stdout
+
+
+@pytest.mark.parametrize("N,M,B,D", [(1000, 500, 2, 3), (64, 64, 1, 3), (4096, 4096, 4, 3), (9000, 12000, 1, 3), (300, 200, 3, 2), (50, 70, 2, 5)])
+def test_chamfer_value_and_grad_is_forward_plus_backward(gpu_fx, oracle, N, M, B, D):
+    """fx3d_chamfer_fwd_bwd (benchmarks/metrics.jl:24-38 "total", examples/fit_mesh.jl:106-110): ONE ABI call
+    returns the loss, both gradients and (on request) the indices -- the same bits as fx3d_chamfer_fwd + fx3d_chamfer_bwd, loss
+    and gradients against the oracle; every launch plan (one launch, split run, exact D = 2, generic D)."""
+    fx = gpu_fx
+    rng = np.random.default_rng(N + M)
+    x, y = _f(rng.random((D, N, B))), _f(rng.random((D, M, B)))
+    dx, dy = fx.gpu(x), fx.gpu(y)
+    l2, ix2, iy2 = fx.chamfer_distance(dx, dy, w1=0.7, w2=1.3, return_indices=True)
+    gx2, gy2 = fx.chamfer_distance_grad(dx, dy, ix2, iy2, w1=0.7, w2=1.3, gout=2.0)
+    l1, gx1, gy1, ix1, iy1 = fx.chamfer_value_and_grad(dx, dy, w1=0.7, w2=1.3, gout=2.0, return_indices=True)
+    assert l1 == l2 and np.array_equal(ix1.to_host(), ix2.to_host()) and np.array_equal(iy1.to_host(), iy2.to_host())
+    assert np.array_equal(gx1.to_host(), gx2.to_host()) and np.array_equal(gy1.to_host(), gy2.to_host())
+    l3, gx3, gy3 = fx.chamfer_value_and_grad(dx, dy, w1=0.7, w2=1.3, gout=2.0)       # indices in the scratch
+    assert l3 == l1 and np.array_equal(gx3.to_host(), gx1.to_host()) and np.array_equal(gy3.to_host(), gy1.to_host())
+    ol, ox, oy, _ = oracle.chamfer_distance(x, y, 0.7, 1.3, return_all=True)
+    assert np.array_equal(ix1.to_host(), ox) and np.array_equal(iy1.to_host(), oy)
+    assert np.isclose(l1, ol, rtol=LOSS_RTOL, atol=0)
+    ogx, ogy = oracle.chamfer_bwd(x, y, ox, oy, 0.7, 1.3, 2.0)
+    assert np.allclose(gx1.to_host(), ogx, rtol=1e-5, atol=1e-9) and np.allclose(gy1.to_host(), ogy, rtol=1e-5, atol=1e-9)
+    from flux3d_jl_amd import _lib
+    rc = _lib.load().fx3d_chamfer_fwd_bwd(dx.ptr, N, dy.ptr, M, B, D, 1.0, 1.0, 1.0, B, gx1.ptr, None, gx1.ptr, gy1.ptr, None, None,
+                                          gx1.ptr, 16, None)
+    assert rc == -6 and "workspace" in _lib.last_error()   # FX3D_ERR_WORKSPACE: a short scratch is refused, nothing is launched
+
+
+def test_edge_and_laplacian_adjoints_gather_forms_are_bit_identical_to_the_oracle(gpu_fx, oracle):
+    """VERDICT r3 #6 / ADVICE r3: the wrappers' adjoints of edge_loss and laplacian_loss are the GATHER forms
+    (fx3d_edge_loss_bwd_adj, fx3d_laplacian_loss_bwd_sym): one launch, no float atomics, no memset -- the oracle's bits, run after
+    run, also when added onto an existing gradient; the raw entry points (scatter, any edge list / any CSR) stay within
+    rounding.  An ASYMMETRIC CSR: the scatter entry is the adjoint of the forward (finite differences of the oracle's loss), the
+    symmetric-only gather reports the entries it cannot see."""
+    fx = gpu_fx
+    from flux3d_jl_amd import _lib
+    m = fx.load_trimesh(os.path.join(GOLDEN, "teapot.obj"), os.path.join(GOLDEN, "sphere.obj"), os.path.join(GOLDEN, "teapot.obj"))
+    v = m.get_verts_packed_host()
+    e0 = m.get_edges_packed().astype(np.int64) - 1
+    rp, ci, va = m.get_laplacian_packed()
+    oe = oracle.edge_loss_bwd(v, e0, 0.05, 1.3)
+    ol = oracle.laplacian_loss_bwd(v, rp.astype(np.int64), ci.astype(np.int64), va, 0.7)
+    md = fx.gpu(m)
+    for _ in range(3):
+        assert np.array_equal(fx.edge_loss_grad(md, 0.05, 1.3).to_host(), oe)
+        assert np.array_equal(fx.laplacian_loss_grad(md, 0.7).to_host(), ol)
+    acc = fx.laplacian_loss_grad(md, 0.7)
+    fx.edge_loss_grad(md, 0.05, 1.3, out=acc)
+    assert np.array_equal(acc.to_host(), ol + oe)
+    V, E = v.shape[1], e0.shape[0]
+    verts, edges = md.dev("verts_packed"), md.dev("edges")
+    g = fx.DeviceArray.empty((3, V), np.float32)
+    _lib.call("fx3d_edge_loss_bwd", verts.ptr, V, edges.ptr, E, 0.05, 1.3, g.ptr, 0, None)       # scatter, bare edge list
+    fx.synchronize()
+    assert np.allclose(g.to_host(), oe, rtol=1e-4, atol=1e-9)
+    _lib.call("fx3d_laplacian_loss_bwd", verts.ptr, V, md.dev("lap_rowptr").ptr, md.dev("lap_colind").ptr, md.dev("lap_vals").ptr,
+              0.7, g.ptr, 0, None)                                                                # scatter, any CSR
+    fx.synchronize()
+    assert np.allclose(g.to_host(), ol, rtol=1e-4, atol=1e-9)
+    # an asymmetric (pruned) matrix: drop every stored entry (r, c) with c > r + 1 -- their transposes stay
+    rng = np.random.default_rng(3)
+    Vs = 200
+    vs = _f(rng.random((3, Vs)))
+    dense = (rng.random((Vs, Vs)) < 0.04).astype(np.float32) * rng.standard_normal((Vs, Vs)).astype(np.float32)
+    dense = dense + dense.T + np.diag(-np.ones(Vs, np.float32))
+    dense[np.triu_indices(Vs, 2)] = 0.0
+    rows = [np.nonzero(dense[r])[0] for r in range(Vs)]
+    rp2 = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    ci2 = np.concatenate(rows).astype(np.int32)
+    va2 = np.concatenate([dense[r][rows[r]] for r in range(Vs)]).astype(np.float32)
+    o2 = oracle.laplacian_loss_bwd(vs, rp2.astype(np.int64), ci2.astype(np.int64), va2, 1.0)
+    dv, drp, dci, dva = fx.gpu(vs), fx.DeviceArray.from_host(rp2), fx.DeviceArray.from_host(ci2), fx.DeviceArray.from_host(va2)
+    g2 = fx.DeviceArray.empty((3, Vs), np.float32)
+    _lib.call("fx3d_laplacian_loss_bwd", dv.ptr, Vs, drp.ptr, dci.ptr, dva.ptr, 1.0, g2.ptr, 0, None)
+    fx.synchronize()
+    assert np.allclose(g2.to_host(), o2, rtol=1e-4, atol=1e-7)
+    missing = fx.DeviceArray.zeros((1,), np.uint32)
+    _lib.call("fx3d_laplacian_loss_bwd_sym", dv.ptr, Vs, drp.ptr, dci.ptr, dva.ptr, 1.0, g2.ptr, 0, missing.ptr, None)
+    fx.synchronize()
+    nsym = sum(1 for r in range(Vs) for c in rows[r] if r not in rows[c])
+    assert nsym > 0 and int(missing.to_host()[0]) == nsym
+    missing = fx.DeviceArray.zeros((1,), np.uint32)                                               # a symmetric L: nothing missing
+    _lib.call("fx3d_laplacian_loss_bwd_sym", verts.ptr, V, md.dev("lap_rowptr").ptr, md.dev("lap_colind").ptr,
+              md.dev("lap_vals").ptr, 0.7, g.ptr, 0, missing.ptr, None)
+    fx.synchronize()
+    assert int(missing.to_host()[0]) == 0 and np.array_equal(g.to_host(), ol)
