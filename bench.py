@@ -475,6 +475,14 @@ def _per_call_ms(fx, fn, n=100, warm=5):
         for _ in range(warm):
             fn()
         s.synchronize()
+        # burn-in: >= 15 ms of the same calls.  A measurement that follows host work (uploads, topology builds) starts on a
+        # device that has dropped its clocks; the first of two otherwise identical measurements read 6-7 us high for calls
+        # of 7-15 us (round 4: the harness's forward column, and with it `back` = total - forward, were off by that much)
+        t_burn = time.perf_counter()
+        while time.perf_counter() - t_burn < 0.015:
+            for _ in range(8):
+                fn()
+        s.synchronize()
         ev = [fx.Event() for _ in range(n + 1)]
         ev[0].record(s)
         for i in range(n):

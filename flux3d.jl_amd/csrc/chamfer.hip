@@ -1014,6 +1014,187 @@ __global__ __launch_bounds__(kThreads) void nn1_split_finalize_kernel(Nn1Params 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// nn1_tiny_kernel (D = 3, round 4): the exact loop for SMALL problems -- 2 B N M below a few ten million pair evaluations
+// (C1, the reference harness's n <= 4096: benchmarks/metrics.jl:40) -- where nn1_f16_kernel's per-cloud statistics, image
+// and 1024-thread blocks are all overhead (C1 17.6 us, n = 64: 13.7 us; an empty launch is ~6 us).  No statistics, no
+// image, no filter, no LDS staging, no barrier before the arithmetic: a 256-thread block owns 16 R queries and ALL
+// candidates of their cloud.  Lane l of wave w holds query l & 15 (+ 16 r) and works on candidate slice s = 4 w + (l >> 4)
+// of 16 contiguous slices.  The slice is consumed in groups of 16 candidates: lane l LOADS candidate (l & 15) of the group
+// (one 12-byte global load per lane and 16 pairs; consecutive lanes, consecutive points) and every lane of the 16-lane
+// row reads it through the DPP row broadcast of the subtraction itself (v_subrev_f32_dpp row_newbcast:i: no move, no LDS):
+// 8 VALU per pair for the oracle's unfused ((dx dx) + dy dy) + dz dz, 8 v_min3 per group of 16, 3 for (best, best group)
+// with a strict `<`.  The winning group is re-scanned for the FIRST candidate that attains the minimum, so a lane's
+// result is its slice's (distance, lowest index); the 16 slices of a query meet in a 64-bit LDS atomicMin on
+// (distance bits << 32 | index) -- the oracle's order (isless, then the lower index; no NaN passes `<`, a query without
+// any distance below +Inf takes nn1_scan_isless).  Loss: per-block Float64 partial + nn1_f16_kernel's fused finalisation.
+constexpr int kTyThreads = 256;
+constexpr int kTyQ = 16;                      // queries per 16-lane row
+constexpr int kTySl = 16;                     // candidate slices per block (4 per wave, one per DPP row)
+constexpr int kTyG = 16;                      // candidates per group (one per lane of a row)
+
+template <int I>
+__device__ __forceinline__ float row_bcast(float v) {  // lane (l & ~15) + I of every 16-lane row, read by the consuming instruction's DPP operand
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + I, 0xF, 0xF, false));
+}
+template <int I>
+__device__ __forceinline__ float tiny_d(const float (&q)[3], float cx, float cy, float cz) {
+    const float t0 = q[0] - row_bcast<I>(cx), t1 = q[1] - row_bcast<I>(cy), t2 = q[2] - row_bcast<I>(cz);
+    return ((t0 * t0) + (t1 * t1)) + (t2 * t2);
+}
+__device__ __forceinline__ void tiny_group(const float (&q)[3], float cx, float cy, float cz, float (&d)[kTyG]) {
+    d[0] = tiny_d<0>(q, cx, cy, cz); d[1] = tiny_d<1>(q, cx, cy, cz); d[2] = tiny_d<2>(q, cx, cy, cz); d[3] = tiny_d<3>(q, cx, cy, cz);
+    d[4] = tiny_d<4>(q, cx, cy, cz); d[5] = tiny_d<5>(q, cx, cy, cz); d[6] = tiny_d<6>(q, cx, cy, cz); d[7] = tiny_d<7>(q, cx, cy, cz);
+    d[8] = tiny_d<8>(q, cx, cy, cz); d[9] = tiny_d<9>(q, cx, cy, cz); d[10] = tiny_d<10>(q, cx, cy, cz); d[11] = tiny_d<11>(q, cx, cy, cz);
+    d[12] = tiny_d<12>(q, cx, cy, cz); d[13] = tiny_d<13>(q, cx, cy, cz); d[14] = tiny_d<14>(q, cx, cy, cz); d[15] = tiny_d<15>(q, cx, cy, cz);
+}
+
+// kTyPF = groups in flight per lane (4; 1 for clouds of <= 256 candidates: a quarter of the code -- the smallest launches are
+// eight blocks on eight cold instruction caches).
+template <int R, int kTyPF, bool WANT_IDX>
+__global__ __launch_bounds__(kTyThreads) void nn1_tiny_kernel(Nn1Params p) {
+    __shared__ unsigned long long slot[2][kTyQ * R];
+    const int tiles = p.tiles;
+    const int c = blockIdx.x / tiles, btile = blockIdx.x - c * tiles;   // cloud id in [0, 2B): dir = c / B
+    const int dir = c >= p.B ? 1 : 0;
+    const int b = dir ? c - p.B : c;
+    const int NQ = dir ? p.M : p.N, NC = dir ? p.N : p.M;
+    if (btile >= (dir ? p.tiles_y : p.tiles_x)) return;
+    const float *__restrict__ qb = (dir ? p.y : p.x) + (size_t)b * NQ * 3;
+    const float *__restrict__ cb = (dir ? p.x : p.y) + (size_t)b * NC * 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane & 15, s = wave * 4 + (lane >> 4);
+    // slice s = candidates [s L, (s + 1) L), L a multiple of 16; this lane loads candidate jl + 16 g of group g
+    const int L = ((NC + kTySl - 1) / kTySl + kTyG - 1) / kTyG * kTyG;
+    const int ngroups = L / kTyG;
+    const int jl = s * L + ql;
+    auto load_group = [&](int g, float &cx, float &cy, float &cz) {
+        const int j = jl + kTyG * g;
+        const bool ok = g < ngroups && j < NC;
+        const P3 t = *reinterpret_cast<const P3 *>(cb + 3ll * (ok ? j : 0));
+        cx = ok ? t.x : INFINITY; cy = ok ? t.y : INFINITY; cz = ok ? t.z : INFINITY;   // padding at +Inf: never below anything
+    };
+    float cur[kTyPF][3], nxt[kTyPF][3];
+#pragma unroll
+    for (int u = 0; u < kTyPF; ++u) load_group(u, cur[u][0], cur[u][1], cur[u][2]);
+    const bool resident = ngroups <= kTyPF;   // the lane's share of the cloud stays in registers across the block's query tiles
+    if (tid < 2 * kTyQ * R) (&slot[0][0])[tid] = ~0ull;
+    __syncthreads();
+
+    // a block takes p.tpb consecutive query tiles of its cloud (one partial sum, one arrival at the ticket per BLOCK: with a
+    // block per tile the 1024+ same-address atomics and the last arriver's pass over as many partials were the launch's tail)
+    const int raw_tiles = (NQ + kTyQ * R - 1) / (kTyQ * R);
+    int32_t *idx_out = dir ? p.idx_y : p.idx_x;
+    float *dmin_out = dir ? p.dmin_y : p.dmin_x;
+    double acc = 0.0;
+    auto load_queries = [&](int tile, float (&qq)[R][3]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int qi = tile * (kTyQ * R) + r * kTyQ + ql;
+            const P3 t = *reinterpret_cast<const P3 *>(qb + 3ll * (qi < NQ ? qi : NQ - 1));
+            qq[r][0] = t.x; qq[r][1] = t.y; qq[r][2] = t.z;
+        }
+    };
+    float qn[R][3];
+    load_queries(btile * p.tpb, qn);
+    for (int tt = 0; tt < p.tpb; ++tt) {
+        const int tile = btile * p.tpb + tt;
+        if (tile >= raw_tiles) break;   // (block-uniform)
+        float q[R][3];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { q[r][0] = qn[r][0]; q[r][1] = qn[r][1]; q[r][2] = qn[r][2]; }
+        if (tt + 1 < p.tpb) load_queries(tile + 1, qn);   // the next tile's queries travel while this one is evaluated
+        if (!resident && tt > 0) {
+#pragma unroll
+            for (int u = 0; u < kTyPF; ++u) load_group(u, cur[u][0], cur[u][1], cur[u][2]);
+        }
+        float best[R];
+        int bg[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { best[r] = INFINITY; bg[r] = 0; }
+        for (int g0 = 0; g0 < ngroups; g0 += kTyPF) {
+            if (g0 + kTyPF < ngroups) {
+#pragma unroll
+                for (int u = 0; u < kTyPF; ++u) load_group(g0 + kTyPF + u, nxt[u][0], nxt[u][1], nxt[u][2]);
+            }
+#pragma unroll
+            for (int u = 0; u < kTyPF; ++u) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float d[kTyG];
+                    tiny_group(q[r], cur[u][0], cur[u][1], cur[u][2], d);
+                    float m = min3f(d[0], d[1], d[2]);
+                    m = min3f(m, d[3], d[4]);
+                    m = min3f(m, d[5], d[6]);
+                    m = min3f(m, d[7], d[8]);
+                    m = min3f(m, d[9], d[10]);
+                    m = min3f(m, d[11], d[12]);
+                    m = min3f(m, d[13], d[14]);
+                    m = __builtin_fminf(m, d[15]);
+                    const bool better = m < best[r];  // strict: the first group that holds the lane's minimum
+                    best[r] = better ? m : best[r];
+                    if (WANT_IDX) bg[r] = better ? g0 + u : bg[r];
+                }
+            }
+            if (g0 + kTyPF < ngroups) {
+#pragma unroll
+                for (int u = 0; u < kTyPF; ++u) { cur[u][0] = nxt[u][0]; cur[u][1] = nxt[u][1]; cur[u][2] = nxt[u][2]; }
+            }
+        }
+        unsigned long long *sl = slot[tt & 1];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int bi = 0;
+            if (WANT_IDX) {
+                // the FIRST candidate of the lane's winning group that attains the minimum.  The winning groups differ lane by
+                // lane, so every lane reads the 16 candidates of its own (16 loads in flight, L1 / L2 hits)
+                float d[kTyG];
+#pragma unroll
+                for (int i = 0; i < kTyG; ++i) {
+                    const int j = s * L + kTyG * bg[r] + i;
+                    const P3 t = *reinterpret_cast<const P3 *>(cb + 3ll * (j < NC ? j : 0));
+                    const float t0 = q[r][0] - t.x, t1 = q[r][1] - t.y, t2 = q[r][2] - t.z;
+                    d[i] = j < NC ? ((t0 * t0) + (t1 * t1)) + (t2 * t2) : INFINITY;
+                }
+#pragma unroll
+                for (int i = kTyG - 1; i >= 0; --i)
+                    if (d[i] == best[r]) bi = s * L + kTyG * bg[r] + i;
+            }
+            if (best[r] < INFINITY)
+                atomicMin(&sl[r * kTyQ + ql], ((unsigned long long)__builtin_bit_cast(unsigned int, best[r]) << 32) | (unsigned int)bi);
+        }
+        __syncthreads();
+        // the first wave writes the tile's results (16 R <= 32 queries) and returns the slots to "empty"; the other buffer
+        // takes the next tile's minima meanwhile (this buffer is used again two tiles on, behind the next barrier)
+        const int qidx = tile * (kTyQ * R) + tid;
+        if (tid < kTyQ * R) {
+            const unsigned long long k = sl[tid];
+            sl[tid] = ~0ull;
+            if (qidx < NQ) {
+                float dd = __builtin_bit_cast(float, (unsigned int)(k >> 32));
+                int ii = (int)(unsigned int)k;
+                if (k == ~0ull) {  // nothing below +Inf (non-finite or overflowing coordinates): the exact scan in isless order
+                    const P3 t = *reinterpret_cast<const P3 *>(qb + 3ll * qidx);
+                    const float qq[3] = {t.x, t.y, t.z};
+                    nn1_scan_isless<3>(qq, cb, NC, dd, ii);
+                }
+                if (WANT_IDX && idx_out) idx_out[(size_t)b * NQ + qidx] = ii;
+                if (dmin_out) dmin_out[(size_t)b * NQ + qidx] = dd;
+                acc += (double)dd;
+            }
+        }
+    }
+    if (tid >= 64 || !p.partials) return;
+    const double tot = __shfl(wave_sum_l63_f64(acc), 63);   // fixed order: deterministic
+    if (!p.ticket) {
+        if (tid == 0) p.partials[(size_t)c * tiles + btile] = tot;
+        return;
+    }
+    const FinalizeArgs fa{reinterpret_cast<unsigned long long *>(p.partials), p.ticket, p.nvalid, p.B, tiles, p.tiles_x, p.tiles_y,
+                          p.sums_out, p.loss_out, p.N, p.M, p.Bg, p.w1, p.w2};
+    (void)fused_finalize_wave0(fa, (size_t)c * tiles + btile, tot, tid);
+}
+
 // Generic dimension (D == 1 or D > 3): one thread per query, candidates read through L1/L2.
 // Correct for any D; not the tuned path (the chamfer configs are all D = 3).
 __global__ __launch_bounds__(kThreads) void nn1_generic_kernel(Nn1Params p, int D) {
@@ -1139,7 +1320,8 @@ __global__ __launch_bounds__(kThreads) void chamfer_bwd_kernel(
 struct Plan {
     int R, tiles_x, tiles_y, tiles, chunk, grid;
     size_t lds_bytes;
-    int variant;  // 0 = exact hot loop (D = 2, and D = 3 under FX3D_NN1_VARIANT=0), 3 = fp16-split MFMA filter + exact re-scan
+    int variant;  // 0 = exact hot loop (D = 2, and D = 3 under FX3D_NN1_VARIANT=0), 3 = fp16-split MFMA filter + exact re-scan,
+                  // 4 = nn1_tiny_kernel (D = 3, small problems: exact, no per-cloud statistics / image)
     int threads, tpb, tpb_y;  // tpb: passes per block of the x -> y direction, tpb_y: of y -> x
     int nsplit;  // fp16 variant: chunk subsets per query tile (multi-chunk clouds with too few blocks)
     int tail;    // fp16 variant: kHTail when clouds of chunk + (1 .. kHTail) points run as one chunk + an exact tail
@@ -1163,6 +1345,26 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
     const int maxc0 = N > M ? N : M;
     const int clouds8 = (2 * B + 7) / 8;
     pl.nsplit = 1;
+    if (pl.variant == 3 && 2ll * B * (long long)N * M <= 1000000ll * opt(OPT_NN1_TINY_MPAIRS)) {
+        // small problem: the exact kernel without statistics / image (C1, the reference harness's n <= 1024).  Two queries per
+        // lane once 16-query blocks would be more than two rounds of the chip
+        pl.variant = 4;
+        pl.threads = kTyThreads;
+        const int cus = device_cus();
+        pl.R = work / kTyQ > 2ll * cus ? 2 : 1;
+        const int per = kTyQ * pl.R;
+        const int rx = (N + per - 1) / per, ry = (M + per - 1) / per;   // query tiles per cloud and direction
+        int tpb = 1;                                                     // consecutive tiles per block: at most ~2 blocks per CU
+        while ((long long)B * ((rx + tpb - 1) / tpb + (ry + tpb - 1) / tpb) > 2ll * cus && tpb < (rx > ry ? rx : ry)) tpb *= 2;
+        pl.tpb = pl.tpb_y = tpb;
+        pl.tiles_x = (rx + tpb - 1) / tpb;
+        pl.tiles_y = (ry + tpb - 1) / tpb;
+        pl.tiles = pl.tiles_x > pl.tiles_y ? pl.tiles_x : pl.tiles_y;
+        pl.chunk = 0;
+        pl.lds_bytes = 0;
+        pl.grid = 2 * B * pl.tiles;
+        return pl;
+    }
     if (pl.variant == 0) {
         const int per_block = kThreads * R;
         pl.tiles_x = (N + per_block - 1) / per_block;
@@ -1264,6 +1466,17 @@ size_t partials_count(const Plan &pl, int B) { return (size_t)2 * B * pl.tiles; 
 
 template <int DIM, bool WANT_IDX>
 fx3d_status launch_small(const Nn1Params &p, const Plan &pl, hipStream_t st) {
+    if (pl.variant == 4) {
+        if (DIM == 3) {
+            const bool small = (p.N > p.M ? p.N : p.M) <= kTySl * kTyG;   // both directions' candidates are one group per slice
+            if (pl.R == 2 && small) hipLaunchKernelGGL((nn1_tiny_kernel<2, 1, WANT_IDX>), dim3(pl.grid), dim3(kTyThreads), 0, st, p);
+            else if (pl.R == 2) hipLaunchKernelGGL((nn1_tiny_kernel<2, 4, WANT_IDX>), dim3(pl.grid), dim3(kTyThreads), 0, st, p);
+            else if (small) hipLaunchKernelGGL((nn1_tiny_kernel<1, 1, WANT_IDX>), dim3(pl.grid), dim3(kTyThreads), 0, st, p);
+            else hipLaunchKernelGGL((nn1_tiny_kernel<1, 4, WANT_IDX>), dim3(pl.grid), dim3(kTyThreads), 0, st, p);
+        }
+        FX3D_LAUNCH_CHECK();
+        return FX3D_OK;
+    }
     if (pl.variant == 3) {
         if (DIM == 3) {
             // > 64 KiB of dynamic LDS needs an explicit opt-in (static LDS of the kernel: < 1 KiB)
@@ -1486,7 +1699,7 @@ static fx3d_status chamfer_common(const float *x, int N, const float *y, int M, 
         FX3D_LAUNCH_CHECK();
         return FX3D_OK;
     }
-    if (pl.variant == 3 && D == 3) {  // one launch: the last block reduces the partials
+    if ((pl.variant == 3 || pl.variant == 4) && D == 3) {  // one launch: the last block reduces the partials
         fx3d_status trc = FX3D_OK;
         unsigned int *ticket = ticket_slot(&trc, st);
         if (!ticket) return trc;

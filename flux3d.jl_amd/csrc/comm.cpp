@@ -14,6 +14,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -56,6 +57,7 @@ struct Rccl {
     CommUserRank_fn user_rank = nullptr;
     CommInitAll_fn init_all = nullptr;
     Group_fn group_start = nullptr, group_end = nullptr;
+    CommDestroy_fn abort = nullptr;  // ncclCommAbort: same signature as ncclCommDestroy
 };
 
 Rccl *rccl() {
@@ -79,6 +81,7 @@ Rccl *rccl() {
             r.init_all = (CommInitAll_fn)dlsym(r.h, "ncclCommInitAll");
             r.group_start = (Group_fn)dlsym(r.h, "ncclGroupStart");
             r.group_end = (Group_fn)dlsym(r.h, "ncclGroupEnd");
+            r.abort = (CommDestroy_fn)dlsym(r.h, "ncclCommAbort");
         }
     });
     return (r.h && r.get_id && r.init_rank && r.destroy && r.allreduce) ? &r : nullptr;
@@ -115,11 +118,15 @@ constexpr uint64_t kMagic = 0x3144495544335846ull;  // "FX3DUID1"
 struct Hello { uint64_t magic, token; int32_t nranks, rank; };
 struct FilePayload { uint64_t magic, nonce; int64_t wall; int32_t nranks, pad; uint8_t id[128]; };
 
-uint64_t job_token() {
+uint64_t job_token(const std::string &host, int port, int nranks) {
+    // FNV-1a of FX3D_COMM_TOKEN when the job exports one; otherwise of "host:port:nranks" -- every rank of a job derives the
+    // same value from its rendezvous string, and a peer of another job (another port or world size) or a stray client
+    // that only knows the magic is refused (token 0 handed the unique id to anybody)
     const char *e = getenv("FX3D_COMM_TOKEN");
-    uint64_t h = 1469598103934665603ull;  // FNV-1a of the string; 0 when unset
-    if (!e || !*e) return 0;
-    for (; *e; ++e) { h ^= (unsigned char)*e; h *= 1099511628211ull; }
+    const std::string dflt = host + ":" + std::to_string(port) + ":" + std::to_string(nranks);
+    const char *src = (e && *e) ? e : dflt.c_str();
+    uint64_t h = 1469598103934665603ull;
+    for (; *src; ++src) { h ^= (unsigned char)*src; h *= 1099511628211ull; }
     return h;
 }
 
@@ -153,7 +160,7 @@ bool recv_all(int fd, void *buf, size_t n) {
 
 fx3d_status boot_tcp(const std::string &host, int port, int nranks, int rank, uint8_t *id128) {
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(kBootTimeoutS);
-    const uint64_t token = job_token();
+    const uint64_t token = job_token(host, port, nranks);
     if (rank == 0) {
         const int ls = ::socket(AF_INET, SOCK_STREAM, 0);
         if (ls < 0) { set_error("fx3d_comm_exchange_id: socket() failed"); return FX3D_ERR_RCCL; }
@@ -164,7 +171,8 @@ fx3d_status boot_tcp(const std::string &host, int port, int nranks, int rank, ui
         a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(loopback ? INADDR_LOOPBACK : INADDR_ANY); a.sin_port = htons((uint16_t)port);
         if (::bind(ls, reinterpret_cast<sockaddr *>(&a), sizeof(a)) != 0 || ::listen(ls, nranks + 8) != 0) {
             ::close(ls);
-            set_error("fx3d_comm_exchange_id: cannot listen on port %d", port);
+            set_error("fx3d_comm_exchange_id: cannot listen on port %d (in use?): choose another one with FX3D_COMM_RENDEZVOUS=tcp://host:port, "
+                      "FX3D_COMM_PORT_OFFSET, or a file:// rendezvous", port);
             return FX3D_ERR_RCCL;
         }
         std::vector<char> served((size_t)nranks, 0);
@@ -203,6 +211,11 @@ fx3d_status boot_tcp(const std::string &host, int port, int nranks, int rank, ui
     fx3d_status rc = FX3D_ERR_RCCL;
     while (std::chrono::steady_clock::now() < deadline) {
         const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
+        if (fd >= 0) {  // a service that accepts on this port and stays silent must not hold this rank beyond the deadline
+            timeval tv{5, 0};
+            ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+            ::setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+        }
         if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
             const Hello h{kMagic, token, nranks, rank};
             uint64_t magic = 0;
@@ -499,10 +512,10 @@ struct Worker {
     std::function<fx3d_status()> job;
     bool has_job = false, busy = false, quit = false;
     fx3d_status rc = FX3D_OK;
+    fx3d_status rc0 = FX3D_OK;   // the worker's own setup (device, stream, result buffers); written by its thread before any job runs
     std::string err;
 
     void loop() {
-        fx3d_status rc0 = FX3D_OK;
         if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess ||
             hipMalloc(reinterpret_cast<void **>(&sums), 2 * sizeof(double)) != hipSuccess ||
             hipMalloc(reinterpret_cast<void **>(&loss), sizeof(float)) != hipSuccess)
@@ -546,6 +559,11 @@ struct Worker {
 
 struct Multi {
     std::vector<Worker *> w;
+    std::vector<int> devs;
+    // set when an evaluation failed AFTER some device had enqueued its collective: those collectives have no partner, the
+    // communicators are aborted and rebuilt before the next evaluation; if the rebuild fails the handle stays
+    // broken and every later call says so
+    bool broken = false;
 };
 
 fx3d_status run_all(Multi *m, const std::function<fx3d_status(Worker &, int)> &f) {
@@ -562,6 +580,36 @@ fx3d_status run_all(Multi *m, const std::function<fx3d_status(Worker &, int)> &f
     }
     if (rc) set_error("%s", err.c_str());
     return rc;
+}
+
+// After a failed phase 2: end every pending collective and drop the communicators (ncclCommAbort where the library has it,
+// else ncclCommDestroy after the streams drained as far as they can).  The handle is marked broken.
+void multi_abort_comms(Multi *m) {
+    Rccl *r = rccl();
+    for (Worker *w : m->w) {
+        if (r && w->comm) (void)(r->abort ? r->abort(w->comm) : r->destroy(w->comm));
+        w->comm = nullptr;
+    }
+    m->broken = true;
+}
+
+fx3d_status multi_rebuild_comms(Multi *m) {
+    Rccl *r = rccl();
+    if (!r || !r->init_all) { set_error("fx3d_chamfer_fwd_multi: the communicators were aborted after a failed evaluation and librccl cannot rebuild them"); return FX3D_ERR_RCCL; }
+    for (Worker *w : m->w) (void)w->wait();
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    std::vector<ncclComm_t_> comms(m->w.size(), nullptr);
+    const int rc = r->init_all(comms.data(), (int)m->w.size(), m->devs.data());
+    (void)hipSetDevice(prev);
+    if (rc) {
+        set_error("fx3d_chamfer_fwd_multi: the communicators were aborted after a failed evaluation; ncclCommInitAll failed to rebuild them (%d): "
+                  "destroy this handle (fx3d_multi_destroy) and create a new one", rc);
+        return FX3D_ERR_RCCL;
+    }
+    for (size_t d = 0; d < m->w.size(); ++d) m->w[d]->comm = comms[d];
+    m->broken = false;
+    return FX3D_OK;
 }
 
 }  // namespace
@@ -587,6 +635,7 @@ fx3d_status fx3d_comm_init_all(fx3d_multi_t *multi, int32_t ndev, const int32_t 
     (void)hipSetDevice(prev);  // (ncclCommInitAll walks the devices)
     if (rc) return rccl_fail(rc, "ncclCommInitAll");
     Multi *m = new Multi;
+    m->devs = devs;
     for (int d = 0; d < ndev; ++d) {
         Worker *w = new Worker;
         w->dev = devs[(size_t)d];
@@ -646,36 +695,70 @@ fx3d_status fx3d_chamfer_fwd_multi(fx3d_multi_t multi, const float *const *x, in
         tot += B_local[d];
     }
     FX3D_REQUIRE(tot <= B_global, "fx3d_chamfer_fwd_multi: the shards hold %lld clouds, B_global = %lld", tot, (long long)B_global);
-    return run_all(m, [&](Worker &w, int d) -> fx3d_status {
+    if (m->broken) {
+        const fx3d_status rrc = multi_rebuild_comms(m);
+        if (rrc) return rrc;
+    }
+    // Phase 1 on every device, NOTHING enqueued: the worker's setup status, the scratch query and (re)allocation.  Only when
+    // every device passed does phase 2 enqueue kernel -> all-reduce -> finalise: a device that fails before its collective
+    // would leave the others' collectives without a partner (the host thread of device 0 would wait for ever).
+    fx3d_status rc = run_all(m, [&](Worker &w, int d) -> fx3d_status {
         const int Bl = B_local[d];
-        fx3d_stream_t st = reinterpret_cast<fx3d_stream_t>(w.stream);
-        if (Bl > 0) {
-            size_t need = 0;
-            fx3d_status rc = fx3d_chamfer_workspace_bytes(N, M, Bl, D, &need);
-            if (rc) return rc;
-            if (need > w.ws_bytes) {
-                FX3D_HIP(hipStreamSynchronize(w.stream));  // (an earlier evaluation may still use the old scratch)
-                if (w.ws) FX3D_HIP(hipFree(w.ws));
-                w.ws = nullptr; w.ws_bytes = 0;
-                FX3D_HIP(hipMalloc(&w.ws, need));
-                w.ws_bytes = need;
-            }
-            rc = fx3d_chamfer_sums(x[d], N, y[d], M, Bl, D, w.sums, nullptr, nullptr, w.ws, w.ws_bytes, st);
-            if (rc) return rc;
-        } else {
-            FX3D_HIP(hipMemsetAsync(w.sums, 0, 2 * sizeof(double), w.stream));
-        }
-        fx3d_status rc = fx3d_comm_allreduce_sum_f64(w.comm, w.sums, 2, st);
-        if (rc) return rc;
-        float *out = losses_dev && losses_dev[d] ? losses_dev[d] : w.loss;
-        rc = fx3d_chamfer_finalize(w.sums, N, M, B_global, D, w1, w2, out, st);
-        if (rc) return rc;
-        if (d == 0 && loss_host) {
-            FX3D_HIP(hipMemcpyAsync(loss_host, out, sizeof(float), hipMemcpyDeviceToHost, w.stream));
-            FX3D_HIP(hipStreamSynchronize(w.stream));
+        if (Bl <= 0) return FX3D_OK;
+        size_t need = 0;
+        const fx3d_status r1 = fx3d_chamfer_workspace_bytes(N, M, Bl, D, &need);
+        if (r1) return r1;
+        if (need > w.ws_bytes) {
+            FX3D_HIP(hipStreamSynchronize(w.stream));  // (an earlier evaluation may still use the old scratch)
+            if (w.ws) FX3D_HIP(hipFree(w.ws));
+            w.ws = nullptr; w.ws_bytes = 0;
+            FX3D_HIP(hipMalloc(&w.ws, need));
+            w.ws_bytes = need;
         }
         return FX3D_OK;
     });
+    if (rc) return rc;
+    std::atomic<int> enq_collectives{0};
+    rc = run_all(m, [&](Worker &w, int d) -> fx3d_status {
+        const int Bl = B_local[d];
+        fx3d_stream_t st = reinterpret_cast<fx3d_stream_t>(w.stream);
+        if (Bl > 0) {
+            const fx3d_status r1 = fx3d_chamfer_sums(x[d], N, y[d], M, Bl, D, w.sums, nullptr, nullptr, w.ws, w.ws_bytes, st);
+            if (r1) return r1;
+        } else {
+            FX3D_HIP(hipMemsetAsync(w.sums, 0, 2 * sizeof(double), w.stream));
+        }
+        fx3d_status r2 = fx3d_comm_allreduce_sum_f64(w.comm, w.sums, 2, st);
+        if (r2) return r2;
+        enq_collectives.fetch_add(1);
+        float *out = losses_dev && losses_dev[d] ? losses_dev[d] : w.loss;
+        r2 = fx3d_chamfer_finalize(w.sums, N, M, B_global, D, w1, w2, out, st);
+        if (r2) return r2;
+        return FX3D_OK;
+    });
+    if (rc) {
+        // a device failed in phase 2: if any other device has its all-reduce enqueued, that collective will never complete.
+        // Abort the communicators (ncclCommAbort ends the pending collectives) and mark the handle: the next evaluation
+        // rebuilds them.  Never a half-enqueued state handed back as if it were usable.
+        char keep[512];
+        keep[0] = 0;
+        fx3d_last_error(keep, sizeof(keep));
+        if (enq_collectives.load() > 0 && enq_collectives.load() < (int)m->w.size()) multi_abort_comms(m);
+        set_error("%s", keep);
+        return rc;
+    }
+    if (loss_host) {  // every device has enqueued its collective: reading device 0's result back cannot wait for a missing partner
+        Worker &w0 = *m->w[0];
+        float *out = losses_dev && losses_dev[0] ? losses_dev[0] : w0.loss;
+        rc = run_all(m, [&](Worker &w, int d) -> fx3d_status {
+            if (d != 0) return FX3D_OK;
+            FX3D_HIP(hipMemcpyAsync(loss_host, out, sizeof(float), hipMemcpyDeviceToHost, w.stream));
+            FX3D_HIP(hipStreamSynchronize(w.stream));
+            return FX3D_OK;
+        });
+        (void)w0;
+    }
+    return rc;
 }
 
 }  // extern "C"

@@ -85,6 +85,8 @@ enum Opt {
     OPT_EDGECONV_UNFUSED,     // 1: EdgeConv graph build as search + feature kernels
     OPT_LAP_BWD_SCATTER,      // 1: fx3d_laplacian_loss_bwd as the scatter with float atomics (any CSR) instead of the gather (symmetric structure)
     OPT_CDF_MULTIBLOCK_FROM,  // faces per mesh from which the sampling CDF takes the multi-block path (0 = the built-in limit)
+    OPT_NN1_TINY_MPAIRS,      // D = 3 nn1 / chamfer: problems of at most this many MILLION ordered pair evaluations (2 B N M) run on the
+                              // exact small-problem kernel (nn1_tiny_kernel) instead of the fp16-filter kernel; 0 = never
     OPT_COUNT
 };
 int opt(Opt o);

@@ -2,6 +2,7 @@
 // Replaces what the reference gets from CUDA.jl + Flux's gpu/cpu functor walkers
 // (src/Flux3D.jl:52-61, src/rep/pcloud.jl:57, src/rep/mesh.jl:189-190).
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <set>
@@ -44,14 +45,22 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"edgeconv_unfused", "FX3D_EDGECONV_UNFUSED", 0},
     {"lap_bwd_scatter", "FX3D_LAP_BWD_SCATTER", 0},
     {"cdf_multiblock_from", "FX3D_CDF_MULTIBLOCK_FROM", 0},
+    {"nn1_tiny_mpairs", "FX3D_NN1_TINY_MPAIRS", 24},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::once_flag g_opt_once;
 void opt_init() {
     std::call_once(g_opt_once, [] {
         for (int i = 0; i < OPT_COUNT; ++i) {
-            const char *e = getenv(kOptDefs[i].env);  // the environment seeds the defaults, once
-            g_opt[i].store(e && *e ? atoi(e) : kOptDefs[i].dflt, std::memory_order_relaxed);
+            const char *e = getenv(kOptDefs[i].env);  // the environment seeds the defaults, once (read-once: INTEGRATION.md)
+            int v = kOptDefs[i].dflt;
+            if (e) {  // a switch that is SET counts as on unless it parses as a number: FX3D_KNN_NO_MFMA=yes and an empty value mean 1
+                char *end = nullptr;
+                const long n = strtol(e, &end, 10);
+                while (end && (*end == ' ' || *end == '\t')) ++end;
+                v = (end == e || (end && *end)) ? 1 : (int)n;
+            }
+            g_opt[i].store(v, std::memory_order_relaxed);
         }
     });
 }

@@ -115,7 +115,7 @@ class ShardedChamfer:
 def default_rendezvous():
     """Where the ranks meet to pass the RCCL unique id (fx3d_comm_bootstrap).  ``FX3D_COMM_RENDEZVOUS`` if set
     (``tcp://host:port`` or ``file://path``).  Under a launcher that exports MASTER_ADDR / MASTER_PORT (torchrun):
-    ``tcp://MASTER_ADDR:(MASTER_PORT + 1)`` -- the launcher's own store owns MASTER_PORT; nothing persists, a crashed
+    ``tcp://MASTER_ADDR:(MASTER_PORT + FX3D_COMM_PORT_OFFSET)`` (offset 1 by default) -- the launcher's own store owns MASTER_PORT; nothing persists, a crashed
     earlier job cannot leave state behind, and it works across nodes.  Without one: a file in the temp directory keyed
     by the launcher's pid (single node; the library removes stale files, confirms a per-job nonce and cleans up)."""
     import os
@@ -125,8 +125,9 @@ def default_rendezvous():
         return r
     addr, port = os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")
     if addr and port and port.isdigit():
-        p = int(port) + 1
-        return f"tcp://{addr}:{p if p < 65536 else int(port) - 1}"
+        off = os.environ.get("FX3D_COMM_PORT_OFFSET", "1")   # (another service on MASTER_PORT + 1: pick another offset)
+        p = int(port) + (int(off) if off.lstrip("-").isdigit() and int(off) != 0 else 1)
+        return f"tcp://{addr}:{p if 0 < p < 65536 else int(port) - 1}"
     return "file://" + os.path.join(tempfile.gettempdir(), f"fx3d_uid_{os.getuid()}_{os.getppid()}")
 
 
