@@ -1319,48 +1319,117 @@ __global__ __launch_bounds__(C::T) void knn_f16_d3_kernel(const float *__restric
             // ---- tau: kk-th smallest of the 128 group minima of every query: 32 in this lane, 32 in its partner
             //      lane, 64 in the other wave of the group.  Sorting network in registers, one exchange with the
             //      partner lane, one exchange with the other wave through LDS, bitonic merges in between.
-            k3_sort_regs<32>(mn);
-            {
-                float oth[32];  // the partner lane's values (v_permlane32_swap: no LDS round trip)
-#pragma unroll
-                for (int r = 0; r < 32; ++r)  // mn[r] <- lanes 0-31's value, oth[r] <- lanes 32-63's, in every lane
-                    // (inline asm: this compiler's __builtin_amdgcn_permlane32_swap returns its first result twice)
-                    asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(mn[r]), "=&v"(oth[r]));
-#pragma unroll
-                for (int r = 0; r < 32; ++r)  // the 32 smallest of the wave's 64 (a bitonic sequence), in both half-lanes
-                    mn[r] = vmin_f32(mn[r], oth[31 - r]);
-            }
-#pragma unroll
-            for (int j = 16; j > 0; j >>= 1) {  // one bitonic merge sorts it ascending
-#pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    const int l = i ^ j;
-                    if (l > i) {
-                        const float lo = vmin_f32(mn[i], mn[l]), hi = vmax_f32(mn[i], mn[l]);
-                        mn[i] = lo;
-                        mn[l] = hi;
-                    }
-                }
-            }
-            float *xch = reinterpret_cast<float *>(lists_all);  // [C::W][32][33]: the lists are not in use yet
-            if (hh == 0) {
-#pragma unroll
-                for (int r = 0; r < 32; ++r) xch[(wv * 32 + jq) * 33 + r] = mn[r];
-            }
-            __syncthreads();
-            // the kk-th smallest of the union of this wave's 32 smallest X and the other wave's Y (both ascending) without merging
-            // them: min over the splits (i values from X, kk - i from Y) of max(X[i-1], Y[kk-i-1]).  For kk <= 32 that is the kk-th
-            // smallest of all 128 group minima; for 32 < kk <= 64 the kk-th smallest of these 64 -- an upper bound of it (equal unless
-            // one wave holds more than 32 of the kk smallest).  ~3 VALU + one LDS read per split instead of 32 reads + a 32-value
-            // bitonic merge (192 VALU).
             float tau = INFINITY;
-            if (C::KKMAX <= 32) {
-                const float *po = xch + (((wv + C::G) % C::W) * 32 + jq) * 33;  // the group's other wave
+            float *xch = reinterpret_cast<float *>(lists_all);  // the lists are not in use yet
+            if (C::KKMAX <= 32 && kk <= 24 && M >= 128) {
+                // ---- round 4: tau from the EIGHT smallest of each HALF of a lane's group minima (16 of its 32) instead of a sort
+                //      of all 32.  The kk-th smallest of any subset of the 128 group minima bounds the kk-th smallest filter value
+                //      (every group minimum is some candidate's value); the subset {8 smallest of each of the query's eight
+                //      half-lane sets of 16} holds the kk <= 24 smallest of all 128 unless one set holds more than 8 of them
+                //      (kk = 21: Bin(21, 1/8) >= 9, 4e-4 per set, and tau is then the next order statistic).  (The 8 smallest of
+                //      each LANE's 32 -- Bin(21, 1/4) -- was cheaper still but let one query in 10^4 end with 40+ survivors: the
+                //      rank phase of its block doubled, and a one-round launch lasts as long as its slowest block: 21.9 -> 23.5 us.)
+                //      Four 19-exchange sorts of 8, two "8 smallest of two sorted 8" steps (8 v_min + a 12-exchange bitonic merge),
+                //      a 16-value merge, the partner lane's sixteen by v_permlane32_swap, a 32-value merge, the other wave's
+                //      through LDS and the split minimum: ~560 VALU per wave where the sort of 32 and two 32-value merges took ~860.
+                float a8[4][8];
 #pragma unroll
-                for (int r = 0; r < 32; ++r) mn[r] = vmin_f32(mn[r], po[31 - r]);     // the 32 smallest of the 128
+                for (int g = 0; g < 4; ++g) {
 #pragma unroll
-                for (int j = 16; j > 0; j >>= 1) {
+                    for (int i = 0; i < 8; ++i) a8[g][i] = mn[8 * g + i];
+                    k3_sort_regs<8>(a8[g]);
+                }
+                auto low8 = [](float (&x)[8], const float (&y)[8]) {  // x <- the 8 smallest of two ascending octets, ascending
 #pragma unroll
+                    for (int i = 0; i < 8; ++i) x[i] = vmin_f32(x[i], y[7 - i]);  // bitonic
+#pragma unroll
+                    for (int j = 4; j > 0; j >>= 1)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int l = i ^ j;
+                            if (l > i) {
+                                const float lo = vmin_f32(x[i], x[l]), hi = vmax_f32(x[i], x[l]);
+                                x[i] = lo;
+                                x[l] = hi;
+                            }
+                        }
+                };
+                low8(a8[0], a8[1]);
+                low8(a8[2], a8[3]);
+                float x32[32];  // [0, 16): this lane's sixteen, ascending after the first merge; then the wave's 32
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { x32[r] = a8[0][r]; x32[8 + r] = a8[2][7 - r]; }  // ascending then descending: bitonic
+#pragma unroll
+                for (int j = 8; j > 0; j >>= 1)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int l = i ^ j;
+                        if (l > i) {
+                            const float lo = vmin_f32(x32[i], x32[l]), hi = vmax_f32(x32[i], x32[l]);
+                            x32[i] = lo;
+                            x32[l] = hi;
+                        }
+                    }
+                {
+                    float oth[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)  // x32[r] <- lanes 0-31's value, oth[r] <- lanes 32-63's, in every lane
+                        asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x32[r]), "=&v"(oth[r]));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x32[16 + r] = oth[15 - r];
+                }
+#pragma unroll
+                for (int j = 16; j > 0; j >>= 1)
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) {
+                        const int l = i ^ j;
+                        if (l > i) {
+                            const float lo = vmin_f32(x32[i], x32[l]), hi = vmax_f32(x32[i], x32[l]);
+                            x32[i] = lo;
+                            x32[l] = hi;
+                        }
+                    }
+                // exchange rows of 27 words per (wave, query): [0] = +inf, [1] = -inf, [2 + r] = the wave's r-th smallest, r < 24
+                float *row = xch + (wv * 32 + jq) * 27;
+                if (hh == 0) {
+#pragma unroll
+                    for (int r = 0; r < 24; ++r) row[2 + r] = x32[r];
+                } else {
+                    row[0] = INFINITY;
+                    row[1] = -INFINITY;
+                }
+                __syncthreads();
+                // the kk-th smallest of the union of X = x32 and the other wave's Y (both ascending) without merging them: min
+                // over the splits (i values from X, kk - i from Y) of max(X'[i-1], Y'[kk-i-1]), X'[-1] = Y'[-1] = -inf; a split with
+                // i > kk reads +inf.  (The offsets depend on the runtime kk: computed here, behind an opaque copy -- hoisted to the
+                // kernel's start they were 25 more long-lived scalars in a kernel that already spills SGPRs.)
+                int kko = kk;
+                asm volatile("" : "+s"(kko));
+                const float *po = xch + (((wv + C::G) % C::W) * 32 + jq) * 27;
+                float yv[25];  // (all reads first)
+#pragma unroll
+                for (int i = 0; i <= 24; ++i) {
+                    const int o = kko - i + 1;
+                    yv[i] = po[o > 0 ? o : 0];
+                }
+                tau = yv[0];   // i = 0: X'[-1] = -inf
+#pragma unroll
+                for (int i = 1; i <= 24; ++i) tau = vmin_f32(tau, vmax_f32(x32[i - 1], yv[i]));
+            } else {
+                k3_sort_regs<32>(mn);
+                {
+                    float oth[32];  // the partner lane's values (v_permlane32_swap: no LDS round trip)
+    #pragma unroll
+                    for (int r = 0; r < 32; ++r)  // mn[r] <- lanes 0-31's value, oth[r] <- lanes 32-63's, in every lane
+                        // (inline asm: this compiler's __builtin_amdgcn_permlane32_swap returns its first result twice)
+                        asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(mn[r]), "=&v"(oth[r]));
+    #pragma unroll
+                    for (int r = 0; r < 32; ++r)  // the 32 smallest of the wave's 64 (a bitonic sequence), in both half-lanes
+                        mn[r] = vmin_f32(mn[r], oth[31 - r]);
+                }
+    #pragma unroll
+                for (int j = 16; j > 0; j >>= 1) {  // one bitonic merge sorts it ascending
+    #pragma unroll
                     for (int i = 0; i < 32; ++i) {
                         const int l = i ^ j;
                         if (l > i) {
@@ -1370,24 +1439,51 @@ __global__ __launch_bounds__(C::T) void knn_f16_d3_kernel(const float *__restric
                         }
                     }
                 }
-                tau = mn[0];  // kk <= 32: among the 32 smallest
-#pragma unroll
-                for (int r = 1; r < 32; ++r) tau = (kk - 1) == r ? mn[r] : tau;
-            } else
-            {
-                const float *po = xch + (((wv + C::G) % C::W) * 32 + jq) * 33;  // the group's other wave
-                float yv[33];  // (all reads first, clamped addresses: a branch per split made them a chain of LDS round trips)
-#pragma unroll
-                for (int i = 0; i <= 32; ++i) {
-                    const int yi = kk - i - 1;
-                    yv[i] = po[yi < 0 ? 0 : (yi > 31 ? 31 : yi)];
+                if (hh == 0) {
+    #pragma unroll
+                    for (int r = 0; r < 32; ++r) xch[(wv * 32 + jq) * 33 + r] = mn[r];
                 }
-#pragma unroll
-                for (int i = 0; i <= 32; ++i) {
-                    const int ny = kk - i;  // (uniform: the selects below take scalar conditions)
-                    const float a = i >= 1 ? mn[i >= 1 ? i - 1 : 0] : -INFINITY;
-                    const float t = vmax_f32(a, ny >= 1 ? yv[i] : -INFINITY);
-                    tau = vmin_f32(tau, (ny >= 0 && ny <= 32) ? t : INFINITY);
+                __syncthreads();
+                // the kk-th smallest of the union of this wave's 32 smallest X and the other wave's Y (both ascending) without merging
+                // them: min over the splits (i values from X, kk - i from Y) of max(X[i-1], Y[kk-i-1]).  For kk <= 32 that is the kk-th
+                // smallest of all 128 group minima; for 32 < kk <= 64 the kk-th smallest of these 64 -- an upper bound of it (equal unless
+                // one wave holds more than 32 of the kk smallest).  ~3 VALU + one LDS read per split instead of 32 reads + a 32-value
+                // bitonic merge (192 VALU).
+                if (C::KKMAX <= 32) {
+                    const float *po = xch + (((wv + C::G) % C::W) * 32 + jq) * 33;  // the group's other wave
+    #pragma unroll
+                    for (int r = 0; r < 32; ++r) mn[r] = vmin_f32(mn[r], po[31 - r]);     // the 32 smallest of the 128
+    #pragma unroll
+                    for (int j = 16; j > 0; j >>= 1) {
+    #pragma unroll
+                        for (int i = 0; i < 32; ++i) {
+                            const int l = i ^ j;
+                            if (l > i) {
+                                const float lo = vmin_f32(mn[i], mn[l]), hi = vmax_f32(mn[i], mn[l]);
+                                mn[i] = lo;
+                                mn[l] = hi;
+                            }
+                        }
+                    }
+                    tau = mn[0];  // kk <= 32: among the 32 smallest
+    #pragma unroll
+                    for (int r = 1; r < 32; ++r) tau = (kk - 1) == r ? mn[r] : tau;
+                } else
+                {
+                    const float *po = xch + (((wv + C::G) % C::W) * 32 + jq) * 33;  // the group's other wave
+                    float yv[33];  // (all reads first, clamped addresses: a branch per split made them a chain of LDS round trips)
+    #pragma unroll
+                    for (int i = 0; i <= 32; ++i) {
+                        const int yi = kk - i - 1;
+                        yv[i] = po[yi < 0 ? 0 : (yi > 31 ? 31 : yi)];
+                    }
+    #pragma unroll
+                    for (int i = 0; i <= 32; ++i) {
+                        const int ny = kk - i;  // (uniform: the selects below take scalar conditions)
+                        const float a = i >= 1 ? mn[i >= 1 ? i - 1 : 0] : -INFINITY;
+                        const float t = vmax_f32(a, ny >= 1 ? yv[i] : -INFINITY);
+                        tau = vmin_f32(tau, (ny >= 0 && ny <= 32) ? t : INFINITY);
+                    }
                 }
             }
             thr = __builtin_fmaf(tau, band_b1, band_a);

@@ -86,6 +86,31 @@ int main(int argc, char **argv) {
             const unsigned long long *q = &pr[b * 32];
             if (q[11] > q[10]) printf("block %d: tail after the output stage (tie re-rank / leftovers) %llu ticks\n", b, q[11] - q[10]);
         }
+    {   // the slowest block (a one-round launch lasts as long as it does): its stamps next to the average block's
+        int worst = 0;
+        double wt = 0;
+        for (int b = 0; b < nb; ++b) {
+            const unsigned long long *q = &pr[b * 32];
+            if (!q[0]) continue;
+            unsigned long long last = 0;
+            for (int k = 1; k < 32; ++k) last = std::max(last, q[k]);
+            if ((double)(last - q[0]) > wt) { wt = (double)(last - q[0]); worst = b; }
+        }
+        printf("slowest block %d:", worst);
+        unsigned long long prev = pr[worst * 32];
+        for (int k = 1; k < 32; ++k) if (pr[worst * 32 + k]) { printf(" %d:+%llu", k, pr[worst * 32 + k] - prev); prev = pr[worst * 32 + k]; }
+        printf("\n");
+        std::vector<double> tot;
+        for (int b = 0; b < nb; ++b) {
+            const unsigned long long *q = &pr[b * 32];
+            if (!q[0]) continue;
+            unsigned long long last = 0;
+            for (int k = 1; k < 32; ++k) last = std::max(last, q[k]);
+            tot.push_back((double)(last - q[0]));
+        }
+        std::sort(tot.begin(), tot.end());
+        if (!tot.empty()) printf("block durations: p50 %.0f p90 %.0f p99 %.0f max %.0f\n", tot[tot.size() / 2], tot[tot.size() * 9 / 10], tot[tot.size() * 99 / 100], tot.back());
+    }
     printf("blocks %d: thread-0 time avg %.0f max %.0f ticks; latest block start +%.0f; first start -> last end %.0f ticks\n", nbk,
            bsum / std::max(nbk, 1), bmax, smax, (double)(tmax - tmin));
     printf("queries %llu slow %llu unusable %llu list-overflow %llu n>cap %llu n<kk %llu sum(n) %llu (x13 launches)\n", pr[4095 * 32], pr[4095 * 32 + 1],
