@@ -96,10 +96,18 @@ int main(int argc, char **argv) {
             for (int k = 1; k < 32; ++k) last = std::max(last, q[k]);
             if ((double)(last - q[0]) > wt) { wt = (double)(last - q[0]); worst = b; }
         }
-        printf("slowest block %d:", worst);
-        unsigned long long prev = pr[worst * 32];
-        for (int k = 1; k < 32; ++k) if (pr[worst * 32 + k]) { printf(" %d:+%llu", k, pr[worst * 32 + k] - prev); prev = pr[worst * 32 + k]; }
-        printf("\n");
+        auto timeline = [&](int b, const char *what) {  // a block's stamps in TIME order
+            std::vector<std::pair<unsigned long long, int>> ev;
+            for (int k = 1; k < 32; ++k) if (pr[b * 32 + k]) ev.push_back({pr[b * 32 + k], k});
+            std::sort(ev.begin(), ev.end());
+            printf("%s %d:", what, b);
+            unsigned long long prev = pr[b * 32];
+            for (auto &e : ev) { printf(" %d:+%llu", e.second, e.first - prev); prev = e.first; }
+            printf("\n");
+        };
+        timeline(worst, "slowest block");
+        timeline(0, "block");
+        timeline(100, "block");
         std::vector<double> tot;
         for (int b = 0; b < nb; ++b) {
             const unsigned long long *q = &pr[b * 32];
