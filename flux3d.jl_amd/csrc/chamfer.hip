@@ -1570,6 +1570,8 @@ void partial_layout(const Plan &pl, int N, int M, int D, int *tiles, int *tx, in
 namespace fx3d {
 static constexpr int kTickets = 1024;      // eager, round robin
 static constexpr int kCapChunk = 4096;     // capture-owned slots per allocation
+// A slot is kTicketStride words: the arrival counter itself at [0] and, 64 bytes apart, the 16 first-level counters of the
+// two-level arrival (fx3d_common.h: ticket_arrive_last) that launches of many blocks use.
 unsigned int *ticket_slot(fx3d_status *rc, hipStream_t st) {
     static std::mutex mu;
     static std::atomic<unsigned int *> pools[64];
@@ -1605,27 +1607,27 @@ unsigned int *ticket_slot(fx3d_status *rc, hipStream_t st) {
             *rc = FX3D_ERR_HIP;
             return nullptr;
         }
-        return cap_chunk[dev] + cap_used[dev].fetch_add(1);
+        return cap_chunk[dev] + (size_t)cap_used[dev].fetch_add(1) * kTicketStride;
     }
     unsigned int *pool = pools[dev].load(std::memory_order_acquire);
     if (!pool || !cap_chunk[dev] || (cap_used[dev].load() > kCapChunk / 2 && !cap_spare[dev])) {
         std::lock_guard<std::mutex> lk(mu);
         pool = pools[dev].load(std::memory_order_relaxed);
         if (!pool) {
-            pool = fresh(kTickets);
+            pool = fresh((size_t)kTickets * kTicketStride);
             if (!pool) return nullptr;
             pools[dev].store(pool, std::memory_order_release);
         }
         if (!cap_chunk[dev]) {
-            cap_chunk[dev] = fresh(kCapChunk);
+            cap_chunk[dev] = fresh((size_t)kCapChunk * kTicketStride);
             if (!cap_chunk[dev]) return nullptr;
             cap_used[dev].store(0);
         } else if (cap_used[dev].load() > kCapChunk / 2 && !cap_spare[dev]) {
-            cap_spare[dev] = fresh(kCapChunk);
+            cap_spare[dev] = fresh((size_t)kCapChunk * kTicketStride);
             if (!cap_spare[dev]) return nullptr;
         }
     }
-    return pool + (next.fetch_add(1) % kTickets);
+    return pool + (size_t)(next.fetch_add(1) % kTickets) * kTicketStride;
 }
 }  // namespace fx3d
 
@@ -1769,6 +1771,8 @@ namespace {
 // term of its own rows, then the scatter of the other side's rows through ds_add_f32, one coalesced write.
 // Replaces 3 (N+M) B D global float atomics by LDS atomics (C2: 27 -> 8 us of kernels).
 constexpr int kBwdThreads = 1024;
+template <bool D3>  // D3: D == 3 with 12-byte row loads and four rows in flight (round 4: the one-row-at-a-time loops were latency
+                    // bound -- 1.6 TB/s of algorithmic bytes at B = 256 x 4096; same arithmetic per element)
 __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_lds_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ y, int M, int D,
     const int32_t *__restrict__ idx_x, const int32_t *__restrict__ idx_y, float ca, float cb,
@@ -1786,18 +1790,63 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_lds_kernel(
     const int per = (R + nsplit - 1) / nsplit;
     const int r0 = part * per < R ? part * per : R, r1 = r0 + per < R ? r0 + per : R;
     float *g = (side ? gy : gx) + (size_t)b * R * D;
-    for (int e = threadIdx.x; e < (r1 - r0) * D; e += kBwdThreads) {
-        const int i = r0 + e / D, d = e % D;
-        acc[e] = c_own * (own[(size_t)i * D + d] - oth[(size_t)idx_own[i] * D + d]);
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < S; j += kBwdThreads) {
-        const int i = idx_oth[j];
-        if (i >= r0 && i < r1)
-            for (int d = 0; d < D; ++d) {
-                const float t = c_oth * (oth[(size_t)j * D + d] - own[(size_t)i * D + d]);
-                atomicAdd(&acc[(size_t)(i - r0) * D + d], -t);
+    if (D3) {
+        for (int i0 = r0 + threadIdx.x; i0 < r1; i0 += 4 * kBwdThreads) {  // direct term: four rows in flight
+            int jj[4];
+            P3 o[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * kBwdThreads < r1 ? i0 + u * kBwdThreads : i0;
+                jj[u] = idx_own[i];
+                w[u] = *reinterpret_cast<const P3 *>(own + (size_t)i * 3);
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = *reinterpret_cast<const P3 *>(oth + (size_t)jj[u] * 3);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * kBwdThreads;
+                if (i < r1) {
+                    float *a = acc + (size_t)(i - r0) * 3;
+                    a[0] = c_own * (w[u].x - o[u].x);
+                    a[1] = c_own * (w[u].y - o[u].y);
+                    a[2] = c_own * (w[u].z - o[u].z);
+                }
+            }
+        }
+        __syncthreads();
+        for (int j0 = threadIdx.x; j0 < S; j0 += 4 * kBwdThreads) {  // scatter: four sweeps' indices in flight, then the hits' rows
+            int ii[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * kBwdThreads;
+                ii[u] = j < S ? idx_oth[j] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * kBwdThreads, i = ii[u];
+                if (i >= r0 && i < r1) {
+                    const P3 o = *reinterpret_cast<const P3 *>(oth + (size_t)j * 3), w = *reinterpret_cast<const P3 *>(own + (size_t)i * 3);
+                    float *a = acc + (size_t)(i - r0) * 3;
+                    atomicAdd(a + 0, -(c_oth * (o.x - w.x)));
+                    atomicAdd(a + 1, -(c_oth * (o.y - w.y)));
+                    atomicAdd(a + 2, -(c_oth * (o.z - w.z)));
+                }
+            }
+        }
+    } else {
+        for (int e = threadIdx.x; e < (r1 - r0) * D; e += kBwdThreads) {
+            const int i = r0 + e / D, d = e % D;
+            acc[e] = c_own * (own[(size_t)i * D + d] - oth[(size_t)idx_own[i] * D + d]);
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < S; j += kBwdThreads) {
+            const int i = idx_oth[j];
+            if (i >= r0 && i < r1)
+                for (int d = 0; d < D; ++d) {
+                    const float t = c_oth * (oth[(size_t)j * D + d] - own[(size_t)i * D + d]);
+                    atomicAdd(&acc[(size_t)(i - r0) * D + d], -t);
+                }
+        }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < (r1 - r0) * D; e += kBwdThreads) g[(size_t)r0 * D + e] = acc[e];
@@ -1908,12 +1957,16 @@ fx3d_status fx3d_chamfer_bwd(const float *x, int32_t N, const float *y, int32_t 
     while ((size_t)((maxr + nsplit - 1) / nsplit) * D * sizeof(float) > 144 * 1024) ++nsplit;  // ... nor more than fit in LDS
     const size_t lds = sizeof(float) * (size_t)((maxr + nsplit - 1) / nsplit) * D;
     if ((long long)2 * B * nsplit < (1ll << 30) && !no_lds) {
-        const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&chamfer_bwd_lds_kernel), 144 * 1024,
-                                                   "chamfer_bwd_lds_kernel");
+        const fx3d_status arc = D == 3 ? ensure_dynamic_lds(reinterpret_cast<const void *>(&chamfer_bwd_lds_kernel<true>), 144 * 1024, "chamfer_bwd_lds_kernel")
+                                       : ensure_dynamic_lds(reinterpret_cast<const void *>(&chamfer_bwd_lds_kernel<false>), 144 * 1024, "chamfer_bwd_lds_kernel");
         if (arc != FX3D_OK) return arc;
         ProfileScope prof("chamfer_bwd", st);
-        hipLaunchKernelGGL(chamfer_bwd_lds_kernel, dim3(2 * B * nsplit), dim3(kBwdThreads), lds, st, x, N, y, M, D, idx_x,
-                           idx_y, ca, cb, gx, gy, nsplit);
+        if (D == 3)
+            hipLaunchKernelGGL(chamfer_bwd_lds_kernel<true>, dim3(2 * B * nsplit), dim3(kBwdThreads), lds, st, x, N, y, M, D, idx_x,
+                               idx_y, ca, cb, gx, gy, nsplit);
+        else
+            hipLaunchKernelGGL(chamfer_bwd_lds_kernel<false>, dim3(2 * B * nsplit), dim3(kBwdThreads), lds, st, x, N, y, M, D, idx_x,
+                               idx_y, ca, cb, gx, gy, nsplit);
         FX3D_LAUNCH_CHECK();
         return FX3D_OK;
     }

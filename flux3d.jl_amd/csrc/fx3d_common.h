@@ -44,6 +44,9 @@ inline hipStream_t as_stream(fx3d_stream_t s) { return reinterpret_cast<hipStrea
 // it to zero (chamfer.hip).  A launch that `st` is capturing into a graph gets a slot of its own, never reused.
 // nullptr + *rc on allocation failure.
 unsigned int *ticket_slot(fx3d_status *rc, hipStream_t st);
+// Words per ticket slot: the arrival counter at [0] + 16 first-level counters, one per 64-byte line (ticket_arrive_last).
+constexpr int kTicketGroups = 16;
+constexpr int kTicketStride = 16 * (kTicketGroups + 1);
 fx3d_status ensure_dynamic_lds(const void *kernel, int bytes, const char *name);
 // compute units of the calling thread's current device (cached per device; 256 on an MI355X in SPX mode, fewer in the
 // partitioned modes): the launch plans size their rounds of blocks with it instead of a constant
@@ -87,11 +90,30 @@ enum Opt {
     OPT_CDF_MULTIBLOCK_FROM,  // faces per mesh from which the sampling CDF takes the multi-block path (0 = the built-in limit)
     OPT_NN1_TINY_MPAIRS,      // D = 3 nn1 / chamfer: problems of at most this many MILLION ordered pair evaluations (2 B N M) run on the
                               // exact small-problem kernel (nn1_tiny_kernel) instead of the fp16-filter kernel; 0 = never
+    OPT_MESH_MAX_BLOCKS,      // grid cap of the grid-stride mesh kernels (areas, losses, adjoints), 256-thread blocks; 0 = automatic
     OPT_COUNT
 };
 int opt(Opt o);
 
 constexpr int kWave = 64;  // gfx950 wavefront
+
+#ifdef __HIPCC__
+// Arrival of one block (ONE thread calls this, after its partial result is stored and drained) at a launch's ticket: true for
+// the last of `nblocks` arrivals.  Same-address device atomics serialise at ~9 ns each: 1024 blocks that finish together -- the
+// grid-stride mesh kernels -- spent 9 us of a 29 us launch queueing at one counter (round 4: edge_loss 24 / 29 / 39 / 61 us at
+// 512 / 1024 / 2048 / 4096 blocks).  Beyond 64 blocks the arrival is two-level: block b counts at first-level counter b % 16
+// (its own cache line), the last arriver of a group resets it and counts at the ticket itself, the last of the 16 groups is
+// the launch's last block.  The caller resets ticket[0] when it is done (as before).
+__device__ __forceinline__ bool ticket_arrive_last(unsigned int *ticket, unsigned int nblocks, unsigned int blk) {
+    if (nblocks <= 64u) return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1u;
+    const unsigned int g = blk % (unsigned int)kTicketGroups;
+    const unsigned int gsize = (nblocks - g + (unsigned int)kTicketGroups - 1u) / (unsigned int)kTicketGroups;
+    unsigned int *c1 = ticket + 16 * (g + 1u);
+    if (__hip_atomic_fetch_add(c1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gsize - 1u) return false;
+    __hip_atomic_store(c1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)kTicketGroups - 1u;
+}
+#endif
 
 // ||(v2-v1) x (v3-v1)|| / 2 : _lg_cross (src/rep/utils.jl:4-21), _norm (:29),
 // compute_faces_areas_packed (src/rep/mesh.jl:772-779).

@@ -15,15 +15,40 @@ using namespace fx3d;
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxBlocks = 1024;
+constexpr int kMaxBlocks = 4096;  // partial-sum slots of the scratch; a launch takes at most grid_for()'s cap of them
 
+// (round 4) Both gather kernels below ran one element per thread and iteration: index load -> vertex gathers -> arithmetic, two
+// dependent round trips per element and 15-22 elements per thread at a 4 M-face mesh (3.2 / 2.1 TB/s of algorithmic bytes,
+// profiles/r04_*_hbm_roofline.txt).  Four elements per iteration now: every index first, then every gather, then the
+// arithmetic (the expressions are unchanged: same bits per element).
+struct __attribute__((packed, aligned(4))) I3 { int32_t a, b, c; };  // one face of a (3, F) index array: a 12-byte load
+__device__ __forceinline__ float tri_area_p(const P3 &v1, const P3 &v2, const P3 &v3) {
+    const float t1[3] = {v1.x, v1.y, v1.z}, t2[3] = {v2.x, v2.y, v2.z}, t3[3] = {v3.x, v3.y, v3.z};
+    return tri_area(t1, t2, t3);
+}
 __global__ __launch_bounds__(kThreads) void faces_areas_packed_kernel(
     const float *__restrict__ verts, const int32_t *__restrict__ faces, long long F,
     float *__restrict__ areas) {
-    for (long long f = (long long)blockIdx.x * kThreads + threadIdx.x; f < F;
-         f += (long long)gridDim.x * kThreads) {
-        const int i1 = faces[3 * f], i2 = faces[3 * f + 1], i3 = faces[3 * f + 2];
-        areas[f] = tri_area(verts + 3ll * i1, verts + 3ll * i2, verts + 3ll * i3);
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long f0 = (long long)blockIdx.x * kThreads + threadIdx.x; f0 < F; f0 += 4 * stride) {
+        I3 fc[4];
+        P3 v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long f = f0 + u * stride;
+            fc[u] = *reinterpret_cast<const I3 *>(faces + 3 * (f < F ? f : f0));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u][0] = *reinterpret_cast<const P3 *>(verts + 3ll * fc[u].a);
+            v[u][1] = *reinterpret_cast<const P3 *>(verts + 3ll * fc[u].b);
+            v[u][2] = *reinterpret_cast<const P3 *>(verts + 3ll * fc[u].c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long f = f0 + u * stride;
+            if (f < F) areas[f] = tri_area_p(v[u][0], v[u][1], v[u][2]);
+        }
     }
 }
 
@@ -54,8 +79,7 @@ __device__ __forceinline__ void mean_finalize_last_block(double tot, double *par
     if (threadIdx.x == 0) {
         __hip_atomic_store(&pp[blockIdx.x], __builtin_bit_cast(unsigned long long, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = old == gridDim.x - 1;
+        is_last = ticket_arrive_last(ticket, gridDim.x, blockIdx.x);
     }
     __syncthreads();
     if (!is_last) return;
@@ -77,13 +101,28 @@ __global__ __launch_bounds__(kThreads) void edge_loss_kernel(
     unsigned int *ticket, float *__restrict__ loss) {
     __shared__ double sm[kThreads / 64];
     double acc = 0.0;
-    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < E;
-         e += (long long)gridDim.x * kThreads) {
-        const float *a = verts + 3ll * e1[e], *b = verts + 3ll * e2[e];
-        const float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
-        const float nrm = sqrtf(((d0 * d0) + (d1 * d1)) + (d2 * d2));
-        const float t = nrm - target;
-        acc += (double)(t * t);
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long e0 = (long long)blockIdx.x * kThreads + threadIdx.x; e0 < E; e0 += 4 * stride) {  // four edges in flight
+        int i1[4], i2[4];
+        P3 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long e = e0 + u * stride < E ? e0 + u * stride : e0;
+            i1[u] = e1[e];
+            i2[u] = e2[e];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const P3 *>(verts + 3ll * i1[u]);
+            b[u] = *reinterpret_cast<const P3 *>(verts + 3ll * i2[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float d0 = a[u].x - b[u].x, d1 = a[u].y - b[u].y, d2 = a[u].z - b[u].z;
+            const float nrm = sqrtf(((d0 * d0) + (d1 * d1)) + (d2 * d2));
+            const float t = nrm - target;
+            if (e0 + u * stride < E) acc += (double)(t * t);
+        }
     }
     const double tot = block_sum<kThreads>(acc, sm);
     mean_finalize_last_block(tot, partials, ticket, (double)E, loss, sm);
@@ -327,8 +366,7 @@ __global__ __launch_bounds__(kThreads) void mesh_losses_kernel(
     if (threadIdx.x == 0) {
         __hip_atomic_store(&pp[blk], __builtin_bit_cast(unsigned long long, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = old == gridDim.x - 1;
+        is_last = ticket_arrive_last(ticket, gridDim.x, blk);
     }
     __syncthreads();
     if (!is_last) return;
@@ -461,10 +499,16 @@ __global__ __launch_bounds__(kThreads) void momentum_offset_kernel(long long n, 
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0) *ctr += inc;
 }
 
-int grid_for(long long n) {
+// Grid of a grid-stride kernel over n elements, 256-thread blocks.  Plain gather / streaming kernels take up to 4096 blocks
+// (every wave slot of the chip twice over); kernels that END IN A REDUCTION (one partial and one ticket arrival per block, the
+// last block adds the partials) stop at 1024: edge_loss 20 / 22 / 26 us at 1024 / 2048 / 4096 blocks
+// (profiles/r04_*_hbm_grid_sweep.txt).  Option mesh_max_blocks != 0 forces one cap for both.
+int grid_for(long long n, bool reduction = false) {
     long long g = (n + kThreads - 1) / kThreads;
     if (g < 1) g = 1;
-    if (g > kMaxBlocks) g = kMaxBlocks;
+    int cap = opt(OPT_MESH_MAX_BLOCKS);
+    if (cap < 1 || cap > kMaxBlocks) cap = reduction ? 1024 : kMaxBlocks;
+    if (g > cap) g = cap;
     return (int)g;
 }
 
@@ -579,7 +623,7 @@ fx3d_status fx3d_edge_loss(const float *verts, int64_t V, const int32_t *edges, 
     fx3d_status trc = FX3D_OK;
     unsigned int *ticket = ticket_slot(&trc, st);
     if (!ticket) return trc;
-    const int g = grid_for(E);
+    const int g = grid_for(E, true);
     {
         ProfileScope prof("edge_loss", st);
         hipLaunchKernelGGL(edge_loss_kernel, dim3(g), dim3(kThreads), 0, st, verts, edges, edges + E,
@@ -631,7 +675,7 @@ fx3d_status fx3d_laplacian_loss(const float *verts, int64_t V, const int32_t *ro
     fx3d_status trc = FX3D_OK;
     unsigned int *ticket = ticket_slot(&trc, st);
     if (!ticket) return trc;
-    const int g = grid_for(V);
+    const int g = grid_for(V, true);
     {
         ProfileScope prof("laplacian_loss", st);
         hipLaunchKernelGGL(laplacian_loss_kernel, dim3(g), dim3(kThreads), 0, st, verts, (long long)V,
@@ -664,7 +708,7 @@ fx3d_status fx3d_mesh_losses(const float *verts, int64_t V, const int32_t *rowpt
     fx3d_status trc = FX3D_OK;
     unsigned int *ticket = ticket_slot(&trc, st);
     if (!ticket) return trc;
-    const int gV = grid_for(V), gE = grid_for(E);
+    const int gV = grid_for(V, true), gE = grid_for(E, true);
     {
         ProfileScope prof("mesh_losses", st);
         hipLaunchKernelGGL(mesh_losses_kernel, dim3(gV + gE), dim3(kThreads), 0, st, verts, (long long)V, rowptr, colind, vals,
@@ -685,13 +729,22 @@ fx3d_status fx3d_mesh_losses_bwd(const float *verts, int64_t V, const int32_t *r
     if (!ws || ws_bytes < need) { set_error("fx3d_mesh_losses_bwd: workspace too small (%zu < %zu bytes)", ws ? ws_bytes : (size_t)0, need); return FX3D_ERR_WORKSPACE; }
     hipStream_t st = as_stream(s);
     float4 *u = reinterpret_cast<float4 *>(reinterpret_cast<double *>(ws) + 2 * kMaxBlocks);
-    if (!reuse_forward) {  // no fx3d_mesh_losses on the same vertices and workspace before this call: build the unit rows
+    if (!reuse_forward && g_lap != 0.0f) {  // no fx3d_mesh_losses on the same vertices and workspace before this call: build the unit rows
         hipLaunchKernelGGL(lap_unit_rows_kernel, dim3(grid_for(V)), dim3(kThreads), 0, st, verts, (long long)V, rowptr, colind, vals, u);
         FX3D_LAUNCH_CHECK();
     }
     ProfileScope prof("mesh_losses_bwd", st);
-    hipLaunchKernelGGL((mesh_losses_bwd_gather_kernel<true, true>), dim3(grid_for(V)), dim3(kThreads), 0, st, verts, (long long)V,
-                       rowptr, colind, u, g_lap / (float)V, g_edge / (float)E, target, gverts, accumulate);
+    // (a weight of exactly zero drops its term: the Laplacian adjoint alone is how the wrappers differentiate laplacian_loss on
+    // LARGE meshes -- the scratch-free fx3d_laplacian_loss_bwd_sym recomputes every neighbour's row, 7 x the traffic)
+    if (g_edge == 0.0f)
+        hipLaunchKernelGGL((mesh_losses_bwd_gather_kernel<true, false>), dim3(grid_for(V)), dim3(kThreads), 0, st, verts, (long long)V,
+                           rowptr, colind, u, g_lap / (float)V, 0.0f, target, gverts, accumulate);
+    else if (g_lap == 0.0f)
+        hipLaunchKernelGGL((mesh_losses_bwd_gather_kernel<false, true>), dim3(grid_for(V)), dim3(kThreads), 0, st, verts, (long long)V,
+                           rowptr, colind, u, 0.0f, g_edge / (float)E, target, gverts, accumulate);
+    else
+        hipLaunchKernelGGL((mesh_losses_bwd_gather_kernel<true, true>), dim3(grid_for(V)), dim3(kThreads), 0, st, verts, (long long)V,
+                           rowptr, colind, u, g_lap / (float)V, g_edge / (float)E, target, gverts, accumulate);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }

@@ -46,6 +46,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"lap_bwd_scatter", "FX3D_LAP_BWD_SCATTER", 0},
     {"cdf_multiblock_from", "FX3D_CDF_MULTIBLOCK_FROM", 0},
     {"nn1_tiny_mpairs", "FX3D_NN1_TINY_MPAIRS", 24},
+    {"mesh_max_blocks", "FX3D_MESH_MAX_BLOCKS", 0},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::once_flag g_opt_once;
