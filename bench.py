@@ -455,6 +455,7 @@ def main():
         out["protocol"] = protocol_numbers(fx, x, y)
         out["configs"] = config_one_liners(fx)
         out["reference_harness"] = reference_harness(fx)
+        out["hbm_bound_kernels"] = hbm_bound_kernels()
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(fx)
     try:  # C stdio of the loaded libraries first (RCCL prints its NCCL_DEBUG=VERSION banner there): the JSON goes last
@@ -607,6 +608,18 @@ def config_one_liners(fx):
     r["roofline"] = _roof(r["min_ms"], flops=3.0 * 64 * 8192 * 8192, nbytes=4.0 * 64 * 8192 + 2 * 4.0 * 20 * 8192)
     out["kNN k=20 self graph, ONE cloud of 8192 points, D=64 (candidate slices of fx3d_knn_ws)"] = r
     return out
+
+
+def hbm_bound_kernels():
+    """SURVEY.md 8(d)'s HBM-bound members of the path at a bandwidth-bound size (a 3.9 M-face sheet; the C4' graph; the chamfer
+    adjoint at B = 256): one roofline object per kernel -- algorithmic bytes / the kernel's own duration (the library's HIP
+    events around the launch) against 8 TB/s nominal and the 6.3 TB/s a plain copy reaches (tools/hbm_roofline.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import hbm_roofline
+    rows = hbm_roofline.measure(cells=1400, reps=10)
+    return {r["kernel"]: {"bound": "hbm", "achieved": r["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac_hbm_peak"],
+                          "frac_of_achievable_6300": r["frac_achievable"], "algorithmic_bytes": r["algorithmic_bytes"],
+                          "kernel_avg_ms": r["kernel_avg_ms"], "size": r["size"]} for r in rows}
 
 
 def reference_harness(fx):

@@ -593,7 +593,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     };
     FX3D_PROBE_MARK(1);
 
+    // Largest scaled norm^2 of a candidate inside the filter (|c~|_inf <= min(cinf sc, 128)): the far-query form of the band below
+    const float cm2 = 3.0f * (fminf(cinf * sc, 128.0f) * fminf(cinf * sc, 128.0f));
     float qr[3], da = 0.0f;  // band: a tile qualifies while its minimum <= best * kBandB1 + da
+    float da_far = 0.0f;     // ... or <= best (1 + 2^-20) + da_far, whichever is lower (round 4)
     bool qfin = true;        // this lane's query has finite coordinates
     int qi = 0;
     bool qok = true;
@@ -666,6 +669,19 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 qfin = fabsf(qr[0]) + fabsf(qr[1]) + fabsf(qr[2]) < INFINITY;
                 const float qn = 0.25f * ((m0 * m0 + m1 * m1) + m2 * m2) / sq;  // sq |q~|^2: the band in the query's unit
                 da = kBandA * qn + 0x1p-24f * (S + 4.0f) + fl_s;
+                // Round 4, queries OUTSIDE the candidate cloud (|q~| >~ Cmax: clouds of different extent -- a unit teapot against a
+                // table in millimetres).  The filter's error is really beta (|c~|^2 + |q~||c~|) + floor (tools/test_f16_filter.hip:
+                // max 2^-20.6 over magnitudes up to the scaled far queries'; beta = 2^-18 keeps 6 x head-room); the form above
+                // charges the cross term as |q~|^2.  With |c~| <= Cmax for every candidate in the filter:
+                //   U_c >= t_c - beta |q~| Cmax - fl,   U_c <= t_c + 2.07 beta Cmax^2 + beta |q~| Cmax + fl
+                //   => U_c* <= Umin (1 + 2^-20) + 2.1 beta Cmax^2 + 2 beta |q~| Cmax + 2^-19 |q~|^2 + floor
+                // (the 2^-20 terms: the oracle's own rounding of the two distances, as in kBandB1 / kBandA).  For |q~| = R Cmax the
+                // band is (2.1 + 2 R + 0.5 R^2) beta Cmax^2 instead of 4.3 R^2: 6 x narrower at R = 12, 8.5 x at R = 250 -- what is
+                // left is the reference's own Float32 rounding of distances that large.  Both are valid; the lower one is used.
+                {
+                    const float c2 = sq * cm2;                     // in the query's unit, like qn = sq |q~|^2
+                    da_far = 2.1f * kBetaC * c2 + 2.0f * kBetaC * sqrtf(qn * c2) + 0x1p-19f * qn + 0x1p-24f * (S + 4.0f) + fl_s;
+                }
                 _Float16 hx, lx, hy, ly, hz, lz;
                 split2h(qok ? m0 : 0.f, hx, lx); split2h(qok ? m1 : 0.f, hy, ly); split2h(qok ? m2 : 0.f, hz, lz);
                 const _Float16 one = (_Float16)sq, pad = (_Float16)kPadF16;
@@ -756,7 +772,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
                 const int lane = (int)(threadIdx.x & 63) + opq, jq = lane & 31, hh = lane >> 5;
                 const float m = fminf(best, __shfl_xor(best, 32, 64));
-                const float thr1 = __builtin_fmaf(m, kBandB1, da);                  // on tile minima (m >= the true minimum)
+                const float thr1 = fminf(__builtin_fmaf(m, kBandB1, da), __builtin_fmaf(m, 1.0f + 0x1p-20f, da_far));  // on tile minima (m >= the true minimum)
                 const float thr1k = __builtin_fmaf(fabsf(thr1), kKeyUp, thr1);      // on keys: t <= thr1  =>  key(t) <= thr1k
                 const bool usable = sane && far_ok && qok && m < INFINITY;  // filter meaningful for this query
                 const bool slow = !usable || !(kc > thr1k);  // a fourth lane tile may lie within the band

@@ -27,8 +27,15 @@ for op in nn1 knn3 knn64; do
   pmc_pass $op l2 TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum
   python "$ROOT/tools/rocprof_summary.py" pmc "$OUT"/pmc_${op}_*/r_results.db > "$OUT/pmc_$op.txt" 2>&1
 done
+# the HBM-bound members at a bandwidth-bound size (tools/hbm_roofline.py): kernel trace, then FETCH / WRITE in their own passes
+python "$ROOT/tools/hbm_roofline.py" --table > "$OUT/hbm_roofline.txt" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/kt_hbm" -o r -- python "$ROOT/tools/hbm_roofline.py" --reps 5 > /dev/null 2>&1
+python "$ROOT/tools/rocprof_summary.py" stats "$OUT/kt_hbm/r_results.db" > "$OUT/hbm_kernel_trace_stats.txt" 2>&1
+rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_hbm_fetch" -o r -- python "$ROOT/tools/hbm_roofline.py" --reps 5 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_hbm_write" -o r -- python "$ROOT/tools/hbm_roofline.py" --reps 5 > /dev/null 2>&1
+python "$ROOT/tools/rocprof_summary.py" pmc "$OUT"/pmc_hbm_*/r_results.db > "$OUT/pmc_hbm.txt" 2>&1
 cp "$OUT/pmc_nn1.txt" "$OUT/pmc.txt"
 python "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 python "$ROOT/tools/bench_ops.py" --cpu > "$OUT/bench_ops.jsonl" 2> "$OUT/bench_ops.err"
-rm -rf "$OUT"/kt/*.db "$OUT"/kt_ops/*.db "$OUT"/pmc_*/*.db 2>/dev/null
+rm -rf "$OUT"/kt/*.db "$OUT"/kt_ops/*.db "$OUT"/kt_hbm/*.db "$OUT"/pmc_*/*.db 2>/dev/null
 ls -la "$OUT"

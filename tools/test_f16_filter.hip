@@ -46,12 +46,13 @@ int main() {
     hipMalloc(&dc, 384); hipMalloc(&dq, 384); hipMalloc(&dout, 4096);
     unsigned s = 7;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
-    double worst = 0, worst_rel = 0, worst_model = 0;
+    double worst = 0, worst_rel = 0, worst_model = 0, worst_cross = 0, worst_cross_far = 0;
     for (int trial = 0; trial < 5600; ++trial) {
         // magnitudes of the robust scaling (|c~| < 2^7, |qm~| < 2^8 for queries inside the cloud) down to a bulk 10^-5 of it
         const float csv[8] = {1.0f, 1e-2f, 0.3f, 1e-4f, 127.0f, 30.0f, 3.0f, 1e-3f};
-        const float qsv[7] = {2.0f, 8.0f, 0.5f, 250.0f, 60.0f, 1e-2f, 2e-3f};
-        const float cs = csv[trial % 8], qs = qsv[trial % 7];
+        // (round 4: + the magnitudes of a per-query-scaled far query, sq S in [2^13, 2^14): |qm~_d| up to ~10^4)
+        const float qsv[9] = {2.0f, 8.0f, 0.5f, 250.0f, 60.0f, 1e-2f, 2e-3f, 3000.0f, 9000.0f};
+        const float cs = csv[trial % 8], qs = qsv[trial % 9];
         for (auto &v : c) v = (2 * rnd() - 1) * cs;
         for (auto &v : q) v = (2 * rnd() - 1) * qs;
         hipMemcpy(dc, c.data(), 384, hipMemcpyHostToDevice); hipMemcpy(dq, q.data(), 384, hipMemcpyHostToDevice);
@@ -71,9 +72,16 @@ int main() {
             // the kernels' model: err <= beta (n_c + |q~|^2) + floor, floor = 2^-25 (S + 2) (subnormal fp16 pieces)
             const double excess = err - 0x1p-25 * (qsum + 2.0);
             if (excess > 0 && excess / (n + qn) > worst_model) worst_model = excess / (n + qn);
+            // the refined model (round 4, far queries): err <= b1 n_c + b2 |q~| |c~| + floor -- the cross term is what a query far
+            // outside the cloud (|q~| >> |c~|) really pays; (n_c + |q~|^2) over-charges it by |q~| / |c~|
+            const double cross = n + sqrt(qn) * sqrt(n);
+            if (excess > 0 && cross > 0 && excess / cross > worst_cross) worst_cross = excess / cross;
+            if (excess > 0 && cross > 0 && qn > 64.0 * n && excess / cross > worst_cross_far) worst_cross_far = excess / cross;
         }
     }
     printf("max |err| / (3 + sum|qm~|) = %.3e  (2^%.2f)   max err/sum|terms| = %.3e\n", worst, log2(worst), worst_rel);
     printf("max (|err| - 2^-25 (S + 2)) / (n_c + |q~|^2) = %.3e  (2^%.2f);  the kernels use beta = 2^-18\n", worst_model, log2(worst_model));
+    printf("max (|err| - 2^-25 (S + 2)) / (n_c + |q~| |c~|) = %.3e  (2^%.2f) over all pairs, %.3e (2^%.2f) over far pairs (|q~| > 8 |c~|)\n",
+           worst_cross, log2(worst_cross), worst_cross_far, log2(worst_cross_far));
     return 0;
 }
