@@ -79,6 +79,14 @@ def test_committed_golden_fixture(gpu_fx):
     assert np.isclose(loss, g["c_loss"], rtol=LOSS_RTOL)
     idx, dist = fx.knn(g["kx"], 20, drop_first=True)
     assert np.array_equal(idx.to_host(), g["k_idx"]) and np.array_equal(dist.to_host(), g["k_dist"])
+    # round 4: one LDS image + an exact tail with a lattice block (ties), a split-plan shape, kNN at C4's size in both spaces
+    for tag in ("g", "p"):
+        loss, ix, iy = fx.chamfer_distance(g[tag + "_x"], g[tag + "_y"], return_indices=True)
+        assert np.array_equal(ix.to_host(), g[tag + "_ix"]) and np.array_equal(iy.to_host(), g[tag + "_iy"]), tag
+        assert np.isclose(loss, g[tag + "_loss"], rtol=LOSS_RTOL), tag
+    for tag in ("k3", "k64"):
+        idx, dist = fx.knn(g[tag + "_x"], 20, drop_first=True)
+        assert np.array_equal(idx.to_host(), g[tag + "_idx"]) and np.array_equal(dist.to_host(), g[tag + "_dist"]), tag
 
 
 @pytest.mark.parametrize("N,M,B", [(1, 1, 1), (1, 77, 3), (33, 4097, 1), (257, 31, 9), (513, 1025, 8),

@@ -304,6 +304,13 @@ def test_committed_golden_vectors(oracle):
     assert np.array_equal(idx, g["k_idx"]) and np.array_equal(dist, g["k_dist"])
     s = oracle.sample_points_seeded(g["s_verts"], g["s_faces0"], g["s_faces_len"], 64, seed=int(g["s_seed"]))
     assert np.array_equal(s, g["s_out"])
+    # round 4: the large vectors (chunk tail + lattice ties, split-plan shape, kNN at C4's size in both spaces)
+    for tag in ("g", "p"):
+        loss, ix, iy, _ = oracle.chamfer_distance(g[tag + "_x"], g[tag + "_y"], return_all=True)
+        assert np.array_equal(ix, g[tag + "_ix"]) and np.array_equal(iy, g[tag + "_iy"]) and np.float32(loss) == g[tag + "_loss"]
+    for tag in ("k3", "k64"):
+        idx, dist = oracle.knn(g[tag + "_x"], 20, drop_first=True)
+        assert np.array_equal(idx, g[tag + "_idx"]) and np.array_equal(dist, g[tag + "_dist"])
 
 
 def test_edge_features_structure(oracle):
