@@ -2384,7 +2384,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                                                              const float *__restrict__ y, int M, int B, int D,
                                                              int k, int drop, int32_t *__restrict__ idx,
                                                              float *__restrict__ dist, int CH, int img_floats,
-                                                             int keep_norms, int two_norms, int srl, void *pre_ws, int xdiv) {
+                                                             int keep_norms, int two_norms, int srl, void *pre_ws, int xdiv, int csl) {
     constexpr int DP = DK * 32;      // padded feature dimension
     constexpr int RS = DP + 4;       // row stride of the query rows staged in the prologue (floats)
     constexpr int PPR = DK * 8;      // 16-byte pieces per candidate row
@@ -3091,6 +3091,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     const int PR = DS >> 2, RPI = srl > 0 ? kMThreads / PR : 0;  // rows per sweep of the block (PR divides the block size)
     const int srow = srl > 0 ? tid / PR : 0, scol = (tid - srow * PR) * 4;
     if (srl > 0) knn_stage_fetch(yb, D, M, 0, srow, RPI, scol, sreg);
+    if (csl > 0) knn_stage_fetch(yb, D, M, 0, tid >> 2, kMThreads / 4, 4 * (tid & 3), sreg);  // column slices: rows (tid >> 2) + 128 i, piece tid & 3
     if (wave_active) {
         // ---- medium path (tight clusters, many duplicates: more candidates inside the band than the key arrays hold):
         //      the wave decodes the query's two lane lists into an id list and selects exactly among those ids,
@@ -3231,7 +3232,65 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     const int mystart = part * per < n ? part * per : n;
     const int mycount = (mystart + per <= n ? per : n - mystart);
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(lists) + (size_t)(cw * 32 + jl) * 33;  // [..][32 + 1 pad]
-    if (srl > 0) {
+    if (csl > 0) {
+        // ---- column slices (round 4): ALL candidate rows pass through LDS, 16 dimensions at a time (csl = D / 16 slices), as four
+        //      planes of 16-byte pieces ([piece c][row], plane stride 16 Mp + 32 bytes: the coalesced staging writes and the reads of
+        //      consecutive rows are conflict-free).  In every slice the four lanes of a query share ALL its survivors evenly -- the
+        //      row stages below share the survivors of one stage at a time: ~1.7 per lane against a fullest lane of 3-4 (42 % of the
+        //      lane slots held a pair); whole queries differ far less (27 +- 5 survivors) -- and a pair's running sum waits in its
+        //      distance slot between slices: the oracle's order of additions.  The query's slice is 16 floats in registers (the row
+        //      stages held the whole row: 64), the next slice's pieces of rows and query are in flight while this one is summed.
+        const int MPc = (M + kMThreads / 4 - 1) / (kMThreads / 4) * (kMThreads / 4);
+        const int PS = MPc * 4 + 8;  // plane stride, floats
+        float *stg = reinterpret_cast<float *>(lists);
+        const bool act = wave_active && fast;
+        const int crow = tid >> 2, cc = tid & 3;
+        const float *qrow = xb + (size_t)(act ? qi : 0) * D;
+        f32x4v qs[4], qnx[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) qs[t] = *reinterpret_cast<const f32x4v *>(qrow + 4 * t);
+        for (int s = 0; s < csl; ++s) {
+            if (s) __syncthreads();  // every lane is done with the previous slice
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = crow + i * (kMThreads / 4);
+                if (row < MPc) *reinterpret_cast<f32x4v *>(stg + (size_t)cc * PS + (size_t)row * 4) = sreg[i];
+            }
+            __syncthreads();
+            if (s < 3) KNN_PROBE_MARK(26 + 2 * s);
+            if (s + 1 < csl) {
+                knn_stage_fetch(yb, D, M, 0, crow, kMThreads / 4, 16 * (s + 1) + 4 * cc, sreg);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) qnx[t] = *reinterpret_cast<const f32x4v *>(qrow + 16 * (s + 1) + 4 * t);
+            }
+            if (act) {
+                for (int p0 = mystart; p0 < mystart + mycount; p0 += 2) {
+                    const bool two = p0 + 1 < mystart + mycount;
+                    const float *cp0 = stg + (size_t)qj[p0] * 4, *cp1 = stg + (size_t)qj[two ? p0 + 1 : p0] * 4;
+                    float s0 = s ? __builtin_bit_cast(float, qd[p0]) : 0.0f;
+                    float s1 = s && two ? __builtin_bit_cast(float, qd[p0 + 1]) : 0.0f;
+                    f32x4v c0[4], c1[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        c0[t] = *reinterpret_cast<const f32x4v *>(cp0 + (size_t)t * PS);
+                        c1[t] = *reinterpret_cast<const f32x4v *>(cp1 + (size_t)t * PS);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const f32x4v d0 = qs[t] - c0[t], d1 = qs[t] - c1[t];
+                        const f32x4v m0 = d0 * d0, m1 = d1 * d1;
+                        s0 = s0 + m0.x; s0 = s0 + m0.y; s0 = s0 + m0.z; s0 = s0 + m0.w;
+                        s1 = s1 + m1.x; s1 = s1 + m1.y; s1 = s1 + m1.z; s1 = s1 + m1.w;
+                    }
+                    qd[p0] = __builtin_bit_cast(unsigned int, s0);
+                    if (two) qd[p0 + 1] = __builtin_bit_cast(unsigned int, s1);
+                }
+            }
+            if (s < 3) KNN_PROBE_MARK(27 + 2 * s);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) qs[t] = qnx[t];
+        }
+    } else if (srl > 0) {
         // staged: the candidate rows come through LDS one stage (2^srl rows) at a time, loaded coalesced once per block
         // (every row exactly once: M * 4D bytes from L2 instead of 4D per survivor), rows 16 bytes apart in the banks.
         // Per stage the four lanes of a query split its survivors of that stage; the query row sits in registers.
@@ -3690,6 +3749,19 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
             }
         }
     }
+    // column slices (round 4) instead of row stages: every row of the cloud, 16 dimensions at a time, as four planes of 16-byte
+    // pieces -- when the whole cloud's slice fits the same tail (M <= 1024 at the kernel's 512 threads x 8 pieces)
+    int csl = 0;
+    if (stageable && !opt(OPT_KNN_ROW_STAGES) && D % 16 == 0 && D <= 64 && M <= 8 * (kMThreads / 4)) {
+        const size_t room = 152 * 1024 - (img * 4 + small);
+        const size_t mpc = (size_t)(M + kMThreads / 4 - 1) / (kMThreads / 4) * (kMThreads / 4);
+        const size_t need = 4 * (mpc * 16 + 32);
+        if (need <= room) {
+            csl = D / 16;
+            srl = 0;  // (the decode does not group the ids by row stage)
+            if (img * 4 + small + need > lds) lds = img * 4 + small + need;
+        }
+    }
     const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_mfma_kernel<DK, F16, SPLIT>), 152 * 1024, "knn_mfma_kernel");
     if (arc != FX3D_OK) return arc;
     FX3D_REQUIRE(lds <= 152 * 1024, "fx3d_knn: internal LDS plan exceeds the CU (D=%d)", D);
@@ -3710,10 +3782,10 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
                                                     "knn_mfma_kernel<pre>");
         if (arc2 != FX3D_OK) return arc2;
         hipLaunchKernelGGL((knn_mfma_kernel<DK, F16, SPLIT, F16 && !SPLIT>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
-                           k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, pre_ws, xdiv);
+                           k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, pre_ws, xdiv, csl);
     } else
         hipLaunchKernelGGL((knn_mfma_kernel<DK, F16, SPLIT>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
-                           k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, nullptr, xdiv);
+                           k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, nullptr, xdiv, csl);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }

@@ -47,6 +47,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"cdf_multiblock_from", "FX3D_CDF_MULTIBLOCK_FROM", 0},
     {"nn1_tiny_mpairs", "FX3D_NN1_TINY_MPAIRS", 24},
     {"mesh_max_blocks", "FX3D_MESH_MAX_BLOCKS", 0},
+    {"knn_row_stages", "FX3D_KNN_ROW_STAGES", 0},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::once_flag g_opt_once;
