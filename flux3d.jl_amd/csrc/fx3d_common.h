@@ -82,7 +82,7 @@ enum Opt {
     OPT_KNN_GATHER,           // 1: exact phase gathers candidate rows from L2 instead of staging them through LDS
     OPT_KNN_D3_WAVE,          // 1: D = 3 kNN on the wave-per-query kernel
     OPT_KNN_D3_NO_COMPACT,    // 1: D = 3 kNN never on the compact geometries (64 queries per block, two blocks per CU)
-    OPT_KNN_PREPASS_FUSED,    // 1: the pre-pass of fx3d_knn_ws as one launch with a cloud-local meeting instead of two (measured equal)
+    OPT_KNN_DIRECT_LDS,       // 1: fx3d_knn_ws brings the image chunks of its search loop in with direct-to-LDS loads (round 3) instead of through registers
     OPT_KNN_SLICES,           // fx3d_knn_ws: candidate slices per cloud: 0 = automatic, 1 = never, 2 / 4 / 8 = forced
     OPT_EDGE_SCALAR_STORES,   // 1: edge features written with 4-byte stores
     OPT_EDGECONV_UNFUSED,     // 1: EdgeConv graph build as search + feature kernels

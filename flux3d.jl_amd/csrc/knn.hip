@@ -23,6 +23,7 @@
 //                                                  k+drop in 33 ... 128 in feature space: 32 nearest per slice, verified merge)
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "fx3d_common.h"
 
@@ -1054,6 +1055,108 @@ __device__ __forceinline__ void k3_sort_regs(float (&v)[NV]) {
     }
 }
 
+// tau = an upper bound of the kk-th smallest filter value of every query (kk <= 24) from its 128 group minima -- 32 in this lane (mn), 32
+// in its partner half-lane, 64 in the other wave of the pair (wave index +- GW) -- shared by knn_f16_d3_kernel and knn_mfma_kernel<PRE>:
+// the EIGHT smallest of each HALF of a lane's group minima (16 of its 32) instead of a sort of all 32.  The kk-th smallest of any
+// subset of the 128 group minima bounds the kk-th smallest filter value (every group minimum is some candidate's value); the subset
+// {8 smallest of each of the query's eight half-lane sets of 16} holds the kk <= 24 smallest of all 128 unless one set holds more
+// than 8 of them (kk = 21: Bin(21, 1/8) >= 9, 4e-4 per set, and tau is then the next order statistic).  (The 8 smallest of each
+// LANE's 32 -- Bin(21, 1/4) -- was cheaper still but let one query in 10^4 end with 40+ survivors: the rank phase of its block
+// doubled, and a one-round launch lasts as long as its slowest block: 21.9 -> 23.5 us.)  Four 19-exchange sorts of 8, two "8
+// smallest of two sorted 8" steps (8 v_min + a 12-exchange bitonic merge), a 16-value merge, the partner lane's sixteen by
+// v_permlane32_swap, a 32-value merge, the other wave's through LDS (xch: [2 GW][32][27] floats) and the split minimum: ~560 VALU per
+// wave where the sort of 32 and two 32-value merges took ~860.  Contains a block barrier: every thread of the block calls it.
+template <int GW>
+__device__ __forceinline__ float knn_tau_8of16(const float (&mn)[32], float *xch, int wv, int jq, int hh, int kk) {
+    float tau;
+    {
+    float a8[4][8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a8[g][i] = mn[8 * g + i];
+            k3_sort_regs<8>(a8[g]);
+        }
+        auto low8 = [](float (&x)[8], const float (&y)[8]) {  // x <- the 8 smallest of two ascending octets, ascending
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = vmin_f32(x[i], y[7 - i]);  // bitonic
+#pragma unroll
+            for (int j = 4; j > 0; j >>= 1)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const float lo = vmin_f32(x[i], x[l]), hi = vmax_f32(x[i], x[l]);
+                        x[i] = lo;
+                        x[l] = hi;
+                    }
+                }
+        };
+        low8(a8[0], a8[1]);
+        low8(a8[2], a8[3]);
+        float x32[32];  // [0, 16): this lane's sixteen, ascending after the first merge; then the wave's 32
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { x32[r] = a8[0][r]; x32[8 + r] = a8[2][7 - r]; }  // ascending then descending: bitonic
+#pragma unroll
+        for (int j = 8; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const float lo = vmin_f32(x32[i], x32[l]), hi = vmax_f32(x32[i], x32[l]);
+                    x32[i] = lo;
+                    x32[l] = hi;
+                }
+            }
+        {
+            float oth[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)  // x32[r] <- lanes 0-31's value, oth[r] <- lanes 32-63's, in every lane
+                asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x32[r]), "=&v"(oth[r]));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x32[16 + r] = oth[15 - r];
+        }
+#pragma unroll
+        for (int j = 16; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const float lo = vmin_f32(x32[i], x32[l]), hi = vmax_f32(x32[i], x32[l]);
+                    x32[i] = lo;
+                    x32[l] = hi;
+                }
+            }
+        // exchange rows of 27 words per (wave, query): [0] = +inf, [1] = -inf, [2 + r] = the wave's r-th smallest, r < 24
+        float *row = xch + (wv * 32 + jq) * 27;
+        if (hh == 0) {
+#pragma unroll
+            for (int r = 0; r < 24; ++r) row[2 + r] = x32[r];
+        } else {
+            row[0] = INFINITY;
+            row[1] = -INFINITY;
+        }
+        __syncthreads();
+        // the kk-th smallest of the union of X = x32 and the other wave's Y (both ascending) without merging them: min
+        // over the splits (i values from X, kk - i from Y) of max(X'[i-1], Y'[kk-i-1]), X'[-1] = Y'[-1] = -inf; a split with
+        // i > kk reads +inf.  (The offsets depend on the runtime kk: computed here, behind an opaque copy -- hoisted to the
+        // kernel's start they were 25 more long-lived scalars in a kernel that already spills SGPRs.)
+        int kko = kk;
+        asm volatile("" : "+s"(kko));
+        const float *po = xch + (((wv + GW) % (2 * GW)) * 32 + jq) * 27;
+        float yv[25];  // (all reads first)
+#pragma unroll
+        for (int i = 0; i <= 24; ++i) {
+            const int o = kko - i + 1;
+            yv[i] = po[o > 0 ? o : 0];
+        }
+        tau = yv[0];   // i = 0: X'[-1] = -inf
+#pragma unroll
+        for (int i = 1; i <= 24; ++i) tau = vmin_f32(tau, vmax_f32(x32[i - 1], yv[i]));
+    }
+    return tau;
+}
+
 // EdgeConv's features of ONE (point i, neighbour rank r) pair for F = 3 (src/models/dgcnn.jl:36-51): cat(x_i, x_j - x_i),
 // layout 0 = (2F,K,N,B), 1 = (K*N,2F,B).  Used by the rare paths of the fused kernel (ties, exact fallback).
 __device__ __forceinline__ void knn_d3_feature_entry(float *__restrict__ feat, int layout, int b, int N, int k, int i, int r,
@@ -1322,99 +1425,8 @@ __global__ __launch_bounds__(C::T) void knn_f16_d3_kernel(const float *__restric
             float tau = INFINITY;
             float *xch = reinterpret_cast<float *>(lists_all);  // the lists are not in use yet
             if (C::KKMAX <= 32 && kk <= 24 && M >= 128) {
-                // ---- round 4: tau from the EIGHT smallest of each HALF of a lane's group minima (16 of its 32) instead of a sort
-                //      of all 32.  The kk-th smallest of any subset of the 128 group minima bounds the kk-th smallest filter value
-                //      (every group minimum is some candidate's value); the subset {8 smallest of each of the query's eight
-                //      half-lane sets of 16} holds the kk <= 24 smallest of all 128 unless one set holds more than 8 of them
-                //      (kk = 21: Bin(21, 1/8) >= 9, 4e-4 per set, and tau is then the next order statistic).  (The 8 smallest of
-                //      each LANE's 32 -- Bin(21, 1/4) -- was cheaper still but let one query in 10^4 end with 40+ survivors: the
-                //      rank phase of its block doubled, and a one-round launch lasts as long as its slowest block: 21.9 -> 23.5 us.)
-                //      Four 19-exchange sorts of 8, two "8 smallest of two sorted 8" steps (8 v_min + a 12-exchange bitonic merge),
-                //      a 16-value merge, the partner lane's sixteen by v_permlane32_swap, a 32-value merge, the other wave's
-                //      through LDS and the split minimum: ~560 VALU per wave where the sort of 32 and two 32-value merges took ~860.
-                float a8[4][8];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) a8[g][i] = mn[8 * g + i];
-                    k3_sort_regs<8>(a8[g]);
-                }
-                auto low8 = [](float (&x)[8], const float (&y)[8]) {  // x <- the 8 smallest of two ascending octets, ascending
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) x[i] = vmin_f32(x[i], y[7 - i]);  // bitonic
-#pragma unroll
-                    for (int j = 4; j > 0; j >>= 1)
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int l = i ^ j;
-                            if (l > i) {
-                                const float lo = vmin_f32(x[i], x[l]), hi = vmax_f32(x[i], x[l]);
-                                x[i] = lo;
-                                x[l] = hi;
-                            }
-                        }
-                };
-                low8(a8[0], a8[1]);
-                low8(a8[2], a8[3]);
-                float x32[32];  // [0, 16): this lane's sixteen, ascending after the first merge; then the wave's 32
-#pragma unroll
-                for (int r = 0; r < 8; ++r) { x32[r] = a8[0][r]; x32[8 + r] = a8[2][7 - r]; }  // ascending then descending: bitonic
-#pragma unroll
-                for (int j = 8; j > 0; j >>= 1)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int l = i ^ j;
-                        if (l > i) {
-                            const float lo = vmin_f32(x32[i], x32[l]), hi = vmax_f32(x32[i], x32[l]);
-                            x32[i] = lo;
-                            x32[l] = hi;
-                        }
-                    }
-                {
-                    float oth[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)  // x32[r] <- lanes 0-31's value, oth[r] <- lanes 32-63's, in every lane
-                        asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x32[r]), "=&v"(oth[r]));
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) x32[16 + r] = oth[15 - r];
-                }
-#pragma unroll
-                for (int j = 16; j > 0; j >>= 1)
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) {
-                        const int l = i ^ j;
-                        if (l > i) {
-                            const float lo = vmin_f32(x32[i], x32[l]), hi = vmax_f32(x32[i], x32[l]);
-                            x32[i] = lo;
-                            x32[l] = hi;
-                        }
-                    }
-                // exchange rows of 27 words per (wave, query): [0] = +inf, [1] = -inf, [2 + r] = the wave's r-th smallest, r < 24
-                float *row = xch + (wv * 32 + jq) * 27;
-                if (hh == 0) {
-#pragma unroll
-                    for (int r = 0; r < 24; ++r) row[2 + r] = x32[r];
-                } else {
-                    row[0] = INFINITY;
-                    row[1] = -INFINITY;
-                }
-                __syncthreads();
-                // the kk-th smallest of the union of X = x32 and the other wave's Y (both ascending) without merging them: min
-                // over the splits (i values from X, kk - i from Y) of max(X'[i-1], Y'[kk-i-1]), X'[-1] = Y'[-1] = -inf; a split with
-                // i > kk reads +inf.  (The offsets depend on the runtime kk: computed here, behind an opaque copy -- hoisted to the
-                // kernel's start they were 25 more long-lived scalars in a kernel that already spills SGPRs.)
-                int kko = kk;
-                asm volatile("" : "+s"(kko));
-                const float *po = xch + (((wv + C::G) % C::W) * 32 + jq) * 27;
-                float yv[25];  // (all reads first)
-#pragma unroll
-                for (int i = 0; i <= 24; ++i) {
-                    const int o = kko - i + 1;
-                    yv[i] = po[o > 0 ? o : 0];
-                }
-                tau = yv[0];   // i = 0: X'[-1] = -inf
-#pragma unroll
-                for (int i = 1; i <= 24; ++i) tau = vmin_f32(tau, vmax_f32(x32[i - 1], yv[i]));
+                // (round 4) the eight smallest of each half-lane set of 16 instead of a sort of all 32: knn_tau_8of16
+                tau = knn_tau_8of16<C::G>(mn, xch, wv, jq, hh, kk);
             } else {
                 k3_sort_regs<32>(mn);
                 {
@@ -2057,7 +2069,7 @@ struct KnnPre {
     size_t stride;        // bytes per cloud
     int Mpad;             // rows of the image (multiple of 256: chunks never need a clamp), DP halves per row
     // offsets inside a cloud's slab (bytes)
-    size_t off_parts, off_hdr, off_cmax, off_sync, off_nup, off_ndn, off_img;
+    size_t off_parts, off_hdr, off_cmax, off_nup, off_ndn, off_img;
     __host__ __device__ static KnnPre make(void *ws, int M, int DP) {
         KnnPre k{};
         k.base = static_cast<unsigned char *>(ws);
@@ -2067,8 +2079,6 @@ struct KnnPre {
         k.off_hdr = o; o += (size_t)(8 + DP) * 4;
         k.off_cmax = o; o += (size_t)kPreParts * 4;
         o = (o + 63) & ~(size_t)63;
-        k.off_sync = o; o += (size_t)(kPreParts + 8) * 8;  // the fused pre-pass kernel's meeting point: 8 slots + the generation word
-        o = (o + 15) & ~(size_t)15;
         k.off_nup = o; o += (size_t)k.Mpad * 4;
         k.off_ndn = o; o += (size_t)k.Mpad * 4;
         k.off_img = o; o += (size_t)k.Mpad * DP * 2;
@@ -2077,7 +2087,6 @@ struct KnnPre {
     }
     __host__ __device__ float *parts(int b) const { return reinterpret_cast<float *>(base + (size_t)b * stride + off_parts); }
     __host__ __device__ float *hdr(int b) const { return reinterpret_cast<float *>(base + (size_t)b * stride + off_hdr); }
-    __host__ __device__ unsigned long long *sync(int b) const { return reinterpret_cast<unsigned long long *>(base + (size_t)b * stride + off_sync); }
     __host__ __device__ unsigned int *cmaxp(int b) const { return reinterpret_cast<unsigned int *>(base + (size_t)b * stride + off_cmax); }
     __host__ __device__ float *nup(int b) const { return reinterpret_cast<float *>(base + (size_t)b * stride + off_nup); }
     __host__ __device__ float *ndn(int b) const { return reinterpret_cast<float *>(base + (size_t)b * stride + off_ndn); }
@@ -2162,6 +2171,24 @@ __device__ __forceinline__ void knn_pre_image_body(const float *__restrict__ y, 
     const float *yb = y + (size_t)b * M * D;
     const int rq = D / 4;
     const float *parts = pre.parts(b);
+    // this part's rows: the first four sweeps (a whole part at C4': 128 rows) are requested BEFORE the parts' statistics are read --
+    // the rows do not depend on them, and the kernel is two dependent global round trips otherwise (round 4)
+    const int per = (M + kPreParts - 1) / kPreParts;
+    const int r_lo = part * per < M ? part * per : M, r_hi = r_lo + per < M ? r_lo + per : M;
+    const int g = tid % G;  // (kPreThreads % G == 0: a thread always converts the same eight dimensions)
+    constexpr int RPS = kPreThreads / G;  // rows per sweep of the block
+    const int d0 = 8 * g < D ? 8 * g : 0, d1 = 8 * g + 4 < D ? 8 * g + 4 : 0;
+    float4 a0[4], a1[4];
+    auto load_rows = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // every load of the four sweeps before the first use (a part is a few sweeps: latency, not bandwidth)
+            const int row = r0 + u * RPS + tid / G;
+            const float *src = yb + (size_t)(row < r_hi ? row : (r_lo < M ? r_lo : 0)) * D;
+            a0[u] = *reinterpret_cast<const float4 *>(src + d0);
+            a1[u] = *reinterpret_cast<const float4 *>(src + d1);
+        }
+    };
+    load_rows(r_lo);
     if (tid < 4) sh[tid] = 0u;
     bool anynan = false;
     for (int p = 0; p < kPreParts; ++p) anynan |= __builtin_bit_cast(int, knn_pre_get(parts + (size_t)p * (3 * DP + 4) + 3 * DP)) != 0;
@@ -2246,27 +2273,15 @@ __device__ __forceinline__ void knn_pre_image_body(const float *__restrict__ y, 
         if (tid < DP) h[8 + tid] = mu[tid];
     }
     // ---- this part's rows -> image, norms
-    const int per = (M + kPreParts - 1) / kPreParts;
-    const int r_lo = part * per < M ? part * per : M, r_hi = r_lo + per < M ? r_lo + per : M;
     _Float16 *img = pre.img(b);
     float *nup = pre.nup(b), *ndn = pre.ndn(b);
-    const int g = tid % G;  // (kPreThreads % G == 0: a thread always converts the same eight dimensions)
     float mu8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) mu8[e] = mu[8 * g + e];
     float tmax = 0.0f;
     bool tnan = false;
-    constexpr int RPS = kPreThreads / G;  // rows per sweep of the block
     for (int r0 = r_lo; r0 < r_hi; r0 += 4 * RPS) {
-        float4 a0[4], a1[4];
-        const int d0 = 8 * g < D ? 8 * g : 0, d1 = 8 * g + 4 < D ? 8 * g + 4 : 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {  // every load of the four sweeps before the first use (a part is a few sweeps: latency, not bandwidth)
-            const int row = r0 + u * RPS + tid / G;
-            const float *src = yb + (size_t)(row < r_hi ? row : r_lo) * D;
-            a0[u] = *reinterpret_cast<const float4 *>(src + d0);
-            a1[u] = *reinterpret_cast<const float4 *>(src + d1);
-        }
+        if (r0 != r_lo) load_rows(r0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = r0 + u * RPS + tid / G;
@@ -2317,34 +2332,23 @@ __global__ __launch_bounds__(kPreThreads) void knn_pre_image_kernel(const float 
     __shared__ unsigned int sh[4];
     knn_pre_image_body<DK>(y, M, D, two_norms, pre, blockIdx.x, blockIdx.y, mu, sh);
 }
-// Both steps in ONE launch (round 3): the eight blocks of a cloud meet between them -- a cloud-local barrier through the slab's sync
-// words (a launch costs ~5 us of dependent start-up here; the meeting of eight neighbouring blocks well under one).  Every block
-// reads the cloud's generation word g at its start, publishes g + 1 in its own slot after its statistics are out, and waits for the
-// eight slots; part 0 then advances the generation.  No initialisation needed (arbitrary workspace contents: stale slots equal
-// g + 1 with probability 2^-64), replay-safe under hipGraph (the state lives in the workspace), and the eight blocks of a cloud
-// are consecutive in dispatch order, so a waiting block never waits for one that cannot be scheduled.
-template <int DK>
-__global__ __launch_bounds__(kPreThreads) void knn_pre_fused_kernel(const float *__restrict__ y, int M, int D, int two_norms, KnnPre pre) {
-    __shared__ float red[(kPreThreads / 64) * 32 * 12];
-    __shared__ float mu[DK * 32];
-    __shared__ unsigned int sh[4];
-    __shared__ unsigned long long gen_s;
-    const int part = blockIdx.x, b = blockIdx.y;
-    unsigned long long *sync = pre.sync(b);  // [0..7] slots, [8] generation
-    if (threadIdx.x == 0) gen_s = __hip_atomic_load(sync + kPreParts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    knn_pre_stats_body(y, M, D, DK * 32, pre, part, b, red);
-    __builtin_amdgcn_s_waitcnt(0);  // this thread's (coherent) stores of the part are performed ...
-    __syncthreads();                // ... every thread's; gen_s is read
-    const unsigned long long want = gen_s + 1;
-    if (threadIdx.x == 0) __hip_atomic_store(sync + part, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x < kPreParts)
-        while (__hip_atomic_load(sync + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(1);  // (relaxed: an
-                                                                     // acquire per poll invalidates the caches under the blocks still working)
-    __syncthreads();  // (the parts are read with coherent loads: knn_pre_get)
-    if (part == 0 && threadIdx.x == 0) __hip_atomic_store(sync + kPreParts, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    knn_pre_image_body<DK>(y, M, D, two_norms, pre, part, b, mu, sh);
-}
+// (Round 4 tried the whole pre-pass as ONE launch of one 1024-thread block per cloud -- the cloud in registers between the statistics
+//  and the conversion, no meeting: 12.7 us under rocprofv3 against 4.8 + 6.4 for the two launches, calls 1-2 us slower at four of five
+//  shapes (profiles/r04_v4_knn_prepass_ab.txt): 32 CUs stream 256 KB each at ~50 GB/s.  Removed; the two launches stay.)
 
+// producer wave pw brings the norms of chunk [j0, j0 + CH) into the block's norm arrays (direct-to-LDS; not waited for here)
+__device__ __forceinline__ void knn_pre_stage_norms(const float *__restrict__ gnup, const float *__restrict__ gndn, int j0, int CH, float *nup,
+                                                    float *ndn, int pw, int lane) {
+    const int nin = CH / 4 / 64;  // wave-instructions per norm array (CH / 4 pieces of four floats); CH = 64 -> a quarter wave
+    for (int i = pw; i < (nin > 0 ? nin : 1); i += kMWaves)
+        if (i * 64 + lane < CH / 4) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gnup + j0 + (size_t)(i * 64 + lane) * 4),
+                                             (__attribute__((address_space(3))) void *)(nup + (size_t)i * 256), 16, 0, 0);
+            if (ndn)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gndn + j0 + (size_t)(i * 64 + lane) * 4),
+                                                 (__attribute__((address_space(3))) void *)(ndn + (size_t)i * 256), 16, 0, 0);
+        }
+}
 // producer wave pw brings chunk [j0, j0 + CH) of the pre-pass image into `img` (single-piece layout of knn_hpiece_off: the
 // rotation sits on the source address) and, in phase A, its norms into the block's norm arrays -- direct-to-LDS loads only
 template <int DK, bool WAIT = true>
@@ -2384,7 +2388,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                                                              const float *__restrict__ y, int M, int B, int D,
                                                              int k, int drop, int32_t *__restrict__ idx,
                                                              float *__restrict__ dist, int CH, int img_floats,
-                                                             int keep_norms, int two_norms, int srl, void *pre_ws, int xdiv, int csl) {
+                                                             int keep_norms, int two_norms, int srl, void *pre_ws, int xdiv, int csl, int regstage) {
     constexpr int DP = DK * 32;      // padded feature dimension
     constexpr int RS = DP + 4;       // row stride of the query rows staged in the prologue (floats)
     constexpr int PPR = DK * 8;      // 16-byte pieces per candidate row
@@ -2461,22 +2465,33 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     }
     float sc = 1.0f;  // F16: power-of-two scale with |sc * c| < 1 for every candidate
     float funit = 1.0f;  // F16: unit of the absolute error terms (see the scale pass)
+    // (round 4) behind the pre-pass the kernel's start is ONE global round trip: the first chunk of the image (and the norms) is requested
+    // right here, and every lane reads its pieces of its query row and of the centre straight from memory (below) -- no staging of the
+    // query rows through LDS, no barrier before the first chunk's.  (It was three dependent round trips -- header, query rows in a loop
+    // of load -> LDS store, first chunk -- and two block barriers: 10.4 k cycles.)
+    const bool early = F16 && use_pre && vec4x;
+    if (early && !consumer) {
+        if (DK <= 2 && regstage)
+            for (int c = 1; c < nchunk; ++c)
+                knn_pre_stage_norms(pre_nup, pre_ndn, c * CH, CH, nall + (size_t)c * CH, nallm ? nallm + (size_t)c * CH : nullptr, wv - kMWaves, lane);
+        knn_pre_stage_chunk<DK, false>(pre_img, pre_nup, pre_ndn, 0, CH, sm, nall, nallm, true, wv - kMWaves, lane);
+    }
     if (F16 && use_pre) {
         // ---- the pre-pass (knn_pre_*_kernel) has the centre, the scale and the largest scaled norm of this cloud
-        __syncthreads();
+        if (!early) __syncthreads();
         const KnnPre pre = KnnPre::make(pre_ws, M, DP);
         const float *h = pre.hdr(b);
         sc = h[0];
         funit = h[1];
-        if (tid < DP) mu[tid] = h[8 + tid];
-        if (tid == 0) {
+        if (!early && tid < DP) mu[tid] = h[8 + tid];
+        if (tid == 0) {  // (the same thread zeroed these words above; they are read after the chunk loop's barriers)
             reinterpret_cast<float *>(cmax)[1] = h[2];
             unsigned int m = h[3] != 0.0f ? 0x7fc00000u : 0u;
             const unsigned int *cp = pre.cmaxp(b);
             for (int p = 0; p < kPreParts; ++p) m = cp[p] > m ? cp[p] : m;  // (NaN pattern > every finite norm)
             *cmax = m;
         }
-        __syncthreads();
+        if (!early) __syncthreads();
     } else if (F16) {
         // ---- centre and scale: per-dimension MEAN mu (robust against a few far points, unlike the mid-range) and the
         //      largest |c - mu| of the cloud, one coalesced pass (F16 => 16-byte loads are legal).  Distances do not
@@ -2641,7 +2656,42 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     kh8 ah[NB16], al[NB16];  // fp16 filter: hi / lo halves of -2 sc q, 8 dimensions per K block and half-wave
     float qn = 0.0f;
     bool qok = true;
-    if (consumer || DUAL) {  // (DUAL: both waves of a pair stage the same rows -- identical values -- and derive the same operands)
+    if (early) {
+        // K block bb covers dimensions 16 bb + 8 h + [0, 8) in half-wave h: hi halves of -2 sc (q - mu), every piece read from memory
+        // (16 bytes of the lane's own row -- rows beyond N read row N - 1 and are never used -- and of the pre-pass header's centre,
+        // zero beyond D); all loads in flight together
+        const float *qg = xb + (size_t)(qi < N ? qi : N - 1) * D;
+        const float *mg = KnnPre::make(pre_ws, M, DP).hdr(b) + 8;
+        float4 qv[NB16][2], mv[NB16][2];
+#pragma unroll
+        for (int bb = 0; bb < NB16; ++bb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int d0 = 16 * bb + 8 * h + 4 * u;
+                qv[bb][u] = *reinterpret_cast<const float4 *>(qg + (d0 < D ? d0 : 0));
+                mv[bb][u] = *reinterpret_cast<const float4 *>(mg + d0);
+            }
+        float amax = 0.0f;
+#pragma unroll
+        for (int bb = 0; bb < NB16; ++bb) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool in = 16 * bb + 8 * h + 4 * u < D;
+                const float v[4] = {qv[bb][u].x, qv[bb][u].y, qv[bb][u].z, qv[bb][u].w}, m4[4] = {mv[bb][u].x, mv[bb][u].y, mv[bb][u].z, mv[bb][u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float qs_ = in ? (v[e] - m4[e]) * sc : 0.0f;  // centred like the candidates
+                    qn = qn + qs_ * qs_;
+                    const float av = -2.0f * qs_;
+                    amax = fmaxf(amax, fabsf(av));
+                    ah[bb][4 * u + e] = (_Float16)av;
+                }
+            }
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        qok = amax < 6.0e4f;  // inside the fp16 range (false for NaN too)
+        qn = qn + __shfl_xor(qn, 32, 64);
+    } else if (consumer || DUAL) {  // (DUAL: both waves of a pair stage the same rows -- identical values -- and derive the same operands)
         float *qs = sm + (size_t)cw * 32 * RS;
         const int nrow = wave_active ? ((N - q0) < 32 ? (N - q0) : 32) : 0;
         const float *src = xb + (size_t)q0 * D;
@@ -2698,7 +2748,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         }
         qn = qn + __shfl_xor(qn, 32, 64);
     }
-    __syncthreads();
+    if (!early) __syncthreads();
     KNN_PROBE_MARK(1);
 
     // ---- chunk schedule: phase A walks the chunks forwards, phase B backwards (its first chunk is resident) ----
@@ -2710,8 +2760,16 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     int stage_ev = 0;                    // F16 producers: staging events done (chunks 0..n-1, n-2..0)
     const int nevents = 2 * nchunk - 1;
     if (F16 && use_pre) {
-        if (!consumer)
+        if (!consumer && early) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces of the first chunk (requested at the kernel's start) have landed
+            __builtin_amdgcn_wave_barrier();
+        } else if (!consumer) {
+            // (regstage: the image chunks of the loop below come through registers; the norms of ALL chunks arrive here, once)
+            if (DK <= 2 && regstage)
+                for (int c = 1; c < nchunk; ++c)
+                    knn_pre_stage_norms(pre_nup, pre_ndn, c * CH, CH, nall + (size_t)c * CH, nallm ? nallm + (size_t)c * CH : nullptr, wv - kMWaves, lane);
             knn_pre_stage_chunk<DK>(pre_img, pre_nup, pre_ndn, 0, CH, sm, nall, nallm, true, wv - kMWaves, lane);
+        }
     } else if (F16) {
         if (!consumer) {
             knn_f16_load_chunk<DK, kMUnits>(yb, D, 0, M < CH ? M : CH, CH, ptid, preg);
@@ -2747,7 +2805,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
 #pragma unroll
     for (int r = 0; r < 32; ++r) mn[r] = INFINITY;
     float thr = 0.0f;
-    int cnt = 0;
+    int cnt = 0, totb = 0;  // list words with a survivor; survivors seen by phase B (all of them: the overflow flag tells when words were lost)
     int *mylist = lists + (DUAL ? wv * LCAP : cw * kMLCap) * 64 + lane;  // entry e at mylist[e * 64]
 
     int cur = 0;  // buffer holding the chunk of this step
@@ -2760,7 +2818,24 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         const int nstep1 = step + 1;
         const int ci_next = nstep1 >= nchunk ? nstep - 1 - nstep1 : nstep1;
         const bool stage_next = nstep1 < nstep && ci_next != ci;
-        if (DUAL && !consumer && stage_next) {  // the next chunk's direct loads first: they land while this wave computes
+        // regstage (round 4): the next chunk of the image through REGISTERS -- every thread requests its 16-byte pieces now and writes
+        // them to the other buffer after its share of the filter (no VALU either way).  The direct-to-LDS loads moved ~16 bytes per
+        // cycle and CU and did not overlap the compute (a 256-row step = its compute, 3.0 k cycles, + its staging, 2.4 k); loads to
+        // registers run at the L1's 64 bytes per cycle.
+        constexpr bool REGST = PRE && DK <= 2;  // (D > 64: eight pieces per thread -- 32 registers the kernel does not have)
+        constexpr int NCR = REGST ? (PPI / 2 > 0 ? PPI / 2 : 1) : 1;  // 16-byte pieces per thread and 256-row chunk
+        f32x4v creg[NCR];
+        if (REGST && stage_next && regstage) {
+            const int j0n = ci_next * CH;
+            constexpr int RPBc = PPI >= 16 ? 1 : 16 / PPI;
+#pragma unroll
+            for (int i = 0; i < NCR; ++i) {
+                const int S = tid + i * kMThreads;
+                const int row = S / PPI, pos = S & (PPI - 1);
+                const int c = (pos - row / RPBc) & (PPI - 1);
+                if (S < CH * PPI) creg[i] = *reinterpret_cast<const f32x4v *>(pre_img + ((size_t)(j0n + row) * PPI + c) * 8);
+            }
+        } else if (DUAL && !consumer && stage_next) {  // the next chunk's direct loads first: they land while this wave computes
             const int j0n = ci_next * CH;
             knn_pre_stage_chunk<DK, false>(pre_img, pre_nup, pre_ndn, j0n, CH, sm + (size_t)(1 - cur) * buf_floats, nall + (size_t)ci_next * CH,
                                            nallm ? nallm + (size_t)ci_next * CH : nullptr, nstep1 < nchunk, wv - kMWaves, lane);
@@ -2772,55 +2847,72 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                 const int npair = cn_pad / 64;
                 const int tile0 = j0 / 32;
                 int pr_first = 0;
+                // phase B of the fp16 filters accumulates on n_c - thr: the sign of the result is the test.  (The Float32 GEMM keeps the
+                // compare: its staging leaves the rows beyond the cloud's end unwritten -- norm +inf, stale pieces -- and inf + NaN has
+                // no usable sign; the fp16 images are zero there.)
+                const float tsub = (F16 && phase) ? thr : 0.0f;
                 if (F16 && !SPLIT && PRE) {  // (without the pre-pass the producers' staging registers leave no room: 68 spills)
                     // single-piece fp16 filter: TWO pairs of tiles per iteration -- the second pair's operand fetches and MFMAs are
                     // issued before the first pair's results are folded, so the fold (VALU) of one overlaps the matrix work of the
-                    // other and one round of LDS latency serves four tiles (a lone consumer wave per SIMD hides nothing otherwise)
+                    // other and one round of LDS latency serves four tiles (a lone consumer wave per SIMD hides nothing otherwise).
+                    // One instantiation per phase (round 4): phase A's accumulators ARE the norm loads' destinations (no VALU) and two
+                    // tiles fold per v_min3 straight from the MFMA registers; phase B starts them at n_c - thr (one v_sub each).
                     constexpr int RPB2 = PPI >= 16 ? 1 : 16 / PPI;
-                    for (; pr_first + 1 < npair; pr_first += 2) {
-                        if (DUAL && ((pr_first >> 1) & 1) != half) continue;  // the pair's waves take alternate double pairs
-                        f32x16v accs[4];
-                        kh8 ops[4][NB16];
+                    auto run4 = [&](auto phc) {
+                        constexpr bool PHB = decltype(phc)::value;
+                        for (; pr_first + 1 < npair; pr_first += 2) {
+                            if (DUAL && ((pr_first >> 1) & 1) != half) continue;  // the pair's waves take alternate double pairs
+                            f32x16v accs[4];
+                            kh8 ops[4][NB16];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {  // q = 2 * (pair) + (tile of the pair)
-                            const int rbase = (pr_first + (q >> 1)) * 64 + 32 * (q & 1);
+                            for (int q = 0; q < 4; ++q) {  // q = 2 * (pair) + (tile of the pair)
+                                const int rbase = (pr_first + (q >> 1)) * 64 + 32 * (q & 1);
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                const float4 n0 = *reinterpret_cast<const float4 *>(cnorm + rbase + 8 * g + 4 * h);
-                                accs[q][4 * g] = n0.x; accs[q][4 * g + 1] = n0.y; accs[q][4 * g + 2] = n0.z; accs[q][4 * g + 3] = n0.w;
+                                for (int g = 0; g < 4; ++g) {
+                                    const float4 n0 = *reinterpret_cast<const float4 *>(cnorm + rbase + 8 * g + 4 * h);
+                                    if (PHB) {
+                                        accs[q][4 * g] = n0.x - thr; accs[q][4 * g + 1] = n0.y - thr; accs[q][4 * g + 2] = n0.z - thr; accs[q][4 * g + 3] = n0.w - thr;
+                                    } else {
+                                        accs[q][4 * g] = n0.x; accs[q][4 * g + 1] = n0.y; accs[q][4 * g + 2] = n0.z; accs[q][4 * g + 3] = n0.w;
+                                    }
+                                }
+                                const float *cq = cand + (size_t)(rbase + jl) * RSI;
+#pragma unroll
+                                for (int bb = 0; bb < NB16; ++bb)
+                                    ops[q][bb] = *reinterpret_cast<const kh8 *>(cq + ((2 * bb + h + jl / RPB2) & (PPI - 1)) * 4);
                             }
-                            const float *cq = cand + (size_t)(rbase + jl) * RSI;
 #pragma unroll
-                            for (int bb = 0; bb < NB16; ++bb)
-                                ops[q][bb] = *reinterpret_cast<const kh8 *>(cq + ((2 * bb + h + jl / RPB2) & (PPI - 1)) * 4);
-                        }
+                            for (int bb = 0; bb < NB16; ++bb) {  // four independent accumulators in turn: no MFMA waits for its predecessor
 #pragma unroll
-                        for (int bb = 0; bb < NB16; ++bb) {  // four independent accumulators in turn: no MFMA waits for its predecessor
+                                for (int q = 0; q < 4; ++q) accs[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ops[q][bb], ah[bb], accs[q], 0, 0, 0);
+                            }
+                            if (!PHB) {
+                                // (any partition of the tiles into the 32 groups of a lane will do; the two accumulators issued last are
+                                //  read 20+ issue slots after their MFMAs: knn_f16_d3_kernel's order)
+                                KNN_MFMA_SETTLE4(accs[0], accs[1], accs[2], accs[3]);
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) accs[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ops[q][bb], ah[bb], accs[q], 0, 0, 0);
-                        }
-                        if (phase == 0) {
-                            KNN_MFMA_SETTLE4(accs[0], accs[1], accs[2], accs[3]);
+                                for (int r = 0; r < 16; ++r) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(mn[r]) : "v"(accs[0][r]), "v"(accs[1][r]));
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) mn[r] = vmin_acc(mn[r], accs[0][r]);
+                                for (int r = 0; r < 16; ++r) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(mn[16 + r]) : "v"(accs[2][r]), "v"(accs[3][r]));
+                            } else {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) mn[16 + r] = vmin_acc(mn[16 + r], accs[1][r]);
+                                for (int q = 0; q < 4; ++q) {
+                                    unsigned int m = 0;
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) mn[r] = vmin_acc(mn[r], accs[2][r]);
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) mn[16 + r] = vmin_acc(mn[16 + r], accs[3][r]);
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                unsigned int m = 0;
-#pragma unroll
-                                for (int r = 0; r < 16; ++r) m |= (accs[q][r] <= thr) ? (1u << r) : 0u;
-                                const int pp = cnt < LCAP - 1 ? cnt : LCAP - 1;
-                                mylist[pp * 64] = (int)((unsigned int)(tile0 + pr_first * 2 + q) << 16 | m);
-                                cnt += m != 0 ? 1 : 0;
+                                    for (int i = 0; i < 16; ++i) {  // the sign of F - thr is the test: one v_alignbit per row shifts it in (row r at bit r)
+                                        const float av = accs[q][15 - i];
+                                        m = __builtin_amdgcn_alignbit(m, __builtin_bit_cast(unsigned int, av), 31);
+                                    }
+                                    const int pp = cnt < LCAP - 1 ? cnt : LCAP - 1;
+                                    mylist[pp * 64] = (int)((unsigned int)(tile0 + pr_first * 2 + q) << 16 | m);
+                                    cnt += m != 0 ? 1 : 0;
+                                    totb += __builtin_popcount(m);
+                                }
                             }
                         }
-                    }
+                    };
+                    if (phase == 0) run4(std::false_type{});
+                    else run4(std::true_type{});
                 }
                 for (int pr = (DUAL && half) ? npair : pr_first; pr < npair; ++pr) {  // (DUAL: a last lone pair goes to the first wave)
                     // rows pr*64 + jl and + 32 share (row mod PPR) = jl mod PPR: one rotated offset per fetch
@@ -2831,8 +2923,8 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                     for (int g = 0; g < 4; ++g) {
                         const float4 n0 = *reinterpret_cast<const float4 *>(cnorm + pr * 64 + 8 * g + 4 * h);
                         const float4 n1 = *reinterpret_cast<const float4 *>(cnorm + pr * 64 + 32 + 8 * g + 4 * h);
-                        acc0[4 * g] = n0.x; acc0[4 * g + 1] = n0.y; acc0[4 * g + 2] = n0.z; acc0[4 * g + 3] = n0.w;
-                        acc1[4 * g] = n1.x; acc1[4 * g + 1] = n1.y; acc1[4 * g + 2] = n1.z; acc1[4 * g + 3] = n1.w;
+                        acc0[4 * g] = n0.x - tsub; acc0[4 * g + 1] = n0.y - tsub; acc0[4 * g + 2] = n0.z - tsub; acc0[4 * g + 3] = n0.w - tsub;
+                        acc1[4 * g] = n1.x - tsub; acc1[4 * g + 1] = n1.y - tsub; acc1[4 * g + 2] = n1.z - tsub; acc1[4 * g + 3] = n1.w - tsub;
                     }
                     if (F16 && SPLIT) {
                         // A = candidate pieces (rows), B = query pieces (columns); hi*hi + lo*hi + hi*lo
@@ -2902,10 +2994,15 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                             // list head unconditionally, the head advances when the mask is not empty
                             unsigned int m = 0;
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) m |= ((tt ? acc1[r] : acc0[r]) <= thr) ? (1u << r) : 0u;
+                            for (int i = 0; i < 16; ++i) {  // (ascending i: a descending unrolled loop over the vector's elements read element 0 every time)
+                                const float av = tt ? acc1[15 - i] : acc0[15 - i];
+                                if (F16) m = __builtin_amdgcn_alignbit(m, __builtin_bit_cast(unsigned int, av), 31);
+                                else m |= (av <= thr) ? (1u << (15 - i)) : 0u;
+                            }
                             const int pp = cnt < LCAP - 1 ? cnt : LCAP - 1;
                             mylist[pp * 64] = (int)((unsigned int)(tile0 + pr * 2 + tt) << 16 | m);
                             cnt += m != 0 ? 1 : 0;
+                            totb += __builtin_popcount(m);
                         }
                     }
                 }
@@ -2940,7 +3037,14 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                                     cmax, phase_a, phase_a || !keep_norms, vec4y, wv - kMWaves, lane);
             }
         }
-        if (DUAL && !consumer && stage_next) {
+        if (REGST && stage_next && regstage) {
+            float *nimg = sm + (size_t)(1 - cur) * buf_floats;
+#pragma unroll
+            for (int i = 0; i < NCR; ++i) {
+                const int S = tid + i * kMThreads;
+                if (S < CH * PPI) *reinterpret_cast<f32x4v *>(nimg + (size_t)S * 4) = creg[i];
+            }
+        } else if (DUAL && !consumer && stage_next) {
             __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces of the next chunk have landed
             __builtin_amdgcn_wave_barrier();
         }
@@ -2950,6 +3054,13 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         if (step == nchunk - 1 && (consumer || DUAL)) {
             // ---- tau: kk-th smallest of the 64 group minima of every query (32 in this lane, 32 in its partner) ----
             const float c2 = __builtin_bit_cast(float, *cmax);
+            float tau;
+            if (DUAL && kk <= 24 && M >= 128) {
+                // 128 group minima per query in the layout of the D = 3 kernel (32 per lane x two half-lanes x the pair's two waves):
+                // its reduced selection (round 4; the sort of all 32 + two 32-value merges below were 5 us of this kernel)
+                tau = knn_tau_8of16<kMWaves>(mn, reinterpret_cast<float *>(lists), wv, jl, h, kk);
+                __syncthreads();  // the exchange space becomes the lane lists
+            } else {
             k3_sort_regs<32>(mn);
             float oth[32];
 #pragma unroll
@@ -3000,7 +3111,8 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             float val = mn[0];
 #pragma unroll
             for (int r = 1; r < 32; ++r) val = (kk - 1) == r ? mn[r] : val;
-            const float tau = __shfl(val, jl, 64);  // kk <= 32: always among the 32 smallest (half 0)
+            tau = __shfl(val, jl, 64);  // kk <= 32: always among the 32 smallest (half 0)
+            }
             float eps;
             if (F16) {
                 // scaled units (c~ = sc c, |c~| < 1; qn = |sc q|^2): split representation 3 2^-22 |a~||c~|, fp32
@@ -3019,6 +3131,11 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                 eps = qn + c2 < 1.0e38f ? eps : INFINITY;  // (|q| + |c|)^2 <= 2 (qn + c2): no exact distance overflows
             }
             thr = tau + 2.0f * eps;  // NaN / inf => slow path below
+            // (round 4) phase B starts the accumulators at n_c - thr instead of n_c and keeps the SIGN of the result (one v_alignbit per
+            // row where the compare cost v_cmp + v_cndmask + v_or and two wait states): the first operand of the accumulation is
+            // rounded once more, |n_c - thr| <= n_c + |thr| -- 2^-21 (c2 + qn + |thr|) covers it four times over, and makes the test
+            // strict (a candidate at the threshold has a negative result, never -0 / +0)
+            thr = thr + 0x1p-21f * ((c2 + qn) + fabsf(thr));
         }
     }
     KNN_PROBE_MARK(20);
@@ -3034,11 +3151,16 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         const int tsh = srl > 0 ? srl - 5 : 31;
         unsigned long long pk = 0;
         int totx = 0;
-        for (int e = 0; e < nv; ++e) {
-            const unsigned int w = (unsigned int)mylist[e * 64];
-            const int pc = __builtin_popcount(w & 0xffffu);
-            totx += pc;
-            pk += (unsigned long long)pc << (srl > 0 ? ((w >> 16) >> tsh) * 8 : 0);
+        if (srl > 0) {
+            for (int e = 0; e < nv; ++e) {
+                const unsigned int w = (unsigned int)mylist[e * 64];
+                const int pc = __builtin_popcount(w & 0xffffu);
+                totx += pc;
+                pk += (unsigned long long)pc << (((w >> 16) >> tsh) * 8);
+            }
+        } else {  // no row stages (column slices, gather): the total phase B counted -- no walk over the list (a chain of LDS round trips)
+            totx = totb;
+            pk = (unsigned long long)(unsigned int)totb;
         }
         // (the bytes are only meaningful while none can carry: a part with more than 63 survivors -- the query is not a fast one
         //  then -- publishes its plain total behind a marker bit instead)
@@ -3249,6 +3371,17 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
         f32x4v qs[4], qnx[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) qs[t] = *reinterpret_cast<const f32x4v *>(qrow + 4 * t);
+        // this lane's pairs stay in registers across the slices: the candidate's plane offset and the running sum (n <= 64 survivors per
+        // query: at most 16 per lane); four pairs are in flight -- their 16 pieces are requested together, their four chains of additions
+        // interleave (a slice of ONE pair is 16 dependent additions: two pairs in flight left the phase latency bound, 2.5 us per slice)
+        const int cnt_l = act ? mycount : 0;
+        int jo[16];
+        float acc[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            jo[u] = u < cnt_l ? qj[mystart + u] * 4 : 0;
+            acc[u] = 0.0f;
+        }
         for (int s = 0; s < csl; ++s) {
             if (s) __syncthreads();  // every lane is done with the previous slice
 #pragma unroll
@@ -3263,33 +3396,40 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
 #pragma unroll
                 for (int t = 0; t < 4; ++t) qnx[t] = *reinterpret_cast<const f32x4v *>(qrow + 16 * (s + 1) + 4 * t);
             }
-            if (act) {
-                for (int p0 = mystart; p0 < mystart + mycount; p0 += 2) {
-                    const bool two = p0 + 1 < mystart + mycount;
-                    const float *cp0 = stg + (size_t)qj[p0] * 4, *cp1 = stg + (size_t)qj[two ? p0 + 1 : p0] * 4;
-                    float s0 = s ? __builtin_bit_cast(float, qd[p0]) : 0.0f;
-                    float s1 = s && two ? __builtin_bit_cast(float, qd[p0 + 1]) : 0.0f;
-                    f32x4v c0[4], c1[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (__ballot(4 * g < cnt_l) != 0ull) {  // (wave-uniform: some lane still has a pair in this group)
+                    f32x4v c[4][4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) c[e][t] = *reinterpret_cast<const f32x4v *>(stg + jo[4 * g + e] + t * PS);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        c0[t] = *reinterpret_cast<const f32x4v *>(cp0 + (size_t)t * PS);
-                        c1[t] = *reinterpret_cast<const f32x4v *>(cp1 + (size_t)t * PS);
-                    }
+                        f32x4v m[4];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const f32x4v d0 = qs[t] - c0[t], d1 = qs[t] - c1[t];
-                        const f32x4v m0 = d0 * d0, m1 = d1 * d1;
-                        s0 = s0 + m0.x; s0 = s0 + m0.y; s0 = s0 + m0.z; s0 = s0 + m0.w;
-                        s1 = s1 + m1.x; s1 = s1 + m1.y; s1 = s1 + m1.z; s1 = s1 + m1.w;
+                        for (int e = 0; e < 4; ++e) {
+                            const f32x4v d = qs[t] - c[e][t];
+                            m[e] = d * d;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[4 * g + e] = acc[4 * g + e] + m[e].x;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[4 * g + e] = acc[4 * g + e] + m[e].y;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[4 * g + e] = acc[4 * g + e] + m[e].z;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[4 * g + e] = acc[4 * g + e] + m[e].w;
                     }
-                    qd[p0] = __builtin_bit_cast(unsigned int, s0);
-                    if (two) qd[p0 + 1] = __builtin_bit_cast(unsigned int, s1);
                 }
             }
             if (s < 3) KNN_PROBE_MARK(27 + 2 * s);
 #pragma unroll
             for (int t = 0; t < 4; ++t) qs[t] = qnx[t];
         }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (u < cnt_l) qd[mystart + u] = __builtin_bit_cast(unsigned int, acc[u]);
     } else if (srl > 0) {
         // staged: the candidate rows come through LDS one stage (2^srl rows) at a time, loaded coalesced once per block
         // (every row exactly once: M * 4D bytes from L2 instead of 4D per survivor), rows 16 bytes apart in the banks.
@@ -3450,21 +3590,26 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     }
     __syncthreads();
     KNN_PROBE_MARK(23);
-    // (4) rank on the distance bits (squared distances are >= +0: unsigned order), verified as in knn_f16_d3_kernel
-    if (wave_active && fast) {
+    // (4) rank on the distance bits (squared distances are >= +0: unsigned order), verified as in knn_f16_d3_kernel.  Passes of eight of
+    //     the lane's entries against all n keys; a remainder of at most four / two entries in every lane of the wave takes a narrower
+    //     pass (round 4: n = 33 ... 36 survivors -- nine entries per lane -- cost a second full pass, 1152 instead of 720 operations).
+    {
+        const int myc = (wave_active && fast) ? mycount : 0;
+        const int nloop = (wave_active && fast) ? n : 0;
         int below = 0;
-        for (int e0 = 0; e0 < mycount; e0 += 8) {
-            unsigned int md[8];
-            int rank[8];
+        auto rank_pass = [&](auto wc, int e0) {
+            constexpr int W = decltype(wc)::value;
+            unsigned int md[W];
+            int rank[W];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                md[u] = e0 + u < mycount ? qd[mystart + e0 + u] : 0xffffffffu;
+            for (int u = 0; u < W; ++u) {
+                md[u] = e0 + u < myc ? qd[mystart + e0 + u] : 0xffffffffu;
                 rank[u] = 0;
             }
-            for (int i = 0; i < n; i += 4) {
+            for (int i = 0; i < nloop; i += 4) {  // (nloop: n for the lanes of a fast query, 0 for the others)
                 const uint4 o = *reinterpret_cast<const uint4 *>(qd + i);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {  // compare + add-with-carry: two VALU ops per pair
+                for (int u = 0; u < W; ++u) {  // compare + add-with-carry: two VALU ops per pair
                     unsigned long long cc;
                     asm("v_cmp_lt_u32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, 0, %0, %1" : "+v"(rank[u]), "=&s"(cc) : "v"(o.x), "v"(md[u]));
                     asm("v_cmp_lt_u32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, 0, %0, %1" : "+v"(rank[u]), "=&s"(cc) : "v"(o.y), "v"(md[u]));
@@ -3473,11 +3618,18 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (e0 + u < mycount && rank[u] < kk) {
+            for (int u = 0; u < W; ++u)
+                if (e0 + u < myc && rank[u] < kk) {
                     slots[rank[u]] = ((unsigned long long)md[u] << 32) | (unsigned int)qj[mystart + e0 + u];
                     below += 1 + (rank[u] << 8);
                 }
+        };
+        for (int e0 = 0;;) {
+            const int rem = myc - e0;
+            if (__ballot(rem > 0) == 0ull) break;
+            if (__ballot(rem > 2) == 0ull) { rank_pass(std::integral_constant<int, 2>{}, e0); e0 += 2; }
+            else if (__ballot(rem > 4) == 0ull) { rank_pass(std::integral_constant<int, 4>{}, e0); e0 += 4; }
+            else { rank_pass(std::integral_constant<int, 8>{}, e0); e0 += 8; }
         }
         if (below) atomicAdd(&qbelow[cw * 32 + jl], below);
     }
@@ -3771,21 +3923,18 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     KnnPre pre{};
     if (use_pre) {
         pre = KnnPre::make(pre_ws, M, DP);
-        if (!opt(OPT_KNN_PREPASS_FUSED)) {  // (the one-launch form measured the same: DESIGN.md 3.2)
-            hipLaunchKernelGGL(knn_pre_stats_kernel, dim3(kPreParts, B), dim3(kPreThreads), 0, st, y, M, D, DP, pre);
-            hipLaunchKernelGGL((knn_pre_image_kernel<DK>), dim3(kPreParts, B), dim3(kPreThreads), 0, st, y, M, D, two_norms, pre);
-        } else
-            hipLaunchKernelGGL((knn_pre_fused_kernel<DK>), dim3(kPreParts, B), dim3(kPreThreads), 0, st, y, M, D, two_norms, pre);
+        hipLaunchKernelGGL(knn_pre_stats_kernel, dim3(kPreParts, B), dim3(kPreThreads), 0, st, y, M, D, DP, pre);
+        hipLaunchKernelGGL((knn_pre_image_kernel<DK>), dim3(kPreParts, B), dim3(kPreThreads), 0, st, y, M, D, two_norms, pre);
     }
     if (use_pre) {
         const fx3d_status arc2 = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_mfma_kernel<DK, F16, SPLIT, F16 && !SPLIT>), 152 * 1024,
                                                     "knn_mfma_kernel<pre>");
         if (arc2 != FX3D_OK) return arc2;
         hipLaunchKernelGGL((knn_mfma_kernel<DK, F16, SPLIT, F16 && !SPLIT>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
-                           k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, pre_ws, xdiv, csl);
+                           k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, pre_ws, xdiv, csl, opt(OPT_KNN_DIRECT_LDS) ? 0 : 1);
     } else
         hipLaunchKernelGGL((knn_mfma_kernel<DK, F16, SPLIT>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
-                           k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, nullptr, xdiv, csl);
+                           k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, nullptr, xdiv, csl, 0);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }

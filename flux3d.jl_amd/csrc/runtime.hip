@@ -39,7 +39,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"knn_gather", "FX3D_KNN_GATHER", 0},
     {"knn_d3_wave", "FX3D_KNN_D3_WAVE", 0},
     {"knn_d3_no_compact", "FX3D_KNN_D3_NO_COMPACT", 0},
-    {"knn_prepass_fused", "FX3D_KNN_PREPASS_FUSED", 0},
+    {"knn_direct_lds", "FX3D_KNN_DIRECT_LDS", 0},
     {"knn_slices", "FX3D_KNN_SLICES", 0},
     {"edge_scalar_stores", "FX3D_EDGE_SCALAR_STORES", 0},
     {"edgeconv_unfused", "FX3D_EDGECONV_UNFUSED", 0},

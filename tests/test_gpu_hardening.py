@@ -610,22 +610,49 @@ def test_laplacian_loss_grad_gather_is_bit_identical_to_the_oracle(gpu_fx, oracl
     assert np.allclose(gs, ol, rtol=1e-4, atol=1e-9)
 
 
-def test_knn_prepass_one_launch_form(gpu_fx, oracle, fx_option):
-    """Option knn_prepass_fused: statistics and image of the pre-pass in one launch, the eight part blocks of a cloud meeting through
-    the slab's generation word and slots (device-coherent accesses, no fences).  Same results as the two-launch form, call after
-    call on the same workspace (the meeting state lives there) and on a fresh, dirty one."""
+@pytest.mark.parametrize("direct", [0, 1])
+def test_knn_prepass_search_staging(gpu_fx, oracle, fx_option, direct):
+    """The search kernel behind the pre-pass (fx3d_knn_ws) with its image chunks brought in through registers (default; the first
+    chunk requested at the kernel's start, the query rows staged behind it) and with direct-to-LDS loads (option knn_direct_lds):
+    the same neighbours as the oracle -- a cloud with a far point (robust centre), C4's rows with queries from another array, a
+    ragged tail (M < the 256-row padding), D = 128, a cloud beyond 1024 rows (row stages instead of column slices), call after call
+    on the same scratch."""
     rng = np.random.default_rng(21)
+    fx_option("knn_direct_lds", str(direct))
     x = np.asfortranarray(rng.standard_normal((32, 700, 5)).astype(np.float32))
+    x[:, 17, 2] += 3.0e4  # one far point: the mean leaves the middle of the range (robust-centre rule)
     oi, od = oracle.knn(x, 12, drop_first=True)
-    fx_option("knn_prepass_fused", "1")
-    for _ in range(4):
+    for _ in range(3):
         idx, dist = gpu_fx.knn(x, 12, drop_first=True)
         assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
-    y = np.asfortranarray(rng.standard_normal((64, 1024, 9)).astype(np.float32))   # another shape on the same (reused, now dirty) scratch
+    y = np.asfortranarray(rng.standard_normal((64, 1024, 9)).astype(np.float32))
     oi2, od2 = oracle.knn(y[:, :200, :], 20, y=y)
     for _ in range(2):
         idx, dist = gpu_fx.knn(np.asfortranarray(y[:, :200, :]), 20, y=y)
         assert np.array_equal(idx.to_host(), oi2) and np.array_equal(dist.to_host(), od2)
+    z = np.asfortranarray((rng.standard_normal((128, 500, 3)) * 7.0 + 2.0).astype(np.float32))
+    oi3, od3 = oracle.knn(z, 9, drop_first=True)
+    idx, dist = gpu_fx.knn(z, 9, drop_first=True)
+    assert np.array_equal(idx.to_host(), oi3) and np.array_equal(dist.to_host(), od3)
+    w = np.asfortranarray(rng.standard_normal((64, 1100, 2)).astype(np.float32))
+    oi4 = oracle.knn(w, 20, drop_first=True, want_dist=False)
+    assert np.array_equal(gpu_fx.knn(w, 20, drop_first=True, return_dist=False).to_host(), oi4)
+
+
+@pytest.mark.parametrize("rows", [0, 1])
+def test_knn_exact_phase_column_slices(gpu_fx, oracle, fx_option, rows):
+    """The exact phase of the feature-space kNN on 16-dimension column slices of the whole cloud (default for D % 16 == 0, D <= 64,
+    M <= 1024) and on row stages (option knn_row_stages): identical lists and distances, equal to the oracle's -- uniform data,
+    duplicated rows (ties: the verified ranking's re-rank), k + drop up to 32, a cloud that is not a multiple of 128 rows."""
+    rng = np.random.default_rng(33)
+    fx_option("knn_row_stages", str(rows))
+    for (D, N, B, k, drop) in ((64, 1024, 3, 20, True), (32, 1000, 2, 31, True), (16, 333, 4, 7, False), (48, 640, 2, 16, True)):
+        x = rng.standard_normal((D, N, B)).astype(np.float32)
+        x[:, N // 2:N // 2 + 40, 0] = x[:, :40, 0]  # exact duplicates: equal distances, ordered by index
+        x = np.asfortranarray(x)
+        oi, od = oracle.knn(x, k, drop_first=drop)
+        idx, dist = gpu_fx.knn(x, k, drop_first=drop)
+        assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od), (D, N, B, k)
 
 
 def _grid_mesh(nx, ny, seed, extra_verts=0):
