@@ -835,17 +835,21 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
 // instruction per KiB and no VGPR round trip -- the producers share their SIMD's issue slots with the
 // consumers' MFMAs, every VALU instruction they do not execute is matrix-core time.
 // knn_gather_kernel with 16-byte elements (F4 = F/4 float4 per row)
+// NT: streaming (non-temporal) stores for tensors beyond the caches (round 4: the F = 64 feature build gained 28 % from them)
+template <bool NT>
 __global__ __launch_bounds__(kThreads) void knn_gather4_kernel(const float *__restrict__ x, int N, int B, int F4, int k,
                                                                const int32_t *__restrict__ idx, float *__restrict__ out) {
     const long long total = (long long)B * N * k * F4;
-    const float4 *x4 = reinterpret_cast<const float4 *>(x);
-    float4 *o4 = reinterpret_cast<float4 *>(out);
+    const f32x4v *x4 = reinterpret_cast<const f32x4v *>(x);
+    f32x4v *o4 = reinterpret_cast<f32x4v *>(out);
     for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total;
          e += (long long)gridDim.x * kThreads) {
         const long long row = e / F4;  // (b*N+i)*k + r
         const int f = (int)(e - row * F4);
         const int b = (int)(row / k / N);
-        o4[e] = x4[((size_t)b * N + idx[row]) * F4 + f];
+        const f32x4v v = x4[((size_t)b * N + idx[row]) * F4 + f];
+        if (NT) __builtin_nontemporal_store(v, o4 + e);
+        else o4[e] = v;
     }
 }
 
@@ -3771,14 +3775,20 @@ __global__ __launch_bounds__(kThreads) void edge_features_mlp_kernel(const float
 // Same, four consecutive (r,i) positions per thread: the 4 x 4 block (4 positions x 4 features) is read as
 // float4 along the features and written as float4 along the positions -- every store is 16 bytes, a wave writes
 // 1 KiB runs.  Needs F % 4 == 0, (k*N) % 4 == 0 and 16-byte aligned x / out.
+// Round 4: blockIdx.z splits the feature loop (fper features per block) -- F = 64 at C4' is 335 MB written by what used to be 640
+// blocks (2.5 per CU, ten waves per CU, each a serial loop of load -> 8 stores); the write stream wants many more waves in
+// flight (tools/ubench_hbm.hip: 4.7 TB/s from 2048 blocks, 6.1 from 32768) -- and NT selects streaming (non-temporal) stores:
+// the tensor is larger than the Infinity Cache and nobody reads it back inside the launch.
+template <bool NT>
 __global__ __launch_bounds__(kThreads) void edge_features_mlp4_kernel(const float *__restrict__ x, int N, int B,
                                                                       int F, int k,
                                                                       const int32_t *__restrict__ idx,
-                                                                      float *__restrict__ out) {
+                                                                      float *__restrict__ out, int fper) {
     const int b = blockIdx.y;
     const long long KN = (long long)k * N;
     const long long e0 = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4;  // i*k + r of the first position
     if (e0 >= KN) return;
+    const int f_lo = blockIdx.z * fper, f_hi = f_lo + fper < F ? f_lo + fper : F;
     const int4 jj = *reinterpret_cast<const int4 *>(idx + (size_t)b * KN + e0);
     const float *xb = x + (size_t)b * N * F;
     const float *xi0 = xb + (size_t)(e0 / k) * F, *xi1 = xb + (size_t)((e0 + 1) / k) * F;
@@ -3786,19 +3796,23 @@ __global__ __launch_bounds__(kThreads) void edge_features_mlp4_kernel(const floa
     const float *xj0 = xb + (size_t)jj.x * F, *xj1 = xb + (size_t)jj.y * F, *xj2 = xb + (size_t)jj.z * F,
                 *xj3 = xb + (size_t)jj.w * F;
     float *o = out + (size_t)b * 2 * F * KN + e0;
-    for (int f = 0; f < F; f += 4) {
+    auto put = [](float *p, const f32x4v &v) {
+        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4v *>(p));
+        else *reinterpret_cast<f32x4v *>(p) = v;
+    };
+    for (int f = f_lo; f < f_hi; f += 4) {
         const float4 a0 = *reinterpret_cast<const float4 *>(xi0 + f), a1 = *reinterpret_cast<const float4 *>(xi1 + f);
         const float4 a2 = *reinterpret_cast<const float4 *>(xi2 + f), a3 = *reinterpret_cast<const float4 *>(xi3 + f);
         const float4 c0 = *reinterpret_cast<const float4 *>(xj0 + f), c1 = *reinterpret_cast<const float4 *>(xj1 + f);
         const float4 c2 = *reinterpret_cast<const float4 *>(xj2 + f), c3 = *reinterpret_cast<const float4 *>(xj3 + f);
-        *reinterpret_cast<float4 *>(o + (size_t)(f + 0) * KN) = float4{a0.x, a1.x, a2.x, a3.x};
-        *reinterpret_cast<float4 *>(o + (size_t)(f + 1) * KN) = float4{a0.y, a1.y, a2.y, a3.y};
-        *reinterpret_cast<float4 *>(o + (size_t)(f + 2) * KN) = float4{a0.z, a1.z, a2.z, a3.z};
-        *reinterpret_cast<float4 *>(o + (size_t)(f + 3) * KN) = float4{a0.w, a1.w, a2.w, a3.w};
-        *reinterpret_cast<float4 *>(o + (size_t)(F + f + 0) * KN) = float4{c0.x - a0.x, c1.x - a1.x, c2.x - a2.x, c3.x - a3.x};
-        *reinterpret_cast<float4 *>(o + (size_t)(F + f + 1) * KN) = float4{c0.y - a0.y, c1.y - a1.y, c2.y - a2.y, c3.y - a3.y};
-        *reinterpret_cast<float4 *>(o + (size_t)(F + f + 2) * KN) = float4{c0.z - a0.z, c1.z - a1.z, c2.z - a2.z, c3.z - a3.z};
-        *reinterpret_cast<float4 *>(o + (size_t)(F + f + 3) * KN) = float4{c0.w - a0.w, c1.w - a1.w, c2.w - a2.w, c3.w - a3.w};
+        put(o + (size_t)(f + 0) * KN, f32x4v{a0.x, a1.x, a2.x, a3.x});
+        put(o + (size_t)(f + 1) * KN, f32x4v{a0.y, a1.y, a2.y, a3.y});
+        put(o + (size_t)(f + 2) * KN, f32x4v{a0.z, a1.z, a2.z, a3.z});
+        put(o + (size_t)(f + 3) * KN, f32x4v{a0.w, a1.w, a2.w, a3.w});
+        put(o + (size_t)(F + f + 0) * KN, f32x4v{c0.x - a0.x, c1.x - a1.x, c2.x - a2.x, c3.x - a3.x});
+        put(o + (size_t)(F + f + 1) * KN, f32x4v{c0.y - a0.y, c1.y - a1.y, c2.y - a2.y, c3.y - a3.y});
+        put(o + (size_t)(F + f + 2) * KN, f32x4v{c0.z - a0.z, c1.z - a1.z, c2.z - a2.z, c3.z - a3.z});
+        put(o + (size_t)(F + f + 3) * KN, f32x4v{c0.w - a0.w, c1.w - a1.w, c2.w - a2.w, c3.w - a3.w});
     }
 }
 
@@ -4312,7 +4326,10 @@ fx3d_status fx3d_knn_gather(const float *x, int32_t N, int32_t B, int32_t F, int
         long long g4 = (total4 + kThreads - 1) / kThreads;
         if (g4 > 16384) g4 = 16384;
         ProfileScope prof4("knn_gather", as_stream(s));
-        hipLaunchKernelGGL(knn_gather4_kernel, dim3((unsigned)g4), dim3(kThreads), 0, as_stream(s), x, N, B, F / 4, k, idx, out);
+        if ((size_t)F * k * N * B * 4 > ((size_t)64 << 20) && !opt(OPT_EDGE_NO_NT))
+            hipLaunchKernelGGL(knn_gather4_kernel<true>, dim3((unsigned)g4), dim3(kThreads), 0, as_stream(s), x, N, B, F / 4, k, idx, out);
+        else
+            hipLaunchKernelGGL(knn_gather4_kernel<false>, dim3((unsigned)g4), dim3(kThreads), 0, as_stream(s), x, N, B, F / 4, k, idx, out);
         FX3D_LAUNCH_CHECK();
         return FX3D_OK;
     }
@@ -4342,9 +4359,21 @@ fx3d_status fx3d_edge_features(const float *x, int32_t N, int32_t B, int32_t F, 
         const long long KN = (long long)k * N;
         dim3 grid((unsigned)((KN + kThreads - 1) / kThreads), B);
         const bool al16 = (((uintptr_t)x | (uintptr_t)out | (uintptr_t)idx) & 15) == 0;
-        if (F % 4 == 0 && KN % 4 == 0 && al16 && !opt(OPT_EDGE_SCALAR_STORES))
-            hipLaunchKernelGGL(edge_features_mlp4_kernel, dim3((unsigned)((KN / 4 + kThreads - 1) / kThreads), B), dim3(kThreads),
-                               0, as_stream(s), x, N, B, F, k, idx, out);
+        if (F % 4 == 0 && KN % 4 == 0 && al16 && !opt(OPT_EDGE_SCALAR_STORES)) {
+            // the feature loop split over blockIdx.z until the grid holds ~16 blocks per CU (option edge_fsplit: 0 = automatic,
+            // n = features per block forced, a multiple of 4; edge_fsplit = F is the single loop of rounds 1-3)
+            const long long gx = (KN / 4 + kThreads - 1) / kThreads;
+            int fper = F;
+            if (opt(OPT_EDGE_FSPLIT) > 0) fper = (opt(OPT_EDGE_FSPLIT) + 3) / 4 * 4;
+            else
+                while (fper > 4 && gx * B * ((F + fper - 1) / fper) < 16ll * device_cus()) fper = (fper / 2 + 3) / 4 * 4;
+            const unsigned gz = (unsigned)((F + fper - 1) / fper);
+            const bool nt = (size_t)2 * F * KN * B * 4 > ((size_t)64 << 20) && !opt(OPT_EDGE_NO_NT);  // (small tensors may be read back from the caches)
+            if (nt)
+                hipLaunchKernelGGL(edge_features_mlp4_kernel<true>, dim3((unsigned)gx, B, gz), dim3(kThreads), 0, as_stream(s), x, N, B, F, k, idx, out, fper);
+            else
+                hipLaunchKernelGGL(edge_features_mlp4_kernel<false>, dim3((unsigned)gx, B, gz), dim3(kThreads), 0, as_stream(s), x, N, B, F, k, idx, out, fper);
+        }
         else if (F % 4 == 0 && ((uintptr_t)x & 15) == 0)
             hipLaunchKernelGGL(edge_features_mlp_kernel<true>, grid, dim3(kThreads), 0, as_stream(s), x, N, B, F, k, idx, out);
         else

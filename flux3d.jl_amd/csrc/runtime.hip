@@ -48,6 +48,8 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"nn1_tiny_mpairs", "FX3D_NN1_TINY_MPAIRS", 24},
     {"mesh_max_blocks", "FX3D_MESH_MAX_BLOCKS", 0},
     {"knn_row_stages", "FX3D_KNN_ROW_STAGES", 0},
+    {"edge_fsplit", "FX3D_EDGE_FSPLIT", 0},
+    {"edge_no_nt", "FX3D_EDGE_NO_NT", 0},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::once_flag g_opt_once;
