@@ -2474,12 +2474,6 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     // query rows through LDS, no barrier before the first chunk's.  (It was three dependent round trips -- header, query rows in a loop
     // of load -> LDS store, first chunk -- and two block barriers: 10.4 k cycles.)
     const bool early = F16 && use_pre && vec4x;
-    if (early && !consumer) {
-        if (DK <= 2 && regstage)
-            for (int c = 1; c < nchunk; ++c)
-                knn_pre_stage_norms(pre_nup, pre_ndn, c * CH, CH, nall + (size_t)c * CH, nallm ? nallm + (size_t)c * CH : nullptr, wv - kMWaves, lane);
-        knn_pre_stage_chunk<DK, false>(pre_img, pre_nup, pre_ndn, 0, CH, sm, nall, nallm, true, wv - kMWaves, lane);
-    }
     if (F16 && use_pre) {
         // ---- the pre-pass (knn_pre_*_kernel) has the centre, the scale and the largest scaled norm of this cloud
         if (!early) __syncthreads();
@@ -2675,6 +2669,15 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                 qv[bb][u] = *reinterpret_cast<const float4 *>(qg + (d0 < D ? d0 : 0));
                 mv[bb][u] = *reinterpret_cast<const float4 *>(mg + d0);
             }
+        // the first chunk's direct-to-LDS loads (and the norms) go out BEHIND this wave's own loads: the memory counter retires in
+        // order, so requested first they made the producer waves wait for the whole chunk before they could touch their header
+        // values (their operands were ready 3 k cycles after the consumers', and the block's first barrier with them)
+        if (!consumer) {
+            if (DK <= 2 && regstage)
+                for (int c = 1; c < nchunk; ++c)
+                    knn_pre_stage_norms(pre_nup, pre_ndn, c * CH, CH, nall + (size_t)c * CH, nallm ? nallm + (size_t)c * CH : nullptr, wv - kMWaves, lane);
+            knn_pre_stage_chunk<DK, false>(pre_img, pre_nup, pre_ndn, 0, CH, sm, nall, nallm, true, wv - kMWaves, lane);
+        }
         float amax = 0.0f;
 #pragma unroll
         for (int bb = 0; bb < NB16; ++bb) {
