@@ -12,6 +12,7 @@
 //   knn_gather[4]_kernel                           X[:, idx] (src/models/dgcnn.jl:6)
 //   knn_select_kernel                              any k + drop <= M, any D (M <= 36864): all keys of a query in LDS, radix select;
 //                                                  also the fallback of the verified slice merge (flagged queries only)
+//   knn_tau_8of16                                  tau of the matrix-core kernels from 128 group minima per query (shared, round 4)
 //   knn_f16_d3_kernel<FEAT, K3Geom>                D = 3: fp16-split matrix-core filter + exact re-scan in three geometries --
 //                                                  base (k+drop <= 32, M >= 64), compact (<= 48, two blocks per CU), wide (<= 64);
 //                                                  FEAT: EdgeConv's cat(X, KNN - X) written by the same kernel
@@ -1900,6 +1901,13 @@ fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int 
 // hi*hi + lo*hi + hi*lo (band 2^-18).  Producers convert while staging.
 // Queries whose band holds more candidates than the key arrays (60) but whose lane lists are intact take the medium
 // path (exact selection among their own survivors, up to kMMedCap); the rest of the leftovers the full exact merge.
+// PRE (fx3d_knn_ws, the pre-pass has built the cloud's fp16 image): both waves of a pair run the filter (DUAL, 128 group minima per
+// query).  Round 4, in this instantiation: every lane reads its pieces of its query row and of the centre straight from memory (no
+// LDS staging, no barrier before the first chunk's); the image chunks come through registers (option knn_direct_lds: direct-to-LDS
+// loads); one instantiation of the four-tile loop per phase (phase A folds two tiles per v_min3 on the MFMA registers, phase B starts
+// the accumulators at n_c - thr and shifts the signs in with v_alignbit); tau by knn_tau_8of16; survivors counted in phase B; the
+// exact phase on 16-dimension COLUMN SLICES of the whole cloud (M <= 1024, D % 16 == 0, D <= 64; option knn_row_stages: the row
+// stages of rounds 2-3), pairs in registers across the slices.  C4': kernel 60.8 -> 50.8 us (profiles/r04_v5_*).
 constexpr int kMLCap = 40;        // rows of a lane's mask list (39 usable + the scratch head)
 constexpr int kMKeyCap = 64;      // survivors per query handled by the fast path (three sentinels follow them inside the stride of 68)
 constexpr int kMMedCap = 512;     // ... by the medium path: exact selection among the query's own survivors
