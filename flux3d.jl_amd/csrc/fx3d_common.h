@@ -93,7 +93,7 @@ enum Opt {
     OPT_MESH_MAX_BLOCKS,      // grid cap of the grid-stride mesh kernels (areas, losses, adjoints), 256-thread blocks; 0 = automatic
     OPT_KNN_ROW_STAGES,       // 1: feature-space kNN exact phase staged by row blocks (rounds 2-3) instead of 16-dimension column slices of the whole cloud
     OPT_EDGE_FSPLIT,          // edge features (mlp layout): features per block of the split feature loop; 0 = automatic (fill the chip), F = one loop
-    OPT_EDGE_NO_NT,           // 1: edge features written with ordinary stores (default: streaming stores for tensors beyond 64 MB)
+    OPT_EDGE_NO_NT,           // 1: edge features written with ordinary stores (default: streaming stores for tensors beyond 192 MB)
     OPT_COUNT
 };
 int opt(Opt o);

@@ -836,7 +836,10 @@ __device__ __forceinline__ void knn_exact_bruteforce(const float *__restrict__ q
 // instruction per KiB and no VGPR round trip -- the producers share their SIMD's issue slots with the
 // consumers' MFMAs, every VALU instruction they do not execute is matrix-core time.
 // knn_gather_kernel with 16-byte elements (F4 = F/4 float4 per row)
-// NT: streaming (non-temporal) stores for tensors beyond the caches (round 4: the F = 64 feature build gained 28 % from them)
+// NT: streaming (non-temporal) stores for tensors beyond the caches (round 4: the F = 64 feature build gained 28 % from them).
+// Only for outputs larger than 3/4 of the 256 MB Infinity Cache: a consumer kernel may still find a smaller tensor there (the
+// 168 MB gather of C4' gains 3 % from streaming stores -- not worth taking that away from its reader).
+constexpr size_t kStreamingStoreBytes = (size_t)192 << 20;
 template <bool NT>
 __global__ __launch_bounds__(kThreads) void knn_gather4_kernel(const float *__restrict__ x, int N, int B, int F4, int k,
                                                                const int32_t *__restrict__ idx, float *__restrict__ out) {
@@ -4337,7 +4340,7 @@ fx3d_status fx3d_knn_gather(const float *x, int32_t N, int32_t B, int32_t F, int
         long long g4 = (total4 + kThreads - 1) / kThreads;
         if (g4 > 16384) g4 = 16384;
         ProfileScope prof4("knn_gather", as_stream(s));
-        if ((size_t)F * k * N * B * 4 > ((size_t)64 << 20) && !opt(OPT_EDGE_NO_NT))
+        if ((size_t)F * k * N * B * 4 > kStreamingStoreBytes && !opt(OPT_EDGE_NO_NT))
             hipLaunchKernelGGL(knn_gather4_kernel<true>, dim3((unsigned)g4), dim3(kThreads), 0, as_stream(s), x, N, B, F / 4, k, idx, out);
         else
             hipLaunchKernelGGL(knn_gather4_kernel<false>, dim3((unsigned)g4), dim3(kThreads), 0, as_stream(s), x, N, B, F / 4, k, idx, out);
@@ -4379,7 +4382,7 @@ fx3d_status fx3d_edge_features(const float *x, int32_t N, int32_t B, int32_t F, 
             else
                 while (fper > 4 && gx * B * ((F + fper - 1) / fper) < 16ll * device_cus()) fper = (fper / 2 + 3) / 4 * 4;
             const unsigned gz = (unsigned)((F + fper - 1) / fper);
-            const bool nt = (size_t)2 * F * KN * B * 4 > ((size_t)64 << 20) && !opt(OPT_EDGE_NO_NT);  // (small tensors may be read back from the caches)
+            const bool nt = (size_t)2 * F * KN * B * 4 > kStreamingStoreBytes && !opt(OPT_EDGE_NO_NT);  // (smaller tensors may be read back from the caches)
             if (nt)
                 hipLaunchKernelGGL(edge_features_mlp4_kernel<true>, dim3((unsigned)gx, B, gz), dim3(kThreads), 0, as_stream(s), x, N, B, F, k, idx, out, fper);
             else
