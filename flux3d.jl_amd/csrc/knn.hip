@@ -3150,10 +3150,14 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
             }
             thr = tau + 2.0f * eps;  // NaN / inf => slow path below
             // (round 4) phase B starts the accumulators at n_c - thr instead of n_c and keeps the SIGN of the result (one v_alignbit per
-            // row where the compare cost v_cmp + v_cndmask + v_or and two wait states): the first operand of the accumulation is
-            // rounded once more, |n_c - thr| <= n_c + |thr| -- 2^-21 (c2 + qn + |thr|) covers it four times over, and makes the test
-            // strict (a candidate at the threshold has a negative result, never -0 / +0)
-            thr = thr + 0x1p-21f * ((c2 + qn) + fabsf(thr));
+            // row where the compare cost v_cmp + v_cndmask + v_or and two wait states).  The accumulation now carries thr through its
+            // D + 1 roundings: against the compare form the result moves by at most (D + 1) u (2 n_c + |thr| + 2 sum |products|)
+            // (65 u (4 n_c + 2 qn + |thr|) at D = 64), u = 2^-24.  The candidate's and the query's own shares sit inside the budget the
+            // filter already grants them (8 (4 D + 8) u = 2112 u each at D = 64, of which the compare form uses ~130 u); the threshold's share,
+            // (K + 1) u |thr| with K = D products (3 D for the split filter), is added here four times over -- at D = 64 2^-16 |thr|,
+            // 1/64 of the band of a candidate at the boundary (its norm is of the threshold's size) -- and it makes the test strict
+            // (a candidate at the threshold gives a negative result, never +-0).
+            thr = thr + (4.0f * (float)((SPLIT ? 3 : 1) * D + 1) * 0x1p-24f) * (fabsf(thr) + qn);
         }
     }
     KNN_PROBE_MARK(20);
