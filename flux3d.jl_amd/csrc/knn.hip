@@ -2904,6 +2904,10 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) accs[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ops[q][bb], ah[bb], accs[q], 0, 0, 0);
                             }
+                            // (round 4) the fold / mask work runs at raised wave priority: the pair's other wave is then the one whose MFMAs are
+                            // in the pipe while this one issues VALU -- same-box A/B 51.95 -> 50.7 us (the reverse, priority on the MFMA block, costs
+                            // 12 us: the issuing wave hogs the slots its partner's fold needs; static priorities by wave role: no effect)
+                            __builtin_amdgcn_s_setprio(1);
                             if (!PHB) {
                                 // (any partition of the tiles into the 32 groups of a lane will do; the two accumulators issued last are
                                 //  read 20+ issue slots after their MFMAs: knn_f16_d3_kernel's order)
@@ -2927,6 +2931,7 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
                                     totb += __builtin_popcount(m);
                                 }
                             }
+                            __builtin_amdgcn_s_setprio(0);
                         }
                     };
                     if (phase == 0) run4(std::false_type{});
