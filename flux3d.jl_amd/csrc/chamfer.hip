@@ -734,10 +734,16 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 ka = vmin(ka, key);                                                                                  \
                 ++lt;                                                                                                \
             }
-            // one step: issue the next block into ISSUE, fold FOLD (issued two steps ago); an odd fold closes its lane tile
+            // one step: issue the next block into ISSUE, fold FOLD (issued two steps ago); an odd fold closes its lane tile.
+            // (round 4) The fold and the tracking run at raised wave priority, the MFMA issue at the base one: among the four
+            // waves of a SIMD the ones with VALU work go first and the matrix pipe drains the others' MFMAs underneath
+            // (same-box A/B, three variants: bench.py 52.3 -> 51.6 us per step, kernel -1.0 ... -1.5 us; priority on the MFMA
+            // issue instead is what costs: knn.hip)
 #define NN1_STEP(ISSUE, FOLD, ODD, OFF)                                                                              \
+            __builtin_amdgcn_s_setprio(0);                                                                           \
             ISSUE = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, bq, zero, 0, 0, 0);                                   \
             an = pa[(OFF) * 64];                                                                                     \
+            __builtin_amdgcn_s_setprio(1);                                                                           \
             NN1_FOLD(FOLD, !(ODD))                                                                                   \
             if (ODD) NN1_TRACK()
             int nb = 2;                        // next block to issue (even); blocks nb - 2, nb - 1 are in acc0, acc1
@@ -759,6 +765,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
 #undef NN1_STEP
 #undef NN1_TRACK
 #undef NN1_FOLD
+            __builtin_amdgcn_s_setprio(0);
             const float ft[kHFifo] = {ka, kb, kc};
             // this lane's smallest tile minimum is <= best (an upper bound of it: the key of the smallest VALUE is >= ka)
             const float best = __builtin_fmaf(fabsf(ka), kKeyUp, ka);
