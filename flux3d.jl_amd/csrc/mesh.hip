@@ -181,17 +181,69 @@ __device__ __forceinline__ void lap_row(const float *__restrict__ verts,
     }
 }
 
+// The same row with its (weight, column) entries taken from a WAVE-staged copy in LDS (round 4): the 64 rows of a wave are one
+// contiguous run of the CSR arrays, which the wave copies with coalesced loads (every byte of the two streams crosses the L1
+// once); a thread per row reading its own entries from memory has lanes ~28 bytes apart, eight partially used lines per load.
+// Same operations in the same order as lap_row.
+constexpr int kLapStage = 1024;  // entries a wave stages (64 rows of a closed mesh hold ~450); longer runs read memory directly
+__device__ __forceinline__ void lap_row_lds(const float *__restrict__ verts, const float *w_s, const int *c_s, int k0, int k1,
+                                            float &s0, float &s1, float &s2) {
+    s0 = 0.0f; s1 = 0.0f; s2 = 0.0f;
+    for (; k0 < k1; k0 += 8) {
+        float w[8];
+        int col[8];
+        P3 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e < k1 ? k0 + e : k1 - 1;
+            w[e] = w_s[k];
+            col[e] = c_s[k];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const P3 *>(verts + 3ll * col[e]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (k0 + e < k1) {
+                s0 = s0 + w[e] * v[e].x;
+                s1 = s1 + w[e] * v[e].y;
+                s2 = s2 + w[e] * v[e].z;
+            }
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void laplacian_loss_kernel(
     const float *__restrict__ verts, long long V, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ colind, const float *__restrict__ vals,
     double *__restrict__ partials, unsigned int *ticket, float *__restrict__ loss) {
     __shared__ double sm[kThreads / 64];
+    __shared__ float w_stage[(kThreads / 64) * kLapStage];
+    __shared__ int c_stage[(kThreads / 64) * kLapStage];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *w_s = w_stage + wv * kLapStage;
+    int *c_s = c_stage + wv * kLapStage;
     double acc = 0.0;
-    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < V;
-         i += (long long)gridDim.x * kThreads) {
+    for (long long ib = (long long)blockIdx.x * kThreads + wv * 64; ib < V; ib += (long long)gridDim.x * kThreads) {  // (wave-uniform)
+        const long long i = ib + lane;
+        const bool ok = i < V;
+        const int k0 = rowptr[ok ? i : V], k1 = ok ? rowptr[i + 1] : k0;
+        const int k_lo = __builtin_amdgcn_readfirstlane(k0), k_hi = __builtin_amdgcn_readlane(k1, 63);
+        const int nent = k_hi - k_lo;
         float s0, s1, s2;
-        lap_row(verts, rowptr, colind, vals, i, s0, s1, s2);
-        acc += (double)sqrtf(((s0 * s0) + (s1 * s1)) + (s2 * s2));
+        if (nent <= kLapStage) {
+            for (int e = lane; e < nent; e += 64) {
+                w_s[e] = vals[k_lo + e];
+                c_s[e] = colind[k_lo + e];
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            lap_row_lds(verts, w_s, c_s, k0 - k_lo, k1 - k_lo, s0, s1, s2);
+            __builtin_amdgcn_wave_barrier();
+        } else if (ok) {
+            lap_row(verts, rowptr, colind, vals, i, s0, s1, s2);
+        } else {
+            s0 = s1 = s2 = 0.0f;
+        }
+        if (ok) acc += (double)sqrtf(((s0 * s0) + (s1 * s1)) + (s2 * s2));
     }
     const double tot = block_sum<kThreads>(acc, sm);
     mean_finalize_last_block(tot, partials, ticket, (double)V, loss, sm);
@@ -336,20 +388,43 @@ __global__ __launch_bounds__(kThreads) void mesh_losses_kernel(
     float4 *__restrict__ u_out) {
     __shared__ double sm[kThreads / 64];
     __shared__ int is_last;
+    __shared__ float w_stage[(kThreads / 64) * kLapStage];
+    __shared__ int c_stage[(kThreads / 64) * kLapStage];
     double acc = 0.0;
     const int blk = blockIdx.x;
     if (blk < gV) {
-        for (long long i = (long long)blk * kThreads + threadIdx.x; i < V; i += (long long)gV * kThreads) {
-            float s0, s1, s2;
-            lap_row(verts, rowptr, colind, vals, i, s0, s1, s2);
-            const float nrm = sqrtf(((s0 * s0) + (s1 * s1)) + (s2 * s2));
-            acc += (double)nrm;
-            if (u_out) {
-                const int k0 = rowptr[i], k1 = rowptr[i + 1];
-                float invdeg = 0.0f;  // any off-diagonal value of the row (all equal 1/deg(i)); 0 for an isolated vertex
+        // (round 4) the rows of a wave from its staged copy of the CSR run: laplacian_loss_kernel
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        float *w_s = w_stage + wv * kLapStage;
+        int *c_s = c_stage + wv * kLapStage;
+        for (long long ib = (long long)blk * kThreads + wv * 64; ib < V; ib += (long long)gV * kThreads) {  // (wave-uniform)
+            const long long i = ib + lane;
+            const bool okr = i < V;
+            const int k0 = rowptr[okr ? i : V], k1 = okr ? rowptr[i + 1] : k0;
+            const int k_lo = __builtin_amdgcn_readfirstlane(k0), k_hi = __builtin_amdgcn_readlane(k1, 63);
+            const int nent = k_hi - k_lo;
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, invdeg = 0.0f;  // invdeg: any off-diagonal value of the row (all equal 1/deg(i)); 0 for an isolated vertex
+            if (nent <= kLapStage) {
+                for (int e = lane; e < nent; e += 64) {
+                    w_s[e] = vals[k_lo + e];
+                    c_s[e] = colind[k_lo + e];
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                lap_row_lds(verts, w_s, c_s, k0 - k_lo, k1 - k_lo, s0, s1, s2);
+                if (k1 - k0 >= 2) invdeg = c_s[k0 - k_lo] == (int)i ? w_s[k0 - k_lo + 1] : w_s[k0 - k_lo];
+                __builtin_amdgcn_wave_barrier();
+            } else if (okr) {
+                lap_row(verts, rowptr, colind, vals, i, s0, s1, s2);
                 if (k1 - k0 >= 2) invdeg = colind[k0] == (int)i ? vals[k0 + 1] : vals[k0];
-                const bool ok = nrm > 0.0f;
-                u_out[i] = float4{ok ? s0 / nrm : 0.0f, ok ? s1 / nrm : 0.0f, ok ? s2 / nrm : 0.0f, invdeg};
+            }
+            if (okr) {
+                const float nrm = sqrtf(((s0 * s0) + (s1 * s1)) + (s2 * s2));
+                acc += (double)nrm;
+                if (u_out) {
+                    const bool ok = nrm > 0.0f;
+                    u_out[i] = float4{ok ? s0 / nrm : 0.0f, ok ? s1 / nrm : 0.0f, ok ? s2 / nrm : 0.0f, invdeg};
+                }
             }
         }
     } else {
