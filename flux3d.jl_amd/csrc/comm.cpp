@@ -102,7 +102,7 @@ constexpr int kNcclSum = 0, kNcclMax = 2, kNcclFloat64 = 8;  // rccl.h: ncclSum 
 //                      -> {magic, id}; a connection that does not speak it (a port scanner, a health probe, a peer of
 //                      another job: wrong token / nranks) is dropped and rank 0 keeps accepting; a rank that connects twice
 //                      is served again but counted once.  The token is FX3D_COMM_TOKEN (any string the launcher exports to
-//                      all ranks), 0 without it.
+//                      all ranks; the only real isolation), a hash of "port:nranks" without it.
 //   "file://path"      single node.  Rank 0 removes whatever an earlier job left at `path` / `path.<r>`, writes
 //                      {magic, nonce, wall-clock, nranks, id} to a fresh temp file (O_EXCL | O_NOFOLLOW, 0600) and renames it
 //                      to `path`; the others poll for `path`, refuse payloads older than kStaleS or for another world
@@ -119,11 +119,13 @@ struct Hello { uint64_t magic, token; int32_t nranks, rank; };
 struct FilePayload { uint64_t magic, nonce; int64_t wall; int32_t nranks, pad; uint8_t id[128]; };
 
 uint64_t job_token(const std::string &host, int port, int nranks) {
-    // FNV-1a of FX3D_COMM_TOKEN when the job exports one; otherwise of "host:port:nranks" -- every rank of a job derives the
-    // same value from its rendezvous string, and a peer of another job (another port or world size) or a stray client
-    // that only knows the magic is refused (token 0 handed the unique id to anybody)
+    // FNV-1a of FX3D_COMM_TOKEN when the job exports one -- the ONLY form that isolates a job from a peer that can reach the
+    // port; otherwise of "port:nranks": every rank derives it from its rendezvous string and it only keeps ACCIDENTAL cross-job
+    // connections out (another port or world size; anybody can compute it).  The host spelling is NOT hashed: ranks may name
+    // one endpoint differently (0.0.0.0 / a hostname on rank 0, MASTER_ADDR elsewhere) and must still agree.
+    (void)host;
     const char *e = getenv("FX3D_COMM_TOKEN");
-    const std::string dflt = host + ":" + std::to_string(port) + ":" + std::to_string(nranks);
+    const std::string dflt = std::to_string(port) + ":" + std::to_string(nranks);
     const char *src = (e && *e) ? e : dflt.c_str();
     uint64_t h = 1469598103934665603ull;
     for (; *src; ++src) { h ^= (unsigned char)*src; h *= 1099511628211ull; }
@@ -228,7 +230,8 @@ fx3d_status boot_tcp(const std::string &host, int port, int nranks, int rank, ui
         std::this_thread::sleep_for(std::chrono::milliseconds(50));  // rank 0 is not listening yet (or refused us: another job's port)
     }
     ::freeaddrinfo(res);
-    if (rc != FX3D_OK) set_error("fx3d_comm_exchange_id: rank %d could not reach rank 0 at %s:%d within %d s", rank, host.c_str(), port, kBootTimeoutS);
+    if (rc != FX3D_OK) set_error("fx3d_comm_exchange_id: rank %d could not reach rank 0 at %s:%d within %d s (refused or unreachable: every rank must "
+                                 "use the same port, world size and FX3D_COMM_TOKEN -- the token is the only real isolation between jobs)", rank, host.c_str(), port, kBootTimeoutS);
     return rc;
 }
 

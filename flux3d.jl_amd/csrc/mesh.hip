@@ -814,19 +814,24 @@ fx3d_status fx3d_mesh_losses_bwd(const float *verts, int64_t V, const int32_t *r
     if (!ws || ws_bytes < need) { set_error("fx3d_mesh_losses_bwd: workspace too small (%zu < %zu bytes)", ws ? ws_bytes : (size_t)0, need); return FX3D_ERR_WORKSPACE; }
     hipStream_t st = as_stream(s);
     float4 *u = reinterpret_cast<float4 *>(reinterpret_cast<double *>(ws) + 2 * kMaxBlocks);
+    if (g_lap == 0.0f && g_edge == 0.0f) {  // both terms dropped: the gradient is exactly zero; never read the (possibly unbuilt) unit rows
+        if (!accumulate) FX3D_HIP(hipMemsetAsync(gverts, 0, sizeof(float) * 3 * (size_t)V, st));
+        return FX3D_OK;
+    }
     if (!reuse_forward && g_lap != 0.0f) {  // no fx3d_mesh_losses on the same vertices and workspace before this call: build the unit rows
         hipLaunchKernelGGL(lap_unit_rows_kernel, dim3(grid_for(V)), dim3(kThreads), 0, st, verts, (long long)V, rowptr, colind, vals, u);
         FX3D_LAUNCH_CHECK();
     }
     ProfileScope prof("mesh_losses_bwd", st);
     // (a weight of exactly zero drops its term: the Laplacian adjoint alone is how the wrappers differentiate laplacian_loss on
-    // LARGE meshes -- the scratch-free fx3d_laplacian_loss_bwd_sym recomputes every neighbour's row, 7 x the traffic)
-    if (g_edge == 0.0f)
-        hipLaunchKernelGGL((mesh_losses_bwd_gather_kernel<true, false>), dim3(grid_for(V)), dim3(kThreads), 0, st, verts, (long long)V,
-                           rowptr, colind, u, g_lap / (float)V, 0.0f, target, gverts, accumulate);
-    else if (g_lap == 0.0f)
+    // LARGE meshes -- the scratch-free fx3d_laplacian_loss_bwd_sym recomputes every neighbour's row, 7 x the traffic).
+    // g_lap == 0 is tested FIRST: that instantiation never touches u, which is unbuilt in exactly that case.
+    if (g_lap == 0.0f)
         hipLaunchKernelGGL((mesh_losses_bwd_gather_kernel<false, true>), dim3(grid_for(V)), dim3(kThreads), 0, st, verts, (long long)V,
                            rowptr, colind, u, 0.0f, g_edge / (float)E, target, gverts, accumulate);
+    else if (g_edge == 0.0f)
+        hipLaunchKernelGGL((mesh_losses_bwd_gather_kernel<true, false>), dim3(grid_for(V)), dim3(kThreads), 0, st, verts, (long long)V,
+                           rowptr, colind, u, g_lap / (float)V, 0.0f, target, gverts, accumulate);
     else
         hipLaunchKernelGGL((mesh_losses_bwd_gather_kernel<true, true>), dim3(grid_for(V)), dim3(kThreads), 0, st, verts, (long long)V,
                            rowptr, colind, u, g_lap / (float)V, g_edge / (float)E, target, gverts, accumulate);

@@ -2,6 +2,7 @@
 // Replaces what the reference gets from CUDA.jl + Flux's gpu/cpu functor walkers
 // (src/Flux3D.jl:52-61, src/rep/pcloud.jl:57, src/rep/mesh.jl:189-190).
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -25,31 +26,31 @@ void set_error(const char *fmt, ...) {
 
 // ---- variant switches ---------------------------------------------------------------------------
 namespace {
-struct OptDef { const char *name, *env; int dflt; };
+struct OptDef { const char *name, *env; int dflt; bool valued; };  // valued: an integer, not an on/off switch
 // (order = enum Opt)
 const OptDef kOptDefs[OPT_COUNT] = {
-    {"nn1_variant", "FX3D_NN1_VARIANT", 3},
-    {"nn1_tpb", "FX3D_NN1_TPB", 0},
-    {"nn1_nosplit", "FX3D_NN1_NOSPLIT", 0},
-    {"bwd_global_atomics", "FX3D_BWD_GLOBAL_ATOMICS", 0},
-    {"knn_f32", "FX3D_KNN_F32", 0},
-    {"knn_f16_split", "FX3D_KNN_F16_SPLIT", 0},
-    {"knn_no_mfma", "FX3D_KNN_NO_MFMA", 0},
-    {"knn_no_prepass", "FX3D_KNN_NO_PREPASS", 0},
-    {"knn_gather", "FX3D_KNN_GATHER", 0},
-    {"knn_d3_wave", "FX3D_KNN_D3_WAVE", 0},
-    {"knn_d3_no_compact", "FX3D_KNN_D3_NO_COMPACT", 0},
-    {"knn_direct_lds", "FX3D_KNN_DIRECT_LDS", 0},
-    {"knn_slices", "FX3D_KNN_SLICES", 0},
-    {"edge_scalar_stores", "FX3D_EDGE_SCALAR_STORES", 0},
-    {"edgeconv_unfused", "FX3D_EDGECONV_UNFUSED", 0},
-    {"lap_bwd_scatter", "FX3D_LAP_BWD_SCATTER", 0},
-    {"cdf_multiblock_from", "FX3D_CDF_MULTIBLOCK_FROM", 0},
-    {"nn1_tiny_mpairs", "FX3D_NN1_TINY_MPAIRS", 24},
-    {"mesh_max_blocks", "FX3D_MESH_MAX_BLOCKS", 0},
-    {"knn_row_stages", "FX3D_KNN_ROW_STAGES", 0},
-    {"edge_fsplit", "FX3D_EDGE_FSPLIT", 0},
-    {"edge_no_nt", "FX3D_EDGE_NO_NT", 0},
+    {"nn1_variant", "FX3D_NN1_VARIANT", 3, true},
+    {"nn1_tpb", "FX3D_NN1_TPB", 0, true},
+    {"nn1_nosplit", "FX3D_NN1_NOSPLIT", 0, false},
+    {"bwd_global_atomics", "FX3D_BWD_GLOBAL_ATOMICS", 0, false},
+    {"knn_f32", "FX3D_KNN_F32", 0, false},
+    {"knn_f16_split", "FX3D_KNN_F16_SPLIT", 0, false},
+    {"knn_no_mfma", "FX3D_KNN_NO_MFMA", 0, false},
+    {"knn_no_prepass", "FX3D_KNN_NO_PREPASS", 0, false},
+    {"knn_gather", "FX3D_KNN_GATHER", 0, false},
+    {"knn_d3_wave", "FX3D_KNN_D3_WAVE", 0, false},
+    {"knn_d3_no_compact", "FX3D_KNN_D3_NO_COMPACT", 0, false},
+    {"knn_direct_lds", "FX3D_KNN_DIRECT_LDS", 0, false},
+    {"knn_slices", "FX3D_KNN_SLICES", 0, true},
+    {"edge_scalar_stores", "FX3D_EDGE_SCALAR_STORES", 0, false},
+    {"edgeconv_unfused", "FX3D_EDGECONV_UNFUSED", 0, false},
+    {"lap_bwd_scatter", "FX3D_LAP_BWD_SCATTER", 0, false},
+    {"cdf_multiblock_from", "FX3D_CDF_MULTIBLOCK_FROM", 0, true},
+    {"nn1_tiny_mpairs", "FX3D_NN1_TINY_MPAIRS", 24, true},
+    {"mesh_max_blocks", "FX3D_MESH_MAX_BLOCKS", 0, true},
+    {"knn_row_stages", "FX3D_KNN_ROW_STAGES", 0, false},
+    {"edge_fsplit", "FX3D_EDGE_FSPLIT", 0, true},
+    {"edge_no_nt", "FX3D_EDGE_NO_NT", 0, false},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::once_flag g_opt_once;
@@ -58,11 +59,14 @@ void opt_init() {
         for (int i = 0; i < OPT_COUNT; ++i) {
             const char *e = getenv(kOptDefs[i].env);  // the environment seeds the defaults, once (read-once: INTEGRATION.md)
             int v = kOptDefs[i].dflt;
-            if (e) {  // a switch that is SET counts as on unless it parses as a number: FX3D_KNN_NO_MFMA=yes and an empty value mean 1
+            if (e && *e) {  // an EMPTY value is "unset" (scripts neutralise a switch with FX3D_X=): the default stands
                 char *end = nullptr;
                 const long n = strtol(e, &end, 10);
                 while (end && (*end == ' ' || *end == '\t')) ++end;
-                v = (end == e || (end && *end)) ? 1 : (int)n;
+                const bool numeric = end != e && !(end && *end);
+                if (numeric) v = (int)n;
+                else if (!kOptDefs[i].valued) v = 1;  // on/off switch set to a word (FX3D_KNN_NO_MFMA=yes): on
+                else fprintf(stderr, "flux3d_hip: %s=\"%s\" is not an integer; keeping the default %d\n", kOptDefs[i].env, e, v);
             }
             g_opt[i].store(v, std::memory_order_relaxed);
         }

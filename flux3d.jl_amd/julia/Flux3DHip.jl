@@ -312,38 +312,49 @@ end
 _chamfer_distance(A::HipArray{Float32,3}, B::HipArray{Float32,3}, w1::Float32 = 1.0f0, w2::Float32 = 1.0f0) =
     _chamfer_fwd(A, B, w1, w2)[1]
 
-# adjoint: indices are constants (`@ignore`, :45); the scatter-add runs on the device
-Zygote.@adjoint function _chamfer_distance(A::HipArray{Float32,3}, B::HipArray{Float32,3}, w1::Float32, w2::Float32)
-    loss, ix, iy = _chamfer_fwd(A, B, w1, w2; indices = true)
-    function back(g)
-        D, N, Bn = size(A); _, M, _ = size(B)
-        gA = HipArray{Float32}(undef, D, N, Bn); gB = HipArray{Float32}(undef, D, M, Bn)
-        check(@ccall LIB.fx3d_chamfer_bwd(A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32, Bn::Int32, D::Int32,
-                                          ix.ptr::Ptr{Cvoid}, iy.ptr::Ptr{Cvoid}, w1::Float32, w2::Float32,
-                                          Float32(g)::Float32, Bn::Int64, gA.ptr::Ptr{Cvoid}, gB.ptr::Ptr{Cvoid},
-                                          DEFAULT_STREAM::Stream)::Int32)
-        return (gA, gB, nothing, nothing)
-    end
-    return loss, back
-end
-
-# value and gradient in ONE ABI call (`Zygote.withgradient(chamfer_distance, A, B)`; what benchmarks/metrics.jl:24-38 times as
-# "total" and examples/fit_mesh.jl:106-110 runs per iteration): forward with indices + adjoint queued back to back, the
-# indices stay in the scratch.  Returns (loss, gA, gB).
+# value and gradient in ONE ABI call (what `Zygote.withgradient(chamfer_distance, A, B)` runs through the adjoint below; what
+# benchmarks/metrics.jl:24-38 times as "total" and examples/fit_mesh.jl:106-110 runs per iteration): forward with indices +
+# adjoint queued back to back.  Returns (loss, gA, gB, ix, iy); ix / iy are `nothing` unless `indices` (they then stay in the
+# scratch).  `B_global`: the batch size the mean divides by (a shard of a larger batch passes the global one; default Bn).
+# `out = (gA, gB)`: caller-owned gradient arrays, overwritten.
 function chamfer_value_and_grad(A::HipArray{Float32,3}, B::HipArray{Float32,3}, w1::Float32 = 1.0f0, w2::Float32 = 1.0f0;
-                                gout::Float32 = 1.0f0)
+                                gout::Float32 = 1.0f0, B_global::Integer = size(A, 3), out = nothing, indices::Bool = false)
     D, N, Bn = size(A); _, M, _ = size(B)
     nb = Ref{Csize_t}(0)
     check(@ccall LIB.fx3d_chamfer_fwd_bwd_workspace_bytes(N::Int32, M::Int32, Bn::Int32, D::Int32, nb::Ref{Csize_t})::Int32)
     ws = workspace(nb[])
     loss_dev = HipArray{Float32}(undef, 1); loss = Ref{Float32}(0)
-    gA = HipArray{Float32}(undef, D, N, Bn); gB = HipArray{Float32}(undef, D, M, Bn)
+    gA = out === nothing ? HipArray{Float32}(undef, D, N, Bn) : out[1]
+    gB = out === nothing ? HipArray{Float32}(undef, D, M, Bn) : out[2]
+    size(gA) == (D, N, Bn) && size(gB) == (D, M, Bn) || throw(DimensionMismatch("chamfer_value_and_grad: out = (gA, gB) must match A and B"))
+    ix = indices ? HipArray{Int32}(undef, N, Bn) : nothing
+    iy = indices ? HipArray{Int32}(undef, M, Bn) : nothing
     check(@ccall LIB.fx3d_chamfer_fwd_bwd(A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32, Bn::Int32, D::Int32,
-                                          w1::Float32, w2::Float32, gout::Float32, Bn::Int64, loss_dev.ptr::Ptr{Cvoid},
-                                          loss::Ref{Float32}, gA.ptr::Ptr{Cvoid}, gB.ptr::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
-                                          C_NULL::Ptr{Cvoid}, ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t,
+                                          w1::Float32, w2::Float32, gout::Float32, Int64(B_global)::Int64, loss_dev.ptr::Ptr{Cvoid},
+                                          loss::Ref{Float32}, gA.ptr::Ptr{Cvoid}, gB.ptr::Ptr{Cvoid},
+                                          (indices ? ix.ptr : C_NULL)::Ptr{Cvoid}, (indices ? iy.ptr : C_NULL)::Ptr{Cvoid},
+                                          ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t, DEFAULT_STREAM::Stream)::Int32)
+    return loss[], gA, gB, ix, iy
+end
+
+# adjoint: indices are constants (`@ignore`, :45).  Zygote calls this method only when a gradient is wanted, so the forward
+# already runs the fused value + gradient call with a cotangent of 1 -- `gradient(() -> chamfer_distance(A, B), ...)` and
+# `withgradient` are ONE ABI call (ADVICE r4) -- and the pullback hands those arrays out when the incoming cotangent is
+# exactly 1 (a plain gradient, the chamfer term of fit_mesh's weighted sum).  Any other cotangent re-runs the adjoint kernel
+# with it on the kept indices: the same bits as the two-call form, never a rescaling of the unit gradient.
+Zygote.@adjoint function _chamfer_distance(A::HipArray{Float32,3}, B::HipArray{Float32,3}, w1::Float32, w2::Float32)
+    loss, gA, gB, ix, iy = chamfer_value_and_grad(A, B, w1, w2; indices = true)
+    function back(g)
+        Float32(g) == 1.0f0 && return (gA, gB, nothing, nothing)
+        D, N, Bn = size(A); _, M, _ = size(B)
+        hA = HipArray{Float32}(undef, D, N, Bn); hB = HipArray{Float32}(undef, D, M, Bn)
+        check(@ccall LIB.fx3d_chamfer_bwd(A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32, Bn::Int32, D::Int32,
+                                          ix.ptr::Ptr{Cvoid}, iy.ptr::Ptr{Cvoid}, w1::Float32, w2::Float32,
+                                          Float32(g)::Float32, Bn::Int64, hA.ptr::Ptr{Cvoid}, hB.ptr::Ptr{Cvoid},
                                           DEFAULT_STREAM::Stream)::Int32)
-    return loss[], gA, gB
+        return (hA, hB, nothing, nothing)
+    end
+    return loss, back
 end
 
 # adjoint of chamfer_distance(m1::TriMesh, m2::TriMesh, n) (src/metrics/mesh.jl:34-44) w.r.t. the padded vertices of m1 and / or

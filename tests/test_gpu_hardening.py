@@ -485,6 +485,56 @@ def test_fused_mesh_losses_degenerate_mesh(gpu_fx, oracle):
     assert lap == fx.laplacian_loss(m) and edge == fx.edge_loss(m)
 
 
+def test_mesh_losses_grad_with_both_weights_zero_never_reads_unbuilt_scratch(gpu_fx):
+    """g_lap == 0 and g_edge == 0 on a FRESH scratch (reuse_forward=False skips the unit-row build when
+    g_lap == 0) used to run the Laplacian-only gather over uninitialised unit rows: 0 * garbage = NaN, poisoning an accumulated
+    gradient.  Now: exact zeros / the accumulator untouched, and g_lap == 0 alone takes the instantiation that never reads u."""
+    fx = gpu_fx
+    m = _mesh_batch(fx, 3)
+    V = m.get_verts_packed_host().shape[1]
+    E = m.get_edges_packed().shape[0]
+    import ctypes as C
+    n = C.c_size_t(0)
+    fx._lib.call("fx3d_mesh_losses_workspace_bytes", int(V), int(E), C.byref(n))
+    nan_bytes = np.frombuffer(np.full((n.value + 3) // 4, np.nan, np.float32).tobytes()[:n.value], np.uint8)
+    m._dev["mesh_fused_ws"] = fx.DeviceArray.from_host(nan_bytes)  # a scratch full of NaN where the unit rows would be
+    g = fx.mesh_losses_grad(m, 0.0, g_lap=0.0, g_edge=0.0).to_host()
+    assert np.array_equal(g, np.zeros_like(g))
+    prev = np.asfortranarray(np.random.default_rng(9).standard_normal(g.shape).astype(np.float32))
+    acc = fx.DeviceArray.from_host(prev)
+    fx.mesh_losses_grad(m, 0.0, g_lap=0.0, g_edge=0.0, out=acc)
+    assert np.array_equal(acc.to_host(), prev)
+    # the edge term alone over the poisoned scratch: finite and equal to the standalone edge adjoint
+    ge = fx.mesh_losses_grad(m, 0.02, g_lap=0.0, g_edge=0.6).to_host()
+    assert np.array_equal(ge, fx.edge_loss_grad(m, 0.02, 0.6).to_host())
+
+
+def test_laplacian_loss_grad_large_mesh_path_is_bit_identical(gpu_fx, oracle):
+    """at V >= 65536 laplacian_loss_grad goes through fx3d_mesh_losses_bwd (unit rows + the <true,false>
+    gather) instead of fx3d_laplacian_loss_bwd_sym.  Same bits as the oracle and as the small-mesh kernel, also with out=."""
+    from flux3d_jl_amd import metrics as fxm
+    fx = gpu_fx
+    v, f = _grid_mesh(260, 260, 4)  # 261 x 261 = 68 121 vertices
+    assert v.shape[1] >= fxm._LAP_BWD_TWO_PASS_FROM
+    m = fx.gpu(fx.TriMesh([v], [f]))
+    rp, ci, va = m.get_laplacian_packed()
+    ol = oracle.laplacian_loss_bwd(v, rp.astype(np.int64), ci.astype(np.int64), va, 0.7)
+    g_large = fx.laplacian_loss_grad(m, 0.7).to_host()
+    assert np.array_equal(g_large, ol)
+    import ctypes as C  # the small-mesh kernel on the same mesh
+    g_sym = fx.DeviceArray.empty(v.shape, np.float32)
+    fx._lib.call("fx3d_laplacian_loss_bwd_sym", m.dev("verts_packed").ptr, v.shape[1], m.dev("lap_rowptr").ptr,
+                 m.dev("lap_colind").ptr, m.dev("lap_vals").ptr, 0.7, g_sym.ptr, 0, None, fx.current_stream().handle)
+    assert np.array_equal(g_sym.to_host(), ol)
+    prev = np.asfortranarray(np.random.default_rng(6).standard_normal(v.shape).astype(np.float32))
+    acc = fx.DeviceArray.from_host(prev)
+    fx.laplacian_loss_grad(m, 0.7, out=acc)
+    assert np.array_equal(acc.to_host(), (prev + ol).astype(np.float32))
+    # the edge term alone on the large mesh (<false,true>) against the oracle
+    e0 = m.get_edges_packed().astype(np.int64) - 1
+    assert np.array_equal(fx.mesh_losses_grad(m, 0.1, g_lap=0.0, g_edge=1.0).to_host(), oracle.edge_loss_bwd(v, e0, 0.1, 1.0))
+
+
 # ------------------------------------------------------------------------------ far outliers: the side list
 @pytest.mark.parametrize("nout,fac", [(1, 1e3), (1, 1e5), (1, 1e7), (5, 1e4), (64, 1e5), (70, 1e5), (300, 1e6)])
 def test_far_outliers_take_the_exact_side_list(gpu_fx, oracle, nout, fac):
