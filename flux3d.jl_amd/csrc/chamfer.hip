@@ -1306,40 +1306,6 @@ __global__ void chamfer_loss_many_kernel(const double *sums, int count, int N, i
     if (i < count) loss[i] = chamfer_loss_from_sums(sums[2 * i], sums[2 * i + 1], N, M, D, Bg, w1, w2);
 }
 
-// Backward (adjoint of the two gathers at :47-48), two ordered passes:
-//   own pass     : gx[i] = ca (x_i - y[ix[i]]),  gy[j] = cb (y_j - x[iy[j]])        plain coalesced stores
-//   scatter pass : gy[ix[i]] -= ca (x_i - y[ix[i]]),  gx[iy[j]] -= cb (y_j - x[iy[j]])   float atomics
-// (no memset, half the atomics of a single all-atomic pass).
-template <bool SCATTER>
-__global__ __launch_bounds__(kThreads) void chamfer_bwd_kernel(
-    const float *__restrict__ x, int N, const float *__restrict__ y, int M, int B, int D,
-    const int32_t *__restrict__ idx_x, const int32_t *__restrict__ idx_y, float ca, float cb,
-    float *gx, float *gy) {
-    const long long total = (long long)B * (N + M);
-    for (long long k = (long long)blockIdx.x * kThreads + threadIdx.x; k < total;
-         k += (long long)gridDim.x * kThreads) {
-        const int b = (int)(k / (N + M));
-        const int r = (int)(k % (N + M));
-        const float *xb = x + (size_t)b * N * D, *yb = y + (size_t)b * M * D;
-        float *gxb = gx + (size_t)b * N * D, *gyb = gy + (size_t)b * M * D;
-        if (r < N) {
-            const int i = r, j = idx_x[(size_t)b * N + i];
-            for (int d = 0; d < D; ++d) {
-                const float t = ca * (xb[(size_t)i * D + d] - yb[(size_t)j * D + d]);
-                if (SCATTER) atomicAdd(&gyb[(size_t)j * D + d], -t);
-                else gxb[(size_t)i * D + d] = t;
-            }
-        } else {
-            const int j = r - N, i = idx_y[(size_t)b * M + j];
-            for (int d = 0; d < D; ++d) {
-                const float t = cb * (yb[(size_t)j * D + d] - xb[(size_t)i * D + d]);
-                if (SCATTER) atomicAdd(&gxb[(size_t)i * D + d], -t);
-                else gyb[(size_t)j * D + d] = t;
-            }
-        }
-    }
-}
-
 struct Plan {
     int R, tiles_x, tiles_y, tiles, chunk, grid;
     size_t lds_bytes;
@@ -1684,6 +1650,14 @@ fx3d_status fx3d_chamfer_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_
 }
 
 
+}  // extern "C"
+
+namespace fx3d {
+fx3d_status chamfer_check_shapes(const char *fn, const void *x, int N, const void *y, int M, int B, int D) { return check_shapes(fn, x, N, y, M, B, D); }
+}
+
+extern "C" {
+
 static fx3d_status chamfer_common(const float *x, int N, const float *y, int M, int B, int D,
                                   double *sums_dev, float *loss_dev, long long Bg, float w1,
                                   float w2, int32_t *idx_x, int32_t *idx_y, void *ws,
@@ -1743,6 +1717,17 @@ static fx3d_status chamfer_common(const float *x, int N, const float *y, int M, 
     return FX3D_OK;
 }
 
+}  // extern "C"
+
+namespace fx3d {  // the forward driver, for the value-and-gradient entry point in chamfer_bwd.hip
+fx3d_status chamfer_forward(const float *x, int N, const float *y, int M, int B, int D, float *loss_dev, long long Bg, float w1,
+                            float w2, int32_t *idx_x, int32_t *idx_y, void *ws, size_t ws_bytes, hipStream_t st, const char *fn) {
+    return chamfer_common(x, N, y, M, B, D, nullptr, loss_dev, Bg, w1, w2, idx_x, idx_y, ws, ws_bytes, st, fn);
+}
+}
+
+extern "C" {
+
 fx3d_status fx3d_chamfer_sums(const float *x, int32_t N, const float *y, int32_t M, int32_t B,
                               int32_t D, double *sums_dev, int32_t *idx_x, int32_t *idx_y,
                               void *ws, size_t ws_bytes, fx3d_stream_t s) {
@@ -1789,306 +1774,6 @@ fx3d_status fx3d_chamfer_fwd(const float *x, int32_t N, const float *y, int32_t 
 
 }  // extern "C"  (reopened below)
 
-namespace {
-// Adjoint with the accumulator of one (cloud, side) in LDS: block (b, side) owns g[side][b] (R rows x D): direct
-// term of its own rows, then the scatter of the other side's rows through ds_add_f32, one coalesced write.
-// Replaces 3 (N+M) B D global float atomics by LDS atomics (C2: 27 -> 8 us of kernels).
-constexpr int kBwdThreads = 1024;
-template <bool D3>  // D3: D == 3 with 12-byte row loads and four rows in flight (round 4: the one-row-at-a-time loops were latency
-                    // bound -- 1.6 TB/s of algorithmic bytes at B = 256 x 4096; same arithmetic per element)
-__global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_lds_kernel(
-    const float *__restrict__ x, int N, const float *__restrict__ y, int M, int D,
-    const int32_t *__restrict__ idx_x, const int32_t *__restrict__ idx_y, float ca, float cb,
-    float *__restrict__ gx, float *__restrict__ gy, int nsplit) {
-    extern __shared__ __attribute__((aligned(16))) float acc[];  // [rows of this block][D]
-    const int part = blockIdx.x % nsplit, bs = blockIdx.x / nsplit;
-    const int b = bs >> 1, side = bs & 1;                        // side 0: gx, 1: gy
-    const float *own = (side ? y : x) + (size_t)b * (side ? M : N) * D;
-    const float *oth = (side ? x : y) + (size_t)b * (side ? N : M) * D;
-    const int32_t *idx_own = (side ? idx_y : idx_x) + (size_t)b * (side ? M : N);   // own row -> other row
-    const int32_t *idx_oth = (side ? idx_x : idx_y) + (size_t)b * (side ? N : M);   // other row -> own row
-    const int R = side ? M : N, S = side ? N : M;
-    const float c_own = side ? cb : ca, c_oth = side ? ca : cb;
-    // this block owns rows [r0, r1) of g[side][b]; it scans ALL rows of the other side and applies the hits
-    const int per = (R + nsplit - 1) / nsplit;
-    const int r0 = part * per < R ? part * per : R, r1 = r0 + per < R ? r0 + per : R;
-    float *g = (side ? gy : gx) + (size_t)b * R * D;
-    if (D3) {
-        for (int i0 = r0 + threadIdx.x; i0 < r1; i0 += 4 * kBwdThreads) {  // direct term: four rows in flight
-            int jj[4];
-            P3 o[4], w[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * kBwdThreads < r1 ? i0 + u * kBwdThreads : i0;
-                jj[u] = idx_own[i];
-                w[u] = *reinterpret_cast<const P3 *>(own + (size_t)i * 3);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) o[u] = *reinterpret_cast<const P3 *>(oth + (size_t)jj[u] * 3);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * kBwdThreads;
-                if (i < r1) {
-                    float *a = acc + (size_t)(i - r0) * 3;
-                    a[0] = c_own * (w[u].x - o[u].x);
-                    a[1] = c_own * (w[u].y - o[u].y);
-                    a[2] = c_own * (w[u].z - o[u].z);
-                }
-            }
-        }
-        __syncthreads();
-        for (int j0 = threadIdx.x; j0 < S; j0 += 4 * kBwdThreads) {  // scatter: four sweeps' indices in flight, then the hits' rows
-            int ii[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u * kBwdThreads;
-                ii[u] = j < S ? idx_oth[j] : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u * kBwdThreads, i = ii[u];
-                if (i >= r0 && i < r1) {
-                    const P3 o = *reinterpret_cast<const P3 *>(oth + (size_t)j * 3), w = *reinterpret_cast<const P3 *>(own + (size_t)i * 3);
-                    float *a = acc + (size_t)(i - r0) * 3;
-                    atomicAdd(a + 0, -(c_oth * (o.x - w.x)));
-                    atomicAdd(a + 1, -(c_oth * (o.y - w.y)));
-                    atomicAdd(a + 2, -(c_oth * (o.z - w.z)));
-                }
-            }
-        }
-    } else {
-        for (int e = threadIdx.x; e < (r1 - r0) * D; e += kBwdThreads) {
-            const int i = r0 + e / D, d = e % D;
-            acc[e] = c_own * (own[(size_t)i * D + d] - oth[(size_t)idx_own[i] * D + d]);
-        }
-        __syncthreads();
-        for (int j = threadIdx.x; j < S; j += kBwdThreads) {
-            const int i = idx_oth[j];
-            if (i >= r0 && i < r1)
-                for (int d = 0; d < D; ++d) {
-                    const float t = c_oth * (oth[(size_t)j * D + d] - own[(size_t)i * D + d]);
-                    atomicAdd(&acc[(size_t)(i - r0) * D + d], -t);
-                }
-        }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < (r1 - r0) * D; e += kBwdThreads) g[(size_t)r0 * D + e] = acc[e];
-}
-
-// Adjoint of chamfer_distance(sample_points(m_x), sample_points(m_y)) w.r.t. the meshes' vertices in one launch: the gradient
-// w.r.t. the sampled points is accumulated in LDS exactly as in chamfer_bwd_lds_kernel (D = 3), then every row is scattered onto
-// the three vertices of its sampled face with the barycentric weights of the draw (sample_bwd_kernel's arithmetic) instead
-// of being written out.  A side without a mesh gradient (gverts == nullptr) is skipped.
-struct SampledSide {
-    const int32_t *faces;     // (3, Fmax, B) mesh-local
-    const int32_t *face_idx;  // (n, B) the draws
-    const float *r1, *r2;
-    float *gverts;            // (3, Vmax, B), added to
-    int Vmax, Fmax;
-};
-__global__ __launch_bounds__(kBwdThreads) void chamfer_sampled_bwd_kernel(
-    const float *__restrict__ x, int N, const float *__restrict__ y, int M, const int32_t *__restrict__ idx_x,
-    const int32_t *__restrict__ idx_y, float ca, float cb, SampledSide sx, SampledSide sy, int nsplit) {
-    extern __shared__ __attribute__((aligned(16))) float acc[];  // [rows of this block][3]
-    const int part = blockIdx.x % nsplit, bs = blockIdx.x / nsplit;
-    const int b = bs >> 1, side = bs & 1;
-    const SampledSide &S = side ? sy : sx;
-    if (!S.gverts) return;
-    const float *own = (side ? y : x) + (size_t)b * (side ? M : N) * 3;
-    const float *oth = (side ? x : y) + (size_t)b * (side ? N : M) * 3;
-    const int32_t *idx_own = (side ? idx_y : idx_x) + (size_t)b * (side ? M : N);
-    const int32_t *idx_oth = (side ? idx_x : idx_y) + (size_t)b * (side ? N : M);
-    const int R = side ? M : N, Sn = side ? N : M;
-    const float c_own = side ? cb : ca, c_oth = side ? ca : cb;
-    const int per = (R + nsplit - 1) / nsplit;
-    const int r0 = part * per < R ? part * per : R, r1 = r0 + per < R ? r0 + per : R;
-    // the kernel is a chain of dependent round trips (index -> row, draw -> face -> vertices): what does not depend on the
-    // LDS phases is requested first -- the first sweep of the scan's indices and this thread's first epilogue row
-    const int j_first = threadIdx.x < Sn ? idx_oth[threadIdx.x] : -1;
-    const int iE = r0 + threadIdx.x;
-    const size_t kE = (size_t)b * R + (iE < r1 ? iE : (r0 < R ? r0 : 0));
-    const int32_t *fcE = S.faces + ((size_t)b * S.Fmax + S.face_idx[kE]) * 3;
-    const int fE[3] = {fcE[0], fcE[1], fcE[2]};
-    const float r1E = S.r1[kE], r2E = S.r2[kE];
-    for (int e = threadIdx.x; e < (r1 - r0) * 3; e += kBwdThreads) {
-        const int i = r0 + e / 3, d = e % 3;
-        acc[e] = c_own * (own[(size_t)i * 3 + d] - oth[(size_t)idx_own[i] * 3 + d]);
-    }
-    __syncthreads();
-    for (int j0 = threadIdx.x; j0 < Sn; j0 += 4 * kBwdThreads) {  // four sweeps' indices in flight, then the hits' rows
-        int ii[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u * kBwdThreads;
-            ii[u] = j < Sn ? (j == (int)threadIdx.x ? j_first : idx_oth[j]) : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u * kBwdThreads, i = ii[u];
-            if (i >= r0 && i < r1) {
-                const P3 o = *reinterpret_cast<const P3 *>(oth + (size_t)j * 3), w = *reinterpret_cast<const P3 *>(own + (size_t)i * 3);
-                float *a = acc + (size_t)(i - r0) * 3;
-                atomicAdd(a + 0, -(c_oth * (o.x - w.x)));
-                atomicAdd(a + 1, -(c_oth * (o.y - w.y)));
-                atomicAdd(a + 2, -(c_oth * (o.z - w.z)));
-            }
-        }
-    }
-    __syncthreads();
-    float *gb = S.gverts + (size_t)b * S.Vmax * 3;
-    for (int i = iE; i < r1; i += kBwdThreads) {  // row i = sample i of mesh b
-        const size_t k = (size_t)b * R + i;
-        int f3[3] = {fE[0], fE[1], fE[2]};
-        float a1 = r1E, a2 = r2E;
-        if (i != iE) {  // (blocks of more than 1024 rows)
-            const int32_t *fc = S.faces + ((size_t)b * S.Fmax + S.face_idx[k]) * 3;
-            f3[0] = fc[0]; f3[1] = fc[1]; f3[2] = fc[2];
-            a1 = S.r1[k]; a2 = S.r2[k];
-        }
-        const float u = sqrtf(a1), v = a2;
-        const float w[3] = {1.0f - u, u * (1.0f - v), u * v};
-        const float *g = acc + (size_t)(i - r0) * 3;
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int d = 0; d < 3; ++d) atomicAdd(&gb[3ll * f3[t] + d], w[t] * g[d]);
-    }
-}
-}  // namespace
-
-extern "C" {
-
-fx3d_status fx3d_chamfer_bwd(const float *x, int32_t N, const float *y, int32_t M, int32_t B,
-                             int32_t D, const int32_t *idx_x, const int32_t *idx_y, float w1,
-                             float w2, float gout, int64_t B_global, float *gx, float *gy,
-                             fx3d_stream_t s) {
-    fx3d_status rc = check_shapes("fx3d_chamfer_bwd", x, N, y, M, B, D);
-    if (rc) return rc;
-    FX3D_REQUIRE(idx_x && idx_y && gx && gy, "fx3d_chamfer_bwd: null pointer");
-    FX3D_REQUIRE(B_global >= B, "fx3d_chamfer_bwd: B_global < B");
-    hipStream_t st = as_stream(s);
-    const float ca = gout * w1 * (float)(6.0 / ((double)D * N * (double)B_global));
-    const float cb = gout * w2 * (float)(6.0 / ((double)D * M * (double)B_global));
-    const long long total = (long long)B * (N + M);
-    long long blocks = (total + kThreads - 1) / kThreads;
-    if (blocks > 4096) blocks = 4096;
-    const bool no_lds = opt(OPT_BWD_GLOBAL_ATOMICS) != 0;  // (fx3d_set_option: the tests flip it)
-    const int maxr = N > M ? N : M;
-    int nsplit = 2 * device_cus() / (2 * B);  // aim at ~2 blocks per CU; a block never owns fewer than 256 rows ...
-    if (nsplit > maxr / 256) nsplit = maxr / 256;
-    if (nsplit < 1) nsplit = 1;
-    while ((size_t)((maxr + nsplit - 1) / nsplit) * D * sizeof(float) > 144 * 1024) ++nsplit;  // ... nor more than fit in LDS
-    const size_t lds = sizeof(float) * (size_t)((maxr + nsplit - 1) / nsplit) * D;
-    if ((long long)2 * B * nsplit < (1ll << 30) && !no_lds) {
-        const fx3d_status arc = D == 3 ? ensure_dynamic_lds(reinterpret_cast<const void *>(&chamfer_bwd_lds_kernel<true>), 144 * 1024, "chamfer_bwd_lds_kernel")
-                                       : ensure_dynamic_lds(reinterpret_cast<const void *>(&chamfer_bwd_lds_kernel<false>), 144 * 1024, "chamfer_bwd_lds_kernel");
-        if (arc != FX3D_OK) return arc;
-        ProfileScope prof("chamfer_bwd", st);
-        if (D == 3)
-            hipLaunchKernelGGL(chamfer_bwd_lds_kernel<true>, dim3(2 * B * nsplit), dim3(kBwdThreads), lds, st, x, N, y, M, D, idx_x,
-                               idx_y, ca, cb, gx, gy, nsplit);
-        else
-            hipLaunchKernelGGL(chamfer_bwd_lds_kernel<false>, dim3(2 * B * nsplit), dim3(kBwdThreads), lds, st, x, N, y, M, D, idx_x,
-                               idx_y, ca, cb, gx, gy, nsplit);
-        FX3D_LAUNCH_CHECK();
-        return FX3D_OK;
-    }
-    {
-        ProfileScope prof("chamfer_bwd", st);
-        hipLaunchKernelGGL(chamfer_bwd_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0, st, x, N, y, M,
-                           B, D, idx_x, idx_y, ca, cb, gx, gy);
-        hipLaunchKernelGGL(chamfer_bwd_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0, st, x, N, y, M,
-                           B, D, idx_x, idx_y, ca, cb, gx, gy);
-    }
-    FX3D_LAUNCH_CHECK();
-    return FX3D_OK;
-}
-
-fx3d_status fx3d_chamfer_sampled_bwd(const float *x, int32_t N, const float *y, int32_t M, int32_t B, const int32_t *idx_x,
-                                     const int32_t *idx_y, float w1, float w2, float gout, int64_t B_global,
-                                     const int32_t *faces_x, int32_t Vmax_x, int32_t Fmax_x, const int32_t *face_idx_x,
-                                     const float *r1_x, const float *r2_x, float *gverts_x, const int32_t *faces_y,
-                                     int32_t Vmax_y, int32_t Fmax_y, const int32_t *face_idx_y, const float *r1_y,
-                                     const float *r2_y, float *gverts_y, int32_t accumulate, fx3d_stream_t s) {
-    fx3d_status rc = check_shapes("fx3d_chamfer_sampled_bwd", x, N, y, M, B, 3);
-    if (rc) return rc;
-    FX3D_REQUIRE(idx_x && idx_y, "fx3d_chamfer_sampled_bwd: null index array");
-    FX3D_REQUIRE(gverts_x || gverts_y, "fx3d_chamfer_sampled_bwd: no gradient requested");
-    FX3D_REQUIRE(!gverts_x || (faces_x && face_idx_x && r1_x && r2_x && Vmax_x > 0 && Fmax_x > 0), "fx3d_chamfer_sampled_bwd: incomplete mesh of x");
-    FX3D_REQUIRE(!gverts_y || (faces_y && face_idx_y && r1_y && r2_y && Vmax_y > 0 && Fmax_y > 0), "fx3d_chamfer_sampled_bwd: incomplete mesh of y");
-    FX3D_REQUIRE(B_global >= B, "fx3d_chamfer_sampled_bwd: B_global < B");
-    hipStream_t st = as_stream(s);
-    if (!accumulate) {
-        if (gverts_x) FX3D_HIP(hipMemsetAsync(gverts_x, 0, sizeof(float) * 3 * (size_t)Vmax_x * B, st));
-        if (gverts_y) FX3D_HIP(hipMemsetAsync(gverts_y, 0, sizeof(float) * 3 * (size_t)Vmax_y * B, st));
-    }
-    const float ca = gout * w1 * (float)(6.0 / (3.0 * N * (double)B_global));
-    const float cb = gout * w2 * (float)(6.0 / (3.0 * M * (double)B_global));
-    const int maxr = N > M ? N : M;
-    int nsplit = 2 * device_cus() / (2 * B);  // as fx3d_chamfer_bwd: ~2 blocks per CU, a block never owns fewer than 256 rows nor more than fit in LDS
-    if (nsplit > maxr / 256) nsplit = maxr / 256;
-    if (nsplit < 1) nsplit = 1;
-    while ((size_t)((maxr + nsplit - 1) / nsplit) * 3 * sizeof(float) > 144 * 1024) ++nsplit;
-    const size_t lds = sizeof(float) * (size_t)((maxr + nsplit - 1) / nsplit) * 3;
-    FX3D_REQUIRE((long long)2 * B * nsplit < (1ll << 30), "fx3d_chamfer_sampled_bwd: batch too large");
-    const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&chamfer_sampled_bwd_kernel), 144 * 1024,
-                                               "chamfer_sampled_bwd_kernel");
-    if (arc != FX3D_OK) return arc;
-    const SampledSide sx{faces_x, face_idx_x, r1_x, r2_x, gverts_x, Vmax_x, Fmax_x}, sy{faces_y, face_idx_y, r1_y, r2_y, gverts_y, Vmax_y, Fmax_y};
-    ProfileScope prof("chamfer_sampled_bwd", st);
-    hipLaunchKernelGGL(chamfer_sampled_bwd_kernel, dim3(2 * B * nsplit), dim3(kBwdThreads), lds, st, x, N, y, M, idx_x, idx_y, ca, cb, sx,
-                       sy, nsplit);
-    FX3D_LAUNCH_CHECK();
-    return FX3D_OK;
-}
-
-// Value AND gradient in one ABI call (the shape of `gradient(() -> chamfer_distance(A, B), ...)`, benchmarks/metrics.jl:24-38,
-// examples/fit_mesh.jl:106-110): the forward with indices and the adjoint are queued back to back on the stream, the
-// nearest-neighbour indices stay in the caller's scratch (or go to idx_x / idx_y when the caller wants them).  Two ABI calls
-// leave the device idle between the launches for as long as the host needs for the second call.
-fx3d_status fx3d_chamfer_fwd_bwd_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_t D, size_t *bytes) {
-    FX3D_REQUIRE(bytes, "fx3d_chamfer_fwd_bwd_workspace_bytes: null output");
-    size_t fwd = 0;
-    const fx3d_status rc = fx3d_chamfer_workspace_bytes(N, M, B, D, &fwd);
-    if (rc) return rc;
-    fwd = (fwd + 255) & ~(size_t)255;
-    *bytes = fwd + ((sizeof(int32_t) * (size_t)B * ((size_t)N + M) + 255) & ~(size_t)255);
-    return FX3D_OK;
-}
-
-fx3d_status fx3d_chamfer_fwd_bwd(const float *x, int32_t N, const float *y, int32_t M, int32_t B, int32_t D, float w1,
-                                 float w2, float gout, int64_t B_global, float *loss_dev, float *loss_host, float *gx,
-                                 float *gy, int32_t *idx_x, int32_t *idx_y, void *ws, size_t ws_bytes, fx3d_stream_t s) {
-    fx3d_status rc = check_shapes("fx3d_chamfer_fwd_bwd", x, N, y, M, B, D);
-    if (rc) return rc;
-    FX3D_REQUIRE(loss_dev && gx && gy, "fx3d_chamfer_fwd_bwd: null output pointer");
-    FX3D_REQUIRE(B_global >= B, "fx3d_chamfer_fwd_bwd: B_global < B");
-    size_t fwd = 0, need = 0;
-    rc = fx3d_chamfer_workspace_bytes(N, M, B, D, &fwd);
-    if (rc) return rc;
-    fx3d_chamfer_fwd_bwd_workspace_bytes(N, M, B, D, &need);
-    fwd = (fwd + 255) & ~(size_t)255;
-    if (!ws || ws_bytes < need) {
-        set_error("fx3d_chamfer_fwd_bwd: workspace too small (%zu < %zu bytes)", ws ? ws_bytes : (size_t)0, need);
-        return FX3D_ERR_WORKSPACE;
-    }
-    int32_t *ix = reinterpret_cast<int32_t *>(static_cast<char *>(ws) + fwd);
-    int32_t *iy = ix + (size_t)B * N;
-    if (idx_x) ix = idx_x;
-    if (idx_y) iy = idx_y;
-    rc = chamfer_common(x, N, y, M, B, D, nullptr, loss_dev, (long long)B_global, w1, w2, ix, iy, ws, fwd, as_stream(s),
-                        "fx3d_chamfer_fwd_bwd");
-    if (rc) return rc;
-    rc = fx3d_chamfer_bwd(x, N, y, M, B, D, ix, iy, w1, w2, gout, B_global, gx, gy, s);
-    if (rc) return rc;
-    if (loss_host) {
-        FX3D_HIP(hipMemcpyAsync(loss_host, loss_dev, sizeof(float), hipMemcpyDeviceToHost, as_stream(s)));
-        FX3D_HIP(hipStreamSynchronize(as_stream(s)));
-    }
-    return FX3D_OK;
-}
-
-}  // extern "C"
 
 // ------------------------------------------------------------------------------------------------
 // The loss in the reference's own arithmetic: Float32 pairwise `mean` of the materialised squared

@@ -1,0 +1,588 @@
+// Adjoint of _chamfer_distance (Zygote through src/metrics/pcloud.jl:45-48 with the nearest-neighbour indices constant, :45
+// `@ignore`), of chamfer_distance(m1::TriMesh, m2::TriMesh, n) (src/metrics/mesh.jl:34-44) w.r.t. the meshes' vertices, and the
+// value-and-gradient entry point (benchmarks/metrics.jl:24-38 "total", examples/fit_mesh.jl:106-110).
+//
+// Round 5: NO float atomics on the default path.  The gradient row of point i of one side is
+//     side x:  g[i] = (0 + ca (x_i - y[ix[i]]))  -  sum over { j : iy[j] == i }, j ASCENDING, of  cb (y_j - x_i)
+//     side y:  g[j] = (0 - sum over { i : ix[i] == j }, i ASCENDING, of ca (x_i - y_j))  +  cb (y_j - x[iy[j]])
+// -- exactly the order in which oracle/flux3d_oracle.c: fx3d_oracle_chamfer_bwd (two loops per batch element) reaches the
+// row, so the result is the oracle's bit for bit and the same from run to run.  A block owns up to 4096 rows of one
+// (cloud, side); per round of 4096 rows of the OTHER side it builds the inverse lists in LDS with a counting sort of their
+// indices (integer LDS atomics only: counts, a block scan, cursor placement), puts every list into ascending order (up to eight
+// entries: a sorting network in the owner's registers; longer ones: a wave sorts the list in place through a 4096-bit bitmap
+// and walks it with lane-parallel gathers and an ordered readlane chain), and the owner of a row subtracts its entries in
+// order.  D = 3: accumulators in registers, 12-byte row loads; other D: the row of g itself is the accumulator.
+#include "fx3d_common.h"
+
+using namespace fx3d;
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// Scatter form with GLOBAL float atomics (option bwd_global_atomics; arrival order decides the last bit), two ordered passes:
+//   own pass     : gx[i] = ca (x_i - y[ix[i]]),  gy[j] = cb (y_j - x[iy[j]])        plain coalesced stores
+//   scatter pass : gy[ix[i]] -= ca (x_i - y[ix[i]]),  gx[iy[j]] -= cb (y_j - x[iy[j]])   float atomics
+template <bool SCATTER>
+__global__ __launch_bounds__(kThreads) void chamfer_bwd_kernel(
+    const float *__restrict__ x, int N, const float *__restrict__ y, int M, int B, int D,
+    const int32_t *__restrict__ idx_x, const int32_t *__restrict__ idx_y, float ca, float cb,
+    float *gx, float *gy) {
+    const long long total = (long long)B * (N + M);
+    for (long long k = (long long)blockIdx.x * kThreads + threadIdx.x; k < total;
+         k += (long long)gridDim.x * kThreads) {
+        const int b = (int)(k / (N + M));
+        const int r = (int)(k % (N + M));
+        const float *xb = x + (size_t)b * N * D, *yb = y + (size_t)b * M * D;
+        float *gxb = gx + (size_t)b * N * D, *gyb = gy + (size_t)b * M * D;
+        if (r < N) {
+            const int i = r, j = idx_x[(size_t)b * N + i];
+            for (int d = 0; d < D; ++d) {
+                const float t = ca * (xb[(size_t)i * D + d] - yb[(size_t)j * D + d]);
+                if (SCATTER) atomicAdd(&gyb[(size_t)j * D + d], -t);
+                else gxb[(size_t)i * D + d] = t;
+            }
+        } else {
+            const int j = r - N, i = idx_y[(size_t)b * M + j];
+            for (int d = 0; d < D; ++d) {
+                const float t = cb * (yb[(size_t)j * D + d] - xb[(size_t)i * D + d]);
+                if (SCATTER) atomicAdd(&gxb[(size_t)i * D + d], -t);
+                else gyb[(size_t)j * D + d] = t;
+            }
+        }
+    }
+}
+
+// ---- the gather form ---------------------------------------------------------------------------------------------------------
+#ifndef FX3D_BG_THREADS
+#define FX3D_BG_THREADS 1024
+#endif
+constexpr int kBgThreads = FX3D_BG_THREADS;
+constexpr int kBgRows = 4096;    // rows of g one block owns at most
+constexpr int kBgPer = kBgRows / kBgThreads;  // rows / scan slots / other-side rows per thread and round
+constexpr int kBgChunk = 4096;   // rows of the other side bucketed per round (their round-local ids fit 16 bits)
+constexpr int kBgSmall = 8;      // lists up to this length are ordered in the owner's registers (one in 10^6 of uniform data's is longer)
+constexpr int kBgSortWaves = kBgThreads / 64;  // every wave takes rows with longer lists (one 4096-bit bitmap each)
+constexpr int kBgBigW = 256;     // long rows whose own point and index travel through LDS (the others re-read them from memory)
+#ifndef FX3D_BG_OCC
+#define FX3D_BG_OCC 4   // waves per SIMD the kernels are compiled for.  4 = one 1024-thread block per CU with up to 128 registers; 8 (two
+#endif                  // blocks per CU, 64 registers) spills and measured 41 - 51 us against 37 at B = 256 x 4096 in every form tried
+
+#ifndef FX3D_BG_STOP
+#define FX3D_BG_STOP 0   // timing experiments only: leave after phase n
+#endif
+#define BG_STOP(n) do { if (FX3D_BG_STOP == (n)) return; } while (0)
+#ifdef FX3D_BG_PROBE   // phase stamps of every block (s_memtime, 100 MHz) for tools/chamfer_bwd_probe.py; never in the shipped build
+__device__ unsigned long long g_bg_probe[1024 * 8];
+#define BG_STAMP(n) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_bg_probe[blockIdx.x * 8 + (n)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BG_STAMP(n) do { } while (0)
+#endif
+
+// 38 KB
+struct BgLds {
+    unsigned int cnt2[kBgRows / 2];     // entries of own row lr in this round, two 16-bit counters per word (<= 4096 each):
+                                        // counted up, then counted DOWN by the placement -- zero again for the next round
+    unsigned short start[kBgRows + 4];  // first list slot of row lr; start[lr + 1] - start[lr] = its length
+    unsigned short list[kBgChunk];      // round-local ids of the other side's rows, list by list
+    unsigned int bitmap[kBgSortWaves][kBgChunk / 32];   // in-place ordering of a long list
+    unsigned short big[kBgChunk / (kBgSmall + 1) + 1];  // rows with long lists (more cannot exist in one round)
+    float4 bigw[kBgBigW];                               // D = 3: (own point, index of its neighbour as bits) of the first long rows
+    __attribute__((aligned(16))) unsigned int wsum[kBgThreads / 64];
+    unsigned int nbig;
+};
+
+__device__ __forceinline__ void ce(unsigned int &a, unsigned int &b) {
+    const unsigned int lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo; b = hi;
+}
+// all LDS traffic this wave issued so far is complete and visible to its other lanes
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+// inclusive wave64 prefix sum on the VALU (DPP row shifts + row broadcasts; __shfl_up would be six ds_bpermute round trips)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned int dpp_zero(unsigned int v) {  // lanes without a source / outside ROWMASK read 0
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xF, false);
+}
+__device__ __forceinline__ unsigned int wave_scan_incl(unsigned int v) {
+    v += dpp_zero<0x111, 0xF>(v);  // row_shr:1
+    v += dpp_zero<0x112, 0xF>(v);  // row_shr:2
+    v += dpp_zero<0x114, 0xF>(v);  // row_shr:4
+    v += dpp_zero<0x118, 0xF>(v);  // row_shr:8
+    v += dpp_zero<0x142, 0xA>(v);  // row_bcast:15 -> rows 1, 3
+    v += dpp_zero<0x143, 0xC>(v);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ float lane_val(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+struct SampledSide {
+    const int32_t *faces;     // (3, Fmax, B) mesh-local
+    const int32_t *face_idx;  // (n, B) the draws
+    const float *r1, *r2;
+    float *gverts;            // (3, Vmax, B), added to
+    int Vmax, Fmax;
+};
+
+struct BgJob {
+    const float *own, *oth;               // this side's rows (R x D) / the other side's (S x D) of one cloud pair
+    const int32_t *idx_own, *idx_oth;     // own row -> other row / other row -> own row
+    int R, S, D, r0, r1, side, b;         // the block owns rows [r0, r1) of side `side` (0: x, 1: y) of cloud pair b
+    float c_own, c_oth;
+    float *g;                             // MODE 0 / 1: this (cloud, side)'s gradient rows (R x D): result, and the accumulator
+                                          // between the rounds of an other side beyond kBgChunk rows
+    P3 *part;                             // MODE 2: the accumulator between rounds, in LDS
+    SampledSide smp;                      // MODE 2: where a finished row goes
+};
+
+// MODE 2: row i of the gradient w.r.t. the sampled points -> the three vertices of sample i's face with the barycentric
+// weights of its draw (sample_bwd_kernel's arithmetic, src/transforms/mesh_func.jl:64-75); a face is drawn many times: float atomics
+__device__ __forceinline__ void bg_scatter_sample(const BgJob &J, int i, P3 a) {
+    const SampledSide &S = J.smp;
+    const size_t k = (size_t)J.b * J.R + i;
+    const int32_t *fc = S.faces + ((size_t)J.b * S.Fmax + S.face_idx[k]) * 3;
+    const int f3[3] = {fc[0], fc[1], fc[2]};
+    const float uu = sqrtf(S.r1[k]), v = S.r2[k];
+    const float wt[3] = {1.0f - uu, uu * (1.0f - v), uu * v};
+    const float gr[3] = {a.x, a.y, a.z};
+    float *gb = S.gverts + (size_t)J.b * S.Vmax * 3;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) atomicAdd(&gb[3ll * f3[t] + d], wt[t] * gr[d]);
+}
+
+// MODE 0: D = 3, rows stored to g;  1: any D, rows accumulated in g (no LDS image: gathers from L2);  2: D = 3, rows scattered
+// onto the sampled faces' vertices
+template <int MODE>
+__device__ __forceinline__ void bg_rows(BgLds &L, const BgJob &J) {
+    constexpr bool D3 = MODE != 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the long-row loop and its readlane chain must not be "divergent")
+    const int nrows = J.r1 - J.r0, D = J.D;
+    const int rpt = (nrows + kBgThreads - 1) / kBgThreads;  // 1 .. 4 rows per thread, kBgThreads apart: a wave's rows are contiguous
+                                                            // (12-byte loads / stores of consecutive lanes coalesce; 48 bytes apart they are 64 transactions)
+    const float *__restrict__ own = J.own;
+    const float *__restrict__ oth = J.oth;
+    const float c_own = J.c_own, c_oth = J.c_oth;
+    const bool own_first = J.side == 0;  // side x: the own term opens the row (the oracle's first loop), side y: it closes it
+    // requested before anything else: this thread's rows and their indices
+    int jown[kBgPer];
+    P3 wr[kBgPer];
+#pragma unroll
+    for (int u = 0; u < kBgPer; ++u) {
+        const bool mine = u < rpt && tid + u * kBgThreads < nrows;
+        jown[u] = mine ? J.idx_own[J.r0 + tid + u * kBgThreads] : 0;
+        if (D3) wr[u] = mine ? *reinterpret_cast<const P3 *>(own + (size_t)(J.r0 + tid + u * kBgThreads) * 3) : P3{0.0f, 0.0f, 0.0f};
+    }
+    BG_STAMP(0);
+#pragma unroll
+    for (int q = 0; q < kBgPer / 2; ++q) L.cnt2[kBgPer / 2 * tid + q] = 0u;  // (the placement of every round leaves the counters at zero)
+
+    for (int c0 = 0; c0 < J.S; c0 += kBgChunk) {
+        const int cn = J.S - c0 < kBgChunk ? J.S - c0 : kBgChunk;
+        const bool first = c0 == 0, last = c0 + kBgChunk >= J.S;
+        // (1) this round's rows of the other side -> LDS image; counts: which of my rows does other row c0 + jl point at
+        if (tid == 0) L.nbig = 0u;
+        int il[kBgPer];
+#pragma unroll
+        for (int v = 0; v < kBgPer; ++v) {
+            const int jl = tid + v * kBgThreads;
+            il[v] = jl < cn ? J.idx_oth[c0 + jl] - J.r0 : -1;
+        }
+        __syncthreads();
+        BG_STAMP(1);
+        BG_STOP(1);
+#pragma unroll
+        for (int v = 0; v < kBgPer; ++v)
+            if ((unsigned int)il[v] < (unsigned int)nrows) atomicAdd(&L.cnt2[il[v] >> 1], (il[v] & 1) ? 0x10000u : 1u);
+        __syncthreads();
+        BG_STAMP(2);
+        BG_STOP(2);
+        // (2) exclusive scan over the rows (thread t: slots 4t .. 4t+3), long lists registered
+        unsigned int cc[kBgPer], s4 = 0u;
+#pragma unroll
+        for (int q = 0; q < kBgPer / 2; ++q) {
+            const unsigned int cw = L.cnt2[kBgPer / 2 * tid + q];
+            cc[2 * q] = cw & 0xFFFFu; cc[2 * q + 1] = cw >> 16;
+            s4 += cc[2 * q] + cc[2 * q + 1];
+        }
+        const unsigned int inc = wave_scan_incl(s4);
+        if (lane == 63) L.wsum[wv] = inc;
+        __syncthreads();
+        {
+            unsigned int base = 0u;
+            {
+#pragma unroll
+                for (int q = 0; q < kBgThreads / 64; q += 4) {
+                    const uint4 t = *reinterpret_cast<const uint4 *>(&L.wsum[q]);
+                    base += (q < wv ? t.x : 0u) + (q + 1 < wv ? t.y : 0u) + (q + 2 < wv ? t.z : 0u) + (q + 3 < wv ? t.w : 0u);
+                }
+            }
+            unsigned int ex = base + inc - s4;
+#pragma unroll
+            for (int q = 0; q < kBgPer / 2; ++q) {
+                const unsigned int lo = ex, hi = ex + cc[2 * q];
+                *reinterpret_cast<unsigned int *>(&L.start[kBgPer * tid + 2 * q]) = lo | (hi << 16);
+                ex = hi + cc[2 * q + 1];
+            }
+            if (tid == kBgThreads - 1) L.start[kBgRows] = (unsigned short)ex;
+        }
+        __syncthreads();
+        BG_STAMP(3);
+        BG_STOP(3);
+        // (3) placement, from the back of every list (arrival order inside a list: whatever the atomics give; put right below);
+        //     the owners register their rows with long lists and hand the waves what they hold of them
+#pragma unroll
+        for (int v = 0; v < kBgPer; ++v)
+            if ((unsigned int)il[v] < (unsigned int)nrows) {
+                const int sh = (il[v] & 1) * 16;
+                const unsigned int old = atomicSub(&L.cnt2[il[v] >> 1], 1u << sh);
+                L.list[L.start[il[v]] + ((old >> sh) & 0xFFFFu) - 1u] = (unsigned short)(tid + v * kBgThreads);
+            }
+#pragma unroll
+        for (int u = 0; u < kBgPer; ++u) {
+            const int lr = tid + u * kBgThreads;
+            if (u < rpt && lr < nrows && (int)L.start[lr + 1] - (int)L.start[lr] > kBgSmall) {
+                const unsigned int k = atomicAdd(&L.nbig, 1u);
+                L.big[k] = (unsigned short)lr;
+                if (D3 && k < (unsigned int)kBgBigW) L.bigw[k] = float4{wr[u].x, wr[u].y, wr[u].z, __builtin_bit_cast(float, jown[u])};
+            }
+        }
+        __syncthreads();
+        BG_STAMP(4);
+        BG_STOP(4);
+        // (4) rows with long lists: one wave each -- bitmap sort in place, lane-parallel gathers, an ordered readlane chain
+        const unsigned int nb = (unsigned int)__builtin_amdgcn_readfirstlane((int)L.nbig);
+        for (unsigned int k = (unsigned int)wv; k < nb; k += kBgSortWaves) {
+            const int lr = __builtin_amdgcn_readfirstlane((int)L.big[k]);
+            const int start = __builtin_amdgcn_readfirstlane((int)L.start[lr]);
+            const int c = __builtin_amdgcn_readfirstlane((int)L.start[lr + 1]) - start;
+            unsigned int *bm = L.bitmap[wv];
+            bm[lane] = 0u;
+            bm[lane + 64] = 0u;
+            wave_lds_sync();
+            for (int e = lane; e < c; e += 64) {
+                const unsigned int j = L.list[start + e];
+                atomicOr(&bm[j >> 5], 1u << (j & 31u));
+            }
+            wave_lds_sync();
+            unsigned int w0 = bm[2 * lane], w1 = bm[2 * lane + 1];
+            const unsigned int p = __popc(w0) + __popc(w1);
+            const unsigned int pin = wave_scan_incl(p);
+            int pos = start + (int)(pin - p);
+            while (w0) { L.list[pos++] = (unsigned short)(64 * lane + __ffs(w0) - 1); w0 &= w0 - 1u; }
+            while (w1) { L.list[pos++] = (unsigned short)(64 * lane + 32 + __ffs(w1) - 1); w1 &= w1 - 1u; }
+            wave_lds_sync();
+            const size_t i = (size_t)(J.r0 + lr);
+            if (D3) {
+                P3 w;
+                int jo;
+                if (k < (unsigned int)kBgBigW) {
+                    const float4 t = L.bigw[k];
+                    w = P3{t.x, t.y, t.z}; jo = __builtin_bit_cast(int, t.w);
+                } else {
+                    w = *reinterpret_cast<const P3 *>(own + i * 3); jo = J.idx_own[i];
+                }
+                P3 ot{0.0f, 0.0f, 0.0f};  // the own term
+                if ((first && own_first) || (last && !own_first)) {
+                    const P3 o = *reinterpret_cast<const P3 *>(oth + (size_t)jo * 3);
+                    ot = P3{c_own * (w.x - o.x), c_own * (w.y - o.y), c_own * (w.z - o.z)};
+                }
+                P3 a{0.0f, 0.0f, 0.0f};
+                if (!first) a = MODE == 2 ? J.part[lr] : *reinterpret_cast<const P3 *>(J.g + i * 3);
+                else if (own_first) a = P3{0.0f + ot.x, 0.0f + ot.y, 0.0f + ot.z};
+                for (int e0 = 0; e0 < c; e0 += 64) {
+                    float tx = 0.0f, ty = 0.0f, tz = 0.0f;
+                    if (e0 + lane < c) {
+                        const P3 o = *reinterpret_cast<const P3 *>(oth + (size_t)(c0 + L.list[start + e0 + lane]) * 3);
+                        tx = c_oth * (o.x - w.x); ty = c_oth * (o.y - w.y); tz = c_oth * (o.z - w.z);
+                    }
+                    const int n = c - e0 < 64 ? c - e0 : 64;
+                    for (int l = 0; l < n; ++l) {
+                        a.x = a.x - lane_val(tx, l); a.y = a.y - lane_val(ty, l); a.z = a.z - lane_val(tz, l);
+                    }
+                }
+                if (last && !own_first) a = P3{a.x + ot.x, a.y + ot.y, a.z + ot.z};
+                if (lane == 0) {
+                    if (MODE == 2) { if (last) bg_scatter_sample(J, (int)i, a); else J.part[lr] = a; }
+                    else *reinterpret_cast<P3 *>(J.g + i * 3) = a;
+                }
+            } else {
+                const int jo = J.idx_own[i];
+                for (int d = 0; d < D; ++d) {
+                    const float wd = own[i * D + d];
+                    const float ot = c_own * (wd - oth[(size_t)jo * D + d]);
+                    float a = first ? (own_first ? 0.0f + ot : 0.0f) : J.g[i * D + d];
+                    for (int e0 = 0; e0 < c; e0 += 64) {
+                        float t = 0.0f;
+                        if (e0 + lane < c) t = c_oth * (oth[(size_t)(c0 + L.list[start + e0 + lane]) * D + d] - wd);
+                        const int n = c - e0 < 64 ? c - e0 : 64;
+                        for (int l = 0; l < n; ++l) a = a - lane_val(t, l);
+                    }
+                    if (last && !own_first) a = a + ot;
+                    if (lane == 0) J.g[i * D + d] = a;
+                }
+            }
+        }
+        BG_STAMP(5);
+        BG_STOP(5);
+        // (5) the owners: short lists ordered in registers, subtracted in order (no barrier between (4) and (5): the waves
+        //     touch only the lists / rows of the long rows, which the owners skip).  Row by row: two rows at a time with every
+        //     stage's LDS reads issued together was measured slower at every list cap (4 / 6 / 8: the arrays of both rows spill)
+#pragma unroll
+        for (int u = 0; u < kBgPer; ++u) {
+            const int lr = tid + u * kBgThreads;
+            if (!(u < rpt && lr < nrows)) continue;
+            const int start = L.start[lr], c = (int)L.start[lr + 1] - start;
+            if (c > kBgSmall || (c == 0 && !first && !last)) continue;
+            unsigned int e[kBgSmall];
+#pragma unroll
+            for (int k = 0; k < kBgSmall; ++k) e[k] = k < c ? (unsigned int)L.list[start + k] : 0xFFFFu;
+            if (c > 4) {
+                ce(e[0], e[1]); ce(e[2], e[3]); ce(e[4], e[5]); ce(e[6], e[7]);
+                ce(e[0], e[2]); ce(e[1], e[3]); ce(e[4], e[6]); ce(e[5], e[7]);
+                ce(e[1], e[2]); ce(e[5], e[6]); ce(e[0], e[4]); ce(e[3], e[7]);
+                ce(e[1], e[5]); ce(e[2], e[6]);
+                ce(e[1], e[4]); ce(e[3], e[6]);
+                ce(e[2], e[4]); ce(e[3], e[5]);
+                ce(e[3], e[4]);
+            } else if (c > 2) {
+                ce(e[0], e[1]); ce(e[2], e[3]); ce(e[0], e[2]); ce(e[1], e[3]); ce(e[1], e[2]);
+            } else if (c == 2) {
+                ce(e[0], e[1]);
+            }
+            const size_t i = (size_t)(J.r0 + lr);
+            const int jo = jown[u];
+            if (D3) {
+                const P3 w = wr[u];
+                P3 ot{0.0f, 0.0f, 0.0f};
+                if ((first && own_first) || (last && !own_first)) {
+                    const P3 o = *reinterpret_cast<const P3 *>(oth + (size_t)jo * 3);
+                    ot = P3{c_own * (w.x - o.x), c_own * (w.y - o.y), c_own * (w.z - o.z)};
+                }
+                P3 a{0.0f, 0.0f, 0.0f};
+                if (!first) a = MODE == 2 ? J.part[lr] : *reinterpret_cast<const P3 *>(J.g + i * 3);
+                else if (own_first) a = P3{0.0f + ot.x, 0.0f + ot.y, 0.0f + ot.z};
+                {
+#pragma unroll
+                    for (int h = 0; h < kBgSmall; h += 4) {  // four gathers in flight
+                        if (h >= c) break;
+                        P3 o[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (h + k < c) o[k] = *reinterpret_cast<const P3 *>(oth + (size_t)(c0 + e[h + k]) * 3);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (h + k < c) {
+                                a.x = a.x - c_oth * (o[k].x - w.x);
+                                a.y = a.y - c_oth * (o[k].y - w.y);
+                                a.z = a.z - c_oth * (o[k].z - w.z);
+                            }
+                    }
+                }
+                if (last && !own_first) a = P3{a.x + ot.x, a.y + ot.y, a.z + ot.z};
+                if (MODE == 2) { if (last) bg_scatter_sample(J, (int)i, a); else J.part[lr] = a; }
+                else *reinterpret_cast<P3 *>(J.g + i * 3) = a;
+            } else {
+                for (int d = 0; d < D; ++d) {
+                    const float wd = own[i * D + d];
+                    const float ot = c_own * (wd - oth[(size_t)jo * D + d]);
+                    float a = first ? (own_first ? 0.0f + ot : 0.0f) : J.g[i * D + d];
+#pragma unroll
+                    for (int k = 0; k < kBgSmall; ++k)
+                        if (k < c) a = a - c_oth * (oth[(size_t)(c0 + e[k]) * D + d] - wd);
+                    if (last && !own_first) a = a + ot;
+                    J.g[i * D + d] = a;
+                }
+            }
+        }
+        BG_STAMP(6);
+        if (!last) __syncthreads();  // the next round reuses the image / start / list (and reads the accumulators back)
+    }
+}
+
+__device__ __forceinline__ BgJob bg_job(const float *x, int N, const float *y, int M, int D, const int32_t *idx_x,
+                                        const int32_t *idx_y, float ca, float cb, int nsplit) {
+    const int part = blockIdx.x % nsplit, bs = blockIdx.x / nsplit;
+    const int b = bs >> 1, side = bs & 1;  // side 0: gx, 1: gy
+    BgJob J{};
+    J.side = side; J.D = D; J.b = b;
+    J.R = side ? M : N; J.S = side ? N : M;
+    J.own = (side ? y : x) + (size_t)b * J.R * D;
+    J.oth = (side ? x : y) + (size_t)b * J.S * D;
+    J.idx_own = (side ? idx_y : idx_x) + (size_t)b * J.R;
+    J.idx_oth = (side ? idx_x : idx_y) + (size_t)b * J.S;
+    J.c_own = side ? cb : ca; J.c_oth = side ? ca : cb;
+    const int per = (J.R + nsplit - 1) / nsplit;
+    J.r0 = part * per < J.R ? part * per : J.R;
+    J.r1 = J.r0 + per < J.R ? J.r0 + per : J.R;
+    return J;
+}
+
+template <bool D3>
+__global__ __launch_bounds__(kBgThreads, FX3D_BG_OCC) void chamfer_bwd_gather_kernel(
+    const float *__restrict__ x, int N, const float *__restrict__ y, int M, int D, const int32_t *__restrict__ idx_x,
+    const int32_t *__restrict__ idx_y, float ca, float cb, float *__restrict__ gx, float *__restrict__ gy, int nsplit) {
+    __shared__ BgLds L;
+    BgJob J = bg_job(x, N, y, M, D, idx_x, idx_y, ca, cb, nsplit);
+    J.g = (J.side ? gy : gx) + (size_t)J.b * J.R * D;
+    bg_rows<D3 ? 0 : 1>(L, J);
+}
+
+// Adjoint of chamfer_distance(sample_points(m_x), sample_points(m_y)) w.r.t. the meshes' vertices in one launch: the gradient
+// w.r.t. the sampled points is formed exactly as in chamfer_bwd_gather_kernel (D = 3), then every finished row goes onto the
+// three vertices of its sampled face instead of being written out.  A side without a mesh gradient (gverts == nullptr) is skipped.
+__global__ __launch_bounds__(kBgThreads, FX3D_BG_OCC) void chamfer_sampled_bwd_kernel(
+    const float *__restrict__ x, int N, const float *__restrict__ y, int M, const int32_t *__restrict__ idx_x,
+    const int32_t *__restrict__ idx_y, float ca, float cb, SampledSide sx, SampledSide sy, int nsplit) {
+    __shared__ BgLds L;
+    extern __shared__ __attribute__((aligned(16))) unsigned char bg_dyn[];  // the accumulators between rounds (n > 4096 samples)
+    BgJob J = bg_job(x, N, y, M, 3, idx_x, idx_y, ca, cb, nsplit);
+    J.smp = J.side ? sy : sx;
+    if (!J.smp.gverts) return;
+    J.part = reinterpret_cast<P3 *>(bg_dyn);
+    bg_rows<2>(L, J);
+}
+
+// blocks per (cloud, side): ONE round of blocks on the chip (a block is a chain of dependent phases: a second round doubles the
+// time), a block never owns fewer than 256 rows nor more than kBgRows.  Measured (kernel us, B x N): 32 x 4096: 15 / 11.7 / 18 / 28
+// at 1 / 4 / 8 / 16 blocks per side; 8 x 5000: 17 / 13.5 / 11.6 at 1 / 4 / 16; 1 x 16384: 31 / 23 / 20 at 1 / 8 / 16.
+int bg_nsplit(int B, int maxr) {
+    int nsplit = device_cus() / (2 * B);
+    if (nsplit > maxr / 256) nsplit = maxr / 256;
+    if (nsplit < 1) nsplit = 1;
+    while ((maxr + nsplit - 1) / nsplit > kBgRows) ++nsplit;
+    return nsplit;
+}
+
+}  // namespace
+
+extern "C" {
+
+fx3d_status fx3d_chamfer_bwd(const float *x, int32_t N, const float *y, int32_t M, int32_t B,
+                             int32_t D, const int32_t *idx_x, const int32_t *idx_y, float w1,
+                             float w2, float gout, int64_t B_global, float *gx, float *gy,
+                             fx3d_stream_t s) {
+    fx3d_status rc = chamfer_check_shapes("fx3d_chamfer_bwd", x, N, y, M, B, D);
+    if (rc) return rc;
+    FX3D_REQUIRE(idx_x && idx_y && gx && gy, "fx3d_chamfer_bwd: null pointer");
+    FX3D_REQUIRE(B_global >= B, "fx3d_chamfer_bwd: B_global < B");
+    hipStream_t st = as_stream(s);
+    const float ca = gout * w1 * (float)(6.0 / ((double)D * N * (double)B_global));
+    const float cb = gout * w2 * (float)(6.0 / ((double)D * M * (double)B_global));
+    const int nsplit = bg_nsplit(B, N > M ? N : M);
+    if ((long long)2 * B * nsplit < (1ll << 30) && !opt(OPT_BWD_GLOBAL_ATOMICS)) {
+        ProfileScope prof("chamfer_bwd", st);
+        if (D == 3)
+            hipLaunchKernelGGL(chamfer_bwd_gather_kernel<true>, dim3(2 * B * nsplit), dim3(kBgThreads), 0, st, x, N, y, M, D, idx_x,
+                               idx_y, ca, cb, gx, gy, nsplit);
+        else
+            hipLaunchKernelGGL(chamfer_bwd_gather_kernel<false>, dim3(2 * B * nsplit), dim3(kBgThreads), 0, st, x, N, y, M, D, idx_x,
+                               idx_y, ca, cb, gx, gy, nsplit);
+        FX3D_LAUNCH_CHECK();
+        return FX3D_OK;
+    }
+    const long long total = (long long)B * (N + M);
+    long long blocks = (total + kThreads - 1) / kThreads;
+    if (blocks > 4096) blocks = 4096;
+    {
+        ProfileScope prof("chamfer_bwd", st);
+        hipLaunchKernelGGL(chamfer_bwd_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0, st, x, N, y, M,
+                           B, D, idx_x, idx_y, ca, cb, gx, gy);
+        hipLaunchKernelGGL(chamfer_bwd_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0, st, x, N, y, M,
+                           B, D, idx_x, idx_y, ca, cb, gx, gy);
+    }
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+#ifdef FX3D_BG_PROBE
+__attribute__((visibility("default"))) int fx3d_debug_bg_probe(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bg_probe), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif
+
+fx3d_status fx3d_chamfer_sampled_bwd(const float *x, int32_t N, const float *y, int32_t M, int32_t B, const int32_t *idx_x,
+                                     const int32_t *idx_y, float w1, float w2, float gout, int64_t B_global,
+                                     const int32_t *faces_x, int32_t Vmax_x, int32_t Fmax_x, const int32_t *face_idx_x,
+                                     const float *r1_x, const float *r2_x, float *gverts_x, const int32_t *faces_y,
+                                     int32_t Vmax_y, int32_t Fmax_y, const int32_t *face_idx_y, const float *r1_y,
+                                     const float *r2_y, float *gverts_y, int32_t accumulate, fx3d_stream_t s) {
+    fx3d_status rc = chamfer_check_shapes("fx3d_chamfer_sampled_bwd", x, N, y, M, B, 3);
+    if (rc) return rc;
+    FX3D_REQUIRE(idx_x && idx_y, "fx3d_chamfer_sampled_bwd: null index array");
+    FX3D_REQUIRE(gverts_x || gverts_y, "fx3d_chamfer_sampled_bwd: no gradient requested");
+    FX3D_REQUIRE(!gverts_x || (faces_x && face_idx_x && r1_x && r2_x && Vmax_x > 0 && Fmax_x > 0), "fx3d_chamfer_sampled_bwd: incomplete mesh of x");
+    FX3D_REQUIRE(!gverts_y || (faces_y && face_idx_y && r1_y && r2_y && Vmax_y > 0 && Fmax_y > 0), "fx3d_chamfer_sampled_bwd: incomplete mesh of y");
+    FX3D_REQUIRE(B_global >= B, "fx3d_chamfer_sampled_bwd: B_global < B");
+    hipStream_t st = as_stream(s);
+    if (!accumulate) {
+        if (gverts_x) FX3D_HIP(hipMemsetAsync(gverts_x, 0, sizeof(float) * 3 * (size_t)Vmax_x * B, st));
+        if (gverts_y) FX3D_HIP(hipMemsetAsync(gverts_y, 0, sizeof(float) * 3 * (size_t)Vmax_y * B, st));
+    }
+    const float ca = gout * w1 * (float)(6.0 / (3.0 * N * (double)B_global));
+    const float cb = gout * w2 * (float)(6.0 / (3.0 * M * (double)B_global));
+    const int nsplit = bg_nsplit(B, N > M ? N : M);
+    FX3D_REQUIRE((long long)2 * B * nsplit < (1ll << 30), "fx3d_chamfer_sampled_bwd: batch too large");
+    const SampledSide sx{faces_x, face_idx_x, r1_x, r2_x, gverts_x, Vmax_x, Fmax_x}, sy{faces_y, face_idx_y, r1_y, r2_y, gverts_y, Vmax_y, Fmax_y};
+    // sides beyond kBgChunk samples (the reference's default is 5000): the accumulators between the rounds live in LDS
+    const int maxr = N > M ? N : M;
+    const size_t dyn = maxr > kBgChunk ? sizeof(P3) * (size_t)((maxr + nsplit - 1) / nsplit) : 0;
+    ProfileScope prof("chamfer_sampled_bwd", st);
+    hipLaunchKernelGGL(chamfer_sampled_bwd_kernel, dim3(2 * B * nsplit), dim3(kBgThreads), dyn, st, x, N, y, M, idx_x, idx_y, ca,
+                       cb, sx, sy, nsplit);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+// Value AND gradient in one ABI call (the shape of `gradient(() -> chamfer_distance(A, B), ...)`, benchmarks/metrics.jl:24-38,
+// examples/fit_mesh.jl:106-110): the forward with indices and the adjoint are queued back to back on the stream, the
+// nearest-neighbour indices stay in the caller's scratch (or go to idx_x / idx_y when the caller wants them).  Two ABI calls
+// leave the device idle between the launches for as long as the host needs for the second call.
+fx3d_status fx3d_chamfer_fwd_bwd_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_t D, size_t *bytes) {
+    FX3D_REQUIRE(bytes, "fx3d_chamfer_fwd_bwd_workspace_bytes: null output");
+    size_t fwd = 0;
+    const fx3d_status rc = fx3d_chamfer_workspace_bytes(N, M, B, D, &fwd);
+    if (rc) return rc;
+    fwd = (fwd + 255) & ~(size_t)255;
+    *bytes = fwd + ((sizeof(int32_t) * (size_t)B * ((size_t)N + M) + 255) & ~(size_t)255);
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_chamfer_fwd_bwd(const float *x, int32_t N, const float *y, int32_t M, int32_t B, int32_t D, float w1,
+                                 float w2, float gout, int64_t B_global, float *loss_dev, float *loss_host, float *gx,
+                                 float *gy, int32_t *idx_x, int32_t *idx_y, void *ws, size_t ws_bytes, fx3d_stream_t s) {
+    fx3d_status rc = chamfer_check_shapes("fx3d_chamfer_fwd_bwd", x, N, y, M, B, D);
+    if (rc) return rc;
+    FX3D_REQUIRE(loss_dev && gx && gy, "fx3d_chamfer_fwd_bwd: null output pointer");
+    FX3D_REQUIRE(B_global >= B, "fx3d_chamfer_fwd_bwd: B_global < B");
+    size_t fwd = 0, need = 0;
+    rc = fx3d_chamfer_workspace_bytes(N, M, B, D, &fwd);
+    if (rc) return rc;
+    fx3d_chamfer_fwd_bwd_workspace_bytes(N, M, B, D, &need);
+    fwd = (fwd + 255) & ~(size_t)255;
+    if (!ws || ws_bytes < need) {
+        set_error("fx3d_chamfer_fwd_bwd: workspace too small (%zu < %zu bytes)", ws ? ws_bytes : (size_t)0, need);
+        return FX3D_ERR_WORKSPACE;
+    }
+    int32_t *ix = reinterpret_cast<int32_t *>(static_cast<char *>(ws) + fwd);
+    int32_t *iy = ix + (size_t)B * N;
+    if (idx_x) ix = idx_x;
+    if (idx_y) iy = idx_y;
+    rc = chamfer_forward(x, N, y, M, B, D, loss_dev, (long long)B_global, w1, w2, ix, iy, ws, fwd, as_stream(s),
+                         "fx3d_chamfer_fwd_bwd");
+    if (rc) return rc;
+    rc = fx3d_chamfer_bwd(x, N, y, M, B, D, ix, iy, w1, w2, gout, B_global, gx, gy, s);
+    if (rc) return rc;
+    if (loss_host) {
+        FX3D_HIP(hipMemcpyAsync(loss_host, loss_dev, sizeof(float), hipMemcpyDeviceToHost, as_stream(s)));
+        FX3D_HIP(hipStreamSynchronize(as_stream(s)));
+    }
+    return FX3D_OK;
+}
+
+}  // extern "C"

@@ -48,6 +48,10 @@ unsigned int *ticket_slot(fx3d_status *rc, hipStream_t st);
 constexpr int kTicketGroups = 16;
 constexpr int kTicketStride = 16 * (kTicketGroups + 1);
 fx3d_status ensure_dynamic_lds(const void *kernel, int bytes, const char *name);
+// chamfer.hip's argument check and forward driver (loss with batch size Bg, optional indices), for chamfer_bwd.hip
+fx3d_status chamfer_check_shapes(const char *fn, const void *x, int N, const void *y, int M, int B, int D);
+fx3d_status chamfer_forward(const float *x, int N, const float *y, int M, int B, int D, float *loss_dev, long long Bg, float w1,
+                            float w2, int32_t *idx_x, int32_t *idx_y, void *ws, size_t ws_bytes, hipStream_t st, const char *fn);
 // compute units of the calling thread's current device (cached per device; 256 on an MI355X in SPX mode, fewer in the
 // partitioned modes): the launch plans size their rounds of blocks with it instead of a constant
 int device_cus();

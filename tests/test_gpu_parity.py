@@ -218,29 +218,67 @@ def test_c2_full_size_parity_and_properties(gpu_fx, oracle):
 
 
 def test_chamfer_backward(gpu_fx, oracle):
-    """Adjoint (test/metrics.jl:112-114 tolerance: atol 1e-2, rtol 1e-3 -- we hold 1e-5)."""
+    """Adjoint (test/metrics.jl:112-114 tolerance: atol 1e-2, rtol 1e-3).  Round 5: the gather form accumulates every row in
+    the oracle's order -- bit for bit."""
     fx = gpu_fx
     x, y = _rand((3, 1000, 2), 21), _rand((3, 500, 2), 22)
     loss, ix, iy = fx.chamfer_distance(x, y, w1=0.7, w2=1.3, return_indices=True)
     gx, gy = fx.chamfer_distance_grad(x, y, ix, iy, w1=0.7, w2=1.3, gout=2.0)
     ogx, ogy = oracle.chamfer_bwd(x, y, ix.to_host(), iy.to_host(), 0.7, 1.3, 2.0)
-    assert np.allclose(gx.to_host(), ogx, rtol=1e-5, atol=1e-9)
-    assert np.allclose(gy.to_host(), ogy, rtol=1e-5, atol=1e-9)
+    assert np.array_equal(gx.to_host(), ogx)
+    assert np.array_equal(gy.to_host(), ogy)
 
 
-@pytest.mark.parametrize("N,M,B", [(4096, 4096, 3), (700, 5000, 1), (14000, 300, 1), (1, 9, 2), (257, 256, 40)])
+@pytest.mark.parametrize("N,M,B", [(4096, 4096, 3), (700, 5000, 1), (14000, 300, 1), (1, 9, 2), (257, 256, 40), (5000, 5000, 8),
+                                   (4097, 9000, 2), (20000, 17000, 1)])
 def test_chamfer_backward_shapes(gpu_fx, oracle, fx_option, N, M, B):
-    """LDS-accumulating adjoint (row ranges split over blocks, clouds beyond one LDS image) and the global-atomics
-    variant against the oracle's adjoint."""
+    """Atomic-free gather adjoint (inverse lists by an LDS counting sort, every row accumulated in the oracle's
+    order; row ranges split over blocks, other sides beyond one 4096-row round) is BIT-IDENTICAL to the oracle's adjoint and
+    the same run after run; the global-atomics variant stays within rounding."""
     fx = gpu_fx
     x, y = _rand((3, N, B), N + 1), _rand((3, M, B), M + 2)
     _, ix, iy = fx.chamfer_distance(x, y, return_indices=True)
     ogx, ogy = oracle.chamfer_bwd(x, y, ix.to_host(), iy.to_host(), 1.0, 0.5, 1.5)
-    for glob in ("0", "1"):
-        fx_option("bwd_global_atomics", glob)
+    for rep in range(2):
         gx, gy = fx.chamfer_distance_grad(x, y, ix, iy, w1=1.0, w2=0.5, gout=1.5)
-        assert np.allclose(gx.to_host(), ogx, rtol=1e-5, atol=1e-9)
-        assert np.allclose(gy.to_host(), ogy, rtol=1e-5, atol=1e-9)
+        assert np.array_equal(gx.to_host(), ogx), (rep, np.abs(gx.to_host() - ogx).max())
+        assert np.array_equal(gy.to_host(), ogy), (rep, np.abs(gy.to_host() - ogy).max())
+    fx_option("bwd_global_atomics", "1")
+    gx, gy = fx.chamfer_distance_grad(x, y, ix, iy, w1=1.0, w2=0.5, gout=1.5)
+    assert np.allclose(gx.to_host(), ogx, rtol=1e-5, atol=1e-9)
+    assert np.allclose(gy.to_host(), ogy, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("D", [3, 2, 5, 64])
+@pytest.mark.parametrize("kind", ["all_to_one", "clusters", "few_targets", "negative_gout"])
+def test_chamfer_backward_long_inverse_lists(gpu_fx, oracle, kind, D):
+    """Index maps with LONG inverse lists (one row the neighbour of thousands, tight clusters, lists of 9 .. 64 entries that
+    take the wave path; lists of 5 .. 8 that take the 8-network) given directly -- the adjoint takes any index arrays -- over
+    more than one 4096-row round; D = 3 (registers) and other D (the row of g is the accumulator): bit-identical to the oracle."""
+    fx = gpu_fx
+    rng = np.random.default_rng(sum(map(ord, kind)) * 131 + D)
+    N, M, B = 6000, 9001, 3
+    x = np.asfortranarray(rng.standard_normal((D, N, B)).astype(np.float32))
+    y = np.asfortranarray(rng.standard_normal((D, M, B)).astype(np.float32))
+    if kind == "all_to_one":
+        ix = np.full((N, B), 7, np.int32); iy = np.full((M, B), N - 1, np.int32)
+        ix[::3, 1] = 8999
+    elif kind == "clusters":
+        ix = rng.integers(0, 40, (N, B)).astype(np.int32) * 200
+        iy = rng.integers(0, 30, (M, B)).astype(np.int32) * 199
+    elif kind == "few_targets":
+        ix = (rng.integers(0, M // 6, (N, B)) * 6).astype(np.int32)  # lists of ~ 4 (Poisson): both networks and the wave path
+        iy = (rng.integers(0, N // 12, (M, B)) * 12).astype(np.int32)  # ~ 18 per target
+    else:
+        ix = rng.integers(0, M, (N, B)).astype(np.int32); iy = rng.integers(0, N, (M, B)).astype(np.int32)
+        x[:, :50, 0] = y[:, ix[:50, 0], 0]  # exact zeros in the own term: 0 + (-0) is +0
+    gout = -1.5 if kind == "negative_gout" else 1.0
+    ix, iy = np.asfortranarray(ix), np.asfortranarray(iy)
+    ogx, ogy = oracle.chamfer_bwd(x, y, ix, iy, 0.9, 1.1, gout)
+    gx, gy = fx.chamfer_distance_grad(x, y, fx.gpu(ix), fx.gpu(iy), w1=0.9, w2=1.1, gout=gout)
+    hx, hy = gx.to_host(), gy.to_host()
+    assert np.array_equal(hx.view(np.uint32), ogx.view(np.uint32)), np.abs(hx - ogx).max()
+    assert np.array_equal(hy.view(np.uint32), ogy.view(np.uint32)), np.abs(hy - ogy).max()
 
 
 def test_invalid_arguments_raise(gpu_fx):

@@ -97,7 +97,7 @@ def measure(cells=1400, reps=20):
     b = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_B, 3, Np, Bc))
     _, ia, ib = fx.chamfer_distance(a, b, return_indices=True)
     avg, mn, _ = kernel_ms("chamfer_bwd", lambda: fx.chamfer_distance_grad(a, b, ia, ib), reps)
-    row("chamfer_bwd_lds_kernel (B=256 N=M=4096)", 2 * (12 * Np * Bc * 2 + 4 * Np * Bc) + 2 * 12 * Np * Bc, avg, mn, "B=256 N=M=4096")
+    row("chamfer_bwd_gather_kernel (B=256 N=M=4096)", 2 * (12 * Np * Bc * 2 + 4 * Np * Bc) + 2 * 12 * Np * Bc, avg, mn, "B=256 N=M=4096")
     return out
 
 
