@@ -207,7 +207,7 @@ def main():
 
     def make_runner(mode):
         """(step, sync_all, read_loss, stream, description) for one way of running a step."""
-        if not use_dist:
+        if not use_dist or mode == "single_plain":
             s = fx.Stream.create()
             loss_dev = fx.DeviceArray.empty((1,), np.float32)
 
@@ -315,7 +315,7 @@ def main():
         t1 = time.perf_counter()
         _lib.call("fx3d_profile_enable", 0)
         elapsed = max_over_ranks(t1 - t0)
-        return {"elapsed": elapsed, "loss": read_loss(), "event_ms": e0.elapsed_ms(e1), "desc": desc,
+        return {"elapsed": elapsed, "t_local": t1 - t0, "loss": read_loss(), "event_ms": e0.elapsed_ms(e1), "desc": desc,
                 "runner": (step, sync_all, s)}
 
     def timed(mode, steps, warmup, profile_every=0, burn_ms=0.0, cold=False):
@@ -359,6 +359,10 @@ def main():
     modes = None
     if use_dist:  # the other ways of placing the collective, same steps, right after (every rank takes part)
         modes = {main_mode: {"ms_per_step": res["elapsed"] * 1e3 / args.steps, "collective": res["desc"]}}
+        if world == 1:  # --force-dist on one device: the plain single-launch loss of the same data is the reference every mode must equal
+            plain = timed("single_plain", 2, 1)
+            modes[main_mode]["loss_equal"] = bool(np.float32(plain["loss"]) == np.float32(res["loss"]))
+            modes["plain_loss"] = float(plain["loss"])
         if calibration is not None:
             modes["auto_calibration_ms_per_step"] = calibration
         for m in ("overlap", "serial", "deferred"):
@@ -366,6 +370,37 @@ def main():
                 r2 = timed(m, args.steps, min(args.warmup, 20))
                 modes[m] = {"ms_per_step": r2["elapsed"] * 1e3 / args.steps, "collective": r2["desc"],
                             "loss_equal": bool(np.float32(r2["loss"]) == np.float32(res["loss"]))}
+
+    # ---- who ran where: every rank's device identity, its own kernel average and its own time per step,
+    #      gathered over the control plane; two ranks on one physical device end the run (an N-rank line must be N devices)
+    if use_dist:
+        pci, uuid_hex = fx.device_identity(local_rank)
+        dom, bus, devfn = pci.split(":")
+        dv, fnn = devfn.split(".")
+        u32 = [int(uuid_hex[8 * i:8 * i + 8], 16) for i in range(4)]
+        local_ms = (res["t_local"] * 1e3 / args.steps) if "t_local" in res else float("nan")
+        rec = [float(int(dom, 16)), float(int(bus, 16)), float(int(dv, 16)), float(int(fnn, 16))] + [float(v) for v in u32] + \
+              [avg.value, local_ms, float(comm_info["nranks"]), float(local_rank), float(res["event_ms"] / args.steps)]
+        if native_comm is not None:
+            table = native_comm.allgather_f64(rec)
+        else:
+            t = torch.tensor(rec, dtype=torch.float64, device="cuda")
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            table = np.stack([q.cpu().numpy() for q in parts])
+        ranks = []
+        for r in range(world):
+            row = table[r]
+            ranks.append({"rank": r, "pci_bus_id": "%04x:%02x:%02x.%x" % tuple(int(v) for v in row[:4]),
+                          "device_uuid": "".join("%08x" % int(v) for v in row[4:8]), "kernel_avg_ms": row[8], "ms_per_step_local": row[9],
+                          "comm_nranks": int(row[10]), "local_device_index": int(row[11]), "stream_event_ms_per_step": row[12]})
+        ids = [(q["pci_bus_id"], q["device_uuid"]) for q in ranks]
+        if len(set(ids)) != world:
+            raise SystemExit(f"[bench] {world} ranks on {len(set(ids))} distinct devices: {ids}")
+        if any(q["comm_nranks"] != world for q in ranks):
+            raise SystemExit(f"[bench] a rank's communicator does not span {world} ranks: {[q['comm_nranks'] for q in ranks]}")
+        comm_info["ranks"] = ranks
+        comm_info["distinct_devices"] = len(set(ids))
 
     if rank != 0:
         if dist is not None:

@@ -13,7 +13,7 @@ from . import _lib
 _lib.load()  # fail loudly (ImportError) if the HIP library has not been built
 
 from ._lib import Flux3DHipError, LIB_PATH  # noqa: E402
-from .device import (DeviceArray, Event, Graph, Stream, cpu, current_stream, device_count,  # noqa: E402
+from .device import (DeviceArray, Event, Graph, Stream, cpu, current_stream, device_count, device_identity,  # noqa: E402
                      device_name, empty_cache, functional, gpu, set_device, stream, synchronize)
 from .rep import (PointCloud, TriMesh, get_edges_packed, get_edges_to_key, get_faces_list,  # noqa: E402
                   get_faces_packed, get_faces_padded, get_faces_to_edges_packed,

@@ -235,6 +235,15 @@ fx3d_status fx3d_device_name(int32_t dev, char *buf, size_t n) {
     return FX3D_OK;
 }
 
+fx3d_status fx3d_device_identity(int32_t dev, char *pci_bus_id, size_t n, uint8_t *uuid16) {
+    FX3D_REQUIRE(pci_bus_id && n >= 16 && uuid16, "fx3d_device_identity: null / short buffer");
+    FX3D_HIP(hipDeviceGetPCIBusId(pci_bus_id, (int)n, dev));
+    hipDeviceProp_t p;
+    FX3D_HIP(hipGetDeviceProperties(&p, dev));
+    memcpy(uuid16, p.uuid.bytes, 16);
+    return FX3D_OK;
+}
+
 fx3d_status fx3d_device_sync(void) {
     FX3D_HIP(hipDeviceSynchronize());
     return FX3D_OK;

@@ -37,6 +37,14 @@ def device_name(dev=0):
     return buf.value.decode()
 
 
+def device_identity(dev=0):
+    """(pci_bus_id, uuid_hex) of device ``dev``: which physical GPU a rank sits on (bench.py ``comm.ranks``)."""
+    buf = C.create_string_buffer(64)
+    uuid = (C.c_uint8 * 16)()
+    _lib.call("fx3d_device_identity", int(dev), buf, 64, uuid)
+    return buf.value.decode(), bytes(uuid).hex()
+
+
 def synchronize():
     _lib.call("fx3d_device_sync")
 

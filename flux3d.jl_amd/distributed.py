@@ -176,6 +176,16 @@ class NativeComm:
     def barrier(self):
         self.max_over_ranks(0.0)
 
+    def allgather_f64(self, values):
+        """Host vector of K doubles per rank -> (nranks, K) array on every rank: an all-reduce(sum) of a zeroed table in
+        which every rank fills its own row (the control plane's gather; K is tiny)."""
+        v = np.asarray(values, np.float64).ravel()
+        table = np.zeros((v.size, self.world_size), np.float64, order="F")  # column r = rank r's record
+        table[:, self.rank] = v
+        buf = DeviceArray.from_host(table)
+        self.allreduce_sum(buf)
+        return np.ascontiguousarray(buf.to_host().T)
+
     def __del__(self):
         if getattr(self, "handle", None):
             try:

@@ -931,6 +931,12 @@ function device_name(dev::Integer = current_device())
     check(@ccall LIB.fx3d_device_name(dev::Int32, buf::Ptr{UInt8}, length(buf)::Csize_t)::Int32)
     return unsafe_string(pointer(buf))
 end
+# (PCI bus id, 16 UUID bytes) of a device: what a multi-process run gathers per rank to prove N ranks sat on N devices
+function device_identity(dev::Integer = current_device())
+    buf = Vector{UInt8}(undef, 64); uuid = Vector{UInt8}(undef, 16)
+    check(@ccall LIB.fx3d_device_identity(dev::Int32, buf::Ptr{UInt8}, length(buf)::Csize_t, uuid::Ptr{UInt8})::Int32)
+    return unsafe_string(pointer(buf)), uuid
+end
 device_synchronize() = check(@ccall LIB.fx3d_device_sync()::Int32)
 function stream_create()
     s = Ref{Stream}(C_NULL); check(@ccall LIB.fx3d_stream_create(s::Ref{Stream})::Int32); return s[]

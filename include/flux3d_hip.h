@@ -71,6 +71,10 @@ FX3D_API fx3d_status fx3d_device_count(int32_t *n);
 FX3D_API fx3d_status fx3d_set_device(int32_t dev);
 FX3D_API fx3d_status fx3d_get_device(int32_t *dev);
 FX3D_API fx3d_status fx3d_device_name(int32_t dev, char *buf, size_t n);
+/* Which physical device `dev` is: its PCI bus id ("0000:c5:00.0", hipDeviceGetPCIBusId) and the 16 bytes of its UUID
+ * (hipDeviceProp_t::uuid) -- what a multi-process run gathers per rank to PROVE that N ranks sat on N devices
+ * (bench.py `comm.ranks`; the reference has no multi-device code). */
+FX3D_API fx3d_status fx3d_device_identity(int32_t dev, char *pci_bus_id, size_t n, uint8_t *uuid16);
 FX3D_API fx3d_status fx3d_device_sync(void);
 FX3D_API fx3d_status fx3d_malloc(void **dev_ptr, size_t bytes);
 FX3D_API fx3d_status fx3d_free(void *dev_ptr);

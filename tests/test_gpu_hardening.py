@@ -1076,6 +1076,16 @@ def test_bench_line_force_dist_equals_plain_and_roofline_is_a_fraction(gpu_fx):
         assert roof["algorithmic_fp32_over_valu_peak"] > 0
     assert np.float32(plain["loss"]) == np.float32(forced["loss"])
     assert plain["config"]["workload"] == forced["config"]["workload"] and forced["comm"]["nranks"] == 1
+    # the N-rank line is self-proving -- per rank the physical device, its own kernel average and time per step, the
+    # communicator's size; every placement of the collective reports whether its loss equals the plain single-launch loss
+    ranks = forced["comm"]["ranks"]
+    assert len(ranks) == 1 and forced["comm"]["distinct_devices"] == 1 and ranks[0]["comm_nranks"] == 1
+    assert ranks[0]["pci_bus_id"] == gpu_fx.device_identity(0)[0] and ranks[0]["device_uuid"] == gpu_fx.device_identity(0)[1]
+    assert 0.02 < ranks[0]["kernel_avg_ms"] < 0.2 and 0.02 < ranks[0]["ms_per_step_local"] < 0.5
+    modes = forced["modes"]
+    assert np.float32(modes["plain_loss"]) == np.float32(plain["loss"])
+    for m in ("serial", "overlap", "deferred"):
+        assert modes[m]["loss_equal"] is True, (m, modes[m])
     assert 0.5 < forced["value"] / plain["value"] < 2.0
     if gpu_fx.device_count() < 2:
         r = subprocess.run([sys.executable, bench, "--gpus", "2"] + common, env=env, capture_output=True, text=True, timeout=600)
