@@ -85,6 +85,9 @@ SIGNATURES = {
     "fx3d_edge_features": [vp, c_i32, c_i32, c_i32, c_i32, vp, c_i32, vp, vp],
     "fx3d_edge_features_bwd": [vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, vp],
     "fx3d_edgeconv_graph": [vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, vp, vp],
+    "fx3d_index_convert": [vp, c_i32, c_i32, c_i64, c_i32, c_i64, vp, vp, vp],
+    "fx3d_index_upload_workspace_bytes": [c_i32, c_i64, C.POINTER(sz)],
+    "fx3d_index_upload": [vp, c_i32, c_i32, c_i64, c_i32, c_i64, vp, vp, vp, sz, vp],
     "fx3d_faces_areas_packed": [vp, c_i64, vp, c_i64, vp, vp],
     "fx3d_faces_areas_padded": [vp, c_i32, vp, c_i32, vp, c_i32, vp, vp],
     "fx3d_sample_points_explicit": [vp, c_i32, vp, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp],

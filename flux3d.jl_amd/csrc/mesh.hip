@@ -875,3 +875,70 @@ fx3d_status fx3d_laplacian_loss_bwd_sym(const float *verts, int64_t V, const int
 }
 
 }  // extern "C"
+
+// ---- the reference's index arrays -> int32 0-based on the device (include/flux3d_hip.h: fx3d_index_convert) -----------------
+namespace {
+template <typename IT>
+__global__ __launch_bounds__(kThreads) void index_convert_kernel(const IT *__restrict__ src, long long n, long long base, int clamp_pad,
+                                                                 long long limit, int32_t *__restrict__ dst, unsigned int *bad) {
+    unsigned int nbad = 0;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        long long v = (long long)src[i] - base;
+        if (v < 0 && clamp_pad) v = 0;  // padding
+        else if (limit > 0 && (v < 0 || v >= limit)) { v = 0; ++nbad; }
+        dst[i] = (int32_t)v;
+    }
+    if (bad && nbad) atomicAdd(bad, nbad);
+}
+size_t index_elem_bytes(int t) { return t == FX3D_IDX_I64 ? 8 : 4; }
+}  // namespace
+
+extern "C" {
+
+fx3d_status fx3d_index_convert(const void *src_dev, int32_t index_type, int32_t index_base, int64_t count, int32_t clamp_pad,
+                               int64_t limit, int32_t *dst_dev, uint32_t *bad_dev, fx3d_stream_t s) {
+    FX3D_REQUIRE(index_type == FX3D_IDX_I32 || index_type == FX3D_IDX_U32 || index_type == FX3D_IDX_I64,
+                 "fx3d_index_convert: index_type %d (FX3D_IDX_I32 / _U32 / _I64)", index_type);
+    FX3D_REQUIRE(count >= 0 && limit >= 0 && limit <= (1ll << 31), "fx3d_index_convert: bad count / limit");
+    if (count == 0) return FX3D_OK;
+    FX3D_REQUIRE(src_dev && dst_dev, "fx3d_index_convert: null pointer");
+    hipStream_t st = as_stream(s);
+    const dim3 g(grid_for(count)), b(kThreads);
+    if (index_type == FX3D_IDX_I64)
+        hipLaunchKernelGGL(index_convert_kernel<long long>, g, b, 0, st, static_cast<const long long *>(src_dev), (long long)count,
+                           (long long)index_base, clamp_pad, (long long)limit, dst_dev, bad_dev);
+    else if (index_type == FX3D_IDX_U32)
+        hipLaunchKernelGGL(index_convert_kernel<unsigned int>, g, b, 0, st, static_cast<const unsigned int *>(src_dev), (long long)count,
+                           (long long)index_base, clamp_pad, (long long)limit, dst_dev, bad_dev);
+    else
+        hipLaunchKernelGGL(index_convert_kernel<int>, g, b, 0, st, static_cast<const int *>(src_dev), (long long)count,
+                           (long long)index_base, clamp_pad, (long long)limit, dst_dev, bad_dev);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_index_upload_workspace_bytes(int32_t index_type, int64_t count, size_t *bytes) {
+    FX3D_REQUIRE(bytes && count >= 0, "fx3d_index_upload_workspace_bytes: bad argument");
+    FX3D_REQUIRE(index_type == FX3D_IDX_I32 || index_type == FX3D_IDX_U32 || index_type == FX3D_IDX_I64,
+                 "fx3d_index_upload_workspace_bytes: index_type %d", index_type);
+    *bytes = index_elem_bytes(index_type) * (size_t)count;
+    return FX3D_OK;
+}
+
+fx3d_status fx3d_index_upload(const void *src_host, int32_t index_type, int32_t index_base, int64_t count, int32_t clamp_pad,
+                              int64_t limit, int32_t *dst_dev, uint32_t *bad_dev, void *ws, size_t ws_bytes, fx3d_stream_t s) {
+    size_t need = 0;
+    const fx3d_status rc = fx3d_index_upload_workspace_bytes(index_type, count, &need);
+    if (rc) return rc;
+    if (count == 0) return FX3D_OK;
+    FX3D_REQUIRE(src_host && dst_dev, "fx3d_index_upload: null pointer");
+    if (!ws || ws_bytes < need) { set_error("fx3d_index_upload: workspace too small (%zu < %zu bytes)", ws ? ws_bytes : (size_t)0, need); return FX3D_ERR_WORKSPACE; }
+    hipStream_t st = as_stream(s);
+    FX3D_HIP(hipMemcpyAsync(ws, src_host, need, hipMemcpyHostToDevice, st));
+    const fx3d_status crc = fx3d_index_convert(ws, index_type, index_base, count, clamp_pad, limit, dst_dev, bad_dev, s);
+    if (crc) return crc;
+    FX3D_HIP(hipStreamSynchronize(st));  // pageable host memory: blocking, like fx3d_memcpy_h2d
+    return FX3D_OK;
+}
+
+}  // extern "C"

@@ -451,11 +451,37 @@ end
 # ---- TriMesh device mirrors: int32 0-based copies of the host integer data (cached per mesh) ---
 const _mirror = WeakKeyDict{Any,Dict{Symbol,Any}}()
 mirror(m::TriMesh) = get!(() -> Dict{Symbol,Any}(), _mirror, m)
-dev_i32(a) = hip(Int32.(a .- 1))
-faces_padded_dev(m) = get!(() -> hip(Int32.(max.(Int64.(get_faces_padded(m)) .- 1, 0))), mirror(m), :faces_padded)
+# The reference's index arrays cross the ABI AS THEY ARE (`R` in {UInt32, Int64}, 1-based: src/rep/mesh.jl:70-98): the library
+# stages the bytes and converts to its device form (Int32, 0-based) with one small kernel -- no host-side `Int32.(a .- 1)` pass.
+# `clamp_pad`: the 0 padding of faces_padded becomes 0 (never dereferenced); `limit`: values outside [0, limit) are an error.
+const IDX_I32 = Int32(0); const IDX_U32 = Int32(1); const IDX_I64 = Int32(2)
+index_type(::Type{Int32}) = IDX_I32; index_type(::Type{UInt32}) = IDX_U32; index_type(::Type{Int64}) = IDX_I64
+function index_upload(a::Array{R}; base::Integer = 1, clamp_pad::Bool = false, limit::Integer = 0) where {R<:Union{Int32,UInt32,Int64}}
+    out = HipArray{Int32}(undef, size(a)...)
+    isempty(a) && return out
+    nb = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_index_upload_workspace_bytes(index_type(R)::Int32, length(a)::Int64, nb::Ref{Csize_t})::Int32)
+    ws = HipArray{UInt8}(undef, Int(nb[])); bad = fill!(HipArray{UInt32}(undef, 1), 0)
+    check(@ccall LIB.fx3d_index_upload(a::Ptr{Cvoid}, index_type(R)::Int32, Int32(base)::Int32, length(a)::Int64, Int32(clamp_pad)::Int32,
+                                       Int64(limit)::Int64, out.ptr::Ptr{Cvoid}, bad.ptr::Ptr{Cvoid}, ws.ptr::Ptr{Cvoid},
+                                       length(ws)::Csize_t, DEFAULT_STREAM::Stream)::Int32)
+    nbad = unhip(bad)[1]
+    nbad == 0 || throw(ArgumentError("index_upload: $nbad indices outside [0, $limit) after subtracting $base"))
+    return out
+end
+index_upload(a::AbstractArray{<:Integer}; kw...) = index_upload(Array{Int64}(a); kw...)
+# the same conversion for an index array that already lives on the device (e.g. faces a HipArray pipeline produced)
+function index_convert(a::HipArray{R}; base::Integer = 1, clamp_pad::Bool = false, limit::Integer = 0) where {R<:Union{Int32,UInt32,Int64}}
+    out = HipArray{Int32}(undef, size(a)...)
+    check(@ccall LIB.fx3d_index_convert(a.ptr::Ptr{Cvoid}, index_type(R)::Int32, Int32(base)::Int32, length(a)::Int64,
+                                        Int32(clamp_pad)::Int32, Int64(limit)::Int64, out.ptr::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
+                                        DEFAULT_STREAM::Stream)::Int32)
+    return out
+end
+faces_padded_dev(m) = get!(() -> index_upload(get_faces_padded(m); clamp_pad = true, limit = m.V), mirror(m), :faces_padded)
 faces_len_dev(m) = get!(() -> hip(Int32.(m._faces_len)), mirror(m), :faces_len)
-faces_packed_dev(m) = get!(() -> hip(Int32.(Int64.(get_faces_packed(m)) .- 1)), mirror(m), :faces_packed)
-edges_dev(m) = get!(() -> dev_i32(get_edges_packed(m)), mirror(m), :edges)          # (E,2) column-major
+faces_packed_dev(m) = get!(() -> index_upload(get_faces_packed(m); limit = sum(m._verts_len)), mirror(m), :faces_packed)
+edges_dev(m) = get!(() -> index_upload(get_edges_packed(m); limit = sum(m._verts_len)), mirror(m), :edges)          # (E,2) column-major
 function laplacian_csr_dev(m)
     get!(mirror(m), :lap) do
         # CSR of L == CSC of L' ; build from the reference's own cached SparseMatrixCSC (src/rep/mesh.jl:559-565)

@@ -133,6 +133,32 @@ def _auxiliary_mesh(lst):
 
 
 # ---------------------------------------------------------------------------------------- TriMesh
+_IDX_TYPES = {np.dtype(np.int32): 0, np.dtype(np.uint32): 1, np.dtype(np.int64): 2}
+
+
+def index_upload(arr, index_base, clamp_pad=False, limit=0):
+    """Host index array of one of the reference's types (UInt32 / Int64, or Int32; src/rep/mesh.jl:70-98) -> device int32
+    0-based of the same (column-major) shape through fx3d_index_upload: the conversion runs on the device.  ``limit`` > 0:
+    values outside [0, limit) raise (counted on the device)."""
+    a = np.asfortranarray(arr)
+    if a.dtype not in _IDX_TYPES:
+        a = a.astype(np.int64)
+    t = _IDX_TYPES[a.dtype]
+    out = DeviceArray.empty(a.shape, np.int32)
+    if a.size == 0:
+        return out
+    n = C.c_size_t(0)
+    _lib.call("fx3d_index_upload_workspace_bytes", t, int(a.size), C.byref(n))
+    ws = DeviceArray.empty((n.value,), np.uint8)
+    bad = DeviceArray.zeros((1,), np.uint32)
+    _lib.call("fx3d_index_upload", a.ctypes.data, t, int(index_base), int(a.size), int(bool(clamp_pad)), int(limit), out.ptr, bad.ptr,
+              ws.ptr, ws.nbytes, current_stream().handle)
+    nbad = int(bad.to_host()[0])
+    if nbad:
+        raise ValueError(f"index_upload: {nbad} indices outside [0, {limit}) after subtracting index_base={index_base}")
+    return out
+
+
 class TriMesh:
     """TriMesh(verts_list, faces_list; offset=-1) -- src/rep/mesh.jl:70-187.
 
@@ -365,16 +391,14 @@ class TriMesh:
             arr = DeviceArray.from_host(self.get_verts_packed_host())
         elif name == "verts_padded":
             arr = DeviceArray.from_host(self.get_verts_padded_host())
-        elif name == "faces_packed":
-            arr = DeviceArray.from_host((self.get_faces_packed().astype(np.int64) - b).astype(np.int32))
-        elif name == "faces_padded":
-            fp = self.get_faces_padded().astype(np.int64) - b
-            fp[fp < 0] = 0  # pad entries (value 0 in the reference) are never dereferenced
-            arr = DeviceArray.from_host(fp.astype(np.int32))
+        elif name == "faces_packed":   # the reference's own arrays (UInt32 / Int64, 1-based) cross the ABI untouched: the
+            arr = index_upload(self.get_faces_packed(), b, limit=int(np.sum(self._verts_len)))   # library converts on the device
+        elif name == "faces_padded":    # (pad entries -- value 0 in the reference -- become 0: never dereferenced)
+            arr = index_upload(self.get_faces_padded(), b, clamp_pad=True, limit=int(self.V))
         elif name == "faces_len":
             arr = DeviceArray.from_host(self._faces_len.astype(np.int32))
         elif name == "edges":
-            arr = DeviceArray.from_host((self.get_edges_packed().astype(np.int64) - b).astype(np.int32))
+            arr = index_upload(self.get_edges_packed(), b, limit=int(np.sum(self._verts_len)))
         elif name in ("lap_rowptr", "lap_colind", "lap_vals"):
             rowptr, colind, vals = self.get_laplacian_packed()
             store["lap_rowptr"] = DeviceArray.from_host(rowptr)

@@ -243,10 +243,29 @@ FX3D_API fx3d_status fx3d_edgeconv_graph(const float *x, int32_t N, int32_t B, i
                                          int32_t layout, int32_t *idx, float *out, fx3d_stream_t s);
 
 /* ---- TriMesh kernels --------------------------------------------------------------------------
- * Faces/edges cross the ABI as int32, 0-based (the shim converts the reference's 1-based
- * UInt32/Int64, src/rep/mesh.jl:87-89).  verts_packed (3,sumV); faces_packed (3,sumF) global
+ * The kernels read faces/edges as int32, 0-based; the reference's 1-based UInt32 / Int64 arrays (src/rep/mesh.jl:87-89)
+ * enter through fx3d_index_upload / fx3d_index_convert below (converted on the device, cached with the mesh).  verts_packed (3,sumV); faces_packed (3,sumF) global
  * ids; verts_padded (3,Vmax,B) zero padded; faces_padded (3,Fmax,B) mesh-local ids (pad entries
  * ignored); faces_len (B) int32 -- all device. */
+
+/* The reference's index arrays as they are (src/rep/mesh.jl:70-98: `TriMesh{T,R}` with R in {UInt32, Int64}, 1-based;
+ * faces_packed / faces_padded / edges_packed, :884-896) -> the library's device form, int32 0-based, converted ON THE
+ * DEVICE (one small kernel): the host passes `m._faces_packed` untouched, once per mesh, and keeps the result with it.
+ *   index_type   FX3D_IDX_I32 / FX3D_IDX_U32 / FX3D_IDX_I64 (element type of src)
+ *   index_base   subtracted from every element (1 for the reference's arrays, 0 for 0-based ones)
+ *   clamp_pad    1: elements below index_base (the 0 padding of faces_padded) become 0 instead of -1
+ *   limit        > 0: converted values must lie in [0, limit) (pad entries excepted); violations are COUNTED in *bad_dev
+ *                (optional caller-zeroed device counter) and stored as 0 -- a kernel never dereferences them
+ * fx3d_index_upload: src is HOST memory (count elements); staged through ws (fx3d_index_upload_workspace_bytes, device)
+ * and converted there; blocking like fx3d_memcpy_h2d.  fx3d_index_convert: src is device memory. */
+typedef enum { FX3D_IDX_I32 = 0, FX3D_IDX_U32 = 1, FX3D_IDX_I64 = 2 } fx3d_index_type;
+FX3D_API fx3d_status fx3d_index_convert(const void *src_dev, int32_t index_type, int32_t index_base, int64_t count,
+                                        int32_t clamp_pad, int64_t limit, int32_t *dst_dev, uint32_t *bad_dev,
+                                        fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_index_upload_workspace_bytes(int32_t index_type, int64_t count, size_t *bytes);
+FX3D_API fx3d_status fx3d_index_upload(const void *src_host, int32_t index_type, int32_t index_base, int64_t count,
+                                       int32_t clamp_pad, int64_t limit, int32_t *dst_dev, uint32_t *bad_dev,
+                                       void *ws, size_t ws_bytes, fx3d_stream_t s);
 
 /* compute_faces_areas_packed (src/rep/mesh.jl:765-780): areas (sumF). */
 FX3D_API fx3d_status fx3d_faces_areas_packed(const float *verts, int64_t V, const int32_t *faces,
