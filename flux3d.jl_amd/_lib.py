@@ -35,6 +35,7 @@ SIGNATURES = {
     "fx3d_set_device": [c_i32],
     "fx3d_get_device": [C.POINTER(c_i32)],
     "fx3d_device_name": [c_i32, C.c_char_p, sz],
+    "fx3d_nn1_plan_describe": [c_i32, c_i32, c_i32, c_i32, C.c_char_p, sz],
     "fx3d_device_identity": [c_i32, C.c_char_p, sz, C.c_void_p],
     "fx3d_device_sync": [],
     "fx3d_malloc": [C.POINTER(vp), sz],

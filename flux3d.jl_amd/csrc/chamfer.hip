@@ -75,6 +75,7 @@ struct Nn1Params {
     int nsplit;                  // 1 = off
     unsigned long long *gres;    // [nsplit][2B][qstride] packed (d_bits << 32 | index): every split block stores its own row (no init, no atomics)
     int qstride;
+    int fuse_split;              // 1: the last block of a query tile's chunk subsets merges their rows itself (arrival counters in the ticket slot's spare words)
     int tail;                    // > 0: a cloud of chunk + (1 .. tail) points is ONE chunk + a tail every query evaluates exactly
 };
 
@@ -954,8 +955,15 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     const unsigned long long r = qres[jq];
                     const float dd = __builtin_bit_cast(float, (unsigned int)(r >> 32));
                     const int ii = (int)(unsigned int)r;
-                    if (p.nsplit > 1) {  // this chunk subset's row; the finalize kernel takes the minimum over the subsets
-                        if (qi < NQ) p.gres[((size_t)split * 2 * p.B + c) * p.qstride + qi] = r;
+                    if (p.nsplit > 1) {  // this chunk subset's row; the finalize kernel (or, fused, the tile's last subset) takes the
+                                         // minimum over the subsets.  Fused: a write-through (agent-scope) store -- the reader may sit
+                                         // on another XCD, behind another L2; a device-wide fence instead costs a whole L2 write-back
+                                         // per block (measured: 32 -> 94 us)
+                        unsigned long long *gp = &p.gres[((size_t)split * 2 * p.B + c) * p.qstride + qi];
+                        if (qi < NQ) {
+                            if (p.fuse_split) __hip_atomic_store(gp, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            else *gp = r;
+                        }
                     } else if (qi < NQ) {
                         if (WANT_IDX && idx_out) idx_out[(size_t)b * NQ + qi] = ii;
                         if (dmin_out) dmin_out[(size_t)b * NQ + qi] = dd;
@@ -967,6 +975,39 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         }
     }
     FX3D_PROBE_MARK(11);
+    if (p.nsplit > 1 && p.fuse_split) {
+        // ---- candidate-split run, merge fused (round 5): the chunk subsets of one query tile arrive at a counter of their own
+        //      (a spare word of the launch's ticket slot: zero between launches, the last arriver returns it to zero); the last one
+        //      takes the 64-bit minimum over the subsets' rows -- (distance bits, index): `isless`, then the lowest index --, writes
+        //      the outputs and is the only one of them to deliver a partial.  One launch instead of two (the second one was a
+        //      dependent launch of ~6 us behind a 26 us kernel at C3's shape, 8 x 5000 x 5000).
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores of its gres rows have left the CU
+        __syncthreads();
+        const int ns = (NC + CH - 1) / CH < p.nsplit ? (NC + CH - 1) / CH : p.nsplit;  // subsets that exist for this direction
+        if (tid == 0) {
+            const unsigned int t = (unsigned int)c * (unsigned int)p.tiles + (unsigned int)tile;
+            unsigned int *ctr = p.ticket + (t / 15u) * 16u + 1u + t % 15u;
+            const unsigned int old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == (unsigned int)ns - 1u;
+            if (s_last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!s_last) return;  // (block-uniform)
+        acc = 0.0;
+        const int qend = (tile + 1) * tpb * QB < NQ ? (tile + 1) * tpb * QB : NQ;
+        for (int q = tile * tpb * QB + tid; q < qend; q += kHThreads) {
+            unsigned long long r = __hip_atomic_load(&p.gres[(size_t)c * p.qstride + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int sp = 1; sp < ns; ++sp) {
+                const unsigned long long o = __hip_atomic_load(&p.gres[((size_t)sp * 2 * p.B + c) * p.qstride + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                r = o < r ? o : r;
+            }
+            const float dd = __builtin_bit_cast(float, (unsigned int)(r >> 32));
+            if (idx_out) idx_out[(size_t)b * NQ + q] = (int)(unsigned int)r;
+            if (dmin_out) dmin_out[(size_t)b * NQ + q] = dd;
+            acc += (double)dd;
+        }
+    }
     if (p.partials) {
         __shared__ double sm[kHThreads / 64];
         const double tot = block_sum<kHThreads>(acc, sm);
@@ -1500,6 +1541,7 @@ fx3d_status check_shapes(const char *fn, const void *x, int N, const void *y, in
     return FX3D_OK;
 }
 
+constexpr long long kSplitFuseMax = 255;  // tile counters of a fused split run: the 15 spare words of each of a ticket slot's 17 lines
 struct Fused {
     unsigned int *ticket;
     unsigned int nvalid;
@@ -1517,6 +1559,7 @@ fx3d_status run_nn1(const float *x, int N, const float *y, int M, int B, int D, 
     p.nsplit = gres ? pl.nsplit : 1;
     p.gres = gres;
     p.qstride = qstride;
+    p.fuse_split = gres && fu && fu->ticket ? 1 : 0;  // (the caller checked that the tile counters fit the ticket slot)
     if (fu) {
         p.ticket = fu->ticket; p.nvalid = fu->nvalid; p.sums_out = fu->sums_out; p.loss_out = fu->loss_out;
         p.w1 = fu->w1; p.w2 = fu->w2; p.Bg = fu->Bg;
@@ -1634,6 +1677,15 @@ fx3d_status fx3d_nn1(const float *x, int32_t N, const float *y, int32_t M, int32
     return run_nn1(x, N, y, M, B, D, idx_x, idx_y, dmin_x, dmin_y, nullptr, pl, as_stream(s));
 }
 
+fx3d_status fx3d_nn1_plan_describe(int32_t N, int32_t M, int32_t B, int32_t D, char *buf, size_t n) {
+    FX3D_REQUIRE(buf && n > 0, "fx3d_nn1_plan_describe: null buffer");
+    FX3D_REQUIRE(N > 0 && M > 0 && B > 0 && D > 0, "fx3d_nn1_plan_describe: empty problem");
+    const Plan pl = make_plan(N, M, B, D);
+    snprintf(buf, n, "variant=%d threads=%d chunk=%d nsplit=%d tpb=%d tpb_y=%d tiles_x=%d tiles_y=%d grid=%d tail=%d lds=%zu",
+             pl.variant, pl.threads, pl.chunk, pl.nsplit, pl.tpb, pl.tpb_y, pl.tiles_x, pl.tiles_y, pl.grid, pl.tail, pl.lds_bytes);
+    return FX3D_OK;
+}
+
 fx3d_status fx3d_chamfer_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_t D, size_t *bytes) {
     FX3D_REQUIRE(bytes, "fx3d_chamfer_workspace_bytes: null output");
     FX3D_REQUIRE(N > 0 && M > 0 && B > 0 && D > 0, "fx3d_chamfer_workspace_bytes: empty input");
@@ -1681,6 +1733,16 @@ static fx3d_status chamfer_common(const float *x, int N, const float *y, int M, 
         // few large clouds: chunk subsets run in parallel blocks, each stores its per-query result row in gres (plain
         // stores: no memset node, no atomics), the finalize kernel merges the rows
         unsigned long long *gres = reinterpret_cast<unsigned long long *>(partials + (size_t)2 * B * tiles_f + 2);
+        if (2ll * B * pl.tiles <= kSplitFuseMax) {
+            // one launch: the last chunk subset of every query tile merges (tile counters in the ticket slot's spare words), the
+            // last of those blocks reduces the partials (layout of the one-chunk path: pl.tiles entries per (direction, cloud))
+            fx3d_status trc = FX3D_OK;
+            unsigned int *ticket = ticket_slot(&trc, st);
+            if (!ticket) return trc;
+            Fused fu{ticket, (unsigned int)((long long)B * pl.tiles_x + (long long)B * pl.tiles_y),
+                     sums_dev ? sums_dev : partials + (size_t)2 * B * tiles_f, loss_dev, w1, w2, Bg};
+            return run_nn1(x, N, y, M, B, D, idx_x, idx_y, nullptr, nullptr, partials, pl, st, &fu, gres, maxq);
+        }
         rc = run_nn1(x, N, y, M, B, D, nullptr, nullptr, nullptr, nullptr, nullptr, pl, st, nullptr, gres, maxq);
         if (rc) return rc;
         Nn1Params fp{};

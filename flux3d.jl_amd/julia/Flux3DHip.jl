@@ -294,6 +294,13 @@ function _nearest_neighbors(x::HipArray{Float32,3}, y::HipArray{Float32,3})
     return nn_for_x, nn_for_y
 end
 
+# which launch plan the library takes for a problem size (text; tools / bug reports)
+function nn1_plan_describe(N::Integer, M::Integer, B::Integer, D::Integer = 3)
+    buf = Vector{UInt8}(undef, 256)
+    check(@ccall LIB.fx3d_nn1_plan_describe(N::Int32, M::Int32, B::Int32, D::Int32, buf::Ptr{UInt8}, length(buf)::Csize_t)::Int32)
+    return unsafe_string(pointer(buf))
+end
+
 # fused forward (never materialises indices on the host): replaces :39-52 for HipArray storage
 function _chamfer_fwd(A::HipArray{Float32,3}, B::HipArray{Float32,3}, w1::Float32, w2::Float32; indices::Bool = false)
     D, N, Bn = size(A); _, M, _ = size(B)

@@ -126,6 +126,10 @@ FX3D_API fx3d_status fx3d_nn1(const float *x, int32_t N, const float *y, int32_t
                               int32_t D, int32_t *idx_x, int32_t *idx_y, float *dmin_x,
                               float *dmin_y, fx3d_stream_t s);
 
+/* The launch plan fx3d_nn1 / fx3d_chamfer_* take for this problem size on the current device, as text (kernel variant,
+ * candidates per LDS image, chunk subsets per query tile, query passes per block, grid): for tools and bug reports. */
+FX3D_API fx3d_status fx3d_nn1_plan_describe(int32_t N, int32_t M, int32_t B, int32_t D, char *buf, size_t n);
+
 /* Scratch needed by the chamfer entry points below (bytes). */
 FX3D_API fx3d_status fx3d_chamfer_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_t D,
                                                   size_t *bytes);
