@@ -201,7 +201,7 @@ def options():
 
 
 class option:
-    """``with option("knn_f32", 1): ...`` -- set for the block, restored afterwards (process-wide: not for concurrent use)."""
+    """``with option("knn_no_mfma", 1): ...`` -- set for the block, restored afterwards (process-wide: not for concurrent use)."""
 
     def __init__(self, name, value):
         self.name, self.value = name, value

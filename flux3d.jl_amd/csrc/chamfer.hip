@@ -1,26 +1,30 @@
-// Nearest-neighbour + chamfer kernels (gfx950).
+// Nearest-neighbour + chamfer forward kernels (gfx950).  (The adjoints live in chamfer_bwd.hip.)
 //
-// Replaces _nearest_neighbors(::CuArray,::CuArray) + the gather/mean of _chamfer_distance
-// (src/metrics/pcloud.jl:39-52, 72-86): instead of materialising the (N,M,B) matrix P and running
-// two argmin passes over it, one launch streams every reference cloud through LDS once per query
-// tile and keeps the running minimum in registers.  HBM traffic is O((N+M)*B); the kernel is
-// bound by fp32 VALU issue (DESIGN.md "Roofline").
+// Replaces _nearest_neighbors(::CuArray,::CuArray) + the gather / mean of _chamfer_distance (src/metrics/pcloud.jl:39-52,
+// 72-86): the reference materialises the (N,M,B) matrix and runs two argmin passes over it; here every cloud is read from HBM
+// once per launch (O((N + M) B) bytes, measured 1.09 x that) and the N x M x B matrix never exists.  Results are the CPU
+// method's (src/metrics/pcloud.jl:54-70 via NearestNeighbors' Euclidean), bit for bit:
+//   d = ((dx dx) + dy dy) + dz dz  in Float32, no fused multiply-add (-ffp-contract=off), ordered like Julia's `isless`,
+//   lowest index on ties  ==  oracle/flux3d_oracle.c: nn1_dir.
 //
-// Arithmetic is the CPU method's (src/metrics/pcloud.jl:54-70 via NearestNeighbors' Euclidean):
-//   d = ((dx*dx) + dy*dy) + dz*dz   in Float32, no fused multiply-add (-ffp-contract=off),
-//   lowest index wins ties  =>  indices are bit-identical to oracle/flux3d_oracle.c:nn1_dir.
-//
-// Structure of nn1_small_d_kernel<DIM,R>:
-//   * block = 256 threads (4 wave64); each thread owns R query points in registers.
-//   * the reference cloud is staged chunk-wise into LDS as structure-of-arrays (x[],y[],z[]):
-//     every lane reads the SAME address (ds_read_b128 broadcast of 4 consecutive x's), so LDS
-//     reads are conflict-free and cost 3 instructions per 4 candidates per wave.
-//   * candidates are consumed in tiles of T=32: the tile minimum is folded with v_min3_f32
-//     (0.5 instruction per pair instead of compare+2 selects), and only once per tile the
-//     running (best, best_tile) is updated.  The argmin is recovered by re-scanning the single
-//     winning tile from LDS (1/128 of the work at M=4096) with the reference's strict `<`.
-//   * grid is 1-D and XCD-aware: block L runs on XCD L%8 (MI355X_MICROARCH.md), so all query
-//     tiles of one (direction,batch) cloud are given ids with equal L%8 and share that XCD's L2.
+// Kernels, by the launch plan's choice (make_plan; fx3d_nn1_plan_describe prints it):
+//   * nn1_f16_kernel (D = 3, the default) -- FILTER on the matrix cores, exact re-scan of what survives.  The
+//     argmin of the distance is the argmin of t = |c'|^2 - 2 q'.c' (cloud centred on its mean, scaled by a power of two), a
+//     K = 16 inner product of 2-way fp16 splits: ONE v_mfma_f32_32x32x16_f16 per 32 x 32 pairs, 8 v_min3 fold 16 rows, a few
+//     VALU ops track each lane's three smallest lane tiles; every candidate inside the error band of the running minimum goes
+//     to a wave-cooperative exact phase (the oracle's arithmetic, 64-bit LDS atomicMin on (distance bits, index)).  1024-thread
+//     blocks share one fp16 image of up to 4096 candidates (128 KiB of LDS), 512 queries per pass, XCD-aware block ids
+//     (block L runs on XCD L % 8: a cloud's blocks share that XCD's L2); larger clouds run in chunks, or as candidate SUBSETS
+//     in parallel blocks whose per-query rows the last subset of a query tile merges itself (round 5: one launch); a robust
+//     range + exact side list for far outliers; a per-query power-of-two scale for queries far outside the cloud.  The loss is
+//     finalised in the same launch (Float64 partials, agent-scope ticket, fixed summation order).  Bound by the matrix pipe +
+//     the VALU fold behind it: roofline.frac 0.27 of the dense f16 peak.
+//   * nn1_tiny_kernel (D = 3, problems below ~24 M pair evaluations) -- the exact loop with candidates broadcast along DPP
+//     rows: no statistics, no image, no barrier before the arithmetic.
+//   * nn1_small_d_kernel<DIM, R> (D = 2, and D = 3 under option nn1_variant = 0: the A/B reference) -- the exact VALU loop of
+//     round 1: candidates staged through LDS as structure-of-arrays, tiles of 32 folded by v_min3, the winning tile re-scanned
+//     with the reference's strict `<`.
+//   * nn1_generic_kernel (any other D).
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -1416,7 +1420,6 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
     const int cmax = kHChunkMax, gran = 32 * kHLT;
     const int ncu = device_cus();  // blocks resident at once: one per CU (256 on an MI355X in SPX mode)
     // a larger cloud of at most cmax + kHTail points is planned (and run) as ONE chunk of cmax with an exact tail
-    const int tpb_env = opt(OPT_NN1_TPB);
     int maxc = maxc0, b_chunk = 0, b_tpb = 1, b_split = 1;
     auto search = [&](int mc) {  // mc: the candidates that go through LDS images
         maxc = mc;
@@ -1431,7 +1434,6 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
                 if (split && (!allow_split || anch == 1 || opt(OPT_NN1_NOSPLIT))) continue;
                 for (int tpb = 1; tpb <= 8; tpb *= 2) {
                     if (!split && anch > 1 && tpb > 1) continue;
-                    if (tpb_env > 0 && tpb != tpb_env && (split || anch == 1)) continue;
                     const long long tiles = ((long long)maxc + 512 * tpb - 1) / (512 * tpb);
                     const long long blocks = 2ll * B * tiles * (split ? anch : 1);
                     const double per_chunk = 5.0 * ch / 4096.0 + 0.5 + tpb * (9.7 * ch / 4096.0 + 0.8);
@@ -1455,7 +1457,7 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
     pl.tpb = pl.tpb_y = b_tpb;
     pl.nsplit = b_split;
     pl.lds_bytes = (size_t)pl.chunk * 8 * sizeof(float) + kHScratchBytes;
-    if (N != M && b_split == 1 && maxc <= b_chunk && tpb_env <= 0) {
+    if (N != M && b_split == 1 && maxc <= b_chunk) {
         // clouds of different sizes, one chunk each: the direction whose CANDIDATES are the large cloud has few, heavy blocks
         // (N = 4096 against M = 1024 at B = 32: 32 blocks as long as C2's on 32 CUs while the rest of the chip idles) -- the
         // passes per block are chosen per direction: t = the slower direction's block, or the chip's throughput if the

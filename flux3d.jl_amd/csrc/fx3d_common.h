@@ -76,28 +76,17 @@ struct ProfileScope {  // brackets one dominant-kernel launch when profiling is 
 //      fx3d_set_option / fx3d_get_option (flux3d_hip.h) change / read them afterwards.  Process-wide, atomic.
 enum Opt {
     OPT_NN1_VARIANT,          // 3 = fp16-split MFMA filter + exact re-scan (default), 0 = the exact VALU loop (A/B)
-    OPT_NN1_TPB,              // > 0: query passes per block forced (launch-plan experiments)
     OPT_NN1_NOSPLIT,          // 1: never split the candidates of a cloud over blocks
     OPT_BWD_GLOBAL_ATOMICS,   // 1: chamfer adjoint with global float atomics instead of the LDS accumulator
-    OPT_KNN_F32,              // 1: feature-space kNN filter as the Float32 GEMM
-    OPT_KNN_F16_SPLIT,        // 1: feature-space kNN filter on 2-way fp16 splits
     OPT_KNN_NO_MFMA,          // 1: wave-per-query kernels only
     OPT_KNN_NO_PREPASS,       // 1: fx3d_knn_ws ignores its scratch (no per-cloud pre-pass)
-    OPT_KNN_GATHER,           // 1: exact phase gathers candidate rows from L2 instead of staging them through LDS
-    OPT_KNN_D3_WAVE,          // 1: D = 3 kNN on the wave-per-query kernel
-    OPT_KNN_D3_NO_COMPACT,    // 1: D = 3 kNN never on the compact geometries (64 queries per block, two blocks per CU)
-    OPT_KNN_DIRECT_LDS,       // 1: fx3d_knn_ws brings the image chunks of its search loop in with direct-to-LDS loads (round 3) instead of through registers
     OPT_KNN_SLICES,           // fx3d_knn_ws: candidate slices per cloud: 0 = automatic, 1 = never, 2 / 4 / 8 = forced
-    OPT_EDGE_SCALAR_STORES,   // 1: edge features written with 4-byte stores
     OPT_EDGECONV_UNFUSED,     // 1: EdgeConv graph build as search + feature kernels
     OPT_LAP_BWD_SCATTER,      // 1: fx3d_laplacian_loss_bwd as the scatter with float atomics (any CSR) instead of the gather (symmetric structure)
     OPT_CDF_MULTIBLOCK_FROM,  // faces per mesh from which the sampling CDF takes the multi-block path (0 = the built-in limit)
     OPT_NN1_TINY_MPAIRS,      // D = 3 nn1 / chamfer: problems of at most this many MILLION ordered pair evaluations (2 B N M) run on the
                               // exact small-problem kernel (nn1_tiny_kernel) instead of the fp16-filter kernel; 0 = never
     OPT_MESH_MAX_BLOCKS,      // grid cap of the grid-stride mesh kernels (areas, losses, adjoints), 256-thread blocks; 0 = automatic
-    OPT_KNN_ROW_STAGES,       // 1: feature-space kNN exact phase staged by row blocks (rounds 2-3) instead of 16-dimension column slices of the whole cloud
-    OPT_EDGE_FSPLIT,          // edge features (mlp layout): features per block of the split feature loop; 0 = automatic (fill the chip), F = one loop
-    OPT_EDGE_NO_NT,           // 1: edge features written with ordinary stores (default: streaming stores for tensors beyond 192 MB)
     OPT_COUNT
 };
 int opt(Opt o);

@@ -1873,7 +1873,7 @@ __host__ inline bool knn_f16_d3_shape_ok(int M, int kk) {
 }
 fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int B, int k, int drop, int32_t *idx,
                               float *dist, hipStream_t st, float *feat = nullptr, int layout = 0, int xdiv = 1) {
-    const bool compact = !opt(OPT_KNN_D3_NO_COMPACT);
+    const bool compact = true;
     if (k + drop <= 32) return launch_knn_f16_d3_geom<K3Base>(x, N, y, M, B, k, drop, idx, dist, st, feat, layout, xdiv);
     // (measured, tools/knn_compact_ab.py: 1.3-1.6 x over the wide geometry at M = 1600 ... 8192 too -- several image chunks --, except
     //  where many queries overflow the 88 keys and fall to the exact merge over a large cloud: k + drop > 44 with M > 4096)
@@ -3885,7 +3885,7 @@ bool knn_pre_shape_ok(int M, int D, int kk);
 bool knn_pre_eligible(const float *x, const float *y, int M, int D, int kk) {
     if (!knn_pre_shape_ok(M, D, kk)) return false;
     if (((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x)) & 15) != 0) return false;
-    return !(opt(OPT_KNN_F32) || opt(OPT_KNN_F16_SPLIT) || opt(OPT_KNN_NO_MFMA) || opt(OPT_KNN_NO_PREPASS));
+    return !(opt(OPT_KNN_NO_MFMA) || opt(OPT_KNN_NO_PREPASS));
 }
 
 template <int DK, bool F16, bool SPLIT>
@@ -3925,8 +3925,7 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     int srl = 0;
     const int DS = DP > 64 && D > 64 ? 64 : D;  // staged width of a row: D > 64 goes through in two column halves
     const int PR = DS / 4;
-    const bool stageable = D % 4 == 0 && (kMThreads % PR) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
-                           !opt(OPT_KNN_GATHER);
+    const bool stageable = D % 4 == 0 && (kMThreads % PR) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
     if (stageable) {
         const size_t room = 152 * 1024 - (img * 4 + small);
         for (int l = 8; l >= 5; --l) {
@@ -3941,7 +3940,7 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
     // column slices (round 4) instead of row stages: every row of the cloud, 16 dimensions at a time, as four planes of 16-byte
     // pieces -- when the whole cloud's slice fits the same tail (M <= 1024 at the kernel's 512 threads x 8 pieces)
     int csl = 0;
-    if (stageable && !opt(OPT_KNN_ROW_STAGES) && D % 16 == 0 && D <= 64 && M <= 8 * (kMThreads / 4)) {
+    if (stageable && D % 16 == 0 && D <= 64 && M <= 8 * (kMThreads / 4)) {
         const size_t room = 152 * 1024 - (img * 4 + small);
         const size_t mpc = (size_t)(M + kMThreads / 4 - 1) / (kMThreads / 4) * (kMThreads / 4);
         const size_t need = 4 * (mpc * 16 + 32);
@@ -3968,7 +3967,7 @@ fx3d_status launch_knn_mfma_dk(const float *x, int N, const float *y, int M, int
                                                     "knn_mfma_kernel<pre>");
         if (arc2 != FX3D_OK) return arc2;
         hipLaunchKernelGGL((knn_mfma_kernel<DK, F16, SPLIT, F16 && !SPLIT>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
-                           k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, pre_ws, xdiv, csl, opt(OPT_KNN_DIRECT_LDS) ? 0 : 1);
+                           k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, pre_ws, xdiv, csl, 1);
     } else
         hipLaunchKernelGGL((knn_mfma_kernel<DK, F16, SPLIT>), dim3(nbx * bpad), dim3(kMThreads), lds, st, x, N, y, M, B, D,
                            k, drop, idx, dist, CH, (int)img, keep_norms, two_norms, srl, nullptr, xdiv, csl, 0);
@@ -3980,16 +3979,8 @@ fx3d_status launch_knn_mfma(const float *x, int N, const float *y, int M, int B,
                             float *dist, hipStream_t st, void *pre_ws = nullptr, int xdiv = 1) {
     const int dk = (D + 31) / 32;
     // fp16-split filter: needs 16-byte loads (D % 4 == 0, aligned clouds) and all norms in LDS up front
-    const bool f32_only = opt(OPT_KNN_F32) != 0;  // (fx3d_set_option: the tests flip it)
-    const bool f16 = !f32_only && D % 4 == 0 && M <= 4096 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
+    const bool f16 = D % 4 == 0 && M <= 4096 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
                      ((size_t)M * D * 4) % 16 == 0;
-    if (f16 && opt(OPT_KNN_F16_SPLIT)) {  // 2-way split operands: 3 MFMAs per K block, band 2^-18 instead of 2^-10
-        switch (dk) {
-            case 1: return launch_knn_mfma_dk<1, true, true>(x, N, y, M, B, D, k, drop, idx, dist, st, nullptr, xdiv);
-            case 2: return launch_knn_mfma_dk<2, true, true>(x, N, y, M, B, D, k, drop, idx, dist, st, nullptr, xdiv);
-            default: return launch_knn_mfma_dk<4, true, true>(x, N, y, M, B, D, k, drop, idx, dist, st, nullptr, xdiv);
-        }
-    }
     if (f16) {
         switch (dk) {
             case 1: return launch_knn_mfma_dk<1, true, false>(x, N, y, M, B, D, k, drop, idx, dist, st, pre_ws, xdiv);
@@ -4028,7 +4019,7 @@ int knn_select_list(int M, int kk, int *nw) {
 bool knn_needs_select(int M, int D, int kk) {
     // (D = 3, 44 < kk <= 64: the wave kernel's candidate list holds 64 - kk entries between merges -- 546 us at kk = 64 and C4's
     //  shape against 188 us here, 160 against ~185 at kk = 41)
-    if (D == 3 && !opt(OPT_KNN_D3_WAVE) && knn_f16_d3_shape_ok(M, kk)) return false;  // (round 3: the matrix-core kernel up to kk = 64)
+    if (D == 3 && knn_f16_d3_shape_ok(M, kk)) return false;  // (round 3: the matrix-core kernel up to kk = 64)
     if (D == 3 && kk > 44 && kk <= 64 && knn_select_waves(M) >= 1) return true;
     return kk > 64 || (D != 3 && !knn_mfma_eligible(M, D, kk) && knn_wave_generic_lds(D) > 64 * 1024);
 }
@@ -4152,7 +4143,7 @@ int knn_slices(int N, int M, int B, int D, int kk) {
     const int force = opt(OPT_KNN_SLICES);  // 0 = automatic, 1 = never, 2 / 4 / 8 = forced (when the shape allows it)
     if (force == 1) return 1;
     const bool d3 = D == 3;
-    if (d3 ? (opt(OPT_KNN_D3_WAVE) || !knn_f16_d3_shape_ok(M, kk)) : (opt(OPT_KNN_NO_MFMA) || !knn_mfma_eligible(M, D, kk))) return 1;
+    if (d3 ? !knn_f16_d3_shape_ok(M, kk) : (opt(OPT_KNN_NO_MFMA) || !knn_mfma_eligible(M, D, kk))) return 1;
     const int qpb = d3 && kk > 32 ? 64 : 128;
     const long long blocks = (long long)B * ((N + qpb - 1) / qpb);
     const int ncu = device_cus();
@@ -4225,7 +4216,7 @@ fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int 
                        int32_t *idx, float *dist, hipStream_t st, void *pre_ws = nullptr, int xdiv = 1) {
     ProfileScope prof("knn", st);
     const int kk = k + drop;
-    const bool grid_y = knn_needs_select(M, D, kk) || (D == 3 ? !(!opt(OPT_KNN_D3_WAVE) && knn_f16_d3_shape_ok(M, kk)) : !knn_mfma_eligible(M, D, kk));
+    const bool grid_y = knn_needs_select(M, D, kk) || (D == 3 ? !knn_f16_d3_shape_ok(M, kk) : !knn_mfma_eligible(M, D, kk));
     FX3D_REQUIRE(!grid_y || B <= 65535, "fx3d_knn: B=%d exceeds the grid's y range for this shape", B);
     if (knn_needs_select(M, D, kk)) {
         int nw = knn_select_waves(M);
@@ -4238,7 +4229,7 @@ fx3d_status launch_knn(const float *x, int N, const float *y, int M, int B, int 
         FX3D_LAUNCH_CHECK();
         return FX3D_OK;
     }
-    if (D == 3 && !opt(OPT_KNN_D3_WAVE) && knn_f16_d3_shape_ok(M, kk))
+    if (D == 3 && knn_f16_d3_shape_ok(M, kk))
         return launch_knn_f16_d3(x, N, y, M, B, k, drop, idx, dist, st, nullptr, 0, xdiv);
     FX3D_REQUIRE(xdiv == 1 || (D != 3 && !opt(OPT_KNN_NO_MFMA) && knn_mfma_eligible(M, D, kk)),
                  "fx3d_knn: internal: candidate slices on a kernel without them");
@@ -4349,7 +4340,7 @@ fx3d_status fx3d_knn_gather(const float *x, int32_t N, int32_t B, int32_t F, int
         long long g4 = (total4 + kThreads - 1) / kThreads;
         if (g4 > 16384) g4 = 16384;
         ProfileScope prof4("knn_gather", as_stream(s));
-        if ((size_t)F * k * N * B * 4 > kStreamingStoreBytes && !opt(OPT_EDGE_NO_NT))
+        if ((size_t)F * k * N * B * 4 > kStreamingStoreBytes)
             hipLaunchKernelGGL(knn_gather4_kernel<true>, dim3((unsigned)g4), dim3(kThreads), 0, as_stream(s), x, N, B, F / 4, k, idx, out);
         else
             hipLaunchKernelGGL(knn_gather4_kernel<false>, dim3((unsigned)g4), dim3(kThreads), 0, as_stream(s), x, N, B, F / 4, k, idx, out);
@@ -4382,16 +4373,13 @@ fx3d_status fx3d_edge_features(const float *x, int32_t N, int32_t B, int32_t F, 
         const long long KN = (long long)k * N;
         dim3 grid((unsigned)((KN + kThreads - 1) / kThreads), B);
         const bool al16 = (((uintptr_t)x | (uintptr_t)out | (uintptr_t)idx) & 15) == 0;
-        if (F % 4 == 0 && KN % 4 == 0 && al16 && !opt(OPT_EDGE_SCALAR_STORES)) {
-            // the feature loop split over blockIdx.z until the grid holds ~16 blocks per CU (option edge_fsplit: 0 = automatic,
-            // n = features per block forced, a multiple of 4; edge_fsplit = F is the single loop of rounds 1-3)
+        if (F % 4 == 0 && KN % 4 == 0 && al16) {
+            // the feature loop split over blockIdx.z until the grid holds ~16 blocks per CU
             const long long gx = (KN / 4 + kThreads - 1) / kThreads;
             int fper = F;
-            if (opt(OPT_EDGE_FSPLIT) > 0) fper = (opt(OPT_EDGE_FSPLIT) + 3) / 4 * 4;
-            else
-                while (fper > 4 && gx * B * ((F + fper - 1) / fper) < 16ll * device_cus()) fper = (fper / 2 + 3) / 4 * 4;
+            while (fper > 4 && gx * B * ((F + fper - 1) / fper) < 16ll * device_cus()) fper = (fper / 2 + 3) / 4 * 4;
             const unsigned gz = (unsigned)((F + fper - 1) / fper);
-            const bool nt = (size_t)2 * F * KN * B * 4 > kStreamingStoreBytes && !opt(OPT_EDGE_NO_NT);  // (smaller tensors may be read back from the caches)
+            const bool nt = (size_t)2 * F * KN * B * 4 > kStreamingStoreBytes;  // (smaller tensors may be read back from the caches)
             if (nt)
                 hipLaunchKernelGGL(edge_features_mlp4_kernel<true>, dim3((unsigned)gx, B, gz), dim3(kThreads), 0, as_stream(s), x, N, B, F, k, idx, out, fper);
             else
@@ -4425,7 +4413,7 @@ fx3d_status fx3d_edgeconv_graph(const float *x, int32_t N, int32_t B, int32_t F,
     FX3D_REQUIRE(idx, "fx3d_edgeconv_graph: idx (k,N,B) is required (it is also the adjoint's side input)");
     FX3D_REQUIRE(x && out && N > 0 && B > 0 && F > 0 && k > 0, "fx3d_edgeconv_graph: bad argument");
     FX3D_REQUIRE(layout == 0 || layout == 1, "fx3d_edgeconv_graph: layout must be 0 (2F,K,N,B) or 1 (K*N,2F,B)");
-    if (F == 3 && k + 1 <= N && knn_f16_d3_shape_ok(N, k + 1) && !opt(OPT_KNN_D3_WAVE) &&
+    if (F == 3 && k + 1 <= N && knn_f16_d3_shape_ok(N, k + 1) &&
         !opt(OPT_EDGECONV_UNFUSED)) {
         // first EdgeConv (coordinates): neighbour search and features in ONE kernel
         ProfileScope prof("edgeconv_graph", as_stream(s));

@@ -30,27 +30,16 @@ struct OptDef { const char *name, *env; int dflt; bool valued; };  // valued: an
 // (order = enum Opt)
 const OptDef kOptDefs[OPT_COUNT] = {
     {"nn1_variant", "FX3D_NN1_VARIANT", 3, true},
-    {"nn1_tpb", "FX3D_NN1_TPB", 0, true},
     {"nn1_nosplit", "FX3D_NN1_NOSPLIT", 0, false},
     {"bwd_global_atomics", "FX3D_BWD_GLOBAL_ATOMICS", 0, false},
-    {"knn_f32", "FX3D_KNN_F32", 0, false},
-    {"knn_f16_split", "FX3D_KNN_F16_SPLIT", 0, false},
     {"knn_no_mfma", "FX3D_KNN_NO_MFMA", 0, false},
     {"knn_no_prepass", "FX3D_KNN_NO_PREPASS", 0, false},
-    {"knn_gather", "FX3D_KNN_GATHER", 0, false},
-    {"knn_d3_wave", "FX3D_KNN_D3_WAVE", 0, false},
-    {"knn_d3_no_compact", "FX3D_KNN_D3_NO_COMPACT", 0, false},
-    {"knn_direct_lds", "FX3D_KNN_DIRECT_LDS", 0, false},
     {"knn_slices", "FX3D_KNN_SLICES", 0, true},
-    {"edge_scalar_stores", "FX3D_EDGE_SCALAR_STORES", 0, false},
     {"edgeconv_unfused", "FX3D_EDGECONV_UNFUSED", 0, false},
     {"lap_bwd_scatter", "FX3D_LAP_BWD_SCATTER", 0, false},
     {"cdf_multiblock_from", "FX3D_CDF_MULTIBLOCK_FROM", 0, true},
     {"nn1_tiny_mpairs", "FX3D_NN1_TINY_MPAIRS", 24, true},
     {"mesh_max_blocks", "FX3D_MESH_MAX_BLOCKS", 0, true},
-    {"knn_row_stages", "FX3D_KNN_ROW_STAGES", 0, false},
-    {"edge_fsplit", "FX3D_EDGE_FSPLIT", 0, true},
-    {"edge_no_nt", "FX3D_EDGE_NO_NT", 0, false},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::once_flag g_opt_once;

@@ -660,15 +660,13 @@ def test_laplacian_loss_grad_gather_is_bit_identical_to_the_oracle(gpu_fx, oracl
     assert np.allclose(gs, ol, rtol=1e-4, atol=1e-9)
 
 
-@pytest.mark.parametrize("direct", [0, 1])
-def test_knn_prepass_search_staging(gpu_fx, oracle, fx_option, direct):
+def test_knn_prepass_search_staging(gpu_fx, oracle):
     """The search kernel behind the pre-pass (fx3d_knn_ws) with its image chunks brought in through registers (default; the first
-    chunk requested at the kernel's start, the query rows staged behind it) and with direct-to-LDS loads (option knn_direct_lds):
+    chunk requested at the kernel's start, the query rows staged behind it; D = 128 keeps the direct-to-LDS loads):
     the same neighbours as the oracle -- a cloud with a far point (robust centre), C4's rows with queries from another array, a
     ragged tail (M < the 256-row padding), D = 128, a cloud beyond 1024 rows (row stages instead of column slices), call after call
     on the same scratch."""
     rng = np.random.default_rng(21)
-    fx_option("knn_direct_lds", str(direct))
     x = np.asfortranarray(rng.standard_normal((32, 700, 5)).astype(np.float32))
     x[:, 17, 2] += 3.0e4  # one far point: the mean leaves the middle of the range (robust-centre rule)
     oi, od = oracle.knn(x, 12, drop_first=True)
@@ -689,14 +687,13 @@ def test_knn_prepass_search_staging(gpu_fx, oracle, fx_option, direct):
     assert np.array_equal(gpu_fx.knn(w, 20, drop_first=True, return_dist=False).to_host(), oi4)
 
 
-@pytest.mark.parametrize("rows", [0, 1])
-def test_knn_exact_phase_column_slices(gpu_fx, oracle, fx_option, rows):
+def test_knn_exact_phase_column_slices(gpu_fx, oracle):
     """The exact phase of the feature-space kNN on 16-dimension column slices of the whole cloud (default for D % 16 == 0, D <= 64,
-    M <= 1024) and on row stages (option knn_row_stages): identical lists and distances, equal to the oracle's -- uniform data,
+    M <= 1024) and on row stages (the other shapes: D = 40, a cloud of 1300 rows): the oracle's lists and distances -- uniform data,
     duplicated rows (ties: the verified ranking's re-rank), k + drop up to 32, a cloud that is not a multiple of 128 rows."""
     rng = np.random.default_rng(33)
-    fx_option("knn_row_stages", str(rows))
-    for (D, N, B, k, drop) in ((64, 1024, 3, 20, True), (32, 1000, 2, 31, True), (16, 333, 4, 7, False), (48, 640, 2, 16, True)):
+    for (D, N, B, k, drop) in ((64, 1024, 3, 20, True), (32, 1000, 2, 31, True), (16, 333, 4, 7, False), (48, 640, 2, 16, True),
+                               (40, 700, 2, 12, True), (64, 1300, 1, 20, True)):
         x = rng.standard_normal((D, N, B)).astype(np.float32)
         x[:, N // 2:N // 2 + 40, 0] = x[:, :40, 0]  # exact duplicates: equal distances, ordered by index
         x = np.asfortranarray(x)
@@ -826,7 +823,7 @@ def test_option_api_replaces_environment_reads(gpu_fx, oracle, monkeypatch):
     fx = gpu_fx
     from flux3d_jl_amd import _lib
     opts = _lib.options()
-    assert set(opts) >= {"nn1_variant", "knn_f32", "knn_no_prepass", "bwd_global_atomics", "cdf_multiblock_from"}
+    assert set(opts) >= {"nn1_variant", "knn_no_mfma", "knn_no_prepass", "bwd_global_atomics", "cdf_multiblock_from"}
     assert opts["nn1_variant"] == 3
     with pytest.raises(fx.Flux3DHipError, match="unknown option"):
         _lib.set_option("no_such_switch", 1)

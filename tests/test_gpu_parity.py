@@ -442,27 +442,22 @@ def test_knn_matrix_core_path(gpu_fx, oracle, D, N, M, B, k, drop, kind):
     assert np.array_equal(dist.to_host(), od)
 
 
-def test_knn_float32_filter_variant(gpu_fx, oracle, fx_option):
-    """FX3D_KNN_F32=1 keeps the Float32 GEMM filter (the default for D % 4 == 0, M <= 4096 is the fp16 split):
-    both must give the oracle's lists."""
-    fx_option("knn_f32", "1")
+def test_knn_float32_filter_variant(gpu_fx, oracle):
+    """The Float32 GEMM filter is what feature-space clouds get that the fp16 filter does not take (D % 4 != 0, or more than 4096
+    candidates): shapes on both sides of either rule must give the oracle's lists."""
     rng = np.random.default_rng(77)
-    for (D, N, M, k) in ((64, 300, 1024, 20), (32, 100, 200, 9), (128, 64, 96, 5)):
+    for (D, N, M, k) in ((62, 300, 1024, 20), (30, 100, 200, 9), (127, 64, 96, 5), (64, 96, 4160, 20), (6, 200, 333, 7)):
         x = np.asfortranarray(rng.standard_normal((D, N, 2)).astype(np.float32))
         y = np.asfortranarray(rng.standard_normal((D, M, 2)).astype(np.float32))
         idx, dist = gpu_fx.knn(x, k, y=y)
         oi, od = oracle.knn(x, k, y=y)
-        assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
+        assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od), (D, N, M, k)
 
 
-@pytest.mark.parametrize("env", [None, "knn_f16_split"])
-def test_knn_fp16_filter_variants(gpu_fx, oracle, fx_option, env):
-    """The default feature-space filter uses the fp16-rounded operands alone (one MFMA per K block, band 2^-10);
-    FX3D_KNN_F16_SPLIT=1 selects the 2-way split (three MFMAs, band 2^-18).  Both must give the oracle's lists, on
-    centred data and on data with a large common offset (the band grows with |q|^2 + |c|^2: more survivors, and
-    past the list capacity the exact fallback)."""
-    if env:
-        fx_option(env, 1)
+def test_knn_fp16_filter(gpu_fx, oracle):
+    """The default feature-space filter uses the fp16-rounded operands alone (one MFMA per K block, band 2^-10): the oracle's
+    lists on centred data and on data with a large common offset (the band grows with |q|^2 + |c|^2: more survivors, and past
+    the list capacity the exact fallback)."""
     rng = np.random.default_rng(78)
     for (D, N, M, k, shift) in ((64, 300, 1024, 20, 0.0), (64, 200, 512, 20, 3.0), (32, 100, 200, 9, 0.0),
                                 (128, 64, 96, 5, 0.5), (16, 130, 700, 31, 10.0), (64, 96, 1024, 12, 40.0)):
@@ -485,11 +480,12 @@ def test_knn_fp16_filter_variants(gpu_fx, oracle, fx_option, env):
     (16, 100, 700, 1, 7, False),
     (4, 333, 2048, 1, 32, False),    # smallest row (one 16-byte piece)
     (64, 100, 4096, 1, 20, False),   # more than 8 stages: the gather from L2 stays
+    (62, 150, 700, 2, 12, False),    # D % 4 != 0: no staging, every survivor's row gathered from L2
 ])
 def test_knn_staged_exact_phase(gpu_fx, oracle, fx_option, D, N, M, B, k, drop):
     """knn_mfma_kernel's exact phase with the candidate rows staged through LDS (default when D/4 divides the block and
-    the cloud makes at most 8 stages) and with the per-survivor gather from L2 (FX3D_KNN_GATHER=1): both are the
-    oracle's lists bit for bit, distances included."""
+    the cloud makes at most 8 stages) and with the per-survivor gather from L2 (clouds of more than 8 stages, rows that are not
+    a multiple of 16 bytes): the oracle's lists bit for bit, distances included."""
     rng = np.random.default_rng(D * 7 + M)
     x = np.asfortranarray(rng.standard_normal((D, N, B)).astype(np.float32))
     y = x if drop else np.asfortranarray(rng.standard_normal((D, M, B)).astype(np.float32))
@@ -497,12 +493,11 @@ def test_knn_staged_exact_phase(gpu_fx, oracle, fx_option, D, N, M, B, k, drop):
         x = y = np.asfortranarray(rng.standard_normal((D, M, B)).astype(np.float32))
     oi, od = oracle.knn(x, k, y=None if y is x else y, drop_first=drop)
     # (default: fx3d_knn_ws with the pre-pass image; FX3D_KNN_NO_PREPASS=1: every block builds its own image, as fx3d_knn does)
-    for gather, nopre in ((False, False), (True, False), (False, True)):
-        fx_option("knn_gather", "1" if gather else "0")
+    for nopre in (False, True):
         fx_option("knn_no_prepass", "1" if nopre else "0")
         idx, dist = gpu_fx.knn(x, k, y=None if y is x else y, drop_first=drop)
-        assert np.array_equal(idx.to_host(), oi), f"gather={gather} nopre={nopre}"
-        assert np.array_equal(dist.to_host(), od), f"gather={gather} nopre={nopre}"
+        assert np.array_equal(idx.to_host(), oi), f"nopre={nopre}"
+        assert np.array_equal(dist.to_host(), od), f"nopre={nopre}"
 
 
 @pytest.mark.parametrize("D,csize,spread", [(64, 80, 1e-3), (32, 200, 1e-4), (64, 700, 1e-3)])
@@ -1243,21 +1238,18 @@ def test_knn_d3_wide_selection(gpu_fx, oracle, M, k, drop, kind):
 
 @pytest.mark.parametrize("M,k,drop", [(1024, 40, True), (1472, 47, False), (1473, 47, True), (130, 33, False), (1024, 48, True),
                                       (3000, 40, True), (5000, 43, True), (5000, 47, False), (4096, 47, True)])
-def test_knn_d3_compact_geometry_against_the_wide_one(gpu_fx, oracle, fx_option, M, k, drop):
+def test_knn_d3_compact_geometry(gpu_fx, oracle, M, k, drop):
     """32 < k + drop <= 48 runs the compact geometry (two blocks per CU, raw coordinates from L2, no medium path; clouds beyond 1472
-    candidates pass through its LDS image in chunks; k + drop > 44 on clouds beyond 4096 stays on the wide one); the option
-    knn_d3_no_compact keeps the wide one: both bit-identical to the oracle, on both sides of the chunk limit, of k + drop = 44 / 48
-    and of M = 4096."""
+    candidates pass through its LDS image in chunks; k + drop > 44 on clouds beyond 4096 stays on the wide one): bit-identical to
+    the oracle on both sides of the chunk limit, of k + drop = 44 / 48 and of M = 4096."""
     rng = np.random.default_rng(M + k)
     x = np.asfortranarray(rng.random((3, 200, 2), dtype=np.float32))
     y = rng.random((3, M, 2), dtype=np.float32)
     y[:, ::5, :] = np.round(y[:, ::5, :] * 8) / 8
     y = np.asfortranarray(y)
     oi, od = oracle.knn(x, k, y=y, drop_first=drop)
-    for no_compact in (0, 1):
-        fx_option("knn_d3_no_compact", str(no_compact))
-        idx, dist = gpu_fx.knn(x, k, y=y, drop_first=drop)
-        assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od), no_compact
+    idx, dist = gpu_fx.knn(x, k, y=y, drop_first=drop)
+    assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
 
 
 def test_knn_d3_wide_selection_full_shape(gpu_fx, oracle):

@@ -1,5 +1,5 @@
 """C3 (chamfer_distance(mesh, mesh, 5000), B = 8 teapots) in pieces: the draw launch, the chamfer launch on the sampled clouds
-under the planner's choice and under forced plans (options nn1_tpb / nn1_nosplit), the whole call.  Kernel time = the library's
+under the planner's choice and under forced plans (option nn1_nosplit), the whole call.  Kernel time = the library's
 events around the launch (fx3d_profile_*), call time = min of single calls between events."""
 import ctypes as C
 import json
@@ -69,7 +69,7 @@ out["nn1_kernel_us(avg,min)"] = kern_us("nn1", lambda: fx.chamfer_distance(PA, P
 if os.environ.get("C3_BRIEF"):
     print(json.dumps({k: out[k] for k in ("plan", "nn1_kernel_uniform_clouds_us(avg,min)", "chamfer_on_samples_call_us")}))
     sys.exit(0)
-for opts in ({"nn1_nosplit": 1}, {"nn1_tpb": 1}, {"nn1_tpb": 2}, {"nn1_tpb": 4}, {"nn1_tpb": 1, "nn1_nosplit": 1}):
+for opts in ({"nn1_nosplit": 1},):
     for k, v in opts.items():
         _lib.set_option(k, v)
     out["chamfer_call_us " + json.dumps(opts)] = call_us(lambda: fx.chamfer_distance(PA, PB, loss_out=loss_dev, sync=False))
