@@ -171,12 +171,16 @@ __device__ __forceinline__ void bg_rows(BgLds &L, const BgJob &J) {
     const bool own_first = J.side == 0;  // side x: the own term opens the row (the oracle's first loop), side y: it closes it
     // requested before anything else: this thread's rows and their indices
     int jown[kBgPer];
-    P3 wr[kBgPer];
+    float wx[kBgPer], wy[kBgPer], wz[kBgPer];  // (plain scalar arrays: an array of the packed 12-byte P3 is not promoted to registers -- it lived in scratch)
 #pragma unroll
     for (int u = 0; u < kBgPer; ++u) {
         const bool mine = u < rpt && tid + u * kBgThreads < nrows;
         jown[u] = mine ? J.idx_own[J.r0 + tid + u * kBgThreads] : 0;
-        if (D3) wr[u] = mine ? *reinterpret_cast<const P3 *>(own + (size_t)(J.r0 + tid + u * kBgThreads) * 3) : P3{0.0f, 0.0f, 0.0f};
+        wx[u] = 0.0f; wy[u] = 0.0f; wz[u] = 0.0f;
+        if (D3 && mine) {
+            const P3 t = *reinterpret_cast<const P3 *>(own + (size_t)(J.r0 + tid + u * kBgThreads) * 3);
+            wx[u] = t.x; wy[u] = t.y; wz[u] = t.z;
+        }
     }
     BG_STAMP(0);
 #pragma unroll
@@ -249,7 +253,7 @@ __device__ __forceinline__ void bg_rows(BgLds &L, const BgJob &J) {
             if (u < rpt && lr < nrows && (int)L.start[lr + 1] - (int)L.start[lr] > kBgSmall) {
                 const unsigned int k = atomicAdd(&L.nbig, 1u);
                 L.big[k] = (unsigned short)lr;
-                if (D3 && k < (unsigned int)kBgBigW) L.bigw[k] = float4{wr[u].x, wr[u].y, wr[u].z, __builtin_bit_cast(float, jown[u])};
+                if (D3 && k < (unsigned int)kBgBigW) L.bigw[k] = float4{wx[u], wy[u], wz[u], __builtin_bit_cast(float, jown[u])};
             }
         }
         __syncthreads();
@@ -358,7 +362,7 @@ __device__ __forceinline__ void bg_rows(BgLds &L, const BgJob &J) {
             const size_t i = (size_t)(J.r0 + lr);
             const int jo = jown[u];
             if (D3) {
-                const P3 w = wr[u];
+                const P3 w{wx[u], wy[u], wz[u]};
                 P3 ot{0.0f, 0.0f, 0.0f};
                 if ((first && own_first) || (last && !own_first)) {
                     const P3 o = *reinterpret_cast<const P3 *>(oth + (size_t)jo * 3);
@@ -371,16 +375,19 @@ __device__ __forceinline__ void bg_rows(BgLds &L, const BgJob &J) {
 #pragma unroll
                     for (int h = 0; h < kBgSmall; h += 4) {  // four gathers in flight
                         if (h >= c) break;
-                        P3 o[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (h + k < c) o[k] = *reinterpret_cast<const P3 *>(oth + (size_t)(c0 + e[h + k]) * 3);
+                        float ox[4], oy[4], oz[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             if (h + k < c) {
-                                a.x = a.x - c_oth * (o[k].x - w.x);
-                                a.y = a.y - c_oth * (o[k].y - w.y);
-                                a.z = a.z - c_oth * (o[k].z - w.z);
+                                const P3 t = *reinterpret_cast<const P3 *>(oth + (size_t)(c0 + e[h + k]) * 3);
+                                ox[k] = t.x; oy[k] = t.y; oz[k] = t.z;
+                            }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (h + k < c) {
+                                a.x = a.x - c_oth * (ox[k] - w.x);
+                                a.y = a.y - c_oth * (oy[k] - w.y);
+                                a.z = a.z - c_oth * (oz[k] - w.z);
                             }
                     }
                 }
