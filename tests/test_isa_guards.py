@@ -89,7 +89,7 @@ def _check(asm):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("name,min_checked", [("knn.hip", 16), ("chamfer.hip", 0)])
+@pytest.mark.parametrize("name,min_checked", [("knn_d3.hip", 8), ("knn_mfma.hip", 8), ("chamfer.hip", 0)])
 def test_inline_asm_consumers_keep_their_distance_from_the_mfma(name, min_checked):
     viol, checked = _check(_assembly(name))
     assert not viol, "\n".join(viol[:10])

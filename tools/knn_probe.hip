@@ -3,6 +3,8 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DFX3D_PROBE -I include -I flux3d.jl_amd/csrc \
 //         tools/knn_probe.hip flux3d.jl_amd/csrc/runtime.hip -o tools/knn_probe
 #include "../flux3d.jl_amd/csrc/knn.hip"
+#include "../flux3d.jl_amd/csrc/knn_d3.hip"
+#include "../flux3d.jl_amd/csrc/knn_mfma.hip"
 
 #include <algorithm>
 #include <cstdio>
