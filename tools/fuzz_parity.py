@@ -128,6 +128,21 @@ def main():
                     desc += f" [indices equal; loss {got!r} vs oracle {exp!r}]"
             else:
                 desc += " [indices differ]"
+            if ok:  # (round 5) the adjoint is atomic-free: bit for bit, on the forward's indices or on arbitrary index maps
+                if rng.random() < 0.5:
+                    jx, jy = ox, oy
+                else:  # many-to-one maps: long inverse lists (the wave path), lists of 5 .. 8 (the networks)
+                    tx = int(rng.integers(1, max(2, M // int(rng.choice([1, 1, 3, 40])))))
+                    ty = int(rng.integers(1, max(2, N // int(rng.choice([1, 1, 3, 40])))))
+                    jx = np.asfortranarray(rng.integers(0, tx, (N, B)).astype(np.int32))
+                    jy = np.asfortranarray(rng.integers(0, ty, (M, B)).astype(np.int32))
+                    desc += f" bwd on random maps (<{tx}, <{ty})"
+                gout = float(rng.choice([1.0, -0.5, 2.0]))
+                gx, gy = fx.chamfer_distance_grad(x, y, fx.gpu(jx), fx.gpu(jy), w1=0.7, w2=1.3, gout=gout)
+                egx, egy = orc.chamfer_bwd(x, y, jx, jy, 0.7, 1.3, gout)
+                ok = np.array_equal(gx.to_host().view(np.uint32), egx.view(np.uint32)) and np.array_equal(gy.to_host().view(np.uint32), egy.view(np.uint32))
+                if not ok:
+                    desc += " [adjoint differs]"
         elif what == 1:  # kNN D = 3
             N, M = int(rng.integers(1, 1500)), int(rng.integers(2, 6000))
             k = int(rng.integers(1, min(33, M)))
