@@ -69,6 +69,47 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def live_pmc_traffic(timeout_s=120):
+    """HBM bytes of ONE nn1 launch at the bench workload, measured now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE -- counters in
+    their own runs, no trace domains next to them) of tools/pmc_driver.py nn1 in subprocesses, read back from the result databases, with
+    the guide's gfx950 correction (FETCH_SIZE counts 128-byte requests as 64: the read side doubled; KiB units).  Any failure -- no
+    rocprofv3, a refused counter, a timeout -- leaves the committed profiles/pmc_latest.json figure in place and says why."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"bytes_per_launch": None, "note": "rocprofv3 not found"}
+    out = {"bytes_per_launch": None, "tool": "rocprofv3 --pmc <counter> -- python tools/pmc_driver.py nn1 (one pass per counter)"}
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="fx3d_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            r = subprocess.run([exe, "--pmc", ctr, "-d", d, "-o", "r", "--", sys.executable, os.path.join(ROOT, "tools", "pmc_driver.py"), "nn1",
+                                "--reps", "6"], cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                out["note"] = f"{ctr} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
+                return out
+            rows = sqlite3.connect(dbs[0]).execute(
+                "select avg(value), count(*) from counters_collection where counter_name = ? and kernel_name like '%nn1_f16_kernel%'", (ctr,)).fetchall()
+            if not rows or rows[0][0] is None:
+                out["note"] = f"{ctr}: no nn1_f16_kernel dispatch in the counter database"
+                return out
+            vals[ctr] = {"avg_kib": rows[0][0], "dispatches": rows[0][1]}
+        out.update({"bytes_per_launch": int(round(2 * vals["FETCH_SIZE"]["avg_kib"] * 1024 + vals["WRITE_SIZE"]["avg_kib"] * 1024)),
+                    "raw": vals, "correction": "gfx950: FETCH_SIZE x 2 (128-byte requests counted as 64 bytes), WRITE_SIZE as is; KiB"})
+    except Exception as e:  # noqa: BLE001
+        out["note"] = f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: N ranks of this script, one per device, RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* exported as torchrun would (the library's TCP rendezvous does the rest).  Fewer than N visible
@@ -467,6 +508,12 @@ def main():
         pmc_note = f"profiles/pmc_latest.json unusable: {e}"
     if pmc_note:
         roof["counters_note"] = pmc_note
+    if world == 1 and not use_dist and not args.no_extras and not os.environ.get("FX3D_BENCH_NO_LIVE_PMC"):
+        live = live_pmc_traffic()   # (round 5) the HBM traffic of one launch measured IN THIS RUN, not read from a committed file
+        if live.get("bytes_per_launch"):
+            roof["traffic_committed_profile"] = roof.get("traffic")
+            roof["traffic"] = live["bytes_per_launch"]
+        roof["traffic_live"] = live
     pipe = None
     out = {
         "metric": "chamfer_point_pairs_per_sec", "value": value, "unit": "pairs/s",

@@ -404,7 +404,10 @@ __device__ __forceinline__ void make_pieces(float cx, float cy, float cz, h8 &p0
     p1 = h8{lz, n1, n2, n3, lx, ly, lz, z};
 }
 
-template <bool WANT_IDX>
+// SPLITFUSE: the instantiation of candidate-split runs with the merge fused into the kernel's tail (a template parameter, not a
+// run-time flag: with the merge code inside, the one-chunk kernel -- the headline path -- spilled a register: 1 MB of scratch
+// writes per launch at C2, where that code never runs)
+template <bool WANT_IDX, bool SPLITFUSE = false>
 __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ __attribute__((aligned(16))) float red[4 * 4 * (kHThreads / 64) + 8];  // per wave: min, max, sum, sum of squares (rows padded to 4 floats); + the block's result
@@ -965,7 +968,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                                          // per block (measured: 32 -> 94 us)
                         unsigned long long *gp = &p.gres[((size_t)split * 2 * p.B + c) * p.qstride + qi];
                         if (qi < NQ) {
-                            if (p.fuse_split) __hip_atomic_store(gp, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (SPLITFUSE) __hip_atomic_store(gp, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             else *gp = r;
                         }
                     } else if (qi < NQ) {
@@ -979,7 +982,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         }
     }
     FX3D_PROBE_MARK(11);
-    if (p.nsplit > 1 && p.fuse_split) {
+    if (SPLITFUSE && p.nsplit > 1) {
         // ---- candidate-split run, merge fused (round 5): the chunk subsets of one query tile arrive at a counter of their own
         //      (a spare word of the launch's ticket slot: zero between launches, the last arriver returns it to zero); the last one
         //      takes the 64-bit minimum over the subsets' rows -- (distance bits, index): `isless`, then the lowest index --, writes
@@ -1512,10 +1515,12 @@ fx3d_status launch_small(const Nn1Params &p, const Plan &pl, hipStream_t st) {
     if (pl.variant == 3) {
         if (DIM == 3) {
             // > 64 KiB of dynamic LDS needs an explicit opt-in (static LDS of the kernel: < 1 KiB)
-            const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&nn1_f16_kernel<WANT_IDX>),
-                                                       (int)(kHChunkMax * 32 + kHScratchBytes), "nn1_f16_kernel");
+            const void *kfn = p.fuse_split ? reinterpret_cast<const void *>(&nn1_f16_kernel<WANT_IDX, true>)
+                                           : reinterpret_cast<const void *>(&nn1_f16_kernel<WANT_IDX, false>);
+            const fx3d_status arc = ensure_dynamic_lds(kfn, (int)(kHChunkMax * 32 + kHScratchBytes), "nn1_f16_kernel");
             if (arc != FX3D_OK) return arc;
-            hipLaunchKernelGGL((nn1_f16_kernel<WANT_IDX>), dim3(pl.grid), dim3(kHThreads), pl.lds_bytes, st, p);
+            if (p.fuse_split) hipLaunchKernelGGL((nn1_f16_kernel<WANT_IDX, true>), dim3(pl.grid), dim3(kHThreads), pl.lds_bytes, st, p);
+            else hipLaunchKernelGGL((nn1_f16_kernel<WANT_IDX, false>), dim3(pl.grid), dim3(kHThreads), pl.lds_bytes, st, p);
         }
         FX3D_LAUNCH_CHECK();
         return FX3D_OK;
