@@ -15,7 +15,7 @@ def main():
     src, kept_as = sys.argv[1], sys.argv[2]
     txt = open(src).read()
     data = json.loads(txt[txt.index("# json") + len("# json"):].strip().splitlines()[0])
-    name = [k for k in data if "nn1_f16_kernel<false>" in k or ("nn1_f16_kernel" in k and "ILb0" in k)]
+    name = [k for k in data if "nn1_f16_kernel<false" in k or ("nn1_f16_kernel" in k and "ILb0" in k)]
     k = data[name[0]]
     fetch_kb, write_kb = k["FETCH_SIZE"]["avg"], k["WRITE_SIZE"]["avg"]
     out = {
