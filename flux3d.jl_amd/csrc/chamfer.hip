@@ -348,7 +348,14 @@ constexpr int kHThreads = 1024;   // 16 waves share one LDS image: 1 block per C
 #define FX3D_HLT 2
 #endif
 constexpr int kHLT = FX3D_HLT;    // 32-candidate blocks per lane tile (lane sees 16 rows of each)
-constexpr int kHFifo = 3;         // lane tiles tracked per lane and pass: the three smallest tile minima
+#ifndef FX3D_HFIFO
+#define FX3D_HFIFO 4
+#endif
+constexpr int kHFifo = FX3D_HFIFO;  // lane tiles tracked per lane and pass: the smallest tile minima.  Round 5: FOUR instead of three -- a query
+                                    // whose band holds four lane tiles no longer sends its wave into the retry pass (the reference harness's
+                                    // collinear A == B input at n = 16384: 68.4 -> 55.0 us, a 1/16 lattice A == B at C2's shape 109 -> 88;
+                                    // uniform C2 unchanged, 51.0 -> 50.5 .. 50.9 on one box: the extra v_med3 per lane tile hides under the MFMAs);
+                                    // five / six cost uniform C2 0.5 - 1.4 us and make the A != B lattice slower (99 -> 122 / 129 us)
 constexpr int kHChunkMax = 4096;  // 32 B per candidate => 128 KiB
 constexpr int kHItemCap = 64 * kHFifo;  // the FIFO path never overflows the list
 constexpr int kHFarCap = 64;      // far candidates kept on the exact side list; more: the chunk falls back to exact scans
@@ -361,7 +368,7 @@ static_assert(kHChunkMax / (32 * kHLT) <= 64, "lane-tile ids live in the six low
 constexpr float kKeyUp = 0x1.2p-17f;
 constexpr float kPadF16 = 65504.0f;  // K slot 15: padding / far candidates get 65504 x 65504 = 4.3e9, finite and above every real
                                      // filter value (|t| <= 3 2^14 (1 + beta) + 128 S, S < 3e4): no +Inf in the image, no NaN keys
-constexpr size_t kHScratchBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 4 + 32 * 3 * 4) + 64 * 32;  // + 2 pad blocks
+constexpr size_t kHScratchBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 2 + 32 * 3 * 4) + 64 * 32;  // + 2 pad blocks
 
 // plain v_min_f32 (fminf() also emits a canonicalising v_max in IEEE mode; the filter values are never
 // signalling NaNs, and a NaN filter value only sends the query down the exact path)
@@ -446,10 +453,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     h8 *imgp = reinterpret_cast<h8 *>(lds);  // piece (blk, half, row) at (blk*2 + half)*32 + row, 16 B each
     float4 *imgf = reinterpret_cast<float4 *>(lds);
     unsigned long long *wres = reinterpret_cast<unsigned long long *>(lds + 8 * (CH + 64));  // image + 2 pad blocks
-    unsigned int *witems = reinterpret_cast<unsigned int *>(wres + (kHThreads / 64) * 32);
+    unsigned short *witems = reinterpret_cast<unsigned short *>(wres + (kHThreads / 64) * 32);  // items: (query << 7) | (half << 6) | lane tile
     float *wq = reinterpret_cast<float *>(witems + (kHThreads / 64) * kHItemCap);
     unsigned long long *qres = wres + wv * 32;
-    unsigned int *items = witems + wv * kHItemCap;
+    unsigned short *items = witems + wv * kHItemCap;
     float *qtab = wq + wv * 96;
     const bool vec = (reinterpret_cast<uintptr_t>(cb) & 15) == 0;
     const bool one_shot = NCm <= CH;
@@ -700,10 +707,12 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 }
             }
 
-            // the three smallest lane-tile minima of this lane, as keys (tile id in the six low mantissa bits): ka <= kb <= kc.
+            // the kHFifo smallest lane-tile minima of this lane, as keys (tile id in the six low mantissa bits): fk[0] <= fk[1] <= ...
             // Four VALU operations per lane tile (v_and_or, 2 x v_med3, v_min) -- the FIFO of the first two rounds (threshold fma,
             // compare, five selects / shifts, min: nine) is gone, and "may the lane have missed a tile" is exact now (kc in band).
-            float tm = INFINITY, ka = INFINITY, kb = INFINITY, kc = INFINITY;
+            float tm = INFINITY, fk[kHFifo];
+#pragma unroll
+            for (int s = 0; s < kHFifo; ++s) fk[s] = INFINITY;
             const unsigned int keymask = ~63u;
 
             // ---- main loop, software-pipelined by TWO 32-candidate blocks ---------------------------------------
@@ -737,9 +746,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             {                                                                                                        \
                 float key;                                                                                           \
                 asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(tm), "v"(keymask), "s"(lt));                     \
-                kc = __builtin_amdgcn_fmed3f(kb, kc, key);                                                           \
-                kb = __builtin_amdgcn_fmed3f(ka, kb, key);                                                           \
-                ka = vmin(ka, key);                                                                                  \
+                _Pragma("unroll") for (int s_ = kHFifo - 1; s_ > 0; --s_) fk[s_] = __builtin_amdgcn_fmed3f(fk[s_ - 1], fk[s_], key);    \
+                fk[0] = vmin(fk[0], key);                                                                            \
                 ++lt;                                                                                                \
             }
             // one step: issue the next block into ISSUE, fold FOLD (issued two steps ago); an odd fold closes its lane tile.
@@ -774,7 +782,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
 #undef NN1_TRACK
 #undef NN1_FOLD
             __builtin_amdgcn_s_setprio(0);
-            const float ft[kHFifo] = {ka, kb, kc};
+            float ft[kHFifo];
+#pragma unroll
+            for (int s = 0; s < kHFifo; ++s) ft[s] = fk[s];
+            const float ka = fk[0];
             // this lane's smallest tile minimum is <= best (an upper bound of it: the key of the smallest VALUE is >= ka)
             const float best = __builtin_fmaf(fabsf(ka), kKeyUp, ka);
             FX3D_PROBE_MARK(tp == 0 ? 3 : 7);
@@ -790,7 +801,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 const float thr1 = fminf(__builtin_fmaf(m, kBandB1, da), __builtin_fmaf(m, 1.0f + 0x1p-20f, da_far));  // on tile minima (m >= the true minimum)
                 const float thr1k = __builtin_fmaf(fabsf(thr1), kKeyUp, thr1);      // on keys: t <= thr1  =>  key(t) <= thr1k
                 const bool usable = sane && far_ok && qok && m < INFINITY;  // filter meaningful for this query
-                const bool slow = !usable || !(kc > thr1k);  // a fourth lane tile may lie within the band
+                const bool slow = !usable || !(fk[kHFifo - 1] > thr1k);  // one more lane tile than the FIFO holds may lie within the band
                 // Common case (no slow lane in the wave): the items are the FIFO entries within the band.
                 // Rare case (degenerate / near-tied data, unusable filter): the wave re-runs its filter pass
                 // with the now known threshold and enqueues exactly the lane tiles within the band (every
@@ -856,7 +867,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                             if (bal) {
                                 const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
                                                          __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
-                                if (qual) items[pos] = ((unsigned int)jq << 16) | ((unsigned int)hh << 12) | (__builtin_bit_cast(unsigned int, ft[s]) & 63u);
+                                if (qual) items[pos] = (unsigned short)(((unsigned int)jq << 7) | ((unsigned int)hh << 6) | (__builtin_bit_cast(unsigned int, ft[s]) & 63u));
                                 nitems += __builtin_popcountll(bal);  // <= 64 * kHFifo == kHItemCap
                             }
                         }
@@ -878,7 +889,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                             if (bal) {
                                 const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
                                                          __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
-                                if (qual) items[pos] = ((unsigned int)jq << 16) | ((unsigned int)hh << 12) | (unsigned int)lt2;
+                                if (qual) items[pos] = (unsigned short)(((unsigned int)jq << 7) | ((unsigned int)hh << 6) | (unsigned int)lt2);
                                 nitems += __builtin_popcountll(bal);
                             }
                         }
@@ -892,7 +903,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                         if (t < ntask) {
                             const unsigned int it = items[t / (kHLT * 4)];
                             const int run = t % (kHLT * 4);
-                            const int qs = it >> 16, ih = (it >> 12) & 1, tl = it & 0xfff;
+                            const int qs = it >> 7, ih = (it >> 6) & 1, tl = it & 63;
                             const int jl0 = (tl * kHLT + (run >> 2)) * 32 + 8 * (run & 3) + 4 * ih;
                             float cx[4], cy[4], cz[4];
                             if (vec && jl0 + 4 <= cnt) {
