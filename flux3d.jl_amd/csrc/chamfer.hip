@@ -473,6 +473,15 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     // ---- bounding box and mean -> centre mu = the MEAN (a stray far point moves the box centre, hardly the mean), largest
     //      |c - mu| cinf, power-of-two scale sc with cinf*sc in [64,128): seven binades of fp16 range above 1, so that a bulk
     //      much smaller than the farthest point keeps its fp16 pieces out of the subnormals; |c~|^2 < 3 * 2^14 fits fp16 ----
+    // Scope of the statistics below (centre, extent, spread -> the image's centre and scale): the whole cloud -- or, in a
+    // candidate-split run whose block takes ONE chunk, that chunk alone (round 5: any centre is correct and the scale only has to
+    // cover the candidates of THIS block's image; C3's blocks walked all 5000 points for an image of 1728, and read their chunk
+    // a second time for the image: it is parked in LDS during the pass now, as in one-chunk runs)
+    const bool own_chunk_only = p.nsplit > 1 && (long long)split * CH + (long long)p.nsplit * CH >= NCm;
+    const int s_lo = own_chunk_only ? split * CH : 0;
+    const int SN = own_chunk_only ? (NCm - s_lo < CH ? NCm - s_lo : CH) : NC;
+    const float *__restrict__ sb = cb + (size_t)s_lo * 3;
+    const bool parked = one_shot || own_chunk_only;  // the raw points of the block's (only) chunk sit in their image slots
     float mu[3], cinf = 0.0f, varmax = 0.0f;
     bool allfin = true;
     {
@@ -480,15 +489,15 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         // 16-byte LDS slots of a wave's points are consecutive: no bank conflicts when they are parked and converted)
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sm3[3] = {0.f, 0.f, 0.f};
         float sqt = 0.0f;  // second moment (all three coordinates) of a SAMPLE about the cloud's first point -- the spread: wave w
-                           // takes its points of every fourth sweep (64-point runs all over the cloud, ~NC/4 points)
-        const float pil[3] = {cb[0], cb[1], cb[2]};
-        const int nsweep = (NC + kHThreads - 1) / kHThreads;
+                           // takes its points of every fourth sweep (64-point runs all over the cloud, ~SN/4 points)
+        const float pil[3] = {sb[0], sb[1], sb[2]};
+        const int nsweep = (SN + kHThreads - 1) / kHThreads;
         for (int i0 = 0; i0 < nsweep; i0 += 4) {
             P3 v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int pt = (i0 + e) * kHThreads + tid;
-                v[e] = *reinterpret_cast<const P3 *>(cb + (size_t)(pt < NC ? pt : NC - 1) * 3);  // (clamped: always valid)
+                v[e] = *reinterpret_cast<const P3 *>(sb + (size_t)(pt < SN ? pt : SN - 1) * 3);  // (clamped: always valid)
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -496,11 +505,11 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 mn[0] = fminf(mn[0], v[e].x); mx[0] = fmaxf(mx[0], v[e].x);
                 mn[1] = fminf(mn[1], v[e].y); mx[1] = fmaxf(mx[1], v[e].y);
                 mn[2] = fminf(mn[2], v[e].z); mx[2] = fmaxf(mx[2], v[e].z);
-                if (pt < NC) {
+                if (pt < SN) {
                     sm3[0] = sm3[0] + v[e].x; sm3[1] = sm3[1] + v[e].y; sm3[2] = sm3[2] + v[e].z;
-                    if (one_shot) imgf[((pt >> 5) * 2) * 32 + (pt & 31)] = float4{v[e].x, v[e].y, v[e].z, 0.0f};  // parked in its own first piece
+                    if (parked) imgf[((pt >> 5) * 2) * 32 + (pt & 31)] = float4{v[e].x, v[e].y, v[e].z, 0.0f};  // parked in its own first piece
                 }
-                if (((i0 + e) & 3) == (wv & 3) && pt < NC) {  // (the first condition is wave-uniform)
+                if (((i0 + e) & 3) == (wv & 3) && pt < SN) {  // (the first condition is wave-uniform)
                     sqt = __builtin_fmaf(v[e].x - pil[0], v[e].x - pil[0], sqt); sqt = __builtin_fmaf(v[e].y - pil[1], v[e].y - pil[1], sqt);
                     sqt = __builtin_fmaf(v[e].z - pil[2], v[e].z - pil[2], sqt);
                 }
@@ -539,14 +548,14 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
 #undef NN1_ROW_SUM
             const float lo3[3] = {lo4.x, lo4.y, lo4.z}, hi3[3] = {hi4.x, hi4.y, hi4.z}, st3[3] = {st4.x, st4.y, st4.z};
             // total variance about the mean from the sampled second moment about the first point (a data point: no cancellation for
-            // clouds far from the origin); the sample holds ~NC/4 points (the gate below is a heuristic: any estimate is correct)
-            float m3[3], ci = 0.0f, vm = st4.w / fmaxf(0.25f * (float)NC, 1.0f);
+            // clouds far from the origin); the sample holds ~SN/4 points (the gate below is a heuristic: any estimate is correct)
+            float m3[3], ci = 0.0f, vm = st4.w / fmaxf(0.25f * (float)SN, 1.0f);
             bool fin = true;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 const float lo = lo3[d], hi = hi3[d], st = st3[d];
-                m3[d] = fminf(fmaxf(st / (float)NC, lo), hi);  // (any centre is correct)
-                const float off = st / (float)NC - pil[d];
+                m3[d] = fminf(fmaxf(st / (float)SN, lo), hi);  // (any centre is correct)
+                const float off = st / (float)SN - pil[d];
                 vm = vm - off * off;
                 ci = fmaxf(ci, fmaxf(hi - m3[d], m3[d] - lo));
                 // a NaN or +-Inf coordinate makes the coordinate sum non-finite (fminf / fmaxf above skip NaNs)
@@ -575,7 +584,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     // (clean clouds never get here -- uniform boxes have cinf^2 = 3 var, Gaussians of a million points 30 var --; a round costs
     //  two barriers, ~1.3 us at C2; all three run only when the first finds the bulk kRobustHarm x below the farthest point)
     if (allfin && cinf < 1.0e16f && 3.0f * cinf * cinf > kRobustGate * varmax) {  // (varmax: the TOTAL variance of the three coordinates)
-        const float4 r = robust_range3<kHThreads, false>(cb, NC, one_shot, imgf, red, mu[0], mu[1], mu[2], cinf);
+        const float4 r = robust_range3<kHThreads, false>(sb, SN, parked, imgf, red, mu[0], mu[1], mu[2], cinf);
         mu[0] = r.x; mu[1] = r.y; mu[2] = r.z; rng = r.w;
     }
     // not sane (non-finite or huge coordinates): the filter is unusable, every query of the block scans every lane
@@ -628,7 +637,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
             h8 p0, p1;
             if (pt < cnt) {
-                if (one_shot) {
+                if (parked) {
                     const float4 r = imgf[i0];  // parked by this thread in the bounding-box pass
                     pieces(r.x, r.y, r.z, pt, p0, p1);
                 } else {
@@ -1001,6 +1010,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         //      dependent launch of ~6 us behind a 26 us kernel at C3's shape, 8 x 5000 x 5000).
         __shared__ int s_last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores of its gres rows have left the CU
+        // (measured with tools/nn1_probe at C3's shape: this drain is 14 k cycles of the last block's 25 k-cycle tail -- the price
+        //  of agent-scope visibility; counter 1.2 k, merge 4.6 k, finalisation 4.9 k)
         __syncthreads();
         const int ns = (NC + CH - 1) / CH < p.nsplit ? (NC + CH - 1) / CH : p.nsplit;  // subsets that exist for this direction
         if (tid == 0) {
@@ -1014,9 +1025,26 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         if (!s_last) return;  // (block-uniform)
         acc = 0.0;
         const int qend = (tile + 1) * tpb * QB < NQ ? (tile + 1) * tpb * QB : NQ;
-        for (int q = tile * tpb * QB + tid; q < qend; q += kHThreads) {
-            unsigned long long r = __hip_atomic_load(&p.gres[(size_t)c * p.qstride + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int sp = 1; sp < ns; ++sp) {
+        // (every row of every query of this thread requested at once: these loads go to memory -- another XCD's block wrote them --
+        //  and one after the other they were three dependent round trips per query, 23 k cycles for the tile's last block)
+        constexpr int kQ = 2, kS = 8;  // queries per thread (tpb <= 2: 1024 queries per tile) x subsets in flight
+        for (int q0 = tile * tpb * QB + tid; q0 < qend; q0 += kQ * kHThreads) {
+          unsigned long long rr[kQ][kS];
+#pragma unroll
+          for (int u = 0; u < kQ; ++u)
+#pragma unroll
+            for (int sp = 0; sp < kS; ++sp) {
+                const int q = q0 + u * kHThreads < qend ? q0 + u * kHThreads : q0;
+                rr[u][sp] = sp < ns ? __hip_atomic_load(&p.gres[((size_t)sp * 2 * p.B + c) * p.qstride + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+            }
+#pragma unroll
+          for (int u = 0; u < kQ; ++u) {
+            const int q = q0 + u * kHThreads;
+            if (q >= qend) break;
+            unsigned long long r = rr[u][0];
+#pragma unroll
+            for (int sp = 1; sp < kS; ++sp) r = rr[u][sp] < r ? rr[u][sp] : r;
+            for (int sp = kS; sp < ns; ++sp) {  // (more than eight subsets: the rest one by one)
                 const unsigned long long o = __hip_atomic_load(&p.gres[((size_t)sp * 2 * p.B + c) * p.qstride + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 r = o < r ? o : r;
             }
@@ -1024,6 +1052,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             if (idx_out) idx_out[(size_t)b * NQ + q] = (int)(unsigned int)r;
             if (dmin_out) dmin_out[(size_t)b * NQ + q] = dd;
             acc += (double)dd;
+          }
         }
     }
     if (p.partials) {

@@ -13,7 +13,8 @@
 #include <vector>
 
 int main(int argc, char **argv) {
-    const int B = 32, N = 4096, M = 4096;
+    // shape: C2 (B = 32, N = M = 4096) unless PB / PN / PM say otherwise (C3's chamfer launch: PB=8 PN=5000 PM=5000 PNB=240)
+    const int B = getenv("PB") ? atoi(getenv("PB")) : 32, N = getenv("PN") ? atoi(getenv("PN")) : 4096, M = getenv("PM") ? atoi(getenv("PM")) : 4096;
     std::vector<float> hx((size_t)3 * N * B), hy((size_t)3 * M * B);
     unsigned s = 12345;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
@@ -43,7 +44,7 @@ int main(int argc, char **argv) {
     // s_memtime runs at 100 MHz on gfx9 (constant), report in ns*10 -> convert: ticks * 10 ns
     const char *names[] = {"start", "bbox done", "c0 image staged", "c0 main loop done", "c0 exact done", "-",
                            "c1 image staged", "c1 main loop done", "c1 exact done", "-", "-", "merge", "end"};
-    int nb = 256;
+    int nb = getenv("PNB") ? atoi(getenv("PNB")) : 256;
     std::vector<double> d(13, 0.0);
     unsigned long long t0min = ~0ull, tmax = 0;
     for (int b = 0; b < nb; ++b) {
