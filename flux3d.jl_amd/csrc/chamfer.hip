@@ -1010,8 +1010,9 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         //      dependent launch of ~6 us behind a 26 us kernel at C3's shape, 8 x 5000 x 5000).
         __shared__ int s_last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores of its gres rows have left the CU
-        // (measured with tools/nn1_probe at C3's shape: this drain is 14 k cycles of the last block's 25 k-cycle tail -- the price
-        //  of agent-scope visibility; counter 1.2 k, merge 4.6 k, finalisation 4.9 k)
+        // (tools/nn1_probe at C3's shape: thread 0 waits ~14 k cycles here -- for the block's slower WAVES at the barrier below, not
+        //  for the stores: a SIMD serves its oldest wave first, wave 0 is done ~20 k cycles before the last one at C2 too --, then
+        //  counter 1.2 k, merge 4.6 k, finalisation 4.9 k cycles)
         __syncthreads();
         const int ns = (NC + CH - 1) / CH < p.nsplit ? (NC + CH - 1) / CH : p.nsplit;  // subsets that exist for this direction
         if (tid == 0) {
