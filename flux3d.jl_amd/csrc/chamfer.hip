@@ -357,7 +357,13 @@ constexpr int kHFifo = FX3D_HFIFO;  // lane tiles tracked per lane and pass: the
                                     // uniform C2 unchanged, 51.0 -> 50.5 .. 50.9 on one box: the extra v_med3 per lane tile hides under the MFMAs);
                                     // five / six cost uniform C2 0.5 - 1.4 us and make the A != B lattice slower (99 -> 122 / 129 us)
 constexpr int kHChunkMax = 4096;  // 32 B per candidate => 128 KiB
-constexpr int kHItemCap = 64 * kHFifo;  // the FIFO path never overflows the list
+#ifndef FX3D_HRUNS_FROM
+#define FX3D_HRUNS_FROM 16
+#endif
+constexpr int kHRunsFrom = FX3D_HRUNS_FROM;  // slow queries in a wave from which its retry pass enqueues runs instead of lane tiles
+constexpr int kHRunCap = 384;        // the retry pass's list of RUN items (four consecutive candidates of one query each): a 32-candidate block
+                                    // appends at most 256, the list is drained when fewer are free
+constexpr int kHItemCap = 64 * kHFifo > kHRunCap ? 64 * kHFifo : kHRunCap;  // (the FIFO path never overflows its 64 * kHFifo)
 constexpr int kHFarCap = 64;      // far candidates kept on the exact side list; more: the chunk falls back to exact scans
 constexpr int kHTail = 64;        // a cloud of up to kHChunkMax + kHTail points stays one LDS image: the last <= 64 candidates are
                                   // compared exactly by every query (N = M = 4097 was 2.1 x N = M = 4096: two half-empty chunks,
@@ -825,7 +831,11 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 // a NaN distance needs a non-finite cloud or a non-finite query (wave-uniform switch of the task code)
                 const bool nonfinite = !sane || __ballot(!qfin) != 0;
                 const int nlt = nblk / kHLT;
-                int lt2 = 0;
+                int lt2 = 0;  // (retry: the next 32-candidate BLOCK of the pass, nblk of them)
+                // (retry) tightly clustered clouds put most queries of a wave over the FIFO: RUN items; a few slow queries
+                // (ties on a lattice, duplicates): lane-tile items, whose filter pass is cheaper (one ballot per 64 candidates)
+                const bool runs = retry && __builtin_popcount(qslow) >= kHRunsFrom;
+                const int lt2_end = runs ? nblk : nlt;
                 do {
                     int nitems = 0;
                     if (!retry && fifo_done) {
@@ -883,37 +893,60 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                         fifo_done = true;
                         lt2 = qslow ? 0 : nlt;
                     } else {
+                        // (round 5) RUN-granular items: a lane's 16 rows of a block are four runs of four consecutive candidates
+                        // (rows 4g .. 4g + 3 = candidates 8g + 4hh + 0..3); a run is an item when its minimum lies within the band.
+                        // Lane-tile items (32 candidates each, as the FIFO path has them) made tightly clustered clouds evaluate
+                        // more than half of all pairs exactly: ~100 candidates of 4096 within the band, one in every other lane tile.
                         const h8 *pb = imgp + hh * 32 + jq;
+                        if (!runs) {
 #pragma unroll 1
-                        for (; lt2 < nlt && nitems <= kHItemCap - 64; ++lt2) {
-                            float t2 = INFINITY;
+                            for (; lt2 < nlt && nitems <= kHItemCap - 64; ++lt2) {
+                                float t2 = INFINITY;
 #pragma unroll
-                            for (int bb = 0; bb < kHLT; ++bb) {
-                                const f32x16 av = __builtin_amdgcn_mfma_f32_32x32x16_f16(pb[(lt2 * kHLT + bb) * 64], bq, zero, 0, 0, 0);
+                                for (int bb = 0; bb < kHLT; ++bb) {
+                                    const f32x16 av = __builtin_amdgcn_mfma_f32_32x32x16_f16(pb[(lt2 * kHLT + bb) * 64], bq, zero, 0, 0, 0);
 #pragma unroll
-                                for (int r = 0; r < 16; r += 2) t2 = min3f(t2, av[r], av[r + 1]);
+                                    for (int r = 0; r < 16; r += 2) t2 = min3f(t2, av[r], av[r + 1]);
+                                }
+                                const bool qual = !usable || t2 <= thr1;
+                                const unsigned long long bal = __ballot(qual);
+                                if (bal) {
+                                    const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
+                                    if (qual) items[pos] = (unsigned short)(((unsigned int)jq << 7) | ((unsigned int)hh << 6) | (unsigned int)lt2);
+                                    nitems += __builtin_popcountll(bal);
+                                }
                             }
-                            const bool qual = !usable || t2 <= thr1;
-                            const unsigned long long bal = __ballot(qual);
-                            if (bal) {
-                                const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
-                                                         __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
-                                if (qual) items[pos] = (unsigned short)(((unsigned int)jq << 7) | ((unsigned int)hh << 6) | (unsigned int)lt2);
-                                nitems += __builtin_popcountll(bal);
+                        } else
+#pragma unroll 1
+                        for (; lt2 < nblk && nitems <= kHItemCap - 256; ++lt2) {
+                            const f32x16 av = __builtin_amdgcn_mfma_f32_32x32x16_f16(pb[lt2 * 64], bq, zero, 0, 0, 0);
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const float mg = vmin(min3f(av[4 * g], av[4 * g + 1], av[4 * g + 2]), av[4 * g + 3]);
+                                const bool qual = !usable || mg <= thr1;
+                                const unsigned long long bal = __ballot(qual);
+                                if (bal) {
+                                    const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
+                                    if (qual) items[pos] = (unsigned short)(((unsigned int)jq << 10) | ((unsigned int)hh << 9) | ((unsigned int)lt2 << 2) | (unsigned int)g);
+                                    nitems += __builtin_popcountll(bal);
+                                }
                             }
                         }
                     }
                     // all 64 lanes share the (item, run-of-4-candidates) tasks
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_wave_barrier();
-                    const int ntask = nitems * (kHLT * 4);
+                    const int ntask = runs ? nitems : nitems * (kHLT * 4);
                     for (int t0 = 0; t0 < ntask; t0 += 64) {
                         const int t = t0 + lane;
                         if (t < ntask) {
-                            const unsigned int it = items[t / (kHLT * 4)];
+                            const unsigned int it = items[runs ? t : t / (kHLT * 4)];
                             const int run = t % (kHLT * 4);
-                            const int qs = it >> 7, ih = (it >> 6) & 1, tl = it & 63;
-                            const int jl0 = (tl * kHLT + (run >> 2)) * 32 + 8 * (run & 3) + 4 * ih;
+                            const int qs = runs ? it >> 10 : it >> 7, ih = runs ? (it >> 9) & 1 : (it >> 6) & 1, tl = it & 63;
+                            const int jl0 = runs ? (int)((it >> 2) & 127u) * 32 + 8 * (int)(it & 3u) + 4 * ih
+                                                  : (tl * kHLT + (run >> 2)) * 32 + 8 * (run & 3) + 4 * ih;
                             float cx[4], cy[4], cz[4];
                             if (vec && jl0 + 4 <= cnt) {
                                 load4pts(cb, j0 + jl0, cx, cy, cz);
@@ -949,7 +982,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                             if (jl0 < cnt) atomicMin(&qres[qs], ((unsigned long long)kb << 32) | (unsigned int)ib);
                         }
                     }
-                } while (lt2 < nlt);
+                } while (lt2 < lt2_end);
                 // the far candidates (outside the filter): every query of the wave against each of them, exactly
                 if (far_ok) {
                     for (int t = lane; t < 32 * nf; t += 64) {

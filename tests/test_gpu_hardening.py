@@ -191,6 +191,24 @@ def test_near_ties_at_the_band_edge(gpu_fx, oracle, scale_exp, offset):
         assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
 
 
+@pytest.mark.parametrize("sigma", [1e-1, 1e-3])
+@pytest.mark.parametrize("shape", [(4096, 4096), (3000, 5000), (700, 9000)])
+def test_tight_clusters_dense_band(gpu_fx, oracle, sigma, shape):
+    """Clouds of 40 tight clusters around SHARED centres (and a cloud against itself): tens to hundreds of candidates of every
+    query lie within the filter's band, every wave re-runs its filter pass and enqueues RUNS of four candidates
+    (csrc/chamfer.hip, the `runs` form of the retry pass; one image, two chunks and a candidate-split shape).  Indices and
+    distances bit for bit, lowest index on the exact ties of the self search."""
+    N, M = shape
+    rng = np.random.default_rng(int(1000 * sigma) + N)
+    c = rng.standard_normal((3, 40)) * 3
+    x = np.asfortranarray((c[:, rng.integers(0, 40, N)] + rng.standard_normal((3, N)) * sigma)[:, :, None].astype(np.float32))
+    y = np.asfortranarray((c[:, rng.integers(0, 40, M)] + rng.standard_normal((3, M)) * sigma)[:, :, None].astype(np.float32))
+    _nn_equal(gpu_fx, oracle, x, y)
+    big = x if N >= M else y
+    big[:, 100:200] = big[:, :100]  # exact duplicates: the lower index wins
+    _nn_equal(gpu_fx, oracle, big, big)
+
+
 def _worst_split_values(rng, n, e_lo, e_hi):
     """Float32 values whose 2-way fp16 split rounds as badly as it can: 24-bit mantissa = (11-bit head) * 2^13 + r with r odd
     and 2^11 <= |r| < 2^12 -- the residual needs 12 bits, so the low piece's round-to-nearest is a tie (error 2^-23 of the

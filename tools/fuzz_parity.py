@@ -27,6 +27,10 @@ def cloud(rng, D, N, B, kind):
     elif kind == "clustered":
         c = rng.standard_normal((D, 1 + N // 50, B)) * 3
         x = c[:, rng.integers(0, c.shape[1], N), :] + rng.standard_normal((D, N, B)) * 0.05
+    elif kind == "tight":
+        # tight clusters around centres every cloud of the run shares (a fixed stream): dense bands, the retry pass's RUN items
+        c = np.random.default_rng(7).standard_normal((D, 40, 1)) * 3
+        x = c[:, rng.integers(0, 40, N), :] + rng.standard_normal((D, N, B)) * rng.choice([1e-1, 1e-2, 1e-3])
     elif kind == "lattice":
         x = rng.integers(0, 6, (D, N, B)).astype(np.float64) * 0.25
     elif kind == "dupes":
@@ -49,7 +53,7 @@ def cloud(rng, D, N, B, kind):
     return np.asfortranarray(x.astype(np.float32))
 
 
-KINDS = ["uniform", "normal", "clustered", "lattice", "dupes", "offset", "range", "worstsplit"]
+KINDS = ["uniform", "normal", "clustered", "tight", "lattice", "dupes", "offset", "range", "worstsplit"]
 
 
 def mesh_batch(rng):

@@ -1,6 +1,6 @@
 """chamfer_distance forward at the C2 shape (B = 32, N = M = 4096, D = 3) on data distributions that stress the filter's
 band and FIFO: uniform, Gaussian, tight clusters, lattice (exact ties everywhere), duplicated points, a far outlier
-(scale set by it), identical clouds.  Prints microseconds per call.   python tools/nn1_distribution_time.py"""
+(scale set by it), identical clouds.  Prints microseconds per call.   python tools/nn1_distribution_time.py [kind,kind,...]"""
 import os
 import sys
 
@@ -35,7 +35,8 @@ def make(kind):
     raise KeyError(kind)
 
 
-for kind in ("uniform", "normal+100", "clusters", "lattice", "dupes", "outlier"):
+KINDS = sys.argv[1].split(",") if len(sys.argv) > 1 else ("uniform", "normal+100", "clusters", "lattice", "dupes", "outlier")
+for kind in KINDS:
     for same in (False, True):
         x = np.asfortranarray(make(kind).astype(np.float32))
         y = x if same else np.asfortranarray(make(kind).astype(np.float32))
