@@ -361,6 +361,10 @@ constexpr int kHChunkMax = 4096;  // 32 B per candidate => 128 KiB
 #define FX3D_HRUNS_FROM 16
 #endif
 constexpr int kHRunsFrom = FX3D_HRUNS_FROM;  // slow queries in a wave from which its retry pass enqueues runs instead of lane tiles
+#ifndef FX3D_SCANU
+#define FX3D_SCANU 2
+#endif
+constexpr int kScanU = FX3D_SCANU;  // runs of four candidates a lane has in flight in the exact scan of ONE slow query
 constexpr int kHRunCap = 384;        // the retry pass's list of RUN items (four consecutive candidates of one query each): a 32-candidate block
                                     // appends at most 256, the list is drained when fewer are free
 constexpr int kHItemCap = 64 * kHFifo > kHRunCap ? 64 * kHFifo : kHRunCap;  // (the FIFO path never overflows its 64 * kHFifo)
@@ -835,6 +839,14 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 // (retry) tightly clustered clouds put most queries of a wave over the FIFO: RUN items; a few slow queries
                 // (ties on a lattice, duplicates): lane-tile items, whose filter pass is cheaper (one ballot per 64 candidates)
                 const bool runs = retry && __builtin_popcount(qslow) >= kHRunsFrom;
+#ifdef FX3D_PROBE_COUNT  // (with FX3D_PROBE; the atomics distort the stamps: counters and stamps in separate builds)
+                if ((threadIdx.x & 63) == 0) {  // wave-passes, with slow queries, retried, with run items, slow queries, unusable lanes
+                    unsigned long long *pc = &g_probe[4095 * 16];
+                    atomicAdd(&pc[0], 1ull); atomicAdd(&pc[1], qslow ? 1ull : 0ull); atomicAdd(&pc[2], retry ? 1ull : 0ull);
+                    atomicAdd(&pc[3], runs ? 1ull : 0ull); atomicAdd(&pc[4], (unsigned long long)__builtin_popcount(qslow));
+                    atomicAdd(&pc[5], (unsigned long long)__builtin_popcountll(__ballot(!usable)));
+                }
+#endif
                 const int lt2_end = runs ? nblk : nlt;
                 do {
                     int nitems = 0;
@@ -849,10 +861,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                         unsigned long long kbest = ~0ull;
                         for (int h = 0; h < 2; ++h) {
                             if (!((sb >> (32 * h + qsl)) & 1ull)) continue;  // (wave-uniform)
-                            for (int r0 = 4 * (2 * lane + h); r0 < cnt; r0 += 2 * 512) {
-                                float cx[2][4], cy[2][4], cz[2][4];
+                            for (int r0 = 4 * (2 * lane + h); r0 < cnt; r0 += kScanU * 512) {
+                                float cx[kScanU][4], cy[kScanU][4], cz[kScanU][4];
 #pragma unroll
-                                for (int u = 0; u < 2; ++u) {
+                                for (int u = 0; u < kScanU; ++u) {
                                     const int jl0 = r0 + 512 * u;
                                     if (vec && jl0 + 4 <= cnt) {
                                         load4pts(cb, j0 + jl0, cx[u], cy[u], cz[u]);
@@ -866,7 +878,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                                     }
                                 }
 #pragma unroll
-                                for (int u = 0; u < 2; ++u)
+                                for (int u = 0; u < kScanU; ++u)
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) {
                                         const int jc = r0 + 512 * u + r;

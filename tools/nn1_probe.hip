@@ -20,6 +20,18 @@ int main(int argc, char **argv) {
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
     for (auto &v : hx) v = rnd();
     for (auto &v : hy) v = rnd();
+    if (getenv("PCLUSTERS")) {  // 40 cluster centres ~ N(0, 3^2) per cloud, jitter PSIGMA (1e-3); PCLUSTERS=shared: y around x's centres; =same: y = x
+        const float sigma = getenv("PSIGMA") ? (float)atof(getenv("PSIGMA")) : 1e-3f;
+        auto gauss = [&]() { float a = 0; for (int i = 0; i < 12; ++i) a += rnd(); return a - 6.0f; };
+        const bool shared = !strcmp(getenv("PCLUSTERS"), "shared"), same = !strcmp(getenv("PCLUSTERS"), "same");
+        for (int b = 0; b < B; ++b) {
+            float cx[40][3], cy[40][3];
+            for (int c = 0; c < 40; ++c) for (int d = 0; d < 3; ++d) { cx[c][d] = 3 * gauss(); cy[c][d] = shared ? cx[c][d] : 3 * gauss(); }
+            for (int i = 0; i < N; ++i) { const int c = (int)(rnd() * 40) % 40; for (int d = 0; d < 3; ++d) hx[((size_t)b * N + i) * 3 + d] = cx[c][d] + sigma * gauss(); }
+            for (int i = 0; i < M; ++i) { const int c = (int)(rnd() * 40) % 40; for (int d = 0; d < 3; ++d) hy[((size_t)b * M + i) * 3 + d] = cy[c][d] + sigma * gauss(); }
+        }
+        if (same) hy = hx;
+    }
     float *x, *y; double *part; float *loss;
     hipMalloc(&x, hx.size() * 4); hipMalloc(&y, hy.size() * 4);
     hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
@@ -56,7 +68,7 @@ int main(int argc, char **argv) {
     }
     printf("kernel span (first block start -> last block end): %llu ticks\n", tmax - t0min);
     for (int k = 1; k <= 12; ++k) printf("  %-20s avg %10.1f ticks\n", names[k], d[k] / nb);
-    printf("wave-passes %llu, with a slow lane %llu, slow lanes %llu (last launch x25 accumulated)\n", pr[4095 * 16], pr[4095 * 16 + 1], pr[4095 * 16 + 2]);
+    printf("accumulated over all launches: wave-passes %llu, with slow queries %llu, retried %llu, with run items %llu; slow queries %llu, lanes with an unusable filter %llu\n", pr[4095 * 16], pr[4095 * 16 + 1], pr[4095 * 16 + 2], pr[4095 * 16 + 3], pr[4095 * 16 + 4], pr[4095 * 16 + 5]);
     if (getenv("RAW"))  // stamps of a few blocks relative to their first one (marks need not be in index order)
         for (int b = 0; b < 3; ++b) {
             printf("block %d:", b);
