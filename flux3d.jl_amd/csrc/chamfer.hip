@@ -361,10 +361,7 @@ constexpr int kHChunkMax = 4096;  // 32 B per candidate => 128 KiB
 #define FX3D_HRUNS_FROM 16
 #endif
 constexpr int kHRunsFrom = FX3D_HRUNS_FROM;  // slow queries in a wave from which its retry pass enqueues runs instead of lane tiles
-#ifndef FX3D_SCANU
-#define FX3D_SCANU 2
-#endif
-constexpr int kScanU = FX3D_SCANU;  // runs of four candidates a lane has in flight in the exact scan of ONE slow query
+constexpr int kScanU = 2;  // runs of four candidates a lane has in flight in the exact scan of ONE slow query (3 measured equal; 4 spills)
 constexpr int kHRunCap = 384;        // the retry pass's list of RUN items (four consecutive candidates of one query each): a 32-candidate block
                                     // appends at most 256, the list is drained when fewer are free
 constexpr int kHItemCap = 64 * kHFifo > kHRunCap ? 64 * kHFifo : kHRunCap;  // (the FIFO path never overflows its 64 * kHFifo)

@@ -20,6 +20,12 @@ int main(int argc, char **argv) {
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
     for (auto &v : hx) v = rnd();
     for (auto &v : hy) v = rnd();
+    if (getenv("PLINE")) {  // the reference harness's input (benchmarks/metrics.jl:11-15): p_i = (i, i, i) / n, the same cloud on both sides
+        for (int b = 0; b < B; ++b) {
+            for (int i = 0; i < N; ++i) for (int d = 0; d < 3; ++d) hx[((size_t)b * N + i) * 3 + d] = (float)(i + 1) / (float)N;
+            for (int i = 0; i < M; ++i) for (int d = 0; d < 3; ++d) hy[((size_t)b * M + i) * 3 + d] = (float)(i + 1) / (float)M;
+        }
+    }
     if (getenv("PCLUSTERS")) {  // 40 cluster centres ~ N(0, 3^2) per cloud, jitter PSIGMA (1e-3); PCLUSTERS=shared: y around x's centres; =same: y = x
         const float sigma = getenv("PSIGMA") ? (float)atof(getenv("PSIGMA")) : 1e-3f;
         auto gauss = [&]() { float a = 0; for (int i = 0; i < 12; ++i) a += rnd(); return a - 6.0f; };
