@@ -58,8 +58,8 @@ FX3D_API size_t fx3d_last_error(char *buf, size_t n); /* thread-local message; r
 
 /* ---- variant switches --------------------------------------------------------------------------------------------
  * The kernels' alternative code paths (A/B measurements, tests) are chosen by named integer options, process-wide and
- * atomic: nn1_variant (3 | 0), nn1_tpb, nn1_nosplit, bwd_global_atomics, knn_f32, knn_f16_split, knn_no_mfma,
- * knn_no_prepass, knn_direct_lds, knn_row_stages, knn_gather, knn_d3_wave, knn_d3_no_compact, knn_slices, lap_bwd_scatter, edge_scalar_stores, edge_fsplit, edge_no_nt, edgeconv_unfused, cdf_multiblock_from, nn1_tiny_mpairs, mesh_max_blocks
+ * atomic -- eleven since round 5: nn1_variant (3 | 0), nn1_nosplit, bwd_global_atomics, knn_no_mfma, knn_no_prepass,
+ * knn_slices, edgeconv_unfused, lap_bwd_scatter, cdf_multiblock_from, nn1_tiny_mpairs, mesh_max_blocks
  * (fx3d_option_count / fx3d_option_name enumerate them).  The environment variables FX3D_<NAME> only seed the defaults,
  * once, at the first use of the library; no entry point reads the environment on its launch path.  A host that runs two
  * configurations in one process sets the option before the calls that need it. */
