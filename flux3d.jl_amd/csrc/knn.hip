@@ -8,7 +8,7 @@
 //
 // Kernels, in file order (dispatch in launch_knn / fx3d_edgeconv_graph at the end of the file):
 //   knn_wave_d3_kernel / knn_wave_generic_kernel   one wave per query, exact distances: every shape the two below do not take
-//   knn_exact_bruteforce / knn_rank_ties           wave-cooperative exact selection / tie re-rank shared by all kernels
+//   knn_exact_bruteforce / knn_rank_ties4          wave-cooperative exact selection / tie re-rank shared by all kernels
 //   knn_gather[4]_kernel                           X[:, idx] (src/models/dgcnn.jl:6)
 //   knn_select_kernel                              any k + drop <= M, any D (M <= 36864): all keys of a query in LDS, radix select;
 //                                                  also the fallback of the verified slice merge (flagged queries only)
@@ -27,6 +27,7 @@
 
 namespace {
 
+#ifndef FX3D_KNN_ONE_TU  // (tools/knn_probe.hip includes the three units into one: the names below are then the units' own)
 // the other units' entry points under the names the dispatch below was written with
 inline fx3d_status launch_knn_f16_d3(const float *x, int N, const float *y, int M, int B, int k, int drop, int32_t *idx, float *dist,
                                      hipStream_t st, float *feat = nullptr, int layout = 0, int xdiv = 1) {
@@ -39,6 +40,7 @@ inline fx3d_status launch_knn_mfma(const float *x, int N, const float *y, int M,
 inline bool knn_pre_shape_ok(int M, int D, int kk) { return knn_mfma_pre_shape_ok(M, D, kk); }
 inline bool knn_pre_eligible(const float *x, const float *y, int M, int D, int kk) { return knn_mfma_pre_eligible(x, y, M, D, kk); }
 inline size_t knn_pre_bytes(int M, int B, int D) { return knn_mfma_pre_bytes(M, B, D); }
+#endif
 
 __global__ __launch_bounds__(kWThreads) void knn_wave_d3_kernel(const float *__restrict__ x, int N,
                                                                 const float *__restrict__ y, int M, int B,

@@ -1,6 +1,6 @@
 // Shared by the translation units of the k-NN kernels (knn.hip: wave / selection / gather / EdgeConv-feature kernels, the
 // dispatch and the C entry points; knn_d3.hip: knn_f16_d3_kernel; knn_mfma.hip: the feature-space pre-pass + knn_mfma_kernel):
-// constants, the wave-level sorting / selection helpers, knn_exact_bruteforce, knn_rank_ties, knn_tau_8of16, and the
+// constants, the wave-level sorting / selection helpers, knn_exact_bruteforce, knn_rank_ties4, knn_tau_8of16, and the
 // declarations of what the units call across.  (File-local helpers live in an anonymous namespace: every unit has its copy.)
 #pragma once
 #include <cmath>
@@ -395,26 +395,33 @@ __device__ __forceinline__ void knn_stage_chunk(const float *__restrict__ yb, in
     }
 }
 
-// Wave-cooperative ranking of ONE query's n survivors on the full (distance bits, index) keys -- the path of the
-// rare query whose distance-only ranks collide (an exact tie among its first kk).  Lane e ranks key e against all
-// n (LDS broadcast reads; qd / qj are padded with sentinels up to a multiple of four); keys are unique, so the
-// ranks below kk are a permutation and slots[0, kk) is the sorted answer.  One tied query costs its wave well
-// under a microsecond (a per-lane loop over the query's keys made the whole grid wait ~10 us for one wave).
-__device__ __forceinline__ void knn_rank_ties(const unsigned int *qd, const int *qj, int n, int kk,
-                                              unsigned long long *slots, int lane) {
-    for (int e = lane; e < n; e += 64) {
-        const unsigned int md = qd[e];
-        const int mj = qj[e];
-        int rank = 0;
+// Ranking of a wave's tied queries on the full (distance bits, index) keys -- the path of a query whose distance-only ranks collide
+// (an exact tie among its first kk): up to SIXTEEN queries at once, four lanes per query (pl = 0..3), every lane called with ITS
+// query's key arrays (n = 0: no query).  A lane ranks entries pl, pl + 4, ... against all n (qd / qj are padded with sentinels up to
+// a multiple of four); keys are unique, so the ranks below kk are a permutation and slots[0, kk) is the sorted answer.  Lattices and
+// duplicated points tie in EVERY query: one query at a time (a wave per query, rounds 2-4) cost the wave 16 x (a chain of LDS round
+// trips + the output stores) -- 23 / 28 us of the 53 / 59 us at C4's shape; here the chains overlap (17 us: what is left is the
+// n^2 compares of four VALU each, run to the longest list of the wave).
+__device__ __forceinline__ void knn_rank_ties4(const unsigned int *qd, const int *qj, int n, int kk, unsigned long long *slots, int pl) {
+    for (int e = pl; e < n; e += 8) {  // two entries of this lane per pass over the keys
+        const bool two = e + 4 < n;
+        const unsigned int md0 = qd[e], md1 = two ? qd[e + 4] : 0xffffffffu;
+        const int mj0 = qj[e], mj1 = two ? qj[e + 4] : 0x7fffffff;
+        int r0 = 0, r1 = 0;
         for (int i = 0; i < n; i += 4) {
             const uint4 od = *reinterpret_cast<const uint4 *>(qd + i);
             const int4 oj = *reinterpret_cast<const int4 *>(qj + i);
-            rank += (int)(od.x < md) | ((int)(od.x == md) & (int)(oj.x < mj));
-            rank += (int)(od.y < md) | ((int)(od.y == md) & (int)(oj.y < mj));
-            rank += (int)(od.z < md) | ((int)(od.z == md) & (int)(oj.z < mj));
-            rank += (int)(od.w < md) | ((int)(od.w == md) & (int)(oj.w < mj));
+            r0 += (int)(od.x < md0) | ((int)(od.x == md0) & (int)(oj.x < mj0));
+            r0 += (int)(od.y < md0) | ((int)(od.y == md0) & (int)(oj.y < mj0));
+            r0 += (int)(od.z < md0) | ((int)(od.z == md0) & (int)(oj.z < mj0));
+            r0 += (int)(od.w < md0) | ((int)(od.w == md0) & (int)(oj.w < mj0));
+            r1 += (int)(od.x < md1) | ((int)(od.x == md1) & (int)(oj.x < mj1));
+            r1 += (int)(od.y < md1) | ((int)(od.y == md1) & (int)(oj.y < mj1));
+            r1 += (int)(od.z < md1) | ((int)(od.z == md1) & (int)(oj.z < mj1));
+            r1 += (int)(od.w < md1) | ((int)(od.w == md1) & (int)(oj.w < mj1));
         }
-        if (rank < kk) slots[rank] = ((unsigned long long)md << 32) | (unsigned int)mj;
+        if (r0 < kk) slots[r0] = ((unsigned long long)md0 << 32) | (unsigned int)mj0;
+        if (two && r1 < kk) slots[r1] = ((unsigned long long)md1 << 32) | (unsigned int)mj1;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();

@@ -1822,19 +1822,21 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     // alternate queries
     const bool slowq = qi < N && !fast && !handled;
     const unsigned long long badmask = __ballot(bad);
-    for (unsigned int bm = (unsigned int)badmask | (unsigned int)(badmask >> 32); bm; bm &= bm - 1) {
-        const int j = __builtin_ctz(bm);  // a tie in the distance among the first kk of query j
-        if ((j & 1) != (consumer ? 0 : 1)) continue;  // (the pair's two waves take alternate queries)
+    if (const unsigned int bad32 = (unsigned int)badmask | (unsigned int)(badmask >> 32)) {
+        // the wave's tied queries at once, four lanes per query (knn_common.h: knn_rank_ties4)
+        const int j = 2 * (lane >> 2) + (consumer ? 0 : 1), pl = lane & 3;
+        const bool mine = ((bad32 >> j) & 1u) != 0;
         const int qs = cw * 32 + j;
         unsigned long long *sj = reinterpret_cast<unsigned long long *>(lists) + (size_t)qs * 33;
-        knn_rank_ties(reinterpret_cast<const unsigned int *>(sm) + (size_t)qs * kMKeyStride,
-                      reinterpret_cast<const int *>(sm) + (size_t)kMWaves * 32 * kMKeyStride + (size_t)qs * kMKeyStride, qn_n[qs], kk,
-                      sj, lane);
-        for (int r = drop + lane; r < kk; r += 64) {
-            const unsigned long long key = sj[r];
-            idx[((size_t)b * N + q0 + j) * k + r - drop] = (int)(unsigned int)key;
-            if (dist) dist[((size_t)b * N + q0 + j) * k + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
-        }
+        knn_rank_ties4(reinterpret_cast<const unsigned int *>(sm) + (size_t)qs * kMKeyStride,
+                       reinterpret_cast<const int *>(sm) + (size_t)kMWaves * 32 * kMKeyStride + (size_t)qs * kMKeyStride, mine ? qn_n[qs] : 0, kk,
+                       sj, pl);
+        if (mine)
+            for (int r = drop + pl; r < kk; r += 4) {
+                const unsigned long long key = sj[r];
+                idx[((size_t)b * N + q0 + j) * k + r - drop] = (int)(unsigned int)key;
+                if (dist) dist[((size_t)b * N + q0 + j) * k + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
+            }
     }
     // leftovers (overflowing lists, non-finite bands), wave-cooperative (scratch: behind all the slots)
     int *wscratch = lists + kMWaves * 32 * 33 * 2 + wv * 128;

@@ -2,9 +2,10 @@
 // includes knn.hip with FX3D_PROBE so that thread 0 of every block stores cycle-counter stamps.  Build:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DFX3D_PROBE -I include -I flux3d.jl_amd/csrc \
 //         tools/knn_probe.hip flux3d.jl_amd/csrc/runtime.hip -o tools/knn_probe
-#include "../flux3d.jl_amd/csrc/knn.hip"
+#define FX3D_KNN_ONE_TU  // the three units of the k-NN family in one translation unit: one g_kprobe, no cross-unit shims
 #include "../flux3d.jl_amd/csrc/knn_d3.hip"
 #include "../flux3d.jl_amd/csrc/knn_mfma.hip"
+#include "../flux3d.jl_amd/csrc/knn.hip"
 
 #include <algorithm>
 #include <cstdio>
