@@ -362,7 +362,10 @@ constexpr int kHChunkMax = 4096;  // 32 B per candidate => 128 KiB
 #endif
 constexpr int kHRunsFrom = FX3D_HRUNS_FROM;  // slow queries in a wave from which its retry pass enqueues runs instead of lane tiles
 constexpr int kScanU = 2;  // runs of four candidates a lane has in flight in the exact scan of ONE slow query (3 measured equal; 4 spills)
-constexpr int kHRunCap = 384;        // the retry pass's list of RUN items (four consecutive candidates of one query each): a 32-candidate block
+#ifndef FX3D_HRUNCAP
+#define FX3D_HRUNCAP 384
+#endif
+constexpr int kHRunCap = FX3D_HRUNCAP;        // the retry pass's list of RUN items (four consecutive candidates of one query each): a 32-candidate block
                                     // appends at most 256, the list is drained when fewer are free
 constexpr int kHItemCap = 64 * kHFifo > kHRunCap ? 64 * kHFifo : kHRunCap;  // (the FIFO path never overflows its 64 * kHFifo)
 constexpr int kHFarCap = 64;      // far candidates kept on the exact side list; more: the chunk falls back to exact scans
@@ -947,15 +950,15 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     // all 64 lanes share the (item, run-of-4-candidates) tasks
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_wave_barrier();
-                    const int ntask = runs ? nitems : nitems * (kHLT * 4);
+                    if (!runs) {
+                    const int ntask = nitems * (kHLT * 4);
                     for (int t0 = 0; t0 < ntask; t0 += 64) {
                         const int t = t0 + lane;
                         if (t < ntask) {
-                            const unsigned int it = items[runs ? t : t / (kHLT * 4)];
+                            const unsigned int it = items[t / (kHLT * 4)];
                             const int run = t % (kHLT * 4);
-                            const int qs = runs ? it >> 10 : it >> 7, ih = runs ? (it >> 9) & 1 : (it >> 6) & 1, tl = it & 63;
-                            const int jl0 = runs ? (int)((it >> 2) & 127u) * 32 + 8 * (int)(it & 3u) + 4 * ih
-                                                  : (tl * kHLT + (run >> 2)) * 32 + 8 * (run & 3) + 4 * ih;
+                            const int qs = it >> 7, ih = (it >> 6) & 1, tl = it & 63;
+                            const int jl0 = (tl * kHLT + (run >> 2)) * 32 + 8 * (run & 3) + 4 * ih;
                             float cx[4], cy[4], cz[4];
                             if (vec && jl0 + 4 <= cnt) {
                                 load4pts(cb, j0 + jl0, cx, cy, cz);
@@ -989,6 +992,32 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                                 }
                             }
                             if (jl0 < cnt) atomicMin(&qres[qs], ((unsigned long long)kb << 32) | (unsigned int)ib);
+                        }
+                    }
+                    } else {
+                        // run items: one task per item, a loop of its own with plain 4-byte loads and canonical keys (the loop above keeps
+                        // the instruction stream it had before the run items existed: sharing it through selects on `runs` cost C2 + 0.7 us
+                        // per step on the same box, sharing the task body -- lambda or macro -- lost its 16-byte loads: + 6.7 us; here the
+                        // loads are not what bounds the tasks: knocked out, the dense case keeps its time)
+#pragma unroll 1
+                        for (int t0 = 0; t0 < nitems; t0 += 64) {
+                            const int t = t0 + lane;
+                            if (t < nitems) {
+                                const unsigned int it = items[t];
+                                const int qs = (int)(it >> 10);
+                                const int jl0 = (int)((it >> 2) & 127u) * 32 + 8 * (int)(it & 3u) + 4 * (int)((it >> 9) & 1u);
+                                const float qq[3] = {qtab[qs * 3], qtab[qs * 3 + 1], qtab[qs * 3 + 2]};
+                                unsigned long long kbest = ~0ull;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int jc = jl0 + r < cnt ? jl0 + r : cnt - 1;
+                                    const float *src = cb + (size_t)(j0 + jc) * 3;
+                                    const float cc3[3] = {src[0], src[1], src[2]};
+                                    const unsigned long long key = ((unsigned long long)dist_key(sqd<3>(qq, cc3)) << 32) | (unsigned int)(j0 + jc);
+                                    if (jl0 + r < cnt && key < kbest) kbest = key;
+                                }
+                                if (jl0 < cnt) atomicMin(&qres[qs], kbest);
+                            }
                         }
                     }
                 } while (lt2 < lt2_end);

@@ -1,6 +1,6 @@
 // Shared by the translation units of the k-NN kernels (knn.hip: wave / selection / gather / EdgeConv-feature kernels, the
 // dispatch and the C entry points; knn_d3.hip: knn_f16_d3_kernel; knn_mfma.hip: the feature-space pre-pass + knn_mfma_kernel):
-// constants, the wave-level sorting / selection helpers, knn_exact_bruteforce, knn_rank_ties4, knn_tau_8of16, and the
+// constants, the wave-level sorting / selection helpers, knn_exact_bruteforce, knn_rank_ties / knn_rank_ties4, knn_tau_8of16, and the
 // declarations of what the units call across.  (File-local helpers live in an anonymous namespace: every unit has its copy.)
 #pragma once
 #include <cmath>
@@ -393,6 +393,31 @@ __device__ __forceinline__ void knn_stage_chunk(const float *__restrict__ yb, in
         const bool anynan = __ballot(wnan) != 0;
         if (lane == 0) atomicMax(cmax, anynan ? 0x7fc00000u : __builtin_bit_cast(unsigned int, wmax));  // NaN > +inf
     }
+}
+
+// Wave-cooperative ranking of ONE query's n survivors on the full (distance bits, index) keys: lane e ranks key e against all n (LDS
+// broadcast reads; qd / qj are padded with sentinels up to a multiple of four); keys are unique, so the ranks below kk are a
+// permutation and slots[0, kk) is the sorted answer.  The form for the rare tied query of ordinary data: well under a microsecond for
+// its wave -- the launch is one round of blocks and waits for it (knn_rank_ties4 below takes ~2.4 us for a single query: measured as
+// + 3 us on C4's kernel when it served every case).
+__device__ __forceinline__ void knn_rank_ties(const unsigned int *qd, const int *qj, int n, int kk,
+                                              unsigned long long *slots, int lane) {
+    for (int e = lane; e < n; e += 64) {
+        const unsigned int md = qd[e];
+        const int mj = qj[e];
+        int rank = 0;
+        for (int i = 0; i < n; i += 4) {
+            const uint4 od = *reinterpret_cast<const uint4 *>(qd + i);
+            const int4 oj = *reinterpret_cast<const int4 *>(qj + i);
+            rank += (int)(od.x < md) | ((int)(od.x == md) & (int)(oj.x < mj));
+            rank += (int)(od.y < md) | ((int)(od.y == md) & (int)(oj.y < mj));
+            rank += (int)(od.z < md) | ((int)(od.z == md) & (int)(oj.z < mj));
+            rank += (int)(od.w < md) | ((int)(od.w == md) & (int)(oj.w < mj));
+        }
+        if (rank < kk) slots[rank] = ((unsigned long long)md << 32) | (unsigned int)mj;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Ranking of a wave's tied queries on the full (distance bits, index) keys -- the path of a query whose distance-only ranks collide

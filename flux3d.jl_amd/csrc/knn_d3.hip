@@ -644,9 +644,27 @@ __global__ __launch_bounds__(C::T) void knn_f16_d3_kernel(const float *__restric
     const bool slowq = qi < N && !fast && !medium;
     const unsigned long long badmask = __ballot(bad), slowmask = __ballot(slowq);
     if ((badmask | slowmask) == 0) return;
-    if (const unsigned int bad32 = (unsigned int)badmask | (unsigned int)(badmask >> 32)) {
-        // ties in the distance among the first kk: ranked again on (distance, index), the wave's tied queries AT ONCE (four lanes per
-        // query; the group's two waves take alternate queries -- lattices and duplicated points tie in every query)
+    const unsigned int bad32 = ((unsigned int)badmask | (unsigned int)(badmask >> 32)) & (half ? 0xaaaaaaaau : 0x55555555u);  // (the group's two waves take alternate queries)
+    if (__builtin_popcount(bad32) <= 3) {
+        // ties in the distance among the first kk of a FEW queries (ordinary data: a handful per launch): the whole wave ranks one
+        // query's keys again on (distance, index) -- the launch waits for this wave, and this form is the quick one for a single query
+        for (unsigned int bm = bad32; bm; bm &= bm - 1) {
+            const int j = __builtin_ctz(bm);
+            const int qs = grp * 32 + j;
+            const int *cj = ctr + qs * 8;
+            unsigned long long *sj = reinterpret_cast<unsigned long long *>(lists_all) + (size_t)qs * C::SS;
+            knn_rank_ties(reinterpret_cast<const unsigned int *>(k3sm) + (size_t)qs * C::KS,
+                          reinterpret_cast<const int *>(k3sm) + (size_t)C::G * 32 * C::KS + (size_t)qs * C::KS,
+                          cj[0] + cj[1] + cj[2] + cj[3], kk, sj, lane);
+            for (int r = drop + lane; r < kk; r += 64) {
+                const unsigned long long key = sj[r];
+                idx[((size_t)b * N + q0 + j) * k + r - drop] = (int)(unsigned int)key;
+                if (dist) dist[((size_t)b * N + q0 + j) * k + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
+                if (FEAT) knn_d3_feature_entry(feat, layout, b, N, k, q0 + j, r - drop, xb + (size_t)(q0 + j) * 3, yb + (size_t)(unsigned int)key * 3);
+            }
+        }
+    } else {
+        // many tied queries (lattices and duplicated points tie in EVERY query): the wave's tied queries AT ONCE, four lanes per query
         const int j = 2 * (lane >> 2) + half, pl = lane & 3;
         const bool mine = ((bad32 >> j) & 1u) != 0;
         const int qs = grp * 32 + j;

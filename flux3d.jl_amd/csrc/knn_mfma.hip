@@ -1822,8 +1822,24 @@ __global__ __launch_bounds__(kMThreads) void knn_mfma_kernel(const float *__rest
     // alternate queries
     const bool slowq = qi < N && !fast && !handled;
     const unsigned long long badmask = __ballot(bad);
-    if (const unsigned int bad32 = (unsigned int)badmask | (unsigned int)(badmask >> 32)) {
-        // the wave's tied queries at once, four lanes per query (knn_common.h: knn_rank_ties4)
+    const unsigned int bad32 = ((unsigned int)badmask | (unsigned int)(badmask >> 32)) & (consumer ? 0x55555555u : 0xaaaaaaaau);  // (the pair's two waves take alternate queries)
+    if (__builtin_popcount(bad32) <= 3) {
+        // a few tied queries (ordinary data): the whole wave per query -- the quick form for a single one (knn_common.h)
+        for (unsigned int bm = bad32; bm; bm &= bm - 1) {
+            const int j = __builtin_ctz(bm);
+            const int qs = cw * 32 + j;
+            unsigned long long *sj = reinterpret_cast<unsigned long long *>(lists) + (size_t)qs * 33;
+            knn_rank_ties(reinterpret_cast<const unsigned int *>(sm) + (size_t)qs * kMKeyStride,
+                          reinterpret_cast<const int *>(sm) + (size_t)kMWaves * 32 * kMKeyStride + (size_t)qs * kMKeyStride, qn_n[qs], kk,
+                          sj, lane);
+            for (int r = drop + lane; r < kk; r += 64) {
+                const unsigned long long key = sj[r];
+                idx[((size_t)b * N + q0 + j) * k + r - drop] = (int)(unsigned int)key;
+                if (dist) dist[((size_t)b * N + q0 + j) * k + r - drop] = __builtin_bit_cast(float, (unsigned int)(key >> 32));
+            }
+        }
+    } else {
+        // many tied queries: the wave's tied queries at once, four lanes per query (knn_common.h: knn_rank_ties4)
         const int j = 2 * (lane >> 2) + (consumer ? 0 : 1), pl = lane & 3;
         const bool mine = ((bad32 >> j) & 1u) != 0;
         const int qs = cw * 32 + j;
