@@ -26,6 +26,11 @@ int main(int argc, char **argv) {
             for (int i = 0; i < M; ++i) for (int d = 0; d < 3; ++d) hy[((size_t)b * M + i) * 3 + d] = (float)(i + 1) / (float)M;
         }
     }
+    if (getenv("PLATTICE")) {  // a 16^3 lattice (exact ties everywhere); PLATTICE=same: y = x
+        for (auto &v : hx) v = (float)((int)(rnd() * 16) % 16) * 0.0625f;
+        for (auto &v : hy) v = (float)((int)(rnd() * 16) % 16) * 0.0625f;
+        if (!strcmp(getenv("PLATTICE"), "same")) hy = hx;
+    }
     if (getenv("PCLUSTERS")) {  // 40 cluster centres ~ N(0, 3^2) per cloud, jitter PSIGMA (1e-3); PCLUSTERS=shared: y around x's centres; =same: y = x
         const float sigma = getenv("PSIGMA") ? (float)atof(getenv("PSIGMA")) : 1e-3f;
         auto gauss = [&]() { float a = 0; for (int i = 0; i < 12; ++i) a += rnd(); return a - 6.0f; };
