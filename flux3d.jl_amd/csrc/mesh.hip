@@ -14,7 +14,10 @@ using namespace fx3d;
 
 namespace {
 
-constexpr int kThreads = 256;
+#ifndef FX3D_MESH_THREADS
+#define FX3D_MESH_THREADS 256
+#endif
+constexpr int kThreads = FX3D_MESH_THREADS;
 constexpr int kMaxBlocks = 4096;  // partial-sum slots of the scratch; a launch takes at most grid_for()'s cap of them
 
 // (round 4) Both gather kernels below ran one element per thread and iteration: index load -> vertex gathers -> arithmetic, two
