@@ -593,7 +593,8 @@ __global__ __launch_bounds__(kThreads) void momentum_offset_kernel(long long n, 
 // (profiles/r04_*_hbm_grid_sweep.txt).  Option mesh_max_blocks != 0 forces one cap for both.
 // (round 5) `ew_cap`: the Laplacian adjoint's gather form wants NO cap -- one vertex per thread, 7 667 blocks at the 2 M-vertex sheet:
 // 27.3 -> 25.2 us = 4.68 TB/s (caps 4 096 / 8 192 / 16 384 / none: 27.3 / 25.7 / 25.2 / 25.4); faces_areas loses half its speed
-// beyond 4 096 (21.0 / 33.3 / 43.3 us), the edge forms do not care: same box, profiles/r05_v8_mesh_grid_caps.txt.
+// beyond 4 096 (21.0 / 33.3 / 43.3 us), the edge forms do not care: same box, profiles/r05_v8_mesh_grid_caps.txt.  Both adjoints in one
+// launch (<true, true>): 38.8 -> 36.9 us without the cap.
 int grid_for(long long n, bool reduction = false, int ew_cap = kMaxBlocks) {
     long long g = (n + kThreads - 1) / kThreads;
     if (g < 1) g = 1;
@@ -839,7 +840,7 @@ fx3d_status fx3d_mesh_losses_bwd(const float *verts, int64_t V, const int32_t *r
         hipLaunchKernelGGL((mesh_losses_bwd_gather_kernel<true, false>), dim3(grid_for(V, false, 1 << 22)), dim3(kThreads), 0, st, verts, (long long)V,
                            rowptr, colind, u, g_lap / (float)V, 0.0f, target, gverts, accumulate);
     else
-        hipLaunchKernelGGL((mesh_losses_bwd_gather_kernel<true, true>), dim3(grid_for(V)), dim3(kThreads), 0, st, verts, (long long)V,
+        hipLaunchKernelGGL((mesh_losses_bwd_gather_kernel<true, true>), dim3(grid_for(V, false, 1 << 22)), dim3(kThreads), 0, st, verts, (long long)V,
                            rowptr, colind, u, g_lap / (float)V, g_edge / (float)E, target, gverts, accumulate);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;

@@ -78,6 +78,9 @@ def measure(cells=1400, reps=20):
     avg, mn, _ = kernel_ms("mesh_losses_bwd", lambda: fx.laplacian_loss_grad(m), reps)
     row("laplacian_loss adjoint, gather over the stored unit rows (mesh_losses_bwd_gather_kernel<true,false>)",
         4 * (V + 1) + 4 * nnz + 16 * V + 12 * V, avg, mn, note)
+    fx.mesh_losses(m, sync=False)  # (the fused adjoint reuses the forward's unit rows)
+    avg, mn, _ = kernel_ms("mesh_losses_bwd", lambda: fx.mesh_losses_grad(m, reuse_forward=True), reps)
+    row("both adjoints in one launch (mesh_losses_bwd_gather_kernel<true,true>)", 4 * (V + 1) + 4 * nnz + 16 * V + 12 * V + 12 * V, avg, mn, note)
     del g, m
 
     # EdgeConv's HBM-bound siblings at C4' (F = 64, k = 20, B = 32 x 1024): the gather and the feature build
