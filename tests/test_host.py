@@ -235,6 +235,14 @@ def test_option_api_without_a_gpu(fx):
     with _lib.option("knn_no_mfma", 1):
         assert _lib.get_option("knn_no_mfma") == 1
     assert _lib.get_option("knn_no_mfma") == 0
+    # the header's list of the switches and README's are the library's table (a stale list survived one pruning)
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "flux3d_hip.h")).read()
+    block = hdr[hdr.index("variant switches"):hdr.index("fx3d_option_count / fx3d_option_name enumerate them")]
+    listed = set(re.findall(r"\b([a-z0-9]+(?:_[a-z0-9]+)+)\b", block)) - {"process_wide"}
+    assert set(_lib.options()) <= listed, sorted(set(_lib.options()) - listed)
+    assert not {n for n in listed if n.startswith(("knn_", "nn1_", "edge", "lap_", "cdf_", "mesh_", "bwd_"))} - set(_lib.options())
 
 
 def test_knn_scratch_plan_without_a_gpu(fx):
