@@ -1530,8 +1530,11 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
     // cost model in microseconds, measured at C2 (tools/nn1_probe.hip): bounding box 2.8 per 4096 candidates of
     // the cloud, image 5.0 per 4096 of the chunk, one pass (filter + exact) 9.7 per 4096, 256 resident blocks.
     // A block either walks all chunks serially (one pass per block: the per-query slot lives in LDS) or takes
-    // ONE chunk of a split run (any number of passes; subsets merge through 64-bit atomicMin slots, +8 us of
-    // extra launches).  Few large clouds want many small chunks, many small clouds want passes.
+    // ONE chunk of a split run (any number of passes; the subsets' rows merge in the same launch since round 5).  A split
+    // plan is charged 8 us: no longer a second launch, a FITTED constant -- swept 8 / 5 / 3 over tools/nn1_shapes_time.py's
+    // shapes on one box, only 8 x 8192 x 8192 changes plan, and the lower charges pick the slower one (62 us against 55.5:
+    // the model under-prices 2048-candidate images run four passes each).  Few large clouds want many small chunks, many
+    // small clouds want passes.
     const int cmax = kHChunkMax, gran = 32 * kHLT;
     const int ncu = device_cus();  // blocks resident at once: one per CU (256 on an MI355X in SPX mode)
     // a larger cloud of at most cmax + kHTail points is planned (and run) as ONE chunk of cmax with an exact tail
