@@ -539,6 +539,11 @@ fx3d_status fx3d_chamfer_sampled_bwd(const float *x, int32_t N, const float *y, 
     // sides beyond kBgChunk samples (the reference's default is 5000): the accumulators between the rounds live in LDS
     const int maxr = N > M ? N : M;
     const size_t dyn = maxr > kBgChunk ? sizeof(P3) * (size_t)((maxr + nsplit - 1) / nsplit) : 0;
+    if (dyn > 0) {  // static BgLds (~38 KB) + up to 48 KB of accumulators: beyond the 64 KB a kernel gets without an opt-in
+        const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&chamfer_sampled_bwd_kernel), (int)(sizeof(P3) * kBgRows),
+                                                   "chamfer_sampled_bwd_kernel");
+        if (arc != FX3D_OK) return arc;
+    }
     ProfileScope prof("chamfer_sampled_bwd", st);
     hipLaunchKernelGGL(chamfer_sampled_bwd_kernel, dim3(2 * B * nsplit), dim3(kBgThreads), dyn, st, x, N, y, M, idx_x, idx_y, ca,
                        cb, sx, sy, nsplit);

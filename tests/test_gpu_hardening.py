@@ -367,6 +367,28 @@ def test_c3_full_size_sample_chamfer_and_gradient_vs_oracle(gpu_fx, oracle):
     assert np.allclose(gv, np.transpose(exp, (2, 1, 0)), rtol=1e-4, atol=1e-9)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb,n", [(2, 5000), (2, 9000), (64, 5000), (3, 4097)])
+def test_chamfer_sampled_adjoint_multi_round_paths(gpu_fx, nb, n):
+    """fx3d_chamfer_sampled_bwd beyond 4096 samples per side (the reference's default num_samples = 5000,
+    src/metrics/mesh.jl:34): the other side is bucketed in rounds and the block's accumulators live in dynamic LDS between
+    them -- at B >= 64 (two blocks per side, 2500 rows each) static + dynamic LDS pass 64 KB and need the opt-in (ADVICE r5);
+    n > 8192: three rounds.  Against fx3d_chamfer_bwd followed by fx3d_sample_points_bwd on the same draws and indices."""
+    fx = gpu_fx
+    paths = [os.path.join(GOLDEN, "teapot.obj"), os.path.join(GOLDEN, "sphere.obj")]
+    ma = fx.gpu(fx.load_trimesh(*[paths[b % 2] for b in range(nb)]))
+    mb = fx.gpu(fx.load_trimesh(*[paths[(b + 1) % 2] for b in range(nb)]))
+    A, fa, ra1, ra2 = fx.sample_points(ma, n, seed=5, return_draws=True)
+    Bp, fb, rb1, rb2 = fx.sample_points(mb, n, seed=6, return_draws=True)
+    loss, ix, iy = fx.chamfer_distance(A, Bp, w1=0.9, w2=1.1, return_indices=True)
+    gA, gB = fx.chamfer_distance_grad(A, Bp, ix, iy, w1=0.9, w2=1.1, gout=1.5)
+    ref_a = fx.sample_points_grad(ma, fa, ra1, ra2, gA).to_host()
+    ref_b = fx.sample_points_grad(mb, fb, rb1, rb2, gB).to_host()
+    ga, gb = fx.chamfer_sampled_grad(A, Bp, ix, iy, ma, (fa, ra1, ra2), mb, (fb, rb1, rb2), w1=0.9, w2=1.1, gout=1.5)
+    assert np.isfinite(ref_a).all() and np.abs(ref_a).max() > 0
+    assert np.allclose(ga.to_host(), ref_a, rtol=2e-4, atol=1e-8) and np.allclose(gb.to_host(), ref_b, rtol=2e-4, atol=1e-8)
+
+
 # ------------------------------------------------------------------------------ multi-GPU entry points on one GPU
 def test_sharded_entry_points_argument_handling_and_overlap_at_world_size_1(gpu_fx, oracle):
     """SURVEY 8(e) on the one GPU a lease has: the library bootstraps its own communicator (no torch), reports nranks / rank
