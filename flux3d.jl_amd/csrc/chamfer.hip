@@ -45,8 +45,14 @@ __device__ unsigned long long g_probe[4096 * 16];
             if ((k) == 12) g_probe[blockIdx.x * 16 + 14] = wall_clock64();                   \
         }                                                                                    \
     } while (0)
+__device__ unsigned long long g_probe2[256 * 16];
+#define FX3D_PROBE_MARK2(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_probe2[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long g_probe3[16 * 16 * 8];   // per WAVE stamps of the first 16 blocks
+#define FX3D_PROBE_MARKW(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 16) g_probe3[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define FX3D_PROBE_MARK(k) do { } while (0)
+#define FX3D_PROBE_MARK2(k) do { } while (0)
+#define FX3D_PROBE_MARKW(k) do { } while (0)
 #endif
 
 namespace {
@@ -81,6 +87,10 @@ struct Nn1Params {
     int qstride;
     int fuse_split;              // 1: the last block of a query tile's chunk subsets merges their rows itself (arrival counters in the ticket slot's spare words)
     int tail;                    // > 0: a cloud of chunk + (1 .. tail) points is ONE chunk + a tail every query evaluates exactly
+    // spatial pruning (round 6, nn1_f16_kernel<.., PRUNE = true>): per-block scratch in the caller's workspace -- the block's candidate
+    // cloud in image order and its window of the query cloud in processing order, as (x, y, z, original index) rows
+    float4 *pscr;                // nullptr: the launch runs the PRUNE = false instantiation
+    int pscr_stride;             // rows per block: kHChunkMax candidates + the query window (passes x 512 + kHTail)
 };
 
 __device__ __forceinline__ float min3f(float a, float b, float c) {
@@ -424,10 +434,10 @@ __device__ __forceinline__ void make_pieces(float cx, float cy, float cz, h8 &p0
 // SPLITFUSE: the instantiation of candidate-split runs with the merge fused into the kernel's tail (a template parameter, not a
 // run-time flag: with the merge code inside, the one-chunk kernel -- the headline path -- spilled a register: 1 MB of scratch
 // writes per launch at C2, where that code never runs)
-template <bool WANT_IDX, bool SPLITFUSE = false>
+template <bool WANT_IDX, bool SPLITFUSE = false, bool PRUNE = false>
 __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ __attribute__((aligned(16))) float red[4 * 4 * (kHThreads / 64) + 8];  // per wave: min, max, sum, sum of squares (rows padded to 4 floats); + the block's result
+    __shared__ __attribute__((aligned(16))) float red[4 * 4 * (kHThreads / 64) + 16];  // per wave: min, max, sum, sum of squares (rows padded to 4 floats); + the block's result (+ the bounding box: PRUNE)
     __shared__ int nfar[2];                          // candidates of the chunk beyond the robust range (chunks alternate) ...
     __shared__ unsigned short farlist[kHFarCap];     // ... their indices within the chunk: compared exactly by every query
     constexpr int QB = (kHThreads / 64) * 32;  // queries per tile pass
@@ -493,6 +503,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
     const float *__restrict__ sb = cb + (size_t)s_lo * 3;
     const bool parked = one_shot || own_chunk_only;  // the raw points of the block's (only) chunk sit in their image slots
     float mu[3], cinf = 0.0f, varmax = 0.0f;
+    float bxlo[3] = {0.f, 0.f, 0.f}, bxhi[3] = {0.f, 0.f, 0.f};  // (PRUNE) the cloud's bounding box: the frame of the sorting grid
     bool allfin = true;
     {
         // thread t takes points t, t + 1024, ...: 12-byte loads, consecutive lanes on consecutive points (coalesced, and the
@@ -575,6 +586,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 float4 *o4 = reinterpret_cast<float4 *>(red) + 4 * (kHThreads / 64);
                 o4[0] = float4{m3[0], m3[1], m3[2], ci * 1.000001f};
                 o4[1] = float4{vm, fin ? 1.0f : 0.0f, 0.0f, 0.0f};
+                if (PRUNE) { o4[2] = float4{lo3[0], lo3[1], lo3[2], 0.0f}; o4[3] = float4{hi3[0], hi3[1], hi3[2], 0.0f}; }
             }
         }
         __syncthreads();
@@ -583,6 +595,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             const float4 a = o4[0], b2 = o4[1];
             mu[0] = a.x; mu[1] = a.y; mu[2] = a.z; cinf = a.w;
             varmax = b2.x; allfin = b2.y != 0.0f;
+            if (PRUNE) {
+                const float4 l4 = o4[2], h4 = o4[3];
+                bxlo[0] = l4.x; bxlo[1] = l4.y; bxlo[2] = l4.z; bxhi[0] = h4.x; bxhi[1] = h4.y; bxhi[2] = h4.z;
+            }
         }
     }
     // ---- robust range: a few points far from the bulk must not set the scale (the bulk would sink below fp16's resolution and
@@ -625,12 +641,171 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             if (f < kHFarCap) farlist[f] = (unsigned short)pt;
         }
     };
+
+    // ---- (PRUNE, round 6) SPATIAL ORDER.  tools/ubench_overlap.hip (profiles/r06_ubench_overlap.txt) shows the main loop at the
+    //      SIMD's VALU-issue bound for its instruction mix -- no schedule of the same pairs is faster -- so the pairs have to go:
+    //      the candidates are laid into the image in Morton order of an 8 x 8 x 8 grid over the cloud's bounding box (counting sort:
+    //      LDS integer atomics, one scan), every lane tile (64 consecutive image rows) gets a bounding box, the block takes its
+    //      queries as a WINDOW of the query cloud in the same order (32 consecutive ones per wave: a compact box), and a wave runs
+    //      the filter only over the lane tiles whose box can hold a nearest neighbour of one of its queries (main loop below).
+    //      Results do not change: a skipped lane tile holds no candidate as near as the one already found (bounds below), ties
+    //      included, and everything that decides a result -- the exact distances, the 64-bit (distance, ORIGINAL index) minima --
+    //      is as before.  The image order of candidates inside a cell is the arrival order of LDS atomics (it only moves a
+    //      candidate between lane tiles); the order of the QUERIES is made unique (cell, then index), because it decides which
+    //      block and lane a query's term of the loss is summed in.  The rows (x, y, z, original index) of both orders go to the
+    //      block's scratch: the exact phase reads candidates by image position from there, the passes read their queries. ----
+    [[maybe_unused]] float4 *cs = nullptr, *qsw = nullptr;
+    [[maybe_unused]] bool sorted_c = false;
+    [[maybe_unused]] int qwlen = 0;
+    [[maybe_unused]] float4 *boxes = nullptr;
+    if constexpr (PRUNE) {
+        cs = p.pscr + (size_t)blockIdx.x * p.pscr_stride;
+        qsw = cs + kHChunkMax;
+        boxes = reinterpret_cast<float4 *>(wq + (kHThreads / 64) * 96);  // [64 lane tiles] x (lo, hi): 2 KiB behind the waves' scratch
+        // (the waves' scratch is idle here: 20.5 of its 22 KiB hold the counters)  Cells are numbered t = ux | uy << 3 | uz << 6; the
+        // SCANS walk them in Morton order, so the image order is the Morton order of the cells at two shifts per point.
+        unsigned int *ccnt = reinterpret_cast<unsigned int *>(wres);  // [512] candidates per cell -> first image row of the cell
+        unsigned int *qtot = ccnt + 520;                               // [512] queries per cell -> first rank of the cell
+        unsigned int *qwh = qtot + 520;                                // [16 waves][256] per-wave counts, two 16-bit cells per word -> counts of the waves before
+        const bool last_t = tile == (dir ? p.tiles_y : p.tiles_x) - 1;
+        const int qw0 = tile * tpb * QB;
+        const int qw1 = last_t || qw0 + tpb * QB > NQ ? NQ : qw0 + tpb * QB;
+        qwlen = qw1 - qw0;
+        const int cnt = NCm;  // (PRUNE launches are one-chunk plans without a tail)
+        const bool do_sort = sane && !has_far && cnt >= 512;
+        // The queries' order must not depend on timing (it decides in which block and lane a query's term of the loss is summed):
+        // wave w counts the queries 256 w .. 256 w + 255 in counters of its own -- returning LDS atomics of ONE wave are served in
+        // program order, lanes of one instruction in the hardware's fixed order --, a query's rank is (queries in cells before its
+        // cell) + (queries of its cell in the waves before) + (the value its own atomic returned).
+        const bool sorted_q = do_sort && NQ <= 4 * kHThreads;
+        P3 qv[4];
+        if (sorted_q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int qp = 256 * wv + 64 * e + lane;
+                qv[e] = *reinterpret_cast<const P3 *>(qb + (size_t)(qp < NQ ? qp : NQ - 1) * 3);
+            }
+        }
+        FX3D_PROBE_MARK2(0);
+        if (do_sort) {
+            for (int i = tid; i < 1040 + 16 * 256; i += kHThreads) ccnt[i] = 0u;
+            float4 cv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int pt = e * kHThreads + tid;
+                cv[e] = float4{0.f, 0.f, 0.f, 0.f};
+                if (pt < cnt) cv[e] = imgf[((pt >> 5) * 2) * 32 + (pt & 31)];  // parked by this thread
+            }
+            __syncthreads();
+            FX3D_PROBE_MARK2(1);
+            float inv[3], off[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                inv[d] = bxhi[d] > bxlo[d] ? 8.0f / (bxhi[d] - bxlo[d]) : 0.0f;
+                off[d] = -bxlo[d] * inv[d];
+            }
+            auto cell = [&](float x, float y, float z) -> unsigned int {  // the 8 x 8 x 8 cell of a point (outside the box: a border cell)
+                const unsigned int ux = (unsigned int)(int)fminf(fmaxf(__builtin_fmaf(x, inv[0], off[0]), 0.0f), 7.0f);
+                const unsigned int uy = (unsigned int)(int)fminf(fmaxf(__builtin_fmaf(y, inv[1], off[1]), 0.0f), 7.0f);
+                const unsigned int uz = (unsigned int)(int)fminf(fmaxf(__builtin_fmaf(z, inv[2], off[2]), 0.0f), 7.0f);
+                return ux | (uy << 3) | (uz << 6);
+            };
+            unsigned int ccr[4], qcr[4];  // (cell << 16) | rank among the cell's points (candidates: arrival; queries: within the wave)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int pt = e * kHThreads + tid;
+                ccr[e] = 0u;
+                if (pt < cnt) {
+                    const unsigned int t = cell(cv[e].x, cv[e].y, cv[e].z);
+                    ccr[e] = (t << 16) | atomicAdd(&ccnt[t], 1u);
+                }
+            }
+            if (sorted_q) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qp = 256 * wv + 64 * e + lane;
+                    qcr[e] = 0u;
+                    if (qp < NQ) {
+                        const unsigned int t = cell(qv[e].x, qv[e].y, qv[e].z), sh = 16u * (t & 1u);
+                        const unsigned int old = atomicAdd(&qwh[wv * 256 + (t >> 1)], 1u << sh);
+                        atomicAdd(&qtot[t], 1u);
+                        qcr[e] = (t << 16) | ((old >> sh) & 0xffffu);
+                    }
+                }
+            }
+            FX3D_PROBE_MARK2(2);
+            __syncthreads();
+            FX3D_PROBE_MARK2(3);
+            if (wv < 2) {  // exclusive scans in Morton order: wave 0 the candidates' cells, wave 1 the queries' (eight cells per lane)
+                unsigned int *a = wv ? qtot : ccnt;
+                const unsigned int l = (unsigned int)lane;
+                const unsigned int tb = ((l & 1u) << 1) | ((l & 8u) >> 1) | ((l & 2u) << 3) | ((l & 16u) << 1) | ((l & 4u) << 5) | ((l & 32u) << 3);
+                const unsigned int tk[8] = {0u, 1u, 8u, 9u, 64u, 65u, 72u, 73u};
+                unsigned int c8[8], tot = 0u;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { c8[k] = a[tb + tk[k]]; tot += c8[k]; }
+                unsigned int inc = tot;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned int v = __shfl_up(inc, o, 64);
+                    if (lane >= o) inc += v;
+                }
+                unsigned int run = inc - tot;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { a[tb + tk[k]] = run; run += c8[k]; }
+            } else if (wv >= 2 && wv < 6 && sorted_q) {  // a pair of cells per thread: counts of the waves before, wave by wave
+                const int w2 = tid - 128;
+                unsigned int run = 0u;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) {
+                    const unsigned int v = qwh[w * 256 + w2];
+                    qwh[w * 256 + w2] = run;
+                    run += v;  // (two 16-bit sums of at most 4096: no carry between them)
+                }
+            }
+            FX3D_PROBE_MARK2(4);
+            __syncthreads();
+            FX3D_PROBE_MARK2(5);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int pt = e * kHThreads + tid;
+                if (pt < cnt) {
+                    const int pos = (int)(ccnt[ccr[e] >> 16] + (ccr[e] & 0xffffu));
+                    imgf[((pos >> 5) * 2) * 32 + (pos & 31)] = float4{cv[e].x, cv[e].y, cv[e].z, __builtin_bit_cast(float, pt)};
+                }
+            }
+            sorted_c = true;
+            if (sorted_q) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qp = 256 * wv + 64 * e + lane;
+                    if (qp < NQ) {
+                        const unsigned int t = qcr[e] >> 16;
+                        const int rank = (int)(qtot[t] + ((qwh[wv * 256 + (t >> 1)] >> (16u * (t & 1u))) & 0xffffu) + (qcr[e] & 0xffffu));
+                        if (rank >= qw0 && rank < qw1) qsw[rank - qw0] = float4{qv[e].x, qv[e].y, qv[e].z, __builtin_bit_cast(float, qp)};
+                    }
+                }
+            }
+            FX3D_PROBE_MARK2(6);
+            __syncthreads();  // (the image rows are in place: the staging below converts them where they lie)
+            FX3D_PROBE_MARK2(7);
+        }
+        if (!sorted_q) {  // index order: the block's window of the query cloud as it lies in memory
+            for (int qp = qw0 + tid; qp < qw1; qp += kHThreads) {
+                const P3 r = *reinterpret_cast<const P3 *>(qb + (size_t)qp * 3);
+                qsw[qp - qw0] = float4{r.x, r.y, r.z, __builtin_bit_cast(float, qp)};
+            }
+        }
+        // (the barrier behind the image staging below orders these stores -- and the image's -- before their readers)
+        FX3D_PROBE_MARK2(8);
+    }
     FX3D_PROBE_MARK(1);
 
     // Largest scaled norm^2 of a candidate inside the filter (|c~|_inf <= min(cinf sc, 128)): the far-query form of the band below
     const float cm2 = 3.0f * (fminf(cinf * sc, 128.0f) * fminf(cinf * sc, 128.0f));
     float qr[3], da = 0.0f;  // band: a tile qualifies while its minimum <= best * kBandB1 + da
     float da_far = 0.0f;     // ... or <= best (1 + 2^-20) + da_far, whichever is lower (round 4)
+    [[maybe_unused]] float dpr = INFINITY;  // (PRUNE) scaled squared distance to the best candidate found <= its filter value + dpr
     bool qfin = true;        // this lane's query has finite coordinates
     int qi = 0;
     bool qok = true;
@@ -643,6 +818,45 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         const int cnt_pad = (cnt + 32 * kHLT - 1) / (32 * kHLT) * (32 * kHLT);
         if (j0 > jfirst) __syncthreads();
         // ---- stage the fp16 split image ------------------------------------------------------------------
+        if constexpr (PRUNE) {
+            // (PRUNE) thread t converts the image rows 4 t .. 4 t + 3 where the sort laid them (or where the cloud pass parked them) and
+            // writes them to the block's scratch; the 16 threads of a DPP row hold one lane tile: its box (image frame) by four row steps
+            for (int base = 4 * tid; base < cnt_pad + 64; base += 4 * kHThreads) {
+                float4 r4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int pt = base + k;
+                    r4[k] = float4{0.f, 0.f, 0.f, 0.f};
+                    if (pt < cnt) r4[k] = imgf[((pt >> 5) * 2) * 32 + (pt & 31)];
+                }
+                float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int pt = base + k, i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
+                    h8 p0, p1;
+                    if (pt < cnt) {
+                        pieces(r4[k].x, r4[k].y, r4[k].z, pt, p0, p1);
+                        const int id = sorted_c ? __builtin_bit_cast(int, r4[k].w) : j0 + pt;
+                        cs[pt] = float4{r4[k].x, r4[k].y, r4[k].z, __builtin_bit_cast(float, id)};
+                        const float b3[3] = {(r4[k].x - mu[0]) * sc, (r4[k].y - mu[1]) * sc, (r4[k].z - mu[2]) * sc};
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) { lo3[d] = fminf(lo3[d], b3[d]); hi3[d] = fmaxf(hi3[d], b3[d]); }
+                    } else {
+                        make_pieces(0.f, 0.f, 0.f, p0, p1);
+                        p1[7] = (_Float16)kPadF16;
+                    }
+                    imgp[i0] = p0;
+                    imgp[i0 + 32] = p1;
+                }
+                float bl[3], bh[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { bl[d] = fkey_inv(row_mm_key<false>(fkey(lo3[d]))); bh[d] = fkey_inv(row_mm_key<true>(fkey(hi3[d]))); }
+                if ((tid & 15) == 0 && (base >> 6) < 64) {
+                    boxes[(base >> 6) * 2] = float4{bl[0], bl[1], bl[2], 0.0f};
+                    boxes[(base >> 6) * 2 + 1] = float4{bh[0], bh[1], bh[2], 0.0f};
+                }
+            }
+        } else
         for (int pt = tid; pt < cnt_pad + 64; pt += kHThreads) {
             const int i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
             h8 p0, p1;
@@ -663,6 +877,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         }
         __syncthreads();
         FX3D_PROBE_MARK(j0 == jfirst ? 2 : 6);
+        FX3D_PROBE_MARKW(0);
 
         const int nf = nfar[fslot];          // far candidates of this chunk (valid after the barrier above)
         if (tid == 0) nfar[fslot ^ 1] = 0;   // the next chunk's counter (its staging starts behind the barrier at the loop top)
@@ -675,7 +890,12 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             if ((tile * tpb + tp) * QB >= NQ) break;  // uniform
             if (j0 == jfirst) {
                 qi = (tile * tpb + tp) * QB + wv * 32 + jq;
-                if (tp == 0) {  // requested before the bounding-box pass
+                if constexpr (PRUNE) {  // row (tp QB + wave's 32 + jq) of the block's window of the query cloud, in processing order
+                    const int wpos = tp * QB + wv * 32 + jq;
+                    const float4 q4 = qsw[wpos < qwlen ? wpos : qwlen - 1];  // (lanes past the window: a valid query, no output)
+                    qr[0] = q4.x; qr[1] = q4.y; qr[2] = q4.z;
+                    qi = wpos < qwlen ? __builtin_bit_cast(int, q4.w) : NQ;
+                } else if (tp == 0) {  // requested before the bounding-box pass
 #pragma unroll
                     for (int d = 0; d < 3; ++d) qr[d] = qpre[d];
                 } else {        // (not prefetched behind the previous pass: three registers live across the main loop would spill)
@@ -716,6 +936,12 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     const float c2 = sq * cm2;                     // in the query's unit, like qn = sq |q~|^2
                     da_far = 2.1f * kBetaC * c2 + 2.0f * kBetaC * sqrtf(qn * c2) + 0x1p-19f * qn + 0x1p-24f * (S + 4.0f) + fl_s;
                 }
+                if constexpr (PRUNE) {
+                    // |q~ - c~|^2 = |q~|^2 + t(c) and t(c) <= (its filter value) + beta (|c~|^2 + |q~|^2) + floor (the filter's error
+                    // model above), |c~|^2 <= cm2: twice that error is added.  Queries with a scale of their own (far outside the
+                    // cloud) or outside the fp16 range do not bound anything: +Inf keeps every lane tile of their wave.
+                    dpr = qok && sq == 1.0f ? qn + 2.0f * kBetaC * (cm2 + qn) + 0x1p-23f * (S + 4.0f) : INFINITY;
+                }
                 _Float16 hx, lx, hy, ly, hz, lz;
                 split2h(qok ? m0 : 0.f, hx, lx); split2h(qok ? m1 : 0.f, hy, ly); split2h(qok ? m2 : 0.f, hz, lz);
                 const _Float16 one = (_Float16)sq, pad = (_Float16)kPadF16;
@@ -746,13 +972,6 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             f32x16 zero;
 #pragma unroll
             for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
-            const h8 *pa = imgp + hh * 32 + jq;
-            f32x16 acc0, acc1, acc2;
-            h8 an = pa[0];                     // operand of the next block to issue (one ds_read_b128 in flight per step)
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, bq, zero, 0, 0, 0); an = pa[1 * 64];
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, bq, zero, 0, 0, 0); an = pa[2 * 64];
-            pa += 3 * 64;                      // -> the operand one block past the next issue
-            int lt = 0;                        // lane tile of the next fold
 #define NN1_FOLD(ACC, FIRST)                                                                                         \
             {                                                                                                        \
                 const float t0 = min3f(ACC[0], ACC[1], ACC[2]), t1 = min3f(ACC[3], ACC[4], ACC[5]);                  \
@@ -761,14 +980,14 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 const float t5 = min3f(t0, t1, t2), t6 = min3f(t3, t4, ACC[15]);                                     \
                 tm = (FIRST) ? vmin(t5, t6) : min3f(tm, t5, t6); /* first block of the lane tile restarts tm */      \
             }
-#define NN1_TRACK()                                                                                                  \
+#define NN1_TRACK_ID(LT)                                                                                             \
             {                                                                                                        \
                 float key;                                                                                           \
-                asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(tm), "v"(keymask), "s"(lt));                     \
+                asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(tm), "v"(keymask), "s"(LT));                     \
                 _Pragma("unroll") for (int s_ = kHFifo - 1; s_ > 0; --s_) fk[s_] = __builtin_amdgcn_fmed3f(fk[s_ - 1], fk[s_], key);    \
                 fk[0] = vmin(fk[0], key);                                                                            \
-                ++lt;                                                                                                \
             }
+#define NN1_TRACK() { NN1_TRACK_ID(lt) ++lt; }
             // one step: issue the next block into ISSUE, fold FOLD (issued two steps ago); an odd fold closes its lane tile.
             // (round 4) The fold and the tracking run at raised wave priority, the MFMA issue at the base one: among the four
             // waves of a SIMD the ones with VALU work go first and the matrix pipe drains the others' MFMAs underneath
@@ -781,6 +1000,14 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             __builtin_amdgcn_s_setprio(1);                                                                           \
             NN1_FOLD(FOLD, !(ODD))                                                                                   \
             if (ODD) NN1_TRACK()
+            if constexpr (!PRUNE) {
+            const h8 *pa = imgp + hh * 32 + jq;
+            f32x16 acc0, acc1, acc2;
+            h8 an = pa[0];                     // operand of the next block to issue (one ds_read_b128 in flight per step)
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, bq, zero, 0, 0, 0); an = pa[1 * 64];
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, bq, zero, 0, 0, 0); an = pa[2 * 64];
+            pa += 3 * 64;                      // -> the operand one block past the next issue
+            int lt = 0;                        // lane tile of the next fold
             int nb = 2;                        // next block to issue (even); blocks nb - 2, nb - 1 are in acc0, acc1
             for (; nb + 6 <= nblk; nb += 6) {
                 NN1_STEP(acc2, acc0, 0, 0) NN1_STEP(acc0, acc1, 1, 1) NN1_STEP(acc1, acc2, 0, 2)
@@ -797,8 +1024,102 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             } else {
                 NN1_FOLD(acc0, true) NN1_FOLD(acc1, false) NN1_TRACK()
             }
+            } else {
+            // ---- (PRUNE) the same pipeline over a LIST of lane tiles, in two phases ----------------------------------------------
+            // Lane l tests lane tile l: squared distance bd between the tile's box and the box of the wave's 32 queries (image frame).
+            // Phase 0 runs the tiles whose box meets the queries' box (or, if none does, the nearest one); that gives every query an
+            // upper bound of its nearest distance, and phase 1 runs the tiles within the largest of them:
+            //   a candidate c' as near as the best one found (or tied with it) has  |q~ - c'~|^2 <= (fk[0] + dpr) (1 + 2^-20)  in real
+            //   arithmetic (the oracle's Float32 distance of either differs from the real one by < 2^-21 relative), the image-frame
+            //   coordinates (x - mu) sc are off by <= 2^-24 of their magnitude -- covered by (1 + 2^-9) and + 2^-8 on the bound (a wide
+            //   margin: 0.2 % of a radius that prunes ~3/4 of the tiles) --, and bd <= |q~ - c'~|^2 for every c' of the tile.
+            // A skipped tile therefore holds neither the nearest candidate nor a tie of it, for any query of the wave; the tracked keys,
+            // the band and the exact phase work on the tiles that ran.  The list is consumed three lane tiles (six blocks) per
+            // iteration -- the rotation of three accumulator sets keeps static register names --, padded with the image's two padding
+            // blocks (lane tile `nlt`: keys of 4.3e9 that no band reaches).
+            const int nltp = nblk / kHLT;      // lane tiles of the chunk; index nltp = the padding blocks
+            const float qsx = (qr[0] - mu[0]) * sc, qsy = (qr[1] - mu[1]) * sc, qsz = (qr[2] - mu[2]) * sc;
+            float bd = INFINITY;
+            {
+                const float qlx = wave_min_f(qsx), qly = wave_min_f(qsy), qlz = wave_min_f(qsz);
+                const float qhx = wave_max_f(qsx), qhy = wave_max_f(qsy), qhz = wave_max_f(qsz);
+                if (lane < nltp) {
+                    const float4 lo = boxes[lane * 2], hi = boxes[lane * 2 + 1];
+                    const float gx = fmaxf(fmaxf(lo.x - qhx, qlx - hi.x), 0.0f), gy = fmaxf(fmaxf(lo.y - qhy, qly - hi.y), 0.0f);
+                    const float gz = fmaxf(fmaxf(lo.z - qhz, qlz - hi.z), 0.0f);
+                    bd = (gx * gx + gy * gy) + gz * gz;  // (NaN for a non-finite query: its wave keeps every tile, below)
+                }
+            }
+            const unsigned long long all_lt = nltp >= 64 ? ~0ull : (1ull << nltp) - 1ull;
+            unsigned long long todo = all_lt, done = 0ull;
+            if (sorted_c) {
+                todo = __ballot(bd == 0.0f);
+                if (!todo) {
+                    const float bmin = wave_min_f(bd);
+                    todo = bmin < INFINITY ? __ballot(bd == bmin) : all_lt;
+                }
+            }
+            const h8 *pbase = imgp + hh * 32 + jq;
+            for (int phase = 0; phase < 2; ++phase) {
+                if (phase == 1) {
+                    if (done == all_lt) break;
+                    // largest upper bound of a nearest squared distance among the wave's queries (+Inf / NaN: every tile)
+                    const float kb = fk[0];
+                    const float bb = __builtin_fmaf(fabsf(kb), kKeyUp, kb);
+                    const float dj = fminf(bb, __shfl_xor(bb, 32, 64)) + dpr;
+                    const float ucut = wave_max_f(__builtin_fmaf(dj, 1.0f + 0x1p-9f, 0x1p-8f));
+                    const bool keep = !(bd > ucut) || !(dj == dj);
+                    todo = (__ballot(!(dj == dj)) ? all_lt : __ballot(keep)) & all_lt & ~done;
+                    if (!todo) break;
+                }
+                done |= todo;
+                unsigned long long mk = todo;
+#define NN1_NEXT(T) { T = nltp; if (mk) { T = __builtin_ctzll(mk); mk &= mk - 1ull; } }
+                int ta, tb, tc;
+                NN1_NEXT(ta) NN1_NEXT(tb) NN1_NEXT(tc)
+                f32x16 acc0, acc1, acc2;
+                const h8 *pn = pbase + ta * (kHLT * 64);
+                h8 an = pn[0];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, bq, zero, 0, 0, 0); an = pn[64];
+                pn = pbase + tb * (kHLT * 64);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, bq, zero, 0, 0, 0); an = pn[0];
+                // one step: issue the block whose operand is in `an`, fetch the operand NEXT, fold FOLD (issued two steps ago)
+#define NN1_PSTEP(ISSUE, FOLD, ODD, LT, NEXT)                                                                         \
+                __builtin_amdgcn_s_setprio(0);                                                                       \
+                ISSUE = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, bq, zero, 0, 0, 0);                               \
+                an = NEXT;                                                                                           \
+                __builtin_amdgcn_s_setprio(1);                                                                       \
+                NN1_FOLD(FOLD, !(ODD))                                                                               \
+                if (ODD) NN1_TRACK_ID(LT)
+                while (true) {
+                    // entry: ta's two blocks are in acc0, acc1 (issued), `an` holds tb's first operand, pn -> tb
+                    const h8 *pc = pbase + tc * (kHLT * 64);
+                    NN1_PSTEP(acc2, acc0, 0, ta, pn[64])
+                    NN1_PSTEP(acc0, acc1, 1, ta, pc[0])
+                    if (tb == nltp) break;     // (uniform) the list ended with ta: what is in flight is padding
+                    int na, nb_, nc;
+                    NN1_NEXT(na) NN1_NEXT(nb_) NN1_NEXT(nc)
+                    const h8 *pna = pbase + na * (kHLT * 64);
+                    NN1_PSTEP(acc1, acc2, 0, tb, pc[64])
+                    NN1_PSTEP(acc2, acc0, 1, tb, pna[0])
+                    if (tc == nltp) break;
+                    pn = pbase + nb_ * (kHLT * 64);
+                    NN1_PSTEP(acc0, acc1, 0, tc, pna[64])
+                    NN1_PSTEP(acc1, acc2, 1, tc, pn[0])
+                    if (na == nltp) break;
+                    ta = na; tb = nb_; tc = nc;
+                }
+#undef NN1_PSTEP
+#undef NN1_NEXT
+                __builtin_amdgcn_s_setprio(0);
+#ifdef FX3D_PROBE_COUNT
+                if ((threadIdx.x & 63) == 0) atomicAdd(&g_probe[4095 * 16 + 6 + phase], (unsigned long long)__builtin_popcountll(todo));
+#endif
+            }
+            }
 #undef NN1_STEP
 #undef NN1_TRACK
+#undef NN1_TRACK_ID
 #undef NN1_FOLD
             __builtin_amdgcn_s_setprio(0);
             float ft[kHFifo];
@@ -808,6 +1129,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             // this lane's smallest tile minimum is <= best (an upper bound of it: the key of the smallest VALUE is >= ka)
             const float best = __builtin_fmaf(fabsf(ka), kKeyUp, ka);
             FX3D_PROBE_MARK(tp == 0 ? 3 : 7);
+            FX3D_PROBE_MARKW(tp == 0 ? 1 : 3);
 
             // ---- exact phase, wave-cooperative ----------------------------------------------------------------
             {
@@ -863,10 +1185,17 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                             if (!((sb >> (32 * h + qsl)) & 1ull)) continue;  // (wave-uniform)
                             for (int r0 = 4 * (2 * lane + h); r0 < cnt; r0 += kScanU * 512) {
                                 float cx[kScanU][4], cy[kScanU][4], cz[kScanU][4];
+                                [[maybe_unused]] int cid[kScanU][4];  // (PRUNE) original indices of the rows
 #pragma unroll
                                 for (int u = 0; u < kScanU; ++u) {
                                     const int jl0 = r0 + 512 * u;
-                                    if (vec && jl0 + 4 <= cnt) {
+                                    if constexpr (PRUNE) {
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r) {
+                                            const float4 v = cs[jl0 + r < cnt ? jl0 + r : cnt - 1];
+                                            cx[u][r] = v.x; cy[u][r] = v.y; cz[u][r] = v.z; cid[u][r] = __builtin_bit_cast(int, v.w);
+                                        }
+                                    } else if (vec && jl0 + 4 <= cnt) {
                                         load4pts(cb, j0 + jl0, cx[u], cy[u], cz[u]);
                                     } else {
 #pragma unroll
@@ -883,7 +1212,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                                     for (int r = 0; r < 4; ++r) {
                                         const int jc = r0 + 512 * u + r;
                                         const float cc3[3] = {cx[u][r], cy[u][r], cz[u][r]};
-                                        const unsigned long long key = ((unsigned long long)dist_key(sqd<3>(qq, cc3)) << 32) | (unsigned int)(j0 + jc);
+                                        const unsigned int cidx = PRUNE ? (unsigned int)cid[u][r] : (unsigned int)(j0 + jc);
+                                        const unsigned long long key = ((unsigned long long)dist_key(sqd<3>(qq, cc3)) << 32) | cidx;
                                         if (jc < cnt && key < kbest) kbest = key;
                                     }
                             }
@@ -960,7 +1290,14 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                             const int qs = it >> 7, ih = (it >> 6) & 1, tl = it & 63;
                             const int jl0 = (tl * kHLT + (run >> 2)) * 32 + 8 * (run & 3) + 4 * ih;
                             float cx[4], cy[4], cz[4];
-                            if (vec && jl0 + 4 <= cnt) {
+                            [[maybe_unused]] int cid[4];
+                            if constexpr (PRUNE) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float4 v = cs[jl0 + r < cnt ? jl0 + r : cnt - 1];
+                                    cx[r] = v.x; cy[r] = v.y; cz[r] = v.z; cid[r] = __builtin_bit_cast(int, v.w);
+                                }
+                            } else if (vec && jl0 + 4 <= cnt) {
                                 load4pts(cb, j0 + jl0, cx, cy, cz);
                             } else {
 #pragma unroll
@@ -973,6 +1310,18 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                             const float qq[3] = {qtab[qs * 3], qtab[qs * 3 + 1], qtab[qs * 3 + 2]};
                             unsigned int kb;
                             int ib = j0 + jl0;  // an all-+Inf run still names a real candidate (its first)
+                            if constexpr (PRUNE) {  // the rows' original indices do not ascend: the run's minimum on full (distance, index) keys
+                                unsigned long long k64 = ~0ull;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float cc3[3] = {cx[r], cy[r], cz[r]};
+                                    const float dd = sqd<3>(qq, cc3);
+                                    const unsigned int kd = nonfinite ? dist_key(dd) : __builtin_bit_cast(unsigned int, dd);
+                                    const unsigned long long key = ((unsigned long long)kd << 32) | (unsigned int)cid[r];
+                                    if (jl0 + r < cnt && key < k64) k64 = key;
+                                }
+                                kb = (unsigned int)(k64 >> 32); ib = (int)(unsigned int)k64;
+                            } else
                             if (!nonfinite) {   // distances are >= 0 or +Inf: float order == key order
                                 float db = INFINITY;
 #pragma unroll
@@ -1011,9 +1360,16 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const int jc = jl0 + r < cnt ? jl0 + r : cnt - 1;
-                                    const float *src = cb + (size_t)(j0 + jc) * 3;
-                                    const float cc3[3] = {src[0], src[1], src[2]};
-                                    const unsigned long long key = ((unsigned long long)dist_key(sqd<3>(qq, cc3)) << 32) | (unsigned int)(j0 + jc);
+                                    float cc3[3];
+                                    unsigned int cidx = (unsigned int)(j0 + jc);
+                                    if constexpr (PRUNE) {
+                                        const float4 v = cs[jc];
+                                        cc3[0] = v.x; cc3[1] = v.y; cc3[2] = v.z; cidx = __builtin_bit_cast(unsigned int, v.w);
+                                    } else {
+                                        const float *src = cb + (size_t)(j0 + jc) * 3;
+                                        cc3[0] = src[0]; cc3[1] = src[1]; cc3[2] = src[2];
+                                    }
+                                    const unsigned long long key = ((unsigned long long)dist_key(sqd<3>(qq, cc3)) << 32) | cidx;
                                     if (jl0 + r < cnt && key < kbest) kbest = key;
                                 }
                                 if (jl0 < cnt) atomicMin(&qres[qs], kbest);
@@ -1026,11 +1382,18 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     for (int t = lane; t < 32 * nf; t += 64) {
                         const int qs = t & 31, jc = farlist[t >> 5];
                         const float qq[3] = {qtab[qs * 3], qtab[qs * 3 + 1], qtab[qs * 3 + 2]};
-                        const float *src = cb + (size_t)(j0 + jc) * 3;
-                        const float cc3[3] = {src[0], src[1], src[2]};
+                        float cc3[3];
+                        unsigned int cidx = (unsigned int)(j0 + jc);
+                        if constexpr (PRUNE) {
+                            const float4 v = cs[jc];
+                            cc3[0] = v.x; cc3[1] = v.y; cc3[2] = v.z; cidx = __builtin_bit_cast(unsigned int, v.w);
+                        } else {
+                            const float *src = cb + (size_t)(j0 + jc) * 3;
+                            cc3[0] = src[0]; cc3[1] = src[1]; cc3[2] = src[2];
+                        }
                         const float dd = sqd<3>(qq, cc3);
                         const unsigned int kd = nonfinite ? dist_key(dd) : __builtin_bit_cast(unsigned int, dd);
-                        atomicMin(&qres[qs], ((unsigned long long)kd << 32) | (unsigned int)(j0 + jc));
+                        atomicMin(&qres[qs], ((unsigned long long)kd << 32) | cidx);
                     }
                 }
                 // the cloud's tail beyond the LDS image (<= kHTail candidates): every query of the wave against each, exactly
@@ -1045,6 +1408,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 }
             }
             FX3D_PROBE_MARK(tp == 0 ? 4 : 8);
+            FX3D_PROBE_MARKW(tp == 0 ? 2 : 4);
 
             if (j0 + jstep >= NCm) {  // last chunk of this block: results of this tile pass
                 __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -1614,6 +1978,18 @@ Plan make_plan(int N, int M, int B, int D, bool allow_split = true) {
 
 size_t partials_count(const Plan &pl, int B) { return (size_t)2 * B * pl.tiles; }
 
+// Spatial pruning (nn1_f16_kernel<.., PRUNE>): one-chunk plans of the fp16 kernel without split or tail, clouds of at least 1024
+// points.  Rows of scratch per block: the candidate cloud in image order + the block's window of the query cloud.
+constexpr size_t kHBoxBytes = 64 * 2 * sizeof(float4);  // LDS: the lane tiles' boxes
+int prune_rows_per_block(const Plan &pl, int N, int M, int D) {
+    const int maxc = N > M ? N : M;
+    if (D != 3 || pl.variant != 3 || pl.nsplit != 1 || pl.tail != 0 || maxc > pl.chunk || maxc < 1024 || !opt(OPT_NN1_PRUNE)) return 0;
+    return kHChunkMax + (pl.tpb > pl.tpb_y ? pl.tpb : pl.tpb_y) * 512 + kHTail;
+}
+size_t prune_scratch_bytes(const Plan &pl, int N, int M, int D) {
+    return (size_t)prune_rows_per_block(pl, N, M, D) * pl.grid * sizeof(float4);
+}
+
 template <int DIM, bool WANT_IDX>
 fx3d_status launch_small(const Nn1Params &p, const Plan &pl, hipStream_t st) {
     if (pl.variant == 4) {
@@ -1630,11 +2006,13 @@ fx3d_status launch_small(const Nn1Params &p, const Plan &pl, hipStream_t st) {
     if (pl.variant == 3) {
         if (DIM == 3) {
             // > 64 KiB of dynamic LDS needs an explicit opt-in (static LDS of the kernel: < 1 KiB)
-            const void *kfn = p.fuse_split ? reinterpret_cast<const void *>(&nn1_f16_kernel<WANT_IDX, true>)
-                                           : reinterpret_cast<const void *>(&nn1_f16_kernel<WANT_IDX, false>);
-            const fx3d_status arc = ensure_dynamic_lds(kfn, (int)(kHChunkMax * 32 + kHScratchBytes), "nn1_f16_kernel");
+            const void *kfn = p.pscr ? reinterpret_cast<const void *>(&nn1_f16_kernel<WANT_IDX, false, true>)
+                              : p.fuse_split ? reinterpret_cast<const void *>(&nn1_f16_kernel<WANT_IDX, true>)
+                                             : reinterpret_cast<const void *>(&nn1_f16_kernel<WANT_IDX, false>);
+            const fx3d_status arc = ensure_dynamic_lds(kfn, (int)(kHChunkMax * 32 + kHScratchBytes + (p.pscr ? kHBoxBytes : 0)), "nn1_f16_kernel");
             if (arc != FX3D_OK) return arc;
-            if (p.fuse_split) hipLaunchKernelGGL((nn1_f16_kernel<WANT_IDX, true>), dim3(pl.grid), dim3(kHThreads), pl.lds_bytes, st, p);
+            if (p.pscr) hipLaunchKernelGGL((nn1_f16_kernel<WANT_IDX, false, true>), dim3(pl.grid), dim3(kHThreads), pl.lds_bytes + kHBoxBytes, st, p);
+            else if (p.fuse_split) hipLaunchKernelGGL((nn1_f16_kernel<WANT_IDX, true>), dim3(pl.grid), dim3(kHThreads), pl.lds_bytes, st, p);
             else hipLaunchKernelGGL((nn1_f16_kernel<WANT_IDX, false>), dim3(pl.grid), dim3(kHThreads), pl.lds_bytes, st, p);
         }
         FX3D_LAUNCH_CHECK();
@@ -1676,8 +2054,11 @@ struct Fused {
 fx3d_status run_nn1(const float *x, int N, const float *y, int M, int B, int D, int32_t *idx_x,
                     int32_t *idx_y, float *dmin_x, float *dmin_y, double *partials,
                     const Plan &pl, hipStream_t st, const Fused *fu = nullptr,
-                    unsigned long long *gres = nullptr, int qstride = 0) {
+                    unsigned long long *gres = nullptr, int qstride = 0, float4 *pscr = nullptr) {
     Nn1Params p{};
+    p.pscr = pscr;
+    p.pscr_stride = pscr ? prune_rows_per_block(pl, N, M, D) : 0;
+    if (!p.pscr_stride) p.pscr = nullptr;
     p.nsplit = gres ? pl.nsplit : 1;
     p.gres = gres;
     p.qstride = qstride;
@@ -1815,6 +2196,7 @@ fx3d_status fx3d_chamfer_workspace_bytes(int32_t N, int32_t M, int32_t B, int32_
     int tiles, tx, ty;
     partial_layout(pl, N, M, D, &tiles, &tx, &ty);
     *bytes = ((size_t)2 * B * tiles + 2) * sizeof(double);
+    if (const size_t ps = prune_scratch_bytes(pl, N, M, D)) *bytes = ((*bytes + 255) & ~(size_t)255) + ps;  // (a smaller workspace still runs: without pruning)
     if (pl.nsplit > 1) {  // split run: 256-query finalize tiles + the per-query merge slots
         const int maxq = N > M ? N : M;
         const int tiles_f = (maxq + kThreads - 1) / kThreads;
@@ -1888,7 +2270,11 @@ static fx3d_status chamfer_common(const float *x, int N, const float *y, int M, 
         if (!ticket) return trc;
         Fused fu{ticket, (unsigned int)((long long)B * tx + (long long)B * ty),
                  sums_dev ? sums_dev : partials + (size_t)2 * B * tiles, loss_dev, w1, w2, Bg};
-        return run_nn1(x, N, y, M, B, D, idx_x, idx_y, nullptr, nullptr, partials, pl, st, &fu);
+        // spatial pruning when the workspace holds the blocks' scratch behind the partial sums (fx3d_chamfer_workspace_bytes asks for it)
+        float4 *pscr = nullptr;
+        const size_t poff = (need + 255) & ~(size_t)255, ps = prune_scratch_bytes(pl, N, M, D);
+        if (ps && ws_bytes >= poff + ps) pscr = reinterpret_cast<float4 *>(static_cast<char *>(ws) + poff);
+        return run_nn1(x, N, y, M, B, D, idx_x, idx_y, nullptr, nullptr, partials, pl, st, &fu, nullptr, 0, pscr);
     }
     rc = run_nn1(x, N, y, M, B, D, idx_x, idx_y, nullptr, nullptr, partials, pl, st);
     if (rc) return rc;

@@ -87,6 +87,7 @@ enum Opt {
     OPT_NN1_TINY_MPAIRS,      // D = 3 nn1 / chamfer: problems of at most this many MILLION ordered pair evaluations (2 B N M) run on the
                               // exact small-problem kernel (nn1_tiny_kernel) instead of the fp16-filter kernel; 0 = never
     OPT_MESH_MAX_BLOCKS,      // grid cap of the grid-stride mesh kernels (areas, losses, adjoints), 256-thread blocks; 0 = automatic
+    OPT_NN1_PRUNE,            // 1 (default): chamfer / nn1 with a workspace run the fp16 kernel with spatial pruning (one-chunk plans); 0 = never
     OPT_COUNT
 };
 int opt(Opt o);

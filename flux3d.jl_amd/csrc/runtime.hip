@@ -40,6 +40,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"cdf_multiblock_from", "FX3D_CDF_MULTIBLOCK_FROM", 0, true},
     {"nn1_tiny_mpairs", "FX3D_NN1_TINY_MPAIRS", 24, true},
     {"mesh_max_blocks", "FX3D_MESH_MAX_BLOCKS", 0, true},
+    {"nn1_prune", "FX3D_NN1_PRUNE", 1, true},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::once_flag g_opt_once;

@@ -58,9 +58,10 @@ FX3D_API size_t fx3d_last_error(char *buf, size_t n); /* thread-local message; r
 
 /* ---- variant switches --------------------------------------------------------------------------------------------
  * The kernels' alternative code paths (A/B measurements, tests) are chosen by named integer options, process-wide and
- * atomic -- eleven since round 5: nn1_variant (3 | 0), nn1_nosplit, bwd_global_atomics, knn_no_mfma, knn_no_prepass,
- * knn_slices, edgeconv_unfused, lap_bwd_scatter, cdf_multiblock_from, nn1_tiny_mpairs, mesh_max_blocks
- * (fx3d_option_count / fx3d_option_name enumerate them).  The environment variables FX3D_<NAME> only seed the defaults,
+ * atomic -- twelve since round 6: nn1_variant (3 | 0), nn1_nosplit, bwd_global_atomics, knn_no_mfma, knn_no_prepass,
+ * knn_slices, edgeconv_unfused, lap_bwd_scatter, cdf_multiblock_from, nn1_tiny_mpairs, mesh_max_blocks, nn1_prune (1 | 0:
+ * the spatial pruning of the fp16 nearest-neighbour kernel, which needs the larger workspace fx3d_chamfer_workspace_bytes
+ * reports while it is on) (fx3d_option_count / fx3d_option_name enumerate them).  The environment variables FX3D_<NAME> only seed the defaults,
  * once, at the first use of the library; no entry point reads the environment on its launch path.  A host that runs two
  * configurations in one process sets the option before the calls that need it. */
 FX3D_API fx3d_status fx3d_set_option(const char *name, int32_t value);

@@ -231,7 +231,7 @@ def test_header_is_plain_c_and_links_from_c(fx, tmp_path):
 
 def test_option_api_without_a_gpu(fx):
     from flux3d_jl_amd import _lib
-    assert _lib.load().fx3d_option_count() == len(_lib.options()) == 11
+    assert _lib.load().fx3d_option_count() == len(_lib.options()) == 12
     with _lib.option("knn_no_mfma", 1):
         assert _lib.get_option("knn_no_mfma") == 1
     assert _lib.get_option("knn_no_mfma") == 0

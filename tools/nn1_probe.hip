@@ -80,6 +80,29 @@ int main(int argc, char **argv) {
     printf("kernel span (first block start -> last block end): %llu ticks\n", tmax - t0min);
     for (int k = 1; k <= 12; ++k) printf("  %-20s avg %10.1f ticks\n", names[k], d[k] / nb);
     printf("accumulated over all launches: wave-passes %llu, with slow queries %llu, retried %llu, with run items %llu; slow queries %llu, lanes with an unusable filter %llu\n", pr[4095 * 16], pr[4095 * 16 + 1], pr[4095 * 16 + 2], pr[4095 * 16 + 3], pr[4095 * 16 + 4], pr[4095 * 16 + 5]);
+    printf("(pruned launches) lane tiles run in phase 0: %llu, in phase 1: %llu -- per wave-pass of %d: %.1f + %.1f\n", pr[4095 * 16 + 6], pr[4095 * 16 + 7],
+           (M + 63) / 64, pr[4095 * 16] ? (double)pr[4095 * 16 + 6] / pr[4095 * 16] : 0.0, pr[4095 * 16] ? (double)pr[4095 * 16 + 7] / pr[4095 * 16] : 0.0);
+    if (getenv("RAW")) {
+        std::vector<unsigned long long> p2(256 * 16);
+        hipMemcpyFromSymbol(p2.data(), HIP_SYMBOL(g_probe2), p2.size() * 8);
+        for (int b = 0; b < 3; ++b) {
+            printf("block %d sort-phase stamps (cycles from the kernel's start):", b);
+            for (int k = 0; k <= 8; ++k) if (p2[b * 16 + k]) printf(" %d:%llu", k, p2[b * 16 + k] - pr[b * 16]);
+            printf("\n");
+        }
+    }
+    if (getenv("RAW")) {
+        std::vector<unsigned long long> p3(16 * 16 * 8);
+        hipMemcpyFromSymbol(p3.data(), HIP_SYMBOL(g_probe3), p3.size() * 8);
+        for (int b = 0; b < 2; ++b) {
+            printf("block %d per wave (cycles from the kernel's start): image staged | pass 0 loop done | pass 0 exact done | pass 1 loop done | pass 1 exact done\n", b);
+            for (int w = 0; w < 16; ++w) {
+                printf("  wave %2d (SIMD %d):", w, w & 3);
+                for (int k = 0; k < 5; ++k) printf(" %7llu", p3[(b * 16 + w) * 8 + k] - pr[b * 16]);
+                printf("\n");
+            }
+        }
+    }
     if (getenv("RAW"))  // stamps of a few blocks relative to their first one (marks need not be in index order)
         for (int b = 0; b < 3; ++b) {
             printf("block %d:", b);
