@@ -388,6 +388,7 @@ static_assert(kHChunkMax / (32 * kHLT) <= 64, "lane-tile ids live in the six low
 constexpr float kKeyUp = 0x1.2p-17f;
 constexpr float kPadF16 = 65504.0f;  // K slot 15: padding / far candidates get 65504 x 65504 = 4.3e9, finite and above every real
                                      // filter value (|t| <= 3 2^14 (1 + beta) + 128 S, S < 3e4): no +Inf in the image, no NaN keys
+constexpr int kHGroupsMax = 8 * 16 + 2;  // (PRUNE) 32-query groups of a block's window: up to eight passes + the folded remainder
 constexpr size_t kHScratchBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 2 + 32 * 3 * 4) + 64 * 32;  // + 2 pad blocks
 
 // plain v_min_f32 (fminf() also emits a canonicalising v_max in IEEE mode; the filter values are never
@@ -487,6 +488,12 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         const int qc0 = q0i < NQ ? q0i : NQ - 1;
 #pragma unroll
         for (int d = 0; d < 3; ++d) qpre[d] = qb[(size_t)qc0 * 3 + d];
+    }
+    if constexpr (PRUNE) {  // the sort's counters (in the waves' scratch, idle until the passes) and the query groups' boxes: the cloud pass's barrier orders this
+        unsigned int *zc = reinterpret_cast<unsigned int *>(wres);
+        for (int i = tid; i < 1040 + 16 * 256; i += kHThreads) zc[i] = 0u;
+        int *gb = reinterpret_cast<int *>(wq + (kHThreads / 64) * 96) + 64 * 8;
+        for (int i = tid; i < kHGroupsMax * 8; i += kHThreads) gb[i] = (i & 4) ? (int)0x80000000 : 0x7fffffff;  // lo keys: +max, hi keys: -max
     }
     FX3D_PROBE_MARK(0);
 
@@ -672,12 +679,15 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         const int qw1 = last_t || qw0 + tpb * QB > NQ ? NQ : qw0 + tpb * QB;
         qwlen = qw1 - qw0;
         const int cnt = NCm;  // (PRUNE launches are one-chunk plans without a tail)
-        const bool do_sort = sane && !has_far && cnt >= 512;
+        const bool do_sort = sane && cnt >= 512;
         // The queries' order must not depend on timing (it decides in which block and lane a query's term of the loss is summed):
         // wave w counts the queries 256 w .. 256 w + 255 in counters of its own -- returning LDS atomics of ONE wave are served in
         // program order, lanes of one instruction in the hardware's fixed order --, a query's rank is (queries in cells before its
         // cell) + (queries of its cell in the waves before) + (the value its own atomic returned).
-        const bool sorted_q = do_sort && NQ <= 4 * kHThreads;
+        // (a query cloud that lies mostly OUTSIDE the candidates' box keeps its index order: its queries would crowd into a few border
+        //  cells -- every same-address LDS atomic serialises -- and their waves' boxes reach most lane tiles anyway.  Every block of the
+        //  cloud takes the same decision: the count is that of the whole query cloud in the frame of the whole candidate cloud.)
+        bool sorted_q = do_sort && NQ <= 4 * kHThreads;
         P3 qv[4];
         if (sorted_q) {
 #pragma unroll
@@ -687,8 +697,13 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             }
         }
         FX3D_PROBE_MARK2(0);
+        int *gbox = reinterpret_cast<int *>(boxes + 64 * 2);  // [groups of 32 window rows] x (lo keys, -, hi keys, -)
+        auto group_box = [&](int wrow, float x, float y, float z) {  // a query of the window: into the box of its group (image frame)
+            int *g = gbox + (wrow >> 5) * 8;
+            atomicMin(g + 0, fkey((x - mu[0]) * sc)); atomicMin(g + 1, fkey((y - mu[1]) * sc)); atomicMin(g + 2, fkey((z - mu[2]) * sc));
+            atomicMax(g + 4, fkey((x - mu[0]) * sc)); atomicMax(g + 5, fkey((y - mu[1]) * sc)); atomicMax(g + 6, fkey((z - mu[2]) * sc));
+        };
         if (do_sort) {
-            for (int i = tid; i < 1040 + 16 * 256; i += kHThreads) ccnt[i] = 0u;
             float4 cv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -696,13 +711,18 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 cv[e] = float4{0.f, 0.f, 0.f, 0.f};
                 if (pt < cnt) cv[e] = imgf[((pt >> 5) * 2) * 32 + (pt & 31)];  // parked by this thread
             }
-            __syncthreads();
             FX3D_PROBE_MARK2(1);
             float inv[3], off[3];
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                inv[d] = bxhi[d] > bxlo[d] ? 8.0f / (bxhi[d] - bxlo[d]) : 0.0f;
-                off[d] = -bxlo[d] * inv[d];
+                // the grid spans the cloud's box, clipped to the filter's range about the centre (|c~| < 128): far outliers -- they
+                // stay out of the filter, on the side list -- fall into border cells instead of squeezing the bulk into one cell
+                // (with far outliers rng = 16 x the bulk's mean max-norm deviation -- 12 half widths of a uniform box, 21 sigma of a
+                //  Gaussian --: an eighth of it about the centre holds the bulk)
+                const float fr = has_far ? 0.125f * rng : 128.0f / sc;
+                const float flo = fmaxf(bxlo[d], mu[d] - fr), fhi = fminf(bxhi[d], mu[d] + fr);
+                inv[d] = fhi > flo ? 8.0f / (fhi - flo) : 0.0f;
+                off[d] = -flo * inv[d];
             }
             auto cell = [&](float x, float y, float z) -> unsigned int {  // the 8 x 8 x 8 cell of a point (outside the box: a border cell)
                 const unsigned int ux = (unsigned int)(int)fminf(fmaxf(__builtin_fmaf(x, inv[0], off[0]), 0.0f), 7.0f);
@@ -710,34 +730,61 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 const unsigned int uz = (unsigned int)(int)fminf(fmaxf(__builtin_fmaf(z, inv[2], off[2]), 0.0f), 7.0f);
                 return ux | (uy << 3) | (uz << 6);
             };
+            auto outside = [&](float x, float y, float z) -> bool {  // beyond the grid by more than a cell (or not a number)
+                const float a = __builtin_fmaf(x, inv[0], off[0]), b2 = __builtin_fmaf(y, inv[1], off[1]), c2 = __builtin_fmaf(z, inv[2], off[2]);
+                return !(fminf(fminf(a, b2), c2) >= -1.0f && fmaxf(fmaxf(a, b2), c2) <= 9.0f);
+            };
             unsigned int ccr[4], qcr[4];  // (cell << 16) | rank among the cell's points (candidates: arrival; queries: within the wave)
+            // Lanes of one instruction that share a cell serialise on its LDS address (a cloud that is a point, a tight cluster beside
+            // far outliers, queries outside the candidates' box that all clamp into one corner cell: 4096 same-address atomics cost a
+            // block 30 k cycles): up to two crowded cells per instruction -- the first uncounted lane's, if eight or more lanes share
+            // it -- are counted by ONE atomic each, their lanes ranked in lane order.
+            auto count_cells = [&](bool valid, unsigned int t, auto &&add) -> unsigned int {  // add(cell, n) -> the count before; returns this lane's rank
+                unsigned int rank = 0u;
+                bool mine = valid;
+                // crowded?  eight or more lanes whose neighbour lane sits in the same cell (uniform data: none) -- then the cells of the
+                // instruction are taken one by one, a cell with four or more lanes by ONE atomic (ranks in lane order)
+                const unsigned int tn = (unsigned int)__builtin_amdgcn_update_dpp((int)~t, (int)t, 0x111, 0xF, 0xF, false);  // row_shr:1
+                if (__builtin_popcountll(__ballot(valid && t == tn)) >= 8) {
+                    unsigned long long rem = __ballot(valid);
+                    for (int it = 0; it < 12 && rem; ++it) {
+                        const unsigned int t0 = (unsigned int)__builtin_amdgcn_readlane((int)t, __builtin_ctzll(rem));
+                        const unsigned long long grp = __ballot(mine && t == t0);
+                        rem &= ~grp;
+                        if (__builtin_popcountll(grp) < 4) continue;
+                        unsigned int base = 0u;
+                        if ((int)lane == __builtin_ctzll(grp)) base = add(t0, (unsigned int)__builtin_popcountll(grp));
+                        base = (unsigned int)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(grp));
+                        if (mine && t == t0) {
+                            rank = base + __builtin_amdgcn_mbcnt_hi((unsigned int)(grp >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)grp, 0u));
+                            mine = false;
+                        }
+                    }
+                }
+                if (mine) rank = add(t, 1u);
+                return rank;
+            };
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int pt = e * kHThreads + tid;
-                ccr[e] = 0u;
-                if (pt < cnt) {
-                    const unsigned int t = cell(cv[e].x, cv[e].y, cv[e].z);
-                    ccr[e] = (t << 16) | atomicAdd(&ccnt[t], 1u);
-                }
+                const unsigned int t = pt < cnt ? cell(cv[e].x, cv[e].y, cv[e].z) : 0u;
+                ccr[e] = (t << 16) | count_cells(pt < cnt, t, [&](unsigned int c, unsigned int n) { return atomicAdd(&ccnt[c], n); });
             }
-            if (sorted_q) {
+            if (sorted_q) {  // queries beyond the grid, counted over the block (one LDS atomic per wave)
+                int nout = 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int qp = 256 * wv + 64 * e + lane;
-                    qcr[e] = 0u;
-                    if (qp < NQ) {
-                        const unsigned int t = cell(qv[e].x, qv[e].y, qv[e].z), sh = 16u * (t & 1u);
-                        const unsigned int old = atomicAdd(&qwh[wv * 256 + (t >> 1)], 1u << sh);
-                        atomicAdd(&qtot[t], 1u);
-                        qcr[e] = (t << 16) | ((old >> sh) & 0xffffu);
-                    }
+                    nout += __builtin_popcountll(__ballot(qp < NQ && outside(qv[e].x, qv[e].y, qv[e].z)));
                 }
+                if (lane == 0 && nout) atomicAdd(&ccnt[516], (unsigned int)nout);
             }
             FX3D_PROBE_MARK2(2);
             __syncthreads();
             FX3D_PROBE_MARK2(3);
-            if (wv < 2) {  // exclusive scans in Morton order: wave 0 the candidates' cells, wave 1 the queries' (eight cells per lane)
-                unsigned int *a = wv ? qtot : ccnt;
+            sorted_q = sorted_q && 4u * ccnt[516] <= (unsigned int)NQ;
+            // exclusive scan of a count array in Morton order by one wave (eight cells per lane)
+            auto morton_scan = [&](unsigned int *a) {
                 const unsigned int l = (unsigned int)lane;
                 const unsigned int tb = ((l & 1u) << 1) | ((l & 8u) >> 1) | ((l & 2u) << 3) | ((l & 16u) << 1) | ((l & 4u) << 5) | ((l & 32u) << 3);
                 const unsigned int tk[8] = {0u, 1u, 8u, 9u, 64u, 65u, 72u, 73u};
@@ -753,14 +800,19 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 unsigned int run = inc - tot;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { a[tb + tk[k]] = run; run += c8[k]; }
-            } else if (wv >= 2 && wv < 6 && sorted_q) {  // a pair of cells per thread: counts of the waves before, wave by wave
-                const int w2 = tid - 128;
-                unsigned int run = 0u;
+            };
+            if (wv == 0) morton_scan(ccnt);  // the candidates' cells -> first image rows
+            if (sorted_q) {                  // the queries' cells, counted per wave
 #pragma unroll
-                for (int w = 0; w < 16; ++w) {
-                    const unsigned int v = qwh[w * 256 + w2];
-                    qwh[w * 256 + w2] = run;
-                    run += v;  // (two 16-bit sums of at most 4096: no carry between them)
+                for (int e = 0; e < 4; ++e) {
+                    const int qp = 256 * wv + 64 * e + lane;
+                    const unsigned int t = qp < NQ ? cell(qv[e].x, qv[e].y, qv[e].z) : 0u;
+                    qcr[e] = (t << 16) | count_cells(qp < NQ, t, [&](unsigned int c, unsigned int n) {
+                                 const unsigned int sh = 16u * (c & 1u);
+                                 const unsigned int old = atomicAdd(&qwh[wv * 256 + (c >> 1)], n << sh);
+                                 atomicAdd(&qtot[c], n);
+                                 return (old >> sh) & 0xffffu;
+                             });
                 }
             }
             FX3D_PROBE_MARK2(4);
@@ -776,24 +828,52 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             }
             sorted_c = true;
             if (sorted_q) {
+                if (wv == 1) {
+                    morton_scan(qtot);       // -> first rank of every cell
+                } else if (wv >= 2 && wv < 6) {  // a pair of cells per thread: counts of the waves before, wave by wave
+                    const int w2 = tid - 128;
+                    unsigned int run = 0u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int qp = 256 * wv + 64 * e + lane;
-                    if (qp < NQ) {
-                        const unsigned int t = qcr[e] >> 16;
-                        const int rank = (int)(qtot[t] + ((qwh[wv * 256 + (t >> 1)] >> (16u * (t & 1u))) & 0xffffu) + (qcr[e] & 0xffffu));
-                        if (rank >= qw0 && rank < qw1) qsw[rank - qw0] = float4{qv[e].x, qv[e].y, qv[e].z, __builtin_bit_cast(float, qp)};
+                    for (int w = 0; w < 16; ++w) {
+                        const unsigned int v = qwh[w * 256 + w2];
+                        qwh[w * 256 + w2] = run;
+                        run += v;  // (two 16-bit sums of at most 4096: no carry between them)
                     }
                 }
             }
             FX3D_PROBE_MARK2(6);
             __syncthreads();  // (the image rows are in place: the staging below converts them where they lie)
             FX3D_PROBE_MARK2(7);
+            if (sorted_q) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qp = 256 * wv + 64 * e + lane;
+                    if (qp < NQ) {
+                        const unsigned int t = qcr[e] >> 16;
+                        const int rank = (int)(qtot[t] + ((qwh[wv * 256 + (t >> 1)] >> (16u * (t & 1u))) & 0xffffu) + (qcr[e] & 0xffffu));
+                        if (rank >= qw0 && rank < qw1) {
+                            qsw[rank - qw0] = float4{qv[e].x, qv[e].y, qv[e].z, __builtin_bit_cast(float, qp)};
+                            group_box(rank - qw0, qv[e].x, qv[e].y, qv[e].z);
+                        }
+                    }
+                }
+            }
         }
         if (!sorted_q) {  // index order: the block's window of the query cloud as it lies in memory
-            for (int qp = qw0 + tid; qp < qw1; qp += kHThreads) {
-                const P3 r = *reinterpret_cast<const P3 *>(qb + (size_t)qp * 3);
-                qsw[qp - qw0] = float4{r.x, r.y, r.z, __builtin_bit_cast(float, qp)};
+            // (the 32 rows of a group are 32 consecutive lanes here: their box by four DPP row steps, two lanes per group go to LDS --
+            //  32 lanes on one LDS address would serialise)
+            for (int q0 = qw0 + wv * 64; q0 < qw1; q0 += kHThreads) {
+                const int qp = q0 + lane;
+                const P3 r = *reinterpret_cast<const P3 *>(qb + (size_t)(qp < qw1 ? qp : qw1 - 1) * 3);  // (lanes past the window repeat its last row)
+                if (qp < qw1) qsw[qp - qw0] = float4{r.x, r.y, r.z, __builtin_bit_cast(float, qp)};
+                const int kx = fkey((r.x - mu[0]) * sc), ky = fkey((r.y - mu[1]) * sc), kz = fkey((r.z - mu[2]) * sc);
+                const int lx = row_mm_key<false>(kx), ly = row_mm_key<false>(ky), lz = row_mm_key<false>(kz);
+                const int hx = row_mm_key<true>(kx), hy = row_mm_key<true>(ky), hz = row_mm_key<true>(kz);
+                if ((lane & 15) == 0 && qp < qw1) {
+                    int *g = gbox + ((qp - qw0) >> 5) * 8;
+                    atomicMin(g + 0, lx); atomicMin(g + 1, ly); atomicMin(g + 2, lz);
+                    atomicMax(g + 4, hx); atomicMax(g + 5, hy); atomicMax(g + 6, hz);
+                }
             }
         }
         // (the barrier behind the image staging below orders these stores -- and the image's -- before their readers)
@@ -819,20 +899,21 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         if (j0 > jfirst) __syncthreads();
         // ---- stage the fp16 split image ------------------------------------------------------------------
         if constexpr (PRUNE) {
-            // (PRUNE) thread t converts the image rows 4 t .. 4 t + 3 where the sort laid them (or where the cloud pass parked them) and
-            // writes them to the block's scratch; the 16 threads of a DPP row hold one lane tile: its box (image frame) by four row steps
-            for (int base = 4 * tid; base < cnt_pad + 64; base += 4 * kHThreads) {
+// (PRUNE) the 16 threads of a DPP row convert the 64 image rows of ONE lane tile where the sort laid them (or where the cloud
+            // pass parked them): row k 16 + (lane of the row) in step k -- 256 contiguous bytes per row and LDS access --, write them to
+            // the block's scratch, and reduce the tile's box (image frame) with four row steps
+            for (int tl = tid >> 4; tl * 64 < cnt_pad + 64; tl += kHThreads / 16) {
                 float4 r4[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int pt = base + k;
+                    const int pt = tl * 64 + k * 16 + (tid & 15);
                     r4[k] = float4{0.f, 0.f, 0.f, 0.f};
                     if (pt < cnt) r4[k] = imgf[((pt >> 5) * 2) * 32 + (pt & 31)];
                 }
                 float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int pt = base + k, i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
+                    const int pt = tl * 64 + k * 16 + (tid & 15), i0 = ((pt >> 5) * 2) * 32 + (pt & 31);
                     h8 p0, p1;
                     if (pt < cnt) {
                         pieces(r4[k].x, r4[k].y, r4[k].z, pt, p0, p1);
@@ -840,7 +921,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                         cs[pt] = float4{r4[k].x, r4[k].y, r4[k].z, __builtin_bit_cast(float, id)};
                         const float b3[3] = {(r4[k].x - mu[0]) * sc, (r4[k].y - mu[1]) * sc, (r4[k].z - mu[2]) * sc};
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) { lo3[d] = fminf(lo3[d], b3[d]); hi3[d] = fmaxf(hi3[d], b3[d]); }
+                        for (int d = 0; d < 3; ++d) { lo3[d] = vmin(lo3[d], b3[d]); hi3[d] = -vmin(-hi3[d], -b3[d]); }
                     } else {
                         make_pieces(0.f, 0.f, 0.f, p0, p1);
                         p1[7] = (_Float16)kPadF16;
@@ -851,9 +932,9 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 float bl[3], bh[3];
 #pragma unroll
                 for (int d = 0; d < 3; ++d) { bl[d] = fkey_inv(row_mm_key<false>(fkey(lo3[d]))); bh[d] = fkey_inv(row_mm_key<true>(fkey(hi3[d]))); }
-                if ((tid & 15) == 0 && (base >> 6) < 64) {
-                    boxes[(base >> 6) * 2] = float4{bl[0], bl[1], bl[2], 0.0f};
-                    boxes[(base >> 6) * 2 + 1] = float4{bh[0], bh[1], bh[2], 0.0f};
+                if ((tid & 15) == 0 && tl < 64) {
+                    boxes[tl * 2] = float4{bl[0], bl[1], bl[2], 0.0f};
+                    boxes[tl * 2 + 1] = float4{bh[0], bh[1], bh[2], 0.0f};
                 }
             }
         } else
@@ -888,6 +969,9 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         const bool last_tile = tile == (dir ? p.tiles_y : p.tiles_x) - 1;
         for (int tp = 0; tp < tpb || (last_tile && one_shot); ++tp) {
             if ((tile * tpb + tp) * QB >= NQ) break;  // uniform
+            if constexpr (PRUNE) {
+                if (tp * QB + wv * 32 >= qwlen) continue;  // (wave-uniform) no query of the window left for this wave: nothing to do, nothing to write
+            }
             if (j0 == jfirst) {
                 qi = (tile * tpb + tp) * QB + wv * 32 + jq;
                 if constexpr (PRUNE) {  // row (tp QB + wave's 32 + jq) of the block's window of the query cloud, in processing order
@@ -1038,11 +1122,13 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             // iteration -- the rotation of three accumulator sets keeps static register names --, padded with the image's two padding
             // blocks (lane tile `nlt`: keys of 4.3e9 that no band reaches).
             const int nltp = nblk / kHLT;      // lane tiles of the chunk; index nltp = the padding blocks
-            const float qsx = (qr[0] - mu[0]) * sc, qsy = (qr[1] - mu[1]) * sc, qsz = (qr[2] - mu[2]) * sc;
             float bd = INFINITY;
             {
-                const float qlx = wave_min_f(qsx), qly = wave_min_f(qsy), qlz = wave_min_f(qsz);
-                const float qhx = wave_max_f(qsx), qhy = wave_max_f(qsy), qhz = wave_max_f(qsz);
+                // the box of the wave's 32 queries (group tp 16 + wave of the window): gathered when the window was laid out
+                const int4 *gq = reinterpret_cast<const int4 *>(boxes + 64 * 2) + (tp * (kHThreads / 64) + wv) * 2;
+                const int4 gl = gq[0], gh = gq[1];
+                const float qlx = fkey_inv(gl.x), qly = fkey_inv(gl.y), qlz = fkey_inv(gl.z);
+                const float qhx = fkey_inv(gh.x), qhy = fkey_inv(gh.y), qhz = fkey_inv(gh.z);
                 if (lane < nltp) {
                     const float4 lo = boxes[lane * 2], hi = boxes[lane * 2 + 1];
                     const float gx = fmaxf(fmaxf(lo.x - qhx, qlx - hi.x), 0.0f), gy = fmaxf(fmaxf(lo.y - qhy, qly - hi.y), 0.0f);
@@ -1074,9 +1160,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 }
                 done |= todo;
                 unsigned long long mk = todo;
+                int nrem = __builtin_popcountll(mk) - 1;  // lane tiles of the list behind the one in flight
 #define NN1_NEXT(T) { T = nltp; if (mk) { T = __builtin_ctzll(mk); mk &= mk - 1ull; } }
-                int ta, tb, tc;
-                NN1_NEXT(ta) NN1_NEXT(tb) NN1_NEXT(tc)
+                int ta, tb;
+                NN1_NEXT(ta) NN1_NEXT(tb)
                 f32x16 acc0, acc1, acc2;
                 const h8 *pn = pbase + ta * (kHLT * 64);
                 h8 an = pn[0];
@@ -1091,23 +1178,38 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 __builtin_amdgcn_s_setprio(1);                                                                       \
                 NN1_FOLD(FOLD, !(ODD))                                                                               \
                 if (ODD) NN1_TRACK_ID(LT)
-                while (true) {
-                    // entry: ta's two blocks are in acc0, acc1 (issued), `an` holds tb's first operand, pn -> tb
+                // invariant: lane tile ta is in flight (acc0, acc1), tb is the next one (the padding tile if the list is exhausted),
+                // `an` holds tb's first operand, pn -> tb
+                while (nrem >= 3) {
+                    int tc, td, te;
+                    NN1_NEXT(tc) NN1_NEXT(td) NN1_NEXT(te)
+                    nrem -= 3;
+                    const h8 *pc = pbase + tc * (kHLT * 64), *pd = pbase + td * (kHLT * 64);
+                    NN1_PSTEP(acc2, acc0, 0, ta, pn[64])
+                    NN1_PSTEP(acc0, acc1, 1, ta, pc[0])
+                    pn = pbase + te * (kHLT * 64);
+                    NN1_PSTEP(acc1, acc2, 0, tb, pc[64])
+                    NN1_PSTEP(acc2, acc0, 1, tb, pd[0])
+                    NN1_PSTEP(acc0, acc1, 0, tc, pd[64])
+                    NN1_PSTEP(acc1, acc2, 1, tc, pn[0])
+                    ta = td; tb = te;
+                }
+                // the last 0, 1 or 2 lane tiles, then the two folds still pending
+                if (nrem == 2) {
+                    int tc;
+                    NN1_NEXT(tc)
                     const h8 *pc = pbase + tc * (kHLT * 64);
                     NN1_PSTEP(acc2, acc0, 0, ta, pn[64])
                     NN1_PSTEP(acc0, acc1, 1, ta, pc[0])
-                    if (tb == nltp) break;     // (uniform) the list ended with ta: what is in flight is padding
-                    int na, nb_, nc;
-                    NN1_NEXT(na) NN1_NEXT(nb_) NN1_NEXT(nc)
-                    const h8 *pna = pbase + na * (kHLT * 64);
                     NN1_PSTEP(acc1, acc2, 0, tb, pc[64])
-                    NN1_PSTEP(acc2, acc0, 1, tb, pna[0])
-                    if (tc == nltp) break;
-                    pn = pbase + nb_ * (kHLT * 64);
-                    NN1_PSTEP(acc0, acc1, 0, tc, pna[64])
-                    NN1_PSTEP(acc1, acc2, 1, tc, pn[0])
-                    if (na == nltp) break;
-                    ta = na; tb = nb_; tc = nc;
+                    NN1_PSTEP(acc2, acc0, 1, tb, pc[64])
+                    NN1_FOLD(acc1, true) NN1_FOLD(acc2, false) NN1_TRACK_ID(tc)
+                } else if (nrem == 1) {
+                    NN1_PSTEP(acc2, acc0, 0, ta, pn[64])
+                    NN1_PSTEP(acc0, acc1, 1, ta, pn[64])
+                    NN1_FOLD(acc2, true) NN1_FOLD(acc0, false) NN1_TRACK_ID(tb)
+                } else {
+                    NN1_FOLD(acc0, true) NN1_FOLD(acc1, false) NN1_TRACK_ID(ta)
                 }
 #undef NN1_PSTEP
 #undef NN1_NEXT
@@ -1980,10 +2082,13 @@ size_t partials_count(const Plan &pl, int B) { return (size_t)2 * B * pl.tiles; 
 
 // Spatial pruning (nn1_f16_kernel<.., PRUNE>): one-chunk plans of the fp16 kernel without split or tail, clouds of at least 1024
 // points.  Rows of scratch per block: the candidate cloud in image order + the block's window of the query cloud.
-constexpr size_t kHBoxBytes = 64 * 2 * sizeof(float4);  // LDS: the lane tiles' boxes
+constexpr size_t kHBoxBytes = 64 * 2 * sizeof(float4) + kHGroupsMax * 32;  // LDS: the lane tiles' boxes + the query groups' boxes
 int prune_rows_per_block(const Plan &pl, int N, int M, int D) {
     const int maxc = N > M ? N : M;
     if (D != 3 || pl.variant != 3 || pl.nsplit != 1 || pl.tail != 0 || maxc > pl.chunk || maxc < 1024 || !opt(OPT_NN1_PRUNE)) return 0;
+    if ((pl.tpb > pl.tpb_y ? pl.tpb : pl.tpb_y) * 16 + 2 > kHGroupsMax) return 0;  // (the query groups' boxes: LDS for eight passes per block)
+    // one pass per block does not repay the sort (measured at B = 8 .. 16 x 4096: 36 against 30 us; two passes -- C2 -- 46 against 53)
+    if ((pl.tpb < pl.tpb_y ? pl.tpb : pl.tpb_y) < 2) return 0;
     return kHChunkMax + (pl.tpb > pl.tpb_y ? pl.tpb : pl.tpb_y) * 512 + kHTail;
 }
 size_t prune_scratch_bytes(const Plan &pl, int N, int M, int D) {

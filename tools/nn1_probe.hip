@@ -20,6 +20,16 @@ int main(int argc, char **argv) {
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
     for (auto &v : hx) v = rnd();
     for (auto &v : hy) v = rnd();
+    if (getenv("PNORMAL")) {  // standard normal coordinates (sum of 12 uniforms)
+        for (auto &v : hx) { float a = 0; for (int i = 0; i < 12; ++i) a += rnd(); v = a - 6.0f; }
+        for (auto &v : hy) { float a = 0; for (int i = 0; i < 12; ++i) a += rnd(); v = a - 6.0f; }
+    }
+    if (getenv("POUTLIER")) {  // tools/nn1_distribution_time.py's "outlier": a tiny bulk and one point 1e4 away per cloud
+        for (auto &v : hx) v *= 1e-2f;
+        for (auto &v : hy) v *= 1e-2f;
+        for (int b = 0; b < B; ++b) for (int d = 0; d < 3; ++d) { hx[(size_t)b * N * 3 + d] = 1e4f; hy[(size_t)b * M * 3 + d] = 1e4f; }
+    }
+    if (getenv("PSHIFT")) for (auto &v : hx) v += (float)atof(getenv("PSHIFT"));
     if (getenv("PLINE")) {  // the reference harness's input (benchmarks/metrics.jl:11-15): p_i = (i, i, i) / n, the same cloud on both sides
         for (int b = 0; b < B; ++b) {
             for (int i = 0; i < N; ++i) for (int d = 0; d < 3; ++d) hx[((size_t)b * N + i) * 3 + d] = (float)(i + 1) / (float)N;

@@ -63,7 +63,9 @@ if use_oracle:
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle  # noqa: E402
 bad = 0
-cases = [("uniform", 4096, 4096, 32), ("uniform", 4096, 4096, 2), ("normal", 4096, 4096, 8), ("sphere", 4096, 4096, 8), ("clusters", 4096, 4096, 8),
+cases = [("uniform", 4096, 4096, 64), ("uniform", 4096, 4096, 256), ("sphere", 4096, 4096, 32), ("normal", 4096, 4096, 32), ("clusters", 4096, 4096, 32),
+         ("lattice", 4096, 4096, 32), ("dupes", 4096, 4096, 32), ("outlier", 4096, 4096, 32), ("shifted", 4096, 4096, 32), ("uniform", 4000, 4090, 32),
+         ("uniform", 4096, 4096, 32), ("uniform", 4096, 4096, 2), ("normal", 4096, 4096, 8), ("sphere", 4096, 4096, 8), ("clusters", 4096, 4096, 8),
          ("lattice", 4096, 4096, 4), ("dupes", 4096, 4096, 4), ("outlier", 4096, 4096, 4), ("line", 4096, 4096, 4), ("uniform", 4000, 3000, 8),
          ("uniform", 1024, 4096, 8), ("uniform", 2048, 2048, 16), ("uniform", 1500, 1100, 8), ("sphere", 3333, 4095, 5), ("uniform", 4097, 4096, 2)]
 for kind, n, m, b in cases:
