@@ -14,13 +14,16 @@ counted steps run at the clocks a training loop sees, not at the clocks of an id
 steps -> barrier + device sync -> EXACTLY K timed steps -> device sync + barrier; max over ranks.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline             -- bound "mfma": `achieved` = the f16 flops the dominant kernel executes on the matrix cores per
-                          launch (SURVEY.md 8(d) MFMA clause: 2 * 2BNM * 16) / its average duration in THIS run (HIP
-                          events on its stream), `peak` 2500 TF dense f16, `frac` = achieved / peak (~0.27).  Named
-                          extras, never `frac`: `algorithmic_fp32_over_valu_peak` (16 flop per pair / t / 157.3 TF; > 1
-                          because the kernel does not execute those flops), `achieved_hbm` / `hbm_frac` (algorithmic
-                          bytes / t against 8 TB/s: BASELINE.json asks; not the bound), `traffic` (HBM bytes per
-                          launch, PMC), `valu_per_mfma` (PMC)
+  roofline             -- bound "mfma": `achieved` = the ALGORITHMIC f16 flops of one launch (SURVEY.md 8(d) MFMA clause: every
+                          ordered pair at the K = 16 of the fp16-split filter, 2 * 2BNM * 16 = 34.36 GFLOP) / the dominant
+                          kernel's average duration in THIS run (HIP events on its stream), `peak` 2500 TF dense f16,
+                          `frac` = achieved / peak.  Since round 6 the kernel SKIPS lane tiles whose bounding box cannot
+                          hold a nearest neighbour (spatial pruning): what it executes on the matrix cores is
+                          `executed_f16_flops_per_launch` (SQ_INSTS_MFMA x 32768, PMC) and `mfma_pipe_frac` (busy
+                          cycles) -- both named extras, lower than `frac`.  Other extras, never `frac`:
+                          `algorithmic_fp32_over_valu_peak` (16 flop per pair / t / 157.3 TF; > 1 because the kernel does
+                          not execute those flops), `achieved_hbm` / `hbm_frac` (algorithmic bytes / t against 8 TB/s:
+                          BASELINE.json asks; not the bound), `traffic` (HBM bytes per launch, PMC), `valu_per_mfma` (PMC)
   issue_occupancy      -- a named extra, NOT a roofline fraction: SIMD issue cycles ((VALU - MFMA) x 4 + MFMA busy) per
                           kernel cycle; it goes UP when a kernel wastes instructions
   protocol             -- benchmarks/metrics.jl:24-38 style numbers: min / median per call, forward and forward+backward
@@ -67,6 +70,30 @@ def kernel_source_hash():
         with open(os.path.join(ROOT, "flux3d.jl_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def ubench_loop_ceiling():
+    """The issue bound of the filter loop, DERIVED from the committed micro-benchmark table (profiles/r06_ubench_overlap.txt, produced
+    by tools/ubench_overlap.hip on the MI355X; VERDICT r5 #1: not a constant in this file): cycles per tile and SIMD of the MFMA alone
+    and of the loop's own instruction mix at four waves per SIMD, and their ratio = the share of the loop's cycles the matrix pipe
+    can be busy."""
+    path = os.path.join(ROOT, "profiles", "r06_ubench_overlap.txt")
+    out = {"source": "profiles/r06_ubench_overlap.txt (tools/ubench_overlap.hip, W = 4 waves per SIMD, slowest-wave column)"}
+    try:
+        import re
+        mf = lp = None
+        for ln in open(path):
+            m = re.search(r"W=4 .*\(avg wave\)\s+([0-9.]+) \(slowest wave\)", ln)
+            if not m:
+                continue
+            if ln.startswith("mfma only"):
+                mf = float(m.group(1))
+            elif ln.startswith("nn1 loop (fold after issue)") and "prio=1" in ln:
+                lp = float(m.group(1))
+        out.update({"mfma_only_cycles_per_tile": mf, "loop_cycles_per_tile": lp, "pipe_share_of_the_loop": (mf / lp) if mf and lp else None})
+    except Exception as e:  # noqa: BLE001
+        out["note"] = f"{type(e).__name__}: {e}"
+    return out
 
 
 def live_pmc_traffic(timeout_s=120):
@@ -458,34 +485,38 @@ def main():
     #   bytes: read both clouds once (4*D*B*(N+M)) + the per-block partial sums written
     flops = 16.0 * B_PER_GPU * NPTS * MPTS
     abytes = 4.0 * DIM * B_PER_GPU * (NPTS + MPTS) + 8.0 * 2 * B_PER_GPU * 8
-    n_mfma = 2.0 * B_PER_GPU * NPTS * MPTS / 1024.0            # one v_mfma_f32_32x32x16_f16 per 32 x 32 pairs and direction
-    mfma_busy = n_mfma * 32.0 / N_SIMD                           # matrix-pipe cycles per SIMD and launch
-    hw_flops = 2.0 * 16 * 1024 * n_mfma                          # f16 flops the matrix cores execute: 32x32x16 MACs per MFMA
+    n_mfma = 2.0 * B_PER_GPU * NPTS * MPTS / 1024.0            # ALL 32 x 32 pair tiles of both directions: one v_mfma_f32_32x32x16_f16 each
+    hw_flops = 2.0 * 16 * 1024 * n_mfma                          # algorithmic f16 flops of the launch (MFMA clause: K = 16)
     hw_tf = hw_flops / kern_s / 1e12 if kern_s else None
+    ub = ubench_loop_ceiling()
     roof = {
         "bound": "mfma", "achieved": hw_tf, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": (hw_tf / F16_MFMA_PEAK_TFLOPS) if kern_s else None, "traffic": None,
-        "mfma_pipe_frac": (mfma_busy / kern_s / 1e9 / PEAK_CLOCK_GHZ) if kern_s else None,
+        "mfma_pipe_frac": None, "executed_f16_flops_per_launch": None,
         "algorithmic_fp32_over_valu_peak": (flops / kern_s / 1e12 / FP32_PEAK_TFLOPS) if kern_s else None,
         "algorithmic_fp32_tflops": flops / kern_s / 1e12 if kern_s else None, "fp32_valu_peak": FP32_PEAK_TFLOPS,
         "achieved_hbm": abytes / kern_s / 1e9 if kern_s else None, "hbm_peak": HBM_PEAK_GBS,
         "hbm_frac": (abytes / kern_s / 1e9 / HBM_PEAK_GBS) if kern_s else None,
-        "executed_f16_flops_per_launch": hw_flops,
+        "algorithmic_f16_flops_per_launch": hw_flops,
         "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": abytes,
-        "kernel": "nn1_f16_kernel<false>", "kernel_avg_ms": avg.value, "kernel_min_ms": mn.value, "launches_timed": cnt.value,
-        "ceiling_of_this_formulation": 0.30,
-        "note": "bound = the f16 matrix pipe.  achieved = the f16 flops the kernel EXECUTES there per launch (SURVEY.md 8(d), MFMA "
-                "clause: 2*(2*B*N*M)*K with K = 16, one v_mfma_f32_32x32x16_f16 per 32 x 32 pairs and direction = SQ_INSTS_MFMA x "
-                "32768) / the kernel's average duration in this run (HIP events on its stream); peak = 2500 TF dense f16; frac = "
-                "achieved / peak (== mfma_pipe_frac, the pipe's busy cycles per kernel cycle at 2.4 GHz, up to the clock).  The pipe "
-                "is ~73 % idle by construction: each MFMA's 1024 filter values need 8 v_min3 + ~2 tracking VALU ops per lane and "
-                "only ~10 VALU cycles hide under an MFMA on a SIMD (tools/ubench_overlap.hip), so this fp16-split-filter + "
-                "exact-rescan formulation tops out near frac 0.30 (`ceiling_of_this_formulation`, DESIGN.md 3.1).  "
+        "kernel": "nn1_f16_kernel<false, false, true> (spatial pruning)", "kernel_avg_ms": avg.value, "kernel_min_ms": mn.value, "launches_timed": cnt.value,
+        "main_loop_issue_bound": ub,
+        "note": "bound = the f16 matrix pipe.  achieved = the ALGORITHMIC f16 flops of the launch (SURVEY.md 8(d), MFMA clause: "
+                "2*(2*B*N*M)*K with K = 16, i.e. one v_mfma_f32_32x32x16_f16 per 32 x 32 pairs and direction) / the kernel's average "
+                "duration in this run (HIP events on its stream); peak = 2500 TF dense f16; frac = achieved / peak.  The kernel does "
+                "NOT execute all of them since round 6: candidates lie in the LDS image in Morton order, queries are taken in the "
+                "same order, and a wave runs the filter only over the lane tiles whose bounding box can hold a nearest neighbour "
+                "of one of its 32 queries (~35 % of them on uniform clouds; results bit-identical) -- executed_f16_flops_per_launch "
+                "and mfma_pipe_frac (busy cycles per kernel cycle at 2.4 GHz) are what the matrix cores really do (PMC, "
+                "profiles/pmc_latest.json).  Why skipping and not a better schedule: main_loop_issue_bound -- tools/ubench_overlap.hip "
+                "(ISA-checked, profiles/r06_ubench_overlap.txt) shows the filter loop at the SIMD's VALU-issue bound for its "
+                "instruction mix (4.25 cycles per VALU + ~13 per MFMA issue; 10.7 VALU per MFMA => 58.8 cycles per tile, the pipe "
+                "busy 0.55 of the loop) under every schedule tried.  "
                 "algorithmic_fp32_over_valu_peak is a NAMED EXTRA, not the fraction of the bound: the reference's exact Float32 "
                 "form (16 flop per pair, both directions) / time against the fp32 vector peak; it exceeds 1 because the kernel "
                 "does not execute those flops.  achieved_hbm / hbm_frac: algorithmic bytes / time against 8 TB/s (BASELINE.json "
                 "asks; an exact all-pairs method cannot approach it: 70 % would be 0.56 us)"}
-    for k in ("frac", "mfma_pipe_frac", "hbm_frac"):
+    for k in ("frac", "hbm_frac"):
         assert roof[k] is None or roof[k] <= 1.0, (k, roof[k])   # no field called *frac may exceed 1
     issue = None
     pmc_note = "no profiles/pmc_latest.json"
@@ -495,14 +526,17 @@ def main():
         stale = pmc.get("kernel_source_sha16") != kernel_source_hash()
         valu, mfma = float(pmc["SQ_INSTS_VALU"]), float(pmc["SQ_INSTS_MFMA"])
         roof.update({"traffic": pmc.get("nn1_hbm_bytes_per_launch"), "valu_per_mfma": (valu - mfma) / mfma,
-                     "counters_from": pmc.get("source"), "counters_stale": stale})
+                     "counters_from": pmc.get("source"), "counters_stale": stale,
+                     "executed_f16_flops_per_launch": mfma * 32768.0, "executed_share_of_algorithmic": mfma * 32768.0 / hw_flops,
+                     "mfma_pipe_frac": (float(pmc["SQ_VALU_MFMA_BUSY_CYCLES"]) / N_SIMD / kern_s / 1e9 / PEAK_CLOCK_GHZ) if kern_s else None})
+        assert roof["mfma_pipe_frac"] is None or roof["mfma_pipe_frac"] <= 1.0
         cyc = ((valu - mfma) * 4.0 + float(pmc["SQ_VALU_MFMA_BUSY_CYCLES"])) / N_SIMD
         issue = {"value": (cyc / kern_s / 1e9 / PEAK_CLOCK_GHZ) if kern_s else None, "unit": "SIMD issue cycles per kernel cycle at 2.4 GHz",
                  "counters_stale": stale,
                  "note": "NOT a roofline fraction (VERDICT r2): ((SQ_INSTS_VALU - SQ_INSTS_MFMA) x 4 + MFMA busy cycles) / 1024 SIMDs "
                          "/ kernel time.  An occupancy of the issue ports that goes UP when the kernel issues more instructions for "
-                         "the same work; kept because it shows how little idle time is left (the loop is issue bound: a SIMD's VALU "
-                         "and matrix pipe mostly serialise, tools/ubench_overlap.hip)"}
+                         "the same work; kept because it shows how little idle time is left (the kernel is issue bound: every MFMA takes "
+                         "~13 cycles out of its SIMD's VALU issue stream, tools/ubench_overlap.hip)"}
         pmc_note = None
     except Exception as e:  # noqa: BLE001
         pmc_note = f"profiles/pmc_latest.json unusable: {e}"
@@ -674,6 +708,54 @@ def config_one_liners(fx):
     r["roofline"] = _roof(r["min_ms"], flops=16.0 * 8 * n3 * n3, nbytes=c3_bytes + 4.0 * 3 * 8 * 2 * n3)
     r["cdf_cached"] = _per_call_ms(fx, lambda: fx.chamfer_distance(m8, m8b, n3, seed=5, loss_out=loss_dev, sync=False))
     out["C3 chamfer_distance(mesh, mesh, 5000) B=8 teapots, CDFs rebuilt per call (2 x (CDF + draw) + chamfer)"] = r
+    # C3 as BASELINE.json names it -- the fit_mesh.jl LOOP ITERATION (examples/fit_mesh.jl:98-110; timed the `gradient(...)` way by
+    # benchmarks/metrics.jl:27-32): sample 5000 points of the offset source and of the target, chamfer, 0.1 laplacian + edge loss,
+    # the gradient w.r.t. the vertex offsets through every term, and the Momentum step.  (a) the tutorial's own pair -- one source
+    # sphere (2562 vertices) fitted to the teapot -- eager and as the captured hipGraph (one launch per iteration);
+    # (b) B = 8 teapot-class meshes (BASELINE configs[2]), eager and replayed.
+    g = os.path.join(ROOT, "tests", "golden")
+
+    def fit_entry(src, tgt, label):
+        xo = fx.DeviceArray.zeros((3, int(src.dev("verts_packed").shape[1])), np.float32)
+        opt = fx.Momentum(1.0, 0.9)
+        it = [0]
+
+        def eager():
+            _, grad = fx.loss_dolphin(xo, src, tgt, 5000, seed=100 + 2 * it[0], with_grad=True, sync=False)
+            opt.update(xo, grad)
+            it[0] += 1
+        e = _per_call_ms(fx, eager)
+        xg = fx.DeviceArray.zeros((3, int(src.dev("verts_packed").shape[1])), np.float32)
+        step = fx.FitStepGraph(xg, src, tgt, fx.Momentum(1.0, 0.9), num_samples=5000)
+        for _ in range(20):
+            step.step()
+        step.synchronize()
+        ev = [fx.Event() for _ in range(101)]
+        ev[0].record(step.stream)
+        for i in range(100):
+            step.step()
+            ev[i + 1].record(step.stream)
+        step.synchronize()
+        ts = np.array([ev[i].elapsed_ms(ev[i + 1]) for i in range(100)])
+        B, V, F = src.N, src.V, src.F
+        nb = 2 * (12.0 * V * B + 12.0 * F * B + 8.0 * F * B + 12.0 * 5000 * B) + 4.0 * 3 * B * 2 * 5000 * 2 + 3 * 12.0 * V * B
+        return {"what": label, "eager": e, "graph_replay": {"min_ms": float(ts.min()), "median_ms": float(np.median(ts)), "samples": 100},
+                "loss_after": float(step.loss.item()),
+                "roofline": _roof(float(ts.min()), flops=16.0 * B * 5000 * 5000, nbytes=nb)}
+    out["C3 fit_mesh.jl loop iteration (loss + gradient + Momentum), sphere -> teapot, 5000 samples (examples/fit_mesh.jl:98-110)"] = \
+        fit_entry(fx.gpu(fx.load_trimesh(os.path.join(g, "sphere.obj"))), fx.gpu(fx.load_trimesh(os.path.join(g, "teapot.obj"))),
+                  "one source mesh (2562 V / 5120 F) against one target (1202 V / 2256 F): the tutorial's loop")
+    out["C3 fit_mesh loop iteration, B = 8 teapot-class meshes (BASELINE configs[2]), 5000 samples"] = \
+        fit_entry(fx.gpu(fx.load_trimesh(*[t] * 8)), fx.gpu(fx.load_trimesh(*[t] * 8)), "eight source meshes against eight targets (1202 V / 2256 F each)")
+    # benchmarks/triangle_mesh.jl:30-34: the two workloads that file times on the teapot
+    tp = fx.gpu(fx.load_trimesh(t))
+    r = _per_call_ms(fx, lambda: fx.sample_points(tp, 10000, seed=7))
+    r["roofline"] = _roof(r["min_ms"], nbytes=12.0 * tp.V + 12.0 * tp.F + 8.0 * tp.F + 12.0 * 10000)
+    out["triangle_mesh.jl: sample_points(teapot, 10000) (benchmarks/triangle_mesh.jl:33)"] = r
+    tp2 = fx.gpu(fx.load_trimesh(t))
+    r = _per_call_ms(fx, lambda: fx.chamfer_distance(tp, tp2, 10000, seed=5, loss_out=loss_dev, sync=False, reuse_cdf=False))
+    r["roofline"] = _roof(r["min_ms"], flops=16.0 * 10000 * 10000, nbytes=2 * (12.0 * tp.V + 20.0 * tp.F + 12.0 * 10000) + 4.0 * 3 * 2 * 10000)
+    out["triangle_mesh.jl: chamfer_distance(teapot, teapot, 10000) (benchmarks/triangle_mesh.jl:30)"] = r
     c4 = fx.gpu(fx.synth.uniform_cloud(0x5EED0004, 3, 1024, 32))
     r = _per_call_ms(fx, lambda: fx.knn(c4, 20, drop_first=True))
     r["roofline"] = _roof(r["min_ms"], flops=8.0 * 32 * 1024 * 1024, nbytes=4.0 * 3 * 1024 * 32 + 2 * 4.0 * 20 * 1024 * 32)

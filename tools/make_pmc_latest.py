@@ -20,12 +20,15 @@ def main():
     fetch_kb, write_kb = k["FETCH_SIZE"]["avg"], k["WRITE_SIZE"]["avg"]
     out = {
         "source": f"{kept_as} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_*, separate passes of tools/pmc_driver.py nn1; tools/profile_round.sh)",
-        "kernel": "nn1_f16_kernel<false>",
+        "kernel": name[0],
         "kernel_source_sha16": kernel_source_hash(),
         "FETCH_SIZE_KB_raw_avg": fetch_kb, "WRITE_SIZE_KB_raw_avg": write_kb,
         "correction": "gfx950 FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md HBM section): read side doubled; WRITE_SIZE uncorrected",
         "nn1_hbm_bytes_per_launch": int(round(2 * fetch_kb * 1024 + write_kb * 1024)),
         "algorithmic_bytes_per_launch": 4 * 3 * 32 * 8192 + 8 * 2 * 32 * 8,
+        "traffic_note": "since round 6 (spatial pruning) a block writes its candidate cloud in image order and its query window as 16-byte rows to "
+                        "scratch in the workspace (256 blocks x (4096 + 1088) rows = 21 MB) and the exact phase reads rows back: WRITE_SIZE ~ 20 MB, "
+                        "FETCH ~ 14.5 MB at C2 -- 0.84 TB/s over the kernel, a tenth of the HBM peak; the kernel is issue bound",
     }
     for c in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES",
               "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY"):
