@@ -388,7 +388,29 @@ static_assert(kHChunkMax / (32 * kHLT) <= 64, "lane-tile ids live in the six low
 constexpr float kKeyUp = 0x1.2p-17f;
 constexpr float kPadF16 = 65504.0f;  // K slot 15: padding / far candidates get 65504 x 65504 = 4.3e9, finite and above every real
                                      // filter value (|t| <= 3 2^14 (1 + beta) + 128 S, S < 3e4): no +Inf in the image, no NaN keys
-constexpr int kHGroupsMax = 8 * 16 + 2;  // (PRUNE) 32-query groups of a block's window: up to eight passes + the folded remainder
+// (PRUNE) the cells t = ux | uy << 3 | uz << 6 of the 8 x 8 x 8 sorting grid along a 3-D Hilbert curve (Skilling's transpose form, generated
+// offline): consecutive cells share a face, so 64 consecutive image rows -- a lane tile -- and 32 consecutive queries -- a wave -- are compact
+// in space even where a surface leaves most cells empty.  (Morton order jumps across the grid between siblings: lane tiles straddling a
+// jump had boxes half the cloud wide; uniform clouds ran 35 % of their lane tiles, 22 % along this curve.)
+__device__ const unsigned short kHilbertCell[512] = {
+    0, 1, 65, 64, 72, 73, 9, 8, 16, 24, 88, 80, 81, 89, 25, 17, 18, 26, 27, 19, 83, 91, 90, 82, 74, 10, 11, 75, 67, 3, 2, 66,
+    130, 194, 195, 131, 139, 203, 202, 138, 146, 154, 155, 147, 211, 219, 218, 210, 209, 217, 153, 145, 144, 152, 216, 208, 200, 201, 137, 136, 128, 129, 193, 192,
+    256, 257, 265, 264, 328, 329, 321, 320, 384, 448, 456, 392, 393, 457, 449, 385, 386, 450, 451, 387, 395, 459, 458, 394, 330, 322, 323, 331, 267, 259, 258, 266,
+    274, 282, 283, 275, 339, 347, 346, 338, 402, 466, 467, 403, 411, 475, 474, 410, 409, 473, 465, 401, 400, 464, 472, 408, 344, 345, 337, 336, 272, 273, 281, 280,
+    288, 296, 297, 289, 353, 361, 360, 352, 416, 480, 481, 417, 425, 489, 488, 424, 432, 496, 504, 440, 441, 505, 497, 433, 369, 368, 376, 377, 313, 312, 304, 305,
+    306, 307, 315, 314, 378, 379, 371, 370, 434, 498, 506, 442, 443, 507, 499, 435, 427, 491, 490, 426, 418, 482, 483, 419, 355, 363, 362, 354, 290, 298, 299, 291,
+    227, 235, 171, 163, 162, 170, 234, 226, 225, 224, 160, 161, 169, 168, 232, 233, 241, 240, 248, 249, 185, 184, 176, 177, 178, 242, 250, 186, 187, 251, 243, 179,
+    115, 51, 59, 123, 122, 58, 50, 114, 113, 112, 120, 121, 57, 56, 48, 49, 41, 40, 104, 105, 97, 96, 32, 33, 34, 42, 106, 98, 99, 107, 43, 35,
+    36, 44, 108, 100, 101, 109, 45, 37, 38, 39, 103, 102, 110, 111, 47, 46, 54, 55, 63, 62, 126, 127, 119, 118, 117, 53, 61, 125, 124, 60, 52, 116,
+    180, 244, 252, 188, 189, 253, 245, 181, 182, 183, 191, 190, 254, 255, 247, 246, 238, 239, 175, 174, 166, 167, 231, 230, 229, 237, 173, 165, 164, 172, 236, 228,
+    292, 300, 301, 293, 357, 365, 364, 356, 420, 484, 485, 421, 429, 493, 492, 428, 436, 500, 508, 444, 445, 509, 501, 437, 373, 372, 380, 381, 317, 316, 308, 309,
+    310, 311, 319, 318, 382, 383, 375, 374, 438, 502, 510, 446, 447, 511, 503, 439, 431, 495, 494, 430, 422, 486, 487, 423, 359, 367, 366, 358, 294, 302, 303, 295,
+    287, 286, 278, 279, 343, 342, 350, 351, 415, 479, 471, 407, 406, 470, 478, 414, 413, 477, 476, 412, 404, 468, 469, 405, 341, 349, 348, 340, 276, 284, 285, 277,
+    269, 261, 260, 268, 332, 324, 325, 333, 397, 461, 460, 396, 388, 452, 453, 389, 390, 454, 462, 398, 399, 463, 455, 391, 327, 326, 334, 335, 271, 270, 262, 263,
+    199, 198, 134, 135, 143, 142, 206, 207, 215, 223, 159, 151, 150, 158, 222, 214, 213, 221, 220, 212, 148, 156, 157, 149, 141, 205, 204, 140, 132, 196, 197, 133,
+    69, 5, 4, 68, 76, 12, 13, 77, 85, 93, 92, 84, 20, 28, 29, 21, 22, 30, 94, 86, 87, 95, 31, 23, 15, 14, 78, 79, 71, 70, 6, 7,
+};
+constexpr int kHGroupsMax = 8 * 16 + 2 + 1;  // (PRUNE) 32-query groups of a block's window: up to eight passes + the folded remainder; + one slot: the query cloud's box
 constexpr size_t kHScratchBytes = (kHThreads / 64) * (32 * 8 + kHItemCap * 2 + 32 * 3 * 4) + 64 * 32;  // + 2 pad blocks
 
 // plain v_min_f32 (fminf() also emits a canonicalising v_max in IEEE mode; the filter values are never
@@ -651,7 +673,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
 
     // ---- (PRUNE, round 6) SPATIAL ORDER.  tools/ubench_overlap.hip (profiles/r06_ubench_overlap.txt) shows the main loop at the
     //      SIMD's VALU-issue bound for its instruction mix -- no schedule of the same pairs is faster -- so the pairs have to go:
-    //      the candidates are laid into the image in Morton order of an 8 x 8 x 8 grid over the cloud's bounding box (counting sort:
+    //      the candidates are laid into the image along a Hilbert curve through an 8 x 8 x 8 grid over the cloud's bounding box (counting sort:
     //      LDS integer atomics, one scan), every lane tile (64 consecutive image rows) gets a bounding box, the block takes its
     //      queries as a WINDOW of the query cloud in the same order (32 consecutive ones per wave: a compact box), and a wave runs
     //      the filter only over the lane tiles whose box can hold a nearest neighbour of one of its queries (main loop below).
@@ -670,7 +692,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         qsw = cs + kHChunkMax;
         boxes = reinterpret_cast<float4 *>(wq + (kHThreads / 64) * 96);  // [64 lane tiles] x (lo, hi): 2 KiB behind the waves' scratch
         // (the waves' scratch is idle here: 20.5 of its 22 KiB hold the counters)  Cells are numbered t = ux | uy << 3 | uz << 6; the
-        // SCANS walk them in Morton order, so the image order is the Morton order of the cells at two shifts per point.
+        // SCANS walk them along the Hilbert curve (kHilbertCell), so the image order is the curve's order of the cells at two shifts per point.
         unsigned int *ccnt = reinterpret_cast<unsigned int *>(wres);  // [512] candidates per cell -> first image row of the cell
         unsigned int *qtot = ccnt + 520;                               // [512] queries per cell -> first rank of the cell
         unsigned int *qwh = qtot + 520;                                // [16 waves][256] per-wave counts, two 16-bit cells per word -> counts of the waves before
@@ -684,10 +706,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         // wave w counts the queries 256 w .. 256 w + 255 in counters of its own -- returning LDS atomics of ONE wave are served in
         // program order, lanes of one instruction in the hardware's fixed order --, a query's rank is (queries in cells before its
         // cell) + (queries of its cell in the waves before) + (the value its own atomic returned).
-        // (a query cloud that lies mostly OUTSIDE the candidates' box keeps its index order: its queries would crowd into a few border
-        //  cells -- every same-address LDS atomic serialises -- and their waves' boxes reach most lane tiles anyway.  Every block of the
-        //  cloud takes the same decision: the count is that of the whole query cloud in the frame of the whole candidate cloud.)
-        bool sorted_q = do_sort && NQ <= 4 * kHThreads;
+        // The queries are ordered in a grid over THEIR OWN bounding box (the clouds of a pair need not overlap, nor be of one size: in the
+        // candidates' frame a chair's points fell outside an aeroplane's flat box and crowded into its border cells), found by the
+        // block while the candidates are counted: integer-key min / max over the wave (DPP), 6 LDS atomics per wave.
+        const bool sorted_q = do_sort && NQ <= 4 * kHThreads;
         P3 qv[4];
         if (sorted_q) {
 #pragma unroll
@@ -712,7 +734,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 if (pt < cnt) cv[e] = imgf[((pt >> 5) * 2) * 32 + (pt & 31)];  // parked by this thread
             }
             FX3D_PROBE_MARK2(1);
-            float inv[3], off[3];
+            float inv[3], off[3], cfl[3], cfh[3];  // (cfl, cfh: the candidates' grid frame)
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 // the grid spans the cloud's box, clipped to the filter's range about the centre (|c~| < 128): far outliers -- they
@@ -723,6 +745,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 const float flo = fmaxf(bxlo[d], mu[d] - fr), fhi = fminf(bxhi[d], mu[d] + fr);
                 inv[d] = fhi > flo ? 8.0f / (fhi - flo) : 0.0f;
                 off[d] = -flo * inv[d];
+                cfl[d] = flo; cfh[d] = fhi;
             }
             auto cell = [&](float x, float y, float z) -> unsigned int {  // the 8 x 8 x 8 cell of a point (outside the box: a border cell)
                 const unsigned int ux = (unsigned int)(int)fminf(fmaxf(__builtin_fmaf(x, inv[0], off[0]), 0.0f), 7.0f);
@@ -730,10 +753,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 const unsigned int uz = (unsigned int)(int)fminf(fmaxf(__builtin_fmaf(z, inv[2], off[2]), 0.0f), 7.0f);
                 return ux | (uy << 3) | (uz << 6);
             };
-            auto outside = [&](float x, float y, float z) -> bool {  // beyond the grid by more than a cell (or not a number)
-                const float a = __builtin_fmaf(x, inv[0], off[0]), b2 = __builtin_fmaf(y, inv[1], off[1]), c2 = __builtin_fmaf(z, inv[2], off[2]);
-                return !(fminf(fminf(a, b2), c2) >= -1.0f && fmaxf(fmaxf(a, b2), c2) <= 9.0f);
-            };
+
             unsigned int ccr[4], qcr[4];  // (cell << 16) | rank among the cell's points (candidates: arrival; queries: within the wave)
             // Lanes of one instruction that share a cell serialise on its LDS address (a cloud that is a point, a tight cluster beside
             // far outliers, queries outside the candidates' box that all clamp into one corner cell: 4096 same-address atomics cost a
@@ -770,27 +790,58 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 const unsigned int t = pt < cnt ? cell(cv[e].x, cv[e].y, cv[e].z) : 0u;
                 ccr[e] = (t << 16) | count_cells(pt < cnt, t, [&](unsigned int c, unsigned int n) { return atomicAdd(&ccnt[c], n); });
             }
-            if (sorted_q) {  // queries beyond the grid, counted over the block (one LDS atomic per wave)
-                int nout = 0;
+            int *qbb = reinterpret_cast<int *>(boxes + 64 * 2 + kHGroupsMax * 2 - 2);  // the query cloud's box as keys: the spare group slot (initialised with the groups')
+            if (sorted_q) {
+                int kl[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, kh[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int qp = 256 * wv + 64 * e + lane;
-                    nout += __builtin_popcountll(__ballot(qp < NQ && outside(qv[e].x, qv[e].y, qv[e].z)));
+                    if (qp < NQ) {
+                        const int k3[3] = {fkey(qv[e].x), fkey(qv[e].y), fkey(qv[e].z)};
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) { kl[d] = kl[d] < k3[d] ? kl[d] : k3[d]; kh[d] = kh[d] > k3[d] ? kh[d] : k3[d]; }
+                    }
                 }
-                if (lane == 0 && nout) atomicAdd(&ccnt[516], (unsigned int)nout);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    int a = row_mm_key<false>(kl[d]), b2 = row_mm_key<true>(kh[d]);
+                    a = imm<false>(a, dpp_keepi<0x142, 0xA>(a)); a = imm<false>(a, dpp_keepi<0x143, 0xC>(a));
+                    b2 = imm<true>(b2, dpp_keepi<0x142, 0xA>(b2)); b2 = imm<true>(b2, dpp_keepi<0x143, 0xC>(b2));
+                    if (lane == 63) { atomicMin(qbb + d, a); atomicMax(qbb + 4 + d, b2); }
+                }
             }
             FX3D_PROBE_MARK2(2);
             __syncthreads();
             FX3D_PROBE_MARK2(3);
-            sorted_q = sorted_q && 4u * ccnt[516] <= (unsigned int)NQ;
-            // exclusive scan of a count array in Morton order by one wave (eight cells per lane)
-            auto morton_scan = [&](unsigned int *a) {
-                const unsigned int l = (unsigned int)lane;
-                const unsigned int tb = ((l & 1u) << 1) | ((l & 8u) >> 1) | ((l & 2u) << 3) | ((l & 16u) << 1) | ((l & 4u) << 5) | ((l & 32u) << 3);
-                const unsigned int tk[8] = {0u, 1u, 8u, 9u, 64u, 65u, 72u, 73u};
+            float qinv[3] = {0.f, 0.f, 0.f}, qoff[3] = {0.f, 0.f, 0.f};
+            if (sorted_q) {
+                // ... clipped to the candidates' frame grown by its largest extent on every side: queries farther out than that (a stray
+                // far point would squeeze all others into one cell) fall into border cells
+                const float ext = fmaxf(fmaxf(cfh[0] - cfl[0], cfh[1] - cfl[1]), cfh[2] - cfl[2]);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const float lo = fmaxf(fkey_inv(qbb[d]), cfl[d] - ext), hi = fminf(fkey_inv(qbb[4 + d]), cfh[d] + ext);  // (fmaxf / fminf drop a NaN bound)
+                    qinv[d] = hi > lo && hi - lo < INFINITY ? 8.0f / (hi - lo) : 0.0f;  // (no extent, or not finite: one cell in this dimension)
+                    qoff[d] = qinv[d] != 0.0f ? -lo * qinv[d] : 0.0f;
+                }
+            }
+            auto qcell = [&](float x, float y, float z) -> unsigned int {
+                const unsigned int ux = (unsigned int)(int)fminf(fmaxf(__builtin_fmaf(x, qinv[0], qoff[0]), 0.0f), 7.0f);
+                const unsigned int uy = (unsigned int)(int)fminf(fmaxf(__builtin_fmaf(y, qinv[1], qoff[1]), 0.0f), 7.0f);
+                const unsigned int uz = (unsigned int)(int)fminf(fmaxf(__builtin_fmaf(z, qinv[2], qoff[2]), 0.0f), 7.0f);
+                return ux | (uy << 3) | (uz << 6);
+            };
+            // exclusive scan of a count array along the Hilbert curve by one wave (eight consecutive cells of the curve per lane)
+            auto curve_scan = [&](unsigned int *a) {
+                unsigned int tc[8];
+                {
+                    const uint4 h = *reinterpret_cast<const uint4 *>(kHilbertCell + 8 * lane);
+                    tc[0] = h.x & 0xffffu; tc[1] = h.x >> 16; tc[2] = h.y & 0xffffu; tc[3] = h.y >> 16;
+                    tc[4] = h.z & 0xffffu; tc[5] = h.z >> 16; tc[6] = h.w & 0xffffu; tc[7] = h.w >> 16;
+                }
                 unsigned int c8[8], tot = 0u;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { c8[k] = a[tb + tk[k]]; tot += c8[k]; }
+                for (int k = 0; k < 8; ++k) { c8[k] = a[tc[k]]; tot += c8[k]; }
                 unsigned int inc = tot;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
@@ -799,14 +850,14 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 }
                 unsigned int run = inc - tot;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { a[tb + tk[k]] = run; run += c8[k]; }
+                for (int k = 0; k < 8; ++k) { a[tc[k]] = run; run += c8[k]; }
             };
-            if (wv == 0) morton_scan(ccnt);  // the candidates' cells -> first image rows
+            if (wv == 0) curve_scan(ccnt);  // the candidates' cells -> first image rows
             if (sorted_q) {                  // the queries' cells, counted per wave
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int qp = 256 * wv + 64 * e + lane;
-                    const unsigned int t = qp < NQ ? cell(qv[e].x, qv[e].y, qv[e].z) : 0u;
+                    const unsigned int t = qp < NQ ? qcell(qv[e].x, qv[e].y, qv[e].z) : 0u;
                     qcr[e] = (t << 16) | count_cells(qp < NQ, t, [&](unsigned int c, unsigned int n) {
                                  const unsigned int sh = 16u * (c & 1u);
                                  const unsigned int old = atomicAdd(&qwh[wv * 256 + (c >> 1)], n << sh);
@@ -829,7 +880,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             sorted_c = true;
             if (sorted_q) {
                 if (wv == 1) {
-                    morton_scan(qtot);       // -> first rank of every cell
+                    curve_scan(qtot);       // -> first rank of every cell
                 } else if (wv >= 2 && wv < 6) {  // a pair of cells per thread: counts of the waves before, wave by wave
                     const int w2 = tid - 128;
                     unsigned int run = 0u;
@@ -2086,7 +2137,7 @@ constexpr size_t kHBoxBytes = 64 * 2 * sizeof(float4) + kHGroupsMax * 32;  // LD
 int prune_rows_per_block(const Plan &pl, int N, int M, int D) {
     const int maxc = N > M ? N : M;
     if (D != 3 || pl.variant != 3 || pl.nsplit != 1 || pl.tail != 0 || maxc > pl.chunk || maxc < 1024 || !opt(OPT_NN1_PRUNE)) return 0;
-    if ((pl.tpb > pl.tpb_y ? pl.tpb : pl.tpb_y) * 16 + 2 > kHGroupsMax) return 0;  // (the query groups' boxes: LDS for eight passes per block)
+    if ((pl.tpb > pl.tpb_y ? pl.tpb : pl.tpb_y) * 16 + 2 > kHGroupsMax - 1) return 0;  // (the query groups' boxes: LDS for eight passes per block)
     // one pass per block does not repay the sort (measured at B = 8 .. 16 x 4096: 36 against 30 us; two passes -- C2 -- 46 against 53)
     if ((pl.tpb < pl.tpb_y ? pl.tpb : pl.tpb_y) < 2) return 0;
     return kHChunkMax + (pl.tpb > pl.tpb_y ? pl.tpb : pl.tpb_y) * 512 + kHTail;

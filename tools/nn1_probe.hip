@@ -20,6 +20,11 @@ int main(int argc, char **argv) {
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
     for (auto &v : hx) v = rnd();
     for (auto &v : hy) v = rnd();
+    if (getenv("PFILE_X") && getenv("PFILE_Y")) {  // raw Float32 (3, N, B) / (3, M, B) files (e.g. bench.py's surface-sampled clouds)
+        FILE *fa = fopen(getenv("PFILE_X"), "rb"), *fb = fopen(getenv("PFILE_Y"), "rb");
+        if (!fa || !fb || fread(hx.data(), 4, hx.size(), fa) != hx.size() || fread(hy.data(), 4, hy.size(), fb) != hy.size()) { printf("cannot read the cloud files\n"); return 1; }
+        fclose(fa); fclose(fb);
+    }
     if (getenv("PNORMAL")) {  // standard normal coordinates (sum of 12 uniforms)
         for (auto &v : hx) { float a = 0; for (int i = 0; i < 12; ++i) a += rnd(); v = a - 6.0f; }
         for (auto &v : hy) { float a = 0; for (int i = 0; i < 12; ++i) a += rnd(); v = a - 6.0f; }
