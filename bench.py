@@ -190,6 +190,107 @@ def self_launch(n):
     return 0
 
 
+def single_gpu_rate(fx, x, y, steps=200, burn_ms=80.0):
+    """Pairs per second of the plain single-GPU step on the current device (burn-in, 20 warm-up, `steps` timed launches): the
+    denominator of scaling_efficiency, measured in the same run, on the same box, before a communicator exists."""
+    import numpy as np
+    s = fx.Stream.create()
+    loss_dev = fx.DeviceArray.empty((1,), np.float32)
+    with fx.stream(s):
+        for _ in range(int(burn_ms / 0.045) + 21):
+            fx.chamfer_distance(x, y, loss_out=loss_dev, sync=False)
+        s.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fx.chamfer_distance(x, y, loss_out=loss_dev, sync=False)
+        s.synchronize()
+        t1 = time.perf_counter()
+    B, N, M = int(x.shape[2]), int(x.shape[1]), int(y.shape[1])
+    return {"value": B * N * M * steps / (t1 - t0), "ms_per_step": (t1 - t0) * 1e3 / steps, "steps": steps}
+
+
+def run_inproc(args, why, value_1=None):
+    """`--launcher inproc`: ONE process, N devices (fx3d_comm_init_all = ncclCommInitAll + a worker thread, a stream and the sharded
+    evaluation's scratch per device; fx3d_chamfer_fwd_multi = kernel -> all-reduce(sum) of 2 Float64 over RCCL -> finalisation with the
+    global batch size on every device).  The same protocol as the process-per-GPU path: burn-in, W warm-up, EXACTLY K steps between two
+    device-wide synchronisations of ALL devices, one JSON line.  Returns the exit status."""
+    import numpy as np
+    import ctypes as C
+    import flux3d_jl_amd as fx
+    from flux3d_jl_amd import _lib
+    from flux3d_jl_amd.distributed import MultiDevice
+    n = args.gpus
+    try:
+        have = fx.device_count()
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] --launcher inproc: cannot count devices ({e})", file=sys.stderr)
+        return 3
+    if have < n:
+        print(f"[bench] --gpus {n} but only {have} device(s) visible: refusing to run (no line is printed)", file=sys.stderr)
+        return 3
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ids = [fx.device_identity(d) for d in range(n)]
+    if len(set(ids)) != n:
+        print(f"[bench] {n} devices but {len(set(ids))} distinct identities: {ids}", file=sys.stderr)
+        return 1
+    fx.set_device(0)
+    if value_1 is None:
+        x0 = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_A, DIM, NPTS, B_PER_GPU))
+        y0 = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_B, DIM, MPTS, B_PER_GPU))
+        value_1 = single_gpu_rate(fx, x0, y0)
+        del x0, y0
+    md = MultiDevice(devices=list(range(n)))
+    info = md.info()
+    if info["ndev"] != n:
+        print(f"[bench] the in-process communicators span {info['ndev']} devices, --gpus {n}", file=sys.stderr)
+        return 1
+    Bg = B_PER_GPU * n
+    xs = [md.shard(fx.synth.uniform_cloud(fx.synth.SEED_A, DIM, NPTS, B_PER_GPU, batch_offset=d * B_PER_GPU), d) for d in range(n)]
+    ys = [md.shard(fx.synth.uniform_cloud(fx.synth.SEED_B, DIM, MPTS, B_PER_GPU, batch_offset=d * B_PER_GPU), d) for d in range(n)]
+    loss = float(md.chamfer_distance(xs, ys, Bg))   # (blocks: the first evaluation, code objects loaded on every device)
+    for _ in range(int(args.burn_ms / 0.045) + 1 + args.warmup):
+        md.enqueue(xs, ys, Bg)
+    md.synchronize()
+    _lib.call("fx3d_profile_enable", 5)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        md.enqueue(xs, ys, Bg)
+    md.synchronize()
+    t1 = time.perf_counter()
+    _lib.call("fx3d_profile_enable", 0)
+    avg, mn, mx, cnt = C.c_double(0), C.c_double(0), C.c_double(0), C.c_int64(0)
+    _lib.call("fx3d_profile_kernel_stats", b"nn1", C.byref(avg), C.byref(mn), C.byref(mx), C.byref(cnt))
+    elapsed = t1 - t0
+    value = Bg * NPTS * MPTS * args.steps / elapsed
+    kern_s = avg.value * 1e-3 if cnt.value else None
+    hw_flops = 2.0 * 16 * 1024 * (2.0 * B_PER_GPU * NPTS * MPTS / 1024.0)
+    out = {
+        "metric": "chamfer_point_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": n, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"chamfer_distance fwd B={Bg} ({B_PER_GPU}/GPU) N=M={NPTS} D=3 Float32 U[0,1)^3 (BASELINE configs[1]; configs[4] shape at 8 GPUs)",
+                   "global_batch": Bg, "points": NPTS,
+                   "parallelism": f"batch-sharded x{n}, one all-reduce(sum) of 2 Float64 per evaluation over RCCL (fx3d_chamfer_fwd_multi)"},
+        "loss": loss,
+        "launcher": "inproc (one process, a worker thread per device, ncclCommInitAll)" + (f" -- FALLBACK: {why}" if why else ""),
+        "value_1gpu_same_run": value_1, "scaling_efficiency": value / (n * value_1["value"]),
+        "roofline": {"bound": "mfma", "achieved": (hw_flops / kern_s / 1e12) if kern_s else None, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": (hw_flops / kern_s / 1e12 / F16_MFMA_PEAK_TFLOPS) if kern_s else None, "traffic": None,
+                     "kernel_avg_ms": avg.value if cnt.value else None, "launches_timed": cnt.value,
+                     "note": "per device: the algorithmic f16 flops of one rank's launch / the kernel's average duration over all devices' "
+                             "profiled launches (the single-GPU line carries the counters)"},
+        "comm": {"nranks": n, "rccl_version": info["rccl_version"], "backend": "fx3d_comm_init_all (ncclCommInitAll) + fx3d_chamfer_fwd_multi",
+                 "devices": [{"index": d, "pci_bus_id": ids[d][0], "device_uuid": ids[d][1]} for d in range(n)], "distinct_devices": len(set(ids))},
+    }
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    print(json.dumps(out), flush=True)
+    md.close()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,10 +312,19 @@ def main():
     ap.add_argument("--allreduce-every", type=int, default=32, help="evaluations per collective in mode `deferred`")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the multi-GPU code path (RCCL communicator, collectives) even at world size 1")
+    ap.add_argument("--launcher", choices=["procs", "inproc"], default="procs",
+                    help="multi-GPU: `procs` = one process per GPU (torchrun, or this script spawning N ranks), the library's "
+                         "RCCL communicator bootstrapped over TCP; `inproc` = ONE process driving the N devices through "
+                         "fx3d_comm_init_all / fx3d_chamfer_fwd_multi (ncclCommInitAll, a worker thread per device) -- also the "
+                         "FALLBACK rank 0 takes by itself when the process-per-GPU bootstrap fails (the line then says so)")
     args = ap.parse_args()
 
     if args.gpus < 1:
         raise SystemExit(f"[bench] --gpus {args.gpus}: need >= 1")
+    if args.launcher == "inproc" and (args.gpus > 1 or args.force_dist):
+        if int(os.environ.get("RANK", "0")) != 0:   # under torchrun: rank 0 drives every device, the other ranks have nothing to do
+            return
+        raise SystemExit(run_inproc(args, None))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # started as a plain `python bench.py --gpus N` (no torchrun): this process becomes the launcher of N ranks
         raise SystemExit(self_launch(args.gpus))
@@ -253,6 +363,10 @@ def main():
     x = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_A, DIM, NPTS, B_PER_GPU, batch_offset=rank * B_PER_GPU))
     y = fx.gpu(fx.synth.uniform_cloud(fx.synth.SEED_B, DIM, MPTS, B_PER_GPU, batch_offset=rank * B_PER_GPU))
 
+    # the single-GPU rate of THIS run, on rank 0, before any communicator exists: scaling_efficiency = value_N / (N value_1)
+    value_1 = None
+    if use_dist and rank == 0:
+        value_1 = single_gpu_rate(fx, x, y)
     native_comm = None
     comm_info = None
     if use_dist and not use_torch:
@@ -260,7 +374,16 @@ def main():
         # rank that cannot join, or a communicator of the wrong size, ends the run (the driver must not record a
         # single-GPU number as an N-GPU one).
         rdv = default_rendezvous()
-        native_comm = NativeComm(rank, world, rendezvous=rdv)
+        try:
+            native_comm = NativeComm(rank, world, rendezvous=rdv)
+        except Exception as e:  # noqa: BLE001 -- the bootstrap is bounded (120 s) and collective: it fails on every rank or on none
+            if world == 1:
+                raise
+            if rank != 0:
+                print(f"[bench] rank {rank}: process-per-GPU bootstrap failed ({e}); rank 0 takes the in-process launcher", file=sys.stderr)
+                return
+            del x, y
+            raise SystemExit(run_inproc(args, f"process-per-GPU bootstrap failed on rank 0: {e}", value_1=value_1))
         comm_info = dict(native_comm.info(), backend="fx3d_comm (RCCL behind the C ABI): data + control plane, no torch",
                          bootstrap=rdv.split(":", 1)[0])
         if comm_info["nranks"] != args.gpus or comm_info["nranks"] != world:
@@ -563,6 +686,10 @@ def main():
         "cold_ms_per_step": res.get("cold_ms_per_step"), "burn_in_steps": res.get("burn_steps"),
         "stream_event_ms_per_step": res["event_ms"] / args.steps,
     }
+    out["launcher"] = "procs (one process per GPU)" if use_dist else "single process, one GPU"
+    if value_1 is not None:
+        out["value_1gpu_same_run"] = value_1
+        out["scaling_efficiency"] = value / (world * value_1["value"])
     if comm_info is not None:
         out["comm"] = comm_info
     if modes is not None:

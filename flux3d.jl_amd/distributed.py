@@ -327,6 +327,17 @@ class MultiDevice:
                   C.byref(loss), None)
         return np.float32(loss.value)
 
+    def enqueue(self, xs, ys, B_global, w1=1.0, w2=1.0):
+        """The same evaluation without the read-back: returns when every device's kernel, collective and finalisation are
+        enqueued (each device keeps its copy of the loss; :meth:`synchronize` waits for all of them)."""
+        k = next(i for i, a in enumerate(xs) if a is not None)
+        D, N, _ = xs[k].shape
+        M = ys[k].shape[1]
+        px = (C.c_void_p * self.ndev)(*[a.ptr if a is not None else None for a in xs])
+        py = (C.c_void_p * self.ndev)(*[a.ptr if a is not None else None for a in ys])
+        bl = (C.c_int32 * self.ndev)(*[a.shape[2] if a is not None else 0 for a in xs])
+        _lib.call("fx3d_chamfer_fwd_multi", self.handle, px, N, py, M, bl, D, int(B_global), float(w1), float(w2), None, None)
+
     def synchronize(self):
         _lib.call("fx3d_multi_sync", self.handle)
 

@@ -288,3 +288,11 @@ def test_bench_refuses_more_gpus_than_visible():
     assert r.returncode != 0 and "n_gpus" not in r.stdout and "WORLD_SIZE=1" in r.stderr, (r.returncode, r.stdout, r.stderr)
     r = subprocess.run([sys.executable, bench, "--gpus", "0"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "n_gpus" not in r.stdout
+    # (round 6) the in-process launcher -- one process driving N devices, also rank 0's fallback when the process-per-GPU bootstrap
+    # fails -- obeys the same rule: too few devices, no line; under a launcher only rank 0 acts, the other ranks leave quietly
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--launcher", "inproc", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout, (r.returncode, r.stdout, r.stderr)
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--launcher", "inproc", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, WORLD_SIZE="8", RANK="3", LOCAL_RANK="3"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "", (r.returncode, r.stdout, r.stderr)
