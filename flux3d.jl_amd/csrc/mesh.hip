@@ -892,7 +892,7 @@ __global__ __launch_bounds__(kThreads) void index_convert_kernel(const IT *__res
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
         long long v = (long long)src[i] - base;
         if (v < 0 && clamp_pad) v = 0;  // padding
-        else if (limit > 0 && (v < 0 || v >= limit)) { v = 0; ++nbad; }
+        else if (limit > 0 ? (v < 0 || v >= limit) : (v < -2147483648ll || v > 2147483647ll)) { v = 0; ++nbad; }  // (no limit: still an int32)
         dst[i] = (int32_t)v;
     }
     if (bad && nbad) atomicAdd(bad, nbad);
@@ -909,6 +909,8 @@ fx3d_status fx3d_index_convert(const void *src_dev, int32_t index_type, int32_t 
     FX3D_REQUIRE(count >= 0 && limit >= 0 && limit <= (1ll << 31), "fx3d_index_convert: bad count / limit");
     if (count == 0) return FX3D_OK;
     FX3D_REQUIRE(src_dev && dst_dev, "fx3d_index_convert: null pointer");
+    // a range check whose violations nobody can see would rewrite corrupt indices to vertex 0 in silence
+    FX3D_REQUIRE(limit == 0 || bad_dev, "fx3d_index_convert: limit > 0 needs bad_dev (a zeroed device counter of the violations)");
     hipStream_t st = as_stream(s);
     const dim3 g(grid_for(count)), b(kThreads);
     if (index_type == FX3D_IDX_I64)

@@ -351,8 +351,15 @@ end
 # with it on the kept indices: the same bits as the two-call form, never a rescaling of the unit gradient.
 Zygote.@adjoint function _chamfer_distance(A::HipArray{Float32,3}, B::HipArray{Float32,3}, w1::Float32, w2::Float32)
     loss, gA, gB, ix, iy = chamfer_value_and_grad(A, B, w1, w2; indices = true)
+    handed_out = Ref(false)
     function back(g)
-        Float32(g) == 1.0f0 && return (gA, gB, nothing, nothing)
+        if Float32(g) == 1.0f0
+            # the first pullback hands out the arrays of the forward; a second one (a jacobian, a caller that mutated the
+            # first result in place) gets copies of its own (ADVICE r5)
+            handed_out[] && return (copy(gA), copy(gB), nothing, nothing)
+            handed_out[] = true
+            return (gA, gB, nothing, nothing)
+        end
         D, N, Bn = size(A); _, M, _ = size(B)
         hA = HipArray{Float32}(undef, D, N, Bn); hB = HipArray{Float32}(undef, D, M, Bn)
         check(@ccall LIB.fx3d_chamfer_bwd(A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32, Bn::Int32, D::Int32,
@@ -480,9 +487,13 @@ index_upload(a::AbstractArray{<:Integer}; kw...) = index_upload(Array{Int64}(a);
 # the same conversion for an index array that already lives on the device (e.g. faces a HipArray pipeline produced)
 function index_convert(a::HipArray{R}; base::Integer = 1, clamp_pad::Bool = false, limit::Integer = 0) where {R<:Union{Int32,UInt32,Int64}}
     out = HipArray{Int32}(undef, size(a)...)
+    isempty(a) && return out
+    bad = fill!(HipArray{UInt32}(undef, 1), 0)   # out-of-range indices are counted, never silently rewritten (ADVICE r5)
     check(@ccall LIB.fx3d_index_convert(a.ptr::Ptr{Cvoid}, index_type(R)::Int32, Int32(base)::Int32, length(a)::Int64,
-                                        Int32(clamp_pad)::Int32, Int64(limit)::Int64, out.ptr::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
+                                        Int32(clamp_pad)::Int32, Int64(limit)::Int64, out.ptr::Ptr{Cvoid}, bad.ptr::Ptr{Cvoid},
                                         DEFAULT_STREAM::Stream)::Int32)
+    nbad = unhip(bad)[1]
+    nbad == 0 || throw(ArgumentError("index_convert: $nbad indices outside the Int32 / [0, $limit) range after subtracting $base"))
     return out
 end
 faces_padded_dev(m) = get!(() -> index_upload(get_faces_padded(m); clamp_pad = true, limit = m.V), mirror(m), :faces_padded)

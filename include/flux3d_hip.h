@@ -260,7 +260,8 @@ FX3D_API fx3d_status fx3d_edgeconv_graph(const float *x, int32_t N, int32_t B, i
  *   index_base   subtracted from every element (1 for the reference's arrays, 0 for 0-based ones)
  *   clamp_pad    1: elements below index_base (the 0 padding of faces_padded) become 0 instead of -1
  *   limit        > 0: converted values must lie in [0, limit) (pad entries excepted); violations are COUNTED in *bad_dev
- *                (optional caller-zeroed device counter) and stored as 0 -- a kernel never dereferences them
+ *                (a caller-zeroed device counter, REQUIRED with a limit) and stored as 0 -- a kernel never dereferences them.
+ *                limit == 0: only the int32 range is checked (UInt32 / Int64 values beyond it count, when bad_dev is given)
  * fx3d_index_upload: src is HOST memory (count elements); staged through ws (fx3d_index_upload_workspace_bytes, device)
  * and converted there; blocking like fx3d_memcpy_h2d.  fx3d_index_convert: src is device memory. */
 typedef enum { FX3D_IDX_I32 = 0, FX3D_IDX_U32 = 1, FX3D_IDX_I64 = 2 } fx3d_index_type;

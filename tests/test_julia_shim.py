@@ -229,8 +229,12 @@ def test_ctypes_twin_matches_the_header_types():
 OPENERS = {"function", "if", "for", "while", "let", "try", "begin", "struct", "module", "do", "quote", "macro"}
 
 
-def test_block_structure_balances():
-    txt = _strip_jl_comments(open(JL).read())
+RUNTESTS = os.path.join(ROOT, "flux3d.jl_amd", "julia", "runtests.jl")
+
+
+@pytest.mark.parametrize("path", [JL, RUNTESTS], ids=["Flux3DHip.jl", "runtests.jl"])
+def test_block_structure_balances(path):
+    txt = _strip_jl_comments(open(path).read())
     txt = re.sub(r'"(?:\\.|[^"\\])*"', '""', txt)  # string literals (may hold $(...) interpolation)
     stack, depth_sq = [], 0
     round_curly = []
@@ -265,8 +269,27 @@ def test_block_structure_balances():
     assert not stack, f"unclosed blocks: {stack}"
     assert not round_curly, f"unclosed brackets: {round_curly}"
     assert depth_sq == 0
-    tail = open(JL).read().rstrip().split("\n")[-1]
-    assert tail.startswith("end") and "module" in tail
+    if path == JL:
+        tail = open(JL).read().rstrip().split("\n")[-1]
+        assert tail.startswith("end") and "module" in tail
+
+
+def test_runtests_uses_only_what_the_shim_and_the_reference_define():
+    """julia/runtests.jl (the day-one validation a maintainer with Julia runs) is unexecuted here: what can be
+    checked is that every name it takes from the shim is exported or defined there, that it mirrors the reference's own test
+    cases (the files it cites exist in INTEGRATION.md's list), and that it never touches CUDA.jl / AMDGPU.jl."""
+    src = _strip_jl_comments(open(RUNTESTS).read())
+    shim = open(JL).read()
+    used = re.search(r"using \.Flux3DHip:(.*?)\n", src).group(1)
+    exported = set(re.findall(r"[\w!]+", re.search(r"^export (.*)$", shim, flags=re.M).group(1)))
+    for name in re.findall(r"[\w!]+", used):
+        assert name in exported, f"{name} is not exported by the shim"
+    for qualified in set(re.findall(r"Flux3DHip\.([\w!]+)", src)) - {"jl"}:   # ("Flux3DHip.jl": the file name in the include)
+        assert re.search(r"^(?:function |const )?" + re.escape(qualified) + r"\b", shim, flags=re.M), qualified
+    for banned in ("CUDA", "AMDGPU", "CuArray", "ROCArray"):
+        assert banned not in src, banned
+    assert "include(joinpath(@__DIR__, \"Flux3DHip.jl\"))" in src
+    assert "runtests.jl" in open(os.path.join(ROOT, "INTEGRATION.md")).read()
 
 
 # ---------------------------------------------------------------- interception checklist (INTEGRATION.md 2a)
