@@ -303,6 +303,20 @@ __device__ __forceinline__ float chamfer_loss_from_sums(double sa, double sb, in
 // double adds, no barrier, 32-bit index math (the block-wide version with two barrier rounds and 64-bit divisions took
 // 6.0 k cycles from ticket to end at C2; this one 2.3 k).  `slot`: this block's entry; rows of `stride` entries per
 // (direction, cloud), the first tiles_x / tiles_y of a row are valid.
+// MEMORY-ORDER NOTE (applies to this hand-off and to the fused split merge further down).  The protocol is
+//   producer:  agent-scope RELAXED atomic stores of the data (sc1: they go THROUGH the XCD's L2 to memory) -> s_waitcnt vmcnt(0) (the
+//              stores have left the CU and are acknowledged) -> relaxed agent-scope fetch_add on the counter
+//   consumer:  the last arriver's relaxed agent-scope atomic LOADS of the data (sc1: served from memory / the coherent fabric,
+//              never from a stale line of its own XCD's L2)
+// i.e. ordering by completion (waitcnt) + coherence by the access kind, not by release / acquire fences.  It is outside the HIP /
+// LLVM memory model on purpose: an agent-scope RELEASE on gfx942 / gfx950 is `buffer_wbl2 sc1` -- a write-back of the WHOLE L2 of
+// the XCD -- and was measured at 32 -> 94 us on the split runs (round 5); with the pruning scratch of round 6 dirty in L2 (21 MB per
+// launch) it would cost more.  The `asm volatile("s_waitcnt vmcnt(0)" ::: "memory")` is both the hardware wait and the compiler
+// barrier (no store may sink below it, no load of the counter may rise above it).  The assumption -- sc1 stores are visible to sc1
+// loads of every XCD once vmcnt has drained -- is MI355X_MICROARCH.md's "valid forms" table; the library is built for gfx950 only:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "chamfer.hip: the relaxed-atomic + s_waitcnt hand-off between blocks is validated on gfx950 only (see the note above)"
+#endif
 struct FinalizeArgs {
     unsigned long long *pp;
     unsigned int *ticket;

@@ -28,11 +28,11 @@ namespace {
 // path (exact selection among their own survivors, up to kMMedCap); the rest of the leftovers the full exact merge.
 // PRE (fx3d_knn_ws, the pre-pass has built the cloud's fp16 image): both waves of a pair run the filter (DUAL, 128 group minima per
 // query).  Round 4, in this instantiation: every lane reads its pieces of its query row and of the centre straight from memory (no
-// LDS staging, no barrier before the first chunk's); the image chunks come through registers (option knn_direct_lds: direct-to-LDS
-// loads); one instantiation of the four-tile loop per phase (phase A folds two tiles per v_min3 on the MFMA registers, phase B starts
+// LDS staging, no barrier before the first chunk's); the image chunks come through registers (the direct-to-LDS form of round 4 measured 1.2 us slower
+// and was removed with its switch in round 5); one instantiation of the four-tile loop per phase (phase A folds two tiles per v_min3 on the MFMA registers, phase B starts
 // the accumulators at n_c - thr and shifts the signs in with v_alignbit); tau by knn_tau_8of16; survivors counted in phase B; the
-// exact phase on 16-dimension COLUMN SLICES of the whole cloud (M <= 1024, D % 16 == 0, D <= 64; option knn_row_stages: the row
-// stages of rounds 2-3), pairs in registers across the slices.  C4': kernel 60.8 -> 50.8 us (profiles/r04_v5_*).
+// exact phase on 16-dimension COLUMN SLICES of the whole cloud (M <= 1024, D % 16 == 0, D <= 64; other shapes take the row
+// stages of rounds 2-3: chosen by shape, the switch is gone), pairs in registers across the slices.  C4': kernel 60.8 -> 50.8 us (profiles/r04_v5_*).
 constexpr int kMLCap = 40;        // rows of a lane's mask list (39 usable + the scratch head)
 constexpr int kMKeyCap = 64;      // survivors per query handled by the fast path (three sentinels follow them inside the stride of 68)
 constexpr int kMMedCap = 512;     // ... by the medium path: exact selection among the query's own survivors

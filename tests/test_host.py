@@ -243,6 +243,15 @@ def test_option_api_without_a_gpu(fx):
     listed = set(re.findall(r"\b([a-z0-9]+(?:_[a-z0-9]+)+)\b", block)) - {"process_wide"}
     assert set(_lib.options()) <= listed, sorted(set(_lib.options()) - listed)
     assert not {n for n in listed if n.startswith(("knn_", "nn1_", "edge", "lap_", "cdf_", "mesh_", "bwd_"))} - set(_lib.options())
+    #  no source comment may cite an option that no longer exists: `option <name>` / `options <name>` in csrc/
+    import glob
+    import re
+    known = set(_lib.options())
+    for path in glob.glob(os.path.join(ROOT, "flux3d.jl_amd", "csrc", "*")):
+        for m in re.finditer(r"\boption\s+([a-z0-9_]+)", open(path, errors="ignore").read()):
+            name = m.group(1)
+            if "_" in name and name.split("_")[0] in ("knn", "nn1", "edgeconv", "lap", "cdf", "mesh", "bwd"):
+                assert name in known, f"{os.path.basename(path)} cites option {name}, which the library does not have"
 
 
 def test_knn_scratch_plan_without_a_gpu(fx):
