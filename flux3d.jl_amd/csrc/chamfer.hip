@@ -834,7 +834,11 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 const float ext = fmaxf(fmaxf(cfh[0] - cfl[0], cfh[1] - cfl[1]), cfh[2] - cfl[2]);
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
-                    const float lo = fmaxf(fkey_inv(qbb[d]), cfl[d] - ext), hi = fminf(fkey_inv(qbb[4 + d]), cfh[d] + ext);  // (fmaxf / fminf drop a NaN bound)
+                    // (a query box more than four times the candidates' extent in this dimension -- a far outlier among the queries --: grown by a
+                    //  quarter only, so that the bulk, which then sits where the candidates are, is not squeezed into the middle cells)
+                    const float ql = fkey_inv(qbb[d]), qh = fkey_inv(qbb[4 + d]);
+                    const float grow = qh - ql > 4.0f * ext ? 0.25f * ext : ext;
+                    const float lo = fmaxf(ql, cfl[d] - grow), hi = fminf(qh, cfh[d] + grow);  // (fmaxf / fminf drop a NaN bound)
                     qinv[d] = hi > lo && hi - lo < INFINITY ? 8.0f / (hi - lo) : 0.0f;  // (no extent, or not finite: one cell in this dimension)
                     qoff[d] = qinv[d] != 0.0f ? -lo * qinv[d] : 0.0f;
                 }
