@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--target", default=os.path.join(ROOT, "tests", "golden", "teapot.obj"))
     ap.add_argument("--samples", type=int, default=5000)
     ap.add_argument("--graph", action="store_true", help="capture one iteration as a hipGraph and replay it")
+    ap.add_argument("--atomics", action="store_true", help="sampling adjoint with float atomics (sums in arrival order) instead of the ordered form")
+    ap.add_argument("--separate-step", action="store_true", help="the optimiser step as a launch of its own")
     args = ap.parse_args()
     src = fx.gpu(normalized(os.path.join(ROOT, "tests", "golden", "sphere.obj")))
     tgt = fx.gpu(normalized(args.target))
@@ -36,7 +38,7 @@ def main():
     opt = fx.Momentum(1.0, 0.9)        # examples/fit_mesh.jl:87-88
     t0 = time.perf_counter()
     if args.graph:
-        step = fx.FitStepGraph(x, src, tgt, opt, args.samples)  # runs iteration 1 eagerly, records iteration 2
+        step = fx.FitStepGraph(x, src, tgt, opt, args.samples, ordered=not args.atomics, step_in_launch=not args.separate_step)  # runs iteration 1 eagerly, records iteration 2
         for it in range(2, args.iters + 1):
             loss = step.step()
             if it % 50 == 1 or it == args.iters:

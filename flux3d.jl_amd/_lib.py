@@ -77,8 +77,12 @@ SIGNATURES = {
     "fx3d_chamfer_fwd_bwd_workspace_bytes": [c_i32, c_i32, c_i32, c_i32, C.POINTER(sz)],
     "fx3d_chamfer_fwd_bwd": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_i64, vp, C.POINTER(c_f32),
                              vp, vp, vp, vp, vp, sz, vp],
+    "fx3d_chamfer_sampled_bwd_workspace_bytes": [c_i32, c_i32, c_i32, C.POINTER(sz)],
     "fx3d_chamfer_sampled_bwd": [vp, c_i32, vp, c_i32, c_i32, vp, vp, c_f32, c_f32, c_f32, c_i64,
-                                 vp, c_i32, c_i32, vp, vp, vp, vp, vp, c_i32, c_i32, vp, vp, vp, vp, c_i32, vp],
+                                 vp, c_i32, c_i32, vp, vp, vp, vp, vp, c_i32, c_i32, vp, vp, vp, vp, c_i32,
+                                 vp, vp, vp, vp, vp, sz, vp],
+    "fx3d_chamfer_sampled_bwd_step": [vp, c_i32, vp, c_i32, vp, vp, c_f32, c_f32, c_f32, vp, c_i32, c_i32, vp, vp, vp, vp, c_i32,
+                                      vp, vp, c_f32, c_f32, vp, vp, vp, vp, vp, C.c_uint64, vp, sz, vp],
     "fx3d_knn": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, vp, vp],
     "fx3d_knn_workspace_bytes": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, C.POINTER(sz)],
     "fx3d_knn_ws": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, sz, vp],
@@ -100,7 +104,9 @@ SIGNATURES = {
     "fx3d_sample_points_cdf_pair": [vp, c_i32, vp, c_i32, vp, c_i32, vp, sz, vp, c_i32, vp, c_i32, vp, c_i32, vp, sz, c_f64, vp],
     "fx3d_sample_points_draw_pair": [vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_u64, vp, sz, vp, vp, vp, vp,
                                      vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_u64, vp, sz, vp, vp, vp, vp, vp, vp],
-    "fx3d_sample_points_bwd": [vp, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp, c_i32, vp],
+    "fx3d_build_vertex_faces": [vp, vp, c_i32, c_i32, c_i32, vp, vp],
+    "fx3d_sample_points_bwd_ordered": [c_i32, c_i32, C.POINTER(c_i32)],
+    "fx3d_sample_points_bwd": [vp, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp, c_i32, vp, vp, vp],
     "fx3d_voxel_workspace_bytes": [c_i32, C.POINTER(sz)],
     "fx3d_pointcloud_to_voxel": [vp, c_i32, c_i32, c_i32, vp, vp, sz, vp],
     "fx3d_lincomb": [c_i64, c_f32, vp, c_f32, vp, c_f32, vp, vp, vp],

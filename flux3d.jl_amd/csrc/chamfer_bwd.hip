@@ -12,7 +12,10 @@
 // entries: a sorting network in the owner's registers; longer ones: a wave sorts the list in place through a 4096-bit bitmap
 // and walks it with lane-parallel gathers and an ordered readlane chain), and the owner of a row subtracts its entries in
 // order.  D = 3: accumulators in registers, 12-byte row loads; other D: the row of g itself is the accumulator.
+#include <algorithm>
+
 #include "fx3d_common.h"
+#include "sample_gather.h"
 
 using namespace fx3d;
 
@@ -125,6 +128,12 @@ struct SampledSide {
     const float *r1, *r2;
     float *gverts;            // (3, Vmax, B), added to
     int Vmax, Fmax;
+    // ordered form (round 6, sample_gather.h): the finished rows go to `gs` with write-through stores, the side's blocks of a mesh
+    // arrive at a counter and the last one gathers them onto the vertices in the oracle's order -- no float atomics
+    const int32_t *vf_rowptr, *vf_ent;  // (Vmax + 1, B), (3 Fmax, B); nullptr: the float-atomic scatter
+    float *gs;                // (3, n, B) scratch
+    int accumulate;
+    sg::SgStep step;          // optional optimiser step on the finished rows (B = 1)
 };
 
 struct BgJob {
@@ -143,6 +152,12 @@ struct BgJob {
 __device__ __forceinline__ void bg_scatter_sample(const BgJob &J, int i, P3 a) {
     const SampledSide &S = J.smp;
     const size_t k = (size_t)J.b * J.R + i;
+    if (S.gs) {  // ordered form: publish the row (sc1: through this XCD's L2 -- the gathering block may sit on another XCD)
+        __hip_atomic_store(S.gs + 3 * k, a.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(S.gs + 3 * k + 1, a.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(S.gs + 3 * k + 2, a.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     const int32_t *fc = S.faces + ((size_t)J.b * S.Fmax + S.face_idx[k]) * 3;
     const int f3[3] = {fc[0], fc[1], fc[2]};
     const float uu = sqrtf(S.r1[k]), v = S.r2[k];
@@ -443,16 +458,100 @@ __global__ __launch_bounds__(kBgThreads, FX3D_BG_OCC) void chamfer_bwd_gather_ke
 // Adjoint of chamfer_distance(sample_points(m_x), sample_points(m_y)) w.r.t. the meshes' vertices in one launch: the gradient
 // w.r.t. the sampled points is formed exactly as in chamfer_bwd_gather_kernel (D = 3), then every finished row goes onto the
 // three vertices of its sampled face instead of being written out.  A side without a mesh gradient (gverts == nullptr) is skipped.
+//   * scatter form (no vertex -> face table): global float atomics, the sums in arrival order.
+//   * ORDERED form (round 6, sample_gather.h): the first 2 B nsplit blocks -- the ROW blocks -- publish their rows (write-through
+//     stores) and arrive at the (mesh, side)'s counter; behind them the launch carries GATHER blocks, sg_parts(V) per (mesh, side):
+//     a gather block buckets the draws by face (that needs face_idx only, so it runs while the rows are still being formed),
+//     waits for the counter, stages the rows and walks its share of the vertices in the oracle's order -- and applies the optimiser
+//     step to them if asked.  The wait cannot starve the row blocks: workgroups are dispatched in the order of their ids (per XCD,
+//     block L on XCD L % 8) and the gather blocks have the highest ids, so every row block holds a CU, or is done, by the time a
+//     gather block spins; the spin is bounded all the same (a gather block that gives up poisons its rows with NaN instead of
+//     hanging the device).  Counters: two spare words of the launch's ticket slot per (mesh, side) -- zero between launches,
+//     the last gather block of the (mesh, side) returns them to zero; chamfer.hip's memory-order note covers the hand-off.
+constexpr unsigned int kSgSpinMax = 200000u;  // polls of ~1 us: 0.2 s
+static_assert(kBgThreads == sg::kSgThreads, "row blocks and gather blocks share one launch");
 __global__ __launch_bounds__(kBgThreads, FX3D_BG_OCC) void chamfer_sampled_bwd_kernel(
-    const float *__restrict__ x, int N, const float *__restrict__ y, int M, const int32_t *__restrict__ idx_x,
-    const int32_t *__restrict__ idx_y, float ca, float cb, SampledSide sx, SampledSide sy, int nsplit) {
-    __shared__ BgLds L;
-    extern __shared__ __attribute__((aligned(16))) unsigned char bg_dyn[];  // the accumulators between rounds (n > 4096 samples)
-    BgJob J = bg_job(x, N, y, M, 3, idx_x, idx_y, ca, cb, nsplit);
-    J.smp = J.side ? sy : sx;
-    if (!J.smp.gverts) return;
-    J.part = reinterpret_cast<P3 *>(bg_dyn);
-    bg_rows<2>(L, J);
+    const float *__restrict__ x, int N, const float *__restrict__ y, int M, int B, const int32_t *__restrict__ idx_x,
+    const int32_t *__restrict__ idx_y, float ca, float cb, SampledSide sx, SampledSide sy, int nsplit, int parts_x, int parts_y,
+    unsigned int *ticket) {
+    // all LDS of this kernel is dynamic: a row block's tables (BgLds, ~38 KB) + its accumulators between rounds (n > 4096
+    // samples), or a gather block's tables and staged rows
+    extern __shared__ __attribute__((aligned(16))) unsigned char bg_dyn[];
+    const int nrow = 2 * B * nsplit;
+    auto counter = [&](int b, int side, int which) {
+        const unsigned int t = 2u * (2u * (unsigned int)b + (unsigned int)side) + (unsigned int)which;
+        return ticket + (t / 15u) * 16u + 1u + t % 15u;
+    };
+#ifdef FX3D_SG_PROBE
+#define SGF_STAMP(k) do { if (threadIdx.x == 0) sg::g_sg_probe[k] = wall_clock64(); } while (0)
+#else
+#define SGF_STAMP(k) do { } while (0)
+#endif
+    if ((int)blockIdx.x < nrow) {
+        if (blockIdx.x == 0) SGF_STAMP(10);
+        BgLds &L = *reinterpret_cast<BgLds *>(bg_dyn);
+        BgJob J = bg_job(x, N, y, M, 3, idx_x, idx_y, ca, cb, nsplit);
+        J.smp = J.side ? sy : sx;
+        if (!J.smp.gverts) return;
+        J.part = reinterpret_cast<P3 *>(bg_dyn + ((sizeof(BgLds) + 15) & ~(size_t)15));
+        bg_rows<2>(L, J);
+        if (!J.smp.gs) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's rows have left the CU
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(counter(J.b, J.side, 0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (blockIdx.x == 0) SGF_STAMP(11);
+        return;
+    }
+    // ---- gather block j of (mesh b, side) ----
+    int g = (int)blockIdx.x - nrow, side = 0;
+    if (sx.gverts) {
+        if (g >= B * parts_x) { g -= B * parts_x; side = 1; }
+    } else {
+        side = 1;
+    }
+    const SampledSide &S = side ? sy : sx;
+    const int parts = side ? parts_y : parts_x;
+    const size_t b = (size_t)(g / parts);
+    const int j = g % parts, n = side ? M : N;
+    const sg::SgMesh m{S.faces + b * S.Fmax * 3, S.face_idx + b * n, S.r1 + b * n, S.r2 + b * n, S.gs + b * n * 3,
+                       S.vf_rowptr + b * (S.Vmax + 1), S.vf_ent + b * S.Fmax * 3, S.gverts + b * S.Vmax * 3, S.Vmax, S.Fmax, n,
+                       S.accumulate};
+    int vb, ve;
+    sg::sg_part_range(S.Vmax, parts, j, vb, ve);
+    if ((int)blockIdx.x == nrow) SGF_STAMP(12);
+    sg::sg_tables(bg_dyn, m);
+    if ((int)blockIdx.x == nrow) SGF_STAMP(13);
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        unsigned int *rows = counter((int)b, side, 0);
+        unsigned int it = 0;
+        while (__hip_atomic_load(rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)nsplit && it < kSgSpinMax) {
+            __builtin_amdgcn_s_sleep(8);
+            ++it;
+        }
+        s_ok = it < kSgSpinMax;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ONE acquire after the match: this CU drops what it may hold of the rows' lines
+    }
+    __syncthreads();
+    if ((int)blockIdx.x == nrow) SGF_STAMP(14);
+    if (s_ok) {
+        sg::sg_finish<false>(bg_dyn, m, S.step, vb, ve);  // plain, coalesced 12-byte row loads
+    } else {  // (never seen: see the note above) loud, not hung
+        for (int v = vb + (int)threadIdx.x; v < ve; v += kBgThreads)
+            *reinterpret_cast<P3 *>(m.gverts + 3 * (size_t)v) = P3{NAN, NAN, NAN};
+    }
+    __syncthreads();
+    if ((int)blockIdx.x == nrow) SGF_STAMP(15);
+#ifdef FX3D_SG_PROBE
+    if (threadIdx.x == 0 && j < 16) sg::g_sg_probe[16 + j] = wall_clock64();
+#endif
+    if (threadIdx.x == 0) {
+        unsigned int *done = counter((int)b, side, 1);
+        if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)parts - 1u) {
+            __hip_atomic_store(counter((int)b, side, 0), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // blocks per (cloud, side): ONE round of blocks on the chip (a block is a chain of dependent phases: a second round doubles the
@@ -507,49 +606,132 @@ fx3d_status fx3d_chamfer_bwd(const float *x, int32_t N, const float *y, int32_t 
     return FX3D_OK;
 }
 
+#ifdef FX3D_SG_PROBE
+__attribute__((visibility("default"))) int fx3d_debug_sgf_probe(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sg::g_sg_probe), sizeof(unsigned long long) * 32);
+}
+#endif
 #ifdef FX3D_BG_PROBE
 __attribute__((visibility("default"))) int fx3d_debug_bg_probe(unsigned long long *host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bg_probe), sizeof(unsigned long long) * 1024 * 8);
 }
 #endif
 
+}  // extern "C"
+
+namespace {
+struct SampledArgs {
+    const int32_t *faces; int32_t Vmax, Fmax; const int32_t *face_idx; const float *r1, *r2; float *gverts;
+    const int32_t *vf_rowptr, *vf_ent;
+};
+size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+// the ordered form's scratch: the adjoint's rows of both sides (published by a mesh's blocks, gathered by the last of them)
+size_t sampled_ws_bytes(int N, int M, int B) {
+    return al256(sizeof(float) * 3 * (size_t)N * B) + al256(sizeof(float) * 3 * (size_t)M * B);
+}
+fx3d_status chamfer_sampled_bwd_impl(const char *fn, const float *x, int32_t N, const float *y, int32_t M, int32_t B, const int32_t *idx_x,
+                                     const int32_t *idx_y, float w1, float w2, float gout, int64_t B_global, const SampledArgs &ax,
+                                     const SampledArgs &ay, int32_t accumulate, const sg::SgStep &step_x, void *ws, size_t ws_bytes,
+                                     fx3d_stream_t s) {
+    fx3d_status rc = chamfer_check_shapes(fn, x, N, y, M, B, 3);
+    if (rc) return rc;
+    FX3D_REQUIRE(idx_x && idx_y, "%s: null index array", fn);
+    FX3D_REQUIRE(ax.gverts || ay.gverts, "%s: no gradient requested", fn);
+    FX3D_REQUIRE(!ax.gverts || (ax.faces && ax.face_idx && ax.r1 && ax.r2 && ax.Vmax > 0 && ax.Fmax > 0), "%s: incomplete mesh of x", fn);
+    FX3D_REQUIRE(!ay.gverts || (ay.faces && ay.face_idx && ay.r1 && ay.r2 && ay.Vmax > 0 && ay.Fmax > 0), "%s: incomplete mesh of y", fn);
+    FX3D_REQUIRE((ax.vf_rowptr == nullptr) == (ax.vf_ent == nullptr) && (ay.vf_rowptr == nullptr) == (ay.vf_ent == nullptr),
+                 "%s: vf_rowptr and vf_ent go together", fn);
+    FX3D_REQUIRE(B_global >= B, "%s: B_global < B", fn);
+    hipStream_t st = as_stream(s);
+    const float ca = gout * w1 * (float)(6.0 / (3.0 * N * (double)B_global));
+    const float cb = gout * w2 * (float)(6.0 / (3.0 * M * (double)B_global));
+    const int nsplit = bg_nsplit(B, N > M ? N : M);
+    FX3D_REQUIRE((long long)2 * B * nsplit < (1ll << 30), "%s: batch too large", fn);
+    // Ordered form (no float atomics, bit-identical to the oracle): every requested side comes with its vertex -> face table and
+    // fits the gather's LDS tables; the (mesh, side) counters fit the ticket slot's spare words.  Otherwise: the float-atomic scatter.
+    const bool ordered = (!ax.gverts || (ax.vf_rowptr && sg::sg_fits(ax.Fmax, N))) && (!ay.gverts || (ay.vf_rowptr && sg::sg_fits(ay.Fmax, M))) &&
+                         4 * (long long)B <= 255;  // (two counters per (mesh, side) in the ticket slot's spare words)
+    FX3D_REQUIRE(!step_x.vel || (ordered && ax.gverts && B == 1), "%s: the optimiser step needs the ordered form on a single mesh (vertex -> face table, "
+                 "at most %d samples)", fn, sg::kSgMaxN);
+    SampledSide sx{ax.faces, ax.face_idx, ax.r1, ax.r2, ax.gverts, ax.Vmax, ax.Fmax, nullptr, nullptr, nullptr, accumulate, sg::SgStep{}};
+    SampledSide sy{ay.faces, ay.face_idx, ay.r1, ay.r2, ay.gverts, ay.Vmax, ay.Fmax, nullptr, nullptr, nullptr, accumulate, sg::SgStep{}};
+    unsigned int *ticket = nullptr;
+    const int maxr = N > M ? N : M;
+    // dynamic LDS: the adjoint's tables + (sides beyond kBgChunk samples) the accumulators between rounds
+    size_t dyn = ((sizeof(BgLds) + 15) & ~(size_t)15) + (maxr > kBgChunk ? sizeof(P3) * (size_t)((maxr + nsplit - 1) / nsplit) : 0);
+    if (ordered) {
+        const size_t need = sampled_ws_bytes(N, M, B);
+        if (!ws || ws_bytes < need) {
+            set_error("%s: workspace too small (%zu < %zu bytes)", fn, ws ? ws_bytes : (size_t)0, need);
+            return FX3D_ERR_WORKSPACE;
+        }
+        char *w = static_cast<char *>(ws);
+        float *gsx = reinterpret_cast<float *>(w); w += al256(sizeof(float) * 3 * (size_t)N * B);
+        float *gsy = reinterpret_cast<float *>(w);
+        sx.vf_rowptr = ax.vf_rowptr; sx.vf_ent = ax.vf_ent; sx.gs = gsx; sx.step = step_x;
+        sy.vf_rowptr = ay.vf_rowptr; sy.vf_ent = ay.vf_ent; sy.gs = gsy;
+        ticket = ticket_slot(&rc, st);
+        if (!ticket) return rc;
+        if (ax.gverts) dyn = std::max(dyn, sg::sg_layout(ax.Fmax, N).total);
+        if (ay.gverts) dyn = std::max(dyn, sg::sg_layout(ay.Fmax, M).total);
+    } else if (!accumulate) {
+        if (ax.gverts) FX3D_HIP(hipMemsetAsync(ax.gverts, 0, sizeof(float) * 3 * (size_t)ax.Vmax * B, st));
+        if (ay.gverts) FX3D_HIP(hipMemsetAsync(ay.gverts, 0, sizeof(float) * 3 * (size_t)ay.Vmax * B, st));
+    }
+    {   // the adjoint's tables + accumulators / the gather's tables + staged rows: beyond the 64 KB a kernel gets without an opt-in
+        const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&chamfer_sampled_bwd_kernel), (int)sg::kSgMaxLds,
+                                                   "chamfer_sampled_bwd_kernel");
+        if (arc != FX3D_OK) return arc;
+    }
+    const int parts_x = ordered && ax.gverts ? sg::sg_parts(ax.Vmax) : 0, parts_y = ordered && ay.gverts ? sg::sg_parts(ay.Vmax) : 0;
+    ProfileScope prof("chamfer_sampled_bwd", st);
+    hipLaunchKernelGGL(chamfer_sampled_bwd_kernel, dim3(2 * B * nsplit + B * (parts_x + parts_y)), dim3(kBgThreads), dyn, st, x, N, y, M, B,
+                       idx_x, idx_y, ca, cb, sx, sy, nsplit, parts_x, parts_y, ticket);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+}  // namespace
+
+extern "C" {
+
+fx3d_status fx3d_chamfer_sampled_bwd_workspace_bytes(int32_t N, int32_t M, int32_t B, size_t *bytes) {
+    FX3D_REQUIRE(bytes, "fx3d_chamfer_sampled_bwd_workspace_bytes: null output");
+    FX3D_REQUIRE(N > 0 && M > 0 && B > 0, "fx3d_chamfer_sampled_bwd_workspace_bytes: bad sizes");
+    *bytes = sampled_ws_bytes(N, M, B);
+    return FX3D_OK;
+}
+
 fx3d_status fx3d_chamfer_sampled_bwd(const float *x, int32_t N, const float *y, int32_t M, int32_t B, const int32_t *idx_x,
                                      const int32_t *idx_y, float w1, float w2, float gout, int64_t B_global,
                                      const int32_t *faces_x, int32_t Vmax_x, int32_t Fmax_x, const int32_t *face_idx_x,
                                      const float *r1_x, const float *r2_x, float *gverts_x, const int32_t *faces_y,
                                      int32_t Vmax_y, int32_t Fmax_y, const int32_t *face_idx_y, const float *r1_y,
-                                     const float *r2_y, float *gverts_y, int32_t accumulate, fx3d_stream_t s) {
-    fx3d_status rc = chamfer_check_shapes("fx3d_chamfer_sampled_bwd", x, N, y, M, B, 3);
-    if (rc) return rc;
-    FX3D_REQUIRE(idx_x && idx_y, "fx3d_chamfer_sampled_bwd: null index array");
-    FX3D_REQUIRE(gverts_x || gverts_y, "fx3d_chamfer_sampled_bwd: no gradient requested");
-    FX3D_REQUIRE(!gverts_x || (faces_x && face_idx_x && r1_x && r2_x && Vmax_x > 0 && Fmax_x > 0), "fx3d_chamfer_sampled_bwd: incomplete mesh of x");
-    FX3D_REQUIRE(!gverts_y || (faces_y && face_idx_y && r1_y && r2_y && Vmax_y > 0 && Fmax_y > 0), "fx3d_chamfer_sampled_bwd: incomplete mesh of y");
-    FX3D_REQUIRE(B_global >= B, "fx3d_chamfer_sampled_bwd: B_global < B");
-    hipStream_t st = as_stream(s);
-    if (!accumulate) {
-        if (gverts_x) FX3D_HIP(hipMemsetAsync(gverts_x, 0, sizeof(float) * 3 * (size_t)Vmax_x * B, st));
-        if (gverts_y) FX3D_HIP(hipMemsetAsync(gverts_y, 0, sizeof(float) * 3 * (size_t)Vmax_y * B, st));
-    }
-    const float ca = gout * w1 * (float)(6.0 / (3.0 * N * (double)B_global));
-    const float cb = gout * w2 * (float)(6.0 / (3.0 * M * (double)B_global));
-    const int nsplit = bg_nsplit(B, N > M ? N : M);
-    FX3D_REQUIRE((long long)2 * B * nsplit < (1ll << 30), "fx3d_chamfer_sampled_bwd: batch too large");
-    const SampledSide sx{faces_x, face_idx_x, r1_x, r2_x, gverts_x, Vmax_x, Fmax_x}, sy{faces_y, face_idx_y, r1_y, r2_y, gverts_y, Vmax_y, Fmax_y};
-    // sides beyond kBgChunk samples (the reference's default is 5000): the accumulators between the rounds live in LDS
-    const int maxr = N > M ? N : M;
-    const size_t dyn = maxr > kBgChunk ? sizeof(P3) * (size_t)((maxr + nsplit - 1) / nsplit) : 0;
-    if (dyn > 0) {  // static BgLds (~38 KB) + up to 48 KB of accumulators: beyond the 64 KB a kernel gets without an opt-in
-        const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&chamfer_sampled_bwd_kernel), (int)(sizeof(P3) * kBgRows),
-                                                   "chamfer_sampled_bwd_kernel");
-        if (arc != FX3D_OK) return arc;
-    }
-    ProfileScope prof("chamfer_sampled_bwd", st);
-    hipLaunchKernelGGL(chamfer_sampled_bwd_kernel, dim3(2 * B * nsplit), dim3(kBgThreads), dyn, st, x, N, y, M, idx_x, idx_y, ca,
-                       cb, sx, sy, nsplit);
-    FX3D_LAUNCH_CHECK();
-    return FX3D_OK;
+                                     const float *r2_y, float *gverts_y, int32_t accumulate, const int32_t *vf_rowptr_x,
+                                     const int32_t *vf_ent_x, const int32_t *vf_rowptr_y, const int32_t *vf_ent_y, void *ws,
+                                     size_t ws_bytes, fx3d_stream_t s) {
+    const SampledArgs ax{faces_x, Vmax_x, Fmax_x, face_idx_x, r1_x, r2_x, gverts_x, vf_rowptr_x, vf_ent_x};
+    const SampledArgs ay{faces_y, Vmax_y, Fmax_y, face_idx_y, r1_y, r2_y, gverts_y, vf_rowptr_y, vf_ent_y};
+    return chamfer_sampled_bwd_impl("fx3d_chamfer_sampled_bwd", x, N, y, M, B, idx_x, idx_y, w1, w2, gout, B_global, ax, ay, accumulate,
+                                    sg::SgStep{}, ws, ws_bytes, s);
 }
+
+fx3d_status fx3d_chamfer_sampled_bwd_step(const float *x, int32_t N, const float *y, int32_t M, const int32_t *idx_x,
+                                          const int32_t *idx_y, float w1, float w2, float gout, const int32_t *faces_x,
+                                          int32_t V, int32_t F, const int32_t *face_idx_x, const float *r1_x, const float *r2_x,
+                                          float *gverts_x, int32_t accumulate, const int32_t *vf_rowptr_x, const int32_t *vf_ent_x,
+                                          float rho, float eta, float *vel, float *params, const float *base, float *out,
+                                          uint64_t *ctr, uint64_t inc, void *ws, size_t ws_bytes, fx3d_stream_t s) {
+    FX3D_REQUIRE(vel && params && base && out && gverts_x, "fx3d_chamfer_sampled_bwd_step: null pointer");
+    const SampledArgs ax{faces_x, V, F, face_idx_x, r1_x, r2_x, gverts_x, vf_rowptr_x, vf_ent_x};
+    const SampledArgs ay{};
+    const sg::SgStep st{rho, eta, vel, params, base, out, reinterpret_cast<unsigned long long *>(ctr), (unsigned long long)inc};
+    return chamfer_sampled_bwd_impl("fx3d_chamfer_sampled_bwd_step", x, N, y, M, 1, idx_x, idx_y, w1, w2, gout, 1, ax, ay, accumulate, st,
+                                    ws, ws_bytes, s);
+}
+
+}  // extern "C"
+
+extern "C" {
 
 // Value AND gradient in one ABI call (the shape of `gradient(() -> chamfer_distance(A, B), ...)`, benchmarks/metrics.jl:24-38,
 // examples/fit_mesh.jl:106-110): the forward with indices and the adjoint are queued back to back on the stream, the

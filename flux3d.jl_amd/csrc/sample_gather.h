@@ -1,0 +1,388 @@
+// Ordered (atomic-free) adjoint of the barycentric sampling  samples = w1 v[f1] + w2 v[f2] + w3 v[f3]
+// (src/transforms/mesh_func.jl:60-73; the reference's CPU adjoint is a gather + weighted sum, Zygote accumulates the three
+// getindex pullbacks): the gradient w.r.t. a vertex v is
+//     g[v] = base[v] + sum over the incident (face f, corner t) of v, ascending (f, t), of  inner(f, t)
+//     inner(f, t) = 0 + sum over the samples k drawn on f, k ASCENDING, of  w_t(k) * gs[k]              (Float32, unfused)
+// -- the order in which oracle/flux3d_oracle.c: fx3d_oracle_sample_points_bwd adds, so the result is the oracle's bit for bit and
+// the same from run to run (round 5 scattered the 9 products of every sample with global float atomics: arrival order).
+// One 1024-thread block per mesh, everything between the first and the last global access in LDS: the draws are bucketed by
+// face with a counting sort (integer atomics, a block scan, placement from the back of every list), every list is put in
+// ascending order in place (up to eight draws: insertion sort by the face's thread; longer: a wave through a bitmap over the
+// sample ids), then (gs, sqrt(r1), r2) of every draw is STAGED in list order -- one round trip to memory for the whole mesh,
+// every load of it in flight at once -- and a thread per vertex walks its (face, corner) entries (fx3d_build_vertex_faces: a CSR
+// over the vertices, entries face * 4 + corner ascending) over contiguous staged rows.  (A first version gathered gs / r1 / r2
+// from memory per (entry, draw): ~22 dependent round trips per thread, 70 us for one mesh of 5000 draws; staged: ~9.)
+// The vertex's thread may go straight on to the optimiser step (SgStep: Flux.Optimise.Momentum + offset,
+// examples/fit_mesh.jl:87-88,108-110) -- it owns the finished gradient row.  What fits: 4 F + 22.25 n bytes of LDS <= kSgMaxLds
+// (n <= ~6200 draws at the 5120 faces of the tutorial's sphere; the reference's default is 5000) -- other meshes keep the scatter.
+// Included by sampler.hip (fx3d_sample_points_bwd) and chamfer_bwd.hip (fx3d_chamfer_sampled_bwd: the last block of a mesh's
+// chamfer adjoint runs this on the rows its siblings published).
+#pragma once
+#include "fx3d_common.h"
+
+namespace fx3d {
+namespace sg {
+
+#ifdef FX3D_SG_PROBE   // phase stamps of block 0 (wall clock, 100 MHz) for tools/sampled_bwd_time.py; never in the shipped build
+__device__ unsigned long long g_sg_probe[32];
+#define SG_STAMP(n) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_sg_probe[n] = wall_clock64(); } while (0)
+#else
+#define SG_STAMP(n) do { } while (0)
+#endif
+
+constexpr int kSgThreads = 1024;
+constexpr int kSgWaves = kSgThreads / 64;
+constexpr int kSgSmall = 8;         // lists up to this length are ordered in the consumer's registers
+constexpr int kSgMaxN = 16384;      // samples per mesh: ids and list offsets are 16-bit in LDS
+constexpr int kSgMaxF = 32768;      // faces per mesh (per-face counters: 16 bits each)
+constexpr size_t kSgMaxLds = 156 * 1024;  // of the CU's 160 KB (the kernels that run this keep their static LDS under 4 KB)
+constexpr int kSgRow = 5;           // staged floats per draw: gs (3), sqrt(r1), r2
+
+struct SgMesh {                 // ONE mesh of the batch (pointers already offset to it)
+    const int32_t *faces;       // (3, Fmax) mesh-local, 0-based -- unused by the gather itself (the table names the corners)
+    const int32_t *face_idx;    // (n) the draws' faces
+    const float *r1, *r2;       // (n) the draws' uniforms
+    const float *gs;            // (3, n) gradient w.r.t. the samples
+    const int32_t *vf_rowptr;   // (V + 1) vertex -> first entry
+    const int32_t *vf_ent;      // (rowptr[V]) face * 4 + corner, ascending within a vertex
+    float *gverts;              // (3, V) result; with `accumulate` also the base
+    int V, F, n, accumulate;
+};
+struct SgStep {                 // optional optimiser step by the vertex's thread (vel == nullptr: none); single-mesh batches only
+    float rho, eta;
+    float *vel, *x;             // (3, V) Momentum's velocity and the parameters (the offsets)
+    const float *base;          // (3, V) the source mesh's vertices
+    float *out;                 // (3, V) base + x: the next iteration's mesh
+    unsigned long long *ctr;    // advanced by inc (the sampling seeds' device counter); may be nullptr
+    unsigned long long inc;
+};
+
+struct SgLayout {
+    size_t cnt, start, list, big, wsum, staged, total;
+    int bmwords;
+};
+__host__ __device__ inline SgLayout sg_layout(int F, int n) {
+    SgLayout L{};
+    size_t o = 0;
+    L.cnt = o;    o += sizeof(unsigned int) * (size_t)((F + 2) / 2);             // two 16-bit counters per word
+    L.start = o;  o += (sizeof(unsigned short) * (size_t)(F + 2) + 3) & ~(size_t)3;
+    L.list = o;   o += (sizeof(unsigned short) * (size_t)(n + 1) + 3) & ~(size_t)3;
+    L.big = o;    o += (sizeof(unsigned short) * (size_t)(n / (kSgSmall + 1) + 2) + 3) & ~(size_t)3;
+    L.wsum = o;   o += sizeof(unsigned int) * (kSgWaves + 4);
+    L.bmwords = (n + 31) / 32;
+    L.staged = o;  // kSgRow floats per draw, in list order; the waves' bitmaps (long lists) live here before the staging
+    const size_t st = sizeof(float) * kSgRow * (size_t)n, bm = sizeof(unsigned int) * (size_t)kSgWaves * (size_t)L.bmwords;
+    o += st > bm ? st : bm;
+    L.total = (o + 15) & ~(size_t)15;
+    return L;
+}
+// meshes the ordered form takes (the others keep the float-atomic scatter)
+inline bool sg_fits(int Fmax, int n) {
+    return n > 0 && n <= kSgMaxN && Fmax > 0 && Fmax <= kSgMaxF && sg_layout(Fmax, n).total <= kSgMaxLds;
+}
+
+__device__ __forceinline__ void sg_ce(unsigned int &a, unsigned int &b) {
+    const unsigned int lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo; b = hi;
+}
+__device__ __forceinline__ void sg_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned int sg_dpp_zero(unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xF, false);
+}
+__device__ __forceinline__ unsigned int sg_wave_scan_incl(unsigned int v) {
+    v += sg_dpp_zero<0x111, 0xF>(v);
+    v += sg_dpp_zero<0x112, 0xF>(v);
+    v += sg_dpp_zero<0x114, 0xF>(v);
+    v += sg_dpp_zero<0x118, 0xF>(v);
+    v += sg_dpp_zero<0x142, 0xA>(v);
+    v += sg_dpp_zero<0x143, 0xC>(v);
+    return v;
+}
+// SC1: read gs with agent-scope loads (rows written by OTHER blocks of this launch without an acquire on this side).  The fused
+// adjoint does NOT use it: 15 000 four-byte sc1 loads per gather block each went to memory on their own (the staging took ~15 us);
+// its gather blocks take ONE agent-scope acquire after the rows' counter is full and then read plain 12-byte rows (the guide's
+// "write-through payload, relaxed poll, one acquire, plain loads" hand-off).
+template <bool SC1>
+__device__ __forceinline__ float sg_ld(const float *p) {
+    if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+
+// All kSgThreads threads of a block call these together (they synchronise).  `lds`: sg_layout(m.F, m.n).total bytes.
+// sg_tables: phases (0) - (4), the draws bucketed by face and every list in ascending order -- reads face_idx only.
+__device__ __forceinline__ void sg_tables(unsigned char *lds, const SgMesh &m) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const SgLayout L = sg_layout(m.F, m.n);
+    unsigned int *cnt2 = reinterpret_cast<unsigned int *>(lds + L.cnt);
+    unsigned short *start = reinterpret_cast<unsigned short *>(lds + L.start);
+    unsigned short *list = reinterpret_cast<unsigned short *>(lds + L.list);
+    unsigned short *big = reinterpret_cast<unsigned short *>(lds + L.big);
+    unsigned int *bitmap = reinterpret_cast<unsigned int *>(lds + L.staged);  // (dead before the staging)
+    unsigned int *wsum = reinterpret_cast<unsigned int *>(lds + L.wsum);  // [kSgWaves] + nbig at [kSgWaves]
+    const int F = m.F, n = m.n;
+    const int nw = (F + 2) / 2;
+    SG_STAMP(0);
+    for (int i = tid; i < nw; i += kSgThreads) cnt2[i] = 0u;
+    if (tid == 0) wsum[kSgWaves] = 0u;
+    __syncthreads();
+    // (1) draws per face
+    for (int k = tid; k < n; k += kSgThreads) {
+        const unsigned int f = (unsigned int)m.face_idx[k];
+        if (f < (unsigned int)F) atomicAdd(&cnt2[f >> 1], (f & 1u) ? 0x10000u : 1u);
+    }
+    __syncthreads();
+    SG_STAMP(1);
+    // (2) exclusive scan over the faces: thread t takes the faces [t fpt, (t + 1) fpt), fpt even
+    const int fpt = 2 * ((F + 2 + 2 * kSgThreads - 1) / (2 * kSgThreads));  // (fpt / 2) * kSgThreads words >= nw
+    unsigned int s = 0u;
+    for (int q = 0; q < fpt / 2; ++q) {
+        const int w = (fpt / 2) * tid + q;
+        if (w < nw) { const unsigned int cw = cnt2[w]; s += (cw & 0xFFFFu) + (cw >> 16); }
+    }
+    const unsigned int inc = sg_wave_scan_incl(s);
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    {
+        unsigned int ex = inc - s;
+        for (int w = 0; w < kSgWaves; ++w) ex += w < wv ? wsum[w] : 0u;
+        for (int q = 0; q < fpt / 2; ++q) {
+            const int w = (fpt / 2) * tid + q;
+            if (w < nw) {
+                const unsigned int cw = cnt2[w];
+                const int f0 = 2 * w;
+                start[f0] = (unsigned short)ex;
+                ex += cw & 0xFFFFu;
+                if (f0 + 1 <= F) start[f0 + 1] = (unsigned short)ex;
+                ex += cw >> 16;
+            }
+        }
+        // (faces are 0 .. F - 1; entry F closes the last list: the word of face F holds a zero count, so it was written above)
+    }
+    __syncthreads();
+    SG_STAMP(2);
+    // (3) placement from the back of every list (arrival order; put right below), long lists registered
+    for (int k = tid; k < n; k += kSgThreads) {
+        const unsigned int f = (unsigned int)m.face_idx[k];
+        if (f < (unsigned int)F) {
+            const unsigned int sh = (f & 1u) * 16u;
+            const unsigned int old = atomicSub(&cnt2[f >> 1], 1u << sh);
+            list[(unsigned int)start[f] + ((old >> sh) & 0xFFFFu) - 1u] = (unsigned short)k;
+        }
+    }
+    for (int f = tid; f < F; f += kSgThreads)
+        if ((int)start[f + 1] - (int)start[f] > kSgSmall) big[atomicAdd(&wsum[kSgWaves], 1u)] = (unsigned short)f;
+    __syncthreads();
+    SG_STAMP(3);
+    // (4) every list in ascending order, in place: short ones by their face's thread, long ones by a wave through a bitmap over
+    //     the sample ids (lane l owns a contiguous run of words)
+    for (int f = tid; f < F; f += kSgThreads) {  // (in registers: an insertion sort in LDS was a chain of dependent LDS round trips, 6 us)
+        const int s0 = start[f], c = (int)start[f + 1] - s0;
+        if (c < 2 || c > kSgSmall) continue;
+        unsigned int id[kSgSmall];
+#pragma unroll
+        for (int k = 0; k < kSgSmall; ++k) id[k] = k < c ? (unsigned int)list[s0 + k] : 0xFFFFu;
+        if (c > 4) {
+            sg_ce(id[0], id[1]); sg_ce(id[2], id[3]); sg_ce(id[4], id[5]); sg_ce(id[6], id[7]);
+            sg_ce(id[0], id[2]); sg_ce(id[1], id[3]); sg_ce(id[4], id[6]); sg_ce(id[5], id[7]);
+            sg_ce(id[1], id[2]); sg_ce(id[5], id[6]); sg_ce(id[0], id[4]); sg_ce(id[3], id[7]);
+            sg_ce(id[1], id[5]); sg_ce(id[2], id[6]);
+            sg_ce(id[1], id[4]); sg_ce(id[3], id[6]);
+            sg_ce(id[2], id[4]); sg_ce(id[3], id[5]);
+            sg_ce(id[3], id[4]);
+        } else if (c > 2) {
+            sg_ce(id[0], id[1]); sg_ce(id[2], id[3]); sg_ce(id[0], id[2]); sg_ce(id[1], id[3]); sg_ce(id[1], id[2]);
+        } else {
+            sg_ce(id[0], id[1]);
+        }
+#pragma unroll
+        for (int k = 0; k < kSgSmall; ++k)
+            if (k < c) list[s0 + k] = (unsigned short)id[k];
+    }
+    {
+        const unsigned int nb = (unsigned int)__builtin_amdgcn_readfirstlane((int)wsum[kSgWaves]);
+        unsigned int *bm = bitmap + (size_t)wv * L.bmwords;
+        const int wpl = (L.bmwords + 63) / 64;
+        for (unsigned int b = (unsigned int)wv; b < nb; b += kSgWaves) {
+            const int f = __builtin_amdgcn_readfirstlane((int)big[b]);
+            const int s0 = __builtin_amdgcn_readfirstlane((int)start[f]);
+            const int c = __builtin_amdgcn_readfirstlane((int)start[f + 1]) - s0;
+            for (int w = lane; w < L.bmwords; w += 64) bm[w] = 0u;
+            sg_wave_lds_sync();
+            for (int e = lane; e < c; e += 64) {
+                const unsigned int j = list[s0 + e];
+                atomicOr(&bm[j >> 5], 1u << (j & 31u));
+            }
+            sg_wave_lds_sync();
+            unsigned int p = 0u;
+            for (int q = 0; q < wpl; ++q) {
+                const int w = lane * wpl + q;
+                if (w < L.bmwords) p += __popc(bm[w]);
+            }
+            const unsigned int pin = sg_wave_scan_incl(p);
+            int pos = s0 + (int)(pin - p);
+            for (int q = 0; q < wpl; ++q) {
+                const int w = lane * wpl + q;
+                unsigned int bits = w < L.bmwords ? bm[w] : 0u;
+                while (bits) { list[pos++] = (unsigned short)(32 * w + __ffs(bits) - 1); bits &= bits - 1u; }
+            }
+            sg_wave_lds_sync();
+        }
+    }
+    __syncthreads();
+    SG_STAMP(4);
+}
+
+// sg_finish: phases (5) - (6) for the vertices [vb, ve) of the mesh -- a mesh's vertices may be shared out over several blocks
+// (each with tables of its own: building them is ~7 us of one CU's time, walking 2500 vertices 12 us).
+template <bool SC1>
+__device__ __forceinline__ void sg_finish(unsigned char *lds, const SgMesh &m, const SgStep &st, int vb, int ve) {
+    const int tid = threadIdx.x;
+    const SgLayout L = sg_layout(m.F, m.n);
+    const unsigned short *start = reinterpret_cast<const unsigned short *>(lds + L.start);
+    const unsigned short *list = reinterpret_cast<const unsigned short *>(lds + L.list);
+    float *staged = reinterpret_cast<float *>(lds + L.staged);
+    const int n = m.n;
+    // (5) stage (gs, sqrt(r1), r2) of every draw, row k = draw k: coalesced loads (consecutive lanes, consecutive draws), the only trip
+    //     to memory for the draws' data, every load in flight at once.  (Staged in LIST order the loads were 25 k scattered dwords,
+    //     one cache line each: 6 us; the walk below pays one more LDS read per draw for the indirection instead.)
+    {
+        constexpr int kU = 4;
+        for (int k0 = tid; k0 < n; k0 += kU * kSgThreads) {
+            float gx[kU], gy[kU], gz[kU], a1[kU], a2[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int k = k0 + u * kSgThreads;
+                const size_t kk = (size_t)(k < n ? k : k0);
+                if constexpr (SC1) {
+                    gx[u] = sg_ld<SC1>(m.gs + 3 * kk); gy[u] = sg_ld<SC1>(m.gs + 3 * kk + 1); gz[u] = sg_ld<SC1>(m.gs + 3 * kk + 2);
+                } else {
+                    const P3 t3 = *reinterpret_cast<const P3 *>(m.gs + 3 * kk);
+                    gx[u] = t3.x; gy[u] = t3.y; gz[u] = t3.z;
+                }
+                a1[u] = m.r1[kk]; a2[u] = m.r2[kk];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int k = k0 + u * kSgThreads;
+                if (k < n) {
+                    float *row = staged + (size_t)kSgRow * k;
+                    row[0] = gx[u]; row[1] = gy[u]; row[2] = gz[u]; row[3] = sqrtf(a1[u]); row[4] = a2[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    SG_STAMP(5);
+    // (6) a thread per vertex: its (face, corner) entries in order, each over the face's staged rows (ascending draws); then the
+    //     row -- and, if asked, the optimiser step on it.  kV vertices of a thread at a time, so that their table reads are two
+    //     round trips (row pointers, then the first entries) instead of two per vertex.
+    constexpr int kV = 3, kE = 8;
+    for (int v0 = vb + tid; v0 < ve; v0 += kV * kSgThreads) {
+        int e0[kV], e1[kV];
+        P3 acc[kV];
+#pragma unroll
+        for (int u = 0; u < kV; ++u) {
+            const int v = v0 + u * kSgThreads;
+            const bool ok = v < ve;
+            e0[u] = ok ? m.vf_rowptr[v] : 0;
+            e1[u] = ok ? m.vf_rowptr[v + 1] : 0;
+            acc[u] = P3{0.0f, 0.0f, 0.0f};
+            if (ok && m.accumulate) acc[u] = *reinterpret_cast<const P3 *>(m.gverts + 3 * (size_t)v);
+        }
+#ifdef FX3D_SG_PROBE
+        if (v0 == vb + tid) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SG_STAMP(7); }
+#endif
+        unsigned int ent[kV][kE];
+#pragma unroll
+        for (int u = 0; u < kV; ++u)
+#pragma unroll
+            for (int q = 0; q < kE; ++q) ent[u][q] = e0[u] + q < e1[u] ? (unsigned int)m.vf_ent[e0[u] + q] : 0u;
+#ifdef FX3D_SG_PROBE
+        if (v0 == vb + tid) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SG_STAMP(8); }
+#endif
+        // kE entries of a vertex are walked TOGETHER, draw i of each in one step: the LDS reads of a step (list slot -> staged row)
+        // are two dependent round trips whatever the number of entries, and a wave runs as many steps as its longest list -- entry
+        // by entry that chain was paid ~5 times per entry (10 us for 15 entries per thread)
+        auto walk = [&](const unsigned int (&en)[kE], int cnt, P3 &a) {
+            int s0[kE], c[kE], t[kE], cmax = 0;
+            float ax[kE], ay[kE], az[kE];
+#pragma unroll
+            for (int q = 0; q < kE; ++q) {
+                const int f = (int)(en[q] >> 2);
+                t[q] = (int)(en[q] & 3u);
+                s0[q] = start[f];
+                c[q] = q < cnt ? (int)start[f + 1] - s0[q] : 0;
+                cmax = c[q] > cmax ? c[q] : cmax;
+                ax[q] = 0.0f; ay[q] = 0.0f; az[q] = 0.0f;
+            }
+            for (int i = 0; i < cmax; ++i) {
+                unsigned int k[kE];
+#pragma unroll
+                for (int q = 0; q < kE; ++q) k[q] = list[i < c[q] ? s0[q] + i : 0];
+#pragma unroll
+                for (int q = 0; q < kE; ++q) {
+                    const float *row = staged + (size_t)kSgRow * k[q];
+                    const float uu = row[3], vv = row[4];
+                    const float w = t[q] == 0 ? 1.0f - uu : (t[q] == 1 ? uu * (1.0f - vv) : uu * vv);
+                    const float nx = ax[q] + w * row[0], ny = ay[q] + w * row[1], nz = az[q] + w * row[2];
+                    const bool on = i < c[q];  // (a select, not a product with 0: a non-finite row of another draw must not leak in)
+                    ax[q] = on ? nx : ax[q]; ay[q] = on ? ny : ay[q]; az[q] = on ? nz : az[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < kE; ++q)
+                if (q < cnt) { a.x = a.x + ax[q]; a.y = a.y + ay[q]; a.z = a.z + az[q]; }
+        };
+#pragma unroll
+        for (int u = 0; u < kV; ++u) {
+            const int v = v0 + u * kSgThreads;
+            if (v >= ve) continue;
+            const int deg = e1[u] - e0[u];
+            walk(ent[u], deg < kE ? deg : kE, acc[u]);
+            for (int eb = e0[u] + kE; eb < e1[u]; eb += kE) {  // (vertices of more than eight corners)
+                unsigned int more[kE];
+#pragma unroll
+                for (int q = 0; q < kE; ++q) more[q] = eb + q < e1[u] ? (unsigned int)m.vf_ent[eb + q] : 0u;
+                walk(more, e1[u] - eb < kE ? e1[u] - eb : kE, acc[u]);
+            }
+#ifdef FX3D_SG_PROBE
+            if (v0 == vb + tid && u == kV - 1) SG_STAMP(9);
+#endif
+            const P3 a = acc[u];
+            *reinterpret_cast<P3 *>(m.gverts + 3 * (size_t)v) = a;
+            if (st.vel) {  // fx3d_momentum_step_offset's arithmetic (mesh.hip: momentum_offset_kernel)
+                const float g3[3] = {a.x, a.y, a.z};
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const size_t i = 3 * (size_t)v + d;
+                    const float vn = (st.rho * st.vel[i]) + (-st.eta * g3[d]);
+                    st.vel[i] = vn;
+                    const float xn = (1.0f * st.x[i]) + (1.0f * vn);
+                    st.x[i] = xn;
+                    st.out[i] = (1.0f * st.base[i]) + (1.0f * xn);
+                }
+            }
+        }
+    }
+    if (st.vel && st.ctr && tid == 0 && vb == 0) *st.ctr += st.inc;
+    SG_STAMP(6);
+}
+
+// blocks that share a mesh's vertices: ~160 vertices each, at most 16 (every block rebuilds the tables)
+__host__ __device__ inline int sg_parts(int V) {
+    const int g = (V + 159) / 160;
+    return g < 1 ? 1 : (g > 16 ? 16 : g);
+}
+__host__ __device__ inline void sg_part_range(int V, int parts, int j, int &vb, int &ve) {
+    const int per = (V + parts - 1) / parts;
+    vb = j * per < V ? j * per : V;
+    ve = vb + per < V ? vb + per : V;
+}
+
+}  // namespace sg
+}  // namespace fx3d

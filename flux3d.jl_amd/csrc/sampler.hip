@@ -13,6 +13,7 @@
 #include <cmath>
 
 #include "fx3d_common.h"
+#include "sample_gather.h"
 
 using namespace fx3d;
 
@@ -507,6 +508,22 @@ __global__ __launch_bounds__(kThreads) void sample_bwd_kernel(
     }
 }
 
+// the ordered form (sample_gather.h): sg_parts(Vmax) blocks per mesh, no float atomics, bit-identical to the oracle's adjoint
+__global__ __launch_bounds__(sg::kSgThreads) void sample_bwd_gather_kernel(
+    const int32_t *__restrict__ faces_padded, int Vmax, int Fmax, int n, const int32_t *__restrict__ face_idx,
+    const float *__restrict__ r1, const float *__restrict__ r2, const float *__restrict__ gout,
+    const int32_t *__restrict__ vf_rowptr, const int32_t *__restrict__ vf_ent, float *gverts, int accumulate, int parts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sg_lds[];
+    const size_t b = blockIdx.x / parts;
+    const int j = blockIdx.x % parts;
+    const sg::SgMesh m{faces_padded + b * Fmax * 3, face_idx + b * n, r1 + b * n, r2 + b * n, gout + b * n * 3,
+                       vf_rowptr + b * (Vmax + 1), vf_ent + b * Fmax * 3, gverts + b * Vmax * 3, Vmax, Fmax, n, accumulate};
+    int vb, ve;
+    sg::sg_part_range(Vmax, parts, j, vb, ve);
+    sg::sg_tables(sg_lds, m);
+    sg::sg_finish<false>(sg_lds, m, sg::SgStep{}, vb, ve);
+}
+
 int grid_for(long long n) {
     long long g = (n + kThreads - 1) / kThreads;
     if (g < 1) g = 1;
@@ -720,13 +737,38 @@ fx3d_status fx3d_sample_points(const float *verts_padded, int32_t Vmax, const in
                                    face_out, r1_out, r2_out, s);
 }
 
+#ifdef FX3D_SG_PROBE
+__attribute__((visibility("default"))) int fx3d_debug_sg_probe(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sg::g_sg_probe), sizeof(unsigned long long) * 16);
+}
+#endif
+
+fx3d_status fx3d_sample_points_bwd_ordered(int32_t Fmax, int32_t n, int32_t *ordered) {
+    FX3D_REQUIRE(ordered, "fx3d_sample_points_bwd_ordered: null output");
+    FX3D_REQUIRE(Fmax > 0 && n > 0, "fx3d_sample_points_bwd_ordered: bad sizes");
+    *ordered = sg::sg_fits(Fmax, n) ? 1 : 0;
+    return FX3D_OK;
+}
+
 fx3d_status fx3d_sample_points_bwd(const int32_t *faces_padded, int32_t Vmax, int32_t Fmax, int32_t B,
                                    int32_t n, const int32_t *face_idx, const float *r1,
                                    const float *r2, const float *gout, float *gverts, int32_t accumulate,
-                                   fx3d_stream_t s) {
+                                   const int32_t *vf_rowptr, const int32_t *vf_ent, fx3d_stream_t s) {
     FX3D_REQUIRE(faces_padded && face_idx && r1 && r2 && gout && gverts, "fx3d_sample_points_bwd: null pointer");
-    FX3D_REQUIRE(Vmax > 0 && Fmax > 0 && B > 0 && n > 0, "fx3d_sample_points_bwd: bad sizes");
+    FX3D_REQUIRE(Vmax > 0 && Fmax > 0 && B > 0 && n > 0 && (long long)B * 16 < (1ll << 30), "fx3d_sample_points_bwd: bad sizes");
+    FX3D_REQUIRE((vf_rowptr == nullptr) == (vf_ent == nullptr), "fx3d_sample_points_bwd: vf_rowptr and vf_ent go together");
     hipStream_t st = as_stream(s);
+    if (vf_rowptr && sg::sg_fits(Fmax, n)) {  // ordered: bit-reproducible, no memset, no float atomics
+        const size_t lds = sg::sg_layout(Fmax, n).total;
+        const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&sample_bwd_gather_kernel), (int)sg::kSgMaxLds,
+                                                   "sample_bwd_gather_kernel");
+        if (arc != FX3D_OK) return arc;
+        const int parts = sg::sg_parts(Vmax);
+        hipLaunchKernelGGL(sample_bwd_gather_kernel, dim3((unsigned)B * parts), dim3(sg::kSgThreads), lds, st, faces_padded, Vmax, Fmax, n,
+                           face_idx, r1, r2, gout, vf_rowptr, vf_ent, gverts, accumulate, parts);
+        FX3D_LAUNCH_CHECK();
+        return FX3D_OK;
+    }
     if (!accumulate) FX3D_HIP(hipMemsetAsync(gverts, 0, sizeof(float) * 3 * (size_t)Vmax * B, st));
     hipLaunchKernelGGL(sample_bwd_kernel, dim3(grid_for((long long)B * n)), dim3(kThreads), 0, st,
                        faces_padded, Vmax, Fmax, B, n, face_idx, r1, r2, gout, gverts);

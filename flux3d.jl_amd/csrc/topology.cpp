@@ -107,4 +107,33 @@ fx3d_status fx3d_build_laplacian_csr(const int64_t *edges, int64_t E, int64_t V,
     return FX3D_OK;
 }
 
+// Vertex -> (face, corner) table of a padded batch, for the ordered sampling adjoint (sample_gather.h): a CSR over the
+// vertices of every mesh, entries face * 4 + corner in ascending order.  Host arrays: faces_padded (3,Fmax,B) int32 0-based
+// mesh-local (entries of padding faces are ignored), faces_len (B); vf_rowptr (Vmax+1,B), vf_ent (3*Fmax,B) (the entries of
+// mesh b fill the first vf_rowptr[Vmax,b] slots of its column).  Like the edge list and the Laplacian it is built once per
+// mesh topology (src/rep/mesh.jl:87-97: faces never change under the loops that differentiate through sample_points).
+fx3d_status fx3d_build_vertex_faces(const int32_t *faces_padded, const int32_t *faces_len, int32_t Vmax, int32_t Fmax,
+                                    int32_t B, int32_t *vf_rowptr, int32_t *vf_ent) {
+    FX3D_REQUIRE(faces_padded && faces_len && vf_rowptr && vf_ent, "fx3d_build_vertex_faces: null pointer");
+    FX3D_REQUIRE(Vmax > 0 && Fmax > 0 && B > 0 && Fmax < (1 << 29), "fx3d_build_vertex_faces: bad sizes");
+    for (int32_t b = 0; b < B; ++b) {
+        const int32_t *fb = faces_padded + (size_t)b * Fmax * 3;
+        int32_t *rp = vf_rowptr + (size_t)b * (Vmax + 1), *en = vf_ent + (size_t)b * 3 * Fmax;
+        const int32_t L = faces_len[b];
+        FX3D_REQUIRE(L >= 0 && L <= Fmax, "fx3d_build_vertex_faces: faces_len[%d] = %d outside 0:%d", b, L, Fmax);
+        std::fill(rp, rp + Vmax + 1, 0);
+        for (int32_t f = 0; f < L; ++f)
+            for (int t = 0; t < 3; ++t) {
+                const int32_t v = fb[3 * (size_t)f + t];
+                FX3D_REQUIRE(v >= 0 && v < Vmax, "fx3d_build_vertex_faces: mesh %d face %d has vertex id %d outside 0:%d", b, f, v, Vmax - 1);
+                rp[v + 1]++;
+            }
+        for (int32_t v = 0; v < Vmax; ++v) rp[v + 1] += rp[v];
+        std::vector<int32_t> cur(rp, rp + Vmax);
+        for (int32_t f = 0; f < L; ++f)          // ascending (face, corner): a stable bucket fill keeps that order per vertex
+            for (int t = 0; t < 3; ++t) en[cur[fb[3 * (size_t)f + t]]++] = f * 4 + t;
+    }
+    return FX3D_OK;
+}
+
 }  // extern "C"

@@ -66,6 +66,11 @@ class Stream:
     def synchronize(self):
         _lib.call("fx3d_stream_sync", self.handle)
 
+    def wait_event(self, ev):
+        """Work queued on this stream after the call starts only when ``ev`` (recorded on another stream) has completed;
+        inside a Graph capture this is how a second stream joins the recording (fork) and returns to it (join)."""
+        _lib.call("fx3d_stream_wait_event", self.handle, ev.handle)
+
     def __del__(self):
         if getattr(self, "_owned", False) and self.handle:
             try:

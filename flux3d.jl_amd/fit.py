@@ -15,11 +15,12 @@ from .transforms import lincomb, offset, sample_points_grad, sample_points_pair
 
 
 def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_lap=0.1, w_edge=1.0, sync=True,
-                 seed_dev=None, m=None):
+                 seed_dev=None, m=None, step=None, ordered=True):
     """Returns the Float32 loss (and the gradient w.r.t. x, device (3,sumV), when with_grad).
     ``sync=False``: the loss stays a 1-element device array (the three terms are combined by fx3d_lincomb in
     the reference's order) and the call enqueues without a single host round trip.  ``seed_dev``: device uint64
-    added to both sampling seeds by the kernels (FitStepGraph advances it between replays)."""
+    added to both sampling seeds by the kernels (FitStepGraph advances it between replays).  ``step``: see
+    :func:`chamfer_sampled_grad` (single source mesh): the optimiser step rides in the last adjoint's launch."""
     if m is None:  # (FitStepGraph passes the offset mesh the previous iteration's optimiser step already wrote)
         m = offset(src, x)
     s1 = None if seed is None else seed
@@ -40,7 +41,9 @@ def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_la
         # unit rows) WRITE the buffer; the chamfer adjoint and the sampling adjoint are ONE launch that scatter-adds on top
         # (the target's half of the chamfer adjoint is not needed and not computed): no memset node in the iteration
         g = mesh_losses_grad(m, 0.0, w_lap, w_edge, reuse_forward=True)
-        chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=m, draws_a=(fa, r1, r2), out_a=g.reshape(3, m.V, 1))
+        # (round 6: ordered -- bit-reproducible -- and, when the caller hands over the optimiser's state, with its step in the
+        #  same launch: the thread that finishes a vertex's gradient row applies Momentum + offset to it)
+        chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=m, draws_a=(fa, r1, r2), out_a=g.reshape(3, m.V, 1), step=step, ordered=ordered)
         return loss, g
     gA, _ = chamfer_distance_grad(A, Bp, ix, iy)
     gpad = sample_points_grad(m, fa, r1, r2, gA)           # (3,Vmax,B), zeroed + scatter-added
@@ -62,6 +65,13 @@ class Momentum:
                   current_stream().handle)
         return x
 
+    def step_args(self, x, base, out, counter=None, inc=0):
+        """The ``step`` tuple of :func:`chamfer_sampled_grad`: this optimiser's update of x (and out = base + x, counter += inc)
+        applied inside the adjoint's launch instead of by :meth:`update_offset` afterwards."""
+        if self.v is None:
+            self.v = DeviceArray.zeros(x.shape, np.float32)
+        return (self.rho, self.eta, self.v, x, base, out, counter, inc)
+
     def update_offset(self, x, g, base, out, counter=None, inc=0):
         """update(x, g) and, in the same launch, out = base + x (the next iteration's offset mesh) and counter += inc."""
         if self.v is None:
@@ -73,7 +83,7 @@ class Momentum:
 
 class FitStepGraph:
     """One iteration of the fit_mesh loop (examples/fit_mesh.jl:98-110: loss, gradient, Momentum update) captured
-    as a hipGraph: nine launch-bound kernels (no memset, no copy) replayed with one launch per iteration.
+    as a hipGraph: six launch-bound kernels (no memset, no copy) replayed with one launch per iteration.
 
     The sampling seeds recorded in the graph are ``seed`` and ``seed + 1`` plus a device counter that the graph
     itself advances by two per replay, so every iteration draws fresh samples (the reference draws from the global
@@ -82,7 +92,7 @@ class FitStepGraph:
     (``float(step.loss.item())`` after ``synchronize()``): the only host round trip.  ``x`` belongs to the graph while
     it is in use: after an external write to it call :meth:`resync`."""
 
-    def __init__(self, x, src, tgt, opt, num_samples=5000, seed=0x5EED0C3, w_lap=0.1, w_edge=1.0):
+    def __init__(self, x, src, tgt, opt, num_samples=5000, seed=0x5EED0C3, w_lap=0.1, w_edge=1.0, ordered=True, step_in_launch=True):
         self.x, self.opt = x, opt
         self.stream = Stream.create()
         self.counter = DeviceArray.zeros((1,), np.uint64)
@@ -95,11 +105,16 @@ class FitStepGraph:
         self._src_verts = src.dev("verts_packed")
         self.mverts = lincomb(1.0, self._src_verts, 1.0, x) if fused else None
 
+        in_launch = fused and hasattr(opt, "step_args") and ordered and step_in_launch  # (round 6) ... and the step itself rides in the last adjoint's launch
+
         def body():
             m = src.with_verts_packed(self.mverts) if fused else None
+            st = opt.step_args(x, src.dev("verts_packed"), self.mverts, self.counter, 2) if in_launch else None
             loss, g = loss_dolphin(x, src, tgt, num_samples, seed=seed, with_grad=True, w_lap=w_lap, w_edge=w_edge,
-                                   sync=False, seed_dev=self.counter, m=m)
-            if fused:
+                                   sync=False, seed_dev=self.counter, m=m, step=st, ordered=ordered)
+            if in_launch:
+                pass
+            elif fused:
                 opt.update_offset(x, g, src.dev("verts_packed"), self.mverts, self.counter, 2)
             else:
                 opt.update(x, g)

@@ -393,18 +393,50 @@ end
 function chamfer_sampled_grad(A::HipArray{Float32,3}, B::HipArray{Float32,3}, ix::HipArray{Int32,2}, iy::HipArray{Int32,2},
                               m1, draws1, m2, draws2; w1::Number = 1.0, w2::Number = 1.0, gout::Number = 1)
     _, N, Bn = size(A); _, M, _ = size(B)
-    side(m, d) = m === nothing ? (C_NULL, Int32(0), Int32(0), C_NULL, C_NULL, C_NULL, nothing) :
-        (faces_padded_dev(m).ptr, Int32(m.V), Int32(m.F), d[1].ptr, d[2].ptr, d[3].ptr, HipArray{Float32}(undef, 3, m.V, m.N))
-    f1, V1, F1, fi1, ra1, rb1, g1 = side(m1, draws1)
-    f2, V2, F2, fi2, ra2, rb2, g2 = side(m2, draws2)
+    side(m, d) = m === nothing ? (C_NULL, Int32(0), Int32(0), C_NULL, C_NULL, C_NULL, nothing, C_NULL, C_NULL) :
+        (faces_padded_dev(m).ptr, Int32(m.V), Int32(m.F), d[1].ptr, d[2].ptr, d[3].ptr, HipArray{Float32}(undef, 3, m.V, m.N),
+         vertex_faces_dev(m)[1].ptr, vertex_faces_dev(m)[2].ptr)
+    f1, V1, F1, fi1, ra1, rb1, g1, vr1, ve1 = side(m1, draws1)
+    f2, V2, F2, fi2, ra2, rb2, g2, vr2, ve2 = side(m2, draws2)
+    nb = Ref{Csize_t}(0)   # the ordered form's scratch (rows of both sides + the per-entry sums); the library falls back to the
+    check(@ccall LIB.fx3d_chamfer_sampled_bwd_workspace_bytes(N::Int32, M::Int32, Bn::Int32, nb::Ref{Csize_t})::Int32)   # float-atomic
+                                                                                                                             # scatter beyond its limits
+    ws = workspace(nb[])
     check(@ccall LIB.fx3d_chamfer_sampled_bwd(A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32, Bn::Int32,
                                               ix.ptr::Ptr{Cvoid}, iy.ptr::Ptr{Cvoid}, Float32(w1)::Float32, Float32(w2)::Float32,
                                               Float32(gout)::Float32, Bn::Int64, f1::Ptr{Cvoid}, V1::Int32, F1::Int32,
                                               fi1::Ptr{Cvoid}, ra1::Ptr{Cvoid}, rb1::Ptr{Cvoid},
                                               (g1 === nothing ? C_NULL : g1.ptr)::Ptr{Cvoid}, f2::Ptr{Cvoid}, V2::Int32, F2::Int32,
                                               fi2::Ptr{Cvoid}, ra2::Ptr{Cvoid}, rb2::Ptr{Cvoid},
-                                              (g2 === nothing ? C_NULL : g2.ptr)::Ptr{Cvoid}, 0::Int32, DEFAULT_STREAM::Stream)::Int32)
+                                              (g2 === nothing ? C_NULL : g2.ptr)::Ptr{Cvoid}, 0::Int32, vr1::Ptr{Cvoid},
+                                              ve1::Ptr{Cvoid}, vr2::Ptr{Cvoid}, ve2::Ptr{Cvoid}, ws.ptr::Ptr{Cvoid},
+                                              length(ws)::Csize_t, DEFAULT_STREAM::Stream)::Int32)
     return g1, g2
+end
+
+# The last launch of a fit_mesh iteration (examples/fit_mesh.jl:106-110) for ONE source mesh: the pullback of
+# chamfer_distance(offset(src, x), tgt, n) onto the source's vertices, added to `g` (the regularisers' gradient), and
+# Flux.Optimise.Momentum(eta, rho) + offset applied to every finished row by the thread that holds it:
+#   vel = rho vel - eta g;  x += vel;  out = base + x;  counter += inc
+function chamfer_sampled_grad_step!(g::HipArray{Float32}, A::HipArray{Float32,3}, B::HipArray{Float32,3}, ix::HipArray{Int32,2},
+                                    iy::HipArray{Int32,2}, m, draws, x::HipArray{Float32}, vel::HipArray{Float32},
+                                    base::HipArray{Float32}, out::HipArray{Float32}; eta = 1.0, rho = 0.9, w1::Number = 1.0,
+                                    w2::Number = 1.0, gout::Number = 1, counter = C_NULL, inc::Integer = 0)
+    _, N, _ = size(A); _, M, _ = size(B)
+    vfr, vfe = vertex_faces_dev(m)
+    nb = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_chamfer_sampled_bwd_workspace_bytes(N::Int32, M::Int32, 1::Int32, nb::Ref{Csize_t})::Int32)
+    ws = workspace(nb[])
+    check(@ccall LIB.fx3d_chamfer_sampled_bwd_step(A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32, ix.ptr::Ptr{Cvoid},
+                                                   iy.ptr::Ptr{Cvoid}, Float32(w1)::Float32, Float32(w2)::Float32,
+                                                   Float32(gout)::Float32, faces_padded_dev(m).ptr::Ptr{Cvoid}, m.V::Int32,
+                                                   m.F::Int32, draws[1].ptr::Ptr{Cvoid}, draws[2].ptr::Ptr{Cvoid},
+                                                   draws[3].ptr::Ptr{Cvoid}, g.ptr::Ptr{Cvoid}, 1::Int32, vfr.ptr::Ptr{Cvoid},
+                                                   vfe.ptr::Ptr{Cvoid}, Float32(rho)::Float32, Float32(eta)::Float32,
+                                                   vel.ptr::Ptr{Cvoid}, x.ptr::Ptr{Cvoid}, base.ptr::Ptr{Cvoid}, out.ptr::Ptr{Cvoid},
+                                                   (counter isa HipArray ? counter.ptr : counter)::Ptr{Cvoid}, UInt64(inc)::UInt64,
+                                                   ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t, DEFAULT_STREAM::Stream)::Int32)
+    return out
 end
 
 # ---- k-NN graph: replaces CreateSingleKNNGraph + the per-batch loop (src/models/dgcnn.jl:3-7,36) --
@@ -500,6 +532,18 @@ faces_padded_dev(m) = get!(() -> index_upload(get_faces_padded(m); clamp_pad = t
 faces_len_dev(m) = get!(() -> hip(Int32.(m._faces_len)), mirror(m), :faces_len)
 faces_packed_dev(m) = get!(() -> index_upload(get_faces_packed(m); limit = sum(m._verts_len)), mirror(m), :faces_packed)
 edges_dev(m) = get!(() -> index_upload(get_edges_packed(m); limit = sum(m._verts_len)), mirror(m), :edges)          # (E,2) column-major
+# vertex -> (face, corner) table of the padded batch (fx3d_build_vertex_faces): what the ordered -- atomic-free, bit-reproducible --
+# adjoint of sample_points walks; built once per topology like the edge list (src/rep/mesh.jl:87-97)
+function vertex_faces_dev(m)
+    get!(mirror(m), :vertex_faces) do
+        fp = Int32.(max.(Int64.(get_faces_padded(m)) .- 1, 0))       # (3, Fmax, B) 0-based, padding clamped (never read)
+        fl = Int32.(m._faces_len)
+        rowptr = Matrix{Int32}(undef, m.V + 1, m.N); ent = Matrix{Int32}(undef, 3 * m.F, m.N)
+        check(@ccall LIB.fx3d_build_vertex_faces(fp::Ptr{Int32}, fl::Ptr{Int32}, m.V::Int32, m.F::Int32, m.N::Int32,
+                                                 rowptr::Ptr{Int32}, ent::Ptr{Int32})::Int32)
+        (hip(rowptr), hip(ent))
+    end
+end
 function laplacian_csr_dev(m)
     get!(mirror(m), :lap) do
         # CSR of L == CSC of L' ; build from the reference's own cached SparseMatrixCSC (src/rep/mesh.jl:559-565)
@@ -681,9 +725,16 @@ Zygote.@adjoint function sample_points_with_draws(m, verts, n, eps, seed)
     out, (face, r1, r2) = sample_points_with_draws(m, verts, n, eps, seed)
     function back(g)
         gv = HipArray{Float32}(undef, 3, m.V, m.N)
+        # ordered form: every vertex's sum in a fixed order (no float atomics); meshes beyond its limits keep the scatter
+        fits = Ref{Int32}(0)
+        check(@ccall LIB.fx3d_sample_points_bwd_ordered(m.F::Int32, n::Int32, fits::Ref{Int32})::Int32)
+        ordered = fits[] != 0
+        vfr, vfe = ordered ? vertex_faces_dev(m) : (nothing, nothing)
         check(@ccall LIB.fx3d_sample_points_bwd(faces_padded_dev(m).ptr::Ptr{Cvoid}, m.V::Int32, m.F::Int32, m.N::Int32,
                                                 n::Int32, face.ptr::Ptr{Cvoid}, r1.ptr::Ptr{Cvoid}, r2.ptr::Ptr{Cvoid},
-                                                g[1].ptr::Ptr{Cvoid}, gv.ptr::Ptr{Cvoid}, 0::Int32, DEFAULT_STREAM::Stream)::Int32)
+                                                g[1].ptr::Ptr{Cvoid}, gv.ptr::Ptr{Cvoid}, 0::Int32,
+                                                (ordered ? vfr.ptr : C_NULL)::Ptr{Cvoid}, (ordered ? vfe.ptr : C_NULL)::Ptr{Cvoid},
+                                                DEFAULT_STREAM::Stream)::Int32)
         return (nothing, gv, nothing, nothing, nothing)
     end
     return (out, (face, r1, r2)), back

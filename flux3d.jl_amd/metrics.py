@@ -148,12 +148,15 @@ def chamfer_value_and_grad(A, B, w1=1.0, w2=1.0, gout=1.0, B_global=None, return
 
 
 def chamfer_sampled_grad(A, B, idx_a, idx_b, mesh_a=None, draws_a=None, mesh_b=None, draws_b=None, w1=1.0, w2=1.0,
-                         gout=1.0, B_global=None, out_a=None, out_b=None):
+                         gout=1.0, B_global=None, out_a=None, out_b=None, ordered=True, step=None):
     """Adjoint of ``chamfer_distance(m_a::TriMesh, m_b::TriMesh, n)`` (src/metrics/mesh.jl:34-44) w.r.t. the padded vertices of
     ``mesh_a`` and / or ``mesh_b`` in ONE launch (fx3d_chamfer_sampled_bwd): ``A`` / ``B`` are the sampled clouds of the forward,
     ``draws_*`` = (face_idx, r1, r2) of :func:`sample_points` (``return_draws=True``), ``idx_*`` the forward's neighbour indices.
-    A mesh that is None is skipped.  ``out_*``: (3,Vmax,B) device arrays the gradient is ADDED to (default: fresh, zeroed).
-    Returns (g_a, g_b) (None for a skipped side)."""
+    A mesh that is None is skipped.  ``out_*``: (3,Vmax,B) device arrays the gradient is ADDED to (default: fresh).
+    ``ordered`` (default): no float atomics -- every vertex's sum in a fixed order, the same bits on every run (meshes whose draws
+    fit one CU's LDS -- ~6200 draws at 5120 faces --, batches up to 63; otherwise, or ``ordered=False``, the float-atomic scatter).
+    ``step`` = (rho, eta, vel, params, base, out, counter, inc): the Momentum step + offset of the fit_mesh loop applied to
+    ``mesh_a``'s finished gradient rows in the same launch (one mesh, ordered form).  Returns (g_a, g_b) (None for a skipped side)."""
     x, y = _as_dev_points(A), _as_dev_points(B)
     D, N, M, Bn = _check_pair(x, y)
     if D != 3:
@@ -161,17 +164,37 @@ def chamfer_sampled_grad(A, B, idx_a, idx_b, mesh_a=None, draws_a=None, mesh_b=N
     if (out_a is None) != (out_b is None) and mesh_a is not None and mesh_b is not None:
         raise ValueError("chamfer_sampled_grad: pass both out arrays or neither")
     accumulate = (out_a is not None) or (out_b is not None)
+    def fits(m, n):
+        if m is None:
+            return True
+        f = C.c_int32(0)
+        _lib.call("fx3d_sample_points_bwd_ordered", m.F, n, C.byref(f))
+        return f.value != 0
+    ordered = bool(ordered) and fits(mesh_a, N) and fits(mesh_b, M) and 4 * Bn <= 255
+    nb = C.c_size_t(0)
+    _lib.call("fx3d_chamfer_sampled_bwd_workspace_bytes", N, M, Bn, C.byref(nb))
+    ws = workspace(nb.value, "chamfer_sampled_bwd") if ordered else None
 
     def side(m, draws, out):
         if m is None:
-            return [None, 0, 0, None, None, None, None], None
+            return [None, 0, 0, None, None, None, None], [None, None], None
         fi, r1, r2 = draws
         g = out if out is not None else DeviceArray.empty((3, m.V, m.N), np.float32)
-        return [m.dev("faces_padded").ptr, m.V, m.F, fi.ptr, r1.ptr, r2.ptr, g.ptr], g
-    sa, ga = side(mesh_a, draws_a, out_a)
-    sb, gb = side(mesh_b, draws_b, out_b)
+        vf = [m.dev("vf_rowptr").ptr, m.dev("vf_ent").ptr] if ordered else [None, None]
+        return [m.dev("faces_padded").ptr, m.V, m.F, fi.ptr, r1.ptr, r2.ptr, g.ptr], vf, g
+    sa, vfa, ga = side(mesh_a, draws_a, out_a)
+    sb, vfb, gb = side(mesh_b, draws_b, out_b)
+    if step is not None:
+        if mesh_a is None or mesh_b is not None or Bn != 1 or not ordered:
+            raise ValueError("chamfer_sampled_grad(step=...): one source mesh (B = 1), gradient w.r.t. mesh_a only, ordered form")
+        rho, eta, vel, params, base, out, counter, inc = step
+        _lib.call("fx3d_chamfer_sampled_bwd_step", x.ptr, N, y.ptr, M, idx_a.ptr, idx_b.ptr, float(w1), float(w2), float(gout),
+                  *sa, int(accumulate), *vfa, float(rho), float(eta), vel.ptr, params.ptr, base.ptr, out.ptr,
+                  counter.ptr if counter is not None else None, int(inc), ws.ptr, ws.nbytes, current_stream().handle)
+        return ga, None
     _lib.call("fx3d_chamfer_sampled_bwd", x.ptr, N, y.ptr, M, Bn, idx_a.ptr, idx_b.ptr, float(w1), float(w2), float(gout),
-              int(B_global or Bn), *sa, *sb, int(accumulate), current_stream().handle)
+              int(B_global or Bn), *sa, *sb, int(accumulate), *vfa, *vfb, ws.ptr if ws is not None else None,
+              ws.nbytes if ws is not None else 0, current_stream().handle)
     return ga, gb
 
 

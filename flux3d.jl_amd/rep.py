@@ -399,6 +399,18 @@ class TriMesh:
             arr = DeviceArray.from_host(self._faces_len.astype(np.int32))
         elif name == "edges":
             arr = index_upload(self.get_edges_packed(), b, limit=int(np.sum(self._verts_len)))
+        elif name in ("vf_rowptr", "vf_ent"):  # vertex -> (face, corner) table of the ordered sampling adjoint (padded batch)
+            fp = np.asfortranarray(self.get_faces_padded().astype(np.int64) - b).astype(np.int32)
+            fp[fp < 0] = 0  # (padding faces: never read, faces_len bounds the walk)
+            fp = np.asfortranarray(fp)
+            fl = np.ascontiguousarray(self._faces_len, dtype=np.int32)
+            rowptr = np.zeros((self.V + 1, self.N), np.int32, order="F")
+            ent = np.zeros((3 * self.F, self.N), np.int32, order="F")
+            _lib.call("fx3d_build_vertex_faces", fp.ctypes.data, fl.ctypes.data, int(self.V), int(self.F), int(self.N),
+                      rowptr.ctypes.data, ent.ctypes.data)
+            store["vf_rowptr"] = DeviceArray.from_host(rowptr)
+            store["vf_ent"] = DeviceArray.from_host(ent)
+            return store[name]
         elif name in ("lap_rowptr", "lap_colind", "lap_vals"):
             rowptr, colind, vals = self.get_laplacian_packed()
             store["lap_rowptr"] = DeviceArray.from_host(rowptr)

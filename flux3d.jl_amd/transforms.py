@@ -145,14 +145,21 @@ def sample_points_pair(ma, mb, num_samples=5000, eps=EPS, seed_a=None, seed_b=No
     return (outs[0], outs[1], fo, ra, rb) if return_draws_a else (outs[0], outs[1])
 
 
-def sample_points_grad(m, face_idx, r1, r2, gout, out=None):
+def sample_points_grad(m, face_idx, r1, r2, gout, out=None, ordered=True):
     """Adjoint of sample_points w.r.t. the padded verts for fixed draws: device (3,Vmax,B).
-    ``out``: scatter-add into this (3,Vmax,B) array instead of a zeroed one (no memset node)."""
+    ``out``: add into this (3,Vmax,B) array instead of starting from zero (no memset node).
+    ``ordered`` (default): the atomic-free form -- every vertex's sum in a fixed order, bit-identical to the oracle's adjoint
+    and from run to run (meshes whose draws fit one CU's LDS: up to ~6200 draws at 5120 faces; larger ones, or ``ordered=False``:
+    float atomics)."""
     n, B = face_idx.shape
     g = DeviceArray.empty((3, m.V, m.N), np.float32) if out is None else out
     gout = gout if isinstance(gout, DeviceArray) else DeviceArray.from_host(np.asarray(gout, np.float32))
+    fits = C.c_int32(0)
+    _lib.call("fx3d_sample_points_bwd_ordered", m.F, n, C.byref(fits))
+    use = bool(ordered) and fits.value != 0
     _lib.call("fx3d_sample_points_bwd", m.dev("faces_padded").ptr, m.V, m.F, B, n, face_idx.ptr,
-              r1.ptr, r2.ptr, gout.ptr, g.ptr, int(out is not None), current_stream().handle)
+              r1.ptr, r2.ptr, gout.ptr, g.ptr, int(out is not None), m.dev("vf_rowptr").ptr if use else None,
+              m.dev("vf_ent").ptr if use else None, current_stream().handle)
     return g
 
 

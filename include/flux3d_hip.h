@@ -187,17 +187,36 @@ FX3D_API fx3d_status fx3d_chamfer_fwd_bwd(const float *x, int32_t N, const float
 
 /* Adjoint of chamfer_distance(m_x::TriMesh, m_y::TriMesh, n) (src/metrics/mesh.jl:34-44: both meshes sampled, then
  * _chamfer_distance) w.r.t. the PADDED VERTICES of either mesh, for the forward's draws and nearest-neighbour indices, in one
- * launch: fx3d_chamfer_bwd's gradient w.r.t. the sampled points (D = 3) is scattered onto the three vertices of every sampled
- * face with the barycentric weights of its draw (fx3d_sample_points_bwd) instead of being written out.  x (3,N,B) / y (3,M,B):
- * the samples; face_idx_*, r1_*, r2_* (n,B): their draws (n = N resp. M); gverts_* (3,Vmax_*,B).  A side whose gverts is NULL is
- * skipped (a fitting loop differentiates w.r.t. the source mesh only).  accumulate = 0 zeroes gverts first. */
+ * launch: fx3d_chamfer_bwd's gradient w.r.t. the sampled points (D = 3) goes onto the three vertices of every sampled face with
+ * the barycentric weights of its draw (fx3d_sample_points_bwd) instead of being written out.  x (3,N,B) / y (3,M,B): the samples;
+ * face_idx_*, r1_*, r2_* (n,B): their draws (n = N resp. M); gverts_* (3,Vmax_*,B).  A side whose gverts is NULL is skipped (a
+ * fitting loop differentiates w.r.t. the source mesh only).  accumulate = 0 overwrites gverts, else adds to it.
+ * vf_rowptr_* / vf_ent_* (device copies of fx3d_build_vertex_faces' tables) select the ORDERED form for meshes it fits
+ * (fx3d_sample_points_bwd_ordered(Fmax, n) for every requested side, B <= 63): no float atomics, every vertex's sum in the
+ * order of fx3d_sample_points_bwd -- bit-reproducible; ws: fx3d_chamfer_sampled_bwd_workspace_bytes.  NULL tables (or a mesh
+ * beyond the limits): the scatter with global float atomics (sums in arrival order), ws unused. */
+FX3D_API fx3d_status fx3d_chamfer_sampled_bwd_workspace_bytes(int32_t N, int32_t M, int32_t B, size_t *bytes);
 FX3D_API fx3d_status fx3d_chamfer_sampled_bwd(const float *x, int32_t N, const float *y, int32_t M, int32_t B,
                                               const int32_t *idx_x, const int32_t *idx_y, float w1, float w2, float gout,
                                               int64_t B_global, const int32_t *faces_x, int32_t Vmax_x, int32_t Fmax_x,
                                               const int32_t *face_idx_x, const float *r1_x, const float *r2_x,
                                               float *gverts_x, const int32_t *faces_y, int32_t Vmax_y, int32_t Fmax_y,
                                               const int32_t *face_idx_y, const float *r1_y, const float *r2_y,
-                                              float *gverts_y, int32_t accumulate, fx3d_stream_t s);
+                                              float *gverts_y, int32_t accumulate, const int32_t *vf_rowptr_x,
+                                              const int32_t *vf_ent_x, const int32_t *vf_rowptr_y, const int32_t *vf_ent_y,
+                                              void *ws, size_t ws_bytes, fx3d_stream_t s);
+/* The same for ONE source mesh (B = 1, gradient w.r.t. mesh x only, ordered form required), with the optimiser step of the
+ * fit_mesh loop (examples/fit_mesh.jl:87-88,108-110: Flux.Optimise.Momentum, then offset) applied by the thread that finishes a
+ * vertex's gradient row g = gverts_x (accumulate: on top of the regularisers' gradient already in it):
+ *   vel = rho vel - eta g;  params += vel;  out = base + params   (fx3d_momentum_step_offset's arithmetic), *ctr += inc.
+ * One launch instead of two at the end of every iteration; gverts_x still receives g. */
+FX3D_API fx3d_status fx3d_chamfer_sampled_bwd_step(const float *x, int32_t N, const float *y, int32_t M, const int32_t *idx_x,
+                                                   const int32_t *idx_y, float w1, float w2, float gout,
+                                                   const int32_t *faces_x, int32_t V, int32_t F, const int32_t *face_idx_x,
+                                                   const float *r1_x, const float *r2_x, float *gverts_x, int32_t accumulate,
+                                                   const int32_t *vf_rowptr_x, const int32_t *vf_ent_x, float rho, float eta,
+                                                   float *vel, float *params, const float *base, float *out, uint64_t *ctr,
+                                                   uint64_t inc, void *ws, size_t ws_bytes, fx3d_stream_t s);
 
 /* ---- k-NN graph (src/models/dgcnn.jl:3-7,36) ---------------------------------------------------
  * knn(KDTree(y), x, k+drop_first, true)[1][1+drop_first:end] for every point of every batch
@@ -339,14 +358,24 @@ FX3D_API fx3d_status fx3d_sample_points_draw_pair(const float *verts0, int32_t V
                                                   const uint64_t *seed_dev, fx3d_stream_t s);
 
 /* Adjoint of sample_points w.r.t. verts_padded for the same draws (Zygote through :67-71):
- * gverts_padded (3,Vmax,B) = scatter of w_k * gout over the sampled faces.  accumulate = 0 overwrites gverts;
+ * gverts_padded (3,Vmax,B) = sum of w_k * gout over the draws that hit each vertex.  accumulate = 0 overwrites gverts;
  * accumulate != 0 adds to it (this and the two mesh-loss adjoints then sum into one gradient buffer: the fit_mesh
- * objective's three terms without separate buffers, memsets and a final sum). */
+ * objective's three terms without separate buffers, memsets and a final sum).
+ * ORDERED form (vf_rowptr (Vmax+1,B) / vf_ent (3 Fmax,B): device copies of fx3d_build_vertex_faces' tables; meshes whose draws
+ * and tables fit one CU's LDS -- 4 Fmax + 22.25 n bytes <= 156 KB, i.e. up to ~6200 draws at 5120 faces (the reference's default is
+ * 5000); fx3d_sample_points_bwd_ordered answers for a shape): g[v] = base[v] + sum over the (face, corner) pairs holding v,
+ * ascending, of (0 + sum over the face's draws k, ascending, of w_corner(k) * gout[k]) in unfused Float32 -- no float atomics, the
+ * same bits on every run (one block per mesh: draws bucketed by face and staged in LDS).
+ * NULL tables, or a mesh beyond those limits: scatter with global float atomics (sums in arrival order). */
+FX3D_API fx3d_status fx3d_build_vertex_faces(const int32_t *faces_padded_host, const int32_t *faces_len_host, int32_t Vmax,
+                                             int32_t Fmax, int32_t B, int32_t *vf_rowptr_host, int32_t *vf_ent_host);
+FX3D_API fx3d_status fx3d_sample_points_bwd_ordered(int32_t Fmax, int32_t n, int32_t *ordered);
 FX3D_API fx3d_status fx3d_sample_points_bwd(const int32_t *faces_padded, int32_t Vmax,
                                             int32_t Fmax, int32_t B, int32_t n,
                                             const int32_t *face_idx, const float *r1,
                                             const float *r2, const float *gout, float *gverts,
-                                            int32_t accumulate, fx3d_stream_t s);
+                                            int32_t accumulate, const int32_t *vf_rowptr, const int32_t *vf_ent,
+                                            fx3d_stream_t s);
 
 /* out[i] = a*x[i] + b*y[i] (+ c*z[i] when z != NULL), Float32, unfused.  The device-side arithmetic of
  * the fit_mesh loop: offset!(m, delta) is verts + delta (src/transforms/mesh_func.jl:409-416, a = b = 1),

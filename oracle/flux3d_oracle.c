@@ -579,6 +579,43 @@ FX_API int fx3d_oracle_sample_points_explicit(const float *verts_padded, int Vma
     return 0;
 }
 
+/* Adjoint of the weighted gather above w.r.t. verts_padded for fixed draws (Zygote through
+ * src/transforms/mesh_func.jl:64-73: samples = w1 .* v[:, f1] + w2 .* v[:, f2] + w3 .* v[:, f3]; the pullback of each
+ * getindex accumulates w_t * gout over the draws that hit the vertex).  Zygote fixes no order for that accumulation; this
+ * restatement fixes the one the device uses, so that the gradient is reproducible bit for bit:
+ *   inner(f, t) = 0 + sum over the draws k of face f, k ascending, of  w_t(k) * gout[k]      (per face and corner)
+ *   g[v] = base[v] + sum over the (face, corner) pairs holding v, ascending (f, t), of inner(f, t)
+ * (Float32, unfused; base = the incoming gverts when accumulate, else 0; an undrawn face adds its +0).
+ * faces_padded (3,Fmax,B) 0-based mesh-local, faces_len (B); gout (3,n,B); gverts (3,Vmax,B). */
+FX_API int fx3d_oracle_sample_points_bwd(const int64_t *faces_padded, const int64_t *faces_len, int Vmax, int Fmax, int B,
+                                         int n, const int32_t *face_idx, const float *r1, const float *r2,
+                                         const float *gout, float *gverts, int accumulate) {
+    float *inner = (float *)malloc(sizeof(float) * 9 * (size_t)Fmax);
+    if (!inner) return -1;
+    for (int b = 0; b < B; ++b) {
+        for (size_t i = 0; i < 9 * (size_t)Fmax; ++i) inner[i] = 0.0f;
+        for (int s = 0; s < n; ++s) {  /* draws in ascending order: every face's sums see its draws ascending */
+            size_t k = (size_t)b * n + s;
+            int f = face_idx[k];
+            if (f < 0 || f >= Fmax) continue;
+            float u = sqrtf(r1[k]), v = r2[k];
+            float w[3] = {1.0f - u, u * (1.0f - v), u * v};
+            for (int t = 0; t < 3; ++t)
+                for (int d = 0; d < 3; ++d) inner[(size_t)f * 9 + t * 3 + d] = inner[(size_t)f * 9 + t * 3 + d] + w[t] * gout[k * 3 + d];
+        }
+        float *gb = gverts + (size_t)b * Vmax * 3;
+        if (!accumulate) for (size_t i = 0; i < 3 * (size_t)Vmax; ++i) gb[i] = 0.0f;
+        for (int64_t f = 0; f < faces_len[b]; ++f)  /* ascending (face, corner): the order every vertex sees its pairs in */
+            for (int t = 0; t < 3; ++t) {
+                int64_t v = faces_padded[((size_t)b * Fmax + f) * 3 + t];
+                if (v < 0 || v >= Vmax) continue;
+                for (int d = 0; d < 3; ++d) gb[3 * v + d] = gb[3 * v + d] + inner[(size_t)f * 9 + t * 3 + d];
+            }
+    }
+    free(inner);
+    return 0;
+}
+
 /* Philox4x32-10 (Salmon et al. 2011), the counter-based generator of the on-device sampler.
  * counter = (sample, mesh, stream, 0), key = (seed_lo, seed_hi). */
 static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {

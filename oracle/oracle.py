@@ -216,6 +216,20 @@ def sample_points_explicit(verts_padded, faces_padded0, face_idx, r1, r2):
     return out
 
 
+def sample_points_bwd(faces_padded0, faces_len, Vmax, face_idx, r1, r2, gout, base=None):
+    """Adjoint of sample_points w.r.t. verts_padded for fixed draws, in the device's (fixed) summation order."""
+    f = _i64(faces_padded0)
+    fl = np.asarray(faces_len, np.int64)
+    fi = np.asfortranarray(face_idx, dtype=np.int32)
+    r1, r2, g = _f32(r1), _f32(r2), _f32(gout)
+    n, B = fi.shape
+    out = np.zeros((3, Vmax, B), np.float32, order="F") if base is None else np.array(base, np.float32, order="F", copy=True)
+    rc = lib().fx3d_oracle_sample_points_bwd(_p(f), _p(fl), int(Vmax), f.shape[1], B, n, _p(fi), _p(r1), _p(r2), _p(g),
+                                             _p(out), int(base is not None))
+    assert rc == 0
+    return out
+
+
 def sample_points_seeded(verts_padded, faces_padded0, faces_len, n, seed, eps=1e-6,
                          return_draws=False):
     v = _f32(verts_padded)

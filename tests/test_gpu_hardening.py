@@ -1250,3 +1250,135 @@ def test_nn1_small_problem_kernel_matches_the_oracle(gpu_fx, oracle, fx_option, 
             fx_option("nn1_tiny_mpairs", 0)
             lf = fx.chamfer_distance(x, y, w1=0.3, w2=1.7)
             assert np.isclose(lf, lt, rtol=1e-6, atol=1e-30), name
+
+
+# ------------------------------------------------------------------------------ ordered (atomic-free) sampling adjoint (round 6)
+def _big_face_mesh(fx, nfan=40):
+    """One triangle that takes nearly all the area (its draws: lists far beyond the eight a sorting network orders) + a fan of
+    small ones, some of them degenerate (a repeated vertex: two corners of a face on one vertex)."""
+    verts = [[0, 0, 0], [10, 0, 0], [0, 10, 0]]
+    faces = [[1, 2, 3]]
+    for i in range(nfan):
+        a = 2 * np.pi * i / nfan
+        verts.append([0.3 * np.cos(a), 0.3 * np.sin(a), 0.5])
+    for i in range(nfan):
+        faces.append([1, 4 + i, 4 + (i + 1) % nfan])
+    faces.append([2, 2, 3])          # degenerate: zero area, never drawn -- but its corners are in the table
+    v = np.asfortranarray(np.array(verts, np.float32).T)
+    f = np.asfortranarray(np.array(faces, np.uint32).T)
+    return v, f
+
+
+def _draws_case(fx, kind, nb):
+    paths = [os.path.join(GOLDEN, "teapot.obj"), os.path.join(GOLDEN, "sphere.obj")]
+    if kind == "bigface":
+        v, f = _big_face_mesh(fx)
+        tv, tf = fx.load_obj(paths[0])
+        return fx.gpu(fx.TriMesh([v, tv][:nb] if nb <= 2 else [v, tv] * (nb // 2), [f, tf][:nb] if nb <= 2 else [f, tf] * (nb // 2)))
+    return fx.gpu(fx.load_trimesh(*[paths[b % 2] for b in range(nb)]))
+
+
+@pytest.mark.parametrize("kind,nb,n", [("ragged", 2, 2000), ("ragged", 8, 5000), ("ragged", 3, 6100), ("bigface", 2, 3000),
+                                       ("bigface", 1, 7)])
+def test_sample_points_adjoint_ordered_form_is_the_oracles_bit_for_bit(gpu_fx, oracle, kind, nb, n):
+    """fx3d_sample_points_bwd with the vertex -> face table: no float atomics, every vertex's sum in the order of
+    oracle.sample_points_bwd (per face and corner over the draws ascending, then the vertex's (face, corner) pairs ascending) --
+    array_equal, also on top of a base, also twice in a row; the float-atomic form (ordered=False) agrees to rounding."""
+    import ctypes as C
+    from flux3d_jl_amd import _lib
+    fx = gpu_fx
+    m = _draws_case(fx, kind, nb)
+    fits = C.c_int32(0)
+    _lib.call("fx3d_sample_points_bwd_ordered", m.F, n, C.byref(fits))
+    assert fits.value == 1
+    _lib.call("fx3d_sample_points_bwd_ordered", m.F, 9000, C.byref(fits))   # (beyond one CU's LDS: the scatter -- tested below)
+    assert fits.value == 0
+    _, fi, r1, r2 = fx.sample_points(m, n, seed=31 + n, return_draws=True)
+    rng = np.random.default_rng(n + nb)
+    gout = np.asfortranarray(rng.standard_normal((3, n, m.N)).astype(np.float32))
+    gout[:, ::7, :] = 0.0
+    fp0 = m.get_faces_padded().astype(np.int64) - 1
+    exp = oracle.sample_points_bwd(fp0, m._faces_len, m.V, fi.to_host(), r1.to_host(), r2.to_host(), gout)
+    g1 = fx.sample_points_grad(m, fi, r1, r2, gout).to_host()
+    g2 = fx.sample_points_grad(m, fi, r1, r2, gout).to_host()
+    assert np.array_equal(g1, exp), np.argwhere(g1 != exp)[:5]
+    assert np.array_equal(g1, g2)
+    if kind == "bigface":
+        assert np.bincount(fi.to_host()[:, 0]).max() > 8 or n <= 8   # the long-list path ran
+    base = np.asfortranarray(rng.standard_normal(exp.shape).astype(np.float32))
+    out = fx.gpu(base.copy(order="F"))
+    g3 = fx.sample_points_grad(m, fi, r1, r2, gout, out=out)
+    assert g3 is out and np.array_equal(out.to_host(), oracle.sample_points_bwd(fp0, m._faces_len, m.V, fi.to_host(), r1.to_host(),
+                                                                             r2.to_host(), gout, base=base))
+    ga = fx.sample_points_grad(m, fi, r1, r2, gout, ordered=False).to_host()
+    assert np.allclose(ga, exp, rtol=2e-4, atol=1e-5)
+    if nb == 3:  # more draws than the ordered form stages: the call takes the float-atomic scatter by itself
+        _, fi9, r19, r29 = fx.sample_points(m, 9000, seed=2, return_draws=True)
+        g9 = np.asfortranarray(rng.standard_normal((3, 9000, m.N)).astype(np.float32))
+        e9 = oracle.sample_points_bwd(fp0, m._faces_len, m.V, fi9.to_host(), r19.to_host(), r29.to_host(), g9)
+        assert np.allclose(fx.sample_points_grad(m, fi9, r19, r29, g9).to_host(), e9, rtol=2e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("nb,n", [(2, 3000), (8, 5000), (2, 6000), (48, 5000), (1, 5000)])
+def test_chamfer_sampled_adjoint_ordered_form_is_the_oracles_chain_bit_for_bit(gpu_fx, oracle, nb, n):
+    """fx3d_chamfer_sampled_bwd, ordered form: the chamfer adjoint's rows (bit-identical to oracle.chamfer_bwd) are published
+    by the blocks of a (mesh, side) and gathered by the last of them in oracle.sample_points_bwd's order: array_equal to the
+    oracle's chain, run to run, one side only, on top of a base; the float-atomic form agrees to rounding."""
+    fx = gpu_fx
+    paths = [os.path.join(GOLDEN, "teapot.obj"), os.path.join(GOLDEN, "sphere.obj")]
+    ma = fx.gpu(fx.load_trimesh(*[paths[b % 2] for b in range(nb)]))
+    mb = fx.gpu(fx.load_trimesh(*[paths[(b + 1) % 2] for b in range(nb)]))
+    A, fa, ra1, ra2 = fx.sample_points(ma, n, seed=5, return_draws=True)
+    Bp, fb, rb1, rb2 = fx.sample_points(mb, n, seed=6, return_draws=True)
+    loss, ix, iy = fx.chamfer_distance(A, Bp, w1=0.9, w2=1.1, return_indices=True)
+    oga, ogb = oracle.chamfer_bwd(A.to_host(), Bp.to_host(), ix.to_host(), iy.to_host(), 0.9, 1.1, 1.5)
+    ea = oracle.sample_points_bwd(ma.get_faces_padded().astype(np.int64) - 1, ma._faces_len, ma.V, fa.to_host(), ra1.to_host(), ra2.to_host(), oga)
+    eb = oracle.sample_points_bwd(mb.get_faces_padded().astype(np.int64) - 1, mb._faces_len, mb.V, fb.to_host(), rb1.to_host(), rb2.to_host(), ogb)
+    for _ in range(2):
+        ga, gb = fx.chamfer_sampled_grad(A, Bp, ix, iy, ma, (fa, ra1, ra2), mb, (fb, rb1, rb2), w1=0.9, w2=1.1, gout=1.5)
+        assert np.array_equal(ga.to_host(), ea), np.argwhere(ga.to_host() != ea)[:5]
+        assert np.array_equal(gb.to_host(), eb), np.argwhere(gb.to_host() != eb)[:5]
+    ga1, none = fx.chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=ma, draws_a=(fa, ra1, ra2), w1=0.9, w2=1.1, gout=1.5)
+    assert none is None and np.array_equal(ga1.to_host(), ea)
+    base = np.asfortranarray(np.random.default_rng(3).standard_normal(eb.shape).astype(np.float32))
+    out = fx.gpu(base.copy(order="F"))
+    fx.chamfer_sampled_grad(A, Bp, ix, iy, mesh_b=mb, draws_b=(fb, rb1, rb2), w1=0.9, w2=1.1, gout=1.5, out_b=out)
+    eb2 = oracle.sample_points_bwd(mb.get_faces_padded().astype(np.int64) - 1, mb._faces_len, mb.V, fb.to_host(), rb1.to_host(), rb2.to_host(),
+                                   ogb, base=base)
+    assert np.array_equal(out.to_host(), eb2)
+    gaa, gba = fx.chamfer_sampled_grad(A, Bp, ix, iy, ma, (fa, ra1, ra2), mb, (fb, rb1, rb2), w1=0.9, w2=1.1, gout=1.5, ordered=False)
+    assert np.allclose(gaa.to_host(), ea, rtol=2e-4, atol=1e-8) and np.allclose(gba.to_host(), eb, rtol=2e-4, atol=1e-8)
+
+
+def test_chamfer_sampled_adjoint_with_the_optimiser_step_in_its_launch(gpu_fx, oracle):
+    """fx3d_chamfer_sampled_bwd_step = fx3d_chamfer_sampled_bwd (ordered, on top of a base gradient) followed by
+    fx3d_momentum_step_offset, bit for bit: velocity, parameters, the next offset mesh, the gradient and the seed counter."""
+    fx = gpu_fx
+    src = fx.gpu(fx.load_trimesh(os.path.join(GOLDEN, "sphere.obj")))
+    tgt = fx.gpu(fx.load_trimesh(os.path.join(GOLDEN, "teapot.obj")))
+    n = 5000
+    A, fa, r1, r2 = fx.sample_points(src, n, seed=1, return_draws=True)
+    Bp = fx.sample_points(tgt, n, seed=2)
+    _, ix, iy = fx.chamfer_distance(A, Bp, return_indices=True)
+    rng = np.random.default_rng(0)
+    V = src.V
+    base_g = np.asfortranarray(rng.standard_normal((3, V, 1)).astype(np.float32) * 1e-3)
+    vel0 = np.asfortranarray(rng.standard_normal((3, V)).astype(np.float32) * 1e-3)
+    x0 = np.asfortranarray(rng.standard_normal((3, V)).astype(np.float32) * 1e-2)
+    basev = src.dev("verts_packed")
+
+    def state():
+        return (fx.gpu(base_g.copy(order="F")), fx.gpu(vel0.copy(order="F")), fx.gpu(x0.copy(order="F")),
+                fx.DeviceArray.zeros((3, V), np.float32), fx.DeviceArray.zeros((1,), np.uint64))
+    g_a, vel_a, x_a, out_a, ctr_a = state()
+    fx.chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=src, draws_a=(fa, r1, r2), out_a=g_a)
+    opt = fx.Momentum(0.7, 0.9)
+    opt.v = vel_a
+    opt.update_offset(x_a, g_a.reshape(3, V), basev, out_a, ctr_a, 2)
+    g_b, vel_b, x_b, out_b, ctr_b = state()
+    fx.chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=src, draws_a=(fa, r1, r2), out_a=g_b,
+                            step=(0.9, 0.7, vel_b, x_b, basev, out_b, ctr_b, 2))
+    for a, b in ((g_a, g_b), (vel_a, vel_b), (x_a, x_b), (out_a, out_b)):
+        assert np.array_equal(a.to_host(), b.to_host())
+    assert int(ctr_a.to_host()[0]) == int(ctr_b.to_host()[0]) == 2
+    assert np.abs(vel_b.to_host() - vel0).max() > 0

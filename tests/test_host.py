@@ -305,3 +305,45 @@ def test_bench_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, bench, "--gpus", "8", "--launcher", "inproc", "--steps", "1", "--warmup", "0"],
                        env=dict(env, WORLD_SIZE="8", RANK="3", LOCAL_RANK="3"), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "", (r.returncode, r.stdout, r.stderr)
+
+
+def test_vertex_face_table_and_the_oracles_sampling_adjoint(fx, oracle):
+    """fx3d_build_vertex_faces (host C++): a CSR over the vertices of every mesh of a padded batch whose entries face * 4 + corner
+    ascend -- against numpy; and the oracle's ordered sampling adjoint (the order the device reproduces) against a float64
+    scatter of the same draws (src/transforms/mesh_func.jl:64-73)."""
+    import ctypes as C
+    from flux3d_jl_amd import _lib
+    m = fx.load_trimesh(os.path.join(GOLDEN, "teapot.obj"), os.path.join(GOLDEN, "sphere.obj"))
+    fp = np.asfortranarray((m.get_faces_padded().astype(np.int64) - 1).clip(min=0).astype(np.int32))
+    fl = np.ascontiguousarray(m._faces_len, dtype=np.int32)
+    rowptr = np.zeros((m.V + 1, m.N), np.int32, order="F")
+    ent = np.zeros((3 * m.F, m.N), np.int32, order="F")
+    _lib.call("fx3d_build_vertex_faces", fp.ctypes.data, fl.ctypes.data, int(m.V), int(m.F), int(m.N), rowptr.ctypes.data, ent.ctypes.data)
+    for b in range(m.N):
+        assert rowptr[0, b] == 0 and rowptr[-1, b] == 3 * fl[b]
+        e = ent[: 3 * fl[b], b]
+        owner = np.repeat(np.arange(m.V), np.diff(rowptr[:, b]))
+        assert np.array_equal(fp[e & 3, e >> 2, b], owner)               # every entry names a corner that holds its vertex
+        assert np.all(np.diff(e)[np.diff(owner) == 0] > 0)                # ascending within a vertex
+        assert len(np.unique(e)) == len(e)                                # every (face, corner) once
+    bad = fp.copy(order="F"); bad[0, 0, 0] = m.V
+    with pytest.raises(_lib.Flux3DHipError):
+        _lib.call("fx3d_build_vertex_faces", bad.ctypes.data, fl.ctypes.data, int(m.V), int(m.F), int(m.N), rowptr.ctypes.data, ent.ctypes.data)
+    # the oracle's adjoint vs float64
+    rng = np.random.default_rng(5)
+    n = 4000
+    fi = np.asfortranarray(np.stack([rng.integers(0, fl[b], n) for b in range(m.N)], axis=1).astype(np.int32))
+    fi[:50, 0] = 7  # a face drawn many times
+    r1 = np.asfortranarray(rng.random((n, m.N), dtype=np.float32)); r2 = np.asfortranarray(rng.random((n, m.N), dtype=np.float32))
+    gout = np.asfortranarray(rng.standard_normal((3, n, m.N)).astype(np.float32))
+    got = oracle.sample_points_bwd(m.get_faces_padded().astype(np.int64) - 1, m._faces_len, m.V, fi, r1, r2, gout)
+    exp = np.zeros((3, m.V, m.N))
+    for b in range(m.N):
+        u = np.sqrt(r1[:, b]).astype(np.float64); v = r2[:, b].astype(np.float64)
+        w = [1 - u, u * (1 - v), u * v]
+        for t in range(3):
+            np.add.at(exp[:, :, b].T, fp[t, fi[:, b], b], (w[t][None, :] * gout[:, :, b]).T)
+    assert np.allclose(got, exp, rtol=1e-4, atol=1e-5)
+    base = np.asfortranarray(rng.standard_normal(got.shape).astype(np.float32))
+    assert np.allclose(oracle.sample_points_bwd(m.get_faces_padded().astype(np.int64) - 1, m._faces_len, m.V, fi, r1, r2, gout, base=base),
+                       exp + base, rtol=1e-4, atol=1e-5)
