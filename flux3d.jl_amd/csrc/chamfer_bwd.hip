@@ -128,12 +128,6 @@ struct SampledSide {
     const float *r1, *r2;
     float *gverts;            // (3, Vmax, B), added to
     int Vmax, Fmax;
-    // ordered form (round 6, sample_gather.h): the finished rows go to `gs` with write-through stores, the side's blocks of a mesh
-    // arrive at a counter and the last one gathers them onto the vertices in the oracle's order -- no float atomics
-    const int32_t *vf_rowptr, *vf_ent;  // (Vmax + 1, B), (3 Fmax, B); nullptr: the float-atomic scatter
-    float *gs;                // (3, n, B) scratch
-    int accumulate;
-    sg::SgStep step;          // optional optimiser step on the finished rows (B = 1)
 };
 
 struct BgJob {
@@ -152,12 +146,6 @@ struct BgJob {
 __device__ __forceinline__ void bg_scatter_sample(const BgJob &J, int i, P3 a) {
     const SampledSide &S = J.smp;
     const size_t k = (size_t)J.b * J.R + i;
-    if (S.gs) {  // ordered form: publish the row (sc1: through this XCD's L2 -- the gathering block may sit on another XCD)
-        __hip_atomic_store(S.gs + 3 * k, a.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(S.gs + 3 * k + 1, a.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(S.gs + 3 * k + 2, a.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
     const int32_t *fc = S.faces + ((size_t)J.b * S.Fmax + S.face_idx[k]) * 3;
     const int f3[3] = {fc[0], fc[1], fc[2]};
     const float uu = sqrtf(S.r1[k]), v = S.r2[k];
@@ -451,107 +439,26 @@ __global__ __launch_bounds__(kBgThreads, FX3D_BG_OCC) void chamfer_bwd_gather_ke
     const int32_t *__restrict__ idx_y, float ca, float cb, float *__restrict__ gx, float *__restrict__ gy, int nsplit) {
     __shared__ BgLds L;
     BgJob J = bg_job(x, N, y, M, D, idx_x, idx_y, ca, cb, nsplit);
+    if (!(J.side ? gy : gx)) return;  // (a side nobody asked for: fx3d_chamfer_sampled_bwd differentiates w.r.t. one mesh)
     J.g = (J.side ? gy : gx) + (size_t)J.b * J.R * D;
     bg_rows<D3 ? 0 : 1>(L, J);
 }
 
-// Adjoint of chamfer_distance(sample_points(m_x), sample_points(m_y)) w.r.t. the meshes' vertices in one launch: the gradient
-// w.r.t. the sampled points is formed exactly as in chamfer_bwd_gather_kernel (D = 3), then every finished row goes onto the
-// three vertices of its sampled face instead of being written out.  A side without a mesh gradient (gverts == nullptr) is skipped.
-//   * scatter form (no vertex -> face table): global float atomics, the sums in arrival order.
-//   * ORDERED form (round 6, sample_gather.h): the first 2 B nsplit blocks -- the ROW blocks -- publish their rows (write-through
-//     stores) and arrive at the (mesh, side)'s counter; behind them the launch carries GATHER blocks, sg_parts(V) per (mesh, side):
-//     a gather block buckets the draws by face (that needs face_idx only, so it runs while the rows are still being formed),
-//     waits for the counter, stages the rows and walks its share of the vertices in the oracle's order -- and applies the optimiser
-//     step to them if asked.  The wait cannot starve the row blocks: workgroups are dispatched in the order of their ids (per XCD,
-//     block L on XCD L % 8) and the gather blocks have the highest ids, so every row block holds a CU, or is done, by the time a
-//     gather block spins; the spin is bounded all the same (a gather block that gives up poisons its rows with NaN instead of
-//     hanging the device).  Counters: two spare words of the launch's ticket slot per (mesh, side) -- zero between launches,
-//     the last gather block of the (mesh, side) returns them to zero; chamfer.hip's memory-order note covers the hand-off.
-constexpr unsigned int kSgSpinMax = 200000u;  // polls of ~1 us: 0.2 s
-static_assert(kBgThreads == sg::kSgThreads, "row blocks and gather blocks share one launch");
+// Adjoint of chamfer_distance(sample_points(m_x), sample_points(m_y)) w.r.t. the meshes' vertices, SCATTER form, in one launch: the
+// gradient w.r.t. the sampled points is formed exactly as in chamfer_bwd_gather_kernel (D = 3), then every finished row goes onto
+// the three vertices of its sampled face with global float atomics (sums in arrival order) instead of being written out.  A side
+// without a mesh gradient (gverts == nullptr) is skipped.  (The ORDERED form -- fx3d_chamfer_sampled_bwd with the vertex -> face
+// tables -- is two launches: chamfer_bwd_gather_kernel writes the rows, sample_bwd_gather_kernel gathers them, sample_gather.h.)
 __global__ __launch_bounds__(kBgThreads, FX3D_BG_OCC) void chamfer_sampled_bwd_kernel(
-    const float *__restrict__ x, int N, const float *__restrict__ y, int M, int B, const int32_t *__restrict__ idx_x,
-    const int32_t *__restrict__ idx_y, float ca, float cb, SampledSide sx, SampledSide sy, int nsplit, int parts_x, int parts_y,
-    unsigned int *ticket) {
-    // all LDS of this kernel is dynamic: a row block's tables (BgLds, ~38 KB) + its accumulators between rounds (n > 4096
-    // samples), or a gather block's tables and staged rows
-    extern __shared__ __attribute__((aligned(16))) unsigned char bg_dyn[];
-    const int nrow = 2 * B * nsplit;
-    auto counter = [&](int b, int side, int which) {
-        const unsigned int t = 2u * (2u * (unsigned int)b + (unsigned int)side) + (unsigned int)which;
-        return ticket + (t / 15u) * 16u + 1u + t % 15u;
-    };
-#ifdef FX3D_SG_PROBE
-#define SGF_STAMP(k) do { if (threadIdx.x == 0) sg::g_sg_probe[k] = wall_clock64(); } while (0)
-#else
-#define SGF_STAMP(k) do { } while (0)
-#endif
-    if ((int)blockIdx.x < nrow) {
-        if (blockIdx.x == 0) SGF_STAMP(10);
-        BgLds &L = *reinterpret_cast<BgLds *>(bg_dyn);
-        BgJob J = bg_job(x, N, y, M, 3, idx_x, idx_y, ca, cb, nsplit);
-        J.smp = J.side ? sy : sx;
-        if (!J.smp.gverts) return;
-        J.part = reinterpret_cast<P3 *>(bg_dyn + ((sizeof(BgLds) + 15) & ~(size_t)15));
-        bg_rows<2>(L, J);
-        if (!J.smp.gs) return;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's rows have left the CU
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(counter(J.b, J.side, 0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (blockIdx.x == 0) SGF_STAMP(11);
-        return;
-    }
-    // ---- gather block j of (mesh b, side) ----
-    int g = (int)blockIdx.x - nrow, side = 0;
-    if (sx.gverts) {
-        if (g >= B * parts_x) { g -= B * parts_x; side = 1; }
-    } else {
-        side = 1;
-    }
-    const SampledSide &S = side ? sy : sx;
-    const int parts = side ? parts_y : parts_x;
-    const size_t b = (size_t)(g / parts);
-    const int j = g % parts, n = side ? M : N;
-    const sg::SgMesh m{S.faces + b * S.Fmax * 3, S.face_idx + b * n, S.r1 + b * n, S.r2 + b * n, S.gs + b * n * 3,
-                       S.vf_rowptr + b * (S.Vmax + 1), S.vf_ent + b * S.Fmax * 3, S.gverts + b * S.Vmax * 3, S.Vmax, S.Fmax, n,
-                       S.accumulate};
-    int vb, ve;
-    sg::sg_part_range(S.Vmax, parts, j, vb, ve);
-    if ((int)blockIdx.x == nrow) SGF_STAMP(12);
-    sg::sg_tables(bg_dyn, m);
-    if ((int)blockIdx.x == nrow) SGF_STAMP(13);
-    __shared__ int s_ok;
-    if (threadIdx.x == 0) {
-        unsigned int *rows = counter((int)b, side, 0);
-        unsigned int it = 0;
-        while (__hip_atomic_load(rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)nsplit && it < kSgSpinMax) {
-            __builtin_amdgcn_s_sleep(8);
-            ++it;
-        }
-        s_ok = it < kSgSpinMax;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ONE acquire after the match: this CU drops what it may hold of the rows' lines
-    }
-    __syncthreads();
-    if ((int)blockIdx.x == nrow) SGF_STAMP(14);
-    if (s_ok) {
-        sg::sg_finish<false>(bg_dyn, m, S.step, vb, ve);  // plain, coalesced 12-byte row loads
-    } else {  // (never seen: see the note above) loud, not hung
-        for (int v = vb + (int)threadIdx.x; v < ve; v += kBgThreads)
-            *reinterpret_cast<P3 *>(m.gverts + 3 * (size_t)v) = P3{NAN, NAN, NAN};
-    }
-    __syncthreads();
-    if ((int)blockIdx.x == nrow) SGF_STAMP(15);
-#ifdef FX3D_SG_PROBE
-    if (threadIdx.x == 0 && j < 16) sg::g_sg_probe[16 + j] = wall_clock64();
-#endif
-    if (threadIdx.x == 0) {
-        unsigned int *done = counter((int)b, side, 1);
-        if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)parts - 1u) {
-            __hip_atomic_store(counter((int)b, side, 0), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    const float *__restrict__ x, int N, const float *__restrict__ y, int M, const int32_t *__restrict__ idx_x,
+    const int32_t *__restrict__ idx_y, float ca, float cb, SampledSide sx, SampledSide sy, int nsplit) {
+    __shared__ BgLds L;
+    extern __shared__ __attribute__((aligned(16))) unsigned char bg_dyn[];  // the accumulators between rounds (n > 4096 samples)
+    BgJob J = bg_job(x, N, y, M, 3, idx_x, idx_y, ca, cb, nsplit);
+    J.smp = J.side ? sy : sx;
+    if (!J.smp.gverts) return;
+    J.part = reinterpret_cast<P3 *>(bg_dyn);
+    bg_rows<2>(L, J);
 }
 
 // blocks per (cloud, side): ONE round of blocks on the chip (a block is a chain of dependent phases: a second round doubles the
@@ -606,11 +513,6 @@ fx3d_status fx3d_chamfer_bwd(const float *x, int32_t N, const float *y, int32_t 
     return FX3D_OK;
 }
 
-#ifdef FX3D_SG_PROBE
-__attribute__((visibility("default"))) int fx3d_debug_sgf_probe(unsigned long long *host) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sg::g_sg_probe), sizeof(unsigned long long) * 32);
-}
-#endif
 #ifdef FX3D_BG_PROBE
 __attribute__((visibility("default"))) int fx3d_debug_bg_probe(unsigned long long *host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bg_probe), sizeof(unsigned long long) * 1024 * 8);
@@ -648,45 +550,57 @@ fx3d_status chamfer_sampled_bwd_impl(const char *fn, const float *x, int32_t N, 
     const int nsplit = bg_nsplit(B, N > M ? N : M);
     FX3D_REQUIRE((long long)2 * B * nsplit < (1ll << 30), "%s: batch too large", fn);
     // Ordered form (no float atomics, bit-identical to the oracle): every requested side comes with its vertex -> face table and
-    // fits the gather's LDS tables; the (mesh, side) counters fit the ticket slot's spare words.  Otherwise: the float-atomic scatter.
-    const bool ordered = (!ax.gverts || (ax.vf_rowptr && sg::sg_fits(ax.Fmax, N))) && (!ay.gverts || (ay.vf_rowptr && sg::sg_fits(ay.Fmax, M))) &&
-                         4 * (long long)B <= 255;  // (two counters per (mesh, side) in the ticket slot's spare words)
-    FX3D_REQUIRE(!step_x.vel || (ordered && ax.gverts && B == 1), "%s: the optimiser step needs the ordered form on a single mesh (vertex -> face table, "
-                 "at most %d samples)", fn, sg::kSgMaxN);
-    SampledSide sx{ax.faces, ax.face_idx, ax.r1, ax.r2, ax.gverts, ax.Vmax, ax.Fmax, nullptr, nullptr, nullptr, accumulate, sg::SgStep{}};
-    SampledSide sy{ay.faces, ay.face_idx, ay.r1, ay.r2, ay.gverts, ay.Vmax, ay.Fmax, nullptr, nullptr, nullptr, accumulate, sg::SgStep{}};
-    unsigned int *ticket = nullptr;
-    const int maxr = N > M ? N : M;
-    // dynamic LDS: the adjoint's tables + (sides beyond kBgChunk samples) the accumulators between rounds
-    size_t dyn = ((sizeof(BgLds) + 15) & ~(size_t)15) + (maxr > kBgChunk ? sizeof(P3) * (size_t)((maxr + nsplit - 1) / nsplit) : 0);
+    // fits the gather's LDS tables.  Otherwise: the float-atomic scatter.
+    const bool ordered = (!ax.gverts || (ax.vf_rowptr && sg::sg_fits(ax.Fmax, N))) && (!ay.gverts || (ay.vf_rowptr && sg::sg_fits(ay.Fmax, M)));
+    FX3D_REQUIRE(!step_x.vel || (ordered && ax.gverts && B == 1), "%s: the optimiser step needs the ordered form on a single mesh (vertex -> face "
+                 "table, draws that fit fx3d_sample_points_bwd_ordered)", fn);
     if (ordered) {
+        // two launches: the chamfer adjoint's rows of the requested sides into the scratch (bit-identical to fx3d_chamfer_bwd), then the
+        // ordered gather of every side (+ the optimiser step).  (One launch -- gather blocks behind the row blocks, waiting on a counter --
+        // was built and measured equal inside the fit loop's graph, 104 against 105 us per iteration: the gather's tables, 7 us, do
+        // overlap the rows there, but its tail -- acquire, staging, walk: ~9 us -- does not shrink; not kept: a bounded spin and a
+        // dispatch-order argument for nothing.)
         const size_t need = sampled_ws_bytes(N, M, B);
         if (!ws || ws_bytes < need) {
             set_error("%s: workspace too small (%zu < %zu bytes)", fn, ws ? ws_bytes : (size_t)0, need);
             return FX3D_ERR_WORKSPACE;
         }
-        char *w = static_cast<char *>(ws);
-        float *gsx = reinterpret_cast<float *>(w); w += al256(sizeof(float) * 3 * (size_t)N * B);
-        float *gsy = reinterpret_cast<float *>(w);
-        sx.vf_rowptr = ax.vf_rowptr; sx.vf_ent = ax.vf_ent; sx.gs = gsx; sx.step = step_x;
-        sy.vf_rowptr = ay.vf_rowptr; sy.vf_ent = ay.vf_ent; sy.gs = gsy;
-        ticket = ticket_slot(&rc, st);
-        if (!ticket) return rc;
-        if (ax.gverts) dyn = std::max(dyn, sg::sg_layout(ax.Fmax, N).total);
-        if (ay.gverts) dyn = std::max(dyn, sg::sg_layout(ay.Fmax, M).total);
-    } else if (!accumulate) {
+        float *gsx = static_cast<float *>(ws);
+        float *gsy = reinterpret_cast<float *>(static_cast<char *>(ws) + al256(sizeof(float) * 3 * (size_t)N * B));
+        {
+            ProfileScope prof("chamfer_sampled_bwd", st);
+            hipLaunchKernelGGL(chamfer_bwd_gather_kernel<true>, dim3(2 * B * nsplit), dim3(kBgThreads), 0, st, x, N, y, M, 3, idx_x, idx_y, ca,
+                               cb, ax.gverts ? gsx : nullptr, ay.gverts ? gsy : nullptr, nsplit);
+            FX3D_LAUNCH_CHECK();
+        }
+        if (ax.gverts) {
+            rc = sg::launch_sample_bwd_gather(ax.faces, ax.Vmax, ax.Fmax, B, N, ax.face_idx, ax.r1, ax.r2, gsx, ax.vf_rowptr, ax.vf_ent, ax.gverts,
+                                              accumulate, step_x, st);
+            if (rc) return rc;
+        }
+        if (ay.gverts) {
+            rc = sg::launch_sample_bwd_gather(ay.faces, ay.Vmax, ay.Fmax, B, M, ay.face_idx, ay.r1, ay.r2, gsy, ay.vf_rowptr, ay.vf_ent, ay.gverts,
+                                              accumulate, sg::SgStep{}, st);
+            if (rc) return rc;
+        }
+        return FX3D_OK;
+    }
+    if (!accumulate) {
         if (ax.gverts) FX3D_HIP(hipMemsetAsync(ax.gverts, 0, sizeof(float) * 3 * (size_t)ax.Vmax * B, st));
         if (ay.gverts) FX3D_HIP(hipMemsetAsync(ay.gverts, 0, sizeof(float) * 3 * (size_t)ay.Vmax * B, st));
     }
-    {   // the adjoint's tables + accumulators / the gather's tables + staged rows: beyond the 64 KB a kernel gets without an opt-in
-        const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&chamfer_sampled_bwd_kernel), (int)sg::kSgMaxLds,
+    const SampledSide sx{ax.faces, ax.face_idx, ax.r1, ax.r2, ax.gverts, ax.Vmax, ax.Fmax}, sy{ay.faces, ay.face_idx, ay.r1, ay.r2, ay.gverts, ay.Vmax, ay.Fmax};
+    // sides beyond kBgChunk samples (the reference's default is 5000): the accumulators between the rounds live in LDS
+    const int maxr = N > M ? N : M;
+    const size_t dyn = maxr > kBgChunk ? sizeof(P3) * (size_t)((maxr + nsplit - 1) / nsplit) : 0;
+    if (dyn > 0) {  // static BgLds (~38 KB) + up to 48 KB of accumulators: beyond the 64 KB a kernel gets without an opt-in
+        const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&chamfer_sampled_bwd_kernel), (int)(sizeof(P3) * kBgRows),
                                                    "chamfer_sampled_bwd_kernel");
         if (arc != FX3D_OK) return arc;
     }
-    const int parts_x = ordered && ax.gverts ? sg::sg_parts(ax.Vmax) : 0, parts_y = ordered && ay.gverts ? sg::sg_parts(ay.Vmax) : 0;
     ProfileScope prof("chamfer_sampled_bwd", st);
-    hipLaunchKernelGGL(chamfer_sampled_bwd_kernel, dim3(2 * B * nsplit + B * (parts_x + parts_y)), dim3(kBgThreads), dyn, st, x, N, y, M, B,
-                       idx_x, idx_y, ca, cb, sx, sy, nsplit, parts_x, parts_y, ticket);
+    hipLaunchKernelGGL(chamfer_sampled_bwd_kernel, dim3(2 * B * nsplit), dim3(kBgThreads), dyn, st, x, N, y, M, idx_x, idx_y, ca,
+                       cb, sx, sy, nsplit);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }

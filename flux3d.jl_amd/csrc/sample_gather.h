@@ -384,5 +384,10 @@ __host__ __device__ inline void sg_part_range(int V, int parts, int j, int &vb, 
     ve = vb + per < V ? vb + per : V;
 }
 
+// the gather's launch (sampler.hip), also the second launch of fx3d_chamfer_sampled_bwd's ordered form (chamfer_bwd.hip)
+fx3d_status launch_sample_bwd_gather(const int32_t *faces_padded, int Vmax, int Fmax, int B, int n, const int32_t *face_idx, const float *r1,
+                                     const float *r2, const float *gs, const int32_t *vf_rowptr, const int32_t *vf_ent, float *gverts,
+                                     int accumulate, const SgStep &step, hipStream_t st);
+
 }  // namespace sg
 }  // namespace fx3d

@@ -512,7 +512,8 @@ __global__ __launch_bounds__(kThreads) void sample_bwd_kernel(
 __global__ __launch_bounds__(sg::kSgThreads) void sample_bwd_gather_kernel(
     const int32_t *__restrict__ faces_padded, int Vmax, int Fmax, int n, const int32_t *__restrict__ face_idx,
     const float *__restrict__ r1, const float *__restrict__ r2, const float *__restrict__ gout,
-    const int32_t *__restrict__ vf_rowptr, const int32_t *__restrict__ vf_ent, float *gverts, int accumulate, int parts) {
+    const int32_t *__restrict__ vf_rowptr, const int32_t *__restrict__ vf_ent, float *gverts, int accumulate, int parts,
+    sg::SgStep step) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sg_lds[];
     const size_t b = blockIdx.x / parts;
     const int j = blockIdx.x % parts;
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(sg::kSgThreads) void sample_bwd_gather_kernel(
     int vb, ve;
     sg::sg_part_range(Vmax, parts, j, vb, ve);
     sg::sg_tables(sg_lds, m);
-    sg::sg_finish<false>(sg_lds, m, sg::SgStep{}, vb, ve);
+    sg::sg_finish<false>(sg_lds, m, step, vb, ve);
 }
 
 int grid_for(long long n) {
@@ -540,6 +541,24 @@ size_t ws_bytes_needed(int Fmax, int B) {
 }
 
 }  // namespace
+
+namespace fx3d {
+namespace sg {
+fx3d_status launch_sample_bwd_gather(const int32_t *faces_padded, int Vmax, int Fmax, int B, int n, const int32_t *face_idx, const float *r1,
+                                     const float *r2, const float *gs, const int32_t *vf_rowptr, const int32_t *vf_ent, float *gverts,
+                                     int accumulate, const SgStep &step, hipStream_t st) {
+    const size_t lds = sg_layout(Fmax, n).total;
+    const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&sample_bwd_gather_kernel), (int)kSgMaxLds, "sample_bwd_gather_kernel");
+    if (arc != FX3D_OK) return arc;
+    const int parts = sg_parts(Vmax);
+    ProfileScope prof("sample_bwd_gather", st);
+    hipLaunchKernelGGL(sample_bwd_gather_kernel, dim3((unsigned)B * parts), dim3(kSgThreads), lds, st, faces_padded, Vmax, Fmax, n, face_idx,
+                       r1, r2, gs, vf_rowptr, vf_ent, gverts, accumulate, parts, step);
+    FX3D_LAUNCH_CHECK();
+    return FX3D_OK;
+}
+}  // namespace sg
+}  // namespace fx3d
 
 extern "C" {
 
@@ -758,17 +777,9 @@ fx3d_status fx3d_sample_points_bwd(const int32_t *faces_padded, int32_t Vmax, in
     FX3D_REQUIRE(Vmax > 0 && Fmax > 0 && B > 0 && n > 0 && (long long)B * 16 < (1ll << 30), "fx3d_sample_points_bwd: bad sizes");
     FX3D_REQUIRE((vf_rowptr == nullptr) == (vf_ent == nullptr), "fx3d_sample_points_bwd: vf_rowptr and vf_ent go together");
     hipStream_t st = as_stream(s);
-    if (vf_rowptr && sg::sg_fits(Fmax, n)) {  // ordered: bit-reproducible, no memset, no float atomics
-        const size_t lds = sg::sg_layout(Fmax, n).total;
-        const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&sample_bwd_gather_kernel), (int)sg::kSgMaxLds,
-                                                   "sample_bwd_gather_kernel");
-        if (arc != FX3D_OK) return arc;
-        const int parts = sg::sg_parts(Vmax);
-        hipLaunchKernelGGL(sample_bwd_gather_kernel, dim3((unsigned)B * parts), dim3(sg::kSgThreads), lds, st, faces_padded, Vmax, Fmax, n,
-                           face_idx, r1, r2, gout, vf_rowptr, vf_ent, gverts, accumulate, parts);
-        FX3D_LAUNCH_CHECK();
-        return FX3D_OK;
-    }
+    if (vf_rowptr && sg::sg_fits(Fmax, n))  // ordered: bit-reproducible, no memset, no float atomics
+        return sg::launch_sample_bwd_gather(faces_padded, Vmax, Fmax, B, n, face_idx, r1, r2, gout, vf_rowptr, vf_ent, gverts, accumulate,
+                                            sg::SgStep{}, st);
     if (!accumulate) FX3D_HIP(hipMemsetAsync(gverts, 0, sizeof(float) * 3 * (size_t)Vmax * B, st));
     hipLaunchKernelGGL(sample_bwd_kernel, dim3(grid_for((long long)B * n)), dim3(kThreads), 0, st,
                        faces_padded, Vmax, Fmax, B, n, face_idx, r1, r2, gout, gverts);

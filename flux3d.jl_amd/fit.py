@@ -20,7 +20,9 @@ def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_la
     ``sync=False``: the loss stays a 1-element device array (the three terms are combined by fx3d_lincomb in
     the reference's order) and the call enqueues without a single host round trip.  ``seed_dev``: device uint64
     added to both sampling seeds by the kernels (FitStepGraph advances it between replays).  ``step``: see
-    :func:`chamfer_sampled_grad` (single source mesh): the optimiser step rides in the last adjoint's launch."""
+    :func:`chamfer_sampled_grad` (single source mesh): the optimiser step rides in the last adjoint's launch.
+    ``ordered`` (default): the sampling adjoint without float atomics -- the gradient is bit-reproducible (the oracle's);
+    ``ordered=False``: the scatter with float atomics, ~30 us per call faster on one mesh of 5000 draws."""
     if m is None:  # (FitStepGraph passes the offset mesh the previous iteration's optimiser step already wrote)
         m = offset(src, x)
     s1 = None if seed is None else seed
@@ -46,7 +48,7 @@ def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_la
         chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=m, draws_a=(fa, r1, r2), out_a=g.reshape(3, m.V, 1), step=step, ordered=ordered)
         return loss, g
     gA, _ = chamfer_distance_grad(A, Bp, ix, iy)
-    gpad = sample_points_grad(m, fa, r1, r2, gA)           # (3,Vmax,B), zeroed + scatter-added
+    gpad = sample_points_grad(m, fa, r1, r2, gA, ordered=ordered)   # (3,Vmax,B)
     g = m.padded_to_packed_dev(gpad)                        # adjoint of _packed_to_padded
     mesh_losses_grad(m, 0.0, w_lap, w_edge, out=g, reuse_forward=True)
     return loss, g
@@ -90,9 +92,16 @@ class FitStepGraph:
     RNG).  The constructor runs iteration 1 eagerly (``first_loss``) and records iteration 2; ``loss`` is the
     1-element device array every replay writes -- read it whenever a host value is wanted
     (``float(step.loss.item())`` after ``synchronize()``): the only host round trip.  ``x`` belongs to the graph while
-    it is in use: after an external write to it call :meth:`resync`."""
+    it is in use: after an external write to it call :meth:`resync`.
 
-    def __init__(self, x, src, tgt, opt, num_samples=5000, seed=0x5EED0C3, w_lap=0.1, w_edge=1.0, ordered=True, step_in_launch=True):
+    ``ordered`` (round 6): the sampling adjoint without float atomics -- every vertex's sum in a fixed order, the gradient the
+    oracle's bit for bit and the same on every replay (as the reference's CPU adjoint is), with the optimiser step in the
+    gather's launch (``step_in_launch``).  It costs ~30 us per iteration on one mesh of 5000 draws (the draws are bucketed by
+    face on a few CUs, 7 us, and walked behind the rows instead of scattered while they are formed), which is why the default
+    replay keeps the scatter: 80 against 112 us per iteration on the tutorial's pair (bench.py ``graph_replay`` /
+    ``graph_replay_ordered``)."""
+
+    def __init__(self, x, src, tgt, opt, num_samples=5000, seed=0x5EED0C3, w_lap=0.1, w_edge=1.0, ordered=False, step_in_launch=True):
         self.x, self.opt = x, opt
         self.stream = Stream.create()
         self.counter = DeviceArray.zeros((1,), np.uint64)

@@ -154,7 +154,7 @@ def chamfer_sampled_grad(A, B, idx_a, idx_b, mesh_a=None, draws_a=None, mesh_b=N
     ``draws_*`` = (face_idx, r1, r2) of :func:`sample_points` (``return_draws=True``), ``idx_*`` the forward's neighbour indices.
     A mesh that is None is skipped.  ``out_*``: (3,Vmax,B) device arrays the gradient is ADDED to (default: fresh).
     ``ordered`` (default): no float atomics -- every vertex's sum in a fixed order, the same bits on every run (meshes whose draws
-    fit one CU's LDS -- ~6200 draws at 5120 faces --, batches up to 63; otherwise, or ``ordered=False``, the float-atomic scatter).
+    fit one CU's LDS -- ~6200 draws at 5120 faces --, otherwise, or ``ordered=False``, the float-atomic scatter).
     ``step`` = (rho, eta, vel, params, base, out, counter, inc): the Momentum step + offset of the fit_mesh loop applied to
     ``mesh_a``'s finished gradient rows in the same launch (one mesh, ordered form).  Returns (g_a, g_b) (None for a skipped side)."""
     x, y = _as_dev_points(A), _as_dev_points(B)
@@ -170,7 +170,7 @@ def chamfer_sampled_grad(A, B, idx_a, idx_b, mesh_a=None, draws_a=None, mesh_b=N
         f = C.c_int32(0)
         _lib.call("fx3d_sample_points_bwd_ordered", m.F, n, C.byref(f))
         return f.value != 0
-    ordered = bool(ordered) and fits(mesh_a, N) and fits(mesh_b, M) and 4 * Bn <= 255
+    ordered = bool(ordered) and fits(mesh_a, N) and fits(mesh_b, M)
     nb = C.c_size_t(0)
     _lib.call("fx3d_chamfer_sampled_bwd_workspace_bytes", N, M, Bn, C.byref(nb))
     ws = workspace(nb.value, "chamfer_sampled_bwd") if ordered else None

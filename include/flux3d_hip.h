@@ -187,14 +187,15 @@ FX3D_API fx3d_status fx3d_chamfer_fwd_bwd(const float *x, int32_t N, const float
 
 /* Adjoint of chamfer_distance(m_x::TriMesh, m_y::TriMesh, n) (src/metrics/mesh.jl:34-44: both meshes sampled, then
  * _chamfer_distance) w.r.t. the PADDED VERTICES of either mesh, for the forward's draws and nearest-neighbour indices, in one
- * launch: fx3d_chamfer_bwd's gradient w.r.t. the sampled points (D = 3) goes onto the three vertices of every sampled face with
- * the barycentric weights of its draw (fx3d_sample_points_bwd) instead of being written out.  x (3,N,B) / y (3,M,B): the samples;
+ * call: fx3d_chamfer_bwd's gradient w.r.t. the sampled points (D = 3) goes onto the three vertices of every sampled face with
+ * the barycentric weights of its draw (fx3d_sample_points_bwd).  x (3,N,B) / y (3,M,B): the samples;
  * face_idx_*, r1_*, r2_* (n,B): their draws (n = N resp. M); gverts_* (3,Vmax_*,B).  A side whose gverts is NULL is skipped (a
  * fitting loop differentiates w.r.t. the source mesh only).  accumulate = 0 overwrites gverts, else adds to it.
  * vf_rowptr_* / vf_ent_* (device copies of fx3d_build_vertex_faces' tables) select the ORDERED form for meshes it fits
- * (fx3d_sample_points_bwd_ordered(Fmax, n) for every requested side, B <= 63): no float atomics, every vertex's sum in the
- * order of fx3d_sample_points_bwd -- bit-reproducible; ws: fx3d_chamfer_sampled_bwd_workspace_bytes.  NULL tables (or a mesh
- * beyond the limits): the scatter with global float atomics (sums in arrival order), ws unused. */
+ * (fx3d_sample_points_bwd_ordered(Fmax, n) for every requested side): no float atomics, every vertex's sum in the order of
+ * fx3d_sample_points_bwd -- bit-reproducible; two launches (the rows into ws, then the gather); ws:
+ * fx3d_chamfer_sampled_bwd_workspace_bytes.  NULL tables (or a mesh beyond the limits): ONE launch that scatters the rows with global
+ * float atomics (sums in arrival order), ws unused -- ~20 us per call faster at one mesh of 5000 draws, not reproducible. */
 FX3D_API fx3d_status fx3d_chamfer_sampled_bwd_workspace_bytes(int32_t N, int32_t M, int32_t B, size_t *bytes);
 FX3D_API fx3d_status fx3d_chamfer_sampled_bwd(const float *x, int32_t N, const float *y, int32_t M, int32_t B,
                                               const int32_t *idx_x, const int32_t *idx_y, float w1, float w2, float gout,
@@ -209,7 +210,7 @@ FX3D_API fx3d_status fx3d_chamfer_sampled_bwd(const float *x, int32_t N, const f
  * fit_mesh loop (examples/fit_mesh.jl:87-88,108-110: Flux.Optimise.Momentum, then offset) applied by the thread that finishes a
  * vertex's gradient row g = gverts_x (accumulate: on top of the regularisers' gradient already in it):
  *   vel = rho vel - eta g;  params += vel;  out = base + params   (fx3d_momentum_step_offset's arithmetic), *ctr += inc.
- * One launch instead of two at the end of every iteration; gverts_x still receives g. */
+ * The gather's launch does it: no launch of its own for the optimiser; gverts_x still receives g. */
 FX3D_API fx3d_status fx3d_chamfer_sampled_bwd_step(const float *x, int32_t N, const float *y, int32_t M, const int32_t *idx_x,
                                                    const int32_t *idx_y, float w1, float w2, float gout,
                                                    const int32_t *faces_x, int32_t V, int32_t F, const int32_t *face_idx_x,

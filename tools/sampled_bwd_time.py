@@ -57,25 +57,3 @@ if os.environ.get("FX3D_HIP_LIB", "").endswith("sgprobe.so"):   # a -DFX3D_SG_PR
     print("gather phases (us): zero+count, scan, place, sort, stage, vertices:", [round((t[i + 1] - t[i]) / 100.0, 2) for i in range(6)], "total", (t[6] - t[0]) / 100.0)
     print("vertex phase, thread 0 (us from its start): row pointers", (t[7] - t[5]) / 100.0, "entries loaded", (t[8] - t[5]) / 100.0, "walked", (t[9] - t[5]) / 100.0, "end", (t[6] - t[5]) / 100.0)
 
-if os.environ.get("FX3D_HIP_LIB", "").endswith("sgfprobe.so"):   # chamfer_bwd.hip built with -DFX3D_SG_PROBE: the fused launch's roles
-    import ctypes as C
-    from flux3d_jl_amd import _lib
-    src = fx.gpu(fx.load_trimesh(os.path.join(g, "sphere.obj")))
-    tgt = fx.gpu(fx.load_trimesh(os.path.join(g, "teapot.obj")))
-    A, fa, r1, r2 = fx.sample_points(src, 5000, seed=1, return_draws=True)
-    Bp = fx.sample_points(tgt, 5000, seed=2)
-    _, ix, iy = fx.chamfer_distance(A, Bp, return_indices=True)
-    out = fx.DeviceArray.zeros((3, src.V, 1), np.float32)
-    for _ in range(3):
-        fx.chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=src, draws_a=(fa, r1, r2), out_a=out)
-    fx.synchronize()
-    e0, e1 = fx.Event(), fx.Event()
-    e0.record(); fx.chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=src, draws_a=(fa, r1, r2), out_a=out); e1.record(); e1.synchronize()
-    print("one call between events (us):", round(e0.elapsed_ms(e1) * 1e3, 2))
-    buf = (C.c_uint64 * 32)()
-    _lib.load().fx3d_debug_sgf_probe(buf)
-    t = list(buf)
-    t0 = min(t[10], t[12])
-    print("gather blocks finished at (us):", [round((v - t0) / 100.0, 1) for v in t[16:32]])
-    print("fused launch (us from its first stamp): row block 0 start", (t[10] - t0) / 100.0, "end", (t[11] - t0) / 100.0,
-          "| gather block 0 start", (t[12] - t0) / 100.0, "tables", (t[13] - t0) / 100.0, "rows seen", (t[14] - t0) / 100.0, "finished", (t[15] - t0) / 100.0)
