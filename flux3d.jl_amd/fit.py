@@ -38,14 +38,14 @@ def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_la
         _, _, loss = mesh_losses(m, 0.0, w_lap, w_edge, base=loss1, sync=False)
     if not with_grad:
         return loss
-    if m.N == 1:
-        # one mesh: padded == packed.  Both mesh-loss adjoints in ONE gather launch (no float atomics, reusing the forward's
+    if m.verts_aliased:
+        # one mesh (or meshes of equal vertex counts): padded == packed.  Both mesh-loss adjoints in ONE gather launch (no float atomics, reusing the forward's
         # unit rows) WRITE the buffer; the chamfer adjoint and the sampling adjoint are ONE launch that scatter-adds on top
         # (the target's half of the chamfer adjoint is not needed and not computed): no memset node in the iteration
         g = mesh_losses_grad(m, 0.0, w_lap, w_edge, reuse_forward=True)
         # (round 6: ordered -- bit-reproducible -- and, when the caller hands over the optimiser's state, with its step in the
         #  same launch: the thread that finishes a vertex's gradient row applies Momentum + offset to it)
-        chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=m, draws_a=(fa, r1, r2), out_a=g.reshape(3, m.V, 1), step=step, ordered=ordered)
+        chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=m, draws_a=(fa, r1, r2), out_a=g.reshape(3, m.V, m.N), step=step, ordered=ordered)
         return loss, g
     gA, _ = chamfer_distance_grad(A, Bp, ix, iy)
     gpad = sample_points_grad(m, fa, r1, r2, gA, ordered=ordered)   # (3,Vmax,B)
@@ -110,11 +110,11 @@ class FitStepGraph:
         # one mesh and an optimiser that offers it: the Momentum launch also writes the next iteration's offset mesh and advances
         # the seed counter (two launches less per iteration); the buffer is re-wrapped per body so that nothing derived from
         # the vertices (padded form, sampling CDF) is cached across iterations
-        fused = src.N == 1 and hasattr(opt, "update_offset")
+        fused = src.verts_aliased and hasattr(opt, "update_offset")
         self._src_verts = src.dev("verts_packed")
         self.mverts = lincomb(1.0, self._src_verts, 1.0, x) if fused else None
 
-        in_launch = fused and hasattr(opt, "step_args") and ordered and step_in_launch  # (round 6) ... and the step itself rides in the last adjoint's launch
+        in_launch = fused and src.N == 1 and hasattr(opt, "step_args") and ordered and step_in_launch  # (round 6) ... and the step itself rides in the last adjoint's launch
 
         def body():
             m = src.with_verts_packed(self.mverts) if fused else None

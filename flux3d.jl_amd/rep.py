@@ -192,6 +192,8 @@ class TriMesh:
         self.V = int(self._verts_len.max())
         self.F = int(self._faces_len.max())
         self.equalised = bool(np.all(self._verts_len == self.V) and np.all(self._faces_len == self.F))
+        # padded (3,Vmax,B) and packed (3,sumV) vertex arrays are the same bytes (one mesh, or equal vertex counts): no copy between them
+        self.verts_aliased = bool(np.all(self._verts_len == self.V))
         self.valid = self._faces_len > 0
         self.offset = int(offset)
 
@@ -252,8 +254,8 @@ class TriMesh:
         if not self._device:
             return self.get_verts_padded_host()
         if "verts_padded" not in self._dev:
-            if self.N == 1:  # one mesh: (3,V) and (3,V,1) are the same bytes
-                self._dev["verts_padded"] = self._dev["verts_packed"].reshape(3, self.V, 1)
+            if self.verts_aliased:  # one mesh, or equal vertex counts: (3,sumV) and (3,V,B) are the same bytes
+                self._dev["verts_padded"] = self._dev["verts_packed"].reshape(3, self.V, self.N)
             else:
                 self._dev["verts_padded"] = self._packed_to_padded_dev(self._dev["verts_packed"])
         return self._dev["verts_padded"]
@@ -267,8 +269,8 @@ class TriMesh:
 
     def padded_to_packed_dev(self, padded):
         """_padded_to_packed (src/rep/utils.jl:159-181) on the device: (3,Vmax,B) -> (3,sumV)."""
-        if self.N == 1:
-            return padded.reshape(3, self.V)
+        if self.verts_aliased:
+            return padded.reshape(3, self.V * self.N)
         out = DeviceArray.empty((3, int(self._verts_len.sum())), np.float32)
         _lib.call("fx3d_padded_to_packed", padded.ptr, self._verts_len.ctypes.data, self.N, self.V, out.ptr,
                   current_stream().handle)
