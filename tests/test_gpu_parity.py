@@ -1339,6 +1339,27 @@ def test_knn_feature_space_wide_selection(gpu_fx, oracle, D, N, M, B, k, drop, k
     assert np.array_equal(idx.to_host(), oi) and np.array_equal(dist.to_host(), od)
 
 
+def test_c_abi_harness_runs_on_the_device(gpu_fx, tmp_path):
+    """examples/c_abi_harness.c: the reference's metric harness sizes (benchmarks/metrics.jl:17-63, A == B) called from plain C --
+    it runs, the losses are the exact zeros of identical clouds, and a forward call costs an FFI caller less than the ctypes path."""
+    import json
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "c_abi_harness")
+    libdir = os.path.dirname(gpu_fx.LIB_PATH)
+    subprocess.run([gcc, "-std=c99", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_harness.c"),
+                    "-o", exe, "-L", libdir, "-lflux3d_hip", "-Wl,-rpath," + libdir], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rows = json.loads(r.stdout)["rows"]
+    assert [row["n"] for row in rows] == [64, 256, 1024, 4096, 16384]
+    assert all(row["loss"] == 0 for row in rows)
+    assert all(0 < row["forward_us"] < row["value_and_grad_us"] for row in rows) and rows[0]["forward_us"] < 15.0
+
+
 def test_c_abi_example_runs_on_the_device(gpu_fx, oracle, tmp_path):
     """examples/c_abi_example.c (plain C against the shared library, no Python in the call path) prints the oracle's
     loss for its LCG clouds."""
