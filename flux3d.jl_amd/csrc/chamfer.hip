@@ -1465,7 +1465,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                             if constexpr (PRUNE) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
-                                    const float4 v = cs[jl0 + r < cnt ? jl0 + r : cnt - 1];
+                                    // (round 6: no clamp -- rows up to cnt_pad <= kHChunkMax lie inside the block's scratch, the ones past cnt hold
+                                    //  whatever they held and are masked below -- and the key form chosen once per wave: the exact phase issues
+                                    //  ~700 VALU per wave and pass, the SIMDs' busiest stretch; same-box A/B 43.0 -> 41.5 us kernel)
+                                    const float4 v = cs[jl0 + r];
                                     cx[r] = v.x; cy[r] = v.y; cz[r] = v.z; cid[r] = __builtin_bit_cast(int, v.w);
                                 }
                             } else if (vec && jl0 + 4 <= cnt) {
@@ -1483,13 +1486,20 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                             int ib = j0 + jl0;  // an all-+Inf run still names a real candidate (its first)
                             if constexpr (PRUNE) {  // the rows' original indices do not ascend: the run's minimum on full (distance, index) keys
                                 unsigned long long k64 = ~0ull;
+                                if (!nonfinite) {  // (wave-uniform) distances are >= 0 or +Inf: their bits are the keys
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const float cc3[3] = {cx[r], cy[r], cz[r]};
-                                    const float dd = sqd<3>(qq, cc3);
-                                    const unsigned int kd = nonfinite ? dist_key(dd) : __builtin_bit_cast(unsigned int, dd);
-                                    const unsigned long long key = ((unsigned long long)kd << 32) | (unsigned int)cid[r];
-                                    if (jl0 + r < cnt && key < k64) k64 = key;
+                                    for (int r = 0; r < 4; ++r) {
+                                        const float cc3[3] = {cx[r], cy[r], cz[r]};
+                                        const unsigned long long key = ((unsigned long long)__builtin_bit_cast(unsigned int, sqd<3>(qq, cc3)) << 32) | (unsigned int)cid[r];
+                                        if (jl0 + r < cnt && key < k64) k64 = key;
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const float cc3[3] = {cx[r], cy[r], cz[r]};
+                                        const unsigned long long key = ((unsigned long long)dist_key(sqd<3>(qq, cc3)) << 32) | (unsigned int)cid[r];
+                                        if (jl0 + r < cnt && key < k64) k64 = key;
+                                    }
                                 }
                                 kb = (unsigned int)(k64 >> 32); ib = (int)(unsigned int)k64;
                             } else
