@@ -373,9 +373,11 @@ constexpr int kHThreads = 1024;   // 16 waves share one LDS image: 1 block per C
 #endif
 constexpr int kHLT = FX3D_HLT;    // 32-candidate blocks per lane tile (lane sees 16 rows of each)
 #ifndef FX3D_HFIFO
-#define FX3D_HFIFO 4
+#define FX3D_HFIFO 5
 #endif
-constexpr int kHFifo = FX3D_HFIFO;  // lane tiles tracked per lane and pass: the smallest tile minima.  Round 5: FOUR instead of three -- a query
+constexpr int kHFifo = FX3D_HFIFO;  // minima tracked per lane and pass (round 6: of 32-candidate BLOCKS, five of them -- same-box, C2's shape:
+                                    // lane tiles x 4: uniform 42.0 us kernel, clusters A != B 69, lattice A != B 70; blocks x 4: 38.1 / 93 / 68;
+                                    // blocks x 5: 38.5 / 77 / 55; blocks x 6: 38.9 / 78 / 52).  Round 5 (lane tiles): FOUR instead of three -- a query
                                     // whose band holds four lane tiles no longer sends its wave into the retry pass (the reference harness's
                                     // collinear A == B input at n = 16384: 68.4 -> 55.0 us, a 1/16 lattice A == B at C2's shape 109 -> 88;
                                     // uniform C2 unchanged, 51.0 -> 50.5 .. 50.9 on one box: the extra v_med3 per lane tile hides under the MFMAs);
@@ -396,10 +398,18 @@ constexpr int kHFarCap = 64;      // far candidates kept on the exact side list;
 constexpr int kHTail = 64;        // a cloud of up to kHChunkMax + kHTail points stays one LDS image: the last <= 64 candidates are
                                   // compared exactly by every query (N = M = 4097 was 2.1 x N = M = 4096: two half-empty chunks,
                                   // three rounds of blocks), and <= 64 queries beyond a block's passes are one more pass of one wave
-static_assert(kHChunkMax / (32 * kHLT) <= 64, "lane-tile ids live in the six low mantissa bits of the tracked keys");
-// Tracking keys: a lane tile's minimum with the tile's id in its six low mantissa bits (one v_and_or): |key - t| < 2^-17 |t|.
-// kKeyUp turns a key into an upper bound of the value it came from (and a threshold on values into one on keys).
-constexpr float kKeyUp = 0x1.2p-17f;
+#ifndef FX3D_HBLKTRACK
+#define FX3D_HBLKTRACK 1
+#endif
+// (round 6) the minima are tracked per 32-candidate BLOCK instead of per lane tile of two: an item of the exact phase is then a
+// lane's 16 rows of one block (four runs of four candidates) instead of 32 rows -- the phase's VALU work, the SIMDs' busiest stretch,
+// halves for 2.5 more VALU per MFMA in the main loop, which pruning has made short.
+constexpr bool kHBlkTrack = FX3D_HBLKTRACK != 0;
+constexpr int kHIdBits = kHBlkTrack ? 7 : 6;
+static_assert(kHChunkMax / (32 * kHLT) <= 64, "lane-tile ids live in the six (block ids: seven) low mantissa bits of the tracked keys");
+// Tracking keys: a lane tile's (block's) minimum with its id in its kHIdBits low mantissa bits (one v_and_or): |key - t| < 2^-17 |t|
+// (2^-16).  kKeyUp turns a key into an upper bound of the value it came from (and a threshold on values into one on keys).
+constexpr float kKeyUp = kHBlkTrack ? 0x1.2p-16f : 0x1.2p-17f;
 constexpr float kPadF16 = 65504.0f;  // K slot 15: padding / far candidates get 65504 x 65504 = 4.3e9, finite and above every real
                                      // filter value (|t| <= 3 2^14 (1 + beta) + 128 S, S < 3e4): no +Inf in the image, no NaN keys
 // (PRUNE) the cells t = ux | uy << 3 | uz << 6 of the 8 x 8 x 8 sorting grid along a 3-D Hilbert curve (Skilling's transpose form, generated
@@ -1111,7 +1121,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             float tm = INFINITY, fk[kHFifo];
 #pragma unroll
             for (int s = 0; s < kHFifo; ++s) fk[s] = INFINITY;
-            const unsigned int keymask = ~63u;
+            const unsigned int keymask = ~((1u << kHIdBits) - 1u);
 
             // ---- main loop, software-pipelined by TWO 32-candidate blocks ---------------------------------------
             // Block b's MFMA is issued two steps before its 16 accumulators are folded (three accumulator sets in rotation):
@@ -1141,6 +1151,10 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 fk[0] = vmin(fk[0], key);                                                                            \
             }
 #define NN1_TRACK() { NN1_TRACK_ID(lt) ++lt; }
+            // closing a fold: per lane tile (the odd block's fold carries on from the even one's and is tracked), or per block
+#define NN1_CLOSE(ACC, ODD, LT)                                                                                      \
+            if constexpr (kHBlkTrack) { NN1_FOLD(ACC, true) NN1_TRACK_ID(2 * (LT) + (ODD)) }                           \
+            else { NN1_FOLD(ACC, !(ODD)) if (ODD) NN1_TRACK_ID(LT) }
             // one step: issue the next block into ISSUE, fold FOLD (issued two steps ago); an odd fold closes its lane tile.
             // (round 4) The fold and the tracking run at raised wave priority, the MFMA issue at the base one: among the four
             // waves of a SIMD the ones with VALU work go first and the matrix pipe drains the others' MFMAs underneath
@@ -1151,8 +1165,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             ISSUE = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, bq, zero, 0, 0, 0);                                   \
             an = pa[(OFF) * 64];                                                                                     \
             __builtin_amdgcn_s_setprio(1);                                                                           \
-            NN1_FOLD(FOLD, !(ODD))                                                                                   \
-            if (ODD) NN1_TRACK()
+            NN1_CLOSE(FOLD, ODD, lt)                                                                                 \
+            if (ODD) ++lt;
             if constexpr (!PRUNE) {
             const h8 *pa = imgp + hh * 32 + jq;
             f32x16 acc0, acc1, acc2;
@@ -1170,12 +1184,12 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             // the last 0, 2 or 4 blocks, then the two folds still pending
             if (nblk - nb == 4) {
                 NN1_STEP(acc2, acc0, 0, 0) NN1_STEP(acc0, acc1, 1, 1) NN1_STEP(acc1, acc2, 0, 2) NN1_STEP(acc2, acc0, 1, 3)
-                NN1_FOLD(acc1, true) NN1_FOLD(acc2, false) NN1_TRACK()
+                NN1_CLOSE(acc1, 0, lt) NN1_CLOSE(acc2, 1, lt)
             } else if (nblk - nb == 2) {
                 NN1_STEP(acc2, acc0, 0, 0) NN1_STEP(acc0, acc1, 1, 1)
-                NN1_FOLD(acc2, true) NN1_FOLD(acc0, false) NN1_TRACK()
+                NN1_CLOSE(acc2, 0, lt) NN1_CLOSE(acc0, 1, lt)
             } else {
-                NN1_FOLD(acc0, true) NN1_FOLD(acc1, false) NN1_TRACK()
+                NN1_CLOSE(acc0, 0, lt) NN1_CLOSE(acc1, 1, lt)
             }
             } else {
             // ---- (PRUNE) the same pipeline over a LIST of lane tiles, in two phases ----------------------------------------------
@@ -1245,8 +1259,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                 ISSUE = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, bq, zero, 0, 0, 0);                               \
                 an = NEXT;                                                                                           \
                 __builtin_amdgcn_s_setprio(1);                                                                       \
-                NN1_FOLD(FOLD, !(ODD))                                                                               \
-                if (ODD) NN1_TRACK_ID(LT)
+                NN1_CLOSE(FOLD, ODD, LT)
                 // invariant: lane tile ta is in flight (acc0, acc1), tb is the next one (the padding tile if the list is exhausted),
                 // `an` holds tb's first operand, pn -> tb
                 while (nrem >= 3) {
@@ -1272,13 +1285,13 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     NN1_PSTEP(acc0, acc1, 1, ta, pc[0])
                     NN1_PSTEP(acc1, acc2, 0, tb, pc[64])
                     NN1_PSTEP(acc2, acc0, 1, tb, pc[64])
-                    NN1_FOLD(acc1, true) NN1_FOLD(acc2, false) NN1_TRACK_ID(tc)
+                    NN1_CLOSE(acc1, 0, tc) NN1_CLOSE(acc2, 1, tc)
                 } else if (nrem == 1) {
                     NN1_PSTEP(acc2, acc0, 0, ta, pn[64])
                     NN1_PSTEP(acc0, acc1, 1, ta, pn[64])
-                    NN1_FOLD(acc2, true) NN1_FOLD(acc0, false) NN1_TRACK_ID(tb)
+                    NN1_CLOSE(acc2, 0, tb) NN1_CLOSE(acc0, 1, tb)
                 } else {
-                    NN1_FOLD(acc0, true) NN1_FOLD(acc1, false) NN1_TRACK_ID(ta)
+                    NN1_CLOSE(acc0, 0, ta) NN1_CLOSE(acc1, 1, ta)
                 }
 #undef NN1_PSTEP
 #undef NN1_NEXT
@@ -1289,6 +1302,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             }
             }
 #undef NN1_STEP
+#undef NN1_CLOSE
 #undef NN1_TRACK
 #undef NN1_TRACK_ID
 #undef NN1_FOLD
@@ -1399,7 +1413,8 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                             if (bal) {
                                 const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
                                                          __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
-                                if (qual) items[pos] = (unsigned short)(((unsigned int)jq << 7) | ((unsigned int)hh << 6) | (__builtin_bit_cast(unsigned int, ft[s]) & 63u));
+                                if (qual) items[pos] = (unsigned short)(((unsigned int)jq << (kHIdBits + 1)) | ((unsigned int)hh << kHIdBits) |
+                                                                        (__builtin_bit_cast(unsigned int, ft[s]) & ((1u << kHIdBits) - 1u)));
                                 nitems += __builtin_popcountll(bal);  // <= 64 * kHFifo == kHItemCap
                             }
                         }
@@ -1413,21 +1428,25 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                         const h8 *pb = imgp + hh * 32 + jq;
                         if (!runs) {
 #pragma unroll 1
-                            for (; lt2 < nlt && nitems <= kHItemCap - 64; ++lt2) {
+                            for (; lt2 < nlt && nitems <= kHItemCap - 64 * kHLT; ++lt2) {
                                 float t2 = INFINITY;
 #pragma unroll
                                 for (int bb = 0; bb < kHLT; ++bb) {
                                     const f32x16 av = __builtin_amdgcn_mfma_f32_32x32x16_f16(pb[(lt2 * kHLT + bb) * 64], bq, zero, 0, 0, 0);
+                                    if (kHBlkTrack) t2 = INFINITY;   // items are blocks
 #pragma unroll
                                     for (int r = 0; r < 16; r += 2) t2 = min3f(t2, av[r], av[r + 1]);
-                                }
-                                const bool qual = !usable || t2 <= thr1;
-                                const unsigned long long bal = __ballot(qual);
-                                if (bal) {
-                                    const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
-                                                             __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
-                                    if (qual) items[pos] = (unsigned short)(((unsigned int)jq << 7) | ((unsigned int)hh << 6) | (unsigned int)lt2);
-                                    nitems += __builtin_popcountll(bal);
+                                    if (kHBlkTrack || bb == kHLT - 1) {
+                                        const bool qual = !usable || t2 <= thr1;
+                                        const unsigned long long bal = __ballot(qual);
+                                        if (bal) {
+                                            const int pos = nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0));
+                                            const unsigned int id = kHBlkTrack ? (unsigned int)(lt2 * kHLT + bb) : (unsigned int)lt2;
+                                            if (qual) items[pos] = (unsigned short)(((unsigned int)jq << (kHIdBits + 1)) | ((unsigned int)hh << kHIdBits) | id);
+                                            nitems += __builtin_popcountll(bal);
+                                        }
+                                    }
                                 }
                             }
                         } else
@@ -1452,14 +1471,15 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_wave_barrier();
                     if (!runs) {
-                    const int ntask = nitems * (kHLT * 4);
+                    constexpr int kRunsPerItem = kHBlkTrack ? 4 : kHLT * 4;
+                    const int ntask = nitems * kRunsPerItem;
                     for (int t0 = 0; t0 < ntask; t0 += 64) {
                         const int t = t0 + lane;
                         if (t < ntask) {
-                            const unsigned int it = items[t / (kHLT * 4)];
-                            const int run = t % (kHLT * 4);
-                            const int qs = it >> 7, ih = (it >> 6) & 1, tl = it & 63;
-                            const int jl0 = (tl * kHLT + (run >> 2)) * 32 + 8 * (run & 3) + 4 * ih;
+                            const unsigned int it = items[t / kRunsPerItem];
+                            const int run = t % kRunsPerItem;
+                            const int qs = it >> (kHIdBits + 1), ih = (it >> kHIdBits) & 1, tl = it & ((1u << kHIdBits) - 1u);
+                            const int jl0 = kHBlkTrack ? tl * 32 + 8 * run + 4 * ih : (tl * kHLT + (run >> 2)) * 32 + 8 * (run & 3) + 4 * ih;
                             float cx[4], cy[4], cz[4];
                             [[maybe_unused]] int cid[4];
                             if constexpr (PRUNE) {
