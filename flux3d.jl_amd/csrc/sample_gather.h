@@ -5,18 +5,20 @@
 //     inner(f, t) = 0 + sum over the samples k drawn on f, k ASCENDING, of  w_t(k) * gs[k]              (Float32, unfused)
 // -- the order in which oracle/flux3d_oracle.c: fx3d_oracle_sample_points_bwd adds, so the result is the oracle's bit for bit and
 // the same from run to run (round 5 scattered the 9 products of every sample with global float atomics: arrival order).
-// One 1024-thread block per mesh, everything between the first and the last global access in LDS: the draws are bucketed by
-// face with a counting sort (integer atomics, a block scan, placement from the back of every list), every list is put in
-// ascending order in place (up to eight draws: insertion sort by the face's thread; longer: a wave through a bitmap over the
-// sample ids), then (gs, sqrt(r1), r2) of every draw is STAGED in list order -- one round trip to memory for the whole mesh,
-// every load of it in flight at once -- and a thread per vertex walks its (face, corner) entries (fx3d_build_vertex_faces: a CSR
-// over the vertices, entries face * 4 + corner ascending) over contiguous staged rows.  (A first version gathered gs / r1 / r2
-// from memory per (entry, draw): ~22 dependent round trips per thread, 70 us for one mesh of 5000 draws; staged: ~9.)
-// The vertex's thread may go straight on to the optimiser step (SgStep: Flux.Optimise.Momentum + offset,
-// examples/fit_mesh.jl:87-88,108-110) -- it owns the finished gradient row.  What fits: 4 F + 22.25 n bytes of LDS <= kSgMaxLds
-// (n <= ~6200 draws at the 5120 faces of the tutorial's sphere; the reference's default is 5000) -- other meshes keep the scatter.
-// Included by sampler.hip (fx3d_sample_points_bwd) and chamfer_bwd.hip (fx3d_chamfer_sampled_bwd: the last block of a mesh's
-// chamfer adjoint runs this on the rows its siblings published).
+// sg_parts(V) 1024-thread blocks per mesh (each builds the tables, each finishes a share of the vertices), everything between the
+// first and the last global access in LDS: the draws are bucketed by face with a counting sort (integer atomics, a block scan,
+// placement from the back of every list), every list is put in ascending order in place (up to eight draws: a sorting network in
+// the face's thread; longer: a wave through a bitmap over the sample ids), (gs, sqrt(r1), r2) of every draw is STAGED with coalesced
+// loads -- one round trip to memory for the whole mesh --, faces of more than eight draws get their nine sums from nine lanes each,
+// a thread per (vertex, corner) ENTRY of the vertex -> face table (fx3d_build_vertex_faces: a CSR over the vertices, entries
+// face * 4 + corner ascending) forms inner(f, t) into LDS and a thread per vertex adds its entries in order.  The vertex's thread
+// may go straight on to the optimiser step (SgStep: Flux.Optimise.Momentum + offset, examples/fit_mesh.jl:87-88,108-110) -- it owns
+// the finished gradient row.  What fits: 4 F + 22.25 n + 18 K bytes of LDS <= kSgMaxLds (n <= ~5300 draws at the 5120 faces of the
+// tutorial's sphere; the reference's default is 5000) -- other meshes keep the scatter.  (Measured on the way, one mesh of 5000 draws:
+// gs / r1 / r2 gathered from memory per (entry, draw) 70 us; staged in list order 26; staged by draw id, one block 20; sixteen
+// blocks 13 on an even mesh but 38 inside the fit loop, whose grown faces draw 20 - 50 each: table of the big faces 28, a thread
+// per entry 19.)
+// Included by sampler.hip (fx3d_sample_points_bwd; the kernel) and chamfer_bwd.hip (fx3d_chamfer_sampled_bwd's second launch).
 #pragma once
 #include "fx3d_common.h"
 
@@ -57,8 +59,9 @@ struct SgStep {                 // optional optimiser step by the vertex's threa
     unsigned long long inc;
 };
 
+constexpr int kSgInnerCap = 1536;   // (vertex, corner) entries whose sums a block parks in LDS at a time (a block's share of a mesh: ~1000)
 struct SgLayout {
-    size_t cnt, start, list, big, wsum, staged, total;
+    size_t cnt, start, list, big, wsum, staged, inner, total;
     int bmwords;
 };
 __host__ __device__ inline SgLayout sg_layout(int F, int n) {
@@ -73,6 +76,7 @@ __host__ __device__ inline SgLayout sg_layout(int F, int n) {
     L.staged = o;  // kSgRow floats per draw, in list order; the waves' bitmaps (long lists) live here before the staging
     const size_t st = sizeof(float) * kSgRow * (size_t)n, bm = sizeof(unsigned int) * (size_t)kSgWaves * (size_t)L.bmwords;
     o += st > bm ? st : bm;
+    L.inner = o;  o += sizeof(float) * 3 * (size_t)kSgInnerCap;
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }
@@ -278,93 +282,103 @@ __device__ __forceinline__ void sg_finish(unsigned char *lds, const SgMesh &m, c
     }
     __syncthreads();
     SG_STAMP(5);
-    // (6) a thread per vertex: its (face, corner) entries in order, each over the face's staged rows (ascending draws); then the
-    //     row -- and, if asked, the optimiser step on it.  kV vertices of a thread at a time, so that their table reads are two
-    //     round trips (row pointers, then the first entries) instead of two per vertex.
-    constexpr int kV = 3, kE = 8;
-    for (int v0 = vb + tid; v0 < ve; v0 += kV * kSgThreads) {
-        int e0[kV], e1[kV];
-        P3 acc[kV];
-#pragma unroll
-        for (int u = 0; u < kV; ++u) {
-            const int v = v0 + u * kSgThreads;
-            const bool ok = v < ve;
-            e0[u] = ok ? m.vf_rowptr[v] : 0;
-            e1[u] = ok ? m.vf_rowptr[v + 1] : 0;
-            acc[u] = P3{0.0f, 0.0f, 0.0f};
-            if (ok && m.accumulate) acc[u] = *reinterpret_cast<const P3 *>(m.gverts + 3 * (size_t)v);
+    // (5b) faces with more than kSgSmall draws (a handful once a fitted mesh has grown uneven: its large faces draw 20 - 50 of 5000):
+    //      their nine sums -- (corner, coordinate) over the face's draws in order -- by nine lanes each, seven faces per wave at a time,
+    //      parked in the bytes of the (dead) per-face counters; the face's first list slot then names its row of the table.  Walked
+    //      as ordinary entries they made the waves of their three vertices run as many eight-entry steps as the face has draws
+    //      (37 us in the fit loop's graph against 13 on an even mesh).
+    {
+        float *bigin = reinterpret_cast<float *>(lds + L.cnt);
+        const int capb = (int)(sizeof(unsigned int) * (size_t)((m.F + 2) / 2) / (9 * sizeof(float)));
+        const unsigned short *big = reinterpret_cast<const unsigned short *>(lds + L.big);
+        const unsigned int *wsum = reinterpret_cast<const unsigned int *>(lds + L.wsum);
+        int nb = (int)wsum[kSgWaves];
+        nb = nb < capb ? nb : capb;  // (more long lists than the table holds: the rest are walked the slow way)
+        unsigned short *listw = reinterpret_cast<unsigned short *>(lds + L.list);
+        const int lane = tid & 63, wv = tid >> 6, grp = lane / 9, sub = lane % 9;
+        for (int b0 = wv * 7; b0 < nb; b0 += kSgWaves * 7) {
+            const int b = b0 + grp;
+            const bool on = grp < 7 && b < nb;
+            const int f = on ? (int)big[b] : 0;
+            const int s0 = start[f], c = on ? (int)start[f + 1] - s0 : 0;
+            const int t = sub / 3, d = sub % 3;
+            float acc = 0.0f;
+            for (int i = 0; i < c; ++i) {
+                const float *row = staged + (size_t)kSgRow * listw[s0 + i];
+                const float uu = row[3], vv = row[4];
+                const float w = t == 0 ? 1.0f - uu : (t == 1 ? uu * (1.0f - vv) : uu * vv);
+                acc = acc + w * row[d];
+            }
+            if (on) bigin[9 * b + sub] = acc;
+            sg_wave_lds_sync();  // (every lane is done with the lists of this sweep's faces)
+            if (on && sub == 0) listw[s0] = (unsigned short)(0x8000u | (unsigned int)b);
         }
-#ifdef FX3D_SG_PROBE
-        if (v0 == vb + tid) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SG_STAMP(7); }
-#endif
-        unsigned int ent[kV][kE];
-#pragma unroll
-        for (int u = 0; u < kV; ++u)
-#pragma unroll
-            for (int q = 0; q < kE; ++q) ent[u][q] = e0[u] + q < e1[u] ? (unsigned int)m.vf_ent[e0[u] + q] : 0u;
-#ifdef FX3D_SG_PROBE
-        if (v0 == vb + tid) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SG_STAMP(8); }
-#endif
-        // kE entries of a vertex are walked TOGETHER, draw i of each in one step: the LDS reads of a step (list slot -> staged row)
-        // are two dependent round trips whatever the number of entries, and a wave runs as many steps as its longest list -- entry
-        // by entry that chain was paid ~5 times per entry (10 us for 15 entries per thread)
-        auto walk = [&](const unsigned int (&en)[kE], int cnt, P3 &a) {
-            int s0[kE], c[kE], t[kE], cmax = 0;
-            float ax[kE], ay[kE], az[kE];
-#pragma unroll
-            for (int q = 0; q < kE; ++q) {
-                const int f = (int)(en[q] >> 2);
-                t[q] = (int)(en[q] & 3u);
-                s0[q] = start[f];
-                c[q] = q < cnt ? (int)start[f + 1] - s0[q] : 0;
-                cmax = c[q] > cmax ? c[q] : cmax;
-                ax[q] = 0.0f; ay[q] = 0.0f; az[q] = 0.0f;
-            }
-            for (int i = 0; i < cmax; ++i) {
-                unsigned int k[kE];
-#pragma unroll
-                for (int q = 0; q < kE; ++q) k[q] = list[i < c[q] ? s0[q] + i : 0];
-#pragma unroll
-                for (int q = 0; q < kE; ++q) {
-                    const float *row = staged + (size_t)kSgRow * k[q];
-                    const float uu = row[3], vv = row[4];
-                    const float w = t[q] == 0 ? 1.0f - uu : (t[q] == 1 ? uu * (1.0f - vv) : uu * vv);
-                    const float nx = ax[q] + w * row[0], ny = ay[q] + w * row[1], nz = az[q] + w * row[2];
-                    const bool on = i < c[q];  // (a select, not a product with 0: a non-finite row of another draw must not leak in)
-                    ax[q] = on ? nx : ax[q]; ay[q] = on ? ny : ay[q]; az[q] = on ? nz : az[q];
+    }
+    __syncthreads();
+    // (6) a thread per (vertex, corner) ENTRY forms inner(f, t) over the face's staged rows (ascending draws) and parks it in LDS; a
+    //     thread per vertex then adds its entries in order, writes the row and, if asked, applies the optimiser step to it.  (A thread
+    //     per vertex walking eight entries together cost a wave ~130 instructions per step for as many steps as its longest list:
+    //     12 us on an even mesh, 28 us once the fitted mesh's faces had grown uneven; per entry a step is ~20 instructions and all
+    //     sixteen waves share the entries.)  Vertices in batches of kSgThreads, a batch's entries in chunks of kSgInnerCap.
+    {
+        float *inner = reinterpret_cast<float *>(lds + L.inner);
+        const float *bigin = reinterpret_cast<const float *>(lds + L.cnt);
+        for (int vb0 = vb; vb0 < ve; vb0 += kSgThreads) {
+            const int vend = vb0 + kSgThreads < ve ? vb0 + kSgThreads : ve;
+            const int v = vb0 + tid;
+            const bool ok = v < vend;
+            const int e0 = ok ? m.vf_rowptr[v] : 0, e1 = ok ? m.vf_rowptr[v + 1] : 0;
+            const int E_lo = m.vf_rowptr[vb0], E_hi = m.vf_rowptr[vend];
+            P3 a{0.0f, 0.0f, 0.0f};
+            if (ok && m.accumulate) a = *reinterpret_cast<const P3 *>(m.gverts + 3 * (size_t)v);
+            for (int ec = E_lo; ec < E_hi; ec += kSgInnerCap) {
+                const int eend = ec + kSgInnerCap < E_hi ? ec + kSgInnerCap : E_hi;
+                for (int e = ec + tid; e < eend; e += kSgThreads) {
+                    const unsigned int en = (unsigned int)m.vf_ent[e];
+                    const int f = (int)(en >> 2), t = (int)(en & 3u);
+                    const int s0 = start[f];
+                    int c = (int)start[f + 1] - s0;
+                    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+                    if (c > kSgSmall) {  // a face of many draws: its sums are in the table (5b) unless the table was full
+                        const unsigned int slot = list[s0];
+                        if (slot & 0x8000u) {
+                            const float *r9 = bigin + 9 * (size_t)(slot & 0x7fffu) + 3 * t;
+                            ax = r9[0]; ay = r9[1]; az = r9[2];
+                            c = 0;
+                        }
+                    }
+                    for (int i = 0; i < c; ++i) {
+                        const float *row = staged + (size_t)kSgRow * list[s0 + i];
+                        const float uu = row[3], vv = row[4];
+                        const float w = t == 0 ? 1.0f - uu : (t == 1 ? uu * (1.0f - vv) : uu * vv);
+                        ax = ax + w * row[0]; ay = ay + w * row[1]; az = az + w * row[2];
+                    }
+                    float *o = inner + 3 * (size_t)(e - ec);
+                    o[0] = ax; o[1] = ay; o[2] = az;
                 }
+                __syncthreads();
+                {
+                    const int lo = e0 > ec ? e0 : ec, hi = e1 < eend ? e1 : eend;
+                    for (int e = lo; e < hi; ++e) {
+                        const float *o = inner + 3 * (size_t)(e - ec);
+                        a.x = a.x + o[0]; a.y = a.y + o[1]; a.z = a.z + o[2];
+                    }
+                }
+                __syncthreads();  // (the next chunk, or the next batch of vertices, overwrites the sums)
             }
+            if (ok) {
+                *reinterpret_cast<P3 *>(m.gverts + 3 * (size_t)v) = a;
+                if (st.vel) {  // fx3d_momentum_step_offset's arithmetic (mesh.hip: momentum_offset_kernel)
+                    const float g3[3] = {a.x, a.y, a.z};
 #pragma unroll
-            for (int q = 0; q < kE; ++q)
-                if (q < cnt) { a.x = a.x + ax[q]; a.y = a.y + ay[q]; a.z = a.z + az[q]; }
-        };
-#pragma unroll
-        for (int u = 0; u < kV; ++u) {
-            const int v = v0 + u * kSgThreads;
-            if (v >= ve) continue;
-            const int deg = e1[u] - e0[u];
-            walk(ent[u], deg < kE ? deg : kE, acc[u]);
-            for (int eb = e0[u] + kE; eb < e1[u]; eb += kE) {  // (vertices of more than eight corners)
-                unsigned int more[kE];
-#pragma unroll
-                for (int q = 0; q < kE; ++q) more[q] = eb + q < e1[u] ? (unsigned int)m.vf_ent[eb + q] : 0u;
-                walk(more, e1[u] - eb < kE ? e1[u] - eb : kE, acc[u]);
-            }
-#ifdef FX3D_SG_PROBE
-            if (v0 == vb + tid && u == kV - 1) SG_STAMP(9);
-#endif
-            const P3 a = acc[u];
-            *reinterpret_cast<P3 *>(m.gverts + 3 * (size_t)v) = a;
-            if (st.vel) {  // fx3d_momentum_step_offset's arithmetic (mesh.hip: momentum_offset_kernel)
-                const float g3[3] = {a.x, a.y, a.z};
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const size_t i = 3 * (size_t)v + d;
-                    const float vn = (st.rho * st.vel[i]) + (-st.eta * g3[d]);
-                    st.vel[i] = vn;
-                    const float xn = (1.0f * st.x[i]) + (1.0f * vn);
-                    st.x[i] = xn;
-                    st.out[i] = (1.0f * st.base[i]) + (1.0f * xn);
+                    for (int d = 0; d < 3; ++d) {
+                        const size_t i = 3 * (size_t)v + d;
+                        const float vn = (st.rho * st.vel[i]) + (-st.eta * g3[d]);
+                        st.vel[i] = vn;
+                        const float xn = (1.0f * st.x[i]) + (1.0f * vn);
+                        st.x[i] = xn;
+                        st.out[i] = (1.0f * st.base[i]) + (1.0f * xn);
+                    }
                 }
             }
         }

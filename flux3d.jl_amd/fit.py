@@ -22,7 +22,7 @@ def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_la
     added to both sampling seeds by the kernels (FitStepGraph advances it between replays).  ``step``: see
     :func:`chamfer_sampled_grad` (single source mesh): the optimiser step rides in the last adjoint's launch.
     ``ordered`` (default): the sampling adjoint without float atomics -- the gradient is bit-reproducible (the oracle's);
-    ``ordered=False``: the scatter with float atomics, ~30 us per call faster on one mesh of 5000 draws."""
+    ``ordered=False``: the scatter with float atomics, ~12 us per call faster on one mesh of 5000 draws (slower at eight)."""
     if m is None:  # (FitStepGraph passes the offset mesh the previous iteration's optimiser step already wrote)
         m = offset(src, x)
     s1 = None if seed is None else seed
@@ -94,14 +94,13 @@ class FitStepGraph:
     (``float(step.loss.item())`` after ``synchronize()``): the only host round trip.  ``x`` belongs to the graph while
     it is in use: after an external write to it call :meth:`resync`.
 
-    ``ordered`` (round 6): the sampling adjoint without float atomics -- every vertex's sum in a fixed order, the gradient the
-    oracle's bit for bit and the same on every replay (as the reference's CPU adjoint is), with the optimiser step in the
-    gather's launch (``step_in_launch``).  It costs ~30 us per iteration on one mesh of 5000 draws (the draws are bucketed by
-    face on a few CUs, 7 us, and walked behind the rows instead of scattered while they are formed), which is why the default
-    replay keeps the scatter: 80 against 112 us per iteration on the tutorial's pair (bench.py ``graph_replay`` /
-    ``graph_replay_ordered``)."""
+    ``ordered`` (round 6, the default): the sampling adjoint without float atomics -- every vertex's sum in a fixed order, the
+    gradient the oracle's bit for bit and the same on every replay (as the reference's CPU adjoint is), with the optimiser step in
+    the gather's launch (``step_in_launch``).  ``ordered=False``: the rows are scattered with float atomics while they are formed
+    (sums in arrival order): 73 against 85 us per iteration on the tutorial's pair, 109 against 106 at eight meshes (bench.py
+    ``graph_replay`` / ``graph_replay_scatter``)."""
 
-    def __init__(self, x, src, tgt, opt, num_samples=5000, seed=0x5EED0C3, w_lap=0.1, w_edge=1.0, ordered=False, step_in_launch=True):
+    def __init__(self, x, src, tgt, opt, num_samples=5000, seed=0x5EED0C3, w_lap=0.1, w_edge=1.0, ordered=True, step_in_launch=True):
         self.x, self.opt = x, opt
         self.stream = Stream.create()
         self.counter = DeviceArray.zeros((1,), np.uint64)

@@ -154,7 +154,7 @@ def chamfer_sampled_grad(A, B, idx_a, idx_b, mesh_a=None, draws_a=None, mesh_b=N
     ``draws_*`` = (face_idx, r1, r2) of :func:`sample_points` (``return_draws=True``), ``idx_*`` the forward's neighbour indices.
     A mesh that is None is skipped.  ``out_*``: (3,Vmax,B) device arrays the gradient is ADDED to (default: fresh).
     ``ordered`` (default): no float atomics -- every vertex's sum in a fixed order, the same bits on every run (meshes whose draws
-    fit one CU's LDS -- ~6200 draws at 5120 faces --, otherwise, or ``ordered=False``, the float-atomic scatter).
+    fit one CU's LDS -- ~5300 draws at 5120 faces --, otherwise, or ``ordered=False``, the float-atomic scatter).
     ``step`` = (rho, eta, vel, params, base, out, counter, inc): the Momentum step + offset of the fit_mesh loop applied to
     ``mesh_a``'s finished gradient rows in the same launch (one mesh, ordered form).  Returns (g_a, g_b) (None for a skipped side)."""
     x, y = _as_dev_points(A), _as_dev_points(B)

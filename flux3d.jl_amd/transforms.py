@@ -149,7 +149,7 @@ def sample_points_grad(m, face_idx, r1, r2, gout, out=None, ordered=True):
     """Adjoint of sample_points w.r.t. the padded verts for fixed draws: device (3,Vmax,B).
     ``out``: add into this (3,Vmax,B) array instead of starting from zero (no memset node).
     ``ordered`` (default): the atomic-free form -- every vertex's sum in a fixed order, bit-identical to the oracle's adjoint
-    and from run to run (meshes whose draws fit one CU's LDS: up to ~6200 draws at 5120 faces; larger ones, or ``ordered=False``:
+    and from run to run (meshes whose draws fit one CU's LDS: up to ~5300 draws at 5120 faces; larger ones, or ``ordered=False``:
     float atomics)."""
     n, B = face_idx.shape
     g = DeviceArray.empty((3, m.V, m.N), np.float32) if out is None else out

@@ -363,7 +363,7 @@ FX3D_API fx3d_status fx3d_sample_points_draw_pair(const float *verts0, int32_t V
  * accumulate != 0 adds to it (this and the two mesh-loss adjoints then sum into one gradient buffer: the fit_mesh
  * objective's three terms without separate buffers, memsets and a final sum).
  * ORDERED form (vf_rowptr (Vmax+1,B) / vf_ent (3 Fmax,B): device copies of fx3d_build_vertex_faces' tables; meshes whose draws
- * and tables fit one CU's LDS -- 4 Fmax + 22.25 n bytes <= 156 KB, i.e. up to ~6200 draws at 5120 faces (the reference's default is
+ * and tables fit one CU's LDS -- 4 Fmax + 22.25 n + 18 K bytes <= 156 KB, i.e. up to ~5300 draws at 5120 faces (the reference's default is
  * 5000); fx3d_sample_points_bwd_ordered answers for a shape): g[v] = base[v] + sum over the (face, corner) pairs holding v,
  * ascending, of (0 + sum over the face's draws k, ascending, of w_corner(k) * gout[k]) in unfused Float32 -- no float atomics, the
  * same bits on every run (one block per mesh: draws bucketed by face and staged in LDS).
