@@ -627,14 +627,16 @@ def main():
         "note": "bound = the f16 matrix pipe.  achieved = the ALGORITHMIC f16 flops of the launch (SURVEY.md 8(d), MFMA clause: "
                 "2*(2*B*N*M)*K with K = 16, i.e. one v_mfma_f32_32x32x16_f16 per 32 x 32 pairs and direction) / the kernel's average "
                 "duration in this run (HIP events on its stream); peak = 2500 TF dense f16; frac = achieved / peak.  The kernel does "
-                "NOT execute all of them since round 6: candidates lie in the LDS image in Morton order, queries are taken in the "
-                "same order, and a wave runs the filter only over the lane tiles whose bounding box can hold a nearest neighbour "
-                "of one of its 32 queries (~35 % of them on uniform clouds; results bit-identical) -- executed_f16_flops_per_launch "
+                "NOT execute all of them since round 6: candidates lie in the LDS image along a Hilbert curve through an 8^3 grid, queries "
+                "are taken in the same order, and a wave runs the filter only over the lane tiles whose bounding box can hold a nearest "
+                "neighbour of one of its 32 queries (22 % of them on uniform clouds; results bit-identical) -- executed_f16_flops_per_launch "
                 "and mfma_pipe_frac (busy cycles per kernel cycle at 2.4 GHz) are what the matrix cores really do (PMC, "
                 "profiles/pmc_latest.json).  Why skipping and not a better schedule: main_loop_issue_bound -- tools/ubench_overlap.hip "
                 "(ISA-checked, profiles/r06_ubench_overlap.txt) shows the filter loop at the SIMD's VALU-issue bound for its "
-                "instruction mix (4.25 cycles per VALU + ~13 per MFMA issue; 10.7 VALU per MFMA => 58.8 cycles per tile, the pipe "
-                "busy 0.55 of the loop) under every schedule tried.  "
+                "instruction mix (4.25 cycles per VALU + ~13 per MFMA issue; 10.7 VALU per MFMA in the table's loop => 58.8 cycles per tile, "
+                "the pipe busy 0.55 of the loop; the shipped loop tracks minima per 32-candidate block: 13.2 VALU per MFMA) under every "
+                "schedule tried.  The whole kernel is VALU-issue bound (3 490 VALU per wave, SQ_INSTS_VALU): DESIGN.md 3.1.  traffic: 20.5 MB "
+                "of it are the blocks' scratch rows of the pruning (written once, read back from L2), not re-reads of the clouds.  "
                 "algorithmic_fp32_over_valu_peak is a NAMED EXTRA, not the fraction of the bound: the reference's exact Float32 "
                 "form (16 flop per pair, both directions) / time against the fp32 vector peak; it exceeds 1 because the kernel "
                 "does not execute those flops.  achieved_hbm / hbm_frac: algorithmic bytes / time against 8 TB/s (BASELINE.json "
