@@ -106,16 +106,6 @@ __device__ __forceinline__ unsigned int sg_wave_scan_incl(unsigned int v) {
     v += sg_dpp_zero<0x143, 0xC>(v);
     return v;
 }
-// SC1: read gs with agent-scope loads (rows written by OTHER blocks of this launch without an acquire on this side).  The fused
-// adjoint does NOT use it: 15 000 four-byte sc1 loads per gather block each went to memory on their own (the staging took ~15 us);
-// its gather blocks take ONE agent-scope acquire after the rows' counter is full and then read plain 12-byte rows (the guide's
-// "write-through payload, relaxed poll, one acquire, plain loads" hand-off).
-template <bool SC1>
-__device__ __forceinline__ float sg_ld(const float *p) {
-    if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *p;
-}
-
 // All kSgThreads threads of a block call these together (they synchronise).  `lds`: sg_layout(m.F, m.n).total bytes.
 // sg_tables: phases (0) - (4), the draws bucketed by face and every list in ascending order -- reads face_idx only.
 __device__ __forceinline__ void sg_tables(unsigned char *lds, const SgMesh &m) {
@@ -243,7 +233,6 @@ __device__ __forceinline__ void sg_tables(unsigned char *lds, const SgMesh &m) {
 
 // sg_finish: phases (5) - (6) for the vertices [vb, ve) of the mesh -- a mesh's vertices may be shared out over several blocks
 // (each with tables of its own: building them is ~7 us of one CU's time, walking 2500 vertices 12 us).
-template <bool SC1>
 __device__ __forceinline__ void sg_finish(unsigned char *lds, const SgMesh &m, const SgStep &st, int vb, int ve) {
     const int tid = threadIdx.x;
     const SgLayout L = sg_layout(m.F, m.n);
@@ -262,12 +251,8 @@ __device__ __forceinline__ void sg_finish(unsigned char *lds, const SgMesh &m, c
             for (int u = 0; u < kU; ++u) {
                 const int k = k0 + u * kSgThreads;
                 const size_t kk = (size_t)(k < n ? k : k0);
-                if constexpr (SC1) {
-                    gx[u] = sg_ld<SC1>(m.gs + 3 * kk); gy[u] = sg_ld<SC1>(m.gs + 3 * kk + 1); gz[u] = sg_ld<SC1>(m.gs + 3 * kk + 2);
-                } else {
-                    const P3 t3 = *reinterpret_cast<const P3 *>(m.gs + 3 * kk);
-                    gx[u] = t3.x; gy[u] = t3.y; gz[u] = t3.z;
-                }
+                const P3 t3 = *reinterpret_cast<const P3 *>(m.gs + 3 * kk);
+                gx[u] = t3.x; gy[u] = t3.y; gz[u] = t3.z;
                 a1[u] = m.r1[kk]; a2[u] = m.r2[kk];
             }
 #pragma unroll

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(sg::kSgThreads) void sample_bwd_gather_kernel(
     int vb, ve;
     sg::sg_part_range(Vmax, parts, j, vb, ve);
     sg::sg_tables(sg_lds, m);
-    sg::sg_finish<false>(sg_lds, m, step, vb, ve);
+    sg::sg_finish(sg_lds, m, step, vb, ve);
 }
 
 int grid_for(long long n) {

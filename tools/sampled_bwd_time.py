@@ -54,6 +54,5 @@ if os.environ.get("FX3D_HIP_LIB", "").endswith("sgprobe.so"):   # a -DFX3D_SG_PR
     buf = (C.c_uint64 * 16)()
     _lib.load().fx3d_debug_sg_probe(buf)
     t = list(buf)[:10]
-    print("gather phases (us): zero+count, scan, place, sort, stage, vertices:", [round((t[i + 1] - t[i]) / 100.0, 2) for i in range(6)], "total", (t[6] - t[0]) / 100.0)
-    print("vertex phase, thread 0 (us from its start): row pointers", (t[7] - t[5]) / 100.0, "entries loaded", (t[8] - t[5]) / 100.0, "walked", (t[9] - t[5]) / 100.0, "end", (t[6] - t[5]) / 100.0)
+    print("gather phases (us): zero+count, scan, place, sort, stage, big faces + entries + vertices:", [round((t[i + 1] - t[i]) / 100.0, 2) for i in range(6)], "total", (t[6] - t[0]) / 100.0)
 
