@@ -90,6 +90,19 @@ def mesh_case(rng):
                                                  m._faces_len, n, seed, return_draws=True)
     ok = ok and np.array_equal(fi.to_host(), efi) and np.array_equal(r1.to_host(), er1) and np.array_equal(r2.to_host(), er2)
     ok = ok and np.array_equal(out.to_host(), eo)
+    # (round 6) the ordered sampling adjoint: bit for bit the oracle's fixed-order sums, alone and behind the chamfer adjoint's rows
+    gs = np.asfortranarray(rng.standard_normal((3, n, m.N)).astype(np.float32))
+    fp0 = m.get_faces_padded().astype(np.int64) - 1
+    base = np.asfortranarray(rng.standard_normal((3, m.V, m.N)).astype(np.float32)) if rng.random() < 0.5 else None
+    dev_base = fx.gpu(base.copy(order="F")) if base is not None else None
+    g = fx.sample_points_grad(m, fi, r1, r2, gs, out=dev_base)
+    ok = ok and np.array_equal(g.to_host(), orc.sample_points_bwd(fp0, m._faces_len, m.V, efi, er1, er2, gs, base=base))
+    if n > 1:
+        y = fx.gpu(np.asfortranarray(rng.standard_normal((3, n, m.N)).astype(np.float32)))
+        _, ix, iy = fx.chamfer_distance(out, y, return_indices=True)
+        ga, _ = fx.chamfer_sampled_grad(out, y, ix, iy, mesh_a=m, draws_a=(fi, r1, r2), w1=0.8, w2=1.2)
+        oga, _ = orc.chamfer_bwd(eo, y.to_host(), ix.to_host(), iy.to_host(), 0.8, 1.2, 1.0)
+        ok = ok and np.array_equal(ga.to_host(), orc.sample_points_bwd(fp0, m._faces_len, m.V, efi, er1, er2, oga))
     return ok, f"mesh batch of {m.N} (V={m.V} F={m.F}) n={n} seed={seed}"
 
 
