@@ -10,7 +10,8 @@ import numpy as np
 
 from . import _lib
 from .device import DeviceArray, Graph, Stream, current_stream, stream
-from .metrics import _chamfer_points, chamfer_distance_grad, chamfer_sampled_grad, mesh_losses, mesh_losses_grad
+from .metrics import (_chamfer_points, chamfer_distance_grad, chamfer_sampled_grad, mesh_losses, mesh_losses_grad,
+                      sampling_adjoint_is_ordered)
 from .transforms import lincomb, offset, sample_points_grad, sample_points_pair
 
 
@@ -113,6 +114,7 @@ class FitStepGraph:
         self._src_verts = src.dev("verts_packed")
         self.mverts = lincomb(1.0, self._src_verts, 1.0, x) if fused else None
 
+        ordered = bool(ordered) and sampling_adjoint_is_ordered(src, num_samples)  # (more draws than the ordered form stages: the scatter)
         in_launch = fused and src.N == 1 and hasattr(opt, "step_args") and ordered and step_in_launch  # (round 6) ... and the step itself rides in the last adjoint's launch
 
         def body():

@@ -147,6 +147,14 @@ def chamfer_value_and_grad(A, B, w1=1.0, w2=1.0, gout=1.0, B_global=None, return
     return (loss, gx, gy, ix, iy) if return_indices else (loss, gx, gy)
 
 
+def sampling_adjoint_is_ordered(m, n):
+    """Whether the ordered (atomic-free, bit-reproducible) sampling adjoint takes meshes of this shape with ``n`` draws each
+    (fx3d_sample_points_bwd_ordered: the draws and their tables must fit one CU's LDS); otherwise the calls scatter with float atomics."""
+    f = C.c_int32(0)
+    _lib.call("fx3d_sample_points_bwd_ordered", int(m.F), int(n), C.byref(f))
+    return f.value != 0
+
+
 def chamfer_sampled_grad(A, B, idx_a, idx_b, mesh_a=None, draws_a=None, mesh_b=None, draws_b=None, w1=1.0, w2=1.0,
                          gout=1.0, B_global=None, out_a=None, out_b=None, ordered=True, step=None):
     """Adjoint of ``chamfer_distance(m_a::TriMesh, m_b::TriMesh, n)`` (src/metrics/mesh.jl:34-44) w.r.t. the padded vertices of

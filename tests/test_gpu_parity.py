@@ -809,6 +809,27 @@ def test_fit_step_graph_matches_eager_loop(gpu_fx):
     assert not any(isinstance(k, tuple) and k[0] == "face_cdf" for k in tgt._dev)
 
 
+def test_fit_step_graph_beyond_the_ordered_adjoints_capacity(gpu_fx):
+    """More draws than the ordered sampling adjoint stages in one CU's LDS (7000 on the 5120-face sphere): FitStepGraph takes the
+    float-atomic scatter and a separate optimiser launch by itself, the ordered form stays the default where it fits; both descend."""
+    fx = gpu_fx
+    tv, tf = fx.load_obj(os.path.join(GOLDEN, "teapot.obj"))
+    tv = tv - tv.mean(1, keepdims=True)
+    tv = np.asfortranarray((tv / np.abs(tv).max()).astype(np.float32))
+    for n in (7000, 3000):
+        src = fx.gpu(fx.load_trimesh(os.path.join(GOLDEN, "sphere.obj")))
+        tgt = fx.gpu(fx.TriMesh([tv], [tf]))
+        assert fx.sampling_adjoint_is_ordered(src, n) == (n == 3000)
+        x = fx.DeviceArray.zeros((3, src.V), np.float32)
+        step = fx.FitStepGraph(x, src, tgt, fx.Momentum(1.0, 0.9), num_samples=n, seed=11)
+        first = float(step.first_loss.item())
+        for _ in range(30):
+            step.step()
+        step.synchronize()
+        last = float(step.loss.item())
+        assert np.isfinite(last) and last < first, (n, first, last)
+
+
 def test_chamfer_sampled_adjoint_in_one_launch(gpu_fx, oracle):
     """fx3d_chamfer_sampled_bwd = fx3d_chamfer_bwd followed by fx3d_sample_points_bwd (the pullback of
     chamfer_distance(m1::TriMesh, m2::TriMesh, n), src/metrics/mesh.jl:34-44): both meshes, one mesh only, added onto an
