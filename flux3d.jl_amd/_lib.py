@@ -81,7 +81,7 @@ SIGNATURES = {
     "fx3d_chamfer_sampled_bwd": [vp, c_i32, vp, c_i32, c_i32, vp, vp, c_f32, c_f32, c_f32, c_i64,
                                  vp, c_i32, c_i32, vp, vp, vp, vp, vp, c_i32, c_i32, vp, vp, vp, vp, c_i32,
                                  vp, vp, vp, vp, vp, sz, vp],
-    "fx3d_chamfer_sampled_bwd_step": [vp, c_i32, vp, c_i32, vp, vp, c_f32, c_f32, c_f32, vp, c_i32, c_i32, vp, vp, vp, vp, c_i32,
+    "fx3d_chamfer_sampled_bwd_step": [vp, c_i32, vp, c_i32, c_i32, vp, vp, c_f32, c_f32, c_f32, vp, c_i32, c_i32, vp, vp, vp, vp, c_i32,
                                       vp, vp, c_f32, c_f32, vp, vp, vp, vp, vp, C.c_uint64, vp, sz, vp],
     "fx3d_knn": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, vp, vp],
     "fx3d_knn_workspace_bytes": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, C.POINTER(sz)],

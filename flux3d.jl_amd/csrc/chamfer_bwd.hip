@@ -552,8 +552,8 @@ fx3d_status chamfer_sampled_bwd_impl(const char *fn, const float *x, int32_t N, 
     // Ordered form (no float atomics, bit-identical to the oracle): every requested side comes with its vertex -> face table and
     // fits the gather's LDS tables.  Otherwise: the float-atomic scatter.
     const bool ordered = (!ax.gverts || (ax.vf_rowptr && sg::sg_fits(ax.Fmax, N))) && (!ay.gverts || (ay.vf_rowptr && sg::sg_fits(ay.Fmax, M)));
-    FX3D_REQUIRE(!step_x.vel || (ordered && ax.gverts && B == 1), "%s: the optimiser step needs the ordered form on a single mesh (vertex -> face "
-                 "table, draws that fit fx3d_sample_points_bwd_ordered)", fn);
+    FX3D_REQUIRE(!step_x.vel || (ordered && ax.gverts), "%s: the optimiser step needs the ordered form (vertex -> face table, draws that fit "
+                 "fx3d_sample_points_bwd_ordered)", fn);
     if (ordered) {
         // two launches: the chamfer adjoint's rows of the requested sides into the scratch (bit-identical to fx3d_chamfer_bwd), then the
         // ordered gather of every side (+ the optimiser step).  (One launch -- gather blocks behind the row blocks, waiting on a counter --
@@ -629,7 +629,7 @@ fx3d_status fx3d_chamfer_sampled_bwd(const float *x, int32_t N, const float *y, 
                                     sg::SgStep{}, ws, ws_bytes, s);
 }
 
-fx3d_status fx3d_chamfer_sampled_bwd_step(const float *x, int32_t N, const float *y, int32_t M, const int32_t *idx_x,
+fx3d_status fx3d_chamfer_sampled_bwd_step(const float *x, int32_t N, const float *y, int32_t M, int32_t B, const int32_t *idx_x,
                                           const int32_t *idx_y, float w1, float w2, float gout, const int32_t *faces_x,
                                           int32_t V, int32_t F, const int32_t *face_idx_x, const float *r1_x, const float *r2_x,
                                           float *gverts_x, int32_t accumulate, const int32_t *vf_rowptr_x, const int32_t *vf_ent_x,
@@ -639,7 +639,7 @@ fx3d_status fx3d_chamfer_sampled_bwd_step(const float *x, int32_t N, const float
     const SampledArgs ax{faces_x, V, F, face_idx_x, r1_x, r2_x, gverts_x, vf_rowptr_x, vf_ent_x};
     const SampledArgs ay{};
     const sg::SgStep st{rho, eta, vel, params, base, out, reinterpret_cast<unsigned long long *>(ctr), (unsigned long long)inc};
-    return chamfer_sampled_bwd_impl("fx3d_chamfer_sampled_bwd_step", x, N, y, M, 1, idx_x, idx_y, w1, w2, gout, 1, ax, ay, accumulate, st,
+    return chamfer_sampled_bwd_impl("fx3d_chamfer_sampled_bwd_step", x, N, y, M, B, idx_x, idx_y, w1, w2, gout, B, ax, ay, accumulate, st,
                                     ws, ws_bytes, s);
 }
 

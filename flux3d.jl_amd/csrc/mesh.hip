@@ -497,7 +497,10 @@ __global__ __launch_bounds__(kThreads) void mesh_losses_bwd_gather_kernel(
     const float *__restrict__ verts, long long V, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
     const float4 *__restrict__ u, float c_lap, float c_edge, float target, float *__restrict__ gverts, int accumulate) {
     // (XCD-contiguous order for the Laplacian form: + 7 %; the edge form measured 8 % SLOWER with it and keeps the plain order)
-    for (long long i = (LAP ? xcd_logical_block(blockIdx.x, gridDim.x) : (long long)blockIdx.x) * kThreads + threadIdx.x; i < V; i += (long long)gridDim.x * kThreads) {
+    // (blockDim.x, not kThreads: small meshes are launched with one wave per block -- the fit loop's 9.6 k vertices are 38 blocks of 256
+    //  but 151 of 64, and a vertex is a chain of dependent gathers: 10.0 -> ... us at eight teapots, round 6)
+    const long long nt = (long long)blockDim.x;
+    for (long long i = (LAP ? xcd_logical_block(blockIdx.x, gridDim.x) : (long long)blockIdx.x) * nt + threadIdx.x; i < V; i += (long long)gridDim.x * nt) {
         const float v0 = verts[3 * i], v1 = verts[3 * i + 1], v2 = verts[3 * i + 2];
         float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
         const int k1 = rowptr[i + 1];
@@ -839,6 +842,9 @@ fx3d_status fx3d_mesh_losses_bwd(const float *verts, int64_t V, const int32_t *r
     else if (g_edge == 0.0f)
         hipLaunchKernelGGL((mesh_losses_bwd_gather_kernel<true, false>), dim3(grid_for(V, false, 1 << 22)), dim3(kThreads), 0, st, verts, (long long)V,
                            rowptr, colind, u, g_lap / (float)V, 0.0f, target, gverts, accumulate);
+    else if (V <= 65536)  // a small mesh: one wave per block, over four times as many CUs
+        hipLaunchKernelGGL((mesh_losses_bwd_gather_kernel<true, true>), dim3((unsigned)((V + 63) / 64)), dim3(64), 0, st, verts, (long long)V,
+                           rowptr, colind, u, g_lap / (float)V, g_edge / (float)E, target, gverts, accumulate);
     else
         hipLaunchKernelGGL((mesh_losses_bwd_gather_kernel<true, true>), dim3(grid_for(V, false, 1 << 22)), dim3(kThreads), 0, st, verts, (long long)V,
                            rowptr, colind, u, g_lap / (float)V, g_edge / (float)E, target, gverts, accumulate);

@@ -50,7 +50,7 @@ struct SgMesh {                 // ONE mesh of the batch (pointers already offse
     float *gverts;              // (3, V) result; with `accumulate` also the base
     int V, F, n, accumulate;
 };
-struct SgStep {                 // optional optimiser step by the vertex's thread (vel == nullptr: none); single-mesh batches only
+struct SgStep {                 // optional optimiser step by the vertex's thread (vel == nullptr: none); meshes of equal vertex counts
     float rho, eta;
     float *vel, *x;             // (3, V) Momentum's velocity and the parameters (the offsets)
     const float *base;          // (3, V) the source mesh's vertices

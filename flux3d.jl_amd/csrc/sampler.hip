@@ -521,6 +521,11 @@ __global__ __launch_bounds__(sg::kSgThreads) void sample_bwd_gather_kernel(
                        vf_rowptr + b * (Vmax + 1), vf_ent + b * Fmax * 3, gverts + b * Vmax * 3, Vmax, Fmax, n, accumulate};
     int vb, ve;
     sg::sg_part_range(Vmax, parts, j, vb, ve);
+    if (step.vel) {  // the optimiser's arrays are packed (3, sum V) = padded (3, Vmax, B): meshes of equal vertex counts
+        const size_t off = b * (size_t)Vmax * 3;
+        step.vel += off; step.x += off; step.base += off; step.out += off;
+        if (b != 0) step.ctr = nullptr;  // (one block advances the seed counter)
+    }
     sg::sg_tables(sg_lds, m);
     sg::sg_finish(sg_lds, m, step, vb, ve);
 }

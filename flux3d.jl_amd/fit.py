@@ -115,7 +115,7 @@ class FitStepGraph:
         self.mverts = lincomb(1.0, self._src_verts, 1.0, x) if fused else None
 
         ordered = bool(ordered) and sampling_adjoint_is_ordered(src, num_samples)  # (more draws than the ordered form stages: the scatter)
-        in_launch = fused and src.N == 1 and hasattr(opt, "step_args") and ordered and step_in_launch  # (round 6) ... and the step itself rides in the last adjoint's launch
+        in_launch = fused and hasattr(opt, "step_args") and ordered and step_in_launch  # (round 6) ... and the step itself rides in the last adjoint's launch
 
         def body():
             m = src.with_verts_packed(self.mverts) if fused else None

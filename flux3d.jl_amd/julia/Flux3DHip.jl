@@ -414,7 +414,7 @@ function chamfer_sampled_grad(A::HipArray{Float32,3}, B::HipArray{Float32,3}, ix
     return g1, g2
 end
 
-# The last launch of a fit_mesh iteration (examples/fit_mesh.jl:106-110) for ONE source mesh: the pullback of
+# The last launch of a fit_mesh iteration (examples/fit_mesh.jl:106-110) for source meshes of equal vertex counts (one mesh: always): the pullback of
 # chamfer_distance(offset(src, x), tgt, n) onto the source's vertices, added to `g` (the regularisers' gradient), and
 # Flux.Optimise.Momentum(eta, rho) + offset applied to every finished row by the thread that holds it:
 #   vel = rho vel - eta g;  x += vel;  out = base + x;  counter += inc
@@ -422,12 +422,12 @@ function chamfer_sampled_grad_step!(g::HipArray{Float32}, A::HipArray{Float32,3}
                                     iy::HipArray{Int32,2}, m, draws, x::HipArray{Float32}, vel::HipArray{Float32},
                                     base::HipArray{Float32}, out::HipArray{Float32}; eta = 1.0, rho = 0.9, w1::Number = 1.0,
                                     w2::Number = 1.0, gout::Number = 1, counter = C_NULL, inc::Integer = 0)
-    _, N, _ = size(A); _, M, _ = size(B)
+    _, N, Bn = size(A); _, M, _ = size(B)
     vfr, vfe = vertex_faces_dev(m)
     nb = Ref{Csize_t}(0)
-    check(@ccall LIB.fx3d_chamfer_sampled_bwd_workspace_bytes(N::Int32, M::Int32, 1::Int32, nb::Ref{Csize_t})::Int32)
+    check(@ccall LIB.fx3d_chamfer_sampled_bwd_workspace_bytes(N::Int32, M::Int32, Bn::Int32, nb::Ref{Csize_t})::Int32)
     ws = workspace(nb[])
-    check(@ccall LIB.fx3d_chamfer_sampled_bwd_step(A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32, ix.ptr::Ptr{Cvoid},
+    check(@ccall LIB.fx3d_chamfer_sampled_bwd_step(A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32, Bn::Int32, ix.ptr::Ptr{Cvoid},
                                                    iy.ptr::Ptr{Cvoid}, Float32(w1)::Float32, Float32(w2)::Float32,
                                                    Float32(gout)::Float32, faces_padded_dev(m).ptr::Ptr{Cvoid}, m.V::Int32,
                                                    m.F::Int32, draws[1].ptr::Ptr{Cvoid}, draws[2].ptr::Ptr{Cvoid},

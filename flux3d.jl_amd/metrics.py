@@ -164,7 +164,7 @@ def chamfer_sampled_grad(A, B, idx_a, idx_b, mesh_a=None, draws_a=None, mesh_b=N
     ``ordered`` (default): no float atomics -- every vertex's sum in a fixed order, the same bits on every run (meshes whose draws
     fit one CU's LDS -- ~5300 draws at 5120 faces --, otherwise, or ``ordered=False``, the float-atomic scatter).
     ``step`` = (rho, eta, vel, params, base, out, counter, inc): the Momentum step + offset of the fit_mesh loop applied to
-    ``mesh_a``'s finished gradient rows in the same launch (one mesh, ordered form).  Returns (g_a, g_b) (None for a skipped side)."""
+    ``mesh_a``'s finished gradient rows in the same launch (meshes of equal vertex counts, ordered form).  Returns (g_a, g_b) (None for a skipped side)."""
     x, y = _as_dev_points(A), _as_dev_points(B)
     D, N, M, Bn = _check_pair(x, y)
     if D != 3:
@@ -193,10 +193,10 @@ def chamfer_sampled_grad(A, B, idx_a, idx_b, mesh_a=None, draws_a=None, mesh_b=N
     sa, vfa, ga = side(mesh_a, draws_a, out_a)
     sb, vfb, gb = side(mesh_b, draws_b, out_b)
     if step is not None:
-        if mesh_a is None or mesh_b is not None or Bn != 1 or not ordered:
-            raise ValueError("chamfer_sampled_grad(step=...): one source mesh (B = 1), gradient w.r.t. mesh_a only, ordered form")
+        if mesh_a is None or mesh_b is not None or not mesh_a.verts_aliased or not ordered:
+            raise ValueError("chamfer_sampled_grad(step=...): gradient w.r.t. mesh_a only, meshes of equal vertex counts, ordered form")
         rho, eta, vel, params, base, out, counter, inc = step
-        _lib.call("fx3d_chamfer_sampled_bwd_step", x.ptr, N, y.ptr, M, idx_a.ptr, idx_b.ptr, float(w1), float(w2), float(gout),
+        _lib.call("fx3d_chamfer_sampled_bwd_step", x.ptr, N, y.ptr, M, Bn, idx_a.ptr, idx_b.ptr, float(w1), float(w2), float(gout),
                   *sa, int(accumulate), *vfa, float(rho), float(eta), vel.ptr, params.ptr, base.ptr, out.ptr,
                   counter.ptr if counter is not None else None, int(inc), ws.ptr, ws.nbytes, current_stream().handle)
         return ga, None

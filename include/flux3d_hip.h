@@ -206,12 +206,13 @@ FX3D_API fx3d_status fx3d_chamfer_sampled_bwd(const float *x, int32_t N, const f
                                               float *gverts_y, int32_t accumulate, const int32_t *vf_rowptr_x,
                                               const int32_t *vf_ent_x, const int32_t *vf_rowptr_y, const int32_t *vf_ent_y,
                                               void *ws, size_t ws_bytes, fx3d_stream_t s);
-/* The same for ONE source mesh (B = 1, gradient w.r.t. mesh x only, ordered form required), with the optimiser step of the
+/* The same for the source meshes alone (gradient w.r.t. mesh x only, ordered form required; B meshes of EQUAL vertex count V, so that
+ * the optimiser's packed (3, B V) arrays are the padded (3, V, B) ones), with the optimiser step of the
  * fit_mesh loop (examples/fit_mesh.jl:87-88,108-110: Flux.Optimise.Momentum, then offset) applied by the thread that finishes a
  * vertex's gradient row g = gverts_x (accumulate: on top of the regularisers' gradient already in it):
  *   vel = rho vel - eta g;  params += vel;  out = base + params   (fx3d_momentum_step_offset's arithmetic), *ctr += inc.
  * The gather's launch does it: no launch of its own for the optimiser; gverts_x still receives g. */
-FX3D_API fx3d_status fx3d_chamfer_sampled_bwd_step(const float *x, int32_t N, const float *y, int32_t M, const int32_t *idx_x,
+FX3D_API fx3d_status fx3d_chamfer_sampled_bwd_step(const float *x, int32_t N, const float *y, int32_t M, int32_t B, const int32_t *idx_x,
                                                    const int32_t *idx_y, float w1, float w2, float gout,
                                                    const int32_t *faces_x, int32_t V, int32_t F, const int32_t *face_idx_x,
                                                    const float *r1_x, const float *r2_x, float *gverts_x, int32_t accumulate,

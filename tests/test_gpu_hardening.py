@@ -1350,31 +1350,33 @@ def test_chamfer_sampled_adjoint_ordered_form_is_the_oracles_chain_bit_for_bit(g
     assert np.allclose(gaa.to_host(), ea, rtol=2e-4, atol=1e-8) and np.allclose(gba.to_host(), eb, rtol=2e-4, atol=1e-8)
 
 
-def test_chamfer_sampled_adjoint_with_the_optimiser_step_in_its_launch(gpu_fx, oracle):
+@pytest.mark.parametrize("nb", [1, 3])
+def test_chamfer_sampled_adjoint_with_the_optimiser_step_in_its_launch(gpu_fx, oracle, nb):
     """fx3d_chamfer_sampled_bwd_step = fx3d_chamfer_sampled_bwd (ordered, on top of a base gradient) followed by
-    fx3d_momentum_step_offset, bit for bit: velocity, parameters, the next offset mesh, the gradient and the seed counter."""
+    fx3d_momentum_step_offset, bit for bit: velocity, parameters, the next offset mesh, the gradient and the seed counter --
+    one mesh, and a batch of meshes of equal vertex counts (padded == packed bytes)."""
     fx = gpu_fx
-    src = fx.gpu(fx.load_trimesh(os.path.join(GOLDEN, "sphere.obj")))
-    tgt = fx.gpu(fx.load_trimesh(os.path.join(GOLDEN, "teapot.obj")))
+    src = fx.gpu(fx.load_trimesh(*[os.path.join(GOLDEN, "sphere.obj")] * nb))
+    tgt = fx.gpu(fx.load_trimesh(*[os.path.join(GOLDEN, "teapot.obj")] * nb))
     n = 5000
     A, fa, r1, r2 = fx.sample_points(src, n, seed=1, return_draws=True)
     Bp = fx.sample_points(tgt, n, seed=2)
     _, ix, iy = fx.chamfer_distance(A, Bp, return_indices=True)
     rng = np.random.default_rng(0)
     V = src.V
-    base_g = np.asfortranarray(rng.standard_normal((3, V, 1)).astype(np.float32) * 1e-3)
-    vel0 = np.asfortranarray(rng.standard_normal((3, V)).astype(np.float32) * 1e-3)
-    x0 = np.asfortranarray(rng.standard_normal((3, V)).astype(np.float32) * 1e-2)
+    base_g = np.asfortranarray(rng.standard_normal((3, V, nb)).astype(np.float32) * 1e-3)
+    vel0 = np.asfortranarray(rng.standard_normal((3, V * nb)).astype(np.float32) * 1e-3)
+    x0 = np.asfortranarray(rng.standard_normal((3, V * nb)).astype(np.float32) * 1e-2)
     basev = src.dev("verts_packed")
 
     def state():
         return (fx.gpu(base_g.copy(order="F")), fx.gpu(vel0.copy(order="F")), fx.gpu(x0.copy(order="F")),
-                fx.DeviceArray.zeros((3, V), np.float32), fx.DeviceArray.zeros((1,), np.uint64))
+                fx.DeviceArray.zeros((3, V * nb), np.float32), fx.DeviceArray.zeros((1,), np.uint64))
     g_a, vel_a, x_a, out_a, ctr_a = state()
     fx.chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=src, draws_a=(fa, r1, r2), out_a=g_a)
     opt = fx.Momentum(0.7, 0.9)
     opt.v = vel_a
-    opt.update_offset(x_a, g_a.reshape(3, V), basev, out_a, ctr_a, 2)
+    opt.update_offset(x_a, g_a.reshape(3, V * nb), basev, out_a, ctr_a, 2)
     g_b, vel_b, x_b, out_b, ctr_b = state()
     fx.chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=src, draws_a=(fa, r1, r2), out_a=g_b,
                             step=(0.9, 0.7, vel_b, x_b, basev, out_b, ctr_b, 2))
