@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="capture one iteration as a hipGraph and replay it")
     ap.add_argument("--atomics", action="store_true", help="sampling adjoint with float atomics (sums in arrival order) instead of the ordered form")
     ap.add_argument("--separate-step", action="store_true", help="the optimiser step as a launch of its own")
+    ap.add_argument("--unfolded", action="store_true", help="the two regularisers as launches of their own (default: they ride in the sampling launches)")
     args = ap.parse_args()
     src = fx.gpu(normalized(os.path.join(ROOT, "tests", "golden", "sphere.obj")))
     tgt = fx.gpu(normalized(args.target))
@@ -38,7 +39,7 @@ def main():
     opt = fx.Momentum(1.0, 0.9)        # examples/fit_mesh.jl:87-88
     t0 = time.perf_counter()
     if args.graph:
-        step = fx.FitStepGraph(x, src, tgt, opt, args.samples, ordered=not args.atomics, step_in_launch=not args.separate_step)  # runs iteration 1 eagerly, records iteration 2
+        step = fx.FitStepGraph(x, src, tgt, opt, args.samples, ordered=not args.atomics, step_in_launch=not args.separate_step, fold=not args.unfolded)  # runs iteration 1 eagerly, records iteration 2
         for it in range(2, args.iters + 1):
             loss = step.step()
             if it % 50 == 1 or it == args.iters:

@@ -20,7 +20,7 @@ from .rep import (PointCloud, TriMesh, get_edges_packed, get_edges_to_key, get_f
                   get_laplacian_packed, get_verts_list, get_verts_packed, get_verts_padded,
                   load_obj, load_off, load_trimesh, npoints)
 from .metrics import (chamfer_distance, chamfer_distance_grad, chamfer_loss_pairwise_f32, chamfer_sampled_grad, chamfer_value_and_grad, edge_loss, edge_loss_grad,  # noqa: E402
-                      laplacian_loss, laplacian_loss_grad, mesh_losses, mesh_losses_grad, nearest_neighbors,
+                      laplacian_loss, laplacian_loss_grad, mesh_losses, mesh_losses_grad, MeshReg, nearest_neighbors,
                       sampling_adjoint_is_ordered)
 from .transforms import (EPS, compute_faces_areas_list, compute_faces_areas_packed,  # noqa: E402
                          compute_faces_areas_padded, lincomb, offset, sample_points, sample_points_grad, sample_points_pair)

@@ -23,6 +23,13 @@ class Flux3DHipError(RuntimeError):
 c_i32, c_i64, c_f32, c_f64, c_u64 = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint64
 vp, sz = C.c_void_p, C.c_size_t
 
+class MeshRegStruct(C.Structure):
+    """include/flux3d_hip.h: fx3d_mesh_reg (the fit iteration's regularisers as passengers of its sampling launches)."""
+    _fields_ = [("verts", vp), ("V", c_i64), ("rowptr", vp), ("colind", vp), ("vals", vp), ("edges", vp), ("E", c_i64),
+                ("target", c_f32), ("w_lap", c_f32), ("w_edge", c_f32), ("base_dev", vp), ("loss_lap_dev", vp),
+                ("loss_edge_dev", vp), ("total_dev", vp), ("ws", vp), ("ws_bytes", sz)]
+
+
 # name -> argtypes  (restype is int32 status unless listed in _RESTYPES)
 SIGNATURES = {
     "fx3d_version": [],
@@ -83,6 +90,8 @@ SIGNATURES = {
                                  vp, vp, vp, vp, vp, sz, vp],
     "fx3d_chamfer_sampled_bwd_step": [vp, c_i32, vp, c_i32, c_i32, vp, vp, c_f32, c_f32, c_f32, vp, c_i32, c_i32, vp, vp, vp, vp, c_i32,
                                       vp, vp, c_f32, c_f32, vp, vp, vp, vp, vp, C.c_uint64, vp, sz, vp],
+    "fx3d_chamfer_sampled_bwd_step_reg": [vp, c_i32, vp, c_i32, c_i32, vp, vp, c_f32, c_f32, c_f32, vp, c_i32, c_i32, vp, vp, vp, vp, c_i32,
+                                          vp, vp, c_f32, c_f32, vp, vp, vp, vp, vp, C.c_uint64, vp, sz, vp, vp],
     "fx3d_knn": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, vp, vp],
     "fx3d_knn_workspace_bytes": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, C.POINTER(sz)],
     "fx3d_knn_ws": [vp, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, sz, vp],
@@ -104,6 +113,8 @@ SIGNATURES = {
     "fx3d_sample_points_cdf_pair": [vp, c_i32, vp, c_i32, vp, c_i32, vp, sz, vp, c_i32, vp, c_i32, vp, c_i32, vp, sz, c_f64, vp],
     "fx3d_sample_points_draw_pair": [vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_u64, vp, sz, vp, vp, vp, vp,
                                      vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_u64, vp, sz, vp, vp, vp, vp, vp, vp],
+    "fx3d_sample_points_draw_pair_reg": [vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_u64, vp, sz, vp, vp, vp, vp,
+                                         vp, c_i32, vp, c_i32, vp, c_i32, c_i32, c_u64, vp, sz, vp, vp, vp, vp, vp, vp, vp],
     "fx3d_build_vertex_faces": [vp, vp, c_i32, c_i32, c_i32, vp, vp],
     "fx3d_sample_points_bwd_ordered": [c_i32, c_i32, C.POINTER(c_i32)],
     "fx3d_sample_points_bwd": [vp, c_i32, c_i32, c_i32, c_i32, vp, vp, vp, vp, vp, c_i32, vp, vp, vp],

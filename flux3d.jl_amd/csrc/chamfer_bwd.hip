@@ -16,6 +16,7 @@
 
 #include "fx3d_common.h"
 #include "sample_gather.h"
+#include "mesh_reg.h"
 
 using namespace fx3d;
 
@@ -433,10 +434,35 @@ __device__ __forceinline__ BgJob bg_job(const float *x, int N, const float *y, i
     return J;
 }
 
+// (round 6) spare blocks behind the row blocks of fx3d_chamfer_sampled_bwd's first launch: block e builds the ordered gather's tables of
+// mesh e of a side -- the draws bucketed by face, sample_gather.h: they depend on the draws alone -- and leaves them in the scratch for the
+// gather's blocks (7 us of a gather block's work done while the rows are formed)
+struct SgTabJobs {
+    const int32_t *face_idx[2];  // (n, B) draws of side x / y; nullptr: no tables for that side
+    unsigned char *blob[2];
+    int F[2], n[2], B;
+};
+static_assert(kBgThreads == sg::kSgThreads, "row blocks and table blocks share a launch");
 template <bool D3>
 __global__ __launch_bounds__(kBgThreads, FX3D_BG_OCC) void chamfer_bwd_gather_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ y, int M, int D, const int32_t *__restrict__ idx_x,
-    const int32_t *__restrict__ idx_y, float ca, float cb, float *__restrict__ gx, float *__restrict__ gy, int nsplit) {
+    const int32_t *__restrict__ idx_y, float ca, float cb, float *__restrict__ gx, float *__restrict__ gy, int nsplit, int nrow,
+    SgTabJobs tj, int ntab, meshreg::Ride ride) {
+    if ((int)blockIdx.x >= nrow) {
+        extern __shared__ __attribute__((aligned(16))) unsigned char tab_lds[];
+        int e = (int)blockIdx.x - nrow, side = 0;
+        if (e >= ntab) {  // the regularisers' adjoint (mesh_reg.h): reads the vertices and the forward's unit rows, writes gverts
+            meshreg::adj_block(ride, e - ntab);
+            return;
+        }
+        if (tj.face_idx[0]) { if (e >= tj.B) { e -= tj.B; side = 1; } } else side = 1;
+        sg::SgMesh m{};
+        m.face_idx = tj.face_idx[side] + (size_t)e * tj.n[side];
+        m.F = tj.F[side]; m.n = tj.n[side];
+        sg::sg_tables(tab_lds, m);
+        sg::sg_tables_store(tab_lds, m.F, m.n, tj.blob[side] + (size_t)e * sg::sg_blob_bytes(m.F, m.n));
+        return;
+    }
     __shared__ BgLds L;
     BgJob J = bg_job(x, N, y, M, D, idx_x, idx_y, ca, cb, nsplit);
     if (!(J.side ? gy : gx)) return;  // (a side nobody asked for: fx3d_chamfer_sampled_bwd differentiates w.r.t. one mesh)
@@ -492,10 +518,10 @@ fx3d_status fx3d_chamfer_bwd(const float *x, int32_t N, const float *y, int32_t 
         ProfileScope prof("chamfer_bwd", st);
         if (D == 3)
             hipLaunchKernelGGL(chamfer_bwd_gather_kernel<true>, dim3(2 * B * nsplit), dim3(kBgThreads), 0, st, x, N, y, M, D, idx_x,
-                               idx_y, ca, cb, gx, gy, nsplit);
+                               idx_y, ca, cb, gx, gy, nsplit, 2 * B * nsplit, SgTabJobs{}, 0, meshreg::Ride{});
         else
             hipLaunchKernelGGL(chamfer_bwd_gather_kernel<false>, dim3(2 * B * nsplit), dim3(kBgThreads), 0, st, x, N, y, M, D, idx_x,
-                               idx_y, ca, cb, gx, gy, nsplit);
+                               idx_y, ca, cb, gx, gy, nsplit, 2 * B * nsplit, SgTabJobs{}, 0, meshreg::Ride{});
         FX3D_LAUNCH_CHECK();
         return FX3D_OK;
     }
@@ -529,12 +555,14 @@ struct SampledArgs {
 size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 // the ordered form's scratch: the adjoint's rows of both sides (published by a mesh's blocks, gathered by the last of them)
 size_t sampled_ws_bytes(int N, int M, int B) {
-    return al256(sizeof(float) * 3 * (size_t)N * B) + al256(sizeof(float) * 3 * (size_t)M * B);
+    // (the tables' blobs are sized for the largest face count the ordered form takes at these draw counts: the caller need not name Fmax)
+    return al256(sizeof(float) * 3 * (size_t)N * B) + al256(sizeof(float) * 3 * (size_t)M * B) +
+           al256(sg::sg_blob_bytes(sg::kSgMaxF, N) * (size_t)B) + al256(sg::sg_blob_bytes(sg::kSgMaxF, M) * (size_t)B);
 }
 fx3d_status chamfer_sampled_bwd_impl(const char *fn, const float *x, int32_t N, const float *y, int32_t M, int32_t B, const int32_t *idx_x,
                                      const int32_t *idx_y, float w1, float w2, float gout, int64_t B_global, const SampledArgs &ax,
                                      const SampledArgs &ay, int32_t accumulate, const sg::SgStep &step_x, void *ws, size_t ws_bytes,
-                                     fx3d_stream_t s) {
+                                     fx3d_stream_t s, const fx3d_mesh_reg *reg = nullptr) {
     fx3d_status rc = chamfer_check_shapes(fn, x, N, y, M, B, 3);
     if (rc) return rc;
     FX3D_REQUIRE(idx_x && idx_y, "%s: null index array", fn);
@@ -554,6 +582,21 @@ fx3d_status chamfer_sampled_bwd_impl(const char *fn, const float *x, int32_t N, 
     const bool ordered = (!ax.gverts || (ax.vf_rowptr && sg::sg_fits(ax.Fmax, N))) && (!ay.gverts || (ay.vf_rowptr && sg::sg_fits(ay.Fmax, M)));
     FX3D_REQUIRE(!step_x.vel || (ordered && ax.gverts), "%s: the optimiser step needs the ordered form (vertex -> face table, draws that fit "
                  "fx3d_sample_points_bwd_ordered)", fn);
+    // the fit iteration's regularisers (fx3d_mesh_reg): their adjoint writes gverts_x, the sampling adjoint then accumulates on top
+    meshreg::Ride ride_v{};
+    const meshreg::Ride *ride = nullptr;
+    if (reg) {
+        FX3D_REQUIRE(ax.gverts && reg->V == (int64_t)ax.Vmax * B, "%s: fx3d_mesh_reg covers the source batch (V = %lld, B * Vmax = %lld)", fn,
+                     (long long)reg->V, (long long)ax.Vmax * B);
+        rc = mesh_reg_plan(reg, gout, ax.gverts, accumulate, st, fn, &ride_v);
+        if (rc) return rc;
+        if (ordered && ride_v.c_lap != 0.0f && ride_v.c_edge != 0.0f) ride = &ride_v;  // rides in the rows launch
+        else {  // (a weight of zero drops its term, fx3d_mesh_losses_bwd knows how; the scatter form is one launch with no room)
+            rc = mesh_reg_adjoint_standalone(reg, gout, ax.gverts, accumulate, st);
+            if (rc) return rc;
+        }
+        accumulate = 1;
+    }
     if (ordered) {
         // two launches: the chamfer adjoint's rows of the requested sides into the scratch (bit-identical to fx3d_chamfer_bwd), then the
         // ordered gather of every side (+ the optimiser step).  (One launch -- gather blocks behind the row blocks, waiting on a counter --
@@ -565,22 +608,42 @@ fx3d_status chamfer_sampled_bwd_impl(const char *fn, const float *x, int32_t N, 
             set_error("%s: workspace too small (%zu < %zu bytes)", fn, ws ? ws_bytes : (size_t)0, need);
             return FX3D_ERR_WORKSPACE;
         }
-        float *gsx = static_cast<float *>(ws);
-        float *gsy = reinterpret_cast<float *>(static_cast<char *>(ws) + al256(sizeof(float) * 3 * (size_t)N * B));
+        char *w = static_cast<char *>(ws);
+        float *gsx = reinterpret_cast<float *>(w); w += al256(sizeof(float) * 3 * (size_t)N * B);
+        float *gsy = reinterpret_cast<float *>(w); w += al256(sizeof(float) * 3 * (size_t)M * B);
+        unsigned char *tbx = reinterpret_cast<unsigned char *>(w); w += al256(ax.gverts ? sg::sg_blob_bytes(ax.Fmax, N) * (size_t)B : 0);
+        unsigned char *tby = reinterpret_cast<unsigned char *>(w);
         {
+            // the rows of the requested sides + (behind them, one block per mesh and side) the gather's tables
+            SgTabJobs tj{};
+            tj.B = B;
+            size_t dyn = 0;
+            int ntab = 0;
+            if (ax.gverts) { tj.face_idx[0] = ax.face_idx; tj.blob[0] = tbx; tj.F[0] = ax.Fmax; tj.n[0] = N; dyn = std::max(dyn, sg::sg_tables_lds_bytes(ax.Fmax, N)); ntab += B; }
+            if (ay.gverts) { tj.face_idx[1] = ay.face_idx; tj.blob[1] = tby; tj.F[1] = ay.Fmax; tj.n[1] = M; dyn = std::max(dyn, sg::sg_tables_lds_bytes(ay.Fmax, M)); ntab += B; }
+            constexpr size_t kTabLds = 112 * 1024;  // beside the row blocks' 38 KB of static LDS
+            if (dyn > kTabLds) {  // (meshes of > ~20 000 faces: every gather block builds its own tables, as fx3d_sample_points_bwd's do)
+                tj = SgTabJobs{};
+                dyn = 0; ntab = 0;
+                tbx = tby = nullptr;
+            } else {
+                const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&chamfer_bwd_gather_kernel<true>), (int)kTabLds, "chamfer_bwd_gather_kernel");
+                if (arc != FX3D_OK) return arc;
+            }
             ProfileScope prof("chamfer_sampled_bwd", st);
-            hipLaunchKernelGGL(chamfer_bwd_gather_kernel<true>, dim3(2 * B * nsplit), dim3(kBgThreads), 0, st, x, N, y, M, 3, idx_x, idx_y, ca,
-                               cb, ax.gverts ? gsx : nullptr, ay.gverts ? gsy : nullptr, nsplit);
+            hipLaunchKernelGGL(chamfer_bwd_gather_kernel<true>, dim3(2 * B * nsplit + ntab + (ride ? ride->nadj : 0)), dim3(kBgThreads), dyn, st, x, N, y, M,
+                               3, idx_x, idx_y, ca, cb, ax.gverts ? gsx : nullptr, ay.gverts ? gsy : nullptr, nsplit, 2 * B * nsplit, tj, ntab,
+                               ride ? *ride : meshreg::Ride{});
             FX3D_LAUNCH_CHECK();
         }
         if (ax.gverts) {
             rc = sg::launch_sample_bwd_gather(ax.faces, ax.Vmax, ax.Fmax, B, N, ax.face_idx, ax.r1, ax.r2, gsx, ax.vf_rowptr, ax.vf_ent, ax.gverts,
-                                              accumulate, step_x, st);
+                                              accumulate, step_x, st, tbx);
             if (rc) return rc;
         }
         if (ay.gverts) {
             rc = sg::launch_sample_bwd_gather(ay.faces, ay.Vmax, ay.Fmax, B, M, ay.face_idx, ay.r1, ay.r2, gsy, ay.vf_rowptr, ay.vf_ent, ay.gverts,
-                                              accumulate, sg::SgStep{}, st);
+                                              accumulate, sg::SgStep{}, st, tby);
             if (rc) return rc;
         }
         return FX3D_OK;
@@ -641,6 +704,21 @@ fx3d_status fx3d_chamfer_sampled_bwd_step(const float *x, int32_t N, const float
     const sg::SgStep st{rho, eta, vel, params, base, out, reinterpret_cast<unsigned long long *>(ctr), (unsigned long long)inc};
     return chamfer_sampled_bwd_impl("fx3d_chamfer_sampled_bwd_step", x, N, y, M, B, idx_x, idx_y, w1, w2, gout, B, ax, ay, accumulate, st,
                                     ws, ws_bytes, s);
+}
+
+fx3d_status fx3d_chamfer_sampled_bwd_step_reg(const float *x, int32_t N, const float *y, int32_t M, int32_t B, const int32_t *idx_x,
+                                              const int32_t *idx_y, float w1, float w2, float gout, const int32_t *faces_x,
+                                              int32_t V, int32_t F, const int32_t *face_idx_x, const float *r1_x, const float *r2_x,
+                                              float *gverts_x, int32_t accumulate, const int32_t *vf_rowptr_x, const int32_t *vf_ent_x,
+                                              float rho, float eta, float *vel, float *params, const float *base, float *out,
+                                              uint64_t *ctr, uint64_t inc, void *ws, size_t ws_bytes, const fx3d_mesh_reg *reg,
+                                              fx3d_stream_t s) {
+    FX3D_REQUIRE(vel && params && base && out && gverts_x && reg, "fx3d_chamfer_sampled_bwd_step_reg: null pointer");
+    const SampledArgs ax{faces_x, V, F, face_idx_x, r1_x, r2_x, gverts_x, vf_rowptr_x, vf_ent_x};
+    const SampledArgs ay{};
+    const sg::SgStep st{rho, eta, vel, params, base, out, reinterpret_cast<unsigned long long *>(ctr), (unsigned long long)inc};
+    return chamfer_sampled_bwd_impl("fx3d_chamfer_sampled_bwd_step_reg", x, N, y, M, B, idx_x, idx_y, w1, w2, gout, B, ax, ay, accumulate, st,
+                                    ws, ws_bytes, s, reg);
 }
 
 }  // extern "C"

@@ -9,6 +9,7 @@
 #include <cmath>
 
 #include "fx3d_common.h"
+#include "mesh_reg.h"
 
 using namespace fx3d;
 
@@ -29,14 +30,7 @@ __device__ __forceinline__ float tri_area_p(const P3 &v1, const P3 &v2, const P3
     const float t1[3] = {v1.x, v1.y, v1.z}, t2[3] = {v2.x, v2.y, v2.z}, t3[3] = {v3.x, v3.y, v3.z};
     return tri_area(t1, t2, t3);
 }
-// XCD-aware work order of the grid-stride kernels (round 4): block L runs on XCD L % 8, each with its own L2.  With work item =
-// blockIdx the eight XCDs each see every eighth 256-item chunk, so the vertices two neighbouring chunks share are fetched into two
-// L2s; with the chunks of an XCD made CONTIGUOUS (XCD x takes logical blocks [start_x, start_x + n_x)) the neighbours share one.
-// A bijection of [0, nb) for any nb.  (Partial sums stay in the slot of the PHYSICAL block.)
-__device__ __forceinline__ long long xcd_logical_block(unsigned int L, unsigned int nb) {
-    const unsigned int x = L & 7u, j = L >> 3, q = nb >> 3, r = nb & 7u;
-    return (long long)x * q + (x < r ? x : r) + j;
-}
+using meshreg::xcd_logical_block;  // (mesh_reg.h)
 
 __global__ __launch_bounds__(kThreads) void faces_areas_packed_kernel(
     const float *__restrict__ verts, const int32_t *__restrict__ faces, long long F,
@@ -161,67 +155,9 @@ __global__ __launch_bounds__(kThreads) void edge_loss_bwd_kernel(
     }
 }
 
-// ---- laplacian_loss (src/metrics/mesh.jl:9-15): row i of L*verts' in ascending column order ----
-__device__ __forceinline__ void lap_row(const float *__restrict__ verts,
-                                        const int32_t *__restrict__ rowptr,
-                                        const int32_t *__restrict__ colind,
-                                        const float *__restrict__ vals, long long i, float &s0,
-                                        float &s1, float &s2) {
-    s0 = 0.0f; s1 = 0.0f; s2 = 0.0f;
-    const int k1 = rowptr[i + 1];
-    // eight entries per sweep (a mesh vertex has ~7: itself + 6 neighbours): every (weight, column) load first, then every
-    // vertex gather, then the sums in ascending column order -- two dependent round trips per row instead of two per entry
-    for (int k0 = rowptr[i]; k0 < k1; k0 += 8) {
-        float w[8];
-        int col[8];
-        P3 v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = k0 + e < k1 ? k0 + e : k1 - 1;
-            w[e] = vals[k];
-            col[e] = colind[k];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const P3 *>(verts + 3ll * col[e]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (k0 + e < k1) {
-                s0 = s0 + w[e] * v[e].x;
-                s1 = s1 + w[e] * v[e].y;
-                s2 = s2 + w[e] * v[e].z;
-            }
-    }
-}
-
-// The same row with its (weight, column) entries taken from a WAVE-staged copy in LDS (round 4): the 64 rows of a wave are one
-// contiguous run of the CSR arrays, which the wave copies with coalesced loads (every byte of the two streams crosses the L1
-// once); a thread per row reading its own entries from memory has lanes ~28 bytes apart, eight partially used lines per load.
-// Same operations in the same order as lap_row.
-constexpr int kLapStage = 1024;  // entries a wave stages (64 rows of a closed mesh hold ~450); longer runs read memory directly
-__device__ __forceinline__ void lap_row_lds(const float *__restrict__ verts, const float *w_s, const int *c_s, int k0, int k1,
-                                            float &s0, float &s1, float &s2) {
-    s0 = 0.0f; s1 = 0.0f; s2 = 0.0f;
-    for (; k0 < k1; k0 += 8) {
-        float w[8];
-        int col[8];
-        P3 v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = k0 + e < k1 ? k0 + e : k1 - 1;
-            w[e] = w_s[k];
-            col[e] = c_s[k];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const P3 *>(verts + 3ll * col[e]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (k0 + e < k1) {
-                s0 = s0 + w[e] * v[e].x;
-                s1 = s1 + w[e] * v[e].y;
-                s2 = s2 + w[e] * v[e].z;
-            }
-    }
-}
+using meshreg::lap_row;
+using meshreg::lap_row_lds;
+using meshreg::kLapStage;  // (mesh_reg.h)
 
 __global__ __launch_bounds__(kThreads) void laplacian_loss_kernel(
     const float *__restrict__ verts, long long V, const int32_t *__restrict__ rowptr,
@@ -392,87 +328,9 @@ __global__ __launch_bounds__(kThreads) void laplacian_loss_bwd_gather_kernel(
 // sorted edges ascending), with its expressions, so the gradients are BIT-IDENTICAL to the oracle -- and run to run:
 // no float atomics (the scatter versions above depend on the atomics' arrival order in the last bit).
 // Requires the CSR to be the Laplacian of the SAME edge list (it is: both are cached per mesh, src/rep/mesh.jl:957-1002).
-__global__ __launch_bounds__(kThreads) void mesh_losses_kernel(
-    const float *__restrict__ verts, long long V, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
-    const float *__restrict__ vals, const int32_t *__restrict__ e1, const int32_t *__restrict__ e2, long long E, float target,
-    int gV, int gE, double *__restrict__ partials, unsigned int *ticket, float w_lap, float w_edge,
-    const float *__restrict__ base, float *__restrict__ loss_lap, float *__restrict__ loss_edge, float *__restrict__ total,
-    float4 *__restrict__ u_out) {
-    __shared__ double sm[kThreads / 64];
-    __shared__ int is_last;
-    __shared__ float w_stage[(kThreads / 64) * kLapStage];
-    __shared__ int c_stage[(kThreads / 64) * kLapStage];
-    double acc = 0.0;
-    const int blk = blockIdx.x;
-    if (blk < gV) {
-        // (round 4) the rows of a wave from its staged copy of the CSR run: laplacian_loss_kernel
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        float *w_s = w_stage + wv * kLapStage;
-        int *c_s = c_stage + wv * kLapStage;
-        for (long long ib = xcd_logical_block(blk, gV) * kThreads + wv * 64; ib < V; ib += (long long)gV * kThreads) {  // (wave-uniform; XCD-contiguous)
-            const long long i = ib + lane;
-            const bool okr = i < V;
-            const int k0 = rowptr[okr ? i : V], k1 = okr ? rowptr[i + 1] : k0;
-            const int k_lo = __builtin_amdgcn_readfirstlane(k0), k_hi = __builtin_amdgcn_readlane(k1, 63);
-            const int nent = k_hi - k_lo;
-            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, invdeg = 0.0f;  // invdeg: any off-diagonal value of the row (all equal 1/deg(i)); 0 for an isolated vertex
-            if (nent <= kLapStage) {
-                for (int e = lane; e < nent; e += 64) {
-                    w_s[e] = vals[k_lo + e];
-                    c_s[e] = colind[k_lo + e];
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                lap_row_lds(verts, w_s, c_s, k0 - k_lo, k1 - k_lo, s0, s1, s2);
-                if (k1 - k0 >= 2) invdeg = c_s[k0 - k_lo] == (int)i ? w_s[k0 - k_lo + 1] : w_s[k0 - k_lo];
-                __builtin_amdgcn_wave_barrier();
-            } else if (okr) {
-                lap_row(verts, rowptr, colind, vals, i, s0, s1, s2);
-                if (k1 - k0 >= 2) invdeg = colind[k0] == (int)i ? vals[k0 + 1] : vals[k0];
-            }
-            if (okr) {
-                const float nrm = sqrtf(((s0 * s0) + (s1 * s1)) + (s2 * s2));
-                acc += (double)nrm;
-                if (u_out) {
-                    const bool ok = nrm > 0.0f;
-                    u_out[i] = float4{ok ? s0 / nrm : 0.0f, ok ? s1 / nrm : 0.0f, ok ? s2 / nrm : 0.0f, invdeg};
-                }
-            }
-        }
-    } else {
-        for (long long e = xcd_logical_block(blk - gV, gE) * kThreads + threadIdx.x; e < E; e += (long long)gE * kThreads) {
-            const float *a = verts + 3ll * e1[e], *b = verts + 3ll * e2[e];
-            const float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
-            const float nrm = sqrtf(((d0 * d0) + (d1 * d1)) + (d2 * d2));
-            const float t = nrm - target;
-            acc += (double)(t * t);
-        }
-    }
-    const double tot = block_sum<kThreads>(acc, sm);
-    unsigned long long *pp = reinterpret_cast<unsigned long long *>(partials);
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&pp[blk], __builtin_bit_cast(unsigned long long, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        is_last = ticket_arrive_last(ticket, gridDim.x, blk);
-    }
-    __syncthreads();
-    if (!is_last) return;
-    double a0 = 0.0, a1 = 0.0;
-    for (int i = threadIdx.x; i < gV; i += kThreads)
-        a0 += __builtin_bit_cast(double, __hip_atomic_load(&pp[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    for (int i = threadIdx.x; i < gE; i += kThreads)
-        a1 += __builtin_bit_cast(double, __hip_atomic_load(&pp[gV + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    __syncthreads();
-    const double t0 = block_sum<kThreads>(a0, sm);
-    __syncthreads();
-    const double t1 = block_sum<kThreads>(a1, sm);
-    if (threadIdx.x == 0) {
-        const float ll = (float)(t0 / (double)V), le = (float)(t1 / (double)E);
-        if (loss_lap) *loss_lap = ll;
-        if (loss_edge) *loss_edge = le;
-        if (total) *total = ((base ? *base : 0.0f) + (w_lap * ll)) + (w_edge * le);  // the tutorial's sum, its order, unfused
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+__global__ __launch_bounds__(kThreads) void mesh_losses_kernel(meshreg::FwdArgs A) {
+    __shared__ meshreg::FwdLds<kThreads> L;
+    meshreg::fwd_block<kThreads>(A, (int)blockIdx.x, L);  // (mesh_reg.h: the same body rides in the sampler's draw launch)
 }
 
 // u_r and 1/deg(r) alone (the adjoint without a preceding fused forward)
@@ -500,58 +358,8 @@ __global__ __launch_bounds__(kThreads) void mesh_losses_bwd_gather_kernel(
     // (blockDim.x, not kThreads: small meshes are launched with one wave per block -- the fit loop's 9.6 k vertices are 38 blocks of 256
     //  but 151 of 64, and a vertex is a chain of dependent gathers: 10.0 -> ... us at eight teapots, round 6)
     const long long nt = (long long)blockDim.x;
-    for (long long i = (LAP ? xcd_logical_block(blockIdx.x, gridDim.x) : (long long)blockIdx.x) * nt + threadIdx.x; i < V; i += (long long)gridDim.x * nt) {
-        const float v0 = verts[3 * i], v1 = verts[3 * i + 1], v2 = verts[3 * i + 2];
-        float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
-        const int k1 = rowptr[i + 1];
-        for (int k0 = rowptr[i]; k0 < k1; k0 += 8) {  // eight entries per sweep: columns, then all gathers, then the sums in order
-            int col[8];
-            float4 urr[8];
-            P3 vrr[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) col[e] = colind[k0 + e < k1 ? k0 + e : k1 - 1];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (LAP) urr[e] = u[col[e]];
-                if (EDGE) vrr[e] = *reinterpret_cast<const P3 *>(verts + 3ll * col[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (!(k0 + e < k1)) continue;
-                const int r = col[e];
-                if (LAP) {  // row r of the oracle's scatter: gverts[i] += (c * L[r,i]) * u_r
-                    const float4 ur = urr[e];
-                    const float w = c_lap * (r == (int)i ? -1.0f : ur.w);
-                    l0 = l0 + w * ur.x;
-                    l1 = l1 + w * ur.y;
-                    l2 = l2 + w * ur.z;
-                }
-                if (EDGE && r != (int)i) {
-                    const float vr[3] = {vrr[e].x, vrr[e].y, vrr[e].z};
-                    if (r < (int)i) {  // edge (r, i): d = v_r - v_i, vertex i receives -= g d
-                        const float d0 = vr[0] - v0, d1 = vr[1] - v1, d2 = vr[2] - v2;
-                        const float nrm = sqrtf(((d0 * d0) + (d1 * d1)) + (d2 * d2));
-                        if (nrm > 0.0f) {
-                            const float g = c_edge * 2.0f * (nrm - target) / nrm;
-                            e0 = e0 - g * d0; e1 = e1 - g * d1; e2 = e2 - g * d2;
-                        }
-                    } else {           // edge (i, r): d = v_i - v_r, vertex i receives += g d
-                        const float d0 = v0 - vr[0], d1 = v1 - vr[1], d2 = v2 - vr[2];
-                        const float nrm = sqrtf(((d0 * d0) + (d1 * d1)) + (d2 * d2));
-                        if (nrm > 0.0f) {
-                            const float g = c_edge * 2.0f * (nrm - target) / nrm;
-                            e0 = e0 + g * d0; e1 = e1 + g * d1; e2 = e2 + g * d2;
-                        }
-                    }
-                }
-            }
-        }
-        // (prev + laplacian term) + edge term: the order of the tutorial's chain (g_chamfer + g_lap) + g_edge
-        float o0 = accumulate ? gverts[3 * i] : 0.0f, o1 = accumulate ? gverts[3 * i + 1] : 0.0f, o2 = accumulate ? gverts[3 * i + 2] : 0.0f;
-        if (LAP) { o0 = accumulate ? o0 + l0 : l0; o1 = accumulate ? o1 + l1 : l1; o2 = accumulate ? o2 + l2 : l2; }
-        if (EDGE) { o0 = (LAP || accumulate) ? o0 + e0 : e0; o1 = (LAP || accumulate) ? o1 + e1 : e1; o2 = (LAP || accumulate) ? o2 + e2 : e2; }
-        gverts[3 * i] = o0; gverts[3 * i + 1] = o1; gverts[3 * i + 2] = o2;
-    }
+    for (long long i = (LAP ? xcd_logical_block(blockIdx.x, gridDim.x) : (long long)blockIdx.x) * nt + threadIdx.x; i < V; i += (long long)gridDim.x * nt)
+        meshreg::adjoint_vertex<LAP, EDGE>(verts, i, rowptr, colind, u, c_lap, c_edge, target, gverts, accumulate);  // (mesh_reg.h)
 }
 
 __global__ __launch_bounds__(kThreads) void lincomb_kernel(long long n, float a, const float *__restrict__ x, float b,
@@ -806,9 +614,9 @@ fx3d_status fx3d_mesh_losses(const float *verts, int64_t V, const int32_t *rowpt
     const int gV = grid_for(V, true), gE = grid_for(E, true);
     {
         ProfileScope prof("mesh_losses", st);
-        hipLaunchKernelGGL(mesh_losses_kernel, dim3(gV + gE), dim3(kThreads), 0, st, verts, (long long)V, rowptr, colind, vals,
-                           edges, edges + E, (long long)E, target, gV, gE, partials, ticket, w_lap, w_edge, base_dev,
-                           loss_lap_dev, loss_edge_dev, total_dev, u);
+        const meshreg::FwdArgs A{verts, (long long)V, rowptr, colind, vals, edges, edges + E, (long long)E, target, gV, gE, partials, ticket,
+                                 w_lap, w_edge, base_dev, loss_lap_dev, loss_edge_dev, total_dev, u};
+        hipLaunchKernelGGL(mesh_losses_kernel, dim3(gV + gE), dim3(kThreads), 0, st, A);
     }
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
@@ -851,6 +659,54 @@ fx3d_status fx3d_mesh_losses_bwd(const float *verts, int64_t V, const int32_t *r
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }
+
+}  // extern "C"
+
+namespace {
+__global__ void mesh_reg_total_kernel(const float *base, float w_lap, const float *ll, float w_edge, const float *le, float *total) {
+    *total = ((base ? *base : 0.0f) + (w_lap * *ll)) + (w_edge * *le);
+}
+}  // namespace
+
+namespace fx3d {
+fx3d_status mesh_reg_plan(const fx3d_mesh_reg *reg, float gout, float *gverts, int accumulate, hipStream_t st, const char *fn, meshreg::Ride *out) {
+    FX3D_REQUIRE(reg && reg->verts && reg->rowptr && reg->colind && reg->vals && reg->edges, "%s: fx3d_mesh_reg with a null pointer", fn);
+    FX3D_REQUIRE(reg->loss_lap_dev && reg->loss_edge_dev, "%s: fx3d_mesh_reg needs loss_lap_dev and loss_edge_dev", fn);
+    FX3D_REQUIRE(reg->V > 0 && reg->E > 0 && reg->V < (1ll << 31), "%s: fx3d_mesh_reg: bad sizes V=%lld E=%lld", fn, (long long)reg->V, (long long)reg->E);
+    size_t need = 0;
+    fx3d_mesh_losses_workspace_bytes(reg->V, reg->E, &need);
+    if (!reg->ws || reg->ws_bytes < need) { set_error("%s: fx3d_mesh_reg workspace too small (%zu < %zu bytes)", fn, reg->ws ? reg->ws_bytes : (size_t)0, need); return FX3D_ERR_WORKSPACE; }
+    fx3d_status trc = FX3D_OK;
+    unsigned int *ticket = ticket_slot(&trc, st);
+    if (!ticket) return trc;
+    double *partials = reinterpret_cast<double *>(reg->ws);
+    float4 *u = reinterpret_cast<float4 *>(partials + 2 * kMaxBlocks);
+    meshreg::Ride R{};
+    R.fwd = meshreg::FwdArgs{reg->verts, (long long)reg->V, reg->rowptr, reg->colind, reg->vals, reg->edges, reg->edges + reg->E, (long long)reg->E,
+                             reg->target, grid_for(reg->V, true), grid_for(reg->E, true), partials, ticket, reg->w_lap, reg->w_edge, reg->base_dev,
+                             reg->loss_lap_dev, reg->loss_edge_dev, reg->total_dev, u};
+    R.c_lap = (reg->w_lap * gout) / (float)reg->V;
+    R.c_edge = (reg->w_edge * gout) / (float)reg->E;
+    R.gverts = gverts;
+    R.accumulate = accumulate;
+    R.nadj = (int)((reg->V + meshreg::kAdjPerBlock - 1) / meshreg::kAdjPerBlock);
+    *out = R;
+    return FX3D_OK;
+}
+fx3d_status mesh_reg_adjoint_standalone(const fx3d_mesh_reg *reg, float gout, float *gverts, int accumulate, hipStream_t st) {
+    const fx3d_status rc = fx3d_mesh_losses_bwd(reg->verts, reg->V, reg->rowptr, reg->colind, reg->vals, reg->E, reg->target, reg->w_lap * gout,
+                                                reg->w_edge * gout, 1, gverts, accumulate, reg->ws, reg->ws_bytes, reinterpret_cast<fx3d_stream_t>(st));
+    if (rc) return rc;
+    if (reg->total_dev) {
+        hipLaunchKernelGGL(mesh_reg_total_kernel, dim3(1), dim3(1), 0, st, reg->base_dev, reg->w_lap, reg->loss_lap_dev, reg->w_edge, reg->loss_edge_dev,
+                           reg->total_dev);
+        FX3D_LAUNCH_CHECK();
+    }
+    return FX3D_OK;
+}
+}  // namespace fx3d
+
+extern "C" {
 
 fx3d_status fx3d_laplacian_loss_bwd(const float *verts, int64_t V, const int32_t *rowptr,
                                     const int32_t *colind, const float *vals, float gout,

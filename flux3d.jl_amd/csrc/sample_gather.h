@@ -231,6 +231,34 @@ __device__ __forceinline__ void sg_tables(unsigned char *lds, const SgMesh &m) {
     SG_STAMP(4);
 }
 
+// The tables as a blob in memory (round 6, late): the bytes [start, staged) of the LDS layout -- list offsets, ordered lists, the faces of
+// many draws and their count.  fx3d_chamfer_sampled_bwd builds them with spare blocks of the launch that forms the adjoint's rows (they need
+// the draws only) and the gather's blocks load them: 7 us of every gather block's 19 leave the iteration's critical path.
+__host__ __device__ inline size_t sg_blob_bytes(int F, int n) {
+    const SgLayout L = sg_layout(F, n);
+    return (L.staged - L.start + 15) & ~(size_t)15;
+}
+__device__ __forceinline__ void sg_tables_store(const unsigned char *lds, int F, int n, unsigned char *blob) {
+    const SgLayout L = sg_layout(F, n);
+    const unsigned int *src = reinterpret_cast<const unsigned int *>(lds + L.start);  // (both offsets are multiples of 4)
+    unsigned int *dst = reinterpret_cast<unsigned int *>(blob);
+    const int nw = (int)((L.staged - L.start) / 4);
+    for (int i = threadIdx.x; i < nw; i += kSgThreads) dst[i] = src[i];
+}
+__device__ __forceinline__ void sg_tables_load(unsigned char *lds, int F, int n, const unsigned char *blob) {
+    const SgLayout L = sg_layout(F, n);
+    unsigned int *dst = reinterpret_cast<unsigned int *>(lds + L.start);
+    const unsigned int *src = reinterpret_cast<const unsigned int *>(blob);
+    const int nw = (int)((L.staged - L.start) / 4);
+    for (int i = threadIdx.x; i < nw; i += kSgThreads) dst[i] = src[i];
+    __syncthreads();
+}
+// LDS a block needs to BUILD the tables only (no staged rows: the long lists' bitmaps end the layout)
+__host__ __device__ inline size_t sg_tables_lds_bytes(int F, int n) {
+    const SgLayout L = sg_layout(F, n);
+    return (L.staged + sizeof(unsigned int) * (size_t)kSgWaves * (size_t)L.bmwords + 15) & ~(size_t)15;
+}
+
 // sg_finish: phases (5) - (6) for the vertices [vb, ve) of the mesh -- a mesh's vertices may be shared out over several blocks
 // (each with tables of its own: building them is ~7 us of one CU's time, walking 2500 vertices 12 us).
 __device__ __forceinline__ void sg_finish(unsigned char *lds, const SgMesh &m, const SgStep &st, int vb, int ve) {
@@ -386,7 +414,7 @@ __host__ __device__ inline void sg_part_range(int V, int parts, int j, int &vb, 
 // the gather's launch (sampler.hip), also the second launch of fx3d_chamfer_sampled_bwd's ordered form (chamfer_bwd.hip)
 fx3d_status launch_sample_bwd_gather(const int32_t *faces_padded, int Vmax, int Fmax, int B, int n, const int32_t *face_idx, const float *r1,
                                      const float *r2, const float *gs, const int32_t *vf_rowptr, const int32_t *vf_ent, float *gverts,
-                                     int accumulate, const SgStep &step, hipStream_t st);
+                                     int accumulate, const SgStep &step, hipStream_t st, const unsigned char *tables = nullptr);
 
 }  // namespace sg
 }  // namespace fx3d

@@ -14,6 +14,7 @@
 
 #include "fx3d_common.h"
 #include "sample_gather.h"
+#include "mesh_reg.h"
 
 using namespace fx3d;
 
@@ -451,7 +452,14 @@ struct DrawSide {
 };
 // (two sides: the draws of both meshes of chamfer_distance(m1, m2, n) in one launch; nb0 = blocks of side 0, each side's blocks
 //  stride over their own samples)
-__global__ __launch_bounds__(kThreads) void sample_seeded_kernel(DrawSide s0, DrawSide s1, int nb0, const uint64_t *__restrict__ seed_dev) {
+// (round 6) blocks [nbd, gridDim.x): the forward of the fit iteration's regularisers (mesh_reg.h) -- they read the vertices only
+__global__ __launch_bounds__(kThreads) void sample_seeded_kernel(DrawSide s0, DrawSide s1, int nb0, int nbd, const uint64_t *__restrict__ seed_dev,
+                                                                 meshreg::FwdArgs reg_fwd) {
+    if ((int)blockIdx.x >= nbd) {
+        __shared__ meshreg::FwdLds<kThreads> L;
+        meshreg::fwd_block<kThreads>(reg_fwd, (int)blockIdx.x - nbd, L);
+        return;
+    }
     const bool second = (int)blockIdx.x >= nb0;
     const DrawSide &S = second ? s1 : s0;
     const float *__restrict__ verts_padded = S.verts_padded;
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(kThreads) void sample_seeded_kernel(DrawSide s0, Dr
     const long long total = (long long)S.B * n;
     const size_t cstride = CdfWs::make(Fmax).stride;
     const uint64_t seed = S.seed_host + (seed_dev ? *seed_dev : 0);  // device part: advanced between replays of a graph
-    const long long blk = second ? (long long)blockIdx.x - nb0 : (long long)blockIdx.x, nblk = second ? (long long)gridDim.x - nb0 : (long long)nb0;
+    const long long blk = second ? (long long)blockIdx.x - nb0 : (long long)blockIdx.x, nblk = second ? (long long)nbd - nb0 : (long long)nb0;
     for (long long k = blk * kThreads + threadIdx.x; k < total; k += nblk * kThreads) {
         const int b = (int)(k / n), sidx = (int)(k % n);
         const double *cdf = ws + (size_t)b * cstride;
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(sg::kSgThreads) void sample_bwd_gather_kernel(
     const int32_t *__restrict__ faces_padded, int Vmax, int Fmax, int n, const int32_t *__restrict__ face_idx,
     const float *__restrict__ r1, const float *__restrict__ r2, const float *__restrict__ gout,
     const int32_t *__restrict__ vf_rowptr, const int32_t *__restrict__ vf_ent, float *gverts, int accumulate, int parts,
-    sg::SgStep step) {
+    sg::SgStep step, const unsigned char *__restrict__ tables) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sg_lds[];
     const size_t b = blockIdx.x / parts;
     const int j = blockIdx.x % parts;
@@ -526,7 +534,8 @@ __global__ __launch_bounds__(sg::kSgThreads) void sample_bwd_gather_kernel(
         step.vel += off; step.x += off; step.base += off; step.out += off;
         if (b != 0) step.ctr = nullptr;  // (one block advances the seed counter)
     }
-    sg::sg_tables(sg_lds, m);
+    if (tables) sg::sg_tables_load(sg_lds, Fmax, n, tables + b * sg::sg_blob_bytes(Fmax, n));  // built by an earlier launch (chamfer_bwd.hip)
+    else sg::sg_tables(sg_lds, m);
     sg::sg_finish(sg_lds, m, step, vb, ve);
 }
 
@@ -551,14 +560,14 @@ namespace fx3d {
 namespace sg {
 fx3d_status launch_sample_bwd_gather(const int32_t *faces_padded, int Vmax, int Fmax, int B, int n, const int32_t *face_idx, const float *r1,
                                      const float *r2, const float *gs, const int32_t *vf_rowptr, const int32_t *vf_ent, float *gverts,
-                                     int accumulate, const SgStep &step, hipStream_t st) {
+                                     int accumulate, const SgStep &step, hipStream_t st, const unsigned char *tables) {
     const size_t lds = sg_layout(Fmax, n).total;
     const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&sample_bwd_gather_kernel), (int)kSgMaxLds, "sample_bwd_gather_kernel");
     if (arc != FX3D_OK) return arc;
     const int parts = sg_parts(Vmax);
     ProfileScope prof("sample_bwd_gather", st);
     hipLaunchKernelGGL(sample_bwd_gather_kernel, dim3((unsigned)B * parts), dim3(kSgThreads), lds, st, faces_padded, Vmax, Fmax, n, face_idx,
-                       r1, r2, gs, vf_rowptr, vf_ent, gverts, accumulate, parts, step);
+                       r1, r2, gs, vf_rowptr, vf_ent, gverts, accumulate, parts, step, tables);
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }
@@ -688,10 +697,12 @@ DrawSide draw_side(const DrawArgs &a) {
     return DrawSide{a.verts_padded, a.faces_padded, a.faces_len, reinterpret_cast<const double *>(a.cdf_ws), a.out, a.r1_out, a.r2_out,
                     a.face_out, a.seed, a.Vmax, a.Fmax, a.B, a.n};
 }
-fx3d_status draw_launch(const DrawArgs &a, const DrawArgs *b, const uint64_t *seed_dev, hipStream_t st) {
+fx3d_status draw_launch(const DrawArgs &a, const DrawArgs *b, const uint64_t *seed_dev, hipStream_t st, const meshreg::FwdArgs *reg = nullptr) {
     ProfileScope prof("sample_draw", st);
     const int g0 = grid_for((long long)a.B * a.n), g1 = b ? grid_for((long long)b->B * b->n) : 0;
-    hipLaunchKernelGGL(sample_seeded_kernel, dim3(g0 + g1), dim3(kThreads), 0, st, draw_side(a), draw_side(b ? *b : a), g0, seed_dev);
+    const int gr = reg ? reg->gV + reg->gE : 0;
+    hipLaunchKernelGGL(sample_seeded_kernel, dim3(g0 + g1 + gr), dim3(kThreads), 0, st, draw_side(a), draw_side(b ? *b : a), g0, g0 + g1, seed_dev,
+                       reg ? *reg : meshreg::FwdArgs{});
     FX3D_LAUNCH_CHECK();
     return FX3D_OK;
 }
@@ -737,6 +748,27 @@ fx3d_status fx3d_sample_points_draw_pair(const float *verts0, int32_t Vmax0, con
     rc = draw_check(b, "fx3d_sample_points_draw_pair");
     if (rc) return rc;
     return draw_launch(a, &b, seed_dev, as_stream(s));
+}
+
+fx3d_status fx3d_sample_points_draw_pair_reg(const float *verts0, int32_t Vmax0, const int32_t *faces0, int32_t Fmax0,
+                                             const int32_t *faces_len0, int32_t B0, int32_t n0, uint64_t seed0, const void *cdf_ws0,
+                                             size_t ws_bytes0, float *out0, int32_t *face_out0, float *r1_out0, float *r2_out0,
+                                             const float *verts1, int32_t Vmax1, const int32_t *faces1, int32_t Fmax1,
+                                             const int32_t *faces_len1, int32_t B1, int32_t n1, uint64_t seed1, const void *cdf_ws1,
+                                             size_t ws_bytes1, float *out1, int32_t *face_out1, float *r1_out1, float *r2_out1,
+                                             const uint64_t *seed_dev, const fx3d_mesh_reg *reg, fx3d_stream_t s) {
+    const DrawArgs a{verts0, faces0, faces_len0, cdf_ws0, ws_bytes0, out0, r1_out0, r2_out0, face_out0, seed0, Vmax0, Fmax0, B0, n0};
+    const DrawArgs b{verts1, faces1, faces_len1, cdf_ws1, ws_bytes1, out1, r1_out1, r2_out1, face_out1, seed1, Vmax1, Fmax1, B1, n1};
+    fx3d_status rc = draw_check(a, "fx3d_sample_points_draw_pair_reg");
+    if (rc) return rc;
+    rc = draw_check(b, "fx3d_sample_points_draw_pair_reg");
+    if (rc) return rc;
+    meshreg::Ride R;
+    rc = mesh_reg_plan(reg, 1.0f, nullptr, 0, as_stream(s), "fx3d_sample_points_draw_pair_reg", &R);
+    if (rc) return rc;
+    R.fwd.total = nullptr;  // (the sum needs the chamfer loss: fx3d_chamfer_sampled_bwd_step_reg writes it)
+    R.fwd.base = nullptr;
+    return draw_launch(a, &b, seed_dev, as_stream(s), &R.fwd);
 }
 
 fx3d_status fx3d_sample_points_draw(const float *verts_padded, int32_t Vmax, const int32_t *faces_padded,

@@ -10,27 +10,37 @@ import numpy as np
 
 from . import _lib
 from .device import DeviceArray, Graph, Stream, current_stream, stream
-from .metrics import (_chamfer_points, chamfer_distance_grad, chamfer_sampled_grad, mesh_losses, mesh_losses_grad,
+from .metrics import (MeshReg, _chamfer_points, chamfer_distance_grad, chamfer_sampled_grad, mesh_losses, mesh_losses_grad,
                       sampling_adjoint_is_ordered)
 from .transforms import lincomb, offset, sample_points_grad, sample_points_pair
 
 
 def loss_dolphin(x, src, tgt, num_samples=5000, seed=None, with_grad=False, w_lap=0.1, w_edge=1.0, sync=True,
-                 seed_dev=None, m=None, step=None, ordered=True):
+                 seed_dev=None, m=None, step=None, ordered=True, fold=False):
     """Returns the Float32 loss (and the gradient w.r.t. x, device (3,sumV), when with_grad).
     ``sync=False``: the loss stays a 1-element device array (the three terms are combined by fx3d_lincomb in
     the reference's order) and the call enqueues without a single host round trip.  ``seed_dev``: device uint64
     added to both sampling seeds by the kernels (FitStepGraph advances it between replays).  ``step``: see
     :func:`chamfer_sampled_grad` (single source mesh): the optimiser step rides in the last adjoint's launch.
     ``ordered`` (default): the sampling adjoint without float atomics -- the gradient is bit-reproducible (the oracle's);
-    ``ordered=False``: the scatter with float atomics, ~12 us per call faster on one mesh of 5000 draws (slower at eight)."""
+    ``ordered=False``: the scatter with float atomics, ~12 us per call faster on one mesh of 5000 draws (slower at eight).
+    ``fold`` (with ``step``, ``sync=False``, ``with_grad``): the two regularisers ride in the sampling launches
+    (:class:`MeshReg`: forward in the draw launch, adjoint in the launch of the chamfer adjoint's rows) -- the same bits, two
+    launches less per iteration."""
     if m is None:  # (FitStepGraph passes the offset mesh the previous iteration's optimiser step already wrote)
         m = offset(src, x)
     s1 = None if seed is None else seed
     s2 = None if seed is None else seed + 1
     # (the source's fresh CDF, then BOTH draws in one launch; the target keeps its CDF while its vertices do not change)
-    A, Bp, fa, r1, r2 = sample_points_pair(m, tgt, num_samples, seed_a=s1, seed_b=s2, seed_dev=seed_dev, return_draws_a=True)
+    fold = bool(fold) and step is not None and with_grad and not sync and m.verts_aliased
+    reg = MeshReg(m, 0.0, w_lap, w_edge) if fold else None
+    A, Bp, fa, r1, r2 = sample_points_pair(m, tgt, num_samples, seed_a=s1, seed_b=s2, seed_dev=seed_dev, return_draws_a=True, reg=reg)
     loss1, ix, iy = _chamfer_points(A, Bp, 1.0, 1.0, return_indices=True, sync=sync)
+    if fold:
+        reg.set_base(loss1)
+        g = DeviceArray.empty((3, m.V * m.N), np.float32)
+        chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=m, draws_a=(fa, r1, r2), out_a=g.reshape(3, m.V, m.N), step=step, ordered=ordered, reg=reg)
+        return reg.total, g
     # both regularisers and the tutorial's sum fl(fl(l1 + fl(w_lap*l2)) + fl(w_edge*l3)) in ONE launch (unfused Float32)
     if sync:
         loss2, loss3, _ = mesh_losses(m, 0.0, w_lap, w_edge, sync=True)
@@ -98,10 +108,11 @@ class FitStepGraph:
     ``ordered`` (round 6, the default): the sampling adjoint without float atomics -- every vertex's sum in a fixed order, the
     gradient the oracle's bit for bit and the same on every replay (as the reference's CPU adjoint is), with the optimiser step in
     the gather's launch (``step_in_launch``).  ``ordered=False``: the rows are scattered with float atomics while they are formed
-    (sums in arrival order): 73 against 85 us per iteration on the tutorial's pair, 109 against 106 at eight meshes (bench.py
-    ``graph_replay`` / ``graph_replay_scatter``)."""
+    (sums in arrival order; bench.py ``graph_replay`` / ``graph_replay_scatter``).  ``fold`` (with the ordered form and the step in
+    its launch): the two regularisers ride in the sampling launches (:class:`MeshReg`) -- five launches per iteration instead of
+    seven, the same bits."""
 
-    def __init__(self, x, src, tgt, opt, num_samples=5000, seed=0x5EED0C3, w_lap=0.1, w_edge=1.0, ordered=True, step_in_launch=True):
+    def __init__(self, x, src, tgt, opt, num_samples=5000, seed=0x5EED0C3, w_lap=0.1, w_edge=1.0, ordered=True, step_in_launch=True, fold=True):
         self.x, self.opt = x, opt
         self.stream = Stream.create()
         self.counter = DeviceArray.zeros((1,), np.uint64)
@@ -121,7 +132,7 @@ class FitStepGraph:
             m = src.with_verts_packed(self.mverts) if fused else None
             st = opt.step_args(x, src.dev("verts_packed"), self.mverts, self.counter, 2) if in_launch else None
             loss, g = loss_dolphin(x, src, tgt, num_samples, seed=seed, with_grad=True, w_lap=w_lap, w_edge=w_edge,
-                                   sync=False, seed_dev=self.counter, m=m, step=st, ordered=ordered)
+                                   sync=False, seed_dev=self.counter, m=m, step=st, ordered=ordered, fold=fold and in_launch)
             if in_launch:
                 pass
             elif fused:

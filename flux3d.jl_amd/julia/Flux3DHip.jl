@@ -439,6 +439,72 @@ function chamfer_sampled_grad_step!(g::HipArray{Float32}, A::HipArray{Float32,3}
     return out
 end
 
+# ---- the fit iteration's regularisers as passengers of its sampling launches (include/flux3d_hip.h: fx3d_mesh_reg) ----
+# examples/fit_mesh.jl:80-83: 0.1 laplacian_loss(m) + edge_loss(m).  Field for field the C struct (isbits: passed by reference).
+struct MeshRegC
+    verts::Ptr{Cvoid}; V::Int64
+    rowptr::Ptr{Cvoid}; colind::Ptr{Cvoid}; vals::Ptr{Cvoid}
+    edges::Ptr{Cvoid}; E::Int64
+    target::Float32; w_lap::Float32; w_edge::Float32
+    base_dev::Ptr{Cvoid}; loss_lap_dev::Ptr{Cvoid}; loss_edge_dev::Ptr{Cvoid}; total_dev::Ptr{Cvoid}
+    ws::Ptr{Cvoid}; ws_bytes::Csize_t
+end
+# `out` (3 Float32 on the device) receives laplacian_loss, edge_loss and ((base + w_lap lap) + w_edge edge); `ws`: mesh_losses_workspace(m)
+function mesh_reg(m::TriMesh{Float32,R,HipArray}, ws::HipArray{UInt8}, out::HipArray{Float32}; target::Number = 0, w_lap::Number = 0.1,
+                  w_edge::Number = 1.0, base::Union{Nothing,HipArray{Float32}} = nothing) where {R}
+    verts = get_verts_packed(m)::HipArray{Float32,2}
+    rowptr, colind, vals = laplacian_csr_dev(m); edges = edges_dev(m)
+    return MeshRegC(verts.ptr, size(verts, 2), rowptr.ptr, colind.ptr, vals.ptr, edges.ptr, size(edges, 1), Float32(target),
+                    Float32(w_lap), Float32(w_edge), base === nothing ? C_NULL : base.ptr, out.ptr, out.ptr + 4, out.ptr + 8, ws.ptr,
+                    length(ws))
+end
+# the draws of chamfer_distance(m1, m2, n) with the regularisers' forward of m1 riding in the launch; also returns m1's draws
+function sample_points_pair_reg(m1::TriMesh{Float32,R1,HipArray}, m2::TriMesh{Float32,R2,HipArray}, reg::MeshRegC, n::Int = 5000;
+                                eps::Number = Flux3D.EPS, seed1::UInt64 = rand(UInt64), seed2::UInt64 = seed1 + 1) where {R1,R2}
+    v1 = get_verts_padded(m1); v2 = get_verts_padded(m2)
+    f1 = faces_padded_dev(m1); l1 = faces_len_dev(m1); f2 = faces_padded_dev(m2); l2 = faces_len_dev(m2)
+    nb1 = Ref{Csize_t}(0); nb2 = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_sample_points_workspace_bytes(m1.F::Int32, m1.N::Int32, nb1::Ref{Csize_t})::Int32)
+    check(@ccall LIB.fx3d_sample_points_workspace_bytes(m2.F::Int32, m2.N::Int32, nb2::Ref{Csize_t})::Int32)
+    w1 = HipArray{UInt8,1}(undef, (Int(nb1[]),)); w2 = HipArray{UInt8,1}(undef, (Int(nb2[]),))
+    check(@ccall LIB.fx3d_sample_points_cdf_pair(v1.ptr::Ptr{Cvoid}, m1.V::Int32, f1.ptr::Ptr{Cvoid}, m1.F::Int32, l1.ptr::Ptr{Cvoid},
+                                                 m1.N::Int32, w1.ptr::Ptr{Cvoid}, length(w1)::Csize_t, v2.ptr::Ptr{Cvoid}, m2.V::Int32,
+                                                 f2.ptr::Ptr{Cvoid}, m2.F::Int32, l2.ptr::Ptr{Cvoid}, m2.N::Int32, w2.ptr::Ptr{Cvoid},
+                                                 length(w2)::Csize_t, Float64(eps)::Float64, DEFAULT_STREAM::Stream)::Int32)
+    o1 = HipArray{Float32,3}(undef, (3, n, m1.N)); o2 = HipArray{Float32,3}(undef, (3, n, m2.N))
+    fi = HipArray{Int32,2}(undef, (n, m1.N)); ra = HipArray{Float32,2}(undef, (n, m1.N)); rb = HipArray{Float32,2}(undef, (n, m1.N))
+    check(@ccall LIB.fx3d_sample_points_draw_pair_reg(v1.ptr::Ptr{Cvoid}, m1.V::Int32, f1.ptr::Ptr{Cvoid}, m1.F::Int32, l1.ptr::Ptr{Cvoid},
+                                                      m1.N::Int32, n::Int32, seed1::UInt64, w1.ptr::Ptr{Cvoid}, length(w1)::Csize_t,
+                                                      o1.ptr::Ptr{Cvoid}, fi.ptr::Ptr{Cvoid}, ra.ptr::Ptr{Cvoid}, rb.ptr::Ptr{Cvoid},
+                                                      v2.ptr::Ptr{Cvoid}, m2.V::Int32, f2.ptr::Ptr{Cvoid}, m2.F::Int32, l2.ptr::Ptr{Cvoid},
+                                                      m2.N::Int32, n::Int32, seed2::UInt64, w2.ptr::Ptr{Cvoid}, length(w2)::Csize_t,
+                                                      o2.ptr::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
+                                                      C_NULL::Ptr{Cvoid}, Ref(reg)::Ref{MeshRegC}, DEFAULT_STREAM::Stream)::Int32)
+    return o1, o2, (fi, ra, rb)
+end
+# chamfer_sampled_grad_step! with the regularisers' adjoint (and the objective's sum) riding in its first launch: g is overwritten
+function chamfer_sampled_grad_step_reg!(g::HipArray{Float32}, A::HipArray{Float32,3}, B::HipArray{Float32,3}, ix::HipArray{Int32,2},
+                                        iy::HipArray{Int32,2}, m, draws, reg::MeshRegC, x::HipArray{Float32}, vel::HipArray{Float32},
+                                        base::HipArray{Float32}, out::HipArray{Float32}; eta = 1.0, rho = 0.9, w1::Number = 1.0,
+                                        w2::Number = 1.0, gout::Number = 1, counter = C_NULL, inc::Integer = 0)
+    _, N, Bn = size(A); _, M, _ = size(B)
+    vfr, vfe = vertex_faces_dev(m)
+    nb = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_chamfer_sampled_bwd_workspace_bytes(N::Int32, M::Int32, Bn::Int32, nb::Ref{Csize_t})::Int32)
+    ws = workspace(nb[])
+    check(@ccall LIB.fx3d_chamfer_sampled_bwd_step_reg(A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32, Bn::Int32, ix.ptr::Ptr{Cvoid},
+                                                       iy.ptr::Ptr{Cvoid}, Float32(w1)::Float32, Float32(w2)::Float32,
+                                                       Float32(gout)::Float32, faces_padded_dev(m).ptr::Ptr{Cvoid}, m.V::Int32,
+                                                       m.F::Int32, draws[1].ptr::Ptr{Cvoid}, draws[2].ptr::Ptr{Cvoid},
+                                                       draws[3].ptr::Ptr{Cvoid}, g.ptr::Ptr{Cvoid}, 0::Int32, vfr.ptr::Ptr{Cvoid},
+                                                       vfe.ptr::Ptr{Cvoid}, Float32(rho)::Float32, Float32(eta)::Float32,
+                                                       vel.ptr::Ptr{Cvoid}, x.ptr::Ptr{Cvoid}, base.ptr::Ptr{Cvoid}, out.ptr::Ptr{Cvoid},
+                                                       (counter isa HipArray ? counter.ptr : counter)::Ptr{Cvoid}, UInt64(inc)::UInt64,
+                                                       ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t, Ref(reg)::Ref{MeshRegC},
+                                                       DEFAULT_STREAM::Stream)::Int32)
+    return out
+end
+
 # ---- k-NN graph: replaces CreateSingleKNNGraph + the per-batch loop (src/models/dgcnn.jl:3-7,36) --
 function knn_graph(X::HipArray{Float32,3}, K::Int)
     F, N, B = size(X)

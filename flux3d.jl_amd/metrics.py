@@ -156,7 +156,7 @@ def sampling_adjoint_is_ordered(m, n):
 
 
 def chamfer_sampled_grad(A, B, idx_a, idx_b, mesh_a=None, draws_a=None, mesh_b=None, draws_b=None, w1=1.0, w2=1.0,
-                         gout=1.0, B_global=None, out_a=None, out_b=None, ordered=True, step=None):
+                         gout=1.0, B_global=None, out_a=None, out_b=None, ordered=True, step=None, reg=None):
     """Adjoint of ``chamfer_distance(m_a::TriMesh, m_b::TriMesh, n)`` (src/metrics/mesh.jl:34-44) w.r.t. the padded vertices of
     ``mesh_a`` and / or ``mesh_b`` in ONE launch (fx3d_chamfer_sampled_bwd): ``A`` / ``B`` are the sampled clouds of the forward,
     ``draws_*`` = (face_idx, r1, r2) of :func:`sample_points` (``return_draws=True``), ``idx_*`` the forward's neighbour indices.
@@ -164,14 +164,19 @@ def chamfer_sampled_grad(A, B, idx_a, idx_b, mesh_a=None, draws_a=None, mesh_b=N
     ``ordered`` (default): no float atomics -- every vertex's sum in a fixed order, the same bits on every run (meshes whose draws
     fit one CU's LDS -- ~5300 draws at 5120 faces --, otherwise, or ``ordered=False``, the float-atomic scatter).
     ``step`` = (rho, eta, vel, params, base, out, counter, inc): the Momentum step + offset of the fit_mesh loop applied to
-    ``mesh_a``'s finished gradient rows in the same launch (meshes of equal vertex counts, ordered form).  Returns (g_a, g_b) (None for a skipped side)."""
+    ``mesh_a``'s finished gradient rows in the same launch (meshes of equal vertex counts, ordered form).
+    ``reg`` (with ``step``): a :class:`MeshReg` of ``mesh_a`` whose forward rode in the draw launch -- its adjoint is written to
+    ``out_a`` by spare blocks of the first launch and the sampling adjoint adds on top (``out_a`` is overwritten, not added to).
+    Returns (g_a, g_b) (None for a skipped side)."""
     x, y = _as_dev_points(A), _as_dev_points(B)
     D, N, M, Bn = _check_pair(x, y)
     if D != 3:
         raise ValueError("chamfer_sampled_grad: sampled clouds are (3, n, B)")
     if (out_a is None) != (out_b is None) and mesh_a is not None and mesh_b is not None:
         raise ValueError("chamfer_sampled_grad: pass both out arrays or neither")
-    accumulate = (out_a is not None) or (out_b is not None)
+    accumulate = ((out_a is not None) or (out_b is not None)) and reg is None
+    if reg is not None and step is None:
+        raise ValueError("chamfer_sampled_grad(reg=...) rides with step=...")
     def fits(m, n):
         if m is None:
             return True
@@ -196,6 +201,11 @@ def chamfer_sampled_grad(A, B, idx_a, idx_b, mesh_a=None, draws_a=None, mesh_b=N
         if mesh_a is None or mesh_b is not None or not mesh_a.verts_aliased or not ordered:
             raise ValueError("chamfer_sampled_grad(step=...): gradient w.r.t. mesh_a only, meshes of equal vertex counts, ordered form")
         rho, eta, vel, params, base, out, counter, inc = step
+        if reg is not None:
+            _lib.call("fx3d_chamfer_sampled_bwd_step_reg", x.ptr, N, y.ptr, M, Bn, idx_a.ptr, idx_b.ptr, float(w1), float(w2), float(gout),
+                      *sa, int(accumulate), *vfa, float(rho), float(eta), vel.ptr, params.ptr, base.ptr, out.ptr,
+                      counter.ptr if counter is not None else None, int(inc), ws.ptr, ws.nbytes, reg.ptr, current_stream().handle)
+            return ga, None
         _lib.call("fx3d_chamfer_sampled_bwd_step", x.ptr, N, y.ptr, M, Bn, idx_a.ptr, idx_b.ptr, float(w1), float(w2), float(gout),
                   *sa, int(accumulate), *vfa, float(rho), float(eta), vel.ptr, params.ptr, base.ptr, out.ptr,
                   counter.ptr if counter is not None else None, int(inc), ws.ptr, ws.nbytes, current_stream().handle)
@@ -309,6 +319,35 @@ def mesh_losses(m, target_length=0.0, w_lap=0.1, w_edge=1.0, base=None, sync=Tru
         h = out.to_host()
         return np.float32(h[0]), np.float32(h[1]), np.float32(h[2])
     return out.slab(0, 1), out.slab(1, 1), out.slab(2, 1)
+
+
+class MeshReg:
+    """``w_lap * laplacian_loss(m) + w_edge * edge_loss(m, target_length)`` of a DEVICE mesh as passengers of the fit iteration's
+    sampling launches (include/flux3d_hip.h: fx3d_mesh_reg; examples/fit_mesh.jl:80-83): hand it to
+    :func:`flux3d_hip.transforms.sample_points_pair` (the forward rides in the draw launch: ``lap`` / ``edge``) and, with ``base``
+    set to the chamfer term, to :func:`chamfer_sampled_grad` (the adjoint rides in the launch of the chamfer adjoint's rows:
+    ``total`` = (base + w_lap lap) + w_edge edge).  The bits of :func:`mesh_losses` / :func:`mesh_losses_grad`, two launches less."""
+
+    def __init__(self, m, target_length=0.0, w_lap=0.1, w_edge=1.0):
+        if not m.on_device or not m.verts_aliased:
+            raise ValueError("MeshReg: a device mesh whose padded vertices are its packed ones (one mesh, or equal vertex counts)")
+        verts, edges = m.dev("verts_packed"), m.dev("edges")
+        V, E = verts.shape[1], edges.shape[0]
+        ws = _mesh_fused_ws(m, V, E)
+        self.out = DeviceArray.empty((3,), np.float32)
+        self.lap, self.edge, self.total = self.out.slab(0, 1), self.out.slab(1, 1), self.out.slab(2, 1)
+        self._keep = (verts, edges, ws, m)
+        self.c = _lib.MeshRegStruct(verts.ptr, V, m.dev("lap_rowptr").ptr, m.dev("lap_colind").ptr, m.dev("lap_vals").ptr, edges.ptr, E,
+                                    float(target_length), float(w_lap), float(w_edge), None, self.lap.ptr, self.edge.ptr,
+                                    self.total.ptr, ws.ptr, ws.nbytes)
+
+    def set_base(self, base):
+        self._base = base
+        self.c.base_dev = base.ptr if base is not None else None
+
+    @property
+    def ptr(self):
+        return C.addressof(self.c)
 
 
 def mesh_losses_grad(m, target_length=0.0, g_lap=0.1, g_edge=1.0, out=None, reuse_forward=False):

@@ -100,11 +100,12 @@ def sample_points(m, num_samples=5000, eps=EPS, seed=None, return_draws=False,
 
 
 def sample_points_pair(ma, mb, num_samples=5000, eps=EPS, seed_a=None, seed_b=None, reuse_cdf=True, seed_dev=None,
-                       return_draws_a=False):
+                       return_draws_a=False, reg=None):
     """``(sample_points(ma, n; seed_a), sample_points(mb, n; seed_b))`` -- what chamfer_distance(m1, m2, n) draws
     (src/metrics/mesh.jl:41-42) -- with both CDF builds in one launch and both draws in one launch
     (fx3d_sample_points_cdf_pair / _draw_pair): identical results, two launch-bound kernels less per evaluation.
-    ``return_draws_a``: also (face_idx, r1, r2) of the first mesh's draws (the fitting loop's adjoint needs them)."""
+    ``return_draws_a``: also (face_idx, r1, r2) of the first mesh's draws (the fitting loop's adjoint needs them).
+    ``reg``: a :class:`flux3d_hip.metrics.MeshReg` of ``ma`` -- the forward of its two regularisers rides in the draw launch."""
     if seed_a is None or seed_b is None:
         _seed_counter[0] = (_seed_counter[0] * 6364136223846793005 + 1442695040888963407) % (1 << 64)
         seed_a = _seed_counter[0] if seed_a is None else seed_a
@@ -138,10 +139,11 @@ def sample_points_pair(ma, mb, num_samples=5000, eps=EPS, seed_a=None, seed_b=No
     fo = DeviceArray.empty((n, m0.N), np.int32) if return_draws_a else None
     ra = DeviceArray.empty((n, m0.N), np.float32) if return_draws_a else None
     rb = DeviceArray.empty((n, m0.N), np.float32) if return_draws_a else None
-    _lib.call("fx3d_sample_points_draw_pair", v0.ptr, m0.V, f0.ptr, m0.F, m0.dev("faces_len").ptr, m0.N, n, int(seed_a) & mask,
+    _lib.call("fx3d_sample_points_draw_pair_reg" if reg is not None else "fx3d_sample_points_draw_pair",
+              v0.ptr, m0.V, f0.ptr, m0.F, m0.dev("faces_len").ptr, m0.N, n, int(seed_a) & mask,
               w0.ptr, w0.nbytes, outs[0].ptr, fo.ptr if fo else None, ra.ptr if ra else None, rb.ptr if rb else None,
               v1.ptr, m1.V, f1.ptr, m1.F, m1.dev("faces_len").ptr, m1.N, n, int(seed_b) & mask, w1.ptr, w1.nbytes, outs[1].ptr,
-              None, None, None, seed_dev.ptr if seed_dev is not None else None, st)
+              None, None, None, seed_dev.ptr if seed_dev is not None else None, *([reg.ptr] if reg is not None else []), st)
     return (outs[0], outs[1], fo, ra, rb) if return_draws_a else (outs[0], outs[1])
 
 

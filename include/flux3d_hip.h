@@ -220,6 +220,46 @@ FX3D_API fx3d_status fx3d_chamfer_sampled_bwd_step(const float *x, int32_t N, co
                                                    float *vel, float *params, const float *base, float *out, uint64_t *ctr,
                                                    uint64_t inc, void *ws, size_t ws_bytes, fx3d_stream_t s);
 
+/* ---- The fit iteration's regularisers as PASSENGERS of its sampling launches (round 6) ----------------------------------
+ * examples/fit_mesh.jl:78-84: loss = chamfer_distance(m, tgt, 5000) + 0.1 laplacian_loss(m) + edge_loss(m).  The two regularisers
+ * are launch-bound at tutorial scale (5 us kernels behind 4.4 us of graph-node latency each); handed over as an fx3d_mesh_reg their
+ * forward runs as extra blocks of the DRAW launch (fx3d_sample_points_draw_pair_reg: loss_lap_dev, loss_edge_dev and the workspace's
+ * unit rows are written; verts must be the vertices the draws' mesh 0 holds) and their adjoint as extra blocks of the launch that
+ * forms the chamfer adjoint's rows (fx3d_chamfer_sampled_bwd_step_reg: gverts_x = accumulate ? gverts_x + g_reg : g_reg with
+ * g_reg = fx3d_mesh_losses_bwd's bits for g_lap = w_lap gout, g_edge = w_edge gout, the sampling adjoint's gather then adds on top;
+ * total_dev, optional, receives ((*base_dev or 0) + w_lap lap) + w_edge edge, fx3d_mesh_losses' sum).  Results are bit-identical to
+ * fx3d_mesh_losses / fx3d_mesh_losses_bwd(reuse_forward = 1) / fx3d_chamfer_sampled_bwd_step(accumulate = 1) called one after the other:
+ * two launches less per iteration.  All pointers are device pointers; V == B * Vmax of the source batch; ws:
+ * fx3d_mesh_losses_workspace_bytes(V, E), the same for both calls. */
+typedef struct fx3d_mesh_reg {
+    const float *verts;          /* (3, V) packed vertices */
+    int64_t V;
+    const int32_t *rowptr, *colind;  /* the Laplacian's CSR, 0-based (fx3d_mesh_losses) */
+    const float *vals;
+    const int32_t *edges;        /* (E, 2) column-major: first vertices, then second vertices */
+    int64_t E;
+    float target, w_lap, w_edge;
+    const float *base_dev;       /* the chamfer loss (optional) */
+    float *loss_lap_dev, *loss_edge_dev;  /* required */
+    float *total_dev;            /* optional */
+    void *ws;
+    size_t ws_bytes;
+} fx3d_mesh_reg;
+FX3D_API fx3d_status fx3d_sample_points_draw_pair_reg(const float *verts0, int32_t Vmax0, const int32_t *faces0, int32_t Fmax0,
+                                                      const int32_t *faces_len0, int32_t B0, int32_t n0, uint64_t seed0, const void *cdf_ws0,
+                                                      size_t ws_bytes0, float *out0, int32_t *face_out0, float *r1_out0, float *r2_out0,
+                                                      const float *verts1, int32_t Vmax1, const int32_t *faces1, int32_t Fmax1,
+                                                      const int32_t *faces_len1, int32_t B1, int32_t n1, uint64_t seed1, const void *cdf_ws1,
+                                                      size_t ws_bytes1, float *out1, int32_t *face_out1, float *r1_out1, float *r2_out1,
+                                                      const uint64_t *seed_dev, const fx3d_mesh_reg *reg, fx3d_stream_t s);
+FX3D_API fx3d_status fx3d_chamfer_sampled_bwd_step_reg(const float *x, int32_t N, const float *y, int32_t M, int32_t B, const int32_t *idx_x,
+                                                       const int32_t *idx_y, float w1, float w2, float gout,
+                                                       const int32_t *faces_x, int32_t V, int32_t F, const int32_t *face_idx_x,
+                                                       const float *r1_x, const float *r2_x, float *gverts_x, int32_t accumulate,
+                                                       const int32_t *vf_rowptr_x, const int32_t *vf_ent_x, float rho, float eta,
+                                                       float *vel, float *params, const float *base, float *out, uint64_t *ctr,
+                                                       uint64_t inc, void *ws, size_t ws_bytes, const fx3d_mesh_reg *reg, fx3d_stream_t s);
+
 /* ---- k-NN graph (src/models/dgcnn.jl:3-7,36) ---------------------------------------------------
  * knn(KDTree(y), x, k+drop_first, true)[1][1+drop_first:end] for every point of every batch
  * element: idx:(k,N,B) int32 0-based sorted by (distance, index); dist:(k,N,B) squared distances

@@ -1384,3 +1384,73 @@ def test_chamfer_sampled_adjoint_with_the_optimiser_step_in_its_launch(gpu_fx, o
         assert np.array_equal(a.to_host(), b.to_host())
     assert int(ctr_a.to_host()[0]) == int(ctr_b.to_host()[0]) == 2
     assert np.abs(vel_b.to_host() - vel0).max() > 0
+
+
+@pytest.mark.parametrize("nb,w_lap", [(1, 0.1), (3, 0.1), (1, 0.0)])
+def test_regularisers_as_passengers_of_the_sampling_launches(gpu_fx, nb, w_lap):
+    """fx3d_mesh_reg (examples/fit_mesh.jl:80-83's 0.1 laplacian_loss + edge_loss): the forward as extra blocks of the draw launch
+    (fx3d_sample_points_draw_pair_reg), the adjoint + the tutorial's sum as extra blocks of the launch of the chamfer adjoint's rows
+    (fx3d_chamfer_sampled_bwd_step_reg) = fx3d_mesh_losses, fx3d_mesh_losses_bwd, fx3d_chamfer_sampled_bwd_step one after the other,
+    bit for bit: samples, both losses, the sum, the gradient, the optimiser's state.  A weight of zero takes launches of its own."""
+    fx = gpu_fx
+    from flux3d_jl_amd.metrics import MeshReg, _chamfer_points
+    from flux3d_jl_amd.transforms import sample_points_pair
+    n, w_edge = 5000, 1.0
+    rng = np.random.default_rng(5)
+
+    def meshes():
+        src = fx.gpu(fx.load_trimesh(*[os.path.join(GOLDEN, "sphere.obj")] * nb))
+        tgt = fx.gpu(fx.load_trimesh(*[os.path.join(GOLDEN, "teapot.obj")] * nb))
+        return src, tgt
+    src, tgt = meshes()
+    V = src.V
+    vel0 = np.asfortranarray(rng.standard_normal((3, V * nb)).astype(np.float32) * 1e-3)
+    x0 = np.asfortranarray(rng.standard_normal((3, V * nb)).astype(np.float32) * 1e-2)
+
+    def state():
+        return (fx.gpu(vel0.copy(order="F")), fx.gpu(x0.copy(order="F")), fx.DeviceArray.zeros((3, V * nb), np.float32),
+                fx.DeviceArray.zeros((1,), np.uint64))
+    # one after the other
+    A, Bp, fa, r1, r2 = sample_points_pair(src, tgt, n, seed_a=21, seed_b=22, return_draws_a=True)
+    loss1, ix, iy = _chamfer_points(A, Bp, 1.0, 1.0, return_indices=True, sync=False)
+    lap, edge, total = fx.mesh_losses(src, 0.0, w_lap, w_edge, base=loss1, sync=False)
+    g_a = fx.mesh_losses_grad(src, 0.0, w_lap, w_edge, reuse_forward=True)
+    vel_a, x_a, out_a, ctr_a = state()
+    fx.chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=src, draws_a=(fa, r1, r2), out_a=g_a.reshape(3, V, nb),
+                            step=(0.9, 0.7, vel_a, x_a, src.dev("verts_packed"), out_a, ctr_a, 2))
+    # as passengers
+    src2, tgt2 = meshes()
+    reg = MeshReg(src2, 0.0, w_lap, w_edge)
+    A2, Bp2, fa2, r12, r22 = sample_points_pair(src2, tgt2, n, seed_a=21, seed_b=22, return_draws_a=True, reg=reg)
+    loss2, ix2, iy2 = _chamfer_points(A2, Bp2, 1.0, 1.0, return_indices=True, sync=False)
+    reg.set_base(loss2)
+    g_b = fx.gpu(np.asfortranarray(rng.standard_normal((3, V * nb)).astype(np.float32)))  # (overwritten, not added to)
+    vel_b, x_b, out_b, ctr_b = state()
+    fx.chamfer_sampled_grad(A2, Bp2, ix2, iy2, mesh_a=src2, draws_a=(fa2, r12, r22), out_a=g_b.reshape(3, V, nb),
+                            step=(0.9, 0.7, vel_b, x_b, src2.dev("verts_packed"), out_b, ctr_b, 2), reg=reg)
+    for a, b in ((A, A2), (Bp, Bp2), (lap, reg.lap), (edge, reg.edge), (total, reg.total), (g_a, g_b), (vel_a, vel_b), (x_a, x_b), (out_a, out_b)):
+        assert np.array_equal(a.to_host(), b.to_host())
+    assert int(ctr_b.to_host()[0]) == 2 and np.isfinite(reg.total.to_host()).all()
+
+
+def test_fit_step_graph_with_and_without_the_folded_regularisers(gpu_fx):
+    """FitStepGraph(fold=True) -- five launches per iteration -- walks the trajectory of fold=False -- seven -- bit for bit (the ordered
+    adjoint has no float atomics: every iteration's loss and the final offsets are equal, not close)."""
+    fx = gpu_fx
+    tv, tf = fx.load_obj(os.path.join(GOLDEN, "teapot.obj"))
+    tv = tv - tv.mean(1, keepdims=True)
+    tv = np.asfortranarray((tv / np.abs(tv).max()).astype(np.float32))
+    runs = []
+    for fold in (False, True):
+        src, tgt = fx.gpu(fx.load_trimesh(os.path.join(GOLDEN, "sphere.obj"))), fx.gpu(fx.TriMesh([tv], [tf]))
+        x = fx.DeviceArray.zeros((3, src.V), np.float32)
+        step = fx.FitStepGraph(x, src, tgt, fx.Momentum(1.0, 0.9), num_samples=5000, seed=77, fold=fold)
+        losses = [float(step.first_loss.item())]
+        for _ in range(25):
+            step.step()
+            step.synchronize()
+            losses.append(float(step.loss.item()))
+        runs.append((losses, x.to_host().copy()))
+    assert runs[0][0] == runs[1][0], (runs[0][0][:4], runs[1][0][:4])
+    assert np.array_equal(runs[0][1], runs[1][1])
+    assert runs[1][0][-1] < runs[1][0][0]

@@ -147,6 +147,36 @@ JL_VAL = {"Int32": "int32_t", "Int64": "int64_t", "UInt64": "uint64_t", "Csize_t
           "Float32": "float", "Float64": "double", "UInt8": "uint8_t"}
 
 
+JL_STRUCTS = {"MeshRegC": "fx3d_mesh_reg"}  # Julia isbits struct -> the C struct it mirrors field for field
+
+
+def test_structs_match_the_header():
+    """Every struct the shim passes by reference has the header's fields, in order, with matching types (both sides lay isbits
+    fields out by the C rules)."""
+    hdr = _strip_c_comments(open(HDR).read())
+    jl = _strip_jl_comments(open(JL).read())
+    for jname, cname in JL_STRUCTS.items():
+        cm = re.search(r"typedef\s+struct\s+" + cname + r"\s*\{(.*?)\}\s*" + cname + r"\s*;", hdr, flags=re.S)
+        assert cm, cname
+        cfields = []
+        for decl in cm.group(1).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            first, *rest = [d.strip() for d in decl.split(",")]
+            ct = _norm_ctype(first)
+            cfields.append(ct)
+            for r in rest:  # `const int32_t *rowptr, *colind`, `float target, w_lap`: the base type carries over, the stars are per name
+                cfields.append(("ptr" if "*" in r else "val", ct[1]))
+        jm = re.search(r"\bstruct\s+" + jname + r"\b(.*?)\bend\b", jl, flags=re.S)
+        assert jm, jname
+        jfields = re.findall(r"\w+::([\w\{\}]+)", jm.group(1))
+        assert len(jfields) == len(cfields), (jname, len(jfields), len(cfields))
+        for i, (jt, ct) in enumerate(zip(jfields, cfields)):
+            ok = (jt == "Ptr{Cvoid}") if ct[0] == "ptr" else JL_VAL.get(jt) == ct[1]
+            assert ok, (jname, i, jt, ct)
+
+
 def _jl_matches(jt, ct):
     """Is the Julia @ccall annotation `jt` a correct way to pass the C parameter `ct`?"""
     jt = JL_ALIASES.get(jt, jt)
@@ -162,6 +192,8 @@ def _jl_matches(jt, ct):
         if not m:
             return False
         inner = m.group(2)
+        if inner in JL_STRUCTS:  # a struct passed by reference (its fields are checked by test_structs_match_the_header)
+            return JL_STRUCTS[inner] == base
         if inner == "T":  # host array of the method's element type: only for `void *`
             return base == "void"
         if inner == "UInt8":
@@ -223,6 +255,29 @@ def test_ctypes_twin_matches_the_header_types():
             if not ok:
                 bad.append(f"{name} arg {i + 1}: {pt} vs {(kind, base)}")
     assert not bad, "\n".join(bad)
+
+
+def test_ctypes_struct_matches_the_header():
+    """_lib.MeshRegStruct is fx3d_mesh_reg field for field (names, order, types)."""
+    from flux3d_jl_amd import _lib
+    hdr = _strip_c_comments(open(HDR).read())
+    cm = re.search(r"typedef\s+struct\s+fx3d_mesh_reg\s*\{(.*?)\}\s*fx3d_mesh_reg\s*;", hdr, flags=re.S)
+    cfields = []
+    for decl in cm.group(1).split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *rest = [d.strip() for d in decl.split(",")]
+        ct = _norm_ctype(first)
+        cfields.append((first.replace("*", " ").split()[-1], ct))
+        for r in rest:
+            cfields.append((r.replace("*", " ").strip(), ("ptr" if "*" in r else "val", ct[1])))
+    val = {"int64_t": C.c_int64, "size_t": C.c_size_t, "float": C.c_float}
+    got = _lib.MeshRegStruct._fields_
+    assert [f[0] for f in got] == [f[0] for f in cfields]
+    for (name, pt), (_, (kind, base)) in zip(got, cfields):
+        assert (pt is C.c_void_p) if kind == "ptr" else (pt is val[base]), (name, pt, kind, base)
+    assert C.sizeof(_lib.MeshRegStruct) == 120
 
 
 # ---------------------------------------------------------------- structure lint
