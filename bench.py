@@ -855,9 +855,9 @@ def config_one_liners(fx):
             it[0] += 1
         e = _per_call_ms(fx, eager)
 
-        def replayed(ordered):
+        def replayed(ordered, fold=True):
             xg = fx.DeviceArray.zeros((3, int(src.dev("verts_packed").shape[1])), np.float32)
-            step = fx.FitStepGraph(xg, src, tgt, fx.Momentum(1.0, 0.9), num_samples=5000, ordered=ordered)
+            step = fx.FitStepGraph(xg, src, tgt, fx.Momentum(1.0, 0.9), num_samples=5000, ordered=ordered, fold=fold)
             for _ in range(20):
                 step.step()
             step.synchronize()
@@ -870,13 +870,17 @@ def config_one_liners(fx):
             ts = np.array([ev[i].elapsed_ms(ev[i + 1]) for i in range(100)])
             return {"min_ms": float(ts.min()), "median_ms": float(np.median(ts)), "samples": 100}, float(step.loss.item())
         det, loss_after = replayed(True)
+        unfolded, _ = replayed(True, fold=False)
         fast, _ = replayed(False)
         B, V, F = src.N, src.V, src.F
         nb = 2 * (12.0 * V * B + 12.0 * F * B + 8.0 * F * B + 12.0 * 5000 * B) + 4.0 * 3 * B * 2 * 5000 * 2 + 3 * 12.0 * V * B
         return {"what": label, "eager": e, "graph_replay": det,
-                "graph_replay_scatter": dict(fast, note="FitStepGraph(ordered=False): the sampling adjoint scatters with float atomics (sums in arrival order); "
-                                                       "the default replay (graph_replay) gathers in a fixed order -- the gradient is the oracle's bit for bit "
-                                                       "and the same on every run (sample_gather.h)"),
+                "graph_replay_unfolded": dict(unfolded, note="FitStepGraph(fold=False): the two regularisers as launches of their own (seven launches per "
+                                                             "iteration); the default (graph_replay) carries them as spare blocks of the draw launch and of "
+                                                             "the launch of the chamfer adjoint's rows (fx3d_mesh_reg: five launches, the same bits)"),
+                "graph_replay_scatter": dict(fast, note="FitStepGraph(ordered=False): the sampling adjoint scatters with float atomics (sums in arrival order), "
+                                                       "six launches; the default replay (graph_replay) gathers in a fixed order -- the gradient is the oracle's "
+                                                       "bit for bit and the same on every run (sample_gather.h)"),
                 "loss_after": loss_after,
                 "roofline": _roof(det["min_ms"], flops=16.0 * B * 5000 * 5000, nbytes=nb)}
     tv, tf = fx.load_obj(os.path.join(g, "teapot.obj"))   # the tutorial's preprocessing of its target (examples/fit_mesh.jl:46-54):
