@@ -416,10 +416,11 @@ __device__ __forceinline__ void bg_rows(BgLds &L, const BgJob &J) {
     }
 }
 
+// blk: the block's number among the launch's row blocks; one_side >= 0: only that side's rows are formed (B * nsplit blocks)
 __device__ __forceinline__ BgJob bg_job(const float *x, int N, const float *y, int M, int D, const int32_t *idx_x,
-                                        const int32_t *idx_y, float ca, float cb, int nsplit) {
-    const int part = blockIdx.x % nsplit, bs = blockIdx.x / nsplit;
-    const int b = bs >> 1, side = bs & 1;  // side 0: gx, 1: gy
+                                        const int32_t *idx_y, float ca, float cb, int nsplit, int blk, int one_side = -1) {
+    const int part = blk % nsplit, bs = blk / nsplit;
+    const int b = one_side >= 0 ? bs : bs >> 1, side = one_side >= 0 ? one_side : bs & 1;  // side 0: gx, 1: gy
     BgJob J{};
     J.side = side; J.D = D; J.b = b;
     J.R = side ? M : N; J.S = side ? N : M;
@@ -443,28 +444,45 @@ struct SgTabJobs {
     int F[2], n[2], B;
 };
 static_assert(kBgThreads == sg::kSgThreads, "row blocks and table blocks share a launch");
-template <bool D3>
-__global__ __launch_bounds__(kBgThreads, FX3D_BG_OCC) void chamfer_bwd_gather_kernel(
-    const float *__restrict__ x, int N, const float *__restrict__ y, int M, int D, const int32_t *__restrict__ idx_x,
-    const int32_t *__restrict__ idx_y, float ca, float cb, float *__restrict__ gx, float *__restrict__ gy, int nsplit, int nrow,
-    SgTabJobs tj, int ntab, meshreg::Ride ride) {
-    if ((int)blockIdx.x >= nrow) {
-        extern __shared__ __attribute__((aligned(16))) unsigned char tab_lds[];
-        int e = (int)blockIdx.x - nrow, side = 0;
-        if (e >= ntab) {  // the regularisers' adjoint (mesh_reg.h): reads the vertices and the forward's unit rows, writes gverts
-            meshreg::adj_block(ride, e - ntab);
-            return;
-        }
-        if (tj.face_idx[0]) { if (e >= tj.B) { e -= tj.B; side = 1; } } else side = 1;
-        sg::SgMesh m{};
-        m.face_idx = tj.face_idx[side] + (size_t)e * tj.n[side];
-        m.F = tj.F[side]; m.n = tj.n[side];
-        sg::sg_tables(tab_lds, m);
-        sg::sg_tables_store(tab_lds, m.F, m.n, tj.blob[side] + (size_t)e * sg::sg_blob_bytes(m.F, m.n));
+#ifdef FX3D_RIDE_NOINLINE  // (A/B: the passengers as calls, the row blocks' register allocation as without them)
+#define FX3D_RIDE_FN __attribute__((noinline))
+#else
+#define FX3D_RIDE_FN __forceinline__
+#endif
+__device__ FX3D_RIDE_FN void bg_passenger_block(int e, const SgTabJobs &tj, int ntab, const meshreg::Ride &ride, unsigned char *tab_lds) {
+    if (e >= ntab) {  // the regularisers' adjoint (mesh_reg.h): reads the vertices and the forward's unit rows, writes gverts
+        meshreg::adj_block(ride, e - ntab);
         return;
     }
+    int side = 0;
+    if (tj.face_idx[0]) { if (e >= tj.B) { e -= tj.B; side = 1; } } else side = 1;
+    sg::SgMesh m{};
+    m.face_idx = tj.face_idx[side] + (size_t)e * tj.n[side];
+    m.F = tj.F[side]; m.n = tj.n[side];
+    sg::sg_tables(tab_lds, m);
+    sg::sg_tables_store(tab_lds, m.F, m.n, tj.blob[side] + (size_t)e * sg::sg_blob_bytes(m.F, m.n));
+}
+// RIDE: the launch carries passengers behind its nrow row blocks (fx3d_chamfer_sampled_bwd's first launch); fx3d_chamfer_bwd's own
+// launches are compiled without them
+template <bool D3, bool RIDE>
+__global__ __launch_bounds__(kBgThreads, FX3D_BG_OCC) void chamfer_bwd_gather_kernel(
+    const float *__restrict__ x, int N, const float *__restrict__ y, int M, int D, const int32_t *__restrict__ idx_x,
+    const int32_t *__restrict__ idx_y, float ca, float cb, float *__restrict__ gx, float *__restrict__ gy, int nsplit, int npass,
+    SgTabJobs tj, int ntab, meshreg::Ride ride) {
+    int blk = (int)blockIdx.x, one_side = -1;
+    if constexpr (RIDE) {
+        // the passengers take the FIRST npass block numbers: blocks are handed to the CUs in order, and behind a full round of row blocks
+        // (eight meshes: 256) the tables started a row block's time late -- the launch took 21 us instead of 10
+        if (blk < npass) {
+            extern __shared__ __attribute__((aligned(16))) unsigned char tab_lds[];
+            bg_passenger_block(blk, tj, ntab, ride, tab_lds);
+            return;
+        }
+        blk -= npass;
+        one_side = !gy ? 0 : (!gx ? 1 : -1);  // (a fitting loop differentiates w.r.t. one mesh: no blocks for the other side's rows)
+    }
     __shared__ BgLds L;
-    BgJob J = bg_job(x, N, y, M, D, idx_x, idx_y, ca, cb, nsplit);
+    BgJob J = bg_job(x, N, y, M, D, idx_x, idx_y, ca, cb, nsplit, blk, one_side);
     if (!(J.side ? gy : gx)) return;  // (a side nobody asked for: fx3d_chamfer_sampled_bwd differentiates w.r.t. one mesh)
     J.g = (J.side ? gy : gx) + (size_t)J.b * J.R * D;
     bg_rows<D3 ? 0 : 1>(L, J);
@@ -480,7 +498,7 @@ __global__ __launch_bounds__(kBgThreads, FX3D_BG_OCC) void chamfer_sampled_bwd_k
     const int32_t *__restrict__ idx_y, float ca, float cb, SampledSide sx, SampledSide sy, int nsplit) {
     __shared__ BgLds L;
     extern __shared__ __attribute__((aligned(16))) unsigned char bg_dyn[];  // the accumulators between rounds (n > 4096 samples)
-    BgJob J = bg_job(x, N, y, M, 3, idx_x, idx_y, ca, cb, nsplit);
+    BgJob J = bg_job(x, N, y, M, 3, idx_x, idx_y, ca, cb, nsplit, (int)blockIdx.x);
     J.smp = J.side ? sy : sx;
     if (!J.smp.gverts) return;
     J.part = reinterpret_cast<P3 *>(bg_dyn);
@@ -490,8 +508,8 @@ __global__ __launch_bounds__(kBgThreads, FX3D_BG_OCC) void chamfer_sampled_bwd_k
 // blocks per (cloud, side): ONE round of blocks on the chip (a block is a chain of dependent phases: a second round doubles the
 // time), a block never owns fewer than 256 rows nor more than kBgRows.  Measured (kernel us, B x N): 32 x 4096: 15 / 11.7 / 18 / 28
 // at 1 / 4 / 8 / 16 blocks per side; 8 x 5000: 17 / 13.5 / 11.6 at 1 / 4 / 16; 1 x 16384: 31 / 23 / 20 at 1 / 8 / 16.
-int bg_nsplit(int B, int maxr) {
-    int nsplit = device_cus() / (2 * B);
+int bg_nsplit(int B, int maxr, int sides = 2) {
+    int nsplit = device_cus() / (sides * B);
     if (nsplit > maxr / 256) nsplit = maxr / 256;
     if (nsplit < 1) nsplit = 1;
     while ((maxr + nsplit - 1) / nsplit > kBgRows) ++nsplit;
@@ -517,11 +535,11 @@ fx3d_status fx3d_chamfer_bwd(const float *x, int32_t N, const float *y, int32_t 
     if ((long long)2 * B * nsplit < (1ll << 30) && !opt(OPT_BWD_GLOBAL_ATOMICS)) {
         ProfileScope prof("chamfer_bwd", st);
         if (D == 3)
-            hipLaunchKernelGGL(chamfer_bwd_gather_kernel<true>, dim3(2 * B * nsplit), dim3(kBgThreads), 0, st, x, N, y, M, D, idx_x,
-                               idx_y, ca, cb, gx, gy, nsplit, 2 * B * nsplit, SgTabJobs{}, 0, meshreg::Ride{});
+            hipLaunchKernelGGL((chamfer_bwd_gather_kernel<true, false>), dim3(2 * B * nsplit), dim3(kBgThreads), 0, st, x, N, y, M, D, idx_x,
+                               idx_y, ca, cb, gx, gy, nsplit, 0, SgTabJobs{}, 0, meshreg::Ride{});
         else
-            hipLaunchKernelGGL(chamfer_bwd_gather_kernel<false>, dim3(2 * B * nsplit), dim3(kBgThreads), 0, st, x, N, y, M, D, idx_x,
-                               idx_y, ca, cb, gx, gy, nsplit, 2 * B * nsplit, SgTabJobs{}, 0, meshreg::Ride{});
+            hipLaunchKernelGGL((chamfer_bwd_gather_kernel<false, false>), dim3(2 * B * nsplit), dim3(kBgThreads), 0, st, x, N, y, M, D, idx_x,
+                               idx_y, ca, cb, gx, gy, nsplit, 0, SgTabJobs{}, 0, meshreg::Ride{});
         FX3D_LAUNCH_CHECK();
         return FX3D_OK;
     }
@@ -627,12 +645,14 @@ fx3d_status chamfer_sampled_bwd_impl(const char *fn, const float *x, int32_t N, 
                 dyn = 0; ntab = 0;
                 tbx = tby = nullptr;
             } else {
-                const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&chamfer_bwd_gather_kernel<true>), (int)kTabLds, "chamfer_bwd_gather_kernel");
+                const fx3d_status arc = ensure_dynamic_lds(reinterpret_cast<const void *>(&chamfer_bwd_gather_kernel<true, true>), (int)kTabLds, "chamfer_bwd_gather_kernel");
                 if (arc != FX3D_OK) return arc;
             }
             ProfileScope prof("chamfer_sampled_bwd", st);
-            hipLaunchKernelGGL(chamfer_bwd_gather_kernel<true>, dim3(2 * B * nsplit + ntab + (ride ? ride->nadj : 0)), dim3(kBgThreads), dyn, st, x, N, y, M,
-                               3, idx_x, idx_y, ca, cb, ax.gverts ? gsx : nullptr, ay.gverts ? gsy : nullptr, nsplit, 2 * B * nsplit, tj, ntab,
+            const int sides = (ax.gverts ? 1 : 0) + (ay.gverts ? 1 : 0), npass = ntab + (ride ? ride->nadj : 0);
+            const int ns = bg_nsplit(B, sides == 2 ? (N > M ? N : M) : (ax.gverts ? N : M), sides);  // (row blocks of the requested sides only)
+            hipLaunchKernelGGL((chamfer_bwd_gather_kernel<true, true>), dim3(npass + sides * B * ns), dim3(kBgThreads), dyn, st, x, N, y, M,
+                               3, idx_x, idx_y, ca, cb, ax.gverts ? gsx : nullptr, ay.gverts ? gsy : nullptr, ns, npass, tj, ntab,
                                ride ? *ride : meshreg::Ride{});
             FX3D_LAUNCH_CHECK();
         }

@@ -106,6 +106,46 @@ def mesh_case(rng):
     return ok, f"mesh batch of {m.N} (V={m.V} F={m.F}) n={n} seed={seed}"
 
 
+def fit_case(rng):
+    """(round 6) The fit iteration's regularisers as passengers of the sampling launches (fx3d_mesh_reg) against the same calls one
+    after the other: samples, both losses, the sum, the gradient and the optimiser's state, bit for bit; the separate calls' gradient
+    against the oracle's adjoints."""
+    from flux3d_jl_amd.metrics import MeshReg, _chamfer_points
+    from flux3d_jl_amd.transforms import sample_points_pair
+    nb = int(rng.integers(1, 4))
+    V, F = int(rng.integers(4, 400)), int(rng.integers(2, 900))
+    vl = [np.asfortranarray(rng.standard_normal((3, V)).astype(np.float32) * np.float32(rng.choice([1e-2, 1.0, 20.0]))) for _ in range(nb)]
+    fl = [np.asfortranarray(np.stack([rng.choice(V, 3, replace=False) for _ in range(F)], axis=1).astype(np.uint32) + 1) for _ in range(nb)]
+    tvl, tfl = mesh_batch(rng)
+    tvl, tfl = [tvl[0]] * nb, [tfl[0]] * nb
+    n, s1, s2 = int(rng.integers(2, 900)), int(rng.integers(0, 1 << 62)), int(rng.integers(0, 1 << 62))
+    w_lap, w_edge = float(rng.choice([0.1, 0.0, 1.5])), float(rng.choice([1.0, 0.0, 0.3]))
+    vel0 = np.asfortranarray(rng.standard_normal((3, V * nb)).astype(np.float32) * 1e-3)
+    x0 = np.asfortranarray(rng.standard_normal((3, V * nb)).astype(np.float32) * 1e-2)
+    res = []
+    for passengers in (False, True):
+        src, tgt = fx.gpu(fx.TriMesh(vl, fl)), fx.gpu(fx.TriMesh(tvl, tfl))
+        if not fx.sampling_adjoint_is_ordered(src, n):
+            return True, "fit case beyond the ordered form (skipped)"
+        vel, x, out, ctr = fx.gpu(vel0.copy(order="F")), fx.gpu(x0.copy(order="F")), fx.DeviceArray.zeros((3, V * nb), np.float32), fx.DeviceArray.zeros((1,), np.uint64)
+        reg = MeshReg(src, 0.0, w_lap, w_edge) if passengers else None
+        A, Bp, fa, r1, r2 = sample_points_pair(src, tgt, n, seed_a=s1, seed_b=s2, return_draws_a=True, reg=reg)
+        loss1, ix, iy = _chamfer_points(A, Bp, 1.0, 1.0, return_indices=True, sync=False)
+        step = (0.9, 0.7, vel, x, src.dev("verts_packed"), out, ctr, 2)
+        if passengers:
+            reg.set_base(loss1)
+            g = fx.DeviceArray.empty((3, V * nb), np.float32)
+            fx.chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=src, draws_a=(fa, r1, r2), out_a=g.reshape(3, V, nb), step=step, reg=reg)
+            lap, edge, total = reg.lap, reg.edge, reg.total
+        else:
+            lap, edge, total = fx.mesh_losses(src, 0.0, w_lap, w_edge, base=loss1, sync=False)
+            g = fx.mesh_losses_grad(src, 0.0, w_lap, w_edge, reuse_forward=True)
+            fx.chamfer_sampled_grad(A, Bp, ix, iy, mesh_a=src, draws_a=(fa, r1, r2), out_a=g.reshape(3, V, nb), step=step)
+        res.append([a.to_host().copy() for a in (A, Bp, lap, edge, total, g, vel, x, out, ctr)])
+    ok = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(*res))
+    return ok, f"fit case nb={nb} V={V} F={F} n={n} seeds={s1},{s2} w=({w_lap},{w_edge})"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300.0)
@@ -115,10 +155,12 @@ def main():
     t0, ncase = time.time(), 0
     while time.time() - t0 < args.seconds:
         kind = KINDS[int(rng.integers(0, len(KINDS)))]
-        what = int(rng.integers(0, 5))
+        what = int(rng.integers(0, 6))
         B = int(rng.integers(1, 4))
         if what == 4:
             ok, desc = mesh_case(rng)
+        elif what == 5:
+            ok, desc = fit_case(rng)
         elif what == 0:  # 1-NN both directions + chamfer
             N, M = int(rng.integers(1, 3000)), int(rng.integers(1, 3000))
             if rng.random() < 0.35:  # (round 3) sizes around the launch plan's boundaries: one LDS image + an exact tail of <= 64
