@@ -1660,11 +1660,15 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         }
         __syncthreads();
         if (!s_last) return;  // (block-uniform)
+        FX3D_PROBE_MARK(6);
         acc = 0.0;
         const int qend = (tile + 1) * tpb * QB < NQ ? (tile + 1) * tpb * QB : NQ;
         // (every row of every query of this thread requested at once: these loads go to memory -- another XCD's block wrote them --
         //  and one after the other they were three dependent round trips per query, 23 k cycles for the tile's last block)
-        constexpr int kQ = 2, kS = 8;  // queries per thread (tpb <= 2: 1024 queries per tile) x subsets in flight
+        // (round 6: one query per thread and sweep, sixteen subsets in flight -- a tile has at most 1024 queries per sweep anyway, and
+        //  the fit iteration's plan, one mesh of 5000 samples against another, has twelve subsets: the four beyond the eighth were
+        //  four more dependent round trips to memory)
+        constexpr int kQ = 1, kS = 16;  // queries per thread and sweep x subsets in flight
         for (int q0 = tile * tpb * QB + tid; q0 < qend; q0 += kQ * kHThreads) {
           unsigned long long rr[kQ][kS];
 #pragma unroll
@@ -1681,7 +1685,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             unsigned long long r = rr[u][0];
 #pragma unroll
             for (int sp = 1; sp < kS; ++sp) r = rr[u][sp] < r ? rr[u][sp] : r;
-            for (int sp = kS; sp < ns; ++sp) {  // (more than eight subsets: the rest one by one)
+            for (int sp = kS; sp < ns; ++sp) {  // (more than sixteen subsets: the rest one by one)
                 const unsigned long long o = __hip_atomic_load(&p.gres[((size_t)sp * 2 * p.B + c) * p.qstride + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 r = o < r ? o : r;
             }
@@ -1691,10 +1695,12 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             acc += (double)dd;
           }
         }
+        FX3D_PROBE_MARK(7);
     }
     if (p.partials) {
         __shared__ double sm[kHThreads / 64];
         const double tot = block_sum<kHThreads>(acc, sm);
+        FX3D_PROBE_MARK(8);
         if (!p.ticket) {
             if (tid == 0) p.partials[(size_t)c * p.tiles + tile] = tot;
         } else {

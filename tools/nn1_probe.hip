@@ -137,6 +137,9 @@ int main(int argc, char **argv) {
         for (int b = 0; b < nb; ++b) {
             const unsigned long long *q = &pr[b * 16];
             if (q[15]) printf("last arriver: block %d, passes done -> ticket %llu cycles, ticket -> end %llu cycles\n", b, q[9] - q[11], q[12] - q[9]);
+            if (q[15] && q[6] > q[11] && q[8] > q[7])  // (candidate-split runs: the tile's last subset)
+                printf("  its tail from passes done (thread 0): barrier + tile counter %llu, merge %llu, block sum %llu, finalisation to the ticket %llu cycles\n",
+                       q[6] - q[11], q[7] - q[6], q[8] - q[7], q[9] - q[8]);
             else { a += (double)(q[9] - q[11]); b2 += (double)(q[12] - q[9]); ++n; }
         }
         printf("other blocks: passes done -> ticket %.0f cycles, ticket -> end %.0f cycles\n", a / n, b2 / n);
