@@ -1645,11 +1645,14 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
         //      the outputs and is the only one of them to deliver a partial.  One launch instead of two (the second one was a
         //      dependent launch of ~6 us behind a 26 us kernel at C3's shape, 8 x 5000 x 5000).
         __shared__ int s_last;
+        FX3D_PROBE_MARK2(10);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores of its gres rows have left the CU
+        FX3D_PROBE_MARK2(11);
         // (tools/nn1_probe at C3's shape: thread 0 waits ~14 k cycles here -- for the block's slower WAVES at the barrier below, not
         //  for the stores: a SIMD serves its oldest wave first, wave 0 is done ~20 k cycles before the last one at C2 too --, then
         //  counter 1.2 k, merge 4.6 k, finalisation 4.9 k cycles)
         __syncthreads();
+        FX3D_PROBE_MARK2(12);
         const int ns = (NC + CH - 1) / CH < p.nsplit ? (NC + CH - 1) / CH : p.nsplit;  // subsets that exist for this direction
         if (tid == 0) {
             const unsigned int t = (unsigned int)c * (unsigned int)p.tiles + (unsigned int)tile;
@@ -1657,6 +1660,7 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
             const unsigned int old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = old == (unsigned int)ns - 1u;
             if (s_last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            FX3D_PROBE_MARK2(13);
         }
         __syncthreads();
         if (!s_last) return;  // (block-uniform)
@@ -1676,8 +1680,16 @@ __global__ __launch_bounds__(kHThreads, 4) void nn1_f16_kernel(Nn1Params p) {
 #pragma unroll
             for (int sp = 0; sp < kS; ++sp) {
                 const int q = q0 + u * kHThreads < qend ? q0 + u * kHThreads : q0;
-                rr[u][sp] = sp < ns ? __hip_atomic_load(&p.gres[((size_t)sp * 2 * p.B + c) * p.qstride + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+                // (UNCONDITIONAL loads, a subset beyond the last re-reads the last one's row: `sp < ns ? load : ~0` compiled to a branch
+                //  around every load with a wait behind it -- twelve dependent round trips to memory, 8.8 k cycles at the fit
+                //  iteration's shape, tools/nn1_probe "tail detail")
+                const int spc = sp < ns ? sp : ns - 1;
+                rr[u][sp] = __hip_atomic_load(&p.gres[((size_t)spc * 2 * p.B + c) * p.qstride + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+#ifdef FX3D_PROBE
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          FX3D_PROBE_MARK2(14);
+#endif
 #pragma unroll
           for (int u = 0; u < kQ; ++u) {
             const int q = q0 + u * kHThreads;

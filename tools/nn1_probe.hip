@@ -137,6 +137,13 @@ int main(int argc, char **argv) {
         for (int b = 0; b < nb; ++b) {
             const unsigned long long *q = &pr[b * 16];
             if (q[15]) printf("last arriver: block %d, passes done -> ticket %llu cycles, ticket -> end %llu cycles\n", b, q[9] - q[11], q[12] - q[9]);
+            if (q[15] && b < 256 && getenv("RAW")) {
+                std::vector<unsigned long long> p2(256 * 16);
+                hipMemcpyFromSymbol(p2.data(), HIP_SYMBOL(g_probe2), p2.size() * 8);
+                printf("  tail detail (cycles from passes done): stores issued %lld, drained %lld, barrier %lld, counter back %lld, tile known %lld, rows loaded %lld, merged %lld\n",
+                       (long long)(p2[b * 16 + 10] - q[11]), (long long)(p2[b * 16 + 11] - q[11]), (long long)(p2[b * 16 + 12] - q[11]), (long long)(p2[b * 16 + 13] - q[11]),
+                       (long long)(q[6] - q[11]), (long long)(p2[b * 16 + 14] - q[11]), (long long)(q[7] - q[11]));
+            }
             if (q[15] && q[6] > q[11] && q[8] > q[7])  // (candidate-split runs: the tile's last subset)
                 printf("  its tail from passes done (thread 0): barrier + tile counter %llu, merge %llu, block sum %llu, finalisation to the ticket %llu cycles\n",
                        q[6] - q[11], q[7] - q[6], q[8] - q[7], q[9] - q[8]);
