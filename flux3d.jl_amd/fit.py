@@ -96,7 +96,7 @@ class Momentum:
 
 class FitStepGraph:
     """One iteration of the fit_mesh loop (examples/fit_mesh.jl:98-110: loss, gradient, Momentum update) captured
-    as a hipGraph: six launch-bound kernels (no memset, no copy) replayed with one launch per iteration.
+    as a hipGraph: five launch-bound kernels (no memset, no copy; seven with ``fold=False``) replayed with one launch per iteration.
 
     The sampling seeds recorded in the graph are ``seed`` and ``seed + 1`` plus a device counter that the graph
     itself advances by two per replay, so every iteration draws fresh samples (the reference draws from the global
