@@ -318,6 +318,20 @@ function _chamfer_fwd(A::HipArray{Float32,3}, B::HipArray{Float32,3}, w1::Float3
 end
 _chamfer_distance(A::HipArray{Float32,3}, B::HipArray{Float32,3}, w1::Float32 = 1.0f0, w2::Float32 = 1.0f0) =
     _chamfer_fwd(A, B, w1, w2)[1]
+# the same with the loss LEFT ON THE DEVICE (no host round trip: the shape of a captured fit iteration, where the regularisers' sum reads it
+# as its base -- mesh_reg(...; base = loss_dev)); returns the neighbour indices
+function chamfer_fwd_dev!(loss_dev::HipArray{Float32}, A::HipArray{Float32,3}, B::HipArray{Float32,3}; w1::Number = 1.0, w2::Number = 1.0)
+    D, N, Bn = size(A); _, M, _ = size(B)
+    nb = Ref{Csize_t}(0)
+    check(@ccall LIB.fx3d_chamfer_workspace_bytes(N::Int32, M::Int32, Bn::Int32, D::Int32, nb::Ref{Csize_t})::Int32)
+    ws = workspace(nb[])
+    ix = HipArray{Int32}(undef, N, Bn); iy = HipArray{Int32}(undef, M, Bn)
+    check(@ccall LIB.fx3d_chamfer_fwd(A.ptr::Ptr{Cvoid}, N::Int32, B.ptr::Ptr{Cvoid}, M::Int32, Bn::Int32, D::Int32,
+                                      Float32(w1)::Float32, Float32(w2)::Float32, loss_dev.ptr::Ptr{Cvoid}, C_NULL::Ptr{Float32},
+                                      ix.ptr::Ptr{Cvoid}, iy.ptr::Ptr{Cvoid}, ws.ptr::Ptr{Cvoid}, length(ws)::Csize_t,
+                                      DEFAULT_STREAM::Stream)::Int32)
+    return ix, iy
+end
 
 # value and gradient in ONE ABI call (what `Zygote.withgradient(chamfer_distance, A, B)` runs through the adjoint below; what
 # benchmarks/metrics.jl:24-38 times as "total" and examples/fit_mesh.jl:106-110 runs per iteration): forward with indices +

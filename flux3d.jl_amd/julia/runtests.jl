@@ -106,4 +106,28 @@ end
         @test all(isapprox.(loss, 0, rtol = 1e-5, atol = 1e-2))
         @test gradient(x -> chamfer_distance(x, x), dm) isa Tuple
     end
+
+    @testset "the tutorial's iteration in five launches (examples/fit_mesh.jl:78-110): passengers = separate calls, bit for bit" begin
+        src = hip(load_trimesh(joinpath(ASSETS, "sphere.obj"))); tgt = hip(load_trimesh(joinpath(ASSETS, "teapot.obj")))
+        nv = size(get_verts_packed(src), 2)
+        state() = (hip(zeros(Float32, 3, nv)), hip(zeros(Float32, 3, nv)), hip(zeros(Float32, 3, nv)), hip(zeros(Float32, 3, nv)))
+        base = get_verts_packed(src)
+        # one after the other: draws, chamfer, both regularisers + the objective's sum, their adjoint, the sampling adjoint + Momentum
+        ws = Flux3DHip.mesh_losses_workspace(src); loss1 = HipArray{Float32}(undef, 1)
+        A, B = Flux3DHip.sample_points_pair(src, tgt, 5000; seed1 = UInt64(21), seed2 = UInt64(22))
+        out_a = HipArray{Float32}(undef, 3)
+        reg_a = Flux3DHip.mesh_reg(src, ws, out_a; base = loss1)
+        A2, B2, draws = Flux3DHip.sample_points_pair_reg(src, tgt, reg_a, 5000; seed1 = UInt64(21), seed2 = UInt64(22))
+        @test unhip(A2) == unhip(A) && unhip(B2) == unhip(B)               # the passengers leave the draws alone
+        ix, iy = Flux3DHip.chamfer_fwd_dev!(loss1, A, B)
+        sep = Flux3DHip.mesh_losses(src, ws; base = loss1)
+        g1 = Flux3DHip.mesh_losses_grad(src, ws; reuse_forward = true)
+        x1, v1, _, o1 = state()
+        Flux3DHip.chamfer_sampled_grad_step!(g1, A, B, ix, iy, src, draws, x1, v1, base, o1; eta = 0.7, rho = 0.9)
+        # as passengers (the forward rode with the draws above)
+        g2 = HipArray{Float32}(undef, 3, nv); x2, v2, _, o2 = state()
+        Flux3DHip.chamfer_sampled_grad_step_reg!(g2, A, B, ix, iy, src, draws, reg_a, x2, v2, base, o2; eta = 0.7, rho = 0.9)
+        @test unhip(out_a) == unhip(sep)
+        @test unhip(g2) == unhip(g1) && unhip(x2) == unhip(x1) && unhip(v2) == unhip(v1) && unhip(o2) == unhip(o1)
+    end
 end
