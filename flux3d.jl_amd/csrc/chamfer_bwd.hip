@@ -186,6 +186,19 @@ __device__ __forceinline__ void bg_rows(BgLds &L, const BgJob &J) {
             wx[u] = t.x; wy[u] = t.y; wz[u] = t.z;
         }
     }
+    // (round 6) the own term's rows of the other side, requested as soon as the indices are here and consumed in phase (5): the request
+    // used to sit inside phase (5)'s per-row branch with a full wait behind it -- one more dependent trip to the L2 per row.
+    // UNCONDITIONAL loads throughout this function (a thread without a row reads row 0): `cond ? load : 0` compiles to a branch
+    // around the load and `s_waitcnt vmcnt(0)` behind it, i.e. the loads of a group leave one after the other.
+    float ojx[kBgPer], ojy[kBgPer], ojz[kBgPer];
+#pragma unroll
+    for (int u = 0; u < kBgPer; ++u) {
+        ojx[u] = 0.0f; ojy[u] = 0.0f; ojz[u] = 0.0f;
+        if (D3) {
+            const P3 t = *reinterpret_cast<const P3 *>(oth + (size_t)jown[u] * 3);
+            ojx[u] = t.x; ojy[u] = t.y; ojz[u] = t.z;
+        }
+    }
     BG_STAMP(0);
 #pragma unroll
     for (int q = 0; q < kBgPer / 2; ++q) L.cnt2[kBgPer / 2 * tid + q] = 0u;  // (the placement of every round leaves the counters at zero)
@@ -199,8 +212,14 @@ __device__ __forceinline__ void bg_rows(BgLds &L, const BgJob &J) {
 #pragma unroll
         for (int v = 0; v < kBgPer; ++v) {
             const int jl = tid + v * kBgThreads;
-            il[v] = jl < cn ? J.idx_oth[c0 + jl] - J.r0 : -1;
+            il[v] = J.idx_oth[c0 + (jl < cn ? jl : 0)];
         }
+        static_assert(kBgPer == 4, "the pin below names four values");
+        // (an empty asm that names all four: the optimiser otherwise sinks every load back into the branch of its `jl < cn` select,
+        //  with a full wait behind it -- four dependent trips to memory instead of one)
+        asm volatile("" : "+v"(il[0]), "+v"(il[1]), "+v"(il[2]), "+v"(il[3]));
+#pragma unroll
+        for (int v = 0; v < kBgPer; ++v) il[v] = tid + v * kBgThreads < cn ? il[v] - J.r0 : -1;
         __syncthreads();
         BG_STAMP(1);
         BG_STOP(1);
@@ -369,7 +388,7 @@ __device__ __forceinline__ void bg_rows(BgLds &L, const BgJob &J) {
                 const P3 w{wx[u], wy[u], wz[u]};
                 P3 ot{0.0f, 0.0f, 0.0f};
                 if ((first && own_first) || (last && !own_first)) {
-                    const P3 o = *reinterpret_cast<const P3 *>(oth + (size_t)jo * 3);
+                    const P3 o{ojx[u], ojy[u], ojz[u]};
                     ot = P3{c_own * (w.x - o.x), c_own * (w.y - o.y), c_own * (w.z - o.z)};
                 }
                 P3 a{0.0f, 0.0f, 0.0f};
@@ -381,11 +400,12 @@ __device__ __forceinline__ void bg_rows(BgLds &L, const BgJob &J) {
                         if (h >= c) break;
                         float ox[4], oy[4], oz[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (h + k < c) {
-                                const P3 t = *reinterpret_cast<const P3 *>(oth + (size_t)(c0 + e[h + k]) * 3);
-                                ox[k] = t.x; oy[k] = t.y; oz[k] = t.z;
-                            }
+                        for (int k = 0; k < 4; ++k) {  // (unconditional: a slot beyond the list re-reads the round's first row)
+                            const P3 t = *reinterpret_cast<const P3 *>(oth + (size_t)(c0 + (h + k < c ? e[h + k] : 0u)) * 3);
+                            ox[k] = t.x; oy[k] = t.y; oz[k] = t.z;
+                        }
+                        asm volatile("" : "+v"(ox[0]), "+v"(oy[0]), "+v"(oz[0]), "+v"(ox[1]), "+v"(oy[1]), "+v"(oz[1]), "+v"(ox[2]), "+v"(oy[2]),
+                                          "+v"(oz[2]), "+v"(ox[3]), "+v"(oy[3]), "+v"(oz[3]));  // (all four requested before the first is used)
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             if (h + k < c) {

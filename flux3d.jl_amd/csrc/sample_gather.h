@@ -121,11 +121,28 @@ __device__ __forceinline__ void sg_tables(unsigned char *lds, const SgMesh &m) {
     const int F = m.F, n = m.n;
     const int nw = (F + 2) / 2;
     SG_STAMP(0);
+    // the thread's draws, requested before anything else and kept for the placement (phase 3): loaded inside the loops they were one
+    // trip to the L2 per sweep, twice (`k < n ? load : skip` is a branch around the load with a full wait behind it).  kSgHold sweeps
+    // live in registers (6144 draws; the ordered form takes ~5300 at 5120 faces), draws beyond them are read where they are used.
+    constexpr int kSgHold = 6;
+    unsigned int fk[kSgHold];
+#pragma unroll
+    for (int u = 0; u < kSgHold; ++u) {
+        const int k = tid + u * kSgThreads;
+        fk[u] = (unsigned int)m.face_idx[k < n ? k : 0];  // (n >= 1)
+    }
+    asm volatile("" : "+v"(fk[0]), "+v"(fk[1]), "+v"(fk[2]), "+v"(fk[3]), "+v"(fk[4]), "+v"(fk[5]));  // (all requested together: see chamfer_bwd.hip)
+    static_assert(kSgHold == 6, "the pin above names six values");
     for (int i = tid; i < nw; i += kSgThreads) cnt2[i] = 0u;
     if (tid == 0) wsum[kSgWaves] = 0u;
     __syncthreads();
     // (1) draws per face
-    for (int k = tid; k < n; k += kSgThreads) {
+#pragma unroll
+    for (int u = 0; u < kSgHold; ++u) {
+        const unsigned int f = fk[u];
+        if (tid + u * kSgThreads < n && f < (unsigned int)F) atomicAdd(&cnt2[f >> 1], (f & 1u) ? 0x10000u : 1u);
+    }
+    for (int k = tid + kSgHold * kSgThreads; k < n; k += kSgThreads) {
         const unsigned int f = (unsigned int)m.face_idx[k];
         if (f < (unsigned int)F) atomicAdd(&cnt2[f >> 1], (f & 1u) ? 0x10000u : 1u);
     }
@@ -160,14 +177,17 @@ __device__ __forceinline__ void sg_tables(unsigned char *lds, const SgMesh &m) {
     __syncthreads();
     SG_STAMP(2);
     // (3) placement from the back of every list (arrival order; put right below), long lists registered
-    for (int k = tid; k < n; k += kSgThreads) {
-        const unsigned int f = (unsigned int)m.face_idx[k];
+    auto place = [&](unsigned int f, int k) {
         if (f < (unsigned int)F) {
             const unsigned int sh = (f & 1u) * 16u;
             const unsigned int old = atomicSub(&cnt2[f >> 1], 1u << sh);
             list[(unsigned int)start[f] + ((old >> sh) & 0xFFFFu) - 1u] = (unsigned short)k;
         }
-    }
+    };
+#pragma unroll
+    for (int u = 0; u < kSgHold; ++u)
+        if (tid + u * kSgThreads < n) place(fk[u], tid + u * kSgThreads);
+    for (int k = tid + kSgHold * kSgThreads; k < n; k += kSgThreads) place((unsigned int)m.face_idx[k], k);
     for (int f = tid; f < F; f += kSgThreads)
         if ((int)start[f + 1] - (int)start[f] > kSgSmall) big[atomicAdd(&wsum[kSgWaves], 1u)] = (unsigned short)f;
     __syncthreads();
@@ -344,6 +364,14 @@ __device__ __forceinline__ void sg_finish(unsigned char *lds, const SgMesh &m, c
             const int E_lo = m.vf_rowptr[vb0], E_hi = m.vf_rowptr[vend];
             P3 a{0.0f, 0.0f, 0.0f};
             if (ok && m.accumulate) a = *reinterpret_cast<const P3 *>(m.gverts + 3 * (size_t)v);
+            // the optimiser's state of this vertex, requested here and used behind the sums: read where it is used it was nine
+            // dependent trips to memory at the kernel's end (the stores between them may alias for all the compiler knows)
+            P3 s_vel{0.0f, 0.0f, 0.0f}, s_x{0.0f, 0.0f, 0.0f}, s_base{0.0f, 0.0f, 0.0f};
+            if (ok && st.vel) {
+                s_vel = *reinterpret_cast<const P3 *>(st.vel + 3 * (size_t)v);
+                s_x = *reinterpret_cast<const P3 *>(st.x + 3 * (size_t)v);
+                s_base = *reinterpret_cast<const P3 *>(st.base + 3 * (size_t)v);
+            }
             for (int ec = E_lo; ec < E_hi; ec += kSgInnerCap) {
                 const int eend = ec + kSgInnerCap < E_hi ? ec + kSgInnerCap : E_hi;
                 for (int e = ec + tid; e < eend; e += kSgThreads) {
@@ -382,16 +410,18 @@ __device__ __forceinline__ void sg_finish(unsigned char *lds, const SgMesh &m, c
             if (ok) {
                 *reinterpret_cast<P3 *>(m.gverts + 3 * (size_t)v) = a;
                 if (st.vel) {  // fx3d_momentum_step_offset's arithmetic (mesh.hip: momentum_offset_kernel)
-                    const float g3[3] = {a.x, a.y, a.z};
+                    const float g3[3] = {a.x, a.y, a.z}, v3[3] = {s_vel.x, s_vel.y, s_vel.z}, x3[3] = {s_x.x, s_x.y, s_x.z},
+                                b3[3] = {s_base.x, s_base.y, s_base.z};
+                    float vn[3], xn[3], on[3];
 #pragma unroll
                     for (int d = 0; d < 3; ++d) {
-                        const size_t i = 3 * (size_t)v + d;
-                        const float vn = (st.rho * st.vel[i]) + (-st.eta * g3[d]);
-                        st.vel[i] = vn;
-                        const float xn = (1.0f * st.x[i]) + (1.0f * vn);
-                        st.x[i] = xn;
-                        st.out[i] = (1.0f * st.base[i]) + (1.0f * xn);
+                        vn[d] = (st.rho * v3[d]) + (-st.eta * g3[d]);
+                        xn[d] = (1.0f * x3[d]) + (1.0f * vn[d]);
+                        on[d] = (1.0f * b3[d]) + (1.0f * xn[d]);
                     }
+                    *reinterpret_cast<P3 *>(st.vel + 3 * (size_t)v) = P3{vn[0], vn[1], vn[2]};
+                    *reinterpret_cast<P3 *>(st.x + 3 * (size_t)v) = P3{xn[0], xn[1], xn[2]};
+                    *reinterpret_cast<P3 *>(st.out + 3 * (size_t)v) = P3{on[0], on[1], on[2]};
                 }
             }
         }
