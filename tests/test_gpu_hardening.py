@@ -1319,6 +1319,28 @@ def test_sample_points_adjoint_ordered_form_is_the_oracles_bit_for_bit(gpu_fx, o
         assert np.allclose(fx.sample_points_grad(m, fi9, r19, r29, g9).to_host(), e9, rtol=2e-4, atol=1e-5)
 
 
+def test_sample_points_adjoint_ordered_beyond_the_draws_held_in_registers(gpu_fx, oracle):
+    """sample_gather.h keeps six sweeps of a thread's draws (6144 per mesh) in registers for both passes over them; a small mesh admits a few
+    more (6300 draws at 8 faces fit the LDS layout): the draws beyond are read where they are used.  Every face holds ~800 draws (the bitmap
+    ordering of long lists, the table of faces with many draws)."""
+    import ctypes as C
+    from flux3d_jl_amd import _lib
+    fx = gpu_fx
+    v = np.asfortranarray(np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32).T)
+    f = np.asfortranarray(np.array([[1, 3, 5], [3, 2, 5], [2, 4, 5], [4, 1, 5], [3, 1, 6], [2, 3, 6], [4, 2, 6], [1, 4, 6]], np.uint32).T)
+    m = fx.gpu(fx.TriMesh([v, v * 2.0], [f, f]))
+    n = 6300
+    fits = C.c_int32(0)
+    _lib.call("fx3d_sample_points_bwd_ordered", m.F, n, C.byref(fits))
+    assert fits.value == 1
+    _, fi, r1, r2 = fx.sample_points(m, n, seed=5, return_draws=True)
+    gout = np.asfortranarray(np.random.default_rng(1).standard_normal((3, n, m.N)).astype(np.float32))
+    fp0 = m.get_faces_padded().astype(np.int64) - 1
+    exp = oracle.sample_points_bwd(fp0, m._faces_len, m.V, fi.to_host(), r1.to_host(), r2.to_host(), gout)
+    got = fx.sample_points_grad(m, fi, r1, r2, gout).to_host()
+    assert np.array_equal(got, exp), np.argwhere(got != exp)[:5]
+
+
 @pytest.mark.parametrize("nb,n", [(2, 3000), (8, 5000), (2, 5300), (64, 5000), (1, 5000)])
 def test_chamfer_sampled_adjoint_ordered_form_is_the_oracles_chain_bit_for_bit(gpu_fx, oracle, nb, n):
     """fx3d_chamfer_sampled_bwd, ordered form: the chamfer adjoint's rows (bit-identical to oracle.chamfer_bwd) go to scratch
