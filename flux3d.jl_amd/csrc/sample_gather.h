@@ -5,8 +5,9 @@
 //     inner(f, t) = 0 + sum over the samples k drawn on f, k ASCENDING, of  w_t(k) * gs[k]              (Float32, unfused)
 // -- the order in which oracle/flux3d_oracle.c: fx3d_oracle_sample_points_bwd adds, so the result is the oracle's bit for bit and
 // the same from run to run (round 5 scattered the 9 products of every sample with global float atomics: arrival order).
-// sg_parts(V) 1024-thread blocks per mesh (each builds the tables, each finishes a share of the vertices), everything between the
-// first and the last global access in LDS: the draws are bucketed by face with a counting sort (integer atomics, a block scan,
+// sg_parts(V) 1024-thread blocks per mesh (each finishes a share of the vertices from tables of the whole mesh: built by the block itself
+// -- fx3d_sample_points_bwd -- or, behind fx3d_chamfer_sampled_bwd's first launch, loaded as the blob a spare block of that launch built:
+// sg_tables_store / _load), everything between the first and the last global access in LDS: the draws are bucketed by face with a counting sort (integer atomics, a block scan,
 // placement from the back of every list), every list is put in ascending order in place (up to eight draws: a sorting network in
 // the face's thread; longer: a wave through a bitmap over the sample ids), (gs, sqrt(r1), r2) of every draw is STAGED with coalesced
 // loads -- one round trip to memory for the whole mesh --, faces of more than eight draws get their nine sums from nine lanes each,
@@ -17,7 +18,7 @@
 // tutorial's sphere; the reference's default is 5000) -- other meshes keep the scatter.  (Measured on the way, one mesh of 5000 draws:
 // gs / r1 / r2 gathered from memory per (entry, draw) 70 us; staged in list order 26; staged by draw id, one block 20; sixteen
 // blocks 13 on an even mesh but 38 inside the fit loop, whose grown faces draw 20 - 50 each: table of the big faces 28, a thread
-// per entry 19.)
+// per entry 19; the tables handed over from the first launch 12; draws and optimiser state requested up front 10.)
 // Included by sampler.hip (fx3d_sample_points_bwd; the kernel) and chamfer_bwd.hip (fx3d_chamfer_sampled_bwd's second launch).
 #pragma once
 #include "fx3d_common.h"
@@ -280,7 +281,7 @@ __host__ __device__ inline size_t sg_tables_lds_bytes(int F, int n) {
 }
 
 // sg_finish: phases (5) - (6) for the vertices [vb, ve) of the mesh -- a mesh's vertices may be shared out over several blocks
-// (each with tables of its own: building them is ~7 us of one CU's time, walking 2500 vertices 12 us).
+// (each with the mesh's tables in its own LDS -- built, ~7 us of one CU's time, or loaded, ~1 us; walking 2500 vertices would be 12 us).
 __device__ __forceinline__ void sg_finish(unsigned char *lds, const SgMesh &m, const SgStep &st, int vb, int ve) {
     const int tid = threadIdx.x;
     const SgLayout L = sg_layout(m.F, m.n);
@@ -430,7 +431,7 @@ __device__ __forceinline__ void sg_finish(unsigned char *lds, const SgMesh &m, c
     SG_STAMP(6);
 }
 
-// blocks that share a mesh's vertices: ~160 vertices each, at most 16 (every block rebuilds the tables)
+// blocks that share a mesh's vertices: ~160 vertices each, at most 16 (every block holds the mesh's tables)
 __host__ __device__ inline int sg_parts(int V) {
     const int g = (V + 159) / 160;
     return g < 1 ? 1 : (g > 16 ? 16 : g);

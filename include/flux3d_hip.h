@@ -193,9 +193,10 @@ FX3D_API fx3d_status fx3d_chamfer_fwd_bwd(const float *x, int32_t N, const float
  * fitting loop differentiates w.r.t. the source mesh only).  accumulate = 0 overwrites gverts, else adds to it.
  * vf_rowptr_* / vf_ent_* (device copies of fx3d_build_vertex_faces' tables) select the ORDERED form for meshes it fits
  * (fx3d_sample_points_bwd_ordered(Fmax, n) for every requested side): no float atomics, every vertex's sum in the order of
- * fx3d_sample_points_bwd -- bit-reproducible; two launches (the rows into ws, then the gather); ws:
- * fx3d_chamfer_sampled_bwd_workspace_bytes.  NULL tables (or a mesh beyond the limits): ONE launch that scatters the rows with global
- * float atomics (sums in arrival order), ws unused -- ~20 us per call faster at one mesh of 5000 draws, not reproducible. */
+ * fx3d_sample_points_bwd -- bit-reproducible; two launches (the rows and, by spare blocks, the gather's per-mesh tables into ws, then the
+ * gather); ws: fx3d_chamfer_sampled_bwd_workspace_bytes.  NULL tables (or a mesh beyond the limits): ONE launch that scatters the rows
+ * with global float atomics (sums in arrival order), ws unused -- ~9 us per call faster at one mesh of 5000 draws as a single call (inside
+ * a fit iteration the ordered form is the faster one), slower at eight meshes, not reproducible. */
 FX3D_API fx3d_status fx3d_chamfer_sampled_bwd_workspace_bytes(int32_t N, int32_t M, int32_t B, size_t *bytes);
 FX3D_API fx3d_status fx3d_chamfer_sampled_bwd(const float *x, int32_t N, const float *y, int32_t M, int32_t B,
                                               const int32_t *idx_x, const int32_t *idx_y, float w1, float w2, float gout,
